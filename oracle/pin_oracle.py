@@ -1,0 +1,306 @@
+#!/usr/bin/env python3
+"""Pin the CPU restatement (liboracle) against the reference itself -- TEST INFRASTRUCTURE.
+
+Runs in the build container only (needs /root/reference for the FASTA fixtures
+and oracle/_ref/ built by `make -C oracle ref`).  For every fixture set:
+
+  * SA: reference divsufsort == own prefix-doubling sorter (+ sufcheck)
+  * LCP / SO: reference compute_lcp / build_SO == restatement
+  * getmums, getmums_rem, getmultimums, getmultimems: reference == restatement
+  * the full aligner recursion: a LIFO loop written here around the REFERENCE's
+    getmums_rem/getmultimums + split + bubble_sort (D-label done by scatter
+    through SAi as reveal.c:1005-1117) with the bench picker / linear
+    graphalign, compared step by step (sub-index key, n, depth, nsamples,
+    scan result, chosen match, child SA and LCP hashes) with ro_align's trace.
+  * the known-answer vectors of SURVEY.md 8(c).
+
+Exit code 0 = every check passed.  `python oracle/pin_oracle.py [--big]`.
+"""
+import os
+import sys
+import time
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import ref_ctypes            # noqa: E402
+import oracle_ctypes         # noqa: E402
+
+REFTESTS = "/root/reference/tests"
+GOLDEN = 0x9E3779B97F4A7C15
+M64 = (1 << 64) - 1
+
+
+def read_fasta(path, toupper=True):
+    """reveal/utils.py:79-160 fasta_reader (defaults): rstrip, upper, drop '-'"""
+    name, seq, out = None, [], []
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(">"):
+                if seq:
+                    out.append((name, "".join(seq)))
+                name, seq = line.replace(">", "").replace("\t", ""), []
+            else:
+                if toupper:
+                    line = line.upper()
+                seq.append(line.replace("-", ""))
+    if seq:
+        out.append((name, "".join(seq)))
+    return out
+
+
+def assemble(files, toupper=True):
+    """reveal/utils.py:325-350 + interface.c:18-95: one sample per file, one
+    '$'-terminated sequence per contig -> (T bytes, nsep, nodes)"""
+    T, nsep, nodes = bytearray(), [], []
+    for k, f in enumerate(files):
+        if k > 0:
+            nsep.append(len(T) - 1)
+        for _, s in (read_fasta(f, toupper) if isinstance(f, str) and os.path.exists(f) else [(None, f)]):
+            b = len(T)
+            T += s.encode() + b"$"
+            nodes.append((b, len(T) - 1))
+    return bytes(T), nsep, nodes
+
+
+def seqhash(vals):
+    v = np.asarray(vals).astype(np.int64).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = v + (np.arange(1, len(v) + 1, dtype=np.uint64) * np.uint64(GOLDEN))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+        x ^= x >> np.uint64(31)
+        return int(x.sum(dtype=np.uint64))
+
+
+def flat_mums(mums):
+    out = []
+    for l, n, spd in mums:
+        out += [l, n]
+        for so, pos in spd:
+            out += [so, pos]
+    return out
+
+
+def bench_picker(mums, nsamples):
+    best = None
+    for m in mums:
+        if m[1] != nsamples:
+            continue
+        mn = min(p for _, p in m[2])
+        if best is None or m[0] > best[0][0] or (m[0] == best[0][0] and mn < best[1]):
+            best = (m, mn)
+    return best[0] if best else None
+
+
+def linear_graphalign(nodes, mum):
+    l, n, spd = mum
+    lead, trail, match, touched = [], [], [], set()
+    for _, sp in spd:
+        hit = [q for q, (b, e) in enumerate(nodes) if b <= sp < e][0]
+        b, e = nodes[hit]
+        assert sp + l <= e
+        touched.add(hit)
+        if sp > b:
+            lead.append((b, sp))
+        if sp + l < e:
+            trail.append((sp + l, e))
+        match.append((sp, sp + l))
+    rest = [iv for q, iv in enumerate(nodes) if q not in touched]
+    return sorted(lead), sorted(trail), sorted(match), sorted(rest)
+
+
+def ref_recursion(R, tbuf, SA, LCP, SAi, SO, nsep, nsamples, nodes, minl, minn, sa_t):
+    """LIFO aligner loop (reveal.c:731-1338) around the reference's own scan,
+    split and bubble_sort.  Yields trace dicts."""
+    nsep_a = np.asarray(nsep, dtype=sa_t)
+
+    def nsamp(iv):
+        if nsamples > 2:
+            return len({int(SO[b]) for b, _ in iv})
+        s = set()
+        for b, _ in iv:
+            if b < nsep[0]:
+                s.add(0)
+            if b > nsep[0]:
+                s.add(1)
+        return len(s)
+    main = R.view(tbuf, SA, LCP, nsep_a, nsamples, SAi=SAi, SO=SO)
+    stack = [dict(SA=SA, LCP=LCP, depth=0, nsamples=nsamples, nodes=list(nodes))]
+    while stack:
+        ix = stack.pop()
+        ri = R.view(tbuf, ix["SA"], ix["LCP"], nsep_a, nsamples, SAi=SAi, SO=SO, nT=len(SA), main=main)
+        if nsamples > 2:
+            mums = R.getmultimums(ri, minl, minn)
+        else:
+            mums = R.getmums_rem(ri, minl)
+        rec = dict(key=min(b for b, _ in ix["nodes"]), n=len(ix["SA"]), depth=ix["depth"], nsamples=ix["nsamples"],
+                   nnodes=len(ix["nodes"]), nmums=len(mums), h_sa=seqhash(ix["SA"]), h_lcp=seqhash(ix["LCP"]),
+                   h_mums=seqhash(flat_mums(mums)) if mums else 0, picked=0, l=0, mn=0, sp_min=0)
+        mum = bench_picker(mums, ix["nsamples"])
+        if mum is None:
+            yield rec
+            continue
+        lead, trail, match, rest = linear_graphalign(ix["nodes"], mum)
+        rec.update(picked=1, l=mum[0], mn=mum[1], sp_min=min(p for _, p in mum[2]))
+        yield rec
+        n = len(ix["SA"])
+        D = np.zeros(n, dtype=np.uint8)                     # reveal.c:1005-1117
+        cnt = [0, 0, 0]
+        for k, (ivs, lab) in enumerate(((lead, 1), (trail, 2), (rest, 4))):
+            for b, e in ivs:
+                D[SAi[b:e]] = lab
+                cnt[k] += e - b
+        for _, sp in mum[2]:
+            D[SAi[sp:sp + mum[0]]] = 3
+        kids = R.split(ri, D, *cnt)                          # reveal.c:1217
+        for _, sp in mum[2]:                                 # reveal.c:1230-1234
+            seg = tbuf[sp:sp + mum[0]]
+            up = (seg >= 65) & (seg <= 90)
+            seg[up] += 32
+        if kids[0] is not None:                              # reveal.c:1250-1252
+            R.bubble_sort(tbuf, kids[0][0], kids[0][1], SAi, match)
+        d = ix["depth"] + 1
+        if kids[2] is not None:                              # push par, lead, trail
+            stack.append(dict(SA=kids[2][0], LCP=kids[2][1], depth=d, nsamples=nsamp(rest), nodes=rest))
+        if kids[0] is not None:
+            stack.append(dict(SA=kids[0][0], LCP=kids[0][1], depth=d, nsamples=nsamp(lead), nodes=lead))
+        if kids[1] is not None:
+            stack.append(dict(SA=kids[1][0], LCP=kids[1][1], depth=d, nsamples=nsamp(trail), nodes=trail))
+
+
+def csr_to_tuples(l, n, off, so, pos):
+    return [(int(l[k]), int(n[k]), tuple((int(so[q]), int(pos[q])) for q in range(off[k], off[k + 1])))
+            for k in range(len(l))]
+
+
+def check(name, cond, info=""):
+    print("  %-52s %s %s" % (name, "ok" if cond else "FAIL", info))
+    if not cond:
+        check.failed += 1
+
+
+check.failed = 0
+
+
+def pin_set(label, files, sa64, minl=20, minn=2, recursion=True, own_sa=True):
+    print("[%s]%s" % (label, " (64-bit)" if sa64 else ""))
+    R = ref_ctypes.Ref(sa64)
+    O = oracle_ctypes.Oracle(sa64)
+    T, nsep, nodes = assemble(files)
+    n, ns = len(T), len(files)
+    tb_r, tb_o = R.textbuf(T), O.textbuf(T)
+    t0 = time.time()
+    SA = R.divsufsort(tb_r[:n])
+    t_dss = time.time() - t0
+    if own_sa:
+        t0 = time.time()
+        SAo = O.suffix_array(tb_o, own=True)
+        check("SA: own sorter == divsufsort", np.array_equal(SA, SAo), "n=%d ref %.2fs own %.2fs" % (n, t_dss, time.time() - t0))
+    check("SA: sufcheck", O.sufcheck(tb_o, SA) == 0)
+    SAi = R.inverse(SA)
+    check("SAi", np.array_equal(SAi, O.inverse(SA)))
+    LCP = R.compute_lcp(tb_r, SA, SAi)
+    LCPo = O.compute_lcp(tb_o, SA, SAi)
+    check("LCP: compute_lcp", np.array_equal(LCP, LCPo), "max=%d" % LCP.max())
+    # closed form of SURVEY.md 7: min(plain lcp, distance to first '$'/'N')
+    SO = None
+    if ns > 2:
+        SO = R.build_so(nsep, ns, n)
+        check("SO: build_SO", np.array_equal(SO, O.build_so(nsep, ns, n)))
+    ri = R.view(tb_r, SA, LCP, nsep, ns, SAi=SAi, SO=SO)
+    if ns >= 2:
+        for ml in sorted({1, minl}):
+            ref = R.getmums(ri, ml)
+            l, a, b = O.getmums(tb_o, SA, LCPo, nsep, ml)
+            mine = [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))]
+            check("getmums(%d)" % ml, ref == mine, "%d mums" % len(ref))
+        ref = R.getmums_rem(ri, minl)
+        l, a, b = O.getmums(tb_o, SA, LCPo, nsep, minl, rem=True)
+        mine = [(int(l[k]), 2, ((0, int(a[k])), (1, int(b[k])))) for k in range(len(l))]
+        check("getmums_rem(%d)" % minl, ref == mine, "%d mums" % len(ref))
+    if ns > 2:
+        for ml, mn in ((minl, minn), (2, 2), (0, 2), (minl, ns)):
+            ref = R.getmultimums(ri, ml, mn)
+            mine = csr_to_tuples(*O.getmultimums(tb_o, SA, LCPo, SO, nsep, ns, ml, mn))
+            check("getmultimums(%d,%d)" % (ml, mn), ref == mine, "%d" % len(ref))
+            ref = R.getmultimems(ri, ml, mn)
+            mine = csr_to_tuples(*O.getmultimums(tb_o, SA, LCPo, SO, nsep, ns, ml, mn, mems=True))
+            check("getmultimems(%d,%d)" % (ml, mn), ref == mine, "%d" % len(ref))
+    if recursion and ns >= 2:
+        t0 = time.time()
+        reft = list(ref_recursion(R, tb_r, SA.copy(), LCP.copy(), SAi.copy(), SO, nsep, ns, nodes, minl, minn, R.sa_t))
+        t_ref = time.time() - t0
+        cons = dict(tbuf=tb_o, SA=SA.copy(), SAi=SAi.copy(), LCP=LCPo.copy(), SO=SO,
+                    nsep=np.asarray(nsep, dtype=O.sa_t), nsamples=ns)
+        res = O.align_bench(cons, nodes, minl, minn, trace_cap=len(reft) + 16)
+        tr = res["trace"]
+        ok = len(tr) == len(reft)
+        bad = None
+        if ok:
+            for k, r in enumerate(reft):
+                t = tr[k]
+                for f in ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums"):
+                    if int(t[f]) != int(r[f]) & (M64 if f.startswith("h_") else -1):
+                        ok, bad = False, (k, f, int(t[f]), r[f])
+                        break
+                if not ok:
+                    break
+        check("recursion trace (scan+label+split+bubble, LIFO)", ok,
+              "%d steps, %d anchors, depth %d, ref-loop %.1fs %s" % (len(reft), res["stats"]["nsplits"], res["stats"]["maxdepth"], t_ref, bad or ""))
+        check("final T (lower-case mask)", bytes(tb_r[:n]) == res["T"], "%d lower" % sum(1 for c in res["T"] if 97 <= c <= 122))
+
+
+def known_answers():
+    print("[known answers, SURVEY.md 8(c)]")
+    for sa64 in (False, True):
+        O = oracle_ctypes.Oracle(sa64)
+        T, nsep, nodes = assemble(["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"])
+        check("T/nsep/nodes", T == b"ACTTGCTAGCTAGTCAG$ACTAGCTAGCTAGTGAG$" and nsep == [17] and nodes == [(0, 17), (18, 35)])
+        c = O.construct(T, nsep, 2)
+        check("SA", list(c["SA"]) == [35, 17, 18, 0, 33, 15, 21, 7, 25, 11, 29, 14, 19, 5, 23, 9, 27, 1, 34, 16, 32, 4, 22, 8, 26, 12, 30, 20, 6, 24, 10, 28, 13, 31, 3, 2])
+        check("LCP", list(c["LCP"]) == [0, 0, 0, 3, 1, 2, 2, 6, 7, 2, 3, 0, 1, 8, 9, 4, 5, 2, 0, 1, 1, 1, 10, 5, 6, 1, 2, 0, 7, 8, 3, 4, 1, 1, 2, 1])
+        l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 1)
+        check("getmums(1)", list(zip(l, a, b)) == [(3, 0, 18), (10, 4, 22), (2, 3, 31)])
+        T, nsep, nodes = assemble(["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"])
+        c = O.construct(T, nsep, 3)
+        check("3 samples n/nsep", len(T) == 54 and nsep == [17, 35])
+        mm = csr_to_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, 3, 2, 2))
+        check("getmultimums(2,2)", mm == [(9, 2, ((0, 0), (2, 36))), (3, 3, ((1, 18), (0, 0), (2, 36))), (10, 2, ((0, 4), (1, 22))),
+                                          (7, 2, ((2, 46), (0, 10))), (4, 3, ((2, 46), (0, 10), (1, 28))), (2, 3, ((1, 31), (0, 3), (2, 39)))])
+        me = csr_to_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, 3, 4, 3, mems=True))
+        check("getmultimems(4,3)", me == [(5, 3, ((0, 4), (1, 22), (2, 40), (0, 8), (1, 26))), (4, 3, ((2, 46), (0, 10), (1, 28)))])
+    # complement table (interface.c:136-145) vs ro_revcomp
+    import ctypes
+    R = ref_ctypes.Ref(False)
+    tab = (ctypes.c_ubyte * 128).in_dll(R.lib, "comp_tab")
+    O = oracle_ctypes.Oracle(False)
+    buf = np.arange(128, dtype=np.uint8)
+    O.revcomp(buf)
+    check("comp_tab", list(buf[::-1]) == list(tab))
+
+
+def main():
+    big = "--big" in sys.argv
+    f = lambda *names: [os.path.join(REFTESTS, x + ".fa") for x in names]
+    known_answers()
+    pin_set("t1+t2 (degenerate 1-bp contigs)", f("t1", "t2"), False, minl=1)
+    pin_set("1a+1b (config 1)", f("1a", "1b"), False)
+    pin_set("1a+1b (config 1)", f("1a", "1b"), True)
+    pin_set("1a+1b+1c (3-way)", f("1a", "1b", "1c"), False)
+    pin_set("1a+1b+1c+1d+1e (5-way, multi-contig)", f("1a", "1b", "1c", "1d", "1e"), False)
+    pin_set("1e+1b (multi-contig)", f("1e", "1b"), False)
+    pin_set("d1+d2 (50k N run)", f("d1", "d2"), False)
+    pin_set("1a+1brc", f("1a", "1brc"), False)
+    pin_set("1a+1a (identical)", f("1a", "1a"), False)
+    pin_set("2a+2b", f("2a", "2b"), False, own_sa=big)
+    if big:
+        pin_set("3a+3b", f("3a", "3b"), False, own_sa=False)
+        pin_set("1a+1b+1c (3-way)", f("1a", "1b", "1c"), True)
+    print("FAILED: %d" % check.failed if check.failed else "ALL PINNED")
+    return 1 if check.failed else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

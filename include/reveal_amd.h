@@ -1,0 +1,183 @@
+/*
+ * reveal_amd.h -- C ABI of the MI355X-native reveallib hot path.
+ *
+ * Drop-in boundary for jasperlinthorst/reveal's `reveallib` / `reveallib64`
+ * C extension (reveallib/interface.c, reveallib/reveal.c).  The reference
+ * binds this path as a CPython type (`index`, interface.c:474-487, 731-785);
+ * this header is what that type's methods would call if the extension were
+ * rebuilt on top of the GPU library (see INTEGRATION.md for the binding).
+ * Plain C: opaque handle, pointers and sizes, no torch / HIP types.
+ *
+ * Two shared objects export the same symbols, mirroring the reference's two
+ * modules (reveallib/reveal.h:7-13, setup.py:19-32):
+ *     libreveal_amd.so    saidx_t = int32_t, lcp_t = int32_t   (reveallib)
+ *     libreveal_amd64.so  saidx_t = int64_t, lcp_t = uint32_t  (reveallib64)
+ * Text positions, counts and interval bounds cross the ABI as int64_t in both;
+ * only rv_get_array() hands out arrays in the native element width.
+ *
+ * Every function returns 0 on success and a negative value on error unless
+ * stated otherwise; rv_last_error() describes the last failure of the calling
+ * thread (the reference raises `reveallib.error` / TypeError there).
+ * All work runs on the handle's own HIP stream; calls are synchronous unless
+ * stated otherwise.  There is NO CPU fallback: without a usable gfx950 device
+ * rv_new() fails.
+ */
+#ifndef REVEAL_AMD_H
+#define REVEAL_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rv_index rv_index;
+
+/* ---- library ------------------------------------------------------------ */
+const char *rv_last_error(void);
+int  rv_abi_version(void);              /* bumped on incompatible changes */
+int  rv_sa_bits(void);                  /* 32 or 64: which module this library is */
+int  rv_device_count(void);             /* visible HIP devices (0 = none) */
+
+/* ---- index lifetime: reveal_init / reveal_dealloc (interface.c:489-521, 787-839) */
+rv_index *rv_new(int device);           /* NULL on failure */
+void rv_free(rv_index *h);
+
+/* ---- text assembly (host) ------------------------------------------------ */
+/* addsample (interface.c:18-49): starts a new sample; records nsep for the
+ * previous one. */
+int rv_add_sample(rv_index *h);
+/* addsequence (interface.c:51-95): appends seq + '$'; returns the half-open
+ * interval [*begin,*end) of the sequence (excluding the '$').  The 32-bit
+ * library fails like interface.c:61-68 when the text would exceed INT_MAX. */
+int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, int64_t *end);
+int64_t rv_n(const rv_index *h);        /* reveal_getn (interface.c:681-689): ranks in the main index */
+int rv_nsamples(const rv_index *h);     /* interface.c:691-695 */
+int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so far */
+
+/* ---- construct (interface.c:160-291) ------------------------------------- */
+/* rc!=0 reverse-complements T[nsep[0]..n) first (interface.c:168-175).
+ * safile / lcpfile (may be NULL or ""): raw native-endian saidx_t[n] / lcp_t[n]
+ * read instead of computed (interface.c:224-232, 255-263).  cache!=0 writes
+ * .reveal.t/.reveal.sa/.reveal.lcp to the CWD (interface.c:182-189, 274-285).
+ * On return T, SA, SAi and LCP live in HBM. */
+int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache);
+
+/* getters (interface.c:538-729).  which: */
+enum { RV_T = 0, RV_SA = 1, RV_SAI = 2, RV_LCP = 3, RV_SO = 4, RV_NSEP = 5, RV_NODES = 6 };
+/* Copies the array to `out` (capacity in elements): T = n chars (current
+ * text incl. lower-case marks), SA/SAI = saidx_t[n], LCP = lcp_t[n], SO =
+ * uint16_t[n] (only when nsamples > 2), NSEP = int64_t[nsamples-1], NODES =
+ * int64_t[2*nnodes].  Returns the element count or <0 (e.g. SA/LCP of the main
+ * index after align(), which the reference frees, reveal.c:1279-1284). */
+int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap);
+
+/* ---- scans on the main index ---------------------------------------------- */
+/* getmums(minl) (reveal.c:55-116): pairwise MUMs between sample 0 and the
+ * rest, increasing SA rank.  rv_getmums runs the scan and returns the number
+ * of matches; rv_fetch_mums copies them (l, a, b; b already rc-remapped). */
+int64_t rv_getmums(rv_index *h, int minl);
+int rv_fetch_mums(rv_index *h, uint32_t *l, int64_t *a, int64_t *b, int64_t cap);
+/* getmultimums / getmultimems (reveal.c:436-580 / 292-434) in CSR form, in the
+ * reference's emission order; mems!=0 selects getmultimems.  Returns the match
+ * count, *members the total member count; rv_fetch_multi copies
+ * l[k], n[k], off[k..k+1], so[], pos[]. */
+int64_t rv_getmultimums(rv_index *h, int minlength, int minn, int mems, int64_t *members);
+int rv_fetch_multi(rv_index *h, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos);
+
+/* ---- the recursion: align() / aligner() (interface.c:293-415, reveal.c:731-1338)
+ *
+ * The reference pops one sub-index at a time (LIFO) and calls back into
+ * Python twice per step.  Children of a split cover disjoint text and never
+ * read each other's state, so this library processes the recursion level by
+ * level: all sub-indices of a level ("the frontier") sit back to back in HBM
+ * and are scanned / split by single launches.  The caller (the Python `index`
+ * type, or rv_align_builtin) supplies the two callbacks' decisions per
+ * sub-index between rv_frontier_scan and rv_frontier_commit. */
+typedef struct {
+    int64_t n;            /* ranks (reveal.h:25) */
+    int32_t depth;        /* reveal.h:28 */
+    int32_t nsamples;     /* reveal.h:29 */
+    int32_t nnodes;       /* intervals of this sub-index (reveal.h:36) */
+    int32_t parent;       /* frontier slot of the parent in the previous level, -1 for the main index */
+    int32_t kind;         /* 0 main, 1 leading, 2 trailing, 3 parallel child */
+    int32_t reserved;
+    int64_t nmums;        /* matches found by the last rv_frontier_scan */
+    int64_t nmembers;     /* total members of those matches */
+} rv_sub;
+
+int rv_align_begin(rv_index *h, int minl, int minn);      /* frontier = {main index} */
+int rv_frontier_size(rv_index *h);
+/* getmums_rem / getmultimums on every sub-index of the frontier (reveal.c:802-822) */
+int rv_frontier_scan(rv_index *h);
+int rv_sub_info(rv_index *h, int s, rv_sub *out);
+int rv_sub_nodes(rv_index *h, int s, int64_t *begin_end /* 2*nnodes */);
+/* matches of sub-index s as (l, n, ((sample,pos)...)) in CSR form */
+int rv_sub_mums(rv_index *h, int s, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos);
+/* SA / LCP of sub-index s (which = RV_SA, RV_LCP, RV_SAI: SAi restricted to
+ * the sub-index' text positions is not contiguous, so RV_SAI returns the whole
+ * shared array like the reference's getter) */
+int64_t rv_sub_array(rv_index *h, int s, int which, void *out, int64_t cap);
+/* Decision for sub-index s: the match chosen by mumpicker (l, member
+ * positions sp[nsp]) and graphalign's interval lists (reveal.c:987), each as
+ * nX (begin,end) pairs.  Sub-indices without a decision end here, exactly
+ * like mumpicker returning () (reveal.c:870-884). */
+int rv_sub_split(rv_index *h, int s, uint32_t l, int nsp, const int64_t *sp,
+                 const int64_t *lead, int nlead, const int64_t *trail, int ntrail,
+                 const int64_t *match, int nmatch, const int64_t *rest, int nrest);
+/* D-label + split + lower-casing + bubble_sort (reveal.c:1005-1252) for every
+ * registered decision; the children become the new frontier.  children (may
+ * be NULL) receives 3 ints per old sub-index: new frontier slots of its
+ * leading, trailing and parallel child, or -1. */
+int rv_frontier_commit(rv_index *h, int32_t *children);
+int rv_align_end(rv_index *h);
+
+/* Whole recursion with the built-in deterministic callbacks used by bench.py
+ * and the parity tests (longest full match, ties -> smallest minimum
+ * coordinate; linear interval model), no Python in the loop. */
+typedef struct {
+    int64_t steps;            /* sub-indices visited */
+    int64_t splits;           /* anchors */
+    int64_t anchored_bp;      /* sum of l */
+    int32_t levels;
+    int32_t maxdepth;
+    int64_t scanned_ranks;    /* ranks streamed by the scan kernel over all levels */
+    double  t_scan, t_host, t_split, t_bubble;   /* seconds, host clock */
+} rv_align_stats;
+int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *st);
+/* anchors chosen by the last rv_align_builtin: l[k], members off[k..k+1] -> pos[] (sorted) */
+int64_t rv_anchor_count(rv_index *h, int64_t *members);
+int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);
+/* per-sub-index trace of the last rv_align_builtin when tracing was enabled
+ * (tests only: costs a D2H copy of every sub-index) */
+typedef struct {
+    int64_t  key, n;
+    int32_t  depth, nsamples, nnodes, picked;
+    int64_t  nmums;
+    uint32_t l; int32_t mn;
+    int64_t  sp_min;
+    uint64_t h_sa, h_lcp, h_mums;
+} rv_trace;
+int rv_set_trace(rv_index *h, int on);
+int64_t rv_trace_count(rv_index *h);
+int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);
+
+/* ---- measurement ------------------------------------------------------------ */
+/* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
+enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,
+       RV_K_BUBBLE = 6, RV_K_COUNT = 8 };
+int rv_prof_enable(rv_index *h, int on);
+int rv_prof_reset(rv_index *h);
+/* launches, total milliseconds and algorithmic bytes of kernel class k since the last reset */
+int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes);
+/* SA-build statistics of the last rv_construct */
+int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_t *sorted_elems, int *radix_passes);
+
+/* ---- self-test hooks for the device primitives (tests/ only) ------------------ */
+int rv_test_exclusive_sum_u32(const uint32_t *in, uint32_t *out, int64_t n);
+int rv_test_inclusive_max_u32(const uint32_t *in, uint32_t *out, int64_t n);
+int rv_test_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, int bit_lo, int bit_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,305 @@
+"""The `index` type of reveallib / reveallib64, on top of the HIP C ABI.
+
+Host-side mirror of the reference's CPython type (reveallib/interface.c:474-487
+method table, :731-785 getset table): same method names, argument meaning and
+error behaviour, so reveal/rem.py-style callers run unchanged:
+
+    idx = reveallib.index(sa="", lcp="", cache=0)
+    idx.addsample(name); idx.addsequence(seq) -> (begin, end)
+    idx.construct(rc=0)
+    idx.getmums(minl); idx.getmultimums(minlength=0, minn=2); idx.getmultimems(...)
+    idx.align(mumpicker, align, threads=0, wpen=0, wscore=0, minl=0, minn=0)
+    idx.n .depth .nsamples .samples .nodes .leftnode .rightnode .nsep .SA .SAi .SO .LCP .T
+
+All compute happens in HBM through libreveal_amd[64].so; nothing here falls
+back to the CPU.
+"""
+import ctypes
+import numpy as np
+
+from . import _lib
+from ._lib import RV_T, RV_SA, RV_SAI, RV_LCP, RV_SO, RV_NSEP
+
+
+def _pairs(iv, sa64):
+    """iterable of (begin, end) -> contiguous int64 array + count (iteration order kept)"""
+    a = np.ascontiguousarray(np.array([(int(b), int(e)) for b, e in iv], dtype=np.int64).reshape(-1, 2))
+    return a, len(a)
+
+
+def make_index_type(sa64, error):
+    """class factory: one `index` type per module (reveallib, reveallib64)."""
+
+    class index(object):
+        """Reveal Index (interface.c:841-881)"""
+
+        def __init__(self, sa="", lcp="", cache=0):       # reveal_init, interface.c:489-521
+            self._lib = _lib.get(sa64)
+            self._dll = self._lib.dll
+            self._h = None
+            self._safile, self._lcpfile, self._cache = sa or "", lcp or "", int(cache)
+            self._samples, self._nodes, self.skipmums = [], set(), []
+            self._leftnode = self._rightnode = None
+            self._depth = 0
+            self._constructed = False
+            self._main = self
+            self._slot = None            # frontier slot while align() runs (sub-indices)
+            self._n_sub = None
+            self._nsamples_sub = None
+            self._h = self._dll.rv_new(0 if not hasattr(index, "_device") else index._device)
+            if not self._h:
+                raise error(self._lib.err())
+
+        def __del__(self):
+            try:
+                if self._h and self._main is self:
+                    self._dll.rv_free(self._h)
+                    self._h = None
+            except Exception:
+                pass
+
+        def _fail(self, exc=None):
+            raise (exc or error)(self._lib.err())
+
+        # ---- text assembly ---------------------------------------------------
+        def addsample(self, *args):                         # interface.c:18-49
+            if len(args) < 1:
+                raise error("Specify name of sample as argument.")
+            if not isinstance(args[0], str):
+                raise error("Sample name has to be a string.")
+            self._samples.append(args[0])
+            self._dll.rv_add_sample(self._h)
+            return None
+
+        def addsequence(self, seq):                         # interface.c:51-95
+            if isinstance(seq, str):
+                seq = seq.encode()
+            elif not isinstance(seq, (bytes, bytearray)):
+                raise TypeError("argument 1 must be str or bytes")
+            b, e = ctypes.c_int64(0), ctypes.c_int64(0)
+            if self._dll.rv_add_sequence(self._h, bytes(seq), len(seq), ctypes.byref(b), ctypes.byref(e)) != 0:
+                self._fail()
+            intv = (b.value, e.value)
+            self._nodes.add(intv)
+            return intv
+
+        # ---- construct --------------------------------------------------------
+        def construct(self, rc=0):                          # interface.c:160-291
+            r = self._dll.rv_construct(self._h, int(rc), self._safile.encode(), self._lcpfile.encode(), self._cache)
+            if r != 0:
+                self._fail()
+            self._constructed = True
+            self._rc = 1 if int(rc) == 1 else 0
+            self._depth = 0
+            self._main = self
+            return None
+
+        # ---- getters (interface.c:538-729) -----------------------------------------
+        @property
+        def n(self):
+            return self._n_sub if self._n_sub is not None else self._dll.rv_n(self._h)
+
+        @property
+        def depth(self):
+            return self._depth
+
+        @property
+        def nsamples(self):
+            return self._nsamples_sub if self._nsamples_sub is not None else self._dll.rv_nsamples(self._h)
+
+        @property
+        def samples(self):
+            return self._main._samples
+
+        @property
+        def nodes(self):
+            return self._nodes
+
+        @property
+        def leftnode(self):
+            return self._leftnode
+
+        @property
+        def rightnode(self):
+            return self._rightnode
+
+        @property
+        def nsep(self):
+            ns = self._dll.rv_nsamples(self._h)
+            out = np.zeros(max(ns - 1, 1), dtype=np.int64)
+            k = self._dll.rv_get_array(self._h, RV_NSEP, out.ctypes.data, len(out))
+            return [int(x) for x in out[:max(k, 0)]]
+
+        def _array(self, which, dtype, count, exc=TypeError):
+            out = np.zeros(max(count, 1), dtype=dtype)
+            if self._slot is not None and which in (RV_SA, RV_LCP):
+                k = self._dll.rv_sub_array(self._h, self._slot, which, out.ctypes.data, len(out))
+            else:
+                k = self._dll.rv_get_array(self._h, which, out.ctypes.data, len(out))
+            if k < 0:
+                raise exc(self._lib.err())
+            return out[:k]
+
+        def _main_n(self):
+            return self._dll.rv_n(self._h)
+
+        @property
+        def SA(self):
+            return self._array(RV_SA, self._lib.sa_t, self.n).tolist()
+
+        @property
+        def LCP(self):
+            return self._array(RV_LCP, self._lib.lcp_t, self.n).tolist()
+
+        @property
+        def SAi(self):
+            return self._array(RV_SAI, self._lib.sa_t, self._main_n()).tolist()
+
+        @property
+        def SO(self):
+            return self._array(RV_SO, np.uint16, self._main_n()).tolist()
+
+        @property
+        def T(self):
+            return self._array(RV_T, np.uint8, self._main_n(), exc=error).tobytes().decode("latin-1")
+
+        # numpy views of the same (not in the reference; cheaper than lists)
+        def array(self, name):
+            which = {"SA": RV_SA, "LCP": RV_LCP, "SAi": RV_SAI, "SO": RV_SO, "T": RV_T}[name]
+            dt = {RV_SA: self._lib.sa_t, RV_LCP: self._lib.lcp_t, RV_SAI: self._lib.sa_t, RV_SO: np.uint16, RV_T: np.uint8}[which]
+            return self._array(which, dt, self.n if which in (RV_SA, RV_LCP) else self._main_n())
+
+        # ---- scans --------------------------------------------------------------
+        def getmums(self, minl=0):                          # reveal.c:55-116
+            cnt = self._dll.rv_getmums(self._h, int(minl))
+            if cnt < 0:
+                self._fail(TypeError if cnt == -2 else error)
+            l = np.zeros(max(cnt, 1), dtype=np.uint32)
+            a = np.zeros(max(cnt, 1), dtype=np.int64)
+            b = np.zeros(max(cnt, 1), dtype=np.int64)
+            if self._dll.rv_fetch_mums(self._h, l.ctypes.data, a.ctypes.data, b.ctypes.data, len(l)) != 0:
+                self._fail()
+            rc = 1 if getattr(self, "_rc", 0) else 0
+            return [(int(l[k]), (int(a[k]), int(b[k])), rc) for k in range(cnt)]
+
+        def _multi(self, minlength, minn, mems):
+            members = ctypes.c_int64(0)
+            cnt = self._dll.rv_getmultimums(self._h, int(minlength), int(minn), mems, ctypes.byref(members))
+            if cnt < 0:
+                self._fail(TypeError if cnt == -2 else error)
+            l = np.zeros(max(cnt, 1), dtype=np.uint32); n = np.zeros(max(cnt, 1), dtype=np.int32)
+            off = np.zeros(cnt + 1, dtype=np.int64)
+            so = np.zeros(max(members.value, 1), dtype=np.uint16); pos = np.zeros(max(members.value, 1), dtype=np.int64)
+            if self._dll.rv_fetch_multi(self._h, l.ctypes.data, n.ctypes.data, off.ctypes.data, so.ctypes.data, pos.ctypes.data) != 0:
+                self._fail()
+            return _csr_to_tuples(cnt, l, n, off, so, pos)
+
+        def getmultimums(self, minlength=0, minn=2):        # reveal.c:436-580
+            return self._multi(minlength, minn, 0)
+
+        def getmultimems(self, minlength=0, minn=2):        # reveal.c:292-434
+            return self._multi(minlength, minn, 1)
+
+        # ---- the recursion -----------------------------------------------------------
+        def align(self, mumpicker, align, threads=0, wpen=0, wscore=0, minl=0, minn=0):
+            """interface.c:293-415 + aligner() reveal.c:731-1338.
+
+            Same callback contracts as the reference; sub-indices are visited
+            level by level instead of LIFO (children of a split are independent,
+            the anchor set is the same)."""
+            if not self._constructed:
+                raise error("Index not yet constructed, alignment stopped.")
+            dll, h = self._dll, self._h
+            if dll.rv_align_begin(h, int(minl), int(minn)) != 0:
+                self._fail()
+            self._depth = 0
+            self._slot = 0
+            frontier = [self]
+            try:
+                while frontier:
+                    if dll.rv_frontier_scan(h) != 0:
+                        self._fail()
+                    decided = {}
+                    for s, idx in enumerate(frontier):
+                        if not callable(mumpicker):
+                            raise TypeError("**** mumpicker isn't callable")      # reveal.c:783-792
+                        info = _lib.RvSub()
+                        dll.rv_sub_info(h, s, ctypes.byref(info))
+                        idx._n_sub, idx._nsamples_sub = info.n, info.nsamples
+                        if len(idx.skipmums) == 0:                                # reveal.c:802-837
+                            mums, pre = idx._fetch_sub_mums(s, info), False
+                        else:
+                            mums, pre = idx.skipmums, True
+                        res = mumpicker(mums, idx, precomputed=pre, minlength=int(minl))
+                        if not isinstance(res, tuple):
+                            raise TypeError("**** call to mumpicker failed")      # reveal.c:859-868
+                        if len(res) == 0:
+                            continue
+                        mum, skipleft, skipright = res
+                        l, mn, spd = mum                                          # reveal.c:901-925
+                        sp = [int(spd[i][1]) for i in range(int(mn))]
+                        r = align(idx, mum)                                       # reveal.c:939
+                        if r is None:
+                            continue
+                        if not isinstance(r, tuple):
+                            raise TypeError("**** call to graphalign failed")     # reveal.c:976-985
+                        leading, trailing, matching, rest, merged, newleft, newright = r
+                        la, nl = _pairs(leading, sa64); ta, nt = _pairs(trailing, sa64)
+                        ma, nm = _pairs(matching, sa64); ra, nr = _pairs(rest, sa64)
+                        spa = np.ascontiguousarray(np.array(sp, dtype=np.int64))
+                        if dll.rv_sub_split(h, s, int(l), len(sp), spa.ctypes.data, la.ctypes.data, nl, ta.ctypes.data, nt,
+                                            ma.ctypes.data, nm, ra.ctypes.data, nr) != 0:
+                            self._fail()
+                        decided[s] = (leading, trailing, rest, newleft, newright, skipleft, skipright)
+                    nf = len(frontier)
+                    kids = np.full(3 * max(nf, 1), -1, dtype=np.int32)
+                    if dll.rv_frontier_commit(h, kids.ctypes.data) != 0:
+                        self._fail()
+                    nxt = {}
+                    for s, (leading, trailing, rest, newleft, newright, skipleft, skipright) in decided.items():
+                        p = frontier[s]
+                        for kind, slot in enumerate(kids[3 * s:3 * s + 3]):
+                            if slot < 0:
+                                continue
+                            c = index.__new__(index)                              # newIndex(), reveal.c:1136-1207
+                            c._lib, c._dll, c._h, c._main = self._lib, dll, h, self
+                            c._samples, c._constructed = self._samples, True
+                            c._depth = p._depth + 1
+                            c._slot = int(slot)
+                            c._n_sub = c._nsamples_sub = None
+                            if kind == 0:
+                                c._nodes, c._leftnode, c._rightnode, c.skipmums = leading, p._leftnode, newright, skipleft
+                            elif kind == 1:
+                                c._nodes, c._leftnode, c._rightnode, c.skipmums = trailing, newleft, p._rightnode, skipright
+                            else:
+                                c._nodes, c._leftnode, c._rightnode, c.skipmums = rest, p._leftnode, p._rightnode, []
+                            nxt[int(slot)] = c
+                    frontier = [nxt[k] for k in sorted(nxt)]
+                    for k, c in enumerate(frontier):
+                        assert c._slot == k
+            finally:
+                dll.rv_align_end(h)
+                self._slot = None
+                self._n_sub = self._nsamples_sub = None
+            return None
+
+        def _fetch_sub_mums(self, s, info):
+            cnt, mem = info.nmums, info.nmembers
+            l = np.zeros(max(cnt, 1), dtype=np.uint32); n = np.zeros(max(cnt, 1), dtype=np.int32)
+            off = np.zeros(cnt + 1, dtype=np.int64)
+            so = np.zeros(max(mem, 1), dtype=np.uint16); pos = np.zeros(max(mem, 1), dtype=np.int64)
+            if self._dll.rv_sub_mums(self._h, s, l.ctypes.data, n.ctypes.data, off.ctypes.data, so.ctypes.data, pos.ctypes.data) != 0:
+                self._fail()
+            return _csr_to_tuples(cnt, l, n, off, so, pos)
+
+        def __reduce__(self):                                # interface.c:417-422 (stub there too)
+            return None
+
+    index.__name__ = "index"
+    index.__qualname__ = "index"
+    return index
+
+
+def _csr_to_tuples(cnt, l, n, off, so, pos):
+    l, n, off, so, pos = l.tolist(), n.tolist(), off.tolist(), so.tolist(), pos.tolist()
+    return [(l[k], n[k], tuple((so[q], pos[q]) for q in range(off[k], off[k + 1]))) for k in range(cnt)]

@@ -1,0 +1,111 @@
+"""ctypes binding of the C ABI in include/reveal_amd.h.
+
+One `Lib` per index width, mirroring the reference's two extension modules
+(setup.py:19-32): libreveal_amd.so (reveallib) and libreveal_amd64.so
+(reveallib64).  There is no Python or CPU fallback: a missing shared object is
+an ImportError, a missing gfx950 device makes rv_new() fail.
+"""
+import ctypes
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+RV_T, RV_SA, RV_SAI, RV_LCP, RV_SO, RV_NSEP, RV_NODES = range(7)
+K_SCAN_PAIR, K_SCAN_MULTI, K_SA_SORT, K_LCP, K_SPLIT, K_LABEL, K_BUBBLE = range(7)
+
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+V = ctypes.c_void_p
+
+
+class RvSub(ctypes.Structure):
+    _fields_ = [("n", ctypes.c_int64), ("depth", ctypes.c_int32), ("nsamples", ctypes.c_int32),
+                ("nnodes", ctypes.c_int32), ("parent", ctypes.c_int32), ("kind", ctypes.c_int32),
+                ("reserved", ctypes.c_int32), ("nmums", ctypes.c_int64), ("nmembers", ctypes.c_int64)]
+
+
+class RvAlignStats(ctypes.Structure):
+    _fields_ = [("steps", ctypes.c_int64), ("splits", ctypes.c_int64), ("anchored_bp", ctypes.c_int64),
+                ("levels", ctypes.c_int32), ("maxdepth", ctypes.c_int32), ("scanned_ranks", ctypes.c_int64),
+                ("t_scan", ctypes.c_double), ("t_host", ctypes.c_double), ("t_split", ctypes.c_double),
+                ("t_bubble", ctypes.c_double)]
+
+
+TRACE_DTYPE = np.dtype([("key", np.int64), ("n", np.int64), ("depth", np.int32), ("nsamples", np.int32),
+                        ("nnodes", np.int32), ("picked", np.int32), ("nmums", np.int64), ("l", np.uint32),
+                        ("mn", np.int32), ("sp_min", np.int64), ("h_sa", np.uint64), ("h_lcp", np.uint64),
+                        ("h_mums", np.uint64)], align=True)
+
+# every symbol include/reveal_amd.h declares: (restype, argtypes)
+_I, _L, _D = ctypes.c_int, ctypes.c_int64, ctypes.c_double
+SYMBOLS = {
+    "rv_last_error": (ctypes.c_char_p, []),
+    "rv_abi_version": (_I, []),
+    "rv_sa_bits": (_I, []),
+    "rv_device_count": (_I, []),
+    "rv_new": (V, [_I]),
+    "rv_free": (None, [V]),
+    "rv_add_sample": (_I, [V]),
+    "rv_add_sequence": (_I, [V, ctypes.c_char_p, _L, c_i64p, c_i64p]),
+    "rv_n": (_L, [V]),
+    "rv_nsamples": (_I, [V]),
+    "rv_nnodes": (_I, [V]),
+    "rv_construct": (_I, [V, _I, ctypes.c_char_p, ctypes.c_char_p, _I]),
+    "rv_get_array": (_L, [V, _I, V, _L]),
+    "rv_getmums": (_L, [V, _I]),
+    "rv_fetch_mums": (_I, [V, V, V, V, _L]),
+    "rv_getmultimums": (_L, [V, _I, _I, _I, c_i64p]),
+    "rv_fetch_multi": (_I, [V, V, V, V, V, V]),
+    "rv_align_begin": (_I, [V, _I, _I]),
+    "rv_frontier_size": (_I, [V]),
+    "rv_frontier_scan": (_I, [V]),
+    "rv_sub_info": (_I, [V, _I, ctypes.POINTER(RvSub)]),
+    "rv_sub_nodes": (_I, [V, _I, V]),
+    "rv_sub_mums": (_I, [V, _I, V, V, V, V, V]),
+    "rv_sub_array": (_L, [V, _I, _I, V, _L]),
+    "rv_sub_split": (_I, [V, _I, ctypes.c_uint32, _I, V, V, _I, V, _I, V, _I, V, _I]),
+    "rv_frontier_commit": (_I, [V, V]),
+    "rv_align_end": (_I, [V]),
+    "rv_align_builtin": (_I, [V, _I, _I, ctypes.POINTER(RvAlignStats)]),
+    "rv_anchor_count": (_L, [V, c_i64p]),
+    "rv_fetch_anchors": (_I, [V, V, V, V]),
+    "rv_set_trace": (_I, [V, _I]),
+    "rv_trace_count": (_L, [V]),
+    "rv_fetch_trace": (_I, [V, V, _L]),
+    "rv_prof_enable": (_I, [V, _I]),
+    "rv_prof_reset": (_I, [V]),
+    "rv_prof_get": (_I, [V, _I, c_i64p, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
+    "rv_sa_stats": (_I, [V] + [ctypes.POINTER(_I)] * 4 + [c_i64p, ctypes.POINTER(_I)]),
+    "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
+    "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
+    "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),
+}
+
+
+class Lib:
+    def __init__(self, sa64=False):
+        self.sa64 = sa64
+        name = "libreveal_amd64.so" if sa64 else "libreveal_amd.so"
+        self.path = os.path.join(_HERE, name)
+        if not os.path.exists(self.path):
+            raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(hipcc --offload-arch=gfx950); reveal_amd has no CPU fallback" % self.path)
+        self.dll = ctypes.CDLL(self.path)
+        for sym, (res, args) in SYMBOLS.items():
+            fn = getattr(self.dll, sym)      # AttributeError = ABI mismatch: fail loudly
+            fn.restype, fn.argtypes = res, args
+        self.sa_t = np.int64 if sa64 else np.int32
+        self.lcp_t = np.uint32 if sa64 else np.int32
+        assert self.dll.rv_sa_bits() == (64 if sa64 else 32)
+
+    def err(self):
+        return (self.dll.rv_last_error() or b"").decode(errors="replace")
+
+
+_libs = {}
+
+
+def get(sa64=False):
+    if sa64 not in _libs:
+        _libs[sa64] = Lib(sa64)
+    return _libs[sa64]

@@ -1,0 +1,374 @@
+// rv_api.hip -- C ABI (include/reveal_amd.h): index lifetime, text assembly,
+// construct, getters, top-level scans, profiling and primitive self-tests.
+// The recursion lives in rv_align.hip.
+#include "rv_index.h"
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <limits.h>
+#include <algorithm>
+
+static thread_local char g_err[1024] = "";
+
+void rv_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+const char *rv_last_error(void) { return g_err; }
+int rv_abi_version(void) { return 1; }
+int rv_sa_bits(void) { return (int)sizeof(sa_t) * 8; }
+int rv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+rv_index *rv_new(int device) {
+    int nd = rv_device_count();
+    if (nd <= 0) { rv_set_error("no HIP device visible: reveal_amd has no CPU fallback"); return nullptr; }
+    if (device < 0 || device >= nd) { rv_set_error("device %d out of range (%d visible)", device, nd); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { rv_set_error("hipSetDevice(%d) failed", device); return nullptr; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) { rv_set_error("hipGetDeviceProperties failed"); return nullptr; }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        rv_set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return nullptr;
+    }
+    rv_index *h = new rv_index();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->ws.stream, hipStreamNonBlocking) != hipSuccess) {
+        rv_set_error("hipStreamCreate failed");
+        delete h;
+        return nullptr;
+    }
+    h->T.push_back('\0');
+    return h;
+}
+
+void rv_free(rv_index *h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
+    rv_align_free(h);
+    h->prof.release();
+    h->dT.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dNsep.release();
+    h->ws.release();
+    if (h->ws.stream) (void)hipStreamDestroy(h->ws.stream);
+    delete h;
+}
+
+/* interface.c:18-49 */
+int rv_add_sample(rv_index *h) {
+    if (h->nsamples > 0) h->nsep.push_back(h->n - 1);
+    h->nsamples++;
+    return 0;
+}
+
+/* interface.c:51-95 */
+int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, int64_t *end) {
+    if (len < 0 || !seq) { rv_set_error("addsequence: bad sequence"); return -1; }
+#ifndef RV_SA64
+    if ((uint64_t)h->n + (uint64_t)(len + 1) + 1 > (uint64_t)INT_MAX) {
+        rv_set_error("Total amount of sequence too large, use \"reveal <subcommand> --64\" to use 64 bit suffix arrays instead.");
+        return -1;
+    }
+#endif
+    const int64_t s = h->n;
+    h->T.resize((size_t)(h->n + len + 2));
+    memcpy(h->T.data() + h->n, seq, (size_t)len);
+    h->T[(size_t)(h->n + len)] = '$';
+    h->T[(size_t)(h->n + len + 1)] = '\0';
+    h->n += len + 1;
+    if (begin) *begin = s;
+    if (end) *end = h->n - 1;
+    h->nodes.push_back(RvIntv{s, h->n - 1});
+    return 0;
+}
+
+int64_t rv_n(const rv_index *h) { return h->n; }
+int rv_nsamples(const rv_index *h) { return h->nsamples; }
+int rv_nnodes(const rv_index *h) { return (int)h->nodes.size(); }
+
+/* interface.c:136-158 */
+static char comp_of(char ch) {
+    static const char up[] = "TVGHEFCDIJMLKNOPQYSAABWXRZ";
+    const unsigned char c = (unsigned char)ch;
+    if (c >= 'A' && c <= 'Z') return up[c - 'A'];
+    if (c >= 'a' && c <= 'z') return (char)(up[c - 'a'] + 32);
+    if (c == 96) return 64;
+    return ch;
+}
+static void revcomp(char *T, int64_t n) {
+    for (int64_t i = 0; i < n >> 1; ++i) {
+        const char c0 = comp_of(T[i]), c1 = comp_of(T[n - 1 - i]);
+        T[i] = c1; T[n - 1 - i] = c0;
+    }
+    if (n & 1) T[n >> 1] = comp_of(T[n >> 1]);
+}
+
+static int read_raw(const char *path, void *dst, size_t bytes) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { rv_set_error("cannot open %s", path); return -1; }
+    size_t got = fread(dst, 1, bytes, f);
+    fclose(f);
+    if (got != bytes) { rv_set_error("%s: expected %zu bytes, got %zu", path, bytes, got); return -1; }
+    return 0;
+}
+static int write_raw(const char *path, const void *src, size_t bytes) {
+    FILE *f = fopen(path, "wb");
+    if (!f) { rv_set_error("cannot write %s", path); return -1; }
+    fwrite(src, 1, bytes, f);
+    fclose(f);
+    return 0;
+}
+
+/* interface.c:160-291 */
+int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache) {
+    RV_HIP(hipSetDevice(h->device));
+    if (rc == 1) {
+        if (h->nsep.empty()) { rv_set_error("construct(rc=1) needs at least two samples"); return -1; }
+        h->rc = 1;
+        revcomp(h->T.data() + h->nsep[0], h->n - h->nsep[0]);
+    } else {
+        h->rc = 0;
+    }
+    if (h->n == 0) { rv_set_error("No text to index."); return -1; }
+    const int64_t n = h->n;
+    if (cache == 1) RV_TRY(write_raw(".reveal.t", h->T.data(), (size_t)n));
+    rv_align_free(h);
+    h->nT = n;
+    hipStream_t q = h->ws.stream;
+    // text -> HBM, zero padded so word-wise readers may run past the end
+    RV_TRY(h->dT.reserve((size_t)n + 64));
+    RV_HIP(hipMemsetAsync(h->dT.p, 0, (size_t)n + 64, q));
+    RV_HIP(hipMemcpyAsync(h->dT.p, h->T.data(), (size_t)n, hipMemcpyHostToDevice, q));
+    RV_TRY(h->dSA.reserve((size_t)(n + 64) * sizeof(sa_t)));
+    RV_TRY(h->dSAi.reserve((size_t)(n + 64) * sizeof(sa_t)));
+    RV_TRY(h->dLCP.reserve((size_t)(n + 64) * sizeof(lcp_t)));
+    memset(&h->sa_stats, 0, sizeof h->sa_stats);
+    if (!safile || !safile[0]) {
+        int id = h->prof.begin(q, RV_K_SA_SORT, 5.0 * (double)n);
+        RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats));
+        h->prof.end(q, id);
+    } else {
+        std::vector<sa_t> tmp((size_t)n);
+        RV_TRY(read_raw(safile, tmp.data(), (size_t)n * sizeof(sa_t)));
+        RV_HIP(hipMemcpyAsync(h->dSA.p, tmp.data(), (size_t)n * sizeof(sa_t), hipMemcpyHostToDevice, q));
+        RV_HIP(hipStreamSynchronize(q));
+    }
+    RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
+    RV_TRY(h->ws.misc[0].reserve(64));
+    u32 *d_max = h->ws.misc[0].as<u32>();
+    if (!lcpfile || !lcpfile[0]) {
+        int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
+        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max));
+        h->prof.end(q, id);
+        RV_HIP(hipMemcpyAsync(&h->maxlcp, d_max, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+    } else {
+        std::vector<lcp_t> tmp((size_t)n);
+        RV_TRY(read_raw(lcpfile, tmp.data(), (size_t)n * sizeof(lcp_t)));
+        u32 mx = 0;
+        for (int64_t i = 0; i < n; i++) if ((u32)tmp[(size_t)i] > mx) mx = (u32)tmp[(size_t)i];
+        h->maxlcp = mx;
+        RV_HIP(hipMemcpyAsync(h->dLCP.p, tmp.data(), (size_t)n * sizeof(lcp_t), hipMemcpyHostToDevice, q));
+        RV_HIP(hipStreamSynchronize(q));
+    }
+    if (cache == 1) {
+        std::vector<sa_t> sa((size_t)n);
+        std::vector<lcp_t> lc((size_t)n);
+        RV_HIP(hipMemcpy(sa.data(), h->dSA.p, (size_t)n * sizeof(sa_t), hipMemcpyDeviceToHost));
+        RV_HIP(hipMemcpy(lc.data(), h->dLCP.p, (size_t)n * sizeof(lcp_t), hipMemcpyDeviceToHost));
+        RV_TRY(write_raw(".reveal.sa", sa.data(), (size_t)n * sizeof(sa_t)));
+        RV_TRY(write_raw(".reveal.lcp", lc.data(), (size_t)n * sizeof(lcp_t)));
+    }
+    h->constructed = true;
+    h->main_arrays_freed = false;
+    return 0;
+}
+
+int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
+    (void)hipSetDevice(h->device);
+    const int64_t n = h->n;
+    switch (which) {
+    case RV_T:
+        if (cap < n) { rv_set_error("buffer too small"); return -1; }
+        if (h->constructed) {
+            if (hipMemcpy(out, h->dT.p, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { rv_set_error("D2H failed"); return -1; }
+        } else {
+            memcpy(out, h->T.data(), (size_t)n);
+        }
+        return n;
+    case RV_SA: case RV_SAI: case RV_LCP: {
+        if (!h->constructed || (which != RV_SAI && h->main_arrays_freed)) { rv_set_error("Index not yet constructed."); return -2; }
+        if (cap < h->nT && which == RV_SAI) { rv_set_error("buffer too small"); return -1; }
+        if (cap < n && which != RV_SAI) { rv_set_error("buffer too small"); return -1; }
+        const void *src = which == RV_SA ? h->dSA.p : which == RV_SAI ? h->dSAi.p : h->dLCP.p;
+        const size_t esz = which == RV_LCP ? sizeof(lcp_t) : sizeof(sa_t);
+        const int64_t cnt = which == RV_SAI ? h->nT : n;
+        (void)hipStreamSynchronize(h->ws.stream);
+        if (hipMemcpy(out, src, (size_t)cnt * esz, hipMemcpyDeviceToHost) != hipSuccess) { rv_set_error("D2H failed"); return -1; }
+        return cnt;
+    }
+    case RV_SO: {   /* build_SO, interface.c:116-134 */
+        if (!h->constructed || h->nsamples <= 2) { rv_set_error("SO not available."); return -2; }
+        if (cap < h->nT) { rv_set_error("buffer too small"); return -1; }
+        uint16_t *so = (uint16_t *)out;
+        int64_t j = 0;
+        for (int i = 0; i < h->nsamples; i++) {
+            const int64_t hi = (i == h->nsamples - 1) ? h->nT - 1 : h->nsep[(size_t)i];
+            for (; j <= hi; j++) so[j] = (uint16_t)i;
+        }
+        return h->nT;
+    }
+    case RV_NSEP:
+        if (cap < (int64_t)h->nsep.size()) { rv_set_error("buffer too small"); return -1; }
+        for (size_t k = 0; k < h->nsep.size(); k++) ((int64_t *)out)[k] = h->nsep[k];
+        return (int64_t)h->nsep.size();
+    case RV_NODES:
+        if (cap < (int64_t)h->nodes.size() * 2) { rv_set_error("buffer too small"); return -1; }
+        for (size_t k = 0; k < h->nodes.size(); k++) { ((int64_t *)out)[2 * k] = h->nodes[k].begin; ((int64_t *)out)[2 * k + 1] = h->nodes[k].end; }
+        return (int64_t)h->nodes.size() * 2;
+    }
+    rv_set_error("unknown array id %d", which);
+    return -1;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// pair scan driver: launch, copy the tile table + records, merge in tile order
+// ---------------------------------------------------------------------------
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, std::vector<RvPairRec> &out) {
+    out.clear();
+    if (m <= 1) return 0;
+    if (h->nsep.empty()) { rv_set_error("pairwise scan needs at least two samples"); return -1; }
+    hipStream_t q = h->ws.stream;
+    const int64_t ntile = ceil_div(m, RV_PAIR_TILE);
+    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &brec = h->ws.misc[3];
+    RV_TRY(bcnt.reserve(64));
+    RV_TRY(btab.reserve((size_t)ntile * sizeof(uint2)));
+    size_t cap = brec.cap / sizeof(RvPairRec);
+    if (cap < 4096) { RV_TRY(brec.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, m / 64))); cap = brec.cap / sizeof(RvPairRec); }
+    std::vector<uint2> tab((size_t)ntile);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        RV_HIP(hipMemsetAsync(bcnt.p, 0, 4, q));
+        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
+        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, h->dT.as<uint8_t>(), (sa_t)h->nsep[0], minl, brec.as<RvPairRec>(), (u32)std::min<size_t>(cap, 0xffffffffu),
+                                   bcnt.as<u32>(), btab.as<uint2>()));
+        h->prof.end(q, id);
+        u32 total = 0;
+        RV_HIP(hipMemcpyAsync(&total, bcnt.p, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(tab.data(), btab.p, (size_t)ntile * sizeof(uint2), hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        if (total <= cap) {
+            std::vector<RvPairRec> raw(total);
+            if (total) RV_HIP(hipMemcpy(raw.data(), brec.p, (size_t)total * sizeof(RvPairRec), hipMemcpyDeviceToHost));
+            out.resize(total);
+            size_t w = 0;
+            for (int64_t t = 0; t < ntile; t++) {
+                const uint2 e = tab[(size_t)t];
+                if (e.y) { memcpy(&out[w], &raw[e.x], (size_t)e.y * sizeof(RvPairRec)); w += e.y; }
+            }
+            return 0;
+        }
+        RV_TRY(brec.reserve((size_t)total * sizeof(RvPairRec)));    // retry with room for everything
+        cap = brec.cap / sizeof(RvPairRec);
+    }
+    rv_set_error("pair scan: output buffer sizing failed");
+    return -1;
+}
+
+extern "C" {
+
+/* reveal.c:55-116 */
+int64_t rv_getmums(rv_index *h, int minl) {
+    if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
+    (void)hipSetDevice(h->device);
+    std::vector<RvPairRec> recs;
+    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->n, minl, recs) != 0) return -1;
+    h->m_l.resize(recs.size()); h->m_a.resize(recs.size()); h->m_b.resize(recs.size());
+    for (size_t k = 0; k < recs.size(); k++) {
+        int64_t b = recs[k].b;
+        if (h->rc == 1) b = h->nsep[0] + (h->nT - b - (int64_t)recs[k].l);     /* reveal.c:98-100 */
+        h->m_l[k] = recs[k].l; h->m_a[k] = recs[k].a; h->m_b[k] = b;
+    }
+    return (int64_t)recs.size();
+}
+
+int rv_fetch_mums(rv_index *h, uint32_t *l, int64_t *a, int64_t *b, int64_t cap) {
+    if (cap < (int64_t)h->m_l.size()) { rv_set_error("buffer too small"); return -1; }
+    for (size_t k = 0; k < h->m_l.size(); k++) { l[k] = h->m_l[k]; a[k] = h->m_a[k]; b[k] = h->m_b[k]; }
+    return 0;
+}
+
+int rv_prof_enable(rv_index *h, int on) { h->prof.on = on != 0; return 0; }
+int rv_prof_reset(rv_index *h) { (void)hipStreamSynchronize(h->ws.stream); h->prof.reset(); return 0; }
+int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes) {
+    if (k < 0 || k >= RV_K_COUNT) { rv_set_error("bad kernel id"); return -1; }
+    (void)hipStreamSynchronize(h->ws.stream);
+    h->prof.resolve();
+    if (launches) *launches = h->prof.launches[k];
+    if (ms) *ms = h->prof.ms[k];
+    if (bytes) *bytes = h->prof.bytes[k];
+    return 0;
+}
+int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_t *sorted_elems, int *radix_passes) {
+    if (sigma) *sigma = h->sa_stats.sigma;
+    if (bits) *bits = h->sa_stats.bits;
+    if (k0) *k0 = h->sa_stats.k0;
+    if (rounds) *rounds = h->sa_stats.rounds;
+    if (sorted_elems) *sorted_elems = h->sa_stats.sorted_elems;
+    if (radix_passes) *radix_passes = h->sa_stats.radix_passes;
+    return 0;
+}
+
+/* ---- primitive self-tests (host buffers in, host buffers out) -------------- */
+static int test_ws(Workspace &ws) {
+    if (rv_device_count() <= 0) { rv_set_error("no HIP device"); return -1; }
+    RV_HIP(hipSetDevice(0));
+    RV_HIP(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
+    return 0;
+}
+static void test_ws_done(Workspace &ws) { ws.release(); (void)hipStreamDestroy(ws.stream); }
+
+static int test_scan(const uint32_t *in, uint32_t *out, int64_t n, bool maxscan) {
+    Workspace ws;
+    RV_TRY(test_ws(ws));
+    DBuf a, b;
+    int r = 0;
+    if (a.reserve((size_t)n * 4 + 64) || b.reserve((size_t)n * 4 + 64)) r = -1;
+    if (!r && hipMemcpy(a.p, in, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) r = -1;
+    if (!r) r = maxscan ? rv_inclusive_max_u32(ws, a.as<u32>(), b.as<u32>(), n) : rv_exclusive_sum_u32(ws, a.as<u32>(), b.as<u32>(), n);
+    if (!r && hipStreamSynchronize(ws.stream) != hipSuccess) { rv_set_error("sync failed: %s", hipGetErrorString(hipGetLastError())); r = -1; }
+    if (!r && hipMemcpy(out, b.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = -1;
+    a.release(); b.release();
+    test_ws_done(ws);
+    return r;
+}
+int rv_test_exclusive_sum_u32(const uint32_t *in, uint32_t *out, int64_t n) { return test_scan(in, out, n, false); }
+int rv_test_inclusive_max_u32(const uint32_t *in, uint32_t *out, int64_t n) { return test_scan(in, out, n, true); }
+
+int rv_test_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, int bit_lo, int bit_hi) {
+    Workspace ws;
+    RV_TRY(test_ws(ws));
+    DBuf k0, k1, v0, v1;
+    int r = 0, in1 = 0;
+    if (k0.reserve((size_t)n * 8 + 64) || k1.reserve((size_t)n * 8 + 64) || v0.reserve((size_t)n * 4 + 64) || v1.reserve((size_t)n * 4 + 64)) r = -1;
+    if (!r && hipMemcpy(k0.p, keys, (size_t)n * 8, hipMemcpyHostToDevice) != hipSuccess) r = -1;
+    if (!r && hipMemcpy(v0.p, vals, (size_t)n * 4, hipMemcpyHostToDevice) != hipSuccess) r = -1;
+    if (!r) r = rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), n, bit_lo, bit_hi, &in1);
+    if (!r && hipStreamSynchronize(ws.stream) != hipSuccess) { rv_set_error("sync failed: %s", hipGetErrorString(hipGetLastError())); r = -1; }
+    if (!r && hipMemcpy(keys, in1 ? k1.p : k0.p, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) r = -1;
+    if (!r && hipMemcpy(vals, in1 ? v1.p : v0.p, (size_t)n * 4, hipMemcpyDeviceToHost) != hipSuccess) r = -1;
+    k0.release(); k1.release(); v0.release(); v1.release();
+    test_ws_done(ws);
+    return r;
+}
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+// rv_common.h -- shared declarations of the reveal_amd HIP library (gfx950 only).
+//
+// Index-width switch exactly like the reference's two modules
+// (reveallib/reveal.h:7-13): default = reveallib (int32 SA, int32 LCP),
+// -DRV_SA64 = reveallib64 (int64 SA, uint32 LCP).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include <vector>
+#include <string>
+
+#ifdef RV_SA64
+typedef int64_t  sa_t;
+typedef uint32_t lcp_t;
+#else
+typedef int32_t  sa_t;
+typedef int32_t  lcp_t;
+#endif
+
+typedef unsigned long long u64;
+typedef unsigned int       u32;
+
+void rv_set_error(const char *fmt, ...);
+
+#define RV_HIP(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess) {                                                                \
+            rv_set_error("%s:%d %s: %s", __FILE__, __LINE__, #x, hipGetErrorString(e_));       \
+            return -1;                                                                         \
+        }                                                                                      \
+    } while (0)
+#define RV_TRY(x)                                                                              \
+    do {                                                                                       \
+        int r_ = (x);                                                                          \
+        if (r_ != 0) return r_;                                                                \
+    } while (0)
+#define RV_LAUNCH_CHECK() RV_HIP(hipGetLastError())
+
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// Grow-only device buffer.
+struct DBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        RV_HIP(hipMalloc(&p, want));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// Pinned host staging buffer (grow-only).
+struct HBuf {
+    void  *p = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        RV_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return (T *)p; }
+};
+
+// Scratch slots used by the primitives (one set per index handle, one stream).
+struct Workspace {
+    hipStream_t stream = nullptr;
+    DBuf scan_tmp[4];      // block sums of the multi-level scan
+    DBuf rs_hist;          // radix sort: per-block digit histograms
+    DBuf misc[8];
+    void release() {
+        for (auto &b : scan_tmp) b.release();
+        rs_hist.release();
+        for (auto &b : misc) b.release();
+    }
+};
+
+// ---- primitives (rv_prims.hip) ---------------------------------------------
+// out[i] = sum_{j<i} in[j]  (in may alias out); n up to 2^40.
+int rv_exclusive_sum_u32(Workspace &ws, const u32 *in, u32 *out, int64_t n);
+int rv_exclusive_sum_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n);
+// out[i] = max_{j<=i} in[j]
+int rv_inclusive_max_u32(Workspace &ws, const u32 *in, u32 *out, int64_t n);
+int rv_inclusive_max_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n);
+
+// Stable LSD radix sort of (64-bit key, 32/64-bit value) pairs on key bits
+// [bit_lo, bit_hi).  Ping-pongs between (k0,v0) and (k1,v1); *result_in_1
+// tells where the sorted data ended up.
+template <class V>
+int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n,
+                        int bit_lo, int bit_hi, int *result_in_1);
+
+// ---- construct (rv_construct.hip) ------------------------------------------
+struct RvSaStats {
+    int    sigma, bits, k0;     // alphabet size, bits per symbol, symbols in the first key
+    int    rounds;              // doubling rounds after the initial sort
+    int64_t sorted_elems;       // sum of elements pushed through the radix sort
+    int    radix_passes;
+};
+// SA of T[0..n) (device pointers).  T must be readable up to n+15 (zero padded).
+int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st);
+int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
+// LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp);

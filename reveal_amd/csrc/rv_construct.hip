@@ -1,0 +1,382 @@
+// rv_construct.hip -- suffix array, inverse and LCP on gfx950.
+//
+// Replaces the reference's construct() pipeline (reveallib/interface.c:160-291):
+//   divsufsort(T,SA,n)            interface.c:215-222  -> rv_build_sa   (prefix doubling + radix sort)
+//   SAi[SA[i]]=i                  interface.c:236-238  -> rv_build_inverse
+//   compute_lcp (Kasai, stops at '$'/'N')  interface.c:97-114 -> rv_build_lcp (closed form, one thread per rank)
+//
+// A suffix array is unique for a text (unsigned byte order, shorter suffix
+// first), so prefix doubling yields divsufsort's SA bit for bit.
+#include "rv_common.h"
+#include <string.h>
+
+#ifdef RV_SA64
+typedef u64 sav_t;   // suffix ids as radix-sort payload
+#else
+typedef u32 sav_t;
+#endif
+
+namespace {
+
+constexpr int TB = 256;
+
+// ---- alphabet ---------------------------------------------------------------
+__global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, int64_t n, u32 *__restrict__ hist) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * TB * 16;
+    for (int64_t base = ((int64_t)blockIdx.x * TB + threadIdx.x) * 16; base < n; base += stride) {
+        if (base + 16 <= n) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(T + base);
+            const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) atomicAdd(&h[(w[k] >> (8 * b)) & 255u], 1u);
+        } else {
+            for (int64_t i = base; i < n; i++) atomicAdd(&h[T[i]], 1u);
+        }
+    }
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+
+// ---- first key: K symbols packed at `bits` bits each -------------------------
+// key(i) = sum_j code[T[i+j]] << bits*(K-1-j), code 0 = past the end of the text
+// (so the shorter suffix sorts first).  A block stages 1024+K symbols as codes
+// in LDS; each thread then packs 4 keys from LDS.
+constexpr int KEY_TILE = 1024;
+__global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
+                                                  int bits, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals) {
+    __shared__ uint8_t code[KEY_TILE + 64];
+    __shared__ uint8_t slut[256];
+    slut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
+    for (int k = threadIdx.x; k < KEY_TILE + K; k += TB) {
+        const int64_t i = base + k;
+        code[k] = (i < n) ? slut[T[i]] : (uint8_t)0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < KEY_TILE / TB; r++) {
+        const int k = r * TB + threadIdx.x;
+        const int64_t i = base + k;
+        if (i < n) {
+            u64 key = 0;
+            for (int j = 0; j < K; j++) key = (key << bits) | code[k + j];
+            keys[i] = key;
+            vals[i] = (sav_t)i;
+        }
+    }
+}
+
+// ---- group heads / ranks ------------------------------------------------------
+// head[j] = 1 if sorted key j starts a new group; seed[j] = head ? j : 0
+__global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j >= n) return;
+    const bool hd = (j == 0) || keys[j] != keys[j - 1];
+    head[j] = hd;
+    seed[j] = hd ? (u32)j : 0u;
+}
+
+// SA[j] = vals[j]; ISA[vals[j]] = grp[j]
+__global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, const u32 *__restrict__ grp, int64_t n,
+                                                 sa_t *__restrict__ SA, u32 *__restrict__ ISA) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j >= n) return;
+    const sav_t s = vals[j];
+    SA[j] = (sa_t)s;
+    ISA[s] = grp[j];
+}
+
+// ---- ordered compaction of the not-yet-unique suffixes -------------------------
+// An element is finished when it is a group of its own: head[j] && head[j+1].
+// Round 0 compacts from the full arrays (pos = j); later rounds compact the
+// previous (already compacted) list.  Two passes: per-tile counts -> scan ->
+// emit, so the order (and with it the group layout) is preserved.
+constexpr int CP_ITEMS = 8;
+constexpr int CP_TILE = TB * CP_ITEMS;
+
+__device__ inline bool unsorted_at(const uint8_t *head, int64_t j, int64_t n) {
+    return !(head[j] && (j + 1 == n || head[j + 1]));
+}
+
+__global__ __launch_bounds__(TB) void k_cp_count(const uint8_t *__restrict__ head, int64_t n, u32 *__restrict__ tilecnt) {
+    __shared__ u32 wsum[TB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < CP_ITEMS; r++) {
+        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
+        if (j < n && unsorted_at(head, j, n)) c++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// emit: P[q] = position in SA, S[q] = suffix, G[q] = group rank.
+// pos_in == nullptr means "position is j itself" (round 0).
+__global__ __launch_bounds__(TB) void k_cp_emit(const uint8_t *__restrict__ head, int64_t n, const u32 *__restrict__ tileoff,
+                                                const u32 *__restrict__ pos_in, const sav_t *__restrict__ suf_in, const u32 *__restrict__ grp_in,
+                                                u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G) {
+    __shared__ u32 wbase[TB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    u32 run = tileoff[blockIdx.x];
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int r = 0; r < CP_ITEMS; r++) {
+        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
+        const bool f = (j < n) && unsorted_at(head, j, n);
+        const u64 bal = __ballot(f);
+        if (lane == 0) wbase[w] = (u32)__popcll(bal);
+        __syncthreads();
+        u32 before = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) { const u32 c = wbase[k]; if (k < w) before += c; tot += c; }
+        if (f) {
+            const u32 q = run + before + (u32)__popcll(bal & lt);
+            P[q] = pos_in ? pos_in[j] : (u32)j;
+            S[q] = suf_in[j];
+            G[q] = grp_in[j];
+        }
+        run += tot;
+        __syncthreads();
+    }
+}
+
+// ---- doubling round ------------------------------------------------------------
+// kk[q] = (G[q] << 32) | (S[q]+h < n ? ISA[S[q]+h] + 1 : 0)
+__global__ __launch_bounds__(TB) void k_round_keys(const sav_t *__restrict__ S, const u32 *__restrict__ G, int64_t m, int64_t n, int64_t h,
+                                                   const u32 *__restrict__ ISA, u64 *__restrict__ kk) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= m) return;
+    const int64_t s2 = (int64_t)S[q] + h;
+    const u32 r2 = (s2 < n) ? ISA[s2] + 1u : 0u;
+    kk[q] = ((u64)G[q] << 32) | r2;
+}
+
+// after the sort: head/seed inside the compacted list, and SA[P[q]] = S[q]
+__global__ __launch_bounds__(TB) void k_round_heads(const u64 *__restrict__ kk, const u32 *__restrict__ P, const sav_t *__restrict__ S, int64_t m,
+                                                    uint8_t *__restrict__ headq, u32 *__restrict__ seed, sa_t *__restrict__ SA) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= m) return;
+    const bool hd = (q == 0) || kk[q] != kk[q - 1];
+    headq[q] = hd;
+    const u32 p = P[q];
+    seed[q] = hd ? p : 0u;
+    SA[p] = (sa_t)S[q];
+}
+
+__global__ __launch_bounds__(TB) void k_round_isa(const sav_t *__restrict__ S, const u32 *__restrict__ newG, int64_t m, u32 *__restrict__ ISA) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= m) return;
+    ISA[S[q]] = newG[q];
+}
+
+__global__ __launch_bounds__(TB) void k_inverse(const sa_t *__restrict__ SA, sa_t *__restrict__ SAi, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i < n) SAi[SA[i]] = (sa_t)i;
+}
+
+// ---- LCP ---------------------------------------------------------------------
+__device__ inline u64 load8(const uint8_t *p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exact at and below the lowest hit
+    return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
+}
+
+// LCP[k] = min( lcp(T[SA[k-1]..], T[SA[k]..]), distance from SA[k] to the first
+// '$' or 'N' )  -- the closed form of compute_lcp (interface.c:97-114).
+__global__ __launch_bounds__(TB) void k_lcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, int64_t n,
+                                            u32 *__restrict__ maxlcp) {
+    const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 h = 0;
+    if (k < n && k > 0) {
+        const uint8_t *pa = T + SA[k - 1], *pb = T + SA[k];
+        for (;;) {
+            const u64 wa = load8(pa + h), wb = load8(pb + h);
+            u64 stop = (wa ^ wb);
+            stop |= zero_bytes(wb ^ 0x2424242424242424ull);   // '$'
+            stop |= zero_bytes(wb ^ 0x4E4E4E4E4E4E4E4Eull);   // 'N'
+            stop |= zero_bytes(wb);                            // end of text (zero padding)
+            if (stop) { h += (u32)(__builtin_ctzll(stop) >> 3); break; }
+            h += 8;
+        }
+    }
+    if (k < n) LCP[k] = (lcp_t)h;
+    u32 m = h;
+    for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxlcp, m);
+}
+
+inline int bitlen(u64 v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
+
+}  // namespace
+
+int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_inverse, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, SAi, n);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp) {
+    if (n <= 0) return 0;
+    RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
+    hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st) {
+    RvSaStats s;
+    memset(&s, 0, sizeof s);
+    if (n <= 0) { if (st) *st = s; return 0; }
+    if (n >= ((int64_t)1 << 32) - 2) { rv_set_error("SA build: n >= 2^32-2 not supported yet"); return -1; }
+    hipStream_t q = ws.stream;
+
+    // -- alphabet -> order-preserving dense codes (0 is reserved for "past the end")
+    DBuf d_hist, d_lut;
+    RV_TRY(d_hist.reserve(256 * sizeof(u32)));
+    RV_TRY(d_lut.reserve(256));
+    RV_HIP(hipMemsetAsync(d_hist.p, 0, 256 * sizeof(u32), q));
+    {
+        int64_t blocks = ceil_div(n, (int64_t)TB * 16);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_hist256, dim3((unsigned)blocks), dim3(TB), 0, q, T, n, d_hist.as<u32>());
+        RV_LAUNCH_CHECK();
+    }
+    u32 hist[256];
+    RV_HIP(hipMemcpyAsync(hist, d_hist.p, sizeof hist, hipMemcpyDeviceToHost, q));
+    RV_HIP(hipStreamSynchronize(q));
+    uint8_t lut[256];
+    int sigma = 0;
+    for (int c = 0; c < 256; c++) lut[c] = hist[c] ? (uint8_t)(++sigma) : (uint8_t)0;
+    int bits = bitlen((u64)sigma);            // codes 0..sigma
+    if (bits < 1) bits = 1;
+    int K = 64 / bits;
+    if (K > 32) K = 32;
+    if (sigma >= 255) { bits = 8; K = 8; for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c; /* 0 byte never occurs in a C-string text */ }
+    s.sigma = sigma; s.bits = bits; s.k0 = K;
+    RV_HIP(hipMemcpyAsync(d_lut.p, lut, 256, hipMemcpyHostToDevice, q));
+
+    // -- buffers
+    DBuf bk0, bk1, bv0, bv1, bhead, bseed, bgrp, bisa, bP0, bP1, bG0, bG1, btile;
+    auto freeall = [&]() {
+        for (DBuf *b : {&d_hist, &d_lut, &bk0, &bk1, &bv0, &bv1, &bhead, &bseed, &bgrp, &bisa, &bP0, &bP1, &bG0, &bG1, &btile}) b->release();
+    };
+#define SA_TRY(x) do { int r__ = (x); if (r__) { freeall(); return r__; } } while (0)
+#define SA_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rv_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); freeall(); return -1; } } while (0)
+    SA_TRY(bk0.reserve((size_t)n * 8)); SA_TRY(bk1.reserve((size_t)n * 8));
+    SA_TRY(bv0.reserve((size_t)n * sizeof(sav_t))); SA_TRY(bv1.reserve((size_t)n * sizeof(sav_t)));
+    SA_TRY(bhead.reserve((size_t)n + 16)); SA_TRY(bseed.reserve((size_t)n * 4)); SA_TRY(bgrp.reserve((size_t)n * 4));
+    SA_TRY(bisa.reserve((size_t)n * 4));
+    const unsigned nblk = (unsigned)ceil_div(n, TB);
+
+    // -- first key, sorted on its K*bits significant bits
+    hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), bits, K,
+                       bk0.as<u64>(), bv0.as<sav_t>());
+    SA_HIP(hipGetLastError());
+    int in1 = 0;
+    SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, K * bits, &in1));
+    s.radix_passes += (K * bits + 7) / 8; s.sorted_elems += n;
+    u64 *ks = in1 ? bk1.as<u64>() : bk0.as<u64>();
+    sav_t *vs = in1 ? bv1.as<sav_t>() : bv0.as<sav_t>();
+    u64 *kt = in1 ? bk0.as<u64>() : bk1.as<u64>();      // the free pair
+    sav_t *vt = in1 ? bv0.as<sav_t>() : bv1.as<sav_t>();
+
+    uint8_t *head = bhead.as<uint8_t>();
+    u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
+    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed);
+    SA_HIP(hipGetLastError());
+    SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
+    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, (const u32 *)grp, n, SA, ISA);
+    SA_HIP(hipGetLastError());
+
+    // -- compaction of the non-unique suffixes (round 0: from the full arrays)
+    int64_t ntile = ceil_div(n, CP_TILE);
+    SA_TRY(btile.reserve((size_t)(ntile + 1) * 4));
+    u32 *tile = btile.as<u32>();
+    auto compact = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in,
+                       u32 *P, sav_t *S, u32 *G, int64_t *m_out) -> int {
+        const int64_t nt = ceil_div(len, CP_TILE);
+        hipLaunchKernelGGL(k_cp_count, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, tile);
+        RV_LAUNCH_CHECK();
+        // one extra slot so the scan also yields the total
+        RV_HIP(hipMemsetAsync(tile + nt, 0, 4, q));
+        RV_TRY(rv_exclusive_sum_u32(ws, tile, tile, nt + 1));
+        u32 tot = 0;
+        RV_HIP(hipMemcpyAsync(&tot, tile + nt, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        *m_out = tot;
+        if (tot == 0) return 0;
+        hipLaunchKernelGGL(k_cp_emit, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, (const u32 *)tile, pos_in, suf_in, grp_in, P, S, G);
+        RV_LAUNCH_CHECK();
+        return 0;
+    };
+
+    // Count first so the list buffers can be sized to m (usually << n later on,
+    // but close to n in round 0).
+    int64_t m = 0;
+    SA_TRY(bP0.reserve((size_t)n * 4)); SA_TRY(bG0.reserve((size_t)n * 4));
+    // round-0 suffix list goes to the free value buffer `vt`
+    SA_TRY(compact(head, n, nullptr, vs, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
+    u32 *P = bP0.as<u32>(), *G = bG0.as<u32>();
+    sav_t *S = vt;          // current list of suffixes (length m)
+    sav_t *Sfree = vs;      // the other value buffer
+    u64 *kA = ks, *kB = kt; // both key buffers are free from here on
+
+    const int lowbits = bitlen((u64)n), highbits = bitlen((u64)(n > 1 ? n - 1 : 1));
+    int64_t h = K;
+    while (m > 0) {
+        if (h >= 2 * n + 2) { rv_set_error("SA build: did not converge"); freeall(); return -1; }
+        s.rounds++;
+        const unsigned mb = (unsigned)ceil_div(m, TB);
+        hipLaunchKernelGGL(k_round_keys, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)G, m, n, h, (const u32 *)ISA, kA);
+        SA_HIP(hipGetLastError());
+        // sort (kk, S): low half on [0,lowbits), then high half on [32,32+highbits)
+        int f1 = 0, f2 = 0;
+        SA_TRY(rv_radix_sort_pairs<sav_t>(ws, kA, S, kB, Sfree, m, 0, lowbits, &f1));
+        u64 *k_in = f1 ? kB : kA, *k_out = f1 ? kA : kB;
+        sav_t *s_in = f1 ? Sfree : S, *s_out = f1 ? S : Sfree;
+        SA_TRY(rv_radix_sort_pairs<sav_t>(ws, k_in, s_in, k_out, s_out, m, 32, 32 + highbits, &f2));
+        u64 *kS = f2 ? k_out : k_in;
+        sav_t *sS = f2 ? s_out : s_in;
+        sav_t *sOther = f2 ? s_in : s_out;
+        u64 *kOther = f2 ? k_in : k_out;
+        s.radix_passes += (lowbits + 7) / 8 + (highbits + 7) / 8; s.sorted_elems += m;
+
+        // heads in the list, SA write-back, new group ranks, ISA update
+        hipLaunchKernelGGL(k_round_heads, dim3(mb), dim3(TB), 0, q, (const u64 *)kS, (const u32 *)P, (const sav_t *)sS, m, head, seed, SA);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));
+        hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)sS, (const u32 *)grp, m, ISA);
+        SA_HIP(hipGetLastError());
+
+        // next list
+        if (!bP1.p) { SA_TRY(bP1.reserve((size_t)m * 4)); SA_TRY(bG1.reserve((size_t)m * 4)); }
+        int64_t m2 = 0;
+        SA_TRY(compact(head, m, P, sS, grp, bP1.as<u32>(), sOther, bG1.as<u32>(), &m2));
+        // swap list buffers
+        { DBuf t = bP0; bP0 = bP1; bP1 = t; t = bG0; bG0 = bG1; bG1 = t; }
+        P = bP0.as<u32>(); G = bG0.as<u32>();
+        S = sOther; Sfree = sS; kA = kS; kB = kOther;
+        m = m2;
+        h *= 2;
+    }
+#undef SA_TRY
+#undef SA_HIP
+    RV_HIP(hipStreamSynchronize(q));
+    freeall();
+    if (st) *st = s;
+    return 0;
+}

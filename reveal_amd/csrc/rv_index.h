@@ -1,0 +1,87 @@
+// rv_index.h -- the index handle behind the C ABI (include/reveal_amd.h).
+#pragma once
+#include "rv_common.h"
+#include "rv_scan.h"
+#include "../../include/reveal_amd.h"
+#include <utility>
+
+struct RvIntv { int64_t begin, end; };
+
+// HIP-event profiler for kernel classes (bench.py's roofline figure).
+struct RvProf {
+    bool on = false;
+    struct Span { hipEvent_t a, b; int k; double bytes; };
+    std::vector<Span> spans;
+    std::vector<hipEvent_t> pool;
+    int64_t launches[RV_K_COUNT] = {0};
+    double ms[RV_K_COUNT] = {0};
+    double bytes[RV_K_COUNT] = {0};
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+    int begin(hipStream_t s, int k, double nbytes) {
+        if (!on) return -1;
+        Span sp; sp.a = get(); sp.b = get(); sp.k = k; sp.bytes = nbytes;
+        (void)hipEventRecord(sp.a, s);
+        spans.push_back(sp);
+        return (int)spans.size() - 1;
+    }
+    void end(hipStream_t s, int id) { if (id >= 0) (void)hipEventRecord(spans[id].b, s); }
+    void resolve() {   // caller has synchronised the stream
+        for (auto &sp : spans) {
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, sp.a, sp.b) == hipSuccess) { ms[sp.k] += t; launches[sp.k]++; bytes[sp.k] += sp.bytes; }
+            pool.push_back(sp.a); pool.push_back(sp.b);
+        }
+        spans.clear();
+    }
+    void reset() { resolve(); for (int k = 0; k < RV_K_COUNT; k++) { launches[k] = 0; ms[k] = 0; bytes[k] = 0; } }
+    void release() { resolve(); for (auto e : pool) (void)hipEventDestroy(e); pool.clear(); }
+};
+
+// One sub-index of the current recursion level (host side bookkeeping; the
+// ranks live in the level arrays at [off, off+n)).
+struct RvSub {
+    int64_t off = 0, n = 0;
+    int depth = 0, nsamples = 0, parent = -1, kind = 0;
+    std::vector<RvIntv> nodes;         // sorted by begin
+    // scan result (host copies), CSR
+    int64_t mum_first = 0, nmums = 0;  // range in the level-wide match arrays
+    // decision
+    bool has_split = false;
+    u32 l = 0;
+    std::vector<int64_t> sp;
+    std::vector<RvIntv> lead, trail, match, rest;
+};
+
+struct rv_index {
+    int device = 0;
+    Workspace ws;
+    RvProf prof;
+    // ---- host text assembly (interface.c:18-95)
+    std::vector<char> T;               // n chars + NUL
+    std::vector<int64_t> nsep;
+    std::vector<RvIntv> nodes;
+    int nsamples = 0;
+    int64_t n = 0, nT = 0;
+    int rc = 0;
+    bool constructed = false, main_arrays_freed = false;
+    // ---- device state
+    DBuf dT, dSA, dSAi, dLCP, dNsep;
+    u32 maxlcp = 0;
+    RvSaStats sa_stats{};
+    // ---- scan results of the main index (getmums / getmultimums)
+    std::vector<u32> m_l; std::vector<int64_t> m_a, m_b;
+    std::vector<u32> mm_l; std::vector<int32_t> mm_n; std::vector<int64_t> mm_off, mm_pos; std::vector<uint16_t> mm_so;
+    // ---- recursion state (rv_align.hip)
+    struct Align *al = nullptr;
+};
+
+// scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, std::vector<RvPairRec> &out);
+
+// rv_align.hip
+void rv_align_free(rv_index *h);

@@ -1,0 +1,235 @@
+// rv_prims.hip -- device-wide primitives for gfx950 (wave64): multi-level
+// scans and a stable LSD radix sort with ballot-based wave ranking and
+// LDS-staged digit buckets.  Used by the SA build (the reference's divsufsort
+// slot, interface.c:215-222) and by the split/compaction steps.
+#include "rv_common.h"
+
+// ---------------------------------------------------------------------------
+// scans
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS   = 8;
+constexpr int SCAN_TILE    = SCAN_THREADS * SCAN_ITEMS;
+
+template <class T> struct OpSum {
+    __device__ static T id() { return (T)0; }
+    __device__ static T f(T a, T b) { return a + b; }
+};
+template <class T> struct OpMax {
+    __device__ static T id() { return (T)0; }
+    __device__ static T f(T a, T b) { return a > b ? a : b; }
+};
+
+template <class T> __device__ inline T shfl_up_t(T v, int d) { return __shfl_up(v, d, 64); }
+template <> __device__ inline u64 shfl_up_t<u64>(u64 v, int d) {
+    u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+
+// block-wide exclusive scan of one value per thread; returns the exclusive
+// prefix, *total receives the block total (valid in every thread).
+template <class T, class Op>
+__device__ inline T block_exclusive(T x, T *lds /* >= 4 */, T *total) {
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    T inc = x;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        T t = shfl_up_t<T>(inc, d);
+        if (lane >= d) inc = Op::f(t, inc);
+    }
+    T exc = shfl_up_t<T>(inc, 1);
+    if (lane == 0) exc = Op::id();
+    if (lane == 63) lds[w] = inc;
+    __syncthreads();
+    T base = Op::id(), tot = Op::id();
+#pragma unroll
+    for (int k = 0; k < SCAN_THREADS / 64; k++) {
+        T v = lds[k];
+        if (k < w) base = Op::f(base, v);
+        tot = Op::f(tot, v);
+    }
+    __syncthreads();
+    *total = tot;
+    return Op::f(base, exc);
+}
+
+template <class T, class Op>
+__global__ __launch_bounds__(SCAN_THREADS) void k_tile_reduce(const T *__restrict__ in, T *__restrict__ totals, int64_t n) {
+    __shared__ T lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T acc = Op::id();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++)
+        if (base + i < n) acc = Op::f(acc, in[base + i]);
+    T tot;
+    (void)block_exclusive<T, Op>(acc, lds, &tot);
+    if (threadIdx.x == 0) totals[blockIdx.x] = tot;
+}
+
+template <class T, class Op, bool INCL>
+__global__ __launch_bounds__(SCAN_THREADS) void k_tile_scan(const T *in, T *out, const T *__restrict__ tile_prefix, int64_t n) {
+    __shared__ T lds[4];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
+    T v[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : Op::id();
+    T acc = Op::id();
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) acc = Op::f(acc, v[i]);
+    T tot;
+    T pre = block_exclusive<T, Op>(acc, lds, &tot);
+    if (tile_prefix) pre = Op::f(tile_prefix[blockIdx.x], pre);
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        T nx = Op::f(pre, v[i]);
+        if (base + i < n) out[base + i] = INCL ? nx : pre;
+        pre = nx;
+    }
+}
+
+template <class T, class Op, bool INCL>
+int scan_rec(Workspace &ws, const T *in, T *out, int64_t n, int level) {
+    if (n <= 0) return 0;
+    const int64_t nt = ceil_div(n, SCAN_TILE);
+    if (nt == 1) {
+        hipLaunchKernelGGL((k_tile_scan<T, Op, INCL>), dim3(1), dim3(SCAN_THREADS), 0, ws.stream, in, out, (const T *)nullptr, n);
+        RV_LAUNCH_CHECK();
+        return 0;
+    }
+    if (level >= 4) { rv_set_error("scan: too many levels"); return -1; }
+    RV_TRY(ws.scan_tmp[level].reserve((size_t)nt * sizeof(T)));
+    T *tot = ws.scan_tmp[level].as<T>();
+    hipLaunchKernelGGL((k_tile_reduce<T, Op>), dim3((unsigned)nt), dim3(SCAN_THREADS), 0, ws.stream, in, tot, n);
+    RV_LAUNCH_CHECK();
+    RV_TRY((scan_rec<T, Op, false>(ws, tot, tot, nt, level + 1)));
+    hipLaunchKernelGGL((k_tile_scan<T, Op, INCL>), dim3((unsigned)nt), dim3(SCAN_THREADS), 0, ws.stream, in, out, (const T *)tot, n);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+int rv_exclusive_sum_u32(Workspace &ws, const u32 *in, u32 *out, int64_t n) { return scan_rec<u32, OpSum<u32>, false>(ws, in, out, n, 0); }
+int rv_exclusive_sum_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n) { return scan_rec<u64, OpSum<u64>, false>(ws, in, out, n, 0); }
+int rv_inclusive_max_u32(Workspace &ws, const u32 *in, u32 *out, int64_t n) { return scan_rec<u32, OpMax<u32>, true>(ws, in, out, n, 0); }
+int rv_inclusive_max_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n) { return scan_rec<u64, OpMax<u64>, true>(ws, in, out, n, 0); }
+
+// ---------------------------------------------------------------------------
+// radix sort: 8-bit digits, 256 threads x 16 keys per block.
+//   pass = histogram kernel -> device scan of (digit-major) block histograms
+//          -> scatter kernel.
+// Stability inside a block comes from the element order (wave, item, lane):
+// wave w owns 1024 consecutive keys, item r covers 64 consecutive keys (one
+// coalesced load per item).  Ranking inside a wave is done with 8 ballots per
+// item (one per digit bit): the lanes holding the same digit form `peers`,
+// the lowest of them bumps the wave's LDS bucket counter, every peer takes
+// old + popcount(peers below me).
+// ---------------------------------------------------------------------------
+namespace {
+
+constexpr int RS_THREADS = 256;
+constexpr int RS_ITEMS   = 16;
+constexpr int RS_TILE    = RS_THREADS * RS_ITEMS;
+constexpr int RS_WAVES   = RS_THREADS / 64;
+
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, int64_t n, int shift, u32 *__restrict__ blockhist, u32 nblocks) {
+    __shared__ u32 h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        int64_t i = base + (int64_t)r * RS_THREADS + threadIdx.x;
+        if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <class V>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ kin, const V *__restrict__ vin,
+                                                            u64 *__restrict__ kout, V *__restrict__ vout, int64_t n, int shift,
+                                                            const u32 *__restrict__ blockoff, u32 nblocks) {
+    __shared__ u32 cnt[RS_WAVES][256];
+    __shared__ u32 gbase[256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int k = threadIdx.x; k < RS_WAVES * 256; k += RS_THREADS) (&cnt[0][0])[k] = 0;
+    gbase[threadIdx.x] = blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    __syncthreads();
+
+    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
+    u64 key[RS_ITEMS];
+    u32 rnk[RS_ITEMS];
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int64_t i = wbase + (int64_t)r * 64 + lane;
+        const bool valid = i < n;
+        key[r] = valid ? kin[i] : ~0ull;
+        const u32 d = (u32)(key[r] >> shift) & 255u;
+        u64 peers = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bal = __ballot(bit);
+            peers &= bit ? bal : ~bal;
+        }
+        const u32 below = (u32)__popcll(peers & lt);
+        const u32 old = cnt[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && below == 0) cnt[w][d] = old + (u32)__popcll(peers);
+        __builtin_amdgcn_wave_barrier();
+        rnk[r] = old + below;
+    }
+    __syncthreads();
+    {   // exclusive prefix over the waves of this block, per digit
+        const int d = threadIdx.x;
+        u32 run = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) { u32 c = cnt[k][d]; cnt[k][d] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < RS_ITEMS; r++) {
+        const int64_t i = wbase + (int64_t)r * 64 + lane;
+        if (i < n) {
+            const u32 d = (u32)(key[r] >> shift) & 255u;
+            const size_t dst = (size_t)gbase[d] + cnt[w][d] + rnk[r];
+            kout[dst] = key[r];
+            vout[dst] = vin[i];
+        }
+    }
+}
+
+}  // namespace
+
+template <class V>
+int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n, int bit_lo, int bit_hi, int *result_in_1) {
+    *result_in_1 = 0;
+    if (n <= 1 || bit_hi <= bit_lo) return 0;
+    if (n >= ((int64_t)1 << 32)) { rv_set_error("radix sort: n >= 2^32 not supported"); return -1; }
+    const u32 nb = (u32)ceil_div(n, RS_TILE);
+    RV_TRY(ws.rs_hist.reserve((size_t)256 * nb * sizeof(u32)));
+    u32 *bh = ws.rs_hist.as<u32>();
+    u64 *ki = k0, *ko = k1;
+    V *vi = v0, *vo = v1;
+    int flip = 0;
+    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, bh, nb);
+        RV_LAUNCH_CHECK();
+        RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, (int64_t)256 * nb));
+        hipLaunchKernelGGL((k_rs_scatter<V>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, (const V *)vi, ko, vo, n, shift,
+                           (const u32 *)bh, nb);
+        RV_LAUNCH_CHECK();
+        u64 *tk = ki; ki = ko; ko = tk;
+        V *tv = vi; vi = vo; vo = tv;
+        flip ^= 1;
+    }
+    *result_in_1 = flip;
+    return 0;
+}
+
+template int rv_radix_sort_pairs<u32>(Workspace &, u64 *, u32 *, u64 *, u32 *, int64_t, int, int, int *);
+template int rv_radix_sort_pairs<u64>(Workspace &, u64 *, u64 *, u64 *, u64 *, int64_t, int, int, int *);

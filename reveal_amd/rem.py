@@ -1,0 +1,126 @@
+"""Python-3 harness around the `index` type: the call protocol of the
+reference's `reveal rem` driver (reveal/rem.py:511-611 align_genomes,
+reveal/utils.py:304-375 read_fasta) plus the deterministic benchmark callbacks
+of SURVEY.md 8(d).  The reference's graph layer (networkx graph, interval tree,
+chaining picker, GFA IO) is out of scope; this module only feeds the index the
+way the reference does and supplies callbacks with the reference's signatures.
+"""
+import gzip
+import os
+
+
+def fasta_reader(fn, toupper=True, keepdash=False):
+    """reveal/utils.py:79-160 with its defaults (truncN=False, cutN=0)."""
+    name, seq = None, []
+    fopen = gzip.open if fn.endswith(".gz") else open
+    with fopen(fn, "rt") as ff:
+        for line in ff:
+            line = line.rstrip()
+            if line.startswith(">"):
+                if seq:
+                    yield name, "".join(seq)
+                name, seq = line.replace(">", "").replace("\t", ""), []
+            else:
+                if toupper:
+                    line = line.upper()
+                if not keepdash:
+                    line = line.replace("-", "")
+                seq.append(line)
+    if seq:
+        yield name, "".join(seq)
+
+
+def read_fasta(fasta, index, contigs=True, toupper=True):
+    """reveal/utils.py:304-375 minus the graph bookkeeping: one addsample per
+    file and one addsequence per contig (or, with contigs=False, one sample per
+    sequence).  Returns [(name, (begin, end))]."""
+    out = []
+    if contigs:
+        index.addsample(os.path.basename(fasta))
+        for name, seq in fasta_reader(fasta, toupper=toupper):
+            out.append((name, index.addsequence(seq)))
+    else:
+        for name, seq in fasta_reader(fasta, toupper=toupper):
+            index.addsample(name)
+            out.append((name, index.addsequence(seq)))
+    return out
+
+
+def add_sequences(index, seqs, names=None):
+    """rem.align's protocol (reveal/rem.py:647-671): one sample per sequence."""
+    out = []
+    for k, s in enumerate(seqs):
+        index.addsample(names[k] if names else "s%d" % k)
+        out.append(index.addsequence(s if isinstance(s, (bytes, bytearray)) else s.upper()))
+    return out
+
+
+# ---- benchmark callbacks (same contracts as schemes.graphmumpicker / rem.graphalign)
+
+def bench_mumpicker(mums, idx, precomputed=False, minlength=0):
+    """mumpicker(mums, idx, precomputed=, minlength=) -> () | (mum, skipleft, skipright)
+    (reveal.c:839-895).  Keeps matches present in every sample of the
+    sub-index (schemes.py:227), takes the longest, ties -> smallest minimum
+    coordinate; no seeds."""
+    best = None
+    ns = idx.nsamples
+    for m in mums:
+        if m[1] != ns:
+            continue
+        mn = min(p for _, p in m[2])
+        if best is None or m[0] > best[0][0] or (m[0] == best[0][0] and mn < best[1]):
+            best = (m, mn)
+    if best is None:
+        return ()
+    return (best[0], [], [])
+
+
+def linear_graphalign(idx, mum):
+    """graphalign(idx, mum) -> (leading, trailing, matching, rest, merged, newleft, newright)
+    (reveal.c:937-999) for the linear interval model: every member lies in one
+    interval of the sub-index; left remainders lead, right remainders trail."""
+    l, n, spd = mum
+    nodes = sorted(idx.nodes)
+    lead, trail, match, touched = [], [], [], set()
+    for _, sp in spd:
+        hit = None
+        for q, (b, e) in enumerate(nodes):
+            if b <= sp < e:
+                hit = q
+                break
+        if hit is None or sp + l > nodes[hit][1]:
+            return None
+        b, e = nodes[hit]
+        touched.add(hit)
+        if sp > b:
+            lead.append((b, sp))
+        if sp + l < e:
+            trail.append((sp + l, e))
+        match.append((sp, sp + l))
+    rest = [iv for q, iv in enumerate(nodes) if q not in touched]
+    merged = tuple(sorted(match)[0])
+    return sorted(lead), sorted(trail), sorted(match), sorted(rest), merged, merged, merged
+
+
+def align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, sa="", lcp="", cache=0,
+                  mumpicker=bench_mumpicker, graphalign=linear_graphalign):
+    """reveal/rem.py:511-611: build the index from FASTA files, construct, align.
+    Returns (idx, anchors) where anchors is the list of matches handed to
+    graphalign, in callback order."""
+    from . import reveallib, reveallib64
+    mod = reveallib64 if sa64 else reveallib
+    idx = mod.index(sa=sa, lcp=lcp, cache=cache)
+    for f in inputfiles:
+        read_fasta(f, idx, contigs=contigs, toupper=toupper)
+    if len(idx.samples) <= 1:
+        raise ValueError("Specify at least 2 targets to construct alignment.")
+    idx.construct()
+    anchors = []
+
+    def galign(i, mum):
+        r = graphalign(i, mum)
+        if r is not None:
+            anchors.append(mum)
+        return r
+    idx.align(mumpicker, galign, threads=0, wpen=1, wscore=1, minl=minlength, minn=minn)
+    return idx, anchors

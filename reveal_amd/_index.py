@@ -283,6 +283,35 @@ def make_index_type(sa64, error):
                 self._n_sub = self._nsamples_sub = None
             return None
 
+        def align_builtin(self, minl=20, minn=2, trace=False):
+            """Not in the reference: the whole recursion with the library's
+            built-in deterministic callbacks (longest full match, linear interval
+            model) -- what bench.py times.  Same result as
+            align(rem.bench_mumpicker, rem.linear_graphalign, minl=, minn=).
+            -> dict(stats, anchors=[(l, (pos...))], trace=structured array | None)"""
+            if not self._constructed:
+                raise error("Index not yet constructed, alignment stopped.")
+            dll, h = self._dll, self._h
+            dll.rv_set_trace(h, 1 if trace else 0)
+            st = _lib.RvAlignStats()
+            if dll.rv_align_builtin(h, int(minl), int(minn), ctypes.byref(st)) != 0:
+                self._fail()
+            mem = ctypes.c_int64(0)
+            na = dll.rv_anchor_count(h, ctypes.byref(mem))
+            l = np.zeros(max(na, 1), dtype=np.uint32); off = np.zeros(na + 1, dtype=np.int64)
+            pos = np.zeros(max(mem.value, 1), dtype=np.int64)
+            if dll.rv_fetch_anchors(h, l.ctypes.data, off.ctypes.data, pos.ctypes.data) != 0:
+                self._fail()
+            tr = None
+            if trace:
+                nt = dll.rv_trace_count(h)
+                tr = np.zeros(max(nt, 1), dtype=_lib.TRACE_DTYPE)
+                if dll.rv_fetch_trace(h, tr.ctypes.data, len(tr)) != 0:
+                    self._fail()
+                tr = tr[:nt]
+            stats = {f[0]: getattr(st, f[0]) for f in _lib.RvAlignStats._fields_}
+            return dict(stats=stats, anchors=(l[:na], off, pos[:mem.value]), trace=tr)
+
         def _fetch_sub_mums(self, s, info):
             cnt, mem = info.nmums, info.nmembers
             l = np.zeros(max(cnt, 1), dtype=np.uint32); n = np.zeros(max(cnt, 1), dtype=np.int32)

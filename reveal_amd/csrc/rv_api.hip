@@ -187,6 +187,12 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         RV_TRY(write_raw(".reveal.sa", sa.data(), (size_t)n * sizeof(sa_t)));
         RV_TRY(write_raw(".reveal.lcp", lc.data(), (size_t)n * sizeof(lcp_t)));
     }
+    {   // sample separators for the multi-sample scans (SO is derived from them on the fly)
+        std::vector<sa_t> ns(h->nsep.size() + 1, 0);
+        for (size_t k = 0; k < h->nsep.size(); k++) ns[k] = (sa_t)h->nsep[k];
+        RV_TRY(h->dNsep.reserve(ns.size() * sizeof(sa_t)));
+        RV_HIP(hipMemcpy(h->dNsep.p, ns.data(), ns.size() * sizeof(sa_t), hipMemcpyHostToDevice));
+    }
     h->constructed = true;
     h->main_arrays_freed = false;
     return 0;
@@ -284,7 +290,86 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, i
     return -1;
 }
 
+// multi-MUM scan driver (same tile-ordered merge as the pair scan)
+int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, int minn, int mems,
+                      std::vector<u32> &l, std::vector<int32_t> &n, std::vector<int64_t> &off, std::vector<uint16_t> &so,
+                      std::vector<int64_t> &pos, std::vector<int64_t> *ub_out) {
+    l.clear(); n.clear(); off.assign(1, 0); so.clear(); pos.clear();
+    if (ub_out) ub_out->clear();
+    if (mems) { rv_set_error("getmultimems is not implemented on the GPU yet"); return -1; }
+    if (h->nsamples < 2) { rv_set_error("multi scan needs at least two samples"); return -1; }
+    if (m <= 1) return 0;
+    hipStream_t q = h->ws.stream;
+    const int64_t ntile = ceil_div(m, RV_MULTI_TILE);
+    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &brec = h->ws.misc[5], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
+    RV_TRY(bcnt.reserve(64));
+    RV_TRY(btab.reserve((size_t)ntile * sizeof(uint4)));
+    if (brec.cap < 4096 * sizeof(RvMultiRec)) RV_TRY(brec.reserve(sizeof(RvMultiRec) * (size_t)std::max<int64_t>(4096, m / 32)));
+    if (bso.cap < 8192 * 2) { RV_TRY(bso.reserve(2 * (size_t)std::max<int64_t>(8192, m / 8))); }
+    RV_TRY(bpos.reserve((bso.cap / 2) * sizeof(sa_t)));
+    std::vector<uint4> tab((size_t)ntile);
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t rcap = brec.cap / sizeof(RvMultiRec), mcap = std::min(bso.cap / 2, bpos.cap / sizeof(sa_t));
+        RV_HIP(hipMemsetAsync(bcnt.p, 0, 8, q));
+        int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
+        RV_TRY(rv_scan_multi_launch(h->ws, SA, LCP, m, h->dT.as<uint8_t>(), h->dNsep.as<sa_t>(), h->nsamples, minl, minn,
+                                    brec.as<RvMultiRec>(), bso.as<uint16_t>(), bpos.as<sa_t>(), (u32)std::min<size_t>(rcap, 0xffffffffu),
+                                    (u32)std::min<size_t>(mcap, 0xffffffffu), bcnt.as<u32>(), btab.as<uint4>()));
+        h->prof.end(q, id);
+        u32 tot[2] = {0, 0};
+        RV_HIP(hipMemcpyAsync(tot, bcnt.p, 8, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(tab.data(), btab.p, (size_t)ntile * sizeof(uint4), hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        if (tot[0] <= rcap && tot[1] <= mcap) {
+            std::vector<RvMultiRec> rr(tot[0]);
+            std::vector<uint16_t> rso(tot[1]);
+            std::vector<sa_t> rpos(tot[1]);
+            if (tot[0]) RV_HIP(hipMemcpy(rr.data(), brec.p, (size_t)tot[0] * sizeof(RvMultiRec), hipMemcpyDeviceToHost));
+            if (tot[1]) {
+                RV_HIP(hipMemcpy(rso.data(), bso.p, (size_t)tot[1] * 2, hipMemcpyDeviceToHost));
+                RV_HIP(hipMemcpy(rpos.data(), bpos.p, (size_t)tot[1] * sizeof(sa_t), hipMemcpyDeviceToHost));
+            }
+            l.reserve(tot[0]); n.reserve(tot[0]); off.reserve(tot[0] + 1); so.reserve(tot[1]); pos.reserve(tot[1]);
+            for (int64_t t = 0; t < ntile; t++) {
+                const uint4 e = tab[(size_t)t];
+                for (u32 k = 0; k < e.y; k++) {
+                    const RvMultiRec &r = rr[e.x + k];
+                    l.push_back(r.l); n.push_back((int32_t)r.n);
+                    if (ub_out) ub_out->push_back((int64_t)r.ub);
+                }
+                for (u32 k = 0; k < e.w; k++) { so.push_back(rso[e.z + k]); pos.push_back((int64_t)rpos[e.z + k]); }
+            }
+            int64_t acc = 0;
+            for (size_t k = 0; k < n.size(); k++) { acc += n[k]; off.push_back(acc); }
+            return 0;
+        }
+        if (tot[0] > rcap) RV_TRY(brec.reserve((size_t)tot[0] * sizeof(RvMultiRec)));
+        if (tot[1] > mcap) { RV_TRY(bso.reserve((size_t)tot[1] * 2)); RV_TRY(bpos.reserve((size_t)tot[1] * sizeof(sa_t))); }
+    }
+    rv_set_error("multi scan: output buffer sizing failed");
+    return -1;
+}
+
 extern "C" {
+
+/* reveal.c:436-580 / 292-434 */
+int64_t rv_getmultimums(rv_index *h, int minlength, int minn, int mems, int64_t *members) {
+    if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
+    if (h->nsamples <= 2) { rv_set_error("getmultimums needs more than two samples (SO not available)"); return -1; }
+    (void)hipSetDevice(h->device);
+    if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr)) return -1;
+    if (members) *members = (int64_t)h->mm_pos.size();
+    return (int64_t)h->mm_l.size();
+}
+
+int rv_fetch_multi(rv_index *h, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos) {
+    memcpy(l, h->mm_l.data(), h->mm_l.size() * 4);
+    memcpy(n, h->mm_n.data(), h->mm_n.size() * 4);
+    memcpy(off, h->mm_off.data(), h->mm_off.size() * 8);
+    memcpy(so, h->mm_so.data(), h->mm_so.size() * 2);
+    memcpy(pos, h->mm_pos.data(), h->mm_pos.size() * 8);
+    return 0;
+}
 
 /* reveal.c:55-116 */
 int64_t rv_getmums(rv_index *h, int minl) {

@@ -135,7 +135,127 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     }
 }
 
+// ---- multi-MUM scan ------------------------------------------------------------
+// Stack-free form of the LCP-interval enumeration of getmultimums
+// (reveal.c:436-580).  The reference closes an interval (l, lb, ub) when it
+// reads LCP[ub+1] < l, deeper intervals first, so its output is ordered by
+// (ub ascending, l descending).  Here the thread at rank u emits every
+// interval with ub == u: it exists iff LCP[u+1] < LCP[u]; walking left from u
+// the interval values are the successive prefix minima of LCP, each > LCP[u+1].
+// Only intervals of at most main.nsamples ranks can qualify (reveal.c:477), so
+// the walk is cut after that many steps.  ismultimum (reveal.c:227-259) is
+// evaluated in place; members are emitted in SA order.
+__device__ inline int sample_of_pos(const sa_t *__restrict__ nsep, int nsep_n, sa_t pos) {   // SO[pos], interface.c:116-134
+    int lo = 0, hi = nsep_n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (nsep[mid] < pos) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+
+__device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t *__restrict__ T, const sa_t *__restrict__ nsep, int nsamples,
+                                      int64_t lb, int64_t ub) {
+    if (nsamples == 2) {
+        if ((SA[ub] > nsep[0]) == (SA[lb] > nsep[0])) return false;
+    } else if (nsamples <= 64) {
+        u64 seen = 0;
+        for (int64_t j = lb; j <= ub; j++) {
+            const u64 bit = 1ull << sample_of_pos(nsep, nsamples - 1, SA[j]);
+            if (seen & bit) return false;
+            seen |= bit;
+        }
+    } else {
+        for (int64_t j = lb; j <= ub; j++) {
+            const int sj = sample_of_pos(nsep, nsamples - 1, SA[j]);
+            for (int64_t k = lb; k < j; k++) if (sample_of_pos(nsep, nsamples - 1, SA[k]) == sj) return false;
+        }
+    }
+    for (int64_t j = lb; j < ub; j++) {
+        const sa_t a = SA[j], b = SA[j + 1];
+        if (a == 0 || b == 0) return true;
+        const uint8_t ca = T[a - 1];
+        if (ca != T[b - 1] || ca == 'N' || ca == '$' || is_lower_c(ca)) return true;
+    }
+    return false;
+}
+
+// EMIT=false: count records/members of rank u; EMIT=true: write them.
+template <bool EMIT>
+__device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ T,
+                                  const sa_t *__restrict__ nsep, int nsamples, int minl, int minn, int64_t u,
+                                  u32 &nrec, u32 &nmem, RvMultiRec *rec_out, uint16_t *so_out, sa_t *pos_out, u32 rec_cap, u32 mem_cap) {
+    nrec = 0; nmem = 0;
+    if (u < 1 || u >= m) return;
+    const u32 lnext = (u + 1 < m) ? (u32)LCP[u + 1] : 0u;
+    u32 cur = (u32)LCP[u];
+    if (cur <= lnext) return;
+    int64_t p = u;                   // invariant: LCP[p+1..u] >= cur, candidate lb is found by moving p left
+    const u32 lmin = (u32)(minl > 1 ? minl : 1);
+    u32 rq = 0, mq = 0;
+    while (cur > lnext && cur >= lmin) {
+        // extend left while LCP[p-1+... ] >= cur : lb = first position (going left) with LCP < cur
+        int64_t lb = p - 1;
+        while (lb >= 0 && (u32)LCP[lb] >= cur) { lb--; if (u - lb + 1 > nsamples) break; }
+        if (lb < 0) break;                                   // cannot happen: LCP of a sub-index' first rank is 0
+        const int64_t n = u - lb + 1;
+        if (n > nsamples) break;                              // every further interval is larger still
+        if (n >= minn && ismultimum_dev(SA, T, nsep, nsamples, lb, u)) {
+            if (EMIT) {
+                if (rq < rec_cap) { RvMultiRec r; r.l = cur; r.n = (u32)n; r.ub = (u32)u; r.pad = 0; rec_out[rq] = r; }
+                for (int64_t j = lb; j <= u; j++, mq++)
+                    if (mq < mem_cap) { so_out[mq] = (uint16_t)sample_of_pos(nsep, nsamples - 1, SA[j]); pos_out[mq] = SA[j]; }
+                rq++;
+            } else {
+                rq++; mq += (u32)n;
+            }
+        }
+        cur = (u32)LCP[lb];                                  // value of the enclosing interval
+        p = lb;
+    }
+    nrec = rq; nmem = mq;
+}
+
+__global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
+                                                   const uint8_t *__restrict__ T, const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
+                                                   RvMultiRec *__restrict__ rec, uint16_t *__restrict__ so, sa_t *__restrict__ pos,
+                                                   u32 rec_cap, u32 mem_cap, u32 *__restrict__ counters, uint4 *__restrict__ tiletab) {
+    __shared__ u32 ws_r[TB / 64], ws_m[TB / 64];
+    __shared__ u32 s_rb, s_mb;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 nr, nm;
+    multi_walk<false>(SA, LCP, m, T, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0);
+    u32 ir = nr, im = nm;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { u32 a = __shfl_up(ir, d, 64), b = __shfl_up(im, d, 64); if (lane >= d) { ir += a; im += b; } }
+    if (lane == 63) { ws_r[w] = ir; ws_m[w] = im; }
+    __syncthreads();
+    u32 br = 0, bm = 0, tr = 0, tm = 0;
+#pragma unroll
+    for (int k = 0; k < TB / 64; k++) { if (k < w) { br += ws_r[k]; bm += ws_m[k]; } tr += ws_r[k]; tm += ws_m[k]; }
+    if (threadIdx.x == 0) {
+        const u32 rb = tr ? atomicAdd(&counters[0], tr) : 0u;
+        const u32 mb = tm ? atomicAdd(&counters[1], tm) : 0u;
+        s_rb = rb; s_mb = mb;
+        tiletab[blockIdx.x] = make_uint4(rb, tr, mb, tm);
+    }
+    __syncthreads();
+    if (nr) {
+        const u32 r0 = s_rb + br + (ir - nr), m0 = s_mb + bm + (im - nm);
+        u32 a2, b2;
+        multi_walk<true>(SA, LCP, m, T, nsep, nsamples, minl, minn, u, a2, b2, rec + r0, so + m0, pos + m0,
+                         r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u);
+    }
+}
+
 }  // namespace
+
+int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *T, const sa_t *nsep, int nsamples,
+                         int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, T, nsep, nsamples, minl, minn,
+                       rec, so, pos, rec_cap, mem_cap, counters, tiletab);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
 
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *T, sa_t nsep0, int minl,
                         RvPairRec *out, u32 out_cap, u32 *counter, uint2 *tiletab) {

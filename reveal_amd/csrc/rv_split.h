@@ -1,0 +1,62 @@
+// rv_split.h -- host interface of the per-level label / split / bubble kernels
+#pragma once
+#include "rv_common.h"
+
+#define RV_SPLIT_TILE 2048
+
+// sorted, non-overlapping interval tables of one level (device pointers)
+struct RvLabelTabs {
+    const sa_t    *cbegin, *cend;   // lead / trail / rest intervals of every split sub-index
+    const uint8_t *ccls;            // 1 lead, 2 trail, 4 rest
+    int            ncls;
+    const sa_t    *mbegin, *mend;   // matched ranges [sp, sp+l)
+    int            nmatch;
+};
+
+struct RvSplitArgs {
+    int64_t ntiles;
+    // per tile, class-major [3][ntiles]
+    u32 *tile_cnt, *tile_has, *tile_post;   // written by the reduce pass
+    u32 *tile_G, *tile_carry;               // exclusive prefixes (k_tile_carry)
+    u32 *total;                             // [3] class totals
+    // per sub-index of the current frontier
+    const int64_t *sub_start;               // [nsubs+1], last = m
+    int            nsubs;
+    const u32     *child_base;              // [nsubs*3] first slot of lead/trail/par child in the next level
+    const u32     *child_n;                 // [nsubs*3] expected sizes
+    u32           *sub_off;                 // [nsubs*3] child_base - (class count before the sub), by k_seg_offsets
+    // windows [cut_lo, cut_hi) in front of the cuts of each sub's leading child
+    const int     *cut_first;               // [nsubs+1]
+    const sa_t    *cut_lo, *cut_hi;
+    // outputs
+    sa_t  *SA_out;
+    lcp_t *LCP_out;
+    sa_t  *SAi;
+    u32   *err;
+};
+
+struct RvBubbleDesc {
+    int64_t off, n;      // leading child's slice of the next-level arrays
+    int64_t B;           // cut = begin of a matched interval
+    int64_t wlo;         // window [wlo, B)
+    int     cut0, cut1;  // this child's windows in cut_lo/cut_hi (for SAi upkeep)
+};
+
+struct RvBubbleArgs {
+    const RvBubbleDesc *desc;
+    const int64_t      *woff;     // prefix sums of window widths over all descriptors (+1)
+    u32                *cnt;      // per descriptor: number of active ranks found
+    u32                *list;     // active ranks, descriptor d at [woff[d], ...)
+    sa_t  *SA;
+    lcp_t *LCP;
+    sa_t  *SAi;
+    const sa_t *cut_lo, *cut_hi;
+    u32   *err;
+};
+
+int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs &t, uint8_t *D);
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, int64_t m, const RvSplitArgs &a,
+                    const int *d_split_subs, int nsplit);
+int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
+int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window);
+int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi);

@@ -1,0 +1,446 @@
+// rv_split.hip -- one recursion level of aligner() for ALL sub-indices at once:
+// D-label, split, lower-casing and bubble_sort (reveallib/reveal.c:1005-1252,
+// split :582-664, bubble_sort :666-727) as segmented kernels over the
+// concatenated level arrays.
+//
+//   k_label        D[i] = label of text position SA[i]  (gather form of the
+//                  scatter at reveal.c:1024-1116; 1 lead, 2 trail, 4 rest, 3 matched)
+//   k_split<false> per 2048-rank tile: class counts + running-min summaries
+//   k_tile_carry   exclusive scan of those summaries over tiles (one block)
+//   k_seg_offsets  per split sub-index: class counts before its first rank ->
+//                  destination offsets of its three children (+ size check)
+//   k_split<true>  stable 3-way partition: child SA, child LCP (running minimum
+//                  of the parent LCP since the previous rank of the same child,
+//                  exactly the minlcp* bookkeeping of reveal.c:636-662 incl.
+//                  its `continue` for unlabelled ranks), windowed SAi
+//   k_lower        T[j] = tolower(T[j]) over the matched ranges (reveal.c:1230-1234)
+//   k_bubble_*     bubble_sort on every leading child, one cut (matched begin)
+//                  per round, in the order graphalign listed them
+#include "rv_common.h"
+#include "rv_split.h"
+
+namespace {
+
+constexpr int TB = 256;
+constexpr int SP_ITEMS = 8;
+constexpr int SP_TILE = TB * SP_ITEMS;      // == RV_SPLIT_TILE
+constexpr u32 INF = 0xFFFFFFFFu;
+
+__device__ inline int cls_index(uint8_t d) { return d == 1 ? 0 : d == 2 ? 1 : d == 4 ? 2 : -1; }
+
+// ---- label -------------------------------------------------------------------
+template <class P>
+__device__ inline int upper_idx(const P *__restrict__ begins, int n, P pos) {   // last idx with begins[idx] <= pos, or -1
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (begins[mid] <= pos) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
+
+__global__ __launch_bounds__(TB) void k_label(const sa_t *__restrict__ SA, int64_t m, RvLabelTabs t, uint8_t *__restrict__ D) {
+    const int64_t i0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
+    if (i0 >= m) return;
+    uint8_t d[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint8_t c = 0;
+        if (i0 + k < m) {
+            const sa_t pos = SA[i0 + k];
+            int e = upper_idx<sa_t>(t.cbegin, t.ncls, pos);
+            if (e >= 0 && pos < t.cend[e]) c = t.ccls[e];
+            e = upper_idx<sa_t>(t.mbegin, t.nmatch, pos);
+            if (e >= 0 && pos < t.mend[e]) c = 3;
+        }
+        d[k] = c;
+    }
+    if (i0 + 4 <= m) {
+        *reinterpret_cast<uchar4 *>(D + i0) = make_uchar4(d[0], d[1], d[2], d[3]);
+    } else {
+        for (int k = 0; k < 4 && i0 + k < m; k++) D[i0 + k] = d[k];
+    }
+}
+
+// ---- split -------------------------------------------------------------------
+struct MinSt { u32 has, val; };
+__device__ inline MinSt ms_combine(MinSt a, MinSt b) {   // a then b
+    MinSt r;
+    r.has = a.has | b.has;
+    r.val = b.has ? b.val : (a.val < b.val ? a.val : b.val);
+    return r;
+}
+
+template <bool EMIT>
+__global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ D,
+                                              int64_t m, RvSplitArgs a) {
+    __shared__ u32   s_cnt[TB / 64][3];
+    __shared__ MinSt s_ms[TB / 64][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t j0 = tile * SP_TILE + (int64_t)threadIdx.x * SP_ITEMS;
+
+    uint8_t d[SP_ITEMS + 1];      // d[0] = label of rank j0-1
+    u32 ev[SP_ITEMS];             // effective LCP (INF where the reference skips the min update)
+    sa_t sa[SP_ITEMS];
+    d[0] = (j0 > 0 && j0 - 1 < m) ? D[j0 - 1] : (uint8_t)0;
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+        const int64_t j = j0 + k;
+        d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
+        const u32 l = (j < m) ? (u32)LCP[j] : INF;
+        ev[k] = (d[k] != 0 && j < m) ? l : INF;
+        if (EMIT) sa[k] = (j < m) ? SA[j] : (sa_t)0;
+    }
+    // thread summaries
+    u32 cnt[3] = {0, 0, 0};
+    MinSt st[3] = {{0, INF}, {0, INF}, {0, INF}};
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) st[c].val = st[c].val < ev[k] ? st[c].val : ev[k];
+        const int c = cls_index(d[k + 1]);
+        if (c >= 0) { cnt[c]++; st[c].has = 1; st[c].val = INF; }
+    }
+    // wave-inclusive scans
+    u32 icnt[3]; MinSt ist[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) { icnt[c] = cnt[c]; ist[c] = st[c]; }
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const u32 tc = __shfl_up(icnt[c], dd, 64);
+            MinSt tm; tm.has = __shfl_up(ist[c].has, dd, 64); tm.val = __shfl_up(ist[c].val, dd, 64);
+            if (lane >= dd) { icnt[c] += tc; ist[c] = ms_combine(tm, ist[c]); }
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s_cnt[w][c] = icnt[c]; s_ms[w][c] = ist[c]; }
+    }
+    __syncthreads();
+    if (!EMIT) {
+        if (threadIdx.x < 3) {
+            const int c = threadIdx.x;
+            u32 tot = 0; MinSt ms = {0, INF};
+            for (int k = 0; k < TB / 64; k++) { tot += s_cnt[k][c]; ms = ms_combine(ms, s_ms[k][c]); }
+            a.tile_cnt[(size_t)c * a.ntiles + tile] = tot;
+            a.tile_has[(size_t)c * a.ntiles + tile] = ms.has;
+            a.tile_post[(size_t)c * a.ntiles + tile] = ms.val;
+        }
+        return;
+    }
+    // exclusive prefixes for this thread: tile carry-in, earlier waves, earlier lanes
+    u32 ecnt[3]; MinSt est[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        u32 bc = a.tile_G[(size_t)c * a.ntiles + tile];
+        MinSt bm; bm.has = 0; bm.val = a.tile_carry[(size_t)c * a.ntiles + tile];
+        for (int k = 0; k < w; k++) { bc += s_cnt[k][c]; bm = ms_combine(bm, s_ms[k][c]); }
+        u32 xc = __shfl_up(icnt[c], 1, 64);
+        MinSt xm; xm.has = __shfl_up(ist[c].has, 1, 64); xm.val = __shfl_up(ist[c].val, 1, 64);
+        if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
+        ecnt[c] = bc + xc;
+        est[c] = ms_combine(bm, xm);
+    }
+    if (j0 >= m) return;
+    // owning sub-index of my first rank, then walk
+    int s = upper_idx<int64_t>(a.sub_start, a.nsubs, j0);
+    int64_t s_end = a.sub_start[s + 1];
+    u32 run[3] = {est[0].val, est[1].val, est[2].val};
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+        const int64_t j = j0 + k;
+        if (j >= m) break;
+        while (j >= s_end) { s++; s_end = a.sub_start[s + 1]; }
+#pragma unroll
+        for (int c = 0; c < 3; c++) run[c] = run[c] < ev[k] ? run[c] : ev[k];
+        const int c = cls_index(d[k + 1]);
+        if (c >= 0) {
+            const u32 base = a.child_base[(size_t)s * 3 + c];
+            const u32 np = a.sub_off[(size_t)s * 3 + c] + ecnt[c];       // mod 2^32
+            const u32 idx = np - base;                                   // rank inside the child
+            a.SA_out[np] = sa[k];
+            a.LCP_out[np] = (lcp_t)(idx == 0 ? 0u : run[c]);
+            if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
+                const int q0 = a.cut_first[s], q1 = a.cut_first[s + 1];
+                for (int q = q0; q < q1; q++)
+                    if (sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q]) { a.SAi[sa[k]] = (sa_t)idx; break; }
+            }
+            ecnt[c]++;
+            run[c] = INF;
+        }
+    }
+}
+
+// exclusive scan over tiles of (count, min-state) for the three classes; one block.
+__global__ __launch_bounds__(TB) void k_tile_carry(RvSplitArgs a) {
+    __shared__ u32   s_c[TB / 64];
+    __shared__ MinSt s_m[TB / 64];
+    __shared__ u32   s_runc;
+    __shared__ MinSt s_runm;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int c = 0; c < 3; c++) {
+        if (threadIdx.x == 0) { s_runc = 0; s_runm.has = 0; s_runm.val = INF; }
+        __syncthreads();
+        for (int64_t base = 0; base < a.ntiles; base += TB) {
+            const int64_t t = base + threadIdx.x;
+            u32 x = 0; MinSt mm = {0, INF};
+            if (t < a.ntiles) {
+                x = a.tile_cnt[(size_t)c * a.ntiles + t];
+                mm.has = a.tile_has[(size_t)c * a.ntiles + t];
+                mm.val = a.tile_post[(size_t)c * a.ntiles + t];
+            }
+            u32 ix = x; MinSt im = mm;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                const u32 tc = __shfl_up(ix, dd, 64);
+                MinSt tm; tm.has = __shfl_up(im.has, dd, 64); tm.val = __shfl_up(im.val, dd, 64);
+                if (lane >= dd) { ix += tc; im = ms_combine(tm, im); }
+            }
+            if (lane == 63) { s_c[w] = ix; s_m[w] = im; }
+            __syncthreads();
+            u32 bc = s_runc; MinSt bm = s_runm;
+            u32 totc = s_runc; MinSt totm = s_runm;
+            for (int k = 0; k < TB / 64; k++) {
+                if (k < w) { bc += s_c[k]; bm = ms_combine(bm, s_m[k]); }
+                totc += s_c[k]; totm = ms_combine(totm, s_m[k]);
+            }
+            u32 xc = __shfl_up(ix, 1, 64);
+            MinSt xm; xm.has = __shfl_up(im.has, 1, 64); xm.val = __shfl_up(im.val, 1, 64);
+            if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
+            if (t < a.ntiles) {
+                a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
+                a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) { s_runc = totc; s_runm = totm; }
+            __syncthreads();
+        }
+    }
+}
+
+// one wave per sub-index with a split decision
+__global__ __launch_bounds__(64) void k_seg_offsets(const uint8_t *__restrict__ D, int64_t m, RvSplitArgs a, const int *__restrict__ split_subs, int nsplit) {
+    const int k = blockIdx.x;
+    if (k >= nsplit) return;
+    const int s = split_subs[k];
+    const int lane = threadIdx.x;
+    u32 g[2][3];
+    for (int side = 0; side < 2; side++) {
+        const int64_t pos = a.sub_start[s + side];       // first rank of the sub / one past its last
+        const int64_t tile = pos / SP_TILE;
+        u32 c0 = 0, c1 = 0, c2 = 0;
+        for (int64_t j = tile * SP_TILE + lane; j < pos; j += 64) {
+            const uint8_t d = D[j];
+            c0 += d == 1; c1 += d == 2; c2 += d == 4;
+        }
+        for (int dd = 32; dd >= 1; dd >>= 1) { c0 += __shfl_down(c0, dd, 64); c1 += __shfl_down(c1, dd, 64); c2 += __shfl_down(c2, dd, 64); }
+        c0 = __shfl(c0, 0, 64); c1 = __shfl(c1, 0, 64); c2 = __shfl(c2, 0, 64);
+        const bool past = tile >= a.ntiles;              // pos == m on a tile boundary
+        g[side][0] = (past ? a.total[0] : a.tile_G[0 * (size_t)a.ntiles + tile]) + c0;
+        g[side][1] = (past ? a.total[1] : a.tile_G[1 * (size_t)a.ntiles + tile]) + c1;
+        g[side][2] = (past ? a.total[2] : a.tile_G[2 * (size_t)a.ntiles + tile]) + c2;
+    }
+    if (lane < 3) {
+        const int c = lane;
+        a.sub_off[(size_t)s * 3 + c] = a.child_base[(size_t)s * 3 + c] - g[0][c];
+        if (g[1][c] - g[0][c] != a.child_n[(size_t)s * 3 + c]) atomicOr(a.err, 1u);   // intervals do not cover what they claim
+    }
+}
+
+// totals per class (needed when a sub ends exactly at m on a tile boundary)
+__global__ void k_totals(RvSplitArgs a) {
+    const int c = threadIdx.x;
+    if (c < 3) {
+        const size_t last = (size_t)c * a.ntiles + (a.ntiles - 1);
+        a.total[c] = a.tile_G[last] + a.tile_cnt[last];
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend,
+                                              const int64_t *__restrict__ mpre, int nmatch, int64_t total) {
+    const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (id >= total) return;
+    const int e = upper_idx<int64_t>(mpre, nmatch, id);
+    const int64_t pos = (int64_t)mbegin[e] + (id - mpre[e]);
+    if (pos < (int64_t)mend[e]) {
+        const uint8_t c = T[pos];
+        if (c >= 'A' && c <= 'Z') T[pos] = c + 32;
+    }
+}
+
+// ---- bubble_sort ---------------------------------------------------------------
+// Round r handles the r-th matched interval of every split sub-index.
+// Window pass: for every text position p in [wlo, B) of a descriptor, look at
+// its rank e = SAi[p] in the leading child and keep it if it could act in this
+// round (superset of the two `if`s at reveal.c:686 / :714 on the values at the
+// start of the round; values of not-yet-visited ranks only decrease during the
+// round, so nothing is missed).
+__global__ __launch_bounds__(TB) void k_bubble_window(RvBubbleArgs b, int first, int count, int64_t total) {
+    const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (id >= total) return;
+    const int dd = first + upper_idx<int64_t>(b.woff + first, count, id + b.woff[first]);
+    const RvBubbleDesc ds = b.desc[dd];
+    const int64_t p = ds.wlo + (id + b.woff[first] - b.woff[dd]);
+    const int64_t e = (int64_t)b.SAi[p];
+    if (e < 0 || e >= ds.n) return;
+    const int64_t i = ds.off + e;
+    const int64_t sa = (int64_t)b.SA[i];
+    if (sa != p) return;
+    const int64_t lc = (int64_t)(u32)b.LCP[i];
+    const int64_t ln = (e + 1 < ds.n) ? (int64_t)(u32)b.LCP[i + 1] : 0;
+    if (sa < ds.B && (sa + lc > ds.B || sa + ln > ds.B)) {
+        const u32 slot = atomicAdd(&b.cnt[dd], 1u);
+        b.list[b.woff[dd] + slot] = (u32)e;
+    }
+}
+
+constexpr int BB_CAP = 4096;
+
+__global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) {
+    __shared__ u32 lst[BB_CAP];
+    __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL, x
+    __shared__ int s_min[TB / 64];
+    const int dd = first + blockIdx.x;
+    const u32 cnt = b.cnt[dd];
+    if (cnt == 0) return;
+    if (cnt > BB_CAP) { if (threadIdx.x == 0) atomicOr(b.err, 2u); return; }
+    const RvBubbleDesc ds = b.desc[dd];
+    sa_t  *SA = b.SA + ds.off;
+    lcp_t *LCP = b.LCP + ds.off;
+    const int64_t n = ds.n, B = ds.B;
+    // sort the active ranks ascending (bitonic in LDS)
+    u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
+    for (u32 k = threadIdx.x; k < np2; k += TB) lst[k] = k < cnt ? b.list[b.woff[dd] + k] : 0xFFFFFFFFu;
+    __syncthreads();
+    for (u32 size = 2; size <= np2; size <<= 1)
+        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+            for (u32 k = threadIdx.x; k < np2 / 2; k += TB) {
+                const u32 lo = (k / stride) * stride * 2 + (k % stride), hi = lo + stride;
+                const bool up = ((lo & size) == 0);
+                const u32 x = lst[lo], y = lst[hi];
+                if ((x > y) == up) { lst[lo] = y; lst[hi] = x; }
+            }
+            __syncthreads();
+        }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (u32 ai = 0; ai < cnt; ai++) {
+        const int64_t e = lst[ai];
+        if (threadIdx.x == 0) {
+            const int64_t sa = (int64_t)SA[e], lc = (int64_t)(u32)LCP[e];
+            int64_t kind = 0;
+            if (sa < B && sa + lc > B) {
+                kind = 1;
+            } else if (e < n - 1) {
+                const int64_t ln = (int64_t)(u32)LCP[e + 1];
+                if (sa < B && sa + ln > B && ln > lc) LCP[e + 1] = (lcp_t)(B - sa);      // reveal.c:714-718
+            }
+            s_v[0] = kind; s_v[1] = sa; s_v[2] = lc;
+        }
+        __syncthreads();
+        if (s_v[0] == 1) {                                                               // reveal.c:686-709
+            const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
+            // x = largest r <= e with r == 0 or LCP[r] < t
+            int64_t cur = e, x = 0;
+            for (;;) {
+                const int64_t r = cur - threadIdx.x;
+                const bool f = (r >= 0) && (r == 0 || (int64_t)(u32)LCP[r] < t);
+                const u64 bal = __ballot(f);
+                if (lane == 0) s_min[w] = bal ? (w * 64 + (int)__builtin_ctzll(bal)) : 0x7fffffff;
+                __syncthreads();
+                int mn = 0x7fffffff;
+                for (int k = 0; k < TB / 64; k++) mn = s_min[k] < mn ? s_min[k] : mn;
+                __syncthreads();
+                if (mn != 0x7fffffff) { x = cur - mn; break; }
+                cur -= TB;
+            }
+            // shift [x, e-1] -> [x+1, e], top chunk first
+            for (int64_t hi = e; hi > x;) {
+                const int64_t lo = (hi - 4 * TB + 1 > x + 1) ? hi - 4 * TB + 1 : x + 1;
+                sa_t vs[4]; lcp_t vl[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
+                    if (idx >= lo) { vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
+                    if (idx >= lo) {
+                        SA[idx] = vs[k]; LCP[idx] = vl[k];
+                        for (int q = ds.cut0; q < ds.cut1; q++)
+                            if (vs[k] >= b.cut_lo[q] && vs[k] < b.cut_hi[q]) { b.SAi[vs[k]] = (sa_t)idx; break; }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();
+                hi = lo - 1;
+            }
+            if (threadIdx.x == 0) {
+                SA[x] = (sa_t)tS;
+                b.SAi[tS] = (sa_t)x;
+                if (x + 1 < n) LCP[x + 1] = (lcp_t)t;
+                if (e < n - 1 && tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = (lcp_t)tL;
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+// SAi[SA[i]] = rank inside the owning sub-index (materialised on demand for the getter)
+__global__ __launch_bounds__(TB) void k_sai_level(const sa_t *__restrict__ SA, int64_t m, const int64_t *__restrict__ sub_start, int nsubs, sa_t *__restrict__ SAi) {
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= m) return;
+    const int s = upper_idx<int64_t>(sub_start, nsubs, i);
+    SAi[SA[i]] = (sa_t)(i - sub_start[s]);
+}
+
+}  // namespace
+
+int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs &t, uint8_t *D) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(k_label, dim3((unsigned)ceil_div(m, TB * 4)), dim3(TB), 0, ws.stream, SA, m, t, D);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, int64_t m, const RvSplitArgs &a,
+                    const int *d_split_subs, int nsplit) {
+    if (m <= 0 || nsplit <= 0) return 0;
+    const unsigned nt = (unsigned)a.ntiles;
+    hipLaunchKernelGGL(k_split<false>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, m, a);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(TB), 0, ws.stream, a);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, ws.stream, a);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_seg_offsets, dim3((unsigned)nsplit), dim3(64), 0, ws.stream, D, m, a, d_split_subs, nsplit);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_split<true>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, m, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total) {
+    if (total <= 0) return 0;
+    hipLaunchKernelGGL(k_lower, dim3((unsigned)ceil_div(total, TB)), dim3(TB), 0, ws.stream, T, mbegin, mend, mpre, nmatch, total);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window) {
+    if (count <= 0 || total_window <= 0) return 0;
+    hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_bubble_apply, dim3((unsigned)count), dim3(TB), 0, ws.stream, b, first);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi) {
+    if (m <= 0) return 0;
+    hipLaunchKernelGGL(k_sai_level, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, m, sub_start, nsubs, SAi);
+    RV_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,115 @@
+"""The recursion (scan -> pick -> label -> split -> bubble_sort) on the GPU against the
+CPU oracle: every sub-index visited must have the same intervals, size, scan result,
+chosen match and child SA/LCP arrays (reveallib/reveal.c:731-1338).  The GPU visits
+level by level, the oracle LIFO; records are matched by (depth, smallest interval begin)."""
+import numpy as np
+import pytest
+
+from helpers import assemble, csr_tuples, fa, feed, oracle, synth
+from reveal_amd import rem
+
+pytestmark = pytest.mark.gpu
+
+FIELDS = ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums")
+
+
+def mod(sa64):
+    from reveal_amd import reveallib, reveallib64
+    return reveallib64 if sa64 else reveallib
+
+
+def oracle_run(inputs, minl, minn, sa64=False):
+    T, nsep, nodes = assemble(inputs)
+    O = oracle(sa64)
+    c = O.construct(T, nsep, len(inputs))
+    return O.align_bench(c, nodes, minl, minn, trace_cap=4 * len(T) // max(minl, 1) + 1000), T
+
+
+def compare(inputs, minl=20, minn=2, sa64=False):
+    ref, T = oracle_run(inputs, minl, minn, sa64)
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(minl, minn, trace=True)
+    rt, gt = ref["trace"], got["trace"]
+    assert len(rt) == len(gt), (len(rt), len(gt))
+    ro = np.lexsort((rt["key"], rt["depth"])); go = np.lexsort((gt["key"], gt["depth"]))
+    for f in FIELDS:
+        a, b = rt[f][ro].astype(np.uint64), gt[f][go].astype(np.uint64)
+        bad = np.nonzero(a != b)[0]
+        assert len(bad) == 0, "field %s differs at %d of %d sub-indices; first: depth=%d key=%d ref=%d got=%d" % (
+            f, len(bad), len(a), rt["depth"][ro][bad[0]], rt["key"][ro][bad[0]], a[bad[0]], b[bad[0]])
+    # anchors as a set
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    gl, goff, gpos = got["anchors"]
+    ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
+    assert ra == ga
+    assert idx.T.encode("latin-1") == ref["T"]            # lower-case mask
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"]
+    assert got["stats"]["steps"] == ref["stats"]["nsteps"]
+    return idx, got, ref
+
+
+@pytest.mark.parametrize("name,inputs,minl", [
+    ("known", ["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"], 2),
+    ("t1t2", fa("t1", "t2"), 1),
+    ("d1d2", fa("d1", "d2"), 20),
+    ("1e1b", fa("1e", "1b"), 20),
+    ("1a1a", fa("1a", "1a"), 20),
+    ("1a1b", fa("1a", "1b"), 20),
+    ("1a1b_m10", fa("1a", "1b"), 10),
+])
+def test_pairwise_recursion(name, inputs, minl):
+    compare(inputs, minl)
+
+
+def test_pairwise_recursion_64bit():
+    compare(fa("1a", "1b"), 20, sa64=True)
+
+
+@pytest.mark.parametrize("L", [2000, 200000, 1000000])
+def test_synthetic_pair(L):
+    seqs = [g.decode() for g in synth.genomes(L, 2)]
+    idx, got, ref = compare(seqs, 20)
+    # test15's invariant (reveal/tests/test_reveal.py:150-159) in array form: every anchored
+    # range is lower case, everything else still upper case, and the text spells the input
+    assert idx.T.upper().encode("latin-1") == assemble(seqs)[0]
+
+
+@pytest.mark.parametrize("name,inputs", [
+    ("known3", ["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"]),
+    ("1a1b1c", fa("1a", "1b", "1c")),
+    ("5way", fa("1a", "1b", "1c", "1d", "1e")),
+])
+def test_multi_recursion(name, inputs):
+    compare(inputs, 20 if name != "known3" else 2, 2)
+
+
+@pytest.mark.parametrize("inputs,minl,minn", [
+    (fa("1a", "1b", "1c"), 20, 2), (fa("1a", "1b", "1c"), 2, 2), (fa("1a", "1b", "1c"), 0, 2), (fa("1a", "1b", "1c"), 20, 3),
+    (fa("1a", "1b", "1c", "1d", "1e"), 20, 2), (fa("1a", "1b", "1c", "1d", "1e"), 2, 2), (fa("1a", "1b", "1c", "1d", "1e"), 20, 5),
+    (["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"], 2, 2),
+])
+def test_getmultimums(inputs, minl, minn):
+    T, nsep, nodes = assemble(inputs)
+    O = oracle(False)
+    c = O.construct(T, nsep, len(inputs))
+    ref = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, len(inputs), minl, minn))
+    idx = feed(mod(False).index(), inputs)
+    idx.construct()
+    assert idx.getmultimums(minlength=minl, minn=minn) == ref
+
+
+def test_python_callbacks_same_anchors():
+    """index.align() with Python callbacks of the reference's signatures (reveal.c:839-999)
+    gives the same anchors and final text as the native driver"""
+    inputs = fa("1a", "1b")
+    ref, T = oracle_run(inputs, 20, 2)
+    idx, anchors = rem.align_genomes(inputs, minlength=20, minn=2)
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    ga = sorted((int(m[0]), tuple(sorted(int(p) for _, p in m[2]))) for m in anchors)
+    assert ra == ga
+    assert idx.T.encode("latin-1") == ref["T"]
+    with pytest.raises(TypeError):
+        idx.SA            # main SA/LCP are gone after align (reveal.c:1279-1284)

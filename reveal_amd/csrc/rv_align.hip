@@ -56,7 +56,7 @@ struct Align {
     // level-wide scan result, CSR
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     // device scratch
-    DBuf dD, dTab, dTile, dList;
+    DBuf dD, dTab, dTile, dList, dFlag;
     // results of rv_align_builtin
     std::vector<u32> an_l; std::vector<int64_t> an_off, an_pos;
     bool trace_on = false;
@@ -64,7 +64,7 @@ struct Align {
     rv_align_stats st{};
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release();
     }
 };
 
@@ -422,6 +422,9 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RvBubbleArgs ba;
     ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
     ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
+    RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
+    RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
+    ba.flag = a->dFlag.as<uint8_t>();
     ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
     id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
     for (size_t r = 0; r + 1 < round_first.size(); r++) {
@@ -433,7 +436,6 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_HIP(hipMemcpyAsync(&err, tb + o_err, 4, hipMemcpyDeviceToHost, q));
     RV_HIP(hipStreamSynchronize(q));
     if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
-    if (err & 2u) { rv_set_error("bubble_sort: more than 4096 active suffixes at one cut (not supported yet)"); return -1; }
 
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
     a->level++;

@@ -47,6 +47,7 @@ struct RvBubbleArgs {
     const int64_t      *woff;     // prefix sums of window widths over all descriptors (+1)
     u32                *cnt;      // per descriptor: number of active ranks found
     u32                *list;     // active ranks, descriptor d at [woff[d], ...)
+    uint8_t            *flag;     // one byte per rank of the next level, zero between rounds
     sa_t  *SA;
     lcp_t *LCP;
     sa_t  *SAi;

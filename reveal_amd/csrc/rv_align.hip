@@ -48,7 +48,7 @@ struct Align {
     int minl = 0, minn = 0;
     bool multi = false;
     int level = 0;
-    DBuf lvSA[2], lvLCP[2];
+    DBuf lvSA[2], lvLCP[2], lvBWT[2];
     int cur = 0;                 // which level buffer holds the frontier (level > 0)
     int64_t m = 0;               // ranks in the frontier
     std::vector<RvSub> subs;
@@ -63,7 +63,7 @@ struct Align {
     std::vector<rv_trace> trace;
     rv_align_stats st{};
     void release() {
-        for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); }
+        for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release();
     }
 };
@@ -73,6 +73,7 @@ void rv_align_free(rv_index *h) {
 }
 
 static const sa_t *cur_sa(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dSA.as<sa_t>() : a->lvSA[a->cur].as<sa_t>(); }
+static const uint8_t *cur_bwt(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dBWT.as<uint8_t>() : a->lvBWT[a->cur].as<uint8_t>(); }
 static const lcp_t *cur_lcp(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dLCP.as<lcp_t>() : a->lvLCP[a->cur].as<lcp_t>(); }
 
 static int sample_of(const rv_index *h, int64_t pos) {       /* SO[pos], interface.c:116-134 */
@@ -130,7 +131,7 @@ int rv_set_trace(rv_index *h, int on) {
 
 }  // extern "C"
 
-int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, int minn, int mems,
+int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn, int mems,
                       std::vector<u32> &l, std::vector<int32_t> &n, std::vector<int64_t> &off, std::vector<uint16_t> &so,
                       std::vector<int64_t> &pos, std::vector<int64_t> *ub_out);
 
@@ -146,7 +147,7 @@ int rv_frontier_scan(rv_index *h) {
     for (auto &s : a->subs) { s.mum_first = 0; s.nmums = 0; }
     if (!a->multi) {
         std::vector<RvPairRec> recs;
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), a->m, a->minl, recs));
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->m, a->minl, recs));
         const size_t nr = recs.size();
         a->ml.resize(nr); a->mn.assign(nr, 2); a->moff.resize(nr + 1); a->mso.resize(2 * nr); a->mpos.resize(2 * nr);
         size_t si = 0;
@@ -163,7 +164,7 @@ int rv_frontier_scan(rv_index *h) {
         a->moff[nr] = (int64_t)(2 * nr);
     } else {
         std::vector<int64_t> ub;
-        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), a->m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub));
+        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub));
         size_t si = 0;
         for (size_t k = 0; k < a->ml.size(); k++) {
             while (si < a->subs.size() && ub[k] >= a->subs[si].off + a->subs[si].n) si++;
@@ -315,8 +316,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     std::vector<int64_t> sub_start((size_t)ns + 1);
     for (int s = 0; s < ns; s++) sub_start[(size_t)s] = a->subs[s].off;
     sub_start[(size_t)ns] = a->m;
-    std::vector<int> cut_first((size_t)ns + 1, 0);
-    std::vector<sa_t> cut_lo, cut_hi;
+    std::vector<int> cut_first((size_t)ns + 1, 0), mend_first((size_t)ns + 1, 0);
+    std::vector<sa_t> cut_lo, cut_hi, mend_pos;
     std::vector<std::vector<RvBubbleDesc>> rounds;
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
@@ -324,9 +325,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         size_t si = 0;
         for (int s = 0; s < ns; s++) {
             cut_first[(size_t)s] = (int)cut_lo.size();
+            mend_first[(size_t)s] = (int)mend_pos.size();
             if (si >= split_subs.size() || split_subs[si] != s) continue;
             si++;
             RvSub &x = a->subs[s];
+            for (int64_t p : x.sp) mend_pos.push_back((sa_t)(p + (int64_t)x.l));
             auto isort = [](std::vector<RvIntv> &v) { std::sort(v.begin(), v.end(), [](const RvIntv &p, const RvIntv &r) { return p.begin < r.begin; }); };
             std::vector<RvIntv> *lists[3] = {&x.lead, &x.trail, &x.rest};
             int64_t lead_off = 0, lead_n = 0;
@@ -366,12 +369,19 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             }
         }
         cut_first[(size_t)ns] = (int)cut_lo.size();
+        mend_first[(size_t)ns] = (int)mend_pos.size();
     }
     const int64_t m_next = running;
     if (m_next >= ((int64_t)1 << 32)) { rv_set_error("level larger than 2^32 ranks not supported yet"); return -1; }
     std::vector<RvBubbleDesc> descs;
-    std::vector<int> round_first;
-    for (auto &r : rounds) { round_first.push_back((int)descs.size()); descs.insert(descs.end(), r.begin(), r.end()); }
+    std::vector<int> round_first, round_small;
+    for (auto &r : rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups)
+        std::stable_partition(r.begin(), r.end(), [](const RvBubbleDesc &d) { return d.n <= RV_BUBBLE_BIG_N; });
+        int nsmall = 0;
+        for (auto &d : r) nsmall += d.n <= RV_BUBBLE_BIG_N;
+        round_first.push_back((int)descs.size()); round_small.push_back(nsmall);
+        descs.insert(descs.end(), r.begin(), r.end());
+    }
     round_first.push_back((int)descs.size());
     std::vector<int64_t> woff(descs.size() + 1, 0);
     for (size_t k = 0; k < descs.size(); k++) woff[k + 1] = woff[k] + (descs[k].B - descs[k].wlo);
@@ -382,7 +392,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_cb = pk.addv(cb), o_ce = pk.addv(ce), o_cc = pk.addv(cc), o_mb = pk.addv(mb), o_me = pk.addv(me), o_mpre = pk.addv(mpre);
     const size_t o_ss = pk.addv(sub_start), o_cbase = pk.addv(child_base), o_cn = pk.addv(child_n), o_cf = pk.addv(cut_first);
     const size_t o_clo = pk.addv(cut_lo), o_chi = pk.addv(cut_hi), o_split = pk.addv(split_subs);
-    const size_t o_desc = pk.addv(descs), o_woff = pk.addv(woff);
+    const size_t o_desc = pk.addv(descs), o_woff = pk.addv(woff), o_mf = pk.addv(mend_first), o_mp = pk.addv(mend_pos);
     const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(descs.size() * 4 + 4);
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
@@ -393,6 +403,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const int nxt = (a->level == 0) ? 0 : (a->cur ^ 1);
     RV_TRY(a->lvSA[nxt].reserve((size_t)(m_next + 64) * sizeof(sa_t)));
     RV_TRY(a->lvLCP[nxt].reserve((size_t)(m_next + 64) * sizeof(lcp_t)));
+    RV_TRY(a->lvBWT[nxt].reserve((size_t)m_next + 64));
 
     RvLabelTabs lt;
     lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc; lt.ncls = (int)cls.size();
@@ -410,10 +421,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.sub_start = (const int64_t *)(tb + o_ss); sa.nsubs = ns;
     sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (u32 *)(tb + o_suboff);
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
-    sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.SAi = h->dSAi.as<sa_t>();
+    sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);
+    sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = (u32 *)(tb + o_err);
     id = h->prof.begin(q, RV_K_SPLIT, (double)a->m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 1)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t)));
-    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), a->m, sa, (const int *)(tb + o_split), (int)split_subs.size()));
+    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), a->m, sa, (const int *)(tb + o_split), (int)split_subs.size()));
     h->prof.end(q, id);
     RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, mpre.back()));
     const double t1 = now_s();
@@ -425,11 +437,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
     RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
     ba.flag = a->dFlag.as<uint8_t>();
-    ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
+    ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
     id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
     for (size_t r = 0; r + 1 < round_first.size(); r++) {
         const int first = round_first[r], count = round_first[r + 1] - first;
-        RV_TRY(rv_bubble_round_launch(h->ws, ba, first, count, woff[(size_t)(first + count)] - woff[(size_t)first]));
+        RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], count - round_small[r], woff[(size_t)(first + count)] - woff[(size_t)first]));
     }
     h->prof.end(q, id);
     u32 err = 0;

@@ -56,7 +56,7 @@ void rv_free(rv_index *h) {
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
     rv_align_free(h);
     h->prof.release();
-    h->dT.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dNsep.release();
+    h->dT.release(); h->dT0.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dBWT.release(); h->dNsep.release();
     h->ws.release();
     if (h->ws.stream) (void)hipStreamDestroy(h->ws.stream);
     delete h;
@@ -84,6 +84,7 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     h->T[(size_t)(h->n + len)] = '$';
     h->T[(size_t)(h->n + len + 1)] = '\0';
     h->n += len + 1;
+    h->text_dirty = true;
     if (begin) *begin = s;
     if (end) *end = h->n - 1;
     h->nodes.push_back(RvIntv{s, h->n - 1});
@@ -127,6 +128,21 @@ static int write_raw(const char *path, const void *src, size_t bytes) {
     return 0;
 }
 
+/* Text -> HBM (pristine copy, zero padded so word-wise readers may run past the
+ * end).  construct() calls it when the host text changed; calling it up front
+ * keeps the PCIe copy out of a timed construct(). */
+int rv_upload(rv_index *h) {
+    RV_HIP(hipSetDevice(h->device));
+    if (!h->text_dirty) return 0;
+    const int64_t n = h->n;
+    RV_TRY(h->dT0.reserve((size_t)n + 64));
+    RV_HIP(hipMemsetAsync(h->dT0.p, 0, (size_t)n + 64, h->ws.stream));
+    RV_HIP(hipMemcpyAsync(h->dT0.p, h->T.data(), (size_t)n, hipMemcpyHostToDevice, h->ws.stream));
+    RV_HIP(hipStreamSynchronize(h->ws.stream));
+    h->text_dirty = false;
+    return 0;
+}
+
 /* interface.c:160-291 */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache) {
     RV_HIP(hipSetDevice(h->device));
@@ -134,6 +150,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         if (h->nsep.empty()) { rv_set_error("construct(rc=1) needs at least two samples"); return -1; }
         h->rc = 1;
         revcomp(h->T.data() + h->nsep[0], h->n - h->nsep[0]);
+        h->text_dirty = true;
     } else {
         h->rc = 0;
     }
@@ -143,13 +160,14 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     rv_align_free(h);
     h->nT = n;
     hipStream_t q = h->ws.stream;
-    // text -> HBM, zero padded so word-wise readers may run past the end
+    // working copy of the (HBM-resident) text: align() lower-cases it in place
+    RV_TRY(rv_upload(h));
     RV_TRY(h->dT.reserve((size_t)n + 64));
-    RV_HIP(hipMemsetAsync(h->dT.p, 0, (size_t)n + 64, q));
-    RV_HIP(hipMemcpyAsync(h->dT.p, h->T.data(), (size_t)n, hipMemcpyHostToDevice, q));
+    RV_HIP(hipMemcpyAsync(h->dT.p, h->dT0.p, (size_t)n + 64, hipMemcpyDeviceToDevice, q));
     RV_TRY(h->dSA.reserve((size_t)(n + 64) * sizeof(sa_t)));
     RV_TRY(h->dSAi.reserve((size_t)(n + 64) * sizeof(sa_t)));
     RV_TRY(h->dLCP.reserve((size_t)(n + 64) * sizeof(lcp_t)));
+    RV_TRY(h->dBWT.reserve((size_t)n + 64));
     memset(&h->sa_stats, 0, sizeof h->sa_stats);
     if (!safile || !safile[0]) {
         int id = h->prof.begin(q, RV_K_SA_SORT, 5.0 * (double)n);
@@ -166,7 +184,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     u32 *d_max = h->ws.misc[0].as<u32>();
     if (!lcpfile || !lcpfile[0]) {
         int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
-        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max));
+        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>()));
         h->prof.end(q, id);
         RV_HIP(hipMemcpyAsync(&h->maxlcp, d_max, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
@@ -177,6 +195,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         for (int64_t i = 0; i < n; i++) if ((u32)tmp[(size_t)i] > mx) mx = (u32)tmp[(size_t)i];
         h->maxlcp = mx;
         RV_HIP(hipMemcpyAsync(h->dLCP.p, tmp.data(), (size_t)n * sizeof(lcp_t), hipMemcpyHostToDevice, q));
+        RV_TRY(rv_build_bwt(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), n, h->dBWT.as<uint8_t>()));
         RV_HIP(hipStreamSynchronize(q));
     }
     if (cache == 1) {
@@ -250,7 +269,7 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 // ---------------------------------------------------------------------------
 // pair scan driver: launch, copy the tile table + records, merge in tile order
 // ---------------------------------------------------------------------------
-int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, std::vector<RvPairRec> &out) {
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out) {
     out.clear();
     if (m <= 1) return 0;
     if (h->nsep.empty()) { rv_set_error("pairwise scan needs at least two samples"); return -1; }
@@ -264,8 +283,8 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, i
     std::vector<uint2> tab((size_t)ntile);
     for (int attempt = 0; attempt < 2; attempt++) {
         RV_HIP(hipMemsetAsync(bcnt.p, 0, 4, q));
-        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
-        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, h->dT.as<uint8_t>(), (sa_t)h->nsep[0], minl, brec.as<RvPairRec>(), (u32)std::min<size_t>(cap, 0xffffffffu),
+        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
+        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, brec.as<RvPairRec>(), (u32)std::min<size_t>(cap, 0xffffffffu),
                                    bcnt.as<u32>(), btab.as<uint2>()));
         h->prof.end(q, id);
         u32 total = 0;
@@ -291,7 +310,7 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, i
 }
 
 // multi-MUM scan driver (same tile-ordered merge as the pair scan)
-int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, int minn, int mems,
+int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn, int mems,
                       std::vector<u32> &l, std::vector<int32_t> &n, std::vector<int64_t> &off, std::vector<uint16_t> &so,
                       std::vector<int64_t> &pos, std::vector<int64_t> *ub_out) {
     l.clear(); n.clear(); off.assign(1, 0); so.clear(); pos.clear();
@@ -312,7 +331,7 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, 
         const size_t rcap = brec.cap / sizeof(RvMultiRec), mcap = std::min(bso.cap / 2, bpos.cap / sizeof(sa_t));
         RV_HIP(hipMemsetAsync(bcnt.p, 0, 8, q));
         int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
-        RV_TRY(rv_scan_multi_launch(h->ws, SA, LCP, m, h->dT.as<uint8_t>(), h->dNsep.as<sa_t>(), h->nsamples, minl, minn,
+        RV_TRY(rv_scan_multi_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), h->nsamples, minl, minn,
                                     brec.as<RvMultiRec>(), bso.as<uint16_t>(), bpos.as<sa_t>(), (u32)std::min<size_t>(rcap, 0xffffffffu),
                                     (u32)std::min<size_t>(mcap, 0xffffffffu), bcnt.as<u32>(), btab.as<uint4>()));
         h->prof.end(q, id);
@@ -357,7 +376,7 @@ int64_t rv_getmultimums(rv_index *h, int minlength, int minn, int mems, int64_t 
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     if (h->nsamples <= 2) { rv_set_error("getmultimums needs more than two samples (SO not available)"); return -1; }
     (void)hipSetDevice(h->device);
-    if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr)) return -1;
+    if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr)) return -1;
     if (members) *members = (int64_t)h->mm_pos.size();
     return (int64_t)h->mm_l.size();
 }
@@ -376,7 +395,7 @@ int64_t rv_getmums(rv_index *h, int minl) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     (void)hipSetDevice(h->device);
     std::vector<RvPairRec> recs;
-    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->n, minl, recs) != 0) return -1;
+    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs) != 0) return -1;
     h->m_l.resize(recs.size()); h->m_a.resize(recs.size()); h->m_b.resize(recs.size());
     for (size_t k = 0; k < recs.size(); k++) {
         int64_t b = recs[k].b;

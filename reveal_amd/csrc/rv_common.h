@@ -111,4 +111,6 @@ struct RvSaStats {
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st);
 int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp);
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT);
+// BWT only (when LCP came from a file)
+int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT);

@@ -196,10 +196,14 @@ __device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exa
 
 // LCP[k] = min( lcp(T[SA[k-1]..], T[SA[k]..]), distance from SA[k] to the first
 // '$' or 'N' )  -- the closed form of compute_lcp (interface.c:97-114).
+// Also emits BWT[k] = T[SA[k]-1] ('$' for SA[k]==0: "nothing to the left" counts
+// as left-maximal exactly like a '$', reveal.c:81-85), the byte the scans use
+// for the left-maximality test.
 __global__ __launch_bounds__(TB) void k_lcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, int64_t n,
-                                            u32 *__restrict__ maxlcp) {
+                                            u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT) {
     const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 h = 0;
+    if (k < n && BWT) { const sa_t p = SA[k]; BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$'; }
     if (k < n && k > 0) {
         const uint8_t *pa = T + SA[k - 1], *pb = T + SA[k];
         for (;;) {
@@ -218,6 +222,11 @@ __global__ __launch_bounds__(TB) void k_lcp(const uint8_t *__restrict__ T, const
     if ((threadIdx.x & 63) == 0 && m) atomicMax(maxlcp, m);
 }
 
+__global__ __launch_bounds__(TB) void k_bwt(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, int64_t n, uint8_t *__restrict__ BWT) {
+    const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (k < n) { const sa_t p = SA[k]; BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$'; }
+}
+
 inline int bitlen(u64 v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
 }  // namespace
@@ -229,10 +238,17 @@ int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n) {
     return 0;
 }
 
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp) {
+int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL(k_bwt, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, n, BWT);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT) {
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
-    hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp);
+    hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -70,7 +70,8 @@ struct rv_index {
     int rc = 0;
     bool constructed = false, main_arrays_freed = false;
     // ---- device state
-    DBuf dT, dSA, dSAi, dLCP, dNsep;
+    DBuf dT, dT0, dSA, dSAi, dLCP, dBWT, dNsep;   // dT0 = pristine text, dT = working copy (lower-cased by align)
+    bool text_dirty = true;
     u32 maxlcp = 0;
     RvSaStats sa_stats{};
     // ---- scan results of the main index (getmums / getmultimums)
@@ -81,7 +82,7 @@ struct rv_index {
 };
 
 // scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)
-int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, int64_t m, int minl, std::vector<RvPairRec> &out);
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out);
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

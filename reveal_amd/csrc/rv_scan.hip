@@ -10,8 +10,8 @@
 // exactly like the array ends of the reference's per-index loops.
 //
 // The pair scan is the roofline-judged kernel: a pure stream of 8 B per rank
-// (4 B SA + 4 B LCP, 16-byte loads per lane), two byte gathers from T only for
-// the ~0.4 % of ranks that survive the LCP tests, and an order-preserving
+// (4 B SA + 4 B LCP, 16-byte loads per lane) plus 1 B of BWT for the
+// left-maximality test (no gathers from T), and an order-preserving
 // append (one atomic per 1024-rank tile, tile table merged on the host).
 #include "rv_common.h"
 #include "rv_scan.h"
@@ -24,13 +24,12 @@ constexpr int PAIR_TILE = TB * PAIR_ITEMS;   // == RV_PAIR_TILE
 
 __device__ inline bool is_lower_c(uint8_t c) { return c >= 'a' && c <= 'z'; }
 
-// left-maximality test of reveal.c:81-85 (only T[a-1] is inspected for N/$/lower)
-__device__ inline bool left_maximal(const uint8_t *__restrict__ T, int64_t a, int64_t b) {
-    if (a > 0 && b > 0) {
-        const uint8_t ca = T[a - 1], cb = T[b - 1];
-        return (ca != cb) || ca == 'N' || ca == '$' || is_lower_c(ca);
-    }
-    return true;
+// left-maximality test of reveal.c:81-85 on the characters in front of the two
+// suffixes (ca belongs to the smaller text position; only it is inspected for
+// N/$/lower).  The characters come from the BWT level array, '$' standing in
+// for "position 0".
+__device__ inline bool left_maximal(uint8_t ca, uint8_t cb) {
+    return (ca != cb) || ca == 'N' || ca == '$' || is_lower_c(ca);
 }
 
 __device__ inline bool lcp_lt(lcp_t v, int minl) {
@@ -42,7 +41,7 @@ __device__ inline bool lcp_lt(lcp_t v, int minl) {
 }
 
 __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
-                                                  const uint8_t *__restrict__ T, sa_t nsep0, int minl,
+                                                  const uint8_t *__restrict__ BWT, sa_t nsep0, int minl,
                                                   RvPairRec *__restrict__ out, u32 out_cap, u32 *__restrict__ counter,
                                                   uint2 *__restrict__ tiletab) {
     __shared__ u32 wsum[TB / 64];
@@ -52,7 +51,10 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 
     sa_t sa[PAIR_ITEMS];
     lcp_t lc[PAIR_ITEMS];
+    uint8_t bw[PAIR_ITEMS];
     if (i0 + PAIR_ITEMS <= m) {
+        const uchar4 bb = *reinterpret_cast<const uchar4 *>(BWT + i0);
+        bw[0] = bb.x; bw[1] = bb.y; bw[2] = bb.z; bw[3] = bb.w;
 #ifndef RV_SA64
         const int4 v = *reinterpret_cast<const int4 *>(SA + i0);
         sa[0] = v.x; sa[1] = v.y; sa[2] = v.z; sa[3] = v.w;
@@ -67,6 +69,7 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         for (int k = 0; k < PAIR_ITEMS; k++) {
             sa[k] = (i0 + k < m) ? SA[i0 + k] : (sa_t)0;
             lc[k] = (i0 + k < m) ? LCP[i0 + k] : (lcp_t)0;
+            bw[k] = (i0 + k < m) ? BWT[i0 + k] : (uint8_t)0;
         }
     }
     // neighbours: previous rank's SA/LCP, next rank's LCP (0 past the end)
@@ -77,8 +80,9 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 #endif
     lcp_t plc = (lcp_t)__shfl_up((int)lc[PAIR_ITEMS - 1], 1, 64);
     lcp_t nlc = (lcp_t)__shfl_down((int)lc[0], 1, 64);
+    uint8_t pbw = (uint8_t)__shfl_up((int)bw[PAIR_ITEMS - 1], 1, 64);
     if (lane == 0) {
-        if (i0 > 0 && i0 - 1 < m) { psa = SA[i0 - 1]; plc = LCP[i0 - 1]; } else { psa = 0; plc = 0; }
+        if (i0 > 0 && i0 - 1 < m) { psa = SA[i0 - 1]; plc = LCP[i0 - 1]; pbw = BWT[i0 - 1]; } else { psa = 0; plc = 0; pbw = 0; }
     }
     if (lane == 63) nlc = (i0 + PAIR_ITEMS < m) ? LCP[i0 + PAIR_ITEMS] : (lcp_t)0;
 
@@ -93,10 +97,8 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         bool ok = (i >= 1) && (i < m) && !lcp_lt(l, minl);
         ok = ok && ((s1 > nsep0) != (s0 > nsep0));          // not a repeat inside one sample
         ok = ok && (lb < l) && (la < l);                    // unique
-        if (ok) {
-            const sa_t a = s1 < s0 ? s1 : s0, b = s1 < s0 ? s0 : s1;
-            ok = left_maximal(T, a, b);
-        }
+        const uint8_t c1 = bw[k], c0 = (k == 0) ? pbw : bw[k - 1];
+        ok = ok && (s1 < s0 ? left_maximal(c1, c0) : left_maximal(c0, c1));
         hit |= ok ? (1u << k) : 0u;
     }
     // order-preserving append of this tile's survivors
@@ -151,7 +153,7 @@ __device__ inline int sample_of_pos(const sa_t *__restrict__ nsep, int nsep_n, s
     return lo;
 }
 
-__device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t *__restrict__ T, const sa_t *__restrict__ nsep, int nsamples,
+__device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t *__restrict__ BWT, const sa_t *__restrict__ nsep, int nsamples,
                                       int64_t lb, int64_t ub) {
     if (nsamples == 2) {
         if ((SA[ub] > nsep[0]) == (SA[lb] > nsep[0])) return false;
@@ -168,18 +170,16 @@ __device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t
             for (int64_t k = lb; k < j; k++) if (sample_of_pos(nsep, nsamples - 1, SA[k]) == sj) return false;
         }
     }
-    for (int64_t j = lb; j < ub; j++) {
-        const sa_t a = SA[j], b = SA[j + 1];
-        if (a == 0 || b == 0) return true;
-        const uint8_t ca = T[a - 1];
-        if (ca != T[b - 1] || ca == 'N' || ca == '$' || is_lower_c(ca)) return true;
+    for (int64_t j = lb; j < ub; j++) {       // reveal.c:246-256; BWT holds '$' where SA == 0
+        const uint8_t ca = BWT[j], cb = BWT[j + 1];
+        if (cb == '$' || ca != cb || ca == 'N' || ca == '$' || is_lower_c(ca)) return true;
     }
     return false;
 }
 
 // EMIT=false: count records/members of rank u; EMIT=true: write them.
 template <bool EMIT>
-__device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ T,
+__device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ BWT,
                                   const sa_t *__restrict__ nsep, int nsamples, int minl, int minn, int64_t u,
                                   u32 &nrec, u32 &nmem, RvMultiRec *rec_out, uint16_t *so_out, sa_t *pos_out, u32 rec_cap, u32 mem_cap) {
     nrec = 0; nmem = 0;
@@ -197,7 +197,7 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
         if (lb < 0) break;                                   // cannot happen: LCP of a sub-index' first rank is 0
         const int64_t n = u - lb + 1;
         if (n > nsamples) break;                              // every further interval is larger still
-        if (n >= minn && ismultimum_dev(SA, T, nsep, nsamples, lb, u)) {
+        if (n >= minn && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
             if (EMIT) {
                 if (rq < rec_cap) { RvMultiRec r; r.l = cur; r.n = (u32)n; r.ub = (u32)u; r.pad = 0; rec_out[rq] = r; }
                 for (int64_t j = lb; j <= u; j++, mq++)
@@ -214,7 +214,7 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
 }
 
 __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
-                                                   const uint8_t *__restrict__ T, const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
+                                                   const uint8_t *__restrict__ BWT, const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
                                                    RvMultiRec *__restrict__ rec, uint16_t *__restrict__ so, sa_t *__restrict__ pos,
                                                    u32 rec_cap, u32 mem_cap, u32 *__restrict__ counters, uint4 *__restrict__ tiletab) {
     __shared__ u32 ws_r[TB / 64], ws_m[TB / 64];
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 nr, nm;
-    multi_walk<false>(SA, LCP, m, T, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0);
+    multi_walk<false>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0);
     u32 ir = nr, im = nm;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { u32 a = __shfl_up(ir, d, 64), b = __shfl_up(im, d, 64); if (lane >= d) { ir += a; im += b; } }
@@ -241,27 +241,27 @@ __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, 
     if (nr) {
         const u32 r0 = s_rb + br + (ir - nr), m0 = s_mb + bm + (im - nm);
         u32 a2, b2;
-        multi_walk<true>(SA, LCP, m, T, nsep, nsamples, minl, minn, u, a2, b2, rec + r0, so + m0, pos + m0,
+        multi_walk<true>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, a2, b2, rec + r0, so + m0, pos + m0,
                          r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u);
     }
 }
 
 }  // namespace
 
-int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *T, const sa_t *nsep, int nsamples,
+int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, T, nsep, nsamples, minl, minn,
+    hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
                        rec, so, pos, rec_cap, mem_cap, counters, tiletab);
     RV_LAUNCH_CHECK();
     return 0;
 }
 
-int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *T, sa_t nsep0, int minl,
+int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
                         RvPairRec *out, u32 out_cap, u32 *counter, uint2 *tiletab) {
     if (m <= 0) return 0;
     const unsigned nb = (unsigned)ceil_div(m, PAIR_TILE);
-    hipLaunchKernelGGL(k_scan_pair, dim3(nb), dim3(TB), 0, ws.stream, SA, LCP, m, T, nsep0, minl, out, out_cap, counter, tiletab);
+    hipLaunchKernelGGL(k_scan_pair, dim3(nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, out, out_cap, counter, tiletab);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -28,9 +28,13 @@ struct RvSplitArgs {
     // windows [cut_lo, cut_hi) in front of the cuts of each sub's leading child
     const int     *cut_first;               // [nsubs+1]
     const sa_t    *cut_lo, *cut_hi;
+    // positions right behind each sub's matched ranges (sp + l): the BWT byte of a trailing suffix starting there turns lower case
+    const int     *mend_first;              // [nsubs+1]
+    const sa_t    *mend_pos;
     // outputs
     sa_t  *SA_out;
     lcp_t *LCP_out;
+    uint8_t *BWT_out;
     sa_t  *SAi;
     u32   *err;
 };
@@ -50,14 +54,17 @@ struct RvBubbleArgs {
     uint8_t            *flag;     // one byte per rank of the next level, zero between rounds
     sa_t  *SA;
     lcp_t *LCP;
+    uint8_t *BWT;
     sa_t  *SAi;
     const sa_t *cut_lo, *cut_hi;
     u32   *err;
 };
 
 int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs &t, uint8_t *D);
-int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, int64_t m, const RvSplitArgs &a,
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, const uint8_t *BWT, int64_t m, const RvSplitArgs &a,
                     const int *d_split_subs, int nsplit);
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
-int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window);
+// descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
+#define RV_BUBBLE_BIG_N 16384
+int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int64_t total_window);
 int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi);

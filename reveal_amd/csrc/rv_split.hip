@@ -70,7 +70,7 @@ __device__ inline MinSt ms_combine(MinSt a, MinSt b) {   // a then b
 
 template <bool EMIT>
 __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ D,
-                                              int64_t m, RvSplitArgs a) {
+                                              const uint8_t *__restrict__ BWT, int64_t m, RvSplitArgs a) {
     __shared__ u32   s_cnt[TB / 64][3];
     __shared__ MinSt s_ms[TB / 64][3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
     uint8_t d[SP_ITEMS + 1];      // d[0] = label of rank j0-1
     u32 ev[SP_ITEMS];             // effective LCP (INF where the reference skips the min update)
     sa_t sa[SP_ITEMS];
+    uint8_t bw[SP_ITEMS];
     d[0] = (j0 > 0 && j0 - 1 < m) ? D[j0 - 1] : (uint8_t)0;
 #pragma unroll
     for (int k = 0; k < SP_ITEMS; k++) {
@@ -87,7 +88,7 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
         d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
         const u32 l = (j < m) ? (u32)LCP[j] : INF;
         ev[k] = (d[k] != 0 && j < m) ? l : INF;
-        if (EMIT) sa[k] = (j < m) ? SA[j] : (sa_t)0;
+        if (EMIT) { sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0; }
     }
     // thread summaries
     u32 cnt[3] = {0, 0, 0};
@@ -160,6 +161,14 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
             const u32 idx = np - base;                                   // rank inside the child
             a.SA_out[np] = sa[k];
             a.LCP_out[np] = (lcp_t)(idx == 0 ? 0u : run[c]);
+            uint8_t bo = bw[k];
+            if (c == 1) {   // trailing child: the character in front of a suffix that starts right behind a
+                            // matched range has just been lower-cased (reveal.c:1230-1234)
+                const int q0 = a.mend_first[s], q1 = a.mend_first[s + 1];
+                for (int q = q0; q < q1; q++)
+                    if (sa[k] == a.mend_pos[q]) { if (bo >= 'A' && bo <= 'Z') bo += 32; break; }
+            }
+            a.BWT_out[np] = bo;
             if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
                 const int q0 = a.cut_first[s], q1 = a.cut_first[s + 1];
                 for (int q = q0; q < q1; q++)
@@ -299,10 +308,12 @@ constexpr int BB_CAP = 4096;
 
 // One visit of the reference's inner loop body (reveal.c:686-721) for rank e of
 // the child, executed by the whole workgroup: thread 0 evaluates the two
-// conditions on the current values; a move (first branch) searches its
-// destination and shifts [x, e-1] up by one cooperatively.
-__device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &ds, sa_t *SA, lcp_t *LCP, int64_t e,
-                                    int64_t *s_v, int *s_min) {
+// conditions on the current values; a move (first branch) walks down from e in
+// chunks of NT*EL ranks, looking for its destination x (largest r <= e with
+// r == 0 or LCP[r] < t) and shifting [x, e-1] up by one as it goes.
+template <int NT, int EL>
+__device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &ds, sa_t *SA, lcp_t *LCP, uint8_t *BW, int64_t e,
+                                    int64_t *s_v, int *s_max) {
     const int64_t n = ds.n, B = ds.B;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
@@ -314,50 +325,49 @@ __device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &d
             const int64_t ln = (int64_t)(u32)LCP[e + 1];
             if (sa < B && sa + ln > B && ln > lc) LCP[e + 1] = (lcp_t)(B - sa);      // reveal.c:714-718
         }
-        s_v[0] = kind; s_v[1] = sa; s_v[2] = lc;
+        s_v[0] = kind; s_v[1] = sa; s_v[2] = lc; s_v[3] = BW[e];
     }
     __syncthreads();
     if (s_v[0] == 1) {                                                               // reveal.c:686-709
         const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
-        // x = largest r <= e with r == 0 or LCP[r] < t
-        int64_t cur = e, x = 0;
-        for (;;) {
-            const int64_t r = cur - threadIdx.x;
-            const bool f = (r >= 0) && (r == 0 || (int64_t)(u32)LCP[r] < t);
-            const u64 bal = __ballot(f);
-            if (lane == 0) s_min[w] = bal ? (w * 64 + (int)__builtin_ctzll(bal)) : 0x7fffffff;
-            __syncthreads();
-            int mn = 0x7fffffff;
-            for (int k = 0; k < TB / 64; k++) mn = s_min[k] < mn ? s_min[k] : mn;
-            __syncthreads();
-            if (mn != 0x7fffffff) { x = cur - mn; break; }
-            cur -= TB;
-        }
-        // shift [x, e-1] -> [x+1, e], top chunk first
-        for (int64_t hi = e; hi > x;) {
-            const int64_t lo = (hi - 4 * TB + 1 > x + 1) ? hi - 4 * TB + 1 : x + 1;
-            sa_t vs[4]; lcp_t vl[4];
+        const uint8_t tB = (uint8_t)s_v[3];
+        int64_t hi = e, x = 0;
+        while (hi > 0) {
+            const int64_t lo = (hi - (int64_t)NT * EL + 1 > 1) ? hi - (int64_t)NT * EL + 1 : 1;
+            sa_t vs[EL]; lcp_t vl[EL]; uint8_t vb[EL];
+            int best = -1;                       // largest offset (idx - lo) in this chunk with LCP[idx] < t
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
-                if (idx >= lo) { vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const int64_t idx = hi - (int64_t)k * TB - threadIdx.x;
+            for (int k = 0; k < EL; k++) {
+                const int64_t idx = hi - (int64_t)k * NT - threadIdx.x;
                 if (idx >= lo) {
-                    SA[idx] = vs[k]; LCP[idx] = vl[k];
+                    const lcp_t here = LCP[idx];
+                    vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; vb[k] = BW[idx - 1];
+                    if ((int64_t)(u32)here < t && (int)(idx - lo) > best) best = (int)(idx - lo);
+                }
+            }
+            for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_down(best, d, 64); best = o > best ? o : best; }
+            if (lane == 0) s_max[w] = best;
+            __syncthreads();
+            int mx = -1;
+            for (int k = 0; k < NT / 64; k++) mx = s_max[k] > mx ? s_max[k] : mx;
+            const int64_t stop = (mx >= 0) ? lo + mx : lo - 1;      // ranks (stop, hi] move up by one
+#pragma unroll
+            for (int k = 0; k < EL; k++) {
+                const int64_t idx = hi - (int64_t)k * NT - threadIdx.x;
+                if (idx >= lo && idx > stop) {
+                    SA[idx] = vs[k]; LCP[idx] = vl[k]; BW[idx] = vb[k];
                     for (int q = ds.cut0; q < ds.cut1; q++)
                         if (vs[k] >= b.cut_lo[q] && vs[k] < b.cut_hi[q]) { b.SAi[vs[k]] = (sa_t)idx; break; }
                 }
             }
             __threadfence_block();
             __syncthreads();
-            hi = lo - 1;
+            if (mx >= 0) { x = stop; break; }
+            hi = lo - 1;                                              // nothing below t in this chunk: keep going
         }
         if (threadIdx.x == 0) {
             SA[x] = (sa_t)tS;
+            BW[x] = tB;
             b.SAi[tS] = (sa_t)x;
             if (x + 1 < n) LCP[x + 1] = (lcp_t)t;
             if (e < n - 1 && tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = (lcp_t)tL;
@@ -372,22 +382,26 @@ __device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &d
 // move).  Few actives: sort the window pass' list in LDS.  Many (closely
 // related samples share long matches across a cut): walk the child's flag
 // bytes 4096 ranks at a time, which yields them already ordered.
-__global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) {
+// NT = 256 for ordinary children, 1024 (8 ranks per thread and step) for the
+// few large ones, whose moves travel up to a quarter of the child.
+template <int NT, int EL>
+__global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL
-    __shared__ int s_min[TB / 64];
-    __shared__ u32 s_w[TB / 64];
+    __shared__ int s_max[NT / 64];
+    __shared__ u32 s_w[NT / 64];
     const int dd = first + blockIdx.x;
     const u32 cnt = b.cnt[dd];
     if (cnt == 0) return;
     const RvBubbleDesc ds = b.desc[dd];
     sa_t  *SA = b.SA + ds.off;
     lcp_t *LCP = b.LCP + ds.off;
+    uint8_t *BW = b.BWT + ds.off;
     uint8_t *flag = b.flag + ds.off;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (cnt <= BB_CAP) {
         u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
-        for (u32 k = threadIdx.x; k < np2; k += TB) {
+        for (u32 k = threadIdx.x; k < np2; k += NT) {
             const u32 v = k < cnt ? b.list[b.woff[dd] + k] : 0xFFFFFFFFu;
             lst[k] = v;
             if (k < cnt) flag[v] = 0;
@@ -395,7 +409,7 @@ __global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) 
         __syncthreads();
         for (u32 size = 2; size <= np2; size <<= 1)
             for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
-                for (u32 k = threadIdx.x; k < np2 / 2; k += TB) {
+                for (u32 k = threadIdx.x; k < np2 / 2; k += NT) {
                     const u32 lo = (k / stride) * stride * 2 + (k % stride), hi = lo + stride;
                     const bool up = ((lo & size) == 0);
                     const u32 x = lst[lo], y = lst[hi];
@@ -403,14 +417,14 @@ __global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) 
                 }
                 __syncthreads();
             }
-        for (u32 ai = 0; ai < cnt; ai++) bubble_visit(b, ds, SA, LCP, (int64_t)lst[ai], s_v, s_min);
+        for (u32 ai = 0; ai < cnt; ai++) bubble_visit<NT, EL>(b, ds, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
         return;
     }
+    constexpr int FL = BB_CAP / NT;     // flag bytes per thread and chunk
     for (int64_t base = 0; base < ds.n; base += BB_CAP) {
-        // flags of ranks [base + 16*tid, +16)
-        const int64_t r0 = base + (int64_t)threadIdx.x * 16;
+        const int64_t r0 = base + (int64_t)threadIdx.x * FL;
         u32 bits = 0;
-        for (int k = 0; k < 16; k++) if (r0 + k < ds.n && flag[r0 + k]) { bits |= 1u << k; flag[r0 + k] = 0; }
+        for (int k = 0; k < FL; k++) if (r0 + k < ds.n && flag[r0 + k]) { bits |= 1u << k; flag[r0 + k] = 0; }
         const u32 mine = __popc(bits);
         u32 inc = mine;
 #pragma unroll
@@ -418,11 +432,11 @@ __global__ __launch_bounds__(TB) void k_bubble_apply(RvBubbleArgs b, int first) 
         if (lane == 63) s_w[w] = inc;
         __syncthreads();
         u32 before = 0, tot = 0;
-        for (int k = 0; k < TB / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+        for (int k = 0; k < NT / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
         u32 q = before + inc - mine;
-        for (int k = 0; k < 16; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
+        for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
         __syncthreads();
-        for (u32 ai = 0; ai < tot; ai++) bubble_visit(b, ds, SA, LCP, (int64_t)lst[ai], s_v, s_min);
+        for (u32 ai = 0; ai < tot; ai++) bubble_visit<NT, EL>(b, ds, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
         __syncthreads();
     }
 }
@@ -444,11 +458,11 @@ int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs 
     return 0;
 }
 
-int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, int64_t m, const RvSplitArgs &a,
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, const uint8_t *BWT, int64_t m, const RvSplitArgs &a,
                     const int *d_split_subs, int nsplit) {
     if (m <= 0 || nsplit <= 0) return 0;
     const unsigned nt = (unsigned)a.ntiles;
-    hipLaunchKernelGGL(k_split<false>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, m, a);
+    hipLaunchKernelGGL(k_split<false>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, BWT, m, a);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(TB), 0, ws.stream, a);
     RV_LAUNCH_CHECK();
@@ -456,7 +470,7 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seg_offsets, dim3((unsigned)nsplit), dim3(64), 0, ws.stream, D, m, a, d_split_subs, nsplit);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_split<true>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, m, a);
+    hipLaunchKernelGGL(k_split<true>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, BWT, m, a);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -468,12 +482,19 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
     return 0;
 }
 
-int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window) {
+int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int64_t total_window) {
+    const int count = count_small + count_big;
     if (count <= 0 || total_window <= 0) return 0;
     hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_bubble_apply, dim3((unsigned)count), dim3(TB), 0, ws.stream, b, first);
-    RV_LAUNCH_CHECK();
+    if (count_small > 0) {
+        hipLaunchKernelGGL((k_bubble_apply<256, 4>), dim3((unsigned)count_small), dim3(256), 0, ws.stream, b, first);
+        RV_LAUNCH_CHECK();
+    }
+    if (count_big > 0) {
+        hipLaunchKernelGGL((k_bubble_apply<1024, 8>), dim3((unsigned)count_big), dim3(1024), 0, ws.stream, b, first + count_small);
+        RV_LAUNCH_CHECK();
+    }
     return 0;
 }
 

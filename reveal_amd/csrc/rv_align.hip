@@ -6,9 +6,13 @@
 // pushes up to three children.  Children cover disjoint text and only read
 // text fixed by their ancestors, so the order is free: here every level of the
 // recursion tree is one batch -- the sub-indices lie back to back in two
-// ping-pong (SA, LCP) level arrays in HBM, one scan launch covers the whole
-// frontier, the host (or the Python callbacks) decides per sub-index, one
+// ping-pong (SA, LCP, BWT) level arrays in HBM, one scan launch covers the
+// whole frontier, the host (or the Python callbacks) decides per sub-index, one
 // label/split/bubble pipeline produces the next level.
+//
+// Host bookkeeping is flat (CSR arrays per level, reused across levels): the
+// recursion visits ~10^5 sub-indices per 10 Mbp, so nothing here allocates per
+// sub-index.
 #include "rv_index.h"
 #include "rv_split.h"
 #include <string.h>
@@ -32,15 +36,51 @@ u64 hash_step(u64 acc, u64 i, int64_t v) {      // same as oracle/reveal_oracle.
 // host staging of several small tables into one upload
 struct Packer {
     std::vector<uint8_t> buf;
+    void clear() { buf.clear(); }
     size_t add(const void *p, size_t bytes) {
-        size_t off = (buf.size() + 15) & ~(size_t)15;
+        const size_t off = (buf.size() + 15) & ~(size_t)15;
         buf.resize(off + bytes);
         if (bytes) memcpy(buf.data() + off, p, bytes);
         return off;
     }
     template <class T> size_t addv(const std::vector<T> &v) { return add(v.data(), v.size() * sizeof(T)); }
-    size_t reserve(size_t bytes) { size_t off = (buf.size() + 15) & ~(size_t)15; buf.resize(off + bytes, 0); return off; }
+    size_t reserve(size_t bytes) { const size_t off = (buf.size() + 15) & ~(size_t)15; buf.resize(off + bytes, 0); return off; }
 };
+
+// One recursion level: sub-index s owns ranks [off[s], off[s]+n[s]) of the level
+// arrays and the intervals nodes[node_first[s] .. node_first[s+1]) (sorted by begin).
+struct Level {
+    int64_t m = 0;
+    std::vector<int64_t> off, n;
+    std::vector<int32_t> depth, nsamples, parent, kind;
+    std::vector<int64_t> node_first;
+    std::vector<RvIntv>  nodes;
+    int size() const { return (int)off.size(); }
+    void clear() { m = 0; off.clear(); n.clear(); depth.clear(); nsamples.clear(); parent.clear(); kind.clear(); node_first.assign(1, 0); nodes.clear(); }
+};
+
+// Decisions of one level (mumpicker + graphalign results), appended in any order.
+struct Decisions {
+    std::vector<int32_t> of_sub;          // per sub: decision index or -1
+    std::vector<int32_t> sub;             // per decision
+    std::vector<u32>     l;
+    std::vector<int64_t> sp_first, lead_first, trail_first, rest_first, match_first;   // CSR, size ndec+1
+    std::vector<int64_t> sp;
+    std::vector<RvIntv>  lead, trail, rest, match;     // lead/trail/rest sorted by begin per decision; match in the given order
+    int size() const { return (int)sub.size(); }
+    void reset(int nsubs) {
+        of_sub.assign((size_t)nsubs, -1);
+        sub.clear(); l.clear();
+        sp_first.assign(1, 0); lead_first.assign(1, 0); trail_first.assign(1, 0); rest_first.assign(1, 0); match_first.assign(1, 0);
+        sp.clear(); lead.clear(); trail.clear(); rest.clear(); match.clear();
+    }
+    void close() {
+        sp_first.push_back((int64_t)sp.size()); lead_first.push_back((int64_t)lead.size()); trail_first.push_back((int64_t)trail.size());
+        rest_first.push_back((int64_t)rest.size()); match_first.push_back((int64_t)match.size());
+    }
+};
+
+inline bool intv_less(const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; }
 
 }  // namespace
 
@@ -50,13 +90,25 @@ struct Align {
     int level = 0;
     DBuf lvSA[2], lvLCP[2], lvBWT[2];
     int cur = 0;                 // which level buffer holds the frontier (level > 0)
-    int64_t m = 0;               // ranks in the frontier
-    std::vector<RvSub> subs;
+    Level lv, nx;                // current frontier / the one being built
+    Decisions dec;
     bool scanned = false;
-    // level-wide scan result, CSR
+    // scan result of the level: pair records in rank order, or CSR for the multi scan
+    std::vector<RvPairRec> recs;
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
+    std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag;
+    Packer pk;
+    std::vector<int> stamp; int epoch = 0;        // count_samples scratch
+    // reusable host tables of commit()
+    std::vector<sa_t> cb, ce, mb, me, cut_lo, cut_hi, mend_pos;
+    std::vector<uint8_t> cc;
+    std::vector<int> ctab_first, mtab_first, cut_first, mend_first, split_subs;
+    std::vector<int64_t> mpre, sub_start, woff;
+    std::vector<u32> child_base, child_n;
+    std::vector<RvBubbleDesc> descs;
+    std::vector<std::vector<RvBubbleDesc>> rounds;
     // results of rv_align_builtin
     std::vector<u32> an_l; std::vector<int64_t> an_off, an_pos;
     bool trace_on = false;
@@ -73,27 +125,55 @@ void rv_align_free(rv_index *h) {
 }
 
 static const sa_t *cur_sa(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dSA.as<sa_t>() : a->lvSA[a->cur].as<sa_t>(); }
-static const uint8_t *cur_bwt(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dBWT.as<uint8_t>() : a->lvBWT[a->cur].as<uint8_t>(); }
 static const lcp_t *cur_lcp(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dLCP.as<lcp_t>() : a->lvLCP[a->cur].as<lcp_t>(); }
+static const uint8_t *cur_bwt(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dBWT.as<uint8_t>() : a->lvBWT[a->cur].as<uint8_t>(); }
 
 static int sample_of(const rv_index *h, int64_t pos) {       /* SO[pos], interface.c:116-134 */
     return (int)(std::lower_bound(h->nsep.begin(), h->nsep.end(), pos) - h->nsep.begin());
 }
 
 /* child sample count, reveal.c:1028-1042 */
-static int count_samples(const rv_index *h, const std::vector<RvIntv> &iv) {
+static int count_samples(rv_index *h, const RvIntv *iv, size_t cnt) {
+    Align *a = h->al;
     if (h->nsamples > 2) {
-        std::vector<int> seen;
-        for (auto &x : iv) { int s = sample_of(h, x.begin); if (std::find(seen.begin(), seen.end(), s) == seen.end()) seen.push_back(s); }
-        return (int)seen.size();
+        if ((int)a->stamp.size() < h->nsamples) a->stamp.assign((size_t)h->nsamples, 0);
+        const int ep = ++a->epoch;
+        int ns = 0;
+        for (size_t k = 0; k < cnt; k++) { const int s = sample_of(h, iv[k].begin); if (a->stamp[(size_t)s] != ep) { a->stamp[(size_t)s] = ep; ns++; } }
+        return ns;
     }
     bool f0 = false, f1 = false;
-    for (auto &x : iv) { if (x.begin < h->nsep[0]) f0 = true; if (x.begin > h->nsep[0]) f1 = true; }
+    for (size_t k = 0; k < cnt; k++) { if (iv[k].begin < h->nsep[0]) f0 = true; if (iv[k].begin > h->nsep[0]) f1 = true; }
     return (int)f0 + (int)f1;
 }
 
 static int need_align(rv_index *h) {
     if (!h->al) { rv_set_error("align not started (rv_align_begin)"); return -1; }
+    return 0;
+}
+static int need_sub(rv_index *h, int s) {
+    RV_TRY(need_align(h));
+    if (s < 0 || s >= h->al->lv.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
+    return 0;
+}
+
+// record one decision; lead/trail/rest are sorted here, match keeps its order (reveal.c:673-674)
+static int add_decision(rv_index *h, int s, u32 l, const int64_t *sp, int nsp,
+                        const RvIntv *lead, int nlead, const RvIntv *trail, int ntrail,
+                        const RvIntv *match, int nmatch, const RvIntv *rest, int nrest) {
+    Decisions &d = h->al->dec;
+    if (d.of_sub[(size_t)s] >= 0) { rv_set_error("sub-index %d already has a decision", s); return -1; }
+    d.of_sub[(size_t)s] = d.size();
+    d.sub.push_back(s); d.l.push_back(l);
+    d.sp.insert(d.sp.end(), sp, sp + nsp);
+    std::sort(d.sp.end() - nsp, d.sp.end());
+    auto put = [](std::vector<RvIntv> &v, const RvIntv *p, int n, bool sorted) {
+        const size_t at = v.size();
+        v.insert(v.end(), p, p + n);
+        if (sorted && n > 1 && !std::is_sorted(v.begin() + at, v.end(), intv_less)) std::sort(v.begin() + at, v.end(), intv_less);
+    };
+    put(d.lead, lead, nlead, true); put(d.trail, trail, ntrail, true); put(d.rest, rest, nrest, true); put(d.match, match, nmatch, false);
+    d.close();
     return 0;
 }
 
@@ -103,28 +183,34 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed, alignment stopped."); return -1; }
     if (h->nsamples < 2) { rv_set_error("align needs at least two samples"); return -1; }
     RV_HIP(hipSetDevice(h->device));
-    rv_align_free(h);
-    Align *a = h->al = new Align();
+    const bool keep_trace = h->al && h->al->trace_on;
+    if (!h->al) h->al = new Align();         // device scratch of an earlier run is reused
+    Align *a = h->al;
+    a->trace_on = keep_trace;
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
-    a->m = h->n;
-    RvSub root;
-    root.off = 0; root.n = h->n; root.depth = 0; root.nsamples = h->nsamples; root.parent = -1; root.kind = 0;
-    root.nodes = h->nodes;
-    std::sort(root.nodes.begin(), root.nodes.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
-    a->subs.push_back(std::move(root));
+    a->level = 0; a->cur = 0; a->scanned = false;
+    memset(&a->st, 0, sizeof a->st);
+    a->lv.clear();
+    a->lv.m = h->n;
+    a->lv.off.push_back(0); a->lv.n.push_back(h->n); a->lv.depth.push_back(0); a->lv.nsamples.push_back(h->nsamples);
+    a->lv.parent.push_back(-1); a->lv.kind.push_back(0);
+    a->lv.nodes = h->nodes;
+    std::sort(a->lv.nodes.begin(), a->lv.nodes.end(), intv_less);
+    a->lv.node_first.push_back((int64_t)a->lv.nodes.size());
+    a->dec.reset(1);
     return 0;
 }
 
-int rv_frontier_size(rv_index *h) { return h->al ? (int)h->al->subs.size() : 0; }
+int rv_frontier_size(rv_index *h) { return h->al ? h->al->lv.size() : 0; }
 
 int rv_align_end(rv_index *h) {
-    if (h->al) { h->al->subs.clear(); h->al->scanned = false; }
+    if (h->al) { h->al->lv.clear(); h->al->scanned = false; }
     return 0;
 }
 
 int rv_set_trace(rv_index *h, int on) {
-    if (!h->al) { h->al = new Align(); }
+    if (!h->al) h->al = new Align();
     h->al->trace_on = on != 0;
     return 0;
 }
@@ -143,87 +229,79 @@ int rv_frontier_scan(rv_index *h) {
     Align *a = h->al;
     RV_HIP(hipSetDevice(h->device));
     const double t0 = now_s();
-    a->ml.clear(); a->mn.clear(); a->moff.assign(1, 0); a->mso.clear(); a->mpos.clear();
-    for (auto &s : a->subs) { s.mum_first = 0; s.nmums = 0; }
+    const int ns = a->lv.size();
+    a->mum_first.assign((size_t)ns, 0); a->nmums.assign((size_t)ns, 0);
     if (!a->multi) {
-        std::vector<RvPairRec> recs;
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->m, a->minl, recs));
-        const size_t nr = recs.size();
-        a->ml.resize(nr); a->mn.assign(nr, 2); a->moff.resize(nr + 1); a->mso.resize(2 * nr); a->mpos.resize(2 * nr);
-        size_t si = 0;
-        for (size_t k = 0; k < nr; k++) {                     /* (l, 2, ((0,a),(1,b)))  reveal.c:166-170 */
-            a->ml[k] = recs[k].l; a->moff[k] = (int64_t)(2 * k);
-            a->mso[2 * k] = 0; a->mpos[2 * k] = recs[k].a;
-            a->mso[2 * k + 1] = 1; a->mpos[2 * k + 1] = recs[k].b;
-            while (si < a->subs.size() && (int64_t)recs[k].rank >= a->subs[si].off + a->subs[si].n) si++;
-            if (si >= a->subs.size()) { rv_set_error("scan record outside the frontier"); return -1; }
-            RvSub &s = a->subs[si];
-            if (s.nmums == 0) s.mum_first = (int64_t)k;
-            s.nmums++;
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs));
+        int si = 0;
+        for (size_t k = 0; k < a->recs.size(); k++) {
+            const int64_t r = (int64_t)a->recs[k].rank;
+            while (si < ns && r >= a->lv.off[(size_t)si] + a->lv.n[(size_t)si]) si++;
+            if (si >= ns) { rv_set_error("scan record outside the frontier"); return -1; }
+            if (a->nmums[(size_t)si] == 0) a->mum_first[(size_t)si] = (int64_t)k;
+            a->nmums[(size_t)si]++;
         }
-        a->moff[nr] = (int64_t)(2 * nr);
     } else {
         std::vector<int64_t> ub;
-        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub));
-        size_t si = 0;
+        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub));
+        int si = 0;
         for (size_t k = 0; k < a->ml.size(); k++) {
-            while (si < a->subs.size() && ub[k] >= a->subs[si].off + a->subs[si].n) si++;
-            if (si >= a->subs.size()) { rv_set_error("scan record outside the frontier"); return -1; }
-            RvSub &s = a->subs[si];
-            if (s.nmums == 0) s.mum_first = (int64_t)k;
-            s.nmums++;
+            while (si < ns && ub[k] >= a->lv.off[(size_t)si] + a->lv.n[(size_t)si]) si++;
+            if (si >= ns) { rv_set_error("scan record outside the frontier"); return -1; }
+            if (a->nmums[(size_t)si] == 0) a->mum_first[(size_t)si] = (int64_t)k;
+            a->nmums[(size_t)si]++;
         }
     }
     a->scanned = true;
-    a->st.scanned_ranks += a->m;
+    a->st.scanned_ranks += a->lv.m;
     a->st.t_scan += now_s() - t0;
     return 0;
 }
 
 int rv_sub_info(rv_index *h, int s, rv_sub *out) {
-    RV_TRY(need_align(h));
+    RV_TRY(need_sub(h, s));
     Align *a = h->al;
-    if (s < 0 || s >= (int)a->subs.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
-    const RvSub &x = a->subs[s];
     memset(out, 0, sizeof *out);
-    out->n = x.n; out->depth = x.depth; out->nsamples = x.nsamples; out->nnodes = (int32_t)x.nodes.size();
-    out->parent = x.parent; out->kind = x.kind; out->nmums = x.nmums;
-    out->nmembers = x.nmums ? a->moff[(size_t)(x.mum_first + x.nmums)] - a->moff[(size_t)x.mum_first] : 0;
+    out->n = a->lv.n[(size_t)s]; out->depth = a->lv.depth[(size_t)s]; out->nsamples = a->lv.nsamples[(size_t)s];
+    out->nnodes = (int32_t)(a->lv.node_first[(size_t)s + 1] - a->lv.node_first[(size_t)s]);
+    out->parent = a->lv.parent[(size_t)s]; out->kind = a->lv.kind[(size_t)s];
+    if (a->scanned) {
+        out->nmums = a->nmums[(size_t)s];
+        if (!a->multi) out->nmembers = 2 * out->nmums;
+        else out->nmembers = out->nmums ? a->moff[(size_t)(a->mum_first[(size_t)s] + out->nmums)] - a->moff[(size_t)a->mum_first[(size_t)s]] : 0;
+    }
     return 0;
 }
 
 int rv_sub_nodes(rv_index *h, int s, int64_t *be) {
-    RV_TRY(need_align(h));
+    RV_TRY(need_sub(h, s));
     Align *a = h->al;
-    if (s < 0 || s >= (int)a->subs.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
-    const RvSub &x = a->subs[s];
-    for (size_t k = 0; k < x.nodes.size(); k++) { be[2 * k] = x.nodes[k].begin; be[2 * k + 1] = x.nodes[k].end; }
+    int64_t k = 0;
+    for (int64_t q = a->lv.node_first[(size_t)s]; q < a->lv.node_first[(size_t)s + 1]; q++, k++) { be[2 * k] = a->lv.nodes[(size_t)q].begin; be[2 * k + 1] = a->lv.nodes[(size_t)q].end; }
     return 0;
 }
 
 int rv_sub_mums(rv_index *h, int s, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos) {
-    RV_TRY(need_align(h));
+    RV_TRY(need_sub(h, s));
     Align *a = h->al;
-    if (s < 0 || s >= (int)a->subs.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
-    const RvSub &x = a->subs[s];
-    const int64_t base = x.nmums ? a->moff[(size_t)x.mum_first] : 0;
-    for (int64_t k = 0; k < x.nmums; k++) {
-        const size_t g = (size_t)(x.mum_first + k);
+    if (!a->scanned) { rv_set_error("rv_sub_mums before rv_frontier_scan"); return -1; }
+    const int64_t first = a->mum_first[(size_t)s], cnt = a->nmums[(size_t)s];
+    if (!a->multi) {                                          /* (l, 2, ((0,a),(1,b)))  reveal.c:166-170 */
+        for (int64_t k = 0; k < cnt; k++) {
+            const RvPairRec &r = a->recs[(size_t)(first + k)];
+            l[k] = r.l; n[k] = 2; off[k] = 2 * k;
+            so[2 * k] = 0; pos[2 * k] = r.a; so[2 * k + 1] = 1; pos[2 * k + 1] = r.b;
+        }
+        off[cnt] = 2 * cnt;
+        return 0;
+    }
+    const int64_t base = cnt ? a->moff[(size_t)first] : 0;
+    for (int64_t k = 0; k < cnt; k++) {
+        const size_t g = (size_t)(first + k);
         l[k] = a->ml[g]; n[k] = a->mn[g]; off[k] = a->moff[g] - base;
         for (int64_t q = a->moff[g]; q < a->moff[g + 1]; q++) { so[q - base] = a->mso[(size_t)q]; pos[q - base] = a->mpos[(size_t)q]; }
     }
-    off[x.nmums] = x.nmums ? a->moff[(size_t)(x.mum_first + x.nmums)] - base : 0;
-    return 0;
-}
-
-static int upload_sub_starts(rv_index *h, DBuf &buf) {
-    Align *a = h->al;
-    std::vector<int64_t> st(a->subs.size() + 1);
-    for (size_t k = 0; k < a->subs.size(); k++) st[k] = a->subs[k].off;
-    st[a->subs.size()] = a->m;
-    RV_TRY(buf.reserve(st.size() * 8));
-    RV_HIP(hipMemcpyAsync(buf.p, st.data(), st.size() * 8, hipMemcpyHostToDevice, h->ws.stream));
-    RV_HIP(hipStreamSynchronize(h->ws.stream));
+    off[cnt] = cnt ? a->moff[(size_t)(first + cnt)] - base : 0;
     return 0;
 }
 
@@ -234,45 +312,42 @@ int64_t rv_sub_array(rv_index *h, int s, int which, void *out, int64_t cap) {
     if (which == RV_SAI) {     /* the shared inverse: rank inside the owning sub-index (reveal.c:597,609,630) */
         if (cap < h->nT) { rv_set_error("buffer too small"); return -1; }
         if (a->level > 0) {
-            if (upload_sub_starts(h, h->ws.misc[4])) return -1;
-            if (rv_sai_level_launch(h->ws, cur_sa(h), a->m, h->ws.misc[4].as<int64_t>(), (int)a->subs.size(), h->dSAi.as<sa_t>())) return -1;
+            std::vector<int64_t> st(a->lv.off);
+            st.push_back(a->lv.m);
+            DBuf &buf = h->ws.misc[9];
+            if (buf.reserve(st.size() * 8)) return -1;
+            if (hipMemcpy(buf.p, st.data(), st.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { rv_set_error("H2D failed"); return -1; }
+            if (rv_sai_level_launch(h->ws, cur_sa(h), a->lv.m, buf.as<int64_t>(), a->lv.size(), h->dSAi.as<sa_t>())) return -1;
         }
         (void)hipStreamSynchronize(h->ws.stream);
         if (hipMemcpy(out, h->dSAi.p, (size_t)h->nT * sizeof(sa_t), hipMemcpyDeviceToHost) != hipSuccess) { rv_set_error("D2H failed"); return -1; }
         return h->nT;
     }
-    if (s < 0 || s >= (int)a->subs.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
-    const RvSub &x = a->subs[s];
-    if (cap < x.n) { rv_set_error("buffer too small"); return -1; }
+    if (need_sub(h, s)) return -1;
+    const int64_t off = a->lv.off[(size_t)s], n = a->lv.n[(size_t)s];
+    if (cap < n) { rv_set_error("buffer too small"); return -1; }
     (void)hipStreamSynchronize(h->ws.stream);
     hipError_t e;
-    if (which == RV_SA) e = hipMemcpy(out, cur_sa(h) + x.off, (size_t)x.n * sizeof(sa_t), hipMemcpyDeviceToHost);
-    else if (which == RV_LCP) e = hipMemcpy(out, cur_lcp(h) + x.off, (size_t)x.n * sizeof(lcp_t), hipMemcpyDeviceToHost);
+    if (which == RV_SA) e = hipMemcpy(out, cur_sa(h) + off, (size_t)n * sizeof(sa_t), hipMemcpyDeviceToHost);
+    else if (which == RV_LCP) e = hipMemcpy(out, cur_lcp(h) + off, (size_t)n * sizeof(lcp_t), hipMemcpyDeviceToHost);
     else { rv_set_error("rv_sub_array: bad array id"); return -1; }
     if (e != hipSuccess) { rv_set_error("D2H failed"); return -1; }
-    return x.n;
+    return n;
 }
 
 int rv_sub_split(rv_index *h, int s, uint32_t l, int nsp, const int64_t *sp,
                  const int64_t *lead, int nlead, const int64_t *trail, int ntrail,
                  const int64_t *match, int nmatch, const int64_t *rest, int nrest) {
-    RV_TRY(need_align(h));
-    Align *a = h->al;
-    if (s < 0 || s >= (int)a->subs.size()) { rv_set_error("sub-index %d out of range", s); return -1; }
-    RvSub &x = a->subs[s];
-    auto fill = [](std::vector<RvIntv> &v, const int64_t *p, int n) {
-        v.resize((size_t)n);
-        for (int k = 0; k < n; k++) { v[(size_t)k].begin = p[2 * k]; v[(size_t)k].end = p[2 * k + 1]; }
-    };
+    RV_TRY(need_sub(h, s));
     for (int k = 0; k < nsp; k++)
         if (sp[k] < 0 || sp[k] + (int64_t)l > h->nT) { rv_set_error("match outside the text"); return -1; }
-    x.has_split = true; x.l = l;
-    x.sp.assign(sp, sp + nsp);
-    fill(x.lead, lead, nlead); fill(x.trail, trail, ntrail); fill(x.match, match, nmatch); fill(x.rest, rest, nrest);
-    for (auto *v : {&x.lead, &x.trail, &x.rest, &x.match})
-        for (auto &iv : *v)
-            if (iv.begin < 0 || iv.end > h->nT || iv.begin > iv.end) { rv_set_error("interval outside the text"); x.has_split = false; return -1; }
-    return 0;
+    const int64_t *lists[4] = {lead, trail, match, rest};
+    const int cnts[4] = {nlead, ntrail, nmatch, nrest};
+    for (int q = 0; q < 4; q++)
+        for (int k = 0; k < cnts[q]; k++)
+            if (lists[q][2 * k] < 0 || lists[q][2 * k + 1] > h->nT || lists[q][2 * k] > lists[q][2 * k + 1]) { rv_set_error("interval outside the text"); return -1; }
+    static_assert(sizeof(RvIntv) == 2 * sizeof(int64_t), "RvIntv layout");
+    return add_decision(h, s, l, sp, nsp, (const RvIntv *)lead, nlead, (const RvIntv *)trail, ntrail, (const RvIntv *)match, nmatch, (const RvIntv *)rest, nrest);
 }
 
 /* reveal.c:1005-1252 for every decided sub-index; children -> next frontier */
@@ -282,134 +357,138 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_HIP(hipSetDevice(h->device));
     hipStream_t q = h->ws.stream;
     const double t0 = now_s();
-    const int ns = (int)a->subs.size();
+    const Level &lv = a->lv;
+    Level &nx = a->nx;
+    const Decisions &dc = a->dec;
+    const int ns = lv.size();
     if (children) for (int k = 0; k < 3 * ns; k++) children[k] = -1;
-    std::vector<int> split_subs;
-    for (int s = 0; s < ns; s++) if (a->subs[s].has_split) split_subs.push_back(s);
     a->scanned = false;
-    if (split_subs.empty()) { a->subs.clear(); a->m = 0; return 0; }
+    nx.clear();
+    if (dc.size() == 0) { a->lv.clear(); a->dec.reset(0); return 0; }
 
-    // ---- interval tables ---------------------------------------------------------
-    struct Ent { int64_t b, e; uint8_t c; };
-    std::vector<Ent> cls;
-    std::vector<RvIntv> mt;
-    for (int s : split_subs) {
-        const RvSub &x = a->subs[s];
-        for (auto &iv : x.lead) if (iv.end > iv.begin) cls.push_back({iv.begin, iv.end, 1});
-        for (auto &iv : x.trail) if (iv.end > iv.begin) cls.push_back({iv.begin, iv.end, 2});
-        for (auto &iv : x.rest) if (iv.end > iv.begin) cls.push_back({iv.begin, iv.end, 4});
-        for (int64_t p : x.sp) if (x.l) mt.push_back({p, p + (int64_t)x.l});
-    }
-    std::sort(cls.begin(), cls.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; });
-    std::sort(mt.begin(), mt.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
-    for (size_t k = 1; k < cls.size(); k++)
-        if (cls[k].b < cls[k - 1].e) { rv_set_error("graphalign returned overlapping intervals [%lld,%lld) / [%lld,%lld)", (long long)cls[k - 1].b, (long long)cls[k - 1].e, (long long)cls[k].b, (long long)cls[k].e); return -1; }
-    std::vector<sa_t> cb(cls.size()), ce(cls.size()), mb(mt.size()), me(mt.size());
-    std::vector<uint8_t> cc(cls.size());
-    std::vector<int64_t> mpre(mt.size() + 1, 0);
-    for (size_t k = 0; k < cls.size(); k++) { cb[k] = (sa_t)cls[k].b; ce[k] = (sa_t)cls[k].e; cc[k] = cls[k].c; }
-    for (size_t k = 0; k < mt.size(); k++) { mb[k] = (sa_t)mt[k].begin; me[k] = (sa_t)mt[k].end; mpre[k + 1] = mpre[k] + (mt[k].end - mt[k].begin); }
-
-    // ---- next level layout + child bookkeeping (reveal.c:1136-1207) -------------------
-    std::vector<RvSub> next;
-    std::vector<u32> child_base((size_t)ns * 3, 0), child_n((size_t)ns * 3, 0);
-    std::vector<int64_t> sub_start((size_t)ns + 1);
-    for (int s = 0; s < ns; s++) sub_start[(size_t)s] = a->subs[s].off;
-    sub_start[(size_t)ns] = a->m;
-    std::vector<int> cut_first((size_t)ns + 1, 0), mend_first((size_t)ns + 1, 0);
-    std::vector<sa_t> cut_lo, cut_hi, mend_pos;
-    std::vector<std::vector<RvBubbleDesc>> rounds;
+    // ---- per-sub tables, next level layout, child bookkeeping (reveal.c:1136-1207) ----------------
+    a->cb.clear(); a->ce.clear(); a->cc.clear(); a->mb.clear(); a->me.clear(); a->mpre.assign(1, 0);
+    a->ctab_first.assign((size_t)ns + 1, 0); a->mtab_first.assign((size_t)ns + 1, 0);
+    a->cut_first.assign((size_t)ns + 1, 0); a->mend_first.assign((size_t)ns + 1, 0);
+    a->cut_lo.clear(); a->cut_hi.clear(); a->mend_pos.clear(); a->split_subs.clear();
+    a->child_base.assign((size_t)ns * 3, 0); a->child_n.assign((size_t)ns * 3, 0);
+    a->sub_start.resize((size_t)ns + 1);
+    for (auto &r : a->rounds) r.clear();
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
-    {
-        size_t si = 0;
-        for (int s = 0; s < ns; s++) {
-            cut_first[(size_t)s] = (int)cut_lo.size();
-            mend_first[(size_t)s] = (int)mend_pos.size();
-            if (si >= split_subs.size() || split_subs[si] != s) continue;
-            si++;
-            RvSub &x = a->subs[s];
-            for (int64_t p : x.sp) mend_pos.push_back((sa_t)(p + (int64_t)x.l));
-            auto isort = [](std::vector<RvIntv> &v) { std::sort(v.begin(), v.end(), [](const RvIntv &p, const RvIntv &r) { return p.begin < r.begin; }); };
-            std::vector<RvIntv> *lists[3] = {&x.lead, &x.trail, &x.rest};
-            int64_t lead_off = 0, lead_n = 0;
-            for (int c = 0; c < 3; c++) {
-                int64_t cn = 0;
-                for (auto &iv : *lists[c]) cn += iv.end - iv.begin;
-                child_base[(size_t)s * 3 + c] = (u32)running;
-                child_n[(size_t)s * 3 + c] = (u32)cn;
-                if (c == 0) { lead_off = running; lead_n = cn; }
-                if (cn > 0) {
-                    RvSub ch;
-                    ch.off = running; ch.n = cn; ch.depth = x.depth + 1; ch.parent = s; ch.kind = c + 1;
-                    ch.nodes = *lists[c];
-                    ch.nsamples = count_samples(h, ch.nodes);
-                    isort(ch.nodes);
-                    if (children) children[3 * s + c] = (int32_t)next.size();
-                    next.push_back(std::move(ch));
-                    running += cn;
-                }
-            }
-            // windows in front of this sub's cuts, in the order graphalign listed the matched intervals
-            if (lead_n > 0) {
-                for (size_t r = 0; r < x.match.size(); r++) {
-                    const int64_t B = x.match[r].begin;
-                    int64_t lo = B;
-                    for (auto &iv : x.lead) if (iv.end == B && iv.begin < B) { lo = std::max(iv.begin, B - lcap); break; }
-                    cut_lo.push_back((sa_t)lo); cut_hi.push_back((sa_t)B);
-                }
-                const int c0 = cut_first[(size_t)s], c1 = (int)cut_lo.size();
-                for (size_t r = 0; r < x.match.size(); r++) {
-                    const int64_t B = x.match[r].begin, lo = (int64_t)cut_lo[(size_t)c0 + r];
-                    if (lo >= B) continue;
-                    if (rounds.size() <= r) rounds.resize(r + 1);
-                    RvBubbleDesc d; d.off = lead_off; d.n = lead_n; d.B = B; d.wlo = lo; d.cut0 = c0; d.cut1 = c1;
-                    rounds[r].push_back(d);
-                }
+    struct Ent { int64_t b, e; uint8_t c; };
+    std::vector<Ent> ent;
+    for (int s = 0; s < ns; s++) {
+        a->sub_start[(size_t)s] = lv.off[(size_t)s];
+        a->ctab_first[(size_t)s] = (int)a->cb.size(); a->mtab_first[(size_t)s] = (int)a->mb.size();
+        a->cut_first[(size_t)s] = (int)a->cut_lo.size(); a->mend_first[(size_t)s] = (int)a->mend_pos.size();
+        const int d = dc.of_sub[(size_t)s];
+        if (d < 0) continue;
+        a->split_subs.push_back(s);
+        const u32 l = dc.l[(size_t)d];
+        const RvIntv *lists[3] = {dc.lead.data() + dc.lead_first[(size_t)d], dc.trail.data() + dc.trail_first[(size_t)d], dc.rest.data() + dc.rest_first[(size_t)d]};
+        const size_t cnts[3] = {(size_t)(dc.lead_first[(size_t)d + 1] - dc.lead_first[(size_t)d]), (size_t)(dc.trail_first[(size_t)d + 1] - dc.trail_first[(size_t)d]),
+                                (size_t)(dc.rest_first[(size_t)d + 1] - dc.rest_first[(size_t)d])};
+        // class table of this sub: lead/trail/rest merged by begin
+        ent.clear();
+        static const uint8_t cls_of[3] = {1, 2, 4};
+        for (int c = 0; c < 3; c++) for (size_t k = 0; k < cnts[c]; k++) if (lists[c][k].end > lists[c][k].begin) ent.push_back({lists[c][k].begin, lists[c][k].end, cls_of[c]});
+        if (!std::is_sorted(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; }))
+            std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; });
+        for (size_t k = 0; k < ent.size(); k++) {
+            if (k && ent[k].b < ent[k - 1].e) { rv_set_error("graphalign returned overlapping intervals [%lld,%lld) / [%lld,%lld)", (long long)ent[k - 1].b, (long long)ent[k - 1].e, (long long)ent[k].b, (long long)ent[k].e); return -1; }
+            a->cb.push_back((sa_t)ent[k].b); a->ce.push_back((sa_t)ent[k].e); a->cc.push_back(ent[k].c);
+        }
+        for (int64_t k = dc.sp_first[(size_t)d]; k < dc.sp_first[(size_t)d + 1]; k++) {       // sorted
+            const int64_t p = dc.sp[(size_t)k];
+            if (l) { a->mb.push_back((sa_t)p); a->me.push_back((sa_t)(p + l)); a->mpre.push_back(a->mpre.back() + l); }
+            a->mend_pos.push_back((sa_t)(p + (int64_t)l));
+        }
+        // children
+        int64_t lead_off = 0, lead_n = 0;
+        for (int c = 0; c < 3; c++) {
+            int64_t cn = 0;
+            for (size_t k = 0; k < cnts[c]; k++) cn += lists[c][k].end - lists[c][k].begin;
+            a->child_base[(size_t)s * 3 + c] = (u32)running;
+            a->child_n[(size_t)s * 3 + c] = (u32)cn;
+            if (c == 0) { lead_off = running; lead_n = cn; }
+            if (cn > 0) {
+                if (children) children[3 * s + c] = nx.size();
+                nx.off.push_back(running); nx.n.push_back(cn); nx.depth.push_back(lv.depth[(size_t)s] + 1);
+                nx.nsamples.push_back(count_samples(h, lists[c], cnts[c]));
+                nx.parent.push_back(s); nx.kind.push_back(c + 1);
+                nx.nodes.insert(nx.nodes.end(), lists[c], lists[c] + cnts[c]);
+                nx.node_first.push_back((int64_t)nx.nodes.size());
+                running += cn;
             }
         }
-        cut_first[(size_t)ns] = (int)cut_lo.size();
-        mend_first[(size_t)ns] = (int)mend_pos.size();
+        // windows in front of this sub's cuts, in the order graphalign listed the matched intervals
+        if (lead_n > 0) {
+            const int64_t m0 = dc.match_first[(size_t)d], m1 = dc.match_first[(size_t)d + 1];
+            const int c0 = (int)a->cut_lo.size();
+            for (int64_t r = m0; r < m1; r++) {
+                const int64_t B = dc.match[(size_t)r].begin;
+                int64_t lo = B;
+                for (size_t k = 0; k < cnts[0]; k++) if (lists[0][k].end == B && lists[0][k].begin < B) { lo = std::max(lists[0][k].begin, B - lcap); break; }
+                a->cut_lo.push_back((sa_t)lo); a->cut_hi.push_back((sa_t)B);
+            }
+            const int c1 = (int)a->cut_lo.size();
+            for (int64_t r = m0; r < m1; r++) {
+                const int64_t B = dc.match[(size_t)r].begin, lo = (int64_t)a->cut_lo[(size_t)(c0 + (r - m0))];
+                if (lo >= B) continue;
+                if ((int64_t)a->rounds.size() <= r - m0) a->rounds.resize((size_t)(r - m0) + 1);
+                RvBubbleDesc bd; bd.off = lead_off; bd.n = lead_n; bd.B = B; bd.wlo = lo; bd.cut0 = c0; bd.cut1 = c1;
+                a->rounds[(size_t)(r - m0)].push_back(bd);
+            }
+        }
     }
+    a->sub_start[(size_t)ns] = lv.m;
+    a->ctab_first[(size_t)ns] = (int)a->cb.size(); a->mtab_first[(size_t)ns] = (int)a->mb.size();
+    a->cut_first[(size_t)ns] = (int)a->cut_lo.size(); a->mend_first[(size_t)ns] = (int)a->mend_pos.size();
+    nx.m = running;
     const int64_t m_next = running;
     if (m_next >= ((int64_t)1 << 32)) { rv_set_error("level larger than 2^32 ranks not supported yet"); return -1; }
-    std::vector<RvBubbleDesc> descs;
+    a->descs.clear();
     std::vector<int> round_first, round_small;
-    for (auto &r : rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups)
-        std::stable_partition(r.begin(), r.end(), [](const RvBubbleDesc &d) { return d.n <= RV_BUBBLE_BIG_N; });
+    for (auto &r : a->rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups)
+        if (r.empty()) { round_first.push_back((int)a->descs.size()); round_small.push_back(0); continue; }
+        std::stable_partition(r.begin(), r.end(), [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_BIG_N; });
         int nsmall = 0;
-        for (auto &d : r) nsmall += d.n <= RV_BUBBLE_BIG_N;
-        round_first.push_back((int)descs.size()); round_small.push_back(nsmall);
-        descs.insert(descs.end(), r.begin(), r.end());
+        for (auto &x : r) nsmall += x.n <= RV_BUBBLE_BIG_N;
+        round_first.push_back((int)a->descs.size()); round_small.push_back(nsmall);
+        a->descs.insert(a->descs.end(), r.begin(), r.end());
     }
-    round_first.push_back((int)descs.size());
-    std::vector<int64_t> woff(descs.size() + 1, 0);
-    for (size_t k = 0; k < descs.size(); k++) woff[k + 1] = woff[k] + (descs[k].B - descs[k].wlo);
+    round_first.push_back((int)a->descs.size());
+    a->woff.assign(a->descs.size() + 1, 0);
+    for (size_t k = 0; k < a->descs.size(); k++) a->woff[k + 1] = a->woff[k] + (a->descs[k].B - a->descs[k].wlo);
 
     // ---- one upload for all the tables ---------------------------------------------------
-    const int64_t ntiles = ceil_div(a->m, RV_SPLIT_TILE);
-    Packer pk;
-    const size_t o_cb = pk.addv(cb), o_ce = pk.addv(ce), o_cc = pk.addv(cc), o_mb = pk.addv(mb), o_me = pk.addv(me), o_mpre = pk.addv(mpre);
-    const size_t o_ss = pk.addv(sub_start), o_cbase = pk.addv(child_base), o_cn = pk.addv(child_n), o_cf = pk.addv(cut_first);
-    const size_t o_clo = pk.addv(cut_lo), o_chi = pk.addv(cut_hi), o_split = pk.addv(split_subs);
-    const size_t o_desc = pk.addv(descs), o_woff = pk.addv(woff), o_mf = pk.addv(mend_first), o_mp = pk.addv(mend_pos);
-    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(descs.size() * 4 + 4);
+    const int64_t ntiles = ceil_div(lv.m, RV_SPLIT_TILE);
+    Packer &pk = a->pk;
+    pk.clear();
+    const size_t o_cb = pk.addv(a->cb), o_ce = pk.addv(a->ce), o_cc = pk.addv(a->cc), o_mb = pk.addv(a->mb), o_me = pk.addv(a->me), o_mpre = pk.addv(a->mpre);
+    const size_t o_ctf = pk.addv(a->ctab_first), o_mtf = pk.addv(a->mtab_first);
+    const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
+    const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
+    const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
+    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4);
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
     uint8_t *tb = a->dTab.as<uint8_t>();
-    RV_TRY(a->dD.reserve((size_t)a->m + 64));
+    RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
-    RV_TRY(a->dList.reserve((size_t)woff.back() * 4 + 64));
+    RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));
     const int nxt = (a->level == 0) ? 0 : (a->cur ^ 1);
     RV_TRY(a->lvSA[nxt].reserve((size_t)(m_next + 64) * sizeof(sa_t)));
     RV_TRY(a->lvLCP[nxt].reserve((size_t)(m_next + 64) * sizeof(lcp_t)));
     RV_TRY(a->lvBWT[nxt].reserve((size_t)m_next + 64));
 
     RvLabelTabs lt;
-    lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc; lt.ncls = (int)cls.size();
-    lt.mbegin = (const sa_t *)(tb + o_mb); lt.mend = (const sa_t *)(tb + o_me); lt.nmatch = (int)mt.size();
-    int id = h->prof.begin(q, RV_K_LABEL, (double)a->m * (sizeof(sa_t) + 1));
-    RV_TRY(rv_label_launch(h->ws, cur_sa(h), a->m, lt, a->dD.as<uint8_t>()));
+    lt.sub_start = (const int64_t *)(tb + o_ss); lt.nsubs = ns;
+    lt.ctab_first = (const int *)(tb + o_ctf); lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc;
+    lt.mtab_first = (const int *)(tb + o_mtf); lt.mbegin = (const sa_t *)(tb + o_mb); lt.mend = (const sa_t *)(tb + o_me); lt.nmatch = (int)a->mb.size();
+    int id = h->prof.begin(q, RV_K_LABEL, (double)lv.m * (sizeof(sa_t) + 1));
+    RV_TRY(rv_label_launch(h->ws, cur_sa(h), lv.m, lt, a->dD.as<uint8_t>()));
     h->prof.end(q, id);
 
     RvSplitArgs sa;
@@ -418,32 +497,34 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.tile_cnt = tiles; sa.tile_has = tiles + 3 * ntiles; sa.tile_post = tiles + 6 * ntiles;
     sa.tile_G = tiles + 9 * ntiles; sa.tile_carry = tiles + 12 * ntiles;
     sa.total = (u32 *)(tb + o_total);
-    sa.sub_start = (const int64_t *)(tb + o_ss); sa.nsubs = ns;
+    sa.sub_start = lt.sub_start; sa.nsubs = ns;
     sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (u32 *)(tb + o_suboff);
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
     sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = (u32 *)(tb + o_err);
-    id = h->prof.begin(q, RV_K_SPLIT, (double)a->m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 1)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t)));
-    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), a->m, sa, (const int *)(tb + o_split), (int)split_subs.size()));
+    id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
+    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, sa, (const int *)(tb + o_split), (int)a->split_subs.size()));
     h->prof.end(q, id);
-    RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, mpre.back()));
+    RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
     const double t1 = now_s();
 
     // ---- bubble_sort rounds (reveal.c:1250-1252, :666-727) -----------------------------------
-    RvBubbleArgs ba;
-    ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
-    ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
-    RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
-    RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
-    ba.flag = a->dFlag.as<uint8_t>();
-    ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
-    id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
-    for (size_t r = 0; r + 1 < round_first.size(); r++) {
-        const int first = round_first[r], count = round_first[r + 1] - first;
-        RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], count - round_small[r], woff[(size_t)(first + count)] - woff[(size_t)first]));
+    if (!a->descs.empty()) {
+        RvBubbleArgs ba;
+        ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
+        ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
+        RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
+        RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
+        ba.flag = a->dFlag.as<uint8_t>();
+        ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
+        id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
+        for (size_t r = 0; r + 1 < round_first.size(); r++) {
+            const int first = round_first[r], count = round_first[r + 1] - first;
+            RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], count - round_small[r], a->woff[(size_t)(first + count)] - a->woff[(size_t)first]));
+        }
+        h->prof.end(q, id);
     }
-    h->prof.end(q, id);
     u32 err = 0;
     RV_HIP(hipMemcpyAsync(&err, tb + o_err, 4, hipMemcpyDeviceToHost, q));
     RV_HIP(hipStreamSynchronize(q));
@@ -452,8 +533,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
     a->level++;
     a->cur = nxt;
-    a->m = m_next;
-    a->subs = std::move(next);
+    std::swap(a->lv, a->nx);
+    a->dec.reset(a->lv.size());
     a->st.t_split += t1 - t0;
     a->st.t_bubble += now_s() - t1;
     return 0;
@@ -461,74 +542,91 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
 
 /* ---- the whole recursion with the built-in benchmark callbacks ------------------- */
 int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
-    const bool trace_on = h->al && h->al->trace_on;
     RV_TRY(rv_align_begin(h, minl, minn));
     Align *a = h->al;
-    a->trace_on = trace_on;
-    memset(&a->st, 0, sizeof a->st);
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
     std::vector<sa_t> hsa; std::vector<lcp_t> hlcp;
-    while (!a->subs.empty()) {
+    std::vector<int64_t> sp;
+    std::vector<RvIntv> lead, trail, match, rest;
+    std::vector<uint8_t> touched;
+    while (a->lv.size() > 0) {
         RV_TRY(rv_frontier_scan(h));
         const double t0 = now_s();
+        const Level &lv = a->lv;
         if (a->trace_on) {
-            hsa.resize((size_t)a->m); hlcp.resize((size_t)a->m);
-            RV_HIP(hipMemcpy(hsa.data(), cur_sa(h), (size_t)a->m * sizeof(sa_t), hipMemcpyDeviceToHost));
-            RV_HIP(hipMemcpy(hlcp.data(), cur_lcp(h), (size_t)a->m * sizeof(lcp_t), hipMemcpyDeviceToHost));
+            hsa.resize((size_t)lv.m); hlcp.resize((size_t)lv.m);
+            RV_HIP(hipMemcpy(hsa.data(), cur_sa(h), (size_t)lv.m * sizeof(sa_t), hipMemcpyDeviceToHost));
+            RV_HIP(hipMemcpy(hlcp.data(), cur_lcp(h), (size_t)lv.m * sizeof(lcp_t), hipMemcpyDeviceToHost));
         }
         a->st.levels++;
-        for (size_t s = 0; s < a->subs.size(); s++) {
-            RvSub &x = a->subs[s];
+        const int ns = lv.size();
+        for (int s = 0; s < ns; s++) {
             a->st.steps++;
-            if (x.depth > a->st.maxdepth) a->st.maxdepth = x.depth;
+            if (lv.depth[(size_t)s] > a->st.maxdepth) a->st.maxdepth = lv.depth[(size_t)s];
+            const RvIntv *nodes = lv.nodes.data() + lv.node_first[(size_t)s];
+            const size_t nn = (size_t)(lv.node_first[(size_t)s + 1] - lv.node_first[(size_t)s]);
+            const int64_t first = a->mum_first[(size_t)s], cnt = a->nmums[(size_t)s];
             rv_trace tr;
             if (a->trace_on) {
                 memset(&tr, 0, sizeof tr);
-                tr.key = x.nodes.empty() ? -1 : x.nodes[0].begin;
-                tr.n = x.n; tr.depth = x.depth; tr.nsamples = x.nsamples; tr.nnodes = (int32_t)x.nodes.size(); tr.nmums = x.nmums;
+                tr.key = nn ? nodes[0].begin : -1;
+                tr.n = lv.n[(size_t)s]; tr.depth = lv.depth[(size_t)s]; tr.nsamples = lv.nsamples[(size_t)s]; tr.nnodes = (int32_t)nn; tr.nmums = cnt;
                 u64 h1 = 0, h2 = 0, h3 = 0, c3 = 0;
-                for (int64_t i = 0; i < x.n; i++) { h1 = hash_step(h1, (u64)i, (int64_t)hsa[(size_t)(x.off + i)]); h2 = hash_step(h2, (u64)i, (int64_t)hlcp[(size_t)(x.off + i)]); }
-                for (int64_t k = x.mum_first; k < x.mum_first + x.nmums; k++) {
-                    h3 = hash_step(h3, c3++, (int64_t)a->ml[(size_t)k]); h3 = hash_step(h3, c3++, a->mn[(size_t)k]);
-                    for (int64_t qq = a->moff[(size_t)k]; qq < a->moff[(size_t)k + 1]; qq++) { h3 = hash_step(h3, c3++, a->mso[(size_t)qq]); h3 = hash_step(h3, c3++, a->mpos[(size_t)qq]); }
+                for (int64_t i = 0; i < lv.n[(size_t)s]; i++) { h1 = hash_step(h1, (u64)i, (int64_t)hsa[(size_t)(lv.off[(size_t)s] + i)]); h2 = hash_step(h2, (u64)i, (int64_t)hlcp[(size_t)(lv.off[(size_t)s] + i)]); }
+                for (int64_t k = first; k < first + cnt; k++) {
+                    if (!a->multi) {
+                        const RvPairRec &r = a->recs[(size_t)k];
+                        const int64_t seq[6] = {(int64_t)r.l, 2, 0, (int64_t)r.a, 1, (int64_t)r.b};
+                        for (int z = 0; z < 6; z++) h3 = hash_step(h3, c3++, seq[z]);
+                    } else {
+                        h3 = hash_step(h3, c3++, (int64_t)a->ml[(size_t)k]); h3 = hash_step(h3, c3++, a->mn[(size_t)k]);
+                        for (int64_t qq = a->moff[(size_t)k]; qq < a->moff[(size_t)k + 1]; qq++) { h3 = hash_step(h3, c3++, a->mso[(size_t)qq]); h3 = hash_step(h3, c3++, a->mpos[(size_t)qq]); }
+                    }
                 }
                 tr.h_sa = h1; tr.h_lcp = h2; tr.h_mums = h3;
             }
             // picker: longest match present in every sample of the sub-index, ties -> smallest minimum coordinate
             int64_t best = -1, bmin = 0; u32 bl = 0;
-            for (int64_t k = x.mum_first; k < x.mum_first + x.nmums; k++) {
-                if (a->mn[(size_t)k] != x.nsamples) continue;
-                int64_t mnp = a->mpos[(size_t)a->moff[(size_t)k]];
-                for (int64_t qq = a->moff[(size_t)k] + 1; qq < a->moff[(size_t)k + 1]; qq++) mnp = std::min(mnp, a->mpos[(size_t)qq]);
-                if (best < 0 || a->ml[(size_t)k] > bl || (a->ml[(size_t)k] == bl && mnp < bmin)) { best = k; bl = a->ml[(size_t)k]; bmin = mnp; }
+            const int want = lv.nsamples[(size_t)s];
+            if (!a->multi) {
+                if (want == 2)
+                    for (int64_t k = first; k < first + cnt; k++) {
+                        const RvPairRec &r = a->recs[(size_t)k];
+                        if (best < 0 || r.l > bl || (r.l == bl && (int64_t)r.a < bmin)) { best = k; bl = r.l; bmin = (int64_t)r.a; }
+                    }
+            } else {
+                for (int64_t k = first; k < first + cnt; k++) {
+                    if (a->mn[(size_t)k] != want) continue;
+                    int64_t mnp = a->mpos[(size_t)a->moff[(size_t)k]];
+                    for (int64_t qq = a->moff[(size_t)k] + 1; qq < a->moff[(size_t)k + 1]; qq++) mnp = std::min(mnp, a->mpos[(size_t)qq]);
+                    if (best < 0 || a->ml[(size_t)k] > bl || (a->ml[(size_t)k] == bl && mnp < bmin)) { best = k; bl = a->ml[(size_t)k]; bmin = mnp; }
+                }
             }
             if (best >= 0) {
                 // graphalign, linear interval model
-                const int64_t q0 = a->moff[(size_t)best], q1 = a->moff[(size_t)best + 1];
-                const int nm = (int)(q1 - q0);
-                std::vector<int64_t> sp(a->mpos.begin() + q0, a->mpos.begin() + q1);
-                std::vector<int64_t> lead, trail, match, rest;
-                std::vector<uint8_t> touched(x.nodes.size(), 0);
+                sp.clear(); lead.clear(); trail.clear(); match.clear(); rest.clear();
+                if (!a->multi) { sp.push_back((int64_t)a->recs[(size_t)best].a); sp.push_back((int64_t)a->recs[(size_t)best].b); }
+                else sp.assign(a->mpos.begin() + a->moff[(size_t)best], a->mpos.begin() + a->moff[(size_t)best + 1]);
                 std::sort(sp.begin(), sp.end());
-                for (int k = 0; k < nm; k++) {
-                    const int64_t p = sp[(size_t)k];
-                    size_t lo = 0, hi = x.nodes.size();
-                    while (lo < hi) { size_t mid = (lo + hi) / 2; if (x.nodes[mid].begin <= p) lo = mid + 1; else hi = mid; }
-                    if (lo == 0 || p >= x.nodes[lo - 1].end || p + (int64_t)bl > x.nodes[lo - 1].end) { rv_set_error("match at %lld is not inside an interval of its sub-index", (long long)p); return -1; }
-                    const RvIntv iv = x.nodes[lo - 1];
+                touched.assign(nn, 0);
+                for (int64_t p : sp) {
+                    size_t lo = 0, hi = nn;
+                    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (nodes[mid].begin <= p) lo = mid + 1; else hi = mid; }
+                    if (lo == 0 || p >= nodes[lo - 1].end || p + (int64_t)bl > nodes[lo - 1].end) { rv_set_error("match at %lld is not inside an interval of its sub-index", (long long)p); return -1; }
+                    const RvIntv iv = nodes[lo - 1];
                     touched[lo - 1] = 1;
-                    if (p > iv.begin) { lead.push_back(iv.begin); lead.push_back(p); }
-                    if (p + (int64_t)bl < iv.end) { trail.push_back(p + bl); trail.push_back(iv.end); }
-                    match.push_back(p); match.push_back(p + bl);
+                    if (p > iv.begin) lead.push_back({iv.begin, p});
+                    if (p + (int64_t)bl < iv.end) trail.push_back({p + (int64_t)bl, iv.end});
+                    match.push_back({p, p + (int64_t)bl});
                 }
-                for (size_t k = 0; k < x.nodes.size(); k++) if (!touched[k]) { rest.push_back(x.nodes[k].begin); rest.push_back(x.nodes[k].end); }
-                RV_TRY(rv_sub_split(h, (int)s, bl, nm, sp.data(), lead.data(), (int)lead.size() / 2, trail.data(), (int)trail.size() / 2,
-                                    match.data(), (int)match.size() / 2, rest.data(), (int)rest.size() / 2));
+                for (size_t k = 0; k < nn; k++) if (!touched[k]) rest.push_back(nodes[k]);
+                RV_TRY(add_decision(h, s, bl, sp.data(), (int)sp.size(), lead.data(), (int)lead.size(), trail.data(), (int)trail.size(),
+                                    match.data(), (int)match.size(), rest.data(), (int)rest.size()));
                 a->an_l.push_back(bl);
                 a->an_pos.insert(a->an_pos.end(), sp.begin(), sp.end());
                 a->an_off.push_back((int64_t)a->an_pos.size());
                 a->st.splits++; a->st.anchored_bp += bl;
-                if (a->trace_on) { tr.picked = 1; tr.l = bl; tr.mn = nm; tr.sp_min = sp[0]; }
+                if (a->trace_on) { tr.picked = 1; tr.l = bl; tr.mn = (int32_t)sp.size(); tr.sp_min = sp[0]; }
             }
             if (a->trace_on) a->trace.push_back(tr);
         }

@@ -157,7 +157,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     if (h->n == 0) { rv_set_error("No text to index."); return -1; }
     const int64_t n = h->n;
     if (cache == 1) RV_TRY(write_raw(".reveal.t", h->T.data(), (size_t)n));
-    rv_align_free(h);
+    if (h->al) (void)rv_align_end(h);        /* a new construct ends any recursion in flight; its device scratch is kept */
     h->nT = n;
     hipStream_t q = h->ws.stream;
     // working copy of the (HBM-resident) text: align() lower-cases it in place
@@ -267,7 +267,8 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 }  // extern "C"
 
 // ---------------------------------------------------------------------------
-// pair scan driver: launch, copy the tile table + records, merge in tile order
+// pair scan driver: scan kernel -> scan of the tile counts -> compaction ->
+// one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out) {
     out.clear();
@@ -275,35 +276,35 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     if (h->nsep.empty()) { rv_set_error("pairwise scan needs at least two samples"); return -1; }
     hipStream_t q = h->ws.stream;
     const int64_t ntile = ceil_div(m, RV_PAIR_TILE);
-    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &brec = h->ws.misc[3];
+    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &bslot = h->ws.misc[3], &bovf = h->ws.misc[4], &bout = h->ws.misc[5];
     RV_TRY(bcnt.reserve(64));
-    RV_TRY(btab.reserve((size_t)ntile * sizeof(uint2)));
-    size_t cap = brec.cap / sizeof(RvPairRec);
-    if (cap < 4096) { RV_TRY(brec.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, m / 64))); cap = brec.cap / sizeof(RvPairRec); }
-    std::vector<uint2> tab((size_t)ntile);
-    for (int attempt = 0; attempt < 2; attempt++) {
-        RV_HIP(hipMemsetAsync(bcnt.p, 0, 4, q));
+    RV_TRY(btab.reserve((size_t)(ntile + 1) * 3 * sizeof(u32)));
+    RV_TRY(bslot.reserve((size_t)ntile * RV_PAIR_SLOTS * sizeof(RvPairRec)));
+    if (bovf.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bovf.reserve(4096 * sizeof(RvPairRec)));
+    if (bout.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bout.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, m / 64)));
+    u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
+    for (int attempt = 0; attempt < 3; attempt++) {
+        const size_t ocap = bout.cap / sizeof(RvPairRec), vcap = bovf.cap / sizeof(RvPairRec);
+        RV_HIP(hipMemsetAsync(bcnt.p, 0, 8, q));
+        RV_HIP(hipMemsetAsync(tilecnt + ntile, 0, 4, q));
         int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
-        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, brec.as<RvPairRec>(), (u32)std::min<size_t>(cap, 0xffffffffu),
-                                   bcnt.as<u32>(), btab.as<uint2>()));
+        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
+                                   (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf));
         h->prof.end(q, id);
-        u32 total = 0;
-        RV_HIP(hipMemcpyAsync(&total, bcnt.p, 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(tab.data(), btab.p, (size_t)ntile * sizeof(uint2), hipMemcpyDeviceToHost, q));
+        RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
+        RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu)));
+        u32 total = 0, novf = 0;
+        RV_HIP(hipMemcpyAsync(&total, tileoff + ntile, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(&novf, bcnt.p, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
-        if (total <= cap) {
-            std::vector<RvPairRec> raw(total);
-            if (total) RV_HIP(hipMemcpy(raw.data(), brec.p, (size_t)total * sizeof(RvPairRec), hipMemcpyDeviceToHost));
+        if (total <= ocap && novf <= vcap) {
             out.resize(total);
-            size_t w = 0;
-            for (int64_t t = 0; t < ntile; t++) {
-                const uint2 e = tab[(size_t)t];
-                if (e.y) { memcpy(&out[w], &raw[e.x], (size_t)e.y * sizeof(RvPairRec)); w += e.y; }
-            }
+            if (total) RV_HIP(hipMemcpy(out.data(), bout.p, (size_t)total * sizeof(RvPairRec), hipMemcpyDeviceToHost));
             return 0;
         }
-        RV_TRY(brec.reserve((size_t)total * sizeof(RvPairRec)));    // retry with room for everything
-        cap = brec.cap / sizeof(RvPairRec);
+        if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
+        if (total > ocap) RV_TRY(bout.reserve((size_t)total * sizeof(RvPairRec)));
     }
     rv_set_error("pair scan: output buffer sizing failed");
     return -1;
@@ -320,7 +321,7 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     if (m <= 1) return 0;
     hipStream_t q = h->ws.stream;
     const int64_t ntile = ceil_div(m, RV_MULTI_TILE);
-    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &brec = h->ws.misc[5], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
+    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &brec = h->ws.misc[8], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
     RV_TRY(bcnt.reserve(64));
     RV_TRY(btab.reserve((size_t)ntile * sizeof(uint4)));
     if (brec.cap < 4096 * sizeof(RvMultiRec)) RV_TRY(brec.reserve(sizeof(RvMultiRec) * (size_t)std::max<int64_t>(4096, m / 32)));

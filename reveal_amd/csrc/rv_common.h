@@ -77,7 +77,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
-    DBuf misc[8];
+    DBuf misc[12];
     void release() {
         for (auto &b : scan_tmp) b.release();
         rs_hist.release();

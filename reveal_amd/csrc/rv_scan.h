@@ -12,11 +12,16 @@ struct RvPairRec {
     u32  rank;
 };
 
-// Streams SA/LCP[0..m) once.  Survivors of tile t (1024 ranks) are written in
-// rank order to out[tiletab[t].x .. +tiletab[t].y); tiles land in atomic
-// order, the host concatenates them in tile order.  *counter must be zeroed.
+#define RV_PAIR_SLOTS 32
+// Streams SA/LCP/BWT[0..m) once.  The first RV_PAIR_SLOTS survivors of tile t
+// (1024 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
+// ovf[tileovf[t] ..] (*ovf_counter zeroed by the caller); tilecnt[t] = number of
+// survivors.  rv_pair_compact_launch packs them densely in rank order given
+// tileoff = exclusive scan of tilecnt.
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
-                        RvPairRec *out, u32 out_cap, u32 *counter, uint2 *tiletab);
+                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf);
+int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap);
 
 #define RV_MULTI_TILE 256
 struct RvMultiRec { u32 l, n, ub, pad; };

@@ -11,8 +11,8 @@
 //
 // The pair scan is the roofline-judged kernel: a pure stream of 8 B per rank
 // (4 B SA + 4 B LCP, 16-byte loads per lane) plus 1 B of BWT for the
-// left-maximality test (no gathers from T), and an order-preserving
-// append (one atomic per 1024-rank tile, tile table merged on the host).
+// left-maximality test (no gathers from T).  Output is order preserving and
+// free of hot atomics: per-tile slots + a small compaction kernel.
 #include "rv_common.h"
 #include "rv_scan.h"
 
@@ -42,8 +42,8 @@ __device__ inline bool lcp_lt(lcp_t v, int minl) {
 
 __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
                                                   const uint8_t *__restrict__ BWT, sa_t nsep0, int minl,
-                                                  RvPairRec *__restrict__ out, u32 out_cap, u32 *__restrict__ counter,
-                                                  uint2 *__restrict__ tiletab) {
+                                                  RvPairRec *__restrict__ slots, RvPairRec *__restrict__ ovf, u32 ovf_cap,
+                                                  u32 *__restrict__ ovf_counter, u32 *__restrict__ tilecnt, u32 *__restrict__ tileovf) {
     __shared__ u32 wsum[TB / 64];
     __shared__ u32 s_base;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -111,30 +111,52 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     u32 before = 0, tot = 0;
 #pragma unroll
     for (int k = 0; k < TB / 64; k++) { const u32 c = wsum[k]; if (k < w) before += c; tot += c; }
+    // The first RV_PAIR_SLOTS survivors of a tile go to the tile's own slots (no
+    // atomics at all in the common case); only a tile with more takes one atomic
+    // for room in the overflow array.  k_pair_compact then packs everything in
+    // tile (= rank) order.
     if (threadIdx.x == 0) {
-        u32 base = tot ? atomicAdd(counter, tot) : 0u;
+        u32 base = 0;
+        if (tot > RV_PAIR_SLOTS) base = atomicAdd(ovf_counter, tot - RV_PAIR_SLOTS);
         s_base = base;
-        tiletab[blockIdx.x] = make_uint2(base, tot);
+        tilecnt[blockIdx.x] = tot;
+        tileovf[blockIdx.x] = base;
     }
     __syncthreads();
     if (mine) {
-        u32 q = s_base + before + (inc - mine);
+        u32 q = before + (inc - mine);          // index inside the tile
 #pragma unroll
         for (int k = 0; k < PAIR_ITEMS; k++) {
             if (hit & (1u << k)) {
-                if (q < out_cap) {
-                    const sa_t s1 = sa[k], s0 = (k == 0) ? psa : sa[k - 1];
-                    RvPairRec r;
-                    r.a = s1 < s0 ? s1 : s0;
-                    r.b = s1 < s0 ? s0 : s1;
-                    r.l = (u32)lc[k];
-                    r.rank = (u32)(i0 + k);
-                    out[q] = r;
-                }
+                const sa_t s1 = sa[k], s0 = (k == 0) ? psa : sa[k - 1];
+                RvPairRec r;
+                r.a = s1 < s0 ? s1 : s0;
+                r.b = s1 < s0 ? s0 : s1;
+                r.l = (u32)lc[k];
+                r.rank = (u32)(i0 + k);
+                if (q < RV_PAIR_SLOTS) slots[(size_t)blockIdx.x * RV_PAIR_SLOTS + q] = r;
+                else { const u32 o = s_base + (q - RV_PAIR_SLOTS); if (o < ovf_cap) ovf[o] = r; }
                 q++;
             }
         }
     }
+}
+
+// one thread per (tile, slot): dense, rank-ordered output
+__global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf,
+                                                     const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf,
+                                                     const u32 *__restrict__ tileoff, int64_t ntile, RvPairRec *__restrict__ out, u32 out_cap) {
+    const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int64_t t = id / RV_PAIR_SLOTS;
+    const u32 j = (u32)(id % RV_PAIR_SLOTS);
+    if (t >= ntile) return;
+    const u32 cnt = tilecnt[t];
+    if (j >= cnt) return;
+    const u32 o = tileoff[t];
+    if (o + j < out_cap) out[o + j] = slots[(size_t)t * RV_PAIR_SLOTS + j];
+    const u32 ob = tileovf[t];
+    for (u32 q = RV_PAIR_SLOTS + j; q < cnt; q += RV_PAIR_SLOTS)
+        if (o + q < out_cap) out[o + q] = ovf[ob + (q - RV_PAIR_SLOTS)];
 }
 
 // ---- multi-MUM scan ------------------------------------------------------------
@@ -258,10 +280,19 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 }
 
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
-                        RvPairRec *out, u32 out_cap, u32 *counter, uint2 *tiletab) {
+                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf) {
     if (m <= 0) return 0;
     const unsigned nb = (unsigned)ceil_div(m, PAIR_TILE);
-    hipLaunchKernelGGL(k_scan_pair, dim3(nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, out, out_cap, counter, tiletab);
+    hipLaunchKernelGGL(k_scan_pair, dim3(nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap) {
+    if (ntile <= 0) return 0;
+    hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB)), dim3(TB), 0, ws.stream, slots, ovf, tilecnt, tileovf,
+                       tileoff, ntile, out, out_cap);
     RV_LAUNCH_CHECK();
     return 0;
 }

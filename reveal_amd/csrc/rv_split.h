@@ -4,13 +4,18 @@
 
 #define RV_SPLIT_TILE 2048
 
-// sorted, non-overlapping interval tables of one level (device pointers)
+// per-sub-index interval tables of one level (device pointers): sub s owns
+// entries [ctab_first[s], ctab_first[s+1]) resp. [mtab_first[s], mtab_first[s+1]),
+// sorted by begin and non-overlapping inside a sub-index
 struct RvLabelTabs {
-    const sa_t    *cbegin, *cend;   // lead / trail / rest intervals of every split sub-index
+    const int64_t *sub_start;       // [nsubs+1], last = m
+    int            nsubs;
+    const int     *ctab_first;      // lead / trail / rest intervals
+    const sa_t    *cbegin, *cend;
     const uint8_t *ccls;            // 1 lead, 2 trail, 4 rest
-    int            ncls;
-    const sa_t    *mbegin, *mend;   // matched ranges [sp, sp+l)
-    int            nmatch;
+    const int     *mtab_first;      // matched ranges [sp, sp+l)
+    const sa_t    *mbegin, *mend;
+    int            nmatch;          // total number of matched ranges
 };
 
 struct RvSplitArgs {

@@ -36,18 +36,37 @@ __device__ inline int upper_idx(const P *__restrict__ begins, int n, P pos) {   
     return lo - 1;
 }
 
+// Each sub-index brings its own short, begin-sorted interval list (typically
+// <= 3 * nsamples entries), so a rank only searches the list of the sub-index
+// it belongs to: one binary search over the sub-index starts per thread, then
+// a few compares per rank.
+template <class P>
+__device__ inline int find_in(const P *__restrict__ begins, int first, int last, P pos) {   // last idx in [first,last) with begins[idx] <= pos, or -1
+    if (last - first <= 8) {
+        int e = -1;
+        for (int k = first; k < last; k++) if (begins[k] <= pos) e = k;
+        return e;
+    }
+    const int r = upper_idx<P>(begins + first, last - first, pos);
+    return r < 0 ? -1 : first + r;
+}
+
 __global__ __launch_bounds__(TB) void k_label(const sa_t *__restrict__ SA, int64_t m, RvLabelTabs t, uint8_t *__restrict__ D) {
     const int64_t i0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
     if (i0 >= m) return;
+    int s = upper_idx<int64_t>(t.sub_start, t.nsubs, i0);
+    int64_t s_end = t.sub_start[s + 1];
     uint8_t d[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint8_t c = 0;
-        if (i0 + k < m) {
-            const sa_t pos = SA[i0 + k];
-            int e = upper_idx<sa_t>(t.cbegin, t.ncls, pos);
+        const int64_t i = i0 + k;
+        if (i < m) {
+            while (i >= s_end) { s++; s_end = t.sub_start[s + 1]; }
+            const sa_t pos = SA[i];
+            int e = find_in<sa_t>(t.cbegin, t.ctab_first[s], t.ctab_first[s + 1], pos);
             if (e >= 0 && pos < t.cend[e]) c = t.ccls[e];
-            e = upper_idx<sa_t>(t.mbegin, t.nmatch, pos);
+            e = find_in<sa_t>(t.mbegin, t.mtab_first[s], t.mtab_first[s + 1], pos);
             if (e >= 0 && pos < t.mend[e]) c = 3;
         }
         d[k] = c;
@@ -143,36 +162,53 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
         est[c] = ms_combine(bm, xm);
     }
     if (j0 >= m) return;
-    // owning sub-index of my first rank, then walk
+    // owning sub-index of my first rank, then walk.  The sub-index' small tables
+    // (child offsets, first two cut windows / matched ends) are pulled into
+    // registers whenever the sub-index changes -- usually once per thread --
+    // instead of being re-read from global memory per rank.
     int s = upper_idx<int64_t>(a.sub_start, a.nsubs, j0);
     int64_t s_end = a.sub_start[s + 1];
     u32 run[3] = {est[0].val, est[1].val, est[2].val};
+    u32 cbase[3], coff[3];
+    int qc0 = 0, qc1 = 0, qm0 = 0, qm1 = 0;
+    sa_t clo[2] = {0, 0}, chi[2] = {0, 0}, mnd[2] = {-1, -1};
+    auto load_sub = [&](int ss) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { cbase[c] = a.child_base[(size_t)ss * 3 + c]; coff[c] = a.sub_off[(size_t)ss * 3 + c]; }
+        qc0 = a.cut_first[ss]; qc1 = a.cut_first[ss + 1]; qm0 = a.mend_first[ss]; qm1 = a.mend_first[ss + 1];
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            clo[k] = (qc0 + k < qc1) ? a.cut_lo[qc0 + k] : (sa_t)0;
+            chi[k] = (qc0 + k < qc1) ? a.cut_hi[qc0 + k] : (sa_t)0;
+            mnd[k] = (qm0 + k < qm1) ? a.mend_pos[qm0 + k] : (sa_t)-1;
+        }
+    };
+    load_sub(s);
 #pragma unroll
     for (int k = 0; k < SP_ITEMS; k++) {
         const int64_t j = j0 + k;
         if (j >= m) break;
-        while (j >= s_end) { s++; s_end = a.sub_start[s + 1]; }
+        if (j >= s_end) { do { s++; s_end = a.sub_start[s + 1]; } while (j >= s_end); load_sub(s); }
 #pragma unroll
         for (int c = 0; c < 3; c++) run[c] = run[c] < ev[k] ? run[c] : ev[k];
         const int c = cls_index(d[k + 1]);
         if (c >= 0) {
-            const u32 base = a.child_base[(size_t)s * 3 + c];
-            const u32 np = a.sub_off[(size_t)s * 3 + c] + ecnt[c];       // mod 2^32
-            const u32 idx = np - base;                                   // rank inside the child
+            const u32 np = coff[c] + ecnt[c];                            // mod 2^32
+            const u32 idx = np - cbase[c];                               // rank inside the child
             a.SA_out[np] = sa[k];
             a.LCP_out[np] = (lcp_t)(idx == 0 ? 0u : run[c]);
             uint8_t bo = bw[k];
             if (c == 1) {   // trailing child: the character in front of a suffix that starts right behind a
                             // matched range has just been lower-cased (reveal.c:1230-1234)
-                const int q0 = a.mend_first[s], q1 = a.mend_first[s + 1];
-                for (int q = q0; q < q1; q++)
-                    if (sa[k] == a.mend_pos[q]) { if (bo >= 'A' && bo <= 'Z') bo += 32; break; }
+                bool hit = (sa[k] == mnd[0]) || (sa[k] == mnd[1]);
+                for (int q = qm0 + 2; q < qm1 && !hit; q++) hit = sa[k] == a.mend_pos[q];
+                if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
             }
             a.BWT_out[np] = bo;
             if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
-                const int q0 = a.cut_first[s], q1 = a.cut_first[s + 1];
-                for (int q = q0; q < q1; q++)
-                    if (sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q]) { a.SAi[sa[k]] = (sa_t)idx; break; }
+                bool hit = (sa[k] >= clo[0] && sa[k] < chi[0]) || (sa[k] >= clo[1] && sa[k] < chi[1]);
+                for (int q = qc0 + 2; q < qc1 && !hit; q++) hit = sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q];
+                if (hit) a.SAi[sa[k]] = (sa_t)idx;
             }
             ecnt[c]++;
             run[c] = INF;
@@ -182,49 +218,61 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
 
 // exclusive scan over tiles of (count, min-state) for the three classes; one block.
 __global__ __launch_bounds__(TB) void k_tile_carry(RvSplitArgs a) {
-    __shared__ u32   s_c[TB / 64];
-    __shared__ MinSt s_m[TB / 64];
-    __shared__ u32   s_runc;
-    __shared__ MinSt s_runm;
+    __shared__ u32   s_c[TB / 64][3];
+    __shared__ MinSt s_m[TB / 64][3];
+    __shared__ u32   s_runc[3];
+    __shared__ MinSt s_runm[3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int c = 0; c < 3; c++) {
-        if (threadIdx.x == 0) { s_runc = 0; s_runm.has = 0; s_runm.val = INF; }
-        __syncthreads();
-        for (int64_t base = 0; base < a.ntiles; base += TB) {
-            const int64_t t = base + threadIdx.x;
-            u32 x = 0; MinSt mm = {0, INF};
-            if (t < a.ntiles) {
-                x = a.tile_cnt[(size_t)c * a.ntiles + t];
-                mm.has = a.tile_has[(size_t)c * a.ntiles + t];
-                mm.val = a.tile_post[(size_t)c * a.ntiles + t];
-            }
-            u32 ix = x; MinSt im = mm;
+    if (threadIdx.x < 3) { s_runc[threadIdx.x] = 0; s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
+    __syncthreads();
+    for (int64_t base = 0; base < a.ntiles; base += TB) {
+        const int64_t t = base + threadIdx.x;
+        u32 ix[3]; MinSt im[3];
 #pragma unroll
-            for (int dd = 1; dd < 64; dd <<= 1) {
-                const u32 tc = __shfl_up(ix, dd, 64);
-                MinSt tm; tm.has = __shfl_up(im.has, dd, 64); tm.val = __shfl_up(im.val, dd, 64);
-                if (lane >= dd) { ix += tc; im = ms_combine(tm, im); }
+        for (int c = 0; c < 3; c++) {
+            ix[c] = 0; im[c].has = 0; im[c].val = INF;
+            if (t < a.ntiles) {
+                ix[c] = a.tile_cnt[(size_t)c * a.ntiles + t];
+                im[c].has = a.tile_has[(size_t)c * a.ntiles + t];
+                im[c].val = a.tile_post[(size_t)c * a.ntiles + t];
             }
-            if (lane == 63) { s_c[w] = ix; s_m[w] = im; }
-            __syncthreads();
-            u32 bc = s_runc; MinSt bm = s_runm;
-            u32 totc = s_runc; MinSt totm = s_runm;
+        }
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const u32 tc = __shfl_up(ix[c], dd, 64);
+                MinSt tm; tm.has = __shfl_up(im[c].has, dd, 64); tm.val = __shfl_up(im[c].val, dd, 64);
+                if (lane >= dd) { ix[c] += tc; im[c] = ms_combine(tm, im[c]); }
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { s_c[w][c] = ix[c]; s_m[w][c] = im[c]; }
+        }
+        __syncthreads();
+        u32 totc[3]; MinSt totm[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u32 bc = s_runc[c]; MinSt bm = s_runm[c];
+            totc[c] = s_runc[c]; totm[c] = s_runm[c];
             for (int k = 0; k < TB / 64; k++) {
-                if (k < w) { bc += s_c[k]; bm = ms_combine(bm, s_m[k]); }
-                totc += s_c[k]; totm = ms_combine(totm, s_m[k]);
+                if (k < w) { bc += s_c[k][c]; bm = ms_combine(bm, s_m[k][c]); }
+                totc[c] += s_c[k][c]; totm[c] = ms_combine(totm[c], s_m[k][c]);
             }
-            u32 xc = __shfl_up(ix, 1, 64);
-            MinSt xm; xm.has = __shfl_up(im.has, 1, 64); xm.val = __shfl_up(im.val, 1, 64);
+            u32 xc = __shfl_up(ix[c], 1, 64);
+            MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
             if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
             if (t < a.ntiles) {
                 a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
                 a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
             }
-            __syncthreads();
-            if (threadIdx.x == 0) { s_runc = totc; s_runm = totm; }
-            __syncthreads();
         }
+        __syncthreads();
+        if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
+        __syncthreads();
     }
+    if (threadIdx.x < 3) a.total[threadIdx.x] = s_runc[threadIdx.x];
 }
 
 // one wave per sub-index with a split decision
@@ -253,15 +301,6 @@ __global__ __launch_bounds__(64) void k_seg_offsets(const uint8_t *__restrict__ 
         const int c = lane;
         a.sub_off[(size_t)s * 3 + c] = a.child_base[(size_t)s * 3 + c] - g[0][c];
         if (g[1][c] - g[0][c] != a.child_n[(size_t)s * 3 + c]) atomicOr(a.err, 1u);   // intervals do not cover what they claim
-    }
-}
-
-// totals per class (needed when a sub ends exactly at m on a tile boundary)
-__global__ void k_totals(RvSplitArgs a) {
-    const int c = threadIdx.x;
-    if (c < 3) {
-        const size_t last = (size_t)c * a.ntiles + (a.ntiles - 1);
-        a.total[c] = a.tile_G[last] + a.tile_cnt[last];
     }
 }
 
@@ -309,11 +348,37 @@ constexpr int BB_CAP = 4096;
 // One visit of the reference's inner loop body (reveal.c:686-721) for rank e of
 // the child, executed by the whole workgroup: thread 0 evaluates the two
 // conditions on the current values; a move (first branch) walks down from e in
-// chunks of NT*EL ranks, looking for its destination x (largest r <= e with
-// r == 0 or LCP[r] < t) and shifting [x, e-1] up by one as it goes.
-template <int NT, int EL>
-__device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &ds, sa_t *SA, lcp_t *LCP, uint8_t *BW, int64_t e,
-                                    int64_t *s_v, int *s_max) {
+// chunks, looking for its destination x (largest r <= e with r == 0 or
+// LCP[r] < t) and shifting [x, e-1] up by one as it goes.
+//
+// The child's cut windows (for the SAi upkeep of shifted suffixes) are staged
+// in LDS once per workgroup: reading them from global memory per shifted rank
+// put a dependent load chain on the critical path (measured: 2 ms for ten
+// moves in a 5 M-rank child).
+constexpr int BB_MAXCUT = 32;
+struct CutWin { sa_t lo[BB_MAXCUT], hi[BB_MAXCUT]; int n; };
+
+__device__ inline void sai_upkeep(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t pos, int64_t rank) {
+    for (int q = 0; q < cw.n; q++)
+        if (pos >= cw.lo[q] && pos < cw.hi[q]) { b.SAi[pos] = (sa_t)rank; return; }
+    for (int q = ds.cut0 + BB_MAXCUT; q < ds.cut1; q++)           // more windows than fit in LDS (many samples)
+        if (pos >= b.cut_lo[q] && pos < b.cut_hi[q]) { b.SAi[pos] = (sa_t)rank; return; }
+}
+
+// 16-byte accesses throughout (measured on MI355X: one workgroup shifts
+// ~2.7 G ranks/s with dword accesses but streams ~100 GB/s with dwordx4).
+// Ranks are handled in aligned groups of four: the search reads LCP[4g..4g+3],
+// the shift loads the sources [4g-1..4g+2] (one unaligned dwordx4 per array,
+// a dword of bytes for BWT) and stores the group aligned.  A chunk is NT*EG
+// groups, top-down; all of a chunk's sources are loaded before its first store.
+template <int NT, int EG>
+__device__ inline void bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW, int64_t e,
+                                        int64_t *s_v, int *s_max) {
+#ifdef RV_SA64
+    typedef longlong4 sa4_t;
+#else
+    typedef int4 sa4_t;
+#endif
     const int64_t n = ds.n, B = ds.B;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (threadIdx.x == 0) {
@@ -331,18 +396,39 @@ __device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &d
     if (s_v[0] == 1) {                                                               // reveal.c:686-709
         const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
         const uint8_t tB = (uint8_t)s_v[3];
-        int64_t hi = e, x = 0;
-        while (hi > 0) {
-            const int64_t lo = (hi - (int64_t)NT * EL + 1 > 1) ? hi - (int64_t)NT * EL + 1 : 1;
-            sa_t vs[EL]; lcp_t vl[EL]; uint8_t vb[EL];
-            int best = -1;                       // largest offset (idx - lo) in this chunk with LCP[idx] < t
+        // the arrays of a child start at an arbitrary rank of the level arrays: align groups on absolute addresses
+        const int64_t skew = (int64_t)((reinterpret_cast<uintptr_t>(LCP) >> 2) & 3);     // LCP + (4g - skew) is 16-byte aligned
+        int64_t x = 0;
+        int64_t gtop = (e + skew) >> 2;                  // group of rank r: (r + skew) >> 2, ranks 4g-skew .. 4g-skew+3
+        bool done = false;
+        while (!done) {
+            const int64_t gl = gtop - (int64_t)NT * EG + 1 > 0 ? gtop - (int64_t)NT * EG + 1 : 0;
+            sa4_t vs[EG]; int4 vl[EG]; u32 vb[EG];
+            int best = -1;                               // largest rank offset (r - rbase) in this chunk with LCP[r] < t
+            const int64_t rbase = 4 * gl - skew;         // lowest rank covered by the chunk (may be < 1)
 #pragma unroll
-            for (int k = 0; k < EL; k++) {
-                const int64_t idx = hi - (int64_t)k * NT - threadIdx.x;
-                if (idx >= lo) {
-                    const lcp_t here = LCP[idx];
-                    vs[k] = SA[idx - 1]; vl[k] = LCP[idx - 1]; vb[k] = BW[idx - 1];
-                    if ((int64_t)(u32)here < t && (int)(idx - lo) > best) best = (int)(idx - lo);
+            for (int k = 0; k < EG; k++) {
+                const int64_t g = gtop - (int64_t)k * NT - threadIdx.x;
+                if (g >= gl) {
+                    const int64_t r0 = 4 * g - skew;     // ranks r0..r0+3
+                    if (r0 >= 1 && r0 + 3 <= e) {
+                        const int4 here = *reinterpret_cast<const int4 *>(LCP + r0);
+                        __builtin_memcpy(&vs[k], SA + r0 - 1, sizeof(sa4_t));
+                        __builtin_memcpy(&vl[k], LCP + r0 - 1, 16);
+                        __builtin_memcpy(&vb[k], BW + r0 - 1, 4);
+                        const u32 hv[4] = {(u32)here.x, (u32)here.y, (u32)here.z, (u32)here.w};
+#pragma unroll
+                        for (int j = 3; j >= 0; j--) if ((int64_t)hv[j] < t) { const int o = (int)(r0 + j - rbase); best = o > best ? o : best; break; }
+                    } else {                             // ragged group at either end: element-wise
+                        sa_t *ps = reinterpret_cast<sa_t *>(&vs[k]); int *pl = reinterpret_cast<int *>(&vl[k]); uint8_t *pb = reinterpret_cast<uint8_t *>(&vb[k]);
+                        for (int j = 0; j < 4; j++) {
+                            const int64_t r = r0 + j;
+                            if (r >= 1 && r <= e) {
+                                ps[j] = SA[r - 1]; pl[j] = (int)LCP[r - 1]; pb[j] = BW[r - 1];
+                                if ((int64_t)(u32)LCP[r] < t) { const int o = (int)(r - rbase); best = o > best ? o : best; }
+                            }
+                        }
+                    }
                 }
             }
             for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_down(best, d, 64); best = o > best ? o : best; }
@@ -350,20 +436,38 @@ __device__ inline void bubble_visit(const RvBubbleArgs &b, const RvBubbleDesc &d
             __syncthreads();
             int mx = -1;
             for (int k = 0; k < NT / 64; k++) mx = s_max[k] > mx ? s_max[k] : mx;
-            const int64_t stop = (mx >= 0) ? lo + mx : lo - 1;      // ranks (stop, hi] move up by one
+            // ranks (stop, min(e, chunk top)] move up by one; rank 0 is a stop by definition
+            int64_t stop = (mx >= 0) ? rbase + mx : rbase - 1;
+            if (stop < 0) stop = 0;
+            if (mx >= 0 || rbase <= 1) done = true;
+            if (done && mx < 0) stop = 0;
 #pragma unroll
-            for (int k = 0; k < EL; k++) {
-                const int64_t idx = hi - (int64_t)k * NT - threadIdx.x;
-                if (idx >= lo && idx > stop) {
-                    SA[idx] = vs[k]; LCP[idx] = vl[k]; BW[idx] = vb[k];
-                    for (int q = ds.cut0; q < ds.cut1; q++)
-                        if (vs[k] >= b.cut_lo[q] && vs[k] < b.cut_hi[q]) { b.SAi[vs[k]] = (sa_t)idx; break; }
+            for (int k = 0; k < EG; k++) {
+                const int64_t g = gtop - (int64_t)k * NT - threadIdx.x;
+                if (g >= gl) {
+                    const int64_t r0 = 4 * g - skew;
+                    if (r0 > stop && r0 + 3 <= e) {
+                        *reinterpret_cast<sa4_t *>(SA + r0) = vs[k];
+                        *reinterpret_cast<int4 *>(LCP + r0) = vl[k];
+                        *reinterpret_cast<u32 *>(BW + r0) = vb[k];
+                        const sa_t *ps = reinterpret_cast<const sa_t *>(&vs[k]);
+                        for (int j = 0; j < 4; j++) sai_upkeep(b, ds, cw, ps[j], r0 + j);
+                    } else {
+                        const sa_t *ps = reinterpret_cast<const sa_t *>(&vs[k]); const int *pl = reinterpret_cast<const int *>(&vl[k]); const uint8_t *pb = reinterpret_cast<const uint8_t *>(&vb[k]);
+                        for (int j = 0; j < 4; j++) {
+                            const int64_t r = r0 + j;
+                            if (r > stop && r >= 1 && r <= e) {
+                                SA[r] = ps[j]; LCP[r] = (lcp_t)pl[j]; BW[r] = pb[j];
+                                sai_upkeep(b, ds, cw, ps[j], r);
+                            }
+                        }
+                    }
                 }
             }
             __threadfence_block();
             __syncthreads();
-            if (mx >= 0) { x = stop; break; }
-            hi = lo - 1;                                              // nothing below t in this chunk: keep going
+            if (done) x = stop;
+            gtop = gl - 1;
         }
         if (threadIdx.x == 0) {
             SA[x] = (sa_t)tS;
@@ -390,10 +494,16 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
     __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL
     __shared__ int s_max[NT / 64];
     __shared__ u32 s_w[NT / 64];
+    __shared__ CutWin cw;
     const int dd = first + blockIdx.x;
     const u32 cnt = b.cnt[dd];
     if (cnt == 0) return;
     const RvBubbleDesc ds = b.desc[dd];
+    {
+        const int nc = ds.cut1 - ds.cut0 < BB_MAXCUT ? ds.cut1 - ds.cut0 : BB_MAXCUT;
+        if ((int)threadIdx.x < nc) { cw.lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw.hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
+        if (threadIdx.x == 0) cw.n = nc;
+    }
     sa_t  *SA = b.SA + ds.off;
     lcp_t *LCP = b.LCP + ds.off;
     uint8_t *BW = b.BWT + ds.off;
@@ -417,7 +527,9 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
                 }
                 __syncthreads();
             }
-        for (u32 ai = 0; ai < cnt; ai++) bubble_visit<NT, EL>(b, ds, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
+        for (u32 ai = 0; ai < cnt; ai++) {
+            bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
+        }
         return;
     }
     constexpr int FL = BB_CAP / NT;     // flag bytes per thread and chunk
@@ -436,7 +548,9 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
         u32 q = before + inc - mine;
         for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
         __syncthreads();
-        for (u32 ai = 0; ai < tot; ai++) bubble_visit<NT, EL>(b, ds, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
+        for (u32 ai = 0; ai < tot; ai++) {
+            bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[ai], s_v, s_max);
+        }
         __syncthreads();
     }
 }
@@ -466,8 +580,6 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(TB), 0, ws.stream, a);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, ws.stream, a);
-    RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_seg_offsets, dim3((unsigned)nsplit), dim3(64), 0, ws.stream, D, m, a, d_split_subs, nsplit);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_split<true>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, BWT, m, a);
@@ -488,11 +600,11 @@ int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int 
     hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
     RV_LAUNCH_CHECK();
     if (count_small > 0) {
-        hipLaunchKernelGGL((k_bubble_apply<256, 4>), dim3((unsigned)count_small), dim3(256), 0, ws.stream, b, first);
+        hipLaunchKernelGGL((k_bubble_apply<256, 1>), dim3((unsigned)count_small), dim3(256), 0, ws.stream, b, first);
         RV_LAUNCH_CHECK();
     }
     if (count_big > 0) {
-        hipLaunchKernelGGL((k_bubble_apply<1024, 8>), dim3((unsigned)count_big), dim3(1024), 0, ws.stream, b, first + count_small);
+        hipLaunchKernelGGL((k_bubble_apply<1024, 4>), dim3((unsigned)count_big), dim3(1024), 0, ws.stream, b, first + count_small);
         RV_LAUNCH_CHECK();
     }
     return 0;

@@ -55,3 +55,35 @@ def feed(idx, inputs, toupper=True):
 
 def csr_tuples(l, n, off, so, pos):
     return [(int(l[k]), int(n[k]), tuple((int(so[q]), int(pos[q])) for q in range(off[k], off[k + 1]))) for k in range(len(l))]
+
+
+# ---- golden vectors produced by the reference itself (oracle/gen_golden.py) ----
+import hashlib   # noqa: E402
+import json      # noqa: E402
+
+M64 = (1 << 64) - 1
+
+
+def golden():
+    with open(os.path.join(GOLD, "vectors.json")) as f:
+        return json.load(f)["sets"]
+
+
+def golden_inputs(rec):
+    return [os.path.join(GOLD, x + ".fa.gz") if os.path.exists(os.path.join(GOLD, x + ".fa.gz")) else x for x in rec["inputs"]]
+
+
+def sha_arr(a):
+    return hashlib.sha256(np.ascontiguousarray(np.asarray(a).astype(np.int64)).tobytes()).hexdigest()
+
+
+def sha_json(obj):
+    return hashlib.sha256(json.dumps(obj).encode()).hexdigest()
+
+
+def trace_digests(tr):
+    """(sha_trace, sha_anchors, anchors, anchored_bp) of a structured trace array, as gen_golden.py computes them"""
+    key = sorted((int(r["depth"]), int(r["key"]), int(r["n"]), int(r["nsamples"]), int(r["nmums"]), int(r["picked"]), int(r["l"]),
+                  int(r["sp_min"]), int(r["h_sa"]) & M64, int(r["h_lcp"]) & M64, int(r["h_mums"]) & M64) for r in tr)
+    anchors = sorted((int(r["l"]), int(r["sp_min"]), int(r["mn"])) for r in tr if r["picked"])
+    return sha_json(key), sha_json(anchors), len(anchors), sum(a[0] for a in anchors)

@@ -1,0 +1,102 @@
+"""CPU suite: the oracle (oracle/reveal_oracle.c) against the golden vectors that
+oracle/gen_golden.py captured from the reference's own C (oracle/_ref), plus the
+known-answer vectors of SURVEY.md 8(c).  No GPU, no /root/reference needed."""
+import numpy as np
+import pytest
+
+from helpers import assemble, csr_tuples, golden, golden_inputs, oracle, sha_arr, sha_json, trace_digests
+
+SETS = golden()
+
+
+@pytest.mark.parametrize("label", sorted(SETS))
+def test_oracle_matches_reference_vectors(label):
+    g = SETS[label]
+    inputs = golden_inputs(g)
+    O = oracle(g["sa64"])
+    T, nsep, nodes = assemble(inputs)
+    assert len(T) == g["n"] and nsep == g["nsep"] and [list(x) for x in nodes] == g["nodes"]
+    c = O.construct(T, nsep, len(inputs))
+    assert sha_arr(c["SA"]) == g["sha_SA"]
+    assert sha_arr(c["LCP"]) == g["sha_LCP"]
+    assert int(c["LCP"].max()) == g["maxlcp"]
+    if "SA" in g:
+        assert [int(x) for x in c["SA"]] == g["SA"] and [int(x) for x in c["LCP"]] == g["LCP"]
+    l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, g["getmums"]["minl"])
+    mums = [[int(l[k]), [int(a[k]), int(b[k])], 0] for k in range(len(l))]
+    assert len(mums) == g["getmums"]["count"] and sha_json(mums) == g["getmums"]["sha"]
+    if "getmultimums" in g:
+        mm = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, len(inputs), g["minl"], g["minn"]))
+        assert len(mm) == g["getmultimums"]["count"] and sha_json(mm) == g["getmultimums"]["sha"]
+    r = O.align_bench(c, nodes, g["minl"], g["minn"], trace_cap=g["recursion"]["steps"] + 8)
+    st, sa_, na, bp = trace_digests(r["trace"])
+    rg = g["recursion"]
+    assert len(r["trace"]) == rg["steps"] and na == rg["anchors"] and bp == rg["anchored_bp"]
+    assert sa_ == rg["sha_anchors"] and st == rg["sha_trace"]
+    import hashlib
+    assert hashlib.sha256(r["T"]).hexdigest() == rg["sha_finalT"]
+    assert r["stats"]["maxdepth"] == rg["maxdepth"]
+
+
+@pytest.mark.parametrize("label", ["known2", "t1t2", "1a1b", "d1d2", "1a1b_64"])
+def test_own_suffix_sorter_matches_reference_sa(label):
+    """the oracle's own prefix-doubling sorter (used when oracle/_ref is absent) gives divsufsort's SA"""
+    g = SETS[label]
+    O = oracle(g["sa64"])
+    T, nsep, nodes = assemble(golden_inputs(g))
+    tb = O.textbuf(T)
+    SA = O.suffix_array(tb, own=True)
+    assert sha_arr(SA) == g["sha_SA"] and O.sufcheck(tb, SA) == 0
+
+
+def test_known_answer_vectors():
+    """captured from the reference on reveal/tests/test_reveal.py:37's input"""
+    O = oracle(False)
+    T, nsep, nodes = assemble(["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"])
+    assert T == b"ACTTGCTAGCTAGTCAG$ACTAGCTAGCTAGTGAG$" and nsep == [17] and nodes == [(0, 17), (18, 35)]
+    c = O.construct(T, nsep, 2)
+    assert list(c["SA"]) == [35, 17, 18, 0, 33, 15, 21, 7, 25, 11, 29, 14, 19, 5, 23, 9, 27, 1, 34, 16, 32, 4, 22, 8, 26, 12, 30, 20, 6, 24, 10, 28, 13, 31, 3, 2]
+    assert list(c["LCP"]) == [0, 0, 0, 3, 1, 2, 2, 6, 7, 2, 3, 0, 1, 8, 9, 4, 5, 2, 0, 1, 1, 1, 10, 5, 6, 1, 2, 0, 7, 8, 3, 4, 1, 1, 2, 1]
+    l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 1)
+    assert list(zip(l, a, b)) == [(3, 0, 18), (10, 4, 22), (2, 3, 31)]
+    T, nsep, nodes = assemble(["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"])
+    c = O.construct(T, nsep, 3)
+    assert len(T) == 54 and nsep == [17, 35]
+    mm = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, 3, 2, 2))
+    assert mm == [(9, 2, ((0, 0), (2, 36))), (3, 3, ((1, 18), (0, 0), (2, 36))), (10, 2, ((0, 4), (1, 22))),
+                  (7, 2, ((2, 46), (0, 10))), (4, 3, ((2, 46), (0, 10), (1, 28))), (2, 3, ((1, 31), (0, 3), (2, 39)))]
+    me = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, 3, 4, 3, mems=True))
+    assert me == [(5, 3, ((0, 4), (1, 22), (2, 40), (0, 8), (1, 26))), (4, 3, ((2, 46), (0, 10), (1, 28)))]
+
+
+def test_lcp_closed_form():
+    """LCP[k] = min(plain lcp with the predecessor, distance to the first '$'/'N') -- the form the HIP kernel uses"""
+    O = oracle(False)
+    T, nsep, nodes = assemble([SETS["d1d2"]["inputs"][0], SETS["d1d2"]["inputs"][1]] if False else golden_inputs(SETS["d1d2"]))
+    c = O.construct(T, nsep, 2)
+    SA, LCP = c["SA"], c["LCP"]
+    t = np.frombuffer(T, dtype=np.uint8)
+    stop = (t == ord("$")) | (t == ord("N"))
+    nxt = np.full(len(t) + 1, len(t), dtype=np.int64)
+    for i in range(len(t) - 1, -1, -1):
+        nxt[i] = i if stop[i] else nxt[i + 1]
+    rng = np.random.default_rng(1)
+    for k in rng.integers(1, len(SA), size=3000):
+        a, b = int(SA[k - 1]), int(SA[k])
+        h = 0
+        while a + h < len(t) and b + h < len(t) and t[a + h] == t[b + h]:
+            h += 1
+        assert LCP[k] == min(h, nxt[b] - b)
+
+
+def test_split_skips_min_update_for_unlabelled_ranks():
+    """reveal.c:616-620: a rank with D==0 `continue`s past the running-minimum update"""
+    O = oracle(False)
+    SA = np.array([10, 11, 12, 13, 14], dtype=np.int32)
+    LCP = np.array([0, 5, 1, 7, 6], dtype=np.int32)
+    D = np.array([1, 1, 0, 1, 1], dtype=np.uint8)       # rank 2 unlabelled
+    SAi = np.zeros(32, dtype=np.int32)
+    kids = O.split(SA, LCP, D, SAi, 4, 0, 0)
+    assert list(kids[0][0]) == [10, 11, 13, 14]
+    # LCP[3]=7 is never folded in (rank 2 skipped its update), LCP[2]=1 is
+    assert list(kids[0][1]) == [0, 5, 1, 6]

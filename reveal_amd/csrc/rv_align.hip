@@ -93,6 +93,7 @@ struct Align {
     Level lv, nx;                // current frontier / the one being built
     Decisions dec;
     bool scanned = false;
+    const u32 *d_err = nullptr;  // error word of the last commit, checked with the next scan's copy
     // scan result of the level: pair records in rank order, or CSR for the multi scan
     std::vector<RvPairRec> recs;
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
@@ -189,7 +190,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->trace_on = keep_trace;
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
-    a->level = 0; a->cur = 0; a->scanned = false;
+    a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr;
     memset(&a->st, 0, sizeof a->st);
     a->lv.clear();
     a->lv.m = h->n;
@@ -232,7 +233,10 @@ int rv_frontier_scan(rv_index *h) {
     const int ns = a->lv.size();
     a->mum_first.assign((size_t)ns, 0); a->nmums.assign((size_t)ns, 0);
     if (!a->multi) {
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs));
+        u32 err = 0;
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->d_err, &err));
+        a->d_err = nullptr;
+        if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
         int si = 0;
         for (size_t k = 0; k < a->recs.size(); k++) {
             const int64_t r = (int64_t)a->recs[k].rank;
@@ -449,13 +453,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const int64_t m_next = running;
     if (m_next >= ((int64_t)1 << 32)) { rv_set_error("level larger than 2^32 ranks not supported yet"); return -1; }
     a->descs.clear();
-    std::vector<int> round_first, round_small;
-    for (auto &r : a->rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups)
-        if (r.empty()) { round_first.push_back((int)a->descs.size()); round_small.push_back(0); continue; }
-        std::stable_partition(r.begin(), r.end(), [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_BIG_N; });
-        int nsmall = 0;
-        for (auto &x : r) nsmall += x.n <= RV_BUBBLE_BIG_N;
-        round_first.push_back((int)a->descs.size()); round_small.push_back(nsmall);
+    std::vector<int> round_first, round_small, round_big;
+    std::vector<int64_t> round_maxhuge;
+    for (auto &r : a->rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups), then the huge ones
+        round_first.push_back((int)a->descs.size());
+        auto cls = [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_BIG_N ? 0 : x.n <= RV_BUBBLE_HUGE_N ? 1 : 2; };
+        std::stable_sort(r.begin(), r.end(), [&](const RvBubbleDesc &x, const RvBubbleDesc &y) { return cls(x) < cls(y); });
+        int nsmall = 0, nbig = 0; int64_t mh = 0;
+        for (auto &x : r) { const int c = cls(x); nsmall += c == 0; nbig += c == 1; if (c == 2 && x.n > mh) mh = x.n; }
+        round_small.push_back(nsmall); round_big.push_back(nbig); round_maxhuge.push_back(mh);
         a->descs.insert(a->descs.end(), r.begin(), r.end());
     }
     round_first.push_back((int)a->descs.size());
@@ -472,6 +478,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
     const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4);
+    const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
     uint8_t *tb = a->dTab.as<uint8_t>();
@@ -518,17 +525,26 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
         ba.flag = a->dFlag.as<uint8_t>();
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
+        ba.state = (RvBubbleState *)(tb + o_bstate);
+        // the parent level is dead once split has run (at level 0 these are the main SA/LCP/BWT, which the
+        // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
+        ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
-            RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], count - round_small[r], a->woff[(size_t)(first + count)] - a->woff[(size_t)first]));
+            RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], round_big[r], count - round_small[r] - round_big[r], round_maxhuge[r],
+                                          a->woff[(size_t)(first + count)] - a->woff[(size_t)first]));
         }
         h->prof.end(q, id);
     }
-    u32 err = 0;
-    RV_HIP(hipMemcpyAsync(&err, tb + o_err, 4, hipMemcpyDeviceToHost, q));
-    RV_HIP(hipStreamSynchronize(q));
-    if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+    if (!a->multi && m_next > 1) {
+        a->d_err = (const u32 *)(tb + o_err);      // pair mode: the next scan's single copy brings the error word along
+    } else {
+        u32 err = 0;
+        RV_HIP(hipMemcpyAsync(&err, tb + o_err, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+    }
 
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
     a->level++;

@@ -58,6 +58,7 @@ void rv_free(rv_index *h) {
     h->prof.release();
     h->dT.release(); h->dT0.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dBWT.release(); h->dNsep.release();
     h->ws.release();
+    h->hscan.release();
     if (h->ws.stream) (void)hipStreamDestroy(h->ws.stream);
     delete h;
 }
@@ -270,9 +271,14 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 // pair scan driver: scan kernel -> scan of the tile counts -> compaction ->
 // one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
-int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out) {
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
+                     const u32 *d_err, u32 *err_out) {
     out.clear();
-    if (m <= 1) return 0;
+    if (err_out) *err_out = 0;
+    if (m <= 1) {
+        if (d_err && err_out) { RV_HIP(hipMemcpyAsync(err_out, d_err, 4, hipMemcpyDeviceToHost, h->ws.stream)); RV_HIP(hipStreamSynchronize(h->ws.stream)); }
+        return 0;
+    }
     if (h->nsep.empty()) { rv_set_error("pairwise scan needs at least two samples"); return -1; }
     hipStream_t q = h->ws.stream;
     const int64_t ntile = ceil_div(m, RV_PAIR_TILE);
@@ -284,7 +290,7 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     if (bout.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bout.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, m / 64)));
     u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
     for (int attempt = 0; attempt < 3; attempt++) {
-        const size_t ocap = bout.cap / sizeof(RvPairRec), vcap = bovf.cap / sizeof(RvPairRec);
+        const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
         RV_HIP(hipMemsetAsync(bcnt.p, 0, 8, q));
         RV_HIP(hipMemsetAsync(tilecnt + ntile, 0, 4, q));
         int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
@@ -293,18 +299,26 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         h->prof.end(q, id);
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
-                                      (u32)std::min<size_t>(ocap, 0xffffffffu)));
-        u32 total = 0, novf = 0;
-        RV_HIP(hipMemcpyAsync(&total, tileoff + ntile, 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(&novf, bcnt.p, 4, hipMemcpyDeviceToHost, q));
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err));
+        // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
+        size_t guess = std::min<size_t>(ocap, h->scan_guess);
+        RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));
+        RV_HIP(hipMemcpyAsync(h->hscan.p, bout.p, (guess + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
+        const u32 *hdr = h->hscan.as<u32>();
+        const u32 total = hdr[0], novf = hdr[1];
+        if (err_out) *err_out = hdr[2];
         if (total <= ocap && novf <= vcap) {
             out.resize(total);
-            if (total) RV_HIP(hipMemcpy(out.data(), bout.p, (size_t)total * sizeof(RvPairRec), hipMemcpyDeviceToHost));
+            const RvPairRec *src = h->hscan.as<RvPairRec>() + RV_PAIR_HDR;
+            const size_t have = std::min<size_t>(total, guess);
+            if (have) memcpy(out.data(), src, have * sizeof(RvPairRec));
+            if (total > have) RV_HIP(hipMemcpy(out.data() + have, bout.as<RvPairRec>() + RV_PAIR_HDR + have, (total - have) * sizeof(RvPairRec), hipMemcpyDeviceToHost));
+            h->scan_guess = (size_t)total + total / 16 + 64;
             return 0;
         }
         if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
-        if (total > ocap) RV_TRY(bout.reserve((size_t)total * sizeof(RvPairRec)));
+        if (total > ocap) RV_TRY(bout.reserve(((size_t)total + RV_PAIR_HDR) * sizeof(RvPairRec)));
     }
     rv_set_error("pair scan: output buffer sizing failed");
     return -1;
@@ -396,7 +410,7 @@ int64_t rv_getmums(rv_index *h, int minl) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     (void)hipSetDevice(h->device);
     std::vector<RvPairRec> recs;
-    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs) != 0) return -1;
+    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs, nullptr, nullptr) != 0) return -1;
     h->m_l.resize(recs.size()); h->m_a.resize(recs.size()); h->m_b.resize(recs.size());
     for (size_t k = 0; k < recs.size(); k++) {
         int64_t b = recs[k].b;

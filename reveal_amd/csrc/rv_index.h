@@ -72,6 +72,8 @@ struct rv_index {
     // ---- device state
     DBuf dT, dT0, dSA, dSAi, dLCP, dBWT, dNsep;   // dT0 = pristine text, dT = working copy (lower-cased by align)
     bool text_dirty = true;
+    HBuf hscan;                        // pinned staging for the scan records
+    size_t scan_guess = 4096;
     u32 maxlcp = 0;
     RvSaStats sa_stats{};
     // ---- scan results of the main index (getmums / getmultimums)
@@ -82,7 +84,9 @@ struct rv_index {
 };
 
 // scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)
-int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out);
+// d_err (optional): device word copied into the scan header and returned through err_out (deferred error check of the previous commit)
+int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
+                     const u32 *d_err, u32 *err_out);
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

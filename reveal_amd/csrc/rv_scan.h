@@ -2,7 +2,7 @@
 #pragma once
 #include "rv_common.h"
 
-#define RV_PAIR_TILE 1024
+#define RV_PAIR_TILE 2048
 
 // one pairwise MUM: a < b text positions, l = LCP[rank], rank inside the
 // scanned (concatenated) array
@@ -14,14 +14,16 @@ struct RvPairRec {
 
 #define RV_PAIR_SLOTS 32
 // Streams SA/LCP/BWT[0..m) once.  The first RV_PAIR_SLOTS survivors of tile t
-// (1024 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
+// (2048 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
 // ovf[tileovf[t] ..] (*ovf_counter zeroed by the caller); tilecnt[t] = number of
 // survivors.  rv_pair_compact_launch packs them densely in rank order given
 // tileoff = exclusive scan of tilecnt.
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
                         RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf);
+// out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records
+#define RV_PAIR_HDR 1
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap);
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, const u32 *ovf_counter, const u32 *err);
 
 #define RV_MULTI_TILE 256
 struct RvMultiRec { u32 l, n, ub, pad; };

@@ -51,12 +51,26 @@ struct RvBubbleDesc {
     int     cut0, cut1;  // this child's windows in cut_lo/cut_hi (for SAi upkeep)
 };
 
+// resume state of one (child, cut) when a long move is handed to the grid-wide kernels
+struct RvBubbleState {
+    int32_t next;        // next entry of the sorted active list to visit
+    int32_t pending;     // 1: a long move waits for k_long_scan_copy / k_long_copyback, then finalisation
+    int32_t sorted;      // the active list in global memory has been sorted
+    uint32_t tB;         // BWT byte of the moving suffix
+    int64_t e, tS, tL, t;
+    unsigned long long x;   // destination rank found by the grid search (atomicMax)
+};
+
 struct RvBubbleArgs {
     const RvBubbleDesc *desc;
     const int64_t      *woff;     // prefix sums of window widths over all descriptors (+1)
     u32                *cnt;      // per descriptor: number of active ranks found
     u32                *list;     // active ranks, descriptor d at [woff[d], ...)
     uint8_t            *flag;     // one byte per rank of the next level, zero between rounds
+    RvBubbleState      *state;    // per descriptor, zeroed per level
+    sa_t  *scrSA;                 // scratch for long moves: the (dead) parent-level arrays, indexed like the next level
+    lcp_t *scrLCP;
+    uint8_t *scrBWT;
     sa_t  *SA;
     lcp_t *LCP;
     uint8_t *BWT;
@@ -71,5 +85,11 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
 // descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
 #define RV_BUBBLE_BIG_N 16384
-int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int64_t total_window);
+// children above this size may hand moves longer than RV_BUBBLE_LONG_DIST ranks to grid-wide kernels
+#define RV_BUBBLE_HUGE_N 262144
+#define RV_BUBBLE_LONG_DIST 65536
+#define RV_BUBBLE_SLICE 32768
+// descriptors of a round are ordered small, big, huge; max_huge_n = largest huge child (0 if none)
+int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int count_huge, int64_t max_huge_n,
+                           int64_t total_window);
 int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi);

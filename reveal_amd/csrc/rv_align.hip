@@ -93,6 +93,7 @@ struct Align {
     Level lv, nx;                // current frontier / the one being built
     Decisions dec;
     bool scanned = false;
+    bool full_only = false;      // multi scan pre-selection (built-in picker, no trace)
     const u32 *d_err = nullptr;  // error word of the last commit, checked with the next scan's copy
     // scan result of the level: pair records in rank order, or CSR for the multi scan
     std::vector<RvPairRec> recs;
@@ -190,7 +191,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->trace_on = keep_trace;
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
-    a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr;
+    a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false;
     memset(&a->st, 0, sizeof a->st);
     a->lv.clear();
     a->lv.m = h->n;
@@ -220,7 +221,8 @@ int rv_set_trace(rv_index *h, int on) {
 
 int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn, int mems,
                       std::vector<u32> &l, std::vector<int32_t> &n, std::vector<int64_t> &off, std::vector<uint16_t> &so,
-                      std::vector<int64_t> &pos, std::vector<int64_t> *ub_out);
+                      std::vector<int64_t> &pos, std::vector<int64_t> *ub_out,
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs);
 
 extern "C" {
 
@@ -247,7 +249,19 @@ int rv_frontier_scan(rv_index *h) {
         }
     } else {
         std::vector<int64_t> ub;
-        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub));
+        const int64_t *d_ss = nullptr; const int *d_want = nullptr;
+        if (a->full_only) {       // built-in picker without tracing: let the scan keep only matches present in every sample of their sub-index
+            Packer &pk = a->pk;
+            pk.clear();
+            std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
+            const size_t o1 = pk.addv(ss), o2 = pk.addv(a->lv.nsamples);
+            DBuf &buf = h->ws.misc[10];
+            RV_TRY(buf.reserve(pk.buf.size() + 64));
+            RV_HIP(hipMemcpyAsync(buf.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, h->ws.stream));
+            d_ss = (const int64_t *)(buf.as<uint8_t>() + o1); d_want = (const int *)(buf.as<uint8_t>() + o2);
+        }
+        RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub,
+                                 d_ss, d_want, ns));
         int si = 0;
         for (size_t k = 0; k < a->ml.size(); k++) {
             while (si < ns && ub[k] >= a->lv.off[(size_t)si] + a->lv.n[(size_t)si]) si++;
@@ -560,6 +574,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
 int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     RV_TRY(rv_align_begin(h, minl, minn));
     Align *a = h->al;
+    a->full_only = !a->trace_on;
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
     std::vector<sa_t> hsa; std::vector<lcp_t> hlcp;
     std::vector<int64_t> sp;

@@ -327,7 +327,8 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
 // multi-MUM scan driver (same tile-ordered merge as the pair scan)
 int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn, int mems,
                       std::vector<u32> &l, std::vector<int32_t> &n, std::vector<int64_t> &off, std::vector<uint16_t> &so,
-                      std::vector<int64_t> &pos, std::vector<int64_t> *ub_out) {
+                      std::vector<int64_t> &pos, std::vector<int64_t> *ub_out,
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs) {
     l.clear(); n.clear(); off.assign(1, 0); so.clear(); pos.clear();
     if (ub_out) ub_out->clear();
     if (mems) { rv_set_error("getmultimems is not implemented on the GPU yet"); return -1; }
@@ -348,7 +349,7 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
         int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
         RV_TRY(rv_scan_multi_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), h->nsamples, minl, minn,
                                     brec.as<RvMultiRec>(), bso.as<uint16_t>(), bpos.as<sa_t>(), (u32)std::min<size_t>(rcap, 0xffffffffu),
-                                    (u32)std::min<size_t>(mcap, 0xffffffffu), bcnt.as<u32>(), btab.as<uint4>()));
+                                    (u32)std::min<size_t>(mcap, 0xffffffffu), bcnt.as<u32>(), btab.as<uint4>(), d_sub_start, d_sub_want, nsubs));
         h->prof.end(q, id);
         u32 tot[2] = {0, 0};
         RV_HIP(hipMemcpyAsync(tot, bcnt.p, 8, hipMemcpyDeviceToHost, q));
@@ -391,7 +392,7 @@ int64_t rv_getmultimums(rv_index *h, int minlength, int minn, int mems, int64_t 
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     if (h->nsamples <= 2) { rv_set_error("getmultimums needs more than two samples (SO not available)"); return -1; }
     (void)hipSetDevice(h->device);
-    if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr)) return -1;
+    if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr, nullptr, nullptr, 0)) return -1;
     if (members) *members = (int64_t)h->mm_pos.size();
     return (int64_t)h->mm_l.size();
 }

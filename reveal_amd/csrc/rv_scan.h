@@ -31,4 +31,5 @@ struct RvMultiRec { u32 l, n, ub, pad; };
 // tile t (256 ranks) land at rec[tab.x .. +tab.y) / so,pos[tab.z .. +tab.w) in
 // the reference's emission order; counters[0..1] must be zeroed.
 int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
-                         int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab);
+                         int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
+                         const int64_t *sub_start, const int *sub_want, int nsubs);   // sub_want != NULL: keep only matches with n == sub_want[sub of ub]

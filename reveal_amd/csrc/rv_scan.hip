@@ -220,7 +220,8 @@ __device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t
 template <bool EMIT>
 __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ BWT,
                                   const sa_t *__restrict__ nsep, int nsamples, int minl, int minn, int64_t u,
-                                  u32 &nrec, u32 &nmem, RvMultiRec *rec_out, uint16_t *so_out, sa_t *pos_out, u32 rec_cap, u32 mem_cap) {
+                                  u32 &nrec, u32 &nmem, RvMultiRec *rec_out, uint16_t *so_out, sa_t *pos_out, u32 rec_cap, u32 mem_cap,
+                                  const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs) {
     nrec = 0; nmem = 0;
     if (u < 1 || u >= m) return;
     const u32 lnext = (u + 1 < m) ? (u32)LCP[u + 1] : 0u;
@@ -236,7 +237,13 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
         if (lb < 0) break;                                   // cannot happen: LCP of a sub-index' first rank is 0
         const int64_t n = u - lb + 1;
         if (n > nsamples) break;                              // every further interval is larger still
-        if (n >= minn && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
+        bool take = n >= minn;
+        if (take && sub_want) {      // pre-selection for the built-in picker: only matches present in every sample of the sub-index
+            int lo2 = 0, hi2 = nsubs;
+            while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
+            take = n == sub_want[lo2 - 1];
+        }
+        if (take && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
             if (EMIT) {
                 if (rq < rec_cap) { RvMultiRec r; r.l = cur; r.n = (u32)n; r.ub = (u32)u; r.pad = 0; rec_out[rq] = r; }
                 for (int64_t j = lb; j <= u; j++, mq++)
@@ -255,13 +262,14 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
 __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
                                                    const uint8_t *__restrict__ BWT, const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
                                                    RvMultiRec *__restrict__ rec, uint16_t *__restrict__ so, sa_t *__restrict__ pos,
-                                                   u32 rec_cap, u32 mem_cap, u32 *__restrict__ counters, uint4 *__restrict__ tiletab) {
+                                                   u32 rec_cap, u32 mem_cap, u32 *__restrict__ counters, uint4 *__restrict__ tiletab,
+                                                   const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs) {
     __shared__ u32 ws_r[TB / 64], ws_m[TB / 64];
     __shared__ u32 s_rb, s_mb;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 nr, nm;
-    multi_walk<false>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0);
+    multi_walk<false>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0, sub_start, sub_want, nsubs);
     u32 ir = nr, im = nm;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { u32 a = __shfl_up(ir, d, 64), b = __shfl_up(im, d, 64); if (lane >= d) { ir += a; im += b; } }
@@ -281,17 +289,18 @@ __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, 
         const u32 r0 = s_rb + br + (ir - nr), m0 = s_mb + bm + (im - nm);
         u32 a2, b2;
         multi_walk<true>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, a2, b2, rec + r0, so + m0, pos + m0,
-                         r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u);
+                         r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u, sub_start, sub_want, nsubs);
     }
 }
 
 }  // namespace
 
 int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
-                         int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab) {
+                         int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
+                         const int64_t *sub_start, const int *sub_want, int nsubs) {
     if (m <= 0) return 0;
     hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
-                       rec, so, pos, rec_cap, mem_cap, counters, tiletab);
+                       rec, so, pos, rec_cap, mem_cap, counters, tiletab, sub_start, sub_want, nsubs);
     RV_LAUNCH_CHECK();
     return 0;
 }

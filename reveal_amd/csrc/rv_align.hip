@@ -111,6 +111,7 @@ struct Align {
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
+    std::vector<RvBubbleDesc> kids_small, kids_big;
     // results of rv_align_builtin
     std::vector<u32> an_l; std::vector<int64_t> an_off, an_pos;
     bool trace_on = false;
@@ -392,6 +393,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->child_base.assign((size_t)ns * 3, 0); a->child_n.assign((size_t)ns * 3, 0);
     a->sub_start.resize((size_t)ns + 1);
     for (auto &r : a->rounds) r.clear();
+    a->kids_small.clear(); a->kids_big.clear();
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
     struct Ent { int64_t b, e; uint8_t c; };
@@ -451,7 +453,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
                 a->cut_lo.push_back((sa_t)lo); a->cut_hi.push_back((sa_t)B);
             }
             const int c1 = (int)a->cut_lo.size();
-            for (int64_t r = m0; r < m1; r++) {
+            if (lead_n <= RV_BUBBLE_HUGE_N) {          // every cut of this child in one workgroup
+                bool any = false;
+                for (int q = c0; q < c1; q++) any = any || a->cut_lo[(size_t)q] < a->cut_hi[(size_t)q];
+                if (any) {
+                    RvBubbleDesc bd; bd.off = lead_off; bd.n = lead_n; bd.B = 0; bd.wlo = 0; bd.cut0 = c0; bd.cut1 = c1;
+                    (lead_n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
+                }
+            } else
+            for (int64_t r = m0; r < m1; r++) {        // huge child: one cut per round, long moves go to the grid kernels
                 const int64_t B = dc.match[(size_t)r].begin, lo = (int64_t)a->cut_lo[(size_t)(c0 + (r - m0))];
                 if (lo >= B) continue;
                 if ((int64_t)a->rounds.size() <= r - m0) a->rounds.resize((size_t)(r - m0) + 1);
@@ -491,6 +501,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
+    const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
     const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
@@ -531,7 +542,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const double t1 = now_s();
 
     // ---- bubble_sort rounds (reveal.c:1250-1252, :666-727) -----------------------------------
-    if (!a->descs.empty()) {
+    if (!a->descs.empty() || !a->kids_small.empty() || !a->kids_big.empty()) {
         RvBubbleArgs ba;
         ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
         ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
@@ -544,6 +555,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
+        RV_TRY(rv_bubble_children_launch(h->ws, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
             RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], round_big[r], count - round_small[r] - round_big[r], round_maxhuge[r],

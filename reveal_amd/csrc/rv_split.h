@@ -92,4 +92,6 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
 // descriptors of a round are ordered small, big, huge; max_huge_n = largest huge child (0 if none)
 int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int count_huge, int64_t max_huge_n,
                            int64_t total_window);
+// all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
+int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
 int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi);

@@ -700,6 +700,95 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
     if (threadIdx.x == 0) b.state[dd].next = 0x7fffffff;
 }
 
+// ---- all cuts of one leading child in one workgroup ---------------------------------------
+// For children up to RV_BUBBLE_HUGE_N ranks.  The workgroup walks the child's cuts in
+// graphalign's order; per cut it runs the window pass itself (the window is at most
+// max-LCP positions), sorts the actives and visits them.  Children advance through
+// their cuts independently of each other, instead of every round waiting for the
+// slowest child of the level.
+template <int NT, int EL>
+__global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc) {
+    __shared__ u32 lst[BB_CAP];
+    __shared__ int64_t s_v[4];
+    __shared__ int s_max[NT / 64];
+    __shared__ u32 s_w[NT / 64];
+    __shared__ CutWin cw;
+    __shared__ ParScratch ps;
+    __shared__ u32 s_first, s_cnt;
+    RvBubbleDesc ds = cdesc[blockIdx.x];
+    {
+        const int nc = ds.cut1 - ds.cut0 < BB_MAXCUT ? ds.cut1 - ds.cut0 : BB_MAXCUT;
+        if ((int)threadIdx.x < nc) { cw.lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw.hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
+        if (threadIdx.x == 0) cw.n = nc;
+    }
+    sa_t  *SA = b.SA + ds.off;
+    lcp_t *LCP = b.LCP + ds.off;
+    uint8_t *BW = b.BWT + ds.off;
+    uint8_t *flag = b.flag + ds.off;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = ds.cut0; q < ds.cut1; q++) {
+        const int64_t B = (int64_t)b.cut_hi[q], wlo = (int64_t)b.cut_lo[q];
+        if (wlo >= B) continue;                                   // uniform
+        ds.B = B;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
+        // window pass (same superset test as k_bubble_window)
+        for (int64_t p = wlo + threadIdx.x; p < B; p += NT) {
+            const int64_t e = (int64_t)b.SAi[p];
+            if (e < 0 || e >= ds.n) continue;
+            if ((int64_t)SA[e] != p) continue;
+            const int64_t lc = (int64_t)(u32)LCP[e];
+            const int64_t ln = (e + 1 < ds.n) ? (int64_t)(u32)LCP[e + 1] : 0;
+            if (p + lc > B || p + ln > B) {
+                const u32 k = atomicAdd(&s_cnt, 1u);
+                if (k < BB_CAP) lst[k] = (u32)e;
+                flag[e] = 1;
+            }
+        }
+        __syncthreads();
+        const u32 cnt = s_cnt;
+        if (cnt == 0) continue;
+        if (cnt <= BB_CAP) {
+            u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
+            for (u32 k = threadIdx.x; k < np2; k += NT) { if (k < cnt) flag[lst[k]] = 0; else lst[k] = 0xFFFFFFFFu; }
+            __syncthreads();
+            for (u32 size = 2; size <= np2; size <<= 1)
+                for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
+                    for (u32 k = threadIdx.x; k < np2 / 2; k += NT) {
+                        const u32 lo = (k / stride) * stride * 2 + (k % stride), hi = lo + stride;
+                        const bool up = ((lo & size) == 0);
+                        const u32 x = lst[lo], y = lst[hi];
+                        if ((x > y) == up) { lst[lo] = y; lst[hi] = x; }
+                    }
+                    __syncthreads();
+                }
+            (void)visit_list<NT, EL, false>(b, ds, cw, SA, LCP, BW, lst, 0, cnt, ps, s_v, s_max, &s_first, nullptr);
+        } else {
+            constexpr int FL = BB_CAP / NT;
+            for (int64_t base = 0; base < ds.n; base += BB_CAP) {
+                const int64_t r0 = base + (int64_t)threadIdx.x * FL;
+                u32 bits = 0;
+                for (int k = 0; k < FL; k++) if (r0 + k < ds.n && flag[r0 + k]) { bits |= 1u << k; flag[r0 + k] = 0; }
+                const u32 mine = __popc(bits);
+                u32 inc = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+                if (lane == 63) s_w[w] = inc;
+                __syncthreads();
+                u32 before = 0, tot = 0;
+                for (int k = 0; k < NT / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+                u32 qq = before + inc - mine;
+                for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[qq++] = (u32)(r0 + k);
+                __syncthreads();
+                (void)visit_list<NT, EL, false>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // ---- long moves: grid-wide search + copy-out, then copy-back shifted by one -------------------
 // blockIdx.x = slice of RV_BUBBLE_SLICE source ranks, blockIdx.y = huge descriptor.
 __global__ __launch_bounds__(TB) void k_long_scan_copy(RvBubbleArgs b, int first) {
@@ -849,6 +938,18 @@ int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int 
             RV_LAUNCH_CHECK();
         }
         hipLaunchKernelGGL((k_bubble_apply<1024, 4, false>), dim3((unsigned)count_huge), dim3(1024), 0, ws.stream, b, h0);   // whatever is left
+        RV_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig) {
+    if (nsmall > 0) {
+        hipLaunchKernelGGL((k_bubble_child<256, 1>), dim3((unsigned)nsmall), dim3(256), 0, ws.stream, b, d_small);
+        RV_LAUNCH_CHECK();
+    }
+    if (nbig > 0) {
+        hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3((unsigned)nbig), dim3(1024), 0, ws.stream, b, d_big);
         RV_LAUNCH_CHECK();
     }
     return 0;

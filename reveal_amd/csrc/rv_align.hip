@@ -15,6 +15,7 @@
 // sub-index.
 #include "rv_index.h"
 #include "rv_split.h"
+#include "rv_leaf.h"
 #include <string.h>
 #include <algorithm>
 #include <chrono>
@@ -101,6 +102,10 @@ struct Align {
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag;
+    DBuf dLeaf, dLeafRoots;      // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root table
+    size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
+    std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
+    std::vector<RvLeafRoot> leaf_roots;
     Packer pk;
     std::vector<int> stamp; int epoch = 0;        // count_samples scratch
     // reusable host tables of commit()
@@ -119,7 +124,7 @@ struct Align {
     rv_align_stats st{};
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dLeaf.release(); dLeafRoots.release();
     }
 };
 
@@ -592,7 +597,63 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     std::vector<int64_t> sp;
     std::vector<RvIntv> lead, trail, match, rest;
     std::vector<uint8_t> touched;
+    // ---- leaf kernel set-up (two samples only): sub-indices of at most RV_LEAF_N ranks finish on the GPU in one launch per level
+    const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
+    hipStream_t q = h->ws.stream;
+    u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
+    if (use_leaf) {
+        a->leaf_anchor_cap = (size_t)(h->nT / std::max(minl, 1)) + 1024;
+        a->leaf_trace_cap = a->trace_on ? 2 * a->leaf_anchor_cap + 1024 : 0;
+        const size_t bytes = 256 + a->leaf_anchor_cap * (4 + 8 + 8) + a->leaf_trace_cap * sizeof(rv_trace) + 64;
+        RV_TRY(a->dLeaf.reserve(bytes));
+        uint8_t *base = a->dLeaf.as<uint8_t>();
+        lf_counters = (u32 *)base;                          // [0] anchors, [1] trace records, [2] error bits
+        lf_stats = (unsigned long long *)(base + 64);
+        lf_a = (int64_t *)(base + 256); lf_b = lf_a + a->leaf_anchor_cap; lf_l = (u32 *)(lf_b + a->leaf_anchor_cap);
+        lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
+        RV_HIP(hipMemsetAsync(base, 0, 256, q));
+    }
     while (a->lv.size() > 0) {
+        if (use_leaf) {
+            const Level &lv0 = a->lv;
+            a->leaf_done.assign((size_t)lv0.size(), 0);
+            a->leaf_roots.clear();
+            for (int s = 0; s < lv0.size(); s++) {
+                if (lv0.n[(size_t)s] > RV_LEAF_N) continue;
+                const int64_t nf = lv0.node_first[(size_t)s], nn = lv0.node_first[(size_t)s + 1] - nf;
+                if (nn < 1 || nn > 2) continue;
+                RvLeafRoot r; r.off = lv0.off[(size_t)s]; r.n = (int32_t)lv0.n[(size_t)s]; r.depth = lv0.depth[(size_t)s];
+                r.a0 = r.a1 = r.b0 = r.b1 = 0;
+                bool ok = true;
+                for (int64_t k = 0; k < nn && ok; k++) {
+                    const RvIntv iv = lv0.nodes[(size_t)(nf + k)];
+                    if (iv.begin < h->nsep[0]) { if (r.a0 < r.a1) ok = false; r.a0 = iv.begin; r.a1 = iv.end; }
+                    else if (iv.begin > h->nsep[0]) { if (r.b0 < r.b1) ok = false; r.b0 = iv.begin; r.b1 = iv.end; }
+                    else ok = false;
+                }
+                if (!ok) continue;
+                a->leaf_done[(size_t)s] = 1;
+                a->leaf_roots.push_back(r);
+            }
+            if (!a->leaf_roots.empty()) {
+                RV_TRY(a->dLeafRoots.reserve(a->leaf_roots.size() * sizeof(RvLeafRoot)));
+                RV_HIP(hipMemcpyAsync(a->dLeafRoots.p, a->leaf_roots.data(), a->leaf_roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, q));
+                RvLeafArgs la;
+                la.roots = a->dLeafRoots.as<RvLeafRoot>();
+                la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
+                la.nsep0 = h->nsep[0]; la.minl = minl; la.lcap = h->maxlcp;
+                la.anchor_count = lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = lf_l; la.anchor_a = lf_a; la.anchor_b = lf_b;
+                la.stats = lf_stats;
+                la.trace = a->trace_on ? 1 : 0; la.trace_count = lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = lf_tr;
+                la.err = lf_counters + 2;
+                RV_TRY(rv_leaf_launch(h->ws, la, (int)a->leaf_roots.size()));
+                if ((size_t)lv0.size() == a->leaf_roots.size()) {       // nothing left for the level path
+                    a->st.levels++;
+                    a->lv.clear();
+                    break;
+                }
+            }
+        }
         RV_TRY(rv_frontier_scan(h));
         const double t0 = now_s();
         const Level &lv = a->lv;
@@ -604,6 +665,7 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         a->st.levels++;
         const int ns = lv.size();
         for (int s = 0; s < ns; s++) {
+            if (use_leaf && a->leaf_done[(size_t)s]) continue;         // finished (with its whole sub-tree) by the leaf kernel
             a->st.steps++;
             if (lv.depth[(size_t)s] > a->st.maxdepth) a->st.maxdepth = lv.depth[(size_t)s];
             const RvIntv *nodes = lv.nodes.data() + lv.node_first[(size_t)s];
@@ -675,6 +737,30 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         }
         a->st.t_host += now_s() - t0;
         RV_TRY(rv_frontier_commit(h, nullptr));
+    }
+    if (use_leaf) {       // collect what the leaf launches produced
+        u32 cnt[4]; unsigned long long stv[4];
+        RV_HIP(hipMemcpyAsync(cnt, lf_counters, sizeof cnt, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(stv, lf_stats, sizeof stv, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        if (cnt[2]) { rv_set_error("leaf kernel: recursion stack overflow"); return -1; }
+        if (cnt[0] > a->leaf_anchor_cap || cnt[1] > a->leaf_trace_cap) { rv_set_error("leaf kernel: output buffer too small"); return -1; }
+        std::vector<u32> ll(cnt[0]); std::vector<int64_t> la_(cnt[0]), lb_(cnt[0]);
+        if (cnt[0]) {
+            RV_HIP(hipMemcpy(ll.data(), lf_l, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
+            RV_HIP(hipMemcpy(la_.data(), lf_a, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
+            RV_HIP(hipMemcpy(lb_.data(), lf_b, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
+        }
+        for (u32 k = 0; k < cnt[0]; k++) {
+            a->an_l.push_back(ll[k]); a->an_pos.push_back(la_[k]); a->an_pos.push_back(lb_[k]); a->an_off.push_back((int64_t)a->an_pos.size());
+        }
+        if (a->trace_on && cnt[1]) {
+            const size_t at = a->trace.size();
+            a->trace.resize(at + cnt[1]);
+            RV_HIP(hipMemcpy(a->trace.data() + at, lf_tr, (size_t)cnt[1] * sizeof(rv_trace), hipMemcpyDeviceToHost));
+        }
+        a->st.steps += (int64_t)stv[0]; a->st.splits += (int64_t)stv[1]; a->st.anchored_bp += (int64_t)stv[2];
+        if ((int64_t)stv[3] > a->st.maxdepth) a->st.maxdepth = (int32_t)stv[3];
     }
     if (out) *out = a->st;
     return 0;

@@ -86,8 +86,8 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
 // descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
 #define RV_BUBBLE_BIG_N 16384
 // children above this size may hand moves longer than RV_BUBBLE_LONG_DIST ranks to grid-wide kernels
-#define RV_BUBBLE_HUGE_N 262144
-#define RV_BUBBLE_LONG_DIST 65536
+#define RV_BUBBLE_HUGE_N 2097152
+#define RV_BUBBLE_LONG_DIST 262144
 #define RV_BUBBLE_SLICE 32768
 // descriptors of a round are ordered small, big, huge; max_huge_n = largest huge child (0 if none)
 int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int count_huge, int64_t max_huge_n,

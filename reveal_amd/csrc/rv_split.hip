@@ -566,6 +566,60 @@ __device__ inline void par_execute(const RvBubbleArgs &b, const RvBubbleDesc &ds
     }
 }
 
+// Few actives: one wave per active.  The 64 lanes search the destination 64 ranks
+// at a time (up to BB_WSCAN ranks) and, if the ranges of the batch are disjoint,
+// shift their own range 64 ranks per step -- no workgroup barrier inside a move.
+constexpr int BB_WSCAN = 2048;
+
+// classify active a (one wave): kind 0 none / 1 move to lo / 2 truncate / 3 long
+__device__ inline void wave_classify(const RvBubbleDesc &ds, const sa_t *SA, const lcp_t *LCP, int64_t e, u32 *lo_out, uint8_t *kind_out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = ds.n, B = ds.B;
+    const int64_t sa = (int64_t)SA[e], lc = (int64_t)(u32)LCP[e];
+    int kind = 0; int64_t lo = e;
+    if (sa < B && sa + lc > B) {
+        const int64_t t = B - sa;
+        kind = 3; lo = e > BB_WSCAN ? e - BB_WSCAN : 0;
+        for (int64_t top = e - 1; top >= 0 && top >= e - BB_WSCAN; top -= 64) {      // ranks top, top-1, ... top-63
+            const int64_t r = top - lane;
+            const bool hit = r >= 0 && (r == 0 || (int64_t)(u32)LCP[r] < t);
+            const u64 bal = __ballot(hit);
+            if (bal) { kind = 1; lo = top - (int64_t)__builtin_ctzll(bal); break; }     // lowest lane = largest rank
+        }
+        if (e == 0) { kind = 1; lo = 0; }
+    } else if (e < n - 1) {
+        const int64_t ln = (int64_t)(u32)LCP[e + 1];
+        if (sa < B && sa + ln > B && ln > lc) kind = 2;
+    }
+    if (lane == 0) { *lo_out = (u32)lo; *kind_out = (uint8_t)kind; }
+}
+
+// execute active a (one wave), kind 1 or 2
+__device__ inline void wave_execute(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW,
+                                    int64_t e, int kind, int64_t x) {
+    const int lane = threadIdx.x & 63;
+    const int64_t n = ds.n, B = ds.B;
+    if (kind == 2) {
+        if (lane == 0) LCP[e + 1] = (lcp_t)(B - (int64_t)SA[e]);
+        return;
+    }
+    if (kind != 1) return;
+    const sa_t tS = SA[e]; const lcp_t tL = LCP[e]; const uint8_t tB = BW[e];
+    for (int64_t top = e; top > x; top -= 64) {                 // destinations top, top-1, ..., down to x+1
+        const int64_t r = top - lane;
+        sa_t vs = 0; lcp_t vl = 0; uint8_t vb = 0;
+        if (r > x) { vs = SA[r - 1]; vl = LCP[r - 1]; vb = BW[r - 1]; }
+        __builtin_amdgcn_wave_barrier();                          // every lane's loads are issued before any store below
+        if (r > x) { SA[r] = vs; LCP[r] = vl; BW[r] = vb; sai_upkeep(b, ds, cw, vs, r); }
+    }
+    if (lane == 0) {
+        SA[x] = tS; BW[x] = tB;
+        b.SAi[tS] = (sa_t)x;
+        if (x + 1 < n) LCP[x + 1] = (lcp_t)(B - (int64_t)tS);
+        if (e < n - 1 && (int64_t)(u32)tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = tL;
+    }
+}
+
 // Visit lst[start .. cnt) in the reference's order.  Returns the index of the
 // active at which a long move was deferred to the grid kernels (DEFER), or cnt.
 template <int NT, int EL, bool DEFER>
@@ -575,8 +629,27 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
     // A handful of actives: classifying them first only adds latency (measured on C2: 12 ms sequential vs 14.5 ms) ->
     // plain sequential visits.  The concurrent path pays off with many actives per cut (closely related samples).
     if (cnt - start <= 32) {
-        for (; cur < cnt; cur++)
-            if (bubble_visit_vec<NT, EL, DEFER>(b, ds, cw, SA, LCP, BW, (int64_t)lst[cur], s_v, s_max, st)) return cur;
+        // a handful of actives: one wave per active, NT/64 at a time
+        constexpr int NW = NT / 64;
+        const int w = threadIdx.x >> 6;
+        while (cur < cnt) {
+            const u32 end = cnt - cur > (u32)NW ? cur + NW : cnt;
+            if (cur + w < end) wave_classify(ds, SA, LCP, (int64_t)lst[cur + w], &ps.lo[cur + w], &ps.kind[cur + w]);
+            if (threadIdx.x == 0) *s_first = end;
+            __syncthreads();
+            {
+                const u32 a = cur + threadIdx.x;
+                if (a < end && (ps.kind[a] == 3 || (a > cur && (int64_t)ps.lo[a] <= (int64_t)lst[a - 1] + 1))) atomicMin(s_first, a);
+            }
+            __syncthreads();
+            const u32 f = *s_first;
+            if (cur + w < f) wave_execute(b, ds, cw, SA, LCP, BW, (int64_t)lst[cur + w], ps.kind[cur + w], (int64_t)ps.lo[cur + w]);
+            __threadfence_block();
+            __syncthreads();
+            if (f >= end) { cur = end; continue; }
+            if (bubble_visit_vec<NT, EL, DEFER>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
+            cur = f + 1;
+        }
         return cnt;
     }
     while (cur < cnt) {

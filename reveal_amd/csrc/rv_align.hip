@@ -102,10 +102,13 @@ struct Align {
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag;
-    DBuf dLeaf, dLeafRoots;      // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root table
+    DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
+    hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
+    hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr};
+    bool leaf_pending[2] = {false, false};   // a leaf launch may still be reading level buffer k
     size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
     std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
-    std::vector<RvLeafRoot> leaf_roots;
+    std::vector<RvLeafRoot> leaf_roots[2];
     Packer pk;
     std::vector<int> stamp; int epoch = 0;        // count_samples scratch
     // reusable host tables of commit()
@@ -124,7 +127,10 @@ struct Align {
     rv_align_stats st{};
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dLeaf.release(); dLeafRoots.release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
+        if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
+        for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
     }
 };
 
@@ -520,6 +526,18 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_TRY(a->lvLCP[nxt].reserve((size_t)(m_next + 64) * sizeof(lcp_t)));
     RV_TRY(a->lvBWT[nxt].reserve((size_t)m_next + 64));
 
+    // A leaf launch of an earlier level may still be reading the buffer this commit writes (ping-pong), and the long-move
+    // path of this commit scribbles over the current (parent) buffer: order after them.
+    {
+        const int cur_id = (a->level == 0) ? 2 : a->cur;            // 2 = the main arrays
+        const int wait_ids[2] = {nxt, !a->descs.empty() ? cur_id : -1};
+        for (int k = 0; k < 2; k++) {
+            const int id = wait_ids[k];
+            if (id < 0) continue;
+            const int slot = id == 2 ? 1 : id;                       // the main arrays share slot 1 (level 0 writes buffer 0)
+            if (a->leaf_pending[slot]) { RV_HIP(hipStreamWaitEvent(q, a->ev_leaf[slot], 0)); a->leaf_pending[slot] = false; }
+        }
+    }
     RvLabelTabs lt;
     lt.sub_start = (const int64_t *)(tb + o_ss); lt.nsubs = ns;
     lt.ctab_first = (const int *)(tb + o_ctf); lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc;
@@ -612,12 +630,21 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         lf_a = (int64_t *)(base + 256); lf_b = lf_a + a->leaf_anchor_cap; lf_l = (u32 *)(lf_b + a->leaf_anchor_cap);
         lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
         RV_HIP(hipMemsetAsync(base, 0, 256, q));
+        if (!a->leaf_stream) {
+            RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
+            for (int k = 0; k < 2; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming));
+        }
+        a->leaf_pending[0] = a->leaf_pending[1] = false;
     }
+    int leaf_flip = 0;
     while (a->lv.size() > 0) {
         if (use_leaf) {
             const Level &lv0 = a->lv;
             a->leaf_done.assign((size_t)lv0.size(), 0);
-            a->leaf_roots.clear();
+            std::vector<RvLeafRoot> &roots = a->leaf_roots[leaf_flip];
+            DBuf &droots = a->dLeafRoots[leaf_flip];
+            roots.clear();
             for (int s = 0; s < lv0.size(); s++) {
                 if (lv0.n[(size_t)s] > RV_LEAF_N) continue;
                 const int64_t nf = lv0.node_first[(size_t)s], nn = lv0.node_first[(size_t)s + 1] - nf;
@@ -633,21 +660,33 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
                 }
                 if (!ok) continue;
                 a->leaf_done[(size_t)s] = 1;
-                a->leaf_roots.push_back(r);
+                roots.push_back(r);
             }
-            if (!a->leaf_roots.empty()) {
-                RV_TRY(a->dLeafRoots.reserve(a->leaf_roots.size() * sizeof(RvLeafRoot)));
-                RV_HIP(hipMemcpyAsync(a->dLeafRoots.p, a->leaf_roots.data(), a->leaf_roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, q));
+            if (!roots.empty()) {
+                // second stream: starts once the level arrays are complete, runs beside this level's scan/split/bubble
+                hipStream_t ls = a->leaf_stream;
+                const int slot = (a->level == 0) ? 1 : a->cur;
+                if (a->leaf_pending[slot]) RV_HIP(hipEventSynchronize(a->ev_leaf[slot]));     // (cannot happen: commit waits first)
+                RV_HIP(hipEventRecord(a->ev_ready, q));
+                RV_HIP(hipStreamWaitEvent(ls, a->ev_ready, 0));
+                RV_TRY(droots.reserve(roots.size() * sizeof(RvLeafRoot)));
+                RV_HIP(hipMemcpyAsync(droots.p, roots.data(), roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, ls));
                 RvLeafArgs la;
-                la.roots = a->dLeafRoots.as<RvLeafRoot>();
+                la.roots = droots.as<RvLeafRoot>();
                 la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
                 la.nsep0 = h->nsep[0]; la.minl = minl; la.lcap = h->maxlcp;
                 la.anchor_count = lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = lf_l; la.anchor_a = lf_a; la.anchor_b = lf_b;
                 la.stats = lf_stats;
                 la.trace = a->trace_on ? 1 : 0; la.trace_count = lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = lf_tr;
                 la.err = lf_counters + 2;
-                RV_TRY(rv_leaf_launch(h->ws, la, (int)a->leaf_roots.size()));
-                if ((size_t)lv0.size() == a->leaf_roots.size()) {       // nothing left for the level path
+                {
+                    Workspace lw; lw.stream = ls;
+                    RV_TRY(rv_leaf_launch(lw, la, (int)roots.size()));
+                }
+                RV_HIP(hipEventRecord(a->ev_leaf[slot], ls));
+                a->leaf_pending[slot] = true;
+                leaf_flip ^= 1;
+                if ((size_t)lv0.size() == roots.size()) {       // nothing left for the level path
                     a->st.levels++;
                     a->lv.clear();
                     break;
@@ -740,6 +779,8 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     }
     if (use_leaf) {       // collect what the leaf launches produced
         u32 cnt[4]; unsigned long long stv[4];
+        RV_HIP(hipStreamSynchronize(a->leaf_stream));
+        a->leaf_pending[0] = a->leaf_pending[1] = false;
         RV_HIP(hipMemcpyAsync(cnt, lf_counters, sizeof cnt, hipMemcpyDeviceToHost, q));
         RV_HIP(hipMemcpyAsync(stv, lf_stats, sizeof stv, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));

@@ -431,10 +431,26 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
                 if (g >= gl) {
                     const int64_t r0 = 4 * g - skew;     // ranks r0..r0+3
                     if (r0 >= 1 && r0 + 3 <= e) {
+#ifdef RV_SA64
                         const int4 here = *reinterpret_cast<const int4 *>(LCP + r0);
                         __builtin_memcpy(&vs[k], SA + r0 - 1, sizeof(sa4_t));
                         __builtin_memcpy(&vl[k], LCP + r0 - 1, 16);
                         __builtin_memcpy(&vb[k], BW + r0 - 1, 4);
+#else
+                        // aligned loads only: this group's ranks r0..r0+3; the source of rank r0 (rank r0-1) is the last
+                        // element of group g-1, which the next lane holds (groups run downwards with the lane index)
+                        const sa4_t cs = *reinterpret_cast<const sa4_t *>(SA + r0);
+                        const int4 here = *reinterpret_cast<const int4 *>(LCP + r0);
+                        const u32 cb = *reinterpret_cast<const u32 *>(BW + r0);
+                        const bool nb = lane < 63 && g - 1 >= gl && r0 - 4 >= 1;      // neighbour lane holds a full group g-1
+                        sa_t ps3 = (sa_t)__shfl_down((int)cs.w, 1, 64);
+                        int pl3 = __shfl_down(here.w, 1, 64);
+                        u32 pb3 = __shfl_down(cb, 1, 64) >> 24;
+                        if (!nb) { ps3 = SA[r0 - 1]; pl3 = (int)LCP[r0 - 1]; pb3 = BW[r0 - 1]; }
+                        vs[k].x = ps3; vs[k].y = cs.x; vs[k].z = cs.y; vs[k].w = cs.z;
+                        vl[k].x = pl3; vl[k].y = here.x; vl[k].z = here.y; vl[k].w = here.z;
+                        vb[k] = (cb << 8) | (pb3 & 0xffu);
+#endif
                         const u32 hv[4] = {(u32)here.x, (u32)here.y, (u32)here.z, (u32)here.w};
 #pragma unroll
                         for (int j = 3; j >= 0; j--) if ((int64_t)hv[j] < t) { const int o = (int)(r0 + j - rbase); best = o > best ? o : best; break; }
@@ -569,7 +585,7 @@ __device__ inline void par_execute(const RvBubbleArgs &b, const RvBubbleDesc &ds
 // Few actives: one wave per active.  The 64 lanes search the destination 64 ranks
 // at a time (up to BB_WSCAN ranks) and, if the ranges of the batch are disjoint,
 // shift their own range 64 ranks per step -- no workgroup barrier inside a move.
-constexpr int BB_WSCAN = 2048;
+constexpr int BB_WSCAN = 512;
 
 // classify active a (one wave): kind 0 none / 1 move to lo / 2 truncate / 3 long
 __device__ inline void wave_classify(const RvBubbleDesc &ds, const sa_t *SA, const lcp_t *LCP, int64_t e, u32 *lo_out, uint8_t *kind_out) {

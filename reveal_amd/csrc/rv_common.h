@@ -78,10 +78,12 @@ struct Workspace {
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf misc[12];
+    DBuf sa[16];           // SA-build scratch, kept between construct() calls
     void release() {
         for (auto &b : scan_tmp) b.release();
         rs_hist.release();
         for (auto &b : misc) b.release();
+        for (auto &b : sa) b.release();
     }
 };
 

@@ -179,6 +179,121 @@ __global__ __launch_bounds__(TB) void k_round_isa(const sav_t *__restrict__ S, c
     ISA[S[q]] = newG[q];
 }
 
+// ---- doubling round, small groups ------------------------------------------------
+// In closely related genomes almost every group that is still unsorted after the
+// first key has two to four members (a suffix and its twins in the other
+// samples).  A group's members sit next to each other in the list (P[q] - G[q] is
+// the offset inside the group), so the group's first thread can sort up to
+// SMALL_GROUP members by the rank of suffix+h directly; only larger groups go
+// through the radix sort.
+constexpr int SMALL_GROUP = 8;
+
+__device__ inline u32 key2_of(sav_t s, int64_t h, int64_t n, const u32 *__restrict__ ISA) {
+    const int64_t s2 = (int64_t)s + h;
+    return (s2 < n) ? ISA[s2] + 1u : 0u;
+}
+
+__global__ __launch_bounds__(TB) void k_round_small(sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P, int64_t m, int64_t n, int64_t h,
+                                                    const u32 *__restrict__ ISA, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag,
+                                                    sa_t *__restrict__ SA) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= m) return;
+    const u32 g = G[q];
+    const u32 off = P[q] - g;
+    const int64_t look = q + (SMALL_GROUP - (int64_t)off);
+    const bool big = off >= (u32)SMALL_GROUP || (look < m && G[look] == g);
+    bigflag[q] = big;
+    if (big || off != 0) return;
+    sav_t s[SMALL_GROUP]; u32 k[SMALL_GROUP];
+    int size = 1;
+    s[0] = S[q]; k[0] = key2_of(s[0], h, n, ISA);
+#pragma unroll
+    for (int j = 1; j < SMALL_GROUP; j++) {
+        if (size == j && q + j < m && G[q + j] == g) { s[j] = S[q + j]; k[j] = key2_of(s[j], h, n, ISA); size = j + 1; }
+    }
+    // insertion sort by k (at most 8 keys; fully unrolled compare-exchange network would also do)
+#pragma unroll
+    for (int a = 1; a < SMALL_GROUP; a++) {
+        if (a < size) {
+            const sav_t cs = s[a]; const u32 ck = k[a];
+            int b = a;
+#pragma unroll
+            for (int t = SMALL_GROUP - 1; t >= 1; t--) {
+                if (t <= a && t == b && k[t - 1] > ck) { s[t] = s[t - 1]; k[t] = k[t - 1]; b = t - 1; }
+            }
+#pragma unroll
+            for (int t = 0; t < SMALL_GROUP; t++) if (t == b) { s[t] = cs; k[t] = ck; }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < SMALL_GROUP; j++) {
+        if (j < size) {
+            S[q + j] = s[j];
+            SA[(size_t)g + j] = (sa_t)s[j];
+            headq[q + j] = (j == 0) || (k[j] != k[j - (j > 0)]);
+        }
+    }
+}
+
+// members of big groups -> sublist (ordered)
+__global__ __launch_bounds__(TB) void k_flag_count(const uint8_t *__restrict__ flag, int64_t n, u32 *__restrict__ tilecnt) {
+    __shared__ u32 wsum[TB / 64];
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    u32 c = 0;
+#pragma unroll
+    for (int r = 0; r < CP_ITEMS; r++) {
+        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
+        if (j < n && flag[j]) c++;
+    }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) tilecnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+__global__ __launch_bounds__(TB) void k_flag_emit(const uint8_t *__restrict__ flag, int64_t n, const u32 *__restrict__ tileoff,
+                                                  const u32 *__restrict__ P, const sav_t *__restrict__ S, const u32 *__restrict__ G, int64_t nn, int64_t h,
+                                                  const u32 *__restrict__ ISA, u32 *__restrict__ Pb, sav_t *__restrict__ Sb, u32 *__restrict__ Qb, u64 *__restrict__ kk) {
+    __shared__ u32 wbase[TB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    u32 run = tileoff[blockIdx.x];
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int r = 0; r < CP_ITEMS; r++) {
+        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
+        const bool f = (j < n) && flag[j];
+        const u64 bal = __ballot(f);
+        if (lane == 0) wbase[w] = (u32)__popcll(bal);
+        __syncthreads();
+        u32 before = 0, tot = 0;
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) { const u32 c = wbase[k]; if (k < w) before += c; tot += c; }
+        if (f) {
+            const u32 qb = run + before + (u32)__popcll(bal & lt);
+            const sav_t s = S[j];
+            Pb[qb] = P[j]; Sb[qb] = s; Qb[qb] = (u32)j;
+            kk[qb] = ((u64)G[j] << 32) | key2_of(s, h, nn, ISA);
+        }
+        run += tot;
+        __syncthreads();
+    }
+}
+// sorted big sublist back into the list
+__global__ __launch_bounds__(TB) void k_big_writeback(const u64 *__restrict__ kk, const u32 *__restrict__ Pb, const u32 *__restrict__ Qb, const sav_t *__restrict__ Sb,
+                                                      int64_t mb, sav_t *__restrict__ S, uint8_t *__restrict__ headq, sa_t *__restrict__ SA) {
+    const int64_t qb = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (qb >= mb) return;
+    const sav_t s = Sb[qb];
+    const u32 q = Qb[qb];
+    S[q] = s;
+    SA[Pb[qb]] = (sa_t)s;
+    headq[q] = (qb == 0) || kk[qb] != kk[qb - 1];
+}
+__global__ __launch_bounds__(TB) void k_seed(const uint8_t *__restrict__ headq, const u32 *__restrict__ P, int64_t m, u32 *__restrict__ seed) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q < m) seed[q] = headq[q] ? P[q] : 0u;
+}
+
 __global__ __launch_bounds__(TB) void k_inverse(const sa_t *__restrict__ SA, sa_t *__restrict__ SAi, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (i < n) SAi[SA[i]] = (sa_t)i;
@@ -281,20 +396,25 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     if (bits < 1) bits = 1;
     int K = 64 / bits;
     if (K > 32) K = 32;
+    {   // no more symbols in the first key than the text size needs: (sigma-1)^K >= 16 n leaves only repeats / twins unresolved
+        const double base = sigma > 2 ? (double)(sigma - 1) : 2.0;
+        int need = 4; double cap = base * base * base * base;
+        while (cap < 16.0 * (double)n && need < K) { cap *= base; need++; }
+        if (need < K) K = need;
+    }
     if (sigma >= 255) { bits = 8; K = 8; for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c; /* 0 byte never occurs in a C-string text */ }
     s.sigma = sigma; s.bits = bits; s.k0 = K;
     RV_HIP(hipMemcpyAsync(d_lut.p, lut, 256, hipMemcpyHostToDevice, q));
 
-    // -- buffers
-    DBuf bk0, bk1, bv0, bv1, bhead, bseed, bgrp, bisa, bP0, bP1, bG0, bG1, btile;
-    auto freeall = [&]() {
-        for (DBuf *b : {&d_hist, &d_lut, &bk0, &bk1, &bv0, &bv1, &bhead, &bseed, &bgrp, &bisa, &bP0, &bP1, &bG0, &bG1, &btile}) b->release();
-    };
+    // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
+    DBuf &bk0 = ws.sa[0], &bk1 = ws.sa[1], &bv0 = ws.sa[2], &bv1 = ws.sa[3], &bhead = ws.sa[4], &bseed = ws.sa[5], &bgrp = ws.sa[6], &bisa = ws.sa[7],
+         &bP0 = ws.sa[8], &bP1 = ws.sa[9], &bG0 = ws.sa[10], &bG1 = ws.sa[11], &btile = ws.sa[12], &bbig = ws.sa[13], &bQb = ws.sa[14], &bPb = ws.sa[15];
+    auto freeall = [&]() { d_hist.release(); d_lut.release(); };
 #define SA_TRY(x) do { int r__ = (x); if (r__) { freeall(); return r__; } } while (0)
 #define SA_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rv_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); freeall(); return -1; } } while (0)
     SA_TRY(bk0.reserve((size_t)n * 8)); SA_TRY(bk1.reserve((size_t)n * 8));
     SA_TRY(bv0.reserve((size_t)n * sizeof(sav_t))); SA_TRY(bv1.reserve((size_t)n * sizeof(sav_t)));
-    SA_TRY(bhead.reserve((size_t)n + 16)); SA_TRY(bseed.reserve((size_t)n * 4)); SA_TRY(bgrp.reserve((size_t)n * 4));
+    SA_TRY(bhead.reserve((size_t)n + 16)); SA_TRY(bseed.reserve((size_t)n * (sizeof(sav_t) > 4 ? sizeof(sav_t) : 4))); SA_TRY(bgrp.reserve((size_t)n * 4));
     SA_TRY(bisa.reserve((size_t)n * 4));
     const unsigned nblk = (unsigned)ceil_div(n, TB);
 
@@ -340,16 +460,16 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         return 0;
     };
 
-    // Count first so the list buffers can be sized to m (usually << n later on,
-    // but close to n in round 0).
     int64_t m = 0;
     SA_TRY(bP0.reserve((size_t)n * 4)); SA_TRY(bG0.reserve((size_t)n * 4));
+    SA_TRY(bP1.reserve((size_t)n * 4)); SA_TRY(bG1.reserve((size_t)n * 4));
     // round-0 suffix list goes to the free value buffer `vt`
     SA_TRY(compact(head, n, nullptr, vs, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
-    u32 *P = bP0.as<u32>(), *G = bG0.as<u32>();
+    u32 *P = bP0.as<u32>(), *G = bG0.as<u32>(), *Pn = bP1.as<u32>(), *Gn = bG1.as<u32>();
     sav_t *S = vt;          // current list of suffixes (length m)
     sav_t *Sfree = vs;      // the other value buffer
     u64 *kA = ks, *kB = kt; // both key buffers are free from here on
+    if (m > 0) { SA_TRY(bbig.reserve((size_t)m + 16)); SA_TRY(bQb.reserve((size_t)m * 4)); SA_TRY(bPb.reserve((size_t)m * 4)); }
 
     const int lowbits = bitlen((u64)n), highbits = bitlen((u64)(n > 1 ? n - 1 : 1));
     int64_t h = K;
@@ -357,35 +477,51 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         if (h >= 2 * n + 2) { rv_set_error("SA build: did not converge"); freeall(); return -1; }
         s.rounds++;
         const unsigned mb = (unsigned)ceil_div(m, TB);
-        hipLaunchKernelGGL(k_round_keys, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)G, m, n, h, (const u32 *)ISA, kA);
+        uint8_t *bigflag = bbig.as<uint8_t>();
+        // groups of up to SMALL_GROUP members: sorted by their first thread, in place
+        hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
         SA_HIP(hipGetLastError());
-        // sort (kk, S): low half on [0,lowbits), then high half on [32,32+highbits)
-        int f1 = 0, f2 = 0;
-        SA_TRY(rv_radix_sort_pairs<sav_t>(ws, kA, S, kB, Sfree, m, 0, lowbits, &f1));
-        u64 *k_in = f1 ? kB : kA, *k_out = f1 ? kA : kB;
-        sav_t *s_in = f1 ? Sfree : S, *s_out = f1 ? S : Sfree;
-        SA_TRY(rv_radix_sort_pairs<sav_t>(ws, k_in, s_in, k_out, s_out, m, 32, 32 + highbits, &f2));
-        u64 *kS = f2 ? k_out : k_in;
-        sav_t *sS = f2 ? s_out : s_in;
-        sav_t *sOther = f2 ? s_in : s_out;
-        u64 *kOther = f2 ? k_in : k_out;
-        s.radix_passes += (lowbits + 7) / 8 + (highbits + 7) / 8; s.sorted_elems += m;
-
-        // heads in the list, SA write-back, new group ranks, ISA update
-        hipLaunchKernelGGL(k_round_heads, dim3(mb), dim3(TB), 0, q, (const u64 *)kS, (const u32 *)P, (const sav_t *)sS, m, head, seed, SA);
+        // members of larger groups: ordered sublist -> radix sort on (group rank, rank of suffix+h) -> back into the list
+        {
+            const int64_t nt = ceil_div(m, CP_TILE);
+            hipLaunchKernelGGL(k_flag_count, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, tile);
+            SA_HIP(hipGetLastError());
+            SA_HIP(hipMemsetAsync(tile + nt, 0, 4, q));
+            SA_TRY(rv_exclusive_sum_u32(ws, tile, tile, nt + 1));
+            u32 mbig = 0;
+            SA_HIP(hipMemcpyAsync(&mbig, tile + nt, 4, hipMemcpyDeviceToHost, q));
+            SA_HIP(hipStreamSynchronize(q));
+            if (mbig > 0) {
+                u32 *Pb = bPb.as<u32>(), *Qb = bQb.as<u32>();
+                hipLaunchKernelGGL(k_flag_emit, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, (const u32 *)tile, (const u32 *)P, (const sav_t *)S,
+                                   (const u32 *)G, n, h, (const u32 *)ISA, Pb, Sfree, Qb, kA);
+                SA_HIP(hipGetLastError());
+                // Sfree holds the sublist's suffixes; its partner buffer for the ping-pong is the seed array (free until k_seed)
+                sav_t *sb0 = Sfree, *sb1 = reinterpret_cast<sav_t *>(bseed.p);
+                int f1 = 0, f2 = 0;
+                SA_TRY(rv_radix_sort_pairs<sav_t>(ws, kA, sb0, kB, sb1, mbig, 0, lowbits, &f1));
+                u64 *k_in = f1 ? kB : kA, *k_out = f1 ? kA : kB;
+                sav_t *s_in = f1 ? sb1 : sb0, *s_out = f1 ? sb0 : sb1;
+                SA_TRY(rv_radix_sort_pairs<sav_t>(ws, k_in, s_in, k_out, s_out, mbig, 32, 32 + highbits, &f2));
+                const u64 *kS = f2 ? k_out : k_in;
+                const sav_t *sS = f2 ? s_out : s_in;
+                s.radix_passes += (lowbits + 7) / 8 + (highbits + 7) / 8; s.sorted_elems += mbig;
+                hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)ceil_div(mbig, TB)), dim3(TB), 0, q, kS, (const u32 *)Pb, (const u32 *)Qb, sS, (int64_t)mbig, S, head, SA);
+                SA_HIP(hipGetLastError());
+            }
+        }
+        // new group ranks from the heads, ISA update
+        hipLaunchKernelGGL(k_seed, dim3(mb), dim3(TB), 0, q, (const uint8_t *)head, (const u32 *)P, m, seed);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));
-        hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)sS, (const u32 *)grp, m, ISA);
+        hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA);
         SA_HIP(hipGetLastError());
 
-        // next list
-        if (!bP1.p) { SA_TRY(bP1.reserve((size_t)m * 4)); SA_TRY(bG1.reserve((size_t)m * 4)); }
+        // next list: what is still not unique
         int64_t m2 = 0;
-        SA_TRY(compact(head, m, P, sS, grp, bP1.as<u32>(), sOther, bG1.as<u32>(), &m2));
-        // swap list buffers
-        { DBuf t = bP0; bP0 = bP1; bP1 = t; t = bG0; bG0 = bG1; bG1 = t; }
-        P = bP0.as<u32>(); G = bG0.as<u32>();
-        S = sOther; Sfree = sS; kA = kS; kB = kOther;
+        SA_TRY(compact(head, m, P, S, grp, Pn, Sfree, Gn, &m2));
+        { u32 *t = P; P = Pn; Pn = t; t = G; G = Gn; Gn = t; }
+        { sav_t *t = S; S = Sfree; Sfree = t; }
         m = m2;
         h *= 2;
     }

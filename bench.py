@@ -123,7 +123,10 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_scan.json")
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                pj = json.load(open(pmc))
+                # per-launch HBM bytes from the PMC passes only describe the workload they were collected on
+                if pj.get("workload") == "%dx%d-%d" % (args.genomes, args.L, 64 if args.sa64 else 32):
+                    traffic = pj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         st = last["stats"]

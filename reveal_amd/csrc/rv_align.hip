@@ -101,7 +101,7 @@ struct Align {
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
-    DBuf dD, dTab, dTile, dList, dFlag;
+    DBuf dD, dTab, dTile, dList, dFlag, dPar;
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
     hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr};
@@ -115,7 +115,7 @@ struct Align {
     std::vector<sa_t> cb, ce, mb, me, cut_lo, cut_hi, mend_pos;
     std::vector<uint8_t> cc;
     std::vector<int> ctab_first, mtab_first, cut_first, mend_first, split_subs;
-    std::vector<int64_t> mpre, sub_start, woff;
+    std::vector<int64_t> mpre, sub_start, woff, toff;
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
@@ -127,7 +127,7 @@ struct Align {
     rv_align_stats st{};
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
@@ -407,6 +407,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->kids_small.clear(); a->kids_big.clear();
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
+    // leading children above this many ranks take the data-parallel bubble rounds (RV_BUBBLE_PAR_MIN: test hook)
+    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_BIG_N;
     struct Ent { int64_t b, e; uint8_t c; };
     std::vector<Ent> ent;
     for (int s = 0; s < ns; s++) {
@@ -464,7 +466,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
                 a->cut_lo.push_back((sa_t)lo); a->cut_hi.push_back((sa_t)B);
             }
             const int c1 = (int)a->cut_lo.size();
-            if (lead_n <= RV_BUBBLE_HUGE_N) {          // every cut of this child in one workgroup
+            if (lead_n <= par_min) {                   // every cut of this child in one workgroup, sequentially
                 bool any = false;
                 for (int q = c0; q < c1; q++) any = any || a->cut_lo[(size_t)q] < a->cut_hi[(size_t)q];
                 if (any) {
@@ -472,7 +474,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
                     (lead_n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
                 }
             } else
-            for (int64_t r = m0; r < m1; r++) {        // huge child: one cut per round, long moves go to the grid kernels
+            for (int64_t r = m0; r < m1; r++) {        // larger child: one cut per round, data-parallel (rv_bubble.hip)
                 const int64_t B = dc.match[(size_t)r].begin, lo = (int64_t)a->cut_lo[(size_t)(c0 + (r - m0))];
                 if (lo >= B) continue;
                 if ((int64_t)a->rounds.size() <= r - m0) a->rounds.resize((size_t)(r - m0) + 1);
@@ -488,20 +490,22 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const int64_t m_next = running;
     if (m_next >= ((int64_t)1 << 32)) { rv_set_error("level larger than 2^32 ranks not supported yet"); return -1; }
     a->descs.clear();
-    std::vector<int> round_first, round_small, round_big;
-    std::vector<int64_t> round_maxhuge;
-    for (auto &r : a->rounds) {      // per round: ordinary children first, then the large ones (bigger workgroups), then the huge ones
+    std::vector<int> round_first;
+    std::vector<uint8_t> round_seq;      // some window of the round exceeds what the parallel path takes: also launch the sequential kernels
+    for (auto &r : a->rounds) {
         round_first.push_back((int)a->descs.size());
-        auto cls = [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_BIG_N ? 0 : x.n <= RV_BUBBLE_HUGE_N ? 1 : 2; };
-        std::stable_sort(r.begin(), r.end(), [&](const RvBubbleDesc &x, const RvBubbleDesc &y) { return cls(x) < cls(y); });
-        int nsmall = 0, nbig = 0; int64_t mh = 0;
-        for (auto &x : r) { const int c = cls(x); nsmall += c == 0; nbig += c == 1; if (c == 2 && x.n > mh) mh = x.n; }
-        round_small.push_back(nsmall); round_big.push_back(nbig); round_maxhuge.push_back(mh);
+        bool seq = false;
+        for (auto &x : r) seq = seq || (x.B - x.wlo) > RV_PB_CAP;
+        round_seq.push_back(seq ? 1 : 0);
         a->descs.insert(a->descs.end(), r.begin(), r.end());
     }
     round_first.push_back((int)a->descs.size());
     a->woff.assign(a->descs.size() + 1, 0);
-    for (size_t k = 0; k < a->descs.size(); k++) a->woff[k + 1] = a->woff[k] + (a->descs[k].B - a->descs[k].wlo);
+    a->toff.assign(a->descs.size() + 1, 0);
+    for (size_t k = 0; k < a->descs.size(); k++) {
+        a->woff[k + 1] = a->woff[k] + (a->descs[k].B - a->descs[k].wlo);
+        a->toff[k + 1] = a->toff[k] + ceil_div(a->descs[k].n, RV_SPLIT_TILE);
+    }
 
     // ---- one upload for all the tables ---------------------------------------------------
     const int64_t ntiles = ceil_div(lv.m, RV_SPLIT_TILE);
@@ -511,9 +515,9 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_ctf = pk.addv(a->ctab_first), o_mtf = pk.addv(a->mtab_first);
     const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
-    const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
+    const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
-    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4);
+    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
@@ -577,12 +581,31 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         // the parent level is dead once split has run (at level 0 these are the main SA/LCP/BWT, which the
         // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
+        if (!a->descs.empty()) {
+            const size_t W = (size_t)a->woff.back() + 16, TT = (size_t)a->toff.back() + 16;
+            RV_TRY(a->dPar.reserve(TT * 4 + W * (7 * 4 + sizeof(sa_t) + 2) + 256));
+            uint8_t *pb = a->dPar.as<uint8_t>();
+            ba.par.toff = (const int64_t *)(tb + o_toff);
+            ba.par.mcnt = (u32 *)(tb + o_mcnt);
+            ba.par.Qs = (sa_t *)pb; pb += W * sizeof(sa_t);
+            ba.par.tmin = (u32 *)pb; pb += TT * 4;
+            ba.par.mrank = (u32 *)pb; pb += W * 4;
+            ba.par.msite = (u32 *)pb; pb += W * 4;
+            ba.par.R = (u32 *)pb; pb += W * 4;
+            ba.par.Qsite = (u32 *)pb; pb += W * 4;
+            ba.par.QF = (u32 *)pb; pb += W * 4;
+            ba.par.Qt = (u32 *)pb; pb += W * 4;
+            ba.par.Qlcp = (u32 *)pb; pb += W * 4;
+            ba.par.Qbw = pb; pb += W;
+            ba.par.Qlast = pb;
+        }
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
         RV_TRY(rv_bubble_children_launch(h->ws, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
-            RV_TRY(rv_bubble_round_launch(h->ws, ba, first, round_small[r], round_big[r], count - round_small[r] - round_big[r], round_maxhuge[r],
-                                          a->woff[(size_t)(first + count)] - a->woff[(size_t)first]));
+            RV_TRY(rv_bubble_par_round_launch(h->ws, ba, first, count, a->woff[(size_t)(first + count)] - a->woff[(size_t)first],
+                                              a->toff[(size_t)(first + count)] - a->toff[(size_t)first]));
+            if (round_seq[r]) RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count));
         }
         h->prof.end(q, id);
     }
@@ -638,7 +661,11 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         a->leaf_pending[0] = a->leaf_pending[1] = false;
     }
     int leaf_flip = 0;
+    const bool level_log = getenv("RV_LEVEL_LOG") != nullptr;      // diagnostics: per-level wall time (adds a sync per level)
     while (a->lv.size() > 0) {
+        const double tl0 = level_log ? now_s() : 0.0;
+        const int log_ns = a->lv.size(); const int64_t log_m = a->lv.m; const int log_level = a->level;
+        size_t log_leaf = 0;
         if (use_leaf) {
             const Level &lv0 = a->lv;
             a->leaf_done.assign((size_t)lv0.size(), 0);
@@ -686,6 +713,7 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
                 RV_HIP(hipEventRecord(a->ev_leaf[slot], ls));
                 a->leaf_pending[slot] = true;
                 leaf_flip ^= 1;
+                log_leaf = roots.size();
                 if ((size_t)lv0.size() == roots.size()) {       // nothing left for the level path
                     a->st.levels++;
                     a->lv.clear();
@@ -775,7 +803,18 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
             if (a->trace_on) a->trace.push_back(tr);
         }
         a->st.t_host += now_s() - t0;
+        const double tl1 = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_commit(h, nullptr));
+        if (level_log) {
+            const double tl2 = now_s();
+            (void)hipStreamSynchronize(q);
+            const double tl3 = now_s();
+            int64_t biggest = 0;
+            for (int s2 = 0; s2 < a->lv.size(); s2++) biggest = std::max<int64_t>(biggest, a->lv.n[(size_t)s2]);
+            fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | scan+host %7.1f us  commit(enqueue) %7.1f us  drain %7.1f us | next: subs %d ranks %lld biggest %lld\n",
+                    log_level, log_ns, log_leaf, (long long)log_m, (tl1 - tl0) * 1e6, (tl2 - tl1) * 1e6, (tl3 - tl2) * 1e6,
+                    a->lv.size(), (long long)a->lv.m, (long long)biggest);
+        }
     }
     if (use_leaf) {       // collect what the leaf launches produced
         u32 cnt[4]; unsigned long long stv[4];

@@ -61,7 +61,21 @@ struct RvBubbleState {
     unsigned long long x;   // destination rank found by the grid search (atomicMax)
 };
 
+// tables of the data-parallel bubble rounds (rv_bubble.hip); per-mover arrays are indexed like `list` (descriptor d at woff[d])
+#define RV_PB_CAP 4096      // candidates per (child, cut) the parallel path takes; more -> sequential kernels
+struct RvParBubble {
+    const int64_t *toff;     // prefix sums of RV_SPLIT_TILE-rank tiles over all descriptors (+1)
+    u32 *tmin;               // per tile: min l' over the non-movers
+    u32 *mcnt;               // per descriptor: number of movers (zeroed per level)
+    u32 *mrank, *msite;      // movers in discovery order: rank in the child, landing site
+    u32 *R;                  // mover ranks, ascending
+    u32 *Qsite, *QF, *Qt, *Qlcp;   // movers by (site, t): site, final rank, t, LCP value at the final rank
+    sa_t *Qs;                // ... suffix
+    uint8_t *Qbw, *Qlast;    // ... BWT byte, 1 = last of its site's group
+};
+
 struct RvBubbleArgs {
+    RvParBubble par;
     const RvBubbleDesc *desc;
     const int64_t      *woff;     // prefix sums of window widths over all descriptors (+1)
     u32                *cnt;      // per descriptor: number of active ranks found
@@ -94,4 +108,9 @@ int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int 
                            int64_t total_window);
 // all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
+// one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)
+int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles);
+int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window);
+// sequential kernels for the (child, cut)s of a round the parallel path left alone (more than RV_PB_CAP candidates)
+int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count);
 int rv_sai_level_launch(Workspace &ws, const sa_t *SA, int64_t m, const int64_t *sub_start, int nsubs, sa_t *SAi);

@@ -1032,6 +1032,20 @@ int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int 
     return 0;
 }
 
+int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window) {
+    if (count <= 0 || total_window <= 0) return 0;
+    hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL((k_bubble_apply<1024, 4, false>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, first);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig) {
     if (nsmall > 0) {
         hipLaunchKernelGGL((k_bubble_child<256, 1>), dim3((unsigned)nsmall), dim3(256), 0, ws.stream, b, d_small);

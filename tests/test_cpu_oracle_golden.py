@@ -100,3 +100,65 @@ def test_split_skips_min_update_for_unlabelled_ranks():
     assert list(kids[0][0]) == [10, 11, 13, 14]
     # LCP[3]=7 is never folded in (rank 2 skipped its update), LCP[2]=1 is
     assert list(kids[0][1]) == [0, 5, 1, 6]
+
+
+def _bubble_closed_form(SA, LCP, B):
+    """the restatement rv_bubble.hip implements (see its header): chains of l', movers, landing sites,
+    final arrangement = for every non-mover k: [movers landing at k by t ascending], k"""
+    n = len(SA)
+    lp = list(LCP)
+    mover = [False] * n
+    for i in range(n):
+        if SA[i] < B and SA[i] + lp[i] > B:
+            if i == 0:
+                if n > 1:
+                    lp[1] = B - SA[0]
+            else:
+                mover[i] = True
+                if i + 1 < n and lp[i] < lp[i + 1]:
+                    lp[i + 1] = lp[i]
+        elif i + 1 < n and SA[i] < B and SA[i] + lp[i + 1] > B and lp[i + 1] > lp[i]:
+            lp[i + 1] = B - SA[i]
+    groups = {}
+    for j in range(n):
+        if not mover[j]:
+            continue
+        t, k = B - SA[j], j - 1
+        while k > 0 and (mover[k] or lp[k] >= t):
+            k -= 1
+        groups.setdefault(k, []).append(j)
+    outS, outL = [], []
+    for r in range(n):
+        if mover[r]:
+            continue
+        gap = lp[r]
+        for j in sorted(groups.get(r, []), key=lambda j: B - SA[j]):
+            outS.append(SA[j]); outL.append(gap); gap = B - SA[j]
+        outS.append(SA[r]); outL.append(gap)
+    return outS, outL
+
+
+def test_bubble_closed_form():
+    """bubble_sort's sequential loop (reveal.c:666-727, oracle ro_bubble_sort) has a closed form; the GPU's
+    data-parallel rounds implement that form, so it is pinned here against the oracle on arbitrary arrays"""
+    import random
+    import numpy as np
+    O = oracle(False)
+    rng = random.Random(7)
+    for it in range(4000):
+        n = rng.randint(1, 40)
+        maxl = rng.choice([2, 5, 12, 30, 100])
+        SA = rng.sample(range(3 * n), n)
+        LCP = [rng.randint(0, maxl) for _ in range(n)]
+        if it % 5:
+            LCP[0] = 0
+        cuts = [rng.randint(0, 3 * n) for _ in range(rng.randint(1, 3))]
+        sa = np.array(SA, dtype=np.int32); lcp = np.array(LCP, dtype=np.int32)
+        sai = np.zeros(3 * n + 1, dtype=np.int32)
+        sai[sa] = np.arange(n, dtype=np.int32)
+        O.bubble_sort(sa, lcp, sai, cuts)
+        cs, cl = list(SA), list(LCP)
+        for B in cuts:
+            cs, cl = _bubble_closed_form(cs, cl, B)
+        assert cs == sa.tolist() and cl == lcp.tolist(), (SA, LCP, cuts)
+        assert (sai[sa] == np.arange(n)).all()

@@ -100,6 +100,31 @@ def test_getmultimums(inputs, minl, minn):
     assert idx.getmultimums(minlength=minl, minn=minn) == ref
 
 
+@pytest.mark.parametrize("par_min", [0, 64, 1000])
+@pytest.mark.parametrize("name,inputs,minl,sa64", [
+    ("t1t2", fa("t1", "t2"), 1, False),
+    ("d1d2", fa("d1", "d2"), 20, False),
+    ("1e1b", fa("1e", "1b"), 20, False),
+    ("1a1a", fa("1a", "1a"), 20, False),       # identical inputs: windows beyond RV_PB_CAP -> sequential kernels inside a parallel round
+    ("1a1b_m10", fa("1a", "1b"), 10, False),
+    ("1a1b_64", fa("1a", "1b"), 20, True),
+    ("1a1b1c", fa("1a", "1b", "1c"), 20, False),
+    ("5way", fa("1a", "1b", "1c", "1d", "1e"), 20, False),
+])
+def test_parallel_bubble_rounds(monkeypatch, par_min, name, inputs, minl, sa64):
+    """the data-parallel bubble_sort (rv_bubble.hip, closed form of reveal.c:666-727) forced onto
+    small leading children too: same child SA/LCP as the oracle's literal loop, sub-index by sub-index"""
+    monkeypatch.setenv("RV_BUBBLE_PAR_MIN", str(par_min))
+    monkeypatch.setenv("RV_NO_LEAF", "1")
+    compare(inputs, minl, 2, sa64=sa64)
+
+
+def test_parallel_bubble_synthetic(monkeypatch):
+    monkeypatch.setenv("RV_BUBBLE_PAR_MIN", "0")
+    seqs = [g.decode() for g in synth.genomes(300000, 3)]
+    compare(seqs, 20)
+
+
 def test_python_callbacks_same_anchors():
     """index.align() with Python callbacks of the reference's signatures (reveal.c:839-999)
     gives the same anchors and final text as the native driver"""

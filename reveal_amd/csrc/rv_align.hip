@@ -120,6 +120,8 @@ struct Align {
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
     std::vector<RvBubbleDesc> kids_small, kids_big;
+    struct Kid { int64_t off, n; int c0, c1; int64_t m0, wsum; };
+    std::vector<Kid> kid_tmp;
     // results of rv_align_builtin
     std::vector<u32> an_l; std::vector<int64_t> an_off, an_pos;
     bool trace_on = false;
@@ -411,6 +413,9 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_BIG_N;
     struct Ent { int64_t b, e; uint8_t c; };
     std::vector<Ent> ent;
+    a->kid_tmp.clear();
+    bool any_par = false;
+    int64_t window_sum = 0;
     for (int s = 0; s < ns; s++) {
         a->sub_start[(size_t)s] = lv.off[(size_t)s];
         a->ctab_first[(size_t)s] = (int)a->cb.size(); a->mtab_first[(size_t)s] = (int)a->mb.size();
@@ -466,21 +471,33 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
                 a->cut_lo.push_back((sa_t)lo); a->cut_hi.push_back((sa_t)B);
             }
             const int c1 = (int)a->cut_lo.size();
-            if (lead_n <= par_min) {                   // every cut of this child in one workgroup, sequentially
-                bool any = false;
-                for (int q = c0; q < c1; q++) any = any || a->cut_lo[(size_t)q] < a->cut_hi[(size_t)q];
-                if (any) {
-                    RvBubbleDesc bd; bd.off = lead_off; bd.n = lead_n; bd.B = 0; bd.wlo = 0; bd.cut0 = c0; bd.cut1 = c1;
-                    (lead_n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
-                }
-            } else
-            for (int64_t r = m0; r < m1; r++) {        // larger child: one cut per round, data-parallel (rv_bubble.hip)
-                const int64_t B = dc.match[(size_t)r].begin, lo = (int64_t)a->cut_lo[(size_t)(c0 + (r - m0))];
-                if (lo >= B) continue;
-                if ((int64_t)a->rounds.size() <= r - m0) a->rounds.resize((size_t)(r - m0) + 1);
-                RvBubbleDesc bd; bd.off = lead_off; bd.n = lead_n; bd.B = B; bd.wlo = lo; bd.cut0 = c0; bd.cut1 = c1;
-                a->rounds[(size_t)(r - m0)].push_back(bd);
+            bool any = false;
+            int64_t wsum = 0;
+            for (int q = c0; q < c1; q++) { any = any || a->cut_lo[(size_t)q] < a->cut_hi[(size_t)q]; wsum += (int64_t)a->cut_hi[(size_t)q] - (int64_t)a->cut_lo[(size_t)q]; }
+            if (any) {
+                a->kid_tmp.push_back({lead_off, lead_n, c0, c1, m0, wsum});
+                if (lead_n > par_min) any_par = true;
+                window_sum += wsum;
             }
+        }
+    }
+    // Leading children above par_min ranks take the data-parallel rounds.  Once a level runs those rounds anyway (or has
+    // many cuts per child), the small children join them as long as the window kernels stay small: their one-workgroup
+    // kernel would only add its own latency in front.
+    const bool all_par = (any_par || a->multi) && window_sum <= ((int64_t)64 << 20) && !getenv("RV_BUBBLE_NO_JOIN");
+    for (const auto &kd : a->kid_tmp) {
+        if (!all_par && kd.n <= par_min) {             // every cut of this child in one workgroup, sequentially
+            RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = 0; bd.wlo = 0; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
+            (kd.n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
+            continue;
+        }
+        for (int q = kd.c0; q < kd.c1; q++) {          // one cut per round, data-parallel (rv_bubble.hip)
+            const int64_t B = (int64_t)a->cut_hi[(size_t)q], lo = (int64_t)a->cut_lo[(size_t)q];
+            if (lo >= B) continue;
+            const size_t r = (size_t)(q - kd.c0);
+            if (a->rounds.size() <= r) a->rounds.resize(r + 1);
+            RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = B; bd.wlo = lo; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
+            a->rounds[r].push_back(bd);
         }
     }
     a->sub_start[(size_t)ns] = lv.m;
@@ -517,7 +534,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
-    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4);
+    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
@@ -583,10 +600,12 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
         if (!a->descs.empty()) {
             const size_t W = (size_t)a->woff.back() + 16, TT = (size_t)a->toff.back() + 16;
-            RV_TRY(a->dPar.reserve(TT * 4 + W * (7 * 4 + sizeof(sa_t) + 2) + 256));
+            RV_TRY(a->dPar.reserve(TT * 4 + W * (8 + 7 * 4 + sizeof(sa_t) + 2) + 256));
             uint8_t *pb = a->dPar.as<uint8_t>();
             ba.par.toff = (const int64_t *)(tb + o_toff);
             ba.par.mcnt = (u32 *)(tb + o_mcnt);
+            ba.par.gcount = (u32 *)(tb + o_gcnt);
+            ba.par.glist = (u64 *)pb; pb += W * 8;
             ba.par.Qs = (sa_t *)pb; pb += W * sizeof(sa_t);
             ba.par.tmin = (u32 *)pb; pb += TT * 4;
             ba.par.mrank = (u32 *)pb; pb += W * 4;

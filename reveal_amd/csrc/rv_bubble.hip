@@ -94,6 +94,7 @@ __global__ __launch_bounds__(TB) void k_pb_runs(RvBubbleArgs b, int first, int c
                 flag[i] = 2;
                 const u32 q = atomicAdd(&b.par.mcnt[dd], 1u);
                 b.par.mrank[b.woff[dd] + q] = (u32)i;
+                b.par.glist[atomicAdd(b.par.gcount, 1u)] = ((u64)(u32)dd << 32) | q;
                 nlp = lp < ln ? lp : ln;
             }
             if (more) LCP[i + 1] = (lcp_t)nlp;
@@ -134,50 +135,77 @@ __global__ __launch_bounds__(TB) void k_pb_tilemin(RvBubbleArgs b, int first, in
 }
 
 // ---- landing sites --------------------------------------------------------------------------
-// largest rank r in [lo, hi] that stops a mover with threshold t (r == 0, or a non-mover with l' < t); -1 if none
+// largest rank r in [lo, hi] that stops a mover with threshold t (r == 0, or a non-mover with l' < t); -1 if none.
+// The first 256 ranks decide almost every move; after that the scan goes 1024 ranks per step with all of a
+// step's loads in flight before the first ballot (one memory round trip per step instead of four).
 __device__ inline int64_t wave_scan_down(const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ flag, int64_t hi, int64_t lo, int64_t t) {
     const int lane = threadIdx.x & 63;
-    for (int64_t top = hi; top >= lo; top -= 256) {
+    {
         u64 bal[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int64_t r = top - 64 * k - lane;
+            const int64_t r = hi - 64 * k - lane;
             const bool hit = r >= lo && (r == 0 || (flag[r] != 2 && (int64_t)(u32)LCP[r] < t));
             bal[k] = __ballot(hit);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (bal[k]) return top - 64 * k - (int64_t)__builtin_ctzll(bal[k]);
+        for (int k = 0; k < 4; k++) if (bal[k]) return hi - 64 * k - (int64_t)__builtin_ctzll(bal[k]);
+    }
+    for (int64_t top = hi - 256; top >= lo; top -= 1024) {
+        u32 v[16]; uint8_t f[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t r = top - 64 * k - lane;
+            const bool in = r >= lo;
+            v[k] = in ? (u32)LCP[r] : INF; f[k] = in ? flag[r] : (uint8_t)2;
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const int64_t r = top - 64 * k - lane;
+            const bool hit = r >= lo && (r == 0 || (f[k] != 2 && (int64_t)v[k] < t));
+            const u64 bal = __ballot(hit);
+            if (bal) return top - 64 * k - (int64_t)__builtin_ctzll(bal);
+        }
     }
     return -1;
 }
 
-__global__ __launch_bounds__(TB) void k_pb_search(RvBubbleArgs b, int first, int count, int64_t total) {
-    const int64_t id = ((int64_t)blockIdx.x * TB + threadIdx.x) >> 6;      // one wave per mover
-    if (id >= total) return;
-    int dd; int64_t slot;
-    slot_of(b, first, count, id, &dd, &slot);
-    if (!par_desc(b, dd) || slot >= (int64_t)b.par.mcnt[dd]) return;
-    const RvBubbleDesc ds = b.desc[dd];
-    const lcp_t *LCP = b.LCP + ds.off;
-    const uint8_t *flag = b.flag + ds.off;
+__global__ __launch_bounds__(TB) void k_pb_search(RvBubbleArgs b) {
     const int lane = threadIdx.x & 63;
-    const int64_t e = (int64_t)b.par.mrank[b.woff[dd] + slot];
-    const int64_t t = ds.B - (int64_t)b.SA[ds.off + e];
-    int64_t tile = e / PT;
-    int64_t k = wave_scan_down(LCP, flag, e - 1, tile * PT, t);
-    if (k < 0) {
-        const u32 *tmin = b.par.tmin + b.par.toff[dd];
-        int64_t hit_tile = 0;                      // tile 0 holds rank 0, which always stops
-        for (int64_t top = tile - 1; top >= 0; top -= 64) {
-            const int64_t q = top - lane;
-            const u64 bal = __ballot(q >= 0 && (int64_t)tmin[q] < t);
-            if (bal) { hit_tile = top - (int64_t)__builtin_ctzll(bal); break; }
+    const u32 total = *b.par.gcount;
+    const u32 nw = gridDim.x * (TB / 64);
+    for (u32 g = blockIdx.x * (TB / 64) + (threadIdx.x >> 6); g < total; g += nw) {      // one wave per mover
+        const u64 ent = b.par.glist[g];
+        const int dd = (int)(ent >> 32);
+        const int64_t slot = (int64_t)(u32)ent;
+        const RvBubbleDesc ds = b.desc[dd];
+        const lcp_t *LCP = b.LCP + ds.off;
+        const uint8_t *flag = b.flag + ds.off;
+        const int64_t e = (int64_t)b.par.mrank[b.woff[dd] + slot];
+        const int64_t t = ds.B - (int64_t)b.SA[ds.off + e];
+        const int64_t tile = e / PT;
+        int64_t k = wave_scan_down(LCP, flag, e - 1, tile * PT, t);
+        if (k < 0) {
+            const u32 *tmin = b.par.tmin + b.par.toff[dd];
+            int64_t hit_tile = 0;                      // tile 0 holds rank 0, which always stops
+            for (int64_t top = tile - 1; top >= 0; top -= 256) {
+                u32 v[4];
+#pragma unroll
+                for (int c = 0; c < 4; c++) { const int64_t q = top - 64 * c - lane; v[c] = q >= 0 ? tmin[q] : INF; }
+                bool found = false;
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    const u64 bal = __ballot((int64_t)v[c] < t);
+                    if (bal && !found) { hit_tile = top - 64 * c - (int64_t)__builtin_ctzll(bal); found = true; }
+                }
+                if (found) break;
+            }
+            const int64_t hi = hit_tile * PT + PT - 1;
+            k = wave_scan_down(LCP, flag, hi < ds.n - 1 ? hi : ds.n - 1, hit_tile * PT, t);
+            if (k < 0) { k = 0; if (lane == 0) atomicOr(b.err, 2u); }       // cannot happen (the tile minimum said otherwise)
         }
-        const int64_t hi = hit_tile * PT + PT - 1;
-        k = wave_scan_down(LCP, flag, hi < ds.n - 1 ? hi : ds.n - 1, hit_tile * PT, t);
-        if (k < 0) { k = 0; if (lane == 0) atomicOr(b.err, 2u); }       // cannot happen (tile minimum said otherwise)
+        if (lane == 0) b.par.msite[b.woff[dd] + slot] = (u32)k;
     }
-    if (lane == 0) b.par.msite[b.woff[dd] + slot] = (u32)k;
 }
 
 // ---- final ranks of the movers ---------------------------------------------------------------
@@ -344,6 +372,7 @@ __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int
     }
     if (slot < (int64_t)b.cnt[dd]) b.flag[ds.off + b.list[base + slot]] = 0;
     if (slot == 0) b.state[dd].next = 0x7fffffff;                    // tells the sequential kernels this (child, cut) is done
+    if (id == 0) *b.par.gcount = 0;                                  // nobody reads it in this kernel: ready for the next round
 }
 
 }  // namespace
@@ -357,7 +386,10 @@ int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, 
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pb_tilemin, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pb_search, dim3((unsigned)ceil_div(total_window * 64, TB)), dim3(TB), 0, q, b, first, count, total_window);
+    {
+        const int64_t want = ceil_div(total_window, TB / 64);
+        hipLaunchKernelGGL(k_pb_search, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(TB), 0, q, b);
+    }
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pb_rank, dim3((unsigned)count), dim3(TB), 0, q, b, first);
     RV_LAUNCH_CHECK();

@@ -68,6 +68,8 @@ struct RvParBubble {
     u32 *tmin;               // per tile: min l' over the non-movers
     u32 *mcnt;               // per descriptor: number of movers (zeroed per level)
     u32 *mrank, *msite;      // movers in discovery order: rank in the child, landing site
+    u32 *gcount;             // movers of the running round over all descriptors (reset by the round's last kernel)
+    u64 *glist;              // ... (descriptor << 32) | index in the descriptor's list
     u32 *R;                  // mover ranks, ascending
     u32 *Qsite, *QF, *Qt, *Qlcp;   // movers by (site, t): site, final rank, t, LCP value at the final rank
     sa_t *Qs;                // ... suffix

@@ -119,6 +119,14 @@ def test_parallel_bubble_rounds(monkeypatch, par_min, name, inputs, minl, sa64):
     compare(inputs, minl, 2, sa64=sa64)
 
 
+def test_sequential_bubble_kept(monkeypatch):
+    """the one-workgroup-per-child kernels stay the fallback (and the small-level path): keep them covered in multi mode"""
+    monkeypatch.setenv("RV_BUBBLE_NO_JOIN", "1")
+    monkeypatch.setenv("RV_BUBBLE_PAR_MIN", str(1 << 40))
+    compare(fa("1a", "1b", "1c"), 20, 2)
+    compare([g.decode() for g in synth.genomes(200000, 2)], 20)
+
+
 def test_parallel_bubble_synthetic(monkeypatch):
     monkeypatch.setenv("RV_BUBBLE_PAR_MIN", "0")
     seqs = [g.decode() for g in synth.genomes(300000, 3)]

@@ -102,9 +102,11 @@ struct Align {
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar;
+    HBuf hLeafRoots[2];
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
-    hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
+    bool roots_inflight[2] = {false, false};
     bool leaf_pending[2] = {false, false};   // a leaf launch may still be reading level buffer k
     size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
     std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
@@ -115,7 +117,8 @@ struct Align {
     std::vector<sa_t> cb, ce, mb, me, cut_lo, cut_hi, mend_pos;
     std::vector<uint8_t> cc;
     std::vector<int> ctab_first, mtab_first, cut_first, mend_first, split_subs;
-    std::vector<int64_t> mpre, sub_start, woff, toff;
+    std::vector<int64_t> mpre, sub_start, woff, toff, next_ss;
+    const int64_t *d_next_ss = nullptr;      // device copy of the next level's sub-index starts (inside dTab)
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
@@ -127,12 +130,14 @@ struct Align {
     bool trace_on = false;
     std::vector<rv_trace> trace;
     rv_align_stats st{};
+    double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
+        for (int k = 0; k < 2; k++) if (ev_roots[k]) { (void)hipEventDestroy(ev_roots[k]); ev_roots[k] = nullptr; }
     }
 };
 
@@ -250,7 +255,11 @@ int rv_frontier_scan(rv_index *h) {
     a->mum_first.assign((size_t)ns, 0); a->nmums.assign((size_t)ns, 0);
     if (!a->multi) {
         u32 err = 0;
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->d_err, &err));
+        // built-in picker without tracing: the device keeps only the record the picker would take.  The sub-index starts of this
+        // level came with the previous commit's table upload (a pageable H2D copy here would wait for the stream to drain and
+        // expose the launch latency of the whole scan).
+        const int64_t *d_ss = (a->full_only && a->level > 0) ? a->d_next_ss : nullptr;
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->d_err, &err, d_ss, ns));
         a->d_err = nullptr;
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
         int si = 0;
@@ -481,10 +490,10 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             }
         }
     }
-    // Leading children above par_min ranks take the data-parallel rounds.  Once a level runs those rounds anyway (or has
-    // many cuts per child), the small children join them as long as the window kernels stay small: their one-workgroup
-    // kernel would only add its own latency in front.
-    const bool all_par = (any_par || a->multi) && window_sum <= ((int64_t)64 << 20) && !getenv("RV_BUBBLE_NO_JOIN");
+    // Leading children above par_min ranks take the data-parallel rounds.  Once a level runs those rounds anyway, the small
+    // children join them as long as there are few of them (measured: with thousands of small children per level the
+    // one-workgroup-per-child kernel is the cheaper way, C3/C4): their kernel would only add its own latency in front.
+    const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !getenv("RV_BUBBLE_NO_JOIN");
     for (const auto &kd : a->kid_tmp) {
         if (!all_par && kd.n <= par_min) {             // every cut of this child in one workgroup, sequentially
             RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = 0; bd.wlo = 0; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
@@ -524,6 +533,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         a->toff[k + 1] = a->toff[k] + ceil_div(a->descs[k].n, RV_SPLIT_TILE);
     }
 
+    a->lg[0] = now_s() - t0;      // tables built
     // ---- one upload for all the tables ---------------------------------------------------
     const int64_t ntiles = ceil_div(lv.m, RV_SPLIT_TILE);
     Packer &pk = a->pk;
@@ -534,11 +544,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
+    a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
+    const size_t o_nss = pk.addv(a->next_ss);
     const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
+    a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
+    a->d_next_ss = (const int64_t *)(tb + o_nss);
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));
@@ -584,6 +598,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     h->prof.end(q, id);
     RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
     const double t1 = now_s();
+    a->lg[2] = t1 - t0;           // label/split/lower enqueued
 
     // ---- bubble_sort rounds (reveal.c:1250-1252, :666-727) -----------------------------------
     if (!a->descs.empty() || !a->kids_small.empty() || !a->kids_big.empty()) {
@@ -675,9 +690,10 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         if (!a->leaf_stream) {
             RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
             RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
-            for (int k = 0; k < 2; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming));
+            for (int k = 0; k < 2; k++) { RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming)); RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming)); }
         }
         a->leaf_pending[0] = a->leaf_pending[1] = false;
+        a->roots_inflight[0] = a->roots_inflight[1] = false;
     }
     int leaf_flip = 0;
     const bool level_log = getenv("RV_LEVEL_LOG") != nullptr;      // diagnostics: per-level wall time (adds a sync per level)
@@ -716,7 +732,14 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
                 RV_HIP(hipEventRecord(a->ev_ready, q));
                 RV_HIP(hipStreamWaitEvent(ls, a->ev_ready, 0));
                 RV_TRY(droots.reserve(roots.size() * sizeof(RvLeafRoot)));
-                RV_HIP(hipMemcpyAsync(droots.p, roots.data(), roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, ls));
+                // pinned staging (one per ping-pong slot): a pageable copy would make the host wait for the leaf stream to drain
+                HBuf &hroots = a->hLeafRoots[leaf_flip];
+                if (a->roots_inflight[leaf_flip]) RV_HIP(hipEventSynchronize(a->ev_roots[leaf_flip]));     // copy of two levels ago (long done)
+                RV_TRY(hroots.reserve(roots.size() * sizeof(RvLeafRoot)));
+                memcpy(hroots.p, roots.data(), roots.size() * sizeof(RvLeafRoot));
+                RV_HIP(hipMemcpyAsync(droots.p, hroots.p, roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, ls));
+                RV_HIP(hipEventRecord(a->ev_roots[leaf_flip], ls));
+                a->roots_inflight[leaf_flip] = true;
                 RvLeafArgs la;
                 la.roots = droots.as<RvLeafRoot>();
                 la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
@@ -740,6 +763,7 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
                 }
             }
         }
+        const double tl_leaf = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_scan(h));
         const double t0 = now_s();
         const Level &lv = a->lv;
@@ -830,9 +854,10 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
             const double tl3 = now_s();
             int64_t biggest = 0;
             for (int s2 = 0; s2 < a->lv.size(); s2++) biggest = std::max<int64_t>(biggest, a->lv.n[(size_t)s2]);
-            fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | scan+host %7.1f us  commit(enqueue) %7.1f us  drain %7.1f us | next: subs %d ranks %lld biggest %lld\n",
-                    log_level, log_ns, log_leaf, (long long)log_m, (tl1 - tl0) * 1e6, (tl2 - tl1) * 1e6, (tl3 - tl2) * 1e6,
-                    a->lv.size(), (long long)a->lv.m, (long long)biggest);
+            fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | leafprep %6.1f scan %6.1f host %6.1f | commit: tables %6.1f upload %6.1f split-enq %6.1f bubble-enq %6.1f | drain %7.1f us | next biggest %lld\n",
+                    log_level, log_ns, log_leaf, (long long)log_m, (tl_leaf - tl0) * 1e6, (t0 - tl_leaf) * 1e6, (tl1 - t0) * 1e6,
+                    a->lg[0] * 1e6, (a->lg[1] - a->lg[0]) * 1e6, (a->lg[2] - a->lg[1]) * 1e6, (tl2 - tl1) * 1e6 - a->lg[2] * 1e6, (tl3 - tl2) * 1e6,
+                    (long long)biggest);
         }
     }
     if (use_leaf) {       // collect what the leaf launches produced

@@ -272,7 +272,7 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 // one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
-                     const u32 *d_err, u32 *err_out) {
+                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs) {
     out.clear();
     if (err_out) *err_out = 0;
     if (m <= 1) {
@@ -300,6 +300,27 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
                                       (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err));
+        if (d_sub_start) {
+            // the built-in picker only wants the best record of each sub-index: pick on the device, copy header + nsubs records
+            DBuf &bbest = h->ws.misc[12], &bpick = h->ws.misc[13];
+            RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bpick.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
+            RV_TRY(rv_pair_pick_launch(h->ws, bout.as<RvPairRec>(), (u32)std::min<size_t>(ocap, 0xffffffffu), d_sub_start, nsubs,
+                                       bbest.as<unsigned long long>(), bpick.as<RvPairRec>()));
+            RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
+            RV_HIP(hipMemcpyAsync(h->hscan.p, bpick.p, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
+            RV_HIP(hipStreamSynchronize(q));
+            const u32 *hdr = h->hscan.as<u32>();
+            const u32 total = hdr[0], novf = hdr[1];
+            if (err_out) *err_out = hdr[2];
+            if (total <= ocap && novf <= vcap) {
+                const RvPairRec *src = h->hscan.as<RvPairRec>() + RV_PAIR_HDR;
+                for (int s2 = 0; s2 < nsubs; s2++) if (src[s2].rank != 0xFFFFFFFFu) out.push_back(src[s2]);
+                return 0;
+            }
+            if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
+            if (total > ocap) RV_TRY(bout.reserve(((size_t)total + RV_PAIR_HDR) * sizeof(RvPairRec)));
+            continue;
+        }
         // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
         size_t guess = std::min<size_t>(ocap, h->scan_guess);
         RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));
@@ -411,7 +432,7 @@ int64_t rv_getmums(rv_index *h, int minl) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     (void)hipSetDevice(h->device);
     std::vector<RvPairRec> recs;
-    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs, nullptr, nullptr) != 0) return -1;
+    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs, nullptr, nullptr, nullptr, 0) != 0) return -1;
     h->m_l.resize(recs.size()); h->m_a.resize(recs.size()); h->m_b.resize(recs.size());
     for (size_t k = 0; k < recs.size(); k++) {
         int64_t b = recs[k].b;

@@ -77,7 +77,7 @@ struct Workspace {
     hipStream_t stream = nullptr;
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
-    DBuf misc[12];
+    DBuf misc[16];
     DBuf sa[16];           // SA-build scratch, kept between construct() calls
     void release() {
         for (auto &b : scan_tmp) b.release();

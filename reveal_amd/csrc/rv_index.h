@@ -86,7 +86,7 @@ struct rv_index {
 // scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)
 // d_err (optional): device word copied into the scan header and returned through err_out (deferred error check of the previous commit)
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
-                     const u32 *d_err, u32 *err_out);
+                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs);   // d_sub_start != NULL: only the best record per sub-index
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

@@ -25,6 +25,9 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
                            const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, const u32 *ovf_counter, const u32 *err);
 
+// built-in picker: picks[0] = header, picks[1+s] = longest record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none
+int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks);
+
 #define RV_MULTI_TILE 256
 struct RvMultiRec { u32 l, n, ub, pad; };
 // Multi-MUM scan (getmultimums, reveal.c:436-580).  Records and members of

@@ -176,6 +176,55 @@ __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict
         if (o + q < out_cap) out[o + q] = ovf[ob + (q - RV_PAIR_SLOTS)];
 }
 
+// ---- built-in picker on the device --------------------------------------------------
+// The recursion's built-in callbacks (longest match, ties -> smallest position) need one
+// record per sub-index, not every MUM of the level: two passes over the packed records, an atomicMax on
+// (l, -a) per sub-index and a gather of the winners.  picks[0] = header, picks[1+s] = winner of sub-index s
+// (rank 0xFFFFFFFF = none; the caller fills the buffer with 0xFF).
+__device__ inline int sub_of_rank(const int64_t *__restrict__ sub_start, int nsubs, int64_t r) {
+    int lo = 0, hi = nsubs;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub_start[mid] <= r) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
+__device__ inline u64 pick_key(const RvPairRec &r) { return ((u64)r.l << 32) | (u64)(0xFFFFFFFFu - (u32)r.a); }
+
+__global__ __launch_bounds__(TB) void k_pair_pick1(const RvPairRec *__restrict__ out, u32 out_cap, const int64_t *__restrict__ sub_start, int nsubs,
+                                                   unsigned long long *__restrict__ best) {
+    const u32 total = reinterpret_cast<const u32 *>(out)[0];
+    const u32 n = total < out_cap ? total : out_cap;
+    out += RV_PAIR_HDR;
+    const int lane = threadIdx.x & 63;
+    for (u32 k0 = blockIdx.x * TB; k0 < n; k0 += gridDim.x * TB) {
+        const u32 k = k0 + threadIdx.x;
+        int sub = -1; u64 key = 0;
+        if (k < n) { const RvPairRec r = out[k]; sub = sub_of_rank(sub_start, nsubs, (int64_t)r.rank); key = pick_key(r); }
+        // records are in rank order, so a wave mostly holds one or two sub-indices: one atomic per (wave, sub-index)
+        // instead of one per record (the top levels have tens of thousands of records for a handful of sub-indices)
+        u64 todo = __ballot(sub >= 0);
+        while (todo) {
+            const int leader = (int)__builtin_ctzll(todo);
+            const int lsub = __shfl(sub, leader, 64);
+            const bool mine = sub == lsub;
+            u64 v = mine ? key : 0;
+            for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+            if (lane == leader) atomicMax(&best[lsub], (unsigned long long)v);
+            todo &= ~__ballot(mine);
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void k_pair_pick2(const RvPairRec *__restrict__ out, u32 out_cap, const int64_t *__restrict__ sub_start, int nsubs,
+                                                   const unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks) {
+    const u32 total = reinterpret_cast<const u32 *>(out)[0];
+    const u32 n = total < out_cap ? total : out_cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) picks[0] = out[0];
+    out += RV_PAIR_HDR;
+    for (u32 k = blockIdx.x * TB + threadIdx.x; k < n; k += gridDim.x * TB) {
+        const RvPairRec r = out[k];
+        const int s = sub_of_rank(sub_start, nsubs, (int64_t)r.rank);
+        if (best[s] == (unsigned long long)pick_key(r)) picks[RV_PAIR_HDR + s] = r;
+    }
+}
+
 // ---- multi-MUM scan ------------------------------------------------------------
 // Stack-free form of the LCP-interval enumeration of getmultimums
 // (reveal.c:436-580).  The reference closes an interval (l, lb, ub) when it
@@ -310,6 +359,17 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
     if (m <= 0) return 0;
     const int64_t nb = ceil_div(m, PAIR_TILE);
     hipLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks) {
+    if (nsubs <= 0) return 0;
+    RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
+    RV_HIP(hipMemsetAsync(picks, 0xFF, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), ws.stream));
+    hipLaunchKernelGGL(k_pair_pick1, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, best);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pair_pick2, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, (const unsigned long long *)best, picks);
     RV_LAUNCH_CHECK();
     return 0;
 }

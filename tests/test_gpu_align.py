@@ -119,6 +119,32 @@ def test_parallel_bubble_rounds(monkeypatch, par_min, name, inputs, minl, sa64):
     compare(inputs, minl, 2, sa64=sa64)
 
 
+@pytest.mark.parametrize("name,inputs,minl", [
+    ("1a1b", fa("1a", "1b"), 20),
+    ("1a1b_m10", fa("1a", "1b"), 10),
+    ("d1d2", fa("d1", "d2"), 20),
+    ("synth_pair", None, 20),
+    ("1a1b1c", fa("1a", "1b", "1c"), 20),
+    ("5way", fa("1a", "1b", "1c", "1d", "1e"), 20),
+])
+def test_untraced_run_same_anchors(name, inputs, minl):
+    """align_builtin(trace=False) is what bench.py times: leaf kernel, device-side picker (pair) and pre-selection (multi)
+    are on, the host never sees the full MUM lists -- the anchor set and the final text must not change"""
+    if inputs is None:
+        inputs = [g.decode() for g in synth.genomes(400000, 2)]
+    ref, T = oracle_run(inputs, minl, 2)
+    idx = feed(mod(False).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(minl, 2, trace=False)
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    gl, goff, gpos = got["anchors"]
+    ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
+    assert ra == ga
+    assert idx.T.encode("latin-1") == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"]
+
+
 def test_sequential_bubble_kept(monkeypatch):
     """the one-workgroup-per-child kernels stay the fallback (and the small-level path): keep them covered in multi mode"""
     monkeypatch.setenv("RV_BUBBLE_NO_JOIN", "1")

@@ -107,6 +107,7 @@ struct Align {
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
     hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
     bool roots_inflight[2] = {false, false};
+    bool flag_clean = false;     // dFlag is all zero
     bool leaf_pending[2] = {false, false};   // a leaf launch may still be reading level buffer k
     size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
     std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
@@ -210,7 +211,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->trace_on = keep_trace;
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
-    a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false;
+    a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
     memset(&a->st, 0, sizeof a->st);
     a->lv.clear();
     a->lv.m = h->n;
@@ -605,8 +606,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         RvBubbleArgs ba;
         ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
         ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
-        RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
-        RV_HIP(hipMemsetAsync(a->dFlag.p, 0, (size_t)m_next + 64, q));
+        {   // every bubble kernel leaves the flag bytes it set at zero again: one memset per alignment (and per reallocation) instead of per level
+            const void *before = a->dFlag.p;
+            RV_TRY(a->dFlag.reserve((size_t)m_next + 64));
+            if (!a->flag_clean || a->dFlag.p != before) { RV_HIP(hipMemsetAsync(a->dFlag.p, 0, a->dFlag.cap, q)); a->flag_clean = true; }
+        }
         ba.flag = a->dFlag.as<uint8_t>();
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
         ba.state = (RvBubbleState *)(tb + o_bstate);

@@ -185,7 +185,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     u32 *d_max = h->ws.misc[0].as<u32>();
     if (!lcpfile || !lcpfile[0]) {
         int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
-        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>()));
+        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>()));
         h->prof.end(q, id);
         RV_HIP(hipMemcpyAsync(&h->maxlcp, d_max, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
@@ -282,8 +282,8 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     if (h->nsep.empty()) { rv_set_error("pairwise scan needs at least two samples"); return -1; }
     hipStream_t q = h->ws.stream;
     const int64_t ntile = ceil_div(m, RV_PAIR_TILE);
-    DBuf &bcnt = h->ws.misc[1], &btab = h->ws.misc[2], &bslot = h->ws.misc[3], &bovf = h->ws.misc[4], &bout = h->ws.misc[5];
-    RV_TRY(bcnt.reserve(64));
+    DBuf &bcnt = h->ws.misc[14], &btab = h->ws.misc[2], &bslot = h->ws.misc[3], &bovf = h->ws.misc[4], &bout = h->ws.misc[5];   // misc[14]: the pair scan's own counter (self-resetting)
+    if (bcnt.cap == 0) { RV_TRY(bcnt.reserve(64)); RV_HIP(hipMemsetAsync(bcnt.p, 0, 64, q)); }      // counters return to zero by themselves afterwards
     RV_TRY(btab.reserve((size_t)(ntile + 1) * 3 * sizeof(u32)));
     RV_TRY(bslot.reserve((size_t)ntile * RV_PAIR_SLOTS * sizeof(RvPairRec)));
     if (bovf.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bovf.reserve(4096 * sizeof(RvPairRec)));
@@ -291,19 +291,18 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
     for (int attempt = 0; attempt < 3; attempt++) {
         const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
-        RV_HIP(hipMemsetAsync(bcnt.p, 0, 8, q));
-        RV_HIP(hipMemsetAsync(tilecnt + ntile, 0, 4, q));
         int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
         RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
                                    (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf));
         h->prof.end(q, id);
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
+        DBuf &bbest = h->ws.misc[12], &bpick = h->ws.misc[13];
+        if (d_sub_start) { RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bpick.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec))); }
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
-                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err));
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err,
+                                      bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), d_sub_start ? nsubs : 0));
         if (d_sub_start) {
             // the built-in picker only wants the best record of each sub-index: pick on the device, copy header + nsubs records
-            DBuf &bbest = h->ws.misc[12], &bpick = h->ws.misc[13];
-            RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bpick.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
             RV_TRY(rv_pair_pick_launch(h->ws, bout.as<RvPairRec>(), (u32)std::min<size_t>(ocap, 0xffffffffu), d_sub_start, nsubs,
                                        bbest.as<unsigned long long>(), bpick.as<RvPairRec>()));
             RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));

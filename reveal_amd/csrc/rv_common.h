@@ -78,7 +78,7 @@ struct Workspace {
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf misc[16];
-    DBuf sa[16];           // SA-build scratch, kept between construct() calls
+    DBuf sa[18];           // SA-build scratch, kept between construct() calls
     void release() {
         for (auto &b : scan_tmp) b.release();
         rs_hist.release();
@@ -113,6 +113,7 @@ struct RvSaStats {
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st);
 int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT);
+// SAi given: text-order (Kasai) evaluation; NULL: every rank from scratch
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT);
 // BWT only (when LCP came from a file)
 int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT);

@@ -3,12 +3,13 @@
 // Replaces the reference's construct() pipeline (reveallib/interface.c:160-291):
 //   divsufsort(T,SA,n)            interface.c:215-222  -> rv_build_sa   (prefix doubling + radix sort)
 //   SAi[SA[i]]=i                  interface.c:236-238  -> rv_build_inverse
-//   compute_lcp (Kasai, stops at '$'/'N')  interface.c:97-114 -> rv_build_lcp (closed form, one thread per rank)
+//   compute_lcp (Kasai, stops at '$'/'N')  interface.c:97-114 -> rv_build_lcp (text order with the h-1 carry; or closed form, one thread per rank)
 //
 // A suffix array is unique for a text (unsigned byte order, shorter suffix
 // first), so prefix doubling yields divsufsort's SA bit for bit.
 #include "rv_common.h"
 #include <string.h>
+#include <stdlib.h>
 
 #ifdef RV_SA64
 typedef u64 sav_t;   // suffix ids as radix-sort payload
@@ -334,7 +335,94 @@ __global__ __launch_bounds__(TB) void k_lcp(const uint8_t *__restrict__ T, const
     if (k < n) LCP[k] = (lcp_t)h;
     u32 m = h;
     for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_down(m, d, 64); m = o > m ? o : m; }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxlcp, m);
+    // one address for the whole grid: only waves that would raise the maximum go to the atomic unit
+    // (an unconditional atomic per wave serialised the kernel: 1.8 ms of 1.9 ms at n = 1e7)
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(maxlcp, __ATOMIC_RELAXED)) atomicMax(maxlcp, m);
+}
+
+// The same LCP in text order (Kasai's invariant): if suffix p shares h symbols with its predecessor in
+// the suffix array, suffix p+1 shares at least h-1 with its own predecessor -- also with the '$'/'N' stops,
+// because the h symbols that matched contained no stop.  One thread walks PHI_K consecutive text positions
+// and only ever compares the symbols beyond h-1, so closely related genomes (long matches) cost about
+// two word compares per position instead of lcp/8.  PLCP[p] is written in text order; k_lcp_gather turns
+// it into LCP[k] = PLCP[SA[k]] and emits BWT and the maximum.
+// A lane whose match goes on after the first word (a new long match right behind a difference) does not loop on
+// its own -- that would stall the other 63 lanes for lcp/8 steps almost every iteration -- the wave compares 64
+// consecutive words of that lane's two suffixes at once.
+constexpr int PHI_K = 32, PHI_B = 8;
+__device__ inline u64 stop_mask(u64 wa, u64 wb) {
+    u64 stop = (wa ^ wb);
+    stop |= zero_bytes(wb ^ 0x2424242424242424ull);   // '$'
+    stop |= zero_bytes(wb ^ 0x4E4E4E4E4E4E4E4Eull);   // 'N'
+    stop |= zero_bytes(wb);                            // end of text (zero padding)
+    return stop;
+}
+__global__ __launch_bounds__(TB) void k_plcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, const sa_t *__restrict__ SAi,
+                                             u32 *__restrict__ PLCP, int64_t n) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * PHI_K;      // (whole waves run past n together: no early return, ballots below)
+    u32 h = 0;
+#pragma unroll 1
+    for (int b = 0; b < PHI_K; b += PHI_B) {
+        int64_t r[PHI_B], q[PHI_B];
+#pragma unroll
+        for (int j = 0; j < PHI_B; j++) { const int64_t p = p0 + b + j; r[j] = p < n ? (int64_t)SAi[p] : 0; }
+#pragma unroll
+        for (int j = 0; j < PHI_B; j++) q[j] = r[j] > 0 ? (int64_t)SA[r[j] - 1] : -1;
+#pragma unroll
+        for (int j = 0; j < PHI_B; j++) {
+            const int64_t p = p0 + b + j;
+            const bool act = p < n && q[j] >= 0;
+            bool more = false;
+            if (p < n && q[j] < 0) h = 0;                                       // rank 0 has no predecessor
+            if (act) {
+                const u64 stop = stop_mask(load8(T + q[j] + h), load8(T + p + h));
+                if (stop) h += (u32)(__builtin_ctzll(stop) >> 3); else { h += 8; more = true; }
+            }
+            u64 todo = __ballot(more);
+            while (todo) {
+                const int l = (int)__builtin_ctzll(todo);
+                const int64_t qa = __shfl((long long)q[j], l, 64), pb = __shfl((long long)p, l, 64);
+                u32 hl = (u32)__shfl((int)h, l, 64);
+                for (;;) {
+                    const int64_t off = (int64_t)hl + 8 * lane;
+                    // the text is zero padded for 64 bytes only: words that would start beyond count as "end of text"
+                    const u64 wa = (qa + off < n + 48) ? load8(T + qa + off) : 0ull;
+                    const u64 wb = (pb + off < n + 48) ? load8(T + pb + off) : 0ull;
+                    const u64 stop = stop_mask(wa, wb);
+                    const u64 bal = __ballot(stop != 0);
+                    if (bal) {
+                        const int f = (int)__builtin_ctzll(bal);
+                        const u32 lo = (u32)__shfl((int)(u32)stop, f, 64), hi = (u32)__shfl((int)(u32)(stop >> 32), f, 64);
+                        const u64 st = ((u64)hi << 32) | lo;
+                        hl += 8u * (u32)f + (u32)(__builtin_ctzll(st) >> 3);
+                        break;
+                    }
+                    hl += 512;
+                }
+                if (lane == l) h = hl;
+                todo &= todo - 1;
+            }
+            if (p < n) PLCP[p] = h;
+            h = h > 0 ? h - 1 : 0;
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void k_lcp_gather(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, const u32 *__restrict__ PLCP,
+                                                   lcp_t *__restrict__ LCP, int64_t n, u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT) {
+    const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 h = 0;
+    if (k < n) {
+        const sa_t p = SA[k];
+        h = PLCP[p];
+        LCP[k] = (lcp_t)h;
+        if (BWT) BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$';
+    }
+    u32 m = h;
+    for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_down(m, d, 64); m = o > m ? o : m; }
+    // one address for the whole grid: only waves that would raise the maximum go to the atomic unit
+    // (an unconditional atomic per wave serialised the kernel: 1.8 ms of 1.9 ms at n = 1e7)
+    if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(maxlcp, __ATOMIC_RELAXED)) atomicMax(maxlcp, m);
 }
 
 __global__ __launch_bounds__(TB) void k_bwt(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, int64_t n, uint8_t *__restrict__ BWT) {
@@ -360,10 +448,19 @@ int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uin
     return 0;
 }
 
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT) {
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT) {
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
-    hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT);
+    if (!SAi || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
+        hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT);
+        RV_LAUNCH_CHECK();
+        return 0;
+    }
+    DBuf &plcp = ws.sa[6];                         // a u32 per position; the SA build is done with its scratch
+    RV_TRY(plcp.reserve((size_t)n * 4));
+    hipLaunchKernelGGL(k_plcp, dim3((unsigned)ceil_div(ceil_div(n, PHI_K), TB)), dim3(TB), 0, ws.stream, T, SA, SAi, plcp.as<u32>(), n);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lcp_gather, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, (const u32 *)plcp.as<u32>(), LCP, n, d_maxlcp, BWT);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -376,7 +473,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     hipStream_t q = ws.stream;
 
     // -- alphabet -> order-preserving dense codes (0 is reserved for "past the end")
-    DBuf d_hist, d_lut;
+    DBuf &d_hist = ws.sa[16], &d_lut = ws.sa[17];
     RV_TRY(d_hist.reserve(256 * sizeof(u32)));
     RV_TRY(d_lut.reserve(256));
     RV_HIP(hipMemsetAsync(d_hist.p, 0, 256 * sizeof(u32), q));
@@ -409,7 +506,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
     DBuf &bk0 = ws.sa[0], &bk1 = ws.sa[1], &bv0 = ws.sa[2], &bv1 = ws.sa[3], &bhead = ws.sa[4], &bseed = ws.sa[5], &bgrp = ws.sa[6], &bisa = ws.sa[7],
          &bP0 = ws.sa[8], &bP1 = ws.sa[9], &bG0 = ws.sa[10], &bG1 = ws.sa[11], &btile = ws.sa[12], &bbig = ws.sa[13], &bQb = ws.sa[14], &bPb = ws.sa[15];
-    auto freeall = [&]() { d_hist.release(); d_lut.release(); };
+    auto freeall = [&]() {};
 #define SA_TRY(x) do { int r__ = (x); if (r__) { freeall(); return r__; } } while (0)
 #define SA_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rv_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); freeall(); return -1; } } while (0)
     SA_TRY(bk0.reserve((size_t)n * 8)); SA_TRY(bk1.reserve((size_t)n * 8));

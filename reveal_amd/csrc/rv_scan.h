@@ -15,15 +15,17 @@ struct RvPairRec {
 #define RV_PAIR_SLOTS 32
 // Streams SA/LCP/BWT[0..m) once.  The first RV_PAIR_SLOTS survivors of tile t
 // (2048 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
-// ovf[tileovf[t] ..] (*ovf_counter zeroed by the caller); tilecnt[t] = number of
-// survivors.  rv_pair_compact_launch packs them densely in rank order given
+// ovf[tileovf[t] ..] (*ovf_counter must be zero: rv_pair_compact_launch leaves it so);
+// tilecnt[t] = number of survivors, tilecnt[ntile] = 0.  rv_pair_compact_launch packs them densely in rank order given
 // tileoff = exclusive scan of tilecnt.
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
                         RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf);
-// out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records
+// out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records.
+// Resets *ovf_counter for the next scan; with nsubs > 0 also initialises the picker tables (best, picks).
 #define RV_PAIR_HDR 1
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, const u32 *ovf_counter, const u32 *err);
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err,
+                           unsigned long long *best, RvPairRec *picks, int nsubs);
 
 // built-in picker: picks[0] = header, picks[1+s] = longest record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none
 int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks);

@@ -53,6 +53,7 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     // block-wide append at the end of a tile then no longer overlaps with another block's loads)
     const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_ITEMS;
+    if (blockIdx.x == 0 && threadIdx.x == 0) tilecnt[gridDim.x] = 0;      // the slot that makes the exclusive scan yield the total
 
     sa_t sa[PAIR_ITEMS];
     lcp_t lc[PAIR_ITEMS];
@@ -157,12 +158,16 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf,
                                                      const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf,
                                                      const u32 *__restrict__ tileoff, int64_t ntile, RvPairRec *__restrict__ out, u32 out_cap,
-                                                     const u32 *__restrict__ ovf_counter, const u32 *__restrict__ err) {
+                                                     u32 *__restrict__ ovf_counter, const u32 *__restrict__ err,
+                                                     unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks, int nsubs) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (id == 0) {
         u32 *hdr = reinterpret_cast<u32 *>(out);
         hdr[0] = tileoff[ntile]; hdr[1] = *ovf_counter; hdr[2] = err ? *err : 0u; hdr[3] = 0;
+        *ovf_counter = 0;          // the scan of this launch sequence is done with it: ready for the next scan (no memset per level)
     }
+    // tables of the device-side picker that runs next (k_pair_pick1/2)
+    for (int64_t s2 = id; s2 < nsubs; s2 += (int64_t)gridDim.x * TB) { best[s2] = 0; picks[RV_PAIR_HDR + s2].rank = 0xFFFFFFFFu; }
     out += RV_PAIR_HDR;
     const int64_t t = id / RV_PAIR_SLOTS;
     const u32 j = (u32)(id % RV_PAIR_SLOTS);
@@ -365,8 +370,6 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
 
 int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks) {
     if (nsubs <= 0) return 0;
-    RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
-    RV_HIP(hipMemsetAsync(picks, 0xFF, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), ws.stream));
     hipLaunchKernelGGL(k_pair_pick1, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, best);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pair_pick2, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, (const unsigned long long *)best, picks);
@@ -375,10 +378,11 @@ int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const 
 }
 
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, const u32 *ovf_counter, const u32 *err) {
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err,
+                           unsigned long long *best, RvPairRec *picks, int nsubs) {
     if (ntile <= 0) return 0;
     hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB)), dim3(TB), 0, ws.stream, slots, ovf, tilecnt, tileovf,
-                       tileoff, ntile, out, out_cap, ovf_counter, err);
+                       tileoff, ntile, out, out_cap, ovf_counter, err, best, picks, nsubs);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -118,6 +118,7 @@ struct Align {
     std::vector<sa_t> cb, ce, mb, me, cut_lo, cut_hi, mend_pos;
     std::vector<uint8_t> cc;
     std::vector<int> ctab_first, mtab_first, cut_first, mend_first, split_subs;
+    std::vector<u32> sub_off_h;
     std::vector<int64_t> mpre, sub_start, woff, toff, next_ss;
     const int64_t *d_next_ss = nullptr;      // device copy of the next level's sub-index starts (inside dTab)
     std::vector<u32> child_base, child_n;
@@ -542,12 +543,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_cb = pk.addv(a->cb), o_ce = pk.addv(a->ce), o_cc = pk.addv(a->cc), o_mb = pk.addv(a->mb), o_me = pk.addv(a->me), o_mpre = pk.addv(a->mpre);
     const size_t o_ctf = pk.addv(a->ctab_first), o_mtf = pk.addv(a->mtab_first);
     const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
-    const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi), o_split = pk.addv(a->split_subs);
+    const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
     const size_t o_nss = pk.addv(a->next_ss);
-    const size_t o_suboff = pk.reserve((size_t)ns * 3 * 4), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
+    a->sub_off_h.assign((size_t)ns * 3, 0);
+    u32 class_total[4] = {0, 0, 0, 0};
+    for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
+    const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
@@ -578,10 +582,6 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     lt.sub_start = (const int64_t *)(tb + o_ss); lt.nsubs = ns;
     lt.ctab_first = (const int *)(tb + o_ctf); lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc;
     lt.mtab_first = (const int *)(tb + o_mtf); lt.mbegin = (const sa_t *)(tb + o_mb); lt.mend = (const sa_t *)(tb + o_me); lt.nmatch = (int)a->mb.size();
-    int id = h->prof.begin(q, RV_K_LABEL, (double)lv.m * (sizeof(sa_t) + 1));
-    RV_TRY(rv_label_launch(h->ws, cur_sa(h), lv.m, lt, a->dD.as<uint8_t>()));
-    h->prof.end(q, id);
-
     RvSplitArgs sa;
     u32 *tiles = a->dTile.as<u32>();
     sa.ntiles = ntiles;
@@ -589,13 +589,13 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.tile_G = tiles + 9 * ntiles; sa.tile_carry = tiles + 12 * ntiles;
     sa.total = (u32 *)(tb + o_total);
     sa.sub_start = lt.sub_start; sa.nsubs = ns;
-    sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (u32 *)(tb + o_suboff);
+    sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (const u32 *)(tb + o_suboff); sa.expect_total = (const u32 *)(tb + o_expect);
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
     sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = (u32 *)(tb + o_err);
-    id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
-    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, sa, (const int *)(tb + o_split), (int)a->split_subs.size()));
+    int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
+    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
     h->prof.end(q, id);
     RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
     const double t1 = now_s();

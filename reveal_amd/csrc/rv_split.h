@@ -29,7 +29,8 @@ struct RvSplitArgs {
     int            nsubs;
     const u32     *child_base;              // [nsubs*3] first slot of lead/trail/par child in the next level
     const u32     *child_n;                 // [nsubs*3] expected sizes
-    u32           *sub_off;                 // [nsubs*3] child_base - (class count before the sub), by k_seg_offsets
+    const u32     *sub_off;                 // [nsubs*3] child_base - (class count before the sub); the host knows the child sizes, so it knows this too
+    const u32     *expect_total;            // [3] class totals the child sizes add up to (checked against the labels)
     // windows [cut_lo, cut_hi) in front of the cuts of each sub's leading child
     const int     *cut_first;               // [nsubs+1]
     const sa_t    *cut_lo, *cut_hi;
@@ -95,9 +96,9 @@ struct RvBubbleArgs {
     u32   *err;
 };
 
-int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs &t, uint8_t *D);
-int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, const uint8_t *BWT, int64_t m, const RvSplitArgs &a,
-                    const int *d_split_subs, int nsplit);
+// D-label + stable 3-way partition of every split sub-index (D: one scratch byte per rank)
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D, const uint8_t *BWT, int64_t m, const RvLabelTabs &t, const RvSplitArgs &a,
+                    int nsplit);
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
 // descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
 #define RV_BUBBLE_BIG_N 16384

@@ -51,31 +51,32 @@ __device__ inline int find_in(const P *__restrict__ begins, int first, int last,
     return r < 0 ? -1 : first + r;
 }
 
-__global__ __launch_bounds__(TB) void k_label(const sa_t *__restrict__ SA, int64_t m, RvLabelTabs t, uint8_t *__restrict__ D) {
-    const int64_t i0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 4;
-    if (i0 >= m) return;
-    int s = upper_idx<int64_t>(t.sub_start, t.nsubs, i0);
-    int64_t s_end = t.sub_start[s + 1];
-    uint8_t d[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint8_t c = 0;
-        const int64_t i = i0 + k;
-        if (i < m) {
-            while (i >= s_end) { s++; s_end = t.sub_start[s + 1]; }
-            const sa_t pos = SA[i];
-            int e = find_in<sa_t>(t.cbegin, t.ctab_first[s], t.ctab_first[s + 1], pos);
-            if (e >= 0 && pos < t.cend[e]) c = t.ccls[e];
-            e = find_in<sa_t>(t.mbegin, t.mtab_first[s], t.mtab_first[s + 1], pos);
-            if (e >= 0 && pos < t.mend[e]) c = 3;
-        }
-        d[k] = c;
+// number of entries of the ascending array a[0..n) that are <= key, by one wave (64 probes per step)
+__device__ inline int wave_count_le(const int64_t *__restrict__ a, int n, int64_t key) {
+    const int lane = threadIdx.x & 63;
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int step = (hi - lo + 63) / 64;
+        const int p = lo + lane * step;
+        const bool le = p < hi && a[p] <= key;
+        const int c = (int)__popcll(__ballot(le));
+        if (c == 0) { hi = lo; break; }
+        const int last = lo + (c - 1) * step;
+        const int nxt = last + step;
+        lo = last + 1;
+        hi = nxt < hi ? nxt : hi;
     }
-    if (i0 + 4 <= m) {
-        *reinterpret_cast<uchar4 *>(D + i0) = make_uchar4(d[0], d[1], d[2], d[3]);
-    } else {
-        for (int k = 0; k < 4 && i0 + k < m; k++) D[i0 + k] = d[k];
-    }
+    return lo;
+}
+
+// D-label of text position pos inside sub-index s (gather form of reveal.c:1024-1116)
+__device__ inline uint8_t label_of(const RvLabelTabs &t, int s, sa_t pos) {
+    uint8_t c = 0;
+    int e = find_in<sa_t>(t.cbegin, t.ctab_first[s], t.ctab_first[s + 1], pos);
+    if (e >= 0 && pos < t.cend[e]) c = t.ccls[e];
+    e = find_in<sa_t>(t.mbegin, t.mtab_first[s], t.mtab_first[s + 1], pos);
+    if (e >= 0 && pos < t.mend[e]) c = 3;
+    return c;
 }
 
 // ---- split -------------------------------------------------------------------
@@ -87,11 +88,119 @@ __device__ inline MinSt ms_combine(MinSt a, MinSt b) {   // a then b
     return r;
 }
 
-template <bool EMIT>
-__global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ D,
-                                              const uint8_t *__restrict__ BWT, int64_t m, RvSplitArgs a) {
+// thread summaries of SP_ITEMS ranks (labels d[1..], previous label d[0], effective LCP ev) and their wave-inclusive scans
+__device__ inline void split_summaries(const uint8_t *d, const u32 *ev, u32 *icnt, MinSt *ist) {
+    const int lane = threadIdx.x & 63;
+    u32 cnt[3] = {0, 0, 0};
+    MinSt st[3] = {{0, INF}, {0, INF}, {0, INF}};
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) st[c].val = st[c].val < ev[k] ? st[c].val : ev[k];
+        const int c = cls_index(d[k + 1]);
+        if (c >= 0) { cnt[c]++; st[c].has = 1; st[c].val = INF; }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; c++) { icnt[c] = cnt[c]; ist[c] = st[c]; }
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const u32 tc = __shfl_up(icnt[c], dd, 64);
+            MinSt tm; tm.has = __shfl_up(ist[c].has, dd, 64); tm.val = __shfl_up(ist[c].val, dd, 64);
+            if (lane >= dd) { icnt[c] += tc; ist[c] = ms_combine(tm, ist[c]); }
+        }
+    }
+}
+
+// Pass 1: D-labels of a 2048-rank tile (written for pass 2) and, from them, the tile's class counts and
+// running-minimum summaries.  The owning sub-index is searched once per tile (one wave, 64 probes per
+// step); a thread then only steps forward from there.
+__global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, RvLabelTabs t, RvSplitArgs a,
+                                                    uint8_t *__restrict__ D) {
     __shared__ u32   s_cnt[TB / 64][3];
     __shared__ MinSt s_ms[TB / 64][3];
+    __shared__ int   s_sub0;
+    __shared__ uint8_t s_last[TB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t tlo = tile * SP_TILE;
+    if (threadIdx.x < 64) {
+        const int c = wave_count_le(t.sub_start, t.nsubs, tlo);
+        if (lane == 0) s_sub0 = c - 1;
+    }
+    __syncthreads();
+    const int64_t j0 = tlo + (int64_t)threadIdx.x * SP_ITEMS;
+    int s = s_sub0;
+    uint8_t d[SP_ITEMS + 1];
+    u32 ev[SP_ITEMS];
+#pragma unroll
+    for (int k = 0; k <= SP_ITEMS; k++) d[k] = 0;
+    if (j0 < m) {
+        int64_t s_end = t.sub_start[s + 1];
+        for (int step = 0; j0 >= s_end && step < 4; step++) { s++; s_end = t.sub_start[s + 1]; }
+        if (j0 >= s_end) { s += upper_idx<int64_t>(t.sub_start + s, t.nsubs - s, j0); s_end = t.sub_start[s + 1]; }
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int64_t i = j0 + k;
+            if (i < m) {
+                while (i >= s_end) { s++; s_end = t.sub_start[s + 1]; }
+                d[k + 1] = label_of(t, s, SA[i]);
+            }
+        }
+    }
+    // label of the rank in front of my first one
+    {
+        const int up = __shfl_up((int)d[SP_ITEMS], 1, 64);
+        if (lane == 63) s_last[w] = d[SP_ITEMS];
+        __syncthreads();
+        if (lane > 0) d[0] = (uint8_t)up;
+        else if (w > 0) d[0] = s_last[w - 1];
+        else if (j0 > 0 && j0 - 1 < m) {                          // first thread of the tile: label the rank before the tile
+            const int sp = (j0 - 1 >= t.sub_start[s_sub0]) ? s_sub0 : s_sub0 - 1;
+            d[0] = label_of(t, sp, SA[j0 - 1]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SP_ITEMS; k++) {
+        const int64_t j = j0 + k;
+        ev[k] = (d[k] != 0 && j < m) ? (u32)LCP[j] : INF;
+    }
+    if (j0 + SP_ITEMS <= m) {
+        u64 pack = 0;
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) pack |= (u64)d[k + 1] << (8 * k);
+        *reinterpret_cast<u64 *>(D + j0) = pack;
+    } else {
+        for (int k = 0; k < SP_ITEMS && j0 + k < m; k++) D[j0 + k] = d[k + 1];
+    }
+    u32 icnt[3]; MinSt ist[3];
+    split_summaries(d, ev, icnt, ist);
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s_cnt[w][c] = icnt[c]; s_ms[w][c] = ist[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        u32 tot = 0; MinSt ms = {0, INF};
+        for (int k = 0; k < TB / 64; k++) { tot += s_cnt[k][c]; ms = ms_combine(ms, s_ms[k][c]); }
+        a.tile_cnt[(size_t)c * a.ntiles + tile] = tot;
+        a.tile_has[(size_t)c * a.ntiles + tile] = ms.has;
+        a.tile_post[(size_t)c * a.ntiles + tile] = ms.val;
+    }
+}
+
+// Pass 2: stable 3-way partition.  A tile's survivors are staged in LDS class by class and leave as
+// consecutive stores (one thread per survivor): written straight from the scan order, every store
+// instruction touched 64 different cache lines.
+__global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ D,
+                                                   const uint8_t *__restrict__ BWT, int64_t m, RvSplitArgs a) {
+    __shared__ u32   s_cnt[TB / 64][3];
+    __shared__ MinSt s_ms[TB / 64][3];
+    __shared__ sa_t  o_sa[SP_TILE];
+    __shared__ u32   o_lcp[SP_TILE], o_np[SP_TILE];
+    __shared__ uint8_t o_bw[SP_TILE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t j0 = tile * SP_TILE + (int64_t)threadIdx.x * SP_ITEMS;
@@ -107,131 +216,119 @@ __global__ __launch_bounds__(TB) void k_split(const sa_t *__restrict__ SA, const
         d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
         const u32 l = (j < m) ? (u32)LCP[j] : INF;
         ev[k] = (d[k] != 0 && j < m) ? l : INF;
-        if (EMIT) { sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0; }
+        sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0;
     }
-    // thread summaries
-    u32 cnt[3] = {0, 0, 0};
-    MinSt st[3] = {{0, INF}, {0, INF}, {0, INF}};
-#pragma unroll
-    for (int k = 0; k < SP_ITEMS; k++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) st[c].val = st[c].val < ev[k] ? st[c].val : ev[k];
-        const int c = cls_index(d[k + 1]);
-        if (c >= 0) { cnt[c]++; st[c].has = 1; st[c].val = INF; }
-    }
-    // wave-inclusive scans
     u32 icnt[3]; MinSt ist[3];
-#pragma unroll
-    for (int c = 0; c < 3; c++) { icnt[c] = cnt[c]; ist[c] = st[c]; }
-#pragma unroll
-    for (int dd = 1; dd < 64; dd <<= 1) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const u32 tc = __shfl_up(icnt[c], dd, 64);
-            MinSt tm; tm.has = __shfl_up(ist[c].has, dd, 64); tm.val = __shfl_up(ist[c].val, dd, 64);
-            if (lane >= dd) { icnt[c] += tc; ist[c] = ms_combine(tm, ist[c]); }
-        }
-    }
+    split_summaries(d, ev, icnt, ist);
     if (lane == 63) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { s_cnt[w][c] = icnt[c]; s_ms[w][c] = ist[c]; }
     }
     __syncthreads();
-    if (!EMIT) {
-        if (threadIdx.x < 3) {
-            const int c = threadIdx.x;
-            u32 tot = 0; MinSt ms = {0, INF};
-            for (int k = 0; k < TB / 64; k++) { tot += s_cnt[k][c]; ms = ms_combine(ms, s_ms[k][c]); }
-            a.tile_cnt[(size_t)c * a.ntiles + tile] = tot;
-            a.tile_has[(size_t)c * a.ntiles + tile] = ms.has;
-            a.tile_post[(size_t)c * a.ntiles + tile] = ms.val;
-        }
-        return;
-    }
-    // exclusive prefixes for this thread: tile carry-in, earlier waves, earlier lanes
-    u32 ecnt[3]; MinSt est[3];
+    // exclusive prefixes for this thread: tile carry-in, earlier waves, earlier lanes; lds = slot in the staging arrays
+    u32 ecnt[3], lds[3], tot[3]; MinSt est[3];
 #pragma unroll
     for (int c = 0; c < 3; c++) {
-        u32 bc = a.tile_G[(size_t)c * a.ntiles + tile];
+        const u32 g = a.tile_G[(size_t)c * a.ntiles + tile];
+        u32 bc = 0; tot[c] = 0;
         MinSt bm; bm.has = 0; bm.val = a.tile_carry[(size_t)c * a.ntiles + tile];
-        for (int k = 0; k < w; k++) { bc += s_cnt[k][c]; bm = ms_combine(bm, s_ms[k][c]); }
+        for (int k = 0; k < TB / 64; k++) { if (k < w) { bc += s_cnt[k][c]; bm = ms_combine(bm, s_ms[k][c]); } tot[c] += s_cnt[k][c]; }
         u32 xc = __shfl_up(icnt[c], 1, 64);
         MinSt xm; xm.has = __shfl_up(ist[c].has, 1, 64); xm.val = __shfl_up(ist[c].val, 1, 64);
         if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
-        ecnt[c] = bc + xc;
+        ecnt[c] = g + bc + xc;
+        lds[c] = bc + xc;
         est[c] = ms_combine(bm, xm);
     }
-    if (j0 >= m) return;
-    // owning sub-index of my first rank, then walk.  The sub-index' small tables
-    // (child offsets, first two cut windows / matched ends) are pulled into
-    // registers whenever the sub-index changes -- usually once per thread --
-    // instead of being re-read from global memory per rank.
-    int s = upper_idx<int64_t>(a.sub_start, a.nsubs, j0);
-    int64_t s_end = a.sub_start[s + 1];
-    u32 run[3] = {est[0].val, est[1].val, est[2].val};
-    u32 cbase[3], coff[3];
-    int qc0 = 0, qc1 = 0, qm0 = 0, qm1 = 0;
-    sa_t clo[2] = {0, 0}, chi[2] = {0, 0}, mnd[2] = {-1, -1};
-    auto load_sub = [&](int ss) {
+    lds[1] += tot[0]; lds[2] += tot[0] + tot[1];
+    if (j0 < m) {
+        // owning sub-index of my first rank, then walk.  The sub-index' small tables (child offsets, first two cut
+        // windows / matched ends) are pulled into registers whenever the sub-index changes -- usually once per thread.
+        int s = upper_idx<int64_t>(a.sub_start, a.nsubs, j0);
+        int64_t s_end = a.sub_start[s + 1];
+        u32 run[3] = {est[0].val, est[1].val, est[2].val};
+        u32 cbase[3], coff[3], cn[3];
+        int qc0 = 0, qc1 = 0, qm0 = 0, qm1 = 0;
+        sa_t clo[2] = {0, 0}, chi[2] = {0, 0}, mnd[2] = {-1, -1};
+        auto load_sub = [&](int ss) {
 #pragma unroll
-        for (int c = 0; c < 3; c++) { cbase[c] = a.child_base[(size_t)ss * 3 + c]; coff[c] = a.sub_off[(size_t)ss * 3 + c]; }
-        qc0 = a.cut_first[ss]; qc1 = a.cut_first[ss + 1]; qm0 = a.mend_first[ss]; qm1 = a.mend_first[ss + 1];
+            for (int c = 0; c < 3; c++) { cbase[c] = a.child_base[(size_t)ss * 3 + c]; coff[c] = a.sub_off[(size_t)ss * 3 + c]; cn[c] = a.child_n[(size_t)ss * 3 + c]; }
+            qc0 = a.cut_first[ss]; qc1 = a.cut_first[ss + 1]; qm0 = a.mend_first[ss]; qm1 = a.mend_first[ss + 1];
 #pragma unroll
-        for (int k = 0; k < 2; k++) {
-            clo[k] = (qc0 + k < qc1) ? a.cut_lo[qc0 + k] : (sa_t)0;
-            chi[k] = (qc0 + k < qc1) ? a.cut_hi[qc0 + k] : (sa_t)0;
-            mnd[k] = (qm0 + k < qm1) ? a.mend_pos[qm0 + k] : (sa_t)-1;
-        }
-    };
-    load_sub(s);
-#pragma unroll
-    for (int k = 0; k < SP_ITEMS; k++) {
-        const int64_t j = j0 + k;
-        if (j >= m) break;
-        if (j >= s_end) { do { s++; s_end = a.sub_start[s + 1]; } while (j >= s_end); load_sub(s); }
-#pragma unroll
-        for (int c = 0; c < 3; c++) run[c] = run[c] < ev[k] ? run[c] : ev[k];
-        const int c = cls_index(d[k + 1]);
-        if (c >= 0) {
-            const u32 np = coff[c] + ecnt[c];                            // mod 2^32
-            const u32 idx = np - cbase[c];                               // rank inside the child
-            a.SA_out[np] = sa[k];
-            a.LCP_out[np] = (lcp_t)(idx == 0 ? 0u : run[c]);
-            uint8_t bo = bw[k];
-            if (c == 1) {   // trailing child: the character in front of a suffix that starts right behind a
-                            // matched range has just been lower-cased (reveal.c:1230-1234)
-                bool hit = (sa[k] == mnd[0]) || (sa[k] == mnd[1]);
-                for (int q = qm0 + 2; q < qm1 && !hit; q++) hit = sa[k] == a.mend_pos[q];
-                if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
+            for (int k = 0; k < 2; k++) {
+                clo[k] = (qc0 + k < qc1) ? a.cut_lo[qc0 + k] : (sa_t)0;
+                chi[k] = (qc0 + k < qc1) ? a.cut_hi[qc0 + k] : (sa_t)0;
+                mnd[k] = (qm0 + k < qm1) ? a.mend_pos[qm0 + k] : (sa_t)-1;
             }
-            a.BWT_out[np] = bo;
-            if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
-                bool hit = (sa[k] >= clo[0] && sa[k] < chi[0]) || (sa[k] >= clo[1] && sa[k] < chi[1]);
-                for (int q = qc0 + 2; q < qc1 && !hit; q++) hit = sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q];
-                if (hit) a.SAi[sa[k]] = (sa_t)idx;
+        };
+        load_sub(s);
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int64_t j = j0 + k;
+            if (j >= m) break;
+            if (j >= s_end) { do { s++; s_end = a.sub_start[s + 1]; } while (j >= s_end); load_sub(s); }
+#pragma unroll
+            for (int c = 0; c < 3; c++) run[c] = run[c] < ev[k] ? run[c] : ev[k];
+            const int c = cls_index(d[k + 1]);
+            if (c >= 0) {
+                const u32 np = coff[c] + ecnt[c];                            // mod 2^32
+                const u32 idx = np - cbase[c];                               // rank inside the child
+                uint8_t bo = bw[k];
+                if (c == 1) {   // trailing child: the character in front of a suffix that starts right behind a
+                                // matched range has just been lower-cased (reveal.c:1230-1234)
+                    bool hit = (sa[k] == mnd[0]) || (sa[k] == mnd[1]);
+                    for (int q = qm0 + 2; q < qm1 && !hit; q++) hit = sa[k] == a.mend_pos[q];
+                    if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
+                }
+                if (idx >= cn[c]) {
+                    atomicOr(a.err, 1u);                                     // more ranks labelled for this child than its intervals hold
+                    o_np[lds[c]] = 0xFFFFFFFFu;
+                } else {
+                    o_sa[lds[c]] = sa[k]; o_lcp[lds[c]] = idx == 0 ? 0u : run[c]; o_bw[lds[c]] = bo; o_np[lds[c]] = np;
+                    if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
+                        bool hit = (sa[k] >= clo[0] && sa[k] < chi[0]) || (sa[k] >= clo[1] && sa[k] < chi[1]);
+                        for (int q = qc0 + 2; q < qc1 && !hit; q++) hit = sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q];
+                        if (hit) a.SAi[sa[k]] = (sa_t)idx;
+                    }
+                }
+                ecnt[c]++; lds[c]++;
+                run[c] = INF;
             }
-            ecnt[c]++;
-            run[c] = INF;
         }
+    }
+    __syncthreads();
+    const u32 total = tot[0] + tot[1] + tot[2];
+    for (u32 q = threadIdx.x; q < total; q += TB) {
+        const u32 np = o_np[q];
+        if (np == 0xFFFFFFFFu) continue;
+        a.SA_out[np] = o_sa[q];
+        a.LCP_out[np] = (lcp_t)o_lcp[q];
+        a.BWT_out[np] = o_bw[q];
     }
 }
 
-// exclusive scan over tiles of (count, min-state) for the three classes; one block.
-__global__ __launch_bounds__(TB) void k_tile_carry(RvSplitArgs a) {
-    __shared__ u32   s_c[TB / 64][3];
-    __shared__ MinSt s_m[TB / 64][3];
+// exclusive scan over tiles of (count, min-state) for the three classes; one block of NT threads.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a, int64_t t_lo, int64_t t_hi, const u32 *__restrict__ in_cnt, const MinSt *__restrict__ in_ms,
+                                                   u32 *__restrict__ out_cnt, MinSt *__restrict__ out_ms) {
+    // tiles [t_lo, t_hi); carry-in (in_cnt[3], in_ms[3]) or zero; totals to out_cnt/out_ms[3] if given
+    __shared__ u32   s_c[NT / 64][3];
+    __shared__ MinSt s_m[NT / 64][3];
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < 3) { s_runc[threadIdx.x] = 0; s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
+    if (threadIdx.x < 3) {
+        s_runc[threadIdx.x] = in_cnt ? in_cnt[threadIdx.x] : 0u;
+        if (in_ms) s_runm[threadIdx.x] = in_ms[threadIdx.x]; else { s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
+    }
     __syncthreads();
-    for (int64_t base = 0; base < a.ntiles; base += TB) {
+    for (int64_t base = t_lo; base < t_hi; base += NT) {
         const int64_t t = base + threadIdx.x;
         u32 ix[3]; MinSt im[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             ix[c] = 0; im[c].has = 0; im[c].val = INF;
-            if (t < a.ntiles) {
+            if (t < t_hi) {
                 ix[c] = a.tile_cnt[(size_t)c * a.ntiles + t];
                 im[c].has = a.tile_has[(size_t)c * a.ntiles + t];
                 im[c].val = a.tile_post[(size_t)c * a.ntiles + t];
@@ -256,14 +353,14 @@ __global__ __launch_bounds__(TB) void k_tile_carry(RvSplitArgs a) {
         for (int c = 0; c < 3; c++) {
             u32 bc = s_runc[c]; MinSt bm = s_runm[c];
             totc[c] = s_runc[c]; totm[c] = s_runm[c];
-            for (int k = 0; k < TB / 64; k++) {
+            for (int k = 0; k < NT / 64; k++) {
                 if (k < w) { bc += s_c[k][c]; bm = ms_combine(bm, s_m[k][c]); }
                 totc[c] += s_c[k][c]; totm[c] = ms_combine(totm[c], s_m[k][c]);
             }
             u32 xc = __shfl_up(ix[c], 1, 64);
             MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
             if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
-            if (t < a.ntiles) {
+            if (t < t_hi) {
                 a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
                 a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
             }
@@ -272,35 +369,126 @@ __global__ __launch_bounds__(TB) void k_tile_carry(RvSplitArgs a) {
         if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
         __syncthreads();
     }
-    if (threadIdx.x < 3) a.total[threadIdx.x] = s_runc[threadIdx.x];
+    if (threadIdx.x < 3) {
+        if (out_cnt) { out_cnt[threadIdx.x] = s_runc[threadIdx.x]; out_ms[threadIdx.x] = s_runm[threadIdx.x]; }
+        else {
+            a.total[threadIdx.x] = s_runc[threadIdx.x];
+            if (s_runc[threadIdx.x] != a.expect_total[threadIdx.x]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
+        }
+    }
 }
 
-// one wave per sub-index with a split decision
-__global__ __launch_bounds__(64) void k_seg_offsets(const uint8_t *__restrict__ D, int64_t m, RvSplitArgs a, const int *__restrict__ split_subs, int nsplit) {
-    const int k = blockIdx.x;
-    if (k >= nsplit) return;
-    const int s = split_subs[k];
-    const int lane = threadIdx.x;
-    u32 g[2][3];
-    for (int side = 0; side < 2; side++) {
-        const int64_t pos = a.sub_start[s + side];       // first rank of the sub / one past its last
-        const int64_t tile = pos / SP_TILE;
-        u32 c0 = 0, c1 = 0, c2 = 0;
-        for (int64_t j = tile * SP_TILE + lane; j < pos; j += 64) {
-            const uint8_t d = D[j];
-            c0 += d == 1; c1 += d == 2; c2 += d == 4;
+// Large levels: the tiles are cut into chunks of CH tiles; every chunk is first reduced to one (count, min-state)
+// triple, one block scans the triples, then every chunk is scanned again with its carry-in.
+constexpr int CARRY_CH = 4096;
+__global__ __launch_bounds__(TB) void k_carry_reduce(RvSplitArgs a, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
+    __shared__ u32   s_c[TB / 64][3];
+    __shared__ MinSt s_m[TB / 64][3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t lo = (int64_t)blockIdx.x * CARRY_CH, hi = lo + CARRY_CH < a.ntiles ? lo + CARRY_CH : a.ntiles;
+    u32 rc[3] = {0, 0, 0}; MinSt rm[3] = {{0, INF}, {0, INF}, {0, INF}};
+    // thread t takes a contiguous run of CARRY_CH / TB tiles (order matters for the min-state)
+    const int per = CARRY_CH / TB;
+    for (int k = 0; k < per; k++) {
+        const int64_t t = lo + (int64_t)threadIdx.x * per + k;
+        if (t < hi) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                MinSt x; x.has = a.tile_has[(size_t)c * a.ntiles + t]; x.val = a.tile_post[(size_t)c * a.ntiles + t];
+                rc[c] += a.tile_cnt[(size_t)c * a.ntiles + t]; rm[c] = ms_combine(rm[c], x);
+            }
         }
-        for (int dd = 32; dd >= 1; dd >>= 1) { c0 += __shfl_down(c0, dd, 64); c1 += __shfl_down(c1, dd, 64); c2 += __shfl_down(c2, dd, 64); }
-        c0 = __shfl(c0, 0, 64); c1 = __shfl(c1, 0, 64); c2 = __shfl(c2, 0, 64);
-        const bool past = tile >= a.ntiles;              // pos == m on a tile boundary
-        g[side][0] = (past ? a.total[0] : a.tile_G[0 * (size_t)a.ntiles + tile]) + c0;
-        g[side][1] = (past ? a.total[1] : a.tile_G[1 * (size_t)a.ntiles + tile]) + c1;
-        g[side][2] = (past ? a.total[2] : a.tile_G[2 * (size_t)a.ntiles + tile]) + c2;
     }
-    if (lane < 3) {
-        const int c = lane;
-        a.sub_off[(size_t)s * 3 + c] = a.child_base[(size_t)s * 3 + c] - g[0][c];
-        if (g[1][c] - g[0][c] != a.child_n[(size_t)s * 3 + c]) atomicOr(a.err, 1u);   // intervals do not cover what they claim
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const u32 tc = __shfl_up(rc[c], dd, 64);
+            MinSt tm; tm.has = __shfl_up(rm[c].has, dd, 64); tm.val = __shfl_up(rm[c].val, dd, 64);
+            if (lane >= dd) { rc[c] += tc; rm[c] = ms_combine(tm, rm[c]); }
+        }
+    }
+    if (lane == 63) {
+#pragma unroll
+        for (int c = 0; c < 3; c++) { s_c[w][c] = rc[c]; s_m[w][c] = rm[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        u32 tc = 0; MinSt tm = {0, INF};
+        for (int k = 0; k < TB / 64; k++) { tc += s_c[k][c]; tm = ms_combine(tm, s_m[k][c]); }
+        ch_cnt[(size_t)blockIdx.x * 3 + c] = tc; ch_ms[(size_t)blockIdx.x * 3 + c] = tm;
+    }
+}
+// exclusive scan of the chunk triples (one wave per class is plenty: a few hundred chunks at most)
+__global__ __launch_bounds__(64) void k_carry_chunks(RvSplitArgs a, int nch, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
+    const int c = threadIdx.x;
+    if (c >= 3) return;
+    u32 rc = 0; MinSt rm = {0, INF};
+    for (int k = 0; k < nch; k++) {
+        const u32 x = ch_cnt[(size_t)k * 3 + c]; const MinSt y = ch_ms[(size_t)k * 3 + c];
+        ch_cnt[(size_t)k * 3 + c] = rc; ch_ms[(size_t)k * 3 + c] = rm;
+        rc += x; rm = ms_combine(rm, y);
+    }
+    a.total[c] = rc;
+    if (rc != a.expect_total[c]) atomicOr(a.err, 1u);
+}
+__global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, const u32 *__restrict__ ch_cnt, const MinSt *__restrict__ ch_ms) {
+    // same body as k_tile_carry<1024> over one chunk, with the chunk's carry-in
+    __shared__ u32   s_c[1024 / 64][3];
+    __shared__ MinSt s_m[1024 / 64][3];
+    __shared__ u32   s_runc[3];
+    __shared__ MinSt s_runm[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t_lo = (int64_t)blockIdx.x * CARRY_CH, t_hi = t_lo + CARRY_CH < a.ntiles ? t_lo + CARRY_CH : a.ntiles;
+    if (threadIdx.x < 3) { s_runc[threadIdx.x] = ch_cnt[(size_t)blockIdx.x * 3 + threadIdx.x]; s_runm[threadIdx.x] = ch_ms[(size_t)blockIdx.x * 3 + threadIdx.x]; }
+    __syncthreads();
+    for (int64_t base = t_lo; base < t_hi; base += 1024) {
+        const int64_t t = base + threadIdx.x;
+        u32 ix[3]; MinSt im[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            ix[c] = 0; im[c].has = 0; im[c].val = INF;
+            if (t < t_hi) {
+                ix[c] = a.tile_cnt[(size_t)c * a.ntiles + t];
+                im[c].has = a.tile_has[(size_t)c * a.ntiles + t];
+                im[c].val = a.tile_post[(size_t)c * a.ntiles + t];
+            }
+        }
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const u32 tc = __shfl_up(ix[c], dd, 64);
+                MinSt tm; tm.has = __shfl_up(im[c].has, dd, 64); tm.val = __shfl_up(im[c].val, dd, 64);
+                if (lane >= dd) { ix[c] += tc; im[c] = ms_combine(tm, im[c]); }
+            }
+        }
+        if (lane == 63) {
+#pragma unroll
+            for (int c = 0; c < 3; c++) { s_c[w][c] = ix[c]; s_m[w][c] = im[c]; }
+        }
+        __syncthreads();
+        u32 totc[3]; MinSt totm[3];
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            u32 bc = s_runc[c]; MinSt bm = s_runm[c];
+            totc[c] = s_runc[c]; totm[c] = s_runm[c];
+            for (int k = 0; k < 1024 / 64; k++) {
+                if (k < w) { bc += s_c[k][c]; bm = ms_combine(bm, s_m[k][c]); }
+                totc[c] += s_c[k][c]; totm[c] = ms_combine(totm[c], s_m[k][c]);
+            }
+            u32 xc = __shfl_up(ix[c], 1, 64);
+            MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
+            if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
+            if (t < t_hi) {
+                a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
+                a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
+        __syncthreads();
     }
 }
 
@@ -968,24 +1156,30 @@ __global__ __launch_bounds__(TB) void k_sai_level(const sa_t *__restrict__ SA, i
 
 }  // namespace
 
-int rv_label_launch(Workspace &ws, const sa_t *SA, int64_t m, const RvLabelTabs &t, uint8_t *D) {
-    if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_label, dim3((unsigned)ceil_div(m, TB * 4)), dim3(TB), 0, ws.stream, SA, m, t, D);
-    RV_LAUNCH_CHECK();
-    return 0;
-}
-
-int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *D, const uint8_t *BWT, int64_t m, const RvSplitArgs &a,
-                    const int *d_split_subs, int nsplit) {
+int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D, const uint8_t *BWT, int64_t m, const RvLabelTabs &t, const RvSplitArgs &a,
+                    int nsplit) {
     if (m <= 0 || nsplit <= 0) return 0;
     const unsigned nt = (unsigned)a.ntiles;
-    hipLaunchKernelGGL(k_split<false>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, BWT, m, a);
+    hipLaunchKernelGGL(k_split_count, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, m, t, a, D);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_tile_carry, dim3(1), dim3(TB), 0, ws.stream, a);
-    RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_seg_offsets, dim3((unsigned)nsplit), dim3(64), 0, ws.stream, D, m, a, d_split_subs, nsplit);
-    RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_split<true>, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, D, BWT, m, a);
+    if (a.ntiles <= 4 * CARRY_CH) {
+        hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a, (int64_t)0, a.ntiles, (const u32 *)nullptr, (const MinSt *)nullptr,
+                           (u32 *)nullptr, (MinSt *)nullptr);
+        RV_LAUNCH_CHECK();
+    } else {
+        const int nch = (int)ceil_div(a.ntiles, CARRY_CH);
+        DBuf &buf = ws.scan_tmp[3];
+        RV_TRY(buf.reserve((size_t)nch * 3 * (sizeof(u32) + sizeof(MinSt)) + 64));
+        MinSt *ch_ms = buf.as<MinSt>();
+        u32 *ch_cnt = (u32 *)(ch_ms + (size_t)nch * 3);
+        hipLaunchKernelGGL(k_carry_reduce, dim3((unsigned)nch), dim3(TB), 0, ws.stream, a, ch_cnt, ch_ms);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_carry_chunks, dim3(1), dim3(64), 0, ws.stream, a, nch, ch_cnt, ch_ms);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)nch), dim3(1024), 0, ws.stream, a, (const u32 *)ch_cnt, (const MinSt *)ch_ms);
+        RV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_split_emit, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, (const uint8_t *)D, BWT, m, a);
     RV_LAUNCH_CHECK();
     return 0;
 }

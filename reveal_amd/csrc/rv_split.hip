@@ -18,6 +18,8 @@
 //                  per round, in the order graphalign listed them
 #include "rv_common.h"
 #include "rv_split.h"
+#include <algorithm>
+#include <stdlib.h>
 
 namespace {
 
@@ -134,18 +136,54 @@ __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA,
     int s = s_sub0;
     uint8_t d[SP_ITEMS + 1];
     u32 ev[SP_ITEMS];
+    sa_t sav[SP_ITEMS];
+    u32 lcv[SP_ITEMS];
 #pragma unroll
     for (int k = 0; k <= SP_ITEMS; k++) d[k] = 0;
+    if (j0 + SP_ITEMS <= m) {      // whole group: vector loads (j0 is a multiple of SP_ITEMS, the level arrays are 16-byte aligned)
+        __builtin_memcpy(sav, SA + j0, sizeof sav);
+        __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
+    } else {
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) { const int64_t i = j0 + k; sav[k] = i < m ? SA[i] : (sa_t)0; lcv[k] = i < m ? (u32)LCP[i] : INF; }
+    }
     if (j0 < m) {
         int64_t s_end = t.sub_start[s + 1];
         for (int step = 0; j0 >= s_end && step < 4; step++) { s++; s_end = t.sub_start[s + 1]; }
         if (j0 >= s_end) { s += upper_idx<int64_t>(t.sub_start + s, t.nsubs - s, j0); s_end = t.sub_start[s + 1]; }
+        // the sub-index' interval table in registers (two samples: at most six class intervals and two matched ranges);
+        // longer tables are searched in global memory
+        constexpr int RC = 6, RM = 2;
+        sa_t cb[RC], ce[RC], mb[RM], me[RM]; uint8_t cc[RC];
+        int nc = 0, nm = 0; bool small = false;
+        auto load_tab = [&](int ss) {
+            const int c0 = t.ctab_first[ss], m0 = t.mtab_first[ss];
+            nc = t.ctab_first[ss + 1] - c0; nm = t.mtab_first[ss + 1] - m0;
+            small = nc <= RC && nm <= RM;
+            if (small) {
+#pragma unroll
+                for (int q = 0; q < RC; q++) { const bool in = q < nc; cb[q] = in ? t.cbegin[c0 + q] : (sa_t)0; ce[q] = in ? t.cend[c0 + q] : (sa_t)0; cc[q] = in ? t.ccls[c0 + q] : (uint8_t)0; }
+#pragma unroll
+                for (int q = 0; q < RM; q++) { const bool in = q < nm; mb[q] = in ? t.mbegin[m0 + q] : (sa_t)0; me[q] = in ? t.mend[m0 + q] : (sa_t)0; }
+            }
+        };
+        load_tab(s);
 #pragma unroll
         for (int k = 0; k < SP_ITEMS; k++) {
             const int64_t i = j0 + k;
             if (i < m) {
-                while (i >= s_end) { s++; s_end = t.sub_start[s + 1]; }
-                d[k + 1] = label_of(t, s, SA[i]);
+                if (i >= s_end) { do { s++; s_end = t.sub_start[s + 1]; } while (i >= s_end); load_tab(s); }
+                const sa_t pos = sav[k];
+                uint8_t c = 0;
+                if (small) {
+#pragma unroll
+                    for (int q = 0; q < RC; q++) if (pos >= cb[q] && pos < ce[q]) c = cc[q];      // empty slots have begin == end
+#pragma unroll
+                    for (int q = 0; q < RM; q++) if (pos >= mb[q] && pos < me[q]) c = 3;
+                } else {
+                    c = label_of(t, s, pos);
+                }
+                d[k + 1] = c;
             }
         }
     }
@@ -164,7 +202,7 @@ __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA,
 #pragma unroll
     for (int k = 0; k < SP_ITEMS; k++) {
         const int64_t j = j0 + k;
-        ev[k] = (d[k] != 0 && j < m) ? (u32)LCP[j] : INF;
+        ev[k] = (d[k] != 0 && j < m) ? lcv[k] : INF;
     }
     if (j0 + SP_ITEMS <= m) {
         u64 pack = 0;
@@ -210,13 +248,23 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     sa_t sa[SP_ITEMS];
     uint8_t bw[SP_ITEMS];
     d[0] = (j0 > 0 && j0 - 1 < m) ? D[j0 - 1] : (uint8_t)0;
+    if (j0 + SP_ITEMS <= m) {
+        u32 lcv[SP_ITEMS];
+        __builtin_memcpy(sa, SA + j0, sizeof sa);
+        __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
+        __builtin_memcpy(d + 1, D + j0, SP_ITEMS);
+        __builtin_memcpy(bw, BWT + j0, SP_ITEMS);
 #pragma unroll
-    for (int k = 0; k < SP_ITEMS; k++) {
-        const int64_t j = j0 + k;
-        d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
-        const u32 l = (j < m) ? (u32)LCP[j] : INF;
-        ev[k] = (d[k] != 0 && j < m) ? l : INF;
-        sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0;
+        for (int k = 0; k < SP_ITEMS; k++) ev[k] = d[k] != 0 ? lcv[k] : INF;
+    } else {
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) {
+            const int64_t j = j0 + k;
+            d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
+            const u32 l = (j < m) ? (u32)LCP[j] : INF;
+            ev[k] = (d[k] != 0 && j < m) ? l : INF;
+            sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0;
+        }
     }
     u32 icnt[3]; MinSt ist[3];
     split_summaries(d, ev, icnt, ist);
@@ -307,32 +355,31 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     }
 }
 
-// exclusive scan over tiles of (count, min-state) for the three classes; one block of NT threads.
+// exclusive scan over tiles of (count, min-state) for the three classes; one block of NT threads, each thread
+// owning CARRY_PER consecutive tiles per pass (all of a pass' loads are in flight before the first combine).
+constexpr int CARRY_PER = 8;
 template <int NT>
-__global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a, int64_t t_lo, int64_t t_hi, const u32 *__restrict__ in_cnt, const MinSt *__restrict__ in_ms,
-                                                   u32 *__restrict__ out_cnt, MinSt *__restrict__ out_ms) {
-    // tiles [t_lo, t_hi); carry-in (in_cnt[3], in_ms[3]) or zero; totals to out_cnt/out_ms[3] if given
-    __shared__ u32   s_c[NT / 64][3];
-    __shared__ MinSt s_m[NT / 64][3];
-    __shared__ u32   s_runc[3];
-    __shared__ MinSt s_runm[3];
+__device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int64_t t_hi, u32 *s_runc, MinSt *s_runm, u32 (*s_c)[3], MinSt (*s_m)[3]) {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x < 3) {
-        s_runc[threadIdx.x] = in_cnt ? in_cnt[threadIdx.x] : 0u;
-        if (in_ms) s_runm[threadIdx.x] = in_ms[threadIdx.x]; else { s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
-    }
-    __syncthreads();
-    for (int64_t base = t_lo; base < t_hi; base += NT) {
-        const int64_t t = base + threadIdx.x;
+    for (int64_t base = t_lo; base < t_hi; base += (int64_t)NT * CARRY_PER) {
+        const int64_t t0 = base + (int64_t)threadIdx.x * CARRY_PER;
+        u32 vc[3][CARRY_PER]; MinSt vm[3][CARRY_PER];
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+#pragma unroll
+            for (int k = 0; k < CARRY_PER; k++) {
+                const int64_t t = t0 + k;
+                const bool in = t < t_hi;
+                vc[c][k] = in ? a.tile_cnt[(size_t)c * a.ntiles + t] : 0u;
+                vm[c][k].has = in ? a.tile_has[(size_t)c * a.ntiles + t] : 0u;
+                vm[c][k].val = in ? a.tile_post[(size_t)c * a.ntiles + t] : INF;
+            }
         u32 ix[3]; MinSt im[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             ix[c] = 0; im[c].has = 0; im[c].val = INF;
-            if (t < t_hi) {
-                ix[c] = a.tile_cnt[(size_t)c * a.ntiles + t];
-                im[c].has = a.tile_has[(size_t)c * a.ntiles + t];
-                im[c].val = a.tile_post[(size_t)c * a.ntiles + t];
-            }
+#pragma unroll
+            for (int k = 0; k < CARRY_PER; k++) { ix[c] += vc[c][k]; im[c] = ms_combine(im[c], vm[c][k]); }
         }
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
@@ -360,35 +407,49 @@ __global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a, int64_t t_lo, 
             u32 xc = __shfl_up(ix[c], 1, 64);
             MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
             if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
-            if (t < t_hi) {
-                a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
-                a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
+            u32 rc = bc + xc; MinSt rm = ms_combine(bm, xm);          // exclusive prefix in front of my first tile
+#pragma unroll
+            for (int k = 0; k < CARRY_PER; k++) {
+                const int64_t t = t0 + k;
+                if (t < t_hi) {
+                    a.tile_G[(size_t)c * a.ntiles + t] = rc;
+                    a.tile_carry[(size_t)c * a.ntiles + t] = rm.val;
+                }
+                rc += vc[c][k]; rm = ms_combine(rm, vm[c][k]);
             }
         }
         __syncthreads();
         if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
         __syncthreads();
     }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a) {
+    __shared__ u32   s_c[NT / 64][3];
+    __shared__ MinSt s_m[NT / 64][3];
+    __shared__ u32   s_runc[3];
+    __shared__ MinSt s_runm[3];
+    if (threadIdx.x < 3) { s_runc[threadIdx.x] = 0u; s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
+    __syncthreads();
+    carry_scan_range<NT>(a, 0, a.ntiles, s_runc, s_runm, s_c, s_m);
     if (threadIdx.x < 3) {
-        if (out_cnt) { out_cnt[threadIdx.x] = s_runc[threadIdx.x]; out_ms[threadIdx.x] = s_runm[threadIdx.x]; }
-        else {
-            a.total[threadIdx.x] = s_runc[threadIdx.x];
-            if (s_runc[threadIdx.x] != a.expect_total[threadIdx.x]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
-        }
+        a.total[threadIdx.x] = s_runc[threadIdx.x];
+        if (s_runc[threadIdx.x] != a.expect_total[threadIdx.x]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
     }
 }
 
 // Large levels: the tiles are cut into chunks of CH tiles; every chunk is first reduced to one (count, min-state)
 // triple, one block scans the triples, then every chunk is scanned again with its carry-in.
-constexpr int CARRY_CH = 4096;
-__global__ __launch_bounds__(TB) void k_carry_reduce(RvSplitArgs a, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
+constexpr int CARRY_CH = 8192;      // default chunk; RV_CARRY_CH overrides it (tests force the chunked path on small inputs)
+__global__ __launch_bounds__(TB) void k_carry_reduce(RvSplitArgs a, int ch, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
     __shared__ u32   s_c[TB / 64][3];
     __shared__ MinSt s_m[TB / 64][3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t lo = (int64_t)blockIdx.x * CARRY_CH, hi = lo + CARRY_CH < a.ntiles ? lo + CARRY_CH : a.ntiles;
+    const int64_t lo = (int64_t)blockIdx.x * ch, hi = lo + ch < a.ntiles ? lo + ch : a.ntiles;
     u32 rc[3] = {0, 0, 0}; MinSt rm[3] = {{0, INF}, {0, INF}, {0, INF}};
     // thread t takes a contiguous run of CARRY_CH / TB tiles (order matters for the min-state)
-    const int per = CARRY_CH / TB;
+    const int per = (ch + TB - 1) / TB;
     for (int k = 0; k < per; k++) {
         const int64_t t = lo + (int64_t)threadIdx.x * per + k;
         if (t < hi) {
@@ -433,63 +494,15 @@ __global__ __launch_bounds__(64) void k_carry_chunks(RvSplitArgs a, int nch, u32
     a.total[c] = rc;
     if (rc != a.expect_total[c]) atomicOr(a.err, 1u);
 }
-__global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, const u32 *__restrict__ ch_cnt, const MinSt *__restrict__ ch_ms) {
-    // same body as k_tile_carry<1024> over one chunk, with the chunk's carry-in
+__global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, int ch, const u32 *__restrict__ ch_cnt, const MinSt *__restrict__ ch_ms) {
     __shared__ u32   s_c[1024 / 64][3];
     __shared__ MinSt s_m[1024 / 64][3];
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t t_lo = (int64_t)blockIdx.x * CARRY_CH, t_hi = t_lo + CARRY_CH < a.ntiles ? t_lo + CARRY_CH : a.ntiles;
+    const int64_t t_lo = (int64_t)blockIdx.x * ch, t_hi = t_lo + ch < a.ntiles ? t_lo + ch : a.ntiles;
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = ch_cnt[(size_t)blockIdx.x * 3 + threadIdx.x]; s_runm[threadIdx.x] = ch_ms[(size_t)blockIdx.x * 3 + threadIdx.x]; }
     __syncthreads();
-    for (int64_t base = t_lo; base < t_hi; base += 1024) {
-        const int64_t t = base + threadIdx.x;
-        u32 ix[3]; MinSt im[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            ix[c] = 0; im[c].has = 0; im[c].val = INF;
-            if (t < t_hi) {
-                ix[c] = a.tile_cnt[(size_t)c * a.ntiles + t];
-                im[c].has = a.tile_has[(size_t)c * a.ntiles + t];
-                im[c].val = a.tile_post[(size_t)c * a.ntiles + t];
-            }
-        }
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                const u32 tc = __shfl_up(ix[c], dd, 64);
-                MinSt tm; tm.has = __shfl_up(im[c].has, dd, 64); tm.val = __shfl_up(im[c].val, dd, 64);
-                if (lane >= dd) { ix[c] += tc; im[c] = ms_combine(tm, im[c]); }
-            }
-        }
-        if (lane == 63) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) { s_c[w][c] = ix[c]; s_m[w][c] = im[c]; }
-        }
-        __syncthreads();
-        u32 totc[3]; MinSt totm[3];
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            u32 bc = s_runc[c]; MinSt bm = s_runm[c];
-            totc[c] = s_runc[c]; totm[c] = s_runm[c];
-            for (int k = 0; k < 1024 / 64; k++) {
-                if (k < w) { bc += s_c[k][c]; bm = ms_combine(bm, s_m[k][c]); }
-                totc[c] += s_c[k][c]; totm[c] = ms_combine(totm[c], s_m[k][c]);
-            }
-            u32 xc = __shfl_up(ix[c], 1, 64);
-            MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
-            if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
-            if (t < t_hi) {
-                a.tile_G[(size_t)c * a.ntiles + t] = bc + xc;
-                a.tile_carry[(size_t)c * a.ntiles + t] = ms_combine(bm, xm).val;
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
-        __syncthreads();
-    }
+    carry_scan_range<1024>(a, t_lo, t_hi, s_runc, s_runm, s_c, s_m);
 }
 
 __global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend,
@@ -1162,21 +1175,21 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     const unsigned nt = (unsigned)a.ntiles;
     hipLaunchKernelGGL(k_split_count, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, m, t, a, D);
     RV_LAUNCH_CHECK();
-    if (a.ntiles <= 4 * CARRY_CH) {
-        hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a, (int64_t)0, a.ntiles, (const u32 *)nullptr, (const MinSt *)nullptr,
-                           (u32 *)nullptr, (MinSt *)nullptr);
+    const int ch = getenv("RV_CARRY_CH") ? std::max(1, atoi(getenv("RV_CARRY_CH"))) : CARRY_CH;
+    if (a.ntiles <= 4 * (int64_t)ch) {
+        hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a);
         RV_LAUNCH_CHECK();
     } else {
-        const int nch = (int)ceil_div(a.ntiles, CARRY_CH);
+        const int nch = (int)ceil_div(a.ntiles, ch);
         DBuf &buf = ws.scan_tmp[3];
         RV_TRY(buf.reserve((size_t)nch * 3 * (sizeof(u32) + sizeof(MinSt)) + 64));
         MinSt *ch_ms = buf.as<MinSt>();
         u32 *ch_cnt = (u32 *)(ch_ms + (size_t)nch * 3);
-        hipLaunchKernelGGL(k_carry_reduce, dim3((unsigned)nch), dim3(TB), 0, ws.stream, a, ch_cnt, ch_ms);
+        hipLaunchKernelGGL(k_carry_reduce, dim3((unsigned)nch), dim3(TB), 0, ws.stream, a, ch, ch_cnt, ch_ms);
         RV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_carry_chunks, dim3(1), dim3(64), 0, ws.stream, a, nch, ch_cnt, ch_ms);
         RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)nch), dim3(1024), 0, ws.stream, a, (const u32 *)ch_cnt, (const MinSt *)ch_ms);
+        hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)nch), dim3(1024), 0, ws.stream, a, ch, (const u32 *)ch_cnt, (const MinSt *)ch_ms);
         RV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_split_emit, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, (const uint8_t *)D, BWT, m, a);

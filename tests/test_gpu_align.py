@@ -145,6 +145,13 @@ def test_untraced_run_same_anchors(name, inputs, minl):
     assert got["stats"]["splits"] == ref["stats"]["nsplits"]
 
 
+def test_chunked_carry_scan(monkeypatch):
+    """levels above 64 M ranks scan their tile summaries in chunks (reduce / scan / apply): force that path on a small input"""
+    monkeypatch.setenv("RV_CARRY_CH", "3")
+    compare([g.decode() for g in synth.genomes(150000, 2)], 20)
+    compare(fa("1a", "1b", "1c"), 20, 2)
+
+
 def test_sequential_bubble_kept(monkeypatch):
     """the one-workgroup-per-child kernels stay the fallback (and the small-level path): keep them covered in multi mode"""
     monkeypatch.setenv("RV_BUBBLE_NO_JOIN", "1")

@@ -421,7 +421,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
     // leading children above this many ranks take the data-parallel bubble rounds (RV_BUBBLE_PAR_MIN: test hook)
-    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_BIG_N;
+    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
     struct Ent { int64_t b, e; uint8_t c; };
     std::vector<Ent> ent;
     a->kid_tmp.clear();

@@ -43,13 +43,15 @@ __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, i
     if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
 }
 
-// ---- first key: K symbols packed at `bits` bits each -------------------------
-// key(i) = sum_j code[T[i+j]] << bits*(K-1-j), code 0 = past the end of the text
-// (so the shorter suffix sorts first).  A block stages 1024+K symbols as codes
-// in LDS; each thread then packs 4 keys from LDS.
+// ---- first key: K symbols as digits of a base-(sigma+1) number -----------------
+// key(i) = sum_j code[T[i+j]] * radix^(K-1-j), code 0 = past the end of the text
+// (so the shorter suffix sorts first).  Packing by radix instead of by bits puts
+// twelve DNA symbols (codes 0..5) into 32 bits: four radix-sort passes for n = 1e7
+// where 3 bits per symbol needed six.  A block stages 1024+K symbols as codes in
+// LDS; each thread then packs 4 keys from LDS.
 constexpr int KEY_TILE = 1024;
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                  int bits, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals) {
+                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
     slut[threadIdx.x] = lut[threadIdx.x];
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         const int64_t i = base + k;
         if (i < n) {
             u64 key = 0;
-            for (int j = 0; j < K; j++) key = (key << bits) | code[k + j];
+            for (int j = 0; j < K; j++) key = key * radix + code[k + j];
             keys[i] = key;
             vals[i] = (sav_t)i;
         }
@@ -236,6 +238,78 @@ __global__ __launch_bounds__(TB) void k_round_small(sav_t *__restrict__ S, const
     }
 }
 
+__device__ inline u64 load8(const uint8_t *p) {
+    u64 v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+
+// First round: the members of a small group are told apart by comparing their texts directly (from symbol h on,
+// big-endian words, at most TEXT_LIM bytes) instead of by the rank of suffix+h.  In closely related genomes a
+// suffix and its twin agree for about 1/divergence symbols: doubling needs log2 of that many rounds over nearly
+// the whole list, the direct comparison finishes them in one.  Members still equal after TEXT_LIM bytes (long
+// repeats, identical inputs) stay one group and go on with the doubling rounds.
+constexpr int TEXT_LIM = 4096;
+__device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, int64_t h) {
+    const uint8_t *pa = T + (int64_t)a + h, *pb = T + (int64_t)b + h;
+    for (int off = 0; off < TEXT_LIM; off += 8) {
+        const u64 wa = __builtin_bswap64(load8(pa + off)), wb = __builtin_bswap64(load8(pb + off));
+        if (wa != wb) return wa < wb ? -1 : 1;      // the shorter suffix runs into the zero padding first and sorts first
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
+                                                   int64_t m, int64_t h, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q >= m) return;
+    const u32 g = G[q];
+    const u32 off = P[q] - g;
+    const int64_t look = q + (SMALL_GROUP - (int64_t)off);
+    const bool big = off >= (u32)SMALL_GROUP || (look < m && G[look] == g);
+    bigflag[q] = big;
+    if (big || off != 0) return;
+    sav_t s[SMALL_GROUP];
+    int size = 1;
+    s[0] = S[q];
+#pragma unroll
+    for (int j = 1; j < SMALL_GROUP; j++) {
+        if (size == j && q + j < m && G[q + j] == g) { s[j] = S[q + j]; size = j + 1; }
+    }
+    if (size == 2) {
+        const int c = cmp_text(T, s[0], s[1], h);
+        const sav_t lo = c <= 0 ? s[0] : s[1], hi = c <= 0 ? s[1] : s[0];
+        S[q] = lo; S[q + 1] = hi;
+        SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
+        headq[q] = 1; headq[q + 1] = c != 0;
+        return;
+    }
+    // all pairs once: less[i] bit j = (s[j] < s[i]); eq likewise; rank = #smaller + #equal with smaller index
+    u32 less[SMALL_GROUP], eq[SMALL_GROUP];
+#pragma unroll
+    for (int i = 0; i < SMALL_GROUP; i++) { less[i] = 0; eq[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < SMALL_GROUP; i++) {
+#pragma unroll
+        for (int j = i + 1; j < SMALL_GROUP; j++) {
+            if (j < size) {
+                const int c = cmp_text(T, s[i], s[j], h);
+                if (c < 0) less[j] |= 1u << i; else if (c > 0) less[i] |= 1u << j; else { eq[j] |= 1u << i; eq[i] |= 1u << j; }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < SMALL_GROUP; i++) {
+        if (i < size) {
+            const u32 before = eq[i] & ((1u << i) - 1u);
+            const int r = __popc(less[i]) + __popc(before);
+            S[q + r] = s[i];
+            SA[(size_t)g + r] = (sa_t)s[i];
+            headq[q + r] = before == 0;
+        }
+    }
+}
+
 // members of big groups -> sublist (ordered)
 __global__ __launch_bounds__(TB) void k_flag_count(const uint8_t *__restrict__ flag, int64_t n, u32 *__restrict__ tilecnt) {
     __shared__ u32 wsum[TB / 64];
@@ -301,11 +375,6 @@ __global__ __launch_bounds__(TB) void k_inverse(const sa_t *__restrict__ SA, sa_
 }
 
 // ---- LCP ---------------------------------------------------------------------
-__device__ inline u64 load8(const uint8_t *p) {
-    u64 v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
 __device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exact at and below the lowest hit
     return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
 }
@@ -489,18 +558,22 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     uint8_t lut[256];
     int sigma = 0;
     for (int c = 0; c < 256; c++) lut[c] = hist[c] ? (uint8_t)(++sigma) : (uint8_t)0;
-    int bits = bitlen((u64)sigma);            // codes 0..sigma
-    if (bits < 1) bits = 1;
-    int K = 64 / bits;
-    if (K > 32) K = 32;
-    {   // no more symbols in the first key than the text size needs: (sigma-1)^K >= 16 n leaves only repeats / twins unresolved
+    // first key: K symbols as a base-(sigma+1) number.  K = what the text size needs ((sigma-1)^K >= n: about one suffix per
+    // key value, so what stays unresolved are twins and repeats), raised as far as the same number of radix passes allows.
+    u32 radix = (u32)sigma + 1;
+    if (sigma >= 255) radix = 256;
+    if (sigma >= 255) for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c;      /* 0 byte never occurs in a C-string text */
+    int K = 1;
+    int bits;
+    {
         const double base = sigma > 2 ? (double)(sigma - 1) : 2.0;
-        int need = 4; double cap = base * base * base * base;
-        while (cap < 16.0 * (double)n && need < K) { cap *= base; need++; }
-        if (need < K) K = need;
+        double cap = base; u64 span = radix;                                   // span = radix^K
+        while (cap < (double)n && span <= (~0ull) / radix / radix) { cap *= base; span *= radix; K++; }
+        int passes = (bitlen(span - 1) + 7) / 8;
+        while (span <= (~0ull) / radix / radix && (bitlen(span * radix - 1) + 7) / 8 == passes) { span *= radix; K++; }
+        bits = bitlen(span - 1);                                               // significant bits of the key
     }
-    if (sigma >= 255) { bits = 8; K = 8; for (int c = 0; c < 256; c++) lut[c] = (uint8_t)c; /* 0 byte never occurs in a C-string text */ }
-    s.sigma = sigma; s.bits = bits; s.k0 = K;
+    s.sigma = sigma; s.bits = bits; s.k0 = K;        // (bits: of the whole first key)
     RV_HIP(hipMemcpyAsync(d_lut.p, lut, 256, hipMemcpyHostToDevice, q));
 
     // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
@@ -516,12 +589,12 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     const unsigned nblk = (unsigned)ceil_div(n, TB);
 
     // -- first key, sorted on its K*bits significant bits
-    hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), bits, K,
+    hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
                        bk0.as<u64>(), bv0.as<sav_t>());
     SA_HIP(hipGetLastError());
     int in1 = 0;
-    SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, K * bits, &in1));
-    s.radix_passes += (K * bits + 7) / 8; s.sorted_elems += n;
+    SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, bits, &in1));
+    s.radix_passes += (bits + 7) / 8; s.sorted_elems += n;
     u64 *ks = in1 ? bk1.as<u64>() : bk0.as<u64>();
     sav_t *vs = in1 ? bv1.as<sav_t>() : bv0.as<sav_t>();
     u64 *kt = in1 ? bk0.as<u64>() : bk1.as<u64>();      // the free pair
@@ -576,7 +649,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         const unsigned mb = (unsigned)ceil_div(m, TB);
         uint8_t *bigflag = bbig.as<uint8_t>();
         // groups of up to SMALL_GROUP members: sorted by their first thread, in place
-        hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
+        if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
+            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, h, head, bigflag, SA);
+        else
+            hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
         SA_HIP(hipGetLastError());
         // members of larger groups: ordered sublist -> radix sort on (group rank, rank of suffix+h) -> back into the list
         {

@@ -102,6 +102,9 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
 // descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
 #define RV_BUBBLE_BIG_N 16384
+// leading children above this many ranks take the data-parallel rounds (rv_bubble.hip); measured on C2: 16 K -> 485 Mbp/s,
+// 256 K -> 541, 512 K -> 555, 1 M -> 550, 2 M -> 511 (below it one workgroup replays the cuts of a child faster than ~18 launches)
+#define RV_BUBBLE_PAR_N 524288
 // children above this size may hand moves longer than RV_BUBBLE_LONG_DIST ranks to grid-wide kernels
 #define RV_BUBBLE_HUGE_N 2097152
 #define RV_BUBBLE_LONG_DIST 262144

@@ -119,6 +119,7 @@ struct Align {
     std::vector<uint8_t> cc;
     std::vector<int> ctab_first, mtab_first, cut_first, mend_first, split_subs;
     std::vector<u32> sub_off_h;
+    std::vector<int> tile_sub;
     std::vector<int64_t> mpre, sub_start, woff, toff, next_ss;
     const int64_t *d_next_ss = nullptr;      // device copy of the next level's sub-index starts (inside dTab)
     std::vector<u32> child_base, child_n;
@@ -538,8 +539,18 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->lg[0] = now_s() - t0;      // tables built
     // ---- one upload for all the tables ---------------------------------------------------
     const int64_t ntiles = ceil_div(lv.m, RV_SPLIT_TILE);
+    a->tile_sub.resize((size_t)ntiles);
+    {
+        int s2 = 0;
+        for (int64_t t = 0; t < ntiles; t++) {
+            const int64_t r = t * RV_SPLIT_TILE;
+            while (s2 + 1 < ns && a->sub_start[(size_t)s2 + 1] <= r) s2++;
+            a->tile_sub[(size_t)t] = s2;
+        }
+    }
     Packer &pk = a->pk;
     pk.clear();
+    const size_t o_tsub = pk.addv(a->tile_sub);
     const size_t o_cb = pk.addv(a->cb), o_ce = pk.addv(a->ce), o_cc = pk.addv(a->cc), o_mb = pk.addv(a->mb), o_me = pk.addv(a->me), o_mpre = pk.addv(a->mpre);
     const size_t o_ctf = pk.addv(a->ctab_first), o_mtf = pk.addv(a->mtab_first);
     const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
@@ -579,7 +590,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         }
     }
     RvLabelTabs lt;
-    lt.sub_start = (const int64_t *)(tb + o_ss); lt.nsubs = ns;
+    lt.sub_start = (const int64_t *)(tb + o_ss); lt.nsubs = ns; lt.tile_sub = (const int *)(tb + o_tsub);
     lt.ctab_first = (const int *)(tb + o_ctf); lt.cbegin = (const sa_t *)(tb + o_cb); lt.cend = (const sa_t *)(tb + o_ce); lt.ccls = tb + o_cc;
     lt.mtab_first = (const int *)(tb + o_mtf); lt.mbegin = (const sa_t *)(tb + o_mb); lt.mend = (const sa_t *)(tb + o_me); lt.nmatch = (int)a->mb.size();
     RvSplitArgs sa;
@@ -588,7 +599,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.tile_cnt = tiles; sa.tile_has = tiles + 3 * ntiles; sa.tile_post = tiles + 6 * ntiles;
     sa.tile_G = tiles + 9 * ntiles; sa.tile_carry = tiles + 12 * ntiles;
     sa.total = (u32 *)(tb + o_total);
-    sa.sub_start = lt.sub_start; sa.nsubs = ns;
+    sa.sub_start = lt.sub_start; sa.nsubs = ns; sa.tile_sub = lt.tile_sub;
     sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (const u32 *)(tb + o_suboff); sa.expect_total = (const u32 *)(tb + o_expect);
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
     sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);

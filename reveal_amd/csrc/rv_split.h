@@ -10,6 +10,7 @@
 struct RvLabelTabs {
     const int64_t *sub_start;       // [nsubs+1], last = m
     int            nsubs;
+    const int     *tile_sub;        // [ntiles] sub-index that owns rank tile * RV_SPLIT_TILE
     const int     *ctab_first;      // lead / trail / rest intervals
     const sa_t    *cbegin, *cend;
     const uint8_t *ccls;            // 1 lead, 2 trail, 4 rest
@@ -27,6 +28,7 @@ struct RvSplitArgs {
     // per sub-index of the current frontier
     const int64_t *sub_start;               // [nsubs+1], last = m
     int            nsubs;
+    const int     *tile_sub;                // [ntiles] sub-index that owns rank tile * RV_SPLIT_TILE
     const u32     *child_base;              // [nsubs*3] first slot of lead/trail/par child in the next level
     const u32     *child_n;                 // [nsubs*3] expected sizes
     const u32     *sub_off;                 // [nsubs*3] child_base - (class count before the sub); the host knows the child sizes, so it knows this too

@@ -102,17 +102,26 @@ __device__ inline void split_summaries(const uint8_t *d, const u32 *ev, u32 *icn
         const int c = cls_index(d[k + 1]);
         if (c >= 0) { cnt[c]++; st[c].has = 1; st[c].val = INF; }
     }
-#pragma unroll
-    for (int c = 0; c < 3; c++) { icnt[c] = cnt[c]; ist[c] = st[c]; }
+    // wave-inclusive scan; the three counts (<= 512 each) share one word and the three has-bits another: five shuffles
+    // per step instead of nine (the shuffles, not the memory traffic, were what bounded both split passes)
+    u32 pc = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
+    u32 ph = st[0].has | (st[1].has << 1) | (st[2].has << 2);
+    u32 v0 = st[0].val, v1 = st[1].val, v2 = st[2].val;
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            const u32 tc = __shfl_up(icnt[c], dd, 64);
-            MinSt tm; tm.has = __shfl_up(ist[c].has, dd, 64); tm.val = __shfl_up(ist[c].val, dd, 64);
-            if (lane >= dd) { icnt[c] += tc; ist[c] = ms_combine(tm, ist[c]); }
+        const u32 tc = __shfl_up(pc, dd, 64), th = __shfl_up(ph, dd, 64);
+        const u32 t0 = __shfl_up(v0, dd, 64), t1 = __shfl_up(v1, dd, 64), t2 = __shfl_up(v2, dd, 64);
+        if (lane >= dd) {
+            pc += tc;
+            if (!(ph & 1u)) v0 = t0 < v0 ? t0 : v0;
+            if (!(ph & 2u)) v1 = t1 < v1 ? t1 : v1;
+            if (!(ph & 4u)) v2 = t2 < v2 ? t2 : v2;
+            ph |= th;
         }
     }
+    icnt[0] = pc & 1023u; icnt[1] = (pc >> 10) & 1023u; icnt[2] = pc >> 20;
+    ist[0].has = ph & 1u; ist[1].has = (ph >> 1) & 1u; ist[2].has = (ph >> 2) & 1u;
+    ist[0].val = v0; ist[1].val = v1; ist[2].val = v2;
 }
 
 // Pass 1: D-labels of a 2048-rank tile (written for pass 2) and, from them, the tile's class counts and
@@ -122,16 +131,11 @@ __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA,
                                                     uint8_t *__restrict__ D) {
     __shared__ u32   s_cnt[TB / 64][3];
     __shared__ MinSt s_ms[TB / 64][3];
-    __shared__ int   s_sub0;
     __shared__ uint8_t s_last[TB / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t tlo = tile * SP_TILE;
-    if (threadIdx.x < 64) {
-        const int c = wave_count_le(t.sub_start, t.nsubs, tlo);
-        if (lane == 0) s_sub0 = c - 1;
-    }
-    __syncthreads();
+    const int s_sub0 = t.tile_sub[tile];      // sub-index of the tile's first rank: tabulated by the host (a search here stalled every block)
     const int64_t j0 = tlo + (int64_t)threadIdx.x * SP_ITEMS;
     int s = s_sub0;
     uint8_t d[SP_ITEMS + 1];
@@ -252,8 +256,10 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
         u32 lcv[SP_ITEMS];
         __builtin_memcpy(sa, SA + j0, sizeof sa);
         __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
-        __builtin_memcpy(d + 1, D + j0, SP_ITEMS);
-        __builtin_memcpy(bw, BWT + j0, SP_ITEMS);
+        static_assert(SP_ITEMS == 8, "labels / BWT bytes of a thread travel as one 64-bit word");
+        const u64 dw = *reinterpret_cast<const u64 *>(D + j0), bwv = *reinterpret_cast<const u64 *>(BWT + j0);
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) { d[k + 1] = (uint8_t)(dw >> (8 * k)); bw[k] = (uint8_t)(bwv >> (8 * k)); }
 #pragma unroll
         for (int k = 0; k < SP_ITEMS; k++) ev[k] = d[k] != 0 ? lcv[k] : INF;
     } else {
@@ -292,8 +298,10 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     if (j0 < m) {
         // owning sub-index of my first rank, then walk.  The sub-index' small tables (child offsets, first two cut
         // windows / matched ends) are pulled into registers whenever the sub-index changes -- usually once per thread.
-        int s = upper_idx<int64_t>(a.sub_start, a.nsubs, j0);
+        int s = a.tile_sub[tile];
         int64_t s_end = a.sub_start[s + 1];
+        for (int step = 0; j0 >= s_end && step < 4; step++) { s++; s_end = a.sub_start[s + 1]; }
+        if (j0 >= s_end) { s += upper_idx<int64_t>(a.sub_start + s, a.nsubs - s, j0); s_end = a.sub_start[s + 1]; }
         u32 run[3] = {est[0].val, est[1].val, est[2].val};
         u32 cbase[3], coff[3], cn[3];
         int qc0 = 0, qc1 = 0, qm0 = 0, qm1 = 0;
@@ -356,30 +364,37 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
 }
 
 // exclusive scan over tiles of (count, min-state) for the three classes; one block of NT threads, each thread
-// owning CARRY_PER consecutive tiles per pass (all of a pass' loads are in flight before the first combine).
+// owning CARRY_PER consecutive tiles per pass.  The summaries come in through LDS with lane-contiguous loads
+// and leave the same way: a thread reading its own eight consecutive words straight from global memory made
+// every load instruction touch 32 cache lines on the one CU this runs on (37 us for 4900 tiles).
 constexpr int CARRY_PER = 8;
 template <int NT>
-__device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int64_t t_hi, u32 *s_runc, MinSt *s_runm, u32 (*s_c)[3], MinSt (*s_m)[3]) {
+__device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int64_t t_hi, u32 *s_runc, MinSt *s_runm, u32 (*s_c)[3], MinSt (*s_m)[3],
+                                        u32 *s_x, u32 *s_y) {      // s_x, s_y: NT*CARRY_PER words each
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t base = t_lo; base < t_hi; base += (int64_t)NT * CARRY_PER) {
+    constexpr int PASS = NT * CARRY_PER;
+    for (int64_t base = t_lo; base < t_hi; base += PASS) {
         const int64_t t0 = base + (int64_t)threadIdx.x * CARRY_PER;
+        u32 ix[3]; MinSt im[3];
         u32 vc[3][CARRY_PER]; MinSt vm[3][CARRY_PER];
 #pragma unroll
-        for (int c = 0; c < 3; c++)
-#pragma unroll
-            for (int k = 0; k < CARRY_PER; k++) {
-                const int64_t t = t0 + k;
-                const bool in = t < t_hi;
-                vc[c][k] = in ? a.tile_cnt[(size_t)c * a.ntiles + t] : 0u;
-                vm[c][k].has = in ? a.tile_has[(size_t)c * a.ntiles + t] : 0u;
-                vm[c][k].val = in ? a.tile_post[(size_t)c * a.ntiles + t] : INF;
-            }
-        u32 ix[3]; MinSt im[3];
-#pragma unroll
         for (int c = 0; c < 3; c++) {
+            // stage class c: x = count | has << 31 (a tile holds 2048 ranks), y = min value
+            __syncthreads();
+            for (int k = threadIdx.x; k < PASS; k += NT) {
+                const int64_t t = base + k;
+                const bool in = t < t_hi;
+                s_x[k] = in ? (a.tile_cnt[(size_t)c * a.ntiles + t] | (a.tile_has[(size_t)c * a.ntiles + t] << 31)) : 0u;
+                s_y[k] = in ? a.tile_post[(size_t)c * a.ntiles + t] : INF;
+            }
+            __syncthreads();
             ix[c] = 0; im[c].has = 0; im[c].val = INF;
 #pragma unroll
-            for (int k = 0; k < CARRY_PER; k++) { ix[c] += vc[c][k]; im[c] = ms_combine(im[c], vm[c][k]); }
+            for (int k = 0; k < CARRY_PER; k++) {
+                const u32 x = s_x[threadIdx.x * CARRY_PER + k];
+                vc[c][k] = x & 0x7FFFFFFFu; vm[c][k].has = x >> 31; vm[c][k].val = s_y[threadIdx.x * CARRY_PER + k];
+                ix[c] += vc[c][k]; im[c] = ms_combine(im[c], vm[c][k]);
+            }
         }
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
@@ -408,16 +423,19 @@ __device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int6
             MinSt xm; xm.has = __shfl_up(im[c].has, 1, 64); xm.val = __shfl_up(im[c].val, 1, 64);
             if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
             u32 rc = bc + xc; MinSt rm = ms_combine(bm, xm);          // exclusive prefix in front of my first tile
+            __syncthreads();                                           // (the staging arrays are free again)
 #pragma unroll
             for (int k = 0; k < CARRY_PER; k++) {
-                const int64_t t = t0 + k;
-                if (t < t_hi) {
-                    a.tile_G[(size_t)c * a.ntiles + t] = rc;
-                    a.tile_carry[(size_t)c * a.ntiles + t] = rm.val;
-                }
+                s_x[threadIdx.x * CARRY_PER + k] = rc; s_y[threadIdx.x * CARRY_PER + k] = rm.val;
                 rc += vc[c][k]; rm = ms_combine(rm, vm[c][k]);
             }
+            __syncthreads();
+            for (int k = threadIdx.x; k < PASS; k += NT) {
+                const int64_t t = base + k;
+                if (t < t_hi) { a.tile_G[(size_t)c * a.ntiles + t] = s_x[k]; a.tile_carry[(size_t)c * a.ntiles + t] = s_y[k]; }
+            }
         }
+        (void)t0;
         __syncthreads();
         if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
         __syncthreads();
@@ -430,9 +448,10 @@ __global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a) {
     __shared__ MinSt s_m[NT / 64][3];
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
+    __shared__ u32   s_x[NT * CARRY_PER], s_y[NT * CARRY_PER];
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = 0u; s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
     __syncthreads();
-    carry_scan_range<NT>(a, 0, a.ntiles, s_runc, s_runm, s_c, s_m);
+    carry_scan_range<NT>(a, 0, a.ntiles, s_runc, s_runm, s_c, s_m, s_x, s_y);
     if (threadIdx.x < 3) {
         a.total[threadIdx.x] = s_runc[threadIdx.x];
         if (s_runc[threadIdx.x] != a.expect_total[threadIdx.x]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
@@ -499,10 +518,11 @@ __global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, int ch, con
     __shared__ MinSt s_m[1024 / 64][3];
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
+    __shared__ u32   s_x[1024 * CARRY_PER], s_y[1024 * CARRY_PER];
     const int64_t t_lo = (int64_t)blockIdx.x * ch, t_hi = t_lo + ch < a.ntiles ? t_lo + ch : a.ntiles;
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = ch_cnt[(size_t)blockIdx.x * 3 + threadIdx.x]; s_runm[threadIdx.x] = ch_ms[(size_t)blockIdx.x * 3 + threadIdx.x]; }
     __syncthreads();
-    carry_scan_range<1024>(a, t_lo, t_hi, s_runc, s_runm, s_c, s_m);
+    carry_scan_range<1024>(a, t_lo, t_hi, s_runc, s_runm, s_c, s_m, s_x, s_y);
 }
 
 __global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend,
@@ -1177,7 +1197,8 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     RV_LAUNCH_CHECK();
     const int ch = getenv("RV_CARRY_CH") ? std::max(1, atoi(getenv("RV_CARRY_CH"))) : CARRY_CH;
     if (a.ntiles <= 4 * (int64_t)ch) {
-        hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a);
+        if (a.ntiles <= 256 * CARRY_PER) hipLaunchKernelGGL(k_tile_carry<256>, dim3(1), dim3(256), 0, ws.stream, a);
+        else hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a);
         RV_LAUNCH_CHECK();
     } else {
         const int nch = (int)ceil_div(a.ntiles, ch);

@@ -2,7 +2,9 @@
 #pragma once
 #include "rv_common.h"
 
+#ifndef RV_PAIR_TILE
 #define RV_PAIR_TILE 2048
+#endif
 
 // one pairwise MUM: a < b text positions, l = LCP[rank], rank inside the
 // scanned (concatenated) array

@@ -19,7 +19,7 @@
 namespace {
 
 constexpr int TB = 256;
-constexpr int PAIR_ITEMS = 8;
+constexpr int PAIR_ITEMS = RV_PAIR_TILE / 256;
 constexpr int PAIR_TILE = TB * PAIR_ITEMS;   // == RV_PAIR_TILE
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
@@ -55,14 +55,26 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     const int64_t i0 = tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_ITEMS;
     if (blockIdx.x == 0 && threadIdx.x == 0) tilecnt[gridDim.x] = 0;      // the slot that makes the exclusive scan yield the total
 
+    // Halo of the wave (the rank in front of its first one, the LCP behind its last one): wave-uniform addresses, issued
+    // before the streaming loads.  Loaded by lane 0 / 63 after the shuffles they were a second, dependent memory round
+    // trip per wave (measured: the bare load pattern of this kernel streams 6.3 TB/s, the kernel 3.5).
+    const int64_t wfirst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63)) * (int64_t)PAIR_ITEMS + tile * PAIR_TILE;
+    const int64_t wnext = wfirst + 64 * PAIR_ITEMS;
+    sa_t h_sa = 0; lcp_t h_lc = 0, h_nlc = 0; uint8_t h_bw = 0;
+    if (wfirst > 0 && wfirst - 1 < m) { h_sa = SA[wfirst - 1]; h_lc = LCP[wfirst - 1]; h_bw = BWT[wfirst - 1]; }
+    if (wnext < m) h_nlc = LCP[wnext];
+
     sa_t sa[PAIR_ITEMS];
     lcp_t lc[PAIR_ITEMS];
     uint8_t bw[PAIR_ITEMS];
     if (i0 + PAIR_ITEMS <= m) {
         // streamed once: non-temporal 16-byte loads (8 B of BWT)
-        const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0));
 #pragma unroll
-        for (int k = 0; k < 4; k++) { bw[k] = (uint8_t)(bb.x >> (8 * k)); bw[4 + k] = (uint8_t)(bb.y >> (8 * k)); }
+        for (int v8 = 0; v8 < PAIR_ITEMS / 8; v8++) {
+            const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0) + v8);
+#pragma unroll
+            for (int k = 0; k < 4; k++) { bw[8 * v8 + k] = (uint8_t)(bb.x >> (8 * k)); bw[8 * v8 + 4 + k] = (uint8_t)(bb.y >> (8 * k)); }
+        }
 #pragma unroll
         for (int v4 = 0; v4 < PAIR_ITEMS / 4; v4++) {
 #ifndef RV_SA64
@@ -92,25 +104,29 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     lcp_t plc = (lcp_t)__shfl_up((int)lc[PAIR_ITEMS - 1], 1, 64);
     lcp_t nlc = (lcp_t)__shfl_down((int)lc[0], 1, 64);
     uint8_t pbw = (uint8_t)__shfl_up((int)bw[PAIR_ITEMS - 1], 1, 64);
-    if (lane == 0) {
-        if (i0 > 0 && i0 - 1 < m) { psa = SA[i0 - 1]; plc = LCP[i0 - 1]; pbw = BWT[i0 - 1]; } else { psa = 0; plc = 0; pbw = 0; }
-    }
-    if (lane == 63) nlc = (i0 + PAIR_ITEMS < m) ? LCP[i0 + PAIR_ITEMS] : (lcp_t)0;
+    if (lane == 0) { psa = h_sa; plc = h_lc; pbw = h_bw; }
+    if (lane == 63) nlc = h_nlc;
 
+    // The predicate, branch-free (bitwise & | on the comparison results): written with && / ?: the compiler emitted one
+    // exec-mask branch per term -- 120 of them per thread -- and the kernel was bound by control flow, not by memory.
+    // Ranks past the end were loaded as zeros and a sub-index' first rank has LCP 0, so neither can pass `lb < l`:
+    // no bounds tests are needed here.
     u32 hit = 0;        // bitmask over my ranks
+    bool side_prev = psa > nsep0;
 #pragma unroll
     for (int k = 0; k < PAIR_ITEMS; k++) {
-        const int64_t i = i0 + k;
         const sa_t  s1 = sa[k], s0 = (k == 0) ? psa : sa[k - 1];
         const lcp_t l = lc[k], lb = (k == 0) ? plc : lc[k - 1];
-        lcp_t la = (k == PAIR_ITEMS - 1) ? nlc : lc[k + 1];
-        if (i + 1 >= m) la = 0;
-        bool ok = (i >= 1) && (i < m) && !lcp_lt(l, minl);
-        ok = ok && ((s1 > nsep0) != (s0 > nsep0));          // not a repeat inside one sample
-        ok = ok && (lb < l) && (la < l);                    // unique
+        const lcp_t la = (k == PAIR_ITEMS - 1) ? nlc : lc[k + 1];
+        const bool side = s1 > nsep0;
         const uint8_t c1 = bw[k], c0 = (k == 0) ? pbw : bw[k - 1];
-        ok = ok && (s1 < s0 ? left_maximal(c1, c0) : left_maximal(c0, c1));
-        hit |= ok ? (1u << k) : 0u;
+        const uint8_t ca = s1 < s0 ? c1 : c0;                  // the character in front of the smaller text position
+        const bool special = (ca == 'N') | (ca == '$') | ((uint8_t)(ca - 'a') < 26);
+        const bool ok = (!lcp_lt(l, minl)) & (side != side_prev)   // long enough; not a repeat inside one sample
+                      & (lb < l) & (la < l)                       // unique
+                      & ((c1 != c0) | special);                   // left-maximal (reveal.c:81-85)
+        hit |= (u32)ok << k;
+        side_prev = side;
     }
     // order-preserving append of this tile's survivors
     const u32 mine = __popc(hit);

@@ -90,34 +90,43 @@ __device__ inline MinSt ms_combine(MinSt a, MinSt b) {   // a then b
     return r;
 }
 
-// thread summaries of SP_ITEMS ranks (labels d[1..], previous label d[0], effective LCP ev) and their wave-inclusive scans
-__device__ inline void split_summaries(const uint8_t *d, const u32 *ev, u32 *icnt, MinSt *ist) {
+#ifdef RV_SA64
+typedef u64 usa_t;
+#else
+typedef u32 usa_t;
+#endif
+
+// Thread summaries of SP_ITEMS ranks and their wave-inclusive scans.  dpack = the labels of my ranks (one byte each),
+// ev[k] = effective LCP of rank k (INF where the reference skips the min update).  Everything is written with selects:
+// the && / if form compiled to an exec-mask branch per term (3500 instructions and 280 branches per thread in the
+// counting pass) and made both passes instruction bound.
+__device__ inline void split_summaries(u64 dpack, const u32 *ev, u32 *icnt, MinSt *ist) {
     const int lane = threadIdx.x & 63;
-    u32 cnt[3] = {0, 0, 0};
-    MinSt st[3] = {{0, INF}, {0, INF}, {0, INF}};
+    u32 pc = 0, ph = 0;
+    u32 v0 = INF, v1 = INF, v2 = INF;
 #pragma unroll
     for (int k = 0; k < SP_ITEMS; k++) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) st[c].val = st[c].val < ev[k] ? st[c].val : ev[k];
-        const int c = cls_index(d[k + 1]);
-        if (c >= 0) { cnt[c]++; st[c].has = 1; st[c].val = INF; }
+        const u32 d = (u32)(dpack >> (8 * k)) & 0xffu;
+        const bool i0 = d == 1u, i1 = d == 2u, i2 = d == 4u;
+        const u32 e = ev[k];
+        v0 = i0 ? INF : (v0 < e ? v0 : e);
+        v1 = i1 ? INF : (v1 < e ? v1 : e);
+        v2 = i2 ? INF : (v2 < e ? v2 : e);
+        pc += (u32)i0 + ((u32)i1 << 10) + ((u32)i2 << 20);
+        ph |= (u32)i0 | ((u32)i1 << 1) | ((u32)i2 << 2);
     }
-    // wave-inclusive scan; the three counts (<= 512 each) share one word and the three has-bits another: five shuffles
-    // per step instead of nine (the shuffles, not the memory traffic, were what bounded both split passes)
-    u32 pc = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
-    u32 ph = st[0].has | (st[1].has << 1) | (st[2].has << 2);
-    u32 v0 = st[0].val, v1 = st[1].val, v2 = st[2].val;
+    // wave-inclusive scan; the three counts (<= 512 each) share one word and the three has-bits another
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
         const u32 tc = __shfl_up(pc, dd, 64), th = __shfl_up(ph, dd, 64);
         const u32 t0 = __shfl_up(v0, dd, 64), t1 = __shfl_up(v1, dd, 64), t2 = __shfl_up(v2, dd, 64);
-        if (lane >= dd) {
-            pc += tc;
-            if (!(ph & 1u)) v0 = t0 < v0 ? t0 : v0;
-            if (!(ph & 2u)) v1 = t1 < v1 ? t1 : v1;
-            if (!(ph & 4u)) v2 = t2 < v2 ? t2 : v2;
-            ph |= th;
-        }
+        const bool act = lane >= dd;
+        const u32 m0 = t0 < v0 ? t0 : v0, m1 = t1 < v1 ? t1 : v1, m2 = t2 < v2 ? t2 : v2;
+        v0 = (act & !(ph & 1u)) ? m0 : v0;
+        v1 = (act & !(ph & 2u)) ? m1 : v1;
+        v2 = (act & !(ph & 4u)) ? m2 : v2;
+        pc += act ? tc : 0u;
+        ph |= act ? th : 0u;
     }
     icnt[0] = pc & 1023u; icnt[1] = (pc >> 10) & 1023u; icnt[2] = pc >> 20;
     ist[0].has = ph & 1u; ist[1].has = (ph >> 1) & 1u; ist[2].has = (ph >> 2) & 1u;
@@ -125,8 +134,10 @@ __device__ inline void split_summaries(const uint8_t *d, const u32 *ev, u32 *icn
 }
 
 // Pass 1: D-labels of a 2048-rank tile (written for pass 2) and, from them, the tile's class counts and
-// running-minimum summaries.  The owning sub-index is searched once per tile (one wave, 64 probes per
-// step); a thread then only steps forward from there.
+// running-minimum summaries.  The sub-index of the tile's first rank comes from a host table; a thread whose
+// eight ranks lie in one sub-index with a short interval table (two samples: <= 6 class intervals, 2 matched
+// ranges) labels them from registers, straight-line; the rest (a sub-index boundary inside the eight ranks,
+// many samples) takes the generic loop.
 __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, RvLabelTabs t, RvSplitArgs a,
                                                     uint8_t *__restrict__ D) {
     __shared__ u32   s_cnt[TB / 64][3];
@@ -135,89 +146,86 @@ __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA,
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t tlo = tile * SP_TILE;
-    const int s_sub0 = t.tile_sub[tile];      // sub-index of the tile's first rank: tabulated by the host (a search here stalled every block)
+    const int s_sub0 = t.tile_sub[tile];
     const int64_t j0 = tlo + (int64_t)threadIdx.x * SP_ITEMS;
     int s = s_sub0;
-    uint8_t d[SP_ITEMS + 1];
     u32 ev[SP_ITEMS];
     sa_t sav[SP_ITEMS];
     u32 lcv[SP_ITEMS];
-#pragma unroll
-    for (int k = 0; k <= SP_ITEMS; k++) d[k] = 0;
-    if (j0 + SP_ITEMS <= m) {      // whole group: vector loads (j0 is a multiple of SP_ITEMS, the level arrays are 16-byte aligned)
+    const bool whole = j0 + SP_ITEMS <= m;
+    if (whole) {      // vector loads (j0 is a multiple of SP_ITEMS, the level arrays are 16-byte aligned)
         __builtin_memcpy(sav, SA + j0, sizeof sav);
         __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
     } else {
 #pragma unroll
         for (int k = 0; k < SP_ITEMS; k++) { const int64_t i = j0 + k; sav[k] = i < m ? SA[i] : (sa_t)0; lcv[k] = i < m ? (u32)LCP[i] : INF; }
     }
+    u64 dpack = 0;
     if (j0 < m) {
         int64_t s_end = t.sub_start[s + 1];
         for (int step = 0; j0 >= s_end && step < 4; step++) { s++; s_end = t.sub_start[s + 1]; }
         if (j0 >= s_end) { s += upper_idx<int64_t>(t.sub_start + s, t.nsubs - s, j0); s_end = t.sub_start[s + 1]; }
-        // the sub-index' interval table in registers (two samples: at most six class intervals and two matched ranges);
-        // longer tables are searched in global memory
         constexpr int RC = 6, RM = 2;
-        sa_t cb[RC], ce[RC], mb[RM], me[RM]; uint8_t cc[RC];
-        int nc = 0, nm = 0; bool small = false;
-        auto load_tab = [&](int ss) {
-            const int c0 = t.ctab_first[ss], m0 = t.mtab_first[ss];
-            nc = t.ctab_first[ss + 1] - c0; nm = t.mtab_first[ss + 1] - m0;
-            small = nc <= RC && nm <= RM;
-            if (small) {
+        const int c0 = t.ctab_first[s], m0 = t.mtab_first[s];
+        const int nc = t.ctab_first[s + 1] - c0, nm = t.mtab_first[s + 1] - m0;
+        if (whole && j0 + SP_ITEMS <= s_end && nc <= RC && nm <= RM) {
+            usa_t tb[RC + RM], tl[RC + RM]; u32 tc[RC + RM];      // (begin, length, class); unused slots have length 0
 #pragma unroll
-                for (int q = 0; q < RC; q++) { const bool in = q < nc; cb[q] = in ? t.cbegin[c0 + q] : (sa_t)0; ce[q] = in ? t.cend[c0 + q] : (sa_t)0; cc[q] = in ? t.ccls[c0 + q] : (uint8_t)0; }
-#pragma unroll
-                for (int q = 0; q < RM; q++) { const bool in = q < nm; mb[q] = in ? t.mbegin[m0 + q] : (sa_t)0; me[q] = in ? t.mend[m0 + q] : (sa_t)0; }
+            for (int q = 0; q < RC; q++) {
+                const bool in = q < nc;
+                const sa_t b = in ? t.cbegin[c0 + q] : (sa_t)0, e = in ? t.cend[c0 + q] : (sa_t)0;
+                tb[q] = (usa_t)b; tl[q] = (usa_t)(e - b); tc[q] = in ? (u32)t.ccls[c0 + q] : 0u;
             }
-        };
-        load_tab(s);
 #pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) {
-            const int64_t i = j0 + k;
-            if (i < m) {
-                if (i >= s_end) { do { s++; s_end = t.sub_start[s + 1]; } while (i >= s_end); load_tab(s); }
-                const sa_t pos = sav[k];
-                uint8_t c = 0;
-                if (small) {
+            for (int q = 0; q < RM; q++) {
+                const bool in = q < nm;
+                const sa_t b = in ? t.mbegin[m0 + q] : (sa_t)0, e = in ? t.mend[m0 + q] : (sa_t)0;
+                tb[RC + q] = (usa_t)b; tl[RC + q] = (usa_t)(e - b); tc[RC + q] = 3u;
+            }
 #pragma unroll
-                    for (int q = 0; q < RC; q++) if (pos >= cb[q] && pos < ce[q]) c = cc[q];      // empty slots have begin == end
+            for (int k = 0; k < SP_ITEMS; k++) {
+                const usa_t pos = (usa_t)sav[k];
+                u32 c = 0;
 #pragma unroll
-                    for (int q = 0; q < RM; q++) if (pos >= mb[q] && pos < me[q]) c = 3;
-                } else {
-                    c = label_of(t, s, pos);
-                }
-                d[k + 1] = c;
+                for (int q = 0; q < RC + RM; q++) c = ((usa_t)(pos - tb[q]) < tl[q]) ? tc[q] : c;      // matched ranges last: they win
+                dpack |= (u64)c << (8 * k);
+            }
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < SP_ITEMS; k++) {
+                const int64_t i = j0 + k;
+                if (i >= m) break;
+                while (i >= s_end) { s++; s_end = t.sub_start[s + 1]; }
+                dpack |= (u64)label_of(t, s, SA[i]) << (8 * k);
             }
         }
     }
     // label of the rank in front of my first one
+    u32 dprev = 0;
     {
-        const int up = __shfl_up((int)d[SP_ITEMS], 1, 64);
-        if (lane == 63) s_last[w] = d[SP_ITEMS];
+        const u32 mylast = (u32)(dpack >> (8 * (SP_ITEMS - 1))) & 0xffu;
+        const u32 up = (u32)__shfl_up((int)mylast, 1, 64);
+        if (lane == 63) s_last[w] = (uint8_t)mylast;
         __syncthreads();
-        if (lane > 0) d[0] = (uint8_t)up;
-        else if (w > 0) d[0] = s_last[w - 1];
+        if (lane > 0) dprev = up;
+        else if (w > 0) dprev = s_last[w - 1];
         else if (j0 > 0 && j0 - 1 < m) {                          // first thread of the tile: label the rank before the tile
             const int sp = (j0 - 1 >= t.sub_start[s_sub0]) ? s_sub0 : s_sub0 - 1;
-            d[0] = label_of(t, sp, SA[j0 - 1]);
+            dprev = label_of(t, sp, SA[j0 - 1]);
         }
     }
+    {
+        const u64 dsh = (dpack << 8) | dprev;                      // byte k = label of the rank in front of rank k
 #pragma unroll
-    for (int k = 0; k < SP_ITEMS; k++) {
-        const int64_t j = j0 + k;
-        ev[k] = (d[k] != 0 && j < m) ? lcv[k] : INF;
+        for (int k = 0; k < SP_ITEMS; k++) ev[k] = (((u32)(dsh >> (8 * k)) & 0xffu) != 0u) ? lcv[k] : INF;      // (past the end: lcv == INF)
     }
-    if (j0 + SP_ITEMS <= m) {
-        u64 pack = 0;
-#pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) pack |= (u64)d[k + 1] << (8 * k);
-        *reinterpret_cast<u64 *>(D + j0) = pack;
+    if (whole) {
+        *reinterpret_cast<u64 *>(D + j0) = dpack;
     } else {
-        for (int k = 0; k < SP_ITEMS && j0 + k < m; k++) D[j0 + k] = d[k + 1];
+        for (int k = 0; k < SP_ITEMS && j0 + k < m; k++) D[j0 + k] = (uint8_t)(dpack >> (8 * k));
     }
     u32 icnt[3]; MinSt ist[3];
-    split_summaries(d, ev, icnt, ist);
+    split_summaries(dpack, ev, icnt, ist);
     if (lane == 63) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { s_cnt[w][c] = icnt[c]; s_ms[w][c] = ist[c]; }
@@ -236,6 +244,61 @@ __global__ __launch_bounds__(TB) void k_split_count(const sa_t *__restrict__ SA,
 // Pass 2: stable 3-way partition.  A tile's survivors are staged in LDS class by class and leave as
 // consecutive stores (one thread per survivor): written straight from the scan order, every store
 // instruction touched 64 different cache lines.
+struct EmitSub {            // per-sub-index tables of pass 2, in registers (scalars, not arrays: a select between
+                            // array elements becomes an indexed load and sends the whole struct to scratch)
+    u32 cbase0, cbase1, cbase2, coff0, coff1, coff2, cn0, cn1, cn2;
+    int qc0, qc1, qm0, qm1;
+    sa_t clo0, clo1, chi0, chi1, mnd0, mnd1;
+};
+__device__ __forceinline__ void emit_load_sub(const RvSplitArgs &a, int ss, EmitSub &e) {
+    e.cbase0 = a.child_base[(size_t)ss * 3]; e.cbase1 = a.child_base[(size_t)ss * 3 + 1]; e.cbase2 = a.child_base[(size_t)ss * 3 + 2];
+    e.coff0 = a.sub_off[(size_t)ss * 3]; e.coff1 = a.sub_off[(size_t)ss * 3 + 1]; e.coff2 = a.sub_off[(size_t)ss * 3 + 2];
+    e.cn0 = a.child_n[(size_t)ss * 3]; e.cn1 = a.child_n[(size_t)ss * 3 + 1]; e.cn2 = a.child_n[(size_t)ss * 3 + 2];
+    e.qc0 = a.cut_first[ss]; e.qc1 = a.cut_first[ss + 1]; e.qm0 = a.mend_first[ss]; e.qm1 = a.mend_first[ss + 1];
+    e.clo0 = (e.qc0 < e.qc1) ? a.cut_lo[e.qc0] : (sa_t)0;         e.chi0 = (e.qc0 < e.qc1) ? a.cut_hi[e.qc0] : (sa_t)0;
+    e.clo1 = (e.qc0 + 1 < e.qc1) ? a.cut_lo[e.qc0 + 1] : (sa_t)0; e.chi1 = (e.qc0 + 1 < e.qc1) ? a.cut_hi[e.qc0 + 1] : (sa_t)0;
+    e.mnd0 = (e.qm0 < e.qm1) ? a.mend_pos[e.qm0] : (sa_t)-1;      e.mnd1 = (e.qm0 + 1 < e.qm1) ? a.mend_pos[e.qm0 + 1] : (sa_t)-1;
+}
+// one rank of pass 2; d = its label, e = its effective LCP; r0..r2 running minima, n0..n2 global class counts, l0..l2 LDS slots
+__device__ __forceinline__ void emit_item(const RvSplitArgs &a, const EmitSub &sb, const u32 coff0, const u32 coff1, const u32 coff2,
+                                          const u32 cbase0, const u32 cbase1, const u32 cbase2, const u32 cn0, const u32 cn1, const u32 cn2,
+                                          u32 d, u32 e, sa_t sa, uint8_t bo,
+                                 u32 &r0, u32 &r1, u32 &r2, u32 &n0, u32 &n1, u32 &n2, u32 &l0, u32 &l1, u32 &l2,
+                                 sa_t *o_sa, u32 *o_lcp, u32 *o_np, uint8_t *o_bw) {
+    r0 = r0 < e ? r0 : e; r1 = r1 < e ? r1 : e; r2 = r2 < e ? r2 : e;
+    const bool i0 = d == 1u, i1 = d == 2u, i2 = d == 4u;
+    if (i0 | i1 | i2) {
+        const u32 run = i0 ? r0 : i1 ? r1 : r2;
+        const u32 ecnt = i0 ? n0 : i1 ? n1 : n2;
+        const u32 slot = i0 ? l0 : i1 ? l1 : l2;
+        const u32 coff = i0 ? coff0 : i1 ? coff1 : coff2;
+        const u32 cbase = i0 ? cbase0 : i1 ? cbase1 : cbase2;
+        const u32 cn = i0 ? cn0 : i1 ? cn1 : cn2;
+        const u32 np = coff + ecnt;                                  // mod 2^32
+        const u32 idx = np - cbase;                                  // rank inside the child
+        if (i1) {   // trailing child: the character in front of a suffix that starts right behind a
+                    // matched range has just been lower-cased (reveal.c:1230-1234)
+            bool hit = (sa == sb.mnd0) | (sa == sb.mnd1);
+            for (int q = sb.qm0 + 2; q < sb.qm1 && !hit; q++) hit = sa == a.mend_pos[q];
+            if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
+        }
+        if (idx >= cn) {
+            atomicOr(a.err, 1u);                                     // more ranks labelled for this child than its intervals hold
+            o_np[slot] = 0xFFFFFFFFu;
+        } else {
+            o_sa[slot] = sa; o_lcp[slot] = idx == 0 ? 0u : run; o_bw[slot] = bo; o_np[slot] = np;
+            if (i0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
+                bool hit = ((sa >= sb.clo0) & (sa < sb.chi0)) | ((sa >= sb.clo1) & (sa < sb.chi1));
+                for (int q = sb.qc0 + 2; q < sb.qc1 && !hit; q++) hit = sa >= a.cut_lo[q] && sa < a.cut_hi[q];
+                if (hit) a.SAi[sa] = (sa_t)idx;
+            }
+        }
+        n0 += i0; n1 += i1; n2 += i2;
+        l0 += i0; l1 += i1; l2 += i2;
+        r0 = i0 ? INF : r0; r1 = i1 ? INF : r1; r2 = i2 ? INF : r2;
+    }
+}
+
 __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ D,
                                                    const uint8_t *__restrict__ BWT, int64_t m, RvSplitArgs a) {
     __shared__ u32   s_cnt[TB / 64][3];
@@ -246,34 +309,34 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t j0 = tile * SP_TILE + (int64_t)threadIdx.x * SP_ITEMS;
+    static_assert(SP_ITEMS == 8, "labels / BWT bytes of a thread travel as one 64-bit word");
 
-    uint8_t d[SP_ITEMS + 1];      // d[0] = label of rank j0-1
     u32 ev[SP_ITEMS];             // effective LCP (INF where the reference skips the min update)
     sa_t sa[SP_ITEMS];
-    uint8_t bw[SP_ITEMS];
-    d[0] = (j0 > 0 && j0 - 1 < m) ? D[j0 - 1] : (uint8_t)0;
-    if (j0 + SP_ITEMS <= m) {
+    u64 dpack = 0, bpack = 0;
+    const u32 dprev = (j0 > 0 && j0 - 1 < m) ? (u32)D[j0 - 1] : 0u;
+    const bool whole = j0 + SP_ITEMS <= m;
+    {
         u32 lcv[SP_ITEMS];
-        __builtin_memcpy(sa, SA + j0, sizeof sa);
-        __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
-        static_assert(SP_ITEMS == 8, "labels / BWT bytes of a thread travel as one 64-bit word");
-        const u64 dw = *reinterpret_cast<const u64 *>(D + j0), bwv = *reinterpret_cast<const u64 *>(BWT + j0);
+        if (whole) {
+            __builtin_memcpy(sa, SA + j0, sizeof sa);
+            __builtin_memcpy(lcv, LCP + j0, sizeof lcv);
+            dpack = *reinterpret_cast<const u64 *>(D + j0); bpack = *reinterpret_cast<const u64 *>(BWT + j0);
+        } else {
 #pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) { d[k + 1] = (uint8_t)(dw >> (8 * k)); bw[k] = (uint8_t)(bwv >> (8 * k)); }
-#pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) ev[k] = d[k] != 0 ? lcv[k] : INF;
-    } else {
-#pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) {
-            const int64_t j = j0 + k;
-            d[k + 1] = (j < m) ? D[j] : (uint8_t)0;
-            const u32 l = (j < m) ? (u32)LCP[j] : INF;
-            ev[k] = (d[k] != 0 && j < m) ? l : INF;
-            sa[k] = (j < m) ? SA[j] : (sa_t)0; bw[k] = (j < m) ? BWT[j] : (uint8_t)0;
+            for (int k = 0; k < SP_ITEMS; k++) {
+                const int64_t j = j0 + k;
+                const bool in = j < m;
+                sa[k] = in ? SA[j] : (sa_t)0; lcv[k] = in ? (u32)LCP[j] : INF;
+                dpack |= (u64)(in ? D[j] : (uint8_t)0) << (8 * k); bpack |= (u64)(in ? BWT[j] : (uint8_t)0) << (8 * k);
+            }
         }
+        const u64 dsh = (dpack << 8) | dprev;
+#pragma unroll
+        for (int k = 0; k < SP_ITEMS; k++) ev[k] = (((u32)(dsh >> (8 * k)) & 0xffu) != 0u) ? lcv[k] : INF;
     }
     u32 icnt[3]; MinSt ist[3];
-    split_summaries(d, ev, icnt, ist);
+    split_summaries(dpack, ev, icnt, ist);
     if (lane == 63) {
 #pragma unroll
         for (int c = 0; c < 3; c++) { s_cnt[w][c] = icnt[c]; s_ms[w][c] = ist[c]; }
@@ -286,7 +349,14 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
         const u32 g = a.tile_G[(size_t)c * a.ntiles + tile];
         u32 bc = 0; tot[c] = 0;
         MinSt bm; bm.has = 0; bm.val = a.tile_carry[(size_t)c * a.ntiles + tile];
-        for (int k = 0; k < TB / 64; k++) { if (k < w) { bc += s_cnt[k][c]; bm = ms_combine(bm, s_ms[k][c]); } tot[c] += s_cnt[k][c]; }
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) {
+            const bool before = k < w;
+            const MinSt comb = ms_combine(bm, s_ms[k][c]);
+            bc += before ? s_cnt[k][c] : 0u;
+            bm.has = before ? comb.has : bm.has; bm.val = before ? comb.val : bm.val;
+            tot[c] += s_cnt[k][c];
+        }
         u32 xc = __shfl_up(icnt[c], 1, 64);
         MinSt xm; xm.has = __shfl_up(ist[c].has, 1, 64); xm.val = __shfl_up(ist[c].val, 1, 64);
         if (lane == 0) { xc = 0; xm.has = 0; xm.val = INF; }
@@ -296,59 +366,29 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     }
     lds[1] += tot[0]; lds[2] += tot[0] + tot[1];
     if (j0 < m) {
-        // owning sub-index of my first rank, then walk.  The sub-index' small tables (child offsets, first two cut
-        // windows / matched ends) are pulled into registers whenever the sub-index changes -- usually once per thread.
         int s = a.tile_sub[tile];
         int64_t s_end = a.sub_start[s + 1];
         for (int step = 0; j0 >= s_end && step < 4; step++) { s++; s_end = a.sub_start[s + 1]; }
         if (j0 >= s_end) { s += upper_idx<int64_t>(a.sub_start + s, a.nsubs - s, j0); s_end = a.sub_start[s + 1]; }
-        u32 run[3] = {est[0].val, est[1].val, est[2].val};
-        u32 cbase[3], coff[3], cn[3];
-        int qc0 = 0, qc1 = 0, qm0 = 0, qm1 = 0;
-        sa_t clo[2] = {0, 0}, chi[2] = {0, 0}, mnd[2] = {-1, -1};
-        auto load_sub = [&](int ss) {
+        u32 r0 = est[0].val, r1 = est[1].val, r2 = est[2].val;
+        u32 n0 = ecnt[0], n1 = ecnt[1], n2 = ecnt[2], l0 = lds[0], l1 = lds[1], l2 = lds[2];
+        EmitSub sb;
+        emit_load_sub(a, s, sb);
+        if (whole && j0 + SP_ITEMS <= s_end) {        // all my ranks in one sub-index: straight-line
 #pragma unroll
-            for (int c = 0; c < 3; c++) { cbase[c] = a.child_base[(size_t)ss * 3 + c]; coff[c] = a.sub_off[(size_t)ss * 3 + c]; cn[c] = a.child_n[(size_t)ss * 3 + c]; }
-            qc0 = a.cut_first[ss]; qc1 = a.cut_first[ss + 1]; qm0 = a.mend_first[ss]; qm1 = a.mend_first[ss + 1];
-#pragma unroll
-            for (int k = 0; k < 2; k++) {
-                clo[k] = (qc0 + k < qc1) ? a.cut_lo[qc0 + k] : (sa_t)0;
-                chi[k] = (qc0 + k < qc1) ? a.cut_hi[qc0 + k] : (sa_t)0;
-                mnd[k] = (qm0 + k < qm1) ? a.mend_pos[qm0 + k] : (sa_t)-1;
-            }
-        };
-        load_sub(s);
-#pragma unroll
-        for (int k = 0; k < SP_ITEMS; k++) {
-            const int64_t j = j0 + k;
-            if (j >= m) break;
-            if (j >= s_end) { do { s++; s_end = a.sub_start[s + 1]; } while (j >= s_end); load_sub(s); }
-#pragma unroll
-            for (int c = 0; c < 3; c++) run[c] = run[c] < ev[k] ? run[c] : ev[k];
-            const int c = cls_index(d[k + 1]);
-            if (c >= 0) {
-                const u32 np = coff[c] + ecnt[c];                            // mod 2^32
-                const u32 idx = np - cbase[c];                               // rank inside the child
-                uint8_t bo = bw[k];
-                if (c == 1) {   // trailing child: the character in front of a suffix that starts right behind a
-                                // matched range has just been lower-cased (reveal.c:1230-1234)
-                    bool hit = (sa[k] == mnd[0]) || (sa[k] == mnd[1]);
-                    for (int q = qm0 + 2; q < qm1 && !hit; q++) hit = sa[k] == a.mend_pos[q];
-                    if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
-                }
-                if (idx >= cn[c]) {
-                    atomicOr(a.err, 1u);                                     // more ranks labelled for this child than its intervals hold
-                    o_np[lds[c]] = 0xFFFFFFFFu;
-                } else {
-                    o_sa[lds[c]] = sa[k]; o_lcp[lds[c]] = idx == 0 ? 0u : run[c]; o_bw[lds[c]] = bo; o_np[lds[c]] = np;
-                    if (c == 0) {   // leading child: publish SAi where bubble_sort will look (windows before its cuts)
-                        bool hit = (sa[k] >= clo[0] && sa[k] < chi[0]) || (sa[k] >= clo[1] && sa[k] < chi[1]);
-                        for (int q = qc0 + 2; q < qc1 && !hit; q++) hit = sa[k] >= a.cut_lo[q] && sa[k] < a.cut_hi[q];
-                        if (hit) a.SAi[sa[k]] = (sa_t)idx;
-                    }
-                }
-                ecnt[c]++; lds[c]++;
-                run[c] = INF;
+            for (int k = 0; k < SP_ITEMS; k++)
+                emit_item(a, sb, sb.coff0, sb.coff1, sb.coff2, sb.cbase0, sb.cbase1, sb.cbase2, sb.cn0, sb.cn1, sb.cn2, (u32)(dpack >> (8 * k)) & 0xffu, ev[k], sa[k], (uint8_t)(bpack >> (8 * k)), r0, r1, r2, n0, n1, n2, l0, l1, l2, o_sa, o_lcp, o_np, o_bw);
+        } else {
+            u32 dp = dprev;
+#pragma unroll 1
+            for (int k = 0; k < SP_ITEMS; k++) {
+                const int64_t j = j0 + k;
+                if (j >= m) break;
+                if (j >= s_end) { do { s++; s_end = a.sub_start[s + 1]; } while (j >= s_end); emit_load_sub(a, s, sb); }
+                const u32 d = (u32)(dpack >> (8 * k)) & 0xffu;
+                const u32 e = dp != 0u ? (u32)LCP[j] : INF;              // (re-read: a register array cannot be indexed by k here)
+                emit_item(a, sb, sb.coff0, sb.coff1, sb.coff2, sb.cbase0, sb.cbase1, sb.cbase2, sb.cn0, sb.cn1, sb.cn2, d, e, SA[j], (uint8_t)(bpack >> (8 * k)), r0, r1, r2, n0, n1, n2, l0, l1, l2, o_sa, o_lcp, o_np, o_bw);
+                dp = d;
             }
         }
     }

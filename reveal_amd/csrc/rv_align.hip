@@ -556,6 +556,9 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi);
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
+    // one launch instead of two when a level has few small children next to large ones (the kernels would run one after the
+    // other on the stream; in a 1024-thread workgroup a small child simply finishes early)
+    if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !getenv("RV_BUBBLE_NO_MERGE")) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
     const size_t o_nss = pk.addv(a->next_ss);

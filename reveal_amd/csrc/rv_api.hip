@@ -291,35 +291,36 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
     for (int attempt = 0; attempt < 3; attempt++) {
         const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
-        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* SURVEY 8(d): 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
-        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
-                                   (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf));
-        h->prof.end(q, id);
-        RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         DBuf &bbest = h->ws.misc[12], &bpick = h->ws.misc[13];
         if (d_sub_start) { RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bpick.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec))); }
-        RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
-                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err,
-                                      bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), d_sub_start ? nsubs : 0));
+        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* SURVEY 8(d): 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
+        RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
+                                   (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf,
+                                   bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), d_sub_start ? nsubs : 0));
+        h->prof.end(q, id);
         if (d_sub_start) {
-            // the built-in picker only wants the best record of each sub-index: pick on the device, copy header + nsubs records
-            RV_TRY(rv_pair_pick_launch(h->ws, bout.as<RvPairRec>(), (u32)std::min<size_t>(ocap, 0xffffffffu), d_sub_start, nsubs,
-                                       bbest.as<unsigned long long>(), bpick.as<RvPairRec>()));
+            // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots,
+            // copy header + nsubs records
+            RV_TRY(rv_pick_slots_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), (u32)std::min<size_t>(vcap, 0xffffffffu), tilecnt, tileovf, ntile,
+                                        d_sub_start, nsubs, bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), bcnt.as<u32>(), d_err));
             RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
             RV_HIP(hipMemcpyAsync(h->hscan.p, bpick.p, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
             RV_HIP(hipStreamSynchronize(q));
             const u32 *hdr = h->hscan.as<u32>();
-            const u32 total = hdr[0], novf = hdr[1];
+            const u32 novf = hdr[1];
             if (err_out) *err_out = hdr[2];
-            if (total <= ocap && novf <= vcap) {
+            if (novf <= vcap) {
                 const RvPairRec *src = h->hscan.as<RvPairRec>() + RV_PAIR_HDR;
                 for (int s2 = 0; s2 < nsubs; s2++) if (src[s2].rank != 0xFFFFFFFFu) out.push_back(src[s2]);
                 return 0;
             }
-            if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
-            if (total > ocap) RV_TRY(bout.reserve(((size_t)total + RV_PAIR_HDR) * sizeof(RvPairRec)));
+            RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
             continue;
         }
+        RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
+        RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err,
+                                      nullptr, nullptr, 0));
         // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
         size_t guess = std::min<size_t>(ocap, h->scan_guess);
         RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));

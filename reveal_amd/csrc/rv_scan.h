@@ -20,8 +20,14 @@ struct RvPairRec {
 // ovf[tileovf[t] ..] (*ovf_counter must be zero: rv_pair_compact_launch leaves it so);
 // tilecnt[t] = number of survivors, tilecnt[ntile] = 0.  rv_pair_compact_launch packs them densely in rank order given
 // tileoff = exclusive scan of tilecnt.
+// nsubs > 0: also initialises the tables of the device-side picker (best, picks) that rv_pick_slots_launch fills.
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
-                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf);
+                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf,
+                        unsigned long long *best, RvPairRec *picks, int nsubs);
+// built-in picker straight from the slots (no compaction): picks[0] = header {0, overflow count, *err, 0}, picks[1+s] = longest
+// record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none; resets *ovf_counter
+int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
+                         const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err);
 // out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records.
 // Resets *ovf_counter for the next scan; with nsubs > 0 also initialises the picker tables (best, picks).
 #define RV_PAIR_HDR 1

@@ -45,7 +45,8 @@ __device__ inline bool lcp_lt(lcp_t v, int minl) {
 __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
                                                   const uint8_t *__restrict__ BWT, sa_t nsep0, int minl,
                                                   RvPairRec *__restrict__ slots, RvPairRec *__restrict__ ovf, u32 ovf_cap,
-                                                  u32 *__restrict__ ovf_counter, u32 *__restrict__ tilecnt, u32 *__restrict__ tileovf) {
+                                                  u32 *__restrict__ ovf_counter, u32 *__restrict__ tilecnt, u32 *__restrict__ tileovf,
+                                                  unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks, int nsubs) {
     __shared__ u32 wsum[TB / 64];
     __shared__ u32 s_base;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -54,6 +55,8 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_ITEMS;
     if (blockIdx.x == 0 && threadIdx.x == 0) tilecnt[gridDim.x] = 0;      // the slot that makes the exclusive scan yield the total
+    // tables of the device-side picker that runs right behind this kernel (k_pick_slots1/2), nsubs = 0 otherwise
+    for (int64_t s2 = (int64_t)blockIdx.x * TB + threadIdx.x; s2 < nsubs; s2 += (int64_t)gridDim.x * TB) { best[s2] = 0; picks[RV_PAIR_HDR + s2].rank = 0xFFFFFFFFu; }
 
     // Halo of the wave (the rank in front of its first one, the LCP behind its last one): wave-uniform addresses, issued
     // before the streaming loads.  Loaded by lane 0 / 63 after the shuffles they were a second, dependent memory round
@@ -233,6 +236,51 @@ __global__ __launch_bounds__(TB) void k_pair_pick1(const RvPairRec *__restrict__
         }
     }
 }
+// The same picker straight from the scan's per-tile slots (+ overflow): no tile-count scan, no compaction -- the
+// untraced recursion never looks at the packed list.  One thread per (tile, slot); it also walks the tile's share of
+// the overflow array.  PASS 1: atomicMax per sub-index; PASS 2: the winners, the header {0, overflow count, *err, 0},
+// and the overflow counter back to zero for the next scan.
+template <int PASS>
+__global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf, u32 ovf_cap,
+                                                   const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf, int64_t ntile,
+                                                   const int64_t *__restrict__ sub_start, int nsubs, unsigned long long *__restrict__ best,
+                                                   RvPairRec *__restrict__ picks, u32 *__restrict__ ovf_counter, const u32 *__restrict__ err) {
+    const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (PASS == 2 && id == 0) {
+        u32 *hdr = reinterpret_cast<u32 *>(picks);
+        hdr[0] = 0; hdr[1] = *ovf_counter; hdr[2] = err ? *err : 0u; hdr[3] = 0;
+        *ovf_counter = 0;
+    }
+    const int64_t t = id / RV_PAIR_SLOTS;
+    const u32 j = (u32)(id % RV_PAIR_SLOTS);
+    const int lane = threadIdx.x & 63;
+    const u32 cnt = t < ntile ? tilecnt[t] : 0u;
+    const u32 ob = t < ntile ? tileovf[t] : 0u;
+    for (u32 q = j; ; q += RV_PAIR_SLOTS) {
+        const bool have = q < cnt && (q < RV_PAIR_SLOTS || ob + (q - RV_PAIR_SLOTS) < ovf_cap);
+        RvPairRec r; int sub = -1; u64 key = 0;
+        if (have) {
+            r = q < RV_PAIR_SLOTS ? slots[(size_t)t * RV_PAIR_SLOTS + q] : ovf[ob + (q - RV_PAIR_SLOTS)];
+            sub = sub_of_rank(sub_start, nsubs, (int64_t)r.rank); key = pick_key(r);
+        }
+        if (PASS == 1) {
+            u64 todo = __ballot(sub >= 0);
+            while (todo) {              // one atomic per (wave, sub-index)
+                const int leader = (int)__builtin_ctzll(todo);
+                const int lsub = __shfl(sub, leader, 64);
+                const bool mine = sub == lsub;
+                u64 v = mine ? key : 0;
+                for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+                if (lane == leader) atomicMax(&best[lsub], (unsigned long long)v);
+                todo &= ~__ballot(mine);
+            }
+        } else if (have && best[sub] == (unsigned long long)key) {
+            picks[RV_PAIR_HDR + sub] = r;
+        }
+        if (!__any(q + RV_PAIR_SLOTS < cnt)) break;       // (the wave leaves the loop together: the ballots above need all lanes)
+    }
+}
+
 __global__ __launch_bounds__(TB) void k_pair_pick2(const RvPairRec *__restrict__ out, u32 out_cap, const int64_t *__restrict__ sub_start, int nsubs,
                                                    const unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks) {
     const u32 total = reinterpret_cast<const u32 *>(out)[0];
@@ -376,10 +424,12 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 }
 
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
-                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf) {
+                        RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf,
+                        unsigned long long *best, RvPairRec *picks, int nsubs) {
     if (m <= 0) return 0;
     const int64_t nb = ceil_div(m, PAIR_TILE);
-    hipLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf);
+    hipLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf,
+                       best, picks, nsubs);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -389,6 +439,17 @@ int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const 
     hipLaunchKernelGGL(k_pair_pick1, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, best);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pair_pick2, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, (const unsigned long long *)best, picks);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
+                          const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err) {
+    if (ntile <= 0 || nsubs <= 0) return 0;
+    const unsigned g = (unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB);
+    hipLaunchKernelGGL(k_pick_slots<1>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_pick_slots<2>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -153,29 +153,8 @@ __global__ __launch_bounds__(TB) void k_cp_emit(const uint8_t *__restrict__ head
     }
 }
 
-// ---- doubling round ------------------------------------------------------------
-// kk[q] = (G[q] << 32) | (S[q]+h < n ? ISA[S[q]+h] + 1 : 0)
-__global__ __launch_bounds__(TB) void k_round_keys(const sav_t *__restrict__ S, const u32 *__restrict__ G, int64_t m, int64_t n, int64_t h,
-                                                   const u32 *__restrict__ ISA, u64 *__restrict__ kk) {
-    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (q >= m) return;
-    const int64_t s2 = (int64_t)S[q] + h;
-    const u32 r2 = (s2 < n) ? ISA[s2] + 1u : 0u;
-    kk[q] = ((u64)G[q] << 32) | r2;
-}
-
-// after the sort: head/seed inside the compacted list, and SA[P[q]] = S[q]
-__global__ __launch_bounds__(TB) void k_round_heads(const u64 *__restrict__ kk, const u32 *__restrict__ P, const sav_t *__restrict__ S, int64_t m,
-                                                    uint8_t *__restrict__ headq, u32 *__restrict__ seed, sa_t *__restrict__ SA) {
-    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (q >= m) return;
-    const bool hd = (q == 0) || kk[q] != kk[q - 1];
-    headq[q] = hd;
-    const u32 p = P[q];
-    seed[q] = hd ? p : 0u;
-    SA[p] = (sa_t)S[q];
-}
-
+// ---- refinement rounds --------------------------------------------------------
+// ISA of the list's suffixes after a round: the start of their (new) group
 __global__ __launch_bounds__(TB) void k_round_isa(const sav_t *__restrict__ S, const u32 *__restrict__ newG, int64_t m, u32 *__restrict__ ISA) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q >= m) return;

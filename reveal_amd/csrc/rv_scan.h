@@ -29,14 +29,10 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
 int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
                          const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err);
 // out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records.
-// Resets *ovf_counter for the next scan; with nsubs > 0 also initialises the picker tables (best, picks).
+// Resets *ovf_counter for the next scan.
 #define RV_PAIR_HDR 1
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err,
-                           unsigned long long *best, RvPairRec *picks, int nsubs);
-
-// built-in picker: picks[0] = header, picks[1+s] = longest record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none
-int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks);
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err);
 
 #define RV_MULTI_TILE 256
 struct RvMultiRec { u32 l, n, ub, pad; };

@@ -177,16 +177,13 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf,
                                                      const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf,
                                                      const u32 *__restrict__ tileoff, int64_t ntile, RvPairRec *__restrict__ out, u32 out_cap,
-                                                     u32 *__restrict__ ovf_counter, const u32 *__restrict__ err,
-                                                     unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks, int nsubs) {
+                                                     u32 *__restrict__ ovf_counter, const u32 *__restrict__ err) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (id == 0) {
         u32 *hdr = reinterpret_cast<u32 *>(out);
         hdr[0] = tileoff[ntile]; hdr[1] = *ovf_counter; hdr[2] = err ? *err : 0u; hdr[3] = 0;
         *ovf_counter = 0;          // the scan of this launch sequence is done with it: ready for the next scan (no memset per level)
     }
-    // tables of the device-side picker that runs next (k_pair_pick1/2)
-    for (int64_t s2 = id; s2 < nsubs; s2 += (int64_t)gridDim.x * TB) { best[s2] = 0; picks[RV_PAIR_HDR + s2].rank = 0xFFFFFFFFu; }
     out += RV_PAIR_HDR;
     const int64_t t = id / RV_PAIR_SLOTS;
     const u32 j = (u32)(id % RV_PAIR_SLOTS);
@@ -204,7 +201,7 @@ __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict
 // The recursion's built-in callbacks (longest match, ties -> smallest position) need one
 // record per sub-index, not every MUM of the level: two passes over the packed records, an atomicMax on
 // (l, -a) per sub-index and a gather of the winners.  picks[0] = header, picks[1+s] = winner of sub-index s
-// (rank 0xFFFFFFFF = none; the caller fills the buffer with 0xFF).
+// (rank 0xFFFFFFFF = none; the scan kernel initialises the tables).
 __device__ inline int sub_of_rank(const int64_t *__restrict__ sub_start, int nsubs, int64_t r) {
     int lo = 0, hi = nsubs;
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub_start[mid] <= r) lo = mid + 1; else hi = mid; }
@@ -212,30 +209,6 @@ __device__ inline int sub_of_rank(const int64_t *__restrict__ sub_start, int nsu
 }
 __device__ inline u64 pick_key(const RvPairRec &r) { return ((u64)r.l << 32) | (u64)(0xFFFFFFFFu - (u32)r.a); }
 
-__global__ __launch_bounds__(TB) void k_pair_pick1(const RvPairRec *__restrict__ out, u32 out_cap, const int64_t *__restrict__ sub_start, int nsubs,
-                                                   unsigned long long *__restrict__ best) {
-    const u32 total = reinterpret_cast<const u32 *>(out)[0];
-    const u32 n = total < out_cap ? total : out_cap;
-    out += RV_PAIR_HDR;
-    const int lane = threadIdx.x & 63;
-    for (u32 k0 = blockIdx.x * TB; k0 < n; k0 += gridDim.x * TB) {
-        const u32 k = k0 + threadIdx.x;
-        int sub = -1; u64 key = 0;
-        if (k < n) { const RvPairRec r = out[k]; sub = sub_of_rank(sub_start, nsubs, (int64_t)r.rank); key = pick_key(r); }
-        // records are in rank order, so a wave mostly holds one or two sub-indices: one atomic per (wave, sub-index)
-        // instead of one per record (the top levels have tens of thousands of records for a handful of sub-indices)
-        u64 todo = __ballot(sub >= 0);
-        while (todo) {
-            const int leader = (int)__builtin_ctzll(todo);
-            const int lsub = __shfl(sub, leader, 64);
-            const bool mine = sub == lsub;
-            u64 v = mine ? key : 0;
-            for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-            if (lane == leader) atomicMax(&best[lsub], (unsigned long long)v);
-            todo &= ~__ballot(mine);
-        }
-    }
-}
 // The same picker straight from the scan's per-tile slots (+ overflow): no tile-count scan, no compaction -- the
 // untraced recursion never looks at the packed list.  One thread per (tile, slot); it also walks the tile's share of
 // the overflow array.  PASS 1: atomicMax per sub-index; PASS 2: the winners, the header {0, overflow count, *err, 0},
@@ -278,19 +251,6 @@ __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__
             picks[RV_PAIR_HDR + sub] = r;
         }
         if (!__any(q + RV_PAIR_SLOTS < cnt)) break;       // (the wave leaves the loop together: the ballots above need all lanes)
-    }
-}
-
-__global__ __launch_bounds__(TB) void k_pair_pick2(const RvPairRec *__restrict__ out, u32 out_cap, const int64_t *__restrict__ sub_start, int nsubs,
-                                                   const unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks) {
-    const u32 total = reinterpret_cast<const u32 *>(out)[0];
-    const u32 n = total < out_cap ? total : out_cap;
-    if (blockIdx.x == 0 && threadIdx.x == 0) picks[0] = out[0];
-    out += RV_PAIR_HDR;
-    for (u32 k = blockIdx.x * TB + threadIdx.x; k < n; k += gridDim.x * TB) {
-        const RvPairRec r = out[k];
-        const int s = sub_of_rank(sub_start, nsubs, (int64_t)r.rank);
-        if (best[s] == (unsigned long long)pick_key(r)) picks[RV_PAIR_HDR + s] = r;
     }
 }
 
@@ -434,15 +394,6 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
     return 0;
 }
 
-int rv_pair_pick_launch(Workspace &ws, const RvPairRec *out, u32 out_cap, const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks) {
-    if (nsubs <= 0) return 0;
-    hipLaunchKernelGGL(k_pair_pick1, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, best);
-    RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pair_pick2, dim3(256), dim3(TB), 0, ws.stream, out, out_cap, sub_start, nsubs, (const unsigned long long *)best, picks);
-    RV_LAUNCH_CHECK();
-    return 0;
-}
-
 int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
                           const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err) {
     if (ntile <= 0 || nsubs <= 0) return 0;
@@ -455,11 +406,10 @@ int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec 
 }
 
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err,
-                           unsigned long long *best, RvPairRec *picks, int nsubs) {
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err) {
     if (ntile <= 0) return 0;
     hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB)), dim3(TB), 0, ws.stream, slots, ovf, tilecnt, tileovf,
-                       tileoff, ntile, out, out_cap, ovf_counter, err, best, picks, nsubs);
+                       tileoff, ntile, out, out_cap, ovf_counter, err);
     RV_LAUNCH_CHECK();
     return 0;
 }

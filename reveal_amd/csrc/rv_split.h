@@ -54,14 +54,10 @@ struct RvBubbleDesc {
     int     cut0, cut1;  // this child's windows in cut_lo/cut_hi (for SAi upkeep)
 };
 
-// resume state of one (child, cut) when a long move is handed to the grid-wide kernels
+// per (child, cut) of the rounds: where the sequential fallback kernel has to start in the sorted active list
+// (the data-parallel round sets it past the end when it has done the cut)
 struct RvBubbleState {
-    int32_t next;        // next entry of the sorted active list to visit
-    int32_t pending;     // 1: a long move waits for k_long_scan_copy / k_long_copyback, then finalisation
-    int32_t sorted;      // the active list in global memory has been sorted
-    uint32_t tB;         // BWT byte of the moving suffix
-    int64_t e, tS, tL, t;
-    unsigned long long x;   // destination rank found by the grid search (atomicMax)
+    int32_t next;
 };
 
 // tables of the data-parallel bubble rounds (rv_bubble.hip); per-mover arrays are indexed like `list` (descriptor d at woff[d])
@@ -87,7 +83,7 @@ struct RvBubbleArgs {
     u32                *list;     // active ranks, descriptor d at [woff[d], ...)
     uint8_t            *flag;     // one byte per rank of the next level, zero between rounds
     RvBubbleState      *state;    // per descriptor, zeroed per level
-    sa_t  *scrSA;                 // scratch for long moves: the (dead) parent-level arrays, indexed like the next level
+    sa_t  *scrSA;                 // scratch of the data-parallel rounds: the (dead) parent-level arrays, indexed like the next level
     lcp_t *scrLCP;
     uint8_t *scrBWT;
     sa_t  *SA;
@@ -102,18 +98,10 @@ struct RvBubbleArgs {
 int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D, const uint8_t *BWT, int64_t m, const RvLabelTabs &t, const RvSplitArgs &a,
                     int nsplit);
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
-// descriptors [first, first+count_small) belong to ordinary children, the next count_big to large ones
 #define RV_BUBBLE_BIG_N 16384
 // leading children above this many ranks take the data-parallel rounds (rv_bubble.hip); measured on C2: 16 K -> 485 Mbp/s,
 // 256 K -> 541, 512 K -> 555, 1 M -> 550, 2 M -> 511 (below it one workgroup replays the cuts of a child faster than ~18 launches)
 #define RV_BUBBLE_PAR_N 524288
-// children above this size may hand moves longer than RV_BUBBLE_LONG_DIST ranks to grid-wide kernels
-#define RV_BUBBLE_HUGE_N 2097152
-#define RV_BUBBLE_LONG_DIST 262144
-#define RV_BUBBLE_SLICE 32768
-// descriptors of a round are ordered small, big, huge; max_huge_n = largest huge child (0 if none)
-int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int count_huge, int64_t max_huge_n,
-                           int64_t total_window);
 // all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
 // one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)

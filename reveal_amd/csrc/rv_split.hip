@@ -632,9 +632,8 @@ __device__ inline void sai_upkeep(const RvBubbleArgs &b, const RvBubbleDesc &ds,
 // the shift loads the sources [4g-1..4g+2] (one unaligned dwordx4 per array,
 // a dword of bytes for BWT) and stores the group aligned.  A chunk is NT*EG
 // groups, top-down; all of a chunk's sources are loaded before its first store.
-// Returns true when the move was handed to the grid-wide kernels (DEFER only):
-// nothing has been shifted yet, the caller records the pending move and leaves.
-template <int NT, int EG, bool DEFER>
+// (Returns false; the bool is what is left of an earlier version that could hand long moves to grid-wide kernels.)
+template <int NT, int EG>
 __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW, int64_t e,
                                         int64_t *s_v, int *s_max, RvBubbleState *st) {
 #ifdef RV_SA64
@@ -659,23 +658,6 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
     if (s_v[0] == 1) {                                                               // reveal.c:686-709
         const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
         const uint8_t tB = (uint8_t)s_v[3];
-        if (DEFER && e > RV_BUBBLE_LONG_DIST) {
-            // probe: is the destination within RV_BUBBLE_LONG_DIST ranks?  (LCP only, nothing is moved)
-            bool found = false;
-            for (int64_t hi = e; hi > e - RV_BUBBLE_LONG_DIST && !found; hi -= (int64_t)NT * 4) {
-                int hit = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int64_t r = hi - (int64_t)k * NT - threadIdx.x;
-                    if (r >= 1 && r > e - RV_BUBBLE_LONG_DIST && (int64_t)(u32)LCP[r] < t) hit = 1;
-                }
-                found = __syncthreads_or(hit) != 0;
-            }
-            if (!found) {
-                if (threadIdx.x == 0) { st->pending = 1; st->e = e; st->tS = tS; st->tL = tL; st->t = t; st->tB = tB; st->x = 0; }
-                return true;
-            }
-        }
         // the arrays of a child start at an arbitrary rank of the level arrays: align groups on absolute addresses
         const int64_t skew = (int64_t)((reinterpret_cast<uintptr_t>(LCP) >> 2) & 3);     // LCP + (4g - skew) is 16-byte aligned
         int64_t x = 0;
@@ -897,9 +879,8 @@ __device__ inline void wave_execute(const RvBubbleArgs &b, const RvBubbleDesc &d
     }
 }
 
-// Visit lst[start .. cnt) in the reference's order.  Returns the index of the
-// active at which a long move was deferred to the grid kernels (DEFER), or cnt.
-template <int NT, int EL, bool DEFER>
+// Visit lst[start .. cnt) in the reference's order.  Returns cnt.
+template <int NT, int EL>
 __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW,
                                  const u32 *lst, u32 start, u32 cnt, ParScratch &ps, int64_t *s_v, int *s_max, u32 *s_first, RvBubbleState *st) {
     u32 cur = start;
@@ -924,7 +905,7 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
             __threadfence_block();
             __syncthreads();
             if (f >= end) { cur = end; continue; }
-            if (bubble_visit_vec<NT, EL, DEFER>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
+            if (bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
             cur = f + 1;
         }
         return cnt;
@@ -945,7 +926,7 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
         __threadfence_block();
         __syncthreads();
         if (f >= end) { cur = end; continue; }
-        if (bubble_visit_vec<NT, EL, DEFER>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
+        if (bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
         cur = f + 1;
     }
     return cnt;
@@ -958,7 +939,7 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
 // bytes 4096 ranks at a time, which yields them already ordered.
 // NT = 256 for ordinary children, 1024 (8 ranks per thread and step) for the
 // few large ones, whose moves travel up to a quarter of the child.
-template <int NT, int EL, bool DEFER>
+template <int NT, int EL>
 __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL
@@ -983,16 +964,16 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     if (cnt <= BB_CAP) {
         RvBubbleState *st = b.state + dd;
-        const int32_t start = st->next, pending = st->pending, sorted = st->sorted;
-        if (start >= (int32_t)cnt && !pending) return;          // finished in an earlier pass
+        const int32_t start = st->next;
+        if (start >= (int32_t)cnt) return;          // done by the data-parallel round (k_pb_movers sets next past the end)
         u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
         for (u32 k = threadIdx.x; k < np2; k += NT) {
             const u32 v = k < cnt ? b.list[b.woff[dd] + k] : 0xFFFFFFFFu;
             lst[k] = v;
-            if (k < cnt && !sorted) flag[v] = 0;
+            if (k < cnt) flag[v] = 0;
         }
         __syncthreads();
-        if (!sorted) {
+        {
             for (u32 size = 2; size <= np2; size <<= 1)
                 for (u32 stride = size >> 1; stride > 0; stride >>= 1) {
                     for (u32 k = threadIdx.x; k < np2 / 2; k += NT) {
@@ -1003,28 +984,9 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
                     }
                     __syncthreads();
                 }
-            if (DEFER) {      // a later pass resumes from the sorted list
-                for (u32 k = threadIdx.x; k < cnt; k += NT) b.list[b.woff[dd] + k] = lst[k];
-                if (threadIdx.x == 0) st->sorted = 1;
-            }
         }
         u32 ai = (u32)start;
-        if (pending) {
-            // the grid kernels have searched x and shifted [x, e-1] up by one: finish the move (reveal.c:700-708)
-            if (threadIdx.x == 0) {
-                const int64_t e = st->e, tS = st->tS, tL = st->tL, t = st->t, x = (int64_t)st->x;
-                SA[x] = (sa_t)tS;
-                BW[x] = (uint8_t)st->tB;
-                b.SAi[tS] = (sa_t)x;
-                if (x + 1 < ds.n) LCP[x + 1] = (lcp_t)t;
-                if (e < ds.n - 1 && tL < (int64_t)(u32)LCP[e + 1]) LCP[e + 1] = (lcp_t)tL;
-                st->pending = 0; st->x = 0;
-            }
-            __threadfence_block();
-            __syncthreads();
-            ai++;
-        }
-        const u32 stopped = visit_list<NT, EL, DEFER>(b, ds, cw, SA, LCP, BW, lst, ai, cnt, ps, s_v, s_max, &s_first, st);
+        const u32 stopped = visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, ai, cnt, ps, s_v, s_max, &s_first, st);
         if (threadIdx.x == 0) st->next = (int32_t)stopped;
         return;
     }
@@ -1044,7 +1006,7 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
         u32 q = before + inc - mine;
         for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
         __syncthreads();
-        (void)visit_list<NT, EL, false>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+        (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
         __syncthreads();
     }
     if (threadIdx.x == 0) b.state[dd].next = 0x7fffffff;
@@ -1112,7 +1074,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
                     }
                     __syncthreads();
                 }
-            (void)visit_list<NT, EL, false>(b, ds, cw, SA, LCP, BW, lst, 0, cnt, ps, s_v, s_max, &s_first, nullptr);
+            (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, cnt, ps, s_v, s_max, &s_first, nullptr);
         } else {
             constexpr int FL = BB_CAP / NT;
             for (int64_t base = 0; base < ds.n; base += BB_CAP) {
@@ -1130,92 +1092,12 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
                 u32 qq = before + inc - mine;
                 for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[qq++] = (u32)(r0 + k);
                 __syncthreads();
-                (void)visit_list<NT, EL, false>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+                (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
                 __syncthreads();
             }
         }
         __threadfence_block();
         __syncthreads();
-    }
-}
-
-// ---- long moves: grid-wide search + copy-out, then copy-back shifted by one -------------------
-// blockIdx.x = slice of RV_BUBBLE_SLICE source ranks, blockIdx.y = huge descriptor.
-__global__ __launch_bounds__(TB) void k_long_scan_copy(RvBubbleArgs b, int first) {
-    const int dd = first + blockIdx.y;
-    const RvBubbleState st = b.state[dd];
-    if (st.pending != 1) return;
-    const RvBubbleDesc ds = b.desc[dd];
-    const int64_t lo = (int64_t)blockIdx.x * RV_BUBBLE_SLICE;
-    const int64_t hi = lo + RV_BUBBLE_SLICE < st.e ? lo + RV_BUBBLE_SLICE : st.e;      // sources are ranks [0, e)
-    if (lo >= hi) return;
-    const sa_t *SA = b.SA + ds.off; const lcp_t *LCP = b.LCP + ds.off; const uint8_t *BW = b.BWT + ds.off;
-    sa_t *oS = b.scrSA + ds.off; lcp_t *oL = b.scrLCP + ds.off; uint8_t *oB = b.scrBWT + ds.off;
-    long long best = -1;
-#ifdef RV_SA64
-    typedef longlong4 sa4_t;
-#else
-    typedef int4 sa4_t;
-#endif
-    for (int64_t r0 = lo + (int64_t)threadIdx.x * 4; r0 < hi; r0 += (int64_t)TB * 4) {
-        if (r0 + 4 <= hi) {       // 16-byte accesses (the child's slice of the level arrays has arbitrary alignment)
-            sa4_t vs; int4 vl; u32 vb;
-            __builtin_memcpy(&vs, SA + r0, sizeof vs); __builtin_memcpy(&vl, LCP + r0, 16); __builtin_memcpy(&vb, BW + r0, 4);
-            __builtin_memcpy(oS + r0, &vs, sizeof vs); __builtin_memcpy(oL + r0, &vl, 16); __builtin_memcpy(oB + r0, &vb, 4);
-            const u32 lv[4] = {(u32)vl.x, (u32)vl.y, (u32)vl.z, (u32)vl.w};
-#pragma unroll
-            for (int j = 0; j < 4; j++) if (r0 + j >= 1 && (int64_t)lv[j] < st.t) best = r0 + j;
-        } else {
-            for (int64_t r = r0; r < hi; r++) {
-                const lcp_t l = LCP[r];
-                oS[r] = SA[r]; oL[r] = l; oB[r] = BW[r];
-                if (r >= 1 && (int64_t)(u32)l < st.t) best = r;
-            }
-        }
-    }
-    for (int d = 32; d >= 1; d >>= 1) { const long long o = __shfl_down(best, d, 64); best = o > best ? o : best; }
-    if ((threadIdx.x & 63) == 0 && best > 0) atomicMax(&b.state[dd].x, (unsigned long long)best);
-}
-
-__global__ __launch_bounds__(TB) void k_long_copyback(RvBubbleArgs b, int first) {
-    __shared__ CutWin cw;
-    const int dd = first + blockIdx.y;
-    const RvBubbleState st = b.state[dd];
-    if (st.pending != 1) return;
-    const RvBubbleDesc ds = b.desc[dd];
-    const int64_t x = (int64_t)st.x;
-    int64_t lo = (int64_t)blockIdx.x * RV_BUBBLE_SLICE;
-    const int64_t hi = lo + RV_BUBBLE_SLICE < st.e ? lo + RV_BUBBLE_SLICE : st.e;
-    if (lo < x) lo = x;                                                             // sources [x, e) move to [x+1, e]
-    if (lo >= hi) return;
-    {
-        const int nc = ds.cut1 - ds.cut0 < BB_MAXCUT ? ds.cut1 - ds.cut0 : BB_MAXCUT;
-        if ((int)threadIdx.x < nc) { cw.lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw.hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
-        if (threadIdx.x == 0) cw.n = nc;
-    }
-    __syncthreads();
-    sa_t *SA = b.SA + ds.off; lcp_t *LCP = b.LCP + ds.off; uint8_t *BW = b.BWT + ds.off;
-    const sa_t *iS = b.scrSA + ds.off; const lcp_t *iL = b.scrLCP + ds.off; const uint8_t *iB = b.scrBWT + ds.off;
-#ifdef RV_SA64
-    typedef longlong4 sa4_t;
-#else
-    typedef int4 sa4_t;
-#endif
-    for (int64_t r0 = lo + (int64_t)threadIdx.x * 4; r0 < hi; r0 += (int64_t)TB * 4) {
-        if (r0 + 4 <= hi) {
-            sa4_t vs; int4 vl; u32 vb;
-            __builtin_memcpy(&vs, iS + r0, sizeof vs); __builtin_memcpy(&vl, iL + r0, 16); __builtin_memcpy(&vb, iB + r0, 4);
-            __builtin_memcpy(SA + r0 + 1, &vs, sizeof vs); __builtin_memcpy(LCP + r0 + 1, &vl, 16); __builtin_memcpy(BW + r0 + 1, &vb, 4);
-            const sa_t *ps = reinterpret_cast<const sa_t *>(&vs);
-#pragma unroll
-            for (int j = 0; j < 4; j++) sai_upkeep(b, ds, cw, ps[j], r0 + j + 1);
-        } else {
-            for (int64_t r = r0; r < hi; r++) {
-                const sa_t p = iS[r];
-                SA[r + 1] = p; LCP[r + 1] = iL[r]; BW[r + 1] = iB[r];
-                sai_upkeep(b, ds, cw, p, r + 1);
-            }
-        }
     }
 }
 
@@ -1265,41 +1147,6 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
     return 0;
 }
 
-int rv_bubble_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count_small, int count_big, int count_huge, int64_t max_huge_n,
-                           int64_t total_window) {
-    const int count = count_small + count_big + count_huge;
-    if (count <= 0 || total_window <= 0) return 0;
-    hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
-    RV_LAUNCH_CHECK();
-    if (count_small > 0) {
-        hipLaunchKernelGGL((k_bubble_apply<256, 1, false>), dim3((unsigned)count_small), dim3(256), 0, ws.stream, b, first);
-        RV_LAUNCH_CHECK();
-    }
-    if (count_big > 0) {
-        hipLaunchKernelGGL((k_bubble_apply<1024, 4, false>), dim3((unsigned)count_big), dim3(1024), 0, ws.stream, b, first + count_small);
-        RV_LAUNCH_CHECK();
-    }
-    if (count_huge > 0) {
-        // huge children: the per-child workgroup stops at a move longer than RV_BUBBLE_LONG_DIST ranks; two grid-wide
-        // kernels do that move; the workgroup resumes.  A child of n ranks has about log4(n / 2*LONG_DIST) such moves per cut.
-        const int h0 = first + count_small + count_big;
-        int rounds = 1;
-        for (int64_t v = max_huge_n / (2 * RV_BUBBLE_LONG_DIST); v >= 4; v /= 4) rounds++;
-        const dim3 grid((unsigned)ceil_div(max_huge_n, RV_BUBBLE_SLICE), (unsigned)count_huge);
-        for (int r = 0; r < rounds; r++) {
-            hipLaunchKernelGGL((k_bubble_apply<1024, 4, true>), dim3((unsigned)count_huge), dim3(1024), 0, ws.stream, b, h0);
-            RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_long_scan_copy, grid, dim3(TB), 0, ws.stream, b, h0);
-            RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_long_copyback, grid, dim3(TB), 0, ws.stream, b, h0);
-            RV_LAUNCH_CHECK();
-        }
-        hipLaunchKernelGGL((k_bubble_apply<1024, 4, false>), dim3((unsigned)count_huge), dim3(1024), 0, ws.stream, b, h0);   // whatever is left
-        RV_LAUNCH_CHECK();
-    }
-    return 0;
-}
-
 int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window) {
     if (count <= 0 || total_window <= 0) return 0;
     hipLaunchKernelGGL(k_bubble_window, dim3((unsigned)ceil_div(total_window, TB)), dim3(TB), 0, ws.stream, b, first, count, total_window);
@@ -1309,7 +1156,7 @@ int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int
 
 int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count) {
     if (count <= 0) return 0;
-    hipLaunchKernelGGL((k_bubble_apply<1024, 4, false>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, first);
+    hipLaunchKernelGGL((k_bubble_apply<1024, 4>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, first);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -122,6 +122,8 @@ struct Align {
     std::vector<int> tile_sub;
     std::vector<int64_t> mpre, sub_start, woff, toff, next_ss;
     const int64_t *d_next_ss = nullptr;      // device copy of the next level's sub-index starts (inside dTab)
+    const int *d_next_want = nullptr;        // ... and of its sub-indices' sample counts
+    std::vector<u32> pick_l; std::vector<sa_t> pick_pos;
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
@@ -274,9 +276,27 @@ int rv_frontier_scan(rv_index *h) {
             a->nmums[(size_t)si]++;
         }
     } else {
+        if (a->full_only && a->level > 0) {
+            // built-in picker without tracing: the device returns, per sub-index, the match the picker would take (the tables
+            // came with the previous commit's upload)
+            RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->pick_l, a->pick_pos));
+            a->ml.clear(); a->mn.clear(); a->moff.assign(1, 0); a->mso.clear(); a->mpos.clear();
+            const int W = h->nsamples;
+            for (int s2 = 0; s2 < ns; s2++) {
+                if (a->pick_l[(size_t)s2] == 0) continue;
+                const int want = a->lv.nsamples[(size_t)s2];
+                a->mum_first[(size_t)s2] = (int64_t)a->ml.size(); a->nmums[(size_t)s2] = 1;
+                a->ml.push_back(a->pick_l[(size_t)s2]); a->mn.push_back(want);
+                for (int k = 0; k < want; k++) {
+                    const int64_t p = (int64_t)a->pick_pos[(size_t)s2 * W + k];
+                    a->mso.push_back((uint16_t)sample_of(h, p)); a->mpos.push_back(p);
+                }
+                a->moff.push_back((int64_t)a->mpos.size());
+            }
+        } else {
         std::vector<int64_t> ub;
         const int64_t *d_ss = nullptr; const int *d_want = nullptr;
-        if (a->full_only) {       // built-in picker without tracing: let the scan keep only matches present in every sample of their sub-index
+        if (a->full_only) {       // (level 0: the device tables of the picker are not there yet) keep only matches present in every sample of their sub-index
             Packer &pk = a->pk;
             pk.clear();
             std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
@@ -294,6 +314,7 @@ int rv_frontier_scan(rv_index *h) {
             if (si >= ns) { rv_set_error("scan record outside the frontier"); return -1; }
             if (a->nmums[(size_t)si] == 0) a->mum_first[(size_t)si] = (int64_t)k;
             a->nmums[(size_t)si]++;
+        }
         }
     }
     a->scanned = true;
@@ -561,7 +582,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !getenv("RV_BUBBLE_NO_MERGE")) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
-    const size_t o_nss = pk.addv(a->next_ss);
+    const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
     u32 class_total[4] = {0, 0, 0, 0};
     for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
@@ -571,7 +592,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
-    a->d_next_ss = (const int64_t *)(tb + o_nss);
+    a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant);
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));

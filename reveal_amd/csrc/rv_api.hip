@@ -405,6 +405,37 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     return -1;
 }
 
+// built-in picker of the untraced recursion, more than two samples: one (l, members) per sub-index, picked on the device
+int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn,
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos) {
+    pick_l.assign((size_t)nsubs, 0); pick_pos.clear();
+    if (m <= 1 || nsubs <= 0) return 0;
+    hipStream_t q = h->ws.stream;
+    const int W = h->nsamples;
+    DBuf &bbest = h->ws.misc[12], &bl = h->ws.misc[13], &bpos = h->ws.misc[7], &bcand = h->ws.misc[8], &bcnt = h->ws.misc[1];
+    RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bl.reserve((size_t)nsubs * 4)); RV_TRY(bpos.reserve((size_t)nsubs * W * sizeof(sa_t)));
+    RV_TRY(bcnt.reserve(64));
+    if (bcand.cap < 65536 * RV_MULTI_CAND_BYTES) RV_TRY(bcand.reserve((size_t)std::max<int64_t>(65536, m / 64) * RV_MULTI_CAND_BYTES));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        const size_t ccap = bcand.cap / RV_MULTI_CAND_BYTES;
+        int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
+        RV_TRY(rv_multi_pick_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), W, minl, minn, d_sub_start, d_sub_want, nsubs,
+                                    bbest.as<unsigned long long>(), bl.as<u32>(), bpos.as<sa_t>(), (RvMultiCand *)bcand.p,
+                                    (u32)std::min<size_t>(ccap, 0xffffffffu), bcnt.as<u32>()));
+        h->prof.end(q, id);
+        u32 ncand = 0;
+        pick_pos.resize((size_t)nsubs * W);
+        RV_HIP(hipMemcpyAsync(&ncand, bcnt.p, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(pick_l.data(), bl.p, (size_t)nsubs * 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(pick_pos.data(), bpos.p, (size_t)nsubs * W * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        if (ncand <= ccap) return 0;
+        RV_TRY(bcand.reserve((size_t)ncand * RV_MULTI_CAND_BYTES));
+    }
+    rv_set_error("multi picker: candidate buffer sizing failed");
+    return -1;
+}
+
 extern "C" {
 
 /* reveal.c:436-580 / 292-434 */

@@ -42,3 +42,12 @@ struct RvMultiRec { u32 l, n, ub, pad; };
 int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
                          const int64_t *sub_start, const int *sub_want, int nsubs);   // sub_want != NULL: keep only matches with n == sub_want[sub of ub]
+
+// Built-in picker for more than two samples: per sub-index the longest match present in every one of its samples
+// (ties: smallest minimum position).  pick_l[s] = its length (0 = none), pick_pos[s*nsamples ..] = its members in SA order.
+// *cand_count > cand_cap afterwards: the candidate list was too small, grow and rerun.
+struct RvMultiCand;
+int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
+                         const int64_t *sub_start, const int *sub_want, int nsubs, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
+                         RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
+#define RV_MULTI_CAND_BYTES 16

@@ -373,6 +373,89 @@ __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, 
 
 }  // namespace
 
+
+// ---- built-in picker for more than two samples ---------------------------------------------
+// The untraced recursion's picker only takes matches present in every sample of their sub-index
+// (schemes.py:227): an LCP interval of exactly want = nsamples(sub-index) ranks.  For a fixed size the
+// interval ending at rank u is known directly -- lb = u - want + 1, l = min LCP[lb+1..u], valid iff
+// LCP[lb] < l > LCP[u+1] -- so no walk through nested intervals, no record lists, no host-side merge:
+// pass 1 takes an atomicMax of (l, -min position) per sub-index over the qualifying ranks (and lists
+// them), pass 2 lets the winners write their members.
+struct RvMultiCand { u32 ub, sub; unsigned long long key; };
+
+__global__ __launch_bounds__(TB) void k_multi_pick1(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ BWT,
+                                                    const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
+                                                    const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs,
+                                                    unsigned long long *__restrict__ best, u32 *__restrict__ /*pick_l: zeroed by the host*/,
+                                                    RvMultiCand *__restrict__ cand, u32 cand_cap, u32 *__restrict__ cand_count) {
+    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const u32 lmin = (u32)(minl > 1 ? minl : 1);
+    bool ok = u >= 1 && u < m;
+    u32 cur = 0, nxt = 0;
+    if (ok) { cur = (u32)LCP[u]; nxt = (u + 1 < m) ? (u32)LCP[u + 1] : 0u; ok = cur > nxt && cur >= lmin; }
+    int s = 0; int64_t lb = 0; u32 l = 0;
+    if (ok) {
+        int lo2 = 0, hi2 = nsubs;
+        while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
+        s = lo2 - 1;
+        const int want = sub_want[s];
+        lb = u - want + 1;
+        ok = want >= minn && want >= 2 && want <= nsamples && lb >= sub_start[s];
+        if (ok) {
+            l = cur;
+            for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
+            ok = l > nxt && l >= lmin && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u);
+        }
+    }
+    unsigned long long key = 0;
+    if (ok) {
+        sa_t mn = SA[lb];
+        for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; }
+        key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
+        atomicMax(&best[s], key);
+    }
+    const u64 bal = __ballot(ok);
+    if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(cand_count, (u32)__popcll(bal));
+        base = __shfl(base, 0, 64);
+        if (ok) {
+            const u32 q = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+            if (q < cand_cap) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)s; c.key = key; cand[q] = c; }
+        }
+    }
+}
+__global__ __launch_bounds__(TB) void k_multi_pick2(const sa_t *__restrict__ SA, const int *__restrict__ sub_want, int W,
+                                                    const unsigned long long *__restrict__ best, const RvMultiCand *__restrict__ cand, u32 cand_cap,
+                                                    const u32 *__restrict__ cand_count, u32 *__restrict__ pick_l, sa_t *__restrict__ pick_pos) {
+    const u32 total = *cand_count < cand_cap ? *cand_count : cand_cap;
+    for (u32 q = blockIdx.x * TB + threadIdx.x; q < total; q += gridDim.x * TB) {
+        const RvMultiCand c = cand[q];
+        if (best[c.sub] != c.key) continue;
+        const int want = sub_want[c.sub];
+        const int64_t lb = (int64_t)c.ub - want + 1;
+        pick_l[c.sub] = (u32)(c.key >> 32);
+        for (int k = 0; k < want; k++) pick_pos[(size_t)c.sub * W + k] = SA[lb + k];      // members in SA order, as the reference emits them
+    }
+}
+
+int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
+                         const int64_t *sub_start, const int *sub_want, int nsubs, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
+                         RvMultiCand *cand, u32 cand_cap, u32 *cand_count) {
+    if (m <= 0 || nsubs <= 0) return 0;
+    RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
+    RV_HIP(hipMemsetAsync(pick_l, 0, (size_t)nsubs * 4, ws.stream));
+    RV_HIP(hipMemsetAsync(cand_count, 0, 4, ws.stream));
+    hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
+                       sub_start, sub_want, nsubs, best, pick_l, cand, cand_cap, cand_count);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_multi_pick2, dim3(256), dim3(TB), 0, ws.stream, SA, sub_want, nsamples, (const unsigned long long *)best,
+                       (const RvMultiCand *)cand, cand_cap, (const u32 *)cand_count, pick_l, pick_pos);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
                          const int64_t *sub_start, const int *sub_want, int nsubs) {

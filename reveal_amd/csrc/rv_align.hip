@@ -101,10 +101,12 @@ struct Align {
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
-    DBuf dD, dTab, dTile, dList, dFlag, dPar;
+    DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg;
     HBuf hLeafRoots[2];
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
+    hipStream_t bub_stream = nullptr;      // LDS-resident bubble kernels run here, beside the main stream's bubble kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
     bool roots_inflight[2] = {false, false};
     bool flag_clean = false;     // dFlag is all zero
@@ -127,7 +129,7 @@ struct Align {
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
     std::vector<std::vector<RvBubbleDesc>> rounds;
-    std::vector<RvBubbleDesc> kids_small, kids_big;
+    std::vector<RvBubbleDesc> kids_small, kids_big, kids_lds;
     struct Kid { int64_t off, n; int c0, c1; int64_t m0, wsum; };
     std::vector<Kid> kid_tmp;
     // results of rv_align_builtin
@@ -138,8 +140,9 @@ struct Align {
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
+        if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); ev_fork = ev_join = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_roots[k]) { (void)hipEventDestroy(ev_roots[k]); ev_roots[k] = nullptr; }
@@ -439,7 +442,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->child_base.assign((size_t)ns * 3, 0); a->child_n.assign((size_t)ns * 3, 0);
     a->sub_start.resize((size_t)ns + 1);
     for (auto &r : a->rounds) r.clear();
-    a->kids_small.clear(); a->kids_big.clear();
+    a->kids_small.clear(); a->kids_big.clear(); a->kids_lds.clear();
+    const int64_t lds_n = getenv("RV_BUBBLE_NO_LDS") ? 0 : RV_BUBBLE_LDS_N;
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
     // leading children above this many ranks take the data-parallel bubble rounds (RV_BUBBLE_PAR_MIN: test hook)
@@ -518,10 +522,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // children join them as long as there are few of them (measured: with thousands of small children per level the
     // one-workgroup-per-child kernel is the cheaper way, C3/C4): their kernel would only add its own latency in front.
     const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !getenv("RV_BUBBLE_NO_JOIN");
+    // The LDS kernels pay off by throughput (thousands of small children per level: many samples, or very large inputs).  A
+    // few hundred small children ride along with the larger ones for free (measured on C2: 612 vs 597 Mbp/s).
+    size_t lds_candidates = 0;
+    for (const auto &kd : a->kid_tmp) lds_candidates += kd.n <= lds_n;
+    const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && getenv("RV_BUBBLE_LDS_ALWAYS"));
     for (const auto &kd : a->kid_tmp) {
-        if (!all_par && kd.n <= par_min) {             // every cut of this child in one workgroup, sequentially
+        if ((!all_par && kd.n <= par_min) || (use_lds && kd.n <= lds_n)) {             // every cut of this child in one workgroup, sequentially
             RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = 0; bd.wlo = 0; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
-            (kd.n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
+            ((use_lds && kd.n <= lds_n) ? a->kids_lds : kd.n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
             continue;
         }
         for (int q = kd.c0; q < kd.c1; q++) {          // one cut per round, data-parallel (rv_bubble.hip)
@@ -580,7 +589,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // one launch instead of two when a level has few small children next to large ones (the kernels would run one after the
     // other on the stream; in a 1024-thread workgroup a small child simply finishes early)
     if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !getenv("RV_BUBBLE_NO_MERGE")) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
-    const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big);
+    int lds_count[3] = {0, 0, 0};
+    {   // LDS children by size class (stable: the order inside a class does not matter)
+        auto cls = [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_LDS_N0 ? 0 : x.n <= RV_BUBBLE_LDS_N1 ? 1 : 2; };
+        std::stable_sort(a->kids_lds.begin(), a->kids_lds.end(), [&](const RvBubbleDesc &x, const RvBubbleDesc &y) { return cls(x) < cls(y); });
+        for (auto &x : a->kids_lds) lds_count[cls(x)]++;
+        // few children: one launch with the largest configuration (occupancy does not matter, a launch does)
+        if (a->kids_lds.size() <= 512) { lds_count[2] = (int)a->kids_lds.size(); lds_count[0] = lds_count[1] = 0; }
+    }
+    const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big), o_kl = pk.addv(a->kids_lds);
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
@@ -637,7 +654,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->lg[2] = t1 - t0;           // label/split/lower enqueued
 
     // ---- bubble_sort rounds (reveal.c:1250-1252, :666-727) -----------------------------------
-    if (!a->descs.empty() || !a->kids_small.empty() || !a->kids_big.empty()) {
+    if (!a->descs.empty() || !a->kids_small.empty() || !a->kids_big.empty() || !a->kids_lds.empty()) {
         RvBubbleArgs ba;
         ba.desc = (const RvBubbleDesc *)(tb + o_desc); ba.woff = (const int64_t *)(tb + o_woff);
         ba.cnt = (u32 *)(tb + o_bcnt); ba.list = a->dList.as<u32>();
@@ -649,6 +666,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         ba.flag = a->dFlag.as<uint8_t>();
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
         ba.state = (RvBubbleState *)(tb + o_bstate);
+        ba.dbg = nullptr;
+        if (getenv("RV_LEVEL_LOG")) { if (!a->dDbg.p) { RV_TRY(a->dDbg.reserve(64)); RV_HIP(hipMemsetAsync(a->dDbg.p, 0, 64, q)); } ba.dbg = a->dDbg.as<unsigned long long>(); }
         // the parent level is dead once split has run (at level 0 these are the main SA/LCP/BWT, which the
         // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
@@ -673,6 +692,21 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             ba.par.Qlast = pb;
         }
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
+        // children that fit into LDS: on their own stream, beside the kernels of the larger children (a kernel boundary on one
+        // stream is a barrier; the level's bubble time is then the longer of the two groups, not their sum)
+        bool forked = false;
+        if (!a->kids_lds.empty()) {
+            if (!a->bub_stream) {
+                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
+                RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+                RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+            }
+            const bool alone = a->kids_small.empty() && a->kids_big.empty() && a->descs.empty();
+            Workspace lw; lw.stream = alone ? q : a->bub_stream;
+            if (!alone) { RV_HIP(hipEventRecord(a->ev_fork, q)); RV_HIP(hipStreamWaitEvent(a->bub_stream, a->ev_fork, 0)); }
+            RV_TRY(rv_bubble_children_lds_launch(lw, ba, (const RvBubbleDesc *)(tb + o_kl), lds_count));
+            if (!alone) { RV_HIP(hipEventRecord(a->ev_join, a->bub_stream)); forked = true; }
+        }
         RV_TRY(rv_bubble_children_launch(h->ws, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
@@ -680,6 +714,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
                                               a->toff[(size_t)(first + count)] - a->toff[(size_t)first]));
             if (round_seq[r]) RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count));
         }
+        if (forked) RV_HIP(hipStreamWaitEvent(q, a->ev_join, 0));
         h->prof.end(q, id);
     }
     if (!a->multi && m_next > 1) {
@@ -893,6 +928,9 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
             const double tl3 = now_s();
             int64_t biggest = 0;
             for (int s2 = 0; s2 < a->lv.size(); s2++) biggest = std::max<int64_t>(biggest, a->lv.n[(size_t)s2]);
+            unsigned long long dbg[8] = {0};
+            if (a->dDbg.p) { (void)hipMemcpy(dbg, a->dDbg.p, 64, hipMemcpyDeviceToHost); (void)hipMemset(a->dDbg.p, 0, 64); }
+            fprintf(stderr, "      bubble (sequential kernels): cuts %llu actives %llu whole-wg visits %llu chunks %llu concurrent %llu\n", dbg[3], dbg[4], dbg[0], dbg[1], dbg[2]);
             fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | leafprep %6.1f scan %6.1f host %6.1f | commit: tables %6.1f upload %6.1f split-enq %6.1f bubble-enq %6.1f | drain %7.1f us | next biggest %lld\n",
                     log_level, log_ns, log_leaf, (long long)log_m, (tl_leaf - tl0) * 1e6, (t0 - tl_leaf) * 1e6, (tl1 - t0) * 1e6,
                     a->lg[0] * 1e6, (a->lg[1] - a->lg[0]) * 1e6, (a->lg[2] - a->lg[1]) * 1e6, (tl2 - tl1) * 1e6 - a->lg[2] * 1e6, (tl3 - tl2) * 1e6,

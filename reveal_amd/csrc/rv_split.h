@@ -92,6 +92,7 @@ struct RvBubbleArgs {
     sa_t  *SAi;
     const sa_t *cut_lo, *cut_hi;
     u32   *err;
+    unsigned long long *dbg;      // RV_LEVEL_LOG: [0] whole-workgroup visits [1] chunks shifted [2] concurrent visits [3] cuts with actives [4] actives
 };
 
 // D-label + stable 3-way partition of every split sub-index (D: one scratch byte per rank)
@@ -99,11 +100,17 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
                     int nsplit);
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
 #define RV_BUBBLE_BIG_N 16384
+// children up to this many ranks are bubbled on LDS copies of their arrays (one workgroup, all cuts)
+#define RV_BUBBLE_LDS_N0 2048
+#define RV_BUBBLE_LDS_N1 4096
+#define RV_BUBBLE_LDS_N2 8192
+#define RV_BUBBLE_LDS_N RV_BUBBLE_LDS_N2
 // leading children above this many ranks take the data-parallel rounds (rv_bubble.hip); measured on C2: 16 K -> 485 Mbp/s,
 // 256 K -> 541, 512 K -> 555, 1 M -> 550, 2 M -> 511 (below it one workgroup replays the cuts of a child faster than ~18 launches)
 #define RV_BUBBLE_PAR_N 524288
 // all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
+int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count3);   // descriptors sorted by size class
 // one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)
 int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles);
 int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window);

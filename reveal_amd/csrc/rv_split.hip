@@ -664,6 +664,7 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
         int64_t gtop = (e + skew) >> 2;                  // group of rank r: (r + skew) >> 2, ranks 4g-skew .. 4g-skew+3
         bool done = false;
         while (!done) {
+            if (b.dbg && threadIdx.x == 0) atomicAdd(&b.dbg[1], 1ull);
             const int64_t gl = gtop - (int64_t)NT * EG + 1 > 0 ? gtop - (int64_t)NT * EG + 1 : 0;
             sa4_t vs[EG]; int4 vl[EG]; u32 vb[EG];
             int best = -1;                               // largest rank offset (r - rbase) in this chunk with LCP[r] < t
@@ -770,11 +771,12 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
 // than BB_SCAN ranks away, or whose range touches its predecessor's, ends the run
 // and goes through the whole-workgroup visit.
 constexpr int BB_SCAN = 32;
-struct ParScratch { u32 lo[BB_CAP]; uint8_t kind[BB_CAP]; };     // per active: first rank of its range, 0 none / 1 move / 2 truncate / 3 long
+template <int CAP> struct ParScratchT { u32 lo[CAP]; uint8_t kind[CAP]; };     // per active: first rank of its range, 0 none / 1 move / 2 truncate / 3 long
+typedef ParScratchT<BB_CAP> ParScratch;
 
 // classify actives [from, cnt) on the current arrays
-template <int NT>
-__device__ inline void par_classify(const RvBubbleDesc &ds, const sa_t *SA, const lcp_t *LCP, const u32 *lst, u32 from, u32 cnt, ParScratch &ps) {
+template <int NT, class PS>
+__device__ inline void par_classify(const RvBubbleDesc &ds, const sa_t *SA, const lcp_t *LCP, const u32 *lst, u32 from, u32 cnt, PS &ps) {
     const int64_t n = ds.n, B = ds.B;
     for (u32 a = from + threadIdx.x; a < cnt; a += NT) {
         const int64_t e = lst[a];
@@ -800,9 +802,9 @@ __device__ inline void par_classify(const RvBubbleDesc &ds, const sa_t *SA, cons
 }
 
 // execute actives [from, to) concurrently (their ranges are disjoint, none is long): reveal.c:686-721 per thread
-template <int NT>
+template <int NT, class PS>
 __device__ inline void par_execute(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW,
-                                   const u32 *lst, u32 from, u32 to, const ParScratch &ps) {
+                                   const u32 *lst, u32 from, u32 to, const PS &ps) {
     const int64_t n = ds.n, B = ds.B;
     for (u32 a = from + threadIdx.x; a < to; a += NT) {
         const int64_t e = lst[a];
@@ -880,9 +882,9 @@ __device__ inline void wave_execute(const RvBubbleArgs &b, const RvBubbleDesc &d
 }
 
 // Visit lst[start .. cnt) in the reference's order.  Returns cnt.
-template <int NT, int EL>
+template <int NT, int EL, class PS>
 __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, const CutWin &cw, sa_t *SA, lcp_t *LCP, uint8_t *BW,
-                                 const u32 *lst, u32 start, u32 cnt, ParScratch &ps, int64_t *s_v, int *s_max, u32 *s_first, RvBubbleState *st) {
+                                 const u32 *lst, u32 start, u32 cnt, PS &ps, int64_t *s_v, int *s_max, u32 *s_first, RvBubbleState *st) {
     u32 cur = start;
     // A handful of actives: classifying them first only adds latency (measured on C2: 12 ms sequential vs 14.5 ms) ->
     // plain sequential visits.  The concurrent path pays off with many actives per cut (closely related samples).
@@ -905,6 +907,7 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
             __threadfence_block();
             __syncthreads();
             if (f >= end) { cur = end; continue; }
+            if (b.dbg && threadIdx.x == 0) atomicAdd(&b.dbg[0], 1ull);
             if (bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
             cur = f + 1;
         }
@@ -912,7 +915,7 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
     }
     while (cur < cnt) {
         const u32 end = cnt - cur > (u32)NT ? cur + NT : cnt;       // look one active per thread ahead
-        par_classify<NT>(ds, SA, LCP, lst, cur, end, ps);
+        par_classify<NT, PS>(ds, SA, LCP, lst, cur, end, ps);
         if (threadIdx.x == 0) *s_first = end;
         __syncthreads();
         // first active that cannot join the run: long, or its range touches the previous one
@@ -922,10 +925,11 @@ __device__ inline u32 visit_list(const RvBubbleArgs &b, const RvBubbleDesc &ds, 
         }
         __syncthreads();
         const u32 f = *s_first;
-        par_execute<NT>(b, ds, cw, SA, LCP, BW, lst, cur, f, ps);
+        par_execute<NT, PS>(b, ds, cw, SA, LCP, BW, lst, cur, f, ps);
         __threadfence_block();
         __syncthreads();
         if (f >= end) { cur = end; continue; }
+        if (b.dbg && threadIdx.x == 0) { atomicAdd(&b.dbg[0], 1ull); atomicAdd(&b.dbg[2], (unsigned long long)(f - cur)); }
         if (bubble_visit_vec<NT, EL>(b, ds, cw, SA, LCP, BW, (int64_t)lst[f], s_v, s_max, st)) return f;
         cur = f + 1;
     }
@@ -986,7 +990,7 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
                 }
         }
         u32 ai = (u32)start;
-        const u32 stopped = visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, ai, cnt, ps, s_v, s_max, &s_first, st);
+        const u32 stopped = visit_list<NT, EL, ParScratch>(b, ds, cw, SA, LCP, BW, lst, ai, cnt, ps, s_v, s_max, &s_first, st);
         if (threadIdx.x == 0) st->next = (int32_t)stopped;
         return;
     }
@@ -1006,7 +1010,7 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
         u32 q = before + inc - mine;
         for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[q++] = (u32)(r0 + k);
         __syncthreads();
-        (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+        (void)visit_list<NT, EL, ParScratch>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
         __syncthreads();
     }
     if (threadIdx.x == 0) b.state[dd].next = 0x7fffffff;
@@ -1042,6 +1046,46 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
         const int64_t B = (int64_t)b.cut_hi[q], wlo = (int64_t)b.cut_lo[q];
         if (wlo >= B) continue;                                   // uniform
         ds.B = B;
+        if (ds.n <= 4 * BB_CAP) {
+            // Small child: the ranks that can act are found by reading the child itself, 4096 ranks at a time -- already in
+            // visiting order, no SAi gathers over the window, no flags, no sort.  (With many samples a level has tens of
+            // thousands of (child, cut) pairs with a few dozen actives each; the window pass and the sort were most of
+            // their 150 us.)  A chunk is examined after the chunks below it have been visited: visits only lower values of
+            // ranks not yet visited, and the test is the one the reference would evaluate at that moment anyway.
+            constexpr int FL = BB_CAP / NT;
+            for (int64_t base = 0; base < ds.n; base += BB_CAP) {
+                const int64_t r0 = base + (int64_t)threadIdx.x * FL;
+                u32 bits = 0;
+#pragma unroll
+                for (int k = 0; k < FL; k++) {
+                    const int64_t r = r0 + k;
+                    if (r < ds.n) {
+                        const int64_t p = (int64_t)SA[r];
+                        const int64_t lc = (int64_t)(u32)LCP[r];
+                        const int64_t ln = (r + 1 < ds.n) ? (int64_t)(u32)LCP[r + 1] : 0;
+                        if ((p >= wlo) & (p < B) & ((p + lc > B) | (p + ln > B))) bits |= 1u << k;
+                    }
+                }
+                const u32 mine = __popc(bits);
+                u32 inc = mine;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+                if (lane == 63) s_w[w] = inc;
+                __syncthreads();
+                u32 before = 0, tot = 0;
+                for (int k = 0; k < NT / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+                u32 qq = before + inc - mine;
+                for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[qq++] = (u32)(r0 + k);
+                __syncthreads();
+                if (tot) {
+                    if (b.dbg && threadIdx.x == 0) { atomicAdd(&b.dbg[3], 1ull); atomicAdd(&b.dbg[4], (unsigned long long)tot); }
+                    (void)visit_list<NT, EL, ParScratch>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+                }
+                __threadfence_block();
+                __syncthreads();
+            }
+            continue;
+        }
         if (threadIdx.x == 0) s_cnt = 0;
         __syncthreads();
         // window pass (same superset test as k_bubble_window)
@@ -1060,7 +1104,11 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
         __syncthreads();
         const u32 cnt = s_cnt;
         if (cnt == 0) continue;
-        if (cnt <= BB_CAP) {
+        if (b.dbg && threadIdx.x == 0) { atomicAdd(&b.dbg[3], 1ull); atomicAdd(&b.dbg[4], (unsigned long long)cnt); }
+        // Order of the visits = ascending rank.  Few actives: sort the list.  Many actives in a small child: walking the
+        // child's flag bytes yields them already ordered and costs less than ~60 bitonic stages (many samples: hundreds of
+        // actives per cut, ten cuts per child).
+        if (cnt <= BB_CAP && !(ds.n <= 4 * BB_CAP && cnt > 128)) {
             u32 np2 = 1; while (np2 < cnt) np2 <<= 1;
             for (u32 k = threadIdx.x; k < np2; k += NT) { if (k < cnt) flag[lst[k]] = 0; else lst[k] = 0xFFFFFFFFu; }
             __syncthreads();
@@ -1074,7 +1122,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
                     }
                     __syncthreads();
                 }
-            (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, cnt, ps, s_v, s_max, &s_first, nullptr);
+            (void)visit_list<NT, EL, ParScratch>(b, ds, cw, SA, LCP, BW, lst, 0, cnt, ps, s_v, s_max, &s_first, nullptr);
         } else {
             constexpr int FL = BB_CAP / NT;
             for (int64_t base = 0; base < ds.n; base += BB_CAP) {
@@ -1092,13 +1140,78 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
                 u32 qq = before + inc - mine;
                 for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[qq++] = (u32)(r0 + k);
                 __syncthreads();
-                (void)visit_list<NT, EL>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+                (void)visit_list<NT, EL, ParScratch>(b, ds, cw, SA, LCP, BW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
                 __syncthreads();
             }
         }
         __threadfence_block();
         __syncthreads();
     }
+}
+
+// The same, for children that fit into LDS (<= RV_BUBBLE_LDS_N ranks): SA / LCP / BWT are copied in once, every cut of
+// the child is replayed on the copies, and they are written back at the end.  The classify / shift loops of a visit are
+// chains of dependent loads and stores; in global memory each link costs a memory round trip (~1 us), which made a cut
+// of a small child cost ~150 us however little it moved -- with many samples a level has tens of thousands of such cuts.
+// The windowed SAi is not needed here (the actives are found by reading the child) and is not kept up.
+template <int NT, int EL, int N, int CH>
+__global__ __launch_bounds__(NT) void k_bubble_child_lds(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc) {
+    __shared__ __attribute__((aligned(16))) sa_t sSA[N];
+    __shared__ __attribute__((aligned(16))) lcp_t sLCP[N];
+    __shared__ __attribute__((aligned(16))) uint8_t sBW[N];
+    __shared__ u32 lst[CH];
+    __shared__ int64_t s_v[4];
+    __shared__ int s_max[NT / 64];
+    __shared__ u32 s_w[NT / 64];
+    __shared__ CutWin cw;
+    __shared__ ParScratchT<CH> ps;
+    __shared__ u32 s_first;
+    RvBubbleDesc ds = cdesc[blockIdx.x];
+    const int cut0 = ds.cut0, cut1 = ds.cut1;
+    ds.cut0 = ds.cut1 = 0;                       // no SAi upkeep inside the visits
+    if (threadIdx.x == 0) cw.n = 0;
+    sa_t  *gSA = b.SA + ds.off;
+    lcp_t *gLCP = b.LCP + ds.off;
+    uint8_t *gBW = b.BWT + ds.off;
+    const int n = (int)ds.n;
+    for (int r = threadIdx.x; r < n; r += NT) { sSA[r] = gSA[r]; sLCP[r] = gLCP[r]; sBW[r] = gBW[r]; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int q = cut0; q < cut1; q++) {
+        const int64_t B = (int64_t)b.cut_hi[q], wlo = (int64_t)b.cut_lo[q];
+        if (wlo >= B) continue;                                   // uniform
+        ds.B = B;
+        constexpr int FL = CH / NT;
+        static_assert(FL >= 1 && FL <= 32, "one bit per rank of a thread");
+        for (int base = 0; base < n; base += CH) {
+            const int r0 = base + (int)threadIdx.x * FL;
+            u32 bits = 0;
+#pragma unroll
+            for (int k = 0; k < FL; k++) {
+                const int r = r0 + k;
+                if (r < n) {
+                    const int64_t p = (int64_t)sSA[r];
+                    const int64_t lc = (int64_t)(u32)sLCP[r];
+                    const int64_t ln = (r + 1 < n) ? (int64_t)(u32)sLCP[r + 1] : 0;
+                    if ((p >= wlo) & (p < B) & ((p + lc > B) | (p + ln > B))) bits |= 1u << k;
+                }
+            }
+            const u32 mine = __popc(bits);
+            u32 inc = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+            if (lane == 63) s_w[w] = inc;
+            __syncthreads();
+            u32 before = 0, tot = 0;
+            for (int k = 0; k < NT / 64; k++) { const u32 c = s_w[k]; if (k < w) before += c; tot += c; }
+            u32 qq = before + inc - mine;
+            for (int k = 0; k < FL; k++) if (bits & (1u << k)) lst[qq++] = (u32)(r0 + k);
+            __syncthreads();
+            if (tot) (void)visit_list<NT, EL, ParScratchT<CH> >(b, ds, cw, sSA, sLCP, sBW, lst, 0, tot, ps, s_v, s_max, &s_first, nullptr);
+            __syncthreads();
+        }
+    }
+    for (int r = threadIdx.x; r < n; r += NT) { gSA[r] = sSA[r]; gLCP[r] = sLCP[r]; gBW[r] = sBW[r]; }
 }
 
 // SAi[SA[i]] = rank inside the owning sub-index (materialised on demand for the getter)
@@ -1158,6 +1271,18 @@ int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int co
     if (count <= 0) return 0;
     hipLaunchKernelGGL((k_bubble_apply<1024, 4>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, first);
     RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count) {
+    // three size classes (RV_BUBBLE_LDS_N0/1/2 ranks), descriptors back to back: smaller children take less LDS, so more
+    // of them run per CU (28 / 46 / 92 KB per workgroup)
+    int first = 0;
+    if (count[0] > 0) { hipLaunchKernelGGL((k_bubble_child_lds<128, 1, RV_BUBBLE_LDS_N0, 1024>), dim3((unsigned)count[0]), dim3(128), 0, ws.stream, b, d_lds + first); RV_LAUNCH_CHECK(); }
+    first += count[0];
+    if (count[1] > 0) { hipLaunchKernelGGL((k_bubble_child_lds<256, 1, RV_BUBBLE_LDS_N1, 1024>), dim3((unsigned)count[1]), dim3(256), 0, ws.stream, b, d_lds + first); RV_LAUNCH_CHECK(); }
+    first += count[1];
+    if (count[2] > 0) { hipLaunchKernelGGL((k_bubble_child_lds<256, 1, RV_BUBBLE_LDS_N2, 2048>), dim3((unsigned)count[2]), dim3(256), 0, ws.stream, b, d_lds + first); RV_LAUNCH_CHECK(); }
     return 0;
 }
 

@@ -152,6 +152,24 @@ def test_chunked_carry_scan(monkeypatch):
     compare(fa("1a", "1b", "1c"), 20, 2)
 
 
+@pytest.mark.parametrize("name,inputs,minl,sa64", [
+    ("1a1b", fa("1a", "1b"), 20, False),
+    ("1a1a", fa("1a", "1a"), 20, False),
+    ("d1d2", fa("d1", "d2"), 20, False),
+    ("1a1b_64", fa("1a", "1b"), 20, True),
+    ("5way", fa("1a", "1b", "1c", "1d", "1e"), 20, False),
+    ("synth3", None, 20, False),
+])
+def test_lds_resident_bubble(monkeypatch, name, inputs, minl, sa64):
+    """children of at most 8192 ranks bubbled on LDS copies of their arrays, on a second stream (the path levels with
+    thousands of small children take): forced on for every level"""
+    monkeypatch.setenv("RV_BUBBLE_LDS_ALWAYS", "1")
+    monkeypatch.setenv("RV_NO_LEAF", "1")
+    if inputs is None:
+        inputs = [g.decode() for g in synth.genomes(200000, 3)]
+    compare(inputs, minl, 2, sa64=sa64)
+
+
 def test_sequential_bubble_kept(monkeypatch):
     """the one-workgroup-per-child kernels stay the fallback (and the small-level path): keep them covered in multi mode"""
     monkeypatch.setenv("RV_BUBBLE_NO_JOIN", "1")

@@ -34,18 +34,42 @@ u64 hash_step(u64 acc, u64 i, int64_t v) {      // same as oracle/reveal_oracle.
     return acc + x;
 }
 
-// host staging of several small tables into one upload
+// host staging of several small tables into one upload.  Pinned memory: the copy is queued and the call returns (a
+// pageable source is staged synchronously, ~10-20 us per level).  The buffer is rewritten only after a stream
+// synchronisation (the next level's scan), so the queued copy has always finished by then.
 struct Packer {
-    std::vector<uint8_t> buf;
-    void clear() { buf.clear(); }
-    size_t add(const void *p, size_t bytes) {
-        const size_t off = (buf.size() + 15) & ~(size_t)15;
-        buf.resize(off + bytes);
-        if (bytes) memcpy(buf.data() + off, p, bytes);
+    uint8_t *p = nullptr;
+    size_t used = 0, cap = 0;
+    void clear() { used = 0; }
+    const uint8_t *data() const { return p; }
+    size_t size() const { return used; }
+    void grow(size_t need) {
+        if (need <= cap) return;
+        size_t want = need + need / 2 + 4096;
+        uint8_t *q = nullptr;
+        if (hipHostMalloc((void **)&q, want, hipHostMallocDefault) != hipSuccess) { q = (uint8_t *)malloc(want); pageable = true; }
+        if (p) { memcpy(q, p, used); release_ptr(); }
+        p = q; cap = want;
+    }
+    size_t add(const void *src, size_t bytes) {
+        const size_t off = (used + 15) & ~(size_t)15;
+        grow(off + bytes);
+        if (off > used) memset(p + used, 0, off - used);
+        if (bytes) memcpy(p + off, src, bytes);
+        used = off + bytes;
         return off;
     }
     template <class T> size_t addv(const std::vector<T> &v) { return add(v.data(), v.size() * sizeof(T)); }
-    size_t reserve(size_t bytes) { const size_t off = (buf.size() + 15) & ~(size_t)15; buf.resize(off + bytes, 0); return off; }
+    size_t reserve(size_t bytes) {
+        const size_t off = (used + 15) & ~(size_t)15;
+        grow(off + bytes);
+        memset(p + used, 0, off + bytes - used);
+        used = off + bytes;
+        return off;
+    }
+    bool pageable = false;
+    void release_ptr() { if (p) { if (pageable) free(p); else (void)hipHostFree(p); } p = nullptr; }
+    void release() { release_ptr(); cap = used = 0; }
 };
 
 // One recursion level: sub-index s owns ranks [off[s], off[s]+n[s]) of the level
@@ -140,7 +164,7 @@ struct Align {
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); ev_fork = ev_join = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
@@ -305,8 +329,8 @@ int rv_frontier_scan(rv_index *h) {
             std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
             const size_t o1 = pk.addv(ss), o2 = pk.addv(a->lv.nsamples);
             DBuf &buf = h->ws.misc[10];
-            RV_TRY(buf.reserve(pk.buf.size() + 64));
-            RV_HIP(hipMemcpyAsync(buf.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, h->ws.stream));
+            RV_TRY(buf.reserve(pk.size() + 64));
+            RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
             d_ss = (const int64_t *)(buf.as<uint8_t>() + o1); d_want = (const int *)(buf.as<uint8_t>() + o2);
         }
         RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub,
@@ -605,8 +629,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
     const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
-    RV_TRY(a->dTab.reserve(pk.buf.size() + 64));
-    RV_HIP(hipMemcpyAsync(a->dTab.p, pk.buf.data(), pk.buf.size(), hipMemcpyHostToDevice, q));
+    RV_TRY(a->dTab.reserve(pk.size() + 64));
+    RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
     a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant);

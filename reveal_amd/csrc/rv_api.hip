@@ -305,7 +305,10 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
                                         d_sub_start, nsubs, bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), bcnt.as<u32>(), d_err));
             RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
             RV_HIP(hipMemcpyAsync(h->hscan.p, bpick.p, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
-            RV_HIP(hipStreamSynchronize(q));
+            // the one host round trip of a level: spin on the stream instead of sleeping in hipStreamSynchronize (its wake-up
+            // costs tens of microseconds, 33 times per alignment)
+            if (getenv("RV_SYNC_BLOCK")) { RV_HIP(hipStreamSynchronize(q)); }
+            else { hipError_t qe; while ((qe = hipStreamQuery(q)) == hipErrorNotReady) {} if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; } }
             const u32 *hdr = h->hscan.as<u32>();
             const u32 novf = hdr[1];
             if (err_out) *err_out = hdr[2];

@@ -248,16 +248,43 @@ __device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, 
     return 0;
 }
 
+constexpr int MEDIUM_GROUP = 64;      // groups of 9..64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
+__global__ __launch_bounds__(TB) void k_medium_back(const uint8_t *__restrict__ flag, const sav_t *__restrict__ Sout, sav_t *__restrict__ S, int64_t m) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q < m && flag[q] == 2) S[q] = Sout[q];
+}
 __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
-                                                   int64_t m, int64_t h, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA) {
+                                                   int64_t m, int64_t h, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                   sav_t *__restrict__ Sout) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q >= m) return;
     const u32 g = G[q];
     const u32 off = P[q] - g;
-    const int64_t look = q + (SMALL_GROUP - (int64_t)off);
-    const bool big = off >= (u32)SMALL_GROUP || (look < m && G[look] == g);
-    bigflag[q] = big;
-    if (big || off != 0) return;
+    const int64_t look = q + (MEDIUM_GROUP - (int64_t)off);
+    const bool big = off >= (u32)MEDIUM_GROUP || (look < m && G[look] == g);
+    const int64_t qs = q - (int64_t)off;                       // the group's first list entry (a group is contiguous in the list)
+    const bool medium = !big && qs + SMALL_GROUP < m && G[qs + SMALL_GROUP] == g;
+    bigflag[q] = big ? 1 : medium ? 2 : 0;
+    if (big) return;
+    if (medium) {
+        // every member finds its own rank: one text comparison with each other member (all lanes of the wave are busy -- a
+        // group's first thread sorting alone left its wave idle for ~g*g/4 comparisons; ten samples: every group has ten members)
+        int size = SMALL_GROUP + 1;
+        while (qs + size < m && G[qs + size] == g) size++;
+        const sav_t mine = S[q];
+        int rank = 0; bool tie_before = false;
+        for (int j = 0; j < size; j++) {
+            if (j == (int)off) continue;
+            const int c = cmp_text(T, S[qs + j], mine, h);
+            rank += (c < 0) | ((c == 0) & (j < (int)off));
+            tie_before |= (c == 0) & (j < (int)off);
+        }
+        Sout[qs + rank] = mine;                                  // (S itself is still being read by the other members)
+        SA[(size_t)g + rank] = (sa_t)mine;
+        headq[qs + rank] = !tie_before;
+        return;
+    }
+    if (off != 0) return;
     sav_t s[SMALL_GROUP];
     int size = 1;
     s[0] = S[q];
@@ -307,7 +334,7 @@ __global__ __launch_bounds__(TB) void k_flag_count(const uint8_t *__restrict__ f
 #pragma unroll
     for (int r = 0; r < CP_ITEMS; r++) {
         const int64_t j = base + (int64_t)r * TB + threadIdx.x;
-        if (j < n && flag[j]) c++;
+        if (j < n && flag[j] == 1) c++;
     }
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -325,7 +352,7 @@ __global__ __launch_bounds__(TB) void k_flag_emit(const uint8_t *__restrict__ fl
 #pragma unroll 1
     for (int r = 0; r < CP_ITEMS; r++) {
         const int64_t j = base + (int64_t)r * TB + threadIdx.x;
-        const bool f = (j < n) && flag[j];
+        const bool f = (j < n) && flag[j] == 1;
         const u64 bal = __ballot(f);
         if (lane == 0) wbase[w] = (u32)__popcll(bal);
         __syncthreads();
@@ -601,8 +628,9 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     int64_t ntile = ceil_div(n, CP_TILE);
     SA_TRY(btile.reserve((size_t)(ntile + 1) * 4));
     u32 *tile = btile.as<u32>();
-    auto compact = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in,
-                       u32 *P, sav_t *S, u32 *G, int64_t *m_out) -> int {
+    // compaction of the not yet unique suffixes in two steps, so that a round that leaves nothing behind can stop
+    // before it updates ISA
+    auto count_unsorted = [&](const uint8_t *hd, int64_t len, int64_t *m_out) -> int {
         const int64_t nt = ceil_div(len, CP_TILE);
         hipLaunchKernelGGL(k_cp_count, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, tile);
         RV_LAUNCH_CHECK();
@@ -613,10 +641,19 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         RV_HIP(hipMemcpyAsync(&tot, tile + nt, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
         *m_out = tot;
-        if (tot == 0) return 0;
+        return 0;
+    };
+    auto emit_unsorted = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in, u32 *P, sav_t *S, u32 *G) -> int {
+        const int64_t nt = ceil_div(len, CP_TILE);
         hipLaunchKernelGGL(k_cp_emit, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, (const u32 *)tile, pos_in, suf_in, grp_in, P, S, G);
         RV_LAUNCH_CHECK();
         return 0;
+    };
+    auto compact = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in,
+                       u32 *P, sav_t *S, u32 *G, int64_t *m_out) -> int {
+        RV_TRY(count_unsorted(hd, len, m_out));
+        if (*m_out == 0) return 0;
+        return emit_unsorted(hd, len, pos_in, suf_in, grp_in, P, S, G);
     };
 
     int64_t m = 0;
@@ -639,7 +676,11 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         uint8_t *bigflag = bbig.as<uint8_t>();
         // groups of up to SMALL_GROUP members: sorted by their first thread, in place
         if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
-            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, h, head, bigflag, SA);
+        {
+            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, h, head, bigflag, SA, Sfree);
+            SA_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_medium_back, dim3(mb), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
+        }
         else
             hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
         SA_HIP(hipGetLastError());
@@ -672,16 +713,18 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
                 SA_HIP(hipGetLastError());
             }
         }
+        // what is still not unique?  Nothing: SA is complete (ISA is only an intermediate of this build)
+        int64_t m2 = 0;
+        SA_TRY(count_unsorted(head, m, &m2));
+        if (m2 == 0) break;
         // new group ranks from the heads, ISA update
         hipLaunchKernelGGL(k_seed, dim3(mb), dim3(TB), 0, q, (const uint8_t *)head, (const u32 *)P, m, seed);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));
         hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA);
         SA_HIP(hipGetLastError());
-
-        // next list: what is still not unique
-        int64_t m2 = 0;
-        SA_TRY(compact(head, m, P, S, grp, Pn, Sfree, Gn, &m2));
+        // next list
+        SA_TRY(emit_unsorted(head, m, P, S, grp, Pn, Sfree, Gn));
         { u32 *t = P; P = Pn; Pn = t; t = G; G = Gn; Gn = t; }
         { sav_t *t = S; S = Sfree; Sfree = t; }
         m = m2;

@@ -31,5 +31,31 @@ def main():
     print("%d kernels in the last step, span %.3f ms, no kernel running for %.3f ms" % (len(sel), (ce - iv[0][0]) / 1e6, idle / 1e6))
 
 
+
+
+def gaps(path, top=12):
+    """main-stream view of the last step: kernel time, and idle time attributed to the kernel that ran before each gap"""
+    c = sqlite3.connect(path)
+    rows = list(c.execute("select name,start,end,stream_id from kernels order by start"))
+    idx = [i for i, r in enumerate(rows) if "k_init_keys" in r[0]]
+    sel = rows[idx[-1]:]
+    # the main stream = the one k_init_keys ran on
+    main = sel[0][3]
+    ms = [(short(n), s, e) for n, s, e, st in sel if st == main]
+    busy = sum(e - s for _, s, e in ms)
+    span = ms[-1][2] - ms[0][1]
+    by = {}
+    for (n0, s0, e0), (n1, s1, e1) in zip(ms, ms[1:]):
+        g = max(0, s1 - e0)
+        k = n0 + " -> " + n1
+        by[k] = by.get(k, 0) + g
+    print("main stream: %d kernels, span %.3f ms, kernels %.3f ms, gaps %.3f ms" % (len(ms), span / 1e6, busy / 1e6, (span - busy) / 1e6))
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1])[:top]:
+        print("  %-60s %8.1f us" % (k, v / 1e3))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 2 and sys.argv[2] == "--gaps":
+        gaps(sys.argv[1])
+    else:
+        main()

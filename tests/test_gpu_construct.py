@@ -68,6 +68,52 @@ def test_construct_synthetic(L, cnt):
     assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))]
 
 
+def _repeat_cases():
+    import random
+    rng = random.Random(11)
+    unit = "".join(rng.choice("ACGT") for _ in range(700))
+    return {
+        # twelve near-copies: every first-key group has twelve members (the ranked-by-text path for 9..64 members)
+        "twelve_samples": [g.decode() for g in synth.genomes(20000, 12)],
+        # a period-2 and a period-3 run of 6000 symbols: first-key groups of thousands, ties far beyond the text-compare cap
+        # (radix path for large groups, then doubling rounds)
+        "periodic": ["AC" * 3000 + unit, "ACG" * 2000 + unit[::-1]],
+        # one repeated unit inside each sample (groups of ~20) plus a homopolymer
+        "tandem": [(unit[:300] * 20) + "A" * 5000, (unit[:300] * 20) + "C" * 100],
+        # 70 identical short contigs in one sample: groups of 70 (> 64) that only the '$' positions tell apart
+        "many_contigs": ["$".join([unit[:50]] * 70), unit[:50]],
+    }
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("name", ["twelve_samples", "periodic", "tandem", "many_contigs"])
+def test_construct_repeats(name, sa64):
+    """group sizes and match lengths that take every branch of the SA refinement (registers / ranked / radix, text round / doubling)"""
+    seqs = _repeat_cases()[name]
+    if name == "many_contigs":      # contigs of one sample: one addsequence per contig
+        contigs = seqs[0].split("$")
+        inputs = [contigs, [seqs[1]]]
+        from reveal_amd import reveallib, reveallib64
+        idx = (reveallib64 if sa64 else reveallib).index()
+        for k, cs in enumerate(inputs):
+            idx.addsample("s%d" % k)
+            for cseq in cs:
+                idx.addsequence(cseq)
+        T = ("$".join(contigs) + "$" + seqs[1] + "$").encode()
+        nsep = [len("$".join(contigs))]
+        nsamples = 2
+    else:
+        T, nsep, nodes = assemble(seqs)
+        idx = feed(mod(sa64).index(), seqs)
+        nsamples = len(seqs)
+    O = oracle(sa64)
+    c = O.construct(T, nsep, nsamples)
+    idx.construct()
+    assert idx.T.encode("latin-1") == T
+    assert np.array_equal(idx.array("SA"), c["SA"])
+    assert np.array_equal(idx.array("LCP"), c["LCP"])
+
+
 def test_construct_rc_and_files(tmp_path, monkeypatch):
     """construct(rc=1) remap (interface.c:168-175, reveal.c:98-100) and the sa=/lcp=/cache= files"""
     monkeypatch.chdir(tmp_path)

@@ -153,7 +153,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
                                                             u64 *__restrict__ kout, V *__restrict__ vout, int64_t n, int shift,
                                                             const u32 *__restrict__ blockoff, u32 nblocks) {
     __shared__ u32 cnt[RS_WAVES][256];
-    __shared__ u32 gbase[256];
+    __shared__ u32 gbase[256], dstart[256], wtot[RS_WAVES];
+    __shared__ u64 skey[RS_TILE];
+    __shared__ V sval[RS_TILE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < RS_WAVES * 256; k += RS_THREADS) (&cnt[0][0])[k] = 0;
     gbase[threadIdx.x] = blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
@@ -184,11 +186,28 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         rnk[r] = old + below;
     }
     __syncthreads();
-    {   // exclusive prefix over the waves of this block, per digit
+    u32 mytot;
+    {   // exclusive prefix over the waves of this block, per digit; mytot = the block's count of digit threadIdx.x
         const int d = threadIdx.x;
         u32 run = 0;
 #pragma unroll
         for (int k = 0; k < RS_WAVES; k++) { u32 c = cnt[k][d]; cnt[k][d] = run; run += c; }
+        mytot = run;
+    }
+    // The tile is first ordered by digit in LDS and then written out: a digit's keys of this block go to one contiguous
+    // run in global memory, so consecutive threads store consecutive addresses.  (Scattering straight from registers made
+    // every store of a wave hit up to 64 different sectors: 200 us per pass for 1e7 keys where the well-clustered top
+    // digit took 55.)
+    {
+        u32 inc = mytot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const u32 t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
+        if (lane == 63) wtot[w] = inc;
+        __syncthreads();
+        u32 before = 0;
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; k++) if (k < w) before += wtot[k];
+        dstart[threadIdx.x] = before + inc - mytot;
     }
     __syncthreads();
 #pragma unroll
@@ -196,10 +215,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         const int64_t i = wbase + (int64_t)r * 64 + lane;
         if (i < n) {
             const u32 d = (u32)(key[r] >> shift) & 255u;
-            const size_t dst = (size_t)gbase[d] + cnt[w][d] + rnk[r];
-            kout[dst] = key[r];
-            vout[dst] = vin[i];
+            const u32 li = dstart[d] + cnt[w][d] + rnk[r];
+            skey[li] = key[r];
+            sval[li] = vin[i];
         }
+    }
+    __syncthreads();
+    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+    const u32 nvalid = (u32)((n - tbase) < (int64_t)RS_TILE ? (n - tbase) : (int64_t)RS_TILE);
+    for (u32 li = threadIdx.x; li < nvalid; li += RS_THREADS) {
+        const u64 k = skey[li];
+        const u32 d = (u32)(k >> shift) & 255u;
+        const size_t dst = (size_t)gbase[d] + (li - dstart[d]);
+        kout[dst] = k;
+        vout[dst] = sval[li];
     }
 }
 

@@ -129,8 +129,8 @@ struct Align {
     HBuf hLeafRoots[2];
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
-    hipStream_t bub_stream = nullptr;      // LDS-resident bubble kernels run here, beside the main stream's bubble kernels
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t bub_stream = nullptr, bub_stream2 = nullptr;      // LDS-resident / one-workgroup bubble kernels run here, beside the main stream's rounds
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
     bool roots_inflight[2] = {false, false};
     bool flag_clean = false;     // dFlag is all zero
@@ -166,7 +166,7 @@ struct Align {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
-        if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); ev_fork = ev_join = nullptr; }
+        if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_roots[k]) { (void)hipEventDestroy(ev_roots[k]); ev_roots[k] = nullptr; }
@@ -550,7 +550,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // few hundred small children ride along with the larger ones for free (measured on C2: 612 vs 597 Mbp/s).
     size_t lds_candidates = 0;
     for (const auto &kd : a->kid_tmp) lds_candidates += kd.n <= lds_n;
-    const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && getenv("RV_BUBBLE_LDS_ALWAYS"));
+    // (more than two samples: many cuts per child, no leaf kernel -- the LDS kernel is always the better one for small children)
+    const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && (a->multi || getenv("RV_BUBBLE_LDS_ALWAYS")));
     for (const auto &kd : a->kid_tmp) {
         if ((!all_par && kd.n <= par_min) || (use_lds && kd.n <= lds_n)) {             // every cut of this child in one workgroup, sequentially
             RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = 0; bd.wlo = 0; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
@@ -716,28 +717,42 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             ba.par.Qlast = pb;
         }
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
-        // children that fit into LDS: on their own stream, beside the kernels of the larger children (a kernel boundary on one
-        // stream is a barrier; the level's bubble time is then the longer of the two groups, not their sum)
-        bool forked = false;
-        if (!a->kids_lds.empty()) {
-            if (!a->bub_stream) {
-                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
-                RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
-                RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
-            }
-            const bool alone = a->kids_small.empty() && a->kids_big.empty() && a->descs.empty();
-            Workspace lw; lw.stream = alone ? q : a->bub_stream;
-            if (!alone) { RV_HIP(hipEventRecord(a->ev_fork, q)); RV_HIP(hipStreamWaitEvent(a->bub_stream, a->ev_fork, 0)); }
-            RV_TRY(rv_bubble_children_lds_launch(lw, ba, (const RvBubbleDesc *)(tb + o_kl), lds_count));
-            if (!alone) { RV_HIP(hipEventRecord(a->ev_join, a->bub_stream)); forked = true; }
+        // Three independent groups of work: children that fit into LDS, children replayed in one workgroup each, and the
+        // data-parallel rounds of the largest ones.  A kernel boundary on one stream is a barrier, so each extra group goes
+        // to its own stream (fork / join by events): the level's bubble time is the longest group, not their sum.
+        bool forked = false, forked2 = false;
+        if (!a->bub_stream) {
+            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
+            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
         }
-        RV_TRY(rv_bubble_children_launch(h->ws, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
+        const bool have_kids = !a->kids_small.empty() || !a->kids_big.empty();
+        const int groups = (int)!a->kids_lds.empty() + (int)have_kids + (int)!a->descs.empty();
+        if (groups > 1) RV_HIP(hipEventRecord(a->ev_fork, q));
+        if (!a->kids_lds.empty()) {
+            const bool side = groups > 1;
+            Workspace lw; lw.stream = side ? a->bub_stream : q;
+            if (side) RV_HIP(hipStreamWaitEvent(a->bub_stream, a->ev_fork, 0));
+            RV_TRY(rv_bubble_children_lds_launch(lw, ba, (const RvBubbleDesc *)(tb + o_kl), lds_count));
+            if (side) { RV_HIP(hipEventRecord(a->ev_join, a->bub_stream)); forked = true; }
+        }
+        if (have_kids) {
+            // (two samples, a few hundred children: the fork/join costs what it saves -- measured on C2)
+            const bool side = !a->descs.empty() && (a->multi || a->kids_small.size() + a->kids_big.size() > 1024);      // the rounds stay on the main stream
+            Workspace lw; lw.stream = side ? a->bub_stream2 : q;
+            if (side) RV_HIP(hipStreamWaitEvent(a->bub_stream2, a->ev_fork, 0));
+            RV_TRY(rv_bubble_children_launch(lw, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
+            if (side) { RV_HIP(hipEventRecord(a->ev_join2, a->bub_stream2)); forked2 = true; }
+        }
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
             RV_TRY(rv_bubble_par_round_launch(h->ws, ba, first, count, a->woff[(size_t)(first + count)] - a->woff[(size_t)first],
                                               a->toff[(size_t)(first + count)] - a->toff[(size_t)first]));
             if (round_seq[r]) RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count));
         }
+        if (forked2) RV_HIP(hipStreamWaitEvent(q, a->ev_join2, 0));
         if (forked) RV_HIP(hipStreamWaitEvent(q, a->ev_join, 0));
         h->prof.end(q, id);
     }

@@ -149,6 +149,8 @@ struct Align {
     std::vector<int64_t> mpre, sub_start, woff, toff, next_ss;
     const int64_t *d_next_ss = nullptr;      // device copy of the next level's sub-index starts (inside dTab)
     const int *d_next_want = nullptr;        // ... and of its sub-indices' sample counts
+    const int *d_next_tsub = nullptr;        // ... and its tile -> sub-index table (more than two samples)
+    std::vector<int> next_tsub;
     std::vector<u32> pick_l; std::vector<sa_t> pick_pos;
     std::vector<u32> child_base, child_n;
     std::vector<RvBubbleDesc> descs;
@@ -306,7 +308,7 @@ int rv_frontier_scan(rv_index *h) {
         if (a->full_only && a->level > 0) {
             // built-in picker without tracing: the device returns, per sub-index, the match the picker would take (the tables
             // came with the previous commit's upload)
-            RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->pick_l, a->pick_pos));
+            RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->d_next_tsub, a->pick_l, a->pick_pos));
             a->ml.clear(); a->mn.clear(); a->moff.assign(1, 0); a->mso.clear(); a->mpos.clear();
             const int W = h->nsamples;
             for (int s2 = 0; s2 < ns; s2++) {
@@ -624,6 +626,19 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     }
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big), o_kl = pk.addv(a->kids_lds);
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
+    size_t o_ntsub = 0;
+    if (a->multi) {       // tile -> sub-index table of the next level (the multi-sample picker looks sub-indices up per candidate)
+        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
+        a->next_tsub.resize((size_t)ntn);
+        int s2 = 0;
+        const int nsn = nx.size();
+        for (int64_t t = 0; t < ntn; t++) {
+            const int64_t r = t * RV_SPLIT_TILE;
+            while (s2 + 1 < nsn && a->next_ss[(size_t)s2 + 1] <= r) s2++;
+            a->next_tsub[(size_t)t] = s2;
+        }
+        o_ntsub = pk.addv(a->next_tsub);
+    }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
     u32 class_total[4] = {0, 0, 0, 0};
@@ -634,7 +649,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
-    a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant);
+    a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant); a->d_next_tsub = (const int *)(tb + o_ntsub);
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));

@@ -410,7 +410,7 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 
 // built-in picker of the untraced recursion, more than two samples: one (l, members) per sub-index, picked on the device
 int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn,
-                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos) {
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos) {
     pick_l.assign((size_t)nsubs, 0); pick_pos.clear();
     if (m <= 1 || nsubs <= 0) return 0;
     hipStream_t q = h->ws.stream;
@@ -422,7 +422,7 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t ccap = bcand.cap / RV_MULTI_CAND_BYTES;
         int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
-        RV_TRY(rv_multi_pick_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), W, minl, minn, d_sub_start, d_sub_want, nsubs,
+        RV_TRY(rv_multi_pick_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), W, minl, minn, d_sub_start, d_sub_want, nsubs, d_tile_sub,
                                     bbest.as<unsigned long long>(), bl.as<u32>(), bpos.as<sa_t>(), (RvMultiCand *)bcand.p,
                                     (u32)std::min<size_t>(ccap, 0xffffffffu), bcnt.as<u32>()));
         h->prof.end(q, id);

@@ -48,6 +48,6 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 // *cand_count > cand_cap afterwards: the candidate list was too small, grow and rerun.
 struct RvMultiCand;
 int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
-                         const int64_t *sub_start, const int *sub_want, int nsubs, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
-                         RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
+                         const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub /* sub-index of rank t * RV_PAIR_TILE */,
+                         unsigned long long *best, u32 *pick_l, sa_t *pick_pos, RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
 #define RV_MULTI_CAND_BYTES 16

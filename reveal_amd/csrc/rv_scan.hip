@@ -386,8 +386,15 @@ struct RvMultiCand { u32 ub, sub; unsigned long long key; };
 __global__ __launch_bounds__(TB) void k_multi_pick1(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const uint8_t *__restrict__ BWT,
                                                     const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
                                                     const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs,
+                                                    const int *__restrict__ tile_sub,
                                                     unsigned long long *__restrict__ best, u32 *__restrict__ /*pick_l: zeroed by the host*/,
                                                     RvMultiCand *__restrict__ cand, u32 cand_cap, u32 *__restrict__ cand_count) {
+    // sample boundaries in LDS: ismultimum looks up the sample of every member (a binary search each)
+    __shared__ sa_t s_nsep[256];
+    const bool lds_sep = nsamples - 1 <= 256;
+    if (lds_sep) { for (int k = threadIdx.x; k < nsamples - 1; k += TB) s_nsep[k] = nsep[k]; }
+    __syncthreads();
+    const sa_t *sep = lds_sep ? s_nsep : nsep;
     const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const u32 lmin = (u32)(minl > 1 ? minl : 1);
@@ -396,16 +403,22 @@ __global__ __launch_bounds__(TB) void k_multi_pick1(const sa_t *__restrict__ SA,
     if (ok) { cur = (u32)LCP[u]; nxt = (u + 1 < m) ? (u32)LCP[u + 1] : 0u; ok = cur > nxt && cur >= lmin; }
     int s = 0; int64_t lb = 0; u32 l = 0;
     if (ok) {
-        int lo2 = 0, hi2 = nsubs;
-        while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
-        s = lo2 - 1;
+        // owning sub-index: from the host's table for the 2048-rank tile of u, then a few steps forward
+        s = tile_sub[u / RV_PAIR_TILE];
+        int64_t s_end = sub_start[s + 1];
+        for (int step = 0; u >= s_end && step < 8; step++) { s++; s_end = sub_start[s + 1]; }
+        if (u >= s_end) {
+            int lo2 = s, hi2 = nsubs;
+            while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
+            s = lo2 - 1;
+        }
         const int want = sub_want[s];
         lb = u - want + 1;
         ok = want >= minn && want >= 2 && want <= nsamples && lb >= sub_start[s];
         if (ok) {
             l = cur;
             for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
-            ok = l > nxt && l >= lmin && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u);
+            ok = l > nxt && l >= lmin && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, sep, nsamples, lb, u);
         }
     }
     unsigned long long key = 0;
@@ -441,14 +454,14 @@ __global__ __launch_bounds__(TB) void k_multi_pick2(const sa_t *__restrict__ SA,
 }
 
 int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
-                         const int64_t *sub_start, const int *sub_want, int nsubs, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
+                         const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
                          RvMultiCand *cand, u32 cand_cap, u32 *cand_count) {
     if (m <= 0 || nsubs <= 0) return 0;
     RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
     RV_HIP(hipMemsetAsync(pick_l, 0, (size_t)nsubs * 4, ws.stream));
     RV_HIP(hipMemsetAsync(cand_count, 0, 4, ws.stream));
     hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
-                       sub_start, sub_want, nsubs, best, pick_l, cand, cand_cap, cand_count);
+                       sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_multi_pick2, dim3(256), dim3(TB), 0, ws.stream, SA, sub_want, nsamples, (const unsigned long long *)best,
                        (const RvMultiCand *)cand, cand_cap, (const u32 *)cand_count, pick_l, pick_pos);

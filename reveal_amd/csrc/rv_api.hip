@@ -291,20 +291,24 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
     u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
     for (int attempt = 0; attempt < 3; attempt++) {
         const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
-        DBuf &bbest = h->ws.misc[12], &bpick = h->ws.misc[13];
-        if (d_sub_start) { RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bpick.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec))); }
+        // picker tables; the picks go straight to pinned host memory (the kernels write them over PCIe: a few KB), so the level's
+        // round trip needs no copy command, only the wait for the stream
+        DBuf &bbest = h->ws.misc[12];
+        RvPairRec *picks = nullptr;
+        if (d_sub_start) {
+            RV_TRY(bbest.reserve((size_t)nsubs * 8));
+            RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
+            picks = h->hscan.as<RvPairRec>();
+        }
         int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
         RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
                                    (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf,
-                                   bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), d_sub_start ? nsubs : 0));
+                                   bbest.as<unsigned long long>(), picks, d_sub_start ? nsubs : 0));
         h->prof.end(q, id);
         if (d_sub_start) {
-            // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots,
-            // copy header + nsubs records
+            // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots
             RV_TRY(rv_pick_slots_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), (u32)std::min<size_t>(vcap, 0xffffffffu), tilecnt, tileovf, ntile,
-                                        d_sub_start, nsubs, bbest.as<unsigned long long>(), bpick.as<RvPairRec>(), bcnt.as<u32>(), d_err));
-            RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
-            RV_HIP(hipMemcpyAsync(h->hscan.p, bpick.p, (size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
+                                        d_sub_start, nsubs, bbest.as<unsigned long long>(), picks, bcnt.as<u32>(), d_err));
             // the one host round trip of a level: spin on the stream instead of sleeping in hipStreamSynchronize (its wake-up
             // costs tens of microseconds, 33 times per alignment)
             if (getenv("RV_SYNC_BLOCK")) { RV_HIP(hipStreamSynchronize(q)); }

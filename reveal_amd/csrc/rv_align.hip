@@ -15,6 +15,7 @@
 // sub-index.
 #include "rv_index.h"
 #include "rv_split.h"
+#include "rv_decide.h"
 #include "rv_leaf.h"
 #include <string.h>
 #include <algorithm>
@@ -134,6 +135,12 @@ struct Align {
     hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
     bool roots_inflight[2] = {false, false};
     bool flag_clean = false;     // dFlag is all zero
+    // device-side decisions (rv_decide.hip): tables of the NEXT level shipped with a commit, state of the early split
+    DBuf dDec, dErr;
+    bool next_dev_ok = false, cur_dev_ok = false, early_done = false, use_leaf = false;
+    const sa_t *d_next_nodes = nullptr; const uint8_t *d_next_flags = nullptr; const int *d_next_tsub2 = nullptr;
+    std::vector<sa_t> next_nodes; std::vector<uint8_t> next_flags;
+    RvLabelTabs e_lt; RvSplitArgs e_sa;
     bool leaf_pending[2] = {false, false};   // a leaf launch may still be reading level buffer k
     size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
     std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
@@ -166,7 +173,7 @@ struct Align {
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
@@ -245,6 +252,9 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
     a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
+    a->next_dev_ok = a->cur_dev_ok = a->early_done = false; a->use_leaf = false;
+    RV_TRY(a->dErr.reserve(64));
+    RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, h->ws.stream));
     memset(&a->st, 0, sizeof a->st);
     a->lv.clear();
     a->lv.m = h->n;
@@ -279,6 +289,65 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 
 extern "C" {
 
+/* The split of the current level (reveal.c:1005-1252 without lower-casing and bubble_sort), queued right behind the picker
+ * kernels with decisions taken on the device (rv_decide.hip): it runs while the host receives the picks and rebuilds the
+ * same decisions for its own bookkeeping.  rv_frontier_commit then finds it done. */
+static int early_split(rv_index *h) {
+    Align *a = h->al;
+    hipStream_t q = h->ws.stream;
+    const Level &lv = a->lv;
+    const int ns = lv.size();
+    const int64_t m = lv.m, ntiles = ceil_div(m, RV_SPLIT_TILE);
+    const int nxt = a->cur ^ 1;
+    RV_TRY(a->dD.reserve((size_t)m + 64));
+    RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
+    RV_TRY(a->lvSA[nxt].reserve((size_t)(m + 64) * sizeof(sa_t)));
+    RV_TRY(a->lvLCP[nxt].reserve((size_t)(m + 64) * sizeof(lcp_t)));
+    RV_TRY(a->lvBWT[nxt].reserve((size_t)m + 64));
+    // a leaf launch of an earlier level may still be reading the buffer the split writes (ping-pong)
+    if (a->leaf_pending[nxt]) { RV_HIP(hipStreamWaitEvent(q, a->ev_leaf[nxt], 0)); a->leaf_pending[nxt] = false; }
+    const size_t S = (size_t)ns;
+    size_t bytes = 0;
+    auto take = [&](size_t b) { const size_t o = (bytes + 15) & ~(size_t)15; bytes = o + b; return o; };
+    const size_t o_cb = take(4 * S * sizeof(sa_t)), o_ce = take(4 * S * sizeof(sa_t)), o_cc = take(4 * S), o_ctf = take((S + 1) * 4);
+    const size_t o_mb = take(2 * S * sizeof(sa_t)), o_me = take(2 * S * sizeof(sa_t)), o_mtf = take((S + 1) * 4);
+    const size_t o_cn = take(3 * S * 4), o_cbase = take(3 * S * 4), o_soff = take(3 * S * 4), o_exp = take(16), o_tot = take(16);
+    const size_t o_cf = take((S + 1) * 4), o_mf = take((S + 1) * 4), o_clo = take(2 * S * sizeof(sa_t)), o_chi = take(2 * S * sizeof(sa_t)), o_mp = take(2 * S * sizeof(sa_t));
+    RV_TRY(a->dDec.reserve(bytes + 64));
+    uint8_t *db = a->dDec.as<uint8_t>();
+    RvDecideArgs d;
+    d.nsubs = ns; d.lcap = h->maxlcp;
+    d.nodes = a->d_next_nodes; d.flags = a->d_next_flags; d.picks = h->hscan.as<RvPairRec>();
+    d.ctab_first = (int *)(db + o_ctf); d.mtab_first = (int *)(db + o_mtf);
+    d.cb = (sa_t *)(db + o_cb); d.ce = (sa_t *)(db + o_ce); d.cc = db + o_cc; d.mb = (sa_t *)(db + o_mb); d.me = (sa_t *)(db + o_me);
+    d.child_n = (u32 *)(db + o_cn); d.child_base = (u32 *)(db + o_cbase); d.sub_off = (u32 *)(db + o_soff); d.expect_total = (u32 *)(db + o_exp);
+    d.cut_first = (int *)(db + o_cf); d.mend_first = (int *)(db + o_mf);
+    d.cut_lo = (sa_t *)(db + o_clo); d.cut_hi = (sa_t *)(db + o_chi); d.mend_pos = (sa_t *)(db + o_mp);
+    d.err = a->dErr.as<u32>();
+    RV_TRY(rv_decide_launch(h->ws, d));
+    RvLabelTabs &lt = a->e_lt;
+    lt.sub_start = a->d_next_ss; lt.nsubs = ns; lt.tile_sub = a->d_next_tsub2;
+    lt.ctab_first = d.ctab_first; lt.cbegin = d.cb; lt.cend = d.ce; lt.ccls = d.cc;
+    lt.mtab_first = d.mtab_first; lt.mbegin = d.mb; lt.mend = d.me; lt.nmatch = 2 * ns;
+    RvSplitArgs &sa = a->e_sa;
+    u32 *tiles = a->dTile.as<u32>();
+    sa.ntiles = ntiles;
+    sa.tile_cnt = tiles; sa.tile_has = tiles + 3 * ntiles; sa.tile_post = tiles + 6 * ntiles;
+    sa.tile_G = tiles + 9 * ntiles; sa.tile_carry = tiles + 12 * ntiles;
+    sa.total = (u32 *)(db + o_tot);
+    sa.sub_start = lt.sub_start; sa.nsubs = ns; sa.tile_sub = lt.tile_sub;
+    sa.child_base = d.child_base; sa.child_n = d.child_n; sa.sub_off = d.sub_off; sa.expect_total = d.expect_total;
+    sa.cut_first = d.cut_first; sa.cut_lo = d.cut_lo; sa.cut_hi = d.cut_hi;
+    sa.mend_first = d.mend_first; sa.mend_pos = d.mend_pos;
+    sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
+    sa.err = a->dErr.as<u32>();
+    int id = h->prof.begin(q, RV_K_SPLIT, (double)m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m * (sizeof(sa_t) + sizeof(lcp_t) + 1));
+    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
+    h->prof.end(q, id);
+    a->early_done = true;
+    return 0;
+}
+
 /* reveal.c:802-822 for every sub-index of the frontier */
 int rv_frontier_scan(rv_index *h) {
     RV_TRY(need_align(h));
@@ -293,9 +362,12 @@ int rv_frontier_scan(rv_index *h) {
         // level came with the previous commit's table upload (a pageable H2D copy here would wait for the stream to drain and
         // expose the launch latency of the whole scan).
         const int64_t *d_ss = (a->full_only && a->level > 0) ? a->d_next_ss : nullptr;
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->d_err, &err, d_ss, ns));
-        a->d_err = nullptr;
+        a->early_done = false;
+        const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
+        if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, early_split, early));
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+        if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
         int si = 0;
         for (size_t k = 0; k < a->recs.size(); k++) {
             const int64_t r = (int64_t)a->recs[k].rank;
@@ -639,17 +711,52 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         }
         o_ntsub = pk.addv(a->next_tsub);
     }
+    // two samples, untraced: the next level's split can be decided on the device if each of its sub-indices owns at most one
+    // interval per sample (rv_decide.hip).  Ship what that needs: node intervals, "finished by the leaf kernel" flags, tiles.
+    size_t o_nnodes = 0, o_nflags = 0, o_ntsub2 = 0;
+    a->next_dev_ok = !a->multi && a->full_only && nx.size() > 0 && nx.size() <= RV_DECIDE_MAX_SUBS && m_next > 0;
+    if (a->next_dev_ok) {
+        const int nsn = nx.size();
+        a->next_nodes.assign((size_t)nsn * 4, 0); a->next_flags.assign((size_t)nsn, 0);
+        const int64_t sep = h->nsep[0];
+        for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
+            const int64_t nf = nx.node_first[(size_t)s2], nn = nx.node_first[(size_t)s2 + 1] - nf;
+            if (nn < 1 || nn > 2) { a->next_dev_ok = false; break; }
+            sa_t *nd = a->next_nodes.data() + (size_t)s2 * 4;
+            for (int64_t k = 0; k < nn; k++) {
+                const RvIntv iv = nx.nodes[(size_t)(nf + k)];
+                if (iv.begin < sep) { if (nd[0] < nd[1]) a->next_dev_ok = false; nd[0] = (sa_t)iv.begin; nd[1] = (sa_t)iv.end; }
+                else if (iv.begin > sep) { if (nd[2] < nd[3]) a->next_dev_ok = false; nd[2] = (sa_t)iv.begin; nd[3] = (sa_t)iv.end; }
+                else a->next_dev_ok = false;
+            }
+            // the leaf kernel takes every sub-index of at most RV_LEAF_N ranks here (same rule as rv_align_builtin)
+            a->next_flags[(size_t)s2] = (a->use_leaf && nx.n[(size_t)s2] <= RV_LEAF_N) ? 1 : 0;
+        }
+    }
+    if (a->next_dev_ok) {
+        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
+        a->next_tsub.resize((size_t)ntn);
+        int s2 = 0;
+        const int nsn = nx.size();
+        for (int64_t t = 0; t < ntn; t++) {
+            const int64_t r = t * RV_SPLIT_TILE;
+            while (s2 + 1 < nsn && a->next_ss[(size_t)s2 + 1] <= r) s2++;
+            a->next_tsub[(size_t)t] = s2;
+        }
+        o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = pk.addv(a->next_tsub);
+    }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
     u32 class_total[4] = {0, 0, 0, 0};
     for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
-    const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_err = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
+    const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.size() + 64));
     RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
     a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant); a->d_next_tsub = (const int *)(tb + o_ntsub);
+    a->d_next_nodes = (const sa_t *)(tb + o_nnodes); a->d_next_flags = tb + o_nflags; a->d_next_tsub2 = (const int *)(tb + o_ntsub2);
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));
@@ -685,9 +792,10 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
     sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
-    sa.err = (u32 *)(tb + o_err);
+    sa.err = a->dErr.as<u32>();      // persistent for the alignment: an early split (rv_decide.hip) runs before this upload exists
     int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
-    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
+    if (!a->early_done)      // (otherwise queued behind the picker already, with the same tables built on the device)
+        RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
     h->prof.end(q, id);
     RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
     const double t1 = now_s();
@@ -772,10 +880,10 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         h->prof.end(q, id);
     }
     if (!a->multi && m_next > 1) {
-        a->d_err = (const u32 *)(tb + o_err);      // pair mode: the next scan's single copy brings the error word along
+        a->d_err = a->dErr.as<u32>();      // pair mode: the next scan's single copy brings the error word along
     } else {
         u32 err = 0;
-        RV_HIP(hipMemcpyAsync(&err, tb + o_err, 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(&err, a->dErr.p, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
     }
@@ -783,6 +891,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
     a->level++;
     a->cur = nxt;
+    a->cur_dev_ok = a->next_dev_ok; a->early_done = false;
     std::swap(a->lv, a->nx);
     a->dec.reset(a->lv.size());
     a->st.t_split += t1 - t0;
@@ -802,6 +911,7 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     std::vector<uint8_t> touched;
     // ---- leaf kernel set-up (two samples only): sub-indices of at most RV_LEAF_N ranks finish on the GPU in one launch per level
     const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
+    a->use_leaf = use_leaf;
     hipStream_t q = h->ws.stream;
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     if (use_leaf) {

@@ -59,6 +59,7 @@ void rv_free(rv_index *h) {
     h->dT.release(); h->dT0.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dBWT.release(); h->dNsep.release();
     h->ws.release();
     h->hscan.release();
+    if (h->ev_picks) { (void)hipEventDestroy(h->ev_picks); h->ev_picks = nullptr; }
     if (h->ws.stream) (void)hipStreamDestroy(h->ws.stream);
     delete h;
 }
@@ -272,7 +273,7 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 // one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
-                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs) {
+                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs, int (*after_pick)(rv_index *), bool use_hook) {
     out.clear();
     if (err_out) *err_out = 0;
     if (m <= 1) {
@@ -309,10 +310,15 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
             // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots
             RV_TRY(rv_pick_slots_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), (u32)std::min<size_t>(vcap, 0xffffffffu), tilecnt, tileovf, ntile,
                                         d_sub_start, nsubs, bbest.as<unsigned long long>(), picks, bcnt.as<u32>(), d_err));
-            // the one host round trip of a level: spin on the stream instead of sleeping in hipStreamSynchronize (its wake-up
-            // costs tens of microseconds, 33 times per alignment)
-            if (getenv("RV_SYNC_BLOCK")) { RV_HIP(hipStreamSynchronize(q)); }
-            else { hipError_t qe; while ((qe = hipStreamQuery(q)) == hipErrorNotReady) {} if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; } }
+            // The one host round trip of a level.  The host waits for the picks only (an event behind the picker kernels), not for
+            // the stream: work that needs nothing but the picks on the device (the level's split, rv_decide.hip) is queued first
+            // and runs while the host works.  Spinning instead of sleeping in a synchronize: its wake-up costs tens of
+            // microseconds, 33 times per alignment.
+            if (!h->ev_picks) RV_HIP(hipEventCreateWithFlags(&h->ev_picks, hipEventDisableTiming));
+            RV_HIP(hipEventRecord(h->ev_picks, q));
+            if (use_hook && after_pick) RV_TRY(after_pick(h));
+            if (getenv("RV_SYNC_BLOCK")) { RV_HIP(hipEventSynchronize(h->ev_picks)); }
+            else { hipError_t qe; while ((qe = hipEventQuery(h->ev_picks)) == hipErrorNotReady) {} if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; } }
             const u32 *hdr = h->hscan.as<u32>();
             const u32 novf = hdr[1];
             if (err_out) *err_out = hdr[2];
@@ -469,7 +475,7 @@ int64_t rv_getmums(rv_index *h, int minl) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
     (void)hipSetDevice(h->device);
     std::vector<RvPairRec> recs;
-    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs, nullptr, nullptr, nullptr, 0) != 0) return -1;
+    if (rv_run_pair_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minl, recs, nullptr, nullptr, nullptr, 0, nullptr, false) != 0) return -1;
     h->m_l.resize(recs.size()); h->m_a.resize(recs.size()); h->m_b.resize(recs.size());
     for (size_t k = 0; k < recs.size(); k++) {
         int64_t b = recs[k].b;

@@ -73,6 +73,7 @@ struct rv_index {
     DBuf dT, dT0, dSA, dSAi, dLCP, dBWT, dNsep;   // dT0 = pristine text, dT = working copy (lower-cased by align)
     bool text_dirty = true;
     HBuf hscan;                        // pinned staging for the scan records
+    hipEvent_t ev_picks = nullptr;     // recorded behind the picker kernels: the host waits for this, not for the stream
     size_t scan_guess = 4096;
     u32 maxlcp = 0;
     RvSaStats sa_stats{};
@@ -88,7 +89,8 @@ struct rv_index {
 int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn,
                       const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos);
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
-                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs);   // d_sub_start != NULL: only the best record per sub-index
+                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs,   // d_sub_start != NULL: only the best record per sub-index
+                     int (*after_pick)(rv_index *), bool use_hook);                        // ... and a hook called once the picker kernels are queued
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

@@ -137,7 +137,8 @@ struct Align {
     bool flag_clean = false;     // dFlag is all zero
     // device-side decisions (rv_decide.hip): tables of the NEXT level shipped with a commit, state of the early split
     DBuf dDec, dErr;
-    bool next_dev_ok = false, cur_dev_ok = false, early_done = false, use_leaf = false;
+    bool next_dev_ok = false, cur_dev_ok = false, early_done = false, early_bubble = false, use_leaf = false;
+    int64_t par_min_cur = RV_BUBBLE_PAR_N;
     const sa_t *d_next_nodes = nullptr; const uint8_t *d_next_flags = nullptr; const int *d_next_tsub2 = nullptr;
     std::vector<sa_t> next_nodes; std::vector<uint8_t> next_flags;
     RvLabelTabs e_lt; RvSplitArgs e_sa;
@@ -252,7 +253,8 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->minl = minl; a->minn = minn;
     a->multi = h->nsamples > 2;
     a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
-    a->next_dev_ok = a->cur_dev_ok = a->early_done = false; a->use_leaf = false;
+    a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false; a->use_leaf = false;
+    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
     RV_TRY(a->dErr.reserve(64));
     RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, h->ws.stream));
     memset(&a->st, 0, sizeof a->st);
@@ -313,6 +315,7 @@ static int early_split(rv_index *h) {
     const size_t o_mb = take(2 * S * sizeof(sa_t)), o_me = take(2 * S * sizeof(sa_t)), o_mtf = take((S + 1) * 4);
     const size_t o_cn = take(3 * S * 4), o_cbase = take(3 * S * 4), o_soff = take(3 * S * 4), o_exp = take(16), o_tot = take(16);
     const size_t o_cf = take((S + 1) * 4), o_mf = take((S + 1) * 4), o_clo = take(2 * S * sizeof(sa_t)), o_chi = take(2 * S * sizeof(sa_t)), o_mp = take(2 * S * sizeof(sa_t));
+    const size_t o_kid = take(S * sizeof(RvBubbleDesc));
     RV_TRY(a->dDec.reserve(bytes + 64));
     uint8_t *db = a->dDec.as<uint8_t>();
     RvDecideArgs d;
@@ -324,6 +327,8 @@ static int early_split(rv_index *h) {
     d.cut_first = (int *)(db + o_cf); d.mend_first = (int *)(db + o_mf);
     d.cut_lo = (sa_t *)(db + o_clo); d.cut_hi = (sa_t *)(db + o_chi); d.mend_pos = (sa_t *)(db + o_mp);
     d.err = a->dErr.as<u32>();
+    d.ovf_cap = (u32)std::min<size_t>(h->ws.misc[4].cap / sizeof(RvPairRec), 0xffffffffu);      // (the scan's overflow buffer)
+    d.kid = (RvBubbleDesc *)(db + o_kid);
     RV_TRY(rv_decide_launch(h->ws, d));
     RvLabelTabs &lt = a->e_lt;
     lt.sub_start = a->d_next_ss; lt.nsubs = ns; lt.tile_sub = a->d_next_tsub2;
@@ -345,6 +350,28 @@ static int early_split(rv_index *h) {
     RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
     h->prof.end(q, id);
     a->early_done = true;
+    // Few sub-indices (so the LDS kernels are not in play): lower-casing and the bubble of every leading child the rounds
+    // do not take follow at once, too -- the whole level except those rounds is then queued before the host has seen the picks.
+    a->early_bubble = false;
+    int64_t biggest = 0;
+    for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
+    // (a level that still has a sub-index above the rounds' threshold keeps the host-built mix of rounds and joined children)
+    if (ns <= 1024 && biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE")) {
+        RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, 2 * ns));
+        {
+            const void *before = a->dFlag.p;
+            RV_TRY(a->dFlag.reserve((size_t)m + 64));
+            if (!a->flag_clean || a->dFlag.p != before) { RV_HIP(hipMemsetAsync(a->dFlag.p, 0, a->dFlag.cap, q)); a->flag_clean = true; }
+        }
+        RvBubbleArgs ba;
+        memset(&ba, 0, sizeof ba);
+        ba.flag = a->dFlag.as<uint8_t>();
+        ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = d.cut_lo; ba.cut_hi = d.cut_hi; ba.err = a->dErr.as<u32>();
+        id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
+        RV_TRY(rv_bubble_children_dev_launch(h->ws, ba, d.kid, ns, a->par_min_cur));
+        h->prof.end(q, id);
+        a->early_bubble = true;
+    }
     return 0;
 }
 
@@ -362,7 +389,7 @@ int rv_frontier_scan(rv_index *h) {
         // level came with the previous commit's table upload (a pageable H2D copy here would wait for the stream to drain and
         // expose the launch latency of the whole scan).
         const int64_t *d_ss = (a->full_only && a->level > 0) ? a->d_next_ss : nullptr;
-        a->early_done = false;
+        a->early_done = false; a->early_bubble = false;
         const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
         RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, early_split, early));
@@ -619,7 +646,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // Leading children above par_min ranks take the data-parallel rounds.  Once a level runs those rounds anyway, the small
     // children join them as long as there are few of them (measured: with thousands of small children per level the
     // one-workgroup-per-child kernel is the cheaper way, C3/C4): their kernel would only add its own latency in front.
-    const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !getenv("RV_BUBBLE_NO_JOIN");
+    const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !getenv("RV_BUBBLE_NO_JOIN") && !a->early_bubble;
     // The LDS kernels pay off by throughput (thousands of small children per level: many samples, or very large inputs).  A
     // few hundred small children ride along with the larger ones for free (measured on C2: 612 vs 597 Mbp/s).
     size_t lds_candidates = 0;
@@ -627,6 +654,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // (more than two samples: many cuts per child, no leaf kernel -- the LDS kernel is always the better one for small children)
     const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && (a->multi || getenv("RV_BUBBLE_LDS_ALWAYS")));
     for (const auto &kd : a->kid_tmp) {
+        if (a->early_bubble && kd.n <= par_min) continue;      // bubbled already, right behind the early split
         if ((!all_par && kd.n <= par_min) || (use_lds && kd.n <= lds_n)) {             // every cut of this child in one workgroup, sequentially
             RvBubbleDesc bd; bd.off = kd.off; bd.n = kd.n; bd.B = 0; bd.wlo = 0; bd.cut0 = kd.c0; bd.cut1 = kd.c1;
             ((use_lds && kd.n <= lds_n) ? a->kids_lds : kd.n <= RV_BUBBLE_BIG_N ? a->kids_small : a->kids_big).push_back(bd);
@@ -752,7 +780,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.size() + 64));
-    RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
+    if (pk.pageable || getenv("RV_TABLES_MEMCPY")) RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
+    else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab.p, pk.size())); }
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
     a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant); a->d_next_tsub = (const int *)(tb + o_ntsub);
@@ -797,7 +826,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (!a->early_done)      // (otherwise queued behind the picker already, with the same tables built on the device)
         RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
     h->prof.end(q, id);
-    RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
+    if (!a->early_bubble)
+        RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
     const double t1 = now_s();
     a->lg[2] = t1 - t0;           // label/split/lower enqueued
 
@@ -891,7 +921,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
     a->level++;
     a->cur = nxt;
-    a->cur_dev_ok = a->next_dev_ok; a->early_done = false;
+    a->cur_dev_ok = a->next_dev_ok; a->early_done = false; a->early_bubble = false;
     std::swap(a->lv, a->nx);
     a->dec.reset(a->lv.size());
     a->st.t_split += t1 - t0;

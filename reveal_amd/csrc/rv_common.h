@@ -102,6 +102,9 @@ template <class V>
 int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n,
                         int bit_lo, int bit_hi, int *result_in_1);
 
+// copy of a small table from pinned host memory by a kernel (bytes rounded up to 16: both buffers must have that room)
+int rv_h2d_copy(Workspace &ws, const void *pinned_src, void *dst, size_t bytes);
+
 // ---- construct (rv_construct.hip) ------------------------------------------
 struct RvSaStats {
     int    sigma, bits, k0;     // alphabet size, bits per symbol, symbols in the first key

@@ -2,6 +2,7 @@
 #pragma once
 #include "rv_common.h"
 #include "rv_scan.h"
+#include "rv_split.h"
 
 struct RvDecideArgs {
     int nsubs;
@@ -19,6 +20,8 @@ struct RvDecideArgs {
     int *cut_first, *mend_first;    // [nsubs+1]
     sa_t *cut_lo, *cut_hi, *mend_pos;       // [2*nsubs]
     u32 *err;
+    u32 ovf_cap;                    // picks[0] carries the scan's overflow count: beyond this the picks are incomplete -> no decisions
+    RvBubbleDesc *kid;              // [nsubs] leading child of every sub-index as a bubble descriptor (n = 0: nothing to do)
 };
 
 #define RV_DECIDE_MAX_SUBS 65536    // above this the single-block offset scan would take longer than the host round trip it hides

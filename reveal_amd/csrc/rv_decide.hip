@@ -28,7 +28,8 @@ __global__ __launch_bounds__(TB) void k_decide(RvDecideArgs d) {
     }
     const sa_t a0 = d.nodes[4 * (size_t)s], a1 = d.nodes[4 * (size_t)s + 1], b0 = d.nodes[4 * (size_t)s + 2], b1 = d.nodes[4 * (size_t)s + 3];
     const RvPairRec rec = d.picks[RV_PAIR_HDR + s];
-    bool have = rec.rank != 0xFFFFFFFFu && !(d.flags[s] & 1) && a0 < a1 && b0 < b1;
+    const bool complete = reinterpret_cast<const u32 *>(d.picks)[1] <= d.ovf_cap;      // (the host reruns the scan with a larger overflow buffer otherwise)
+    bool have = complete && rec.rank != 0xFFFFFFFFu && !(d.flags[s] & 1) && a0 < a1 && b0 < b1;
     sa_t a = 0, b = 0; sa_t l = 0;
     if (have) {
         a = rec.a; b = rec.b; l = (sa_t)rec.l;
@@ -89,6 +90,11 @@ __global__ __launch_bounds__(1024) void k_decide_offsets(RvDecideArgs d) {
             const u32 lead_base = g0 + g1, trail_base = lead_base + c0;   // (sub-index, class) order, rest children are empty here
             d.child_base[3 * (size_t)s] = lead_base; d.child_base[3 * (size_t)s + 1] = trail_base; d.child_base[3 * (size_t)s + 2] = trail_base + c1;
             d.sub_off[3 * (size_t)s] = lead_base - g0; d.sub_off[3 * (size_t)s + 1] = trail_base - g1; d.sub_off[3 * (size_t)s + 2] = trail_base + c1;
+            // the leading child as a bubble descriptor (all its cuts in one workgroup, rv_split.hip)
+            RvBubbleDesc kd; kd.off = (int64_t)lead_base; kd.B = 0; kd.wlo = 0; kd.cut0 = 2 * s; kd.cut1 = 2 * s + 2;
+            const bool win = d.cut_lo[2 * (size_t)s] < d.cut_hi[2 * (size_t)s] || d.cut_lo[2 * (size_t)s + 1] < d.cut_hi[2 * (size_t)s + 1];
+            kd.n = win ? (int64_t)c0 : 0;
+            d.kid[s] = kd;
         }
         __syncthreads();
         if (threadIdx.x == 0) { s_run[0] += t0; s_run[1] += t1; }

@@ -260,5 +260,21 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
     return 0;
 }
 
+// Small host -> device table copy as an ordinary kernel (src = pinned host memory).  A hipMemcpyAsync goes through
+// the copy path of the runtime; the kernel that follows it on the stream then started ~28 us late at every level of
+// the recursion (cross-queue dependency), a kernel-to-kernel dependency costs ~6 us.
+__global__ __launch_bounds__(256) void k_h2d_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+int rv_h2d_copy(Workspace &ws, const void *pinned_src, void *dst, size_t bytes) {
+    const size_t n16 = (bytes + 15) / 16;
+    if (n16 == 0) return 0;
+    size_t blocks = (n16 + 255) / 256;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(k_h2d_copy, dim3((unsigned)blocks), dim3(256), 0, ws.stream, (const uint4 *)pinned_src, (uint4 *)dst, n16);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 template int rv_radix_sort_pairs<u32>(Workspace &, u64 *, u32 *, u64 *, u32 *, int64_t, int, int, int *);
 template int rv_radix_sort_pairs<u64>(Workspace &, u64 *, u64 *, u64 *, u64 *, int64_t, int, int, int *);

@@ -110,6 +110,8 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
 #define RV_BUBBLE_PAR_N 524288
 // all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
+int rv_lower_ranges_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, int nranges);
+int rv_bubble_children_dev_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n);
 int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count3);   // descriptors sorted by size class
 // one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)
 int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles);

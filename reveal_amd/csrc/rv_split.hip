@@ -577,6 +577,17 @@ __global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_
     }
 }
 
+// the same, one wave per matched range (device-built tables have no prefix sums over the range lengths)
+__global__ __launch_bounds__(TB) void k_lower_ranges(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend, int nranges) {
+    const int e = (int)(((int64_t)blockIdx.x * TB + threadIdx.x) >> 6);
+    if (e >= nranges) return;
+    const int64_t lo = (int64_t)mbegin[e], hi = (int64_t)mend[e];
+    for (int64_t pos = lo + (threadIdx.x & 63); pos < hi; pos += 64) {
+        const uint8_t c = T[pos];
+        if (c >= 'A' && c <= 'Z') T[pos] = c + 32;
+    }
+}
+
 // ---- bubble_sort ---------------------------------------------------------------
 // Round r handles the r-th matched interval of every split sub-index.
 // Window pass: for every text position p in [wlo, B) of a descriptor, look at
@@ -1023,7 +1034,7 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
 // their cuts independently of each other, instead of every round waiting for the
 // slowest child of the level.
 template <int NT, int EL>
-__global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc) {
+__global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc, int64_t max_n) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];
     __shared__ int s_max[NT / 64];
@@ -1032,6 +1043,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
     __shared__ ParScratch ps;
     __shared__ u32 s_first, s_cnt;
     RvBubbleDesc ds = cdesc[blockIdx.x];
+    if (ds.n <= 0 || ds.n > max_n) return;      // device-built descriptor arrays hold one entry per sub-index: empty ones, and children the rounds take
     {
         const int nc = ds.cut1 - ds.cut0 < BB_MAXCUT ? ds.cut1 - ds.cut0 : BB_MAXCUT;
         if ((int)threadIdx.x < nc) { cw.lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw.hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
@@ -1274,6 +1286,21 @@ int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int co
     return 0;
 }
 
+int rv_lower_ranges_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, int nranges) {
+    if (nranges <= 0) return 0;
+    hipLaunchKernelGGL(k_lower_ranges, dim3((unsigned)ceil_div((int64_t)nranges * 64, TB)), dim3(TB), 0, ws.stream, T, mbegin, mend, nranges);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// one descriptor per sub-index (built on the device): entries with n <= 0 or n > max_n are skipped
+int rv_bubble_children_dev_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n) {
+    if (count <= 0) return 0;
+    hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, d_desc, max_n);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count) {
     // three size classes (RV_BUBBLE_LDS_N0/1/2 ranks), descriptors back to back: smaller children take less LDS, so more
     // of them run per CU (28 / 46 / 92 KB per workgroup)
@@ -1288,11 +1315,11 @@ int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const Rv
 
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig) {
     if (nsmall > 0) {
-        hipLaunchKernelGGL((k_bubble_child<256, 1>), dim3((unsigned)nsmall), dim3(256), 0, ws.stream, b, d_small);
+        hipLaunchKernelGGL((k_bubble_child<256, 1>), dim3((unsigned)nsmall), dim3(256), 0, ws.stream, b, d_small, (int64_t)1 << 62);
         RV_LAUNCH_CHECK();
     }
     if (nbig > 0) {
-        hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3((unsigned)nbig), dim3(1024), 0, ws.stream, b, d_big);
+        hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3((unsigned)nbig), dim3(1024), 0, ws.stream, b, d_big, (int64_t)1 << 62);
         RV_LAUNCH_CHECK();
     }
     return 0;

@@ -244,7 +244,8 @@ __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__
                 const bool mine = sub == lsub;
                 u64 v = mine ? key : 0;
                 for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-                if (lane == leader) atomicMax(&best[lsub], (unsigned long long)v);
+                // (only a wave that would raise the maximum goes to the atomic unit: with a handful of sub-indices every wave hits the same few words)
+                if (lane == leader && (unsigned long long)v > __atomic_load_n(&best[lsub], __ATOMIC_RELAXED)) atomicMax(&best[lsub], (unsigned long long)v);
                 todo &= ~__ballot(mine);
             }
         } else if (have && best[sub] == (unsigned long long)key) {

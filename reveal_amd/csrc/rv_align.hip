@@ -136,7 +136,7 @@ struct Align {
     bool roots_inflight[2] = {false, false};
     bool flag_clean = false;     // dFlag is all zero
     // device-side decisions (rv_decide.hip): tables of the NEXT level shipped with a commit, state of the early split
-    DBuf dDec, dErr;
+    DBuf dDec, dErr, dTab0;
     bool next_dev_ok = false, cur_dev_ok = false, early_done = false, early_bubble = false, use_leaf = false;
     int64_t par_min_cur = RV_BUBBLE_PAR_N;
     const sa_t *d_next_nodes = nullptr; const uint8_t *d_next_flags = nullptr; const int *d_next_tsub2 = nullptr;
@@ -174,7 +174,7 @@ struct Align {
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
@@ -300,7 +300,7 @@ static int early_split(rv_index *h) {
     const Level &lv = a->lv;
     const int ns = lv.size();
     const int64_t m = lv.m, ntiles = ceil_div(m, RV_SPLIT_TILE);
-    const int nxt = a->cur ^ 1;
+    const int nxt = (a->level == 0) ? 0 : (a->cur ^ 1);
     RV_TRY(a->dD.reserve((size_t)m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->lvSA[nxt].reserve((size_t)(m + 64) * sizeof(sa_t)));
@@ -388,7 +388,7 @@ int rv_frontier_scan(rv_index *h) {
         // built-in picker without tracing: the device keeps only the record the picker would take.  The sub-index starts of this
         // level came with the previous commit's table upload (a pageable H2D copy here would wait for the stream to drain and
         // expose the launch latency of the whole scan).
-        const int64_t *d_ss = (a->full_only && a->level > 0) ? a->d_next_ss : nullptr;
+        const int64_t *d_ss = (a->full_only && (a->level > 0 || a->cur_dev_ok)) ? a->d_next_ss : nullptr;
         a->early_done = false; a->early_bubble = false;
         const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
@@ -942,6 +942,32 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     // ---- leaf kernel set-up (two samples only): sub-indices of at most RV_LEAF_N ranks finish on the GPU in one launch per level
     const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
     a->use_leaf = use_leaf;
+    // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
+    // the levels after it), so the first level takes the same path as the others
+    if (!a->multi && a->full_only && !a->lv.nodes.empty() && a->lv.nodes.size() <= 2 && h->n < ((int64_t)1 << 32)) {
+        sa_t nd[4] = {0, 0, 0, 0};
+        bool ok = true;
+        for (const RvIntv &iv : a->lv.nodes) {
+            if (iv.begin < h->nsep[0]) { if (nd[0] < nd[1]) ok = false; nd[0] = (sa_t)iv.begin; nd[1] = (sa_t)iv.end; }
+            else if (iv.begin > h->nsep[0]) { if (nd[2] < nd[3]) ok = false; nd[2] = (sa_t)iv.begin; nd[3] = (sa_t)iv.end; }
+            else ok = false;
+        }
+        if (ok) {
+            Packer &pk = a->pk;
+            pk.clear();
+            const int64_t ss[2] = {0, h->n};
+            const uint8_t fl[16] = {(uint8_t)((use_leaf && h->n <= RV_LEAF_N) ? 1 : 0)};
+            a->next_tsub.assign((size_t)ceil_div(h->n, RV_SPLIT_TILE), 0);
+            const size_t o1 = pk.add(ss, sizeof ss), o2 = pk.add(nd, sizeof nd), o3 = pk.add(fl, sizeof fl), o4 = pk.addv(a->next_tsub);
+            RV_TRY(a->dTab0.reserve(pk.size() + 64));
+            if (pk.pageable) RV_HIP(hipMemcpyAsync(a->dTab0.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
+            else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab0.p, pk.size())); }
+            RV_HIP(hipStreamSynchronize(h->ws.stream));      // (the staging buffer is reused by the first commit)
+            const uint8_t *t0b = a->dTab0.as<uint8_t>();
+            a->d_next_ss = (const int64_t *)(t0b + o1); a->d_next_nodes = (const sa_t *)(t0b + o2); a->d_next_flags = t0b + o3; a->d_next_tsub2 = (const int *)(t0b + o4);
+            a->cur_dev_ok = true;
+        }
+    }
     hipStream_t q = h->ws.stream;
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     if (use_leaf) {

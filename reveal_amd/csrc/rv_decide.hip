@@ -19,8 +19,7 @@ namespace {
 
 constexpr int TB = 256;
 
-__global__ __launch_bounds__(TB) void k_decide(RvDecideArgs d) {
-    const int s = blockIdx.x * TB + threadIdx.x;
+__device__ inline void decide_one(const RvDecideArgs &d, int s) {
     if (s > d.nsubs) return;
     if (s == d.nsubs) {      // closing entries of the fixed-stride index arrays
         d.ctab_first[s] = 4 * s; d.mtab_first[s] = 2 * s; d.cut_first[s] = 2 * s; d.mend_first[s] = 2 * s;
@@ -63,12 +62,20 @@ __global__ __launch_bounds__(TB) void k_decide(RvDecideArgs d) {
     mend[0] = a + l; mend[1] = b + l;
 }
 
+__global__ __launch_bounds__(TB) void k_decide(RvDecideArgs d) { decide_one(d, blockIdx.x * TB + threadIdx.x); }
+
 // child offsets: running offset over (sub-index, class) and the class totals in front of every sub-index.
 // One block; sub-index counts beyond its reach use rv_decide_offsets_large.
+template <bool FUSED>
 __global__ __launch_bounds__(1024) void k_decide_offsets(RvDecideArgs d) {
     __shared__ u32 s_w[16][3];
     __shared__ u32 s_run[3];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (FUSED) {      // few sub-indices: the decisions themselves in the same (single) workgroup -- one launch less per level
+        for (int s = threadIdx.x; s <= d.nsubs; s += 1024) decide_one(d, s);
+        __threadfence_block();
+        __syncthreads();
+    }
     if (threadIdx.x < 3) s_run[threadIdx.x] = 0;
     __syncthreads();
     for (int base = 0; base < d.nsubs; base += 1024) {
@@ -107,9 +114,14 @@ __global__ __launch_bounds__(1024) void k_decide_offsets(RvDecideArgs d) {
 
 int rv_decide_launch(Workspace &ws, const RvDecideArgs &d) {
     if (d.nsubs <= 0) return 0;
+    if (d.nsubs <= 4096) {
+        hipLaunchKernelGGL(k_decide_offsets<true>, dim3(1), dim3(1024), 0, ws.stream, d);
+        RV_LAUNCH_CHECK();
+        return 0;
+    }
     hipLaunchKernelGGL(k_decide, dim3((unsigned)ceil_div((int64_t)d.nsubs + 1, TB)), dim3(TB), 0, ws.stream, d);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_decide_offsets, dim3(1), dim3(1024), 0, ws.stream, d);
+    hipLaunchKernelGGL(k_decide_offsets<false>, dim3(1), dim3(1024), 0, ws.stream, d);
     RV_LAUNCH_CHECK();
     return 0;
 }

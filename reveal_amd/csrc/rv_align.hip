@@ -199,6 +199,17 @@ static int sample_of(const rv_index *h, int64_t pos) {       /* SO[pos], interfa
 static int count_samples(rv_index *h, const RvIntv *iv, size_t cnt) {
     Align *a = h->al;
     if (h->nsamples > 2) {
+        // the intervals are sorted by begin, so their samples are non-decreasing: one walk along the sample boundaries
+        bool sorted = true;
+        for (size_t k = 1; k < cnt && sorted; k++) sorted = iv[k - 1].begin <= iv[k].begin;
+        if (sorted) {
+            int ns = 0, last = -1; size_t sp = 0;
+            for (size_t k = 0; k < cnt; k++) {
+                while (sp < h->nsep.size() && h->nsep[sp] < iv[k].begin) sp++;
+                if ((int)sp != last) { ns++; last = (int)sp; }
+            }
+            return ns;
+        }
         if ((int)a->stamp.size() < h->nsamples) a->stamp.assign((size_t)h->nsamples, 0);
         const int ep = ++a->epoch;
         int ns = 0;
@@ -629,7 +640,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             for (int64_t r = m0; r < m1; r++) {
                 const int64_t B = dc.match[(size_t)r].begin;
                 int64_t lo = B;
-                for (size_t k = 0; k < cnts[0]; k++) if (lists[0][k].end == B && lists[0][k].begin < B) { lo = std::max(lists[0][k].begin, B - lcap); break; }
+                {   // the leading interval that ends at this cut (the list is sorted and non-overlapping: binary search on the ends)
+                    size_t x = 0, y = cnts[0];
+                    while (x < y) { const size_t mid = (x + y) / 2; if (lists[0][mid].end < B) x = mid + 1; else y = mid; }
+                    if (x < cnts[0] && lists[0][x].end == B && lists[0][x].begin < B) lo = std::max(lists[0][x].begin, B - lcap);
+                }
                 a->cut_lo.push_back((sa_t)lo); a->cut_hi.push_back((sa_t)B);
             }
             const int c1 = (int)a->cut_lo.size();

@@ -49,7 +49,7 @@ struct Packer {
         size_t want = need + need / 2 + 4096;
         uint8_t *q = nullptr;
         if (hipHostMalloc((void **)&q, want, hipHostMallocDefault) != hipSuccess) { q = (uint8_t *)malloc(want); pageable = true; }
-        if (p) { memcpy(q, p, used); release_ptr(); }
+        if (p) { (void)hipDeviceSynchronize(); memcpy(q, p, used); release_ptr(); }      // (a queued copy kernel may still read the old buffer)
         p = q; cap = want;
     }
     size_t add(const void *src, size_t bytes) {

@@ -62,8 +62,9 @@ struct HBuf {
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
-        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
+        // (kernels read and write pinned buffers directly -- picks, table staging: nothing may be in flight when one is replaced)
+        if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 2 + 4096;
         RV_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
         cap = want;
         return 0;

@@ -361,13 +361,13 @@ static int early_split(rv_index *h) {
     RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
     h->prof.end(q, id);
     a->early_done = true;
-    // Few sub-indices (so the LDS kernels are not in play): lower-casing and the bubble of every leading child the rounds
+    // Few sub-indices (above a few thousand the LDS kernels on their own stream are the better choice): lower-casing and the bubble of every leading child the rounds
     // do not take follow at once, too -- the whole level except those rounds is then queued before the host has seen the picks.
     a->early_bubble = false;
     int64_t biggest = 0;
     for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
     // (a level that still has a sub-index above the rounds' threshold keeps the host-built mix of rounds and joined children)
-    if (ns <= 1024 && biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE")) {
+    if (ns <= 4096 && biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE")) {
         RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, 2 * ns));
         {
             const void *before = a->dFlag.p;

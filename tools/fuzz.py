@@ -1,0 +1,116 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: the GPU recursion (traced and untraced, default and forced code paths) against the CPU oracle
+on random inputs -- SNPs, indels, tandem repeats, N runs, several contigs, 2-4 samples.  Test infrastructure.
+usage: python tools/fuzz.py [seconds] [seed]"""
+import os
+import random
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from helpers import assemble, feed, oracle  # noqa: E402
+from reveal_amd import reveallib, reveallib64  # noqa: E402
+
+FIELDS = ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums")
+ENVS = [
+    {},
+    {"RV_BUBBLE_PAR_MIN": "0", "RV_NO_LEAF": "1"},
+    {"RV_BUBBLE_PAR_MIN": "256"},
+    {"RV_BUBBLE_LDS_ALWAYS": "1", "RV_NO_LEAF": "1"},
+    {"RV_NO_EARLY_SPLIT": "1"},
+    {"RV_CARRY_CH": "2", "RV_SA_NO_TEXT": "1", "RV_LCP_BY_RANK": "1"},
+]
+
+
+def mutate(rng, base, snp, indel):
+    out = []
+    i = 0
+    L = len(base)
+    while i < L:
+        r = rng.random()
+        if r < snp:
+            out.append(rng.choice("ACGT")); i += 1
+        elif r < snp + indel:
+            if rng.random() < 0.5:
+                i += rng.randint(1, 30)
+            else:
+                out.append("".join(rng.choice("ACGT") for _ in range(rng.randint(1, 30))))
+        else:
+            out.append(base[i]); i += 1
+    return "".join(out)
+
+
+def make_case(rng):
+    L = rng.choice([300, 2000, 20000, 80000, 250000])
+    ns = rng.choice([2, 2, 2, 3, 4])
+    base = "".join(rng.choice("ACGT") for _ in range(L))
+    if rng.random() < 0.4:      # tandem repeats / low complexity
+        p = rng.randint(0, L - 1); unit = base[p:p + rng.randint(1, 40)] or "A"
+        base = base[:p] + unit * rng.randint(3, 200) + base[p:]
+    if rng.random() < 0.3:      # an N run
+        p = rng.randint(0, len(base) - 1)
+        base = base[:p] + "N" * rng.randint(1, 400) + base[p:]
+    snp = rng.choice([0.0, 0.001, 0.01, 0.05])
+    indel = rng.choice([0.0, 0.0, 0.0005, 0.003])
+    seqs = [base] + [mutate(rng, base, snp, indel) for _ in range(ns - 1)]
+    if rng.random() < 0.2:      # identical copy
+        seqs[-1] = seqs[0]
+    return seqs, rng.choice([10, 20, 20, 30])
+
+
+def digest(tr):
+    o = np.lexsort((tr["key"], tr["depth"]))
+    return {f: tr[f][o].astype(np.uint64) for f in FIELDS}
+
+
+def anchors_set(a):
+    if len(a) == 4:
+        l, n, off, pos = a
+    else:
+        l, off, pos = a
+    return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+
+
+def main():
+    budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
+    rng = random.Random(seed)
+    t_end = time.time() + budget
+    ncase = 0
+    while time.time() < t_end:
+        seqs, minl = make_case(rng)
+        sa64 = rng.random() < 0.2
+        T, nsep, nodes = assemble(seqs)
+        O = oracle(sa64)
+        c = O.construct(T, nsep, len(seqs))
+        sa_ref, lcp_ref = c["SA"].copy(), c["LCP"].copy()
+        ref = O.align_bench(c, nodes, minl, 2, trace_cap=4 * len(T) // max(minl, 1) + 1000)
+        rd, ra = digest(ref["trace"]), anchors_set(ref["anchors"])
+        for env in ENVS:
+            for k in list(os.environ):
+                if k.startswith("RV_"):
+                    del os.environ[k]
+            os.environ.update(env)
+            for trace in (True, False):
+                idx = feed((reveallib64 if sa64 else reveallib).index(), seqs)
+                idx.construct()
+                tag = "seed %d case %d env %s trace %s sa64 %s (L %d, %d samples, minl %d)" % (seed, ncase, env, trace, sa64, len(seqs[0]), len(seqs), minl)
+                assert np.array_equal(idx.array("SA"), sa_ref), "SA " + tag
+                assert np.array_equal(idx.array("LCP"), lcp_ref), "LCP " + tag
+                got = idx.align_builtin(minl, 2, trace=trace)
+                assert anchors_set(got["anchors"]) == ra, "anchors " + tag
+                assert idx.T.encode("latin-1") == ref["T"], "text " + tag
+                if trace:
+                    gd = digest(got["trace"])
+                    for f in FIELDS:
+                        assert len(gd[f]) == len(rd[f]) and (gd[f] == rd[f]).all(), "trace field %s %s" % (f, tag)
+        ncase += 1
+    print("fuzz: %d cases x %d configurations x 2 (traced / untraced) identical to the oracle (seed %d)" % (ncase, len(ENVS), seed))
+
+
+if __name__ == "__main__":
+    main()

@@ -16,6 +16,7 @@
 #include "rv_index.h"
 #include "rv_split.h"
 #include "rv_decide.h"
+static_assert(RV_TSUB_TILE == RV_SPLIT_TILE, "one tile -> sub-index table serves the split passes and the multi-sample picker");
 #include "rv_leaf.h"
 #include <string.h>
 #include <algorithm>

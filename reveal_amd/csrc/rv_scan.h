@@ -2,9 +2,8 @@
 #pragma once
 #include "rv_common.h"
 
-#ifndef RV_PAIR_TILE
-#define RV_PAIR_TILE 2048
-#endif
+#define RV_PAIR_TILE 512     // ranks per tile of the pair scan = what one wave scans
+#define RV_TSUB_TILE 2048    // granularity of the tile -> sub-index tables the host ships (== RV_SPLIT_TILE)
 
 // one pairwise MUM: a < b text positions, l = LCP[rank], rank inside the
 // scanned (concatenated) array
@@ -14,9 +13,9 @@ struct RvPairRec {
     u32  rank;
 };
 
-#define RV_PAIR_SLOTS 32
+#define RV_PAIR_SLOTS 8
 // Streams SA/LCP/BWT[0..m) once.  The first RV_PAIR_SLOTS survivors of tile t
-// (2048 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
+// (512 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
 // ovf[tileovf[t] ..] (*ovf_counter must be zero: rv_pair_compact_launch leaves it so);
 // tilecnt[t] = number of survivors, tilecnt[ntile] = 0.  rv_pair_compact_launch packs them densely in rank order given
 // tileoff = exclusive scan of tilecnt.
@@ -48,6 +47,6 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 // *cand_count > cand_cap afterwards: the candidate list was too small, grow and rerun.
 struct RvMultiCand;
 int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
-                         const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub /* sub-index of rank t * RV_PAIR_TILE */,
+                         const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub /* sub-index of rank t * RV_TSUB_TILE */,
                          unsigned long long *best, u32 *pick_l, sa_t *pick_pos, RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
 #define RV_MULTI_CAND_BYTES 16

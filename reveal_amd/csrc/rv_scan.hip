@@ -19,8 +19,9 @@
 namespace {
 
 constexpr int TB = 256;
-constexpr int PAIR_ITEMS = RV_PAIR_TILE / 256;
-constexpr int PAIR_TILE = TB * PAIR_ITEMS;   // == RV_PAIR_TILE
+constexpr int PAIR_ITEMS = RV_PAIR_TILE / 64;   // ranks per lane; a tile (RV_PAIR_TILE ranks) is what one wave scans
+constexpr int PAIR_TILE = TB * PAIR_ITEMS;      // ranks per workgroup
+__device__ inline int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 
@@ -47,14 +48,12 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
                                                   RvPairRec *__restrict__ slots, RvPairRec *__restrict__ ovf, u32 ovf_cap,
                                                   u32 *__restrict__ ovf_counter, u32 *__restrict__ tilecnt, u32 *__restrict__ tileovf,
                                                   unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks, int nsubs) {
-    __shared__ u32 wsum[TB / 64];
-    __shared__ u32 s_base;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // one 2048-rank tile per block (persistent blocks walking several tiles measured 25 % slower: the
+    // one 2048-rank stretch per block (persistent blocks walking several tiles measured 25 % slower: the
     // block-wide append at the end of a tile then no longer overlaps with another block's loads)
     const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_ITEMS;
-    if (blockIdx.x == 0 && threadIdx.x == 0) tilecnt[gridDim.x] = 0;      // the slot that makes the exclusive scan yield the total
+    if (blockIdx.x == 0 && threadIdx.x == 0) tilecnt[ceil_div_dev(m, RV_PAIR_TILE)] = 0;      // the slot that makes the exclusive scan yield the total
     // tables of the device-side picker that runs right behind this kernel (k_pick_slots1/2), nsubs = 0 otherwise
     for (int64_t s2 = (int64_t)blockIdx.x * TB + threadIdx.x; s2 < nsubs; s2 += (int64_t)gridDim.x * TB) { best[s2] = 0; picks[RV_PAIR_HDR + s2].rank = 0xFFFFFFFFu; }
 
@@ -131,30 +130,27 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         hit |= (u32)ok << k;
         side_prev = side;
     }
-    // order-preserving append of this tile's survivors
+    // order-preserving append of the survivors.  A tile is what one wave scans (512 ranks): no workgroup barrier, a wave
+    // retires as soon as its own loads are consumed.
     const u32 mine = __popc(hit);
     u32 inc = mine;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) wsum[w] = inc;
-    __syncthreads();
-    u32 before = 0, tot = 0;
-#pragma unroll
-    for (int k = 0; k < TB / 64; k++) { const u32 c = wsum[k]; if (k < w) before += c; tot += c; }
-    // The first RV_PAIR_SLOTS survivors of a tile go to the tile's own slots (no
-    // atomics at all in the common case); only a tile with more takes one atomic
-    // for room in the overflow array.  k_pair_compact then packs everything in
-    // tile (= rank) order.
-    if (threadIdx.x == 0) {
-        u32 base = 0;
+    const u32 tot = (u32)__shfl((int)inc, 63, 64);
+    const int64_t wtile = tile * (TB / 64) + w;
+    if (wfirst >= m) return;                     // (a wave entirely past the end)
+    // The first RV_PAIR_SLOTS survivors of a tile go to the tile's own slots (no atomics at all in the common case); only a
+    // tile with more takes one atomic for room in the overflow array.  k_pair_compact / k_pick_slots read them in tile
+    // (= rank) order.
+    u32 base = 0;
+    if (lane == 0) {
         if (tot > RV_PAIR_SLOTS) base = atomicAdd(ovf_counter, tot - RV_PAIR_SLOTS);
-        s_base = base;
-        tilecnt[tile] = tot;
-        tileovf[tile] = base;
+        tilecnt[wtile] = tot;
+        tileovf[wtile] = base;
     }
-    __syncthreads();
+    base = (u32)__shfl((int)base, 0, 64);
     if (mine) {
-        u32 q = before + (inc - mine);          // index inside the tile
+        u32 q = inc - mine;                      // index inside the tile
 #pragma unroll
         for (int k = 0; k < PAIR_ITEMS; k++) {
             if (hit & (1u << k)) {
@@ -164,8 +160,8 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
                 r.b = s1 < s0 ? s0 : s1;
                 r.l = (u32)lc[k];
                 r.rank = (u32)(i0 + k);
-                if (q < RV_PAIR_SLOTS) slots[(size_t)tile * RV_PAIR_SLOTS + q] = r;
-                else { const u32 o = s_base + (q - RV_PAIR_SLOTS); if (o < ovf_cap) ovf[o] = r; }
+                if (q < RV_PAIR_SLOTS) slots[(size_t)wtile * RV_PAIR_SLOTS + q] = r;
+                else { const u32 o = base + (q - RV_PAIR_SLOTS); if (o < ovf_cap) ovf[o] = r; }
                 q++;
             }
         }
@@ -405,7 +401,7 @@ __global__ __launch_bounds__(TB) void k_multi_pick1(const sa_t *__restrict__ SA,
     int s = 0; int64_t lb = 0; u32 l = 0;
     if (ok) {
         // owning sub-index: from the host's table for the 2048-rank tile of u, then a few steps forward
-        s = tile_sub[u / RV_PAIR_TILE];
+        s = tile_sub[u / RV_TSUB_TILE];
         int64_t s_end = sub_start[s + 1];
         for (int step = 0; u >= s_end && step < 8; step++) { s++; s_end = sub_start[s + 1]; }
         if (u >= s_end) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity soak: the GPU recursion (traced and untraced, default and forced code paths) against the CPU oracle
 on random inputs -- SNPs, indels, tandem repeats, N runs, several contigs, 2-4 samples.  Test infrastructure.
-usage: python tools/fuzz.py [seconds] [seed]"""
+usage: python tools/fuzz.py [seconds] [seed]      (FUZZ_BIG=1 adds inputs of 1 and 2.5 Mbp per sample)"""
 import os
 import random
 import sys
@@ -45,7 +45,7 @@ def mutate(rng, base, snp, indel):
 
 
 def make_case(rng):
-    L = rng.choice([300, 2000, 20000, 80000, 250000])
+    L = rng.choice([300, 2000, 20000, 80000, 250000] + ([1000000, 2500000] if os.environ.get("FUZZ_BIG") else []))
     ns = rng.choice([2, 2, 2, 3, 4])
     base = "".join(rng.choice("ACGT") for _ in range(L))
     if rng.random() < 0.4:      # tandem repeats / low complexity

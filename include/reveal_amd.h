@@ -148,6 +148,37 @@ typedef struct {
     double  t_scan, t_host, t_split, t_bubble;   /* seconds, host clock */
 } rv_align_stats;
 int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *st);
+
+/* ---- one alignment over several devices: frontier hand-off -------------------
+ * No counterpart in the reference's API: it is the work-queue reading of its own
+ * recursion (reveal.c:21-25 stack, :731-1338 aligner threads popping independent
+ * sub-indices; children of a split cover disjoint text and disjoint ranges of the
+ * shared SAi, reveal.c:597-630, and are pushed after their parent's lower-casing,
+ * :1230-1234 before :1296).  SURVEY.md 8(e), second granularity.
+ *   owner :  rv_align_builtin_until(stop_subs) -> frontier of >= stop_subs sub-indices
+ *            rv_frontier_counts / rv_frontier_export -> metadata
+ *            rv_frontier_pack(subset) -> SA / LCP / BWT segments of a subset (9 B/rank,
+ *            13 B in the 64-bit library), into device memory (peer / RCCL send) or host memory
+ *            rv_frontier_import(own subset) ; rv_align_builtin_resume
+ *   worker:  rv_new, rv_add_sample / rv_add_sequence (same text, no construct)
+ *            rv_frontier_import(received subset) ; rv_align_builtin_resume
+ * The union of all handles' anchors (rv_fetch_anchors) is the anchor set of the
+ * undivided run; the lower-cased text is the pristine text with every anchor's
+ * members lower-cased. */
+/* returns the frontier size (0: the run finished before reaching stop_subs and has been collected), < 0 on error */
+int rv_align_builtin_until(rv_index *h, int minl, int minn, int stop_subs, rv_align_stats *st);
+int rv_align_builtin_resume(rv_index *h, rv_align_stats *st);
+/* out[0..3] = sub-indices, ranks, intervals of the frontier, level */
+int rv_frontier_counts(rv_index *h, int64_t *out);
+/* meta: 6 per sub-index (offset, n, depth, nsamples, kind, parent); node_first: nsubs+1; nodes: (begin,end) pairs */
+int rv_frontier_export(rv_index *h, int64_t *meta, int64_t *node_first, int64_t *nodes);
+/* segments of the listed sub-indices back to back -> caller memory; returns the ranks written */
+int64_t rv_frontier_pack(rv_index *h, const int32_t *subs, int k, void *sa, void *lcp, void *bwt, int on_device);
+int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int level, int nsubs, const int64_t *meta,
+                       const int64_t *node_first, const int64_t *nodes, int64_t m,
+                       const void *sa, const void *lcp, const void *bwt, int on_device);
+/* largest LCP value of the constructed index (= window of bubble_sort, reveal.c:666-727; workers need the owner's) */
+uint32_t rv_maxlcp(const rv_index *h);
 /* anchors chosen by the last rv_align_builtin: l[k], members off[k..k+1] -> pos[] (sorted) */
 int64_t rv_anchor_count(rv_index *h, int64_t *members);
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);

@@ -322,6 +322,10 @@ def make_index_type(sa64, error):
             st = _lib.RvAlignStats()
             if dll.rv_align_builtin(h, int(minl), int(minn), ctypes.byref(st)) != 0:
                 self._fail()
+            return self._builtin_result(st, trace)
+
+        def _builtin_result(self, st, trace):
+            dll, h = self._dll, self._h
             mem = ctypes.c_int64(0)
             na = dll.rv_anchor_count(h, ctypes.byref(mem))
             l = np.zeros(max(na, 1), dtype=np.uint32); off = np.zeros(na + 1, dtype=np.int64)
@@ -338,6 +342,71 @@ def make_index_type(sa64, error):
             stats = {f[0]: getattr(st, f[0]) for f in _lib.RvAlignStats._fields_}
             return dict(stats=stats, anchors=(l[:na], off, pos[:mem.value]), trace=tr)
 
+        # ---- one alignment over several devices (include/reveal_amd.h "frontier hand-off"; reveal_amd/shard.py drives it)
+        @property
+        def maxlcp(self):
+            return int(self._dll.rv_maxlcp(self._h))
+
+        def align_builtin_until(self, stop_subs, minl=20, minn=2, trace=False):
+            """align_builtin that stops once the frontier holds >= stop_subs sub-indices.
+            -> frontier size (0: the run finished first; align_builtin_resume() still returns its result)"""
+            if not self._constructed:
+                raise error("Index not yet constructed, alignment stopped.")
+            self._dll.rv_set_trace(self._h, 1 if trace else 0)
+            self._st = _lib.RvAlignStats()
+            self._trace = bool(trace)
+            r = self._dll.rv_align_builtin_until(self._h, int(minl), int(minn), int(stop_subs), ctypes.byref(self._st))
+            if r < 0:
+                self._fail()
+            self._pending = r > 0
+            return r
+
+        def frontier(self):
+            """-> dict(level, m, meta[nsubs,6] = (offset, n, depth, nsamples, kind, parent), node_first[nsubs+1], nodes[nnodes,2])"""
+            c = np.zeros(4, dtype=np.int64)
+            if self._dll.rv_frontier_counts(self._h, c.ctypes.data) != 0:
+                self._fail()
+            ns, m, nn, level = (int(x) for x in c)
+            meta = np.zeros((max(ns, 1), 6), dtype=np.int64); nf = np.zeros(ns + 1, dtype=np.int64); nodes = np.zeros((max(nn, 1), 2), dtype=np.int64)
+            if self._dll.rv_frontier_export(self._h, meta.ctypes.data, nf.ctypes.data, nodes.ctypes.data) != 0:
+                self._fail()
+            return dict(level=level, m=m, meta=meta[:ns], node_first=nf, nodes=nodes[:nn])
+
+        def frontier_pack(self, subs, sa, lcp, bwt):
+            """segments of the sub-indices `subs` back to back into sa / lcp / bwt: numpy arrays (host) or torch
+            tensors of this device (dtype = the library's SA / LCP types, uint8); -> ranks written"""
+            subs = np.ascontiguousarray(subs, dtype=np.int32)
+            ptr, dev = _pointers(sa, lcp, bwt)
+            r = self._dll.rv_frontier_pack(self._h, subs.ctypes.data, len(subs), ptr[0], ptr[1], ptr[2], dev)
+            if r < 0:
+                self._fail()
+            return int(r)
+
+        def frontier_import(self, part, sa, lcp, bwt, minl=20, minn=2, maxlcp=None, trace=False):
+            """make `part` (a subset of a frontier() dict: level, meta, node_first, nodes) with its packed segments the
+            frontier of this index.  An index that only holds its samples (no construct) becomes a worker."""
+            meta = np.ascontiguousarray(part["meta"], dtype=np.int64).reshape(-1, 6)
+            nf = np.ascontiguousarray(part["node_first"], dtype=np.int64); nodes = np.ascontiguousarray(part["nodes"], dtype=np.int64).reshape(-1, 2)
+            m = int(meta[:, 1].sum()) if len(meta) else 0
+            ptr, dev = _pointers(sa, lcp, bwt)
+            if not getattr(self, "_pending", False):
+                self._dll.rv_set_trace(self._h, 1 if trace else 0)
+                self._st = _lib.RvAlignStats()
+                self._trace = bool(trace)
+            ml = self.maxlcp if maxlcp is None else int(maxlcp)
+            if self._dll.rv_frontier_import(self._h, int(minl), int(minn), ml, int(part.get("level", 1)), len(meta), meta.ctypes.data, nf.ctypes.data,
+                                            nodes.ctypes.data, m, ptr[0], ptr[1], ptr[2], dev) != 0:
+                self._fail()
+            self._pending = True
+
+        def align_builtin_resume(self):
+            """finish the run started by align_builtin_until / frontier_import; result as align_builtin"""
+            if getattr(self, "_pending", False):
+                if self._dll.rv_align_builtin_resume(self._h, ctypes.byref(self._st)) != 0:
+                    self._fail()
+            self._pending = False
+            return self._builtin_result(self._st, self._trace)
+
         def _fetch_sub_mums(self, s, info):
             cnt, mem = info.nmums, info.nmembers
             l = np.zeros(max(cnt, 1), dtype=np.uint32); n = np.zeros(max(cnt, 1), dtype=np.int32)
@@ -353,6 +422,25 @@ def make_index_type(sa64, error):
     index.__name__ = "index"
     index.__qualname__ = "index"
     return index
+
+
+def _pointers(*bufs):
+    """addresses of numpy arrays or torch tensors, and whether they are device memory"""
+    ptr, dev = [], None
+    for b in bufs:
+        on_dev = bool(getattr(b, "is_cuda", False))
+        if dev is not None and on_dev != dev:
+            raise ValueError("sa, lcp and bwt must live in the same kind of memory")
+        dev = on_dev
+        if hasattr(b, "data_ptr"):
+            if not b.is_contiguous():
+                raise ValueError("contiguous buffers needed")
+            ptr.append(b.data_ptr())
+        else:
+            if not b.flags["C_CONTIGUOUS"]:
+                raise ValueError("contiguous buffers needed")
+            ptr.append(b.ctypes.data)
+    return ptr, 1 if dev else 0
 
 
 def _csr_to_tuples(cnt, l, n, off, so, pos):

@@ -6,7 +6,9 @@ One `Lib` per index width, mirroring the reference's two extension modules
 an ImportError, a missing gfx950 device makes rv_new() fail.
 """
 import ctypes
+import importlib.util
 import os
+import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -68,6 +70,13 @@ SYMBOLS = {
     "rv_frontier_commit": (_I, [V, V]),
     "rv_align_end": (_I, [V]),
     "rv_align_builtin": (_I, [V, _I, _I, ctypes.POINTER(RvAlignStats)]),
+    "rv_align_builtin_until": (_I, [V, _I, _I, _I, ctypes.POINTER(RvAlignStats)]),
+    "rv_align_builtin_resume": (_I, [V, ctypes.POINTER(RvAlignStats)]),
+    "rv_frontier_counts": (_I, [V, V]),
+    "rv_frontier_export": (_I, [V, V, V, V]),
+    "rv_frontier_pack": (_L, [V, V, _I, V, V, V, _I]),
+    "rv_frontier_import": (_I, [V, _I, _I, ctypes.c_uint32, _I, _I, V, V, V, _L, V, V, V, _I]),
+    "rv_maxlcp": (ctypes.c_uint32, [V]),
     "rv_anchor_count": (_L, [V, c_i64p]),
     "rv_fetch_anchors": (_I, [V, V, V, V]),
     "rv_set_trace": (_I, [V, _I]),
@@ -83,9 +92,29 @@ SYMBOLS = {
 }
 
 
+def _share_torch_runtime():
+    """PyTorch-ROCm wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's, different file).  Two HIP
+    runtimes in one process do not both get the GPU: whichever starts second reports "no HIP GPUs", and device pointers
+    of one mean nothing to the other.  The hand-off of reveal_amd/shard.py passes torch device tensors (RCCL send/recv)
+    to this library, so when torch is installed its copy is loaded first and the library binds to it, whatever the
+    import order.  RV_SYSTEM_HIP=1 keeps the system runtime (then import torch before reveal_amd, or not at all)."""
+    if os.environ.get("RV_SYSTEM_HIP") or "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+
+
 class Lib:
     def __init__(self, sa64=False):
         self.sa64 = sa64
+        _share_torch_runtime()
         name = "libreveal_amd64.so" if sa64 else "libreveal_amd.so"
         self.path = os.path.join(_HERE, name)
         if not os.path.exists(self.path):

@@ -173,6 +173,10 @@ struct Align {
     std::vector<rv_trace> trace;
     rv_align_stats st{};
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
+    // rv_align_builtin split into set-up / levels / collection, so that a frontier can be handed to other devices in between
+    int leaf_flip = 0;
+    bool running = false;        // a built-in run is between its set-up and its collection
+    u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
@@ -555,6 +559,45 @@ int rv_sub_split(rv_index *h, int s, uint32_t l, int nsp, const int64_t *sp,
     return add_decision(h, s, l, sp, nsp, (const RvIntv *)lead, nlead, (const RvIntv *)trail, ntrail, (const RvIntv *)match, nmatch, (const RvIntv *)rest, nrest);
 }
 
+// Tables the scan and the device-side decisions of a level need; the commit in front of the level ships them with its own
+// upload (a frontier import ships them itself): sub-index starts, and
+//  - more than two samples: tile -> sub-index table (the multi-sample picker looks sub-indices up per candidate)
+//  - two samples, untraced: the level's split can be decided on the device if each of its sub-indices owns at most one
+//    interval per sample (rv_decide.hip): node intervals, "finished by the leaf kernel" flags, tiles.
+static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next) {
+    Align *a = h->al;
+    const int nsn = nx.size();
+    a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
+    a->next_dev_ok = !a->multi && a->full_only && nsn > 0 && nsn <= RV_DECIDE_MAX_SUBS && m_next > 0;
+    if (a->next_dev_ok) {
+        a->next_nodes.assign((size_t)nsn * 4, 0); a->next_flags.assign((size_t)nsn, 0);
+        const int64_t sep = h->nsep[0];
+        for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
+            const int64_t nf = nx.node_first[(size_t)s2], nn = nx.node_first[(size_t)s2 + 1] - nf;
+            if (nn < 1 || nn > 2) { a->next_dev_ok = false; break; }
+            sa_t *nd = a->next_nodes.data() + (size_t)s2 * 4;
+            for (int64_t k = 0; k < nn; k++) {
+                const RvIntv iv = nx.nodes[(size_t)(nf + k)];
+                if (iv.begin < sep) { if (nd[0] < nd[1]) a->next_dev_ok = false; nd[0] = (sa_t)iv.begin; nd[1] = (sa_t)iv.end; }
+                else if (iv.begin > sep) { if (nd[2] < nd[3]) a->next_dev_ok = false; nd[2] = (sa_t)iv.begin; nd[3] = (sa_t)iv.end; }
+                else a->next_dev_ok = false;
+            }
+            // the leaf kernel takes every sub-index of at most RV_LEAF_N ranks here (same rule as builtin_levels)
+            a->next_flags[(size_t)s2] = (a->use_leaf && nx.n[(size_t)s2] <= RV_LEAF_N) ? 1 : 0;
+        }
+    }
+    if (a->multi || a->next_dev_ok) {
+        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
+        a->next_tsub.resize((size_t)ntn);
+        int s2 = 0;
+        for (int64_t t = 0; t < ntn; t++) {
+            const int64_t r = t * RV_SPLIT_TILE;
+            while (s2 + 1 < nsn && a->next_ss[(size_t)s2 + 1] <= r) s2++;
+            a->next_tsub[(size_t)t] = s2;
+        }
+    }
+}
+
 /* reveal.c:1005-1252 for every decided sub-index; children -> next frontier */
 int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_TRY(need_align(h));
@@ -741,54 +784,10 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         if (a->kids_lds.size() <= 512) { lds_count[2] = (int)a->kids_lds.size(); lds_count[0] = lds_count[1] = 0; }
     }
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big), o_kl = pk.addv(a->kids_lds);
-    a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
-    size_t o_ntsub = 0;
-    if (a->multi) {       // tile -> sub-index table of the next level (the multi-sample picker looks sub-indices up per candidate)
-        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
-        a->next_tsub.resize((size_t)ntn);
-        int s2 = 0;
-        const int nsn = nx.size();
-        for (int64_t t = 0; t < ntn; t++) {
-            const int64_t r = t * RV_SPLIT_TILE;
-            while (s2 + 1 < nsn && a->next_ss[(size_t)s2 + 1] <= r) s2++;
-            a->next_tsub[(size_t)t] = s2;
-        }
-        o_ntsub = pk.addv(a->next_tsub);
-    }
-    // two samples, untraced: the next level's split can be decided on the device if each of its sub-indices owns at most one
-    // interval per sample (rv_decide.hip).  Ship what that needs: node intervals, "finished by the leaf kernel" flags, tiles.
-    size_t o_nnodes = 0, o_nflags = 0, o_ntsub2 = 0;
-    a->next_dev_ok = !a->multi && a->full_only && nx.size() > 0 && nx.size() <= RV_DECIDE_MAX_SUBS && m_next > 0;
-    if (a->next_dev_ok) {
-        const int nsn = nx.size();
-        a->next_nodes.assign((size_t)nsn * 4, 0); a->next_flags.assign((size_t)nsn, 0);
-        const int64_t sep = h->nsep[0];
-        for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
-            const int64_t nf = nx.node_first[(size_t)s2], nn = nx.node_first[(size_t)s2 + 1] - nf;
-            if (nn < 1 || nn > 2) { a->next_dev_ok = false; break; }
-            sa_t *nd = a->next_nodes.data() + (size_t)s2 * 4;
-            for (int64_t k = 0; k < nn; k++) {
-                const RvIntv iv = nx.nodes[(size_t)(nf + k)];
-                if (iv.begin < sep) { if (nd[0] < nd[1]) a->next_dev_ok = false; nd[0] = (sa_t)iv.begin; nd[1] = (sa_t)iv.end; }
-                else if (iv.begin > sep) { if (nd[2] < nd[3]) a->next_dev_ok = false; nd[2] = (sa_t)iv.begin; nd[3] = (sa_t)iv.end; }
-                else a->next_dev_ok = false;
-            }
-            // the leaf kernel takes every sub-index of at most RV_LEAF_N ranks here (same rule as rv_align_builtin)
-            a->next_flags[(size_t)s2] = (a->use_leaf && nx.n[(size_t)s2] <= RV_LEAF_N) ? 1 : 0;
-        }
-    }
-    if (a->next_dev_ok) {
-        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
-        a->next_tsub.resize((size_t)ntn);
-        int s2 = 0;
-        const int nsn = nx.size();
-        for (int64_t t = 0; t < ntn; t++) {
-            const int64_t r = t * RV_SPLIT_TILE;
-            while (s2 + 1 < nsn && a->next_ss[(size_t)s2 + 1] <= r) s2++;
-            a->next_tsub[(size_t)t] = s2;
-        }
-        o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = pk.addv(a->next_tsub);
-    }
+    prep_level_tables(h, nx, m_next);
+    size_t o_ntsub = 0, o_nnodes = 0, o_nflags = 0, o_ntsub2 = 0;
+    if (a->multi) o_ntsub = pk.addv(a->next_tsub);
+    if (a->next_dev_ok) { o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = pk.addv(a->next_tsub); }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
     u32 class_total[4] = {0, 0, 0, 0};
@@ -946,16 +945,38 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
 }
 
 /* ---- the whole recursion with the built-in benchmark callbacks ------------------- */
-int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
+// output buffers of the leaf kernel (two samples only): sub-indices of at most RV_LEAF_N ranks finish on the GPU in one launch per level
+static int builtin_leaf_setup(rv_index *h) {
+    Align *a = h->al;
+    hipStream_t q = h->ws.stream;
+    a->use_leaf = !a->multi && !getenv("RV_NO_LEAF");
+    a->leaf_flip = 0;
+    if (!a->use_leaf) return 0;
+    a->leaf_anchor_cap = (size_t)(h->nT / std::max(a->minl, 1)) + 1024;
+    a->leaf_trace_cap = a->trace_on ? 2 * a->leaf_anchor_cap + 1024 : 0;
+    const size_t bytes = 256 + a->leaf_anchor_cap * (4 + 8 + 8) + a->leaf_trace_cap * sizeof(rv_trace) + 64;
+    RV_TRY(a->dLeaf.reserve(bytes));
+    uint8_t *base = a->dLeaf.as<uint8_t>();
+    a->lf_counters = (u32 *)base;                          // [0] anchors, [1] trace records, [2] error bits
+    a->lf_stats = (unsigned long long *)(base + 64);
+    a->lf_a = (int64_t *)(base + 256); a->lf_b = a->lf_a + a->leaf_anchor_cap; a->lf_l = (u32 *)(a->lf_b + a->leaf_anchor_cap);
+    a->lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
+    RV_HIP(hipMemsetAsync(base, 0, 256, q));
+    if (!a->leaf_stream) {
+        RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
+        RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) { RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming)); RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming)); }
+    }
+    a->leaf_pending[0] = a->leaf_pending[1] = false;
+    a->roots_inflight[0] = a->roots_inflight[1] = false;
+    return 0;
+}
+
+static int builtin_setup(rv_index *h, int minl, int minn) {
     RV_TRY(rv_align_begin(h, minl, minn));
     Align *a = h->al;
     a->full_only = !a->trace_on;
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
-    std::vector<sa_t> hsa; std::vector<lcp_t> hlcp;
-    std::vector<int64_t> sp;
-    std::vector<RvIntv> lead, trail, match, rest;
-    std::vector<uint8_t> touched;
-    // ---- leaf kernel set-up (two samples only): sub-indices of at most RV_LEAF_N ranks finish on the GPU in one launch per level
     const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
     a->use_leaf = use_leaf;
     // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
@@ -984,30 +1005,26 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
             a->cur_dev_ok = true;
         }
     }
+    RV_TRY(builtin_leaf_setup(h));
+    a->running = true;
+    return 0;
+}
+
+// levels of the recursion until the frontier is empty, or (stop_subs > 0) until it holds at least stop_subs sub-indices
+static int builtin_levels(rv_index *h, int stop_subs) {
+    Align *a = h->al;
+    const int minl = a->minl;
+    std::vector<sa_t> hsa; std::vector<lcp_t> hlcp;
+    std::vector<int64_t> sp;
+    std::vector<RvIntv> lead, trail, match, rest;
+    std::vector<uint8_t> touched;
+    const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
-    u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
-    if (use_leaf) {
-        a->leaf_anchor_cap = (size_t)(h->nT / std::max(minl, 1)) + 1024;
-        a->leaf_trace_cap = a->trace_on ? 2 * a->leaf_anchor_cap + 1024 : 0;
-        const size_t bytes = 256 + a->leaf_anchor_cap * (4 + 8 + 8) + a->leaf_trace_cap * sizeof(rv_trace) + 64;
-        RV_TRY(a->dLeaf.reserve(bytes));
-        uint8_t *base = a->dLeaf.as<uint8_t>();
-        lf_counters = (u32 *)base;                          // [0] anchors, [1] trace records, [2] error bits
-        lf_stats = (unsigned long long *)(base + 64);
-        lf_a = (int64_t *)(base + 256); lf_b = lf_a + a->leaf_anchor_cap; lf_l = (u32 *)(lf_b + a->leaf_anchor_cap);
-        lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
-        RV_HIP(hipMemsetAsync(base, 0, 256, q));
-        if (!a->leaf_stream) {
-            RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
-            RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
-            for (int k = 0; k < 2; k++) { RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming)); RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming)); }
-        }
-        a->leaf_pending[0] = a->leaf_pending[1] = false;
-        a->roots_inflight[0] = a->roots_inflight[1] = false;
-    }
-    int leaf_flip = 0;
+    u32 *lf_counters = a->lf_counters; unsigned long long *lf_stats = a->lf_stats; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
+    int &leaf_flip = a->leaf_flip;
     const bool level_log = getenv("RV_LEVEL_LOG") != nullptr;      // diagnostics: per-level wall time (adds a sync per level)
     while (a->lv.size() > 0) {
+        if (stop_subs > 0 && a->level > 0 && a->lv.size() >= stop_subs) break;      // hand-off point (rv_frontier_export)
         const double tl0 = level_log ? now_s() : 0.0;
         const int log_ns = a->lv.size(); const int64_t log_m = a->lv.m; const int log_level = a->level;
         size_t log_leaf = 0;
@@ -1173,7 +1190,23 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
                     (long long)biggest);
         }
     }
-    if (use_leaf) {       // collect what the leaf launches produced
+    // drained, and the deferred error word of the last commit looked at: a hand-off must not export a broken level
+    RV_HIP(hipStreamSynchronize(q));
+    if (a->lv.size() > 0) {
+        u32 err = 0;
+        RV_HIP(hipMemcpy(&err, a->dErr.p, 4, hipMemcpyDeviceToHost));
+        if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+        if (err) { rv_set_error("device-side error %u in the level before the hand-off", err); return -1; }
+    }
+    return 0;
+}
+
+// collect what the leaf launches produced
+static int builtin_finish(rv_index *h, rv_align_stats *out) {
+    Align *a = h->al;
+    hipStream_t q = h->ws.stream;
+    if (a->use_leaf && a->running) {
+        u32 *lf_counters = a->lf_counters; unsigned long long *lf_stats = a->lf_stats; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
         u32 cnt[4]; unsigned long long stv[4];
         RV_HIP(hipStreamSynchronize(a->leaf_stream));
         a->leaf_pending[0] = a->leaf_pending[1] = false;
@@ -1199,9 +1232,172 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
         a->st.steps += (int64_t)stv[0]; a->st.splits += (int64_t)stv[1]; a->st.anchored_bp += (int64_t)stv[2];
         if ((int64_t)stv[3] > a->st.maxdepth) a->st.maxdepth = (int32_t)stv[3];
     }
+    a->running = false;
     if (out) *out = a->st;
     return 0;
 }
+
+int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
+    RV_TRY(builtin_setup(h, minl, minn));
+    RV_TRY(builtin_levels(h, 0));
+    return builtin_finish(h, out);
+}
+
+/* ---- frontier hand-off (second granularity) ---------------------------
+ * After a split the children of a sub-index cover disjoint text and disjoint ranges of the shared inverse, and never
+ * read what a sibling writes (reveal.c:1230-1234 lower-cases before the push at :1296), so the sub-indices of a frontier
+ * are independent units of work.  A built-in run can stop once the frontier is wide enough, hand any subset of its
+ * sub-indices (metadata + their SA / LCP / BWT segments, 9 B per rank) to index handles on other devices that only hold the
+ * text, and every handle finishes its share with the same level loop.  The union of the anchors is the anchor set of the
+ * undivided run; the lower-cased text follows from the anchors.  No collective: segments travel point to point. */
+int rv_align_builtin_until(rv_index *h, int minl, int minn, int stop_subs, rv_align_stats *out) {
+    RV_TRY(builtin_setup(h, minl, minn));
+    RV_TRY(builtin_levels(h, stop_subs));
+    Align *a = h->al;
+    if (a->lv.size() == 0) { RV_TRY(builtin_finish(h, out)); return 0; }
+    if (out) *out = a->st;
+    return a->lv.size();
+}
+
+int rv_align_builtin_resume(rv_index *h, rv_align_stats *out) {
+    RV_TRY(need_align(h));
+    if (!h->al->running) { rv_set_error("no built-in run in progress (rv_align_builtin_until / rv_frontier_import)"); return -1; }
+    RV_HIP(hipSetDevice(h->device));
+    RV_TRY(builtin_levels(h, 0));
+    return builtin_finish(h, out);
+}
+
+int rv_frontier_counts(rv_index *h, int64_t *out) {
+    RV_TRY(need_align(h));
+    const Level &lv = h->al->lv;
+    out[0] = lv.size(); out[1] = lv.size() ? lv.m : 0; out[2] = (int64_t)lv.nodes.size(); out[3] = h->al->level;
+    return 0;
+}
+
+/* meta: 6 numbers per sub-index (off, n, depth, nsamples, kind, parent); node_first: nsubs+1; nodes: (begin, end) pairs */
+int rv_frontier_export(rv_index *h, int64_t *meta, int64_t *node_first, int64_t *nodes) {
+    RV_TRY(need_align(h));
+    const Level &lv = h->al->lv;
+    for (int s = 0; s < lv.size(); s++) {
+        int64_t *m6 = meta + 6 * (size_t)s;
+        m6[0] = lv.off[(size_t)s]; m6[1] = lv.n[(size_t)s]; m6[2] = lv.depth[(size_t)s]; m6[3] = lv.nsamples[(size_t)s]; m6[4] = lv.kind[(size_t)s]; m6[5] = lv.parent[(size_t)s];
+    }
+    for (size_t k = 0; k < lv.node_first.size(); k++) node_first[k] = lv.node_first[k];
+    for (size_t k = 0; k < lv.nodes.size(); k++) { nodes[2 * k] = lv.nodes[k].begin; nodes[2 * k + 1] = lv.nodes[k].end; }
+    return 0;
+}
+
+/* rank segments of the listed sub-indices, back to back in list order, into caller memory (device or host) */
+int64_t rv_frontier_pack(rv_index *h, const int32_t *subs, int k, void *sa, void *lcp, void *bwt, int on_device) {
+    if (need_align(h)) return -1;
+    Align *a = h->al;
+    if (hipSetDevice(h->device) != hipSuccess) { rv_set_error("hipSetDevice failed"); return -1; }
+    hipStream_t q = h->ws.stream;
+    const Level &lv = a->lv;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    int64_t at = 0;
+    for (int i = 0; i < k;) {
+        if (subs[i] < 0 || subs[i] >= lv.size()) { rv_set_error("sub-index %d out of range", (int)subs[i]); return -1; }
+        int j = i;       // neighbours in the level arrays leave as one copy
+        int64_t cnt = lv.n[(size_t)subs[i]];
+        while (j + 1 < k && subs[j + 1] == subs[j] + 1) { j++; cnt += lv.n[(size_t)subs[j]]; }
+        const int64_t off = lv.off[(size_t)subs[i]];
+        hipError_t e = hipMemcpyAsync((sa_t *)sa + at, cur_sa(h) + off, (size_t)cnt * sizeof(sa_t), kind, q);
+        if (e == hipSuccess) e = hipMemcpyAsync((lcp_t *)lcp + at, cur_lcp(h) + off, (size_t)cnt * sizeof(lcp_t), kind, q);
+        if (e == hipSuccess) e = hipMemcpyAsync((uint8_t *)bwt + at, cur_bwt(h) + off, (size_t)cnt, kind, q);
+        if (e != hipSuccess) { rv_set_error("rv_frontier_pack: copy failed: %s", hipGetErrorString(e)); return -1; }
+        at += cnt;
+        i = j + 1;
+    }
+    if (hipStreamSynchronize(q) != hipSuccess) { rv_set_error("rv_frontier_pack: stream failed"); return -1; }
+    return at;
+}
+
+/* Replace the frontier of the handle by the given sub-indices (segments back to back in sa / lcp / bwt, m ranks in all).
+ * A handle with a run in progress keeps its anchors and goes on with the new frontier (the share it keeps for itself);
+ * any other handle only needs its samples (no construct): it becomes a worker that starts at this frontier. */
+int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int level, int nsubs, const int64_t *meta,
+                       const int64_t *node_first, const int64_t *nodes, int64_t m, const void *sa, const void *lcp, const void *bwt, int on_device) {
+    RV_HIP(hipSetDevice(h->device));
+    if (h->nsamples < 2) { rv_set_error("align needs at least two samples"); return -1; }
+    if (nsubs < 0 || m < 0 || m >= ((int64_t)1 << 32)) { rv_set_error("rv_frontier_import: bad sizes"); return -1; }
+    hipStream_t q = h->ws.stream;
+    const bool fresh = !(h->al && h->al->running);
+    if (fresh) {
+        if (!h->constructed || h->main_arrays_freed) RV_TRY(rv_text_only(h, maxlcp));
+        const bool keep_trace = h->al && h->al->trace_on;
+        if (!h->al) h->al = new Align();
+        Align *a = h->al;
+        a->trace_on = keep_trace;
+        a->minl = minl; a->minn = minn;
+        a->multi = h->nsamples > 2;
+        a->scanned = false; a->d_err = nullptr; a->flag_clean = false;
+        a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
+        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+        RV_TRY(a->dErr.reserve(64));
+        memset(&a->st, 0, sizeof a->st);
+        a->full_only = !a->trace_on;
+        a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
+        RV_TRY(builtin_leaf_setup(h));
+    }
+    Align *a = h->al;
+    RV_HIP(hipStreamSynchronize(q));
+    if (a->leaf_stream) RV_HIP(hipStreamSynchronize(a->leaf_stream));      // (a leaf launch may read the level buffers replaced below)
+    a->leaf_pending[0] = a->leaf_pending[1] = false;
+    RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, q));
+    Level &lv = a->lv;
+    lv.clear();
+    int64_t off = 0;
+    for (int s = 0; s < nsubs; s++) {
+        const int64_t *m6 = meta + 6 * (size_t)s;
+        const int64_t nf = node_first[s], nl = node_first[s + 1];
+        if (m6[1] <= 0 || nf > nl) { rv_set_error("rv_frontier_import: bad sub-index %d", s); return -1; }
+        lv.off.push_back(off); lv.n.push_back(m6[1]); lv.depth.push_back((int32_t)m6[2]); lv.nsamples.push_back((int32_t)m6[3]);
+        lv.kind.push_back((int32_t)m6[4]); lv.parent.push_back(-1);
+        for (int64_t k = nf; k < nl; k++) {
+            if (nodes[2 * k] < 0 || nodes[2 * k + 1] > h->nT || nodes[2 * k] > nodes[2 * k + 1]) { rv_set_error("rv_frontier_import: interval outside the text"); return -1; }
+            lv.nodes.push_back({nodes[2 * k], nodes[2 * k + 1]});
+        }
+        lv.node_first.push_back((int64_t)lv.nodes.size());
+        off += m6[1];
+    }
+    if (off != m) { rv_set_error("rv_frontier_import: the sub-index sizes add up to %lld, not %lld", (long long)off, (long long)m); return -1; }
+    lv.m = m;
+    a->nx.clear();
+    a->level = std::max(level, 1);
+    a->cur = 0;
+    RV_TRY(a->lvSA[0].reserve((size_t)(m + 64) * sizeof(sa_t)));
+    RV_TRY(a->lvLCP[0].reserve((size_t)(m + 64) * sizeof(lcp_t)));
+    RV_TRY(a->lvBWT[0].reserve((size_t)m + 64));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (m) {
+        RV_HIP(hipMemcpyAsync(a->lvSA[0].p, sa, (size_t)m * sizeof(sa_t), kind, q));
+        RV_HIP(hipMemcpyAsync(a->lvLCP[0].p, lcp, (size_t)m * sizeof(lcp_t), kind, q));
+        RV_HIP(hipMemcpyAsync(a->lvBWT[0].p, bwt, (size_t)m, kind, q));
+    }
+    // what the commit in front of a level ships for it
+    prep_level_tables(h, lv, m);
+    Packer &pk = a->pk;
+    pk.clear();
+    const size_t o_ss = pk.addv(a->next_ss), o_want = pk.addv(lv.nsamples);
+    size_t o_tsub = 0, o_nodes = 0, o_flags = 0, o_tsub2 = 0;
+    if (a->multi) o_tsub = pk.addv(a->next_tsub);
+    if (a->next_dev_ok) { o_nodes = pk.addv(a->next_nodes); o_flags = pk.addv(a->next_flags); o_tsub2 = pk.addv(a->next_tsub); }
+    RV_TRY(a->dTab0.reserve(pk.size() + 64));
+    if (pk.pageable) RV_HIP(hipMemcpyAsync(a->dTab0.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
+    else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab0.p, pk.size())); }
+    RV_HIP(hipStreamSynchronize(q));
+    const uint8_t *tb = a->dTab0.as<uint8_t>();
+    a->d_next_ss = (const int64_t *)(tb + o_ss); a->d_next_want = (const int *)(tb + o_want); a->d_next_tsub = (const int *)(tb + o_tsub);
+    a->d_next_nodes = (const sa_t *)(tb + o_nodes); a->d_next_flags = tb + o_flags; a->d_next_tsub2 = (const int *)(tb + o_tsub2);
+    a->cur_dev_ok = a->next_dev_ok; a->early_done = false; a->early_bubble = false;
+    a->scanned = false; a->d_err = nullptr;
+    a->dec.reset(lv.size());
+    a->running = true;
+    return 0;
+}
+
+uint32_t rv_maxlcp(const rv_index *h) { return h->maxlcp; }
 
 int64_t rv_anchor_count(rv_index *h, int64_t *members) {
     if (need_align(h)) return -1;

@@ -216,6 +216,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     }
     h->constructed = true;
     h->main_arrays_freed = false;
+    h->text_only = false;
     return 0;
 }
 
@@ -225,7 +226,7 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
     switch (which) {
     case RV_T:
         if (cap < n) { rv_set_error("buffer too small"); return -1; }
-        if (h->constructed) {
+        if (h->constructed || h->text_only) {
             if (hipMemcpy(out, h->dT.p, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) { rv_set_error("D2H failed"); return -1; }
         } else {
             memcpy(out, h->T.data(), (size_t)n);
@@ -267,6 +268,27 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 }
 
 }  // extern "C"
+
+int rv_text_only(rv_index *h, u32 maxlcp) {
+    RV_HIP(hipSetDevice(h->device));
+    if (h->n == 0) { rv_set_error("No text to index."); return -1; }
+    if (h->nsep.empty()) { rv_set_error("a worker index needs at least two samples"); return -1; }
+    const int64_t n = h->n;
+    hipStream_t q = h->ws.stream;
+    h->rc = 0; h->nT = n;
+    RV_TRY(rv_upload(h));
+    RV_TRY(h->dT.reserve((size_t)n + 64));
+    RV_HIP(hipMemcpyAsync(h->dT.p, h->dT0.p, (size_t)n + 64, hipMemcpyDeviceToDevice, q));
+    RV_TRY(h->dSAi.reserve((size_t)(n + 64) * sizeof(sa_t)));      // written by every split in front of its cuts before bubble_sort reads there
+    std::vector<sa_t> ns(h->nsep.size() + 1, 0);
+    for (size_t k = 0; k < h->nsep.size(); k++) ns[k] = (sa_t)h->nsep[k];
+    RV_TRY(h->dNsep.reserve(ns.size() * sizeof(sa_t)));
+    RV_HIP(hipMemcpy(h->dNsep.p, ns.data(), ns.size() * sizeof(sa_t), hipMemcpyHostToDevice));
+    RV_HIP(hipStreamSynchronize(q));
+    h->maxlcp = maxlcp;
+    h->constructed = false; h->main_arrays_freed = true; h->text_only = true;
+    return 0;
+}
 
 // ---------------------------------------------------------------------------
 // pair scan driver: scan kernel -> scan of the tile counts -> compaction ->

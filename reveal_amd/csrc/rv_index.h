@@ -72,6 +72,7 @@ struct rv_index {
     // ---- device state
     DBuf dT, dT0, dSA, dSAi, dLCP, dBWT, dNsep;   // dT0 = pristine text, dT = working copy (lower-cased by align)
     bool text_dirty = true;
+    bool text_only = false;            // a worker of a divided alignment: text and shared inverse in HBM, no main SA / LCP
     HBuf hscan;                        // pinned staging for the scan records
     hipEvent_t ev_picks = nullptr;     // recorded behind the picker kernels: the host waits for this, not for the stream
     size_t scan_guess = 4096;
@@ -91,6 +92,9 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
                      const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs,   // d_sub_start != NULL: only the best record per sub-index
                      int (*after_pick)(rv_index *), bool use_hook);                        // ... and a hook called once the picker kernels are queued
+
+// text, shared inverse and separators in HBM without an index (rv_api.hip); maxlcp = window size of bubble_sort
+int rv_text_only(rv_index *h, u32 maxlcp);
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

@@ -1,0 +1,121 @@
+"""One alignment divided over several index handles (include/reveal_amd.h "frontier hand-off",
+reveal_amd/shard.py; SURVEY.md 8(e) second granularity): the owner stops once its frontier is wide
+enough, shares of the sub-indices go to handles that only hold the text, every handle finishes its
+share.  The union must be what the undivided recursion of the oracle visits: same sub-indices (sizes,
+intervals, SA / LCP hashes, scan results, picks), same anchors, same lower-cased text."""
+import numpy as np
+import pytest
+
+from helpers import assemble, fa, feed, synth
+from reveal_amd import shard
+from test_gpu_align import FIELDS, mod, oracle_run
+
+pytestmark = pytest.mark.gpu
+
+
+def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, device_buffers=False):
+    M = mod(sa64)
+    owner = feed(M.index(), inputs)
+    owner.construct()
+    lib = owner._lib
+    left = owner.align_builtin_until(stop_subs, minl, minn, trace=trace)
+    results, shares = [], []
+    if left > 0:
+        fr = owner.frontier()
+        assert len(fr["meta"]) == left >= stop_subs
+        parts = shard.partition(fr["meta"][:, 1], nparts)
+        packed = []
+        for subs in parts:
+            part = shard.subset(fr, subs)
+            m = int(part["meta"][:, 1].sum())
+            if device_buffers:
+                bufs = shard._buffers(lib, m, "cuda:0")
+            else:
+                bufs = (np.zeros(max(m, 1), lib.sa_t), np.zeros(max(m, 1), lib.lcp_t), np.zeros(max(m, 1), np.uint8))
+            assert owner.frontier_pack(subs, *bufs) == m
+            packed.append((part, bufs))
+            shares.append(m)
+        assert sum(shares) == fr["m"]
+        owner.frontier_import(packed[0][0], *packed[0][1], minl=minl, minn=minn)
+        for part, bufs in packed[1:]:
+            w = feed(M.index(), inputs)          # a worker: samples only, no construct
+            if len(part["meta"]) == 0:
+                results.append(shard.empty_result(trace))
+                continue
+            w.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=owner.maxlcp, trace=trace)
+            results.append(w.align_builtin_resume())
+    results.insert(0, owner.align_builtin_resume())
+    return shard.merge(results), shares, left
+
+
+def check(inputs, minl=20, minn=2, stop_subs=4, nparts=3, sa64=False, device_buffers=False):
+    ref, T = oracle_run(inputs, minl, minn, sa64)
+    got, shares, left = divided(inputs, minl, minn, stop_subs, nparts, sa64, True, device_buffers)
+    rt, gt = ref["trace"], got["trace"]
+    assert len(rt) == len(gt), (len(rt), len(gt))
+    ro = np.lexsort((rt["key"], rt["depth"])); go = np.lexsort((gt["key"], gt["depth"]))
+    for f in FIELDS:
+        a, b = rt[f][ro].astype(np.uint64), gt[f][go].astype(np.uint64)
+        assert np.array_equal(a, b), "field %s differs at %d of %d sub-indices" % (f, int((a != b).sum()), len(a))
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    gl, goff, gpos = got["anchors"]
+    ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
+    assert ra == ga
+    assert shard.lower_text(T, got["anchors"]).tobytes() == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"]
+    assert got["stats"]["steps"] == ref["stats"]["nsteps"]
+    return shares, left
+
+
+@pytest.mark.parametrize("name,inputs,minl,stop,parts", [
+    ("1a1b", fa("1a", "1b"), 20, 4, 3),
+    ("1a1b_wide", fa("1a", "1b"), 10, 16, 4),
+    ("1e1b", fa("1e", "1b"), 20, 2, 2),
+    ("d1d2_never_wide", fa("d1", "d2"), 20, 1000, 2),      # the run ends before the frontier is that wide
+])
+def test_divided_pair(name, inputs, minl, stop, parts):
+    check(inputs, minl, 2, stop, parts)
+
+
+def test_divided_pair_64bit():
+    check(fa("1a", "1b"), 20, 2, 4, 2, sa64=True)
+
+
+@pytest.mark.parametrize("L,stop,parts", [(200000, 8, 8), (1000000, 32, 4)])
+def test_divided_synthetic_pair(L, stop, parts):
+    seqs = [g.decode() for g in synth.genomes(L, 2)]
+    shares, left = check(seqs, 20, 2, stop, parts)
+    assert left >= stop and len(shares) == parts and max(shares) < 2 * (sum(shares) // parts + max(shares) // 4 + 1)
+
+
+def test_divided_multi():
+    check(fa("1a", "1b", "1c"), 20, 3, 4, 3)
+    seqs = [g.decode() for g in synth.genomes(60000, 5)]
+    check(seqs, 20, 5, 8, 4)
+
+
+def test_divided_device_buffers():
+    """segments packed into / imported from device memory (what the nccl transport uses)"""
+    pytest.importorskip("torch")
+    seqs = [g.decode() for g in synth.genomes(300000, 2)]
+    check(seqs, 20, 2, 8, 3, device_buffers=True)
+
+
+def test_divided_untraced_matches_undivided():
+    """the production configuration (no trace: device-side picker, decisions, early split, leaf kernel)"""
+    seqs = [g.decode() for g in synth.genomes(1500000, 2)]
+    M = mod(False)
+    idx = feed(M.index(), seqs)
+    idx.construct()
+    one = idx.align_builtin(20, 2)
+    got, shares, left = divided(seqs, 20, 2, 16, 4, trace=False)
+    assert left >= 16
+
+    def aset(r):
+        l, off, pos = r["anchors"]
+        return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+    assert aset(one) == aset(got)
+    for k in ("steps", "splits", "anchored_bp"):
+        assert one["stats"][k] == got["stats"][k], k
+    assert shard.lower_text(assemble(seqs)[0], got["anchors"]).tobytes() == idx.T.encode("latin-1")

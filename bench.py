@@ -66,6 +66,9 @@ def main():
     ap.add_argument("--minn", type=int, default=2)
     ap.add_argument("--sa64", action="store_true")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--divide", action="store_true",
+                    help="N>1: ONE alignment divided over the ranks (frontier hand-off, reveal_amd/shard.py; strong scaling) "
+                         "instead of one alignment per rank")
     ap.add_argument("--cpu-L", type=int, default=0, help="genome length for the CPU sample (default: same as --L, capped at 5 Mbp)")
     args = ap.parse_args()
 
@@ -76,12 +79,18 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if os.environ.get("RV_BENCH_SHARE_GPU"):      # plumbing check on a one-GPU box: every rank on device 0, gloo instead of RCCL
+            local_rank = 0
+            torch.cuda.set_device(0)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     from reveal_amd import _lib, synth
     _lib.set_device(local_rank)
 
-    seqs = synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank)
+    divide = args.divide and world > 1
+    seqs = synth.genomes(args.L, args.genomes, seed=42 + (0 if divide else 1000 * rank))
     bases = sum(len(s) for s in seqs)
     idx = build_index(seqs, args.sa64)
 
@@ -92,6 +101,9 @@ def main():
         torch.cuda.synchronize()
 
     def step():
+        if divide:      # rank 0 constructs and runs the top levels, every rank finishes a share of the frontier
+            from reveal_amd import shard
+            return shard.align_sharded(idx, args.minl, args.minn)
         idx.construct()
         return idx.align_builtin(args.minl, args.minn)
 
@@ -114,6 +126,8 @@ def main():
         b = torch.tensor([bases], dtype=torch.float64, device="cuda")
         dist.all_reduce(b, op=dist.ReduceOp.SUM)
         tmax, total_bases = float(t.item()), float(b.item())
+        if divide:
+            total_bases = float(bases)      # every rank worked on the same inputs
 
     if rank == 0:
         kname = "scan_multi" if args.genomes > 2 else "scan_pair"
@@ -139,13 +153,15 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if divide else "weak",
             "vs_baseline": None,
             "dtype": "int64" if args.sa64 else "int32",
             "data": "synthetic",
             "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42+1000*rank), rem -m %d -n %d, "
                                    "construct + full recursion, bench picker" % (args.genomes, args.L / 1e6, args.minl, args.minn),
-                       "bases_per_gpu": bases, "index": "64-bit" if args.sa64 else "32-bit"},
+                       "bases_per_gpu": bases, "index": "64-bit" if args.sa64 else "32-bit",
+                       "sharding": ("one alignment divided over %d ranks (frontier hand-off), shares %s" % (world, last.get("shares"))) if divide
+                                   else "one alignment per rank, no exchange"},
             "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("multi" if args.genomes > 2 else "pair"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,

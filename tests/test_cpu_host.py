@@ -121,3 +121,113 @@ def test_two_rank_sharding_gloo(tmp_path):
     line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
     r = json.loads(line)
     assert r["tmax"] == 1.5 and r["bases"] == 80000.0 and r["distinct_inputs"] == 2
+
+
+# ---- one alignment divided over ranks (reveal_amd/shard.py): pure parts + the exchange protocol with a stand-in index
+
+def test_shard_partition_subset_merge_lower():
+    from reveal_amd import shard
+    sizes = [5, 100, 7, 40, 40, 1, 60]
+    parts = shard.partition(sizes, 3)
+    assert sorted(int(x) for p in parts for x in p) == list(range(len(sizes)))       # every sub-index exactly once
+    loads = [sum(sizes[int(s)] for s in p) for p in parts]
+    assert max(loads) == 100 and min(loads) >= 73                                     # largest first into the lightest share
+    assert all(list(p) == sorted(p) for p in parts)
+    assert [len(p) for p in shard.partition([3, 2], 4)] == [1, 1, 0, 0]                # fewer sub-indices than ranks
+    fr = dict(level=3, m=sum(sizes), meta=np.array([[0, n, 2, 2, 0, -1] for n in sizes], dtype=np.int64),
+              node_first=np.array([0, 2, 4, 5, 7, 9, 10, 12], dtype=np.int64), nodes=np.arange(24, dtype=np.int64).reshape(12, 2))
+    sub = shard.subset(fr, [1, 2, 6])
+    assert sub["meta"][:, 1].tolist() == [100, 7, 60] and sub["node_first"].tolist() == [0, 2, 3, 5]
+    assert sub["nodes"][:, 0].tolist() == [4, 6, 8, 20, 22] and sub["level"] == 3
+    a = dict(stats=dict(steps=3, splits=2, anchored_bp=30, scanned_ranks=10, levels=4, maxdepth=3, t_scan=.1, t_host=.1, t_split=.1, t_bubble=.1),
+             anchors=(np.array([10, 20], np.uint32), np.array([0, 2, 4]), np.array([1, 50, 20, 70])), trace=None)
+    b = dict(stats=dict(steps=1, splits=1, anchored_bp=5, scanned_ranks=4, levels=6, maxdepth=5, t_scan=.2, t_host=0, t_split=0, t_bubble=0),
+             anchors=(np.array([5], np.uint32), np.array([0, 2]), np.array([40, 95])), trace=None)
+    m = shard.merge([a, shard.empty_result(), b])
+    assert m["anchors"][0].tolist() == [10, 20, 5] and m["anchors"][1].tolist() == [0, 2, 4, 6] and m["anchors"][2].tolist() == [1, 50, 20, 70, 40, 95]
+    assert m["stats"]["steps"] == 4 and m["stats"]["levels"] == 6 and m["stats"]["anchored_bp"] == 35
+    T = b"A" * 45 + b"$" + b"C" * 54
+    low = shard.lower_text(T, m["anchors"]).tobytes()
+    assert low[:1] == b"A" and low[1:11] == b"a" * 10 and low[11:20] == b"A" * 9 and low[20:45] == b"a" * 25 and low[45:46] == b"$"
+    assert low[46:50] == b"C" * 4 and low[50:60] == b"c" * 10 and low[60:70] == b"C" * 10 and low[70:90] == b"c" * 20 and low[95:] == b"c" * 5
+
+
+SHARD_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+from reveal_amd import shard
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+
+class FakeLib: sa64 = False
+class FakeIndex:
+    """the methods shard.align_sharded drives, on numpy: a frontier of 7 sub-indices whose 'recursion' turns every sub-index
+    into one anchor (l = its size, members = checksums of the segments it was handed)"""
+    _lib = FakeLib()
+    n = 1000
+    maxlcp = 77
+    def __init__(self): self.constructed = False; self.front = None; self.done = []
+    def construct(self): self.constructed = True
+    def align_builtin_until(self, stop, minl, minn, trace=False):
+        assert self.constructed and rank == 0
+        self.sizes = np.array([5, 100, 7, 40, 40, 1, 60])
+        self.SA = np.arange(self.sizes.sum(), dtype=np.int32) * 3 + 1
+        self.done = [(9, (0, 500))]                    # an anchor of the levels in front of the hand-off
+        return len(self.sizes)
+    def frontier(self):
+        off = np.concatenate([[0], np.cumsum(self.sizes)[:-1]])
+        meta = np.stack([off, self.sizes, np.full(7, 2), np.full(7, 2), np.zeros(7, int), np.full(7, -1)], axis=1).astype(np.int64)
+        return dict(level=3, m=int(self.sizes.sum()), meta=meta, node_first=np.arange(8, dtype=np.int64), nodes=np.stack([off, off + self.sizes], axis=1).astype(np.int64))
+    def frontier_pack(self, subs, sa, lcp, bwt):
+        at = 0
+        fr = self.frontier()
+        for s in subs:
+            o, n = int(fr["meta"][s, 0]), int(fr["meta"][s, 1])
+            sa[at:at + n] = torch.from_numpy(self.SA[o:o + n]); lcp[at:at + n] = 7; bwt[at:at + n] = 65
+            at += n
+        return at
+    def frontier_import(self, part, sa, lcp, bwt, minl=20, minn=2, maxlcp=None, trace=False):
+        assert rank == 0 or (maxlcp == 77 and not self.constructed)
+        self.front = (part, sa.numpy().copy(), lcp.numpy().copy(), bwt.numpy().copy())
+    def align_builtin_resume(self):
+        part, sa, lcp, bwt = self.front
+        at = 0
+        for k in range(len(part["meta"])):
+            n = int(part["meta"][k, 1])
+            assert (lcp[at:at + n] == 7).all() and (bwt[at:at + n] == 65).all()
+            assert part["nodes"][part["node_first"][k], 1] - part["nodes"][part["node_first"][k], 0] == n
+            self.done.append((n, (int(sa[at:at + n].sum()), int(part["nodes"][part["node_first"][k], 0]))))
+            at += n
+        l = np.array([d[0] for d in self.done], np.uint32); pos = np.array([p for d in self.done for p in d[1]], np.int64)
+        st = shard.empty_result()["stats"]; st["splits"] = len(self.done)
+        return dict(stats=st, anchors=(l, np.arange(0, 2 * len(l) + 1, 2), pos), trace=None)
+
+import torch
+res = shard.align_sharded(FakeIndex(), 20, 2, stop_subs=4)
+if rank == 0:
+    l, off, pos = res["anchors"]
+    print(json.dumps({"anchors": sorted((int(l[k]), [int(x) for x in pos[off[k]:off[k + 1]]]) for k in range(len(l))), "shares": res["shares"], "splits": res["stats"]["splits"]}))
+else:
+    assert res is None
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_divided_alignment_protocol_gloo(tmp_path):
+    """shard.align_sharded on two ranks (gloo, host memory) around a stand-in index: every sub-index of the frontier reaches
+    exactly one rank with its own segments and metadata, and rank 0 ends up with all anchors"""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % ROOT)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29519", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    sizes = [5, 100, 7, 40, 40, 1, 60]
+    SA = np.arange(sum(sizes)) * 3 + 1
+    off = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    want = sorted([(9, [0, 500])] + [(n, [int(SA[o:o + n].sum()), int(o)]) for o, n in zip(off, sizes)])
+    assert [tuple(a) for a in r["anchors"]] == [(l, p) for l, p in want]
+    assert sorted(r["shares"]) == [113, 140] and r["splits"] == 8      # (LPT, not optimal: 100+40 | 60+40+7+5+1)

@@ -408,7 +408,8 @@ int rv_frontier_scan(rv_index *h) {
         a->early_done = false; a->early_bubble = false;
         const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, early_split, early));
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, early_split, early,
+                                (d_ss && a->cur_dev_ok) ? a->d_next_tsub2 : nullptr));
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
         if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
         int si = 0;
@@ -1183,7 +1184,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             for (int s2 = 0; s2 < a->lv.size(); s2++) biggest = std::max<int64_t>(biggest, a->lv.n[(size_t)s2]);
             unsigned long long dbg[8] = {0};
             if (a->dDbg.p) { (void)hipMemcpy(dbg, a->dDbg.p, 64, hipMemcpyDeviceToHost); (void)hipMemset(a->dDbg.p, 0, 64); }
-            fprintf(stderr, "      bubble (sequential kernels): cuts %llu actives %llu whole-wg visits %llu chunks %llu concurrent %llu\n", dbg[3], dbg[4], dbg[0], dbg[1], dbg[2]);
+            fprintf(stderr, "      bubble (sequential kernels): cuts %llu actives %llu whole-wg visits %llu chunks %llu concurrent %llu | slowest child: total %.1f us (%llu actives), finding actives %.1f, sort+visits %.1f\n", dbg[3], dbg[4], dbg[0], dbg[1], dbg[2], (dbg[5] >> 24) / 100.0, dbg[5] & 0xFFFFFFull, dbg[6] / 100.0, dbg[7] / 100.0);
             fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | leafprep %6.1f scan %6.1f host %6.1f | commit: tables %6.1f upload %6.1f split-enq %6.1f bubble-enq %6.1f | drain %7.1f us | next biggest %lld\n",
                     log_level, log_ns, log_leaf, (long long)log_m, (tl_leaf - tl0) * 1e6, (t0 - tl_leaf) * 1e6, (tl1 - t0) * 1e6,
                     a->lg[0] * 1e6, (a->lg[1] - a->lg[0]) * 1e6, (a->lg[2] - a->lg[1]) * 1e6, (tl2 - tl1) * 1e6 - a->lg[2] * 1e6, (tl3 - tl2) * 1e6,

@@ -295,7 +295,8 @@ int rv_text_only(rv_index *h, u32 maxlcp) {
 // one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
-                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs, int (*after_pick)(rv_index *), bool use_hook) {
+                     const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs, int (*after_pick)(rv_index *), bool use_hook,
+                     const int *d_tile_sub) {
     out.clear();
     if (err_out) *err_out = 0;
     if (m <= 1) {
@@ -331,7 +332,7 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         if (d_sub_start) {
             // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots
             RV_TRY(rv_pick_slots_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), (u32)std::min<size_t>(vcap, 0xffffffffu), tilecnt, tileovf, ntile,
-                                        d_sub_start, nsubs, bbest.as<unsigned long long>(), picks, bcnt.as<u32>(), d_err));
+                                        d_sub_start, nsubs, bbest.as<unsigned long long>(), picks, bcnt.as<u32>(), d_err, d_tile_sub, ceil_div(m, RV_TSUB_TILE)));
             // The one host round trip of a level.  The host waits for the picks only (an event behind the picker kernels), not for
             // the stream: work that needs nothing but the picks on the device (the level's split, rv_decide.hip) is queued first
             // and runs while the host works.  Spinning instead of sleeping in a synchronize: its wake-up costs tens of

@@ -91,7 +91,8 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
                       const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos);
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
                      const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs,   // d_sub_start != NULL: only the best record per sub-index
-                     int (*after_pick)(rv_index *), bool use_hook);                        // ... and a hook called once the picker kernels are queued
+                     int (*after_pick)(rv_index *), bool use_hook,
+                     const int *d_tile_sub = nullptr);                                       // ... tile -> sub-index table of the level (optional, speeds the picker's look-ups)                        // ... and a hook called once the picker kernels are queued
 
 // text, shared inverse and separators in HBM without an index (rv_api.hip); maxlcp = window size of bubble_sort
 int rv_text_only(rv_index *h, u32 maxlcp);

@@ -26,7 +26,8 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
 // built-in picker straight from the slots (no compaction): picks[0] = header {0, overflow count, *err, 0}, picks[1+s] = longest
 // record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none; resets *ovf_counter
 int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
-                         const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err);
+                         const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err,
+                         const int *tile_sub, int64_t ntsub);      // tile_sub (optional): sub-index of the first rank of every RV_TSUB_TILE ranks
 // out holds RV_PAIR_HDR header records ({total, overflow count, *err, 0} as u32) followed by the packed records.
 // Resets *ovf_counter for the next scan.
 #define RV_PAIR_HDR 1

@@ -203,6 +203,16 @@ __device__ inline int sub_of_rank(const int64_t *__restrict__ sub_start, int nsu
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub_start[mid] <= r) lo = mid + 1; else hi = mid; }
     return lo - 1;
 }
+// the same with a tile -> sub-index table (sub-index of the first rank of every RV_TSUB_TILE ranks): two independent loads
+// bound the search to the sub-indices that start inside the tile -- usually none or one -- instead of log2(nsubs) dependent ones
+__device__ inline int sub_of_rank_t(const int64_t *__restrict__ sub_start, int nsubs, const int *__restrict__ tile_sub, int64_t ntsub, int64_t r) {
+    if (!tile_sub) return sub_of_rank(sub_start, nsubs, r);
+    const int64_t tt = r / RV_TSUB_TILE;
+    int lo = tile_sub[tt] + 1;
+    int hi = tt + 1 < ntsub ? tile_sub[tt + 1] + 1 : nsubs;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sub_start[mid] <= r) lo = mid + 1; else hi = mid; }
+    return lo - 1;
+}
 __device__ inline u64 pick_key(const RvPairRec &r) { return ((u64)r.l << 32) | (u64)(0xFFFFFFFFu - (u32)r.a); }
 
 // The same picker straight from the scan's per-tile slots (+ overflow): no tile-count scan, no compaction -- the
@@ -213,7 +223,8 @@ template <int PASS>
 __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf, u32 ovf_cap,
                                                    const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf, int64_t ntile,
                                                    const int64_t *__restrict__ sub_start, int nsubs, unsigned long long *__restrict__ best,
-                                                   RvPairRec *__restrict__ picks, u32 *__restrict__ ovf_counter, const u32 *__restrict__ err) {
+                                                   RvPairRec *__restrict__ picks, u32 *__restrict__ ovf_counter, const u32 *__restrict__ err,
+                                                   const int *__restrict__ tile_sub, int64_t ntsub) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (PASS == 2 && id == 0) {
         u32 *hdr = reinterpret_cast<u32 *>(picks);
@@ -230,7 +241,7 @@ __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__
         RvPairRec r; int sub = -1; u64 key = 0;
         if (have) {
             r = q < RV_PAIR_SLOTS ? slots[(size_t)t * RV_PAIR_SLOTS + q] : ovf[ob + (q - RV_PAIR_SLOTS)];
-            sub = sub_of_rank(sub_start, nsubs, (int64_t)r.rank); key = pick_key(r);
+            sub = sub_of_rank_t(sub_start, nsubs, tile_sub, ntsub, (int64_t)r.rank); key = pick_key(r);
         }
         if (PASS == 1) {
             u64 todo = __ballot(sub >= 0);
@@ -488,12 +499,13 @@ int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t
 }
 
 int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,
-                          const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err) {
+                          const int64_t *sub_start, int nsubs, unsigned long long *best, RvPairRec *picks, u32 *ovf_counter, const u32 *err,
+                          const int *tile_sub, int64_t ntsub) {
     if (ntile <= 0 || nsubs <= 0) return 0;
     const unsigned g = (unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB);
-    hipLaunchKernelGGL(k_pick_slots<1>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err);
+    hipLaunchKernelGGL(k_pick_slots<1>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err, tile_sub, ntsub);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pick_slots<2>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err);
+    hipLaunchKernelGGL(k_pick_slots<2>, dim3(g), dim3(TB), 0, ws.stream, slots, ovf, ovf_cap, tilecnt, tileovf, ntile, sub_start, nsubs, best, picks, ovf_counter, err, tile_sub, ntsub);
     RV_LAUNCH_CHECK();
     return 0;
 }

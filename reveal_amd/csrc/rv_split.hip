@@ -654,26 +654,24 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
 #endif
     const int64_t n = ds.n, B = ds.B;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    if (threadIdx.x == 0) {
-        const int64_t sa = (int64_t)SA[e], lc = (int64_t)(u32)LCP[e];
-        int64_t kind = 0;
-        if (sa < B && sa + lc > B) {
-            kind = 1;
-        } else if (e < n - 1) {
-            const int64_t ln = (int64_t)(u32)LCP[e + 1];
-            if (sa < B && sa + ln > B && ln > lc) LCP[e + 1] = (lcp_t)(B - sa);      // reveal.c:714-718
-        }
-        s_v[0] = kind; s_v[1] = sa; s_v[2] = lc; s_v[3] = BW[e];
+    // every thread evaluates the two conditions itself (same addresses: one transaction per wave); handing thread 0's result
+    // round through LDS cost a barrier per visit.  The arrays are quiescent here: every visit ends with a barrier.
+    const int64_t sa_e = (int64_t)SA[e], lc_e = (int64_t)(u32)LCP[e];
+    const uint8_t bw_e = BW[e];
+    const bool moves = sa_e < B && sa_e + lc_e > B;
+    if (!moves && e < n - 1 && threadIdx.x == 0) {
+        const int64_t ln = (int64_t)(u32)LCP[e + 1];
+        if (sa_e < B && sa_e + ln > B && ln > lc_e) LCP[e + 1] = (lcp_t)(B - sa_e);      // reveal.c:714-718
     }
-    __syncthreads();
-    if (s_v[0] == 1) {                                                               // reveal.c:686-709
-        const int64_t tS = s_v[1], tL = s_v[2], t = B - tS;
-        const uint8_t tB = (uint8_t)s_v[3];
+    if (moves) {                                                                     // reveal.c:686-709
+        const int64_t tS = sa_e, tL = lc_e, t = B - tS;
+        const uint8_t tB = bw_e;
         // the arrays of a child start at an arbitrary rank of the level arrays: align groups on absolute addresses
         const int64_t skew = (int64_t)((reinterpret_cast<uintptr_t>(LCP) >> 2) & 3);     // LCP + (4g - skew) is 16-byte aligned
         int64_t x = 0;
         int64_t gtop = (e + skew) >> 2;                  // group of rank r: (r + skew) >> 2, ranks 4g-skew .. 4g-skew+3
         bool done = false;
+        int step = 0;
         while (!done) {
             if (b.dbg && threadIdx.x == 0) atomicAdd(&b.dbg[1], 1ull);
             const int64_t gl = gtop - (int64_t)NT * EG + 1 > 0 ? gtop - (int64_t)NT * EG + 1 : 0;
@@ -722,10 +720,15 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
                 }
             }
             for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_down(best, d, 64); best = o > best ? o : best; }
-            if (lane == 0) s_max[w] = best;
+            // One barrier per chunk (all sources loaded, stop rank known).  The stores below need no barrier of their own:
+            // the next chunk reads and writes lower ranks only, so its loads are issued while these stores drain.  The
+            // per-wave maxima alternate between two buffers so that a fast wave's next write cannot overtake a slow wave's read.
+            int *smx = s_max + (step & 1) * (NT / 64);
+            step++;
+            if (lane == 0) smx[w] = best;
             __syncthreads();
             int mx = -1;
-            for (int k = 0; k < NT / 64; k++) mx = s_max[k] > mx ? s_max[k] : mx;
+            for (int k = 0; k < NT / 64; k++) mx = smx[k] > mx ? smx[k] : mx;
             // ranks (stop, min(e, chunk top)] move up by one; rank 0 is a stop by definition
             int64_t stop = (mx >= 0) ? rbase + mx : rbase - 1;
             if (stop < 0) stop = 0;
@@ -754,11 +757,11 @@ __device__ inline bool bubble_visit_vec(const RvBubbleArgs &b, const RvBubbleDes
                     }
                 }
             }
-            __threadfence_block();
-            __syncthreads();
             if (done) x = stop;
             gtop = gl - 1;
         }
+        __threadfence_block();
+        __syncthreads();      // (the last chunk's stores to x+1 come before the values written below)
         if (threadIdx.x == 0) {
             SA[x] = (sa_t)tS;
             BW[x] = tB;
@@ -852,11 +855,20 @@ __device__ inline void wave_classify(const RvBubbleDesc &ds, const sa_t *SA, con
     if (sa < B && sa + lc > B) {
         const int64_t t = B - sa;
         kind = 3; lo = e > BB_WSCAN ? e - BB_WSCAN : 0;
-        for (int64_t top = e - 1; top >= 0 && top >= e - BB_WSCAN; top -= 64) {      // ranks top, top-1, ... top-63
-            const int64_t r = top - lane;
-            const bool hit = r >= 0 && (r == 0 || (int64_t)(u32)LCP[r] < t);
+        // all BB_WSCAN ranks below e at once (independent loads: one memory round trip; a loop of 64-rank steps that stopped at the
+        // first hit cost one round trip per step, eight for every mover that turns out to be long), then the nearest hit
+        lcp_t v[BB_WSCAN / 64];
+#pragma unroll
+        for (int k = 0; k < BB_WSCAN / 64; k++) {
+            const int64_t r = e - 1 - 64 * k - lane;
+            v[k] = r > 0 ? LCP[r] : (lcp_t)0;
+        }
+#pragma unroll
+        for (int k = 0; k < BB_WSCAN / 64; k++) {
+            const int64_t r = e - 1 - 64 * k - lane;
+            const bool hit = r >= 0 && (r == 0 || (int64_t)(u32)v[k] < t);
             const u64 bal = __ballot(hit);
-            if (bal) { kind = 1; lo = top - (int64_t)__builtin_ctzll(bal); break; }     // lowest lane = largest rank
+            if (bal && kind == 3) { kind = 1; lo = e - 1 - 64 * k - (int64_t)__builtin_ctzll(bal); }     // lowest lane = largest rank
         }
         if (e == 0) { kind = 1; lo = 0; }
     } else if (e < n - 1) {
@@ -958,7 +970,7 @@ template <int NT, int EL>
 __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];      // decision broadcast: kind, tS, tL
-    __shared__ int s_max[NT / 64];
+    __shared__ int s_max[2 * (NT / 64)];
     __shared__ u32 s_w[NT / 64];
     __shared__ CutWin cw;
     __shared__ ParScratch ps;
@@ -1037,7 +1049,7 @@ template <int NT, int EL>
 __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc, int64_t max_n) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];
-    __shared__ int s_max[NT / 64];
+    __shared__ int s_max[2 * (NT / 64)];
     __shared__ u32 s_w[NT / 64];
     __shared__ CutWin cw;
     __shared__ ParScratch ps;
@@ -1054,10 +1066,14 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
     uint8_t *BW = b.BWT + ds.off;
     uint8_t *flag = b.flag + ds.off;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    // RV_LEVEL_LOG: where the slowest child of the launch spends its time (100 MHz clock; maxima over the workgroups)
+    const unsigned long long tk0 = b.dbg ? wall_clock64() : 0ull;
+    unsigned long long t_find = 0, t_visit = 0, n_act = 0;
     for (int q = ds.cut0; q < ds.cut1; q++) {
         const int64_t B = (int64_t)b.cut_hi[q], wlo = (int64_t)b.cut_lo[q];
         if (wlo >= B) continue;                                   // uniform
         ds.B = B;
+        const unsigned long long tc0 = b.dbg ? wall_clock64() : 0ull;
         if (ds.n <= 4 * BB_CAP) {
             // Small child: the ranks that can act are found by reading the child itself, 4096 ranks at a time -- already in
             // visiting order, no SAi gathers over the window, no flags, no sort.  (With many samples a level has tens of
@@ -1115,8 +1131,11 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
         }
         __syncthreads();
         const u32 cnt = s_cnt;
+        if (b.dbg) t_find += wall_clock64() - tc0;
         if (cnt == 0) continue;
         if (b.dbg && threadIdx.x == 0) { atomicAdd(&b.dbg[3], 1ull); atomicAdd(&b.dbg[4], (unsigned long long)cnt); }
+        const unsigned long long tc1 = b.dbg ? wall_clock64() : 0ull;
+        n_act += cnt;
         // Order of the visits = ascending rank.  Few actives: sort the list.  Many actives in a small child: walking the
         // child's flag bytes yields them already ordered and costs less than ~60 bitonic stages (many samples: hundreds of
         // actives per cut, ten cuts per child).
@@ -1158,6 +1177,10 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
         }
         __threadfence_block();
         __syncthreads();
+        if (b.dbg) t_visit += wall_clock64() - tc1;
+    }
+    if (b.dbg && threadIdx.x == 0) {
+        atomicMax(&b.dbg[5], ((wall_clock64() - tk0) << 24) | (n_act & 0xFFFFFFull)); atomicMax(&b.dbg[6], t_find); atomicMax(&b.dbg[7], t_visit);
     }
 }
 
@@ -1173,7 +1196,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child_lds(RvBubbleArgs b, const R
     __shared__ __attribute__((aligned(16))) uint8_t sBW[N];
     __shared__ u32 lst[CH];
     __shared__ int64_t s_v[4];
-    __shared__ int s_max[NT / 64];
+    __shared__ int s_max[2 * (NT / 64)];
     __shared__ u32 s_w[NT / 64];
     __shared__ CutWin cw;
     __shared__ ParScratchT<CH> ps;

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assemble, feed, oracle  # noqa: E402
-from reveal_amd import reveallib, reveallib64  # noqa: E402
+from reveal_amd import reveallib, reveallib64, shard  # noqa: E402
 
 FIELDS = ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums")
 ENVS = [
@@ -75,6 +75,33 @@ def anchors_set(a):
     return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
 
 
+def divided(M, seqs, minl, stop, nparts, trace):
+    """one alignment over `nparts` handles (frontier hand-off, reveal_amd/shard.py), in this process"""
+    owner = feed(M.index(), seqs)
+    owner.construct()
+    lib = owner._lib
+    left = owner.align_builtin_until(stop, minl, 2, trace=trace)
+    res = []
+    if left > 0:
+        fr = owner.frontier()
+        packed = []
+        for subs in shard.partition(fr["meta"][:, 1], nparts):
+            part = shard.subset(fr, subs)
+            m = int(part["meta"][:, 1].sum())
+            bufs = (np.zeros(max(m, 1), lib.sa_t), np.zeros(max(m, 1), lib.lcp_t), np.zeros(max(m, 1), np.uint8))
+            owner.frontier_pack(subs, *bufs)
+            packed.append((part, bufs))
+        owner.frontier_import(packed[0][0], *packed[0][1], minl=minl, minn=2)
+        for part, bufs in packed[1:]:
+            if len(part["meta"]) == 0:
+                continue
+            w = feed(M.index(), seqs)
+            w.frontier_import(part, *bufs, minl=minl, minn=2, maxlcp=owner.maxlcp, trace=trace)
+            res.append(w.align_builtin_resume())
+    res.insert(0, owner.align_builtin_resume())
+    return shard.merge(res)
+
+
 def main():
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else int(time.time())
@@ -108,8 +135,22 @@ def main():
                     gd = digest(got["trace"])
                     for f in FIELDS:
                         assert len(gd[f]) == len(rd[f]) and (gd[f] == rd[f]).all(), "trace field %s %s" % (f, tag)
+        # the same alignment divided over several handles at a random level (default code paths)
+        for k in list(os.environ):
+            if k.startswith("RV_"):
+                del os.environ[k]
+        for trace in (True, False):
+            stop, nparts = rng.choice([2, 3, 8, 32]), rng.choice([2, 3, 5])
+            tag = "seed %d case %d divided stop %d parts %d trace %s sa64 %s" % (seed, ncase, stop, nparts, trace, sa64)
+            got = divided(reveallib64 if sa64 else reveallib, seqs, minl, stop, nparts, trace)
+            assert anchors_set(got["anchors"]) == ra, "anchors " + tag
+            assert shard.lower_text(T, got["anchors"]).tobytes() == ref["T"], "text " + tag
+            if trace:
+                gd = digest(got["trace"])
+                for f in FIELDS:
+                    assert len(gd[f]) == len(rd[f]) and (gd[f] == rd[f]).all(), "trace field %s %s" % (f, tag)
         ncase += 1
-    print("fuzz: %d cases x %d configurations x 2 (traced / untraced) identical to the oracle (seed %d)" % (ncase, len(ENVS), seed))
+    print("fuzz: %d cases x (%d configurations + divided run) x 2 (traced / untraced) identical to the oracle (seed %d)" % (ncase, len(ENVS), seed))
 
 
 if __name__ == "__main__":

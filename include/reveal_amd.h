@@ -200,6 +200,8 @@ int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,
        RV_K_BUBBLE = 6, RV_K_COUNT = 8 };
+/* on: 0 = off, 1 = every class, otherwise bit k+1 selects class k (an event pair costs the stream a few
+ * microseconds, so a timed run times only what it reports) */
 int rv_prof_enable(rv_index *h, int on);
 int rv_prof_reset(rv_index *h);
 /* launches, total milliseconds and algorithmic bytes of kernel class k since the last reset */

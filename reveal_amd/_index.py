@@ -89,10 +89,16 @@ def make_index_type(sa64, error):
             if self._dll.rv_upload(self._h) != 0:
                 self._fail()
 
-        def prof(self, enable=None, reset=False):
-            """HIP-event kernel timing on the index' stream -> {kernel: (launches, ms, bytes)}"""
+        def prof(self, enable=None, reset=False, only=None):
+            """HIP-event kernel timing on the index' stream -> {kernel: (launches, ms, bytes)}
+            only = names of the kernel classes to time (default: all; every timed span costs the stream two events)"""
+            ids = {"scan_pair": _lib.K_SCAN_PAIR, "scan_multi": _lib.K_SCAN_MULTI, "sa_build": _lib.K_SA_SORT, "lcp": _lib.K_LCP,
+                   "split": _lib.K_SPLIT, "label": _lib.K_LABEL, "bubble": _lib.K_BUBBLE}
             if enable is not None:
-                self._dll.rv_prof_enable(self._h, 1 if enable else 0)
+                on = 0
+                if enable:
+                    on = 1 if only is None else sum(2 << ids[k] for k in only)
+                self._dll.rv_prof_enable(self._h, on)
             if reset:
                 self._dll.rv_prof_reset(self._h)
             out = {}

@@ -175,6 +175,8 @@ struct Align {
     double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     // rv_align_builtin split into set-up / levels / collection, so that a frontier can be handed to other devices in between
     int leaf_flip = 0;
+    bool leaf_launch_due = false, hook_early = false;   // the level's leaf launch waits until the level's scan / split kernels are queued
+    size_t last_leaf_count = 0;
     bool running = false;        // a built-in run is between its set-up and its collection
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     void release() {
@@ -307,6 +309,53 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 
 extern "C" {
 
+static int early_split(rv_index *h);
+
+/* the leaf kernel of the current level (roots prepared by builtin_levels) on its own stream */
+static int leaf_launch(rv_index *h) {
+    Align *a = h->al;
+    a->leaf_launch_due = false;
+    const int leaf_flip = a->leaf_flip;
+    std::vector<RvLeafRoot> &roots = a->leaf_roots[leaf_flip];
+    DBuf &droots = a->dLeafRoots[leaf_flip];
+    hipStream_t ls = a->leaf_stream;
+    const int slot = (a->level == 0) ? 1 : a->cur;
+    if (a->leaf_pending[slot]) RV_HIP(hipEventSynchronize(a->ev_leaf[slot]));     // (cannot happen: commit waits first)
+    RV_TRY(droots.reserve(roots.size() * sizeof(RvLeafRoot)));
+    // pinned staging (one per ping-pong slot): a pageable copy would make the host wait for the leaf stream to drain
+    HBuf &hroots = a->hLeafRoots[leaf_flip];
+    if (a->roots_inflight[leaf_flip]) RV_HIP(hipEventSynchronize(a->ev_roots[leaf_flip]));     // copy of two levels ago (long done)
+    RV_TRY(hroots.reserve(roots.size() * sizeof(RvLeafRoot)));
+    memcpy(hroots.p, roots.data(), roots.size() * sizeof(RvLeafRoot));
+    RV_HIP(hipMemcpyAsync(droots.p, hroots.p, roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, ls));
+    RV_HIP(hipEventRecord(a->ev_roots[leaf_flip], ls));
+    a->roots_inflight[leaf_flip] = true;
+    RvLeafArgs la;
+    la.roots = droots.as<RvLeafRoot>();
+    la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
+    la.nsep0 = h->nsep[0]; la.minl = a->minl; la.lcap = h->maxlcp;
+    la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_a = a->lf_a; la.anchor_b = a->lf_b;
+    la.stats = a->lf_stats;
+    la.trace = a->trace_on ? 1 : 0; la.trace_count = a->lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = a->lf_tr;
+    la.err = a->lf_counters + 2;
+    {
+        Workspace lw; lw.stream = ls;
+        RV_TRY(rv_leaf_launch(lw, la, (int)roots.size()));
+    }
+    RV_HIP(hipEventRecord(a->ev_leaf[slot], ls));
+    a->leaf_pending[slot] = true;
+    a->leaf_flip ^= 1;
+    return 0;
+}
+
+/* called by the pair scan once its kernels and the picker's are queued, before the host waits for the picks */
+static int level_hook(rv_index *h) {
+    Align *a = h->al;
+    if (a->hook_early) RV_TRY(early_split(h));
+    if (a->leaf_launch_due) RV_TRY(leaf_launch(h));
+    return 0;
+}
+
 /* The split of the current level (reveal.c:1005-1252 without lower-casing and bubble_sort), queued right behind the picker
  * kernels with decisions taken on the device (rv_decide.hip): it runs while the host receives the picks and rebuilds the
  * same decisions for its own bookkeeping.  rv_frontier_commit then finds it done. */
@@ -407,8 +456,9 @@ int rv_frontier_scan(rv_index *h) {
         const int64_t *d_ss = (a->full_only && (a->level > 0 || a->cur_dev_ok)) ? a->d_next_ss : nullptr;
         a->early_done = false; a->early_bubble = false;
         const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
+        a->hook_early = early;
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
-        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, early_split, early,
+        RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, level_hook, early || a->leaf_launch_due,
                                 (d_ss && a->cur_dev_ok) ? a->d_next_tsub2 : nullptr));
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
         if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
@@ -1014,14 +1064,12 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
 // levels of the recursion until the frontier is empty, or (stop_subs > 0) until it holds at least stop_subs sub-indices
 static int builtin_levels(rv_index *h, int stop_subs) {
     Align *a = h->al;
-    const int minl = a->minl;
     std::vector<sa_t> hsa; std::vector<lcp_t> hlcp;
     std::vector<int64_t> sp;
     std::vector<RvIntv> lead, trail, match, rest;
     std::vector<uint8_t> touched;
     const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
-    u32 *lf_counters = a->lf_counters; unsigned long long *lf_stats = a->lf_stats; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
     int &leaf_flip = a->leaf_flip;
     const bool level_log = getenv("RV_LEVEL_LOG") != nullptr;      // diagnostics: per-level wall time (adds a sync per level)
     while (a->lv.size() > 0) {
@@ -1033,7 +1081,6 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             const Level &lv0 = a->lv;
             a->leaf_done.assign((size_t)lv0.size(), 0);
             std::vector<RvLeafRoot> &roots = a->leaf_roots[leaf_flip];
-            DBuf &droots = a->dLeafRoots[leaf_flip];
             roots.clear();
             for (int s = 0; s < lv0.size(); s++) {
                 if (lv0.n[(size_t)s] > RV_LEAF_N) continue;
@@ -1053,38 +1100,16 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                 roots.push_back(r);
             }
             if (!roots.empty()) {
-                // second stream: starts once the level arrays are complete, runs beside this level's scan/split/bubble
-                hipStream_t ls = a->leaf_stream;
-                const int slot = (a->level == 0) ? 1 : a->cur;
-                if (a->leaf_pending[slot]) RV_HIP(hipEventSynchronize(a->ev_leaf[slot]));     // (cannot happen: commit waits first)
+                // second stream: starts once the level arrays are complete (the event is recorded here, in front of this level's
+                // kernels), runs beside this level's scan / split / bubble.  The launch itself (staging of the roots, copy,
+                // kernel, events: ~15 us of host time) is issued after the level's own kernels are queued, while the host would
+                // otherwise only wait for the picks -- issued first, it left the main stream idle that long at every level.
                 RV_HIP(hipEventRecord(a->ev_ready, q));
-                RV_HIP(hipStreamWaitEvent(ls, a->ev_ready, 0));
-                RV_TRY(droots.reserve(roots.size() * sizeof(RvLeafRoot)));
-                // pinned staging (one per ping-pong slot): a pageable copy would make the host wait for the leaf stream to drain
-                HBuf &hroots = a->hLeafRoots[leaf_flip];
-                if (a->roots_inflight[leaf_flip]) RV_HIP(hipEventSynchronize(a->ev_roots[leaf_flip]));     // copy of two levels ago (long done)
-                RV_TRY(hroots.reserve(roots.size() * sizeof(RvLeafRoot)));
-                memcpy(hroots.p, roots.data(), roots.size() * sizeof(RvLeafRoot));
-                RV_HIP(hipMemcpyAsync(droots.p, hroots.p, roots.size() * sizeof(RvLeafRoot), hipMemcpyHostToDevice, ls));
-                RV_HIP(hipEventRecord(a->ev_roots[leaf_flip], ls));
-                a->roots_inflight[leaf_flip] = true;
-                RvLeafArgs la;
-                la.roots = droots.as<RvLeafRoot>();
-                la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
-                la.nsep0 = h->nsep[0]; la.minl = minl; la.lcap = h->maxlcp;
-                la.anchor_count = lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = lf_l; la.anchor_a = lf_a; la.anchor_b = lf_b;
-                la.stats = lf_stats;
-                la.trace = a->trace_on ? 1 : 0; la.trace_count = lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = lf_tr;
-                la.err = lf_counters + 2;
-                {
-                    Workspace lw; lw.stream = ls;
-                    RV_TRY(rv_leaf_launch(lw, la, (int)roots.size()));
-                }
-                RV_HIP(hipEventRecord(a->ev_leaf[slot], ls));
-                a->leaf_pending[slot] = true;
-                leaf_flip ^= 1;
+                RV_HIP(hipStreamWaitEvent(a->leaf_stream, a->ev_ready, 0));
+                a->leaf_launch_due = true;
                 log_leaf = roots.size();
                 if ((size_t)lv0.size() == roots.size()) {       // nothing left for the level path
+                    RV_TRY(leaf_launch(h));
                     a->st.levels++;
                     a->lv.clear();
                     break;
@@ -1093,6 +1118,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
         }
         const double tl_leaf = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_scan(h));
+        if (a->leaf_launch_due) RV_TRY(leaf_launch(h));      // (scan paths without the hook)
         const double t0 = now_s();
         const Level &lv = a->lv;
         if (a->trace_on) {

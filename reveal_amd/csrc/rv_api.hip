@@ -514,7 +514,11 @@ int rv_fetch_mums(rv_index *h, uint32_t *l, int64_t *a, int64_t *b, int64_t cap)
     return 0;
 }
 
-int rv_prof_enable(rv_index *h, int on) { h->prof.on = on != 0; return 0; }
+int rv_prof_enable(rv_index *h, int on) {      /* 0 off; 1 every class; otherwise bit k+1 selects class k */
+    h->prof.on = on != 0;
+    h->prof.mask = (on & 1) ? 0xFFFFFFFFu : ((u32)on >> 1);
+    return 0;
+}
 int rv_prof_reset(rv_index *h) { (void)hipStreamSynchronize(h->ws.stream); h->prof.reset(); return 0; }
 int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes) {
     if (k < 0 || k >= RV_K_COUNT) { rv_set_error("bad kernel id"); return -1; }

@@ -10,6 +10,7 @@ struct RvIntv { int64_t begin, end; };
 // HIP-event profiler for kernel classes (bench.py's roofline figure).
 struct RvProf {
     bool on = false;
+    u32 mask = 0xFFFFFFFFu;           // kernel classes that are timed (an event pair costs the stream a few microseconds per span)
     struct Span { hipEvent_t a, b; int k; double bytes; };
     std::vector<Span> spans;
     std::vector<hipEvent_t> pool;
@@ -23,7 +24,7 @@ struct RvProf {
         return e;
     }
     int begin(hipStream_t s, int k, double nbytes) {
-        if (!on) return -1;
+        if (!on || !((mask >> k) & 1u)) return -1;
         Span sp; sp.a = get(); sp.b = get(); sp.k = k; sp.bytes = nbytes;
         (void)hipEventRecord(sp.a, s);
         spans.push_back(sp);

@@ -15,6 +15,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from helpers import assemble, feed, oracle  # noqa: E402
 from reveal_amd import reveallib, reveallib64, shard  # noqa: E402
 
+VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))      # print every configuration before it runs (to find the case behind a GPU fault)
+ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))
 FIELDS = ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums")
 ENVS = [
     {},
@@ -111,6 +113,13 @@ def main():
     while time.time() < t_end:
         seqs, minl = make_case(rng)
         sa64 = rng.random() < 0.2
+        if ONLY >= 0 and ncase != ONLY:      # replay the generator up to one case (FUZZ_ONLY=<case>)
+            for _ in range(2):
+                rng.choice([2, 3, 8, 32]); rng.choice([2, 3, 5])
+            ncase += 1
+            if ncase > ONLY:
+                break
+            continue
         T, nsep, nodes = assemble(seqs)
         O = oracle(sa64)
         c = O.construct(T, nsep, len(seqs))
@@ -126,6 +135,8 @@ def main():
                 idx = feed((reveallib64 if sa64 else reveallib).index(), seqs)
                 idx.construct()
                 tag = "seed %d case %d env %s trace %s sa64 %s (L %d, %d samples, minl %d)" % (seed, ncase, env, trace, sa64, len(seqs[0]), len(seqs), minl)
+                if VERBOSE:
+                    print(tag, file=sys.stderr, flush=True)
                 assert np.array_equal(idx.array("SA"), sa_ref), "SA " + tag
                 assert np.array_equal(idx.array("LCP"), lcp_ref), "LCP " + tag
                 got = idx.align_builtin(minl, 2, trace=trace)
@@ -142,6 +153,8 @@ def main():
         for trace in (True, False):
             stop, nparts = rng.choice([2, 3, 8, 32]), rng.choice([2, 3, 5])
             tag = "seed %d case %d divided stop %d parts %d trace %s sa64 %s" % (seed, ncase, stop, nparts, trace, sa64)
+            if VERBOSE:
+                print(tag, file=sys.stderr, flush=True)
             got = divided(reveallib64 if sa64 else reveallib, seqs, minl, stop, nparts, trace)
             assert anchors_set(got["anchors"]) == ra, "anchors " + tag
             assert shard.lower_text(T, got["anchors"]).tobytes() == ref["T"], "text " + tag

@@ -355,7 +355,7 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         }
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
-                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err));
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err, (u32)std::min<size_t>(vcap, 0xffffffffu)));
         // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
         size_t guess = std::min<size_t>(ocap, h->scan_guess);
         RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));

@@ -36,7 +36,18 @@ void rv_set_error(const char *fmt, ...);
         int r_ = (x);                                                                          \
         if (r_ != 0) return r_;                                                                \
     } while (0)
-#define RV_LAUNCH_CHECK() RV_HIP(hipGetLastError())
+// RV_LAUNCH_TRACE=1 (diagnostics): print the source line of every kernel launch and wait for it, so that a GPU memory fault
+// (which aborts the process) names the kernel behind it
+static inline bool rv_launch_trace_on() { static const int on = getenv("RV_LAUNCH_TRACE") ? 1 : 0; return on != 0; }
+#define RV_LAUNCH_CHECK()                                                                      \
+    do {                                                                                       \
+        RV_HIP(hipGetLastError());                                                             \
+        if (rv_launch_trace_on()) {                                                            \
+            fprintf(stderr, "launch %s:%d\n", __FILE__, __LINE__);                             \
+            fflush(stderr);                                                                    \
+            RV_HIP(hipDeviceSynchronize());                                                    \
+        }                                                                                      \
+    } while (0)
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

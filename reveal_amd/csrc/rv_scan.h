@@ -32,7 +32,7 @@ int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec 
 // Resets *ovf_counter for the next scan.
 #define RV_PAIR_HDR 1
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err);
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err, u32 ovf_cap);
 
 #define RV_MULTI_TILE 256
 struct RvMultiRec { u32 l, n, ub, pad; };

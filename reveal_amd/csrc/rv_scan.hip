@@ -173,7 +173,7 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict__ slots, const RvPairRec *__restrict__ ovf,
                                                      const u32 *__restrict__ tilecnt, const u32 *__restrict__ tileovf,
                                                      const u32 *__restrict__ tileoff, int64_t ntile, RvPairRec *__restrict__ out, u32 out_cap,
-                                                     u32 *__restrict__ ovf_counter, const u32 *__restrict__ err) {
+                                                     u32 *__restrict__ ovf_counter, const u32 *__restrict__ err, u32 ovf_cap) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (id == 0) {
         u32 *hdr = reinterpret_cast<u32 *>(out);
@@ -189,8 +189,9 @@ __global__ __launch_bounds__(TB) void k_pair_compact(const RvPairRec *__restrict
     const u32 o = tileoff[t];
     if (o + j < out_cap) out[o + j] = slots[(size_t)t * RV_PAIR_SLOTS + j];
     const u32 ob = tileovf[t];
+    // (a scan whose overflow did not fit is repeated with a larger buffer: what it could not store must not be read either)
     for (u32 q = RV_PAIR_SLOTS + j; q < cnt; q += RV_PAIR_SLOTS)
-        if (o + q < out_cap) out[o + q] = ovf[ob + (q - RV_PAIR_SLOTS)];
+        if (o + q < out_cap && ob + (q - RV_PAIR_SLOTS) < ovf_cap) out[o + q] = ovf[ob + (q - RV_PAIR_SLOTS)];
 }
 
 // ---- built-in picker on the device --------------------------------------------------
@@ -511,10 +512,10 @@ int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec 
 }
 
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
-                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err) {
+                           const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err, u32 ovf_cap) {
     if (ntile <= 0) return 0;
     hipLaunchKernelGGL(k_pair_compact, dim3((unsigned)ceil_div(ntile * RV_PAIR_SLOTS, TB)), dim3(TB), 0, ws.stream, slots, ovf, tilecnt, tileovf,
-                       tileoff, ntile, out, out_cap, ovf_counter, err);
+                       tileoff, ntile, out, out_cap, ovf_counter, err, ovf_cap);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -68,6 +68,22 @@ def test_construct_synthetic(L, cnt):
     assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))]
 
 
+def test_getmums_dense_hits_overflow():
+    """diverged samples (10 % SNP): tens of thousands of short MUMs, more per 512-rank tile than its own slots hold and more in
+    all than the first overflow buffer -- the scan is repeated with a larger one (and must not read what it could not store)"""
+    seqs = [g.decode() for g in synth.genomes(1500000, 2, seed=5, snp=0.1)]
+    T, nsep, nodes = assemble(seqs)
+    O = oracle(False)
+    c = O.construct(T, nsep, 2)
+    idx = feed(mod(False).index(), seqs)
+    idx.construct()
+    for minl in (12, 11):
+        l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, minl)
+        got = idx.getmums(minl)
+        assert len(got) == len(l) > 30000
+        assert got == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))]
+
+
 def _repeat_cases():
     import random
     rng = random.Random(11)

@@ -128,7 +128,7 @@ struct Align {
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg;
-    HBuf hLeafRoots[2];
+    HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
     hipStream_t bub_stream = nullptr, bub_stream2 = nullptr;      // LDS-resident / one-workgroup bubble kernels run here, beside the main stream's rounds
@@ -181,7 +181,7 @@ struct Align {
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
@@ -1233,23 +1233,29 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
     Align *a = h->al;
     hipStream_t q = h->ws.stream;
     if (a->use_leaf && a->running) {
-        u32 *lf_counters = a->lf_counters; unsigned long long *lf_stats = a->lf_stats; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
-        u32 cnt[4]; unsigned long long stv[4];
+        u32 *lf_counters = a->lf_counters; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
+        // everything through pinned staging (pageable destinations are staged by the runtime, copy by copy: ~0.25 ms per run)
         RV_HIP(hipStreamSynchronize(a->leaf_stream));
         a->leaf_pending[0] = a->leaf_pending[1] = false;
-        RV_HIP(hipMemcpyAsync(cnt, lf_counters, sizeof cnt, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(stv, lf_stats, sizeof stv, hipMemcpyDeviceToHost, q));
+        RV_TRY(a->hLeafOut.reserve(256));
+        RV_HIP(hipMemcpyAsync(a->hLeafOut.p, lf_counters, 128, hipMemcpyDeviceToHost, q));      // counters at +0, statistics at +64
         RV_HIP(hipStreamSynchronize(q));
+        u32 cnt[4]; unsigned long long stv[4];
+        memcpy(cnt, a->hLeafOut.p, sizeof cnt); memcpy(stv, a->hLeafOut.as<uint8_t>() + 64, sizeof stv);
         if (cnt[2]) { rv_set_error("leaf kernel: recursion stack overflow"); return -1; }
         if (cnt[0] > a->leaf_anchor_cap || cnt[1] > a->leaf_trace_cap) { rv_set_error("leaf kernel: output buffer too small"); return -1; }
-        std::vector<u32> ll(cnt[0]); std::vector<int64_t> la_(cnt[0]), lb_(cnt[0]);
         if (cnt[0]) {
-            RV_HIP(hipMemcpy(ll.data(), lf_l, (size_t)cnt[0] * 4, hipMemcpyDeviceToHost));
-            RV_HIP(hipMemcpy(la_.data(), lf_a, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
-            RV_HIP(hipMemcpy(lb_.data(), lf_b, (size_t)cnt[0] * 8, hipMemcpyDeviceToHost));
-        }
-        for (u32 k = 0; k < cnt[0]; k++) {
-            a->an_l.push_back(ll[k]); a->an_pos.push_back(la_[k]); a->an_pos.push_back(lb_[k]); a->an_off.push_back((int64_t)a->an_pos.size());
+            const size_t na = cnt[0];
+            RV_TRY(a->hLeafOut.reserve(na * 20 + 64));
+            int64_t *pa = a->hLeafOut.as<int64_t>(), *pb = pa + na; u32 *pl = (u32 *)(pb + na);
+            RV_HIP(hipMemcpyAsync(pa, lf_a, na * 8, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(pb, lf_b, na * 8, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(pl, lf_l, na * 4, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipStreamSynchronize(q));
+            const size_t at = a->an_l.size(), pat = a->an_pos.size();
+            a->an_l.resize(at + na); a->an_pos.resize(pat + 2 * na); a->an_off.resize(at + na + 1);
+            u32 *ol = a->an_l.data() + at; int64_t *op = a->an_pos.data() + pat, *oo = a->an_off.data() + at + 1;
+            for (size_t k = 0; k < na; k++) { ol[k] = pl[k]; op[2 * k] = pa[k]; op[2 * k + 1] = pb[k]; oo[k] = (int64_t)(pat + 2 * (k + 1)); }
         }
         if (a->trace_on && cnt[1]) {
             const size_t at = a->trace.size();

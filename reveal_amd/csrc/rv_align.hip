@@ -1050,7 +1050,7 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
             RV_TRY(a->dTab0.reserve(pk.size() + 64));
             if (pk.pageable) RV_HIP(hipMemcpyAsync(a->dTab0.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
             else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab0.p, pk.size())); }
-            RV_HIP(hipStreamSynchronize(h->ws.stream));      // (the staging buffer is reused by the first commit)
+            // (the staging buffer is reused by the first commit, which comes after the host has waited for the first scan's result)
             const uint8_t *t0b = a->dTab0.as<uint8_t>();
             a->d_next_ss = (const int64_t *)(t0b + o1); a->d_next_nodes = (const sa_t *)(t0b + o2); a->d_next_flags = t0b + o3; a->d_next_tsub2 = (const int *)(t0b + o4);
             a->cur_dev_ok = true;

@@ -188,8 +188,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
         RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>()));
         h->prof.end(q, id);
-        RV_HIP(hipMemcpyAsync(&h->maxlcp, d_max, 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipStreamSynchronize(q));
+        RV_TRY(rv_read_back(h->ws, &h->maxlcp, d_max, 4));
     } else {
         std::vector<lcp_t> tmp((size_t)n);
         RV_TRY(read_raw(lcpfile, tmp.data(), (size_t)n * sizeof(lcp_t)));
@@ -209,10 +208,13 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         RV_TRY(write_raw(".reveal.lcp", lc.data(), (size_t)n * sizeof(lcp_t)));
     }
     {   // sample separators for the multi-sample scans (SO is derived from them on the fly)
-        std::vector<sa_t> ns(h->nsep.size() + 1, 0);
-        for (size_t k = 0; k < h->nsep.size(); k++) ns[k] = (sa_t)h->nsep[k];
-        RV_TRY(h->dNsep.reserve(ns.size() * sizeof(sa_t)));
-        RV_HIP(hipMemcpy(h->dNsep.p, ns.data(), ns.size() * sizeof(sa_t), hipMemcpyHostToDevice));
+        if (h->nsep_dev != h->nsep || !h->dNsep.p) {      // (a synchronous copy: only when the separators changed)
+            std::vector<sa_t> ns(h->nsep.size() + 1, 0);
+            for (size_t k = 0; k < h->nsep.size(); k++) ns[k] = (sa_t)h->nsep[k];
+            RV_TRY(h->dNsep.reserve(ns.size() * sizeof(sa_t)));
+            RV_HIP(hipMemcpy(h->dNsep.p, ns.data(), ns.size() * sizeof(sa_t), hipMemcpyHostToDevice));
+            h->nsep_dev = h->nsep;
+        }
     }
     h->constructed = true;
     h->main_arrays_freed = false;
@@ -284,6 +286,7 @@ int rv_text_only(rv_index *h, u32 maxlcp) {
     for (size_t k = 0; k < h->nsep.size(); k++) ns[k] = (sa_t)h->nsep[k];
     RV_TRY(h->dNsep.reserve(ns.size() * sizeof(sa_t)));
     RV_HIP(hipMemcpy(h->dNsep.p, ns.data(), ns.size() * sizeof(sa_t), hipMemcpyHostToDevice));
+    h->nsep_dev = h->nsep;
     RV_HIP(hipStreamSynchronize(q));
     h->maxlcp = maxlcp;
     h->constructed = false; h->main_arrays_freed = true; h->text_only = true;

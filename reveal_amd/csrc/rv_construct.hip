@@ -569,8 +569,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         RV_LAUNCH_CHECK();
     }
     u32 hist[256];
-    RV_HIP(hipMemcpyAsync(hist, d_hist.p, sizeof hist, hipMemcpyDeviceToHost, q));
-    RV_HIP(hipStreamSynchronize(q));
+    RV_TRY(rv_read_back(ws, hist, d_hist.p, sizeof hist));
     uint8_t lut[256];
     int sigma = 0;
     for (int c = 0; c < 256; c++) lut[c] = hist[c] ? (uint8_t)(++sigma) : (uint8_t)0;
@@ -638,8 +637,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         RV_HIP(hipMemsetAsync(tile + nt, 0, 4, q));
         RV_TRY(rv_exclusive_sum_u32(ws, tile, tile, nt + 1));
         u32 tot = 0;
-        RV_HIP(hipMemcpyAsync(&tot, tile + nt, 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipStreamSynchronize(q));
+        RV_TRY(rv_read_back(ws, &tot, tile + nt, 4));
         *m_out = tot;
         return 0;
     };
@@ -692,8 +690,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             SA_HIP(hipMemsetAsync(tile + nt, 0, 4, q));
             SA_TRY(rv_exclusive_sum_u32(ws, tile, tile, nt + 1));
             u32 mbig = 0;
-            SA_HIP(hipMemcpyAsync(&mbig, tile + nt, 4, hipMemcpyDeviceToHost, q));
-            SA_HIP(hipStreamSynchronize(q));
+            SA_TRY(rv_read_back(ws, &mbig, tile + nt, 4));
             if (mbig > 0) {
                 u32 *Pb = bPb.as<u32>(), *Qb = bQb.as<u32>();
                 hipLaunchKernelGGL(k_flag_emit, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, (const u32 *)tile, (const u32 *)P, (const sav_t *)S,
@@ -732,7 +729,6 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     }
 #undef SA_TRY
 #undef SA_HIP
-    RV_HIP(hipStreamSynchronize(q));
     freeall();
     if (st) *st = s;
     return 0;

@@ -65,6 +65,7 @@ struct rv_index {
     // ---- host text assembly (interface.c:18-95)
     std::vector<char> T;               // n chars + NUL
     std::vector<int64_t> nsep;
+    std::vector<int64_t> nsep_dev;     // what dNsep holds
     std::vector<RvIntv> nodes;
     int nsamples = 0;
     int64_t n = 0, nT = 0;

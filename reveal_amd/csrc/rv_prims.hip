@@ -3,6 +3,7 @@
 // LDS-staged digit buckets.  Used by the SA build (the reference's divsufsort
 // slot, interface.c:215-222) and by the split/compaction steps.
 #include "rv_common.h"
+#include <string.h>
 
 // ---------------------------------------------------------------------------
 // scans
@@ -266,6 +267,18 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
 __global__ __launch_bounds__(256) void k_h2d_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n16) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) dst[i] = src[i];
 }
+int rv_read_back(Workspace &ws, void *dst, const void *dsrc, size_t bytes) {
+    RV_TRY(ws.hpin.reserve(bytes < 4096 ? 4096 : bytes));
+    if (!ws.ev_rb) RV_HIP(hipEventCreateWithFlags(&ws.ev_rb, hipEventDisableTiming));
+    RV_HIP(hipMemcpyAsync(ws.hpin.p, dsrc, bytes, hipMemcpyDeviceToHost, ws.stream));
+    RV_HIP(hipEventRecord(ws.ev_rb, ws.stream));
+    hipError_t e;
+    while ((e = hipEventQuery(ws.ev_rb)) == hipErrorNotReady) {}
+    if (e != hipSuccess) { rv_set_error("rv_read_back: %s", hipGetErrorString(e)); return -1; }
+    memcpy(dst, ws.hpin.p, bytes);
+    return 0;
+}
+
 int rv_h2d_copy(Workspace &ws, const void *pinned_src, void *dst, size_t bytes) {
     const size_t n16 = (bytes + 15) / 16;
     if (n16 == 0) return 0;

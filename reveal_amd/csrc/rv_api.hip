@@ -464,10 +464,20 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
         h->prof.end(q, id);
         u32 ncand = 0;
         pick_pos.resize((size_t)nsubs * W);
-        RV_HIP(hipMemcpyAsync(&ncand, bcnt.p, 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(pick_l.data(), bl.p, (size_t)nsubs * 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(pick_pos.data(), bpos.p, (size_t)nsubs * W * sizeof(sa_t), hipMemcpyDeviceToHost, q));
-        RV_HIP(hipStreamSynchronize(q));
+        {   // the level's one round trip: three arrays into pinned memory, one polled event (pageable destinations are staged copy by copy)
+            const size_t b1 = (size_t)nsubs * 4, b2 = (size_t)nsubs * W * sizeof(sa_t), o1 = 64, o2 = (o1 + b1 + 63) & ~(size_t)63;
+            RV_TRY(h->ws.hpin.reserve(o2 + b2 + 64));
+            uint8_t *hp = h->ws.hpin.as<uint8_t>();
+            if (!h->ws.ev_rb) RV_HIP(hipEventCreateWithFlags(&h->ws.ev_rb, hipEventDisableTiming));
+            RV_HIP(hipMemcpyAsync(hp, bcnt.p, 4, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(hp + o1, bl.p, b1, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(hp + o2, bpos.p, b2, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipEventRecord(h->ws.ev_rb, q));
+            hipError_t qe;
+            while ((qe = hipEventQuery(h->ws.ev_rb)) == hipErrorNotReady) {}
+            if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; }
+            memcpy(&ncand, hp, 4); memcpy(pick_l.data(), hp + o1, b1); memcpy(pick_pos.data(), hp + o2, b2);
+        }
         if (ncand <= ccap) return 0;
         RV_TRY(bcand.reserve((size_t)ncand * RV_MULTI_CAND_BYTES));
     }

@@ -327,11 +327,11 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
             RV_TRY(h->hscan.reserve((size_t)(nsubs + RV_PAIR_HDR) * sizeof(RvPairRec)));
             picks = h->hscan.as<RvPairRec>();
         }
-        int id = h->prof.begin(q, RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));   /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
+        hipEvent_t ev_a, ev_b;      /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
+        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)), &ev_a, &ev_b);
         RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
                                    (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf,
-                                   bbest.as<unsigned long long>(), picks, d_sub_start ? nsubs : 0));
-        h->prof.end(q, id);
+                                   bbest.as<unsigned long long>(), picks, d_sub_start ? nsubs : 0, ev_a, ev_b));
         if (d_sub_start) {
             // the built-in picker only wants the best record of each sub-index: pick on the device straight from the slots
             RV_TRY(rv_pick_slots_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), (u32)std::min<size_t>(vcap, 0xffffffffu), tilecnt, tileovf, ntile,

@@ -31,6 +31,15 @@ struct RvProf {
         return (int)spans.size() - 1;
     }
     void end(hipStream_t s, int id) { if (id >= 0) (void)hipEventRecord(spans[id].b, s); }
+    // span whose two events are handed to hipExtLaunchKernelGGL: start / stop of that one kernel, no packets of their own
+    int attach(int k, double nbytes, hipEvent_t *ea, hipEvent_t *eb) {
+        *ea = *eb = nullptr;
+        if (!on || !((mask >> k) & 1u)) return -1;
+        Span sp; sp.a = get(); sp.b = get(); sp.k = k; sp.bytes = nbytes;
+        spans.push_back(sp);
+        *ea = sp.a; *eb = sp.b;
+        return (int)spans.size() - 1;
+    }
     void resolve() {   // caller has synchronised the stream
         for (auto &sp : spans) {
             float t = 0.f;

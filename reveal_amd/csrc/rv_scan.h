@@ -22,7 +22,8 @@ struct RvPairRec {
 // nsubs > 0: also initialises the tables of the device-side picker (best, picks) that rv_pick_slots_launch fills.
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
                         RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf,
-                        unsigned long long *best, RvPairRec *picks, int nsubs);
+                        unsigned long long *best, RvPairRec *picks, int nsubs,
+                        hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);   // both given: the kernel's own start / stop (hipExtLaunchKernelGGL)
 // built-in picker straight from the slots (no compaction): picks[0] = header {0, overflow count, *err, 0}, picks[1+s] = longest
 // record of sub-index s (smallest a on ties), rank 0xFFFFFFFF = none; resets *ovf_counter
 int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, u32 ovf_cap, const u32 *tilecnt, const u32 *tileovf, int64_t ntile,

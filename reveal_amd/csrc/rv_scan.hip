@@ -15,6 +15,7 @@
 // free of hot atomics: per-tile slots + a small compaction kernel.
 #include "rv_common.h"
 #include "rv_scan.h"
+#include <hip/hip_ext.h>
 
 namespace {
 
@@ -490,11 +491,15 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 
 int rv_scan_pair_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, sa_t nsep0, int minl,
                         RvPairRec *slots, RvPairRec *ovf, u32 ovf_cap, u32 *ovf_counter, u32 *tilecnt, u32 *tileovf,
-                        unsigned long long *best, RvPairRec *picks, int nsubs) {
+                        unsigned long long *best, RvPairRec *picks, int nsubs, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (m <= 0) return 0;
     const int64_t nb = ceil_div(m, PAIR_TILE);
-    hipLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf,
-                       best, picks, nsubs);
+    if (ev_start && ev_stop)      // timed launch: the events ride on the kernel's own dispatch packet (no marker packets around it)
+        hipExtLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, ev_start, ev_stop, 0, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter,
+                              tilecnt, tileovf, best, picks, nsubs);
+    else
+        hipLaunchKernelGGL(k_scan_pair, dim3((unsigned)nb), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep0, minl, slots, ovf, ovf_cap, ovf_counter, tilecnt, tileovf,
+                           best, picks, nsubs);
     RV_LAUNCH_CHECK();
     return 0;
 }

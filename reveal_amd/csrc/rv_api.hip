@@ -390,8 +390,55 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
                       const int64_t *d_sub_start, const int *d_sub_want, int nsubs) {
     l.clear(); n.clear(); off.assign(1, 0); so.clear(); pos.clear();
     if (ub_out) ub_out->clear();
-    if (mems) { rv_set_error("getmultimems is not implemented on the GPU yet"); return -1; }
     if (h->nsamples < 2) { rv_set_error("multi scan needs at least two samples"); return -1; }
+    if (mems) {
+        /* reveal.c:292-434 by one wavefront (rv_mems.hip).  The sample census of an interval is a 64-bit mask there. */
+        if (h->nsamples > 64) { rv_set_error("getmultimems: more than 64 samples not supported yet"); return -1; }
+        if (m <= 1) return 0;
+        hipStream_t q = h->ws.stream;
+        DBuf &bst = h->ws.misc[11], &brec = h->ws.misc[13], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
+        const int64_t g_cap = (int64_t)h->maxlcp + 16;      // the stack holds strictly increasing LCP values
+        RV_TRY(bst.reserve((size_t)g_cap * 12 + 64));
+        size_t rcap = (size_t)std::max<int64_t>(4096, m / 16), mcap = (size_t)std::max<int64_t>(8192, m / 2);
+        for (int attempt = 0; attempt < 2; attempt++) {
+            RV_TRY(brec.reserve(64 + rcap * 16 + 64));
+            RV_TRY(bso.reserve(mcap * 2 + 64));
+            RV_TRY(bpos.reserve(mcap * sizeof(sa_t) + 64));
+            uint8_t *rb = brec.as<uint8_t>();
+            unsigned long long *d_out = (unsigned long long *)rb;
+            int64_t *rec_first = (int64_t *)(rb + 64); u32 *rec_l = (u32 *)(rec_first + rcap); int32_t *rec_c = (int32_t *)(rec_l + rcap);
+            int64_t *g_lb = bst.as<int64_t>(); u32 *g_lcp = (u32 *)(g_lb + g_cap);
+            int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
+            RV_TRY(rv_multimems_launch(h->ws, SA, LCP, BWT, m, h->dNsep.as<sa_t>(), h->nsamples, minl, minn, g_lcp, g_lb, g_cap, rec_l, rec_c, rec_first,
+                                       bso.as<uint16_t>(), bpos.as<sa_t>(), rcap, mcap, d_out));
+            h->prof.end(q, id);
+            unsigned long long res[3] = {0, 0, 0};
+            RV_TRY(rv_read_back(h->ws, res, d_out, sizeof res));
+            if (res[2]) { rv_set_error("getmultimems: interval stack deeper than the largest LCP value"); return -1; }
+            if (res[0] <= rcap && res[1] <= mcap) {
+                const size_t nr = (size_t)res[0], nm = (size_t)res[1];
+                std::vector<int64_t> first(nr); std::vector<int32_t> cc(nr); std::vector<uint16_t> rso(nm); std::vector<sa_t> rpos(nm);
+                l.resize(nr);
+                if (nr) {
+                    RV_HIP(hipMemcpy(first.data(), rec_first, nr * 8, hipMemcpyDeviceToHost));
+                    RV_HIP(hipMemcpy(l.data(), rec_l, nr * 4, hipMemcpyDeviceToHost));
+                    RV_HIP(hipMemcpy(cc.data(), rec_c, nr * 4, hipMemcpyDeviceToHost));
+                }
+                if (nm) {
+                    RV_HIP(hipMemcpy(rso.data(), bso.p, nm * 2, hipMemcpyDeviceToHost));
+                    RV_HIP(hipMemcpy(rpos.data(), bpos.p, nm * sizeof(sa_t), hipMemcpyDeviceToHost));
+                }
+                n.assign(cc.begin(), cc.end());
+                off.assign(first.begin(), first.end()); off.push_back((int64_t)nm);
+                so.assign(rso.begin(), rso.end());
+                pos.assign(rpos.begin(), rpos.end());
+                return 0;
+            }
+            rcap = std::max<size_t>(rcap, (size_t)res[0]); mcap = std::max<size_t>(mcap, (size_t)res[1]);
+        }
+        rv_set_error("getmultimems: output buffer sizing failed");
+        return -1;
+    }
     if (m <= 1) return 0;
     hipStream_t q = h->ws.stream;
     const int64_t ntile = ceil_div(m, RV_MULTI_TILE);
@@ -490,7 +537,12 @@ extern "C" {
 /* reveal.c:436-580 / 292-434 */
 int64_t rv_getmultimums(rv_index *h, int minlength, int minn, int mems, int64_t *members) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return -2; }
-    if (h->nsamples <= 2) { rv_set_error("getmultimums needs more than two samples (SO not available)"); return -1; }
+    if (h->nsamples <= 2) {
+        /* two samples, getmultimems: every qualifying interval counts one "sample" (the flag_so index trick, reveal.c:268) and
+         * leaves through `continue` when minn >= 2: an empty list.  (With minn < 2 the reference dereferences the missing SO.) */
+        if (mems && h->nsamples == 2 && minn >= 2) { h->mm_l.clear(); h->mm_n.clear(); h->mm_off.assign(1, 0); h->mm_so.clear(); h->mm_pos.clear(); if (members) *members = 0; return 0; }
+        rv_set_error("getmultimums needs more than two samples (SO not available)"); return -1;
+    }
     (void)hipSetDevice(h->device);
     if (rv_run_multi_scan(h, h->dSA.as<sa_t>(), h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), h->n, minlength, minn, mems, h->mm_l, h->mm_n, h->mm_off, h->mm_so, h->mm_pos, nullptr, nullptr, nullptr, 0)) return -1;
     if (members) *members = (int64_t)h->mm_pos.size();

@@ -44,6 +44,11 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
                          const int64_t *sub_start, const int *sub_want, int nsubs);   // sub_want != NULL: keep only matches with n == sub_want[sub of ub]
 
+// getmultimems (reveal.c:292-434) replayed by one wavefront (rv_mems.hip); counts beyond the capacities are still counted
+int rv_multimems_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int nsamples, int minl, int minn,
+                        u32 *g_lcp, int64_t *g_lb, int64_t g_cap, u32 *rec_l, int32_t *rec_c, int64_t *rec_first, uint16_t *so, sa_t *pos,
+                        unsigned long long rec_cap, unsigned long long mem_cap, unsigned long long *out);
+
 // Built-in picker for more than two samples: per sub-index the longest match present in every one of its samples
 // (ties: smallest minimum position).  pick_l[s] = its length (0 = none), pick_pos[s*nsamples ..] = its members in SA order.
 // *cand_count > cand_cap afterwards: the candidate list was too small, grow and rerun.

@@ -100,6 +100,43 @@ def test_getmultimums(inputs, minl, minn):
     assert idx.getmultimums(minlength=minl, minn=minn) == ref
 
 
+@pytest.mark.parametrize("inputs,minl,minn,sa64", [
+    (fa("1a", "1b", "1c"), 20, 2, False), (fa("1a", "1b", "1c"), 8, 2, False), (fa("1a", "1b", "1c"), 20, 3, False), (fa("1a", "1b", "1c"), 4, 3, False),
+    (fa("1a", "1b", "1c", "1d", "1e"), 20, 2, False), (fa("1a", "1b", "1c", "1d", "1e"), 12, 5, False), (fa("1a", "1b", "1c", "1d", "1e"), 6, 4, True),
+    (["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"], 2, 2, False),
+    (["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG", "ACTTGCTAGGTAGTCAG"], 1, 3, False),
+    (fa("1a", "1a", "1b"), 15, 3, False),          # a repeated sample: intervals with many members from few samples (the `continue` path)
+])
+def test_getmultimems(inputs, minl, minn, sa64):
+    """reveal.c:292-434 incl. its order dependence (a multi-MEM covering fewer than minn samples leaves the loop body before
+    `lb = i_lb`, reveal.c:340-342 / :362): same list, same order as the oracle's restatement (pinned against the reference)"""
+    T, nsep, nodes = assemble(inputs)
+    O = oracle(sa64)
+    c = O.construct(T, nsep, len(inputs))
+    ref = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, len(inputs), minl, minn, mems=True))
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct()
+    got = idx.getmultimems(minlength=minl, minn=minn)
+    assert len(got) == len(ref)
+    assert got == ref
+
+
+def test_getmultimems_synthetic_and_two_samples():
+    seqs = [g.decode() for g in synth.genomes(120000, 4, seed=11)]
+    T, nsep, nodes = assemble(seqs)
+    O = oracle(False)
+    c = O.construct(T, nsep, 4)
+    idx = feed(mod(False).index(), seqs)
+    idx.construct()
+    for minl, minn in ((18, 2), (14, 4), (25, 3)):
+        ref = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, 4, minl, minn, mems=True))
+        assert idx.getmultimems(minlength=minl, minn=minn) == ref and len(ref) > 100
+    # two samples: every qualifying interval counts one "sample" and is skipped for minn >= 2 (reveal.c:268, :340): empty
+    pair = feed(mod(False).index(), seqs[:2])
+    pair.construct()
+    assert pair.getmultimems(minlength=20, minn=2) == []
+
+
 @pytest.mark.parametrize("par_min", [0, 64, 1000])
 @pytest.mark.parametrize("name,inputs,minl,sa64", [
     ("t1t2", fa("t1", "t2"), 1, False),

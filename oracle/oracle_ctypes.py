@@ -54,6 +54,10 @@ class Oracle:
                                self.c_lcp, V, V, V]
         L.ro_split.argtypes = [V, V, c_sa, V, V] + [V] * 6 + [V] * 3
         L.ro_bubble_sort.argtypes = [V, V, c_sa, V, V, ctypes.c_int]
+        L.ro_splitindex.argtypes = [V, V, V, c_sa, V, V, V, ctypes.c_int] + [V, ctypes.c_int] * 4 + [V] * 6 + [V, V]
+        L.ro_splitindex.restype = None
+        L.ro_extract.argtypes = [V, V, V, c_sa, V, V, c_sa, ctypes.c_int, V, ctypes.c_int, V, V]
+        L.ro_extract.restype = c_sa
         L.ro_align.argtypes = [V, V, V, c_sa, V, ctypes.c_int, V, V, V, ctypes.c_int, ctypes.c_int,
                                V, ctypes.c_int64, V]
         L.ro_align.restype = ctypes.c_int
@@ -207,6 +211,33 @@ class Oracle:
     def bubble_sort(self, SA, LCP, SAi, match_begins):
         mb = np.ascontiguousarray(np.asarray(match_begins, dtype=self.sa_t))
         self.lib.ro_bubble_sort(SA.ctypes.data, LCP.ctypes.data, len(SA), SAi.ctypes.data, mb.ctypes.data, len(mb))
+
+    # -- host-driven single steps (reveal.c:1386-1748) -----------------------------
+    def splitindex(self, tbuf, SA, LCP, SAi, SO, nsep, main_nsamples, lead, trail, match, rest):
+        """ro_splitindex: tbuf is lower-cased and SAi rewritten in place.
+        -> [(SA, LCP, nsamples) | None] * 3 for the leading, trailing and parallel child"""
+        la, nl_ = self._iv(lead); ta, nt_ = self._iv(trail); ma, nm_ = self._iv(match); ra, nr_ = self._iv(rest)
+        sizes = [int((x[:, 1] - x[:, 0]).sum()) if len(x) else 0 for x in (la, ta, ra)]
+        kids = [(np.zeros(max(c, 1), dtype=self.sa_t), np.zeros(max(c, 1), dtype=self.lcp_t)) for c in sizes]
+        counts = np.zeros(3, dtype=self.sa_t); ns = np.zeros(3, dtype=np.int32)
+        nsep = np.ascontiguousarray(np.asarray(nsep, dtype=self.sa_t))
+        self.lib.ro_splitindex(tbuf.ctypes.data, SA.ctypes.data, LCP.ctypes.data, len(SA), SAi.ctypes.data, _ptr(SO), nsep.ctypes.data,
+                               main_nsamples, la.ctypes.data, nl_, ta.ctypes.data, nt_, ma.ctypes.data, nm_, ra.ctypes.data, nr_,
+                               kids[0][0].ctypes.data, kids[0][1].ctypes.data, kids[1][0].ctypes.data, kids[1][1].ctypes.data,
+                               kids[2][0].ctypes.data, kids[2][1].ctypes.data, counts.ctypes.data, ns.ctypes.data)
+        return [(k[0][:c], k[1][:c], int(q)) if c > 0 else None for k, c, q in zip(kids, counts.tolist(), ns)]
+
+    def extract(self, tbuf, SA, LCP, SAi, nsep, intervals, rc=0, nT=None):
+        """ro_extract: tbuf lower-cased, SAi rewritten in place -> (SA, LCP, intervals after the rc remap)"""
+        iv, niv = self._iv(intervals)
+        iv = iv.copy()
+        oSA = np.zeros(max(len(SA), 1), dtype=self.sa_t); oLCP = np.zeros(max(len(SA), 1), dtype=self.lcp_t)
+        nsep = np.ascontiguousarray(np.asarray(nsep, dtype=self.sa_t))
+        nn = self.lib.ro_extract(tbuf.ctypes.data, SA.ctypes.data, LCP.ctypes.data, len(SA), SAi.ctypes.data, nsep.ctypes.data,
+                                 nT if nT is not None else len(SA), rc, iv.ctypes.data, niv, oSA.ctypes.data, oLCP.ctypes.data)
+        if nn < 0:
+            raise ValueError("extract: rank 0 is matched (the reference overruns its buffers there)")
+        return oSA[:nn].copy(), oLCP[:nn].copy(), [(int(b), int(e)) for b, e in iv]
 
     # -- the recursion with the bench callbacks --------------------------------
     def align_bench(self, cons, nodes, minl, minn=2, trace_cap=0, anchor_cap=None):

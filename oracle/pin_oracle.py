@@ -12,6 +12,10 @@ and oracle/_ref/ built by `make -C oracle ref`).  For every fixture set:
     through SAi as reveal.c:1005-1117) with the bench picker / linear
     graphalign, compared step by step (sub-index key, n, depth, nsamples,
     scan result, chosen match, child SA and LCP hashes) with ro_align's trace.
+  * splitindex (reveal.c:1515-1748): ro_splitindex == label scatter + the
+    reference's split + bubble_sort, two steps deep; extract (reveal.c:1386-1505):
+    ro_extract == the reference's own extract() (ranks 1.. of SA -- the reference
+    never writes SA[0] -- LCP, SAi, T), also with rc=1 interval remapping.
   * the known-answer vectors of SURVEY.md 8(c).
 
 Exit code 0 = every check passed.  `python oracle/pin_oracle.py [--big]`.
@@ -252,6 +256,82 @@ def pin_set(label, files, sa64, minl=20, minn=2, recursion=True, own_sa=True):
         check("final T (lower-case mask)", bytes(tb_r[:n]) == res["T"], "%d lower" % sum(1 for c in res["T"] if 97 <= c <= 122))
 
 
+
+def pin_single_steps(label, files, sa64, minl=20, minn=2):
+    """splitindex / extract of reveal.c:1386-1748, driven like the commented loop rem.py:580-609"""
+    print("[single steps: %s]%s" % (label, " (64-bit)" if sa64 else ""))
+    R = ref_ctypes.Ref(sa64)
+    O = oracle_ctypes.Oracle(sa64)
+    T, nsep, nodes = assemble(files)
+    n, ns = len(T), len(files)
+    tb_r, tb_o = R.textbuf(T), O.textbuf(T)
+    SA = R.divsufsort(tb_r[:n]); SAi = R.inverse(SA); LCP = R.compute_lcp(tb_r, SA, SAi)
+    SO = R.build_so(nsep, ns, n) if ns > 2 else None
+    SAi_r, SAi_o = SAi.copy(), SAi.copy()
+    main = R.view(tb_r, SA, LCP, nsep, ns, SAi=SAi_r, SO=SO)
+    work = [(SA, LCP, list(nodes), ns, 0)]
+    steps = 0
+    first_match = None
+    while work and steps < 7:
+        sa, lcp, nd, nsub, depth = work.pop(0)
+        ri = R.view(tb_r, sa, lcp, nsep, ns, SAi=SAi_r, SO=SO, nT=n, main=main)
+        mums = R.getmultimums(ri, minl, minn) if ns > 2 else R.getmums_rem(ri, minl)
+        mum = bench_picker(mums, nsub)
+        if mum is None:
+            continue
+        lead, trail, match, rest = linear_graphalign(nd, mum)
+        if first_match is None:
+            first_match = match
+        # reference side: label (scatter, reveal.c:1548-1640) + split + bubble_sort
+        D = np.zeros(len(sa), dtype=np.uint8)
+        cnt = [0, 0, 0]
+        for b, e in lead:
+            D[SAi_r[b:e]] = 1; cnt[0] += e - b
+        for b, e in trail:
+            D[SAi_r[b:e]] = 2; cnt[1] += e - b
+        for b, e in match:
+            D[SAi_r[b:e]] = 3
+            seg = tb_r[b:e]; up = (seg >= 65) & (seg <= 90); seg[up] += 32
+        for b, e in rest:
+            D[SAi_r[b:e]] = 4; cnt[2] += e - b
+        kids_r = R.split(ri, D, *cnt)
+        if kids_r[0] is not None:
+            R.bubble_sort(tb_r, kids_r[0][0], kids_r[0][1], SAi_r, match)
+        kids_o = O.splitindex(tb_o, sa, lcp, SAi_o, SO, nsep, ns, lead, trail, match, rest)
+        ok = all((a is None) == (b is None) and (a is None or (np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]))) for a, b in zip(kids_r, kids_o))
+        # (SAi entries of dropped ranks keep stale values on both sides)
+        ok = ok and np.array_equal(SAi_r, SAi_o) and bytes(tb_r) == bytes(tb_o)
+        check("splitindex step %d (depth %d, n=%d, l=%d)" % (steps, depth, len(sa), mum[0]), ok)
+        for k, ivs in enumerate((lead, trail, rest)):
+            if kids_o[k] is not None:
+                work.append((kids_o[k][0], kids_o[k][1], ivs, kids_o[k][2], depth + 1))
+        steps += 1
+    # extract on the untouched main index: the first match of the run above, then a second, disjoint set on the result
+    for rc in (0, 1):
+        tb_r, tb_o = R.textbuf(T), O.textbuf(T)
+        SAi_r, SAi_o = SAi.copy(), SAi.copy()
+        ivs = list(first_match) if first_match else [(1, 3)]
+        if rc == 1:       # hand in query-side intervals in reverse-complement coordinates (reveal.c:1411-1427 maps them back)
+            ivs = [(b, e) if b <= nsep[0] else (nsep[0] + n - e, nsep[0] + n - b) for b, e in ivs]
+        sa_r, lcp_r, iv_r = R.extract(tb_r, SA, LCP, SAi_r, nsep, ivs, rc=rc, nT=n)
+        sa_o, lcp_o, iv_o = O.extract(tb_o, SA, LCP, SAi_o, nsep, ivs, rc=rc, nT=n)
+        ok = len(sa_r) == len(sa_o) and np.array_equal(sa_r[1:], sa_o[1:]) and np.array_equal(lcp_r, lcp_o) and sa_o[0] == SA[0]
+        ok = ok and np.array_equal(SAi_r, SAi_o) and bytes(tb_r) == bytes(tb_o)
+        check("extract (rc=%d, %d intervals, %d -> %d ranks)" % (rc, len(ivs), n, len(sa_o)), ok)
+        if rc == 0:
+            check("extract rc=0 leaves the intervals alone", iv_o == [(int(b), int(e)) for b, e in ivs])
+        else:
+            check("extract rc=1 remaps query intervals", iv_o == [(int(b), int(e)) for b, e in first_match] if first_match else True)
+        if rc == 0 and first_match:
+            b0 = first_match[0][0]
+            second = [(max(b0 - 40, nodes[0][0]), max(b0 - 25, nodes[0][0] + 1))]
+            if second[0][0] < second[0][1] <= b0:
+                sa_r2, lcp_r2, _ = R.extract(tb_r, sa_o, lcp_o, SAi_r, nsep, second, nT=n)
+                sa_o2, lcp_o2, _ = O.extract(tb_o, sa_o, lcp_o, SAi_o, nsep, second, nT=n)
+                ok = np.array_equal(sa_r2[1:], sa_o2[1:]) and np.array_equal(lcp_r2, lcp_o2) and np.array_equal(SAi_r, SAi_o) and bytes(tb_r) == bytes(tb_o)
+                check("extract again on the result (%d ranks)" % len(sa_o2), ok)
+
+
 def known_answers():
     print("[known answers, SURVEY.md 8(c)]")
     for sa64 in (False, True):
@@ -295,6 +375,10 @@ def main():
     pin_set("1a+1brc", f("1a", "1brc"), False)
     pin_set("1a+1a (identical)", f("1a", "1a"), False)
     pin_set("2a+2b", f("2a", "2b"), False, own_sa=big)
+    pin_single_steps("1a+1b", f("1a", "1b"), False)
+    pin_single_steps("1a+1b", f("1a", "1b"), True)
+    pin_single_steps("1a+1b+1c", f("1a", "1b", "1c"), False)
+    pin_single_steps("1e+1b (multi-contig)", f("1e", "1b"), False)
     if big:
         pin_set("3a+3b", f("3a", "3b"), False, own_sa=False)
         pin_set("1a+1b+1c (3-way)", f("1a", "1b", "1c"), True)

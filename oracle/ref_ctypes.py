@@ -12,6 +12,7 @@ the reference's plain-C entry points:
     getmultimums / getmultimems    reveallib/reveal.c:436 / :292
     split                          reveallib/reveal.c:582
     bubble_sort                    reveallib/reveal.c:666
+    extract                        reveallib/reveal.c:1386
 
 Nothing here is importable by the product (reveal_amd/); tests, golden-vector
 generation and pinning of the CPU restatement only.  Opened RTLD_LAZY because
@@ -71,6 +72,8 @@ class Ref:
         L.split.restype = None
         L.bubble_sort.argtypes = [ctypes.POINTER(RevealIndex), ctypes.py_object]
         L.bubble_sort.restype = None
+        L.extract.argtypes = [ctypes.POINTER(RevealIndex), ctypes.py_object, ctypes.py_object]
+        L.extract.restype = ctypes.py_object
 
     def divsufsort_addr(self):
         return ctypes.cast(self._dss, ctypes.c_void_p).value
@@ -171,3 +174,28 @@ class Ref:
         c.T = tbuf.ctypes.data
         c.SA, c.LCP, c.SAi, c.n = SA.ctypes.data, LCP.ctypes.data, SAi.ctypes.data, len(SA)
         self.lib.bubble_sort(ctypes.byref(c), [(int(b), int(e)) for b, e in matching])
+
+    def extract(self, tbuf, SA, LCP, SAi, nsep, intervals, rc=0, nT=None):
+        """reference extract() (reveal.c:1386-1505).  It frees idx->SA / idx->LCP and
+        installs malloc'ed replacements, so the struct gets malloc'ed copies.  tbuf and
+        SAi are modified in place.  -> (SA, LCP, intervals) with SA[0] = whatever the
+        heap held (the reference never writes it)."""
+        libc = ctypes.CDLL(None)
+        libc.malloc.restype = ctypes.c_void_p
+        libc.malloc.argtypes = [ctypes.c_size_t]
+        libc.free.argtypes = [ctypes.c_void_p]
+        c = self.RevealIndex()
+        c.ob_refcnt = 1 << 30
+        sa_p = libc.malloc(max(SA.nbytes, 8)); lcp_p = libc.malloc(max(LCP.nbytes, 8))
+        ctypes.memmove(sa_p, SA.ctypes.data, SA.nbytes); ctypes.memmove(lcp_p, LCP.ctypes.data, LCP.nbytes)
+        nsep = np.ascontiguousarray(np.asarray(nsep, dtype=self.sa_t))
+        c.T, c.SA, c.LCP, c.SAi, c.n = tbuf.ctypes.data, sa_p, lcp_p, SAi.ctypes.data, len(SA)
+        c.nT = nT if nT is not None else len(SA)
+        c.nsep, c.rc = nsep.ctypes.data, rc
+        iv = [(int(b), int(e)) for b, e in intervals]
+        self.lib.extract(ctypes.byref(c), (iv,), None)
+        nn = int(c.n)
+        oSA = np.ctypeslib.as_array(ctypes.cast(c.SA, ctypes.POINTER(self.c_sa)), shape=(max(nn, 1),))[:nn].astype(self.sa_t)
+        oLCP = np.ctypeslib.as_array(ctypes.cast(c.LCP, ctypes.POINTER(self.c_lcp)), shape=(max(nn, 1),))[:nn].astype(self.lcp_t)
+        libc.free(c.SA); libc.free(c.LCP)
+        return oSA, oLCP, iv

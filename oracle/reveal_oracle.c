@@ -441,6 +441,118 @@ void ro_bubble_sort(ro_saidx_t *SA, ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi
 }
 
 /* ------------------------------------------------------------------------ */
+/* host-driven single steps: splitindex / extract (reveal.c:1386-1748)       */
+/* ------------------------------------------------------------------------ */
+
+/* sample count of an interval list, reveal.c:1552-1567 (the same rule as the aligner's, reveal.c:1028-1042) */
+static int count_samples_raw(const ro_saidx_t *iv, int niv, const uint16_t *SO, const ro_saidx_t *nsep, int main_nsamples) {
+    int ns = 0;
+    int *flag = (int *)calloc((size_t)(main_nsamples > 2 ? main_nsamples : 2), sizeof(int));
+    for (int k = 0; k < niv; k++) {
+        ro_saidx_t begin = iv[2 * k];
+        if (main_nsamples > 2) {
+            if (flag[SO[begin]] == 0) { flag[SO[begin]] = 1; ns++; }
+        } else {
+            if (begin < nsep[0] && flag[0] == 0) { flag[0] = 1; ns++; }
+            if (begin > nsep[0] && flag[1] == 0) { flag[1] = 1; ns++; }
+        }
+    }
+    free(flag);
+    return ns;
+}
+
+/* splitindex (reveal.c:1515-1748): D-label from the four interval lists in the
+ * reference's order (leading 1, trailing 2, matching 3 + lower-casing, rest 4),
+ * split, bubble_sort of the leading child over the matching intervals in the
+ * order given.  Child arrays are caller-allocated (sum of the interval lengths
+ * each); counts[3] / nsamples[3] receive leadingn/trailingn/parn and the
+ * children's sample counts. */
+void ro_splitindex(char *T, const ro_saidx_t *SA, const ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi,
+                   const uint16_t *SO, const ro_saidx_t *nsep, int main_nsamples,
+                   const ro_saidx_t *lead, int nlead, const ro_saidx_t *trail, int ntrail,
+                   const ro_saidx_t *match, int nmatch, const ro_saidx_t *rest, int nrest,
+                   ro_saidx_t *lSA, ro_lcp_t *lLCP, ro_saidx_t *tSA, ro_lcp_t *tLCP, ro_saidx_t *pSA, ro_lcp_t *pLCP,
+                   ro_saidx_t *counts, int *nsamples) {
+    uint8_t *D = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    ro_saidx_t j, leadingn = 0, trailingn = 0, parn = 0;
+    for (int k = 0; k < nlead; k++)  for (j = lead[2 * k];  j < lead[2 * k + 1];  j++) { D[SAi[j]] = 1; leadingn++; }     /* :1548-1551 */
+    for (int k = 0; k < ntrail; k++) for (j = trail[2 * k]; j < trail[2 * k + 1]; j++) { D[SAi[j]] = 2; trailingn++; }   /* :1583-1586 */
+    for (int k = 0; k < nmatch; k++) for (j = match[2 * k]; j < match[2 * k + 1]; j++) {                                 /* :1618-1621 */
+        D[SAi[j]] = 3;
+        if (T[j] >= 'A' && T[j] <= 'Z') T[j] = (char)(T[j] + 32);
+    }
+    for (int k = 0; k < nrest; k++)  for (j = rest[2 * k];  j < rest[2 * k + 1];  j++) { D[SAi[j]] = 4; parn++; }        /* :1637-1640 */
+    counts[0] = leadingn; counts[1] = trailingn; counts[2] = parn;
+    nsamples[0] = count_samples_raw(lead, nlead, SO, nsep, main_nsamples);
+    nsamples[1] = count_samples_raw(trail, ntrail, SO, nsep, main_nsamples);
+    nsamples[2] = count_samples_raw(rest, nrest, SO, nsep, main_nsamples);
+    ro_saidx_t il = 0, it = 0, ip = 0;
+    ro_split(SA, LCP, n, D, SAi, lSA, lLCP, tSA, tLCP, pSA, pLCP, &il, &it, &ip);                                        /* :1738 */
+    if (leadingn > 0) {                                                                                                   /* :1740-1742 */
+        ro_saidx_t *mb = (ro_saidx_t *)malloc(sizeof(ro_saidx_t) * (size_t)(nmatch > 0 ? nmatch : 1));
+        for (int k = 0; k < nmatch; k++) mb[k] = match[2 * k];
+        ro_bubble_sort(lSA, lLCP, il, SAi, mb, nmatch);
+        free(mb);
+    }
+    free(D);
+}
+
+/* extract (reveal.c:1386-1505): drop the suffixes of the given intervals from
+ * the index in place (here: into oSA / oLCP, n - matching entries), lower-case
+ * them, bubble_sort over the intervals.  With rc==1 query-side intervals are
+ * remapped first (:1411-1427; the remapped pairs are written back to
+ * `intervals`, as the reference replaces the list items).
+ * The reference never writes _SA[0] (its loop starts at i=1, j=1; :1454-1460):
+ * the entry is uninitialised heap there.  Here it is SA[0], the evident intent
+ * (rank 0 stays rank 0); pinning compares ranks 1.. and SAi.  When rank 0
+ * itself is matched the reference writes one entry past both buffers: -1 here.
+ * Returns the new n. */
+ro_saidx_t ro_extract(char *T, const ro_saidx_t *SA, const ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi,
+                      const ro_saidx_t *nsep, ro_saidx_t nT, int rc,
+                      ro_saidx_t *intervals, int niv, ro_saidx_t *oSA, ro_lcp_t *oLCP) {
+    uint8_t *D = (uint8_t *)calloc((size_t)(n > 0 ? n : 1), 1);
+    ro_saidx_t i, j, matching = 0;
+    for (int k = 0; k < niv; k++) {
+        ro_saidx_t begin = intervals[2 * k], end = intervals[2 * k + 1];
+        if (rc == 1 && begin > nsep[0]) {
+            ro_saidx_t b2 = nsep[0] + (nT - begin - (end - begin));
+            ro_saidx_t e2 = nsep[0] + (nT - begin);
+            begin = b2; end = e2;
+            intervals[2 * k] = begin; intervals[2 * k + 1] = end;
+        }
+        for (j = begin; j < end; j++) {
+            D[SAi[j]] = 3;
+            if (T[j] >= 'A' && T[j] <= 'Z') T[j] = (char)(T[j] + 32);
+            matching++;
+        }
+    }
+    if (n > 0 && D[0] == 3) { free(D); return -1; }
+    ro_lcp_t minlcp = 0;
+    j = 1;
+    oLCP[0] = 0;
+    oSA[0] = SA[0];
+    for (i = 1; i < n; i++) {
+        if (D[i] != 3) {
+            oSA[j] = SA[i];
+            SAi[oSA[j]] = j;
+            if (D[i - 1] == 3) oLCP[j] = (minlcp < LCP[i]) ? minlcp : LCP[i];
+            else oLCP[j] = LCP[i];
+            j++;
+        } else {
+            if (D[i - 1] != 3) minlcp = LCP[i];
+            else if (LCP[i] < minlcp) minlcp = LCP[i];
+        }
+    }
+    free(D);
+    ro_saidx_t nn = n - matching;
+    ro_saidx_t *mb = (ro_saidx_t *)malloc(sizeof(ro_saidx_t) * (size_t)(niv > 0 ? niv : 1));
+    for (int k = 0; k < niv; k++) mb[k] = intervals[2 * k];
+    ro_bubble_sort(oSA, oLCP, nn, SAi, mb, niv);                                                                          /* :1496 */
+    free(mb);
+    return nn;
+}
+
+/* ------------------------------------------------------------------------ */
 /* aligner loop (reveal.c:731-1338; queue reveal.c:18-53)                   */
 /* ------------------------------------------------------------------------ */
 

@@ -113,6 +113,24 @@ void ro_split(const ro_saidx_t *SA, const ro_lcp_t *LCP, ro_saidx_t n, const uin
 void ro_bubble_sort(ro_saidx_t *SA, ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi,
                     const ro_saidx_t *match_begin, int nmatch);
 
+/* ---- host-driven single steps (reveal.c:1386-1748) ---------------------- */
+
+/* splitindex (reveal.c:1515-1748) = label from interval lists + split +
+ * bubble_sort(leading, matching).  Interval lists are (begin,end) pairs. */
+void ro_splitindex(char *T, const ro_saidx_t *SA, const ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi,
+                   const uint16_t *SO, const ro_saidx_t *nsep, int main_nsamples,
+                   const ro_saidx_t *lead, int nlead, const ro_saidx_t *trail, int ntrail,
+                   const ro_saidx_t *match, int nmatch, const ro_saidx_t *rest, int nrest,
+                   ro_saidx_t *lSA, ro_lcp_t *lLCP, ro_saidx_t *tSA, ro_lcp_t *tLCP, ro_saidx_t *pSA, ro_lcp_t *pLCP,
+                   ro_saidx_t *counts, int *nsamples);
+
+/* extract (reveal.c:1386-1505); returns the new n (-1: rank 0 matched, where
+ * the reference overruns its buffers).  oSA[0] = SA[0] (never written by the
+ * reference). */
+ro_saidx_t ro_extract(char *T, const ro_saidx_t *SA, const ro_lcp_t *LCP, ro_saidx_t n, ro_saidx_t *SAi,
+                      const ro_saidx_t *nsep, ro_saidx_t nT, int rc,
+                      ro_saidx_t *intervals, int niv, ro_saidx_t *oSA, ro_lcp_t *oLCP);
+
 /* ---- aligner work loop (reveal.c:731-1338, interface.c:293-415) -------- */
 
 typedef struct { ro_saidx_t begin, end; } ro_intv;

@@ -196,6 +196,31 @@ int rv_set_trace(rv_index *h, int on);
 int64_t rv_trace_count(rv_index *h);
 int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);
 
+/* ---- host-driven single steps: copy / splitindex / extract ----------------------
+ * (interface.c:432-470 copy, reveal.c:1515-1748 splitindex, reveal.c:1386-1505 extract; public methods of the
+ * reference's index type with no live caller in its package -- the Python-driven form of the recursion that
+ * rem.py:580-609 sketches: scan a (sub)index, split it, go on with the children it returns.)
+ * A detached (sub)index owns SA / LCP (and BWT) in HBM and borrows text, shared inverse and separators of its main
+ * handle, like the reference's child objects (reveal.c:1679-1735); it must be freed before the handle. */
+typedef struct rv_subindex rv_subindex;
+rv_index *rv_clone(rv_index *h);                      /* copy() of a main index: an independent handle (own text and arrays) */
+rv_subindex *rv_sx_main(rv_index *h);                 /* the constructed main index as a detached (depth 0) index; NULL on failure */
+rv_subindex *rv_sx_copy(rv_subindex *x);
+void rv_sx_free(rv_subindex *x);
+int rv_sx_info(const rv_subindex *x, rv_sub *out);    /* n, depth, nsamples, nnodes */
+int rv_sx_nodes(const rv_subindex *x, int64_t *begin_end);
+int64_t rv_sx_array(rv_subindex *x, int which, void *out, int64_t cap);      /* RV_SA, RV_LCP */
+/* getmums / getmultimums over this index: number of matches (members through *members); rv_sx_fetch hands them out in
+ * the CSR form of rv_sub_mums */
+int64_t rv_sx_scan(rv_subindex *x, int minl, int minn, int64_t *members);
+int rv_sx_fetch(rv_subindex *x, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos);
+/* splitindex: interval lists as (begin,end) pairs; out[0..2] = leading, trailing, parallel child or NULL.  Lower-cases
+ * the matching intervals, bubble_sorts the leading child over them in the order given.  x itself keeps its arrays. */
+int rv_sx_split(rv_subindex *x, const int64_t *lead, int nlead, const int64_t *trail, int ntrail,
+                const int64_t *match, int nmatch, const int64_t *rest, int nrest, rv_subindex **out);
+/* extract, in place.  `intervals` is rewritten where construct(rc=1) makes the reference remap it (reveal.c:1411-1427). */
+int rv_sx_extract(rv_subindex *x, int64_t *intervals, int niv);
+
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,

@@ -65,6 +65,15 @@ def one(label, inputs, minl, minn=2, sa64=False):
     if ns > 2:
         mm = R.getmultimums(ri, minl, minn)
         rec["getmultimums"] = dict(count=len(mm), sha=hashlib.sha256(json.dumps(mm).encode()).hexdigest(), head=mm[:4])
+    # extract() (reveal.c:1386-1505) of the longest full match, on fresh copies; the reference never writes the new SA[0]
+    full = [m for m in (R.getmultimums(ri, minl, minn) if ns > 2 else R.getmums_rem(ri, minl)) if m[1] == ns]
+    if full and n > 64:
+        pick = P.bench_picker(full, ns)
+        ivs = [(int(p), int(p) + int(pick[0])) for _, p in pick[2]]
+        tb2, SAi2 = R.textbuf(T), SAi.copy()
+        xsa, xlcp, _ = R.extract(tb2, SA, LCP, SAi2, nsep, ivs, nT=n)
+        rec["extract"] = dict(intervals=ivs, n=len(xsa), sha_SA1=sha(xsa[1:].astype(np.int64)), sha_LCP=sha(xlcp.astype(np.int64)),
+                              sha_T=hashlib.sha256(bytes(tb2[:n])).hexdigest())
     trace = list(P.ref_recursion(R, tb, SA.copy(), LCP.copy(), SAi.copy(), SO, nsep, ns, nodes, minl, minn, R.sa_t))
     anchors = sorted((r["l"], r["sp_min"], r["mn"]) for r in trace if r["picked"])
     key = sorted((r["depth"], r["key"], r["n"], r["nsamples"], r["nmums"], r["picked"], r["l"], r["sp_min"],

@@ -44,6 +44,7 @@ def make_index_type(sa64, error):
             self._constructed = False
             self._main = self
             self._slot = None            # frontier slot while align() runs (sub-indices)
+            self._sx = None              # detached (sub)index behind splitindex / extract (include/reveal_amd.h, rv_sx_*)
             self._n_sub = None
             self._nsamples_sub = None
             self._h = self._dll.rv_new(_lib.device())
@@ -52,6 +53,9 @@ def make_index_type(sa64, error):
 
         def __del__(self):
             try:
+                if getattr(self, "_sx", None):
+                    self._dll.rv_sx_free(self._sx)     # (children keep their main object alive through _main)
+                    self._sx = None
                 if self._h and self._main is self:
                     self._dll.rv_free(self._h)
                     self._h = None
@@ -117,6 +121,9 @@ def make_index_type(sa64, error):
 
         # ---- construct --------------------------------------------------------
         def construct(self, rc=0):                          # interface.c:160-291
+            if self._sx:
+                self._dll.rv_sx_free(self._sx)
+                self._sx = None
             r = self._dll.rv_construct(self._h, int(rc), self._safile.encode(), self._lcpfile.encode(), self._cache)
             if r != 0:
                 self._fail()
@@ -127,8 +134,15 @@ def make_index_type(sa64, error):
             return None
 
         # ---- getters (interface.c:538-729) -----------------------------------------
+        def _sx_info(self):
+            info = _lib.RvSub()
+            self._dll.rv_sx_info(self._sx, ctypes.byref(info))
+            return info
+
         @property
         def n(self):
+            if self._sx:
+                return self._sx_info().n
             return self._n_sub if self._n_sub is not None else self._dll.rv_n(self._h)
 
         @property
@@ -137,6 +151,8 @@ def make_index_type(sa64, error):
 
         @property
         def nsamples(self):
+            if self._sx and self._depth > 0:
+                return self._sx_info().nsamples
             return self._nsamples_sub if self._nsamples_sub is not None else self._dll.rv_nsamples(self._h)
 
         @property
@@ -164,7 +180,9 @@ def make_index_type(sa64, error):
 
         def _array(self, which, dtype, count, exc=TypeError):
             out = np.zeros(max(count, 1), dtype=dtype)
-            if self._slot is not None and which in (RV_SA, RV_LCP):
+            if self._sx and which in (RV_SA, RV_LCP):
+                k = self._dll.rv_sx_array(self._sx, which, out.ctypes.data, len(out))
+            elif self._slot is not None and which in (RV_SA, RV_LCP):
                 k = self._dll.rv_sub_array(self._h, self._slot, which, out.ctypes.data, len(out))
             else:
                 k = self._dll.rv_get_array(self._h, which, out.ctypes.data, len(out))
@@ -202,7 +220,29 @@ def make_index_type(sa64, error):
             return self._array(which, dt, self.n if which in (RV_SA, RV_LCP) else self._main_n())
 
         # ---- scans --------------------------------------------------------------
+        def _sx_mums(self, minl, minn):
+            """scan of a detached (sub)index -> [(l, n, ((sample, pos), ...))]"""
+            mem = ctypes.c_int64(0)
+            cnt = self._dll.rv_sx_scan(self._sx, int(minl), int(minn), ctypes.byref(mem))
+            if cnt < 0:
+                self._fail()
+            l = np.zeros(max(cnt, 1), dtype=np.uint32); n = np.zeros(max(cnt, 1), dtype=np.int32)
+            off = np.zeros(cnt + 1, dtype=np.int64)
+            so = np.zeros(max(mem.value, 1), dtype=np.uint16); pos = np.zeros(max(mem.value, 1), dtype=np.int64)
+            if self._dll.rv_sx_fetch(self._sx, l.ctypes.data, n.ctypes.data, off.ctypes.data, so.ctypes.data, pos.ctypes.data) != 0:
+                self._fail()
+            return _csr_to_tuples(cnt, l, n, off, so, pos)
+
         def getmums(self, minl=0):                          # reveal.c:55-116
+            if self._sx:
+                if self._dll.rv_nsamples(self._h) != 2:
+                    raise error("getmums on a sub-index needs a two-sample main index")
+                rc = 1 if getattr(self._main, "_rc", 0) else 0
+                out = [(l, (spd[0][1], spd[1][1]), rc) for l, _, spd in self._sx_mums(minl, 0)]
+                if rc:                                                            # reveal.c:98-100
+                    nsep0, nT = self.nsep[0], self._main_n()
+                    out = [(l, (a, nsep0 + (nT - b - l)), rc) for l, (a, b), _ in out]
+                return out
             cnt = self._dll.rv_getmums(self._h, int(minl))
             if cnt < 0:
                 self._fail(TypeError if cnt == -2 else error)
@@ -215,6 +255,10 @@ def make_index_type(sa64, error):
             return [(int(l[k]), (int(a[k]), int(b[k])), rc) for k in range(cnt)]
 
         def _multi(self, minlength, minn, mems):
+            if self._sx:
+                if mems or self._dll.rv_nsamples(self._h) <= 2:
+                    raise error("only getmultimums of an index with more than two samples is available on a sub-index")
+                return self._sx_mums(minlength, minn)
             members = ctypes.c_int64(0)
             cnt = self._dll.rv_getmultimums(self._h, int(minlength), int(minn), mems, ctypes.byref(members))
             if cnt < 0:
@@ -297,7 +341,7 @@ def make_index_type(sa64, error):
                             c._lib, c._dll, c._h, c._main = self._lib, dll, h, self
                             c._samples, c._constructed = self._samples, True
                             c._depth = p._depth + 1
-                            c._slot = int(slot)
+                            c._slot, c._sx = int(slot), None
                             c._n_sub = c._nsamples_sub = None
                             if kind == 0:
                                 c._nodes, c._leftnode, c._rightnode, c.skipmums = leading, p._leftnode, newright, skipleft
@@ -314,6 +358,93 @@ def make_index_type(sa64, error):
                 self._slot = None
                 self._n_sub = self._nsamples_sub = None
             return None
+
+        # ---- host-driven single steps (reveal.c:1386-1748, interface.c:432-470) ----------
+        def _need_sx(self):
+            if not self._constructed:
+                raise TypeError("Index not yet constructed.")
+            if self._slot is not None:
+                raise error("not available on a sub-index handed to an align() callback")
+            if not self._sx:
+                self._sx = self._dll.rv_sx_main(self._h)
+                if not self._sx:
+                    self._fail()
+            return self._sx
+
+        def splitindex(self, leading_intervals, trailing_intervals, matching_intervals, rest, merged, newleftnode, newrightnode,
+                       skipmumsleft, skipmumsright):
+            """reveal.c:1515-1748 -> (leading, trailing, parallel) index objects or None.
+            The Python-driven form of one recursion step (rem.py:580-609): this index keeps its SA / LCP."""
+            sx = self._need_sx()
+            la, nl = _pairs(leading_intervals, sa64); ta, nt = _pairs(trailing_intervals, sa64)
+            ma, nm = _pairs(matching_intervals, sa64); ra, nr = _pairs(rest, sa64)
+            out = (ctypes.c_void_p * 3)()
+            if self._dll.rv_sx_split(sx, la.ctypes.data, nl, ta.ctypes.data, nt, ma.ctypes.data, nm, ra.ctypes.data, nr, out) != 0:
+                self._fail()
+            kids = []
+            for kind in range(3):
+                if not out[kind]:
+                    kids.append(None)
+                    continue
+                c = index.__new__(index)                                          # newIndex(), reveal.c:1679-1735
+                c._lib, c._dll, c._h, c._main = self._lib, self._dll, self._h, self._main
+                c._samples, c._constructed = self._main._samples, True
+                c._depth = self._depth + 1
+                c._slot, c._sx = None, out[kind]
+                c._n_sub = c._nsamples_sub = None
+                if kind == 0:
+                    c._nodes, c._leftnode, c._rightnode, c.skipmums = leading_intervals, self._leftnode, newrightnode, skipmumsleft
+                elif kind == 1:
+                    c._nodes, c._leftnode, c._rightnode, c.skipmums = trailing_intervals, newleftnode, self._rightnode, skipmumsright
+                else:
+                    c._nodes, c._leftnode, c._rightnode, c.skipmums = rest, self._leftnode, self._rightnode, []
+                kids.append(c)
+            return tuple(kids)
+
+        def extract(self, intervals):
+            """reveal.c:1386-1505: the suffixes of `intervals` leave this index (in place), the intervals are lower-cased
+            in T.  After construct(rc=1) query-side intervals are mapped back and replaced in the list, as in the reference."""
+            sx = self._need_sx()
+            iv = list(intervals)
+            a, k = _pairs(iv, sa64)
+            before = a.copy()
+            if self._dll.rv_sx_extract(sx, a.ctypes.data, k) != 0:
+                self._fail()
+            if isinstance(intervals, list):                                        # PyList_SetItem, reveal.c:1426
+                for q in range(k):
+                    if (a[q] != before[q]).any():
+                        intervals[q] = (int(a[q][0]), int(a[q][1]))
+            return None
+
+        def copy(self):
+            """interface.c:432-470: an independent copy (own text and arrays).  A sub-index copies its SA / LCP and
+            goes on sharing the text of its main index."""
+            if not self._constructed:
+                raise TypeError("Index not yet constructed.")
+            if self._slot is not None:
+                raise error("not available on a sub-index handed to an align() callback")
+            c = index.__new__(index)
+            c._lib, c._dll = self._lib, self._dll
+            c._safile, c._lcpfile, c._cache = "", "", 0
+            c._samples, c._nodes, c.skipmums = list(self._samples), set(self._nodes), list(self.skipmums)
+            c._leftnode, c._rightnode, c._depth = self._leftnode, self._rightnode, self._depth
+            c._constructed, c._slot, c._sx = True, None, None
+            c._n_sub = c._nsamples_sub = None
+            c._rc = getattr(self, "_rc", 0)
+            if self._main is self:
+                if self._sx:
+                    raise error("copy() after extract() / splitindex() on the main index is not supported")
+                c._h = self._dll.rv_clone(self._h)
+                if not c._h:
+                    self._fail()
+                c._main = c
+            else:
+                c._h, c._main = self._h, self._main
+                c._samples = self._main._samples
+                c._sx = self._dll.rv_sx_copy(self._sx)
+                if not c._sx:
+                    self._fail()
+            return c
 
         def align_builtin(self, minl=20, minn=2, trace=False):
             """Not in the reference: the whole recursion with the library's

@@ -82,6 +82,17 @@ SYMBOLS = {
     "rv_set_trace": (_I, [V, _I]),
     "rv_trace_count": (_L, [V]),
     "rv_fetch_trace": (_I, [V, V, _L]),
+    "rv_clone": (V, [V]),
+    "rv_sx_main": (V, [V]),
+    "rv_sx_copy": (V, [V]),
+    "rv_sx_free": (None, [V]),
+    "rv_sx_info": (_I, [V, ctypes.POINTER(RvSub)]),
+    "rv_sx_nodes": (_I, [V, V]),
+    "rv_sx_array": (_L, [V, _I, V, _L]),
+    "rv_sx_scan": (_L, [V, _I, _I, c_i64p]),
+    "rv_sx_fetch": (_I, [V, V, V, V, V, V]),
+    "rv_sx_split": (_I, [V, V, _I, V, _I, V, _I, V, _I, V]),
+    "rv_sx_extract": (_I, [V, V, _I]),
     "rv_prof_enable": (_I, [V, _I]),
     "rv_prof_reset": (_I, [V]),
     "rv_prof_get": (_I, [V, _I, c_i64p, ctypes.POINTER(_D), ctypes.POINTER(_D)]),

@@ -93,13 +93,16 @@ struct Decisions {
     std::vector<u32>     l;
     std::vector<int64_t> sp_first, lead_first, trail_first, rest_first, match_first;   // CSR, size ndec+1
     std::vector<int64_t> sp;
+    std::vector<u32>     spl;             // length of the matched range at sp[k] (the match length; splitindex / extract: any)
+    bool                 host_lists = false;   // some decision carries interval lists from the caller (not the built-in linear model)
     std::vector<RvIntv>  lead, trail, rest, match;     // lead/trail/rest sorted by begin per decision; match in the given order
     int size() const { return (int)sub.size(); }
     void reset(int nsubs) {
         of_sub.assign((size_t)nsubs, -1);
         sub.clear(); l.clear();
         sp_first.assign(1, 0); lead_first.assign(1, 0); trail_first.assign(1, 0); rest_first.assign(1, 0); match_first.assign(1, 0);
-        sp.clear(); lead.clear(); trail.clear(); rest.clear(); match.clear();
+        sp.clear(); spl.clear(); lead.clear(); trail.clear(); rest.clear(); match.clear();
+        host_lists = false;
     }
     void close() {
         sp_first.push_back((int64_t)sp.size()); lead_first.push_back((int64_t)lead.size()); trail_first.push_back((int64_t)trail.size());
@@ -241,13 +244,21 @@ static int need_sub(rv_index *h, int s) {
 // record one decision; lead/trail/rest are sorted here, match keeps its order (reveal.c:673-674)
 static int add_decision(rv_index *h, int s, u32 l, const int64_t *sp, int nsp,
                         const RvIntv *lead, int nlead, const RvIntv *trail, int ntrail,
-                        const RvIntv *match, int nmatch, const RvIntv *rest, int nrest) {
+                        const RvIntv *match, int nmatch, const RvIntv *rest, int nrest, bool ranges_from_match = false) {
     Decisions &d = h->al->dec;
     if (d.of_sub[(size_t)s] >= 0) { rv_set_error("sub-index %d already has a decision", s); return -1; }
     d.of_sub[(size_t)s] = d.size();
     d.sub.push_back(s); d.l.push_back(l);
-    d.sp.insert(d.sp.end(), sp, sp + nsp);
-    std::sort(d.sp.end() - nsp, d.sp.end());
+    if (ranges_from_match) d.host_lists = true;
+    if (ranges_from_match) {      // splitindex / extract: the matched ranges are the matching intervals themselves (reveal.c:1618-1621)
+        std::vector<RvIntv> mm(match, match + nmatch);
+        std::sort(mm.begin(), mm.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
+        for (const RvIntv &iv : mm) { d.sp.push_back(iv.begin); d.spl.push_back((u32)(iv.end - iv.begin)); }
+    } else {
+        d.sp.insert(d.sp.end(), sp, sp + nsp);
+        std::sort(d.sp.end() - nsp, d.sp.end());
+        d.spl.insert(d.spl.end(), (size_t)nsp, l);
+    }
     auto put = [](std::vector<RvIntv> &v, const RvIntv *p, int n, bool sorted) {
         const size_t at = v.size();
         v.insert(v.end(), p, p + n);
@@ -607,7 +618,9 @@ int rv_sub_split(rv_index *h, int s, uint32_t l, int nsp, const int64_t *sp,
         for (int k = 0; k < cnts[q]; k++)
             if (lists[q][2 * k] < 0 || lists[q][2 * k + 1] > h->nT || lists[q][2 * k] > lists[q][2 * k + 1]) { rv_set_error("interval outside the text"); return -1; }
     static_assert(sizeof(RvIntv) == 2 * sizeof(int64_t), "RvIntv layout");
-    return add_decision(h, s, l, sp, nsp, (const RvIntv *)lead, nlead, (const RvIntv *)trail, ntrail, (const RvIntv *)match, nmatch, (const RvIntv *)rest, nrest);
+    RV_TRY(add_decision(h, s, l, sp, nsp, (const RvIntv *)lead, nlead, (const RvIntv *)trail, ntrail, (const RvIntv *)match, nmatch, (const RvIntv *)rest, nrest));
+    h->al->dec.host_lists = true;
+    return 0;
 }
 
 // Tables the scan and the device-side decisions of a level need; the commit in front of the level ships them with its own
@@ -691,7 +704,6 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         const int d = dc.of_sub[(size_t)s];
         if (d < 0) continue;
         a->split_subs.push_back(s);
-        const u32 l = dc.l[(size_t)d];
         const RvIntv *lists[3] = {dc.lead.data() + dc.lead_first[(size_t)d], dc.trail.data() + dc.trail_first[(size_t)d], dc.rest.data() + dc.rest_first[(size_t)d]};
         const size_t cnts[3] = {(size_t)(dc.lead_first[(size_t)d + 1] - dc.lead_first[(size_t)d]), (size_t)(dc.trail_first[(size_t)d + 1] - dc.trail_first[(size_t)d]),
                                 (size_t)(dc.rest_first[(size_t)d + 1] - dc.rest_first[(size_t)d])};
@@ -707,6 +719,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         }
         for (int64_t k = dc.sp_first[(size_t)d]; k < dc.sp_first[(size_t)d + 1]; k++) {       // sorted
             const int64_t p = dc.sp[(size_t)k];
+            const u32 l = dc.spl[(size_t)k];
             if (l) { a->mb.push_back((sa_t)p); a->me.push_back((sa_t)(p + l)); a->mpre.push_back(a->mpre.back() + l); }
             a->mend_pos.push_back((sa_t)(p + (int64_t)l));
         }
@@ -886,6 +899,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.child_base = (const u32 *)(tb + o_cbase); sa.child_n = (const u32 *)(tb + o_cn); sa.sub_off = (const u32 *)(tb + o_suboff); sa.expect_total = (const u32 *)(tb + o_expect);
     sa.cut_first = (const int *)(tb + o_cf); sa.cut_lo = (const sa_t *)(tb + o_clo); sa.cut_hi = (const sa_t *)(tb + o_chi);
     sa.mend_first = (const int *)(tb + o_mf); sa.mend_pos = (const sa_t *)(tb + o_mp);
+    sa.mend_all = dc.host_lists ? 1 : 0;
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = a->dErr.as<u32>();      // persistent for the alignment: an early split (rv_decide.hip) runs before this upload exists
     int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
@@ -1346,33 +1360,11 @@ int64_t rv_frontier_pack(rv_index *h, const int32_t *subs, int k, void *sa, void
     return at;
 }
 
-/* Replace the frontier of the handle by the given sub-indices (segments back to back in sa / lcp / bwt, m ranks in all).
- * A handle with a run in progress keeps its anchors and goes on with the new frontier (the share it keeps for itself);
- * any other handle only needs its samples (no construct): it becomes a worker that starts at this frontier. */
-int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int level, int nsubs, const int64_t *meta,
-                       const int64_t *node_first, const int64_t *nodes, int64_t m, const void *sa, const void *lcp, const void *bwt, int on_device) {
-    RV_HIP(hipSetDevice(h->device));
-    if (h->nsamples < 2) { rv_set_error("align needs at least two samples"); return -1; }
-    if (nsubs < 0 || m < 0 || m >= ((int64_t)1 << 32)) { rv_set_error("rv_frontier_import: bad sizes"); return -1; }
+// the given sub-indices (segments back to back in sa / lcp / bwt) become the frontier of the handle; the per-level tables a
+// commit would have shipped for them go with it
+static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *meta, const int64_t *node_first, const int64_t *nodes, int64_t m,
+                            const void *sa, const void *lcp, const void *bwt, int on_device) {
     hipStream_t q = h->ws.stream;
-    const bool fresh = !(h->al && h->al->running);
-    if (fresh) {
-        if (!h->constructed || h->main_arrays_freed) RV_TRY(rv_text_only(h, maxlcp));
-        const bool keep_trace = h->al && h->al->trace_on;
-        if (!h->al) h->al = new Align();
-        Align *a = h->al;
-        a->trace_on = keep_trace;
-        a->minl = minl; a->minn = minn;
-        a->multi = h->nsamples > 2;
-        a->scanned = false; a->d_err = nullptr; a->flag_clean = false;
-        a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
-        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
-        RV_TRY(a->dErr.reserve(64));
-        memset(&a->st, 0, sizeof a->st);
-        a->full_only = !a->trace_on;
-        a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
-        RV_TRY(builtin_leaf_setup(h));
-    }
     Align *a = h->al;
     RV_HIP(hipStreamSynchronize(q));
     if (a->leaf_stream) RV_HIP(hipStreamSynchronize(a->leaf_stream));      // (a leaf launch may read the level buffers replaced below)
@@ -1426,7 +1418,316 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
     a->cur_dev_ok = a->next_dev_ok; a->early_done = false; a->early_bubble = false;
     a->scanned = false; a->d_err = nullptr;
     a->dec.reset(lv.size());
-    a->running = true;
+    return 0;
+}
+
+
+/* Replace the frontier of the handle by the given sub-indices (segments back to back in sa / lcp / bwt, m ranks in all).
+ * A handle with a run in progress keeps its anchors and goes on with the new frontier (the share it keeps for itself);
+ * any other handle only needs its samples (no construct): it becomes a worker that starts at this frontier. */
+int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int level, int nsubs, const int64_t *meta,
+                       const int64_t *node_first, const int64_t *nodes, int64_t m, const void *sa, const void *lcp, const void *bwt, int on_device) {
+    RV_HIP(hipSetDevice(h->device));
+    if (h->nsamples < 2) { rv_set_error("align needs at least two samples"); return -1; }
+    if (nsubs < 0 || m < 0 || m >= ((int64_t)1 << 32)) { rv_set_error("rv_frontier_import: bad sizes"); return -1; }
+    const bool fresh = !(h->al && h->al->running);
+    if (fresh) {
+        if (!h->constructed || h->main_arrays_freed) RV_TRY(rv_text_only(h, maxlcp));
+        const bool keep_trace = h->al && h->al->trace_on;
+        if (!h->al) h->al = new Align();
+        Align *a = h->al;
+        a->trace_on = keep_trace;
+        a->minl = minl; a->minn = minn;
+        a->multi = h->nsamples > 2;
+        a->scanned = false; a->d_err = nullptr; a->flag_clean = false;
+        a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
+        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+        RV_TRY(a->dErr.reserve(64));
+        memset(&a->st, 0, sizeof a->st);
+        a->full_only = !a->trace_on;
+        a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
+        RV_TRY(builtin_leaf_setup(h));
+    }
+    RV_TRY(install_frontier(h, level, nsubs, meta, node_first, nodes, m, sa, lcp, bwt, on_device));
+    h->al->running = true;
+    return 0;
+}
+
+/* ---- host-driven single steps: splitindex / extract / copy (reveal.c:1386-1748, interface.c:432-470) ----------------
+ * A detached (sub)index owns its SA / LCP / BWT in HBM and borrows text, shared inverse and separators from its main
+ * handle, like the reference's child objects (reveal.c:1679-1735).  Every step loads it as a one-sub-index frontier and
+ * runs the same label / split / lower-casing / bubble kernels as a level of align(). */
+}  // extern "C"
+
+struct rv_subindex {
+    rv_index *h = nullptr;
+    int64_t n = 0;
+    int32_t depth = 0, nsamples = 0;
+    std::vector<RvIntv> nodes;     // the interval list this index was made from (reveal.h:36)
+    std::vector<RvIntv> cover;     // text positions whose suffixes are ranks of this index: sorted, disjoint
+    DBuf sa, lcp, bwt;
+    ~rv_subindex() { sa.release(); lcp.release(); bwt.release(); }
+};
+
+static int sx_alloc(rv_subindex *x, int64_t n) {
+    RV_TRY(x->sa.reserve((size_t)(n + 64) * sizeof(sa_t)));
+    RV_TRY(x->lcp.reserve((size_t)(n + 64) * sizeof(lcp_t)));
+    RV_TRY(x->bwt.reserve((size_t)n + 64));
+    x->n = n;
+    return 0;
+}
+
+// x becomes the frontier of its handle in host-driven mode (what rv_align_begin sets up, one level down)
+static int sx_load(rv_subindex *x, int minl, int minn) {
+    rv_index *h = x->h;
+    RV_HIP(hipSetDevice(h->device));
+    if (!h->constructed && !h->text_only) { rv_set_error("Index not yet constructed."); return -1; }
+    if (h->al && h->al->running) { rv_set_error("a built-in alignment is in progress on this index"); return -1; }
+    if (h->nsamples < 2) { rv_set_error("at least two samples are needed"); return -1; }
+    if (x->n <= 0 || x->n >= ((int64_t)1 << 32)) { rv_set_error("sub-index of %lld ranks not supported", (long long)x->n); return -1; }
+    const bool keep_trace = h->al && h->al->trace_on;
+    if (!h->al) h->al = new Align();
+    Align *a = h->al;
+    a->trace_on = keep_trace;
+    a->minl = minl; a->minn = minn;
+    a->multi = h->nsamples > 2;
+    a->scanned = false; a->d_err = nullptr; a->flag_clean = false; a->full_only = false; a->use_leaf = false; a->leaf_launch_due = false;
+    a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
+    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+    RV_TRY(a->dErr.reserve(64));
+    memset(&a->st, 0, sizeof a->st);
+    const int64_t meta[6] = {0, x->n, x->depth, x->nsamples, 0, -1};
+    const int64_t nf[2] = {0, (int64_t)x->nodes.size()};
+    static_assert(sizeof(RvIntv) == 2 * sizeof(int64_t), "RvIntv layout");
+    RV_TRY(install_frontier(h, std::max((int)x->depth, 1), 1, meta, nf, (const int64_t *)x->nodes.data(), x->n, x->sa.p, x->lcp.p, x->bwt.p, 1));
+    return 0;
+}
+
+// the error word of the last commit (pair mode defers it to the next scan; a single step has none)
+static int sx_commit_check(rv_index *h) {
+    u32 err = 0;
+    RV_HIP(hipMemcpyAsync(&err, h->al->dErr.p, 4, hipMemcpyDeviceToHost, h->ws.stream));
+    RV_HIP(hipStreamSynchronize(h->ws.stream));
+    h->al->d_err = nullptr;
+    if (err & 1u) { rv_set_error("split: the intervals do not partition the index (child size mismatch)"); return -1; }
+    if (err) { rv_set_error("split / bubble_sort reported error bits %u", err); return -1; }
+    return 0;
+}
+
+// sorted copy; fails on intervals outside cover or overlapping each other
+static int sx_check_inside(const rv_subindex *x, const RvIntv *iv, int n, const char *what, std::vector<RvIntv> &sorted) {
+    sorted.assign(iv, iv + n);
+    std::sort(sorted.begin(), sorted.end(), intv_less);
+    size_t c = 0;
+    for (size_t k = 0; k < sorted.size(); k++) {
+        const RvIntv &v = sorted[k];
+        if (v.begin >= v.end) { rv_set_error("%s: empty interval [%lld,%lld)", what, (long long)v.begin, (long long)v.end); return -1; }
+        if (k && v.begin < sorted[k - 1].end) { rv_set_error("%s: overlapping intervals", what); return -1; }
+        while (c < x->cover.size() && x->cover[c].end <= v.begin) c++;
+        if (c >= x->cover.size() || v.begin < x->cover[c].begin || v.end > x->cover[c].end) {
+            rv_set_error("%s: interval [%lld,%lld) is not part of this index", what, (long long)v.begin, (long long)v.end);
+            return -1;
+        }
+    }
+    return 0;
+}
+
+// bubble_sort visits the matching intervals in the order given (reveal.c:673-674).  The kernels look for crossing suffixes
+// only in the window in front of each cut, which is the same thing unless a LATER interval of the list begins less than
+// maxlcp in front of an earlier one with no separator in between (a suffix could then cross both cuts and the reference
+// would move it twice).  A match never does that (its members lie in different sequences); refuse the rest.
+static int sx_check_cut_order(const rv_index *h, const RvIntv *match, int nmatch) {
+    for (int i = 0; i < nmatch; i++)
+        for (int j = i + 1; j < nmatch; j++) {
+            if (match[j].begin >= match[i].begin) continue;
+            if (match[i].begin - match[j].begin >= (int64_t)h->maxlcp) continue;
+            bool sep = false;
+            for (int64_t p = match[j].begin; p < match[i].begin && !sep; p++) sep = h->T[(size_t)p] == '$' || h->T[(size_t)p] == 'N';
+            if (!sep) { rv_set_error("matching intervals closer than the longest repeat must be listed in ascending order"); return -1; }
+        }
+    return 0;
+}
+
+static rv_subindex *sx_take_child(rv_index *h, int slot, int depth, const RvIntv *nodes, size_t nnodes) {
+    Align *a = h->al;
+    rv_subindex *c = new rv_subindex();
+    c->h = h; c->depth = depth; c->nsamples = a->lv.nsamples[(size_t)slot];
+    c->nodes.assign(nodes, nodes + nnodes);
+    c->cover = c->nodes;
+    std::sort(c->cover.begin(), c->cover.end(), intv_less);
+    const int64_t off = a->lv.off[(size_t)slot], n = a->lv.n[(size_t)slot];
+    hipStream_t q = h->ws.stream;
+    bool ok = sx_alloc(c, n) == 0;
+    ok = ok && hipMemcpyAsync(c->sa.p, cur_sa(h) + off, (size_t)n * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->lcp.p, cur_lcp(h) + off, (size_t)n * sizeof(lcp_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->bwt.p, cur_bwt(h) + off, (size_t)n, hipMemcpyDeviceToDevice, q) == hipSuccess;
+    if (!ok) { rv_set_error("copy of a child index failed"); delete c; return nullptr; }
+    return c;
+}
+
+extern "C" {
+
+/* the main index as a detached copy (its SA / LCP stay untouched by the steps below: the reference's splitindex leaves
+ * the parent's arrays alone too, reveal.c:1738) */
+rv_subindex *rv_sx_main(rv_index *h) {
+    if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return nullptr; }
+    if (hipSetDevice(h->device) != hipSuccess) { rv_set_error("hipSetDevice failed"); return nullptr; }
+    rv_subindex *x = new rv_subindex();
+    x->h = h; x->depth = 0; x->nsamples = h->nsamples;
+    x->nodes = h->nodes;
+    std::sort(x->nodes.begin(), x->nodes.end(), intv_less);
+    x->cover.assign(1, RvIntv{0, h->nT});
+    hipStream_t q = h->ws.stream;
+    bool ok = sx_alloc(x, h->n) == 0;
+    ok = ok && hipMemcpyAsync(x->sa.p, h->dSA.p, (size_t)h->n * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(x->lcp.p, h->dLCP.p, (size_t)h->n * sizeof(lcp_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(x->bwt.p, h->dBWT.p, (size_t)h->n, hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipStreamSynchronize(q) == hipSuccess;
+    if (!ok) { rv_set_error("copy of the main index failed"); delete x; return nullptr; }
+    return x;
+}
+
+rv_subindex *rv_sx_copy(rv_subindex *x) {
+    rv_index *h = x->h;
+    if (hipSetDevice(h->device) != hipSuccess) { rv_set_error("hipSetDevice failed"); return nullptr; }
+    rv_subindex *c = new rv_subindex();
+    c->h = h; c->depth = x->depth; c->nsamples = x->nsamples; c->nodes = x->nodes; c->cover = x->cover;
+    hipStream_t q = h->ws.stream;
+    bool ok = sx_alloc(c, x->n) == 0;
+    ok = ok && hipMemcpyAsync(c->sa.p, x->sa.p, (size_t)x->n * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->lcp.p, x->lcp.p, (size_t)x->n * sizeof(lcp_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->bwt.p, x->bwt.p, (size_t)x->n, hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipStreamSynchronize(q) == hipSuccess;
+    if (!ok) { rv_set_error("copy of a sub-index failed"); delete c; return nullptr; }
+    return c;
+}
+
+void rv_sx_free(rv_subindex *x) {
+    if (!x) return;
+    (void)hipSetDevice(x->h->device);
+    (void)hipStreamSynchronize(x->h->ws.stream);
+    delete x;
+}
+
+int rv_sx_info(const rv_subindex *x, rv_sub *out) {
+    memset(out, 0, sizeof *out);
+    out->n = x->n; out->depth = x->depth; out->nsamples = x->nsamples; out->nnodes = (int32_t)x->nodes.size(); out->parent = -1;
+    return 0;
+}
+
+int rv_sx_nodes(const rv_subindex *x, int64_t *be) {
+    for (size_t k = 0; k < x->nodes.size(); k++) { be[2 * k] = x->nodes[k].begin; be[2 * k + 1] = x->nodes[k].end; }
+    return 0;
+}
+
+int64_t rv_sx_array(rv_subindex *x, int which, void *out, int64_t cap) {
+    (void)hipSetDevice(x->h->device);
+    if (which != RV_SA && which != RV_LCP) { rv_set_error("rv_sx_array: bad array id"); return -1; }
+    if (cap < x->n) { rv_set_error("buffer too small"); return -1; }
+    (void)hipStreamSynchronize(x->h->ws.stream);
+    const hipError_t e = which == RV_SA ? hipMemcpy(out, x->sa.p, (size_t)x->n * sizeof(sa_t), hipMemcpyDeviceToHost)
+                                        : hipMemcpy(out, x->lcp.p, (size_t)x->n * sizeof(lcp_t), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { rv_set_error("D2H failed"); return -1; }
+    return x->n;
+}
+
+/* getmums / getmultimums (reveal.c:55-116, :436-580) over this index: count (and member count); rv_sx_fetch hands them out
+ * in the CSR form of rv_sub_mums */
+int64_t rv_sx_scan(rv_subindex *x, int minl, int minn, int64_t *members) {
+    rv_index *h = x->h;
+    if (sx_load(x, minl, minn)) return -1;
+    if (rv_frontier_scan(h)) return -1;
+    rv_sub info;
+    if (rv_sub_info(h, 0, &info)) return -1;
+    if (members) *members = info.nmembers;
+    return info.nmums;
+}
+
+int rv_sx_fetch(rv_subindex *x, uint32_t *l, int32_t *n, int64_t *off, uint16_t *so, int64_t *pos) {
+    return rv_sub_mums(x->h, 0, l, n, off, so, pos);
+}
+
+/* splitindex (reveal.c:1515-1748): label by the four interval lists, split, lower-case the matching intervals, bubble_sort
+ * the leading child over them in the order given.  out[0..2] = leading, trailing, parallel child or NULL (reveal.c:1744). */
+int rv_sx_split(rv_subindex *x, const int64_t *lead, int nlead, const int64_t *trail, int ntrail,
+                const int64_t *match, int nmatch, const int64_t *rest, int nrest, rv_subindex **out) {
+    rv_index *h = x->h;
+    out[0] = out[1] = out[2] = nullptr;
+    std::vector<RvIntv> all, tmp;
+    const int64_t *lists[4] = {lead, trail, match, rest};
+    const int cnts[4] = {nlead, ntrail, nmatch, nrest};
+    for (int q = 0; q < 4; q++) all.insert(all.end(), (const RvIntv *)lists[q], (const RvIntv *)lists[q] + cnts[q]);
+    RV_TRY(sx_check_inside(x, all.data(), (int)all.size(), "splitindex", tmp));
+    RV_TRY(sx_check_cut_order(h, (const RvIntv *)match, nmatch));
+    RV_TRY(sx_load(x, 0, 0));
+    RV_TRY(add_decision(h, 0, 0, nullptr, 0, (const RvIntv *)lead, nlead, (const RvIntv *)trail, ntrail, (const RvIntv *)match, nmatch,
+                        (const RvIntv *)rest, nrest, true));
+    int32_t kids[3] = {-1, -1, -1};
+    RV_TRY(rv_frontier_commit(h, kids));
+    RV_TRY(sx_commit_check(h));
+    const int cls_list[3] = {0, 1, 3};
+    for (int c = 0; c < 3; c++) {
+        if (kids[c] < 0) continue;
+        out[c] = sx_take_child(h, kids[c], x->depth + 1, (const RvIntv *)lists[cls_list[c]], (size_t)cnts[cls_list[c]]);
+        if (!out[c]) { for (int k = 0; k < 3; k++) { delete out[k]; out[k] = nullptr; } return -1; }
+    }
+    RV_HIP(hipStreamSynchronize(h->ws.stream));
+    (void)rv_align_end(h);
+    return 0;
+}
+
+/* extract (reveal.c:1386-1505): the suffixes of the given intervals leave the index, the intervals are lower-cased, the rest
+ * is bubble_sorted over them.  With rc=1 query-side intervals arrive in reverse-complement coordinates and are mapped back
+ * (written to `intervals`, as the reference replaces the list items, reveal.c:1411-1427).  The reference never writes the
+ * new SA[0] (it stays rank 0 here) and overruns its buffers when rank 0 itself is matched: that case is refused. */
+int rv_sx_extract(rv_subindex *x, int64_t *intervals, int niv) {
+    rv_index *h = x->h;
+    RV_HIP(hipSetDevice(h->device));
+    RvIntv *iv = (RvIntv *)intervals;
+    if (h->rc == 1)
+        for (int k = 0; k < niv; k++)
+            if (iv[k].begin > h->nsep[0]) {
+                const int64_t b = h->nsep[0] + (h->nT - iv[k].begin - (iv[k].end - iv[k].begin)), e = h->nsep[0] + (h->nT - iv[k].begin);
+                iv[k].begin = b; iv[k].end = e;
+            }
+    std::vector<RvIntv> sorted, lead;
+    RV_TRY(sx_check_inside(x, iv, niv, "extract", sorted));
+    RV_TRY(sx_check_cut_order(h, iv, niv));
+    {   // rank 0
+        sa_t first = 0;
+        RV_HIP(hipStreamSynchronize(h->ws.stream));
+        RV_HIP(hipMemcpy(&first, x->sa.p, sizeof(sa_t), hipMemcpyDeviceToHost));
+        for (const RvIntv &v : sorted)
+            if ((int64_t)first >= v.begin && (int64_t)first < v.end) { rv_set_error("extract: the first suffix of the index is matched (the reference overruns its buffers there)"); return -1; }
+    }
+    size_t m = 0;
+    int64_t left = 0;
+    for (const RvIntv &c : x->cover) {       // what stays = cover minus the intervals
+        int64_t at = c.begin;
+        while (m < sorted.size() && sorted[m].begin < c.end) {
+            if (sorted[m].begin > at) lead.push_back({at, sorted[m].begin});
+            at = sorted[m].end;
+            m++;
+        }
+        if (at < c.end) lead.push_back({at, c.end});
+    }
+    for (const RvIntv &v : lead) left += v.end - v.begin;
+    if (niv == 0) return 0;
+    RV_TRY(sx_load(x, 0, 0));
+    RV_TRY(add_decision(h, 0, 0, nullptr, 0, lead.data(), (int)lead.size(), nullptr, 0, iv, niv, nullptr, 0, true));
+    int32_t kids[3] = {-1, -1, -1};
+    RV_TRY(rv_frontier_commit(h, kids));
+    RV_TRY(sx_commit_check(h));
+    if (kids[0] < 0 || h->al->lv.n[(size_t)kids[0]] != left) { rv_set_error("extract: internal size mismatch"); return -1; }
+    const int64_t off = h->al->lv.off[(size_t)kids[0]];
+    hipStream_t q = h->ws.stream;
+    RV_HIP(hipMemcpyAsync(x->sa.p, cur_sa(h) + off, (size_t)left * sizeof(sa_t), hipMemcpyDeviceToDevice, q));
+    RV_HIP(hipMemcpyAsync(x->lcp.p, cur_lcp(h) + off, (size_t)left * sizeof(lcp_t), hipMemcpyDeviceToDevice, q));
+    RV_HIP(hipMemcpyAsync(x->bwt.p, cur_bwt(h) + off, (size_t)left, hipMemcpyDeviceToDevice, q));
+    RV_HIP(hipStreamSynchronize(q));
+    x->n = left;
+    x->cover.swap(lead);
+    (void)rv_align_end(h);
     return 0;
 }
 

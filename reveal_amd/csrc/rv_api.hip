@@ -64,6 +64,34 @@ void rv_free(rv_index *h) {
     delete h;
 }
 
+/* copy() (interface.c:432-470) of a main index: an independent handle with its own text (incl. the lower-case marks of
+ * the working copy), SA, SAi, LCP.  The reference also resets depth / file names of the source and hands its SO to nobody
+ * (self->SO = NULL, interface.c:462): not imitated. */
+rv_index *rv_clone(rv_index *h) {
+    if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return nullptr; }
+    rv_index *c = rv_new(h->device);
+    if (!c) return nullptr;
+    c->T = h->T; c->nsep = h->nsep; c->nodes = h->nodes; c->nsamples = h->nsamples; c->n = h->n; c->nT = h->nT; c->rc = h->rc;
+    c->maxlcp = h->maxlcp; c->sa_stats = h->sa_stats; c->text_dirty = true;
+    const int64_t n = h->n;
+    hipStream_t q = c->ws.stream;
+    bool ok = rv_upload(c) == 0;
+    ok = ok && c->dT.reserve((size_t)n + 64) == 0 && c->dSA.reserve((size_t)(n + 64) * sizeof(sa_t)) == 0 && c->dSAi.reserve((size_t)(n + 64) * sizeof(sa_t)) == 0
+            && c->dLCP.reserve((size_t)(n + 64) * sizeof(lcp_t)) == 0 && c->dBWT.reserve((size_t)n + 64) == 0 && c->dNsep.reserve((h->nsep.size() + 1) * sizeof(sa_t)) == 0;
+    ok = ok && hipStreamSynchronize(h->ws.stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dT.p, h->dT.p, (size_t)n + 64, hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dSA.p, h->dSA.p, (size_t)n * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dSAi.p, h->dSAi.p, (size_t)n * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dLCP.p, h->dLCP.p, (size_t)n * sizeof(lcp_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dBWT.p, h->dBWT.p, (size_t)n, hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->dNsep.p, h->dNsep.p, (h->nsep.size() + 1) * sizeof(sa_t), hipMemcpyDeviceToDevice, q) == hipSuccess;
+    ok = ok && hipStreamSynchronize(q) == hipSuccess;
+    if (!ok) { rv_set_error("copy of the index failed"); rv_free(c); return nullptr; }
+    c->nsep_dev = h->nsep_dev;
+    c->constructed = true;
+    return c;
+}
+
 /* interface.c:18-49 */
 int rv_add_sample(rv_index *h) {
     if (h->nsamples > 0) h->nsep.push_back(h->n - 1);

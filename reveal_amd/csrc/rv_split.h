@@ -39,6 +39,7 @@ struct RvSplitArgs {
     // positions right behind each sub's matched ranges (sp + l): the BWT byte of a trailing suffix starting there turns lower case
     const int     *mend_first;              // [nsubs+1]
     const sa_t    *mend_pos;
+    int            mend_all = 0;            // host-supplied interval lists: a suffix of ANY child may start right behind a matched range
     // outputs
     sa_t  *SA_out;
     lcp_t *LCP_out;

@@ -276,8 +276,8 @@ __device__ __forceinline__ void emit_item(const RvSplitArgs &a, const EmitSub &s
         const u32 cn = i0 ? cn0 : i1 ? cn1 : cn2;
         const u32 np = coff + ecnt;                                  // mod 2^32
         const u32 idx = np - cbase;                                  // rank inside the child
-        if (i1) {   // trailing child: the character in front of a suffix that starts right behind a
-                    // matched range has just been lower-cased (reveal.c:1230-1234)
+        if (i1 | (a.mend_all != 0)) {   // trailing child (the linear interval model puts nothing else there): the character in front
+                    // of a suffix that starts right behind a matched range has just been lower-cased (reveal.c:1230-1234)
             bool hit = (sa == sb.mnd0) | (sa == sb.mnd1);
             for (int q = sb.qm0 + 2; q < sb.qm1 && !hit; q++) hit = sa == a.mend_pos[q];
             if (hit && bo >= 'A' && bo <= 'Z') bo += 32;

@@ -38,6 +38,52 @@ def test_oracle_matches_reference_vectors(label):
     assert r["stats"]["maxdepth"] == rg["maxdepth"]
 
 
+@pytest.mark.parametrize("label", sorted(k for k in SETS if "extract" in SETS[k]))
+def test_oracle_extract_matches_reference_vectors(label):
+    """ro_extract against the reference's own extract() (reveal.c:1386-1505) on the longest full match"""
+    import hashlib
+    g = SETS[label]
+    inputs = golden_inputs(g)
+    O = oracle(g["sa64"])
+    T, nsep, nodes = assemble(inputs)
+    c = O.construct(T, nsep, len(inputs))
+    e = g["extract"]
+    sa, lcp, iv = O.extract(c["tbuf"], c["SA"], c["LCP"], c["SAi"], nsep, [tuple(x) for x in e["intervals"]], nT=len(T))
+    assert len(sa) == e["n"] and sha_arr(sa[1:]) == e["sha_SA1"] and sha_arr(lcp) == e["sha_LCP"]
+    assert sa[0] == c["SA"][0]
+    assert hashlib.sha256(bytes(c["tbuf"][:len(T)])).hexdigest() == e["sha_T"]
+
+
+def test_oracle_splitindex_is_one_step_of_the_recursion():
+    """ro_splitindex (reveal.c:1515-1748) from interval lists = label + split + bubble_sort of the aligner: driving it
+    with the bench callbacks reproduces the anchors of ro_align (which the golden trace pins)"""
+    from reveal_amd import rem
+    g = SETS["1a1b"]
+    O = oracle(False)
+    T, nsep, nodes = assemble(golden_inputs(g))
+    c = O.construct(T, nsep, 2)
+    ref = O.align_bench(O.construct(T, nsep, 2), nodes, 20, 2, trace_cap=g["recursion"]["steps"] + 8)
+
+    class View(object):
+        pass
+    queue, anchors = [(c["SA"], c["LCP"], sorted(nodes), 2)], []
+    while queue:
+        sa, lcp, nd, ns = queue.pop()
+        l, a, b = O.getmums(c["tbuf"], sa, lcp, nsep, 20, rem=True, nT=len(T))
+        v = View(); v.nodes, v.nsamples = nd, ns
+        r = rem.bench_mumpicker([(int(l[k]), 2, ((0, int(a[k])), (1, int(b[k])))) for k in range(len(l))], v)
+        if r == ():
+            continue
+        lead, trail, match, rest = rem.linear_graphalign(v, r[0])[:4]
+        anchors.append((r[0][0], min(p for _, p in r[0][2]), 2))
+        kids = O.splitindex(c["tbuf"], sa, lcp, c["SAi"], None, nsep, 2, lead, trail, match, rest)
+        for k, ivs in zip(kids, (lead, trail, rest)):
+            if k is not None:
+                queue.append((k[0], k[1], ivs, k[2]))
+    assert sha_json(sorted(anchors)) == g["recursion"]["sha_anchors"]
+    assert bytes(c["tbuf"][:len(T)]) == ref["T"]
+
+
 @pytest.mark.parametrize("label", ["known2", "t1t2", "1a1b", "d1d2", "1a1b_64"])
 def test_own_suffix_sorter_matches_reference_sa(label):
     """the oracle's own prefix-doubling sorter (used when oracle/_ref is absent) gives divsufsort's SA"""

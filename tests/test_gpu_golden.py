@@ -34,3 +34,18 @@ def test_hip_matches_reference_vectors(label):
     assert st == rg["sha_trace"]           # every sub-index: intervals, size, scan result, choice, SA and LCP arrays
     assert hashlib.sha256(idx.T.encode("latin-1")).hexdigest() == rg["sha_finalT"]
     assert got["stats"]["maxdepth"] == rg["maxdepth"]
+
+
+@pytest.mark.parametrize("label", sorted(k for k in SETS if "extract" in SETS[k]))
+def test_hip_extract_matches_reference_vectors(label):
+    """extract() against the output of the reference's own extract() (reveal.c:1386-1505); the reference never
+    writes the new SA[0], so it is compared from rank 1 on"""
+    from reveal_amd import reveallib, reveallib64
+    g = SETS[label]
+    idx = feed((reveallib64 if g["sa64"] else reveallib).index(), golden_inputs(g))
+    idx.construct()
+    e = g["extract"]
+    idx.extract([tuple(x) for x in e["intervals"]])
+    assert idx.n == e["n"]
+    assert sha_arr(idx.array("SA")[1:]) == e["sha_SA1"] and sha_arr(idx.array("LCP")) == e["sha_LCP"]
+    assert hashlib.sha256(idx.T.encode("latin-1")).hexdigest() == e["sha_T"]

@@ -1,0 +1,217 @@
+"""splitindex / extract / copy (reveallib/reveal.c:1386-1748, interface.c:432-470) on the GPU against the CPU
+oracle's restatements (oracle/reveal_oracle.c ro_splitindex / ro_extract, pinned against the reference's own
+split / bubble_sort / extract by oracle/pin_oracle.py).  The recursion is driven from Python the way the
+commented loop of reveal/rem.py:580-609 does it: scan a (sub)index, pick, split, go on with the children."""
+import numpy as np
+import pytest
+
+from helpers import assemble, fa, feed, oracle, synth
+from reveal_amd import rem
+
+pytestmark = pytest.mark.gpu
+
+
+def mod(sa64):
+    from reveal_amd import reveallib, reveallib64
+    return reveallib64 if sa64 else reveallib
+
+
+def oracle_scan(O, c, sa, lcp, ns, minl, minn):
+    if ns > 2:
+        l, n, off, so, pos = O.getmultimums(c["tbuf"], sa, lcp, c["SO"], c["nsep"], ns, minl, minn)
+        return [(int(l[k]), int(n[k]), tuple((int(so[q]), int(pos[q])) for q in range(off[k], off[k + 1]))) for k in range(len(l))]
+    l, a, b = O.getmums(c["tbuf"], sa, lcp, c["nsep"], minl, rem=True, nT=len(c["SA"]))
+    return [(int(l[k]), 2, ((0, int(a[k])), (1, int(b[k])))) for k in range(len(l))]
+
+
+class Node(object):       # what bench_mumpicker / linear_graphalign read from an index
+    def __init__(self, nodes, nsamples):
+        self.nodes, self.nsamples = nodes, nsamples
+
+
+def drive(inputs, minl=20, minn=2, sa64=False, max_steps=200):
+    """the same Python-driven recursion on the GPU index (splitindex) and on the oracle, compared step by step"""
+    T, nsep, nodes = assemble(inputs)
+    ns = len(inputs)
+    O = oracle(sa64)
+    c = O.construct(T, nsep, ns)
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct()
+    queue = [(idx, c["SA"], c["LCP"], sorted(nodes), ns)]
+    steps = 0
+    while queue and steps < max_steps:
+        g, sa, lcp, nd, nsub = queue.pop(0)
+        assert g.n == len(sa) and g.nsamples == nsub
+        assert np.array_equal(g.array("SA"), sa) and np.array_equal(g.array("LCP"), lcp)
+        want = oracle_scan(O, c, sa, lcp, ns, minl, minn)
+        if ns > 2:
+            got = g.getmultimums(minlength=minl, minn=minn)
+            assert got == want
+        else:
+            got = g.getmums(minl)
+            assert got == [(l, (spd[0][1], spd[1][1]), 0) for l, _, spd in want]
+        view = Node(nd, nsub)
+        r = rem.bench_mumpicker(want, view)
+        if r == ():
+            continue
+        mum = r[0]
+        ga = rem.linear_graphalign(view, mum)
+        if ga is None:
+            continue
+        lead, trail, match, rest, merged, newleft, newright = ga
+        kids_o = O.splitindex(c["tbuf"], sa, lcp, c["SAi"], c["SO"], c["nsep"], ns, lead, trail, match, rest)
+        kids_g = g.splitindex(lead, trail, match, rest, merged, newleft, newright, [], [])
+        assert idx.T.encode("latin-1") == bytes(c["tbuf"][:len(T)])
+        for k, ivs in enumerate((lead, trail, rest)):
+            assert (kids_o[k] is None) == (kids_g[k] is None)
+            if kids_o[k] is None:
+                continue
+            assert kids_g[k].depth == g.depth + 1
+            assert kids_g[k].nodes is ivs
+            if len(kids_o[k][0]) > 1:
+                queue.append((kids_g[k], kids_o[k][0], kids_o[k][1], ivs, kids_o[k][2]))
+            else:
+                assert kids_g[k].n == 1 and kids_g[k].SA == [int(kids_o[k][0][0])]
+        # the parent keeps its arrays (reveal.c:1738 only reads them)
+        assert np.array_equal(g.array("SA"), sa) and np.array_equal(g.array("LCP"), lcp)
+        steps += 1
+    return steps
+
+
+@pytest.mark.parametrize("name,inputs,minl,sa64", [
+    ("known", ["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"], 2, False),
+    ("1a1b", fa("1a", "1b"), 20, False),
+    ("1a1b_64", fa("1a", "1b"), 20, True),
+    ("1e1b", fa("1e", "1b"), 20, False),
+    ("1a1b1c", fa("1a", "1b", "1c"), 20, False),
+    ("d1d2", fa("d1", "d2"), 20, False),
+])
+def test_splitindex_recursion(name, inputs, minl, sa64):
+    steps = drive(inputs, minl=minl, sa64=sa64, max_steps=120)
+    assert steps > 0
+
+
+def test_splitindex_synthetic_large():
+    g = synth.genomes(300000, 2, seed=11)
+    steps = drive(g, minl=20, max_steps=40)
+    assert steps == 40
+
+
+def extract_case(inputs, intervals_of, rc=0, sa64=False, again=None):
+    T, nsep, nodes = assemble(inputs)
+    ns = len(inputs)
+    O = oracle(sa64)
+    tb = bytearray(T)
+    if rc:
+        q = np.frombuffer(bytes(T[nsep[0]:]), dtype=np.uint8).copy()
+        O.revcomp(q)
+        tb[nsep[0]:] = q.tobytes()
+    c = O.construct(bytes(tb), nsep, ns)
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct(rc=rc)
+    assert idx.T.encode("latin-1") == bytes(c["tbuf"][:len(T)])
+    n = len(T)
+    ivs = intervals_of(c, n, nsep, nodes)
+    sa_o, lcp_o, iv_o = O.extract(c["tbuf"], c["SA"], c["LCP"], c["SAi"], c["nsep"], ivs, rc=rc, nT=n)
+    given = list(ivs)
+    assert idx.extract(given) is None
+    assert given == iv_o                                           # rc remap written back into the list
+    assert idx.n == len(sa_o)
+    assert np.array_equal(idx.array("SA"), sa_o) and np.array_equal(idx.array("LCP"), lcp_o)
+    assert idx.T.encode("latin-1") == bytes(c["tbuf"][:n])
+    if again:
+        iv2 = again(c, n, nsep, nodes, iv_o)
+        sa_o2, lcp_o2, _ = O.extract(c["tbuf"], sa_o, lcp_o, c["SAi"], c["nsep"], iv2, rc=0, nT=n)
+        idx.extract(list(iv2))
+        assert np.array_equal(idx.array("SA"), sa_o2) and np.array_equal(idx.array("LCP"), lcp_o2)
+        assert idx.T.encode("latin-1") == bytes(c["tbuf"][:n])
+        sa_o, lcp_o = sa_o2, lcp_o2
+    # the shrunken index is still an index: its scan is the oracle's scan of the same arrays
+    if ns == 2:
+        l, a, b = O.getmums(c["tbuf"], sa_o, lcp_o, c["nsep"], 20, rc=rc, nT=n)
+        assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 1 if rc else 0) for k in range(len(l))]
+    return idx
+
+
+def top_mum_intervals(c, n, nsep, nodes):
+    O = oracle(c["SA"].dtype == np.int64)
+    l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], c["nsep"], 20)
+    k = int(np.argmax(l))
+    return [(int(a[k]), int(a[k] + l[k])), (int(b[k]), int(b[k] + l[k]))]
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_extract_top_mum(sa64):
+    extract_case(fa("1a", "1b"), top_mum_intervals, sa64=sa64,
+                 again=lambda c, n, nsep, nodes, first: [(max(first[0][0] - 300, 1), max(first[0][0] - 200, 2)), (first[1][1] + 5, first[1][1] + 90)])
+
+
+def test_extract_many_intervals():
+    def ivs(c, n, nsep, nodes):
+        rng = np.random.default_rng(5)
+        out, at = [], 10
+        while at + 400 < nsep[0]:
+            ln = int(rng.integers(1, 120))
+            out.append((at, at + ln))
+            at += ln + int(rng.integers(1, 900))
+        return out
+    extract_case(fa("1a", "1b"), ivs)
+
+
+def test_extract_multi_sample():
+    def ivs(c, n, nsep, nodes):
+        return [(100, 400), (nsep[0] + 50, nsep[0] + 350), (nsep[1] + 70, nsep[1] + 370)]
+    extract_case(fa("1a", "1b", "1c"), ivs)
+
+
+def test_extract_rc():
+    def ivs(c, n, nsep, nodes):
+        # reference-side interval as is, query-side interval in reverse-complement coordinates (reveal.c:1411-1427)
+        return [(200, 260), (nsep[0] + 1000, nsep[0] + 1060)]
+    extract_case(fa("1a", "1brc"), ivs, rc=1)
+
+
+def test_extract_refusals():
+    from reveal_amd import reveallib
+    idx = feed(reveallib.index(), ["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"])
+    with pytest.raises(TypeError):
+        idx.extract([(1, 3)])                                      # not constructed
+    idx.construct()
+    sa0 = idx.SA[0]
+    with pytest.raises(reveallib.error):
+        idx.extract([(sa0, sa0 + 1)])                              # rank 0 matched: the reference overruns its buffers
+    with pytest.raises(reveallib.error):
+        idx.extract([(2, 5), (4, 8)])                              # overlapping
+    with pytest.raises(reveallib.error):
+        idx.extract([(30, 40)])                                    # outside the text
+    idx.extract([(2, 5)])
+    with pytest.raises(reveallib.error):
+        idx.extract([(3, 4)])                                      # not part of the index any more
+
+
+def test_copy_is_independent():
+    from reveal_amd import reveallib
+    inputs = fa("1a", "1b")
+    idx = feed(reveallib.index(), inputs)
+    idx.construct()
+    cp = idx.copy()
+    assert cp.n == idx.n and cp.nsamples == idx.nsamples and cp.samples == idx.samples and cp.nodes == idx.nodes
+    for name in ("SA", "LCP", "SAi"):
+        assert np.array_equal(cp.array(name), idx.array(name))
+    assert cp.T == idx.T and cp.getmums(20) == idx.getmums(20)
+    before = (idx.array("SA").copy(), idx.array("LCP").copy(), idx.T)
+    r = cp.align_builtin(20, 2)                                    # lower-cases the copy's text, consumes its arrays
+    assert r["stats"]["splits"] > 0
+    assert cp.T != before[2]
+    assert np.array_equal(idx.array("SA"), before[0]) and np.array_equal(idx.array("LCP"), before[1]) and idx.T == before[2]
+    r2 = idx.align_builtin(20, 2)
+    assert r2["stats"]["splits"] == r["stats"]["splits"] and idx.T == cp.T
+    # a child copies its arrays and keeps sharing the text
+    idx2 = feed(reveallib.index(), inputs)
+    idx2.construct()
+    mum = rem.bench_mumpicker([(l, 2, ((0, a), (1, b))) for l, (a, b), _ in idx2.getmums(20)], idx2)[0]
+    lead, trail, match, rest, merged, nl, nr = rem.linear_graphalign(idx2, mum)
+    kl, kt, kp = idx2.splitindex(lead, trail, match, rest, merged, nl, nr, [], [])
+    kc = kl.copy()
+    assert kc.n == kl.n and kc.SA == kl.SA and kc.LCP == kl.LCP and kc.depth == 1
+    assert kc.getmums(20) == kl.getmums(20)

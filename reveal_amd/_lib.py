@@ -127,7 +127,7 @@ class Lib:
         self.sa64 = sa64
         _share_torch_runtime()
         name = "libreveal_amd64.so" if sa64 else "libreveal_amd.so"
-        self.path = os.path.join(_HERE, name)
+        self.path = os.path.join(os.environ.get("RV_LIB_DIR") or _HERE, name)     # RV_LIB_DIR: another build of the two libraries
         if not os.path.exists(self.path):
             raise ImportError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); reveal_amd has no CPU fallback" % self.path)

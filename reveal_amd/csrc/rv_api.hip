@@ -2,6 +2,7 @@
 // construct, getters, top-level scans, profiling and primitive self-tests.
 // The recursion lives in rv_align.hip.
 #include "rv_index.h"
+#include <limits>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -108,6 +109,13 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
         return -1;
     }
 #endif
+    {   // bit 7 of the BWT bytes carries the sample side (rv_common.h): sequence text has to be ASCII
+        uint64_t acc = 0;
+        int64_t k = 0;
+        for (; k + 8 <= len; k += 8) { uint64_t w; memcpy(&w, seq + k, 8); acc |= w; }
+        for (; k < len; k++) acc |= (uint64_t)(uint8_t)seq[k] << 0;
+        if (acc & 0x8080808080808080ull) { rv_set_error("addsequence: the sequence contains non-ASCII bytes"); return -1; }
+    }
     const int64_t s = h->n;
     h->T.resize((size_t)(h->n + len + 2));
     memcpy(h->T.data() + h->n, seq, (size_t)len);
@@ -212,9 +220,10 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
     RV_TRY(h->ws.misc[0].reserve(64));
     u32 *d_max = h->ws.misc[0].as<u32>();
+    const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
     if (!lcpfile || !lcpfile[0]) {
         int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
-        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>()));
+        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>(), side_sep));
         h->prof.end(q, id);
         RV_TRY(rv_read_back(h->ws, &h->maxlcp, d_max, 4));
     } else {
@@ -224,7 +233,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         for (int64_t i = 0; i < n; i++) if ((u32)tmp[(size_t)i] > mx) mx = (u32)tmp[(size_t)i];
         h->maxlcp = mx;
         RV_HIP(hipMemcpyAsync(h->dLCP.p, tmp.data(), (size_t)n * sizeof(lcp_t), hipMemcpyHostToDevice, q));
-        RV_TRY(rv_build_bwt(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), n, h->dBWT.as<uint8_t>()));
+        RV_TRY(rv_build_bwt(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), n, h->dBWT.as<uint8_t>(), side_sep));
         RV_HIP(hipStreamSynchronize(q));
     }
     if (cache == 1) {

@@ -51,6 +51,13 @@ static inline bool rv_launch_trace_on() { static const int on = getenv("RV_LAUNC
 
 static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// BWT level arrays: one byte per rank = the character in front of the suffix ('$' for text position 0); all of them are
+// ASCII, so bit 7 is free: it says on which side of the first sample separator the suffix starts (reveal.c:73).  The pair
+// scan then needs LCP and this byte only (5 B per rank instead of 9) and fetches SA for its few survivors.  The byte travels
+// with its rank through split, bubble_sort and the frontier hand-off; readers of the character mask the bit.
+#define RV_BWT_SIDE 0x80u
+#define RV_BWT_CHAR 0x7fu
+
 // Grow-only device buffer.
 struct DBuf {
     void  *p = nullptr;
@@ -138,6 +145,8 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
 // SAi given: text-order (Kasai) evaluation; NULL: every rank from scratch
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT);
+// side_sep: text position of the first sample separator, nsep[0] (bit RV_BWT_SIDE of a BWT byte = the suffix starts behind
+// it), or the largest sa_t for a single sample (the bit stays clear)
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep);
 // BWT only (when LCP came from a file)
-int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT);
+int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT, sa_t side_sep);

@@ -401,10 +401,10 @@ __device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exa
 // as left-maximal exactly like a '$', reveal.c:81-85), the byte the scans use
 // for the left-maximality test.
 __global__ __launch_bounds__(TB) void k_lcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, int64_t n,
-                                            u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT) {
+                                            u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT, sa_t side_sep) {
     const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 h = 0;
-    if (k < n && BWT) { const sa_t p = SA[k]; BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$'; }
+    if (k < n && BWT) { const sa_t p = SA[k]; BWT[k] = (uint8_t)((p > 0 ? T[p - 1] : (uint8_t)'$') | (p > side_sep ? RV_BWT_SIDE : 0)); }
     if (k < n && k > 0) {
         const uint8_t *pa = T + SA[k - 1], *pb = T + SA[k];
         for (;;) {
@@ -494,14 +494,14 @@ __global__ __launch_bounds__(TB) void k_plcp(const uint8_t *__restrict__ T, cons
     }
 }
 __global__ __launch_bounds__(TB) void k_lcp_gather(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, const u32 *__restrict__ PLCP,
-                                                   lcp_t *__restrict__ LCP, int64_t n, u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT) {
+                                                   lcp_t *__restrict__ LCP, int64_t n, u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT, sa_t side_sep) {
     const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 h = 0;
     if (k < n) {
         const sa_t p = SA[k];
         h = PLCP[p];
         LCP[k] = (lcp_t)h;
-        if (BWT) BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$';
+        if (BWT) BWT[k] = (uint8_t)((p > 0 ? T[p - 1] : (uint8_t)'$') | (p > side_sep ? RV_BWT_SIDE : 0));
     }
     u32 m = h;
     for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_down(m, d, 64); m = o > m ? o : m; }
@@ -510,9 +510,9 @@ __global__ __launch_bounds__(TB) void k_lcp_gather(const uint8_t *__restrict__ T
     if ((threadIdx.x & 63) == 0 && m > __atomic_load_n(maxlcp, __ATOMIC_RELAXED)) atomicMax(maxlcp, m);
 }
 
-__global__ __launch_bounds__(TB) void k_bwt(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, int64_t n, uint8_t *__restrict__ BWT) {
+__global__ __launch_bounds__(TB) void k_bwt(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, int64_t n, uint8_t *__restrict__ BWT, sa_t side_sep) {
     const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (k < n) { const sa_t p = SA[k]; BWT[k] = p > 0 ? T[p - 1] : (uint8_t)'$'; }
+    if (k < n) { const sa_t p = SA[k]; BWT[k] = (uint8_t)((p > 0 ? T[p - 1] : (uint8_t)'$') | (p > side_sep ? RV_BWT_SIDE : 0)); }
 }
 
 inline int bitlen(u64 v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
@@ -526,18 +526,18 @@ int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n) {
     return 0;
 }
 
-int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT) {
+int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT, sa_t side_sep) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL(k_bwt, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, n, BWT);
+    hipLaunchKernelGGL(k_bwt, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, n, BWT, side_sep);
     RV_LAUNCH_CHECK();
     return 0;
 }
 
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT) {
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep) {
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
     if (!SAi || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
-        hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT);
+        hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT, side_sep);
         RV_LAUNCH_CHECK();
         return 0;
     }
@@ -545,7 +545,7 @@ int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SA
     RV_TRY(plcp.reserve((size_t)n * 4));
     hipLaunchKernelGGL(k_plcp, dim3((unsigned)ceil_div(ceil_div(n, PHI_K), TB)), dim3(TB), 0, ws.stream, T, SA, SAi, plcp.as<u32>(), n);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_lcp_gather, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, (const u32 *)plcp.as<u32>(), LCP, n, d_maxlcp, BWT);
+    hipLaunchKernelGGL(k_lcp_gather, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, (const u32 *)plcp.as<u32>(), LCP, n, d_maxlcp, BWT, side_sep);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -115,7 +115,7 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
     const RvLeafRoot root = A.roots[blockIdx.x];
     const int tid = threadIdx.x;
     for (int i = tid; i < root.n; i += NT) {
-        sa[i] = A.SA[root.off + i]; lc[i] = (u32)A.LCP[root.off + i]; bw[i] = A.BWT[root.off + i];
+        sa[i] = A.SA[root.off + i]; lc[i] = (u32)A.LCP[root.off + i]; bw[i] = A.BWT[root.off + i] & RV_BWT_CHAR;      /* (the side bit is for the streaming scan; here SA is in LDS) */
     }
     if (tid == 0) {
         Frame f; f.start = 0; f.len = (int)root.n; f.depth = root.depth; f.a0 = root.a0; f.a1 = root.a1; f.b0 = root.b0; f.b1 = root.b1;

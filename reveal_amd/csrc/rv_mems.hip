@@ -70,7 +70,7 @@ __global__ __launch_bounds__(64) void k_multimems_seq(MemsArgs A) {
             if (j <= ub) {
                 if (A.nsamples > 2) my = in_lds ? (int)r_so[j & (RING - 1)] : sample_of_pos(A.nsep, nsep_n, A.SA[j]);
                 if (j < ub) {
-                    const uint8_t ca = in_lds ? r_bw[j & (RING - 1)] : A.BWT[j], cb = in_lds ? r_bw[(j + 1) & (RING - 1)] : A.BWT[j + 1];      // '$' stands for "position 0" (SA == 0)
+                    const uint8_t ca = in_lds ? r_bw[j & (RING - 1)] : (uint8_t)(A.BWT[j] & RV_BWT_CHAR), cb = in_lds ? r_bw[(j + 1) & (RING - 1)] : (uint8_t)(A.BWT[j + 1] & RV_BWT_CHAR);      // '$' stands for "position 0" (SA == 0)
                     maximal |= (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | is_lower_c(ca);
                 }
             }
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(64) void k_multimems_seq(MemsArgs A) {
             if (r < A.n) {
                 const sa_t p = A.SA[r];
                 s_lcp[k] = (u32)A.LCP[r];
-                r_sa[r & (RING - 1)] = p; r_bw[r & (RING - 1)] = A.BWT[r];
+                r_sa[r & (RING - 1)] = p; r_bw[r & (RING - 1)] = A.BWT[r] & RV_BWT_CHAR;
                 r_so[r & (RING - 1)] = (uint8_t)(A.nsamples > 2 ? sample_of_pos(A.nsep, nsep_n, p) : (p > sep0 ? 1 : 0));
             } else s_lcp[k] = 0u;
         }

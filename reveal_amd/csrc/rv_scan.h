@@ -2,7 +2,9 @@
 #pragma once
 #include "rv_common.h"
 
+#ifndef RV_PAIR_TILE
 #define RV_PAIR_TILE 512     // ranks per tile of the pair scan = what one wave scans
+#endif
 #define RV_TSUB_TILE 2048    // granularity of the tile -> sub-index tables the host ships (== RV_SPLIT_TILE)
 
 // one pairwise MUM: a < b text positions, l = LCP[rank], rank inside the

@@ -63,15 +63,22 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     // trip per wave (measured: the bare load pattern of this kernel streams 6.3 TB/s, the kernel 3.5).
     const int64_t wfirst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63)) * (int64_t)PAIR_ITEMS + tile * PAIR_TILE;
     const int64_t wnext = wfirst + 64 * PAIR_ITEMS;
-    sa_t h_sa = 0; lcp_t h_lc = 0, h_nlc = 0; uint8_t h_bw = 0;
-    if (wfirst > 0 && wfirst - 1 < m) { h_sa = SA[wfirst - 1]; h_lc = LCP[wfirst - 1]; h_bw = BWT[wfirst - 1]; }
+    lcp_t h_lc = 0, h_nlc = 0; uint8_t h_bw = 0;
+    if (wfirst > 0 && wfirst - 1 < m) { h_lc = LCP[wfirst - 1]; h_bw = BWT[wfirst - 1]; }
     if (wnext < m) h_nlc = LCP[wnext];
 
-    sa_t sa[PAIR_ITEMS];
+    // What is streamed: LCP (4 B) and the BWT byte, whose bit 7 says on which side of the separator the suffix starts
+    // (RV_BWT_SIDE, rv_common.h) -- the predicate of reveal.c:61-85 needs nothing else of SA.  SA is fetched for the
+    // survivors only (one in a few hundred ranks).
     lcp_t lc[PAIR_ITEMS];
     uint8_t bw[PAIR_ITEMS];
     if (i0 + PAIR_ITEMS <= m) {
         // streamed once: non-temporal 16-byte loads (8 B of BWT)
+        if (PAIR_ITEMS == 4) {
+            const u32 bb = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(BWT + i0));
+#pragma unroll
+            for (int k = 0; k < 4 && k < PAIR_ITEMS; k++) bw[k] = (uint8_t)(bb >> (8 * k));
+        }
 #pragma unroll
         for (int v8 = 0; v8 < PAIR_ITEMS / 8; v8++) {
             const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0) + v8);
@@ -80,34 +87,21 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         }
 #pragma unroll
         for (int v4 = 0; v4 < PAIR_ITEMS / 4; v4++) {
-#ifndef RV_SA64
-            const v4i v = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(SA + i0) + v4);
-            sa[4 * v4] = v.x; sa[4 * v4 + 1] = v.y; sa[4 * v4 + 2] = v.z; sa[4 * v4 + 3] = v.w;
-#else
-#pragma unroll
-            for (int k = 0; k < 4; k++) sa[4 * v4 + k] = __builtin_nontemporal_load(SA + i0 + 4 * v4 + k);
-#endif
             const v4i c = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(LCP + i0) + v4);
             lc[4 * v4] = (lcp_t)c.x; lc[4 * v4 + 1] = (lcp_t)c.y; lc[4 * v4 + 2] = (lcp_t)c.z; lc[4 * v4 + 3] = (lcp_t)c.w;
         }
     } else {
 #pragma unroll
         for (int k = 0; k < PAIR_ITEMS; k++) {
-            sa[k] = (i0 + k < m) ? SA[i0 + k] : (sa_t)0;
             lc[k] = (i0 + k < m) ? LCP[i0 + k] : (lcp_t)0;
             bw[k] = (i0 + k < m) ? BWT[i0 + k] : (uint8_t)0;
         }
     }
-    // neighbours: previous rank's SA/LCP, next rank's LCP (0 past the end)
-#ifdef RV_SA64
-    sa_t  psa = (sa_t)__shfl_up((long long)sa[PAIR_ITEMS - 1], 1, 64);
-#else
-    sa_t  psa = (sa_t)__shfl_up((int)sa[PAIR_ITEMS - 1], 1, 64);
-#endif
+    // neighbours: previous rank's LCP / BWT byte, next rank's LCP (0 past the end)
     lcp_t plc = (lcp_t)__shfl_up((int)lc[PAIR_ITEMS - 1], 1, 64);
     lcp_t nlc = (lcp_t)__shfl_down((int)lc[0], 1, 64);
     uint8_t pbw = (uint8_t)__shfl_up((int)bw[PAIR_ITEMS - 1], 1, 64);
-    if (lane == 0) { psa = h_sa; plc = h_lc; pbw = h_bw; }
+    if (lane == 0) { plc = h_lc; pbw = h_bw; }
     if (lane == 63) nlc = h_nlc;
 
     // The predicate, branch-free (bitwise & | on the comparison results): written with && / ?: the compiler emitted one
@@ -115,21 +109,19 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     // Ranks past the end were loaded as zeros and a sub-index' first rank has LCP 0, so neither can pass `lb < l`:
     // no bounds tests are needed here.
     u32 hit = 0;        // bitmask over my ranks
-    bool side_prev = psa > nsep0;
 #pragma unroll
     for (int k = 0; k < PAIR_ITEMS; k++) {
-        const sa_t  s1 = sa[k], s0 = (k == 0) ? psa : sa[k - 1];
         const lcp_t l = lc[k], lb = (k == 0) ? plc : lc[k - 1];
         const lcp_t la = (k == PAIR_ITEMS - 1) ? nlc : lc[k + 1];
-        const bool side = s1 > nsep0;
-        const uint8_t c1 = bw[k], c0 = (k == 0) ? pbw : bw[k - 1];
-        const uint8_t ca = s1 < s0 ? c1 : c0;                  // the character in front of the smaller text position
-        const bool special = (ca == 'N') | (ca == '$') | ((uint8_t)(ca - 'a') < 26);
-        const bool ok = (!lcp_lt(l, minl)) & (side != side_prev)   // long enough; not a repeat inside one sample
+        const u32 b1 = bw[k], b0 = (k == 0) ? pbw : bw[k - 1];
+        const u32 c1 = b1 & RV_BWT_CHAR, c0 = b0 & RV_BWT_CHAR;
+        // reveal.c:81-85 inspects the character in front of the SMALLER text position for N / $ / lower case; that only
+        // decides anything when the two characters are equal, and then either of them will do
+        const bool special = (c1 == 'N') | (c1 == '$') | ((c1 - 'a') < 26u);
+        const bool ok = (!lcp_lt(l, minl)) & (((b1 ^ b0) & RV_BWT_SIDE) != 0)   // long enough; not a repeat inside one sample
                       & (lb < l) & (la < l)                       // unique
                       & ((c1 != c0) | special);                   // left-maximal (reveal.c:81-85)
         hit |= (u32)ok << k;
-        side_prev = side;
     }
     // order-preserving append of the survivors.  A tile is what one wave scans (512 ranks): no workgroup barrier, a wave
     // retires as soon as its own loads are consumed.
@@ -155,7 +147,7 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
 #pragma unroll
         for (int k = 0; k < PAIR_ITEMS; k++) {
             if (hit & (1u << k)) {
-                const sa_t s1 = sa[k], s0 = (k == 0) ? psa : sa[k - 1];
+                const sa_t s1 = SA[i0 + k], s0 = SA[i0 + k - 1];      // (a survivor is never the first rank of the arrays: its LCP is 0)
                 RvPairRec r;
                 r.a = s1 < s0 ? s1 : s0;
                 r.b = s1 < s0 ? s0 : s1;
@@ -298,7 +290,7 @@ __device__ inline bool ismultimum_dev(const sa_t *__restrict__ SA, const uint8_t
         }
     }
     for (int64_t j = lb; j < ub; j++) {       // reveal.c:246-256; BWT holds '$' where SA == 0
-        const uint8_t ca = BWT[j], cb = BWT[j + 1];
+        const uint8_t ca = BWT[j] & RV_BWT_CHAR, cb = BWT[j + 1] & RV_BWT_CHAR;
         if (cb == '$' || ca != cb || ca == 'N' || ca == '$' || is_lower_c(ca)) return true;
     }
     return false;

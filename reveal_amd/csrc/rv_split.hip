@@ -280,7 +280,8 @@ __device__ __forceinline__ void emit_item(const RvSplitArgs &a, const EmitSub &s
                     // of a suffix that starts right behind a matched range has just been lower-cased (reveal.c:1230-1234)
             bool hit = (sa == sb.mnd0) | (sa == sb.mnd1);
             for (int q = sb.qm0 + 2; q < sb.qm1 && !hit; q++) hit = sa == a.mend_pos[q];
-            if (hit && bo >= 'A' && bo <= 'Z') bo += 32;
+            const uint8_t ch = bo & RV_BWT_CHAR;                      // (bit 7 = side of the separator, kept)
+            if (hit && ch >= 'A' && ch <= 'Z') bo += 32;
         }
         if (idx >= cn) {
             atomicOr(a.err, 1u);                                     // more ranks labelled for this child than its intervals hold

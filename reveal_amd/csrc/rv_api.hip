@@ -537,7 +537,7 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     const int W = h->nsamples;
     DBuf &bbest = h->ws.misc[12], &bl = h->ws.misc[13], &bpos = h->ws.misc[7], &bcand = h->ws.misc[8], &bcnt = h->ws.misc[1];
     RV_TRY(bbest.reserve((size_t)nsubs * 8)); RV_TRY(bl.reserve((size_t)nsubs * 4)); RV_TRY(bpos.reserve((size_t)nsubs * W * sizeof(sa_t)));
-    RV_TRY(bcnt.reserve(64));
+    RV_TRY(bcnt.reserve((RV_MULTI_REGIONS * 64 + 16) * 4));
     if (bcand.cap < 65536 * RV_MULTI_CAND_BYTES) RV_TRY(bcand.reserve((size_t)std::max<int64_t>(65536, m / 64) * RV_MULTI_CAND_BYTES));
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t ccap = bcand.cap / RV_MULTI_CAND_BYTES;
@@ -553,7 +553,7 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
             RV_TRY(h->ws.hpin.reserve(o2 + b2 + 64));
             uint8_t *hp = h->ws.hpin.as<uint8_t>();
             if (!h->ws.ev_rb) RV_HIP(hipEventCreateWithFlags(&h->ws.ev_rb, hipEventDisableTiming));
-            RV_HIP(hipMemcpyAsync(hp, bcnt.p, 4, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(hp, bcnt.as<u32>() + RV_MULTI_REGIONS * 64, 4, hipMemcpyDeviceToHost, q));      // the fullest region of the list
             RV_HIP(hipMemcpyAsync(hp + o1, bl.p, b1, hipMemcpyDeviceToHost, q));
             RV_HIP(hipMemcpyAsync(hp + o2, bpos.p, b2, hipMemcpyDeviceToHost, q));
             RV_HIP(hipEventRecord(h->ws.ev_rb, q));
@@ -562,8 +562,8 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
             if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; }
             memcpy(&ncand, hp, 4); memcpy(pick_l.data(), hp + o1, b1); memcpy(pick_pos.data(), hp + o2, b2);
         }
-        if (ncand <= ccap) return 0;
-        RV_TRY(bcand.reserve((size_t)ncand * RV_MULTI_CAND_BYTES));
+        if ((size_t)ncand <= ccap / RV_MULTI_REGIONS) return 0;
+        RV_TRY(bcand.reserve(((size_t)ncand + ncand / 2 + 64) * RV_MULTI_REGIONS * RV_MULTI_CAND_BYTES));
     }
     rv_set_error("multi picker: candidate buffer sizing failed");
     return -1;

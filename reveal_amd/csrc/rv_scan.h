@@ -59,3 +59,4 @@ int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
                          const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub /* sub-index of rank t * RV_TSUB_TILE */,
                          unsigned long long *best, u32 *pick_l, sa_t *pick_pos, RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
 #define RV_MULTI_CAND_BYTES 16
+#define RV_MULTI_REGIONS 64      // the picker's candidate list: regions with a counter each (counter r at word 64 * r, the largest count at word 64 * RV_MULTI_REGIONS)

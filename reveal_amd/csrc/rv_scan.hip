@@ -391,62 +391,185 @@ __global__ __launch_bounds__(TB) void k_multi_pick1(const sa_t *__restrict__ SA,
                                                     const int *__restrict__ tile_sub,
                                                     unsigned long long *__restrict__ best, u32 *__restrict__ /*pick_l: zeroed by the host*/,
                                                     RvMultiCand *__restrict__ cand, u32 cand_cap, u32 *__restrict__ cand_count) {
-    // sample boundaries in LDS: ismultimum looks up the sample of every member (a binary search each)
+    // One block per 2048-rank tile of the host's tile -> sub-index table (so the sub-index of the block's first rank needs
+    // no search), eight ranks per thread.  All global reads a tile needs are issued up front -- LCP and BWT of its ranks
+    // and of the MP_HALO ranks in front (a candidate interval of up to MP_HALO ranks ends at u), the starts and sample
+    // counts of the sub-indices that begin inside it -- and land in LDS; the interval's value, left-maximality and the
+    // owning sub-index then cost no further memory round trip.  (One block per 256 ranks with its own search for the
+    // first sub-index ran at 13 ps per rank: a chain of three to four round trips per 256 ranks, 2048 blocks in flight.)
+    // At the top levels one rank in `nsamples` closes a candidate interval (every conserved position closes the group of
+    // its copies) and only left-maximality thins them out; SA is gathered for the few ranks that pass.
+    constexpr int MP_HALO = 16, MP_TILE = RV_TSUB_TILE, MP_ITEMS = MP_TILE / TB;
     __shared__ sa_t s_nsep[256];
+    __shared__ u32 s_lcp[MP_TILE + MP_HALO + 1];
+    __shared__ uint8_t s_bw[MP_TILE + MP_HALO + 1];
+    __shared__ short s_ss[MP_TILE + 2];        // starts of the tile's sub-indices relative to u0 (clipped below at -2 * MP_HALO)
+    __shared__ uint8_t s_want[MP_TILE + 2];    // their sample counts, 255 = more than MP_HALO (LDS is what limits the tiles in flight)
     const bool lds_sep = nsamples - 1 <= 256;
     if (lds_sep) { for (int k = threadIdx.x; k < nsamples - 1; k += TB) s_nsep[k] = nsep[k]; }
-    __syncthreads();
     const sa_t *sep = lds_sep ? s_nsep : nsep;
-    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int64_t tt = blockIdx.x, u0 = tt * MP_TILE, ntsub = (m + MP_TILE - 1) / MP_TILE;
     const int lane = threadIdx.x & 63;
-    const u32 lmin = (u32)(minl > 1 ? minl : 1);
-    bool ok = u >= 1 && u < m;
-    u32 cur = 0, nxt = 0;
-    if (ok) { cur = (u32)LCP[u]; nxt = (u + 1 < m) ? (u32)LCP[u + 1] : 0u; ok = cur > nxt && cur >= lmin; }
-    int s = 0; int64_t lb = 0; u32 l = 0;
-    if (ok) {
-        // owning sub-index: from the host's table for the 2048-rank tile of u, then a few steps forward
-        s = tile_sub[u / RV_TSUB_TILE];
-        int64_t s_end = sub_start[s + 1];
-        for (int step = 0; u >= s_end && step < 8; step++) { s++; s_end = sub_start[s + 1]; }
-        if (u >= s_end) {
-            int lo2 = s, hi2 = nsubs;
-            while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
-            s = lo2 - 1;
+#pragma unroll
+    for (int i = 0; i < MP_ITEMS; i++) {
+        const int at = i * TB + (int)threadIdx.x;
+        const int64_t j = u0 + at;
+        s_lcp[MP_HALO + at] = j < m ? (u32)LCP[j] : 0u;
+        s_bw[MP_HALO + at] = j < m ? (uint8_t)(BWT[j] & RV_BWT_CHAR) : (uint8_t)0;
+    }
+    if (threadIdx.x <= MP_HALO) {      // MP_HALO ranks in front, one behind
+        const int64_t j = threadIdx.x < MP_HALO ? u0 - MP_HALO + threadIdx.x : u0 + MP_TILE;
+        const int at = threadIdx.x < MP_HALO ? (int)threadIdx.x : MP_HALO + MP_TILE;
+        const bool in = j >= 0 && j < m;
+        s_lcp[at] = in ? (u32)LCP[j] : 0u;
+        s_bw[at] = in ? (uint8_t)(BWT[j] & RV_BWT_CHAR) : (uint8_t)0;
+    }
+    const int s0 = tile_sub[tt];                                               // sub-index of rank u0
+    const int s1 = tt + 1 < ntsub ? tile_sub[tt + 1] : nsubs - 1;              // ... of the next tile's first rank
+    const int nss = s1 - s0 + 1;                                               // sub-indices with ranks in this tile: at most MP_TILE + 1
+    for (int k = threadIdx.x; k < nss + 1 && k < MP_TILE + 2; k += TB) {
+        const int q = s0 + k;
+        const int64_t rel = sub_start[q < nsubs ? q : nsubs] - u0;            // (sub_start[nsubs] = m)
+        s_ss[k] = (short)(rel < -2 * MP_HALO ? -2 * MP_HALO : rel > 2 * MP_TILE ? 2 * MP_TILE : (int)rel);
+        const int wv = sub_want[q < nsubs ? q : nsubs - 1];
+        s_want[k] = (uint8_t)(wv < 0 ? 0 : wv > 254 ? 255 : wv);
+    }
+    __syncthreads();
+    // left-maximality evidence per pair of neighbouring ranks (reveal.c:246-256; BWT holds '$' where SA == 0) as one bit each:
+    // a candidate then tests its whole window with a shift and a mask instead of a loop (the kernel is bound by instruction
+    // issue: one rank in `nsamples` is a candidate, so every wave walks the slow path)
+    __shared__ u64 s_d[(MP_TILE + MP_HALO) / 64 + 2];
+    for (int q = threadIdx.x; q < MP_TILE + MP_HALO + 64; q += TB) {
+        bool d = false;
+        if (q < MP_TILE + MP_HALO) {
+            const u32 ca = s_bw[q], cb = s_bw[q + 1];
+            d = (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca - 'a') < 26u);
         }
-        const int want = sub_want[s];
-        lb = u - want + 1;
-        ok = want >= minn && want >= 2 && want <= nsamples && lb >= sub_start[s];
-        if (ok) {
+        const u64 bits = __ballot(d);
+        if (lane == 0) s_d[q >> 6] = bits;
+    }
+    __syncthreads();
+    const u32 lmin = (u32)(minl > 1 ? minl : 1);
+    // Phase 1, from LDS only: the ranks that close an interval of the wanted size with the right value and left-maximal.
+    // They are few (about one in a hundred) but spread over every wave; checking their members' samples right here cost
+    // every wave a gather of SA per item, eight items one after the other.  They are listed instead, and in phase 2 one
+    // thread per listed rank fetches all its members at once: one more round trip per tile.
+    constexpr int MP_LIST = 256;
+    __shared__ u32 s_list[MP_LIST][3];     // (LDS index | want << 16, sub-index slot, interval value)
+    __shared__ u32 s_nlist;
+    if (threadIdx.x == 0) s_nlist = 0;
+    __syncthreads();
+    for (int i = 0; i < MP_ITEMS; i++) {
+        const int me = MP_HALO + i * TB + (int)threadIdx.x;
+        const int rel = i * TB + (int)threadIdx.x;
+        const int64_t u = u0 + rel;
+        bool ok = u >= 1 && u < m;
+        u32 cur = 0, nxt = 0;
+        if (ok) { cur = s_lcp[me]; nxt = s_lcp[me + 1]; ok = cur > nxt && cur >= lmin; }      // (past the end: stored as 0)
+        if (!ok) continue;
+        int lo2 = 0, hi2 = nss - 1;                                    // largest k with s_ss[k] <= rel
+        while (lo2 < hi2) { const int mid = (lo2 + hi2 + 1) >> 1; if (s_ss[mid] <= rel) lo2 = mid; else hi2 = mid - 1; }
+        int want = s_want[lo2];
+        if (want == 255) want = sub_want[s0 + lo2];
+        ok = want >= minn && want >= 2 && want <= nsamples && rel - want + 1 >= (want > MP_HALO ? sub_start[s0 + lo2] - u0 : (int64_t)s_ss[lo2]);
+        if (!ok) continue;
+        u32 l = cur;
+        bool listed = false;
+        if (want <= MP_HALO && nsamples > 2 && nsamples <= 64) {
+            const int w0 = me - (want - 1);                               // pairs (w0, w0+1) .. (me-1, me)
+            const int off = w0 & 63;
+            u64 bits = s_d[w0 >> 6] >> off;
+            if (off) bits |= s_d[(w0 >> 6) + 1] << (64 - off);
+            ok = (bits & ((1ull << (want - 1)) - 1ull)) != 0;             // left-maximal: what thins the candidates out
+            if (ok) {
+                // value of the interval [lb, u] = min LCP[lb+1 .. u]; it is an interval iff LCP[lb] < value > LCP[u+1]
+                for (int k = 1; k < want - 1; k++) { const u32 v = s_lcp[me - k]; l = v < l ? v : l; }
+                ok = l > nxt && l >= lmin && s_lcp[w0] < l;
+            }
+            if (ok) {
+                const u32 at = atomicAdd(&s_nlist, 1u);
+                if (at < MP_LIST) { s_list[at][0] = (u32)me | ((u32)want << 16); s_list[at][1] = (u32)lo2; s_list[at][2] = l; listed = true; }
+            }
+        }
+        if (ok && !listed) {       // the general form (more than MP_HALO or 64 samples, or a full list): everything from global memory
+            const int64_t lb = u - want + 1;
+            const int sub = s0 + lo2;
             l = cur;
             for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
             ok = l > nxt && l >= lmin && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, sep, nsamples, lb, u);
+            if (ok) {
+                sa_t mn = SA[lb];
+                for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; }
+                const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
+                if (key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
+                    atomicMax(&best[sub], key);
+                    const u32 reg = blockIdx.x % RV_MULTI_REGIONS, rcap = cand_cap / RV_MULTI_REGIONS;
+                    const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
+                    if (q < rcap) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rcap + q] = c; }
+                }
+            }
         }
     }
-    unsigned long long key = 0;
-    if (ok) {
-        sa_t mn = SA[lb];
-        for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; }
-        key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
-        atomicMax(&best[s], key);
-    }
-    const u64 bal = __ballot(ok);
-    if (bal) {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(cand_count, (u32)__popcll(bal));
-        base = __shfl(base, 0, 64);
+    __syncthreads();
+    // Phase 2: the members of every listed rank in one round trip (independent, predicated loads): their samples must all
+    // differ (reveal.c:231-244); the smallest position goes into the key.
+    const u32 nlist = s_nlist < (u32)MP_LIST ? s_nlist : (u32)MP_LIST;
+    for (u32 base = 0; base < nlist; base += TB) {
+        const u32 t = base + threadIdx.x;
+        bool ok = t < nlist;
+        unsigned long long key = 0; int64_t u = 0; int sub = 0;
         if (ok) {
-            const u32 q = base + (u32)__popcll(bal & ((1ull << lane) - 1ull));
-            if (q < cand_cap) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)s; c.key = key; cand[q] = c; }
+            const u32 e0 = s_list[t][0];
+            const int me = (int)(e0 & 0xffffu), want = (int)(e0 >> 16);
+            const u32 l = s_list[t][2];
+            sub = s0 + (int)s_list[t][1];
+            u = u0 + (me - MP_HALO);
+            const int64_t lb = u - want + 1;
+            sa_t sv[MP_HALO];
+#pragma unroll
+            for (int k = 0; k < MP_HALO; k++) sv[k] = SA[k < want ? lb + k : u];
+            u64 seen = 0; bool distinct = true;
+            sa_t mn = sv[0];
+#pragma unroll
+            for (int k = 0; k < MP_HALO; k++) {
+                if (k < want) {
+                    const u64 bit = 1ull << sample_of_pos(sep, nsamples - 1, sv[k]);
+                    distinct &= !(seen & bit); seen |= bit;
+                    mn = sv[k] < mn ? sv[k] : mn;
+                }
+            }
+            key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
+            // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be
+            // the winner pass 2 looks for (the maximum never falls): the others are not even listed.  At the top levels every
+            // candidate of the level aims at the same few words, and one list counter took an atomic from every other wave
+            // (160 K atomics on one address: 0.9 ms per level, whatever else the kernel did).
+            ok = distinct && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED);
+            if (ok) atomicMax(&best[sub], key);
+        }
+        // the list is kept in RV_MULTI_REGIONS regions with a counter each (256 B apart: different L2 channels), chosen by block
+        const u64 bal = __ballot(ok);
+        if (bal) {
+            const u32 reg = blockIdx.x % RV_MULTI_REGIONS, rcap = cand_cap / RV_MULTI_REGIONS;
+            u32 qb = 0;
+            if (lane == 0) qb = atomicAdd(&cand_count[reg * 64], (u32)__popcll(bal));
+            qb = __shfl(qb, 0, 64);
+            if (ok) {
+                const u32 q = qb + (u32)__popcll(bal & ((1ull << lane) - 1ull));
+                if (q < rcap) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rcap + q] = c; }
+            }
         }
     }
 }
 __global__ __launch_bounds__(TB) void k_multi_pick2(const sa_t *__restrict__ SA, const int *__restrict__ sub_want, int W,
                                                     const unsigned long long *__restrict__ best, const RvMultiCand *__restrict__ cand, u32 cand_cap,
                                                     const u32 *__restrict__ cand_count, u32 *__restrict__ pick_l, sa_t *__restrict__ pick_pos) {
-    const u32 total = *cand_count < cand_cap ? *cand_count : cand_cap;
-    for (u32 q = blockIdx.x * TB + threadIdx.x; q < total; q += gridDim.x * TB) {
-        const RvMultiCand c = cand[q];
+    // grid = RV_MULTI_REGIONS x 4 blocks: four blocks per region of the list
+    const u32 reg = blockIdx.x / 4, part = blockIdx.x % 4, rcap = cand_cap / RV_MULTI_REGIONS;
+    const u32 cnt = cand_count[reg * 64];
+    if (part == 0 && threadIdx.x == 0) atomicMax(const_cast<u32 *>(&cand_count[RV_MULTI_REGIONS * 64]), cnt);      // what the host sizes the list by
+    const u32 total = cnt < rcap ? cnt : rcap;
+    for (u32 q = part * TB + threadIdx.x; q < total; q += 4 * TB) {
+        const RvMultiCand c = cand[(size_t)reg * rcap + q];
         if (best[c.sub] != c.key) continue;
         const int want = sub_want[c.sub];
         const int64_t lb = (int64_t)c.ub - want + 1;
@@ -461,11 +584,11 @@ int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
     if (m <= 0 || nsubs <= 0) return 0;
     RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
     RV_HIP(hipMemsetAsync(pick_l, 0, (size_t)nsubs * 4, ws.stream));
-    RV_HIP(hipMemsetAsync(cand_count, 0, 4, ws.stream));
-    hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
+    RV_HIP(hipMemsetAsync(cand_count, 0, (RV_MULTI_REGIONS * 64 + 1) * 4, ws.stream));
+    hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, RV_TSUB_TILE)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
                        sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_multi_pick2, dim3(256), dim3(TB), 0, ws.stream, SA, sub_want, nsamples, (const unsigned long long *)best,
+    hipLaunchKernelGGL(k_multi_pick2, dim3(RV_MULTI_REGIONS * 4), dim3(TB), 0, ws.stream, SA, sub_want, nsamples, (const unsigned long long *)best,
                        (const RvMultiCand *)cand, cand_cap, (const u32 *)cand_count, pick_l, pick_pos);
     RV_LAUNCH_CHECK();
     return 0;

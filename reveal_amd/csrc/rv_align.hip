@@ -197,6 +197,10 @@ void rv_align_free(rv_index *h) {
     if (h->al) { h->al->release(); delete h->al; h->al = nullptr; }
 }
 
+// leading children above this many ranks take the data-parallel bubble rounds.  Measured crossovers: two samples (one cut per
+// sample, C2) 512 K; more samples (a cut per sample and child, C3: 184 ms per step against 195) 256 K
+static int64_t bubble_par_default(bool multi) { return multi ? (int64_t)RV_BUBBLE_PAR_N / 2 : (int64_t)RV_BUBBLE_PAR_N; }
+
 static const sa_t *cur_sa(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dSA.as<sa_t>() : a->lvSA[a->cur].as<sa_t>(); }
 static const lcp_t *cur_lcp(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dLCP.as<lcp_t>() : a->lvLCP[a->cur].as<lcp_t>(); }
 static const uint8_t *cur_bwt(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dBWT.as<uint8_t>() : a->lvBWT[a->cur].as<uint8_t>(); }
@@ -283,7 +287,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->multi = h->nsamples > 2;
     a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false; a->use_leaf = false;
-    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
     RV_TRY(a->dErr.reserve(64));
     RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, h->ws.stream));
     memset(&a->st, 0, sizeof a->st);
@@ -691,7 +695,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
     // leading children above this many ranks take the data-parallel bubble rounds (RV_BUBBLE_PAR_MIN: test hook)
-    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
     struct Ent { int64_t b, e; uint8_t c; };
     std::vector<Ent> ent;
     a->kid_tmp.clear();
@@ -1441,7 +1445,7 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         a->multi = h->nsamples > 2;
         a->scanned = false; a->d_err = nullptr; a->flag_clean = false;
         a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
-        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
         a->full_only = !a->trace_on;
@@ -1493,7 +1497,7 @@ static int sx_load(rv_subindex *x, int minl, int minn) {
     a->multi = h->nsamples > 2;
     a->scanned = false; a->d_err = nullptr; a->flag_clean = false; a->full_only = false; a->use_leaf = false; a->leaf_launch_due = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
-    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : (int64_t)RV_BUBBLE_PAR_N;
+    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
     RV_TRY(a->dErr.reserve(64));
     memset(&a->st, 0, sizeof a->st);
     const int64_t meta[6] = {0, x->n, x->depth, x->nsamples, 0, -1};

@@ -163,12 +163,17 @@ def test_parallel_bubble_rounds(monkeypatch, par_min, name, inputs, minl, sa64):
     ("synth_pair", None, 20),
     ("1a1b1c", fa("1a", "1b", "1c"), 20),
     ("5way", fa("1a", "1b", "1c", "1d", "1e"), 20),
+    ("synth12", (30000, 12), 20),       # picker windows from LDS (up to 16 samples)
+    ("synth20", (20000, 20), 20),       # more than 16 samples: the picker's general form
+    ("synth70", (4000, 70), 15),        # more than 64 samples: sample sets no longer fit a bit mask
 ])
 def test_untraced_run_same_anchors(name, inputs, minl):
     """align_builtin(trace=False) is what bench.py times: leaf kernel, device-side picker (pair) and pre-selection (multi)
     are on, the host never sees the full MUM lists -- the anchor set and the final text must not change"""
     if inputs is None:
         inputs = [g.decode() for g in synth.genomes(400000, 2)]
+    elif isinstance(inputs, tuple):
+        inputs = [g.decode() for g in synth.genomes(inputs[0], inputs[1], seed=3)]
     ref, T = oracle_run(inputs, minl, 2)
     idx = feed(mod(False).index(), inputs)
     idx.construct()

@@ -235,6 +235,23 @@ static int count_samples(rv_index *h, const RvIntv *iv, size_t cnt) {
     return (int)f0 + (int)f1;
 }
 
+/* can the sub-index made of these intervals (sorted by begin) still hold a match of minl bases present in each of its samples? */
+static bool child_is_dead(const rv_index *h, const RvIntv *iv, size_t cnt, int minl, int minn) {
+    const int64_t need = std::max(minl, 1);
+    int ns = 0; size_t sp = 0; int last = -1; int64_t best = 0;
+    for (size_t k = 0; k < cnt; k++) {
+        if (k && iv[k].begin < iv[k - 1].begin) return false;          // (not sorted: no shortcut)
+        while (sp < h->nsep.size() && h->nsep[sp] < iv[k].begin) sp++;
+        if ((int)sp != last) {
+            if (last >= 0 && best < need) return true;
+            ns++; last = (int)sp; best = 0;
+        }
+        best = std::max(best, iv[k].end - iv[k].begin);
+    }
+    if (last >= 0 && best < need) return true;
+    return ns < std::max(minn, 2);
+}
+
 static int need_align(rv_index *h) {
     if (!h->al) { rv_set_error("align not started (rv_align_begin)"); return -1; }
     return 0;
@@ -711,10 +728,20 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         const RvIntv *lists[3] = {dc.lead.data() + dc.lead_first[(size_t)d], dc.trail.data() + dc.trail_first[(size_t)d], dc.rest.data() + dc.rest_first[(size_t)d]};
         const size_t cnts[3] = {(size_t)(dc.lead_first[(size_t)d + 1] - dc.lead_first[(size_t)d]), (size_t)(dc.trail_first[(size_t)d + 1] - dc.trail_first[(size_t)d]),
                                 (size_t)(dc.rest_first[(size_t)d + 1] - dc.rest_first[(size_t)d])};
+        // Untraced runs with the built-in picker and more than two samples: a child in which some sample owns no interval of
+        // minl bases can never hold a match present in all its samples (a match lies inside one interval per sample), so
+        // the picker would return () for it and it would leave after one more level of being split off, bubble-sorted,
+        // scanned and book-kept for nothing -- about every second sub-index of a run is such a leaf.  Its ranks get the
+        // label of matched suffixes (dropped by split, minima updated as for any labelled rank: reveal.c:640-662 treats
+        // them like members of another child), the child is never made.  Anchors and text are unaffected; the number of
+        // sub-indices visited is smaller than the reference's.
+        bool dead[3] = {false, false, false};
+        if (a->multi && a->full_only && !dc.host_lists && !getenv("RV_KEEP_DEAD"))
+            for (int c = 0; c < 3; c++) dead[c] = cnts[c] > 0 && child_is_dead(h, lists[c], cnts[c], a->minl, a->minn);
         // class table of this sub: lead/trail/rest merged by begin
         ent.clear();
         static const uint8_t cls_of[3] = {1, 2, 4};
-        for (int c = 0; c < 3; c++) for (size_t k = 0; k < cnts[c]; k++) if (lists[c][k].end > lists[c][k].begin) ent.push_back({lists[c][k].begin, lists[c][k].end, cls_of[c]});
+        for (int c = 0; c < 3; c++) for (size_t k = 0; k < cnts[c]; k++) if (lists[c][k].end > lists[c][k].begin) ent.push_back({lists[c][k].begin, lists[c][k].end, dead[c] ? (uint8_t)3 : cls_of[c]});
         if (!std::is_sorted(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; }))
             std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; });
         for (size_t k = 0; k < ent.size(); k++) {
@@ -731,7 +758,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         int64_t lead_off = 0, lead_n = 0;
         for (int c = 0; c < 3; c++) {
             int64_t cn = 0;
-            for (size_t k = 0; k < cnts[c]; k++) cn += lists[c][k].end - lists[c][k].begin;
+            if (!dead[c]) for (size_t k = 0; k < cnts[c]; k++) cn += lists[c][k].end - lists[c][k].begin;
             a->child_base[(size_t)s * 3 + c] = (u32)running;
             a->child_n[(size_t)s * 3 + c] = (u32)cn;
             if (c == 0) { lead_off = running; lead_n = cn; }

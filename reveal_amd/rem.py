@@ -2,8 +2,10 @@
 reference's `reveal rem` driver (reveal/rem.py:511-611 align_genomes,
 reveal/utils.py:304-375 read_fasta) plus the deterministic benchmark callbacks
 of SURVEY.md 8(d).  The reference's graph layer (networkx graph, interval tree,
-chaining picker, GFA IO) is out of scope; this module only feeds the index the
-way the reference does and supplies callbacks with the reference's signatures.
+chaining picker) is out of scope; this module feeds the index the way the
+reference does, supplies callbacks with the reference's signatures, and -- for the
+linear interval model of those callbacks -- writes the resulting graph as GFA1
+(reveal_amd/gfa.py; `python -m reveal_amd.rem a.fa b.fa -o out.gfa`).
 """
 import gzip
 import os
@@ -124,3 +126,53 @@ def align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, to
         return r
     idx.align(mumpicker, galign, threads=0, wpen=1, wscore=1, minl=minlength, minn=minn)
     return idx, anchors
+
+
+def rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, builtin=True):
+    """`reveal rem` for FASTA inputs with the benchmark callbacks: index, align, graph, GFA.
+    builtin=True runs the recursion without Python in the loop (index.align_builtin), False through align() and the
+    two Python callbacks -- same anchors.  -> (index, (segments, links, paths), path of the GFA file or None)"""
+    from . import gfa, reveallib, reveallib64
+    mod = reveallib64 if sa64 else reveallib
+    idx = mod.index()
+    seqs = []
+    for f in inputfiles:
+        seqs += read_fasta(f, idx, contigs=contigs, toupper=toupper)
+    if len(idx.samples) <= 1:
+        raise ValueError("Specify at least 2 targets to construct alignment.")
+    text = idx.T.encode("latin-1")                       # before align() lower-cases the matched parts
+    idx.construct()
+    if builtin:
+        l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
+        anchors = [(int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l))]
+    else:
+        picked = []
+
+        def galign(i, mum):
+            r = linear_graphalign(i, mum)
+            if r is not None:
+                picked.append(mum)
+            return r
+        idx.align(bench_mumpicker, galign, threads=0, wpen=1, wscore=1, minl=minlength, minn=minn)
+        anchors = [(m[0], tuple(p for _, p in m[2])) for m in picked]
+    graph = gfa.build_graph(text, seqs, anchors)
+    fn = gfa.write_gfa(output, *graph, toupper=toupper) if output else None
+    return idx, graph, fn
+
+
+def main(argv=None):
+    import argparse
+    ap = argparse.ArgumentParser(prog="python -m reveal_amd.rem", description="recursive exact matching of FASTA files on an MI355X -> GFA1")
+    ap.add_argument("inputfiles", nargs="+")
+    ap.add_argument("-o", "--output", default="reveal_amd.gfa")
+    ap.add_argument("-m", dest="minlength", type=int, default=20)
+    ap.add_argument("-n", dest="minn", type=int, default=2)
+    ap.add_argument("--64", dest="sa64", action="store_true")
+    ap.add_argument("--nocontigs", dest="contigs", action="store_false")
+    a = ap.parse_args(argv)
+    idx, (segments, links, paths), fn = rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs)
+    print("%s: %d segments, %d links, %d paths" % (fn, len(segments), len(links), len(paths)))
+
+
+if __name__ == "__main__":
+    main()

@@ -231,3 +231,33 @@ def test_divided_alignment_protocol_gloo(tmp_path):
     want = sorted([(9, [0, 500])] + [(n, [int(SA[o:o + n].sum()), int(o)]) for o, n in zip(off, sizes)])
     assert [tuple(a) for a in r["anchors"]] == [(l, p) for l, p in want]
     assert sorted(r["shares"]) == [113, 140] and r["splits"] == 8      # (LPT, not optimal: 100+40 | 60+40+7+5+1)
+
+
+@pytest.mark.parametrize("names", [("1a", "1b"), ("1e", "1b"), ("1a", "1b", "1c", "1d", "1e"), ("d1", "d2")])
+def test_gfa_paths_spell_the_inputs(tmp_path, names):
+    """the invariant of the reference's test15 (reveal/tests/test_reveal.py:150-159) for reveal_amd/gfa.py: the graph
+    built from a run's anchors (here: the oracle's, no GPU) spells every input sequence along its path"""
+    from helpers import assemble, fa, oracle
+    from reveal_amd import gfa, rem
+    inputs = fa(*names)
+    T, nsep, nodes = assemble(inputs)
+    O = oracle(False)
+    r = O.align_bench(O.construct(T, nsep, len(inputs)), nodes, 20, 2)
+    l, n, off, pos = r["anchors"]
+    anchors = [(int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l))]
+    records = [(name, s) for f in inputs for name, s in rem.fasta_reader(f)]
+    seqs = [(name, iv) for (name, _), iv in zip(records, nodes)]
+    segments, links, paths = gfa.build_graph(T, seqs, anchors)
+    assert len(paths) == len(records)
+    shared = sum(1 for k in range(len(segments)) if sum(ids.count(k + 1) for _, ids in paths) > 1)
+    assert shared == len(anchors)                              # every anchor is one node on more than one path
+    fn = gfa.write_gfa(str(tmp_path / "out.gfa"), segments, links, paths)
+    seg, lk, pp = gfa.read_gfa(fn)
+    assert [name for name, _ in pp] == [name for name, _ in records]
+    ls = set(lk)
+    for (name, ids), (_, s) in zip(pp, records):
+        assert all((u, v) in ls for u, v in zip(ids, ids[1:]))
+        assert "".join(seg[i] for i in ids) == s.upper()
+    # gzip output and the default extension
+    fn2 = gfa.write_gfa(str(tmp_path / "out2"), segments, links, paths)
+    assert fn2.endswith(".gfa.gz") and gfa.read_gfa(fn2)[2] == pp

@@ -215,3 +215,34 @@ def test_copy_is_independent():
     kc = kl.copy()
     assert kc.n == kl.n and kc.SA == kl.SA and kc.LCP == kl.LCP and kc.depth == 1
     assert kc.getmums(20) == kl.getmums(20)
+
+
+@pytest.mark.parametrize("names,sa64", [(("1a", "1b"), False), (("1e", "1b"), False), (("1a", "1b", "1c"), False), (("1a", "1b"), True)])
+def test_rem_driver_writes_a_graph_that_spells_the_inputs(tmp_path, names, sa64):
+    """FASTA -> index -> recursion -> graph -> GFA (reveal_amd/rem.py rem(), gfa.py): the invariant of the reference's
+    test15 (test_reveal.py:150-159); the built-in recursion and the Python-callback recursion give the same graph"""
+    from reveal_amd import gfa
+    inputs = fa(*names)
+    idx, graph, fn = rem.rem(inputs, str(tmp_path / "a.gfa"), sa64=sa64)
+    records = [(name, s) for f in inputs for name, s in rem.fasta_reader(f)]
+    seg, links, paths = gfa.read_gfa(fn)
+    assert [n for n, _ in paths] == [n for n, _ in records]
+    for (name, ids), (_, s) in zip(paths, records):
+        assert "".join(seg[i] for i in ids) == s.upper()
+    assert gfa.spell_paths(fn)[records[0][0]] == records[0][1].upper()
+    if not sa64:
+        _, graph2, _ = rem.rem(inputs, None, builtin=False)
+        # same anchors in another order: compare the graphs up to node numbering
+        def canon(g):
+            segs, _, pths = g
+            return sorted((name, tuple(bytes(segs[i - 1]).upper() for i in ids)) for name, ids in pths)
+        assert canon(graph) == canon(graph2)
+        assert len(graph[0]) == len(graph2[0]) and len(graph[1]) == len(graph2[1])
+
+
+def test_rem_command_line(tmp_path, capsys):
+    out = str(tmp_path / "cli.gfa")
+    rem.main(fa("1a", "1b") + ["-o", out, "-m", "20"])
+    assert "segments" in capsys.readouterr().out
+    from reveal_amd import gfa
+    assert len(gfa.read_gfa(out)[2]) == 2

@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--divide", action="store_true",
                     help="N>1: ONE alignment divided over the ranks (frontier hand-off, reveal_amd/shard.py; strong scaling) "
                          "instead of one alignment per rank")
+    ap.add_argument("--jobs", type=int, default=1,
+                    help="independent alignments per rank, run concurrently (one index handle, HIP stream and host thread each): "
+                         "config 5's 20 independent 5-genome jobs on 8 GPUs (reveal/align.py:45-53); the default 1 is the metric's config")
     ap.add_argument("--cpu-L", type=int, default=0, help="genome length for the CPU sample (default: same as --L, capped at 5 Mbp)")
     args = ap.parse_args()
 
@@ -91,9 +94,13 @@ def main():
     _lib.set_device(local_rank)
 
     divide = args.divide and world > 1
+    jobs = max(1, args.jobs) if not divide else 1
     seqs = synth.genomes(args.L, args.genomes, seed=42 + (0 if divide else 1000 * rank))
     bases = sum(len(s) for s in seqs)
     idx = build_index(seqs, args.sa64)
+    # further jobs of this rank: their own inputs (other seeds), handles and streams
+    extra = [build_index(synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank + 17 * j), args.sa64) for j in range(1, jobs)]
+    bases *= jobs
 
     def barrier():
         torch.cuda.synchronize()
@@ -105,6 +112,22 @@ def main():
         if divide:      # rank 0 constructs and runs the top levels, every rank finishes a share of the frontier
             from reveal_amd import shard
             return shard.align_sharded(idx, args.minl, args.minn)
+        if extra:      # (ctypes releases the GIL inside the library calls: the jobs' level loops overlap on the GPU)
+            import threading
+            res = [None] * (1 + len(extra))
+
+            def run(k, ix):
+                ix.construct()
+                res[k] = ix.align_builtin(args.minl, args.minn)
+            th = [threading.Thread(target=run, args=(k + 1, ix)) for k, ix in enumerate(extra)]
+            for t in th:
+                t.start()
+            run(0, idx)
+            for t in th:
+                t.join()
+            if any(r is None for r in res):
+                raise RuntimeError("a concurrent job failed")
+            return res[0]
         idx.construct()
         return idx.align_builtin(args.minl, args.minn)
 
@@ -113,7 +136,8 @@ def main():
     # inside the timed region only the roofline-judged kernel is timed (two HIP events per launch on the library's stream);
     # the per-class breakdown comes from two extra, untimed steps with every class timed
     kname = "scan_multi" if args.genomes > 2 else "scan_pair"
-    idx.prof(enable=True, reset=True, only=None if args.prof_all else (kname,))
+    for ix in [idx] + extra:
+        ix.prof(enable=True, reset=True, only=None if args.prof_all else (kname,))
     barrier()
     t0 = time.perf_counter()
     last = None
@@ -122,6 +146,9 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     prof = idx.prof(enable=False)
+    for ix in extra:      # the judged kernel over all jobs (launches that overlap other jobs' kernels share the GPU with them)
+        p2 = ix.prof(enable=False)
+        prof = {k: tuple(a + b for a, b in zip(prof[k], p2[k])) for k in prof}
     breakdown = None
     if rank == 0 and not divide:
         idx.prof(enable=True, reset=True)
@@ -171,8 +198,10 @@ def main():
             "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42+1000*rank), rem -m %d -n %d, "
                                    "construct + full recursion, bench picker" % (args.genomes, args.L / 1e6, args.minl, args.minn),
                        "bases_per_gpu": bases, "index": "64-bit" if args.sa64 else "32-bit",
+                       "jobs_per_gpu": jobs,
                        "sharding": ("one alignment divided over %d ranks (frontier hand-off), shares %s" % (world, last.get("shares"))) if divide
-                                   else "one alignment per rank, no exchange"},
+                                   else ("one alignment per rank, no exchange" if jobs == 1 else
+                                         "%d independent alignments per rank, concurrently (a handle, stream and host thread each), no exchange" % jobs)},
             "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("multi" if args.genomes > 2 else "pair"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,

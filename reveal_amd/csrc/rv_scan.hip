@@ -142,22 +142,21 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         tileovf[wtile] = base;
     }
     base = (u32)__shfl((int)base, 0, 64);
-    if (mine) {
-        u32 q = inc - mine;                      // index inside the tile
-#pragma unroll
-        for (int k = 0; k < PAIR_ITEMS; k++) {
-            if (hit & (1u << k)) {
-                const sa_t s1 = SA[i0 + k], s0 = SA[i0 + k - 1];      // (a survivor is never the first rank of the arrays: its LCP is 0)
-                RvPairRec r;
-                r.a = s1 < s0 ? s1 : s0;
-                r.b = s1 < s0 ? s0 : s1;
-                r.l = (u32)lc[k];
-                r.rank = (u32)(i0 + k);
-                if (q < RV_PAIR_SLOTS) slots[(size_t)wtile * RV_PAIR_SLOTS + q] = r;
-                else { const u32 o = base + (q - RV_PAIR_SLOTS); if (o < ovf_cap) ovf[o] = r; }
-                q++;
-            }
-        }
+    // one trip per survivor of the lane (usually one), not one per rank: walking all PAIR_ITEMS bits cost every wave with a
+    // survivor anywhere some forty instructions, a third of the kernel's VALU work (SQ_INSTS_VALU: 28 per rank)
+    u32 hh = hit, q = inc - mine;                // q: index inside the tile
+    while (hh) {
+        const int k = __builtin_ctz(hh);
+        hh &= hh - 1;
+        const sa_t s1 = SA[i0 + k], s0 = SA[i0 + k - 1];      // (a survivor is never the first rank of the arrays: its LCP is 0)
+        RvPairRec r;
+        r.a = s1 < s0 ? s1 : s0;
+        r.b = s1 < s0 ? s0 : s1;
+        r.l = (u32)LCP[i0 + k];                  // (from cache; indexing the register copy by k would send it to scratch)
+        r.rank = (u32)(i0 + k);
+        if (q < RV_PAIR_SLOTS) slots[(size_t)wtile * RV_PAIR_SLOTS + q] = r;
+        else { const u32 o = base + (q - RV_PAIR_SLOTS); if (o < ovf_cap) ovf[o] = r; }
+        q++;
     }
 }
 

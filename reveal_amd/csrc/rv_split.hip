@@ -409,24 +409,24 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
 // and leave the same way: a thread reading its own eight consecutive words straight from global memory made
 // every load instruction touch 32 cache lines on the one CU this runs on (37 us for 4900 tiles).
 constexpr int CARRY_PER = 8;
-template <int NT>
-__device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int64_t t_hi, u32 *s_runc, MinSt *s_runm, u32 (*s_c)[3], MinSt (*s_m)[3],
+template <int NT, int NC>
+__device__ inline void carry_scan_range(const RvSplitArgs &a, int c0, int64_t t_lo, int64_t t_hi, u32 *s_runc, MinSt *s_runm, u32 (*s_c)[3], MinSt (*s_m)[3],
                                         u32 *s_x, u32 *s_y) {      // s_x, s_y: NT*CARRY_PER words each
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int PASS = NT * CARRY_PER;
     for (int64_t base = t_lo; base < t_hi; base += PASS) {
         const int64_t t0 = base + (int64_t)threadIdx.x * CARRY_PER;
-        u32 ix[3]; MinSt im[3];
-        u32 vc[3][CARRY_PER]; MinSt vm[3][CARRY_PER];
+        u32 ix[NC]; MinSt im[NC];
+        u32 vc[NC][CARRY_PER]; MinSt vm[NC][CARRY_PER];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
+        for (int c = 0; c < NC; c++) {
             // stage class c: x = count | has << 31 (a tile holds 2048 ranks), y = min value
             __syncthreads();
             for (int k = threadIdx.x; k < PASS; k += NT) {
                 const int64_t t = base + k;
                 const bool in = t < t_hi;
-                s_x[k] = in ? (a.tile_cnt[(size_t)c * a.ntiles + t] | (a.tile_has[(size_t)c * a.ntiles + t] << 31)) : 0u;
-                s_y[k] = in ? a.tile_post[(size_t)c * a.ntiles + t] : INF;
+                s_x[k] = in ? (a.tile_cnt[(size_t)(c0 + c) * a.ntiles + t] | (a.tile_has[(size_t)(c0 + c) * a.ntiles + t] << 31)) : 0u;
+                s_y[k] = in ? a.tile_post[(size_t)(c0 + c) * a.ntiles + t] : INF;
             }
             __syncthreads();
             ix[c] = 0; im[c].has = 0; im[c].val = INF;
@@ -440,7 +440,7 @@ __device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int6
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) {
+            for (int c = 0; c < NC; c++) {
                 const u32 tc = __shfl_up(ix[c], dd, 64);
                 MinSt tm; tm.has = __shfl_up(im[c].has, dd, 64); tm.val = __shfl_up(im[c].val, dd, 64);
                 if (lane >= dd) { ix[c] += tc; im[c] = ms_combine(tm, im[c]); }
@@ -448,12 +448,12 @@ __device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int6
         }
         if (lane == 63) {
 #pragma unroll
-            for (int c = 0; c < 3; c++) { s_c[w][c] = ix[c]; s_m[w][c] = im[c]; }
+            for (int c = 0; c < NC; c++) { s_c[w][c] = ix[c]; s_m[w][c] = im[c]; }
         }
         __syncthreads();
-        u32 totc[3]; MinSt totm[3];
+        u32 totc[NC]; MinSt totm[NC];
 #pragma unroll
-        for (int c = 0; c < 3; c++) {
+        for (int c = 0; c < NC; c++) {
             u32 bc = s_runc[c]; MinSt bm = s_runm[c];
             totc[c] = s_runc[c]; totm[c] = s_runm[c];
             for (int k = 0; k < NT / 64; k++) {
@@ -473,16 +473,21 @@ __device__ inline void carry_scan_range(const RvSplitArgs &a, int64_t t_lo, int6
             __syncthreads();
             for (int k = threadIdx.x; k < PASS; k += NT) {
                 const int64_t t = base + k;
-                if (t < t_hi) { a.tile_G[(size_t)c * a.ntiles + t] = s_x[k]; a.tile_carry[(size_t)c * a.ntiles + t] = s_y[k]; }
+                if (t < t_hi) { a.tile_G[(size_t)(c0 + c) * a.ntiles + t] = s_x[k]; a.tile_carry[(size_t)(c0 + c) * a.ntiles + t] = s_y[k]; }
             }
         }
         (void)t0;
         __syncthreads();
-        if (threadIdx.x < 3) { s_runc[threadIdx.x] = totc[threadIdx.x]; s_runm[threadIdx.x] = totm[threadIdx.x]; }
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int c = 0; c < NC; c++) { s_runc[c] = totc[c]; s_runm[c] = totm[c]; }
+        }
         __syncthreads();
     }
 }
 
+// one workgroup per class: the three scans are independent, and one workgroup doing all of them was bound by instruction
+// issue on its one CU (~4600 VALU instructions per wave, four waves per SIMD: 23 us for 4900 tiles)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a) {
     __shared__ u32   s_c[NT / 64][3];
@@ -490,17 +495,16 @@ __global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a) {
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
     __shared__ u32   s_x[NT * CARRY_PER], s_y[NT * CARRY_PER];
+    const int c0 = blockIdx.x;
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = 0u; s_runm[threadIdx.x].has = 0; s_runm[threadIdx.x].val = INF; }
     __syncthreads();
-    carry_scan_range<NT>(a, 0, a.ntiles, s_runc, s_runm, s_c, s_m, s_x, s_y);
-    if (threadIdx.x < 3) {
-        a.total[threadIdx.x] = s_runc[threadIdx.x];
-        if (s_runc[threadIdx.x] != a.expect_total[threadIdx.x]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
+    carry_scan_range<NT, 1>(a, c0, 0, a.ntiles, s_runc, s_runm, s_c, s_m, s_x, s_y);
+    if (threadIdx.x == 0) {
+        a.total[c0] = s_runc[0];
+        if (s_runc[0] != a.expect_total[c0]) atomicOr(a.err, 1u);     // the intervals do not cover what they claim
     }
 }
 
-// Large levels: the tiles are cut into chunks of CH tiles; every chunk is first reduced to one (count, min-state)
-// triple, one block scans the triples, then every chunk is scanned again with its carry-in.
 constexpr int CARRY_CH = 8192;      // default chunk; RV_CARRY_CH overrides it (tests force the chunked path on small inputs)
 __global__ __launch_bounds__(TB) void k_carry_reduce(RvSplitArgs a, int ch, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
     __shared__ u32   s_c[TB / 64][3];
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, int ch, con
     const int64_t t_lo = (int64_t)blockIdx.x * ch, t_hi = t_lo + ch < a.ntiles ? t_lo + ch : a.ntiles;
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = ch_cnt[(size_t)blockIdx.x * 3 + threadIdx.x]; s_runm[threadIdx.x] = ch_ms[(size_t)blockIdx.x * 3 + threadIdx.x]; }
     __syncthreads();
-    carry_scan_range<1024>(a, t_lo, t_hi, s_runc, s_runm, s_c, s_m, s_x, s_y);
+    carry_scan_range<1024, 3>(a, 0, t_lo, t_hi, s_runc, s_runm, s_c, s_m, s_x, s_y);
 }
 
 __global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend,
@@ -1268,8 +1272,8 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     RV_LAUNCH_CHECK();
     const int ch = getenv("RV_CARRY_CH") ? std::max(1, atoi(getenv("RV_CARRY_CH"))) : CARRY_CH;
     if (a.ntiles <= 4 * (int64_t)ch) {
-        if (a.ntiles <= 256 * CARRY_PER) hipLaunchKernelGGL(k_tile_carry<256>, dim3(1), dim3(256), 0, ws.stream, a);
-        else hipLaunchKernelGGL(k_tile_carry<1024>, dim3(1), dim3(1024), 0, ws.stream, a);
+        if (a.ntiles <= 256 * CARRY_PER) hipLaunchKernelGGL(k_tile_carry<256>, dim3(3), dim3(256), 0, ws.stream, a);
+        else hipLaunchKernelGGL(k_tile_carry<1024>, dim3(3), dim3(1024), 0, ws.stream, a);
         RV_LAUNCH_CHECK();
     } else {
         const int nch = (int)ceil_div(a.ntiles, ch);

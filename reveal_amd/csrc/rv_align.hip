@@ -198,8 +198,9 @@ void rv_align_free(rv_index *h) {
 }
 
 // leading children above this many ranks take the data-parallel bubble rounds.  Measured crossovers: two samples (one cut per
-// sample, C2) 512 K; more samples (a cut per sample and child, C3: 184 ms per step against 195) 256 K
-static int64_t bubble_par_default(bool multi) { return multi ? (int64_t)RV_BUBBLE_PAR_N / 2 : (int64_t)RV_BUBBLE_PAR_N; }
+// sample; C2: 256 K 758, 384 K - 512 K 777, 768 K - 1 M 789, 1.5 M 724 Mbp/s; no difference at 2 x 50 Mbp) 768 K; more samples
+// (a cut per sample and child; C3: 184 ms per step against 195 at 512 K) 256 K
+static int64_t bubble_par_default(bool multi) { return multi ? (int64_t)262144 : (int64_t)RV_BUBBLE_PAR_N; }
 
 static const sa_t *cur_sa(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dSA.as<sa_t>() : a->lvSA[a->cur].as<sa_t>(); }
 static const lcp_t *cur_lcp(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dLCP.as<lcp_t>() : a->lvLCP[a->cur].as<lcp_t>(); }

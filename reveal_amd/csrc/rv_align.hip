@@ -130,7 +130,7 @@ struct Align {
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     std::vector<int64_t> mum_first, nmums;       // per sub
     // device scratch
-    DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg;
+    DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
@@ -184,6 +184,7 @@ struct Align {
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     void release() {
         for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
+        scrSA.release(); scrLCP.release(); scrBWT.release();
         dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
@@ -906,10 +907,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_TRY(a->lvBWT[nxt].reserve((size_t)m_next + 64));
 
     // A leaf launch of an earlier level may still be reading the buffer this commit writes (ping-pong), and the long-move
-    // path of this commit scribbles over the current (parent) buffer: order after them.
+    // path of this commit scribbled over the current (parent) buffer when that was its scratch: order after them.
     {
         const int cur_id = (a->level == 0) ? 2 : a->cur;            // 2 = the main arrays
-        const int wait_ids[2] = {nxt, !a->descs.empty() ? cur_id : -1};
+        (void)cur_id;
+        const int wait_ids[2] = {nxt, getenv("RV_BUBBLE_PARENT_SCRATCH") && !a->descs.empty() ? cur_id : -1};
         for (int k = 0; k < 2; k++) {
             const int id = wait_ids[k];
             if (id < 0) continue;
@@ -961,6 +963,15 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         // the parent level is dead once split has run (at level 0 these are the main SA/LCP/BWT, which the
         // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
+        if (!a->descs.empty() && !getenv("RV_BUBBLE_PARENT_SCRATCH")) {
+            // ... but this level's leaf launch (second stream, ~180 us) still reads them, and waiting for it left the main
+            // stream idle for ~40 us at every level that has both leaf sub-indices and data-parallel rounds: own scratch
+            // (9 B per rank of the next level; RV_BUBBLE_PARENT_SCRATCH=1 = the parent arrays and the wait, as before)
+            RV_TRY(a->scrSA.reserve((size_t)(m_next + 64) * sizeof(sa_t)));
+            RV_TRY(a->scrLCP.reserve((size_t)(m_next + 64) * sizeof(lcp_t)));
+            RV_TRY(a->scrBWT.reserve((size_t)m_next + 64));
+            ba.scrSA = a->scrSA.as<sa_t>(); ba.scrLCP = a->scrLCP.as<lcp_t>(); ba.scrBWT = a->scrBWT.as<uint8_t>();
+        }
         if (!a->descs.empty()) {
             const size_t W = (size_t)a->woff.back() + 16, TT = (size_t)a->toff.back() + 16;
             RV_TRY(a->dPar.reserve(TT * 4 + W * (8 + 7 * 4 + sizeof(sa_t) + 2) + 256));

@@ -118,7 +118,9 @@ struct Align {
     int minl = 0, minn = 0;
     bool multi = false;
     int level = 0;
-    DBuf lvSA[2], lvLCP[2], lvBWT[2];
+    // three level buffers in rotation: the split of level k writes (k+1) % 3 while the leaf launch of level k-1 (second stream,
+    // ~200 us) may still be reading (k-1) % 3 -- with two buffers the deep levels, shorter than a leaf launch, each waited for it
+    DBuf lvSA[RV_LEVEL_BUFS], lvLCP[RV_LEVEL_BUFS], lvBWT[RV_LEVEL_BUFS];
     int cur = 0;                 // which level buffer holds the frontier (level > 0)
     Level lv, nx;                // current frontier / the one being built
     Decisions dec;
@@ -133,10 +135,11 @@ struct Align {
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
-    hipStream_t leaf_stream = nullptr;   // leaf launches overlap the level pipeline
+    hipStream_t leaf_stream = nullptr, leaf_stream2 = nullptr;   // leaf launches overlap the level pipeline -- and, on alternating streams, each other:
+                                                                 // at the deep levels a launch (~180 us) takes as long as a level, and one stream in order made them the critical path
     hipStream_t bub_stream = nullptr, bub_stream2 = nullptr;      // LDS-resident / one-workgroup bubble kernels run here, beside the main stream's rounds
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_leaf[2] = {nullptr, nullptr}, ev_roots[2] = {nullptr, nullptr};
+    hipEvent_t ev_ready = nullptr, ev_leaf[RV_LEVEL_BUFS + 1] = {}, ev_roots[2] = {nullptr, nullptr};      // ev_leaf[RV_LEVEL_BUFS]: the leaf launch of level 0 (reads the main arrays)
     bool roots_inflight[2] = {false, false};
     bool flag_clean = false;     // dFlag is all zero
     // device-side decisions (rv_decide.hip): tables of the NEXT level shipped with a commit, state of the early split
@@ -146,7 +149,7 @@ struct Align {
     const sa_t *d_next_nodes = nullptr; const uint8_t *d_next_flags = nullptr; const int *d_next_tsub2 = nullptr;
     std::vector<sa_t> next_nodes; std::vector<uint8_t> next_flags;
     RvLabelTabs e_lt; RvSplitArgs e_sa;
-    bool leaf_pending[2] = {false, false};   // a leaf launch may still be reading level buffer k
+    bool leaf_pending[RV_LEVEL_BUFS + 1] = {};   // a leaf launch may still be reading level buffer k
     size_t leaf_anchor_cap = 0, leaf_trace_cap = 0;
     std::vector<uint8_t> leaf_done;   // per sub of the current level: handed to the leaf kernel
     std::vector<RvLeafRoot> leaf_roots[2];
@@ -183,13 +186,14 @@ struct Align {
     bool running = false;        // a built-in run is between its set-up and its collection
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
     void release() {
-        for (int k = 0; k < 2; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
+        for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release();
         dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
+        if (leaf_stream2) { (void)hipStreamSynchronize(leaf_stream2); (void)hipStreamDestroy(leaf_stream2); leaf_stream2 = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
-        for (int k = 0; k < 2; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
+        for (int k = 0; k <= RV_LEVEL_BUFS; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_roots[k]) { (void)hipEventDestroy(ev_roots[k]); ev_roots[k] = nullptr; }
     }
 };
@@ -352,8 +356,8 @@ static int leaf_launch(rv_index *h) {
     const int leaf_flip = a->leaf_flip;
     std::vector<RvLeafRoot> &roots = a->leaf_roots[leaf_flip];
     DBuf &droots = a->dLeafRoots[leaf_flip];
-    hipStream_t ls = a->leaf_stream;
-    const int slot = (a->level == 0) ? 1 : a->cur;
+    hipStream_t ls = leaf_flip ? a->leaf_stream2 : a->leaf_stream;
+    const int slot = (a->level == 0) ? RV_LEVEL_BUFS : a->cur;
     if (a->leaf_pending[slot]) RV_HIP(hipEventSynchronize(a->ev_leaf[slot]));     // (cannot happen: commit waits first)
     RV_TRY(droots.reserve(roots.size() * sizeof(RvLeafRoot)));
     // pinned staging (one per ping-pong slot): a pageable copy would make the host wait for the leaf stream to drain
@@ -399,7 +403,7 @@ static int early_split(rv_index *h) {
     const Level &lv = a->lv;
     const int ns = lv.size();
     const int64_t m = lv.m, ntiles = ceil_div(m, RV_SPLIT_TILE);
-    const int nxt = (a->level == 0) ? 0 : (a->cur ^ 1);
+    const int nxt = (a->level == 0) ? 0 : (a->cur + 1) % RV_LEVEL_BUFS;
     RV_TRY(a->dD.reserve((size_t)m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->lvSA[nxt].reserve((size_t)(m + 64) * sizeof(sa_t)));
@@ -901,7 +905,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));
-    const int nxt = (a->level == 0) ? 0 : (a->cur ^ 1);
+    const int nxt = (a->level == 0) ? 0 : (a->cur + 1) % RV_LEVEL_BUFS;
     RV_TRY(a->lvSA[nxt].reserve((size_t)(m_next + 64) * sizeof(sa_t)));
     RV_TRY(a->lvLCP[nxt].reserve((size_t)(m_next + 64) * sizeof(lcp_t)));
     RV_TRY(a->lvBWT[nxt].reserve((size_t)m_next + 64));
@@ -909,13 +913,13 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // A leaf launch of an earlier level may still be reading the buffer this commit writes (ping-pong), and the long-move
     // path of this commit scribbled over the current (parent) buffer when that was its scratch: order after them.
     {
-        const int cur_id = (a->level == 0) ? 2 : a->cur;            // 2 = the main arrays
+        const int cur_id = (a->level == 0) ? RV_LEVEL_BUFS : a->cur;            // RV_LEVEL_BUFS = the main arrays
         (void)cur_id;
         const int wait_ids[2] = {nxt, getenv("RV_BUBBLE_PARENT_SCRATCH") && !a->descs.empty() ? cur_id : -1};
         for (int k = 0; k < 2; k++) {
             const int id = wait_ids[k];
             if (id < 0) continue;
-            const int slot = id == 2 ? 1 : id;                       // the main arrays share slot 1 (level 0 writes buffer 0)
+            const int slot = id;
             if (a->leaf_pending[slot]) { RV_HIP(hipStreamWaitEvent(q, a->ev_leaf[slot], 0)); a->leaf_pending[slot] = false; }
         }
     }
@@ -1072,10 +1076,12 @@ static int builtin_leaf_setup(rv_index *h) {
     RV_HIP(hipMemsetAsync(base, 0, 256, q));
     if (!a->leaf_stream) {
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
+        RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream2, hipStreamNonBlocking));
         RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
-        for (int k = 0; k < 2; k++) { RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming)); RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming)); }
+        for (int k = 0; k <= RV_LEVEL_BUFS; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming));
+        for (int k = 0; k < 2; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming));
     }
-    a->leaf_pending[0] = a->leaf_pending[1] = false;
+    for (int k = 0; k <= RV_LEVEL_BUFS; k++) a->leaf_pending[k] = false;
     a->roots_inflight[0] = a->roots_inflight[1] = false;
     return 0;
 }
@@ -1162,7 +1168,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                 // kernel, events: ~15 us of host time) is issued after the level's own kernels are queued, while the host would
                 // otherwise only wait for the picks -- issued first, it left the main stream idle that long at every level.
                 RV_HIP(hipEventRecord(a->ev_ready, q));
-                RV_HIP(hipStreamWaitEvent(a->leaf_stream, a->ev_ready, 0));
+                RV_HIP(hipStreamWaitEvent(leaf_flip ? a->leaf_stream2 : a->leaf_stream, a->ev_ready, 0));
                 a->leaf_launch_due = true;
                 log_leaf = roots.size();
                 if ((size_t)lv0.size() == roots.size()) {       // nothing left for the level path
@@ -1293,7 +1299,8 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
         u32 *lf_counters = a->lf_counters; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
         // everything through pinned staging (pageable destinations are staged by the runtime, copy by copy: ~0.25 ms per run)
         RV_HIP(hipStreamSynchronize(a->leaf_stream));
-        a->leaf_pending[0] = a->leaf_pending[1] = false;
+        RV_HIP(hipStreamSynchronize(a->leaf_stream2));
+        for (int k = 0; k <= RV_LEVEL_BUFS; k++) a->leaf_pending[k] = false;
         RV_TRY(a->hLeafOut.reserve(256));
         RV_HIP(hipMemcpyAsync(a->hLeafOut.p, lf_counters, 128, hipMemcpyDeviceToHost, q));      // counters at +0, statistics at +64
         RV_HIP(hipStreamSynchronize(q));
@@ -1410,8 +1417,8 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
     hipStream_t q = h->ws.stream;
     Align *a = h->al;
     RV_HIP(hipStreamSynchronize(q));
-    if (a->leaf_stream) RV_HIP(hipStreamSynchronize(a->leaf_stream));      // (a leaf launch may read the level buffers replaced below)
-    a->leaf_pending[0] = a->leaf_pending[1] = false;
+    if (a->leaf_stream) { RV_HIP(hipStreamSynchronize(a->leaf_stream)); RV_HIP(hipStreamSynchronize(a->leaf_stream2)); }      // (a leaf launch may read the level buffers replaced below)
+    for (int k = 0; k <= RV_LEVEL_BUFS; k++) a->leaf_pending[k] = false;
     RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, q));
     Level &lv = a->lv;
     lv.clear();

@@ -108,6 +108,7 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
 #define RV_BUBBLE_LDS_N RV_BUBBLE_LDS_N2
 // leading children above this many ranks take the data-parallel rounds (rv_bubble.hip); measured on C2: 16 K -> 485 Mbp/s,
 // 256 K -> 541, 512 K -> 555, 1 M -> 550, 2 M -> 511 (below it one workgroup replays the cuts of a child faster than ~18 launches)
+#define RV_LEVEL_BUFS 3            // level arrays of the recursion, in rotation (rv_align.hip)
 #define RV_BUBBLE_PAR_N 786432
 // all cuts of each (non-huge) leading child in one workgroup; descriptors use off, n, cut0, cut1 (cut windows in order)
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);

@@ -193,6 +193,13 @@ typedef struct {
     uint64_t h_sa, h_lcp, h_mums;
 } rv_trace;
 int rv_set_trace(rv_index *h, int on);
+/* Anchor pre-selection for the callback protocol (not in the reference's C, it restates what its Python picker
+ * does first with every list: schemes.py:227 keep the matches with n == idx.nsamples, schemes.py:240 + 245-247 + 287-289 of
+ * those the `maxmums` longest, of equal lengths the later emitted).  With maxmums > 0, rv_sub_info / rv_sub_mums between
+ * rv_align_begin and rv_align_end report only those, in emission order; a sub-index without a match in every sample keeps
+ * its whole list (schemes.py:229-232 segments over all of them).  0 = off.  A picker that starts with the same filter and
+ * cap (graphmumpicker with --maxmums, no --trim) returns what it returns on the full list. */
+int rv_set_preselect(rv_index *h, int64_t maxmums);
 int64_t rv_trace_count(rv_index *h);
 int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);
 

@@ -446,6 +446,20 @@ def make_index_type(sa64, error):
                     self._fail()
             return c
 
+        def preselect(self, maxmums):
+            """Not in the reference: from the next align() on, mumpicker
+            receives of every scan only what schemes.graphmumpicker keeps of it before
+            chaining -- the matches present in every sample of the sub-index
+            (schemes.py:227), of those the `maxmums` longest (schemes.py:240, 287-289; of
+            equal lengths the later emitted) -- still in emission order; a sub-index
+            without such a match gets its whole list (schemes.py:229-232).  The selection
+            happens inside the library, so the tuples of the others are never built.
+            0 / None switches it off."""
+            if self._depth != 0:
+                raise error("preselect() is set on the main index")
+            if self._dll.rv_set_preselect(self._h, int(maxmums or 0)) != 0:
+                self._fail()
+
         def align_builtin(self, minl=20, minn=2, trace=False):
             """Not in the reference: the whole recursion with the library's
             built-in deterministic callbacks (longest full match, linear interval

@@ -80,6 +80,7 @@ SYMBOLS = {
     "rv_anchor_count": (_L, [V, c_i64p]),
     "rv_fetch_anchors": (_I, [V, V, V, V]),
     "rv_set_trace": (_I, [V, _I]),
+    "rv_set_preselect": (_I, [V, _L]),
     "rv_trace_count": (_L, [V]),
     "rv_fetch_trace": (_I, [V, V, _L]),
     "rv_clone": (V, [V]),

@@ -131,6 +131,9 @@ struct Align {
     std::vector<RvPairRec> recs;
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     std::vector<int64_t> mum_first, nmums;       // per sub
+    // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
+    int64_t presel = 0; bool presel_on = false;
+    std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
@@ -310,6 +313,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     a->multi = h->nsamples > 2;
     a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false; a->use_leaf = false;
+    a->presel_on = a->presel > 0;
     a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
     RV_TRY(a->dErr.reserve(64));
     RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, h->ws.stream));
@@ -335,6 +339,16 @@ int rv_align_end(rv_index *h) {
 int rv_set_trace(rv_index *h, int on) {
     if (!h->al) h->al = new Align();
     h->al->trace_on = on != 0;
+    return 0;
+}
+
+/* What schemes.graphmumpicker keeps of a scan before it chains (schemes.py:227 the matches present in every sample of the
+ * sub-index; :240, :245-247, :287-289 of those the `maxmums` longest -- two stable sorts, so of equal lengths the later
+ * emitted ones stay), applied inside the library so that only those cross into Python.  0 = off (the reference's lists). */
+int rv_set_preselect(rv_index *h, int64_t maxmums) {
+    if (maxmums < 0) { rv_set_error("rv_set_preselect: maxmums must not be negative"); return -1; }
+    if (!h->al) h->al = new Align();
+    h->al->presel = maxmums;
     return 0;
 }
 
@@ -478,6 +492,36 @@ static int early_split(rv_index *h) {
     return 0;
 }
 
+/* rv_set_preselect: per sub-index the record numbers that go to mumpicker.  No match in every sample (schemes.py:229-232
+ * goes on with segment() over all of them): the whole list, uncapped. */
+static void build_preselection(Align *a) {
+    const int ns = a->lv.size();
+    a->sel.clear(); a->sel_first.assign((size_t)ns + 1, 0);
+    std::vector<int64_t> &tmp = a->sel_tmp;
+    for (int s = 0; s < ns; s++) {
+        const int64_t first = a->mum_first[(size_t)s], cnt = a->nmums[(size_t)s];
+        tmp.clear();
+        if (a->multi) {
+            const int32_t want = a->lv.nsamples[(size_t)s];
+            for (int64_t k = first; k < first + cnt; k++) if (a->mn[(size_t)k] == want) tmp.push_back(k);
+        } else
+            for (int64_t k = first; k < first + cnt; k++) tmp.push_back(k);
+        if (tmp.empty()) for (int64_t k = first; k < first + cnt; k++) tmp.push_back(k);
+        else if ((int64_t)tmp.size() > a->presel) {
+            const size_t drop = tmp.size() - (size_t)a->presel;
+            auto below = [a](int64_t x, int64_t y) {
+                const u32 lx = a->multi ? a->ml[(size_t)x] : a->recs[(size_t)x].l, ly = a->multi ? a->ml[(size_t)y] : a->recs[(size_t)y].l;
+                return lx < ly || (lx == ly && x < y);
+            };
+            std::nth_element(tmp.begin(), tmp.begin() + (ptrdiff_t)drop, tmp.end(), below);
+            tmp.erase(tmp.begin(), tmp.begin() + (ptrdiff_t)drop);
+            std::sort(tmp.begin(), tmp.end());
+        }
+        a->sel.insert(a->sel.end(), tmp.begin(), tmp.end());
+        a->sel_first[(size_t)s + 1] = (int64_t)a->sel.size();
+    }
+}
+
 /* reveal.c:802-822 for every sub-index of the frontier */
 int rv_frontier_scan(rv_index *h) {
     RV_TRY(need_align(h));
@@ -551,6 +595,7 @@ int rv_frontier_scan(rv_index *h) {
         }
     }
     a->scanned = true;
+    if (a->presel_on && !a->full_only) build_preselection(a);
     a->st.scanned_ranks += a->lv.m;
     a->st.t_scan += now_s() - t0;
     return 0;
@@ -563,7 +608,11 @@ int rv_sub_info(rv_index *h, int s, rv_sub *out) {
     out->n = a->lv.n[(size_t)s]; out->depth = a->lv.depth[(size_t)s]; out->nsamples = a->lv.nsamples[(size_t)s];
     out->nnodes = (int32_t)(a->lv.node_first[(size_t)s + 1] - a->lv.node_first[(size_t)s]);
     out->parent = a->lv.parent[(size_t)s]; out->kind = a->lv.kind[(size_t)s];
-    if (a->scanned) {
+    if (a->scanned && a->presel_on && !a->full_only) {
+        out->nmums = a->sel_first[(size_t)s + 1] - a->sel_first[(size_t)s];
+        if (!a->multi) out->nmembers = 2 * out->nmums;
+        else for (int64_t q = a->sel_first[(size_t)s]; q < a->sel_first[(size_t)s + 1]; q++) { const size_t g = (size_t)a->sel[(size_t)q]; out->nmembers += a->moff[g + 1] - a->moff[g]; }
+    } else if (a->scanned) {
         out->nmums = a->nmums[(size_t)s];
         if (!a->multi) out->nmembers = 2 * out->nmums;
         else out->nmembers = out->nmums ? a->moff[(size_t)(a->mum_first[(size_t)s] + out->nmums)] - a->moff[(size_t)a->mum_first[(size_t)s]] : 0;
@@ -583,6 +632,23 @@ int rv_sub_mums(rv_index *h, int s, uint32_t *l, int32_t *n, int64_t *off, uint1
     RV_TRY(need_sub(h, s));
     Align *a = h->al;
     if (!a->scanned) { rv_set_error("rv_sub_mums before rv_frontier_scan"); return -1; }
+    if (a->presel_on && !a->full_only) {                      /* the pre-selected records only (rv_set_preselect) */
+        int64_t k = 0, w = 0;
+        for (int64_t q = a->sel_first[(size_t)s]; q < a->sel_first[(size_t)s + 1]; q++, k++) {
+            const size_t g = (size_t)a->sel[(size_t)q];
+            off[k] = w;
+            if (!a->multi) {
+                const RvPairRec &r = a->recs[g];
+                l[k] = r.l; n[k] = 2;
+                so[w] = 0; pos[w++] = r.a; so[w] = 1; pos[w++] = r.b;
+            } else {
+                l[k] = a->ml[g]; n[k] = a->mn[g];
+                for (int64_t m = a->moff[g]; m < a->moff[g + 1]; m++) { so[w] = a->mso[(size_t)m]; pos[w++] = a->mpos[(size_t)m]; }
+            }
+        }
+        off[k] = w;
+        return 0;
+    }
     const int64_t first = a->mum_first[(size_t)s], cnt = a->nmums[(size_t)s];
     if (!a->multi) {                                          /* (l, 2, ((0,a),(1,b)))  reveal.c:166-170 */
         for (int64_t k = 0; k < cnt; k++) {
@@ -1543,6 +1609,7 @@ static int sx_load(rv_subindex *x, int minl, int minn) {
     a->multi = h->nsamples > 2;
     a->scanned = false; a->d_err = nullptr; a->flag_clean = false; a->full_only = false; a->use_leaf = false; a->leaf_launch_due = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
+    a->presel_on = false;        // getmums / getmultimums of a detached index hand out every match
     a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
     RV_TRY(a->dErr.reserve(64));
     memset(&a->st, 0, sizeof a->st);

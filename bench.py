@@ -3,20 +3,30 @@
 
 One step = construct() (suffix array, inverse, LCP) + the full recursive
 anchoring (scan -> pick -> label/split/bubble per level) of one batch of
-synthetic genomes whose text is already resident in HBM, with the deterministic
-benchmark callbacks of SURVEY.md 8(d).  Default workload = BASELINE.json
-configs[1]: 2 x 5 Mbp, 1 % SNP, -m 20.
+synthetic genomes whose text is ALREADY RESIDENT IN HBM when the timed region
+starts (the host->device copy of the text is outside it), with the deterministic
+benchmark callbacks of SURVEY.md 8(d).
+
+Default workload = BASELINE.json configs[3], the largest single-GPU
+configuration: 2 x 250 Mbp, 1 % SNP, -m 20 (n = 5*10^8, 32-bit index).
+`--L 5000000` gives configs[1] (2 x 5 Mbp), `--L 5000000 --genomes 10` configs[2].
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU, every rank anchors its own genome pair (different
-seed), no collective on the data path (the path shards by independent inputs);
-value = bases of all ranks / max-over-ranks time.  Rank 0 prints one JSON line.
+N > 1, one process per GPU, no collective on the data path either way:
+  * inputs of at least 100 Mbp (the default): ONE alignment divided over the
+    ranks -- rank 0 constructs and runs the top levels, every rank finishes a
+    share of the frontier's sub-indices (reveal_amd/shard.py; BASELINE config 4's
+    "interval-split scaling"; "scaling": "strong");
+  * smaller inputs: every rank anchors its own genome set ("weak").
+  --mode per-rank / --mode divide override the choice.
+value = bases of the whole job / max-over-ranks time.  Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -24,6 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+CPU_SAMPLE_L = 5_000_000   # the CPU legs and the parity leg run on a 2 x 5 Mbp sample of the same generator (BASELINE configs[1])
 
 
 def build_index(seqs, sa64=False):
@@ -55,25 +66,68 @@ def cpu_baseline(seqs, minl, minn):
     return dict(t_construct=t1 - t0, t_align=t2 - t1, result=r, ref_divsufsort=O.ref_divsufsort)
 
 
+def cpu_all_cores(L, genomes, minl, minn, max_workers=0):
+    """All host cores: P independent single-threaded alignments at once (the reference's only parallelism is independent
+    `reveal rem` jobs, reveal/align.py:45-53; its C path is single-threaded).  P = the cores this process may use, capped by
+    free memory (~0.7 GB per 2 x 5 Mbp job).  Workers are separate processes (oracle/cpu_worker.py) released at a common
+    start time; rate = all bases / (latest end - earliest start)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    P = cores
+    try:
+        import psutil
+        per_job = 0.07e9 * genomes * (L / 1e6) / 10.0 * 10 + 0.2e9      # ~0.7 GB for 2 x 5 Mbp + the interpreter
+        P = max(1, min(P, int(psutil.virtual_memory().available * 0.6 / per_job)))
+    except Exception:
+        pass
+    if max_workers:
+        P = min(P, max_workers)
+    start_at = time.time() + max(6.0, 0.06 * P)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), "--L", str(L), "--genomes", str(genomes),
+                               "--seed", str(5000 + 13 * k), "--minl", str(minl), "--minn", str(minn), "--start-at", repr(start_at)],
+                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=dict(os.environ, OMP_NUM_THREADS="1")) for k in range(P)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate()
+        if p.returncode == 0:
+            try:
+                res.append(json.loads(out.decode().strip().splitlines()[-1]))
+            except Exception:
+                pass
+    if not res:
+        return None
+    span = max(r["t_end"] for r in res) - min(r["t_begin"] for r in res)
+    return dict(workers=len(res), launched=P, cores=cores, bases=sum(r["bases"] for r in res), seconds=span,
+                late=max(r["late"] for r in res), value=sum(r["bases"] for r in res) / span / 1e6)
+
+
+def anchor_set(l, off, pos):
+    return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--L", type=int, default=5_000_000, help="genome length (bp)")
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--L", type=int, default=250_000_000, help="genome length (bp)")
     ap.add_argument("--genomes", type=int, default=2)
     ap.add_argument("--minl", type=int, default=20)
     ap.add_argument("--minn", type=int, default=2)
     ap.add_argument("--sa64", action="store_true")
-    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
+    ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
+    ap.add_argument("--no-check", action="store_true", help="skip the full-size property check of the last step's result")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class inside the timed region (adds events to every level)")
-    ap.add_argument("--divide", action="store_true",
-                    help="N>1: ONE alignment divided over the ranks (frontier hand-off, reveal_amd/shard.py; strong scaling) "
-                         "instead of one alignment per rank")
+    ap.add_argument("--mode", choices=("auto", "per-rank", "divide"), default="auto",
+                    help="N>1: 'divide' = ONE alignment divided over the ranks (frontier hand-off, reveal_amd/shard.py; strong scaling), "
+                         "'per-rank' = one alignment per rank (weak); auto = divide for inputs of >= 100 Mbp")
+    ap.add_argument("--divide", action="store_true", help="same as --mode divide")
     ap.add_argument("--jobs", type=int, default=1,
                     help="independent alignments per rank, run concurrently (one index handle, HIP stream and host thread each): "
                          "config 5's 20 independent 5-genome jobs on 8 GPUs (reveal/align.py:45-53); the default 1 is the metric's config")
-    ap.add_argument("--cpu-L", type=int, default=0, help="genome length for the CPU sample (default: same as --L, capped at 5 Mbp)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,10 +144,14 @@ def main():
         else:
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    from reveal_amd import _lib, synth
+    import numpy as np
+    from reveal_amd import _lib, synth, check
     _lib.set_device(local_rank)
 
-    divide = args.divide and world > 1
+    mode = "divide" if args.divide else args.mode
+    if mode == "auto":
+        mode = "divide" if args.L * args.genomes >= 100_000_000 else "per-rank"
+    divide = mode == "divide" and world > 1
     jobs = max(1, args.jobs) if not divide else 1
     seqs = synth.genomes(args.L, args.genomes, seed=42 + (0 if divide else 1000 * rank))
     bases = sum(len(s) for s in seqs)
@@ -149,6 +207,20 @@ def main():
     for ix in extra:      # the judged kernel over all jobs (launches that overlap other jobs' kernels share the GPU with them)
         p2 = ix.prof(enable=False)
         prof = {k: tuple(a + b for a, b in zip(prof[k], p2[k])) for k in prof}
+    # full-size properties of the last timed step's result (reveal_amd/check.py), before the breakdown steps run again
+    properties = None
+    if rank == 0 and not args.no_check:
+        T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
+        if divide:      # (a divided run lower-cases each share on its own rank: rebuild the text from the merged anchors)
+            from reveal_amd import shard
+            T1 = shard.lower_text(T0, last["anchors"])
+        else:
+            T1 = idx.array("T")
+        nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
+        properties = check.recursion_properties(T0, T1, last["anchors"], nsep, args.minl)
+        if divide:
+            properties["text"] = "lower-cased text rebuilt from the merged anchors (each rank lower-cases its own share)"
+        del T0, T1
     breakdown = None
     if rank == 0 and not divide:
         idx.prof(enable=True, reset=True)
@@ -172,16 +244,28 @@ def main():
         launches, ms, nbytes = prof[kname]
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_scan.json")
-        if os.path.exists(pmc):
-            try:
-                pj = json.load(open(pmc))
-                # per-launch HBM bytes from the PMC passes only describe the workload they were collected on
-                if pj.get("workload") == "%dx%d-%d" % (args.genomes, args.L, 64 if args.sa64 else 32):
-                    traffic = pj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        for name in ("pmc_scan_%dx%d-%d.json" % (args.genomes, args.L, 64 if args.sa64 else 32), "pmc_scan.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if os.path.exists(pmc):
+                try:
+                    pj = json.load(open(pmc))
+                    # per-launch HBM bytes from the PMC passes only describe the workload they were collected on
+                    if pj.get("workload") == "%dx%d-%d" % (args.genomes, args.L, 64 if args.sa64 else 32):
+                        traffic = pj.get("hbm_bytes_per_launch")
+                        break
+                except Exception:
+                    pass
+        try:
+            read_gbs, copy_gbs = _lib.measure_bandwidth(1 << 30, 10)      # the node's practical ceiling (streaming kernels, 1 GiB)
+        except Exception:
+            read_gbs = copy_gbs = None
         st = last["stats"]
+        if divide:
+            sharding = "one alignment divided over %d ranks (frontier hand-off after the top levels, no collective), ranks per share %s" % (world, last.get("shares"))
+        elif jobs == 1:
+            sharding = "one alignment per rank, no exchange"
+        else:
+            sharding = "%d independent alignments per rank, concurrently (a handle, stream and host thread each), no exchange" % jobs
         out = {
             "metric": "Mbp/s indexed+MUM-anchored (reveal rem)",
             "value": total_bases * args.steps / tmax / 1e6,
@@ -195,42 +279,59 @@ def main():
             "vs_baseline": None,
             "dtype": "int64" if args.sa64 else "int32",
             "data": "synthetic",
-            "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42+1000*rank), rem -m %d -n %d, "
-                                   "construct + full recursion, bench picker" % (args.genomes, args.L / 1e6, args.minl, args.minn),
-                       "bases_per_gpu": bases, "index": "64-bit" if args.sa64 else "32-bit",
-                       "jobs_per_gpu": jobs,
-                       "sharding": ("one alignment divided over %d ranks (frontier hand-off), shares %s" % (world, last.get("shares"))) if divide
-                                   else ("one alignment per rank, no exchange" if jobs == 1 else
-                                         "%d independent alignments per rank, concurrently (a handle, stream and host thread each), no exchange" % jobs)},
+            "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42%s), rem -m %d -n %d, construct + full recursion, "
+                                   "bench picker; text resident in HBM before the timed region (host->device copy of the text not timed)"
+                                   % (args.genomes, args.L / 1e6, "" if divide else "+1000*rank", args.minl, args.minn),
+                       "bases_per_gpu": bases if not divide else bases / world, "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
+                       "jobs_per_gpu": jobs, "sharding": sharding},
             "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("multi" if args.genomes > 2 else "pair"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,
-                         "algorithmic_bytes_per_launch": (nbytes / launches) if launches else None},
+                         "algorithmic_bytes_per_launch": (nbytes / launches) if launches else None,
+                         "copy_peak": {"read_GBps": read_gbs, "copy_GBps_read_plus_write": copy_gbs, "bytes": 1 << 30,
+                                       "frac_of_read_peak": (achieved / read_gbs) if read_gbs else None}},
             "breakdown_ms_per_step": breakdown,
             "recursion": {"anchors": st["splits"], "anchored_bp": st["anchored_bp"], "levels": st["levels"], "subindices": st["steps"],
                           "scanned_ranks": st["scanned_ranks"], "host_s": st["t_host"], "scan_s": st["t_scan"],
                           "split_s": st["t_split"], "bubble_s": st["t_bubble"]},
             "sa_build": idx.sa_stats(),
+            "properties_full_size": properties,
         }
         if world == 1 and not args.no_cpu:
-            cl = args.cpu_L or min(args.L, 5_000_000)
-            cseqs = seqs if cl == args.L else synth.genomes(cl, args.genomes, seed=42)
+            # CPU legs and bit-exact parity on a stated sample: 2 x 5 Mbp (or the workload itself when it is not larger)
+            cl = min(args.L, CPU_SAMPLE_L)
+            same = cl == args.L
+            cseqs = seqs if same else synth.genomes(cl, args.genomes, seed=42)
             cb = cpu_baseline(cseqs, args.minl, args.minn)
             cbases = sum(len(s) for s in cseqs)
+            sample = "%dx %g Mbp (same generator, seed 42)" % (args.genomes, cl / 1e6)
             out["cpu_baseline"] = {
                 "value": cbases / (cb["t_construct"] + cb["t_align"]) / 1e6, "unit": "Mbp/s", "cores": 1, "kind": "port",
-                "sample": "%dx %g Mbp (same generator), construct %.2f s + recursion %.2f s, single thread, SA by %s" % (
-                    args.genomes, cl / 1e6, cb["t_construct"], cb["t_align"],
+                "sample": "%s, construct %.2f s + recursion %.2f s, single thread, SA by %s" % (
+                    sample, cb["t_construct"], cb["t_align"],
                     "the reference's divsufsort (oracle/_ref)" if cb["ref_divsufsort"] else "the oracle's own sorter"),
                 "host_cores_available": os.cpu_count(),
             }
-            if cl == args.L:          # free full-size parity check: same anchors as the CPU path
-                rl, rn, roff, rpos = cb["result"]["anchors"]
-                gl, goff, gpos = last["anchors"]
-                ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
-                ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
-                out["parity"] = {"anchors_gpu": len(ga), "anchors_cpu": len(ra), "identical_anchor_set": ra == ga,
-                                 "identical_final_text": idx.T.encode("latin-1") == cb["result"]["T"]}
+            if not args.no_allcores:
+                ac = cpu_all_cores(cl, args.genomes, args.minl, args.minn)
+                if ac:
+                    out["cpu_baseline"]["all_cores"] = {
+                        "value": ac["value"], "unit": "Mbp/s", "cores": ac["workers"],
+                        "sample": "%d independent single-threaded alignments of %s at once (one process per core this process may use, "
+                                  "capped by free memory), %.1f s from first start to last end" % (ac["workers"], sample.replace("seed 42", "seeds 5000+13k"), ac["seconds"])}
+            # the same sample through the HIP path: anchors and final text must be identical to the CPU path's
+            if same:
+                gres, gT = last, idx.array("T").tobytes()
+            else:
+                pidx = build_index(cseqs, args.sa64)
+                pidx.construct()
+                gres = pidx.align_builtin(args.minl, args.minn)
+                gT = pidx.array("T").tobytes()
+            rl, rn, roff, rpos = cb["result"]["anchors"]
+            ra = anchor_set(rl, roff, rpos)
+            ga = anchor_set(*gres["anchors"])
+            out["parity"] = {"sample": sample, "anchors_gpu": len(ga), "anchors_cpu": len(ra), "identical_anchor_set": ra == ga,
+                             "identical_final_text": gT == cb["result"]["T"]}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -48,7 +48,9 @@ void rv_free(rv_index *h);
 int rv_add_sample(rv_index *h);
 /* addsequence (interface.c:51-95): appends seq + '$'; returns the half-open
  * interval [*begin,*end) of the sequence (excluding the '$').  The 32-bit
- * library fails like interface.c:61-68 when the text would exceed INT_MAX. */
+ * library fails like interface.c:61-68 when the text would exceed INT_MAX.
+ * rv_add_sample / rv_add_sequence after a construct() make the index
+ * "not yet constructed" again (the arrays in HBM describe the old text). */
 int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, int64_t *end);
 int64_t rv_n(const rv_index *h);        /* reveal_getn (interface.c:681-689): ranks in the main index */
 int rv_nsamples(const rv_index *h);     /* interface.c:691-695 */
@@ -238,6 +240,10 @@ int rv_prof_enable(rv_index *h, int on);
 int rv_prof_reset(rv_index *h);
 /* launches, total milliseconds and algorithmic bytes of kernel class k since the last reset */
 int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes);
+/* The practical HBM ceiling of this device ("also report measured copy-kernel bandwidth on the node"): a
+ * streaming read kernel and a copy kernel over `bytes` of freshly allocated memory, `iters` timed launches each, HIP events.
+ * GB/s; the copy figure counts bytes read + bytes written. */
+int rv_measure_bandwidth(int device, int64_t bytes, int iters, double *read_gbs, double *copy_gbs);
 /* SA-build statistics of the last rv_construct */
 int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_t *sorted_elems, int *radix_passes);
 

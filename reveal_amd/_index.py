@@ -73,6 +73,7 @@ def make_index_type(sa64, error):
                 raise error("Sample name has to be a string.")
             self._samples.append(args[0])
             self._dll.rv_add_sample(self._h)
+            self._constructed = False          # (the arrays in HBM describe the text as it was)
             return None
 
         def addsequence(self, seq):                         # interface.c:51-95
@@ -85,6 +86,7 @@ def make_index_type(sa64, error):
                 self._fail()
             intv = (b.value, e.value)
             self._nodes.add(intv)
+            self._constructed = False
             return intv
 
         def upload(self):

@@ -97,6 +97,7 @@ SYMBOLS = {
     "rv_prof_enable": (_I, [V, _I]),
     "rv_prof_reset": (_I, [V]),
     "rv_prof_get": (_I, [V, _I, c_i64p, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
+    "rv_measure_bandwidth": (_I, [_I, _L, _I, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "rv_sa_stats": (_I, [V] + [ctypes.POINTER(_I)] * 4 + [c_i64p, ctypes.POINTER(_I)]),
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
@@ -156,6 +157,15 @@ def set_device(i):
 
 def device():
     return _device
+
+
+def measure_bandwidth(nbytes=1 << 30, iters=10):
+    """-> (read GB/s, copy GB/s counting read + write) of streaming kernels on the current device: the node's practical HBM ceiling"""
+    lib = get(False)
+    r, c = _D(0), _D(0)
+    if lib.dll.rv_measure_bandwidth(device(), int(nbytes), int(iters), ctypes.byref(r), ctypes.byref(c)) != 0:
+        raise RuntimeError(lib.err())
+    return r.value, c.value
 
 
 def get(sa64=False):

@@ -97,6 +97,7 @@ rv_index *rv_clone(rv_index *h) {
 int rv_add_sample(rv_index *h) {
     if (h->nsamples > 0) h->nsep.push_back(h->n - 1);
     h->nsamples++;
+    h->constructed = false; h->text_only = false;      /* the device arrays describe the text as it was: every getter and scan needs a new construct() */
     return 0;
 }
 
@@ -123,6 +124,7 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     h->T[(size_t)(h->n + len + 1)] = '\0';
     h->n += len + 1;
     h->text_dirty = true;
+    h->constructed = false; h->text_only = false;      /* SA / LCP / BWT in HBM are sized for the old text (the getters would read past them) */
     if (begin) *begin = s;
     if (end) *end = h->n - 1;
     h->nodes.push_back(RvIntv{s, h->n - 1});
@@ -161,8 +163,9 @@ static int read_raw(const char *path, void *dst, size_t bytes) {
 static int write_raw(const char *path, const void *src, size_t bytes) {
     FILE *f = fopen(path, "wb");
     if (!f) { rv_set_error("cannot write %s", path); return -1; }
-    fwrite(src, 1, bytes, f);
-    fclose(f);
+    const size_t put = fwrite(src, 1, bytes, f);
+    const int rc = fclose(f);
+    if (put != bytes || rc != 0) { rv_set_error("%s: short write (%zu of %zu bytes)", path, put, bytes); return -1; }
     return 0;
 }
 
@@ -194,6 +197,9 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     }
     if (h->n == 0) { rv_set_error("No text to index."); return -1; }
     const int64_t n = h->n;
+    // ranks, child sizes and scan records are carried as u32 inside the library (rv_scan.h, rv_split.h), whatever the width of
+    // sa_t and however SA is obtained (built, or read from a file)
+    if (n >= ((int64_t)1 << 32) - 2) { rv_set_error("index of %lld positions: this build carries ranks in 32 bits (n < 2^32 - 2)", (long long)n); return -1; }
     if (cache == 1) RV_TRY(write_raw(".reveal.t", h->T.data(), (size_t)n));
     if (h->al) (void)rv_align_end(h);        /* a new construct ends any recursion in flight; its device scratch is kept */
     h->nT = n;
@@ -217,7 +223,8 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         RV_HIP(hipMemcpyAsync(h->dSA.p, tmp.data(), (size_t)n * sizeof(sa_t), hipMemcpyHostToDevice, q));
         RV_HIP(hipStreamSynchronize(q));
     }
-    RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
+    if (safile && safile[0]) RV_TRY(rv_build_inverse_checked(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
+    else RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
     RV_TRY(h->ws.misc[0].reserve(64));
     u32 *d_max = h->ws.misc[0].as<u32>();
     const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
@@ -638,6 +645,51 @@ int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_
     if (rounds) *rounds = h->sa_stats.rounds;
     if (sorted_elems) *sorted_elems = h->sa_stats.sorted_elems;
     if (radix_passes) *radix_passes = h->sa_stats.radix_passes;
+    return 0;
+}
+
+/* ---- the node's practical HBM ceiling (SURVEY 8(d) "Roofline": measured copy-kernel bandwidth beside the 8 TB/s spec) ---- */
+}  // extern "C"
+namespace {
+typedef int bw_v4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_bw_read(const bw_v4 *__restrict__ a, int64_t n16, unsigned *sink) {
+    bw_v4 acc = {0, 0, 0, 0};
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) acc ^= __builtin_nontemporal_load(a + i);
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) sink[0] = 1;      // (never true for the fill pattern: keeps the loads alive)
+}
+__global__ __launch_bounds__(256) void k_bw_copy(const bw_v4 *__restrict__ a, bw_v4 *__restrict__ b, int64_t n16) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) __builtin_nontemporal_store(__builtin_nontemporal_load(a + i), b + i);
+}
+}  // namespace
+extern "C" {
+int rv_measure_bandwidth(int device, int64_t bytes, int iters, double *read_gbs, double *copy_gbs) {
+    if (bytes < (1 << 20) || iters < 1) { rv_set_error("rv_measure_bandwidth: bytes >= 1 MiB and iters >= 1 needed"); return -1; }
+    RV_HIP(hipSetDevice(device));
+    const int64_t n16 = bytes / 16;
+    void *a = nullptr, *b = nullptr; unsigned *sink = nullptr;
+    hipStream_t q = nullptr; hipEvent_t e0 = nullptr, e1 = nullptr;
+    RV_HIP(hipMalloc(&a, (size_t)n16 * 16)); RV_HIP(hipMalloc(&b, (size_t)n16 * 16)); RV_HIP(hipMalloc((void **)&sink, 64));
+    RV_HIP(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+    RV_HIP(hipEventCreate(&e0)); RV_HIP(hipEventCreate(&e1));
+    RV_HIP(hipMemsetAsync(a, 1, (size_t)n16 * 16, q)); RV_HIP(hipMemsetAsync(b, 2, (size_t)n16 * 16, q));
+    const unsigned grid = 256 * 16;      // 16 workgroups per CU, grid-stride
+    double out[2] = {0, 0};
+    for (int pass = 0; pass < 2; pass++) {
+        for (int r = -1; r < iters; r++) {       // (r = -1: warm-up)
+            if (r == 0) RV_HIP(hipEventRecord(e0, q));
+            if (pass == 0) hipLaunchKernelGGL(k_bw_read, dim3(grid), dim3(256), 0, q, (const bw_v4 *)a, n16, sink);
+            else hipLaunchKernelGGL(k_bw_copy, dim3(grid), dim3(256), 0, q, (const bw_v4 *)a, (bw_v4 *)b, n16);
+        }
+        RV_HIP(hipEventRecord(e1, q));
+        RV_HIP(hipEventSynchronize(e1));
+        float ms = 0.f;
+        RV_HIP(hipEventElapsedTime(&ms, e0, e1));
+        out[pass] = (double)n16 * 16 * (pass ? 2 : 1) * iters / ((double)ms * 1e6);      // GB/s; the copy counts read + write
+    }
+    if (read_gbs) *read_gbs = out[0];
+    if (copy_gbs) *copy_gbs = out[1];
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipStreamDestroy(q);
+    (void)hipFree(a); (void)hipFree(b); (void)hipFree(sink);
     return 0;
 }
 

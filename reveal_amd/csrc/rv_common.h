@@ -143,6 +143,8 @@ struct RvSaStats {
 // SA of T[0..n) (device pointers).  T must be readable up to n+15 (zero padded).
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st);
 int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
+// the same for an SA that came from a file: fails unless it is a permutation of 0..n-1
+int rv_build_inverse_checked(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
 // SAi given: text-order (Kasai) evaluation; NULL: every rank from scratch
 // side_sep: text position of the first sample separator, nsep[0] (bit RV_BWT_SIDE of a BWT byte = the suffix starts behind

@@ -390,6 +390,21 @@ __global__ __launch_bounds__(TB) void k_inverse(const sa_t *__restrict__ SA, sa_
     if (i < n) SAi[SA[i]] = (sa_t)i;
 }
 
+// SA read from a `sa=` file (interface.c:224-232) is untrusted: scatter only in-range entries, then every text position must
+// have got its own rank back -- anything else (stale cache, wrong width) is an error, not an out-of-bounds write
+__global__ __launch_bounds__(TB) void k_inverse_checked(const sa_t *__restrict__ SA, sa_t *__restrict__ SAi, int64_t n, u32 *__restrict__ err) {
+    const int64_t i = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    const sa_t v = SA[i];
+    if ((u64)v < (u64)n) SAi[v] = (sa_t)i; else atomicOr(err, 1u);
+}
+__global__ __launch_bounds__(TB) void k_inverse_verify(const sa_t *__restrict__ SA, const sa_t *__restrict__ SAi, int64_t n, u32 *__restrict__ err) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j >= n) return;
+    const sa_t r = SAi[j];
+    if ((u64)r >= (u64)n || SA[r] != (sa_t)j) atomicOr(err, 2u);
+}
+
 // ---- LCP ---------------------------------------------------------------------
 __device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exact at and below the lowest hit
     return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
@@ -523,6 +538,22 @@ int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n) {
     if (n <= 0) return 0;
     hipLaunchKernelGGL(k_inverse, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, SAi, n);
     RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_build_inverse_checked(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n) {
+    if (n <= 0) return 0;
+    RV_TRY(ws.misc[1].reserve(64));
+    u32 *d_err = ws.misc[1].as<u32>();
+    RV_HIP(hipMemsetAsync(d_err, 0, 4, ws.stream));
+    RV_HIP(hipMemsetAsync(SAi, 0xFF, (size_t)n * sizeof(sa_t), ws.stream));
+    hipLaunchKernelGGL(k_inverse_checked, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, SAi, n, d_err);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_inverse_verify, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, (const sa_t *)SAi, n, d_err);
+    RV_LAUNCH_CHECK();
+    u32 err = 0;
+    RV_TRY(rv_read_back(ws, &err, d_err, 4));
+    if (err) { rv_set_error("the suffix array file does not hold a permutation of 0..n-1 (%s): stale or foreign cache file?", (err & 1u) ? "entry out of range" : "duplicate entries"); return -1; }
     return 0;
 }
 

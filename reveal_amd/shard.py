@@ -163,6 +163,10 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False)
             src = dist.get_global_rank(group, 0) if group is not None else 0
             for b in bufs:
                 dist.recv(b[:m], src=src, group=group)
+            if on_dev:
+                # RCCL's recv only orders torch's current stream behind the transfer; the library copies from these buffers on
+                # its own (non-blocking) stream, so the host has to see the transfers finished first
+                torch.cuda.current_stream().synchronize()
             idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=head["maxlcp"], trace=trace)
             res = idx.align_builtin_resume()
     out = [None] * world if rank == 0 else None

@@ -160,3 +160,53 @@ def test_errors():
     idx.addsample("a"); idx.addsequence("ACGT")
     with pytest.raises(TypeError):
         idx.SA                                # "Index not yet constructed."
+
+
+def test_text_growth_after_construct_unconstructs():
+    """addsample / addsequence after construct(): the arrays in HBM describe the old text, so every getter and scan
+    refuses until the next construct() (never an out-of-bounds device read)"""
+    m = mod(False)
+    idx = feed(m.index(), SETS["known"])
+    idx.construct()
+    n0 = idx.n
+    assert len(idx.SA) == n0
+    idx.addsample("late")
+    idx.addsequence("ACTTGCTAGGTAGTCAG")
+    assert idx.n == n0 + 18
+    with pytest.raises(TypeError):
+        idx.SA
+    with pytest.raises(TypeError):
+        idx.LCP
+    with pytest.raises((TypeError, m.error)):
+        idx.getmums(1)
+    assert idx.T == "ACTTGCTAGCTAGTCAG$ACTAGCTAGCTAGTGAG$ACTTGCTAGGTAGTCAG$"      # the host text, all of it
+    idx.construct()
+    T, nsep, nodes = assemble(SETS["known"] + ["ACTTGCTAGGTAGTCAG"])
+    c = oracle(False).construct(T, nsep, 3)
+    assert np.array_equal(idx.array("SA"), c["SA"]) and np.array_equal(idx.array("LCP"), c["LCP"])
+
+
+def test_corrupt_sa_file_is_an_error(tmp_path, monkeypatch):
+    """sa= files are range- and permutation-checked on the device before anything scatters through them (interface.c:224-232
+    reads them unchecked)"""
+    monkeypatch.chdir(tmp_path)
+    m = mod(False)
+    idx = feed(m.index(cache=1), fa("1a", "1b"))
+    idx.construct()
+    sa = np.fromfile(tmp_path / ".reveal.sa", dtype=np.int32)
+    for kind in ("range", "dup", "short"):
+        bad = sa.copy()
+        if kind == "range":
+            bad[len(bad) // 2] = len(bad) + 12345
+        elif kind == "dup":
+            bad[7] = bad[8]
+        else:
+            bad = bad[:-5]
+        bad.tofile(tmp_path / "bad.sa")
+        idx2 = feed(m.index(sa=str(tmp_path / "bad.sa")), fa("1a", "1b"))
+        with pytest.raises(m.error):
+            idx2.construct()
+    # an index larger than the 32-bit rank range is refused whatever the source of SA (ranks travel as u32 inside the library)
+    good = feed(m.index(sa=str(tmp_path / ".reveal.sa"), lcp=str(tmp_path / ".reveal.lcp")), fa("1a", "1b"))
+    good.construct()
+    assert np.array_equal(good.array("SA"), sa)

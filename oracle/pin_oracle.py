@@ -17,6 +17,12 @@ and oracle/_ref/ built by `make -C oracle ref`).  For every fixture set:
     ro_extract == the reference's own extract() (ranks 1.. of SA -- the reference
     never writes SA[0] -- LCP, SAi, T), also with rc=1 interval remapping.
   * the known-answer vectors of SURVEY.md 8(c).
+  * "aligner() itself": the reference's own recursion driver (reveal.c:731-1338, entered through index.align,
+    interface.c:293-415) executed for real -- module oracle/_ref/reveallib[64].so = the reference's sources built as
+    the CPython module they define (`make -C oracle refmod`, Python-2 API names mapped by oracle/refmod/py3_names.[ch])
+    -- with the benchmark callbacks written as Python 3 functions of the reference's callback signatures.  Its
+    per-callback trace (sub-index key, n, depth, nsamples, nodes, scan result, SA / LCP hashes of every sub-index it
+    pops), the chosen matches and the final text must equal ro_align's AND the digests in tests/golden/vectors.json.
 
 Exit code 0 = every check passed.  `python oracle/pin_oracle.py [--big]`.
 """
@@ -172,6 +178,94 @@ def ref_recursion(R, tbuf, SA, LCP, SAi, SO, nsep, nsamples, nodes, minl, minn, 
             stack.append(dict(SA=kids[0][0], LCP=kids[0][1], depth=d, nsamples=nsamp(lead), nodes=lead))
         if kids[1] is not None:
             stack.append(dict(SA=kids[1][0], LCP=kids[1][1], depth=d, nsamples=nsamp(trail), nodes=trail))
+
+
+def load_refmod(sa64):
+    """the reference as the CPython module it defines (oracle/_ref/reveallib[64].so, `make -C oracle refmod`) or None"""
+    import importlib.machinery
+    import importlib.util
+    name = "reveallib64" if sa64 else "reveallib"
+    path = os.path.join(HERE, "_ref", name + ".so")
+    if not os.path.exists(path):
+        return None
+    loader = importlib.machinery.ExtensionFileLoader(name, path)
+    spec = importlib.util.spec_from_loader(name, loader)
+    mod = importlib.util.module_from_spec(spec)
+    loader.exec_module(mod)
+    return mod
+
+
+def run_real_aligner(mod, files, minl, minn):
+    """index.align() of the reference itself (interface.c:293-415 -> aligner(), reveal.c:731-1338) with the benchmark
+    callbacks in the reference's own callback signatures (reveal.c:839-999).  -> (trace records in pop order, final T)"""
+    idx = mod.index()
+    for f in files:
+        if isinstance(f, str) and os.path.exists(f):
+            idx.addsample(os.path.basename(f))
+            for _, s in read_fasta(f):
+                idx.addsequence(s)
+        else:
+            idx.addsample("lit")
+            idx.addsequence(f)
+    idx.construct()
+    trace = []
+
+    def mumpicker(mums, sub, precomputed=False, minlength=0):          # reveal.c:839-857: (multimums, idx, precomputed=, minlength=)
+        nodes = sorted((int(b), int(e)) for b, e in sub.nodes)
+        rec = dict(key=min(b for b, _ in nodes), n=int(sub.n), depth=int(sub.depth), nsamples=int(sub.nsamples), nnodes=len(nodes),
+                   nmums=len(mums), h_sa=seqhash(sub.SA), h_lcp=seqhash(sub.LCP), h_mums=seqhash(flat_mums(mums)) if mums else 0,
+                   picked=0, l=0, mn=0, sp_min=0, nodes=nodes)
+        trace.append(rec)
+        mum = bench_picker(mums, sub.nsamples)
+        if mum is None:
+            return ()                                                  # reveal.c:870-884
+        rec.update(picked=1, l=int(mum[0]), mn=int(mum[1]), sp_min=min(int(p) for _, p in mum[2]))
+        return (mum, [], [])                                           # (mum, skipmumsleft, skipmumsright), reveal.c:901
+
+    def graphalign(sub, mum):                                          # reveal.c:939: (idx, mum) -> 7-tuple, :987
+        lead, trail, match, rest = linear_graphalign(sorted((int(b), int(e)) for b, e in sub.nodes), mum)
+        return (lead, trail, match, rest, None, None, None)
+
+    idx.align(mumpicker, graphalign, threads=0, minl=minl, minn=minn)
+    return trace, idx.T.encode("latin-1")
+
+
+def pin_aligner(label, files, sa64, minl=20, minn=2, golden=None):
+    print("[aligner() itself: %s]%s" % (label, " (64-bit)" if sa64 else ""))
+    mod = load_refmod(sa64)
+    if mod is None:
+        check("reference module built (make -C oracle refmod)", False)
+        return
+    t0 = time.time()
+    reft, finalT = run_real_aligner(mod, files, minl, minn)
+    t_ref = time.time() - t0
+    O = oracle_ctypes.Oracle(sa64)
+    T, nsep, nodes = assemble(files)
+    cons = O.construct(T, nsep, len(files))
+    res = O.align_bench(cons, nodes, minl, minn, trace_cap=len(reft) + 16)
+    tr = res["trace"]
+    ok, bad = len(tr) == len(reft), None
+    if ok:
+        for k, r in enumerate(reft):          # same LIFO order on both sides: record by record
+            for f in ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums"):
+                if int(tr[k][f]) != int(r[f]) & (M64 if f.startswith("h_") else -1):
+                    ok, bad = False, (k, f, int(tr[k][f]), r[f])
+                    break
+            if not ok:
+                break
+    check("aligner() trace == ro_align trace (every popped sub-index)", ok,
+          "%d callbacks, %d anchors, aligner() %.1fs %s" % (len(reft), sum(r["picked"] for r in reft), t_ref, bad or ""))
+    check("aligner() final T == ro_align final T", finalT == res["T"])
+    if golden is not None:
+        import hashlib
+        import json
+        g = golden["recursion"]
+        anchors = sorted((r["l"], r["sp_min"], r["mn"]) for r in reft if r["picked"])
+        key = sorted((r["depth"], r["key"], r["n"], r["nsamples"], r["nmums"], r["picked"], r["l"], r["sp_min"],
+                      r["h_sa"] & M64, r["h_lcp"] & M64, r["h_mums"] & M64) for r in reft)
+        check("aligner() trace == tests/golden/vectors.json sha_trace", hashlib.sha256(json.dumps(key).encode()).hexdigest() == g["sha_trace"], "%d steps" % g["steps"])
+        check("aligner() anchors == vectors.json sha_anchors", hashlib.sha256(json.dumps(anchors).encode()).hexdigest() == g["sha_anchors"], "%d anchors" % g["anchors"])
+        check("aligner() final T == vectors.json sha_finalT", hashlib.sha256(finalT).hexdigest() == g["sha_finalT"])
 
 
 def csr_to_tuples(l, n, off, so, pos):
@@ -379,6 +473,21 @@ def main():
     pin_single_steps("1a+1b", f("1a", "1b"), True)
     pin_single_steps("1a+1b+1c", f("1a", "1b", "1c"), False)
     pin_single_steps("1e+1b (multi-contig)", f("1e", "1b"), False)
+    gold = {}
+    try:
+        import json
+        with open(os.path.join(os.path.dirname(HERE), "tests", "golden", "vectors.json")) as fh:
+            gold = json.load(fh)["sets"]
+    except Exception:
+        pass
+    pin_aligner("known answers, 2 samples", ["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"], False, minl=1, golden=gold.get("known2"))
+    pin_aligner("t1+t2", f("t1", "t2"), False, minl=1, golden=gold.get("t1t2"))
+    pin_aligner("1a+1b (config 1)", f("1a", "1b"), False, golden=gold.get("1a1b"))
+    pin_aligner("1a+1b (config 1)", f("1a", "1b"), True, golden=gold.get("1a1b_64"))
+    pin_aligner("1a+1b+1c (3-way)", f("1a", "1b", "1c"), False, golden=gold.get("1a1b1c"))
+    pin_aligner("1a+1b+1c+1d+1e (5-way, multi-contig)", f("1a", "1b", "1c", "1d", "1e"), False, golden=gold.get("5way"))
+    pin_aligner("1e+1b (multi-contig)", f("1e", "1b"), False, golden=gold.get("1e1b"))
+    pin_aligner("d1+d2 (50k N run)", f("d1", "d2"), False, golden=gold.get("d1d2"))
     if big:
         pin_set("3a+3b", f("3a", "3b"), False, own_sa=False)
         pin_set("1a+1b+1c (3-way)", f("1a", "1b", "1c"), True)

@@ -208,3 +208,37 @@ def test_bubble_closed_form():
             cs, cl = _bubble_closed_form(cs, cl, B)
         assert cs == sa.tolist() and cl == lcp.tolist(), (SA, LCP, cuts)
         assert (sai[sa] == np.arange(n)).all()
+
+
+def test_reference_aligner_itself_pins_the_oracle(tmp_path):
+    """The reference's own aligner() (reveal.c:731-1338, through index.align, interface.c:293-415) executed for real with
+    the benchmark callbacks as Python 3 functions: its per-callback trace, anchors and final text equal ro_align's and the
+    digests in vectors.json.  Needs oracle/_ref/reveallib.so (`make -C oracle refmod`: the reference's sources built as the
+    CPython module they define); where that is absent (no /root/reference at build time) the test is skipped."""
+    import gzip
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(os.path.dirname(here), "oracle"))
+    import pin_oracle as P
+    if P.load_refmod(False) is None:
+        pytest.skip("oracle/_ref/reveallib.so not built (make -C oracle refmod needs /root/reference)")
+    gold = golden()
+
+    def files(names):
+        out = []
+        for x in names:
+            src = os.path.join(here, "golden", x + ".fa.gz")
+            if not os.path.exists(src):
+                out.append(x)
+                continue
+            dst = tmp_path / (x + ".fa")
+            with gzip.open(src, "rt") as f:
+                dst.write_text(f.read())
+            out.append(str(dst))
+        return out
+    P.check.failed = 0
+    for label, sa64 in (("known2", False), ("t1t2", False), ("1a1b", False), ("1a1b_64", True), ("1a1b1c", False), ("5way", False), ("d1d2", False)):
+        g = gold[label]
+        P.pin_aligner(label, files(g["inputs"]), sa64, minl=g["minl"], minn=g["minn"], golden=g)
+    assert P.check.failed == 0

@@ -115,6 +115,10 @@ int rv_align_begin(rv_index *h, int minl, int minn);      /* frontier = {main in
 int rv_frontier_size(rv_index *h);
 /* getmums_rem / getmultimums on every sub-index of the frontier (reveal.c:802-822) */
 int rv_frontier_scan(rv_index *h);
+/* Sub-index s of the current frontier (made by the last rv_frontier_commit) was seeded by its parent's mumpicker -- its Python
+ * object carries a non-empty `skipmums` list (reveal.c:1157, 1180) -- so, like the reference (reveal.c:802, 830-837), it is
+ * not scanned: rv_frontier_scan reports no matches for it, and skips its launch when every sub-index of the level is seeded. */
+int rv_sub_skip_scan(rv_index *h, int s);
 int rv_sub_info(rv_index *h, int s, rv_sub *out);
 int rv_sub_nodes(rv_index *h, int s, int64_t *begin_end /* 2*nnodes */);
 /* matches of sub-index s as (l, n, ((sample,pos)...)) in CSR form */

@@ -89,6 +89,33 @@ def one(label, inputs, minl, minn=2, sa64=False):
     return rec
 
 
+def seeded(label, inputs, minl, minn=2, sa64=False):
+    """the reference's REAL aligner() (module oracle/_ref/reveallib[64].so, `make -C oracle refmod`) under a picker that seeds
+    its children (non-empty skipmums: reveal.c:802, 830-837, 1157, 1180) -- the callbacks are reveal_amd/rem.py's, the same
+    objects the GPU test hands to reveal_amd's index.align"""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import helpers as H
+    from reveal_amd import rem
+    mod = P.load_refmod(sa64)
+    idx = mod.index()
+    for x in inputs:
+        f = load(x)
+        if os.path.exists(f):
+            idx.addsample(os.path.basename(f))
+            for _, s in P.read_fasta(f):
+                idx.addsequence(s)
+        else:
+            idx.addsample("lit"); idx.addsequence(f)
+    idx.construct()
+    pick, galign, trace = H.traced_callbacks(rem.seeding_mumpicker, rem.linear_graphalign)
+    idx.align(pick, galign, threads=0, minl=minl, minn=minn)
+    d = H.callback_trace_digest(trace)
+    d.update(inputs=inputs, minl=minl, minn=minn, sa64=sa64, sha_finalT=hashlib.sha256(idx.T.encode("latin-1")).hexdigest())
+    print("%-28s seeded: calls=%d precomputed=%d anchors=%d" % (label, d["calls"], d["precomputed_calls"], d["anchors"]))
+    return d
+
+
 def main():
     sets = {
         "known2": (["ACTTGCTAGCTAGTCAG", "ACTAGCTAGCTAGTGAG"], 1, 2),
@@ -105,6 +132,9 @@ def main():
     for label, (inputs, minl, minn) in sets.items():
         out["sets"][label] = one(label, inputs, minl, minn)
     out["sets"]["1a1b_64"] = one("1a1b_64", ["1a", "1b"], 20, 2, sa64=True)
+    if P.load_refmod(False) is not None:      # aligner() itself with seeded children (skipmums)
+        out["seeded"] = {"1a1b": seeded("1a1b", ["1a", "1b"], 20), "1a1b1c": seeded("1a1b1c", ["1a", "1b", "1c"], 20),
+                         "5way": seeded("5way", ["1a", "1b", "1c", "1d", "1e"], 20), "1a1b_64": seeded("1a1b_64", ["1a", "1b"], 20, sa64=True)}
     with open(os.path.join(GOLD, "vectors.json"), "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
     print("wrote tests/golden/vectors.json")

@@ -355,6 +355,8 @@ def make_index_type(sa64, error):
                     frontier = [nxt[k] for k in sorted(nxt)]
                     for k, c in enumerate(frontier):
                         assert c._slot == k
+                        if len(c.skipmums) != 0 and dll.rv_sub_skip_scan(h, k) != 0:      # seeded: not scanned (reveal.c:802, 830-837)
+                            self._fail()
             finally:
                 dll.rv_align_end(h)
                 self._slot = None

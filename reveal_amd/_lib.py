@@ -62,6 +62,7 @@ SYMBOLS = {
     "rv_align_begin": (_I, [V, _I, _I]),
     "rv_frontier_size": (_I, [V]),
     "rv_frontier_scan": (_I, [V]),
+    "rv_sub_skip_scan": (_I, [V, _I]),
     "rv_sub_info": (_I, [V, _I, ctypes.POINTER(RvSub)]),
     "rv_sub_nodes": (_I, [V, _I, V]),
     "rv_sub_mums": (_I, [V, _I, V, V, V, V, V]),

@@ -125,6 +125,7 @@ struct Align {
     Level lv, nx;                // current frontier / the one being built
     Decisions dec;
     bool scanned = false;
+    std::vector<uint8_t> skip_scan;   // per sub of the current level: its matches come from the caller (skipmums, reveal.c:802,830-837), the scan's are not wanted
     bool full_only = false;      // multi scan pre-selection (built-in picker, no trace)
     const u32 *d_err = nullptr;  // error word of the last commit, checked with the next scan's copy
     // scan result of the level: pair records in rank order, or CSR for the multi scan
@@ -301,10 +302,15 @@ static int add_decision(rv_index *h, int s, u32 l, const int64_t *sp, int nsp,
 
 extern "C" {
 
-int rv_align_begin(rv_index *h, int minl, int minn) {
+static int align_begin(rv_index *h, int minl, int minn, bool need_sai);
+/* the callback protocol: sub-indices are visible to the caller, the shared inverse (reveal.c:597,609,630) is a getter of theirs */
+int rv_align_begin(rv_index *h, int minl, int minn) { return align_begin(h, minl, minn, true); }
+
+static int align_begin(rv_index *h, int minl, int minn, bool need_sai) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed, alignment stopped."); return -1; }
     if (h->nsamples < 2) { rv_set_error("align needs at least two samples"); return -1; }
     RV_HIP(hipSetDevice(h->device));
+    if (need_sai) RV_TRY(rv_need_sai(h));
     const bool keep_trace = h->al && h->al->trace_on;
     if (!h->al) h->al = new Align();         // device scratch of an earlier run is reused
     Align *a = h->al;
@@ -326,6 +332,7 @@ int rv_align_begin(rv_index *h, int minl, int minn) {
     std::sort(a->lv.nodes.begin(), a->lv.nodes.end(), intv_less);
     a->lv.node_first.push_back((int64_t)a->lv.nodes.size());
     a->dec.reset(1);
+    a->skip_scan.assign(1, 0);
     return 0;
 }
 
@@ -530,7 +537,17 @@ int rv_frontier_scan(rv_index *h) {
     const double t0 = now_s();
     const int ns = a->lv.size();
     a->mum_first.assign((size_t)ns, 0); a->nmums.assign((size_t)ns, 0);
-    if (!a->multi) {
+    bool all_skipped = ns > 0 && (int)a->skip_scan.size() == ns && !a->full_only;
+    for (int s2 = 0; s2 < ns && all_skipped; s2++) all_skipped = a->skip_scan[(size_t)s2] != 0;
+    if (all_skipped) {       // every sub-index of the level brings its own matches: no launch at all (the deferred error word is read here instead)
+        a->recs.clear(); a->ml.clear(); a->mn.clear(); a->moff.assign(1, 0); a->mso.clear(); a->mpos.clear();
+        if (a->d_err) {
+            u32 err = 0;
+            RV_HIP(hipMemcpyAsync(&err, a->dErr.p, 4, hipMemcpyDeviceToHost, h->ws.stream));
+            RV_HIP(hipStreamSynchronize(h->ws.stream));
+            if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+        }
+    } else if (!a->multi) {
         u32 err = 0;
         // built-in picker without tracing: the device keeps only the record the picker would take.  The sub-index starts of this
         // level came with the previous commit's table upload (a pageable H2D copy here would wait for the stream to drain and
@@ -594,10 +611,25 @@ int rv_frontier_scan(rv_index *h) {
         }
         }
     }
+    for (int s2 = 0; s2 < ns && s2 < (int)a->skip_scan.size(); s2++)
+        if (a->skip_scan[(size_t)s2]) { a->nmums[(size_t)s2] = 0; a->mum_first[(size_t)s2] = 0; }
     a->scanned = true;
     if (a->presel_on && !a->full_only) build_preselection(a);
     a->st.scanned_ranks += a->lv.m;
     a->st.t_scan += now_s() - t0;
+    return 0;
+}
+
+/* Sub-index s of the new frontier was seeded by its parent's mumpicker (non-empty skipmums, reveal.c:1157, 1180): the reference
+ * does not scan such an index (reveal.c:802 `if (PyList_Size(idx->skipmums)==0)` ... else :830-837 uses the list).  To be called
+ * between the commit that created s and the next rv_frontier_scan; the scan then reports no matches for s, and a level made
+ * of seeded sub-indices only is not scanned at all. */
+int rv_sub_skip_scan(rv_index *h, int s) {
+    RV_TRY(need_sub(h, s));
+    Align *a = h->al;
+    if (a->scanned) { rv_set_error("rv_sub_skip_scan after rv_frontier_scan"); return -1; }
+    if ((int)a->skip_scan.size() != a->lv.size()) a->skip_scan.assign((size_t)a->lv.size(), 0);
+    a->skip_scan[(size_t)s] = 1;
     return 0;
 }
 
@@ -1117,6 +1149,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->cur_dev_ok = a->next_dev_ok; a->early_done = false; a->early_bubble = false;
     std::swap(a->lv, a->nx);
     a->dec.reset(a->lv.size());
+    a->skip_scan.assign((size_t)a->lv.size(), 0);
     a->st.t_split += t1 - t0;
     a->st.t_bubble += now_s() - t1;
     return 0;
@@ -1153,7 +1186,8 @@ static int builtin_leaf_setup(rv_index *h) {
 }
 
 static int builtin_setup(rv_index *h, int minl, int minn) {
-    RV_TRY(rv_align_begin(h, minl, minn));
+    // (an untraced built-in run never hands a sub-index out: the inverse stays unmade unless somebody asked for it before)
+    RV_TRY(align_begin(h, minl, minn, h->al && h->al->trace_on));
     Align *a = h->al;
     a->full_only = !a->trace_on;
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
@@ -1534,6 +1568,7 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
     a->cur_dev_ok = a->next_dev_ok; a->early_done = false; a->early_bubble = false;
     a->scanned = false; a->d_err = nullptr;
     a->dec.reset(lv.size());
+    a->skip_scan.assign((size_t)lv.size(), 0);
     return 0;
 }
 
@@ -1689,6 +1724,7 @@ extern "C" {
 rv_subindex *rv_sx_main(rv_index *h) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return nullptr; }
     if (hipSetDevice(h->device) != hipSuccess) { rv_set_error("hipSetDevice failed"); return nullptr; }
+    if (rv_need_sai(h)) return nullptr;
     rv_subindex *x = new rv_subindex();
     x->h = h; x->depth = 0; x->nsamples = h->nsamples;
     x->nodes = h->nodes;

@@ -70,6 +70,7 @@ void rv_free(rv_index *h) {
  * (self->SO = NULL, interface.c:462): not imitated. */
 rv_index *rv_clone(rv_index *h) {
     if (!h->constructed || h->main_arrays_freed) { rv_set_error("Index not yet constructed."); return nullptr; }
+    if (rv_need_sai(h)) return nullptr;
     rv_index *c = rv_new(h->device);
     if (!c) return nullptr;
     c->T = h->T; c->nsep = h->nsep; c->nodes = h->nodes; c->nsamples = h->nsamples; c->n = h->n; c->nT = h->nT; c->rc = h->rc;
@@ -89,7 +90,7 @@ rv_index *rv_clone(rv_index *h) {
     ok = ok && hipStreamSynchronize(q) == hipSuccess;
     if (!ok) { rv_set_error("copy of the index failed"); rv_free(c); return nullptr; }
     c->nsep_dev = h->nsep_dev;
-    c->constructed = true;
+    c->constructed = true; c->sai_valid = true;
     return c;
 }
 
@@ -223,14 +224,14 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
         RV_HIP(hipMemcpyAsync(h->dSA.p, tmp.data(), (size_t)n * sizeof(sa_t), hipMemcpyHostToDevice, q));
         RV_HIP(hipStreamSynchronize(q));
     }
-    if (safile && safile[0]) RV_TRY(rv_build_inverse_checked(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
-    else RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n));
+    h->sai_valid = false;
+    if (safile && safile[0]) { RV_TRY(rv_build_inverse_checked(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n)); h->sai_valid = true; }      // (the check of an untrusted SA needs it anyway)
     RV_TRY(h->ws.misc[0].reserve(64));
     u32 *d_max = h->ws.misc[0].as<u32>();
     const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
     if (!lcpfile || !lcpfile[0]) {
         int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
-        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>(), side_sep));
+        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), false, h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>(), side_sep));
         h->prof.end(q, id);
         RV_TRY(rv_read_back(h->ws, &h->maxlcp, d_max, 4));
     } else {
@@ -280,6 +281,7 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
         return n;
     case RV_SA: case RV_SAI: case RV_LCP: {
         if (!h->constructed || (which != RV_SAI && h->main_arrays_freed)) { rv_set_error("Index not yet constructed."); return -2; }
+        if (which == RV_SAI && rv_need_sai(h)) return -2;
         if (cap < h->nT && which == RV_SAI) { rv_set_error("buffer too small"); return -1; }
         if (cap < n && which != RV_SAI) { rv_set_error("buffer too small"); return -1; }
         const void *src = which == RV_SA ? h->dSA.p : which == RV_SAI ? h->dSAi.p : h->dLCP.p;
@@ -315,6 +317,15 @@ int64_t rv_get_array(rv_index *h, int which, void *out, int64_t cap) {
 
 }  // extern "C"
 
+int rv_need_sai(rv_index *h) {
+    if (h->sai_valid) return 0;
+    if (!h->constructed || h->main_arrays_freed) { rv_set_error("the inverse suffix array was not requested before align() consumed the main index"); return -1; }
+    RV_HIP(hipSetDevice(h->device));
+    RV_TRY(rv_build_inverse(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), h->n));
+    h->sai_valid = true;
+    return 0;
+}
+
 int rv_text_only(rv_index *h, u32 maxlcp) {
     RV_HIP(hipSetDevice(h->device));
     if (h->n == 0) { rv_set_error("No text to index."); return -1; }
@@ -333,7 +344,7 @@ int rv_text_only(rv_index *h, u32 maxlcp) {
     h->nsep_dev = h->nsep;
     RV_HIP(hipStreamSynchronize(q));
     h->maxlcp = maxlcp;
-    h->constructed = false; h->main_arrays_freed = true; h->text_only = true;
+    h->constructed = false; h->main_arrays_freed = true; h->text_only = true; h->sai_valid = false;
     return 0;
 }
 

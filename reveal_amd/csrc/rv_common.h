@@ -146,9 +146,9 @@ int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // the same for an SA that came from a file: fails unless it is a permutation of 0..n-1
 int rv_build_inverse_checked(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // LCP with the reference's stop characters (interface.c:97-114); also returns max LCP.
-// SAi given: text-order (Kasai) evaluation; NULL: every rank from scratch
+// by_rank: every rank from scratch (one thread per rank); otherwise text order with Kasai's carry (PHI scatter, no inverse needed)
 // side_sep: text position of the first sample separator, nsep[0] (bit RV_BWT_SIDE of a BWT byte = the suffix starts behind
 // it), or the largest sa_t for a single sample (the bit stays clear)
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep);
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep);
 // BWT only (when LCP came from a file)
 int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uint8_t *BWT, sa_t side_sep);

@@ -85,14 +85,18 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     seed[j] = hd ? (u32)j : 0u;
 }
 
-// SA[j] = vals[j]; ISA[vals[j]] = grp[j]
-__global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, const u32 *__restrict__ grp, int64_t n,
-                                                 sa_t *__restrict__ SA, u32 *__restrict__ ISA) {
+// SA[j] = vals[j].  ISA (rank of every suffix's group) is only an intermediate of the doubling rounds and of the radix
+// path for groups above MEDIUM_GROUP: related genomes finish in the text round without either, so the scatter
+// ISA[SA[j]] = grp[j] (a random 4-byte write per position, 21 ms at n = 5e8) waits until something asks for it.
+__global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, int64_t n, sa_t *__restrict__ SA) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (j >= n) return;
-    const sav_t s = vals[j];
-    SA[j] = (sa_t)s;
-    ISA[s] = grp[j];
+    if (j < n) SA[j] = (sa_t)vals[j];
+}
+// Group ranks are rank ranges and every round only permutes suffixes inside their group, so (SA, grp of round 0) still
+// describe round 0's ISA after the text round has reordered SA.
+__global__ __launch_bounds__(TB) void k_isa_from_groups(const sa_t *__restrict__ SA, const u32 *__restrict__ grp, int64_t n, u32 *__restrict__ ISA) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j < n) ISA[SA[j]] = grp[j];
 }
 
 // ---- ordered compaction of the not-yet-unique suffixes -------------------------
@@ -457,18 +461,26 @@ __device__ inline u64 stop_mask(u64 wa, u64 wb) {
     stop |= zero_bytes(wb);                            // end of text (zero padding)
     return stop;
 }
-__global__ __launch_bounds__(TB) void k_plcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, const sa_t *__restrict__ SAi,
-                                             u32 *__restrict__ PLCP, int64_t n) {
+// PHI[p] = the suffix in front of suffix p in the suffix array (-1 for rank 0): one scatter in rank order, after which the
+// text-order pass reads its partner positions as a stream.  (With the inverse instead -- SAi[p], then SA[SAi[p] - 1] -- the
+// pass paid a random gather per position on top of the scatter that built SAi; the inverse itself is not needed by
+// construct or by the recursion any more and is made on demand, rv_build_inverse.)
+__global__ __launch_bounds__(TB) void k_phi(const sa_t *__restrict__ SA, int64_t n, sa_t *__restrict__ PHI) {
+    const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (k >= n) return;
+    PHI[SA[k]] = k > 0 ? SA[k - 1] : (sa_t)-1;
+}
+// PL[p] = PLCP[p] | (BWT byte of suffix p) << 32: the rank-order pass then fetches both with ONE random 8-byte gather
+// per rank instead of one for PLCP[SA[k]] and one for T[SA[k] - 1].
+__global__ __launch_bounds__(TB) void k_plcp(const uint8_t *__restrict__ T, const sa_t *__restrict__ PHI, u64 *__restrict__ PL, int64_t n, sa_t side_sep) {
     const int lane = threadIdx.x & 63;
     const int64_t p0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * PHI_K;      // (whole waves run past n together: no early return, ballots below)
     u32 h = 0;
 #pragma unroll 1
     for (int b = 0; b < PHI_K; b += PHI_B) {
-        int64_t r[PHI_B], q[PHI_B];
+        int64_t q[PHI_B];
 #pragma unroll
-        for (int j = 0; j < PHI_B; j++) { const int64_t p = p0 + b + j; r[j] = p < n ? (int64_t)SAi[p] : 0; }
-#pragma unroll
-        for (int j = 0; j < PHI_B; j++) q[j] = r[j] > 0 ? (int64_t)SA[r[j] - 1] : -1;
+        for (int j = 0; j < PHI_B; j++) { const int64_t p = p0 + b + j; q[j] = p < n ? (int64_t)PHI[p] : -1; }
 #pragma unroll
         for (int j = 0; j < PHI_B; j++) {
             const int64_t p = p0 + b + j;
@@ -503,20 +515,23 @@ __global__ __launch_bounds__(TB) void k_plcp(const uint8_t *__restrict__ T, cons
                 if (lane == l) h = hl;
                 todo &= todo - 1;
             }
-            if (p < n) PLCP[p] = h;
+            if (p < n) {
+                const u32 bw = (u32)(p > 0 ? T[p - 1] : (uint8_t)'$') | (p > (int64_t)side_sep ? RV_BWT_SIDE : 0u);
+                PL[p] = (u64)h | ((u64)bw << 32);
+            }
             h = h > 0 ? h - 1 : 0;
         }
     }
 }
-__global__ __launch_bounds__(TB) void k_lcp_gather(const uint8_t *__restrict__ T, const sa_t *__restrict__ SA, const u32 *__restrict__ PLCP,
-                                                   lcp_t *__restrict__ LCP, int64_t n, u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT, sa_t side_sep) {
+__global__ __launch_bounds__(TB) void k_lcp_gather(const sa_t *__restrict__ SA, const u64 *__restrict__ PL,
+                                                   lcp_t *__restrict__ LCP, int64_t n, u32 *__restrict__ maxlcp, uint8_t *__restrict__ BWT) {
     const int64_t k = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 h = 0;
     if (k < n) {
-        const sa_t p = SA[k];
-        h = PLCP[p];
+        const u64 v = PL[SA[k]];
+        h = (u32)v;
         LCP[k] = (lcp_t)h;
-        if (BWT) BWT[k] = (uint8_t)((p > 0 ? T[p - 1] : (uint8_t)'$') | (p > side_sep ? RV_BWT_SIDE : 0));
+        if (BWT) BWT[k] = (uint8_t)(v >> 32);
     }
     u32 m = h;
     for (int d = 32; d >= 1; d >>= 1) { u32 o = __shfl_down(m, d, 64); m = o > m ? o : m; }
@@ -564,19 +579,24 @@ int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uin
     return 0;
 }
 
-int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, const sa_t *SAi, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep) {
+int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep) {
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
-    if (!SAi || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
+    if (by_rank || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
         hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT, side_sep);
         RV_LAUNCH_CHECK();
         return 0;
     }
-    DBuf &plcp = ws.sa[6];                         // a u32 per position; the SA build is done with its scratch
-    RV_TRY(plcp.reserve((size_t)n * 4));
-    hipLaunchKernelGGL(k_plcp, dim3((unsigned)ceil_div(ceil_div(n, PHI_K), TB)), dim3(TB), 0, ws.stream, T, SA, SAi, plcp.as<u32>(), n);
+    // text order (Kasai's carry): PHI scatter -> PLCP (+ BWT byte) per position -> one gather per rank.  The SA build is done
+    // with its scratch: the two key buffers hold PHI and the packed PLCP.
+    DBuf &bphi = ws.sa[1], &bpl = ws.sa[0];
+    RV_TRY(bphi.reserve((size_t)n * sizeof(sa_t)));
+    RV_TRY(bpl.reserve((size_t)n * 8));
+    hipLaunchKernelGGL(k_phi, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, n, bphi.as<sa_t>());
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_lcp_gather, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, (const u32 *)plcp.as<u32>(), LCP, n, d_maxlcp, BWT, side_sep);
+    hipLaunchKernelGGL(k_plcp, dim3((unsigned)ceil_div(ceil_div(n, PHI_K), TB)), dim3(TB), 0, ws.stream, T, (const sa_t *)bphi.as<sa_t>(), bpl.as<u64>(), n, side_sep);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_lcp_gather, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, SA, (const u64 *)bpl.as<u64>(), LCP, n, d_maxlcp, BWT);
     RV_LAUNCH_CHECK();
     return 0;
 }
@@ -651,8 +671,16 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed);
     SA_HIP(hipGetLastError());
     SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
-    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, (const u32 *)grp, n, SA, ISA);
+    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA);
     SA_HIP(hipGetLastError());
+    bool isa_built = false;
+    auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)
+        if (isa_built) return 0;
+        hipLaunchKernelGGL(k_isa_from_groups, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, (const u32 *)grp, n, ISA);
+        RV_LAUNCH_CHECK();
+        isa_built = true;
+        return 0;
+    };
 
     // -- compaction of the non-unique suffixes (round 0: from the full arrays)
     int64_t ntile = ceil_div(n, CP_TILE);
@@ -710,8 +738,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             SA_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_medium_back, dim3(mb), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }
-        else
+        else {
+            SA_TRY(need_isa());
             hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
+        }
         SA_HIP(hipGetLastError());
         // members of larger groups: ordered sublist -> radix sort on (group rank, rank of suffix+h) -> back into the list
         {
@@ -723,6 +753,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             u32 mbig = 0;
             SA_TRY(rv_read_back(ws, &mbig, tile + nt, 4));
             if (mbig > 0) {
+                SA_TRY(need_isa());
                 u32 *Pb = bPb.as<u32>(), *Qb = bQb.as<u32>();
                 hipLaunchKernelGGL(k_flag_emit, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, (const u32 *)tile, (const u32 *)P, (const sav_t *)S,
                                    (const u32 *)G, n, h, (const u32 *)ISA, Pb, Sfree, Qb, kA);
@@ -746,6 +777,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_TRY(count_unsorted(head, m, &m2));
         if (m2 == 0) break;
         // new group ranks from the heads, ISA update
+        SA_TRY(need_isa());
         hipLaunchKernelGGL(k_seed, dim3(mb), dim3(TB), 0, q, (const uint8_t *)head, (const u32 *)P, m, seed);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));

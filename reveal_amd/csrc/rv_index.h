@@ -80,6 +80,7 @@ struct rv_index {
     int64_t n = 0, nT = 0;
     int rc = 0;
     bool constructed = false, main_arrays_freed = false;
+    bool sai_valid = false;            // dSAi holds the inverse of the main SA (made on demand: rv_need_sai)
     // ---- device state
     DBuf dT, dT0, dSA, dSAi, dLCP, dBWT, dNsep;   // dT0 = pristine text, dT = working copy (lower-cased by align)
     bool text_dirty = true;
@@ -107,6 +108,11 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
 
 // text, shared inverse and separators in HBM without an index (rv_api.hip); maxlcp = window size of bubble_sort
 int rv_text_only(rv_index *h, u32 maxlcp);
+
+// The inverse suffix array of the main index in HBM (interface.c:236-238).  Neither construct (LCP goes through PHI) nor the
+// untraced built-in recursion (the split writes the windows of the shared inverse that bubble_sort reads) needs it, so it is
+// made when somebody asks: the SAi getter, copy(), the detached-index steps, and align() with callbacks / tracing (rv_api.hip).
+int rv_need_sai(rv_index *h);
 
 // rv_align.hip
 void rv_align_free(rv_index *h);

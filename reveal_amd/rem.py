@@ -77,6 +77,30 @@ def bench_mumpicker(mums, idx, precomputed=False, minlength=0):
     return (best[0], [], [])
 
 
+def seeding_mumpicker(mums, idx, precomputed=False, minlength=0):
+    """bench_mumpicker that also seeds the children the way schemes.graphmumpicker does with its chain
+    (schemes.py:291-361: `return splitmum, skipleft, skipright`): of the full matches it was given, those lying in front of the
+    pick in every sample go to the leading child as `skipmums`, those behind it to the trailing child; a child that
+    received a non-empty list is not scanned (reveal.c:802, 830-837) and is called with precomputed=True and that list."""
+    r = bench_mumpicker(mums, idx, precomputed=precomputed, minlength=minlength)
+    if not r:
+        return ()
+    pick = r[0]
+    l = pick[0]
+    at = {so: p for so, p in pick[2]}
+    ns = idx.nsamples
+    left, right = [], []
+    for m in mums:
+        if m is pick or m[1] != ns or m[0] < max(minlength, 1):
+            continue
+        if all(so in at for so, _ in m[2]):
+            if all(p + m[0] <= at[so] for so, p in m[2]):
+                left.append(m)
+            elif all(p >= at[so] + l for so, p in m[2]):
+                right.append(m)
+    return (pick, left, right)
+
+
 def linear_graphalign(idx, mum):
     """graphalign(idx, mum) -> (leading, trailing, matching, rest, merged, newleft, newright)
     (reveal.c:937-999) for the linear interval model: every member lies in one

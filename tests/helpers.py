@@ -69,6 +69,12 @@ def golden():
         return json.load(f)["sets"]
 
 
+def golden_seeded():
+    """digests of the reference's real aligner() under rem.seeding_mumpicker (oracle/gen_golden.py `seeded`)"""
+    with open(os.path.join(GOLD, "vectors.json")) as f:
+        return json.load(f).get("seeded", {})
+
+
 def golden_inputs(rec):
     return [os.path.join(GOLD, x + ".fa.gz") if os.path.exists(os.path.join(GOLD, x + ".fa.gz")) else x for x in rec["inputs"]]
 
@@ -87,3 +93,53 @@ def trace_digests(tr):
                   int(r["sp_min"]), int(r["h_sa"]) & M64, int(r["h_lcp"]) & M64, int(r["h_mums"]) & M64) for r in tr)
     anchors = sorted((int(r["l"]), int(r["sp_min"]), int(r["mn"])) for r in tr if r["picked"])
     return sha_json(key), sha_json(anchors), len(anchors), sum(a[0] for a in anchors)
+
+
+# ---- callback tracing: the same wrapper drives the reference's own module (oracle/gen_golden.py) and reveal_amd's index
+GOLDEN64 = 0x9E3779B97F4A7C15
+
+
+def seqhash(vals):
+    """order-sensitive 64-bit digest of an integer sequence (same function as oracle/pin_oracle.py seqhash / ro_hash_step)"""
+    v = np.asarray(vals).astype(np.int64).astype(np.uint64)
+    with np.errstate(over="ignore"):
+        x = v + (np.arange(1, len(v) + 1, dtype=np.uint64) * np.uint64(GOLDEN64))
+        x ^= x >> np.uint64(30); x *= np.uint64(0xbf58476d1ce4e5b9)
+        x ^= x >> np.uint64(27); x *= np.uint64(0x94d049bb133111eb)
+        x ^= x >> np.uint64(31)
+        return int(x.sum(dtype=np.uint64))
+
+
+def flat_mums(mums):
+    out = []
+    for l, n, spd in mums:
+        out += [l, n]
+        for so, pos in spd:
+            out += [so, pos]
+    return out
+
+
+def traced_callbacks(mumpicker, graphalign, arrays=True):
+    """-> (mumpicker', graphalign', trace): one record per mumpicker call with what the callback could see of its sub-index"""
+    trace = []
+
+    def pick(mums, sub, precomputed=False, minlength=0):
+        nodes = sorted((int(b), int(e)) for b, e in sub.nodes)
+        rec = dict(depth=int(sub.depth), key=min(b for b, _ in nodes), n=int(sub.n), nsamples=int(sub.nsamples), nnodes=len(nodes),
+                   precomputed=1 if precomputed else 0, nmums=len(mums), h_mums=seqhash(flat_mums(mums)) if len(mums) else 0,
+                   h_sa=seqhash(sub.SA) if arrays else 0, h_lcp=seqhash(sub.LCP) if arrays else 0, picked=0, l=0, mn=0, sp_min=0)
+        trace.append(rec)
+        r = mumpicker(mums, sub, precomputed=precomputed, minlength=minlength)
+        if isinstance(r, tuple) and len(r) == 3:
+            m = r[0]
+            rec.update(picked=1, l=int(m[0]), mn=int(m[1]), sp_min=min(int(p) for _, p in m[2]))
+        return r
+    return pick, graphalign, trace
+
+
+def callback_trace_digest(trace):
+    key = sorted((r["depth"], r["key"], r["n"], r["nsamples"], r["nnodes"], r["precomputed"], r["nmums"], r["picked"], r["l"], r["mn"], r["sp_min"],
+                  r["h_sa"] & M64, r["h_lcp"] & M64, r["h_mums"] & M64) for r in trace)
+    anchors = sorted((r["l"], r["sp_min"], r["mn"]) for r in trace if r["picked"])
+    return dict(calls=len(trace), precomputed_calls=sum(r["precomputed"] for r in trace), anchors=len(anchors),
+                sha_trace=sha_json(key), sha_anchors=sha_json(anchors))

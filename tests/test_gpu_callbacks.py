@@ -110,6 +110,7 @@ def test_raising_callbacks_propagate_and_close_the_run():
     with pytest.raises(Boom, match="picker"):
         idx.align(bad_pick, rem.linear_graphalign, minl=20, minn=2)
     _still_usable(idx)
+    idx.construct()
     with pytest.raises(Boom, match="graphalign"):
         idx.align(rem.bench_mumpicker, bad_align, minl=20, minn=2)
     _still_usable(idx)

@@ -234,6 +234,17 @@ int rv_sx_split(rv_subindex *x, const int64_t *lead, int nlead, const int64_t *t
 /* extract, in place.  `intervals` is rewritten where construct(rc=1) makes the reference remap it (reveal.c:1411-1427). */
 int rv_sx_extract(rv_subindex *x, int64_t *intervals, int niv);
 
+/* ---- host side of the anchor picker -----------------------------------
+ * chain() of the reference's Python picker (reveal/schemes.py:20-105 with utils.gapcost, utils.py:162-183): the best-scoring
+ * collinear chain through m pre-selected matches over k paths, between the sentinels `left` and `right`.  Match i has length
+ * len[i], spans nmem[i] samples and starts at crd[i*k + j] on path j (path 0 = the reference's `ref` dimension); score of a
+ * match = wscore * len * nmem*(nmem-1)/2, penalty = wpen * gapcost(end of predecessor, start of match); model 0 = sumofpairs,
+ * 1 = star-avg, 2 = star-med.  Plain host code (the DP is O(m^2 k^2) on at most --maxmums matches).  out_idx / out_score
+ * (capacity m) receive the chain from left to right: input indices and the running scores.  Returns the chain length, < 0 on
+ * error.  Decision-for-decision identical to the reference's function, ties included (tests/golden/chain_vectors.json). */
+int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t *nmem, const int64_t *crd, const int64_t *left,
+                 const int64_t *right, int64_t wscore, int64_t wpen, int model, int64_t *out_idx, int64_t *out_score);
+
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,

@@ -95,6 +95,7 @@ SYMBOLS = {
     "rv_sx_fetch": (_I, [V, V, V, V, V, V]),
     "rv_sx_split": (_I, [V, V, _I, V, _I, V, _I, V, _I, V]),
     "rv_sx_extract": (_I, [V, V, _I]),
+    "rv_chain": (_L, [_L, _I, V, V, V, V, V, _L, _L, _I, V, V]),
     "rv_prof_enable": (_I, [V, _I]),
     "rv_prof_reset": (_I, [V]),
     "rv_prof_get": (_I, [V, _I, c_i64p, ctypes.POINTER(_D), ctypes.POINTER(_D)]),

@@ -1,0 +1,431 @@
+"""The alignment graph of `reveal rem` for Python 3 (reveal/rem.py:14-382, reveal/utils.py:304-677, 710-839).
+
+The reference keeps a networkx MultiDiGraph whose sequence nodes are intervals of the index text, plus an interval tree for
+"which node holds text position p".  Neither library is needed for what the recursion's callbacks do, so this module has
+its own small structure:
+
+  * a sequence node is the tuple (begin, end) of its text interval -- the very objects the index hands to and takes from the
+    callbacks (`idx.nodes`, the interval lists returned by graphalign); sentinels (start / end of a path or component) are str
+  * offsets[node] = {path id: offset of the node on that path}, aligned[node] = 0 / 1 (sentinels have no entry)
+  * succ[u][(v, ofrom, oto)] = set of path ids, pred[v][(u, ofrom, oto)] = the same set object
+  * nodes never overlap in the text and are only ever split, so position lookup is a bisect over the sorted node begins
+
+Functions follow the reference's semantics (cited at each one); the code is not a translation.
+"""
+import bisect
+import gzip
+import sys
+import uuid
+
+try:
+    from sortedcontainers import SortedList
+except ImportError:      # plain list + insort: same behaviour, O(n) inserts
+    class SortedList(list):
+        def add(self, x):
+            bisect.insort(self, x)
+
+        def bisect_right(self, x):
+            return bisect.bisect_right(self, x)
+
+
+class AlnGraph:
+    def __init__(self):
+        self.offsets = {}          # node -> {sid: offset}; insertion order = node order of the GFA writer
+        self.aligned = {}          # sequence nodes only
+        self.seq = {}              # sentinels / nodes that carry their own sequence ("" for merged start / end nodes)
+        self.succ, self.pred = {}, {}
+        self.paths, self.path2id, self.id2path, self.id2end = [], {}, {}, {}
+        self.startnodes, self.endnodes = [], []
+        self._begins = SortedList()
+        self._end_of = {}
+
+    # ---- nodes and edges -------------------------------------------------------------------
+    def add_node(self, node, offsets=None, aligned=None, seq=None):
+        self.offsets[node] = offsets if offsets is not None else {}
+        self.succ.setdefault(node, {})
+        self.pred.setdefault(node, {})
+        if aligned is not None:
+            self.aligned[node] = aligned
+        if seq is not None:
+            self.seq[node] = seq
+        if isinstance(node, tuple):
+            if node[0] not in self._end_of:
+                self._begins.add(node[0])
+            self._end_of[node[0]] = node[1]
+
+    def remove_node(self, node):
+        for (v, a, b) in list(self.succ[node]):
+            del self.pred[v][(node, a, b)]
+        for (u, a, b) in list(self.pred[node]):
+            del self.succ[u][(node, a, b)]
+        del self.succ[node], self.pred[node], self.offsets[node]
+        self.aligned.pop(node, None)
+        self.seq.pop(node, None)
+        if isinstance(node, tuple) and self._end_of.get(node[0]) == node[1]:
+            self._end_of[node[0]] = node[0]          # an empty interval: lookups fall through
+
+    def add_edge(self, u, v, paths, ofrom="+", oto="+"):
+        """one edge per (u, v, ofrom, oto); adding it again merges the path sets"""
+        key = (v, ofrom, oto)
+        if key in self.succ[u]:
+            self.succ[u][key] |= paths
+        else:
+            self.succ[u][key] = paths
+            self.pred[v][(u, ofrom, oto)] = paths
+
+    def has_node(self, node):
+        return node in self.offsets
+
+    def seq_nodes(self):
+        return [n for n in self.offsets if isinstance(n, tuple)]
+
+    def node_at(self, pos):
+        """the sequence node whose text interval holds pos (the reference's `t[pos]`, rem.py:334)"""
+        i = self._begins.bisect_right(pos) - 1
+        if i >= 0:
+            b = self._begins[i]
+            e = self._end_of[b]
+            if pos < e and (b, e) in self.offsets:
+                return (b, e)
+        raise KeyError("no node holds text position %d" % pos)
+
+    def _real(self, paths):
+        return any(not self.id2path[p].startswith("*") for p in paths)
+
+    # ---- callbacks' graph surgery ----------------------------------------------------------------
+    def breaknode(self, node, pos, l):
+        """rem.py:14-131: cut [pos, pos+l) out of `node`; -> (match node, set of the prefix / suffix nodes created)"""
+        mn = (pos, pos + l)
+        other = set()
+        if mn == node:
+            return node, other
+        att = self.offsets[node]
+        in_edges = [(u, a, b, p) for (u, a, b), p in self.pred[node].items()]
+        out_edges = [(v, a, b, p) for (v, a, b), p in self.succ[node].items()]
+        moffsets = {s: o + (pos - node[0]) for s, o in att.items()}
+        soffsets = {s: o + (pos + l - node[0]) for s, o in att.items()}
+        negpaths, pospaths = set(), set()
+        negstrand = False
+        if not in_edges and not out_edges:
+            pospaths = set(att)
+        else:
+            for u, a, b, p in in_edges:               # the strand a path enters the node on
+                if b == "-":
+                    negstrand = True
+                    negpaths |= p
+                else:
+                    pospaths |= p
+            for v, a, b, p in out_edges:
+                if a == "-":
+                    negstrand = True
+                    negpaths |= p
+                else:
+                    pospaths |= p
+        if pospaths & negpaths:
+            raise ValueError("paths traverse node %s on both strands: cannot break it" % (node,))
+        self.add_node(mn, offsets=moffsets, aligned=0)
+        pn = sn = mn
+        if node[0] != pos:
+            pn = (node[0], pos)
+            self.add_node(pn, offsets=dict(att), aligned=0)
+            self.add_edge(pn, mn, set(pospaths), "+", "+")
+            if negstrand:
+                self.add_edge(mn, pn, set(negpaths), "-", "-")
+            other.add(pn)
+        if node[1] != pos + l:
+            sn = (pos + l, node[1])
+            self.add_node(sn, offsets=soffsets, aligned=0)
+            self.add_edge(mn, sn, set(pospaths), "+", "+")
+            if negstrand:
+                self.add_edge(sn, mn, set(negpaths), "-", "-")
+            other.add(sn)
+        self.remove_node(node)
+        if mn[0] == node[0]:                          # (remove_node blanked the begin the match / prefix node shares with the old node)
+            self._end_of[mn[0]] = mn[1]
+        if pn is not mn:
+            self._end_of[pn[0]] = pn[1]
+        for u, a, b, p in in_edges:
+            self.add_edge(u, pn if b == "+" else sn, p, a, b)
+        for v, a, b, p in out_edges:
+            self.add_edge(sn if a == "+" else pn, v, p, a, b)
+        return mn, other
+
+    def mergenodes(self, mns):
+        """rem.py:133-200: the first node absorbs the others (offsets united, edges moved, equal edges merge their paths)"""
+        ref = mns[0]
+        merged = {}
+        for node in mns:
+            merged.update(self.offsets[node])
+        self.offsets[ref] = merged
+        self.aligned[ref] = 1
+        for mn in mns[1:]:
+            for (u, a, b), p in list(self.pred[mn].items()):
+                self.add_edge(u, ref, p, a, b)
+            for (v, a, b), p in list(self.succ[mn].items()):
+                self.add_edge(ref, v, p, a, b)
+            self.remove_node(mn)
+        return ref
+
+    def _bfs(self, source, reverse=False, ignore=()):
+        """rem.py:228-258: walk from `source` over edges carried by at least one real (non-'*') path; unaligned nodes are
+        walked through (kind 0), aligned nodes stop the walk (kind 1) unless listed in `ignore`, sentinels stop it (kind 2)"""
+        adj = self.pred if reverse else self.succ
+        visited = {source}
+        queue = [source]
+        qi = 0
+        while qi < len(queue):
+            parent = queue[qi]
+            qi += 1
+            seen_here = set()
+            for (child, a, b), p in adj[parent].items():
+                if child in visited or child in seen_here or not self._real(p):
+                    continue
+                seen_here.add(child)
+                visited.add(child)
+                if child not in self.aligned:
+                    yield child, 2
+                elif self.aligned[child] == 0 or child in ignore:
+                    queue.append(child)
+                    yield child, 0
+                else:
+                    yield child, 1
+
+    def segmentgraph(self, node, nodes):
+        """rem.py:260-316: of the sub-index' intervals `nodes`, those behind the merged node (trailing: reachable forward
+        through unaligned nodes, and -- when the walk ends at several places -- also reachable backward from each of them),
+        those in front of it (leading, mirrored), and the rest"""
+        nodes = set(nodes)
+
+        def side(reverse):
+            walk, endpoints = set(), set()
+            for c, t in self._bfs(node, reverse=reverse):
+                if t == 0:
+                    walk.add(c)
+                else:
+                    endpoints.add(c)
+            if len(endpoints) > 1:
+                back = set()
+                for ep in endpoints:
+                    for c, t in self._bfs(ep, reverse=not reverse, ignore=endpoints):
+                        if t == 0:
+                            back.add(c)
+                walk &= back
+            return {c for c in walk if isinstance(c, tuple)} & nodes
+        trailing = side(False)
+        leading = side(True)
+        return leading, trailing, nodes - (leading | trailing)
+
+    def prune_nodes(self, T):
+        """rem.py:384-447: sibling nodes with identical sequence that hang on one parent (or one child) and have no other
+        parent (child) are merged, until nothing changes"""
+        def seq_of(n):
+            return self.seq[n] if n in self.seq else (T[n[0]:n[1]] if isinstance(n, tuple) else None)
+        converged = False
+        while not converged:
+            converged = True
+            for node in list(self.offsets):
+                if node not in self.offsets:
+                    continue
+                for adj, back in ((self.succ, self.pred), (self.pred, self.succ)):
+                    neis = [v for (v, a, b) in adj[node] if a == "+" and b == "+"]
+                    groups = {}
+                    for nei in neis:
+                        s = seq_of(nei)
+                        if s is None:
+                            continue
+                        groups.setdefault(s, []).append(nei)
+                    for group in groups.values():
+                        if len(group) > 1 and all(sum(1 for (u, a, b) in back[v] if a == "+" and b == "+") <= 1 for v in group):
+                            self.mergenodes(list(group))
+                            converged = False
+
+    # ---- invariants used by the tests ----------------------------------------------------------------
+    def spell(self, sample, T):
+        """the sequence a path spells: walk its edges from its start sentinel (what `reveal extract` prints, test15)"""
+        sid = self.path2id[sample]
+        out = []
+        for start in self.startnodes:
+            if start in self.offsets and sid in self.offsets[start]:
+                node = start
+                while True:
+                    nxt = [(v, b) for (v, a, b), p in self.succ[node].items() if sid in p]
+                    if len(nxt) != 1:
+                        if len(nxt) > 1:
+                            raise ValueError("path %s is ambiguous at %s" % (sample, node))
+                        break
+                    node, strand = nxt[0]
+                    if isinstance(node, tuple):
+                        if strand != "+":
+                            raise NotImplementedError("reverse-strand traversal")
+                        out.append(T[node[0]:node[1]])
+                    elif node in self.endnodes:
+                        break
+                break
+        return "".join(out).upper()
+
+
+# ---- readers (reveal/utils.py:304-375, 377-677) -------------------------------------------------------
+
+def _new_path(G, name, length=None):
+    if name in G.path2id:
+        raise ValueError("the graph already contains a path named %r" % name)
+    sid = len(G.path2id)
+    G.paths.append(name)
+    G.path2id[name] = sid
+    G.id2path[sid] = name
+    if length is not None:
+        G.id2end[sid] = length
+    return sid
+
+
+def read_fasta(fasta, index, G, contigs=True, toupper=True):
+    """utils.py:304-375: one sample per file (or per sequence with contigs=False), one node + start / end sentinel per sequence"""
+    from .rem import fasta_reader
+    import os
+    if contigs:
+        index.addsample(os.path.basename(fasta))
+    for name, seq in fasta_reader(fasta, toupper=toupper):
+        if not contigs:
+            index.addsample(name)
+        name = name.replace(":", "").replace(";", "")
+        sid = _new_path(G, name, len(seq))
+        intv = tuple(index.addsequence(seq))
+        start, end = uuid.uuid4().hex, uuid.uuid4().hex
+        G.add_node(start, offsets={sid: 0})
+        G.startnodes.append(start)
+        G.add_node(intv, offsets={sid: 0}, aligned=0)
+        G.add_node(end, offsets={sid: len(seq)})
+        G.endnodes.append(end)
+        G.add_edge(start, intv, {sid})
+        G.add_edge(intv, end, {sid})
+
+
+def read_gfa(gfafile, index, G):
+    """utils.py:377-677 (the defaults `reveal rem` uses for graph inputs: every S-line becomes one '$'-terminated sequence of
+    the current sample; P-lines give the node offsets; untraversed nodes / edges go; per connected component the start
+    sentinels of its paths are merged into one, likewise the end sentinels)"""
+    fopen = gzip.open if gfafile.endswith(".gz") else open
+    nmap, edges, plines = {}, [], []
+    with fopen(gfafile, "rt") as f:
+        for line in f:
+            if line.startswith("S"):
+                s = line.rstrip("\n").split("\t")
+                seq = s[2] if len(s) > 2 else ""
+                intv = tuple(index.addsequence(seq.upper()))
+                G.add_node(intv, offsets={}, aligned=0)
+                nmap[s[1]] = intv
+            elif line.startswith("L"):
+                edges.append(line)
+            elif line.startswith("P"):
+                plines.append(line)
+    for line in edges:
+        e = line.rstrip("\n").split("\t")
+        G.add_edge(nmap[e[1]], nmap[e[3]], set(), e[2], e[4])
+    if not plines:
+        raise ValueError("no paths defined in %s" % gfafile)
+    starts, ends = set(), set()
+    for line in plines:
+        cols = line.rstrip("\n").split("\t")
+        sample = cols[1]
+        sid = _new_path(G, sample)
+        o = 0
+        path = [(x[:-1], x[-1:]) for x in cols[2].split(",")] if len(cols) >= 3 and cols[2] else []
+        prev = None
+        for nid, strand in path:
+            node = nmap[nid]
+            G.offsets[node][sid] = o
+            o += node[1] - node[0]
+            if prev is not None:
+                key = (node, prev[1], strand)
+                if key not in G.succ[prev[0]]:
+                    raise ValueError("path %s steps %s -> %s but the graph has no such link" % (sample, prev[0], node))
+                G.succ[prev[0]][key].add(sid)
+            prev = (node, strand)
+        start, end = uuid.uuid4().hex, uuid.uuid4().hex
+        G.add_node(start, offsets={sid: 0})
+        G.add_node(end, offsets={sid: o})
+        if path:
+            G.add_edge(start, nmap[path[0][0]], {sid}, "+", path[0][1])
+            G.add_edge(nmap[path[-1][0]], end, {sid}, path[-1][1], "+")
+        starts.add(start); ends.add(end)
+        G.id2end[sid] = o
+    for u in list(G.succ):                              # untraversed edges, then untraversed nodes
+        for key, p in list(G.succ[u].items()):
+            if not p:
+                del G.succ[u][key]
+                del G.pred[key[0]][(u, key[1], key[2])]
+    mine = set(nmap.values())
+    for n in [n for n in mine if not G.offsets[n]]:
+        G.remove_node(n)
+        mine.discard(n)
+    # weakly connected components of what this file added; one start and one end sentinel per component
+    todo = mine | starts | ends
+    while todo:
+        comp, stack = set(), [next(iter(todo))]
+        while stack:
+            x = stack.pop()
+            if x in comp:
+                continue
+            comp.add(x)
+            stack.extend(v for (v, a, b) in G.succ[x] if v not in comp)
+            stack.extend(u for (u, a, b) in G.pred[x] if u not in comp)
+        todo -= comp
+        for group, register, forward in ((comp & ends, G.endnodes, False), (comp & starts, G.startnodes, True)):
+            if not group:
+                continue
+            sentinel = uuid.uuid4().hex
+            G.add_node(sentinel, offsets={}, seq="")
+            register.append(sentinel)
+            for old in group:
+                G.offsets[sentinel].update(G.offsets[old])
+                if forward:
+                    for (v, a, b), p in list(G.succ[old].items()):
+                        G.add_edge(sentinel, v, p, a, b)
+                else:
+                    for (u, a, b), p in list(G.pred[old].items()):
+                        G.add_edge(u, sentinel, p, a, b)
+                G.remove_node(old)
+
+
+# ---- writer (reveal/utils.py:710-839 after rem.align_cmd's seq2node, utils.py:1036-1049) ----------------
+
+def write_gfa(G, T, outputfile, cmdline=None):
+    """GFA1: S per sequence node (ids 1.. in node order; aligned nodes upper-cased as seq2node does), L per edge between
+    sequence nodes, P per path (walked from the start sentinels).  -> the file name written"""
+    if not outputfile.endswith(".gfa") and not outputfile.endswith(".gfa.gz"):
+        outputfile += ".gfa.gz"
+    fopen = gzip.open if outputfile.endswith(".gz") else open
+    nodes = G.seq_nodes()
+    ident = {n: i + 1 for i, n in enumerate(nodes)}
+    with fopen(outputfile, "wt") as f:
+        f.write("H\tVN:Z:1.0\tCL:Z:%s\n" % (cmdline if cmdline is not None else " ".join(sys.argv)))
+        for n in nodes:
+            s = G.seq[n] if n in G.seq else T[n[0]:n[1]]
+            if G.aligned.get(n, 0) > 0:
+                s = s.upper()
+            f.write("S\t%d\t%s\n" % (ident[n], s))
+            for (v, a, b), p in G.succ[n].items():
+                if isinstance(v, tuple):
+                    f.write("L\t%d\t%s\t%d\t%s\t0M\n" % (ident[n], a, ident[v], b))
+        endset = set(G.endnodes)
+        for sample, sid in G.path2id.items():
+            path, cigar = [], []
+            for start in G.startnodes:
+                if start not in G.offsets or sid not in G.offsets[start]:
+                    continue
+                node = start
+                while True:
+                    out = [(v, b) for (v, a, b), p in G.succ[node].items() if sid in p]
+                    if len(out) != 1:
+                        break
+                    v, strand = out[0]
+                    if v in endset:
+                        break
+                    if isinstance(v, tuple):
+                        path.append("%d%s" % (ident[v], strand))
+                        if isinstance(node, tuple):
+                            cigar.append("0M")
+                    node = v
+                break
+            f.write("P\t%s\t%s\t%s\n" % (sample, ",".join(path), ",".join(cigar)))
+    return outputfile

@@ -1,11 +1,16 @@
-"""Python-3 harness around the `index` type: the call protocol of the
-reference's `reveal rem` driver (reveal/rem.py:511-611 align_genomes,
-reveal/utils.py:304-375 read_fasta) plus the deterministic benchmark callbacks
-of SURVEY.md 8(d).  The reference's graph layer (networkx graph, interval tree,
-chaining picker) is out of scope; this module feeds the index the way the
-reference does, supplies callbacks with the reference's signatures, and -- for the
-linear interval model of those callbacks -- writes the resulting graph as GFA1
-(reveal_amd/gfa.py; `python -m reveal_amd.rem a.fa b.fa -o out.gfa`).
+"""`reveal rem` for Python 3 around the `index` type (reveal/rem.py, reveal/utils.py, reveal/schemes.py).
+
+Two drivers share the index protocol of rem.py:511-611 (`addsample` per file, `addsequence` per contig / per graph
+node, `construct`, `align` with two callbacks):
+
+  * `graph_rem(inputs, output)` -- the reference's own pair of callbacks: `GraphAligner.graphalign` (rem.py:318-382:
+    break the nodes under the match, merge them, segment the graph into leading / trailing / parallel intervals) and
+    `schemes.GraphPicker.graphmumpicker` (schemes.py:197-361: filter, trim, map to path offsets, chain -- the DP in C++
+    behind the ABI -- split on the largest match, seed the children).  Inputs are FASTA files and / or GFA graphs written
+    by earlier runs (one sample per file, one '$'-terminated sequence per S-line: utils.py:377-677), the output is GFA1
+    (utils.py:710-839) -- what `reveal align --order=sequential` chains level by level (reveal_amd/align.py).
+  * `rem(inputs, output)` -- the deterministic benchmark callbacks of SURVEY.md 8(d) (longest full match, linear interval
+    model), which the library also has built in (`index.align_builtin`): what bench.py times and the parity tests trace.
 """
 import gzip
 import os
@@ -128,6 +133,81 @@ def linear_graphalign(idx, mum):
     return sorted(lead), sorted(trail), sorted(match), sorted(rest), merged, merged, merged
 
 
+class GraphAligner:
+    """graphalign bound to an alignment graph (reveal_amd/alngraph.py); rem.py:318-382"""
+
+    def __init__(self, graph):
+        self.G = graph
+        self.calls = 0
+
+    def graphalign(self, index, mum):
+        G = self.G
+        self.calls += 1
+        l, n, spd = mum
+        nodes = index.nodes                        # the set handed out by an earlier call: edited in place, as in the reference
+        mns, matching = [], set()
+        for _, pos in spd:
+            matching.add((pos, pos + l))
+            old = G.node_at(pos)
+            mn, other = G.breaknode(old, pos, l)
+            mns.append(mn)
+            nodes.remove(old)
+            nodes.update(other)
+        mn = G.mergenodes(mns)
+        msamples = set(G.offsets[mn])
+        leading, trailing, rest = G.segmentgraph(mn, nodes)
+        newleft = newright = mn
+        if any(not set(G.offsets[iv]) <= msamples for iv in leading):      # no clean dissection of all paths on the left
+            newright = index.rightnode
+        if any(not set(G.offsets[iv]) <= msamples for iv in trailing):
+            newleft = index.leftnode
+        return leading, trailing, matching, rest, mn, newleft, newright
+
+
+def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None):
+    """rem.py:511-611 align_genomes: index + graph from FASTA / GFA inputs, construct, align with the graph callbacks.
+    preselect: let the library hand the picker only what it keeps anyway (index.preselect(maxmums): the matches spanning
+    every sample of the sub-index, capped at --maxmums) -- not valid with --trim, which looks at the others
+    indexmod: the module that provides `index` (default reveal_amd.reveallib / reveallib64; tests pass the reference's own module)
+    -> (graph, index, picker, aligner)"""
+    from . import alngraph, schemes
+    if indexmod is None:
+        from . import reveallib, reveallib64
+        indexmod = reveallib64 if sa64 else reveallib
+    idx = indexmod.index()
+    G = alngraph.AlnGraph()
+    for f in inputfiles:
+        if f.endswith(".gfa") or f.endswith(".gfa.gz"):
+            idx.addsample(os.path.basename(f))
+            alngraph.read_gfa(f, idx, G)
+        else:
+            alngraph.read_fasta(f, idx, G, contigs=contigs, toupper=toupper)
+    if len(idx.samples) <= 1:
+        raise ValueError("Specify at least 2 targets to construct alignment. In case of multi-fasta, consider the --nocontigs flag.")
+    args = args or schemes.PickerArgs()
+    picker, aligner = schemes.GraphPicker(G, args), GraphAligner(G)
+    idx.construct()
+    if preselect and not args.trim and args.maxmums and hasattr(idx, "preselect"):
+        idx.preselect(args.maxmums)
+    idx.align(picker.graphmumpicker, aligner.graphalign, threads=0, wpen=args.wpen, wscore=args.wscore, minl=minlength, minn=minn)
+    return G, idx, picker, aligner
+
+
+def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None):
+    """`reveal rem inputs -o output` (rem.py:449-509 align_cmd): align, merge equal siblings when more than two paths took part,
+    write GFA1.  -> (graph, index, file name or None)"""
+    from . import alngraph
+    G, idx, picker, aligner = graph_align_genomes(inputfiles, sa64=sa64, minlength=minlength, minn=minn, contigs=contigs, toupper=toupper,
+                                                  args=args, preselect=preselect, indexmod=indexmod)
+    T = idx.T
+    if len(G.paths) > 2:
+        G.prune_nodes(T)
+    fn = None
+    if output:
+        fn = alngraph.write_gfa(G, T, output, cmdline="reveal_amd.rem " + " ".join(inputfiles))
+    return G, idx, fn
+
+
 def align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, sa="", lcp="", cache=0,
                   mumpicker=bench_mumpicker, graphalign=linear_graphalign):
     """reveal/rem.py:511-611: build the index from FASTA files, construct, align.
@@ -193,9 +273,24 @@ def main(argv=None):
     ap.add_argument("-n", dest="minn", type=int, default=2)
     ap.add_argument("--64", dest="sa64", action="store_true")
     ap.add_argument("--nocontigs", dest="contigs", action="store_false")
+    ap.add_argument("--bench-callbacks", action="store_true", help="the deterministic benchmark callbacks (FASTA inputs only) instead of the reference's graph callbacks")
+    ap.add_argument("--wp", dest="wpen", type=int, default=1)
+    ap.add_argument("--ws", dest="wscore", type=int, default=1)
+    ap.add_argument("--seedsize", type=int, default=10000)
+    ap.add_argument("--maxmums", type=int, default=1000)
+    ap.add_argument("--gcmodel", choices=["sumofpairs", "star-avg", "star-med"], default="sumofpairs")
+    ap.add_argument("--notrim", dest="trim", action="store_false")
+    ap.add_argument("--maxbubblesize", dest="maxsize", type=int, default=None)
+    ap.add_argument("-p", dest="pcutoff", type=float, default=1e-8)
     a = ap.parse_args(argv)
-    idx, (segments, links, paths), fn = rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs)
-    print("%s: %d segments, %d links, %d paths" % (fn, len(segments), len(links), len(paths)))
+    if a.bench_callbacks:
+        idx, (segments, links, paths), fn = rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs)
+        print("%s: %d segments, %d links, %d paths" % (fn, len(segments), len(links), len(paths)))
+        return
+    from . import schemes
+    pa = schemes.PickerArgs(wscore=a.wscore, wpen=a.wpen, maxmums=a.maxmums, seedsize=a.seedsize, gcmodel=a.gcmodel, trim=a.trim, maxsize=a.maxsize, pcutoff=a.pcutoff)
+    G, idx, fn = graph_rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs, args=pa)
+    print("%s: %d nodes, %d paths" % (fn, len(G.seq_nodes()), len(G.paths)))
 
 
 if __name__ == "__main__":

@@ -1,0 +1,127 @@
+"""The Python-3 `reveal rem` graph driver (reveal_amd/rem.py graph_rem, alngraph.py, schemes.py, align.py) on the CPU.
+
+The graph layer is host code; what it needs from an index it gets through the reference's own callback protocol, so in the
+build container it can be driven by the REFERENCE's index -- its C sources built as the CPython module they define
+(oracle/_ref/reveallib.so, `make -C oracle refmod`), real aligner() and all.  Without that module (no /root/reference at
+build time) the index-driven tests are skipped; the graph-surgery unit tests and the plan need nothing."""
+import os
+import sys
+
+import pytest
+
+import graphrem_cases as C
+from reveal_amd import align, alngraph
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+
+@pytest.fixture(scope="module")
+def refmod():
+    import pin_oracle as P
+    mod = P.load_refmod(False)
+    if mod is None:
+        pytest.skip("oracle/_ref/reveallib.so not built (make -C oracle refmod needs /root/reference)")
+    return mod
+
+
+def test_config1_figures_with_the_reference_index(tmp_path, refmod):
+    C.config1(tmp_path, refmod)
+
+
+def test_hierarchical_plan_with_the_reference_index(tmp_path, refmod):
+    C.hierarchical(tmp_path, refmod)
+
+
+def test_multi_and_multicontig_with_the_reference_index(tmp_path, refmod):
+    C.multi_fasta(tmp_path, refmod)
+
+
+def test_sequential_plan_is_align_py():
+    """reveal/align.py:30-54"""
+    plan = align.sequential_plan(["g%d.fa" % i for i in range(100)], 5, output="out")
+    assert [len(jobs) for jobs in plan] == [20, 4, 1]                       # BASELINE config 5
+    assert all(len(i) == 5 for i, _ in plan[0]) and all(len(i) == 5 for i, _ in plan[1]) and len(plan[2][0][0]) == 4
+    assert plan[2][0][1] == "out.gfa"
+    assert [len(j) for j in align.sequential_plan(list("abcdefg"), 2)] == [3, 2, 1]
+    p = align.sequential_plan(list("abcdefg"), 2)
+    assert p[1][0][0][0] == "g"                                               # the left-over input leads the next level
+    assert [len(j) for j in align.sequential_plan(list("abcdef"), 2)] == [3, 1, 1]
+    assert [len(j) for j in align.sequential_plan(list("abc"), 5)] == [1]
+
+
+def _two_paths():
+    """two paths over one node each: a = [0,100), b = [101,201)"""
+    G = alngraph.AlnGraph()
+    for sid, (name, iv) in enumerate((("a", (0, 100)), ("b", (101, 201)))):
+        G.paths.append(name); G.path2id[name] = sid; G.id2path[sid] = name; G.id2end[sid] = 100
+        s, e = "s%d" % sid, "e%d" % sid
+        G.add_node(s, offsets={sid: 0}); G.startnodes.append(s)
+        G.add_node(iv, offsets={sid: 0}, aligned=0)
+        G.add_node(e, offsets={sid: 100}); G.endnodes.append(e)
+        G.add_edge(s, iv, {sid}); G.add_edge(iv, e, {sid})
+    return G
+
+
+def test_breaknode_mergenodes_segmentgraph():
+    """rem.py:14-131, 133-200, 260-316 on a graph small enough to check by eye"""
+    G = _two_paths()
+    assert G.node_at(0) == (0, 100) and G.node_at(150) == (101, 201)
+    with pytest.raises(KeyError):
+        G.node_at(100)                                                         # the '$' belongs to nobody
+    m1, o1 = G.breaknode((0, 100), 40, 20)
+    assert m1 == (40, 60) and o1 == {(0, 40), (60, 100)}
+    assert G.offsets[(40, 60)] == {0: 40} and G.offsets[(60, 100)] == {0: 60} and G.offsets[(0, 40)] == {0: 0}
+    assert G.node_at(39) == (0, 40) and G.node_at(40) == (40, 60) and G.node_at(99) == (60, 100)
+    m2, o2 = G.breaknode((101, 201), 131, 20)
+    assert m2 == (131, 151) and o2 == {(101, 131), (151, 201)}
+    mn = G.mergenodes([m1, m2])
+    assert mn == (40, 60) and G.aligned[mn] == 1 and G.offsets[mn] == {0: 40, 1: 30}
+    assert not G.has_node((131, 151))
+    assert set(v for (v, a, b) in G.succ[mn]) == {(60, 100), (151, 201)} and set(u for (u, a, b) in G.pred[mn]) == {(0, 40), (101, 131)}
+    nodes = {(0, 40), (60, 100), (101, 131), (151, 201)}
+    lead, trail, rest = G.segmentgraph(mn, nodes)
+    assert lead == {(0, 40), (101, 131)} and trail == {(60, 100), (151, 201)} and rest == set()
+    # a node that is not breakable: the whole node is the match
+    m3, o3 = G.breaknode((0, 40), 0, 40)
+    assert m3 == (0, 40) and o3 == set()
+    # prefix-only / suffix-only cuts
+    m4, o4 = G.breaknode((60, 100), 60, 10)
+    assert m4 == (60, 70) and o4 == {(70, 100)} and G.node_at(60) == (60, 70) and G.node_at(70) == (70, 100)
+    m5, o5 = G.breaknode((151, 201), 191, 10)
+    assert m5 == (191, 201) and o5 == {(151, 191)}
+    # paths still walk through everything
+    T = "A" * 40 + "G" * 20 + "A" * 40 + "$" + "C" * 30 + "G" * 20 + "C" * 50 + "$"      # the merged stretch is the same 20 bases on both paths
+    assert G.spell("a", T) == T[0:100] and G.spell("b", T) == T[101:201]
+
+
+def test_segmentgraph_parallel_rest():
+    """a third path that does not take part in the match: its node is neither in front nor behind -> rest"""
+    G = _two_paths()
+    G.paths.append("c"); G.path2id["c"] = 2; G.id2path[2] = "c"; G.id2end[2] = 50
+    G.add_node("s2", offsets={2: 0}); G.startnodes.append("s2")
+    G.add_node((202, 252), offsets={2: 0}, aligned=0)
+    G.add_node("e2", offsets={2: 50}); G.endnodes.append("e2")
+    G.add_edge("s2", (202, 252), {2}); G.add_edge((202, 252), "e2", {2})
+    m1, _ = G.breaknode((0, 100), 10, 30)
+    m2, _ = G.breaknode((101, 201), 111, 30)
+    mn = G.mergenodes([m1, m2])
+    nodes = {(0, 10), (40, 100), (101, 111), (141, 201), (202, 252)}
+    lead, trail, rest = G.segmentgraph(mn, nodes)
+    assert lead == {(0, 10), (101, 111)} and trail == {(40, 100), (141, 201)} and rest == {(202, 252)}
+
+
+def test_gfa_round_trip_without_an_index(tmp_path):
+    G = _two_paths()
+    m1, _ = G.breaknode((0, 100), 40, 20)
+    m2, _ = G.breaknode((101, 201), 141, 20)
+    G.mergenodes([m1, m2])
+    T = "ACGT" * 10 + "g" * 20 + "TTGA" * 10 + "$" + "CCAT" * 10 + "g" * 20 + "AAAC" * 10 + "$"
+    fn = alngraph.write_gfa(G, T, str(tmp_path / "x.gfa"), cmdline="test")
+    lines = open(fn).read().splitlines()
+    assert lines[0] == "H\tVN:Z:1.0\tCL:Z:test"
+    assert sum(1 for l in lines if l.startswith("S")) == 5 and sum(1 for l in lines if l.startswith("L")) == 4
+    assert "S\t%d\t%s" % (1 + G.seq_nodes().index((40, 60)), "G" * 20) in lines            # aligned nodes are written upper case
+    spelled, G2 = C.spelled_by_file(fn)
+    assert spelled == {"a": T[0:100].upper(), "b": T[101:201].upper()}
+    assert len(G2.startnodes) == 1 and len(G2.endnodes) == 1                                   # one component: sentinels merged

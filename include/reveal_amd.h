@@ -174,6 +174,9 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *st);
 /* returns the frontier size (0: the run finished before reaching stop_subs and has been collected), < 0 on error */
 int rv_align_builtin_until(rv_index *h, int minl, int minn, int stop_subs, rv_align_stats *st);
 int rv_align_builtin_resume(rv_index *h, rv_align_stats *st);
+/* a run stopped by rv_align_builtin_until goes on (at least one more level) until its frontier holds >= stop_subs sub-indices;
+ * returns the new frontier size, 0 when the run finished on the way (collected, as rv_align_builtin_until does) */
+int rv_align_builtin_continue(rv_index *h, int stop_subs, rv_align_stats *st);
 /* out[0..3] = sub-indices, ranks, intervals of the frontier, level */
 int rv_frontier_counts(rv_index *h, int64_t *out);
 /* meta: 6 per sub-index (offset, n, depth, nsamples, kind, parent); node_first: nsubs+1; nodes: (begin,end) pairs */

@@ -516,6 +516,17 @@ def make_index_type(sa64, error):
             self._pending = r > 0
             return r
 
+        def align_builtin_continue(self, stop_subs):
+            """widen the frontier of a run stopped by align_builtin_until: at least one more level, until it holds >= stop_subs
+            sub-indices.  -> new frontier size (0: finished on the way)"""
+            if not getattr(self, "_pending", False):
+                return 0
+            r = self._dll.rv_align_builtin_continue(self._h, int(stop_subs), ctypes.byref(self._st))
+            if r < 0:
+                self._fail()
+            self._pending = r > 0
+            return r
+
         def frontier(self):
             """-> dict(level, m, meta[nsubs,6] = (offset, n, depth, nsamples, kind, parent), node_first[nsubs+1], nodes[nnodes,2])"""
             c = np.zeros(4, dtype=np.int64)

@@ -73,6 +73,7 @@ SYMBOLS = {
     "rv_align_builtin": (_I, [V, _I, _I, ctypes.POINTER(RvAlignStats)]),
     "rv_align_builtin_until": (_I, [V, _I, _I, _I, ctypes.POINTER(RvAlignStats)]),
     "rv_align_builtin_resume": (_I, [V, ctypes.POINTER(RvAlignStats)]),
+    "rv_align_builtin_continue": (_I, [V, _I, ctypes.POINTER(RvAlignStats)]),
     "rv_frontier_counts": (_I, [V, V]),
     "rv_frontier_export": (_I, [V, V, V, V]),
     "rv_frontier_pack": (_L, [V, V, _I, V, V, V, _I]),

@@ -217,27 +217,44 @@ class AlnGraph:
 
     def prune_nodes(self, T):
         """rem.py:384-447: sibling nodes with identical sequence that hang on one parent (or one child) and have no other
-        parent (child) are merged, until nothing changes"""
+        parent (child) are merged, until nothing changes.  The reference rescans every node of the graph after each pass that
+        merged something -- merges cascade one step per pass along a region, so a graph of 2*10^5 nodes took minutes -- here a
+        merge puts the nodes whose neighbourhood it changed back on a work list; full passes repeat until one merges nothing,
+        so the result is the same fixpoint."""
+        from collections import deque
+
         def seq_of(n):
             return self.seq[n] if n in self.seq else (T[n[0]:n[1]] if isinstance(n, tuple) else None)
-        converged = False
-        while not converged:
-            converged = True
-            for node in list(self.offsets):
+        while True:
+            merged_any = False
+            queue = deque(self.offsets)
+            queued = set(queue)
+            while queue:
+                node = queue.popleft()
+                queued.discard(node)
                 if node not in self.offsets:
                     continue
                 for adj, back in ((self.succ, self.pred), (self.pred, self.succ)):
                     neis = [v for (v, a, b) in adj[node] if a == "+" and b == "+"]
+                    if len(neis) < 2:
+                        continue
                     groups = {}
                     for nei in neis:
-                        s = seq_of(nei)
-                        if s is None:
+                        sq = seq_of(nei)
+                        if sq is None:
                             continue
-                        groups.setdefault(s, []).append(nei)
+                        groups.setdefault(sq, []).append(nei)
                     for group in groups.values():
                         if len(group) > 1 and all(sum(1 for (u, a, b) in back[v] if a == "+" and b == "+") <= 1 for v in group):
-                            self.mergenodes(list(group))
-                            converged = False
+                            ref = self.mergenodes(list(group))
+                            merged_any = True
+                            again = [node, ref] + [v for (v, a, b) in self.succ[ref]] + [u for (u, a, b) in self.pred[ref]]
+                            for x in again:
+                                if x not in queued and x in self.offsets:
+                                    queue.append(x)
+                                    queued.add(x)
+            if not merged_any:
+                break
 
     # ---- invariants used by the tests ----------------------------------------------------------------
     def spell(self, sample, T):

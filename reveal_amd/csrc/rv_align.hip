@@ -1456,6 +1456,21 @@ int rv_align_builtin_until(rv_index *h, int minl, int minn, int stop_subs, rv_al
     return a->lv.size();
 }
 
+/* a run stopped by rv_align_builtin_until goes on until its frontier holds at least stop_subs sub-indices: the owner of a divided
+ * alignment widens the frontier while its largest sub-index is still too large a share for one device (reveal_amd/shard.py) */
+int rv_align_builtin_continue(rv_index *h, int stop_subs, rv_align_stats *out) {
+    RV_TRY(need_align(h));
+    if (!h->al->running) { rv_set_error("no built-in run in progress (rv_align_builtin_until / rv_frontier_import)"); return -1; }
+    if (stop_subs < 1) { rv_set_error("rv_align_builtin_continue: stop_subs must be positive"); return -1; }
+    RV_HIP(hipSetDevice(h->device));
+    Align *a = h->al;
+    // (builtin_levels stops before a level when the frontier is already wide enough: ask for one sub-index more than there is)
+    RV_TRY(builtin_levels(h, std::max(stop_subs, a->lv.size() + 1)));
+    if (a->lv.size() == 0) { RV_TRY(builtin_finish(h, out)); return 0; }
+    if (out) *out = a->st;
+    return a->lv.size();
+}
+
 int rv_align_builtin_resume(rv_index *h, rv_align_stats *out) {
     RV_TRY(need_align(h));
     if (!h->al->running) { rv_set_error("no built-in run in progress (rv_align_builtin_until / rv_frontier_import)"); return -1; }

@@ -214,9 +214,15 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     RV_TRY(h->dLCP.reserve((size_t)(n + 64) * sizeof(lcp_t)));
     RV_TRY(h->dBWT.reserve((size_t)n + 64));
     memset(&h->sa_stats, 0, sizeof h->sa_stats);
+    RV_TRY(h->ws.misc[0].reserve(64));
+    u32 *d_max = h->ws.misc[0].as<u32>();
+    const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
+    const bool lcp_from_file = lcpfile && lcpfile[0];
+    bool lcp_done = false;
     if (!safile || !safile[0]) {
         int id = h->prof.begin(q, RV_K_SA_SORT, 5.0 * (double)n);
-        RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats));
+        if (lcp_from_file) RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats));
+        else RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats, h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), side_sep, d_max, &lcp_done));
         h->prof.end(q, id);
     } else {
         std::vector<sa_t> tmp((size_t)n);
@@ -226,13 +232,12 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     }
     h->sai_valid = false;
     if (safile && safile[0]) { RV_TRY(rv_build_inverse_checked(h->ws, h->dSA.as<sa_t>(), h->dSAi.as<sa_t>(), n)); h->sai_valid = true; }      // (the check of an untrusted SA needs it anyway)
-    RV_TRY(h->ws.misc[0].reserve(64));
-    u32 *d_max = h->ws.misc[0].as<u32>();
-    const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
-    if (!lcpfile || !lcpfile[0]) {
-        int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
-        RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), false, h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>(), side_sep));
-        h->prof.end(q, id);
+    if (!lcp_from_file) {
+        if (!lcp_done) {       // (SA from a file, or an order the first key + text round did not finish)
+            int id = h->prof.begin(q, RV_K_LCP, 13.0 * (double)n);
+            RV_TRY(rv_build_lcp(h->ws, h->dT.as<uint8_t>(), h->dSA.as<sa_t>(), false, h->dLCP.as<lcp_t>(), n, d_max, h->dBWT.as<uint8_t>(), side_sep));
+            h->prof.end(q, id);
+        }
         RV_TRY(rv_read_back(h->ws, &h->maxlcp, d_max, 4));
     } else {
         std::vector<lcp_t> tmp((size_t)n);

@@ -50,8 +50,9 @@ __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, i
 // where 3 bits per symbol needed six.  A block stages 1024+K symbols as codes in
 // LDS; each thread then packs 4 keys from LDS.
 constexpr int KEY_TILE = 1024;
+constexpr u64 KEY_MASK = (1ull << 56) - 1;
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals) {
+                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
     slut[threadIdx.x] = lut[threadIdx.x];
@@ -69,7 +70,10 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         if (i < n) {
             u64 key = 0;
             for (int j = 0; j < K; j++) key = key * radix + code[k + j];
-            keys[i] = key;
+            // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
+            // travels with the key instead of being gathered from the text at the end ('$' for position 0)
+            const u64 prev = pay ? (u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56 : 0ull;
+            keys[i] = key | prev;
             vals[i] = (sav_t)i;
         }
     }
@@ -77,20 +81,45 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 
 // ---- group heads / ranks ------------------------------------------------------
 // head[j] = 1 if sorted key j starts a new group; seed[j] = head ? j : 0
-__global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed) {
+// LCP != NULL (the fused path of rv_build_sa): a head's LCP with its predecessor in the suffix array -- whichever member of the
+// group in front ends up last, it shares that group's K symbols -- is the common prefix of the two keys, cut at the first
+// '$' / 'N' (interface.c:97-114): the digits of both keys, least significant first, by multiply-high division.
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; };      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+__global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
+                                              lcp_t *__restrict__ LCP, KeyDigits kd) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (j >= n) return;
-    const bool hd = (j == 0) || keys[j] != keys[j - 1];
+    const u64 kb = keys[j] & KEY_MASK, ka = j > 0 ? keys[j - 1] & KEY_MASK : 0ull;
+    const bool hd = (j == 0) || ka != kb;
     head[j] = hd;
     seed[j] = hd ? (u32)j : 0u;
+    if (LCP && hd) {
+        u32 l = 0;
+        if (j > 0) {
+            u64 x = ka, y = kb;
+            l = (u32)kd.K;
+            for (int pos = kd.K - 1; pos >= 0; pos--) {
+                const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
+                const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
+                x = qx; y = qy;
+                l = ((dx != dy) | (dy == kd.stop0) | (dy == kd.stop1) | (dy == 0u)) ? (u32)pos : l;      // going up: the last hit is the first position
+            }
+        }
+        LCP[j] = (lcp_t)l;
+    }
 }
 
 // SA[j] = vals[j].  ISA (rank of every suffix's group) is only an intermediate of the doubling rounds and of the radix
 // path for groups above MEDIUM_GROUP: related genomes finish in the text round without either, so the scatter
 // ISA[SA[j]] = grp[j] (a random 4-byte write per position, 21 ms at n = 5e8) waits until something asks for it.
-__global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, int64_t n, sa_t *__restrict__ SA) {
+__global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, int64_t n, sa_t *__restrict__ SA,
+                                                 const u64 *__restrict__ keys, uint8_t *__restrict__ BWT, sa_t side_sep) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (j < n) SA[j] = (sa_t)vals[j];
+    if (j >= n) return;
+    const sav_t s = vals[j];
+    SA[j] = (sa_t)s;
+    // (fused path) final for every suffix that is alone in its group; members of larger groups are rewritten where they are ordered
+    if (BWT) BWT[j] = (uint8_t)((u32)(keys[j] >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
 }
 // Group ranks are rank ranges and every round only permutes suffixes inside their group, so (SA, grp of round 0) still
 // describe round 0's ISA after the text round has reordered SA.
@@ -221,6 +250,9 @@ __global__ __launch_bounds__(TB) void k_round_small(sav_t *__restrict__ S, const
     }
 }
 
+__device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exact at and below the lowest hit
+    return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
+}
 __device__ inline u64 load8(const uint8_t *p) {
     u64 v;
     __builtin_memcpy(&v, p, 8);
@@ -235,21 +267,50 @@ __device__ inline u64 load8(const uint8_t *p) {
 constexpr int TEXT_LIM = 4096;
 // 32 bytes per side and step: the loop is a chain of dependent memory round trips (the next step starts when this
 // one's compare is known), and a wave takes as many steps as its longest pair -- fewer, fatter steps.
-__device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, int64_t h) {
-    const uint8_t *pa = T + (int64_t)a + h, *pb = T + (int64_t)b + h;
+// -> order of suffixes a, b (-1 / +1; 0 = equal for TEXT_LIM bytes); *lcp = their common prefix as compute_lcp counts it
+// (interface.c:97-114: equal characters up to the first '$' / 'N' / end of text), valid when the result is not 0.  The
+// compare starts at the suffixes' first byte although their first h symbols are known to be equal: a stop among those
+// symbols ends the LCP, and the first 32-byte step covers them anyway.
+__device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, u32 *lcp) {
+    const uint8_t *pa = T + (int64_t)a, *pb = T + (int64_t)b;
+    u32 stop_at = 0xFFFFFFFFu;
     for (int off = 0; off < TEXT_LIM; off += 32) {
         u64 wa[4], wb[4];
         __builtin_memcpy(wa, pa + off, 32);
         __builtin_memcpy(wb, pb + off, 32);
+        if (stop_at == 0xFFFFFFFFu) {
+            u64 st[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) st[k] = zero_bytes(wb[k] ^ 0x2424242424242424ull) | zero_bytes(wb[k] ^ 0x4E4E4E4E4E4E4E4Eull) | zero_bytes(wb[k]);
+            if (st[0] | st[1] | st[2] | st[3]) {
+                const int k = st[0] ? 0 : st[1] ? 1 : st[2] ? 2 : 3;
+                const u64 m = st[0] ? st[0] : st[1] ? st[1] : st[2] ? st[2] : st[3];
+                stop_at = (u32)off + 8u * (u32)k + (u32)(__builtin_ctzll(m) >> 3);
+            }
+        }
         const bool d0 = wa[0] != wb[0], d1 = wa[1] != wb[1], d2 = wa[2] != wb[2], d3 = wa[3] != wb[3];
         if (d0 | d1 | d2 | d3) {
             const u64 x = d0 ? wa[0] : d1 ? wa[1] : d2 ? wa[2] : wa[3];
             const u64 y = d0 ? wb[0] : d1 ? wb[1] : d2 ? wb[2] : wb[3];
+            const u32 dpos = (u32)off + (d0 ? 0u : d1 ? 8u : d2 ? 16u : 24u) + (u32)(__builtin_ctzll(x ^ y) >> 3);
+            *lcp = dpos < stop_at ? dpos : stop_at;
             // big-endian compare of the first differing word; the shorter suffix runs into the zero padding first and sorts first
             return __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;
         }
     }
+    *lcp = 0;
     return 0;
+}
+
+// what the fused path writes besides SA: BWT byte of every member at its final rank, LCP of every member but the group's first
+// (its LCP with the member in front of it = the largest common prefix it has with any smaller member), the running maximum
+struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; };
+__device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp) {
+    f.BWT[rank] = (uint8_t)(pay | ((sa_t)suf > f.side_sep ? RV_BWT_SIDE : 0u));
+    if (!first) {
+        f.LCP[rank] = (lcp_t)lcp;
+        if (lcp > __atomic_load_n(f.maxlcp, __ATOMIC_RELAXED)) atomicMax(f.maxlcp, lcp);      // (only threads that raise it reach the atomic unit)
+    }
 }
 
 constexpr int MEDIUM_GROUP = 64;      // groups of 9..64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
@@ -258,8 +319,8 @@ __global__ __launch_bounds__(TB) void k_medium_back(const uint8_t *__restrict__ 
     if (q < m && flag[q] == 2) S[q] = Sout[q];
 }
 __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
-                                                   int64_t m, int64_t h, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
-                                                   sav_t *__restrict__ Sout) {
+                                                   int64_t m, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                   sav_t *__restrict__ Sout, FusedOut fo) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q >= m) return;
     const u32 g = G[q];
@@ -270,22 +331,26 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
     const bool medium = !big && qs + SMALL_GROUP < m && G[qs + SMALL_GROUP] == g;
     bigflag[q] = big ? 1 : medium ? 2 : 0;
     if (big) return;
+    const bool fused = fo.LCP != nullptr;
     if (medium) {
         // every member finds its own rank: one text comparison with each other member (all lanes of the wave are busy -- a
         // group's first thread sorting alone left its wave idle for ~g*g/4 comparisons; ten samples: every group has ten members)
         int size = SMALL_GROUP + 1;
         while (qs + size < m && G[qs + size] == g) size++;
         const sav_t mine = S[q];
-        int rank = 0; bool tie_before = false;
+        int rank = 0; bool tie_before = false; u32 best = 0;
         for (int j = 0; j < size; j++) {
             if (j == (int)off) continue;
-            const int c = cmp_text(T, S[qs + j], mine, h);
+            u32 l;
+            const int c = cmp_text(T, S[qs + j], mine, &l);
             rank += (c < 0) | ((c == 0) & (j < (int)off));
             tie_before |= (c == 0) & (j < (int)off);
+            best = (c < 0 && l > best) ? l : best;
         }
         Sout[qs + rank] = mine;                                  // (S itself is still being read by the other members)
         SA[(size_t)g + rank] = (sa_t)mine;
         headq[qs + rank] = !tie_before;
+        if (fused) fused_put(fo, (size_t)g + rank, mine, (u32)(fo.keys[(size_t)g + off] >> 56), rank == 0, best);
         return;
     }
     if (off != 0) return;
@@ -297,24 +362,34 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         if (size == j && q + j < m && G[q + j] == g) { s[j] = S[q + j]; size = j + 1; }
     }
     if (size == 2) {
-        const int c = cmp_text(T, s[0], s[1], h);
+        u32 l;
+        const int c = cmp_text(T, s[0], s[1], &l);
         const sav_t lo = c <= 0 ? s[0] : s[1], hi = c <= 0 ? s[1] : s[0];
         S[q] = lo; S[q + 1] = hi;
         SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
         headq[q] = 1; headq[q + 1] = c != 0;
+        if (fused) {
+            const u32 p0 = (u32)(fo.keys[(size_t)g] >> 56), p1 = (u32)(fo.keys[(size_t)g + 1] >> 56);
+            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0);
+            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l);
+        }
         return;
     }
-    // all pairs once: less[i] bit j = (s[j] < s[i]); eq likewise; rank = #smaller + #equal with smaller index
-    u32 less[SMALL_GROUP], eq[SMALL_GROUP];
+    // all pairs once: less[i] bit j = (s[j] < s[i]); eq likewise; rank = #smaller + #equal with smaller index.
+    // best[i] = the largest common prefix of member i with a smaller member = its LCP with the one that ends up in front of it
+    u32 less[SMALL_GROUP], eq[SMALL_GROUP], best[SMALL_GROUP];
 #pragma unroll
-    for (int i = 0; i < SMALL_GROUP; i++) { less[i] = 0; eq[i] = 0; }
+    for (int i = 0; i < SMALL_GROUP; i++) { less[i] = 0; eq[i] = 0; best[i] = 0; }
 #pragma unroll
     for (int i = 0; i < SMALL_GROUP; i++) {
 #pragma unroll
         for (int j = i + 1; j < SMALL_GROUP; j++) {
             if (j < size) {
-                const int c = cmp_text(T, s[i], s[j], h);
-                if (c < 0) less[j] |= 1u << i; else if (c > 0) less[i] |= 1u << j; else { eq[j] |= 1u << i; eq[i] |= 1u << j; }
+                u32 l;
+                const int c = cmp_text(T, s[i], s[j], &l);
+                if (c < 0) { less[j] |= 1u << i; best[j] = l > best[j] ? l : best[j]; }
+                else if (c > 0) { less[i] |= 1u << j; best[i] = l > best[i] ? l : best[i]; }
+                else { eq[j] |= 1u << i; eq[i] |= 1u << j; }
             }
         }
     }
@@ -326,6 +401,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
             S[q + r] = s[i];
             SA[(size_t)g + r] = (sa_t)s[i];
             headq[q + r] = before == 0;
+            if (fused) fused_put(fo, (size_t)g + r, s[i], (u32)(fo.keys[(size_t)g + i] >> 56), r == 0, best[i]);
         }
     }
 }
@@ -410,9 +486,6 @@ __global__ __launch_bounds__(TB) void k_inverse_verify(const sa_t *__restrict__ 
 }
 
 // ---- LCP ---------------------------------------------------------------------
-__device__ inline u64 zero_bytes(u64 y) {   // 0x80 in every zero byte of y; exact at and below the lowest hit
-    return (y - 0x0101010101010101ull) & ~y & 0x8080808080808080ull;
-}
 
 // LCP[k] = min( lcp(T[SA[k-1]..], T[SA[k]..]), distance from SA[k] to the first
 // '$' or 'N' )  -- the closed form of compute_lcp (interface.c:97-114).
@@ -601,9 +674,11 @@ int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, 
     return 0;
 }
 
-int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st) {
+int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st,
+                lcp_t *LCP, uint8_t *BWT, sa_t side_sep, u32 *d_maxlcp, bool *fused_done) {
     RvSaStats s;
     memset(&s, 0, sizeof s);
+    if (fused_done) *fused_done = false;
     if (n <= 0) { if (st) *st = s; return 0; }
     if (n >= ((int64_t)1 << 32) - 2) { rv_set_error("SA build: n >= 2^32-2 not supported yet"); return -1; }
     hipStream_t q = ws.stream;
@@ -641,6 +716,17 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     }
     s.sigma = sigma; s.bits = bits; s.k0 = K;        // (bits: of the whole first key)
     RV_HIP(hipMemcpyAsync(d_lut.p, lut, 256, hipMemcpyHostToDevice, q));
+    // Fused LCP / BWT (interface.c:97-114 folded into the build).  Related genomes are finished by the first key plus the text
+    // round, and both already hold what LCP needs: two suffixes of different groups share less than K symbols -- their LCP is the
+    // common prefix of the two keys -- and the members of a group are told apart by a text comparison that finds their common
+    // prefix on the way; the byte in front of every suffix rides in the spare top bits of its key.  So LCP and BWT leave in
+    // rank order with the suffix array itself, and the three gather / scatter passes of rv_build_lcp (PHI, PLCP, rank-order
+    // gather: 95 ms of a 160 ms construct at n = 5e8) are not run.  Whatever the text round cannot finish (ties beyond 4 KB,
+    // groups above 64 members: repeats, identical inputs) falls back to rv_build_lcp for the whole index.
+    bool fused = LCP && BWT && d_maxlcp && bits <= 48 && !getenv("RV_NO_FUSED_LCP");
+    KeyDigits kd;
+    kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
+    if (fused) RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
 
     // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
     DBuf &bk0 = ws.sa[0], &bk1 = ws.sa[1], &bv0 = ws.sa[2], &bv1 = ws.sa[3], &bhead = ws.sa[4], &bseed = ws.sa[5], &bgrp = ws.sa[6], &bisa = ws.sa[7],
@@ -656,7 +742,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     // -- first key, sorted on its K*bits significant bits
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>());
+                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, bits, &in1));
@@ -668,10 +754,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     uint8_t *head = bhead.as<uint8_t>();
     u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
-    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed);
+    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd);
     SA_HIP(hipGetLastError());
     SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
-    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA);
+    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep);
     SA_HIP(hipGetLastError());
     bool isa_built = false;
     auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)
@@ -734,11 +820,14 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // groups of up to SMALL_GROUP members: sorted by their first thread, in place
         if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
         {
-            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, h, head, bigflag, SA, Sfree);
+            FusedOut fo;
+            fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = ks; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep;
+            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo);
             SA_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_medium_back, dim3(mb), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }
         else {
+            fused = false;      // (a doubling round orders by ranks, not by text: no common prefixes come out of it)
             SA_TRY(need_isa());
             hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
         }
@@ -753,6 +842,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             u32 mbig = 0;
             SA_TRY(rv_read_back(ws, &mbig, tile + nt, 4));
             if (mbig > 0) {
+                fused = false;
                 SA_TRY(need_isa());
                 u32 *Pb = bPb.as<u32>(), *Qb = bQb.as<u32>();
                 hipLaunchKernelGGL(k_flag_emit, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, (const u32 *)tile, (const u32 *)P, (const sav_t *)S,
@@ -776,6 +866,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         int64_t m2 = 0;
         SA_TRY(count_unsorted(head, m, &m2));
         if (m2 == 0) break;
+        fused = false;
         // new group ranks from the heads, ISA update
         SA_TRY(need_isa());
         hipLaunchKernelGGL(k_seed, dim3(mb), dim3(TB), 0, q, (const uint8_t *)head, (const u32 *)P, m, seed);
@@ -794,5 +885,6 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 #undef SA_HIP
     freeall();
     if (st) *st = s;
+    if (fused_done) *fused_done = fused;
     return 0;
 }

@@ -103,6 +103,25 @@ def _buffers(lib, m, device):
             torch.empty(max(m, 1), dtype=torch.uint8, device=device))
 
 
+def balanced_frontier(idx, world, stop_subs, minl, minn, trace=False, tolerance=1.15, max_subs=None):
+    """owner side: levels until the frontier is wide enough AND its largest-first partition is balanced -- a share may exceed
+    the mean by `tolerance` at most -- or the frontier has grown to max_subs sub-indices (each further level costs the owner a
+    pass over the ranks it still holds, so the widening stops there).  The top of a recursion tree is lopsided (the longest
+    match splits a genome anywhere), and a sub-index is the unit of work: the widening is what divides a share that is too
+    large for one device.  -> (frontier size, frontier dict or None, parts)"""
+    left = idx.align_builtin_until(stop_subs, minl, minn, trace=trace)
+    max_subs = max_subs or 64 * world
+    while left > 0:
+        fr = idx.frontier()
+        sizes = fr["meta"][:, 1]
+        parts = partition(sizes, world)
+        loads = np.array([int(sizes[p].sum()) for p in parts], dtype=np.float64)
+        if loads.max() <= tolerance * loads.mean() or left >= max_subs:
+            return left, fr, parts
+        left = idx.align_builtin_continue(min(2 * left, max_subs))
+    return 0, None, [np.zeros(0, np.int32)] * world
+
+
 def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False):
     """Divide ONE alignment over the ranks of `group`.  Every rank passes an index that holds the same samples
     (addsample / addsequence done, construct not needed); rank 0's is constructed here.
@@ -122,13 +141,10 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False)
     shares = None
     if rank == 0:
         idx.construct()
-        left = idx.align_builtin_until(stop_subs or 8 * world, minl, minn, trace=trace)
+        left, fr, parts = balanced_frontier(idx, world, stop_subs or 4 * world, minl, minn, trace=trace)
         if left > 0:
-            fr = idx.frontier()
-            parts = partition(fr["meta"][:, 1], world)
             heads = [dict(part=subset(fr, p), maxlcp=idx.maxlcp) for p in parts]
         else:
-            parts = [np.zeros(0, np.int32)] * world
             heads = [dict(part=None, maxlcp=0)] * world
         shares = [int(h["part"]["meta"][:, 1].sum()) if h["part"] is not None else 0 for h in heads]
     else:

@@ -169,3 +169,46 @@ def test_two_processes_divide_one_alignment(tmp_path):
     r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
     assert r["same_anchors"] and r["same_text"] and r["same_counts"] and r["anchors"] > 1000
     assert len(r["shares"]) == 2 and min(r["shares"]) > 0
+
+
+def test_widened_frontier_divides_evenly():
+    """shard.balanced_frontier: the owner goes on level by level (rv_align_builtin_continue) until no share of the
+    largest-first partition exceeds the mean by more than the tolerance; the divided result is still the undivided one"""
+    seqs = [g.decode() for g in synth.genomes(1500000, 2, seed=5)]
+    M = mod(False)
+    one = feed(M.index(), seqs)
+    one.construct()
+    ref = one.align_builtin(20, 2)
+    owner = feed(M.index(), seqs)
+    owner.construct()
+    world = 4
+    left, fr, parts = shard.balanced_frontier(owner, world, 2, 20, 2, tolerance=1.10)
+    assert left > 2 and len(parts) == world
+    sizes = fr["meta"][:, 1]
+    loads = np.array([int(sizes[p].sum()) for p in parts], dtype=np.float64)
+    assert loads.max() <= 1.10 * loads.mean() or left >= 64 * world
+    lib = owner._lib
+    results = []
+    packed = []
+    for subs in parts:
+        part = shard.subset(fr, subs)
+        m = int(part["meta"][:, 1].sum())
+        bufs = (np.zeros(max(m, 1), lib.sa_t), np.zeros(max(m, 1), lib.lcp_t), np.zeros(max(m, 1), np.uint8))
+        assert owner.frontier_pack(subs, *bufs) == m
+        packed.append((part, bufs))
+    owner.frontier_import(packed[0][0], *packed[0][1], minl=20, minn=2)
+    for part, bufs in packed[1:]:
+        w = feed(M.index(), seqs)
+        w.frontier_import(part, *bufs, minl=20, minn=2, maxlcp=owner.maxlcp)
+        results.append(w.align_builtin_resume())
+    results.insert(0, owner.align_builtin_resume())
+    got = shard.merge(results)
+
+    def aset(r):
+        l, off, pos = r["anchors"]
+        return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+    assert aset(got) == aset(ref)
+    for k in ("steps", "splits", "anchored_bp"):
+        assert got["stats"][k] == ref["stats"][k], k
+    # continue on a finished / never-started run is a no-op
+    assert one.align_builtin_continue(8) == 0

@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""BASELINE config 5 end to end: N synthetic genomes of L bp, `reveal align --order=sequential --chunksize=C` as a plan of
+independent `reveal rem` jobs (reveal/align.py:27-54; 100 genomes, C = 5 -> 20 / 4 / 1), every job through the graph
+callbacks (reveal_amd/rem.py graph_rem) on this process' GPU, graphs feeding graphs as GFA files; at the end every input must
+be spelled by its path of the final graph (the reference's test15 invariant).  Prints one JSON line with per-level times.
+
+    python tools/config5.py --genomes 100 --L 100000 --chunksize 5 [--jobs-only 0]      # --jobs-only k: only level k
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--genomes", type=int, default=100)
+    ap.add_argument("--L", type=int, default=100000)
+    ap.add_argument("--chunksize", type=int, default=5)
+    ap.add_argument("--minl", type=int, default=20)
+    ap.add_argument("--minn", type=int, default=2)
+    ap.add_argument("--max-jobs", type=int, default=0, help="run at most this many jobs of level 0 and stop (timing of single jobs)")
+    ap.add_argument("--dir", default=None)
+    a = ap.parse_args()
+    from reveal_amd import align, synth
+    import graphrem_cases as C
+    d = a.dir or tempfile.mkdtemp(prefix="config5_")
+    os.makedirs(d, exist_ok=True)
+    t0 = time.perf_counter()
+    seqs = synth.genomes(a.L, a.genomes, seed=42)
+    files = []
+    for k, s in enumerate(seqs):
+        fn = os.path.join(d, "g%03d.fa" % k)
+        with open(fn, "w") as f:
+            f.write(">genome%03d\n%s\n" % (k, s.decode()))
+        files.append(fn)
+    t_gen = time.perf_counter() - t0
+    levels = align.sequential_plan(files, a.chunksize, output=os.path.join(d, "prg"), tmpdir=d)
+    if a.max_jobs:
+        levels = [levels[0][:a.max_jobs]]
+    logs = []
+    t1 = time.perf_counter()
+    done = align.run_plan(levels, minlength=a.minl, minn=a.minn, log=lambda m: (logs.append(m), print(m, file=sys.stderr)))
+    t_run = time.perf_counter() - t1
+    per_level = {}
+    for lv, j, dt, nodes, paths in done:
+        e = per_level.setdefault(lv, dict(jobs=0, seconds=0.0, max_job_s=0.0, nodes=0))
+        e["jobs"] += 1; e["seconds"] += dt; e["max_job_s"] = max(e["max_job_s"], dt); e["nodes"] += nodes
+    out = dict(genomes=a.genomes, L=a.L, chunksize=a.chunksize, plan=[len(j) for j in levels], t_generate_s=t_gen, t_run_s=t_run,
+               levels={str(k): v for k, v in per_level.items()}, bases=a.genomes * a.L)
+    if not a.max_jobs:
+        t2 = time.perf_counter()
+        spelled, G = C.spelled_by_file(levels[-1][-1][1])
+        out["paths_spell_inputs"] = spelled == {"genome%03d" % k: s.decode() for k, s in enumerate(seqs)}
+        out["final_nodes"] = len(G.seq_nodes())
+        out["final_nodes_in_all_paths"] = sum(1 for n in G.seq_nodes() if len(G.offsets[n]) == a.genomes)
+        out["t_check_s"] = time.perf_counter() - t2
+        out["Mbp_per_s_end_to_end"] = a.genomes * a.L / t_run / 1e6
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -242,7 +242,11 @@ def test_rem_driver_writes_a_graph_that_spells_the_inputs(tmp_path, names, sa64)
 
 def test_rem_command_line(tmp_path, capsys):
     out = str(tmp_path / "cli.gfa")
-    rem.main(fa("1a", "1b") + ["-o", out, "-m", "20"])
+    rem.main(fa("1a", "1b") + ["-o", out, "-m", "20", "--bench-callbacks"])
     assert "segments" in capsys.readouterr().out
     from reveal_amd import gfa
     assert len(gfa.read_gfa(out)[2]) == 2
+    out2 = str(tmp_path / "cli_graph.gfa")                      # the default: the reference's graph callbacks (reveal rem)
+    rem.main(fa("1a", "1b") + ["-o", out2, "-m", "20"])
+    assert "1642 nodes, 2 paths" in capsys.readouterr().out
+    assert len(gfa.read_gfa(out2)[2]) == 2

@@ -85,6 +85,18 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 // group in front ends up last, it shares that group's K symbols -- is the common prefix of the two keys, cut at the first
 // '$' / 'N' (interface.c:97-114): the digits of both keys, least significant first, by multiply-high division.
 struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; };      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+// first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF
+__device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
+    u64 x = key & KEY_MASK;
+    u32 at = 0xFFFFFFFFu;
+    for (int pos = kd.K - 1; pos >= 0; pos--) {
+        const u64 qx = __umul64hi(x, kd.magic);
+        const u32 d = (u32)(x - qx * kd.radix);
+        x = qx;
+        at = ((d == kd.stop0) | (d == kd.stop1) | (d == 0u)) ? (u32)pos : at;
+    }
+    return at;
+}
 __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
                                               lcp_t *__restrict__ LCP, KeyDigits kd) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
@@ -271,28 +283,38 @@ constexpr int TEXT_LIM = 4096;
 // (interface.c:97-114: equal characters up to the first '$' / 'N' / end of text), valid when the result is not 0.  The
 // compare starts at the suffixes' first byte although their first h symbols are known to be equal: a stop among those
 // symbols ends the LCP, and the first 32-byte step covers them anyway.
-__device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, u32 *lcp) {
+template <int W>
+__device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, u32 *lcp, int h0 = 0, u32 stop0 = 0xFFFFFFFFu) {
+    // 8 * W bytes per side and step.  The loop is a chain of dependent memory round trips and a wave takes as many steps as its
+    // slowest lane: with 1 % divergence a 32-byte step ends a comparison with probability 0.28 (ten steps until 32 of them are
+    // through), a 64-byte step with 0.47 (five).
+    // h0 / stop0: the first h0 symbols are known to be equal (same key) and their first stop, if any, is known from the key
     const uint8_t *pa = T + (int64_t)a, *pb = T + (int64_t)b;
-    u32 stop_at = 0xFFFFFFFFu;
-    for (int off = 0; off < TEXT_LIM; off += 32) {
-        u64 wa[4], wb[4];
-        __builtin_memcpy(wa, pa + off, 32);
-        __builtin_memcpy(wb, pb + off, 32);
+    u32 stop_at = stop0;
+    for (int off = h0; off < TEXT_LIM; off += 8 * W) {
+        u64 wa[W], wb[W];
+        __builtin_memcpy(wa, pa + off, 8 * W);
+        __builtin_memcpy(wb, pb + off, 8 * W);
         if (stop_at == 0xFFFFFFFFu) {
-            u64 st[4];
+            u64 any = 0;
 #pragma unroll
-            for (int k = 0; k < 4; k++) st[k] = zero_bytes(wb[k] ^ 0x2424242424242424ull) | zero_bytes(wb[k] ^ 0x4E4E4E4E4E4E4E4Eull) | zero_bytes(wb[k]);
-            if (st[0] | st[1] | st[2] | st[3]) {
-                const int k = st[0] ? 0 : st[1] ? 1 : st[2] ? 2 : 3;
-                const u64 m = st[0] ? st[0] : st[1] ? st[1] : st[2] ? st[2] : st[3];
-                stop_at = (u32)off + 8u * (u32)k + (u32)(__builtin_ctzll(m) >> 3);
+            for (int k = 0; k < W; k++) any |= zero_bytes(wb[k] ^ 0x2424242424242424ull) | zero_bytes(wb[k] ^ 0x4E4E4E4E4E4E4E4Eull) | zero_bytes(wb[k]);
+            if (any) {
+#pragma unroll
+                for (int k = W - 1; k >= 0; k--) {       // (downwards: the last assignment is the first word with a stop)
+                    const u64 st = zero_bytes(wb[k] ^ 0x2424242424242424ull) | zero_bytes(wb[k] ^ 0x4E4E4E4E4E4E4E4Eull) | zero_bytes(wb[k]);
+                    stop_at = st ? (u32)off + 8u * (u32)k + (u32)(__builtin_ctzll(st) >> 3) : stop_at;
+                }
             }
         }
-        const bool d0 = wa[0] != wb[0], d1 = wa[1] != wb[1], d2 = wa[2] != wb[2], d3 = wa[3] != wb[3];
-        if (d0 | d1 | d2 | d3) {
-            const u64 x = d0 ? wa[0] : d1 ? wa[1] : d2 ? wa[2] : wa[3];
-            const u64 y = d0 ? wb[0] : d1 ? wb[1] : d2 ? wb[2] : wb[3];
-            const u32 dpos = (u32)off + (d0 ? 0u : d1 ? 8u : d2 ? 16u : 24u) + (u32)(__builtin_ctzll(x ^ y) >> 3);
+        u64 x = 0, y = 0; u32 at = 0; bool diff = false;
+#pragma unroll
+        for (int k = W - 1; k >= 0; k--) {               // (downwards: ends with the first differing word)
+            const bool d = wa[k] != wb[k];
+            x = d ? wa[k] : x; y = d ? wb[k] : y; at = d ? 8u * (u32)k : at; diff |= d;
+        }
+        if (diff) {
+            const u32 dpos = (u32)off + at + (u32)(__builtin_ctzll(x ^ y) >> 3);
             *lcp = dpos < stop_at ? dpos : stop_at;
             // big-endian compare of the first differing word; the shorter suffix runs into the zero padding first and sorts first
             return __builtin_bswap64(x) < __builtin_bswap64(y) ? -1 : 1;
@@ -304,7 +326,7 @@ __device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, 
 
 // what the fused path writes besides SA: BWT byte of every member at its final rank, LCP of every member but the group's first
 // (its LCP with the member in front of it = the largest common prefix it has with any smaller member), the running maximum
-struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; };
+struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; };
 __device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp) {
     f.BWT[rank] = (uint8_t)(pay | ((sa_t)suf > f.side_sep ? RV_BWT_SIDE : 0u));
     if (!first) {
@@ -313,11 +335,15 @@ __device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 
     }
 }
 
-constexpr int MEDIUM_GROUP = 64;      // groups of 9..64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
+constexpr int MEDIUM_GROUP = 64;      // groups of up to 64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
 __global__ __launch_bounds__(TB) void k_medium_back(const uint8_t *__restrict__ flag, const sav_t *__restrict__ Sout, sav_t *__restrict__ S, int64_t m) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q < m && flag[q] == 2) S[q] = Sout[q];
 }
+// MODE 2: every member of a group finds its own rank -- one text comparison with each other member, all lanes busy.
+// MODE 1: the same for groups of three and more; a pair is ordered by its first thread alone.
+// MODE 0: groups of up to SMALL_GROUP members are ordered by their first thread (all pairs in registers), larger ones rank themselves.
+template <int W, int MODE>
 __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
                                                    int64_t m, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
                                                    sav_t *__restrict__ Sout, FusedOut fo) {
@@ -328,24 +354,26 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
     const int64_t look = q + (MEDIUM_GROUP - (int64_t)off);
     const bool big = off >= (u32)MEDIUM_GROUP || (look < m && G[look] == g);
     const int64_t qs = q - (int64_t)off;                       // the group's first list entry (a group is contiguous in the list)
-    const bool medium = !big && qs + SMALL_GROUP < m && G[qs + SMALL_GROUP] == g;
-    bigflag[q] = big ? 1 : medium ? 2 : 0;
-    if (big) return;
     const bool fused = fo.LCP != nullptr;
-    if (medium) {
-        // every member finds its own rank: one text comparison with each other member (all lanes of the wave are busy -- a
-        // group's first thread sorting alone left its wave idle for ~g*g/4 comparisons; ten samples: every group has ten members)
-        int size = SMALL_GROUP + 1;
+    // the comparisons start behind the h symbols the group's key stands for; a stop among those symbols comes from the key's digits
+    const int h0 = fo.h;
+    const u32 stop0 = (fused && !big) ? key_first_stop(fo.keys[g], fo.kd) : 0xFFFFFFFFu;
+    constexpr int DIRECT = MODE == 0 ? SMALL_GROUP : MODE == 1 ? 2 : 1;      // groups up to this size are ordered by their first thread
+    const bool self = !big && qs + DIRECT < m && G[qs + DIRECT] == g;
+    bigflag[q] = big ? 1 : self ? 2 : 0;
+    if (big) return;
+    if (self) {
+        int size = (int)off + 1;
         while (qs + size < m && G[qs + size] == g) size++;
         const sav_t mine = S[q];
         int rank = 0; bool tie_before = false; u32 best = 0;
         for (int j = 0; j < size; j++) {
             if (j == (int)off) continue;
             u32 l;
-            const int c = cmp_text(T, S[qs + j], mine, &l);
+            const int c = cmp_text<W>(T, S[qs + j], mine, &l, h0, stop0);
             rank += (c < 0) | ((c == 0) & (j < (int)off));
             tie_before |= (c == 0) & (j < (int)off);
-            best = (c < 0 && l > best) ? l : best;
+            best = (c < 0 && l > best) ? l : best;               // LCP with the member in front = the longest common prefix with any smaller one
         }
         Sout[qs + rank] = mine;                                  // (S itself is still being read by the other members)
         SA[(size_t)g + rank] = (sa_t)mine;
@@ -354,6 +382,21 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         return;
     }
     if (off != 0) return;
+    if (MODE >= 1) {                                             // a pair
+        const sav_t s0 = S[q], s1 = S[q + 1];
+        u32 l;
+        const int c = cmp_text<W>(T, s0, s1, &l, h0, stop0);
+        const sav_t lo = c <= 0 ? s0 : s1, hi = c <= 0 ? s1 : s0;
+        S[q] = lo; S[q + 1] = hi;
+        SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
+        headq[q] = 1; headq[q + 1] = c != 0;
+        if (fused) {
+            const u32 p0 = (u32)(fo.keys[(size_t)g] >> 56), p1 = (u32)(fo.keys[(size_t)g + 1] >> 56);
+            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0);
+            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l);
+        }
+        return;
+    }
     sav_t s[SMALL_GROUP];
     int size = 1;
     s[0] = S[q];
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
     }
     if (size == 2) {
         u32 l;
-        const int c = cmp_text(T, s[0], s[1], &l);
+        const int c = cmp_text<W>(T, s[0], s[1], &l, h0, stop0);
         const sav_t lo = c <= 0 ? s[0] : s[1], hi = c <= 0 ? s[1] : s[0];
         S[q] = lo; S[q + 1] = hi;
         SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
@@ -386,7 +429,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         for (int j = i + 1; j < SMALL_GROUP; j++) {
             if (j < size) {
                 u32 l;
-                const int c = cmp_text(T, s[i], s[j], &l);
+                const int c = cmp_text<W>(T, s[i], s[j], &l, h0, stop0);
                 if (c < 0) { less[j] |= 1u << i; best[j] = l > best[j] ? l : best[j]; }
                 else if (c > 0) { less[i] |= 1u << j; best[i] = l > best[i] ? l : best[i]; }
                 else { eq[j] |= 1u << i; eq[i] |= 1u << j; }
@@ -821,8 +864,16 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
         {
             FusedOut fo;
-            fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = ks; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep;
-            hipLaunchKernelGGL(k_round_text, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo);
+            fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = ks; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep; fo.kd = kd;
+            fo.h = (int)h;
+            // measured (2 x 250 Mbp / 10 x 5 Mbp / 2 x 5 Mbp, ms of the whole build): first-thread pairs + self-ranking larger groups
+            // 116-120 / 22.6 / 2.27; everything by the first thread (up to 8 members) 122 / 32.0 / 2.37; everything self-ranking
+            // 125 / 22.6 / 2.33; 64-byte steps instead of 32: +14 / +3 / +0.3 (the round is bound by sector traffic, not by the
+            // length of its dependent-load chains); 16-byte steps: +4 / -1 / +0.03.  RV_TEXT_MODE: test hook for the other two.
+            const int tmode = getenv("RV_TEXT_MODE") ? atoi(getenv("RV_TEXT_MODE")) : 1;
+#define RT_LAUNCH(M_) hipLaunchKernelGGL((k_round_text<4, M_>), dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo)
+            if (tmode == 0) RT_LAUNCH(0); else if (tmode == 2) RT_LAUNCH(2); else RT_LAUNCH(1);
+#undef RT_LAUNCH
             SA_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_medium_back, dim3(mb), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }

@@ -210,3 +210,43 @@ def test_corrupt_sa_file_is_an_error(tmp_path, monkeypatch):
     good = feed(m.index(sa=str(tmp_path / ".reveal.sa"), lcp=str(tmp_path / ".reveal.lcp")), fa("1a", "1b"))
     good.construct()
     assert np.array_equal(good.array("SA"), sa)
+
+
+@pytest.mark.parametrize("mode", ["0", "2"])
+@pytest.mark.parametrize("name", ["1a1b", "5way", "d1d2", "1a1a"])
+def test_text_round_variants(monkeypatch, name, mode):
+    """the other two work divisions of the SA build's text round (first thread orders its whole group / every member ranks
+    itself; the default mixes them) and the fused LCP / BWT they emit: same SA, LCP and scan results"""
+    monkeypatch.setenv("RV_TEXT_MODE", mode)
+    T, nsep, nodes = assemble(SETS[name])
+    O = oracle(False)
+    c = O.construct(T, nsep, len(SETS[name]))
+    idx = feed(mod(False).index(), SETS[name])
+    idx.construct()
+    assert np.array_equal(idx.array("SA"), c["SA"]) and np.array_equal(idx.array("LCP"), c["LCP"])
+    l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 20)
+    assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))]
+
+
+def test_fused_lcp_equals_the_separate_pass(monkeypatch):
+    """LCP / BWT written by the SA build itself (head LCP from the keys, member LCP from the text round) against the PHI / PLCP
+    pass (RV_NO_FUSED_LCP), on inputs with N runs, '$' inside the first-key window and lower case"""
+    seqs = ["ACGTNNNNNNNNNNACGTACGTTTGACCANNACGT" * 40 + "ACGTAC", "ACGTNNNNNNNNNNACGTACGTTTGACCANNACGA" * 40 + "ACGTAC", "ACG", "A", "acgtacgtACGTacgtNNacgt" * 30]
+    seqs += [g.decode() for g in synth.genomes(30000, 3, seed=9)]
+    m = mod(False)
+
+    def build():
+        idx = m.index()
+        for k, s_ in enumerate(seqs):
+            idx.addsample("s%d" % k)
+            idx.addsequence(s_)
+        idx.construct()
+        return idx.array("SA"), idx.array("LCP"), idx.getmultimums(5, 2), idx.maxlcp
+    fused = build()
+    monkeypatch.setenv("RV_NO_FUSED_LCP", "1")
+    plain = build()
+    assert np.array_equal(fused[0], plain[0]) and np.array_equal(fused[1], plain[1])
+    assert fused[2] == plain[2] and fused[3] == plain[3]
+    T, nsep, nodes = assemble(seqs, toupper=False)
+    c = oracle(False).construct(T, nsep, len(seqs))
+    assert np.array_equal(fused[0], c["SA"]) and np.array_equal(fused[1], c["LCP"])

@@ -137,6 +137,7 @@ struct Align {
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
+    DBuf dTmin;                  // per RV_SPLIT_TILE ranks of the level being written: lower bound of its LCP values (split -> bubble rounds)
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
     hipStream_t leaf_stream = nullptr, leaf_stream2 = nullptr;   // leaf launches overlap the level pipeline -- and, on alternating streams, each other:
@@ -192,7 +193,7 @@ struct Align {
     void release() {
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release();
-        dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dTmin.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (leaf_stream2) { (void)hipStreamSynchronize(leaf_stream2); (void)hipStreamDestroy(leaf_stream2); leaf_stream2 = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
@@ -470,6 +471,9 @@ static int early_split(rv_index *h) {
     sa.mend_first = d.mend_first; sa.mend_pos = d.mend_pos;
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = a->dErr.as<u32>();
+    RV_TRY(a->dTmin.reserve((size_t)(m / RV_SPLIT_TILE + 2) * 4));      // (the next level is not larger than this one)
+    RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(m / RV_SPLIT_TILE + 2) * 4, q));
+    sa.tmin_out = a->dTmin.as<u32>();
     int id = h->prof.begin(q, RV_K_SPLIT, (double)m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m * (sizeof(sa_t) + sizeof(lcp_t) + 1));
     RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
     h->prof.end(q, id);
@@ -1039,8 +1043,12 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = a->dErr.as<u32>();      // persistent for the alignment: an early split (rv_decide.hip) runs before this upload exists
     int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
-    if (!a->early_done)      // (otherwise queued behind the picker already, with the same tables built on the device)
+    if (!a->early_done) {     // (otherwise queued behind the picker already, with the same tables built on the device)
+        RV_TRY(a->dTmin.reserve((size_t)(lv.m / RV_SPLIT_TILE + 2) * 4));
+        RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(lv.m / RV_SPLIT_TILE + 2) * 4, q));
+        sa.tmin_out = a->dTmin.as<u32>();
         RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
+    }
     h->prof.end(q, id);
     if (!a->early_bubble)
         RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
@@ -1083,7 +1091,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             ba.par.gcount = (u32 *)(tb + o_gcnt);
             ba.par.glist = (u64 *)pb; pb += W * 8;
             ba.par.Qs = (sa_t *)pb; pb += W * sizeof(sa_t);
-            ba.par.tmin = (u32 *)pb; pb += TT * 4;
+            ba.par.tmin = a->dTmin.as<u32>(); pb += TT * 4;
             ba.par.mrank = (u32 *)pb; pb += W * 4;
             ba.par.msite = (u32 *)pb; pb += W * 4;
             ba.par.R = (u32 *)pb; pb += W * 4;
@@ -1124,11 +1132,12 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             RV_TRY(rv_bubble_children_launch(lw, ba, (const RvBubbleDesc *)(tb + o_ks), (int)a->kids_small.size(), (const RvBubbleDesc *)(tb + o_kb), (int)a->kids_big.size()));
             if (side) { RV_HIP(hipEventRecord(a->ev_join2, a->bub_stream2)); forked2 = true; }
         }
+        bool seq_before = false;      // an earlier round of this level ran the sequential kernels: the tile bounds have to be refreshed
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
             RV_TRY(rv_bubble_par_round_launch(h->ws, ba, first, count, a->woff[(size_t)(first + count)] - a->woff[(size_t)first],
-                                              a->toff[(size_t)(first + count)] - a->toff[(size_t)first]));
-            if (round_seq[r]) RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count));
+                                              a->toff[(size_t)(first + count)] - a->toff[(size_t)first], seq_before));
+            if (round_seq[r]) { RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count)); seq_before = true; }
         }
         if (forked2) RV_HIP(hipStreamWaitEvent(q, a->ev_join2, 0));
         if (forked) RV_HIP(hipStreamWaitEvent(q, a->ev_join, 0));

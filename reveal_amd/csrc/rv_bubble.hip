@@ -27,7 +27,9 @@
 // Kernels of one round (all participating children at once):
 //   k_bubble_window (rv_split.hip)  ranks that can act, via the windowed SAi
 //   k_pb_runs      the l' chains: movers flagged (2) and listed, LCP patched in place
-//   k_pb_tilemin   per 2048-rank tile: min l' over non-movers (search accelerator)
+//   (tile bounds)  per 2048-rank tile of the level arrays a lower bound of l' (search accelerator): written by the split's
+//                  scatter, lowered by every kernel below that lowers or moves a value; k_pb_tilemin only refreshes them
+//                  after a round that ran the sequential kernels
 //   k_pb_search    one wave per mover: its landing site
 //   k_pb_rank      one workgroup per child: movers sorted by rank and by (site, t) -> final ranks
 //   k_pb_copyout   tiles whose ranks change -> scratch (the dead parent-level arrays)
@@ -97,40 +99,43 @@ __global__ __launch_bounds__(TB) void k_pb_runs(RvBubbleArgs b, int first, int c
                 b.par.glist[atomicAdd(b.par.gcount, 1u)] = ((u64)(u32)dd << 32) | q;
                 nlp = lp < ln ? lp : ln;
             }
-            if (more) LCP[i + 1] = (lcp_t)nlp;
+            if (more) { LCP[i + 1] = (lcp_t)nlp; atomicMin(&b.par.tmin[(ds.off + i + 1) >> 11], (u32)nlp); }
         } else if (more && s < B && s + ln > B && ln > lp) {
             nlp = B - s;
             LCP[i + 1] = (lcp_t)nlp;
+            atomicMin(&b.par.tmin[(ds.off + i + 1) >> 11], (u32)nlp);
         }
         if (!more || !flag[i + 1]) break;
         lp = nlp; i++;
     }
 }
 
-// ---- per-tile minimum of l' over the non-movers --------------------------------------------
+// ---- refresh of the tile bounds ---------------------------------------------------------------
+// The bounds come from the split and are kept by every kernel of these rounds; the sequential kernels (a cut with more than
+// RV_PB_CAP candidates) do not keep them.  After such a round the values in place are folded into the bounds again.
 __global__ __launch_bounds__(TB) void k_pb_tilemin(RvBubbleArgs b, int first, int count) {
-    __shared__ u32 wmin[TB / 64];
     int dd; int64_t ti;
     tile_of(b, first, count, blockIdx.x, &dd, &ti);
-    if (!par_desc(b, dd) || b.par.mcnt[dd] == 0) return;
     const RvBubbleDesc ds = b.desc[dd];
     const lcp_t *LCP = b.LCP + ds.off;
-    const uint8_t *flag = b.flag + ds.off;
-    u32 mn = INF;
+    const int lane = threadIdx.x & 63;
 #pragma unroll
     for (int k = 0; k < PT / TB; k++) {
         const int64_t r = ti * PT + (int64_t)k * TB + threadIdx.x;
-        if (r < ds.n) {
-            const u32 v = (r == 0) ? 0u : (flag[r] == 2 ? INF : (u32)LCP[r]);
-            mn = v < mn ? v : mn;
+        const bool in = r < ds.n;
+        const u32 key = in ? (u32)((ds.off + r) >> 11) : 0xFFFFFFFFu;
+        const u32 val = in ? (r == 0 ? 0u : (u32)LCP[r]) : INF;
+        u64 todo = __ballot(in);
+        while (todo) {                                   // (a wave's 64 ranks lie in one or two global tiles)
+            const int l0 = (int)__builtin_ctzll(todo);
+            const u32 k0 = (u32)__shfl((int)key, l0, 64);
+            const bool mine = in && key == k0;
+            u32 v = mine ? val : INF;
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+            if (lane == l0) atomicMin(&b.par.tmin[k0], v);
+            todo &= ~__ballot(mine);
         }
-    }
-    for (int d = 32; d >= 1; d >>= 1) { const u32 o = __shfl_down(mn, d, 64); mn = o < mn ? o : mn; }
-    if ((threadIdx.x & 63) == 0) wmin[threadIdx.x >> 6] = mn;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int k = 1; k < TB / 64; k++) mn = wmin[k] < mn ? wmin[k] : mn;
-        b.par.tmin[b.par.toff[dd] + ti] = mn;
     }
 }
 
@@ -183,26 +188,30 @@ __global__ __launch_bounds__(TB) void k_pb_search(RvBubbleArgs b) {
         const uint8_t *flag = b.flag + ds.off;
         const int64_t e = (int64_t)b.par.mrank[b.woff[dd] + slot];
         const int64_t t = ds.B - (int64_t)b.SA[ds.off + e];
-        const int64_t tile = e / PT;
-        int64_t k = wave_scan_down(LCP, flag, e - 1, tile * PT, t);
-        if (k < 0) {
-            const u32 *tmin = b.par.tmin + b.par.toff[dd];
-            int64_t hit_tile = 0;                      // tile 0 holds rank 0, which always stops
-            for (int64_t top = tile - 1; top >= 0; top -= 256) {
+        // tiles are those of the level arrays (global rank >> 11); inside the child they start at child rank gt * PT - off
+        const int64_t gtile = (ds.off + e) >> 11, gfirst = ds.off >> 11;
+        int64_t lo = gtile * PT - ds.off;
+        int64_t k = wave_scan_down(LCP, flag, e - 1, lo > 0 ? lo : 0, t);
+        int64_t top = gtile - 1;
+        while (k < 0) {
+            if (top < gfirst) { k = 0; if (lane == 0) atomicOr(b.err, 2u); break; }      // cannot happen: the child's first tile holds its rank 0
+            // the nearest lower tile whose bound promises a stopper (the child's first tile always does: LCP of its rank 0 is 0)
+            int64_t hit_tile = -1;
+            for (int64_t tp = top; tp >= gfirst && hit_tile < 0; tp -= 256) {
                 u32 v[4];
 #pragma unroll
-                for (int c = 0; c < 4; c++) { const int64_t q = top - 64 * c - lane; v[c] = q >= 0 ? tmin[q] : INF; }
-                bool found = false;
+                for (int c = 0; c < 4; c++) { const int64_t q = tp - 64 * c - lane; v[c] = q >= gfirst ? b.par.tmin[q] : INF; }
 #pragma unroll
                 for (int c = 0; c < 4; c++) {
                     const u64 bal = __ballot((int64_t)v[c] < t);
-                    if (bal && !found) { hit_tile = top - 64 * c - (int64_t)__builtin_ctzll(bal); found = true; }
+                    if (bal && hit_tile < 0) hit_tile = tp - 64 * c - (int64_t)__builtin_ctzll(bal);
                 }
-                if (found) break;
             }
-            const int64_t hi = hit_tile * PT + PT - 1;
-            k = wave_scan_down(LCP, flag, hi < ds.n - 1 ? hi : ds.n - 1, hit_tile * PT, t);
-            if (k < 0) { k = 0; if (lane == 0) atomicOr(b.err, 2u); }       // cannot happen (the tile minimum said otherwise)
+            if (hit_tile < 0) { k = 0; if (lane == 0) atomicOr(b.err, 2u); break; }
+            lo = hit_tile * PT - ds.off;
+            const int64_t hi = lo + PT - 1;
+            k = wave_scan_down(LCP, flag, hi < ds.n - 1 ? hi : ds.n - 1, lo > 0 ? lo : 0, t);
+            top = hit_tile - 1;                            // (a bound is only a promise: movers and values that moved on count in it)
         }
         if (lane == 0) b.par.msite[b.woff[dd] + slot] = (u32)k;
     }
@@ -343,7 +352,9 @@ __global__ __launch_bounds__(TB) void k_pb_scatter(RvBubbleArgs b, int first, in
         const int64_t f = r - (int64_t)x + (int64_t)u;
         const int64_t g = ds.off + r, gf = ds.off + f;
         const sa_t s = b.scrSA[g];
-        b.SA[gf] = s; b.LCP[gf] = b.scrLCP[g]; b.BWT[gf] = b.scrBWT[g];
+        const lcp_t lv = b.scrLCP[g];
+        b.SA[gf] = s; b.LCP[gf] = lv; b.BWT[gf] = b.scrBWT[g];
+        if ((gf >> 11) != (g >> 11)) atomicMin(&b.par.tmin[gf >> 11], (u32)lv);
         if (f != r) {                                                // reveal.c:692 SAi[SA[x-1]] = x, kept only where a later cut will look
             bool in = false;
             for (int q = 0; q < ncw && !in; q++) in = s >= cw_lo[q] && s < cw_hi[q];
@@ -366,9 +377,13 @@ __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int
         const sa_t s = b.par.Qs[base + slot];
         b.SA[ds.off + F] = s;                                        // reveal.c:700-703
         b.LCP[ds.off + F] = (lcp_t)b.par.Qlcp[base + slot];
+        atomicMin(&b.par.tmin[(ds.off + F) >> 11], b.par.Qlcp[base + slot]);
         b.BWT[ds.off + F] = b.par.Qbw[base + slot];
         b.SAi[s] = (sa_t)F;
-        if (b.par.Qlast[base + slot] && F + 1 < ds.n) b.LCP[ds.off + F + 1] = (lcp_t)b.par.Qt[base + slot];
+        if (b.par.Qlast[base + slot] && F + 1 < ds.n) {
+            b.LCP[ds.off + F + 1] = (lcp_t)b.par.Qt[base + slot];
+            atomicMin(&b.par.tmin[(ds.off + F + 1) >> 11], b.par.Qt[base + slot]);
+        }
     }
     if (slot < (int64_t)b.cnt[dd]) b.flag[ds.off + b.list[base + slot]] = 0;
     if (slot == 0) b.state[dd].next = 0x7fffffff;                    // tells the sequential kernels this (child, cut) is done
@@ -377,15 +392,17 @@ __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int
 
 }  // namespace
 
-int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles) {
+int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles, bool refresh_tmin) {
     if (count <= 0 || total_window <= 0) return 0;
     hipStream_t q = ws.stream;
     const unsigned wb = (unsigned)ceil_div(total_window, TB);
     RV_TRY(rv_bubble_window_launch(ws, b, first, count, total_window));
     hipLaunchKernelGGL(k_pb_runs, dim3(wb), dim3(TB), 0, q, b, first, count, total_window);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pb_tilemin, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
-    RV_LAUNCH_CHECK();
+    if (refresh_tmin || getenv("RV_PB_REFRESH_TMIN")) {
+        hipLaunchKernelGGL(k_pb_tilemin, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
+        RV_LAUNCH_CHECK();
+    }
     {
         const int64_t want = ceil_div(total_window, TB / 64);
         hipLaunchKernelGGL(k_pb_search, dim3((unsigned)(want < 2048 ? want : 2048)), dim3(TB), 0, q, b);

@@ -46,6 +46,9 @@ struct RvSplitArgs {
     uint8_t *BWT_out;
     sa_t  *SAi;
     u32   *err;
+    // per RV_SPLIT_TILE ranks of the NEXT level (global tiles of the output arrays, preset to 0xFFFFFFFF): a lower bound of the
+    // LCP values written there -- the search accelerator of the data-parallel bubble rounds, for free with the scatter
+    u32   *tmin_out = nullptr;
 };
 
 struct RvBubbleDesc {
@@ -65,7 +68,9 @@ struct RvBubbleState {
 #define RV_PB_CAP 4096      // candidates per (child, cut) the parallel path takes; more -> sequential kernels
 struct RvParBubble {
     const int64_t *toff;     // prefix sums of RV_SPLIT_TILE-rank tiles over all descriptors (+1)
-    u32 *tmin;               // per tile: min l' over the non-movers
+    u32 *tmin;               // per GLOBAL tile of the level arrays (rank >> 11): a lower bound of l' over the ranks in it.  Written by
+                             // the split (RvSplitArgs::tmin_out), lowered by whatever lowers or moves a value afterwards; never raised,
+                             // so a tile may promise a stopper it does not hold (the search then goes on), but never hides one
     u32 *mcnt;               // per descriptor: number of movers (zeroed per level)
     u32 *mrank, *msite;      // movers in discovery order: rank in the child, landing site
     u32 *gcount;             // movers of the running round over all descriptors (reset by the round's last kernel)
@@ -116,7 +121,9 @@ int rv_lower_ranges_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const 
 int rv_bubble_children_dev_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n);
 int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count3);   // descriptors sorted by size class
 // one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)
-int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles);
+// refresh_tmin: an earlier round of this level ran the sequential kernels on some of these children (they do not keep the tile
+// bounds): lower the bounds to the values now in place first
+int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window, int64_t total_tiles, bool refresh_tmin);
 int rv_bubble_window_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count, int64_t total_window);
 // sequential kernels for the (child, cut)s of a round the parallel path left alone (more than RV_PB_CAP candidates)
 int rv_bubble_seq_launch(Workspace &ws, const RvBubbleArgs &b, int first, int count);

@@ -395,12 +395,32 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     }
     __syncthreads();
     const u32 total = tot[0] + tot[1] + tot[2];
-    for (u32 q = threadIdx.x; q < total; q += TB) {
-        const u32 np = o_np[q];
-        if (np == 0xFFFFFFFFu) continue;
-        a.SA_out[np] = o_sa[q];
-        a.LCP_out[np] = (lcp_t)o_lcp[q];
-        a.BWT_out[np] = o_bw[q];
+    for (u32 q0 = 0; q0 < total; q0 += TB) {
+        const u32 q = q0 + threadIdx.x;
+        const bool on = q < total;
+        const u32 np = on ? o_np[q] : 0xFFFFFFFFu;
+        const bool ok = np != 0xFFFFFFFFu;
+        const u32 lc = ok ? o_lcp[q] : INF;
+        if (ok) {
+            a.SA_out[np] = o_sa[q];
+            a.LCP_out[np] = (lcp_t)lc;
+            a.BWT_out[np] = o_bw[q];
+        }
+        if (a.tmin_out) {
+            // lower bound of the LCP values per tile of the output arrays.  A wave's 64 slots are consecutive ranks of at most a few
+            // runs (one per class and child), so they fall into two or three output tiles: one atomic per (wave, tile)
+            u64 todo = __ballot(ok);
+            while (todo) {
+                const int l0 = (int)__builtin_ctzll(todo);
+                const u32 key = (u32)__shfl((int)(np >> 11), l0, 64);
+                const bool mine = ok && (np >> 11) == key;
+                u32 v = mine ? lc : INF;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+                if (lane == l0) atomicMin(&a.tmin_out[key], v);
+                todo &= ~__ballot(mine);
+            }
+        }
     }
 }
 

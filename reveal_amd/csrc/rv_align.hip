@@ -471,9 +471,16 @@ static int early_split(rv_index *h) {
     sa.mend_first = d.mend_first; sa.mend_pos = d.mend_pos;
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = a->dErr.as<u32>();
-    RV_TRY(a->dTmin.reserve((size_t)(m / RV_SPLIT_TILE + 2) * 4));      // (the next level is not larger than this one)
-    RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(m / RV_SPLIT_TILE + 2) * 4, q));
-    sa.tmin_out = a->dTmin.as<u32>();
+    {   // tile bounds for the data-parallel bubble rounds: only a level that can still have a child above their threshold needs them
+        int64_t big0 = 0;
+        for (int s2 = 0; s2 < ns; s2++) big0 = std::max<int64_t>(big0, lv.n[(size_t)s2]);
+        sa.tmin_out = nullptr;
+        if (big0 > a->par_min_cur) {
+            RV_TRY(a->dTmin.reserve((size_t)(m / RV_SPLIT_TILE + 2) * 4));      // (the next level is not larger than this one)
+            RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(m / RV_SPLIT_TILE + 2) * 4, q));
+            sa.tmin_out = a->dTmin.as<u32>();
+        }
+    }
     int id = h->prof.begin(q, RV_K_SPLIT, (double)m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m * (sizeof(sa_t) + sizeof(lcp_t) + 1));
     RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
     h->prof.end(q, id);
@@ -1044,9 +1051,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.err = a->dErr.as<u32>();      // persistent for the alignment: an early split (rv_decide.hip) runs before this upload exists
     int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
     if (!a->early_done) {     // (otherwise queued behind the picker already, with the same tables built on the device)
-        RV_TRY(a->dTmin.reserve((size_t)(lv.m / RV_SPLIT_TILE + 2) * 4));
-        RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(lv.m / RV_SPLIT_TILE + 2) * 4, q));
-        sa.tmin_out = a->dTmin.as<u32>();
+        if (!a->descs.empty()) {      // tile bounds: the level has data-parallel bubble rounds
+            RV_TRY(a->dTmin.reserve((size_t)(lv.m / RV_SPLIT_TILE + 2) * 4));
+            RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(lv.m / RV_SPLIT_TILE + 2) * 4, q));
+            sa.tmin_out = a->dTmin.as<u32>();
+        }
         RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
     }
     h->prof.end(q, id);

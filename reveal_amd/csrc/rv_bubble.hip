@@ -128,11 +128,9 @@ __global__ __launch_bounds__(TB) void k_pb_tilemin(RvBubbleArgs b, int first, in
         u64 todo = __ballot(in);
         while (todo) {                                   // (a wave's 64 ranks lie in one or two global tiles)
             const int l0 = (int)__builtin_ctzll(todo);
-            const u32 k0 = (u32)__shfl((int)key, l0, 64);
+            const u32 k0 = (u32)__builtin_amdgcn_readlane((int)key, l0);
             const bool mine = in && key == k0;
-            u32 v = mine ? val : INF;
-#pragma unroll
-            for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
+            const u32 v = rv_wave_min_u32(mine ? val : INF);
             if (lane == l0) atomicMin(&b.par.tmin[k0], v);
             todo &= ~__ballot(mine);
         }

@@ -58,6 +58,27 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 #define RV_BWT_SIDE 0x80u
 #define RV_BWT_CHAR 0x7fu
 
+#ifdef __HIPCC__
+// wave-wide minimum of a u32, broadcast to every lane, without LDS traffic: DPP row operations inside the four 16-lane rows,
+// row broadcasts across them, the total read from lane 63.  (Six __shfl_xor steps are six ds_bpermute round trips through the
+// LDS pipeline, ~100 cycles each and serialised by their dependence: fine once per tile, ruinous once per 64 ranks.)
+__device__ inline u32 rv_wave_min_u32(u32 v) {
+    const int inf = -1;      // 0xFFFFFFFF: what a lane without a source lane sees
+    int x = (int)v, y;
+#define RV_DPP_MIN(ctrl, rmask)                                                        \
+    y = __builtin_amdgcn_update_dpp(inf, x, ctrl, rmask, 0xf, false);                  \
+    x = (int)(((u32)y < (u32)x) ? (u32)y : (u32)x);
+    RV_DPP_MIN(0xB1, 0xf)     // quad_perm [1,0,3,2]
+    RV_DPP_MIN(0x4E, 0xf)     // quad_perm [2,3,0,1]
+    RV_DPP_MIN(0x141, 0xf)    // row_half_mirror
+    RV_DPP_MIN(0x140, 0xf)    // row_mirror: every lane of a row holds the row's minimum
+    RV_DPP_MIN(0x142, 0xa)    // row_bcast:15 into rows 1 and 3
+    RV_DPP_MIN(0x143, 0xc)    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave's minimum
+#undef RV_DPP_MIN
+    return (u32)__builtin_amdgcn_readlane(x, 63);
+}
+#endif
+
 // Grow-only device buffer.
 struct DBuf {
     void  *p = nullptr;

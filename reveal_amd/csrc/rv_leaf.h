@@ -3,7 +3,9 @@
 #include "rv_common.h"
 #include "../../include/reveal_amd.h"
 
+#ifndef RV_LEAF_N
 #define RV_LEAF_N 2048
+#endif
 
 // a sub-index of a two-sample alignment with at most RV_LEAF_N ranks and at most one interval per sample
 struct RvLeafRoot {

@@ -47,7 +47,7 @@ struct RvSplitArgs {
     sa_t  *SAi;
     u32   *err;
     // per RV_SPLIT_TILE ranks of the NEXT level (global tiles of the output arrays, preset to 0xFFFFFFFF): a lower bound of the
-    // LCP values written there -- the search accelerator of the data-parallel bubble rounds, for free with the scatter
+    // LCP values the LEADING children get there -- the search accelerator of the data-parallel bubble rounds, from the scatter
     u32   *tmin_out = nullptr;
 };
 

@@ -307,9 +307,11 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     __shared__ sa_t  o_sa[SP_TILE];
     __shared__ u32   o_lcp[SP_TILE], o_np[SP_TILE];
     __shared__ uint8_t o_bw[SP_TILE];
+    __shared__ u32   t_key[16], t_val[16];      // tile bounds of this workgroup's output: (output tile, minimum), open addressing
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t tile = blockIdx.x;
     const int64_t j0 = tile * SP_TILE + (int64_t)threadIdx.x * SP_ITEMS;
+    if (threadIdx.x < 16) { t_key[threadIdx.x] = 0xFFFFFFFFu; t_val[threadIdx.x] = INF; }
     static_assert(SP_ITEMS == 8, "labels / BWT bytes of a thread travel as one 64-bit word");
 
     u32 ev[SP_ITEMS];             // effective LCP (INF where the reference skips the min update)
@@ -395,32 +397,38 @@ __global__ __launch_bounds__(TB) void k_split_emit(const sa_t *__restrict__ SA, 
     }
     __syncthreads();
     const u32 total = tot[0] + tot[1] + tot[2];
-    for (u32 q0 = 0; q0 < total; q0 += TB) {
-        const u32 q = q0 + threadIdx.x;
-        const bool on = q < total;
-        const u32 np = on ? o_np[q] : 0xFFFFFFFFu;
-        const bool ok = np != 0xFFFFFFFFu;
-        const u32 lc = ok ? o_lcp[q] : INF;
-        if (ok) {
-            a.SA_out[np] = o_sa[q];
-            a.LCP_out[np] = (lcp_t)lc;
-            a.BWT_out[np] = o_bw[q];
+    // Tile bounds (a.tmin_out): a lower bound of the LCP values per RV_SPLIT_TILE ranks of the output arrays.  A thread's slots are
+    // 256 ranks apart inside long runs, so its output tile changes every eighth slot at most: it keeps one (tile, minimum) pair
+    // in registers and hands it to a 16-entry LDS table (open addressing) when the tile changes and at the end; the table leaves
+    // as one global atomic per (workgroup, output tile).  (Wave-wide reductions per 64 slots -- by shuffles or by DPP -- doubled
+    // the time of this pass: a chain of cross-lane operations and a single lane's atomics in front of every store.)
+    u32 ck = 0xFFFFFFFFu, cv = INF;
+    auto flush = [&](u32 key, u32 v) {
+        bool done = false;
+        for (u32 i = key & 15u, tries = 0; tries < 16 && !done; i = (i + 1) & 15u, tries++) {
+            const u32 cur = t_key[i];
+            const u32 old = cur == key ? key : atomicCAS(&t_key[i], 0xFFFFFFFFu, key);
+            if (old == 0xFFFFFFFFu || old == key) { atomicMin(&t_val[i], v); done = true; }
         }
-        if (a.tmin_out) {
-            // lower bound of the LCP values per tile of the output arrays.  A wave's 64 slots are consecutive ranks of at most a few
-            // runs (one per class and child), so they fall into two or three output tiles: one atomic per (wave, tile)
-            u64 todo = __ballot(ok);
-            while (todo) {
-                const int l0 = (int)__builtin_ctzll(todo);
-                const u32 key = (u32)__shfl((int)(np >> 11), l0, 64);
-                const bool mine = ok && (np >> 11) == key;
-                u32 v = mine ? lc : INF;
-#pragma unroll
-                for (int d = 32; d >= 1; d >>= 1) { const u32 o = (u32)__shfl_xor((int)v, d, 64); v = o < v ? o : v; }
-                if (lane == l0) atomicMin(&a.tmin_out[key], v);
-                todo &= ~__ballot(mine);
-            }
+        if (!done) atomicMin(&a.tmin_out[key], v);
+    };
+    for (u32 q = threadIdx.x; q < total; q += TB) {
+        const u32 np = o_np[q];
+        if (np == 0xFFFFFFFFu) continue;
+        const u32 lc = o_lcp[q];
+        a.SA_out[np] = o_sa[q];
+        a.LCP_out[np] = (lcp_t)lc;
+        a.BWT_out[np] = o_bw[q];
+        if (a.tmin_out && q < tot[0]) {       // (only leading children are bubble-sorted: the staging area holds their ranks first)
+            const u32 key = np >> 11;
+            if (key != ck) { if (ck != 0xFFFFFFFFu) flush(ck, cv); ck = key; cv = lc; }
+            else cv = lc < cv ? lc : cv;
         }
+    }
+    if (a.tmin_out) {
+        if (ck != 0xFFFFFFFFu) flush(ck, cv);
+        __syncthreads();
+        if (threadIdx.x < 16 && t_key[threadIdx.x] != 0xFFFFFFFFu) atomicMin(&a.tmin_out[t_key[threadIdx.x]], t_val[threadIdx.x]);
     }
 }
 

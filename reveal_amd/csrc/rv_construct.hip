@@ -279,6 +279,43 @@ __device__ inline u64 load8(const uint8_t *p) {
 constexpr int TEXT_LIM = 4096;
 // 32 bytes per side and step: the loop is a chain of dependent memory round trips (the next step starts when this
 // one's compare is known), and a wave takes as many steps as its longest pair -- fewer, fatter steps.
+// ---- 2-bit text for the text round -----------------------------------------------------------
+// The round is bound by the sectors its comparisons fetch (wider byte steps made it slower).  DNA needs two bits per base:
+// packed 32 bases to a 64-bit word (base i of a word in bits 2i, 2i+1; A, C, G, T = 0..3 keeps the byte order), one 40-byte
+// read per side covers 128 bases where a 32-byte read of the text covers 32.  Everything that is not exactly A, C, G or T
+// ('$', 'N', IUPAC codes, lower case, the zero padding) is an exception: one flag byte per 128-base block (4 MB for 5e8
+// bases: cache resident); a comparison window that touches a flagged block goes on byte by byte on the text itself.
+constexpr int PK_BLOCK = 128;
+__global__ __launch_bounds__(TB) void k_pack2(const uint8_t *__restrict__ T, int64_t n, u64 *__restrict__ Tp, uint8_t *__restrict__ blk, int64_t nwords) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t p0 = w * 32;
+    u64 word = 0; bool exc = false;
+    if (p0 + 32 <= n) {
+        u64 v[4];
+        __builtin_memcpy(v, T + p0, 32);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u32 c = (u32)(v[k] >> (8 * j)) & 0xffu;
+                const u32 code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+                exc |= code > 3u;
+                word |= (u64)(code & 3u) << (2 * (8 * k + j));
+            }
+    } else {
+        exc = true;                                  // the tail (and everything behind the text)
+        for (int j = 0; j < 32 && p0 + j < n; j++) {
+            const u32 c = T[p0 + j];
+            const u32 code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 0u;
+            word |= (u64)code << (2 * j);
+        }
+    }
+    Tp[w] = word;
+    if (exc) blk[p0 / PK_BLOCK] = 1;
+}
+struct Packed { const u64 *Tp; const uint8_t *blk; };
+
 // -> order of suffixes a, b (-1 / +1; 0 = equal for TEXT_LIM bytes); *lcp = their common prefix as compute_lcp counts it
 // (interface.c:97-114: equal characters up to the first '$' / 'N' / end of text), valid when the result is not 0.  The
 // compare starts at the suffixes' first byte although their first h symbols are known to be equal: a stop among those
@@ -324,9 +361,40 @@ __device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, 
     return 0;
 }
 
+// the same comparison on the 2-bit text, 128 bases per step; leaves to cmp_text where a window touches an exception block
+template <int W>
+__device__ inline int cmp_suffix(const uint8_t *__restrict__ T, const Packed &pk, sav_t a, sav_t b, u32 *lcp, int h0, u32 stop0) {
+    if (pk.Tp == nullptr) return cmp_text<W>(T, a, b, lcp, h0, stop0);
+    for (int off = h0; off < TEXT_LIM; off += PK_BLOCK) {
+        const int64_t pa = (int64_t)a + off, pb = (int64_t)b + off;
+        const int64_t ba = pa / PK_BLOCK, bb = pb / PK_BLOCK;
+        if (pk.blk[ba] | pk.blk[ba + 1] | pk.blk[bb] | pk.blk[bb + 1]) return cmp_text<W>(T, a, b, lcp, off, stop0);
+        u64 ra[5], rb[5];
+        __builtin_memcpy(ra, pk.Tp + (pa >> 5), 40);
+        __builtin_memcpy(rb, pk.Tp + (pb >> 5), 40);
+        const int sa = (int)(pa & 31) * 2, sb = (int)(pb & 31) * 2;
+        u64 x = 0, y = 0; u32 at = 0; bool diff = false;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {                       // (downwards: ends with the first differing word)
+            const u64 xa = sa ? (ra[k] >> sa) | (ra[k + 1] << (64 - sa)) : ra[k];
+            const u64 xb = sb ? (rb[k] >> sb) | (rb[k + 1] << (64 - sb)) : rb[k];
+            const bool d = xa != xb;
+            x = d ? xa : x; y = d ? xb : y; at = d ? 32u * (u32)k : at; diff |= d;
+        }
+        if (diff) {
+            const int bit = __builtin_ctzll(x ^ y) & ~1;
+            const u32 dpos = (u32)off + at + (u32)(bit >> 1);
+            *lcp = dpos < stop0 ? dpos : stop0;
+            return ((x >> bit) & 3u) < ((y >> bit) & 3u) ? -1 : 1;
+        }
+    }
+    *lcp = 0;
+    return 0;
+}
+
 // what the fused path writes besides SA: BWT byte of every member at its final rank, LCP of every member but the group's first
 // (its LCP with the member in front of it = the largest common prefix it has with any smaller member), the running maximum
-struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; };
+struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; Packed pk; };
 __device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp) {
     f.BWT[rank] = (uint8_t)(pay | ((sa_t)suf > f.side_sep ? RV_BWT_SIDE : 0u));
     if (!first) {
@@ -370,7 +438,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         for (int j = 0; j < size; j++) {
             if (j == (int)off) continue;
             u32 l;
-            const int c = cmp_text<W>(T, S[qs + j], mine, &l, h0, stop0);
+            const int c = cmp_suffix<W>(T, fo.pk, S[qs + j], mine, &l, h0, stop0);
             rank += (c < 0) | ((c == 0) & (j < (int)off));
             tie_before |= (c == 0) & (j < (int)off);
             best = (c < 0 && l > best) ? l : best;               // LCP with the member in front = the longest common prefix with any smaller one
@@ -385,7 +453,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
     if (MODE >= 1) {                                             // a pair
         const sav_t s0 = S[q], s1 = S[q + 1];
         u32 l;
-        const int c = cmp_text<W>(T, s0, s1, &l, h0, stop0);
+        const int c = cmp_suffix<W>(T, fo.pk, s0, s1, &l, h0, stop0);
         const sav_t lo = c <= 0 ? s0 : s1, hi = c <= 0 ? s1 : s0;
         S[q] = lo; S[q + 1] = hi;
         SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
@@ -406,7 +474,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
     }
     if (size == 2) {
         u32 l;
-        const int c = cmp_text<W>(T, s[0], s[1], &l, h0, stop0);
+        const int c = cmp_suffix<W>(T, fo.pk, s[0], s[1], &l, h0, stop0);
         const sav_t lo = c <= 0 ? s[0] : s[1], hi = c <= 0 ? s[1] : s[0];
         S[q] = lo; S[q + 1] = hi;
         SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
@@ -429,7 +497,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         for (int j = i + 1; j < SMALL_GROUP; j++) {
             if (j < size) {
                 u32 l;
-                const int c = cmp_text<W>(T, s[i], s[j], &l, h0, stop0);
+                const int c = cmp_suffix<W>(T, fo.pk, s[i], s[j], &l, h0, stop0);
                 if (c < 0) { less[j] |= 1u << i; best[j] = l > best[j] ? l : best[j]; }
                 else if (c > 0) { less[i] |= 1u << j; best[i] = l > best[i] ? l : best[i]; }
                 else { eq[j] |= 1u << i; eq[i] |= 1u << j; }
@@ -864,6 +932,17 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
         {
             FusedOut fo;
+            fo.pk.Tp = nullptr; fo.pk.blk = nullptr;
+            if (!getenv("RV_NO_PACKED_TEXT")) {       // 2-bit copy of the text for the comparisons (n/4 bytes + a flag per 128 bases)
+                DBuf &bTp = ws.sa[18], &bBlk = ws.sa[19];
+                const int64_t nwords = n / 32 + 4, nblk = n / PK_BLOCK + 8;      // (windows read one word / test one block beyond)
+                SA_TRY(bTp.reserve((size_t)(nwords + 8) * 8)); SA_TRY(bBlk.reserve((size_t)nblk + 16));
+                SA_HIP(hipMemsetAsync(bBlk.p, 0, (size_t)nblk + 16, q));
+                SA_HIP(hipMemsetAsync(bTp.as<u64>() + nwords, 0, 64, q));
+                hipLaunchKernelGGL(k_pack2, dim3((unsigned)ceil_div(nwords, TB)), dim3(TB), 0, q, T, n, bTp.as<u64>(), bBlk.as<uint8_t>(), nwords);
+                SA_HIP(hipGetLastError());
+                fo.pk.Tp = bTp.as<u64>(); fo.pk.blk = bBlk.as<uint8_t>();
+            }
             fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = ks; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep; fo.kd = kd;
             fo.h = (int)h;
             // measured (2 x 250 Mbp / 10 x 5 Mbp / 2 x 5 Mbp, ms of the whole build): first-thread pairs + self-ranking larger groups

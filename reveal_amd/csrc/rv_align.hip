@@ -189,7 +189,8 @@ struct Align {
     bool leaf_launch_due = false, hook_early = false;   // the level's leaf launch waits until the level's scan / split kernels are queued
     size_t last_leaf_count = 0;
     bool running = false;        // a built-in run is between its set-up and its collection
-    u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_a = nullptr, *lf_b = nullptr; rv_trace *lf_tr = nullptr;
+    u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_pos = nullptr; rv_trace *lf_tr = nullptr;
+    size_t leaf_na = 0;          // anchors of the leaf launches of the last run: they stay in the pinned staging buffer (hLeafOut: pos[2 na], l[na]) until fetched
     void release() {
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release();
@@ -394,7 +395,7 @@ static int leaf_launch(rv_index *h) {
     la.roots = droots.as<RvLeafRoot>();
     la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
     la.nsep0 = h->nsep[0]; la.minl = a->minl; la.lcap = h->maxlcp;
-    la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_a = a->lf_a; la.anchor_b = a->lf_b;
+    la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_pos = a->lf_pos;
     la.stats = a->lf_stats;
     la.trace = a->trace_on ? 1 : 0; la.trace_count = a->lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = a->lf_tr;
     la.err = a->lf_counters + 2;
@@ -1188,10 +1189,11 @@ static int builtin_leaf_setup(rv_index *h) {
     uint8_t *base = a->dLeaf.as<uint8_t>();
     a->lf_counters = (u32 *)base;                          // [0] anchors, [1] trace records, [2] error bits
     a->lf_stats = (unsigned long long *)(base + 64);
-    a->lf_a = (int64_t *)(base + 256); a->lf_b = a->lf_a + a->leaf_anchor_cap; a->lf_l = (u32 *)(a->lf_b + a->leaf_anchor_cap);
+    a->lf_pos = (int64_t *)(base + 256); a->lf_l = (u32 *)(a->lf_pos + 2 * a->leaf_anchor_cap);
     a->lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
     RV_HIP(hipMemsetAsync(base, 0, 256, q));
     if (!a->leaf_stream) {
+        // (tried: lowest stream priority for the leaf launches, highest for the level pipeline -- no gain, 306 against 302 ms at C4)
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream2, hipStreamNonBlocking));
         RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
@@ -1208,7 +1210,7 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     RV_TRY(align_begin(h, minl, minn, h->al && h->al->trace_on));
     Align *a = h->al;
     a->full_only = !a->trace_on;
-    a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
+    a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
     const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
     a->use_leaf = use_leaf;
     // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
@@ -1414,7 +1416,7 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
     Align *a = h->al;
     hipStream_t q = h->ws.stream;
     if (a->use_leaf && a->running) {
-        u32 *lf_counters = a->lf_counters; u32 *lf_l = a->lf_l; int64_t *lf_a = a->lf_a, *lf_b = a->lf_b; rv_trace *lf_tr = a->lf_tr;
+        u32 *lf_counters = a->lf_counters; u32 *lf_l = a->lf_l; int64_t *lf_pos = a->lf_pos; rv_trace *lf_tr = a->lf_tr;
         // everything through pinned staging (pageable destinations are staged by the runtime, copy by copy: ~0.25 ms per run)
         RV_HIP(hipStreamSynchronize(a->leaf_stream));
         RV_HIP(hipStreamSynchronize(a->leaf_stream2));
@@ -1426,18 +1428,17 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
         memcpy(cnt, a->hLeafOut.p, sizeof cnt); memcpy(stv, a->hLeafOut.as<uint8_t>() + 64, sizeof stv);
         if (cnt[2]) { rv_set_error("leaf kernel: recursion stack overflow"); return -1; }
         if (cnt[0] > a->leaf_anchor_cap || cnt[1] > a->leaf_trace_cap) { rv_set_error("leaf kernel: output buffer too small"); return -1; }
+        a->leaf_na = 0;
         if (cnt[0]) {
+            // the anchors stay in the pinned buffer in the layout rv_fetch_anchors hands out (2 x 10^6 of them at 2 x 250 Mbp: appending
+            // them to the host vectors one by one cost 5 ms per run, most of it page faults of the freshly grown vectors)
             const size_t na = cnt[0];
             RV_TRY(a->hLeafOut.reserve(na * 20 + 64));
-            int64_t *pa = a->hLeafOut.as<int64_t>(), *pb = pa + na; u32 *pl = (u32 *)(pb + na);
-            RV_HIP(hipMemcpyAsync(pa, lf_a, na * 8, hipMemcpyDeviceToHost, q));
-            RV_HIP(hipMemcpyAsync(pb, lf_b, na * 8, hipMemcpyDeviceToHost, q));
+            int64_t *pp = a->hLeafOut.as<int64_t>(); u32 *pl = (u32 *)(pp + 2 * na);
+            RV_HIP(hipMemcpyAsync(pp, lf_pos, na * 16, hipMemcpyDeviceToHost, q));
             RV_HIP(hipMemcpyAsync(pl, lf_l, na * 4, hipMemcpyDeviceToHost, q));
             RV_HIP(hipStreamSynchronize(q));
-            const size_t at = a->an_l.size(), pat = a->an_pos.size();
-            a->an_l.resize(at + na); a->an_pos.resize(pat + 2 * na); a->an_off.resize(at + na + 1);
-            u32 *ol = a->an_l.data() + at; int64_t *op = a->an_pos.data() + pat, *oo = a->an_off.data() + at + 1;
-            for (size_t k = 0; k < na; k++) { ol[k] = pl[k]; op[2 * k] = pa[k]; op[2 * k + 1] = pb[k]; oo[k] = (int64_t)(pat + 2 * (k + 1)); }
+            a->leaf_na = na;
         }
         if (a->trace_on && cnt[1]) {
             const size_t at = a->trace.size();
@@ -1629,7 +1630,7 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
         a->full_only = !a->trace_on;
-        a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear();
+        a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
         RV_TRY(builtin_leaf_setup(h));
     }
     RV_TRY(install_frontier(h, level, nsubs, meta, node_first, nodes, m, sa, lcp, bwt, on_device));
@@ -1921,15 +1922,22 @@ uint32_t rv_maxlcp(const rv_index *h) { return h->maxlcp; }
 
 int64_t rv_anchor_count(rv_index *h, int64_t *members) {
     if (need_align(h)) return -1;
-    if (members) *members = (int64_t)h->al->an_pos.size();
-    return (int64_t)h->al->an_l.size();
+    if (members) *members = (int64_t)(h->al->an_pos.size() + 2 * h->al->leaf_na);
+    return (int64_t)(h->al->an_l.size() + h->al->leaf_na);
 }
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos) {
     RV_TRY(need_align(h));
     Align *a = h->al;
-    memcpy(l, a->an_l.data(), a->an_l.size() * 4);
+    const size_t nl = a->an_l.size(), np = a->an_pos.size(), na = a->leaf_na;
+    memcpy(l, a->an_l.data(), nl * 4);
     memcpy(off, a->an_off.data(), a->an_off.size() * 8);
-    memcpy(pos, a->an_pos.data(), a->an_pos.size() * 8);
+    memcpy(pos, a->an_pos.data(), np * 8);
+    if (na) {      // the leaf launches' anchors, still in the pinned staging buffer (pos[2 na], l[na])
+        const int64_t *pp = a->hLeafOut.as<int64_t>(); const u32 *pl = (const u32 *)(pp + 2 * na);
+        memcpy(l + nl, pl, na * 4);
+        memcpy(pos + np, pp, na * 16);
+        for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1));
+    }
     return 0;
 }
 int64_t rv_trace_count(rv_index *h) { return h->al ? (int64_t)h->al->trace.size() : 0; }

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
         if (tid == 0) {
             my_splits++; my_bp += L;
             const u32 slot = atomicAdd(A.anchor_count, 1u);
-            if (slot < A.anchor_cap) { A.anchor_l[slot] = L; A.anchor_a[slot] = pa; A.anchor_b[slot] = pb; }
+            if (slot < A.anchor_cap) { A.anchor_l[slot] = L; A.anchor_pos[2 * (size_t)slot] = pa; A.anchor_pos[2 * (size_t)slot + 1] = pb; }
         }
         // ---- linear graphalign: lead = left remainders, trail = right remainders ------------------
         const int64_t la0 = f.a0, la1 = pa, lb0 = f.b0, lb1 = pb;                     // leading intervals (may be empty)

@@ -371,6 +371,7 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 extern "C" {
 
 static int early_split(rv_index *h);
+static int early_split_multi(rv_index *h);
 
 /* the leaf kernel of the current level (roots prepared by builtin_levels) on its own stream */
 static int leaf_launch(rv_index *h) {
@@ -511,6 +512,77 @@ static int early_split(rv_index *h) {
     return 0;
 }
 
+/* The same for more than two samples: decisions of the built-in callbacks on the device (rv_decide.hip, k_decide_multi) right behind
+ * the multi-sample picker, then the level's split -- it runs while the host receives the picks and rebuilds the same decisions
+ * for its own bookkeeping (thousands of sub-indices per level with ten samples: 30 of 163 ms at 10 x 5 Mbp with no kernel running). */
+static int early_split_multi(rv_index *h) {
+    Align *a = h->al;
+    hipStream_t q = h->ws.stream;
+    const Level &lv = a->lv;
+    const int ns = lv.size(), W = h->nsamples;
+    const int64_t m = lv.m, ntiles = ceil_div(m, RV_SPLIT_TILE);
+    const int nxt = (a->level == 0) ? 0 : (a->cur + 1) % RV_LEVEL_BUFS;
+    RV_TRY(a->dD.reserve((size_t)m + 64));
+    RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
+    RV_TRY(a->lvSA[nxt].reserve((size_t)(m + 64) * sizeof(sa_t)));
+    RV_TRY(a->lvLCP[nxt].reserve((size_t)(m + 64) * sizeof(lcp_t)));
+    RV_TRY(a->lvBWT[nxt].reserve((size_t)m + 64));
+    const size_t S = (size_t)ns;
+    size_t bytes = 0;
+    auto take = [&](size_t b) { const size_t o = (bytes + 15) & ~(size_t)15; bytes = o + b; return o; };
+    const size_t o_cb = take(2 * W * S * sizeof(sa_t)), o_ce = take(2 * W * S * sizeof(sa_t)), o_cc = take(2 * W * S), o_ctf = take((S + 1) * 4);
+    const size_t o_mb = take(W * S * sizeof(sa_t)), o_me = take(W * S * sizeof(sa_t)), o_mtf = take((S + 1) * 4);
+    const size_t o_cn = take(3 * S * 4), o_cbase = take(3 * S * 4), o_soff = take(3 * S * 4), o_exp = take(16), o_tot = take(16);
+    const size_t o_cf = take((S + 1) * 4), o_mf = take((S + 1) * 4), o_clo = take(W * S * sizeof(sa_t)), o_chi = take(W * S * sizeof(sa_t)), o_mp = take(W * S * sizeof(sa_t));
+    RV_TRY(a->dDec.reserve(bytes + 64));
+    uint8_t *db = a->dDec.as<uint8_t>();
+    RvDecideMultiArgs d;
+    d.nsubs = ns; d.W = W; d.minl = a->minl; d.minn = a->minn; d.lcap = h->maxlcp;
+    d.nodes = a->d_next_nodes; d.want = a->d_next_want;
+    // the picker's device buffers (rv_run_multi_pick, rv_api.hip)
+    d.pick_l = h->ws.misc[13].as<u32>(); d.pick_pos = h->ws.misc[7].as<sa_t>();
+    d.cand_count = h->ws.misc[1].as<u32>() + RV_MULTI_REGIONS * 64;
+    d.cand_cap = (u32)std::min<size_t>(h->ws.misc[8].cap / RV_MULTI_CAND_BYTES / RV_MULTI_REGIONS, 0xffffffffu);
+    d.ctab_first = (int *)(db + o_ctf); d.mtab_first = (int *)(db + o_mtf); d.cut_first = (int *)(db + o_cf); d.mend_first = (int *)(db + o_mf);
+    d.cb = (sa_t *)(db + o_cb); d.ce = (sa_t *)(db + o_ce); d.cc = db + o_cc; d.mb = (sa_t *)(db + o_mb); d.me = (sa_t *)(db + o_me);
+    d.cut_lo = (sa_t *)(db + o_clo); d.cut_hi = (sa_t *)(db + o_chi); d.mend_pos = (sa_t *)(db + o_mp);
+    d.child_n = (u32 *)(db + o_cn); d.child_base = (u32 *)(db + o_cbase); d.sub_off = (u32 *)(db + o_soff); d.expect_total = (u32 *)(db + o_exp);
+    d.err = a->dErr.as<u32>();
+    RV_TRY(rv_decide_multi_launch(h->ws, d));
+    RvLabelTabs &lt = a->e_lt;
+    lt.sub_start = a->d_next_ss; lt.nsubs = ns; lt.tile_sub = a->d_next_tsub;
+    lt.ctab_first = d.ctab_first; lt.cbegin = d.cb; lt.cend = d.ce; lt.ccls = d.cc;
+    lt.mtab_first = d.mtab_first; lt.mbegin = d.mb; lt.mend = d.me; lt.nmatch = W * ns;
+    RvSplitArgs &sa = a->e_sa;
+    u32 *tiles = a->dTile.as<u32>();
+    sa.ntiles = ntiles;
+    sa.tile_cnt = tiles; sa.tile_has = tiles + 3 * ntiles; sa.tile_post = tiles + 6 * ntiles;
+    sa.tile_G = tiles + 9 * ntiles; sa.tile_carry = tiles + 12 * ntiles;
+    sa.total = (u32 *)(db + o_tot);
+    sa.sub_start = lt.sub_start; sa.nsubs = ns; sa.tile_sub = lt.tile_sub;
+    sa.child_base = d.child_base; sa.child_n = d.child_n; sa.sub_off = d.sub_off; sa.expect_total = d.expect_total;
+    sa.cut_first = d.cut_first; sa.cut_lo = d.cut_lo; sa.cut_hi = d.cut_hi;
+    sa.mend_first = d.mend_first; sa.mend_pos = d.mend_pos; sa.mend_all = 0;
+    sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
+    sa.err = a->dErr.as<u32>();
+    {   // tile bounds for the data-parallel bubble rounds (see early_split)
+        int64_t big0 = 0;
+        for (int s2 = 0; s2 < ns; s2++) big0 = std::max<int64_t>(big0, lv.n[(size_t)s2]);
+        sa.tmin_out = nullptr;
+        if (big0 > a->par_min_cur) {
+            RV_TRY(a->dTmin.reserve((size_t)(m / RV_SPLIT_TILE + 2) * 4));
+            RV_HIP(hipMemsetAsync(a->dTmin.p, 0xFF, (size_t)(m / RV_SPLIT_TILE + 2) * 4, q));
+            sa.tmin_out = a->dTmin.as<u32>();
+        }
+    }
+    int id = h->prof.begin(q, RV_K_SPLIT, (double)m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m * (sizeof(sa_t) + sizeof(lcp_t) + 1));
+    RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), m, lt, sa, 1));
+    h->prof.end(q, id);
+    a->early_done = true;
+    a->early_bubble = false;
+    return 0;
+}
+
 /* rv_set_preselect: per sub-index the record numbers that go to mumpicker.  No match in every sample (schemes.py:229-232
  * goes on with segment() over all of them): the whole list, uncapped. */
 static void build_preselection(Align *a) {
@@ -585,7 +657,12 @@ int rv_frontier_scan(rv_index *h) {
         if (a->full_only && a->level > 0) {
             // built-in picker without tracing: the device returns, per sub-index, the match the picker would take (the tables
             // came with the previous commit's upload)
-            RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->d_next_tsub, a->pick_l, a->pick_pos));
+            a->early_done = false; a->early_bubble = false;
+            const bool early = a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
+            bool redo = false;
+            RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->d_next_tsub, a->pick_l, a->pick_pos,
+                                     early ? early_split_multi : nullptr, &redo));
+            if (redo) a->early_done = false;      // (the early split saw an overflowed candidate list and decided nothing: the commit splits again)
             a->ml.clear(); a->mn.clear(); a->moff.assign(1, 0); a->mso.clear(); a->mpos.clear();
             const int W = h->nsamples;
             for (int s2 = 0; s2 < ns; s2++) {
@@ -769,8 +846,27 @@ static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next) {
     Align *a = h->al;
     const int nsn = nx.size();
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
-    a->next_dev_ok = !a->multi && a->full_only && nsn > 0 && nsn <= RV_DECIDE_MAX_SUBS && m_next > 0;
-    if (a->next_dev_ok) {
+    a->next_dev_ok = a->full_only && nsn > 0 && nsn <= RV_DECIDE_MAX_SUBS && m_next > 0;
+    if (a->next_dev_ok && a->multi) {
+        // more than two samples: one (begin, end) slot per sample and sub-index; a sub-index with two intervals of one sample
+        // (multi-contig inputs) sends the level to the host path
+        const int W = h->nsamples;
+        a->next_dev_ok = W <= 64 && !getenv("RV_KEEP_DEAD") && !a->trace_on;
+        if (a->next_dev_ok) {
+            a->next_nodes.assign((size_t)nsn * 2 * W, 0); a->next_flags.assign((size_t)nsn, 0);
+            for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
+                sa_t *nd = a->next_nodes.data() + (size_t)s2 * 2 * W;
+                size_t sp = 0;
+                for (int64_t k = nx.node_first[(size_t)s2]; k < nx.node_first[(size_t)s2 + 1]; k++) {
+                    const RvIntv iv = nx.nodes[(size_t)k];
+                    while (sp < h->nsep.size() && h->nsep[sp] < iv.begin) sp++;         // (sorted by begin: the sample index only grows)
+                    if (iv.end <= iv.begin) continue;
+                    if (nd[2 * sp] < nd[2 * sp + 1]) { a->next_dev_ok = false; break; }      // a second interval of this sample
+                    nd[2 * sp] = (sa_t)iv.begin; nd[2 * sp + 1] = (sa_t)iv.end;
+                }
+            }
+        }
+    } else if (a->next_dev_ok) {
         a->next_nodes.assign((size_t)nsn * 4, 0); a->next_flags.assign((size_t)nsn, 0);
         const int64_t sep = h->nsep[0];
         for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
@@ -998,7 +1094,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     prep_level_tables(h, nx, m_next);
     size_t o_ntsub = 0, o_nnodes = 0, o_nflags = 0, o_ntsub2 = 0;
     if (a->multi) o_ntsub = pk.addv(a->next_tsub);
-    if (a->next_dev_ok) { o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = pk.addv(a->next_tsub); }
+    if (a->next_dev_ok) { o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = a->multi ? o_ntsub : pk.addv(a->next_tsub); }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign((size_t)ns * 3, 0);
     u32 class_total[4] = {0, 0, 0, 0};
@@ -1160,6 +1256,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         RV_HIP(hipMemcpyAsync(&err, a->dErr.p, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
         if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+        if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
     }
 
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */
@@ -1591,7 +1688,7 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
     const size_t o_ss = pk.addv(a->next_ss), o_want = pk.addv(lv.nsamples);
     size_t o_tsub = 0, o_nodes = 0, o_flags = 0, o_tsub2 = 0;
     if (a->multi) o_tsub = pk.addv(a->next_tsub);
-    if (a->next_dev_ok) { o_nodes = pk.addv(a->next_nodes); o_flags = pk.addv(a->next_flags); o_tsub2 = pk.addv(a->next_tsub); }
+    if (a->next_dev_ok) { o_nodes = pk.addv(a->next_nodes); o_flags = pk.addv(a->next_flags); o_tsub2 = a->multi ? o_tsub : pk.addv(a->next_tsub); }
     RV_TRY(a->dTab0.reserve(pk.size() + 64));
     if (pk.pageable) RV_HIP(hipMemcpyAsync(a->dTab0.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab0.p, pk.size())); }

@@ -553,7 +553,8 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 
 // built-in picker of the untraced recursion, more than two samples: one (l, members) per sub-index, picked on the device
 int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn,
-                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos) {
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos,
+                      int (*after_pick)(rv_index *), bool *redo) {
     pick_l.assign((size_t)nsubs, 0); pick_pos.clear();
     if (m <= 1 || nsubs <= 0) return 0;
     hipStream_t q = h->ws.stream;
@@ -580,12 +581,14 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
             RV_HIP(hipMemcpyAsync(hp + o1, bl.p, b1, hipMemcpyDeviceToHost, q));
             RV_HIP(hipMemcpyAsync(hp + o2, bpos.p, b2, hipMemcpyDeviceToHost, q));
             RV_HIP(hipEventRecord(h->ws.ev_rb, q));
+            if (attempt == 0 && after_pick) RV_TRY(after_pick(h));      // (queued behind the copies: the host gets the picks first)
             hipError_t qe;
             while ((qe = hipEventQuery(h->ws.ev_rb)) == hipErrorNotReady) {}
             if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; }
             memcpy(&ncand, hp, 4); memcpy(pick_l.data(), hp + o1, b1); memcpy(pick_pos.data(), hp + o2, b2);
         }
         if ((size_t)ncand <= ccap / RV_MULTI_REGIONS) return 0;
+        if (redo) *redo = true;
         RV_TRY(bcand.reserve(((size_t)ncand + ncand / 2 + 64) * RV_MULTI_REGIONS * RV_MULTI_CAND_BYTES));
     }
     rv_set_error("multi picker: candidate buffer sizing failed");

@@ -110,7 +110,141 @@ __global__ __launch_bounds__(1024) void k_decide_offsets(RvDecideArgs d) {
     if (threadIdx.x == 0) { d.expect_total[0] = s_run[0]; d.expect_total[1] = s_run[1]; d.expect_total[2] = 0; d.expect_total[3] = 0; }
 }
 
+// ---- more than two samples ---------------------------------------------------------------------------
+// the member of the pick that lies inside [b, e), or -1
+__device__ inline int64_t member_in(const RvDecideMultiArgs &d, int s, int want, sa_t b, sa_t e, sa_t l) {
+    int64_t p = -1;
+    for (int k = 0; k < want; k++) {
+        const sa_t x = d.pick_pos[(size_t)s * d.W + k];
+        if (x >= b && x + l <= e) p = (int64_t)x;
+    }
+    return p;
+}
+
+__global__ __launch_bounds__(TB) void k_decide_multi(RvDecideMultiArgs d) {
+    const int s = blockIdx.x * TB + threadIdx.x;
+    if (s > d.nsubs) return;
+    const int W = d.W;
+    d.ctab_first[s] = 2 * W * s; d.mtab_first[s] = W * s; d.cut_first[s] = W * s; d.mend_first[s] = W * s;
+    if (s == d.nsubs) return;
+    const sa_t *nd = d.nodes + (size_t)2 * W * s;
+    sa_t *cb = d.cb + (size_t)2 * W * s, *ce = d.ce + (size_t)2 * W * s;
+    uint8_t *cc = d.cc + (size_t)2 * W * s;
+    sa_t *mb = d.mb + (size_t)W * s, *me = d.me + (size_t)W * s;
+    sa_t *clo = d.cut_lo + (size_t)W * s, *chi = d.cut_hi + (size_t)W * s, *mend = d.mend_pos + (size_t)W * s;
+    u32 *cn = d.child_n + (size_t)3 * s;
+    const bool complete = *d.cand_count <= d.cand_cap;
+    const sa_t l = complete ? (sa_t)d.pick_l[s] : (sa_t)0;
+    const int want = d.want[s];
+    bool have = l > 0;
+    // pass 1: sizes and the "cannot hold another match" rule (child_is_dead of rv_frontier_commit, one interval per sample)
+    const int64_t need = d.minl > 1 ? d.minl : 1;
+    const int nsmin = d.minn > 2 ? d.minn : 2;
+    int64_t n0 = 0, n1 = 0, n2 = 0;
+    int c0 = 0, c1 = 0, c2 = 0, members = 0;
+    bool sh0 = false, sh1 = false, sh2 = false;
+    if (have) {
+        for (int q = 0; q < W; q++) {
+            const sa_t b = nd[2 * q], e = nd[2 * q + 1];
+            if (b >= e) continue;
+            const int64_t p = member_in(d, s, want, b, e, l);
+            if (p >= 0) {
+                members++;
+                const int64_t ll = p - b, tl = (int64_t)e - p - l;
+                if (ll > 0) { n0 += ll; c0++; sh0 |= ll < need; }
+                if (tl > 0) { n1 += tl; c1++; sh1 |= tl < need; }
+            } else {
+                n2 += (int64_t)e - b; c2++; sh2 |= ((int64_t)e - b) < need;
+            }
+        }
+        if (members != want) { atomicOr(d.err, 4u); have = false; }      // a member outside the intervals of its sub-index
+    }
+    if (!have) {
+        for (int k = 0; k < 2 * W; k++) { cb[k] = 0; ce[k] = 0; cc[k] = 0; }
+        for (int k = 0; k < W; k++) { mb[k] = 0; me[k] = 0; clo[k] = 0; chi[k] = 0; mend[k] = (sa_t)-1; }
+        cn[0] = cn[1] = cn[2] = 0;
+        return;
+    }
+    const bool dead0 = c0 > 0 && (sh0 || c0 < nsmin), dead1 = c1 > 0 && (sh1 || c1 < nsmin), dead2 = c2 > 0 && (sh2 || c2 < nsmin);
+    cn[0] = dead0 ? 0u : (u32)n0; cn[1] = dead1 ? 0u : (u32)n1; cn[2] = dead2 ? 0u : (u32)n2;
+    const uint8_t k0 = dead0 ? 3 : 1, k1 = dead1 ? 3 : 2, k2 = dead2 ? 3 : 4;
+    // pass 2: the tables, in text order (samples lie one behind the other); empty slots are empty intervals at the running position
+    const sa_t lcap = (sa_t)d.lcap;
+    sa_t cur = 0, curm = 0;
+    for (int q = 0; q < W; q++) {
+        const sa_t b = nd[2 * q], e = nd[2 * q + 1];
+        if (b >= e) {
+            cb[2 * q] = cur; ce[2 * q] = cur; cc[2 * q] = 0; cb[2 * q + 1] = cur; ce[2 * q + 1] = cur; cc[2 * q + 1] = 0;
+            mb[q] = curm; me[q] = curm; clo[q] = 0; chi[q] = 0; mend[q] = (sa_t)-1;
+            continue;
+        }
+        const int64_t pp = member_in(d, s, want, b, e, l);
+        if (pp >= 0) {
+            const sa_t p = (sa_t)pp;
+            cb[2 * q] = b; ce[2 * q] = p; cc[2 * q] = k0;
+            cb[2 * q + 1] = p + l; ce[2 * q + 1] = e; cc[2 * q + 1] = k1;
+            mb[q] = p; me[q] = p + l; curm = p + l;
+            clo[q] = p > b ? (p - lcap > b ? p - lcap : b) : p; chi[q] = p;
+            mend[q] = p + l;
+        } else {
+            cb[2 * q] = b; ce[2 * q] = e; cc[2 * q] = k2;
+            cb[2 * q + 1] = e; ce[2 * q + 1] = e; cc[2 * q + 1] = 0;
+            mb[q] = curm > b ? curm : b; me[q] = mb[q]; curm = mb[q];
+            clo[q] = 0; chi[q] = 0; mend[q] = (sa_t)-1;
+        }
+        cur = e;
+    }
+}
+
+// child offsets for three classes: running offset over (sub-index, class), class totals in front of every sub-index; one block
+__global__ __launch_bounds__(1024) void k_decide_offsets3(RvDecideMultiArgs d) {
+    __shared__ u32 s_w[16][3];
+    __shared__ u32 s_run[3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (threadIdx.x < 3) s_run[threadIdx.x] = 0;
+    __syncthreads();
+    for (int base = 0; base < d.nsubs; base += 1024) {
+        const int s = base + threadIdx.x;
+        u32 c[3] = {0, 0, 0};
+        if (s < d.nsubs) { c[0] = d.child_n[3 * (size_t)s]; c[1] = d.child_n[3 * (size_t)s + 1]; c[2] = d.child_n[3 * (size_t)s + 2]; }
+        u32 i[3] = {c[0], c[1], c[2]};
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const u32 t = __shfl_up(i[k], dd, 64); if (lane >= dd) i[k] += t; }
+        }
+        if (lane == 63) { s_w[w][0] = i[0]; s_w[w][1] = i[1]; s_w[w][2] = i[2]; }
+        __syncthreads();
+        u32 g[3], tot[3];
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            u32 b = s_run[k], t = 0;
+            for (int v = 0; v < 16; v++) { if (v < w) b += s_w[v][k]; t += s_w[v][k]; }
+            g[k] = b + i[k] - c[k];                                   // class-k ranks in front of sub-index s
+            tot[k] = t;
+        }
+        if (s < d.nsubs) {
+            const u32 lead_base = g[0] + g[1] + g[2], trail_base = lead_base + c[0], rest_base = trail_base + c[1];
+            d.child_base[3 * (size_t)s] = lead_base; d.child_base[3 * (size_t)s + 1] = trail_base; d.child_base[3 * (size_t)s + 2] = rest_base;
+            d.sub_off[3 * (size_t)s] = lead_base - g[0]; d.sub_off[3 * (size_t)s + 1] = trail_base - g[1]; d.sub_off[3 * (size_t)s + 2] = rest_base - g[2];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { s_run[0] += tot[0]; s_run[1] += tot[1]; s_run[2] += tot[2]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { d.expect_total[0] = s_run[0]; d.expect_total[1] = s_run[1]; d.expect_total[2] = s_run[2]; d.expect_total[3] = 0; }
+}
+
 }  // namespace
+
+int rv_decide_multi_launch(Workspace &ws, const RvDecideMultiArgs &d) {
+    if (d.nsubs <= 0) return 0;
+    hipLaunchKernelGGL(k_decide_multi, dim3((unsigned)ceil_div((int64_t)d.nsubs + 1, TB)), dim3(TB), 0, ws.stream, d);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_decide_offsets3, dim3(1), dim3(1024), 0, ws.stream, d);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
 
 int rv_decide_launch(Workspace &ws, const RvDecideArgs &d) {
     if (d.nsubs <= 0) return 0;

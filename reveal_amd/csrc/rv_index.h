@@ -99,8 +99,12 @@ struct rv_index {
 
 // scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)
 // d_err (optional): device word copied into the scan header and returned through err_out (deferred error check of the previous commit)
+// after_pick (optional): called once the picker kernels and the copy of the picks are queued, before the host waits for them; it
+// may queue work that needs nothing but the picks on the device (the level's split with device-side decisions).  *redo is set
+// when the picks had to be computed a second time (candidate list grown): whatever the hook queued saw incomplete picks
 int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, int minn,
-                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos);
+                      const int64_t *d_sub_start, const int *d_sub_want, int nsubs, const int *d_tile_sub, std::vector<u32> &pick_l, std::vector<sa_t> &pick_pos,
+                      int (*after_pick)(rv_index *) = nullptr, bool *redo = nullptr);
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
                      const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs,   // d_sub_start != NULL: only the best record per sub-index
                      int (*after_pick)(rv_index *), bool use_hook,

@@ -130,14 +130,17 @@ int rv_inclusive_max_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n) { re
 // ---------------------------------------------------------------------------
 namespace {
 
-constexpr int RS_THREADS = 256;
+#ifndef RV_RS_THREADS
+#define RV_RS_THREADS 256      // (512 x 16 = 8192 keys per block -- a digit's run in the output twice as long -- measures the same: 89 ms of SA build at 5e8 either way)
+#endif
+constexpr int RS_THREADS = RV_RS_THREADS;
 constexpr int RS_ITEMS   = 16;
 constexpr int RS_TILE    = RS_THREADS * RS_ITEMS;
 constexpr int RS_WAVES   = RS_THREADS / 64;
 
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, int64_t n, int shift, u32 *__restrict__ blockhist, u32 nblocks) {
     __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    if (threadIdx.x < 256) h[threadIdx.x] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll
@@ -146,7 +149,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
         if (i < n) atomicAdd(&h[(u32)(keys[i] >> shift) & 255u], 1u);
     }
     __syncthreads();
-    blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    if (threadIdx.x < 256) blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
 }
 
 template <class V>
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     __shared__ V sval[RS_TILE];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int k = threadIdx.x; k < RS_WAVES * 256; k += RS_THREADS) (&cnt[0][0])[k] = 0;
-    gbase[threadIdx.x] = blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    if (threadIdx.x < 256) gbase[threadIdx.x] = blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
     __syncthreads();
 
     const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
@@ -187,8 +190,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         rnk[r] = old + below;
     }
     __syncthreads();
-    u32 mytot;
-    {   // exclusive prefix over the waves of this block, per digit; mytot = the block's count of digit threadIdx.x
+    u32 mytot = 0;
+    if (threadIdx.x < 256) {   // exclusive prefix over the waves of this block, per digit; mytot = the block's count of digit threadIdx.x
         const int d = threadIdx.x;
         u32 run = 0;
 #pragma unroll
@@ -200,15 +203,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     // every store of a wave hit up to 64 different sectors: 200 us per pass for 1e7 keys where the well-clustered top
     // digit took 55.)
     {
-        u32 inc = mytot;
+        u32 inc = mytot;       // (the digits live in the first four waves)
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) { const u32 t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
-        if (lane == 63) wtot[w] = inc;
+        if (lane == 63 && w < 4) wtot[w] = inc;
         __syncthreads();
-        u32 before = 0;
+        if (threadIdx.x < 256) {
+            u32 before = 0;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) if (k < w) before += wtot[k];
-        dstart[threadIdx.x] = before + inc - mytot;
+            for (int k = 0; k < 4; k++) if (k < w) before += wtot[k];
+            dstart[threadIdx.x] = before + inc - mytot;
+        }
     }
     __syncthreads();
 #pragma unroll

@@ -534,9 +534,11 @@ static int early_split_multi(rv_index *h) {
     const size_t o_mb = take(W * S * sizeof(sa_t)), o_me = take(W * S * sizeof(sa_t)), o_mtf = take((S + 1) * 4);
     const size_t o_cn = take(3 * S * 4), o_cbase = take(3 * S * 4), o_soff = take(3 * S * 4), o_exp = take(16), o_tot = take(16);
     const size_t o_cf = take((S + 1) * 4), o_mf = take((S + 1) * 4), o_clo = take(W * S * sizeof(sa_t)), o_chi = take(W * S * sizeof(sa_t)), o_mp = take(W * S * sizeof(sa_t));
+    const size_t o_kid = take(S * sizeof(RvBubbleDesc));
     RV_TRY(a->dDec.reserve(bytes + 64));
     uint8_t *db = a->dDec.as<uint8_t>();
     RvDecideMultiArgs d;
+    d.kid = (RvBubbleDesc *)(db + o_kid);
     d.nsubs = ns; d.W = W; d.minl = a->minl; d.minn = a->minn; d.lcap = h->maxlcp;
     d.nodes = a->d_next_nodes; d.want = a->d_next_want;
     // the picker's device buffers (rv_run_multi_pick, rv_api.hip)
@@ -580,6 +582,42 @@ static int early_split_multi(rv_index *h) {
     h->prof.end(q, id);
     a->early_done = true;
     a->early_bubble = false;
+    // No sub-index above the rounds' threshold: lower-casing and the bubble of every leading child follow at once, from the
+    // device-built descriptors (all size classes: LDS kernels and one-workgroup kernels on their own streams, as the host-built
+    // launches of rv_frontier_commit) -- the whole level is queued before the host has seen the picks.
+    int64_t biggest = 0;
+    for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
+    if (biggest <= a->par_min_cur && !getenv("RV_NO_EARLY_BUBBLE")) {
+        RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, W * ns));
+        {
+            const void *before = a->dFlag.p;
+            RV_TRY(a->dFlag.reserve((size_t)m + 64));
+            if (!a->flag_clean || a->dFlag.p != before) { RV_HIP(hipMemsetAsync(a->dFlag.p, 0, a->dFlag.cap, q)); a->flag_clean = true; }
+        }
+        RvBubbleArgs ba;
+        memset(&ba, 0, sizeof ba);
+        ba.flag = a->dFlag.as<uint8_t>();
+        ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = d.cut_lo; ba.cut_hi = d.cut_hi; ba.err = a->dErr.as<u32>();
+        if (!a->bub_stream) {
+            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
+            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
+        }
+        id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
+        RV_HIP(hipEventRecord(a->ev_fork, q));
+        RV_HIP(hipStreamWaitEvent(a->bub_stream, a->ev_fork, 0));
+        RV_HIP(hipStreamWaitEvent(a->bub_stream2, a->ev_fork, 0));
+        Workspace wl, wk; wl.stream = a->bub_stream; wk.stream = a->bub_stream2;
+        RV_TRY(rv_bubble_children_dev_classes_launch(wl, wk, ba, d.kid, ns, a->par_min_cur));
+        RV_HIP(hipEventRecord(a->ev_join, a->bub_stream));
+        RV_HIP(hipEventRecord(a->ev_join2, a->bub_stream2));
+        RV_HIP(hipStreamWaitEvent(q, a->ev_join, 0));
+        RV_HIP(hipStreamWaitEvent(q, a->ev_join2, 0));
+        h->prof.end(q, id);
+        a->early_bubble = true;
+    }
     return 0;
 }
 

@@ -51,5 +51,6 @@ struct RvDecideMultiArgs {
     u32 *child_n, *child_base, *sub_off;    // [3*nsubs]
     u32 *expect_total;              // [4]
     u32 *err;
+    RvBubbleDesc *kid;              // [nsubs] leading child of every sub-index as a bubble descriptor (n = 0: nothing to do)
 };
 int rv_decide_multi_launch(Workspace &ws, const RvDecideMultiArgs &d);

@@ -227,6 +227,11 @@ __global__ __launch_bounds__(1024) void k_decide_offsets3(RvDecideMultiArgs d) {
             const u32 lead_base = g[0] + g[1] + g[2], trail_base = lead_base + c[0], rest_base = trail_base + c[1];
             d.child_base[3 * (size_t)s] = lead_base; d.child_base[3 * (size_t)s + 1] = trail_base; d.child_base[3 * (size_t)s + 2] = rest_base;
             d.sub_off[3 * (size_t)s] = lead_base - g[0]; d.sub_off[3 * (size_t)s + 1] = trail_base - g[1]; d.sub_off[3 * (size_t)s + 2] = rest_base - g[2];
+            RvBubbleDesc kd; kd.off = (int64_t)lead_base; kd.B = 0; kd.wlo = 0; kd.cut0 = d.W * s; kd.cut1 = d.W * s + d.W;
+            bool win = false;
+            for (int q = 0; q < d.W; q++) win |= d.cut_lo[(size_t)d.W * s + q] < d.cut_hi[(size_t)d.W * s + q];
+            kd.n = win ? (int64_t)c[0] : 0;
+            d.kid[s] = kd;
         }
         __syncthreads();
         if (threadIdx.x == 0) { s_run[0] += tot[0]; s_run[1] += tot[1]; s_run[2] += tot[2]; }

@@ -119,7 +119,9 @@ int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *m
 int rv_bubble_children_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_small, int nsmall, const RvBubbleDesc *d_big, int nbig);
 int rv_lower_ranges_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, int nranges);
 int rv_bubble_children_dev_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n);
-int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count3);   // descriptors sorted by size class
+int rv_bubble_children_lds_launch(Workspace &ws, const RvBubbleArgs &b, const RvBubbleDesc *d_lds, const int *count3);
+// device-built descriptors (one per sub-index), every size class up to max_n: LDS kernels on ws_lds' stream, one-workgroup kernels on ws_kid's
+int rv_bubble_children_dev_classes_launch(Workspace &ws_lds, Workspace &ws_kid, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n);   // descriptors sorted by size class
 // one cut of every child in descriptors [first, first+count): data-parallel (rv_bubble.hip)
 // refresh_tmin: an earlier round of this level ran the sequential kernels on some of these children (they do not keep the tile
 // bounds): lower the bounds to the values now in place first

@@ -1079,7 +1079,7 @@ __global__ __launch_bounds__(NT) void k_bubble_apply(RvBubbleArgs b, int first) 
 // their cuts independently of each other, instead of every round waiting for the
 // slowest child of the level.
 template <int NT, int EL>
-__global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc, int64_t max_n) {
+__global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc, int64_t max_n, int64_t min_n = 0) {
     __shared__ u32 lst[BB_CAP];
     __shared__ int64_t s_v[4];
     __shared__ int s_max[2 * (NT / 64)];
@@ -1088,7 +1088,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
     __shared__ ParScratch ps;
     __shared__ u32 s_first, s_cnt;
     RvBubbleDesc ds = cdesc[blockIdx.x];
-    if (ds.n <= 0 || ds.n > max_n) return;      // device-built descriptor arrays hold one entry per sub-index: empty ones, and children the rounds take
+    if (ds.n <= min_n || ds.n > max_n) return;      // device-built descriptor arrays hold one entry per sub-index: empty ones, children of another size class, children the rounds take
     {
         const int nc = ds.cut1 - ds.cut0 < BB_MAXCUT ? ds.cut1 - ds.cut0 : BB_MAXCUT;
         if ((int)threadIdx.x < nc) { cw.lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw.hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
@@ -1223,7 +1223,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child(RvBubbleArgs b, const RvBub
 // of a small child cost ~150 us however little it moved -- with many samples a level has tens of thousands of such cuts.
 // The windowed SAi is not needed here (the actives are found by reading the child) and is not kept up.
 template <int NT, int EL, int N, int CH>
-__global__ __launch_bounds__(NT) void k_bubble_child_lds(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc) {
+__global__ __launch_bounds__(NT) void k_bubble_child_lds(RvBubbleArgs b, const RvBubbleDesc *__restrict__ cdesc, int64_t min_n = 0, int64_t max_n = (int64_t)1 << 62) {
     __shared__ __attribute__((aligned(16))) sa_t sSA[N];
     __shared__ __attribute__((aligned(16))) lcp_t sLCP[N];
     __shared__ __attribute__((aligned(16))) uint8_t sBW[N];
@@ -1235,6 +1235,7 @@ __global__ __launch_bounds__(NT) void k_bubble_child_lds(RvBubbleArgs b, const R
     __shared__ ParScratchT<CH> ps;
     __shared__ u32 s_first;
     RvBubbleDesc ds = cdesc[blockIdx.x];
+    if (ds.n <= min_n || ds.n > max_n) return;   // (device-built descriptor arrays: one entry per sub-index, every size class looks at all of them)
     const int cut0 = ds.cut0, cut1 = ds.cut1;
     ds.cut0 = ds.cut1 = 0;                       // no SAi upkeep inside the visits
     if (threadIdx.x == 0) cw.n = 0;
@@ -1354,6 +1355,28 @@ int rv_bubble_children_dev_launch(Workspace &ws, const RvBubbleArgs &b, const Rv
     if (count <= 0) return 0;
     hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3((unsigned)count), dim3(1024), 0, ws.stream, b, d_desc, max_n);
     RV_LAUNCH_CHECK();
+    return 0;
+}
+
+// one device-built descriptor per sub-index, all size classes: the LDS kernels on ws_lds, the one-workgroup kernels on ws_kid
+// (each launch covers every descriptor and leaves those of another class at once); children above max_n are left to the rounds
+int rv_bubble_children_dev_classes_launch(Workspace &ws_lds, Workspace &ws_kid, const RvBubbleArgs &b, const RvBubbleDesc *d_desc, int count, int64_t max_n) {
+    if (count <= 0) return 0;
+    const unsigned g = (unsigned)count;
+    hipLaunchKernelGGL((k_bubble_child_lds<128, 1, RV_BUBBLE_LDS_N0, 1024>), dim3(g), dim3(128), 0, ws_lds.stream, b, d_desc, (int64_t)0, (int64_t)RV_BUBBLE_LDS_N0);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_bubble_child_lds<256, 1, RV_BUBBLE_LDS_N1, 1024>), dim3(g), dim3(256), 0, ws_lds.stream, b, d_desc, (int64_t)RV_BUBBLE_LDS_N0, (int64_t)RV_BUBBLE_LDS_N1);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL((k_bubble_child_lds<256, 1, RV_BUBBLE_LDS_N2, 2048>), dim3(g), dim3(256), 0, ws_lds.stream, b, d_desc, (int64_t)RV_BUBBLE_LDS_N1, (int64_t)RV_BUBBLE_LDS_N2);
+    RV_LAUNCH_CHECK();
+    if (max_n > RV_BUBBLE_LDS_N2) {
+        hipLaunchKernelGGL((k_bubble_child<256, 1>), dim3(g), dim3(256), 0, ws_kid.stream, b, d_desc, std::min<int64_t>(max_n, RV_BUBBLE_BIG_N), (int64_t)RV_BUBBLE_LDS_N2);
+        RV_LAUNCH_CHECK();
+    }
+    if (max_n > RV_BUBBLE_BIG_N) {
+        hipLaunchKernelGGL((k_bubble_child<1024, 4>), dim3(g), dim3(1024), 0, ws_kid.stream, b, d_desc, max_n, (int64_t)RV_BUBBLE_BIG_N);
+        RV_LAUNCH_CHECK();
+    }
     return 0;
 }
 

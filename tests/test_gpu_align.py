@@ -239,3 +239,24 @@ def test_python_callbacks_same_anchors():
     assert idx.T.encode("latin-1") == ref["T"]
     with pytest.raises(TypeError):
         idx.SA            # main SA/LCP are gone after align (reveal.c:1279-1284)
+
+
+@pytest.mark.parametrize("env", ["RV_NO_EARLY_SPLIT", "RV_NO_EARLY_BUBBLE"])
+@pytest.mark.parametrize("name,inputs", [("1a1b1c", fa("1a", "1b", "1c")), ("synth12", (30000, 12)), ("synth5_big", (400000, 5))])
+def test_untraced_multi_host_paths(monkeypatch, name, inputs, env):
+    """more than two samples, untraced: the level's split (and, without round-sized children, lower-casing and bubble) are queued from
+    decisions taken on the device (rv_decide.hip k_decide_multi) while the host rebuilds them; with the switches the host-built
+    tables drive the same kernels -- same anchors, same text, equal to the oracle's"""
+    monkeypatch.setenv(env, "1")
+    if isinstance(inputs, tuple):
+        inputs = [g.decode() for g in synth.genomes(inputs[0], inputs[1], seed=3)]
+    ref, T = oracle_run(inputs, 20, 2)
+    idx = feed(mod(False).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(20, 2, trace=False)
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    gl, goff, gpos = got["anchors"]
+    ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
+    assert ra == ga
+    assert idx.T.encode("latin-1") == ref["T"]

@@ -493,7 +493,7 @@ static int early_split(rv_index *h) {
     int64_t biggest = 0;
     for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
     // (a level that still has a sub-index above the rounds' threshold keeps the host-built mix of rounds and joined children)
-    if (ns <= 4096 && biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE")) {
+    if (biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE") && (ns <= 4096 || !getenv("RV_NO_EARLY_BUBBLE_MANY"))) {
         RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, 2 * ns));
         {
             const void *before = a->dFlag.p;
@@ -505,7 +505,28 @@ static int early_split(rv_index *h) {
         ba.flag = a->dFlag.as<uint8_t>();
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = d.cut_lo; ba.cut_hi = d.cut_hi; ba.err = a->dErr.as<u32>();
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
-        RV_TRY(rv_bubble_children_dev_launch(h->ws, ba, d.kid, ns, a->par_min_cur));
+        if (ns <= 4096) {
+            RV_TRY(rv_bubble_children_dev_launch(h->ws, ba, d.kid, ns, a->par_min_cur));
+        } else {
+            // thousands of sub-indices (the deep levels of large inputs): the size-class kernels, LDS-resident ones included, each on
+            // its own stream -- the host-built launches of rv_frontier_commit, minus the wait for the host's tables
+            if (!a->bub_stream) {
+                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
+                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+                RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
+                RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
+                RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
+            }
+            RV_HIP(hipEventRecord(a->ev_fork, q));
+            RV_HIP(hipStreamWaitEvent(a->bub_stream, a->ev_fork, 0));
+            RV_HIP(hipStreamWaitEvent(a->bub_stream2, a->ev_fork, 0));
+            Workspace wl, wk; wl.stream = a->bub_stream; wk.stream = a->bub_stream2;
+            RV_TRY(rv_bubble_children_dev_classes_launch(wl, wk, ba, d.kid, ns, a->par_min_cur));
+            RV_HIP(hipEventRecord(a->ev_join, a->bub_stream));
+            RV_HIP(hipEventRecord(a->ev_join2, a->bub_stream2));
+            RV_HIP(hipStreamWaitEvent(q, a->ev_join, 0));
+            RV_HIP(hipStreamWaitEvent(q, a->ev_join2, 0));
+        }
         h->prof.end(q, id);
         a->early_bubble = true;
     }

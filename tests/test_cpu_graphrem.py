@@ -125,3 +125,46 @@ def test_gfa_round_trip_without_an_index(tmp_path):
     spelled, G2 = C.spelled_by_file(fn)
     assert spelled == {"a": T[0:100].upper(), "b": T[101:201].upper()}
     assert len(G2.startnodes) == 1 and len(G2.endnodes) == 1                                   # one component: sentinels merged
+
+
+PLAN_WORKER = r"""
+import os, sys, json
+sys.path.insert(0, %r); sys.path.insert(0, os.path.join(%r, "oracle")); sys.path.insert(0, os.path.join(%r, "tests"))
+import torch.distributed as dist
+import pin_oracle as P
+from reveal_amd import align
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dist.init_process_group("gloo")
+files = sorted(os.path.join(%r, f) for f in os.listdir(%r) if f.endswith(".fa"))
+levels = align.sequential_plan(files, 2, output=os.path.join(%r, "prg"), tmpdir=%r)
+done = align.run_plan(levels, rank=rank, world=world, barrier=dist.barrier, indexmod=P.load_refmod(False))
+out = [None] * world
+dist.all_gather_object(out, [(lv, j) for lv, j, *_ in done])
+if rank == 0:
+    print(json.dumps({"plan": [len(j) for j in levels], "jobs_by_rank": out, "final": levels[-1][-1][1]}))
+dist.barrier(); dist.destroy_process_group()
+"""
+
+
+def test_plan_over_two_ranks_gloo(tmp_path, refmod):
+    """N > 1 for config 5's shape: the jobs of a level are independent `reveal rem` runs (reveal/align.py:45-53) -- job j of a level
+    belongs to rank j mod world, the GFA files are the only exchange, a barrier separates the levels.  Two gloo processes on the
+    CPU (index = the reference's own module); the final graph spells every input."""
+    import json
+    import subprocess
+    from helpers import ROOT
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d", "1e"])
+    want = C.input_sequences(files)
+    script = tmp_path / "plan_worker.py"
+    d = str(tmp_path)
+    script.write_text(PLAN_WORKER % (ROOT, ROOT, ROOT, d, d, d, d))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert r["plan"] == [2, 1, 1]
+    assert sorted(tuple(x) for x in r["jobs_by_rank"][0] + r["jobs_by_rank"][1]) == [(0, 0), (0, 1), (1, 0), (2, 0)]
+    assert [tuple(x) for x in r["jobs_by_rank"][1]] == [(0, 1)]                 # rank 1 took job 1 of level 0
+    spelled, _ = C.spelled_by_file(r["final"])
+    assert spelled == want

@@ -88,43 +88,6 @@ def test_bench_callbacks_contract():
     assert rem.linear_graphalign(idx, (30, 2, ((0, 90), (1, 150)))) is None    # would cross an interval end
 
 
-WORKER = r'''
-import os, sys, json
-sys.path.insert(0, %r)
-import torch, torch.distributed as dist
-from reveal_amd import synth
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-dist.init_process_group("gloo")
-seqs = synth.genomes(20000, 2, seed=42 + 1000 * rank)          # bench.py's per-rank shard: its own genome pair
-bases = sum(len(s) for s in seqs)
-elapsed = 0.5 + rank                                           # pretend timings
-t = torch.tensor([elapsed], dtype=torch.float64); dist.all_reduce(t, op=dist.ReduceOp.MAX)
-b = torch.tensor([float(bases)], dtype=torch.float64); dist.all_reduce(b, op=dist.ReduceOp.SUM)
-import hashlib
-h = torch.tensor([int(hashlib.sha256(seqs[0]).hexdigest()[:12], 16)], dtype=torch.int64)
-hs = [torch.zeros_like(h) for _ in range(world)]; dist.all_gather(hs, h)
-if rank == 0:
-    print(json.dumps({"tmax": t.item(), "bases": b.item(), "distinct_inputs": len({int(x.item()) for x in hs})}))
-dist.barrier(); dist.destroy_process_group()
-'''
-
-
-def test_two_rank_sharding_gloo(tmp_path):
-    """N>1 plumbing of bench.py on CPU: ranks take disjoint inputs (different seeds), no data-path
-    collective, value = sum of bases / max time"""
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29517")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29517", str(script)], capture_output=True, text=True, env=env, timeout=300)
-    assert out.returncode == 0, out.stderr[-2000:]
-    line = [x for x in out.stdout.splitlines() if x.startswith("{")][-1]
-    r = json.loads(line)
-    assert r["tmax"] == 1.5 and r["bases"] == 80000.0 and r["distinct_inputs"] == 2
-
-
-# ---- one alignment divided over ranks (reveal_amd/shard.py): pure parts + the exchange protocol with a stand-in index
-
 def test_shard_partition_subset_merge_lower():
     from reveal_amd import shard
     sizes = [5, 100, 7, 40, 40, 1, 60]

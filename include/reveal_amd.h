@@ -61,7 +61,10 @@ int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so
  * safile / lcpfile (may be NULL or ""): raw native-endian saidx_t[n] / lcp_t[n]
  * read instead of computed (interface.c:224-232, 255-263).  cache!=0 writes
  * .reveal.t/.reveal.sa/.reveal.lcp to the CWD (interface.c:182-189, 274-285).
- * On return T, SA, SAi and LCP live in HBM. */
+ * On return T, SA and LCP live in HBM (the inverse SAi is made when something asks for it: the RV_SAI getter, rv_clone,
+ * rv_sx_main, rv_align_begin).  Both libraries carry ranks, child sizes and scan records in 32 bits: an index of
+ * n >= 2^32 - 2 positions is refused here, whatever the width of saidx_t and wherever SA comes from (built, or read from
+ * safile, which is range- and permutation-checked on the device before anything scatters through it). */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache);
 /* Copies the assembled text to HBM now (construct does it on demand).  Lets a
  * caller keep the host->device copy out of a timed construct(); repeated

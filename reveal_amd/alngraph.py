@@ -170,21 +170,23 @@ class AlnGraph:
         """rem.py:228-258: walk from `source` over edges carried by at least one real (non-'*') path; unaligned nodes are
         walked through (kind 0), aligned nodes stop the walk (kind 1) unless listed in `ignore`, sentinels stop it (kind 2)"""
         adj = self.pred if reverse else self.succ
+        aligned = self.aligned
+        star = any(p.startswith("*") for p in self.paths)      # (no '*' path at all: every edge is carried by a real one)
         visited = {source}
         queue = [source]
         qi = 0
         while qi < len(queue):
             parent = queue[qi]
             qi += 1
-            seen_here = set()
-            for (child, a, b), p in adj[parent].items():
-                if child in visited or child in seen_here or not self._real(p):
+            for key, p in adj[parent].items():
+                child = key[0]
+                if child in visited or (star and not self._real(p)):
                     continue
-                seen_here.add(child)
                 visited.add(child)
-                if child not in self.aligned:
+                al = aligned.get(child)
+                if al is None:
                     yield child, 2
-                elif self.aligned[child] == 0 or child in ignore:
+                elif al == 0 or child in ignore:
                     queue.append(child)
                     yield child, 0
                 else:
@@ -192,8 +194,21 @@ class AlnGraph:
 
     def segmentgraph(self, node, nodes):
         """rem.py:260-316: of the sub-index' intervals `nodes`, those behind the merged node (trailing: reachable forward
-        through unaligned nodes, and -- when the walk ends at several places -- also reachable backward from each of them),
-        those in front of it (leading, mirrored), and the rest"""
+        through unaligned nodes), those in front of it (leading, mirrored), and the rest.
+
+        The reference follows each walk, when it ended at more than one place, by a walk back from every end point and
+        intersects (rem.py:282-287, 303-308).  That second step never removes anything: a node of the forward walk goes on,
+        through unaligned nodes, to the first aligned node or sentinel on its way -- which the forward walk also reached and
+        listed as an end point -- so the walk back from that end point finds it.  It is left out here (it tripled the cost of
+        a call, and a merge of graphs spends nearly all its time in these walks); `segmentgraph_literal` keeps the reference's
+        form, tests/test_cpu_graphrem.py runs both on every call of the fixture alignments."""
+        nodes = set(nodes)
+        trailing = {c for c, t in self._bfs(node) if t == 0 and isinstance(c, tuple)} & nodes
+        leading = {c for c, t in self._bfs(node, reverse=True) if t == 0 and isinstance(c, tuple)} & nodes
+        return leading, trailing, nodes - (leading | trailing)
+
+    def segmentgraph_literal(self, node, nodes):
+        """rem.py:260-316 step by step (with the walks back from the end points)"""
         nodes = set(nodes)
 
         def side(reverse):

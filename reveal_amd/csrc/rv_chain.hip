@@ -29,9 +29,18 @@ int64_t gapcost(const int64_t *a, const int64_t *b, int k, int model, std::vecto
         std::sort(D.begin(), D.end());
         return D[(size_t)(k / 2)];
     }
-    int64_t p = 0;               // sumofpairs: all pairwise differences of the per-path gaps
-    for (int i = 0; i < k; i++)
-        for (int j = i + 1; j < k; j++) { const int64_t d = D[(size_t)i] - D[(size_t)j]; p += d < 0 ? -d : d; }
+    // sumofpairs: all pairwise differences of the per-path gaps.  Sorted ascending, D[i] is added i times and subtracted
+    // k-1-i times: sum_{i<j} |D_i - D_j| = sum_i (2i - k + 1) D_(i) -- the same integer in O(k log k) instead of O(k^2)
+    // (a merge of four graphs of 25 genomes chains over 100 paths: the quadratic form was the whole job)
+    if (k <= 8) {
+        int64_t p = 0;
+        for (int i = 0; i < k; i++)
+            for (int j = i + 1; j < k; j++) { const int64_t d = D[(size_t)i] - D[(size_t)j]; p += d < 0 ? -d : d; }
+        return p;
+    }
+    std::sort(D.begin(), D.end());
+    int64_t p = 0;
+    for (int i = 0; i < k; i++) p += (int64_t)(2 * i - k + 1) * D[(size_t)i];
     return p;
 }
 

@@ -168,3 +168,25 @@ def test_plan_over_two_ranks_gloo(tmp_path, refmod):
     assert [tuple(x) for x in r["jobs_by_rank"][1]] == [(0, 1)]                 # rank 1 took job 1 of level 0
     spelled, _ = C.spelled_by_file(r["final"])
     assert spelled == want
+
+
+def test_segmentgraph_without_the_walks_back_is_the_reference_form(tmp_path, refmod, monkeypatch):
+    """every graphalign call of a pair, a three-way and a graph-of-graphs alignment: the walks back from the end points
+    (rem.py:282-287, 303-308) never change leading / trailing / rest"""
+    calls = [0]
+    fast = alngraph.AlnGraph.segmentgraph
+
+    def both(self, node, nodes):
+        a = fast(self, node, nodes)
+        b = self.segmentgraph_literal(node, nodes)
+        assert a == b
+        calls[0] += 1
+        return a
+    monkeypatch.setattr(alngraph.AlnGraph, "segmentgraph", both)
+    from reveal_amd import rem
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d"])
+    rem.graph_rem(files[:2], str(tmp_path / "ab.gfa"), indexmod=refmod)
+    rem.graph_rem(files[2:], str(tmp_path / "cd.gfa"), indexmod=refmod)
+    rem.graph_rem(files[:3], str(tmp_path / "abc.gfa"), indexmod=refmod)
+    rem.graph_rem([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], str(tmp_path / "abcd.gfa"), indexmod=refmod)
+    assert calls[0] > 1500

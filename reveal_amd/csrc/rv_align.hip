@@ -493,7 +493,9 @@ static int early_split(rv_index *h) {
     int64_t biggest = 0;
     for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
     // (a level that still has a sub-index above the rounds' threshold keeps the host-built mix of rounds and joined children)
-    if (biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE") && (ns <= 4096 || !getenv("RV_NO_EARLY_BUBBLE_MANY"))) {
+    // (ns > 4096 through the size-class launches below: tried at 2 x 250 Mbp, 304 against 300 ms -- five launches over every
+    // descriptor cost more GPU time than the hidden host time is worth; RV_EARLY_BUBBLE_MANY=1 switches it on)
+    if (biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE") && (ns <= 4096 || getenv("RV_EARLY_BUBBLE_MANY"))) {
         RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, 2 * ns));
         {
             const void *before = a->dFlag.p;

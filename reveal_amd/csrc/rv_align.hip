@@ -394,7 +394,7 @@ static int leaf_launch(rv_index *h) {
     a->roots_inflight[leaf_flip] = true;
     RvLeafArgs la;
     la.roots = droots.as<RvLeafRoot>();
-    la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h); la.T = h->dT.as<uint8_t>();
+    la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h);
     la.nsep0 = h->nsep[0]; la.minl = a->minl; la.lcap = h->maxlcp;
     la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_pos = a->lf_pos;
     la.stats = a->lf_stats;
@@ -1582,15 +1582,18 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
         RV_TRY(a->hLeafOut.reserve(256));
         RV_HIP(hipMemcpyAsync(a->hLeafOut.p, lf_counters, 128, hipMemcpyDeviceToHost, q));      // counters at +0, statistics at +64
         RV_HIP(hipStreamSynchronize(q));
-        u32 cnt[4]; unsigned long long stv[4];
+        u32 cnt[4]; unsigned long long stv[8];
         memcpy(cnt, a->hLeafOut.p, sizeof cnt); memcpy(stv, a->hLeafOut.as<uint8_t>() + 64, sizeof stv);
-        if (cnt[2]) { rv_set_error("leaf kernel: recursion stack overflow"); return -1; }
+        if (getenv("RV_LEAF_PROF"))      // (a build with -DRV_LEAF_PROF: wave cycles waiting for a sub-index / scan + pick / split / bubble + children)
+            fprintf(stderr, "leaf: steps %llu splits %llu | cycles idle %llu scan %llu split %llu bubble %llu\n", stv[0], stv[1], stv[4], stv[5], stv[6], stv[7]);
+        if (cnt[2]) { rv_set_error(cnt[2] & 4u ? "leaf kernel: recursion stack overflow" : "leaf kernel: a sub-index does not match its intervals"); return -1; }
         if (cnt[0] > a->leaf_anchor_cap || cnt[1] > a->leaf_trace_cap) { rv_set_error("leaf kernel: output buffer too small"); return -1; }
         a->leaf_na = 0;
         if (cnt[0]) {
             // the anchors stay in the pinned buffer in the layout rv_fetch_anchors hands out (2 x 10^6 of them at 2 x 250 Mbp: appending
             // them to the host vectors one by one cost 5 ms per run, most of it page faults of the freshly grown vectors)
             const size_t na = cnt[0];
+            RV_TRY(rv_leaf_lower_launch(h->ws, h->dT.as<uint8_t>(), lf_pos, lf_l, (u32)na));      // their matched text (nothing read it during the run)
             RV_TRY(a->hLeafOut.reserve(na * 20 + 64));
             int64_t *pp = a->hLeafOut.as<int64_t>(); u32 *pl = (u32 *)(pp + 2 * na);
             RV_HIP(hipMemcpyAsync(pp, lf_pos, na * 16, hipMemcpyDeviceToHost, q));

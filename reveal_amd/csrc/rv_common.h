@@ -79,6 +79,29 @@ __device__ inline u32 rv_wave_min_u32(u32 v) {
 }
 #endif
 
+#ifdef __HIPCC__
+// One step of a wave-wide inclusive scan by DPP: the value of the lane `shift` lanes below inside a 16-lane row (row_shr), of
+// lane 15 of the previous row (row_bcast:15 into rows 1 and 3), of lane 31 (row_bcast:31 into rows 2 and 3).  `take` says
+// whether this lane has such a source: Hillis-Steele inside the rows (shifts 1, 2, 4, 8), then the two broadcasts --
+// six DPP moves per scanned word where __shfl_up needs six trips through the LDS crossbar.
+template <int CTRL, int ROWMASK> __device__ inline u32 rv_dpp_u32(u32 x) { return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, ROWMASK, 0xf, false); }
+#define RV_WAVE_SCAN_STEPS(STEP)                                                     \
+    STEP(0x111, 0xf, (lane & 15) >= 1)                                               \
+    STEP(0x112, 0xf, (lane & 15) >= 2)                                               \
+    STEP(0x114, 0xf, (lane & 15) >= 4)                                               \
+    STEP(0x118, 0xf, (lane & 15) >= 8)                                               \
+    STEP(0x142, 0xa, (lane & 31) >= 16)                                              \
+    STEP(0x143, 0xc, lane >= 32)
+// inclusive prefix sum over the wave
+__device__ inline u32 rv_wave_incl_sum_u32(u32 v) {
+    const int lane = threadIdx.x & 63;
+#define RV_STEP_(CTRL, RM, TAKE) { const u32 t = rv_dpp_u32<CTRL, RM>(v); v += (TAKE) ? t : 0u; }
+    RV_WAVE_SCAN_STEPS(RV_STEP_)
+#undef RV_STEP_
+    return v;
+}
+#endif
+
 // Grow-only device buffer.
 struct DBuf {
     void  *p = nullptr;

@@ -17,7 +17,6 @@ struct RvLeafRoot {
 struct RvLeafArgs {
     const RvLeafRoot *roots;
     const sa_t *SA; const lcp_t *LCP; const uint8_t *BWT;   // current level arrays (read only)
-    uint8_t *T;                                              // working text (matched ranges are lower-cased)
     int64_t nsep0;
     int minl;
     u32 lcap;                                                // bound on every LCP value (max LCP of the main index)
@@ -29,3 +28,5 @@ struct RvLeafArgs {
 };
 
 int rv_leaf_launch(Workspace &ws, const RvLeafArgs &a, int nroots);
+// lower-cases the matched text of the anchors the leaf launches wrote (reveal.c:1230-1234), once, when the run ends
+int rv_leaf_lower_launch(Workspace &ws, uint8_t *T, const int64_t *pos, const u32 *len, u32 na);

@@ -3,7 +3,8 @@
 // The recursion of aligner() (reveallib/reveal.c:731-1338) produces ~10^5
 // sub-indices per 10 Mbp, most of a few hundred ranks.  Once a sub-index of a
 // two-sample alignment has at most RV_LEAF_N ranks, its whole sub-tree is
-// finished here by one workgroup, depth first, with the arrays in LDS:
+// finished here by one workgroup with the arrays in LDS -- one wavefront per sub-index, the waves of the workgroup taking
+// sub-indices of the root's tree from a shared stack, no workgroup barrier in between:
 //   scan   getmums_rem predicate                      reveal.c:119-180
 //   pick   built-in picker (longest full match, ties -> smallest coordinate)
 //   split  D-label + stable partition + running-min LCP + lower-casing   reveal.c:1005-1234, 582-664
@@ -13,15 +14,19 @@
 // callbacks (rv_align_builtin), never when Python callbacks drive the recursion.
 #include "rv_common.h"
 #include "rv_leaf.h"
+#include <type_traits>
 
 namespace {
 
 constexpr int NT = 256;
 constexpr int LN = RV_LEAF_N;
 constexpr u32 INF = 0xFFFFFFFFu;
-constexpr int MAXSTACK = 256;
+constexpr int NW = NT / 64;
+constexpr int MAXSTACK = 128;
+constexpr int ACAP = 256;            // anchors staged per workgroup (a root of 2048 ranks holds ~5 at minl 20)
 
-struct Frame { int start, len, depth; int64_t a0, a1, b0, b1; };   // sample-0 interval [a0,a1), sample-1 interval [b0,b1); empty if a0>=a1
+typedef std::make_unsigned<sa_t>::type usa_t;      // positions compared in their own width (32 bits in reveallib)
+struct Frame { int start, len, depth, buf; int64_t a0, a1, b0, b1; };   // sample-0 interval [a0,a1), sample-1 interval [b0,b1); empty if a0>=a1
 
 __device__ inline bool is_lower_c(uint8_t c) { return c >= 'a' && c <= 'z'; }
 __device__ inline bool left_maximal(uint8_t ca, uint8_t cb) { return (ca != cb) || ca == 'N' || ca == '$' || is_lower_c(ca); }
@@ -34,166 +39,179 @@ __device__ inline u64 hash_step(u64 acc, u64 i, int64_t v) {      // oracle/reve
     return acc + x;
 }
 
-// block-wide reductions / scans over one value per thread (NT threads, 4 waves)
-__device__ inline u64 block_max_u64(u64 v, u64 *lds) {
-    for (int d = 32; d >= 1; d >>= 1) { const u64 o = ((u64)__shfl_down((u32)(v >> 32), d, 64) << 32) | __shfl_down((u32)v, d, 64); v = o > v ? o : v; }
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-    __syncthreads();
-    u64 r = lds[0];
-    for (int k = 1; k < NT / 64; k++) r = lds[k] > r ? lds[k] : r;
-    __syncthreads();
+// ---- wave-level collectives (DPP, rv_common.h) ------------------------------------------
+// Every sub-index is processed by ONE wavefront: no workgroup barrier inside the recursion, the four waves of a workgroup
+// work on different sub-indices of the same root (disjoint rank ranges of the LDS arrays).
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ inline u64 wave_max_u64(u64 v) {
+#define LF_STEP_(CTRL, RM, TAKE) { const u64 t = ((u64)rv_dpp_u32<CTRL, RM>((u32)(v >> 32)) << 32) | rv_dpp_u32<CTRL, RM>((u32)v); v = t > v ? t : v; }
+    RV_WAVE_SCAN_STEPS(LF_STEP_)        // (a lane without a source lane sees 0: the identity)
+#undef LF_STEP_
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
+}
+__device__ inline u64 wave_sum_u64(u64 v) {       // trace mode only
+    for (int d = 32; d >= 1; d >>= 1) v += ((u64)__shfl_xor((u32)(v >> 32), d, 64) << 32) | __shfl_xor((u32)v, d, 64);
+    return v;
+}
+__device__ inline u32 lanes_below(u64 mask) { return __builtin_amdgcn_mbcnt_hi((u32)(mask >> 32), __builtin_amdgcn_mbcnt_lo((u32)mask, 0u)); }
+// the value of the lane below (lane 0: `first`)
+__device__ inline u32 from_lane_below(u32 x, u32 first) { return (u32)__builtin_amdgcn_update_dpp((int)first, (int)x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false); }
+
+// Running minimum of the LCP values since the last rank of class 0 / class 1 (reveal.c:582-664 keeps one running minimum per
+// child): has = bit k set once a rank of class k was seen, v[k] = minimum since then.  Inclusive scan over the wave.
+struct MinSt2 { u32 has, v0, v1; };
+__device__ inline MinSt2 ms2_combine(MinSt2 a, MinSt2 b) {      // a, then b
+    MinSt2 r; r.has = a.has | b.has;
+    r.v0 = (b.has & 1u) ? b.v0 : (a.v0 < b.v0 ? a.v0 : b.v0);
+    r.v1 = (b.has & 2u) ? b.v1 : (a.v1 < b.v1 ? a.v1 : b.v1);
     return r;
 }
-__device__ inline u64 block_sum_u64(u64 v, u64 *lds) {
-    for (int d = 32; d >= 1; d >>= 1) v += ((u64)__shfl_down((u32)(v >> 32), d, 64) << 32) | __shfl_down((u32)v, d, 64);
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-    __syncthreads();
-    u64 r = 0;
-    for (int k = 0; k < NT / 64; k++) r += lds[k];
-    __syncthreads();
-    return r;
-}
-__device__ inline int block_max_int(int v, int *lds) {
-    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_down(v, d, 64); v = o > v ? o : v; }
-    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
-    __syncthreads();
-    int r = lds[0];
-    for (int k = 1; k < NT / 64; k++) r = lds[k] > r ? lds[k] : r;
-    __syncthreads();
-    return r;
-}
-// exclusive prefix sum of one u32 per thread; *total = block total
-__device__ inline u32 block_excl_u32(u32 v, u32 *lds, u32 *total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    u32 inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    u32 before = 0, tot = 0;
-    for (int k = 0; k < NT / 64; k++) { const u32 c = lds[k]; if (k < w) before += c; tot += c; }
-    __syncthreads();
-    *total = tot;
-    return before + inc - v;
-}
-struct MinSt { u32 has, val; };
-__device__ inline MinSt ms_combine(MinSt a, MinSt b) { MinSt r; r.has = a.has | b.has; r.val = b.has ? b.val : (a.val < b.val ? a.val : b.val); return r; }
-// exclusive scan of the running-minimum state; *total = block aggregate
-__device__ inline MinSt block_excl_ms(MinSt v, MinSt *lds, MinSt *total) {
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    MinSt inc = v;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        MinSt t; t.has = __shfl_up(inc.has, d, 64); t.val = __shfl_up(inc.val, d, 64);
-        if (lane >= d) inc = ms_combine(t, inc);
+__device__ inline MinSt2 wave_incl_ms2(MinSt2 m) {
+    const int lane = threadIdx.x & 63;
+#define LF_STEP_(CTRL, RM, TAKE) {                                                                                    \
+        MinSt2 t; t.has = rv_dpp_u32<CTRL, RM>(m.has); t.v0 = rv_dpp_u32<CTRL, RM>(m.v0); t.v1 = rv_dpp_u32<CTRL, RM>(m.v1);    \
+        const MinSt2 c = ms2_combine(t, m);                                                                           \
+        if (TAKE) m = c;                                                                                              \
     }
-    MinSt exc; exc.has = __shfl_up(inc.has, 1, 64); exc.val = __shfl_up(inc.val, 1, 64);
-    if (lane == 0) { exc.has = 0; exc.val = INF; }
-    if (lane == 63) lds[w] = inc;
-    __syncthreads();
-    MinSt before = {0, INF}, tot = {0, INF};
-    for (int k = 0; k < NT / 64; k++) { if (k < w) before = ms_combine(before, lds[k]); tot = ms_combine(tot, lds[k]); }
-    __syncthreads();
-    *total = tot;
-    return ms_combine(before, exc);
+    RV_WAVE_SCAN_STEPS(LF_STEP_)
+#undef LF_STEP_
+    return m;
 }
 
 __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
-    __shared__ sa_t  sa[LN], tsa[LN];
-    __shared__ u32   lc[LN], tlc[LN];
-    __shared__ uint8_t bw[LN], tbw[LN];
+    // two copies of the arrays: a split reads one and writes the children into the other, a sub-index remembers which one holds it
+    __shared__ sa_t  sa2[2][LN];
+    __shared__ u32   lc2[2][LN];
+    __shared__ uint8_t bw2[2][LN];
+    __shared__ uint16_t act[LN];
     __shared__ Frame stack[MAXSTACK];
-    __shared__ u64 r64[NT / 64];
-    __shared__ int ri[NT / 64];
-    __shared__ u32 ru[NT / 64];
-    __shared__ MinSt rm[NT / 64];
-    __shared__ int64_t s_pick[2];
-    __shared__ int64_t s_v[4];
-    __shared__ u32 act[LN];
-    __shared__ int s_sp;
+    __shared__ Frame cur[NW];
+#ifdef RV_LEAF_PAD
+    __shared__ u32 pad_[RV_LEAF_PAD / 4];      // (tuning: fewer workgroups per CU)
+    if (A.minl == -12345) pad_[threadIdx.x] = 0;
+#endif
+    __shared__ int s_top, s_pending, s_lock;
+    // The anchors of the root are collected here and leave with ONE reservation per workgroup: a reservation per anchor was
+    // 1.7 x 10^6 returning atomics on one address per run of 2 x 250 Mbp, ~50 ns each at the L2 -- the launches took exactly that long.
+    __shared__ u32 an_l[ACAP]; __shared__ sa_t an_a[ACAP], an_b[ACAP];
+    __shared__ u32 s_na, s_base;
+    __shared__ unsigned long long s_stats[4];
 
     const RvLeafRoot root = A.roots[blockIdx.x];
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     for (int i = tid; i < root.n; i += NT) {
-        sa[i] = A.SA[root.off + i]; lc[i] = (u32)A.LCP[root.off + i]; bw[i] = A.BWT[root.off + i] & RV_BWT_CHAR;      /* (the side bit is for the streaming scan; here SA is in LDS) */
+        sa2[0][i] = A.SA[root.off + i]; lc2[0][i] = (u32)A.LCP[root.off + i]; bw2[0][i] = A.BWT[root.off + i] & RV_BWT_CHAR;      /* (the side bit is for the streaming scan; here SA is in LDS) */
     }
     if (tid == 0) {
-        Frame f; f.start = 0; f.len = (int)root.n; f.depth = root.depth; f.a0 = root.a0; f.a1 = root.a1; f.b0 = root.b0; f.b1 = root.b1;
-        stack[0] = f; s_sp = 1;
+        Frame f; f.start = 0; f.len = (int)root.n; f.depth = root.depth; f.buf = 0; f.a0 = root.a0; f.a1 = root.a1; f.b0 = root.b0; f.b1 = root.b1;
+        cur[0] = f; s_top = 0; s_pending = 1; s_lock = 0; s_na = 0;
+        s_stats[0] = s_stats[1] = s_stats[2] = s_stats[3] = 0;
     }
-    __syncthreads();
-    const int64_t nsep0 = A.nsep0;
-    u32 my_steps = 0, my_splits = 0, my_maxdepth = 0; u64 my_bp = 0;     // accumulated by thread 0
+    __syncthreads();                                   // the only workgroup barrier
+    const sa_t nsep0 = (sa_t)A.nsep0;
+    const u32 minl = A.minl > 0 ? (u32)A.minl : 0u;
+    u32 my_steps = 0, my_splits = 0, my_maxdepth = 0; u64 my_bp = 0;     // accumulated by lane 0 of every wave
+    bool have = wv == 0;
+#ifdef RV_LEAF_PROF
+    long long pt = clock64(), p_idle = 0, p_scan = 0, p_split = 0, p_bub = 0;
+#define LF_PROF(acc) { const long long now_ = clock64(); acc += now_ - pt; pt = now_; }
+#else
+#define LF_PROF(acc)
+#endif
 
-    while (s_sp > 0) {
-        const Frame f = stack[s_sp - 1];
-        __syncthreads();
-        if (tid == 0) s_sp = s_sp - 1;
+    for (;;) {
+        LF_PROF(p_bub)
+        if (!have) {
+            // take a sub-index from the shared stack, or leave once every sub-index of the root is finished
+            int got = 0;
+            if (lane == 0) {
+                for (;;) {
+                    if (__hip_atomic_load(&s_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == 0) { got = -1; break; }
+                    if (__hip_atomic_load(&s_top, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) > 0) {
+                        while (atomicCAS(&s_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const int t = s_top;
+                        if (t > 0) { cur[wv] = stack[t - 1]; s_top = t - 1; got = 1; }
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        atomicExch(&s_lock, 0);
+                        if (got) break;
+                    }
+                    __builtin_amdgcn_s_sleep(4);
+                }
+            }
+            got = __builtin_amdgcn_readfirstlane(got);
+            if (got < 0) break;
+        }
+        WSYNC();
+        const Frame f = cur[wv];
+        have = false;
+        LF_PROF(p_idle)
+        const int b = f.buf;
+        sa_t *cs = sa2[b], *ns = sa2[b ^ 1];
+        u32 *cl = lc2[b], *nl_ = lc2[b ^ 1];
+        uint8_t *cb = bw2[b], *nb = bw2[b ^ 1];
         const int S = f.start, E = f.start + f.len;
         const bool both = f.a0 < f.a1 && f.b0 < f.b1;           // nsamples == 2 (reveal.c:1034-1041)
-        if (tid == 0) { my_steps++; if ((u32)f.depth > my_maxdepth) my_maxdepth = (u32)f.depth; }
+        if (lane == 0) { my_steps++; if ((u32)f.depth > my_maxdepth) my_maxdepth = (u32)f.depth; }
 
         // ---- scan (reveal.c:131-159) + picker ------------------------------------------------
-        u64 best = 0;
+        u64 best = 0; sa_t bpart = 0;          // the lane's best candidate and its other member
         u64 hsa = 0, hlc = 0;
-        for (int i = S + tid; i < E; i += NT) {
-            if (A.trace) { hsa = hash_step(hsa, (u64)(i - S), (int64_t)sa[i]); hlc = hash_step(hlc, (u64)(i - S), (int64_t)lc[i]); }
+        for (int i = S + lane; i < E; i += 64) {
+            if (A.trace) { hsa = hash_step(hsa, (u64)(i - S), (int64_t)cs[i]); hlc = hash_step(hlc, (u64)(i - S), (int64_t)cl[i]); }
             if (i == S) continue;
-            const u32 l = lc[i];
-            if ((int64_t)l < (int64_t)A.minl) continue;
-            const sa_t s1 = sa[i], s0 = sa[i - 1];
-            if (((int64_t)s1 > nsep0) == ((int64_t)s0 > nsep0)) continue;
-            const u32 la = (i + 1 < E) ? lc[i + 1] : 0u;
-            if (!(lc[i - 1] < l && la < l)) continue;
-            const bool ok = s1 < s0 ? left_maximal(bw[i], bw[i - 1]) : left_maximal(bw[i - 1], bw[i]);
+            const u32 l = cl[i];
+            if (l < minl) continue;
+            const sa_t s1 = cs[i], s0 = cs[i - 1];
+            if ((s1 > nsep0) == (s0 > nsep0)) continue;
+            const u32 la = (i + 1 < E) ? cl[i + 1] : 0u;
+            if (!(cl[i - 1] < l && la < l)) continue;
+            const bool ok = s1 < s0 ? left_maximal(cb[i], cb[i - 1]) : left_maximal(cb[i - 1], cb[i]);
             if (!ok) continue;
             const u64 a = (u64)(s1 < s0 ? s1 : s0);
             const u64 key = ((u64)l << 40) | (0xFFFFFFFFFFull - a);           // longest, then smallest position (< 2^40)
-            if (key > best) best = key;
+            if (key > best) { best = key; bpart = s1 < s0 ? s0 : s1; }
         }
         u64 hm = 0; u32 total_cand = 0;
         if (A.trace) {
             // scan-result hash needs each candidate's ordinal in rank order: second pass with a running count
             u32 run = 0;
-            for (int base = S; base < E; base += NT) {
-                const int i = base + tid;
+            for (int base = S; base < E; base += 64) {
+                const int i = base + lane;
                 bool ok = false; u32 l = 0; sa_t s1 = 0, s0 = 0;
                 if (i < E && i > S) {
-                    l = lc[i]; s1 = sa[i]; s0 = sa[i - 1];
-                    const u32 la = (i + 1 < E) ? lc[i + 1] : 0u;
-                    ok = (int64_t)l >= (int64_t)A.minl && (((int64_t)s1 > nsep0) != ((int64_t)s0 > nsep0)) && lc[i - 1] < l && la < l &&
-                         (s1 < s0 ? left_maximal(bw[i], bw[i - 1]) : left_maximal(bw[i - 1], bw[i]));
+                    l = cl[i]; s1 = cs[i]; s0 = cs[i - 1];
+                    const u32 la = (i + 1 < E) ? cl[i + 1] : 0u;
+                    ok = l >= minl && ((s1 > nsep0) != (s0 > nsep0)) && cl[i - 1] < l && la < l &&
+                         (s1 < s0 ? left_maximal(cb[i], cb[i - 1]) : left_maximal(cb[i - 1], cb[i]));
                 }
-                u32 tot;
-                const u32 k = run + block_excl_u32(ok ? 1u : 0u, ru, &tot);
+                const u64 mask = __ballot(ok);
+                const u32 k = run + lanes_below(mask);
                 if (ok) {
-                    const int64_t a = (int64_t)(s1 < s0 ? s1 : s0), b = (int64_t)(s1 < s0 ? s0 : s1);
-                    const int64_t seq[6] = {(int64_t)l, 2, 0, a, 1, b};
-                    for (int z = 0; z < 6; z++) hm = hash_step(hm, (u64)k * 6 + z, seq[z]);
+                    const int64_t a = (int64_t)(s1 < s0 ? s1 : s0), bb = (int64_t)(s1 < s0 ? s0 : s1);
+                    const u64 o = (u64)k * 6;                  // the candidate as the oracle hashes it: l, n = 2, (0, a), (1, b)
+                    hm = hash_step(hm, o, (int64_t)l); hm = hash_step(hm, o + 1, 2); hm = hash_step(hm, o + 2, 0);
+                    hm = hash_step(hm, o + 3, a); hm = hash_step(hm, o + 4, 1); hm = hash_step(hm, o + 5, bb);
                 }
-                run += tot;
+                run += (u32)__popcll(mask);
             }
             total_cand = run;
-            hsa = block_sum_u64(hsa, r64); hlc = block_sum_u64(hlc, r64); hm = block_sum_u64(hm, r64);
+            hsa = wave_sum_u64(hsa); hlc = wave_sum_u64(hlc); hm = wave_sum_u64(hm);
         }
-        best = block_max_u64(best, r64);
+        const u64 mine = best;
+        best = wave_max_u64(best);
         const bool picked = both && best != 0;
         const u32 L = (u32)(best >> 40);
         const int64_t pa = (int64_t)(0xFFFFFFFFFFull - (best & 0xFFFFFFFFFFull));
+        int64_t pb = 0;
         if (picked) {
-            // the partner position b of the chosen match
-            for (int i = S + 1 + tid; i < E; i += NT) {
-                if (lc[i] != L) continue;
-                const sa_t s1 = sa[i], s0 = sa[i - 1];
-                if ((int64_t)(s1 < s0 ? s1 : s0) != pa) continue;
-                if (((int64_t)s1 > nsep0) == ((int64_t)s0 > nsep0)) continue;
-                const u32 la = (i + 1 < E) ? lc[i + 1] : 0u;
-                if (lc[i - 1] < L && la < L) s_pick[0] = (int64_t)(s1 < s0 ? s0 : s1);
-            }
+            // the other member of the chosen match: held by the one lane whose candidate won (a position pairs with one rank only)
+            const int owner = (int)__builtin_ctzll(__ballot(mine == best));
+            const u64 bp = (u64)bpart;
+            pb = (int64_t)(((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(bp >> 32), owner) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)bp, owner));
         }
-        __syncthreads();
-        const int64_t pb = picked ? s_pick[0] : 0;
-        if (A.trace && tid == 0) {
+        if (A.trace && lane == 0) {
             const u32 slot = atomicAdd(A.trace_count, 1u);
             if (slot < A.trace_cap) {
                 rv_trace t;
@@ -203,60 +221,85 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
                 A.trace_out[slot] = t;
             }
         }
-        if (!picked) { __syncthreads(); continue; }
-        if (tid == 0) {
-            my_splits++; my_bp += L;
-            const u32 slot = atomicAdd(A.anchor_count, 1u);
-            if (slot < A.anchor_cap) { A.anchor_l[slot] = L; A.anchor_pos[2 * (size_t)slot] = pa; A.anchor_pos[2 * (size_t)slot + 1] = pb; }
+        LF_PROF(p_scan)
+        if (!picked) {
+            if (lane == 0) atomicSub(&s_pending, 1);
+            continue;
         }
+        if (lane == 0) {
+            my_splits++; my_bp += L;
+            const u32 k = atomicAdd(&s_na, 1u);
+            if (k < (u32)ACAP) { an_l[k] = L; an_a[k] = (sa_t)pa; an_b[k] = (sa_t)pb; }
+            else {                                   // (more anchors than the staging holds: minl of a few bases)
+                const u32 slot = atomicAdd(A.anchor_count, 1u);
+                if (slot < A.anchor_cap) { A.anchor_l[slot] = L; A.anchor_pos[2 * (size_t)slot] = pa; A.anchor_pos[2 * (size_t)slot + 1] = pb; }
+            }
+        }
+        // (the matched text is lower-cased from the anchor list when the run ends: k_leaf_lower; nothing reads it before)
         // ---- linear graphalign: lead = left remainders, trail = right remainders ------------------
         const int64_t la0 = f.a0, la1 = pa, lb0 = f.b0, lb1 = pb;                     // leading intervals (may be empty)
         const int64_t ta0 = pa + L, ta1 = f.a1, tb0 = pb + L, tb1 = f.b1;             // trailing intervals
-        // ---- label + split (reveal.c:1005-1117, 582-664) -----------------------------------------
-        u32 cnt0 = 0, cnt1 = 0;                   // ranks already written to lead / trail
-        MinSt car0 = {0, INF}, car1 = {0, INF};   // running-minimum carries
-        for (int base = S; base < E; base += NT) {
-            const int i = base + tid;
-            int c = -1; u32 ev = INF; sa_t pos = 0; uint8_t bo = 0;
-            if (i < E) {
-                pos = sa[i]; bo = bw[i];
-                const int64_t p = (int64_t)pos;
-                if ((p >= la0 && p < la1) || (p >= lb0 && p < lb1)) c = 0;
-                else if ((p >= ta0 && p < ta1) || (p >= tb0 && p < tb1)) c = 1;
-                ev = (i > S) ? lc[i] : INF;      // every rank of a leaf sub-index is labelled (lead, trail or matched): no skipped updates
-                if (c == 1 && (p == ta0 || p == tb0) && bo >= 'A' && bo <= 'Z') bo += 32;   // its left neighbour was just matched
+        // ---- label + split (reveal.c:1005-1117, 582-664) into the other copy: lead at S, trail right behind it ------
+        // A sub-index holds exactly the suffixes of its intervals: the children's sizes follow from the interval lengths.  A lane
+        // takes four consecutive ranks, so the wave-wide scans (counts, running minima) run once per 256 ranks.
+        const usa_t LA0 = (usa_t)la0, LAn = la1 > la0 ? (usa_t)(la1 - la0) : 0, LB0 = (usa_t)lb0, LBn = lb1 > lb0 ? (usa_t)(lb1 - lb0) : 0;
+        const usa_t TA0 = (usa_t)ta0, TAn = ta1 > ta0 ? (usa_t)(ta1 - ta0) : 0, TB0 = (usa_t)tb0, TBn = tb1 > tb0 ? (usa_t)(tb1 - tb0) : 0;
+        const u32 nlead = (u32)(LAn + LBn);
+        u32 cnt0 = 0, cnt1 = 0;                       // ranks already written to lead / trail
+        MinSt2 car; car.has = 0; car.v0 = INF; car.v1 = INF;      // running-minimum carry
+        for (int base = S; base < E; base += 4 * 64) {
+            const int i0 = base + 4 * lane;
+            u32 ev[4]; sa_t pos[4]; uint8_t bo[4]; u32 cls = 0;      // cls: two bits per rank (1 = lead, 2 = trail)
+            MinSt2 agg; agg.has = 0; agg.v0 = INF; agg.v1 = INF;
+            u32 n01 = 0;                                             // lead count | trail count << 16
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = i0 + r;
+                u32 c = 0; ev[r] = INF; pos[r] = 0; bo[r] = 0;
+                if (i < E) {
+                    pos[r] = cs[i]; bo[r] = cb[i];
+                    const usa_t p = (usa_t)pos[r];
+                    if ((usa_t)(p - LA0) < LAn || (usa_t)(p - LB0) < LBn) c = 1;
+                    else if ((usa_t)(p - TA0) < TAn || (usa_t)(p - TB0) < TBn) c = 2;
+                    ev[r] = (i > S) ? cl[i] : INF;      // every rank of a leaf sub-index is labelled (lead, trail or matched): no skipped updates
+                    if (c == 2 && (p == TA0 || p == TB0) && bo[r] >= 'A' && bo[r] <= 'Z') bo[r] += 32;   // its left neighbour was just matched
+                }
+                cls |= c << (2 * r);
+                n01 += (c == 1 ? 1u : 0u) + (c == 2 ? 0x10000u : 0u);
+                agg.has |= c;
+                agg.v0 = c == 1 ? INF : (agg.v0 < ev[r] ? agg.v0 : ev[r]);
+                agg.v1 = c == 2 ? INF : (agg.v1 < ev[r] ? agg.v1 : ev[r]);
             }
-            u32 t0, t1; MinSt a0, a1;
-            const u32 e0 = block_excl_u32(c == 0 ? 1u : 0u, ru, &t0);
-            const u32 e1 = block_excl_u32(c == 1 ? 1u : 0u, ru, &t1);
-            MinSt m0; m0.has = c == 0; m0.val = c == 0 ? INF : ev;
-            MinSt m1; m1.has = c == 1; m1.val = c == 1 ? INF : ev;
-            MinSt x0 = block_excl_ms(m0, rm, &a0);
-            MinSt x1 = block_excl_ms(m1, rm, &a1);
-            x0 = ms_combine(car0, x0); x1 = ms_combine(car1, x1);
-            if (c == 0) {
-                const u32 idx = cnt0 + e0;
-                const u32 v = x0.val < ev ? x0.val : ev;
-                tsa[S + idx] = pos; tlc[S + idx] = idx == 0 ? 0u : v; tbw[S + idx] = bo;
-            } else if (c == 1) {
-                const u32 idx = cnt1 + e1;
-                const u32 v = x1.val < ev ? x1.val : ev;
-                // trail goes behind lead: its final place is known only after the loop -> park it from the top of the range
-                tsa[E - 1 - idx] = pos; tlc[E - 1 - idx] = idx == 0 ? 0u : v; tbw[E - 1 - idx] = bo;
+            const MinSt2 inc = wave_incl_ms2(agg);
+            const u32 ninc = rv_wave_incl_sum_u32(n01);
+            MinSt2 x; x.has = from_lane_below(inc.has, 0u); x.v0 = from_lane_below(inc.v0, INF); x.v1 = from_lane_below(inc.v1, INF);
+            x = ms2_combine(car, x);                   // the state in front of this lane's first rank
+            u32 e0 = cnt0 + ((ninc - n01) & 0xFFFFu), e1 = cnt1 + ((ninc - n01) >> 16);
+            u32 r0 = x.v0, r1 = x.v1;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const u32 c = (cls >> (2 * r)) & 3u;
+                if (c == 1) {
+                    const u32 v = r0 < ev[r] ? r0 : ev[r];
+                    ns[S + e0] = pos[r]; nl_[S + e0] = e0 == 0 ? 0u : v; nb[S + e0] = bo[r];
+                    e0++;
+                } else if (c == 2) {
+                    const u32 v = r1 < ev[r] ? r1 : ev[r];
+                    ns[S + nlead + e1] = pos[r]; nl_[S + nlead + e1] = e1 == 0 ? 0u : v; nb[S + nlead + e1] = bo[r];
+                    e1++;
+                }
+                r0 = c == 1 ? INF : (r0 < ev[r] ? r0 : ev[r]);
+                r1 = c == 2 ? INF : (r1 < ev[r] ? r1 : ev[r]);
             }
-            cnt0 += t0; cnt1 += t1;
-            car0 = ms_combine(car0, a0); car1 = ms_combine(car1, a1);
+            const u32 ntot = (u32)__builtin_amdgcn_readlane((int)ninc, 63);
+            cnt0 += ntot & 0xFFFFu; cnt1 += ntot >> 16;
+            MinSt2 tot; tot.has = (u32)__builtin_amdgcn_readlane((int)inc.has, 63); tot.v0 = (u32)__builtin_amdgcn_readlane((int)inc.v0, 63); tot.v1 = (u32)__builtin_amdgcn_readlane((int)inc.v1, 63);
+            car = ms2_combine(car, tot);
         }
-        __syncthreads();
+        WSYNC();
+        LF_PROF(p_split)
         const int nl = (int)cnt0, ntr = (int)cnt1;
-        for (int i = tid; i < nl; i += NT) { sa[S + i] = tsa[S + i]; lc[S + i] = tlc[S + i]; bw[S + i] = tbw[S + i]; }
-        for (int i = tid; i < ntr; i += NT) { sa[S + nl + i] = tsa[E - 1 - i]; lc[S + nl + i] = tlc[E - 1 - i]; bw[S + nl + i] = tbw[E - 1 - i]; }
-        // lower-case the matched text (reveal.c:1230-1234)
-        for (int64_t j = tid; j < (int64_t)L; j += NT) {
-            uint8_t ch = A.T[pa + j]; if (ch >= 'A' && ch <= 'Z') A.T[pa + j] = ch + 32;
-            ch = A.T[pb + j]; if (ch >= 'A' && ch <= 'Z') A.T[pb + j] = ch + 32;
-        }
-        __syncthreads();
+        if (lane == 0 && (cnt0 != nlead || cnt1 != (u32)(TAn + TBn))) atomicOr(A.err, 8u);      // (a sub-index that is not the suffixes of its intervals)
         // ---- bubble_sort on the leading child, cuts in ascending order (reveal.c:666-727) ---------------
         for (int cut = 0; cut < 2 && nl > 0; cut++) {
             const int64_t B = cut == 0 ? pa : pb;
@@ -265,70 +308,118 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
             const int64_t wlo = (B - (int64_t)A.lcap > ib) ? B - (int64_t)A.lcap : ib;
             // actives in rank order
             u32 nact = 0;
-            for (int base = 0; base < nl; base += NT) {
-                const int e = base + tid;
+            for (int base = 0; base < nl; base += 64) {
+                const int e = base + lane;
                 bool on = false;
                 if (e < nl) {
-                    const int64_t p = (int64_t)sa[S + e];
+                    const int64_t p = (int64_t)ns[S + e];
                     if (p >= wlo && p < B) {
-                        const int64_t l0 = (int64_t)lc[S + e], l1 = (e + 1 < nl) ? (int64_t)lc[S + e + 1] : 0;
+                        const int64_t l0 = (int64_t)nl_[S + e], l1 = (e + 1 < nl) ? (int64_t)nl_[S + e + 1] : 0;
                         on = p + l0 > B || p + l1 > B;
                     }
                 }
-                u32 tot;
-                const u32 k = nact + block_excl_u32(on ? 1u : 0u, ru, &tot);
-                if (on) act[k] = (u32)e;
-                nact += tot;
+                const u64 mask = __ballot(on);
+                if (on) act[S + nact + lanes_below(mask)] = (uint16_t)e;
+                nact += (u32)__popcll(mask);
             }
-            __syncthreads();
+            WSYNC();
             for (u32 ai = 0; ai < nact; ai++) {
-                const int e = (int)act[ai];
-                if (tid == 0) {
-                    const int64_t p = (int64_t)sa[S + e], l0 = (int64_t)lc[S + e];
-                    int64_t kind = 0;
-                    if (p < B && p + l0 > B) kind = 1;
-                    else if (e < nl - 1) { const int64_t l1 = (int64_t)lc[S + e + 1]; if (p < B && p + l1 > B && l1 > l0) lc[S + e + 1] = (u32)(B - p); }
-                    s_v[0] = kind; s_v[1] = p; s_v[2] = l0; s_v[3] = bw[S + e];
-                }
-                __syncthreads();
-                if (s_v[0] == 1) {
-                    const int64_t tS = s_v[1], tL = s_v[2], t = B - tS; const uint8_t tB = (uint8_t)s_v[3];
+                const int e = (int)act[S + ai];
+                const int64_t p = (int64_t)ns[S + e], l0 = (int64_t)nl_[S + e];          // (the same address for every lane: one broadcast read)
+                if (p < B && p + l0 > B) {
+                    const int64_t t = B - p; const uint8_t tB = nb[S + e];
                     // x = largest r <= e with r == 0 or LCP[r] < t
-                    int bestr = -1;
-                    for (int r = e - tid; r >= 0; r -= NT) if (r == 0 || (int64_t)lc[S + r] < t) { bestr = r; break; }
-                    const int x = block_max_int(bestr, ri);
-                    // shift [x, e-1] -> [x+1, e]: read everything, then write
-                    sa_t vs[LN / NT]; u32 vl[LN / NT]; uint8_t vb[LN / NT];
-#pragma unroll
-                    for (int k = 0; k < LN / NT; k++) { const int r = e - k * NT - tid; if (r > x) { vs[k] = sa[S + r - 1]; vl[k] = lc[S + r - 1]; vb[k] = bw[S + r - 1]; } }
-                    __syncthreads();
-#pragma unroll
-                    for (int k = 0; k < LN / NT; k++) { const int r = e - k * NT - tid; if (r > x) { sa[S + r] = vs[k]; lc[S + r] = vl[k]; bw[S + r] = vb[k]; } }
-                    __syncthreads();
-                    if (tid == 0) {
-                        sa[S + x] = (sa_t)tS; bw[S + x] = tB;
-                        if (x + 1 < nl) lc[S + x + 1] = (u32)t;
-                        if (e < nl - 1 && tL < (int64_t)lc[S + e + 1]) lc[S + e + 1] = (u32)tL;
+                    int x = 0;
+                    for (int hi = e;; hi -= 64) {
+                        const int r = hi - lane;
+                        const u64 mask = __ballot(r >= 0 && (r == 0 || (int64_t)nl_[S + r] < t));
+                        if (mask) { x = hi - (int)__builtin_ctzll(mask); break; }
                     }
+                    const u32 lnext = (e < nl - 1) ? nl_[S + e + 1] : 0u;
+                    // shift [x, e-1] -> [x+1, e], from the top in pieces of 64: a piece reads below what it writes, the wave reads before it writes
+                    for (int hi = e; hi > x; hi -= 64) {
+                        const int r = hi - lane;
+                        sa_t vs = 0; u32 vl = 0; uint8_t vb = 0;
+                        if (r > x) { vs = ns[S + r - 1]; vl = nl_[S + r - 1]; vb = nb[S + r - 1]; }
+                        WSYNC();
+                        if (r > x) { ns[S + r] = vs; nl_[S + r] = vl; nb[S + r] = vb; }
+                        WSYNC();
+                    }
+                    if (lane == 0) {
+                        ns[S + x] = (sa_t)p; nb[S + x] = tB;
+                        if (x + 1 < nl) nl_[S + x + 1] = (u32)t;
+                        if (e < nl - 1 && l0 < (int64_t)lnext) nl_[S + e + 1] = (u32)l0;
+                    }
+                } else if (e < nl - 1) {
+                    const int64_t l1 = (int64_t)nl_[S + e + 1];
+                    if (lane == 0 && p < B && p + l1 > B && l1 > l0) nl_[S + e + 1] = (u32)(B - p);
                 }
-                __syncthreads();
+                WSYNC();
             }
         }
-        // ---- children (reveal.c:1296-1324): trailing first so the leading child is handled next; order is free ----
-        if (tid == 0) {
-            int sp = s_sp;
-            if (ntr > 0 && sp < MAXSTACK) { Frame c; c.start = S + nl; c.len = ntr; c.depth = f.depth + 1; c.a0 = ta0; c.a1 = ta1; c.b0 = tb0; c.b1 = tb1; stack[sp++] = c; }
-            if (nl > 0 && sp < MAXSTACK) { Frame c; c.start = S; c.len = nl; c.depth = f.depth + 1; c.a0 = la0; c.a1 = la1; c.b0 = lb0; c.b1 = lb1; stack[sp++] = c; }
-            if (sp >= MAXSTACK) atomicOr(A.err, 4u);
-            s_sp = sp;
+        // ---- children (reveal.c:1296-1324); their order is free: this wave goes on with the smaller one, the larger one goes to
+        // the stack for any wave (the stack stays O(waves x log n) deep whatever the shape of the tree) -------------------------
+        const int cdepth = f.depth + 1;
+        bool do_lead = nl > 0, do_trail = ntr > 0;
+        if (!A.trace) {
+            // a child without both samples has nothing to match: counted as visited (reveal.c:1034-1041 returns at once), not scanned
+            if (do_lead && !(la0 < la1 && lb0 < lb1)) { do_lead = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
+            if (do_trail && !(ta0 < ta1 && tb0 < tb1)) { do_trail = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
         }
-        __syncthreads();
+        if (lane == 0) {
+            const bool keep_lead = do_lead && (!do_trail || nl <= ntr);      // which child this wave goes on with (if any)
+            if (do_lead && do_trail) {
+                while (atomicCAS(&s_lock, 0, 1) != 0) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int t = s_top;
+                if (t < MAXSTACK) {
+                    Frame *o = &stack[t];                                     // the other child
+                    o->start = keep_lead ? S + nl : S; o->len = keep_lead ? ntr : nl; o->depth = cdepth; o->buf = b ^ 1;
+                    o->a0 = keep_lead ? ta0 : la0; o->a1 = keep_lead ? ta1 : la1; o->b0 = keep_lead ? tb0 : lb0; o->b1 = keep_lead ? tb1 : lb1;
+                    s_top = t + 1; atomicAdd(&s_pending, 1);
+                } else atomicOr(A.err, 4u);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                atomicExch(&s_lock, 0);
+            }
+            if (do_lead || do_trail) {
+                Frame *o = &cur[wv];
+                o->start = keep_lead ? S : S + nl; o->len = keep_lead ? nl : ntr; o->depth = cdepth; o->buf = b ^ 1;
+                o->a0 = keep_lead ? la0 : ta0; o->a1 = keep_lead ? la1 : ta1; o->b0 = keep_lead ? lb0 : tb0; o->b1 = keep_lead ? lb1 : tb1;
+            } else {
+                atomicSub(&s_pending, 1);
+            }
+        }
+        have = do_lead || do_trail;
     }
+    if (lane == 0) {
+        atomicAdd(&s_stats[0], (unsigned long long)my_steps); atomicAdd(&s_stats[1], (unsigned long long)my_splits);
+        atomicAdd(&s_stats[2], (unsigned long long)my_bp); atomicMax(&s_stats[3], (unsigned long long)my_maxdepth);
+#ifdef RV_LEAF_PROF
+        atomicAdd(&A.stats[4], (unsigned long long)p_idle); atomicAdd(&A.stats[5], (unsigned long long)p_scan);
+        atomicAdd(&A.stats[6], (unsigned long long)p_split); atomicAdd(&A.stats[7], (unsigned long long)p_bub);
+#endif
+    }
+    __syncthreads();                                   // every wave has left the loop: the root is finished
+    const u32 na = s_na < (u32)ACAP ? s_na : (u32)ACAP;
     if (tid == 0) {
-        atomicAdd(&A.stats[0], (unsigned long long)my_steps);
-        atomicAdd(&A.stats[1], (unsigned long long)my_splits);
-        atomicAdd(&A.stats[2], (unsigned long long)my_bp);
-        atomicMax(&A.stats[3], (unsigned long long)my_maxdepth);
+        s_base = na ? atomicAdd(A.anchor_count, na) : 0u;
+        atomicAdd(&A.stats[0], s_stats[0]); atomicAdd(&A.stats[1], s_stats[1]); atomicAdd(&A.stats[2], s_stats[2]); atomicMax(&A.stats[3], s_stats[3]);
+    }
+    __syncthreads();
+    for (u32 k = tid; k < na; k += NT) {
+        const size_t slot = (size_t)s_base + k;
+        if (slot < A.anchor_cap) { A.anchor_l[slot] = an_l[k]; A.anchor_pos[2 * slot] = (int64_t)an_a[k]; A.anchor_pos[2 * slot + 1] = (int64_t)an_b[k]; }
+    }
+}
+
+// the matched text of the anchors the leaf launches found, lower-cased when the run ends (reveal.c:1230-1234): one wave per anchor
+__global__ __launch_bounds__(NT) void k_leaf_lower(uint8_t *__restrict__ T, const int64_t *__restrict__ pos, const u32 *__restrict__ len, u32 na) {
+    const u32 e = (u32)(((int64_t)blockIdx.x * NT + threadIdx.x) >> 6);
+    if (e >= na) return;
+    const int64_t l = (int64_t)len[e], pa = pos[2 * (size_t)e], pb = pos[2 * (size_t)e + 1];
+    for (int64_t j = threadIdx.x & 63; j < l; j += 64) {
+        uint8_t ch = T[pa + j]; if (ch >= 'A' && ch <= 'Z') T[pa + j] = ch + 32;
+        ch = T[pb + j]; if (ch >= 'A' && ch <= 'Z') T[pb + j] = ch + 32;
     }
 }
 
@@ -337,6 +428,13 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
 int rv_leaf_launch(Workspace &ws, const RvLeafArgs &a, int nroots) {
     if (nroots <= 0) return 0;
     hipLaunchKernelGGL(k_leaf, dim3((unsigned)nroots), dim3(NT), 0, ws.stream, a);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
+int rv_leaf_lower_launch(Workspace &ws, uint8_t *T, const int64_t *pos, const u32 *len, u32 na) {
+    if (na == 0) return 0;
+    hipLaunchKernelGGL(k_leaf_lower, dim3((unsigned)ceil_div((int64_t)na * 64, NT)), dim3(NT), 0, ws.stream, T, pos, len, na);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -116,6 +116,7 @@ __device__ inline void split_summaries(u64 dpack, const u32 *ev, u32 *icnt, MinS
         ph |= (u32)i0 | ((u32)i1 << 1) | ((u32)i2 << 2);
     }
     // wave-inclusive scan; the three counts (<= 512 each) share one word and the three has-bits another
+#ifdef RV_SPLIT_SHFL
 #pragma unroll
     for (int dd = 1; dd < 64; dd <<= 1) {
         const u32 tc = __shfl_up(pc, dd, 64), th = __shfl_up(ph, dd, 64);
@@ -128,6 +129,22 @@ __device__ inline void split_summaries(u64 dpack, const u32 *ev, u32 *icnt, MinS
         pc += act ? tc : 0u;
         ph |= act ? th : 0u;
     }
+#else
+    // by DPP (rv_common.h): five words per step through the crossbar of the LDS pipe was a third of both passes' instructions
+#define SP_STEP_(CTRL, RM, TAKE) {                                                                                   \
+        const u32 tc = rv_dpp_u32<CTRL, RM>(pc), th = rv_dpp_u32<CTRL, RM>(ph);                                      \
+        const u32 t0 = rv_dpp_u32<CTRL, RM>(v0), t1 = rv_dpp_u32<CTRL, RM>(v1), t2 = rv_dpp_u32<CTRL, RM>(v2);      \
+        const bool act = (TAKE);                                                                                     \
+        const u32 m0 = t0 < v0 ? t0 : v0, m1 = t1 < v1 ? t1 : v1, m2 = t2 < v2 ? t2 : v2;                            \
+        v0 = (act & !(ph & 1u)) ? m0 : v0;                                                                           \
+        v1 = (act & !(ph & 2u)) ? m1 : v1;                                                                           \
+        v2 = (act & !(ph & 4u)) ? m2 : v2;                                                                           \
+        pc += act ? tc : 0u;                                                                                         \
+        ph |= act ? th : 0u;                                                                                         \
+    }
+    RV_WAVE_SCAN_STEPS(SP_STEP_)
+#undef SP_STEP_
+#endif
     icnt[0] = pc & 1023u; icnt[1] = (pc >> 10) & 1023u; icnt[2] = pc >> 20;
     ist[0].has = ph & 1u; ist[1].has = (ph >> 1) & 1u; ist[2].has = (ph >> 2) & 1u;
     ist[0].val = v0; ist[1].val = v1; ist[2].val = v2;

@@ -300,8 +300,17 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
         LF_PROF(p_split)
         const int nl = (int)cnt0, ntr = (int)cnt1;
         if (lane == 0 && (cnt0 != nlead || cnt1 != (u32)(TAn + TBn))) atomicOr(A.err, 8u);      // (a sub-index that is not the suffixes of its intervals)
-        // ---- bubble_sort on the leading child, cuts in ascending order (reveal.c:666-727) ---------------
-        for (int cut = 0; cut < 2 && nl > 0; cut++) {
+        const int cdepth = f.depth + 1;
+        bool do_lead = nl > 0, do_trail = ntr > 0;
+        if (!A.trace) {
+            // A child without both samples has nothing to match, and neither has one with an interval shorter than minl (bubble_sort
+            // keeps every LCP value inside the intervals): counted as visited (reveal.c:1034-1041 / an empty scan), not scanned
+            const int64_t need = minl > 1 ? (int64_t)minl : 1;
+            if (do_lead && !(la1 - la0 >= need && lb1 - lb0 >= need)) { do_lead = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
+            if (do_trail && !(ta1 - ta0 >= need && tb1 - tb0 >= need)) { do_trail = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
+        }
+        // ---- bubble_sort on the leading child, cuts in ascending order (reveal.c:666-727); a child nobody scans needs none ----
+        for (int cut = 0; cut < 2 && do_lead; cut++) {
             const int64_t B = cut == 0 ? pa : pb;
             const int64_t ib = cut == 0 ? la0 : lb0;
             if (!(ib < B)) continue;                                        // no leading interval ends at this cut
@@ -359,13 +368,6 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
         }
         // ---- children (reveal.c:1296-1324); their order is free: this wave goes on with the smaller one, the larger one goes to
         // the stack for any wave (the stack stays O(waves x log n) deep whatever the shape of the tree) -------------------------
-        const int cdepth = f.depth + 1;
-        bool do_lead = nl > 0, do_trail = ntr > 0;
-        if (!A.trace) {
-            // a child without both samples has nothing to match: counted as visited (reveal.c:1034-1041 returns at once), not scanned
-            if (do_lead && !(la0 < la1 && lb0 < lb1)) { do_lead = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
-            if (do_trail && !(ta0 < ta1 && tb0 < tb1)) { do_trail = false; if (lane == 0) { my_steps++; if ((u32)cdepth > my_maxdepth) my_maxdepth = (u32)cdepth; } }
-        }
         if (lane == 0) {
             const bool keep_lead = do_lead && (!do_trail || nl <= ntr);      // which child this wave goes on with (if any)
             if (do_lead && do_trail) {

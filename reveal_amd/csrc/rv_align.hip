@@ -137,6 +137,7 @@ struct Align {
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
+    DBuf dNextTsub;              // tile -> sub-index of the level being written (rv_tile_sub_launch)
     DBuf dTmin;                  // per RV_SPLIT_TILE ranks of the level being written: lower bound of its LCP values (split -> bubble rounds)
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
     DBuf dLeaf, dLeafRoots[2];   // leaf kernel outputs (counters, stats, anchors, trace) and its per-level root tables
@@ -183,7 +184,7 @@ struct Align {
     bool trace_on = false;
     std::vector<rv_trace> trace;
     rv_align_stats st{};
-    double lg[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
+    double lg[8] = {0}, lgx[8] = {0};          // RV_LEVEL_LOG: host time stamps inside the current level
     // rv_align_builtin split into set-up / levels / collection, so that a frontier can be handed to other devices in between
     int leaf_flip = 0;
     bool leaf_launch_due = false, hook_early = false;   // the level's leaf launch waits until the level's scan / split kernels are queued
@@ -903,7 +904,7 @@ int rv_sub_split(rv_index *h, int s, uint32_t l, int nsp, const int64_t *sp,
 //  - more than two samples: tile -> sub-index table (the multi-sample picker looks sub-indices up per candidate)
 //  - two samples, untraced: the level's split can be decided on the device if each of its sub-indices owns at most one
 //    interval per sample (rv_decide.hip): node intervals, "finished by the leaf kernel" flags, tiles.
-static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next) {
+static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next, bool tsub_on_device = false) {
     Align *a = h->al;
     const int nsn = nx.size();
     a->next_ss.assign(nx.off.begin(), nx.off.end()); a->next_ss.push_back(m_next);
@@ -944,7 +945,8 @@ static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next) {
             a->next_flags[(size_t)s2] = (a->use_leaf && nx.n[(size_t)s2] <= RV_LEAF_N) ? 1 : 0;
         }
     }
-    if (a->multi || a->next_dev_ok) {
+    a->next_tsub.clear();
+    if ((a->multi || a->next_dev_ok) && !tsub_on_device) {
         const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
         a->next_tsub.resize((size_t)ntn);
         int s2 = 0;
@@ -991,6 +993,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->kid_tmp.clear();
     bool any_par = false;
     int64_t window_sum = 0;
+    const bool split_tabs = !a->early_done;       // the split is still to be launched, from the tables built here
+    const bool lower_tabs = !a->early_bubble;     // ... and so is the lower-casing of the matched ranges
     for (int s = 0; s < ns; s++) {
         a->sub_start[(size_t)s] = lv.off[(size_t)s];
         a->ctab_first[(size_t)s] = (int)a->cb.size(); a->mtab_first[(size_t)s] = (int)a->mb.size();
@@ -1011,21 +1015,25 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         bool dead[3] = {false, false, false};
         if (a->multi && a->full_only && !dc.host_lists && !getenv("RV_KEEP_DEAD"))
             for (int c = 0; c < 3; c++) dead[c] = cnts[c] > 0 && child_is_dead(h, lists[c], cnts[c], a->minl, a->minn);
-        // class table of this sub: lead/trail/rest merged by begin
-        ent.clear();
-        static const uint8_t cls_of[3] = {1, 2, 4};
-        for (int c = 0; c < 3; c++) for (size_t k = 0; k < cnts[c]; k++) if (lists[c][k].end > lists[c][k].begin) ent.push_back({lists[c][k].begin, lists[c][k].end, dead[c] ? (uint8_t)3 : cls_of[c]});
-        if (!std::is_sorted(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; }))
-            std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; });
-        for (size_t k = 0; k < ent.size(); k++) {
-            if (k && ent[k].b < ent[k - 1].e) { rv_set_error("graphalign returned overlapping intervals [%lld,%lld) / [%lld,%lld)", (long long)ent[k - 1].b, (long long)ent[k - 1].e, (long long)ent[k].b, (long long)ent[k].e); return -1; }
-            a->cb.push_back((sa_t)ent[k].b); a->ce.push_back((sa_t)ent[k].e); a->cc.push_back(ent[k].c);
+        // class table of this sub: lead/trail/rest merged by begin (the split's tables: not needed when the split of this level ran
+        // already, from the same tables built on the device -- early_split; those decisions come from the built-in picker, whose
+        // intervals need no checking)
+        if (split_tabs) {
+            ent.clear();
+            static const uint8_t cls_of[3] = {1, 2, 4};
+            for (int c = 0; c < 3; c++) for (size_t k = 0; k < cnts[c]; k++) if (lists[c][k].end > lists[c][k].begin) ent.push_back({lists[c][k].begin, lists[c][k].end, dead[c] ? (uint8_t)3 : cls_of[c]});
+            if (!std::is_sorted(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; }))
+                std::sort(ent.begin(), ent.end(), [](const Ent &x, const Ent &y) { return x.b < y.b; });
+            for (size_t k = 0; k < ent.size(); k++) {
+                if (k && ent[k].b < ent[k - 1].e) { rv_set_error("graphalign returned overlapping intervals [%lld,%lld) / [%lld,%lld)", (long long)ent[k - 1].b, (long long)ent[k - 1].e, (long long)ent[k].b, (long long)ent[k].e); return -1; }
+                a->cb.push_back((sa_t)ent[k].b); a->ce.push_back((sa_t)ent[k].e); a->cc.push_back(ent[k].c);
+            }
         }
         for (int64_t k = dc.sp_first[(size_t)d]; k < dc.sp_first[(size_t)d + 1]; k++) {       // sorted
             const int64_t p = dc.sp[(size_t)k];
             const u32 l = dc.spl[(size_t)k];
-            if (l) { a->mb.push_back((sa_t)p); a->me.push_back((sa_t)(p + l)); a->mpre.push_back(a->mpre.back() + l); }
-            a->mend_pos.push_back((sa_t)(p + (int64_t)l));
+            if (l && lower_tabs) { a->mb.push_back((sa_t)p); a->me.push_back((sa_t)(p + l)); a->mpre.push_back(a->mpre.back() + l); }
+            if (split_tabs) a->mend_pos.push_back((sa_t)(p + (int64_t)l));
         }
         // children
         int64_t lead_off = 0, lead_n = 0;
@@ -1123,8 +1131,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->lg[0] = now_s() - t0;      // tables built
     // ---- one upload for all the tables ---------------------------------------------------
     const int64_t ntiles = ceil_div(lv.m, RV_SPLIT_TILE);
-    a->tile_sub.resize((size_t)ntiles);
-    {
+    a->tile_sub.resize(split_tabs ? (size_t)ntiles : 0);
+    if (split_tabs) {
         int s2 = 0;
         for (int64_t t = 0; t < ntiles; t++) {
             const int64_t r = t * RV_SPLIT_TILE;
@@ -1132,14 +1140,18 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             a->tile_sub[(size_t)t] = s2;
         }
     }
+    a->lgx[0] = now_s() - t0;     // tile -> sub-index table
     Packer &pk = a->pk;
     pk.clear();
     const size_t o_tsub = pk.addv(a->tile_sub);
     const size_t o_cb = pk.addv(a->cb), o_ce = pk.addv(a->ce), o_cc = pk.addv(a->cc), o_mb = pk.addv(a->mb), o_me = pk.addv(a->me), o_mpre = pk.addv(a->mpre);
-    const size_t o_ctf = pk.addv(a->ctab_first), o_mtf = pk.addv(a->mtab_first);
-    const size_t o_ss = pk.addv(a->sub_start), o_cbase = pk.addv(a->child_base), o_cn = pk.addv(a->child_n), o_cf = pk.addv(a->cut_first);
+    // (tables only the split reads stay at home when it has run already: ~100 bytes per sub-index, 50000 sub-indices per level at 2 x 250 Mbp)
+    static const std::vector<int> no_int; static const std::vector<u32> no_u32; static const std::vector<int64_t> no_i64;
+    const size_t o_ctf = pk.addv(split_tabs ? a->ctab_first : no_int), o_mtf = pk.addv(split_tabs ? a->mtab_first : no_int);
+    const size_t o_ss = pk.addv(split_tabs ? a->sub_start : no_i64), o_cbase = pk.addv(split_tabs ? a->child_base : no_u32), o_cn = pk.addv(split_tabs ? a->child_n : no_u32);
+    const size_t o_cf = pk.addv(split_tabs ? a->cut_first : no_int);
     const size_t o_clo = pk.addv(a->cut_lo), o_chi = pk.addv(a->cut_hi);
-    const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(a->mend_first), o_mp = pk.addv(a->mend_pos);
+    const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(split_tabs ? a->mend_first : no_int), o_mp = pk.addv(a->mend_pos);
     // one launch instead of two when a level has few small children next to large ones (the kernels would run one after the
     // other on the stream; in a 1024-thread workgroup a small child simply finishes early)
     if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !getenv("RV_BUBBLE_NO_MERGE")) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
@@ -1152,23 +1164,33 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         if (a->kids_lds.size() <= 512) { lds_count[2] = (int)a->kids_lds.size(); lds_count[0] = lds_count[1] = 0; }
     }
     const size_t o_ks = pk.addv(a->kids_small), o_kb = pk.addv(a->kids_big), o_kl = pk.addv(a->kids_lds);
-    prep_level_tables(h, nx, m_next);
+    a->lgx[1] = now_s() - t0;     // packed
+    prep_level_tables(h, nx, m_next, true);
+    a->lgx[2] = now_s() - t0;     // tables of the next level
     size_t o_ntsub = 0, o_nnodes = 0, o_nflags = 0, o_ntsub2 = 0;
     if (a->multi) o_ntsub = pk.addv(a->next_tsub);
     if (a->next_dev_ok) { o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = a->multi ? o_ntsub : pk.addv(a->next_tsub); }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
-    a->sub_off_h.assign((size_t)ns * 3, 0);
+    a->sub_off_h.assign(split_tabs ? (size_t)ns * 3 : 0, 0);
     u32 class_total[4] = {0, 0, 0, 0};
-    for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
+    if (split_tabs)
+        for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }
     const size_t o_suboff = pk.addv(a->sub_off_h), o_expect = pk.add(class_total, sizeof class_total), o_total = pk.reserve(16), o_bcnt = pk.reserve(a->descs.size() * 4 + 4), o_mcnt = pk.reserve(a->descs.size() * 4 + 4), o_gcnt = pk.reserve(16);
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.size() + 64));
+    a->lgx[3] = now_s() - t0;     // offsets packed
     if (pk.pageable || getenv("RV_TABLES_MEMCPY")) RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab.p, pk.size())); }
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
     a->d_next_ss = (const int64_t *)(tb + o_nss); a->d_next_want = (const int *)(tb + o_nwant); a->d_next_tsub = (const int *)(tb + o_ntsub);
     a->d_next_nodes = (const sa_t *)(tb + o_nnodes); a->d_next_flags = tb + o_nflags; a->d_next_tsub2 = (const int *)(tb + o_ntsub2);
+    if (a->multi || a->next_dev_ok) {      // the next level's tile -> sub-index table, from its sub-index starts (queued behind the upload)
+        const int64_t ntn = ceil_div(m_next, RV_SPLIT_TILE);
+        RV_TRY(a->dNextTsub.reserve((size_t)ntn * 4 + 64));
+        RV_TRY(rv_tile_sub_launch(h->ws, a->d_next_ss, nx.size(), a->dNextTsub.as<int>(), ntn));
+        a->d_next_tsub = a->d_next_tsub2 = a->dNextTsub.as<int>();
+    }
     RV_TRY(a->dD.reserve((size_t)lv.m + 64));
     RV_TRY(a->dTile.reserve((size_t)ntiles * 3 * 5 * 4 + 64));
     RV_TRY(a->dList.reserve((size_t)a->woff.back() * 4 + 64));
@@ -1552,6 +1574,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             unsigned long long dbg[8] = {0};
             if (a->dDbg.p) { (void)hipMemcpy(dbg, a->dDbg.p, 64, hipMemcpyDeviceToHost); (void)hipMemset(a->dDbg.p, 0, 64); }
             fprintf(stderr, "      bubble (sequential kernels): cuts %llu actives %llu whole-wg visits %llu chunks %llu concurrent %llu | slowest child: total %.1f us (%llu actives), finding actives %.1f, sort+visits %.1f\n", dbg[3], dbg[4], dbg[0], dbg[1], dbg[2], (dbg[5] >> 24) / 100.0, dbg[5] & 0xFFFFFFull, dbg[6] / 100.0, dbg[7] / 100.0);
+            fprintf(stderr, "      upload: tile_sub %.1f pack %.1f next-level tables %.1f offsets %.1f copy %.1f us (%zu bytes)\n", (a->lgx[0] - a->lg[0]) * 1e6, (a->lgx[1] - a->lgx[0]) * 1e6,
+                    (a->lgx[2] - a->lgx[1]) * 1e6, (a->lgx[3] - a->lgx[2]) * 1e6, (a->lg[1] - a->lgx[3]) * 1e6, a->pk.size());
             fprintf(stderr, "level %3d subs %7d (leaf %7zu) ranks %10lld | leafprep %6.1f scan %6.1f host %6.1f | commit: tables %6.1f upload %6.1f split-enq %6.1f bubble-enq %6.1f | drain %7.1f us | next biggest %lld\n",
                     log_level, log_ns, log_leaf, (long long)log_m, (tl_leaf - tl0) * 1e6, (t0 - tl_leaf) * 1e6, (tl1 - t0) * 1e6,
                     a->lg[0] * 1e6, (a->lg[1] - a->lg[0]) * 1e6, (a->lg[2] - a->lg[1]) * 1e6, (tl2 - tl1) * 1e6 - a->lg[2] * 1e6, (tl3 - tl2) * 1e6,

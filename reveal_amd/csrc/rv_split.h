@@ -105,6 +105,8 @@ struct RvBubbleArgs {
 int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D, const uint8_t *BWT, int64_t m, const RvLabelTabs &t, const RvSplitArgs &a,
                     int nsplit);
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
+// tile_sub[t] = the sub-index that holds rank t * RV_SPLIT_TILE (sub_start ascending, nsubs entries)
+int rv_tile_sub_launch(Workspace &ws, const int64_t *sub_start, int nsubs, int *tile_sub, int64_t ntiles);
 #define RV_BUBBLE_BIG_N 16384
 // children up to this many ranks are bubbled on LDS copies of their arrays (one workgroup, all cuts)
 #define RV_BUBBLE_LDS_N0 2048

@@ -1339,6 +1339,20 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     return 0;
 }
 
+// tile -> the sub-index of its first rank (what rv_frontier_commit used to fill on the host: one entry per 2048 ranks, 0.4 ms per level at 2 x 250 Mbp)
+__global__ __launch_bounds__(TB) void k_tile_sub(const int64_t *__restrict__ ss, int nsubs, int *__restrict__ tsub, int64_t ntiles) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= ntiles) return;
+    const int s = upper_idx<int64_t>(ss, nsubs, t * (int64_t)RV_SPLIT_TILE);
+    tsub[t] = s < 0 ? 0 : s;
+}
+int rv_tile_sub_launch(Workspace &ws, const int64_t *sub_start, int nsubs, int *tile_sub, int64_t ntiles) {
+    if (ntiles <= 0) return 0;
+    hipLaunchKernelGGL(k_tile_sub, dim3((unsigned)ceil_div(ntiles, TB)), dim3(TB), 0, ws.stream, sub_start, nsubs, tile_sub, ntiles);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total) {
     if (total <= 0) return 0;
     hipLaunchKernelGGL(k_lower, dim3((unsigned)ceil_div(total, TB)), dim3(TB), 0, ws.stream, T, mbegin, mend, mpre, nmatch, total);

@@ -137,6 +137,7 @@ struct Align {
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
+    DBuf dPbReady; u32 pb_epoch = 0;   // k_pb_shift: per tile of a round, the number of the launch that read it
     DBuf dNextTsub;              // tile -> sub-index of the level being written (rv_tile_sub_launch)
     DBuf dTmin;                  // per RV_SPLIT_TILE ranks of the level being written: lower bound of its LCP values (split -> bubble rounds)
     HBuf hLeafRoots[2], hLeafOut;   // pinned staging: roots per ping-pong slot; counters + anchors of the leaf launches at the end of a run
@@ -1290,6 +1291,13 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             ba.par.Qlcp = (u32 *)pb; pb += W * 4;
             ba.par.Qbw = pb; pb += W;
             ba.par.Qlast = pb;
+            ba.par.tready = nullptr; ba.par.epoch = 0;
+            if (!getenv("RV_PB_TWO_PASS")) {      // (test hook: copy-out + scatter as two kernels through the scratch arrays)
+                const size_t before = a->dPbReady.cap;
+                RV_TRY(a->dPbReady.reserve(TT * 4 + 64));
+                if (a->dPbReady.cap != before) RV_HIP(hipMemsetAsync(a->dPbReady.p, 0, a->dPbReady.cap, q));      // launch numbers start at 1
+                ba.par.tready = a->dPbReady.as<u32>();
+            }
         }
         id = h->prof.begin(q, RV_K_BUBBLE, 0.0);
         // Three independent groups of work: children that fit into LDS, children replayed in one workgroup each, and the
@@ -1324,6 +1332,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         bool seq_before = false;      // an earlier round of this level ran the sequential kernels: the tile bounds have to be refreshed
         for (size_t r = 0; r + 1 < round_first.size(); r++) {
             const int first = round_first[r], count = round_first[r + 1] - first;
+            ba.par.epoch = ++a->pb_epoch;
+            if (a->pb_epoch == 0xFFFFFFFFu) { a->pb_epoch = 0; RV_HIP(hipMemsetAsync(a->dPbReady.p, 0, a->dPbReady.cap, q)); }
             RV_TRY(rv_bubble_par_round_launch(h->ws, ba, first, count, a->woff[(size_t)(first + count)] - a->woff[(size_t)first],
                                               a->toff[(size_t)(first + count)] - a->toff[(size_t)first], seq_before));
             if (round_seq[r]) { RV_TRY(rv_bubble_seq_launch(h->ws, ba, first, count)); seq_before = true; }
@@ -1373,7 +1383,8 @@ static int builtin_leaf_setup(rv_index *h) {
     a->lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
     RV_HIP(hipMemsetAsync(base, 0, 256, q));
     if (!a->leaf_stream) {
-        // (tried: lowest stream priority for the leaf launches, highest for the level pipeline -- no gain, 306 against 302 ms at C4)
+        // (tried twice: lowest stream priority for the leaf launches -- 306 against 302 ms at C4 while the launches were bound by their
+        // atomics, 282 against 277 ms after that)
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream2, hipStreamNonBlocking));
         RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));

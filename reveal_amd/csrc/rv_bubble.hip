@@ -362,6 +362,86 @@ __global__ __launch_bounds__(TB) void k_pb_scatter(RvBubbleArgs b, int first, in
     }
 }
 
+// Copy-out and scatter in one pass over the ranks that change place: non-movers only move towards higher ranks, by at most the
+// number of movers, so a tile writes into itself and into the first ranks of the tile (or, with thousands of movers, tiles) above it.  Every tile reads its ranks into
+// registers, says so (tready), and writes once the tile above it has said the same.  Tiles are taken from the top of the round
+// down: a workgroup only ever waits for one that was dispatched before it.  Half the traffic of the two-pass form (which moved
+// 198 x 10^6 ranks per cut at the top levels of 2 x 250 Mbp: 36 bytes per rank).
+__global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int count, int64_t total_tiles) {
+    __shared__ TileMap tm;
+    __shared__ sa_t cw_lo[32], cw_hi[32];
+    int dd; int64_t ti;
+    tile_of(b, first, count, total_tiles - 1 - (int64_t)blockIdx.x, &dd, &ti);
+    u32 *ready = b.par.tready + (b.par.toff[dd] + ti);
+    const u32 epoch = b.par.epoch;
+    const u32 M = par_desc(b, dd) ? b.par.mcnt[dd] : 0u;
+    const RvBubbleDesc ds = b.desc[dd];
+    const int64_t lo = ti * PT, hi = lo + PT < ds.n ? lo + PT : ds.n;
+    bool dirty = false;
+    if (M > 0) {
+        const int ncw = ds.cut1 - ds.cut0 < 32 ? ds.cut1 - ds.cut0 : 32;
+        if ((int)threadIdx.x < ncw) { cw_lo[threadIdx.x] = b.cut_lo[ds.cut0 + threadIdx.x]; cw_hi[threadIdx.x] = b.cut_hi[ds.cut0 + threadIdx.x]; }
+        tile_map(b, dd, M, lo, hi, &tm);
+        dirty = tm.dirty;
+    }
+    if (!dirty) {      // nothing of this tile moves, nothing moves into it
+        if (threadIdx.x == 0) __hip_atomic_store(ready, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    constexpr int PER = PT / TB;
+    sa_t vs[PER]; lcp_t vl[PER]; uint8_t vb[PER], vf[PER];
+    const uint8_t *flag = b.flag + ds.off;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int64_t r = lo + threadIdx.x + (int64_t)k * TB;
+        if (r < hi) { const int64_t g = ds.off + r; vs[k] = b.SA[g]; vl[k] = b.LCP[g]; vb[k] = b.BWT[g]; vf[k] = flag[r]; }
+        else { vs[k] = 0; vl[k] = 0; vb[k] = 0; vf[k] = 2; }
+    }
+    // The word only says "my loads have returned": nothing another workgroup reads is published with it, so neither side needs a
+    // release or an acquire (at device scope those write back / invalidate the L2 of the XCD: 96000 times per launch that was 2.3 x
+    // the time of the two-pass form).  The loads are waited for explicitly, the barrier collects the workgroup.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ready, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the tiles above that are written from here: a rank moves up by (sites at or below it) - (movers below it) <= b1 - a0
+        const int64_t top = hi - 1 + (int64_t)(tm.b1 - tm.a0);
+        const int64_t t_last = (top < ds.n ? top : ds.n - 1) / PT;
+        for (int64_t t = ti + 1; t <= t_last; t++)
+            while (__hip_atomic_load(ready + (t - ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+    }
+    const int ncw = ds.cut1 - ds.cut0 < 32 ? ds.cut1 - ds.cut0 : 32;
+    const u32 *R = b.par.R + b.woff[dd], *S = b.par.Qsite + b.woff[dd];
+    int64_t fr[PER];
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const int64_t r = lo + threadIdx.x + (int64_t)k * TB;
+        fr[k] = -1;
+        if (vf[k] == 2) continue;                                   // movers are placed by k_pb_movers
+        u32 x = tm.a0, y = tm.a1;                                   // movers with rank < r
+        while (x < y) { const u32 mid = (x + y) >> 1; if (R[mid] < (u32)r) x = mid + 1; else y = mid; }
+        u32 u = tm.b0, v = tm.b1;                                   // sites <= r
+        while (u < v) { const u32 mid = (u + v) >> 1; if (S[mid] <= (u32)r) u = mid + 1; else v = mid; }
+        fr[k] = r - (int64_t)x + (int64_t)u;
+    }
+    __syncthreads();                                    // thread 0 has seen the tile above read
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        if (fr[k] < 0) continue;
+        const int64_t r = lo + threadIdx.x + (int64_t)k * TB, f = fr[k];
+        const int64_t g = ds.off + r, gf = ds.off + f;
+        const sa_t s = vs[k];
+        b.SA[gf] = s; b.LCP[gf] = vl[k]; b.BWT[gf] = vb[k];
+        if ((gf >> 11) != (g >> 11)) atomicMin(&b.par.tmin[gf >> 11], (u32)vl[k]);
+        if (f != r) {                                                // reveal.c:692 SAi[SA[x-1]] = x, kept only where a later cut will look
+            bool in = false;
+            for (int q = 0; q < ncw && !in; q++) in = s >= cw_lo[q] && s < cw_hi[q];
+            for (int q = ds.cut0 + 32; q < ds.cut1 && !in; q++) in = s >= b.cut_lo[q] && s < b.cut_hi[q];
+            if (in) b.SAi[s] = (sa_t)f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int count, int64_t total) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (id >= total) return;
@@ -408,10 +488,15 @@ int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, 
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_pb_rank, dim3((unsigned)count), dim3(TB), 0, q, b, first);
     RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pb_copyout, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
-    RV_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_pb_scatter, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
-    RV_LAUNCH_CHECK();
+    if (b.par.tready) {
+        hipLaunchKernelGGL(k_pb_shift, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count, total_tiles);
+        RV_LAUNCH_CHECK();
+    } else {
+        hipLaunchKernelGGL(k_pb_copyout, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_pb_scatter, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
+        RV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_pb_movers, dim3(wb), dim3(TB), 0, q, b, first, count, total_window);
     RV_LAUNCH_CHECK();
     return 0;

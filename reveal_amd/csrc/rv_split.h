@@ -79,6 +79,8 @@ struct RvParBubble {
     u32 *Qsite, *QF, *Qt, *Qlcp;   // movers by (site, t): site, final rank, t, LCP value at the final rank
     sa_t *Qs;                // ... suffix
     uint8_t *Qbw, *Qlast;    // ... BWT byte, 1 = last of its site's group
+    u32 *tready;             // per tile of the round (toff numbering): the launch number in which the tile was read (k_pb_shift); nullptr =
+    u32 epoch;               // the two-pass form (copy-out + scatter).  epoch: this launch's number, never 0, never repeated for a buffer
 };
 
 struct RvBubbleArgs {

@@ -550,7 +550,12 @@ __global__ __launch_bounds__(NT) void k_tile_carry(RvSplitArgs a) {
     }
 }
 
-constexpr int CARRY_CH = 8192;      // default chunk; RV_CARRY_CH overrides it (tests force the chunked path on small inputs)
+// default chunk; RV_CARRY_CH overrides it (tests force the chunked path on small inputs).  One pass of a CARRY_NT-thread workgroup:
+// 16 KB of LDS.  (It was 8192 tiles in a 1024-thread workgroup with 64 KB: next to a leaf launch, whose workgroups fill the LDS
+// of every CU and are replaced one by one as they finish, such a workgroup waited for the whole launch -- 1 ms at the deep
+// levels of 2 x 250 Mbp, 35 us without the neighbour.)
+constexpr int CARRY_NT = 256;
+constexpr int CARRY_CH = CARRY_NT * CARRY_PER;
 __global__ __launch_bounds__(TB) void k_carry_reduce(RvSplitArgs a, int ch, u32 *__restrict__ ch_cnt, MinSt *__restrict__ ch_ms) {
     __shared__ u32   s_c[TB / 64][3];
     __shared__ MinSt s_m[TB / 64][3];
@@ -603,16 +608,16 @@ __global__ __launch_bounds__(64) void k_carry_chunks(RvSplitArgs a, int nch, u32
     a.total[c] = rc;
     if (rc != a.expect_total[c]) atomicOr(a.err, 1u);
 }
-__global__ __launch_bounds__(1024) void k_carry_apply(RvSplitArgs a, int ch, const u32 *__restrict__ ch_cnt, const MinSt *__restrict__ ch_ms) {
-    __shared__ u32   s_c[1024 / 64][3];
-    __shared__ MinSt s_m[1024 / 64][3];
+__global__ __launch_bounds__(CARRY_NT) void k_carry_apply(RvSplitArgs a, int ch, const u32 *__restrict__ ch_cnt, const MinSt *__restrict__ ch_ms) {
+    __shared__ u32   s_c[CARRY_NT / 64][3];
+    __shared__ MinSt s_m[CARRY_NT / 64][3];
     __shared__ u32   s_runc[3];
     __shared__ MinSt s_runm[3];
-    __shared__ u32   s_x[1024 * CARRY_PER], s_y[1024 * CARRY_PER];
+    __shared__ u32   s_x[CARRY_NT * CARRY_PER], s_y[CARRY_NT * CARRY_PER];
     const int64_t t_lo = (int64_t)blockIdx.x * ch, t_hi = t_lo + ch < a.ntiles ? t_lo + ch : a.ntiles;
     if (threadIdx.x < 3) { s_runc[threadIdx.x] = ch_cnt[(size_t)blockIdx.x * 3 + threadIdx.x]; s_runm[threadIdx.x] = ch_ms[(size_t)blockIdx.x * 3 + threadIdx.x]; }
     __syncthreads();
-    carry_scan_range<1024, 3>(a, 0, t_lo, t_hi, s_runc, s_runm, s_c, s_m, s_x, s_y);
+    carry_scan_range<CARRY_NT, 3>(a, 0, t_lo, t_hi, s_runc, s_runm, s_c, s_m, s_x, s_y);
 }
 
 __global__ __launch_bounds__(TB) void k_lower(uint8_t *__restrict__ T, const sa_t *__restrict__ mbegin, const sa_t *__restrict__ mend,
@@ -1317,9 +1322,10 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     hipLaunchKernelGGL(k_split_count, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, m, t, a, D);
     RV_LAUNCH_CHECK();
     const int ch = getenv("RV_CARRY_CH") ? std::max(1, atoi(getenv("RV_CARRY_CH"))) : CARRY_CH;
+    // up to four passes of one small workgroup per class (one launch instead of three: 2 x 5 Mbp has 24 such levels); the
+    // 1024-thread form with its 66 KB of LDS took one pass there, but had to wait for room next to a leaf launch (0.3-0.6 ms)
     if (a.ntiles <= 4 * (int64_t)ch) {
-        if (a.ntiles <= 256 * CARRY_PER) hipLaunchKernelGGL(k_tile_carry<256>, dim3(3), dim3(256), 0, ws.stream, a);
-        else hipLaunchKernelGGL(k_tile_carry<1024>, dim3(3), dim3(1024), 0, ws.stream, a);
+        hipLaunchKernelGGL(k_tile_carry<256>, dim3(3), dim3(256), 0, ws.stream, a);
         RV_LAUNCH_CHECK();
     } else {
         const int nch = (int)ceil_div(a.ntiles, ch);
@@ -1331,7 +1337,7 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
         RV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_carry_chunks, dim3(1), dim3(64), 0, ws.stream, a, nch, ch_cnt, ch_ms);
         RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)nch), dim3(1024), 0, ws.stream, a, ch, (const u32 *)ch_cnt, (const MinSt *)ch_ms);
+        hipLaunchKernelGGL(k_carry_apply, dim3((unsigned)nch), dim3(CARRY_NT), 0, ws.stream, a, ch, (const u32 *)ch_cnt, (const MinSt *)ch_ms);
         RV_LAUNCH_CHECK();
     }
     hipLaunchKernelGGL(k_split_emit, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, (const uint8_t *)D, BWT, m, a);

@@ -1,5 +1,5 @@
 OUT=gpurun_out/$1; mkdir -p $OUT
-timeout 900 python -m pytest tests/test_gpu_align.py tests/test_gpu_golden.py tests/test_gpu_fullsize.py tests/test_gpu_single_steps.py tests/test_gpu_handoff.py tests/test_gpu_callbacks.py -m gpu -x -q 2>&1 | tail -6 > $OUT/pytest.log
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -6 > $OUT/pytest.log
 run() { lab=$1; shift
   env "$@" timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu --no-check 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); b=d['breakdown_ms_per_step']; print('C4 $lab', round(d['ms_per_step'],1), {k: round(v,1) for k,v in b.items()})" >> $OUT/ab.txt
   env "$@" timeout 300 python bench.py --L 5000000 --steps 10 --warmup 3 --no-cpu --no-check 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); b=d['breakdown_ms_per_step']; print('C2 $lab', round(d['ms_per_step'],2), {k: round(v,2) for k,v in b.items()})" >> $OUT/ab.txt
@@ -7,6 +7,6 @@ run() { lab=$1; shift
 }
 for rep in 1 2; do
 run new FOO=1
+run twopass RV_PB_TWO_PASS=1
 run prev RV_LIB_DIR=$PWD/gpurun_ab/prev
 done
-timeout 400 python tools/level_log.py 2 250000000 2> $OUT/level_c4.txt < /dev/null

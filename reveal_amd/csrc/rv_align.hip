@@ -196,7 +196,7 @@ struct Align {
     void release() {
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release();
-        dTmin.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
+        dTmin.release(); dPbReady.release(); dNextTsub.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (leaf_stream2) { (void)hipStreamSynchronize(leaf_stream2); (void)hipStreamDestroy(leaf_stream2); leaf_stream2 = nullptr; }
         if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
@@ -1383,6 +1383,8 @@ static int builtin_leaf_setup(rv_index *h) {
     a->lf_tr = (rv_trace *)(base + 256 + a->leaf_anchor_cap * 20 + ((8 - (a->leaf_anchor_cap * 20) % 8) % 8));
     RV_HIP(hipMemsetAsync(base, 0, 256, q));
     if (!a->leaf_stream) {
+        // (tried: the largest LDS class and the 1024-thread replays of the bubble on streams of their own, four side streams instead of two,
+        // and the lower-casing queued behind their fork -- 267.4 / 267.9 / 265.4 ms for both / one / neither at C4: no gain)
         // (tried twice: lowest stream priority for the leaf launches -- 306 against 302 ms at C4 while the launches were bound by their
         // atomics, 282 against 277 ms after that)
         RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));

@@ -92,6 +92,13 @@ template <int CTRL, int ROWMASK> __device__ inline u32 rv_dpp_u32(u32 x) { retur
     STEP(0x118, 0xf, (lane & 15) >= 8)                                               \
     STEP(0x142, 0xa, (lane & 31) >= 16)                                              \
     STEP(0x143, 0xc, lane >= 32)
+// maximum over the wave (every lane gets it)
+__device__ inline u64 rv_wave_max_u64(u64 v) {
+#define RV_STEP_(CTRL, RM, TAKE) { const u64 t = ((u64)rv_dpp_u32<CTRL, RM>((u32)(v >> 32)) << 32) | rv_dpp_u32<CTRL, RM>((u32)v); v = t > v ? t : v; }
+    RV_WAVE_SCAN_STEPS(RV_STEP_)        // (a lane without a source lane sees 0: the identity)
+#undef RV_STEP_
+    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
+}
 // inclusive prefix sum over the wave
 __device__ inline u32 rv_wave_incl_sum_u32(u32 v) {
     const int lane = threadIdx.x & 63;

@@ -82,12 +82,7 @@ __global__ __launch_bounds__(1024) void k_decide_offsets(RvDecideArgs d) {
         const int s = base + threadIdx.x;
         u32 c0 = 0, c1 = 0;
         if (s < d.nsubs) { c0 = d.child_n[3 * (size_t)s]; c1 = d.child_n[3 * (size_t)s + 1]; }
-        u32 i0 = c0, i1 = c1;
-#pragma unroll
-        for (int dd = 1; dd < 64; dd <<= 1) {
-            const u32 t0 = __shfl_up(i0, dd, 64), t1 = __shfl_up(i1, dd, 64);
-            if (lane >= dd) { i0 += t0; i1 += t1; }
-        }
+        const u32 i0 = rv_wave_incl_sum_u32(c0), i1 = rv_wave_incl_sum_u32(c1);      // (DPP: this one workgroup is a chain of latencies, 50 rounds at 50000 sub-indices)
         if (lane == 63) { s_w[w][0] = i0; s_w[w][1] = i1; }
         __syncthreads();
         u32 b0 = s_run[0], b1 = s_run[1], t0 = 0, t1 = 0;

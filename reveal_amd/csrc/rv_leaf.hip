@@ -44,12 +44,7 @@ __device__ inline u64 hash_step(u64 acc, u64 i, int64_t v) {      // oracle/reve
 // work on different sub-indices of the same root (disjoint rank ranges of the LDS arrays).
 #define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-__device__ inline u64 wave_max_u64(u64 v) {
-#define LF_STEP_(CTRL, RM, TAKE) { const u64 t = ((u64)rv_dpp_u32<CTRL, RM>((u32)(v >> 32)) << 32) | rv_dpp_u32<CTRL, RM>((u32)v); v = t > v ? t : v; }
-    RV_WAVE_SCAN_STEPS(LF_STEP_)        // (a lane without a source lane sees 0: the identity)
-#undef LF_STEP_
-    return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
-}
+__device__ inline u64 wave_max_u64(u64 v) { return rv_wave_max_u64(v); }
 __device__ inline u64 wave_sum_u64(u64 v) {       // trace mode only
     for (int d = 32; d >= 1; d >>= 1) v += ((u64)__shfl_xor((u32)(v >> 32), d, 64) << 32) | __shfl_xor((u32)v, d, 64);
     return v;

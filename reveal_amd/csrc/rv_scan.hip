@@ -229,6 +229,12 @@ __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__
     const int lane = threadIdx.x & 63;
     const u32 cnt = t < ntile ? tilecnt[t] : 0u;
     const u32 ob = t < ntile ? tileovf[t] : 0u;
+    // PASS 1: the wave's best of ONE sub-index stays in registers and is merged over the workgroup at the end (with a handful of
+    // sub-indices every wave of the grid aims at the same few words of `best`); a wave that meets further sub-indices sends those on at once
+    int st_sub = -1; u64 st_key = 0;
+    auto raise = [&](int lsub, u64 v) {      // (only a wave that would raise the maximum goes to the atomic unit)
+        if ((unsigned long long)v > __atomic_load_n(&best[lsub], __ATOMIC_RELAXED)) atomicMax(&best[lsub], (unsigned long long)v);
+    };
     for (u32 q = j; ; q += RV_PAIR_SLOTS) {
         const bool have = q < cnt && (q < RV_PAIR_SLOTS || ob + (q - RV_PAIR_SLOTS) < ovf_cap);
         RvPairRec r; int sub = -1; u64 key = 0;
@@ -238,20 +244,34 @@ __global__ __launch_bounds__(TB) void k_pick_slots(const RvPairRec *__restrict__
         }
         if (PASS == 1) {
             u64 todo = __ballot(sub >= 0);
-            while (todo) {              // one atomic per (wave, sub-index)
+            while (todo) {              // one candidate per (wave, sub-index)
                 const int leader = (int)__builtin_ctzll(todo);
-                const int lsub = __shfl(sub, leader, 64);
+                const int lsub = __builtin_amdgcn_readlane(sub, leader);
                 const bool mine = sub == lsub;
-                u64 v = mine ? key : 0;
-                for (int d = 32; d >= 1; d >>= 1) { const u64 o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
-                // (only a wave that would raise the maximum goes to the atomic unit: with a handful of sub-indices every wave hits the same few words)
-                if (lane == leader && (unsigned long long)v > __atomic_load_n(&best[lsub], __ATOMIC_RELAXED)) atomicMax(&best[lsub], (unsigned long long)v);
+                const u64 v = rv_wave_max_u64(mine ? key : 0);
+                if (st_sub < 0 || st_sub == lsub) { st_sub = lsub; st_key = v > st_key ? v : st_key; }
+                else if (lane == 0) raise(lsub, v);
                 todo &= ~__ballot(mine);
             }
         } else if (have && best[sub] == (unsigned long long)key) {
             picks[RV_PAIR_HDR + sub] = r;
         }
         if (!__any(q + RV_PAIR_SLOTS < cnt)) break;       // (the wave leaves the loop together: the ballots above need all lanes)
+    }
+    if (PASS == 1) {
+        __shared__ int s_sub[TB / 64];
+        __shared__ u64 s_key[TB / 64];
+        if (lane == 0) { s_sub[threadIdx.x >> 6] = st_sub; s_key[threadIdx.x >> 6] = st_key; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int k = 0; k < TB / 64; k++) {
+                const int sb = s_sub[k];
+                if (sb < 0) continue;
+                u64 v = s_key[k];
+                for (int k2 = k + 1; k2 < TB / 64; k2++) if (s_sub[k2] == sb) { v = s_key[k2] > v ? s_key[k2] : v; s_sub[k2] = -1; }
+                raise(sb, v);
+            }
+        }
     }
 }
 

@@ -7,6 +7,6 @@ run() { lab=$1; shift
 }
 for rep in 1 2; do
 run new FOO=1
-run twopass RV_PB_TWO_PASS=1
 run prev RV_LIB_DIR=$PWD/gpurun_ab/prev
+
 done

@@ -185,6 +185,39 @@ def test_untraced_run_same_anchors(name, inputs, minl):
     assert ra == ga
     assert idx.T.encode("latin-1") == ref["T"]
     assert got["stats"]["splits"] == ref["stats"]["nsplits"]
+    if len(inputs) == 2:      # two samples: every sub-index the reference visits is counted (the leaf kernel counts the ones it does not scan)
+        assert got["stats"]["steps"] == ref["stats"]["nsteps"]
+
+
+@pytest.mark.parametrize("L,minl,trace", [(900, 1, False), (900, 2, False), (900, 2, True), (5000, 3, False), (40000, 4, False)])
+def test_leaf_many_short_anchors(L, minl, trace):
+    """unrelated random sequences with a tiny minl: hundreds of anchors per leaf root -- more than the leaf kernel stages in LDS per
+    workgroup (256), so the overflow path writes some of them straight to the output; L = 900: the whole index is one leaf root"""
+    rng = np.random.default_rng(L + minl)
+    inputs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(2)]
+    if trace:
+        compare(inputs, minl)
+        return
+    ref, T = oracle_run(inputs, minl, 2)
+    idx = feed(mod(False).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(minl, 2, trace=False)
+    rl, rn, roff, rpos = ref["anchors"]
+    ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    gl, goff, gpos = got["anchors"]
+    ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
+    assert len(ra) > 256 and ra == ga
+    assert idx.T.encode("latin-1") == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"] and got["stats"]["steps"] == ref["stats"]["nsteps"]
+
+
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b_m10", fa("1a", "1b"), 10), ("1a1a", fa("1a", "1a"), 20), ("5way", fa("1a", "1b", "1c", "1d", "1e"), 20)])
+def test_bubble_rounds_two_pass_form(monkeypatch, name, inputs, minl):
+    """RV_PB_TWO_PASS=1: copy-out + scatter through the scratch arrays instead of the one-pass shift (k_pb_shift) -- same arrays"""
+    monkeypatch.setenv("RV_BUBBLE_PAR_MIN", "64")
+    monkeypatch.setenv("RV_NO_LEAF", "1")
+    monkeypatch.setenv("RV_PB_TWO_PASS", "1")
+    compare(inputs, minl, 2)
 
 
 def test_chunked_carry_scan(monkeypatch):

@@ -398,6 +398,7 @@ static int leaf_launch(rv_index *h) {
     la.roots = droots.as<RvLeafRoot>();
     la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h);
     la.nsep0 = h->nsep[0]; la.minl = a->minl; la.lcap = h->maxlcp;
+    la.stage_cap = getenv("RV_LEAF_ACAP") ? (u32)atoi(getenv("RV_LEAF_ACAP")) : 256u;
     la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_pos = a->lf_pos;
     la.stats = a->lf_stats;
     la.trace = a->trace_on ? 1 : 0; la.trace_count = a->lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = a->lf_tr;

@@ -21,6 +21,7 @@ struct RvLeafArgs {
     int minl;
     u32 lcap;                                                // bound on every LCP value (max LCP of the main index)
     // outputs
+    u32 stage_cap;                                           // anchors a workgroup stages in LDS before it writes them out (<= 256; RV_LEAF_ACAP: test hook)
     u32 *anchor_count; u32 anchor_cap; u32 *anchor_l; int64_t *anchor_pos;      // anchor k: length anchor_l[k], members anchor_pos[2k], [2k+1]
     unsigned long long *stats;                               // [0] sub-indices visited, [1] anchors, [2] anchored bp, [3] max depth
     int trace; u32 *trace_count; u32 trace_cap; rv_trace *trace_out;

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
     __syncthreads();                                   // the only workgroup barrier
     const sa_t nsep0 = (sa_t)A.nsep0;
     const u32 minl = A.minl > 0 ? (u32)A.minl : 0u;
+    const u32 acap = A.stage_cap < (u32)ACAP ? A.stage_cap : (u32)ACAP;
     u32 my_steps = 0, my_splits = 0, my_maxdepth = 0; u64 my_bp = 0;     // accumulated by lane 0 of every wave
     bool have = wv == 0;
 #ifdef RV_LEAF_PROF
@@ -224,7 +225,7 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
         if (lane == 0) {
             my_splits++; my_bp += L;
             const u32 k = atomicAdd(&s_na, 1u);
-            if (k < (u32)ACAP) { an_l[k] = L; an_a[k] = (sa_t)pa; an_b[k] = (sa_t)pb; }
+            if (k < acap) { an_l[k] = L; an_a[k] = (sa_t)pa; an_b[k] = (sa_t)pb; }
             else {                                   // (more anchors than the staging holds: minl of a few bases)
                 const u32 slot = atomicAdd(A.anchor_count, 1u);
                 if (slot < A.anchor_cap) { A.anchor_l[slot] = L; A.anchor_pos[2 * (size_t)slot] = pa; A.anchor_pos[2 * (size_t)slot + 1] = pb; }
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
 #endif
     }
     __syncthreads();                                   // every wave has left the loop: the root is finished
-    const u32 na = s_na < (u32)ACAP ? s_na : (u32)ACAP;
+    const u32 na = s_na < acap ? s_na : acap;
     if (tid == 0) {
         s_base = na ? atomicAdd(A.anchor_count, na) : 0u;
         atomicAdd(&A.stats[0], s_stats[0]); atomicAdd(&A.stats[1], s_stats[1]); atomicAdd(&A.stats[2], s_stats[2]); atomicMax(&A.stats[3], s_stats[3]);

@@ -189,15 +189,14 @@ def test_untraced_run_same_anchors(name, inputs, minl):
         assert got["stats"]["steps"] == ref["stats"]["nsteps"]
 
 
-@pytest.mark.parametrize("L,minl,trace", [(900, 1, False), (900, 2, False), (900, 2, True), (5000, 3, False), (40000, 4, False)])
-def test_leaf_many_short_anchors(L, minl, trace):
-    """unrelated random sequences with a tiny minl: hundreds of anchors per leaf root -- more than the leaf kernel stages in LDS per
-    workgroup (256), so the overflow path writes some of them straight to the output; L = 900: the whole index is one leaf root"""
-    rng = np.random.default_rng(L + minl)
-    inputs = ["".join(rng.choice(list("ACGT"), size=L)) for _ in range(2)]
-    if trace:
-        compare(inputs, minl)
-        return
+@pytest.mark.parametrize("acap", [0, 1, 3])
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b", fa("1a", "1b"), 20), ("1a1b_m10", fa("1a", "1b"), 10), ("d1d2", fa("d1", "d2"), 20), ("synth_pair", None, 20)])
+def test_leaf_anchor_staging_overflow(monkeypatch, acap, name, inputs, minl):
+    """RV_LEAF_ACAP: the leaf kernel stages that many anchors per workgroup in LDS (256 by default) and writes the rest straight
+    to the output, one reservation each -- forced here with a staging area of 0 / 1 / 3 anchors"""
+    monkeypatch.setenv("RV_LEAF_ACAP", str(acap))
+    if inputs is None:
+        inputs = [g.decode() for g in synth.genomes(400000, 2)]
     ref, T = oracle_run(inputs, minl, 2)
     idx = feed(mod(False).index(), inputs)
     idx.construct()
@@ -206,7 +205,7 @@ def test_leaf_many_short_anchors(L, minl, trace):
     ra = sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
     gl, goff, gpos = got["anchors"]
     ga = sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl)))
-    assert len(ra) > 256 and ra == ga
+    assert ra == ga
     assert idx.T.encode("latin-1") == ref["T"]
     assert got["stats"]["splits"] == ref["stats"]["nsplits"] and got["stats"]["steps"] == ref["stats"]["nsteps"]
 

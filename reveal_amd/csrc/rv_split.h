@@ -109,7 +109,11 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
 int rv_lower_launch(Workspace &ws, uint8_t *T, const sa_t *mbegin, const sa_t *mend, const int64_t *mpre, int nmatch, int64_t total);
 // tile_sub[t] = the sub-index that holds rank t * RV_SPLIT_TILE (sub_start ascending, nsubs entries)
 int rv_tile_sub_launch(Workspace &ws, const int64_t *sub_start, int nsubs, int *tile_sub, int64_t ntiles);
-#define RV_BUBBLE_BIG_N 16384
+// children up to this many ranks are replayed by a 256-thread workgroup, larger ones by 1024 threads (8 against 2 workgroups per CU: the replay is
+// a chain of latencies, so the level is done sooner with more of them resident -- C4 bubble 42.5 -> 40.0 ms from 16 K to 64 K, 41.5 at 256 K, 44.9 at 8 K)
+#ifndef RV_BUBBLE_BIG_N
+#define RV_BUBBLE_BIG_N 65536
+#endif
 // children up to this many ranks are bubbled on LDS copies of their arrays (one workgroup, all cuts)
 #define RV_BUBBLE_LDS_N0 2048
 #define RV_BUBBLE_LDS_N1 4096

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, i
 constexpr int KEY_TILE = 1024;
 constexpr u64 KEY_MASK = (1ull << 56) - 1;
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay) {
+                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
     slut[threadIdx.x] = lut[threadIdx.x];
@@ -69,10 +69,15 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         const int64_t i = base + k;
         if (i < n) {
             u64 key = 0;
+            u32 at = 0xFFu;            // first of the K symbols that is a stop ('$', 'N', past the end), 0xFF = none
+            for (int j = K - 1; j >= 0; j--) { const u32 c = code[k + j]; at = ((c == stop0) | (c == stop1) | (c == 0u)) ? (u32)j : at; }
             for (int j = 0; j < K; j++) key = key * radix + code[k + j];
             // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
-            // travels with the key instead of being gathered from the text at the end ('$' for position 0)
-            const u64 prev = pay ? (u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56 : 0ull;
+            // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Bits 48..55 (the
+            // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --
+            // k_heads and the text round read it instead of taking the key apart digit by digit (a function of the digits:
+            // keys that are equal in their digits are equal here too)
+            const u64 prev = pay ? ((u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56) | ((u64)at << 48) : 0ull;
             keys[i] = key | prev;
             vals[i] = (sav_t)i;
         }
@@ -84,18 +89,29 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 // LCP != NULL (the fused path of rv_build_sa): a head's LCP with its predecessor in the suffix array -- whichever member of the
 // group in front ends up last, it shares that group's K symbols -- is the common prefix of the two keys, cut at the first
 // '$' / 'N' (interface.c:97-114): the digits of both keys, least significant first, by multiply-high division.
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; };      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
-// first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF
-__device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
-    u64 x = key & KEY_MASK;
-    u32 at = 0xFFFFFFFFu;
-    for (int pos = kd.K - 1; pos >= 0; pos--) {
-        const u64 qx = __umul64hi(x, kd.magic);
-        const u32 d = (u32)(x - qx * kd.radix);
-        x = qx;
-        at = ((d == kd.stop0) | (d == kd.stop1) | (d == 0u)) ? (u32)pos : at;
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+// first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
+__device__ inline u32 key_first_stop(u64 key, const KeyDigits &) {
+    const u32 at = (u32)(key >> 48) & 0xFFu;
+    return at == 0xFFu ? 0xFFFFFFFFu : at;
+}
+// number of leading digits (of K) two keys share: both are taken apart from the top, 8 / 4 / 2 / 1 digits at a time (as 16-digit
+// numbers with leading zeros), following the half that differs -- four rounds of two divisions instead of K
+__device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
+    u32 cnt = 0;
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+        const u64 d = kd.pw[st], mg = kd.pmagic[st];
+        u64 qx = __umul64hi(x, mg), qy = __umul64hi(y, mg);
+        u64 rx = x - qx * d, ry = y - qy * d;
+        // (the rounded-up reciprocal can overshoot by one when the divisor is large; x, y < 2^48)
+        if ((int64_t)rx < 0) { qx--; rx += d; }
+        if ((int64_t)ry < 0) { qy--; ry += d; }
+        const bool top = qx != qy;            // the difference lies in the upper half
+        cnt += top ? 0u : (8u >> st);
+        x = top ? qx : rx; y = top ? qy : ry;
     }
-    return at;
+    return cnt - (16u - (u32)kd.K);
 }
 __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
                                               lcp_t *__restrict__ LCP, KeyDigits kd) {
@@ -108,14 +124,21 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     if (LCP && hd) {
         u32 l = 0;
         if (j > 0) {
-            u64 x = ka, y = kb;
-            l = (u32)kd.K;
-            for (int pos = kd.K - 1; pos >= 0; pos--) {
-                const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
-                const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
-                x = qx; y = qy;
-                l = ((dx != dy) | (dy == kd.stop0) | (dy == kd.stop1) | (dy == 0u)) ? (u32)pos : l;      // going up: the last hit is the first position
+            const u64 dm = (1ull << 48) - 1;
+            if (kd.K <= 16) {
+                l = key_common_digits(ka & dm, kb & dm, kd);
+            } else {      // (tiny alphabets: more than 16 symbols in 48 bits) digit by digit
+                u64 x = ka & dm, y = kb & dm;
+                l = (u32)kd.K;
+                for (int pos = kd.K - 1; pos >= 0; pos--) {
+                    const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
+                    const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
+                    x = qx; y = qy;
+                    l = (dx != dy) ? (u32)pos : l;      // going up: the last hit is the first position
+                }
             }
+            const u32 st = key_first_stop(keys[j], kd);
+            l = l < st ? l : st;
         }
         LCP[j] = (lcp_t)l;
     }
@@ -837,6 +860,11 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     bool fused = LCP && BWT && d_maxlcp && bits <= 48 && !getenv("RV_NO_FUSED_LCP");
     KeyDigits kd;
     kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
+    for (int st = 0; st < 4; st++) {
+        u64 d = 1;
+        for (int e = 0; e < (8 >> st); e++) d = d > (~0ull) / radix ? ~0ull : d * radix;      // (saturates for large alphabets: nothing is ever that large then)
+        kd.pw[st] = d; kd.pmagic[st] = d == ~0ull ? 0ull : (~0ull) / d + 1;
+    }
     if (fused) RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
 
     // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
@@ -853,7 +881,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     // -- first key, sorted on its K*bits significant bits
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0);
+                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, bits, &in1));

@@ -117,7 +117,9 @@ int rv_tile_sub_launch(Workspace &ws, const int64_t *sub_start, int nsubs, int *
 // children up to this many ranks are bubbled on LDS copies of their arrays (one workgroup, all cuts)
 #define RV_BUBBLE_LDS_N0 2048
 #define RV_BUBBLE_LDS_N1 4096
+#ifndef RV_BUBBLE_LDS_N2
 #define RV_BUBBLE_LDS_N2 8192
+#endif
 #define RV_BUBBLE_LDS_N RV_BUBBLE_LDS_N2
 // leading children above this many ranks take the data-parallel rounds (rv_bubble.hip); measured on C2: 16 K -> 485 Mbp/s,
 // 256 K -> 541, 512 K -> 555, 1 M -> 550, 2 M -> 511 (below it one workgroup replays the cuts of a child faster than ~18 launches)

@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-CPU_SAMPLE_L = 5_000_000   # the CPU legs and the parity leg run on a 2 x 5 Mbp sample of the same generator (BASELINE configs[1])
+CPU_SAMPLE_L = 20_000_000   # the CPU legs and the parity leg run on a 2 x 20 Mbp sample of the same generator (about 11 s of single-thread CPU work)
 
 
 def build_index(seqs, sa64=False):
@@ -69,7 +69,7 @@ def cpu_baseline(seqs, minl, minn):
 def cpu_all_cores(L, genomes, minl, minn, max_workers=0):
     """All host cores: P independent single-threaded alignments at once (the reference's only parallelism is independent
     `reveal rem` jobs, reveal/align.py:45-53; its C path is single-threaded).  P = the cores this process may use, capped by
-    free memory (~0.7 GB per 2 x 5 Mbp job).  Workers are separate processes (oracle/cpu_worker.py) released at a common
+    free memory (~0.9 GB per 2 x 5 Mbp job, ~3 GB per 2 x 20 Mbp).  Workers are separate processes (oracle/cpu_worker.py) released at a common
     start time; rate = all bases / (latest end - earliest start)."""
     try:
         cores = len(os.sched_getaffinity(0))
@@ -310,7 +310,7 @@ def main():
             "properties_full_size": properties,
         }
         if world == 1 and not args.no_cpu:
-            # CPU legs and bit-exact parity on a stated sample: 2 x 5 Mbp (or the workload itself when it is not larger)
+            # CPU legs and bit-exact parity on a stated sample: 2 x 20 Mbp (or the workload itself when it is not larger)
             cl = min(args.L, CPU_SAMPLE_L)
             same = cl == args.L
             cseqs = seqs if same else synth.genomes(cl, args.genomes, seed=42)

@@ -7,5 +7,5 @@ run() { lab=$1; shift
 }
 for rep in 1 2 3; do
 run new FOO=1
-run prev RV_LIB_DIR=$PWD/gpurun_ab/prev
+run unfused RV_PB_UNFUSED=1
 done

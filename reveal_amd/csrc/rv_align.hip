@@ -213,6 +213,17 @@ void rv_align_free(rv_index *h) {
 // leading children above this many ranks take the data-parallel bubble rounds.  Measured crossovers: two samples (one cut per
 // sample; C2: 256 K 758, 384 K - 512 K 777, 768 K - 1 M 789, 1.5 M 724 Mbp/s; no difference at 2 x 50 Mbp) 768 K; more samples
 // (a cut per sample and child; C3: 184 ms per step against 195 at 512 K) 256 K
+// the device-side error word of the recursion (bits: 1 split sizes, 2 bubble search found no landing site, 4 device-side decision outside its
+// intervals, 16 a tile of the one-pass shift waited too long for its neighbour) -> message
+static int report_dev_err(u32 err) {
+    if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+    if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
+    if (err & 2u) { rv_set_error("bubble_sort (data-parallel rounds): a mover found no landing site"); return -1; }
+    if (err & 16u) { rv_set_error("bubble_sort (data-parallel rounds): a tile waited in vain for the tile above it (workgroups not dispatched in index order?)"); return -1; }
+    if (err) { rv_set_error("device-side error word %u", err); return -1; }
+    return 0;
+}
+
 static int64_t bubble_par_default(bool multi) { return multi ? (int64_t)262144 : (int64_t)RV_BUBBLE_PAR_N; }
 
 static const sa_t *cur_sa(rv_index *h) { Align *a = h->al; return a->level == 0 ? h->dSA.as<sa_t>() : a->lvSA[a->cur].as<sa_t>(); }
@@ -707,8 +718,7 @@ int rv_frontier_scan(rv_index *h) {
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
         RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, level_hook, early || a->leaf_launch_due,
                                 (d_ss && a->cur_dev_ok) ? a->d_next_tsub2 : nullptr));
-        if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
-        if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
+        RV_TRY(report_dev_err(err));
         int si = 0;
         for (size_t k = 0; k < a->recs.size(); k++) {
             const int64_t r = (int64_t)a->recs[k].rank;
@@ -1349,8 +1359,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         u32 err = 0;
         RV_HIP(hipMemcpyAsync(&err, a->dErr.p, 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
-        if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
-        if (err & 4u) { rv_set_error("device-side decision: a picked match does not lie inside the intervals of its sub-index"); return -1; }
+        RV_TRY(report_dev_err(err));
     }
 
     if (a->level == 0) h->main_arrays_freed = true;      /* reveal.c:1279-1284 */

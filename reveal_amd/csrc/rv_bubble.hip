@@ -407,8 +407,15 @@ __global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int 
         // the tiles above that are written from here: a rank moves up by (sites at or below it) - (movers below it) <= b1 - a0
         const int64_t top = hi - 1 + (int64_t)(tm.b1 - tm.a0);
         const int64_t t_last = (top < ds.n ? top : ds.n - 1) / PT;
-        for (int64_t t = ti + 1; t <= t_last; t++)
-            while (__hip_atomic_load(ready + (t - ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) __builtin_amdgcn_s_sleep(2);
+        // (workgroups are dispatched in index order and this one only waits for earlier ones; should that ever not hold, the wait ends
+        // after ~a second with the error word set instead of hanging the device)
+        for (int64_t t = ti + 1; t <= t_last; t++) {
+            u32 spins = 0;
+            while (__hip_atomic_load(ready + (t - ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > (1u << 24)) { atomicOr(b.err, 16u); break; }
+            }
+        }
     }
     const int ncw = ds.cut1 - ds.cut0 < 32 ? ds.cut1 - ds.cut0 : 32;
     const u32 *R = b.par.R + b.woff[dd], *S = b.par.Qsite + b.woff[dd];
@@ -445,6 +452,9 @@ __global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int 
 __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int count, int64_t total) {
     const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (id >= total) return;
+    if (id == 0) *b.par.gcount = 0;                                  // nobody reads it in this kernel: ready for the next round.  (In front of the
+                                                                     // return below: behind it, a round whose first cut had no candidates left its
+                                                                     // movers on the list, and the next round's search went over them again)
     int dd; int64_t slot;
     slot_of(b, first, count, id, &dd, &slot);
     if (!par_desc(b, dd)) return;
@@ -465,7 +475,6 @@ __global__ __launch_bounds__(TB) void k_pb_movers(RvBubbleArgs b, int first, int
     }
     if (slot < (int64_t)b.cnt[dd]) b.flag[ds.off + b.list[base + slot]] = 0;
     if (slot == 0) b.state[dd].next = 0x7fffffff;                    // tells the sequential kernels this (child, cut) is done
-    if (id == 0) *b.par.gcount = 0;                                  // nobody reads it in this kernel: ready for the next round
 }
 
 }  // namespace

@@ -177,12 +177,18 @@ __device__ inline bool unsorted_at(const uint8_t *head, int64_t j, int64_t n) {
 
 __global__ __launch_bounds__(TB) void k_cp_count(const uint8_t *__restrict__ head, int64_t n, u32 *__restrict__ tilecnt) {
     __shared__ u32 wsum[TB / 64];
-    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    // a thread counts CP_ITEMS consecutive entries from one 8-byte load (+ the byte behind them): counts only, so the order inside the
+    // tile does not matter (k_cp_emit keeps its strided, order-preserving layout)
+    static_assert(CP_ITEMS == 8, "eight head bytes per load");
+    const int64_t j0 = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;
     u32 c = 0;
+    if (j0 + CP_ITEMS < n) {
+        const u64 hb = *reinterpret_cast<const u64 *>(head + j0);
+        const u64 nx = (hb >> 8) | ((u64)head[j0 + CP_ITEMS] << 56);        // byte k = head[j + 1]
 #pragma unroll
-    for (int r = 0; r < CP_ITEMS; r++) {
-        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
-        if (j < n && unsorted_at(head, j, n)) c++;
+        for (int k = 0; k < CP_ITEMS; k++) c += !(((hb >> (8 * k)) & 0xFFu) && ((nx >> (8 * k)) & 0xFFu));
+    } else {
+        for (int64_t j = j0; j < j0 + CP_ITEMS && j < n; j++) c += unsorted_at(head, j, n);
     }
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -428,8 +434,18 @@ __device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 
 
 constexpr int MEDIUM_GROUP = 64;      // groups of up to 64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
 __global__ __launch_bounds__(TB) void k_medium_back(const uint8_t *__restrict__ flag, const sav_t *__restrict__ Sout, sav_t *__restrict__ S, int64_t m) {
-    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (q < m && flag[q] == 2) S[q] = Sout[q];
+    // eight list entries per thread, their flags in one load (one byte load per thread made this 1.3 ms at m = 5e8: 7.8e6 waves for 0.5 GB)
+    const int64_t q0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * 8;
+    if (q0 >= m) return;
+    if (q0 + 8 <= m) {
+        const u64 f = *reinterpret_cast<const u64 *>(flag + q0);
+        if (((f ^ 0x0202020202020202ull) - 0x0101010101010101ull) & ~(f ^ 0x0202020202020202ull) & 0x8080808080808080ull) {      // some byte == 2
+#pragma unroll
+            for (int k = 0; k < 8; k++) if (((f >> (8 * k)) & 0xFFu) == 2u) S[q0 + k] = Sout[q0 + k];
+        }
+    } else {
+        for (int64_t q = q0; q < m; q++) if (flag[q] == 2) S[q] = Sout[q];
+    }
 }
 // MODE 2: every member of a group finds its own rank -- one text comparison with each other member, all lanes busy.
 // MODE 1: the same for groups of three and more; a pair is ordered by its first thread alone.
@@ -543,12 +559,14 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
 // members of big groups -> sublist (ordered)
 __global__ __launch_bounds__(TB) void k_flag_count(const uint8_t *__restrict__ flag, int64_t n, u32 *__restrict__ tilecnt) {
     __shared__ u32 wsum[TB / 64];
-    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    const int64_t j0 = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;      // (consecutive entries per thread: counts only)
     u32 c = 0;
+    if (j0 + CP_ITEMS <= n) {
+        const u64 f = *reinterpret_cast<const u64 *>(flag + j0);
 #pragma unroll
-    for (int r = 0; r < CP_ITEMS; r++) {
-        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
-        if (j < n && flag[j] == 1) c++;
+        for (int k = 0; k < CP_ITEMS; k++) c += ((f >> (8 * k)) & 0xFFu) == 1u;
+    } else {
+        for (int64_t j = j0; j < n && j < j0 + CP_ITEMS; j++) c += flag[j] == 1;
     }
     for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
@@ -982,7 +1000,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             if (tmode == 0) RT_LAUNCH(0); else if (tmode == 2) RT_LAUNCH(2); else RT_LAUNCH(1);
 #undef RT_LAUNCH
             SA_HIP(hipGetLastError());
-            hipLaunchKernelGGL(k_medium_back, dim3(mb), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
+            hipLaunchKernelGGL(k_medium_back, dim3((unsigned)ceil_div(m, (int64_t)TB * 8)), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }
         else {
             fused = false;      // (a doubling round orders by ranks, not by text: no common prefixes come out of it)

@@ -61,9 +61,16 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_reduce(const T *__restric
     __shared__ T lds[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     T acc = Op::id();
+    if (base + SCAN_ITEMS <= n) {      // a thread's items as vector loads (element by element every load instruction touched SCAN_ITEMS times the lines)
+        T v[SCAN_ITEMS];
+        __builtin_memcpy(v, in + base, sizeof v);
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++)
-        if (base + i < n) acc = Op::f(acc, in[base + i]);
+        for (int i = 0; i < SCAN_ITEMS; i++) acc = Op::f(acc, v[i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++)
+            if (base + i < n) acc = Op::f(acc, in[base + i]);
+    }
     T tot;
     (void)block_exclusive<T, Op>(acc, lds, &tot);
     if (threadIdx.x == 0) totals[blockIdx.x] = tot;
@@ -74,14 +81,25 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_tile_scan(const T *in, T *out,
     __shared__ T lds[4];
     const int64_t base = (int64_t)blockIdx.x * SCAN_TILE + (int64_t)threadIdx.x * SCAN_ITEMS;
     T v[SCAN_ITEMS];
+    const bool whole = base + SCAN_ITEMS <= n;
+    if (whole) __builtin_memcpy(v, in + base, sizeof v);
+    else {
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : Op::id();
+        for (int i = 0; i < SCAN_ITEMS; i++) v[i] = (base + i < n) ? in[base + i] : Op::id();
+    }
     T acc = Op::id();
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) acc = Op::f(acc, v[i]);
     T tot;
     T pre = block_exclusive<T, Op>(acc, lds, &tot);
     if (tile_prefix) pre = Op::f(tile_prefix[blockIdx.x], pre);
+    if (whole) {
+        T o[SCAN_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) { const T nx = Op::f(pre, v[i]); o[i] = INCL ? nx : pre; pre = nx; }
+        __builtin_memcpy(out + base, o, sizeof o);
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; i++) {
         T nx = Op::f(pre, v[i]);

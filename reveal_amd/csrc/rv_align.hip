@@ -1251,8 +1251,12 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         RV_TRY(rv_split_launch(h->ws, cur_sa(h), cur_lcp(h), a->dD.as<uint8_t>(), cur_bwt(h), lv.m, lt, sa, (int)a->split_subs.size()));
     }
     h->prof.end(q, id);
-    if (!a->early_bubble)
-        RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
+    if (!a->early_bubble) {
+        // many short ranges (the deep levels: 10^5 matches of ~100 bases): a wave per range; few long ones: a thread per base, which looks
+        // its range up by a binary search over the prefix sums (17 dependent loads per base at 10^5 ranges: 0.2 ms per level at C4)
+        if (lt.nmatch > 256 && a->mpre.back() / lt.nmatch <= 512) RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, lt.nmatch));
+        else RV_TRY(rv_lower_launch(h->ws, h->dT.as<uint8_t>(), lt.mbegin, lt.mend, (const int64_t *)(tb + o_mpre), lt.nmatch, a->mpre.back()));
+    }
     const double t1 = now_s();
     a->lg[2] = t1 - t0;           // label/split/lower enqueued
 

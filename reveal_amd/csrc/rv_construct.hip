@@ -70,8 +70,11 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         if (i < n) {
             u64 key = 0;
             u32 at = 0xFFu;            // first of the K symbols that is a stop ('$', 'N', past the end), 0xFF = none
-            for (int j = K - 1; j >= 0; j--) { const u32 c = code[k + j]; at = ((c == stop0) | (c == stop1) | (c == 0u)) ? (u32)j : at; }
-            for (int j = 0; j < K; j++) key = key * radix + code[k + j];
+            for (int j = 0; j < K; j++) {
+                const u32 c = code[k + j];
+                key = key * radix + c;
+                at = ((at == 0xFFu) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at;
+            }
             // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
             // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Bits 48..55 (the
             // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --

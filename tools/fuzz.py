@@ -25,6 +25,8 @@ ENVS = [
     {"RV_BUBBLE_LDS_ALWAYS": "1", "RV_NO_LEAF": "1"},
     {"RV_NO_EARLY_SPLIT": "1"},
     {"RV_CARRY_CH": "2", "RV_SA_NO_TEXT": "1", "RV_LCP_BY_RANK": "1"},
+    {"RV_BUBBLE_PAR_MIN": "64", "RV_PB_TWO_PASS": "1", "RV_NO_LEAF": "1"},
+    {"RV_LEAF_ACAP": "2"},
 ]
 
 

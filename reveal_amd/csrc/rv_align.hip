@@ -704,7 +704,7 @@ int rv_frontier_scan(rv_index *h) {
             u32 err = 0;
             RV_HIP(hipMemcpyAsync(&err, a->dErr.p, 4, hipMemcpyDeviceToHost, h->ws.stream));
             RV_HIP(hipStreamSynchronize(h->ws.stream));
-            if (err & 1u) { rv_set_error("split: the intervals returned by graphalign do not partition the sub-index (child size mismatch)"); return -1; }
+            RV_TRY(report_dev_err(err));
         }
     } else if (!a->multi) {
         u32 err = 0;

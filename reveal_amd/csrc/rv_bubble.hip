@@ -370,6 +370,8 @@ __global__ __launch_bounds__(TB) void k_pb_scatter(RvBubbleArgs b, int first, in
 __global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int count, int64_t total_tiles) {
     __shared__ TileMap tm;
     __shared__ sa_t cw_lo[32], cw_hi[32];
+    __shared__ int s_gave_up;
+    if (threadIdx.x == 0) s_gave_up = 0;
     int dd; int64_t ti;
     tile_of(b, first, count, total_tiles - 1 - (int64_t)blockIdx.x, &dd, &ti);
     u32 *ready = b.par.tready + (b.par.toff[dd] + ti);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int 
             u32 spins = 0;
             while (__hip_atomic_load(ready + (t - ti), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) {
                 __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1u << 24)) { atomicOr(b.err, 16u); break; }
+                if (++spins > (1u << 24)) { atomicOr(b.err, 16u); s_gave_up = 1; break; }
             }
         }
     }
@@ -432,6 +434,7 @@ __global__ __launch_bounds__(TB) void k_pb_shift(RvBubbleArgs b, int first, int 
         fr[k] = r - (int64_t)x + (int64_t)u;
     }
     __syncthreads();                                    // thread 0 has seen the tile above read
+    if (s_gave_up) return;                              // (never seen; the run fails on the error word -- but nothing is written over ranks nobody has read)
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         if (fr[k] < 0) continue;

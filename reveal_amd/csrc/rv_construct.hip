@@ -117,15 +117,17 @@ __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
     return cnt - (16u - (u32)kd.K);
 }
 __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
-                                              lcp_t *__restrict__ LCP, KeyDigits kd) {
+                                              lcp_t *__restrict__ LCP, KeyDigits kd, u32 *__restrict__ d_maxlcp) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (j >= n) return;
-    const u64 kb = keys[j] & KEY_MASK, ka = j > 0 ? keys[j - 1] & KEY_MASK : 0ull;
-    const bool hd = (j == 0) || ka != kb;
-    head[j] = hd;
-    seed[j] = hd ? (u32)j : 0u;
+    // the payload bits (56..63 the byte in front, 48..55 the first stop) only exist on the fused path; without it the key may
+    // use all 64 bits (sigma = 3 and n > 2^28: 29 symbols in 58 bits) and is compared whole
+    const u64 mask = LCP ? KEY_MASK : ~0ull;
+    const bool in = j < n;
+    const u64 kb = in ? keys[j] & mask : 0ull, ka = (in && j > 0) ? keys[j - 1] & mask : 0ull;
+    const bool hd = in && ((j == 0) || ka != kb);
+    if (in) { head[j] = hd; seed[j] = hd ? (u32)j : 0u; }
+    u32 l = 0;
     if (LCP && hd) {
-        u32 l = 0;
         if (j > 0) {
             const u64 dm = (1ull << 48) - 1;
             if (kd.K <= 16) {
@@ -144,6 +146,12 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
             l = l < st ? l : st;
         }
         LCP[j] = (lcp_t)l;
+    }
+    // the largest LCP of the index also counts the heads' values (fused_put only sees the other group members): one guarded
+    // atomic per wave -- the values are below K, so after the first few waves nothing passes the guard any more
+    if (LCP && d_maxlcp) {
+        const u32 wm = (u32)rv_wave_max_u64((u64)l);
+        if ((threadIdx.x & 63) == 0 && wm > *reinterpret_cast<volatile u32 *>(d_maxlcp)) atomicMax(d_maxlcp, wm);
     }
 }
 
@@ -914,7 +922,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     uint8_t *head = bhead.as<uint8_t>();
     u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
-    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd);
+    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd, fused ? d_maxlcp : (u32 *)nullptr);
     SA_HIP(hipGetLastError());
     SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
     hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep);

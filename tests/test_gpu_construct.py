@@ -250,3 +250,21 @@ def test_fused_lcp_equals_the_separate_pass(monkeypatch):
     T, nsep, nodes = assemble(seqs, toupper=False)
     c = oracle(False).construct(T, nsep, len(seqs))
     assert np.array_equal(fused[0], c["SA"]) and np.array_equal(fused[1], c["LCP"])
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_maxlcp_counts_the_group_heads(sa64):
+    """The fused SA/LCP build takes the index' largest LCP from two places: members of a first-key group (text round) and the
+    group heads (common prefix of two keys).  Unrelated short inputs have no group with two members at all, so the maximum
+    is a head's value; it bounds the cut windows of bubble_sort (reveal.c:666-727), so it must not come out too small."""
+    rng = np.random.default_rng(7)
+    for L in (40, 300, 3000):
+        seqs = ["".join("ACGT"[x] for x in rng.integers(0, 4, L)) for _ in range(2)]
+        idx = feed(mod(sa64).index(), seqs)
+        idx.construct()
+        lcp = idx.array("LCP")
+        assert idx.maxlcp == int(lcp.max()), (L, idx.maxlcp, int(lcp.max()))
+    # every group cut short by a '$' / 'N' inside its key
+    idx = feed(mod(sa64).index(), ["ACGTNACGTNACGTN", "ACGTNACGT"])
+    idx.construct()
+    assert idx.maxlcp == int(idx.array("LCP").max())

@@ -14,13 +14,18 @@ configuration: 2 x 250 Mbp, 1 % SNP, -m 20 (n = 5*10^8, 32-bit index).
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1, one process per GPU, no collective on the data path either way:
-  * inputs of at least 100 Mbp (the default): ONE alignment divided over the
-    ranks -- rank 0 constructs and runs the top levels, every rank finishes a
-    share of the frontier's sub-indices (reveal_amd/shard.py; BASELINE config 4's
-    "interval-split scaling"; "scaling": "strong");
-  * smaller inputs: every rank anchors its own genome set ("weak").
-  --mode per-rank / --mode divide override the choice.
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes itself under
+torch.distributed.run with N ranks (one process per GPU); under a launcher whose
+WORLD_SIZE differs from --gpus it refuses to run.
+
+N > 1, one process per GPU, no collective on the data path in either mode
+(independent `reveal rem` jobs are the reference's only parallelism, reveal/align.py:27-54):
+  * per-rank ("weak"): every rank anchors its own genome set -- the line's `value`;
+  * divide ("strong"): ONE alignment divided over the ranks -- rank 0 constructs and
+    runs the top levels, the ranks pull batches of the frontier's sub-indices from it
+    (reveal_amd/shard.py; BASELINE config 4's "interval-split scaling") -- reported in
+    the same line under "divide" for inputs of at least 100 Mbp (the default workload).
+  --mode per-rank / --mode divide run one of the two only.
 value = bases of the whole job / max-over-ranks time.  Rank 0 prints one JSON line.
 """
 import argparse
@@ -43,7 +48,11 @@ def build_index(seqs, sa64=False):
     for k, s in enumerate(seqs):
         idx.addsample("g%d" % k)
         idx.addsequence(s)
+    import torch
+    t0 = time.perf_counter()
     idx.upload()               # text resident in HBM before anything is timed
+    torch.cuda.synchronize()
+    idx.upload_ms = (time.perf_counter() - t0) * 1e3
     return idx
 
 
@@ -115,6 +124,17 @@ def cpu_all_cores(L, genomes, minl, minn, max_workers=0):
                 late=max(r["late"] for r in res), value=sum(r["bases"] for r in res) / span / 1e6)
 
 
+def spawn_ranks(n):
+    """`bench.py --gpus N` outside a launcher: the same command line again under torch.distributed.run, one rank per GPU"""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
+
+
 def anchor_set(l, off, pos):
     return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
 
@@ -142,11 +162,28 @@ def main():
                          "config 5's 20 independent 5-genome jobs on 8 GPUs (reveal/align.py:45-53); the default 1 is the metric's config")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks" % (args.gpus, os.environ.get("WORLD_SIZE")))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    if os.environ.get("RV_BENCH_DRYRUN"):      # launcher plumbing only (tests/test_cpu_host.py, no GPU): the ranks meet, count themselves, rank 0 reports
+        import torch.distributed as dist
+        if world > 1:
+            dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.int64)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_counted": int(t.item()), "gpus_flag": args.gpus}))
+        if world > 1:
+            dist.destroy_process_group()
+        return
     if world > 1:
         import torch.distributed as dist
         if os.environ.get("RV_BENCH_SHARE_GPU"):      # plumbing check on a one-GPU box: every rank on device 0, gloo instead of RCCL
@@ -161,16 +198,24 @@ def main():
     _lib.set_device(local_rank)
 
     mode = "divide" if args.divide else args.mode
-    if mode == "auto":
-        mode = "divide" if args.L * args.genomes >= 100_000_000 else "per-rank"
-    divide = mode == "divide" and world > 1
-    jobs = max(1, args.jobs) if not divide else 1
-    seqs = synth.genomes(args.L, args.genomes, seed=42 + (0 if divide else 1000 * rank))
+    big = args.L * args.genomes >= 100_000_000
+    if world == 1:
+        modes = ["per-rank"]
+    elif mode == "auto":      # both in one invocation: throughput (weak) and the interval-split curve (strong)
+        modes = ["per-rank"] + (["divide"] if big else [])
+    else:
+        modes = [mode]
+    jobs = max(1, args.jobs) if "per-rank" in modes else 1
+    seqs = synth.genomes(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0))
     bases = sum(len(s) for s in seqs)
     idx = build_index(seqs, args.sa64)
+    upload_ms = idx.upload_ms      # host->device copy of the assembled text (rv_upload), outside every timed region
     # further jobs of this rank: their own inputs (other seeds), handles and streams
     extra = [build_index(synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank + 17 * j), args.sa64) for j in range(1, jobs)]
-    bases *= jobs
+    # a divided run works on ONE input: rank 0's (seed 42); the other ranks hold its text
+    idx_div = idx
+    if "divide" in modes and "per-rank" in modes and rank != 0:
+        idx_div = build_index(synth.genomes(args.L, args.genomes, seed=42), args.sa64)
 
     def barrier():
         torch.cuda.synchronize()
@@ -178,10 +223,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        if divide:      # rank 0 constructs and runs the top levels, every rank finishes a share of the frontier
+    def step(divide):
+        if divide:      # rank 0 constructs and runs the top levels, the ranks pull sub-index batches from it
             from reveal_amd import shard
-            return shard.align_sharded(idx, args.minl, args.minn)
+            return shard.align_sharded(idx_div, args.minl, args.minn)
         if extra:      # (ctypes releases the GIL inside the library calls: the jobs' level loops overlap on the GPU)
             import threading
             res = [None] * (1 + len(extra))
@@ -201,38 +246,62 @@ def main():
         idx.construct()
         return idx.align_builtin(args.minl, args.minn)
 
-    for _ in range(args.warmup):
-        step()
-    # inside the timed region only the roofline-judged kernel is timed (two HIP events per launch on the library's stream);
-    # the per-class breakdown comes from two extra, untimed steps with every class timed
     kname = "scan_multi" if args.genomes > 2 else "scan_pair"
-    for ix in [idx] + extra:
-        ix.prof(enable=True, reset=True, only=None if args.prof_all else (kname,))
-    barrier()
-    t0 = time.perf_counter()
-    last = None
-    for _ in range(args.steps):
-        last = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    prof = idx.prof(enable=False)
-    for ix in extra:      # the judged kernel over all jobs (launches that overlap other jobs' kernels share the GPU with them)
-        p2 = ix.prof(enable=False)
-        prof = {k: tuple(a + b for a, b in zip(prof[k], p2[k])) for k in prof}
+
+    def timed(divide):
+        """W untimed + K timed steps of one mode -> (max-over-ranks seconds, result of the last step, profile of the judged kernel)"""
+        for _ in range(args.warmup):
+            step(divide)
+        # inside the timed region only the roofline-judged kernel is timed (HIP events riding on its own dispatch, on the library's stream);
+        # the per-class breakdown comes from two extra, untimed steps with every class timed
+        for ix in [idx, idx_div] + extra:
+            ix.prof(enable=True, reset=True, only=None if args.prof_all else (kname,))
+        barrier()
+        t0 = time.perf_counter()
+        last = None
+        for _ in range(args.steps):
+            last = step(divide)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if rank == 0 and not divide and not args.no_check and len(modes) > 1:
+            last["T_after"] = idx.array("T")      # (the divided run of the same invocation works on the same handle afterwards)
+        prof = (idx_div if divide else idx).prof(enable=False)
+        for ix in extra:      # the judged kernel over all jobs (launches that overlap other jobs' kernels share the GPU with them)
+            p2 = ix.prof(enable=False)
+            prof = {k: tuple(a + b for a, b in zip(prof[k], p2[k])) for k in prof}
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not os.environ.get("RV_BENCH_SHARE_GPU") else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        return elapsed, last, prof
+
+    runs = {m: timed(m == "divide") for m in modes}
+    primary = modes[0]
+    divide = primary == "divide"
+    tmax, last, prof = runs[primary]
     # full-size properties of the last timed step's result (reveal_amd/check.py), before the breakdown steps run again
     properties = None
     if rank == 0 and not args.no_check:
         T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
+        nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
         if divide:      # (a divided run lower-cases each share on its own rank: rebuild the text from the merged anchors)
             from reveal_amd import shard
             T1 = shard.lower_text(T0, last["anchors"])
         else:
-            T1 = idx.array("T")
-        nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
+            T1 = last.pop("T_after", None)
+            if T1 is None:
+                T1 = idx.array("T")
         properties = check.recursion_properties(T0, T1, last["anchors"], nsep, args.minl)
         if divide:
             properties["text"] = "lower-cased text rebuilt from the merged anchors (each rank lower-cases its own share)"
-        del T0, T1
+        del T1
+        if "divide" in runs and not divide:      # the divided run of the same invocation: its merged anchors against the same checks
+            from reveal_amd import shard
+            dl = runs["divide"][1]
+            dp = check.recursion_properties(T0, shard.lower_text(T0, dl["anchors"]), dl["anchors"], nsep, args.minl)
+            properties["divide_all"] = dp["all"]
+            properties["divide_same_anchor_set_as_rank0_alone"] = anchor_set(*dl["anchors"]) == anchor_set(*last["anchors"])
+        del T0
     breakdown = None
     if rank == 0 and not divide:
         idx.prof(enable=True, reset=True)
@@ -242,20 +311,12 @@ def main():
         breakdown = {k: v[1] / 2 for k, v in idx.prof(enable=False).items() if v[0]}
     barrier()
 
-    total_bases, tmax = bases, elapsed
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        b = torch.tensor([bases], dtype=torch.float64, device="cuda")
-        dist.all_reduce(b, op=dist.ReduceOp.SUM)
-        tmax, total_bases = float(t.item()), float(b.item())
-        if divide:
-            total_bases = float(bases)      # every rank worked on the same inputs
+    total_bases = float(bases * jobs) * (1 if divide else world)
 
     if rank == 0:
         launches, ms, nbytes = prof[kname]
         achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
-        traffic = None
+        traffic = traffic_source = None
         for name in ("pmc_scan_%dx%d-%d.json" % (args.genomes, args.L, 64 if args.sa64 else 32), "pmc_scan.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if os.path.exists(pmc):
@@ -264,6 +325,9 @@ def main():
                     # per-launch HBM bytes from the PMC passes only describe the workload they were collected on
                     if pj.get("workload") == "%dx%d-%d" % (args.genomes, args.L, 64 if args.sa64 else 32):
                         traffic = pj.get("hbm_bytes_per_launch")
+                        # not measured in this run: rocprofv3's counter passes cannot run inside a timed bench
+                        traffic_source = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `bench.py` on this workload, %s launches, file dated %s)" % (
+                            name, pj.get("launches"), time.strftime("%Y-%m-%d", time.gmtime(os.path.getmtime(pmc))))
                         break
                 except Exception:
                     pass
@@ -294,11 +358,15 @@ def main():
             "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42%s), rem -m %d -n %d, construct + full recursion, "
                                    "bench picker; text resident in HBM before the timed region (host->device copy of the text not timed)"
                                    % (args.genomes, args.L / 1e6, "" if divide else "+1000*rank", args.minl, args.minn),
-                       "bases_per_gpu": bases if not divide else bases / world, "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
+                       "bases_per_gpu": bases * jobs if not divide else bases / world, "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
                        "jobs_per_gpu": jobs, "sharding": sharding},
+            # the text's way into HBM, outside the timed region (SURVEY 8(d) asks for it as a sub-timing): the host->device copy of the
+            # assembled text, once per input; value_incl_upload charges it to every step
+            "upload_ms": upload_ms,
+            "value_incl_upload": total_bases * args.steps / (tmax + args.steps * upload_ms / 1e3) / 1e6,
             "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("multi" if args.genomes > 2 else "pair"),
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,
+                         "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,
                          "algorithmic_bytes_per_launch": (nbytes / launches) if launches else None,
                          "copy_peak": {"read_GBps": read_gbs, "copy_GBps_read_plus_write": copy_gbs, "bytes": 1 << 30,
                                        "frac_of_read_peak": (achieved / read_gbs) if read_gbs else None}},
@@ -309,6 +377,12 @@ def main():
             "sa_build": idx.sa_stats(),
             "properties_full_size": properties,
         }
+        if "divide" in runs and not divide:
+            dt, dl, _ = runs["divide"]
+            out["divide"] = {"value": float(bases) * args.steps / dt / 1e6, "unit": "Mbp/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "strong",
+                             "what": "ONE alignment (rank 0's input) divided over the %d ranks in the same invocation: rank 0 constructs and runs the top "
+                                     "levels, the ranks pull batches of the frontier's sub-indices from it, no collective" % world,
+                             "ranks_per_share": dl.get("shares"), "speedup_vs_rank0_alone": (tmax / args.steps) / (dt / args.steps)}
         if world == 1 and not args.no_cpu:
             # CPU legs and bit-exact parity on a stated sample: 2 x 20 Mbp (or the workload itself when it is not larger)
             cl = min(args.L, CPU_SAMPLE_L)
@@ -323,6 +397,8 @@ def main():
                     sample, cb["t_construct"], cb["t_align"],
                     "the reference's divsufsort (oracle/_ref)" if cb["ref_divsufsort"] else "the oracle's own sorter"),
                 "host_cores_available": os.cpu_count(),
+                "note": "measured on the sample, not on the workload: suffix sorting is n log n, so the CPU's rate per base at the full "
+                        "workload size is lower than this figure -- the GPU/CPU ratio read off this line is on the generous-to-CPU side",
             }
             if not args.no_allcores:
                 ac = cpu_all_cores(cl, args.genomes, args.minl, args.minn)

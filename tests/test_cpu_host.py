@@ -196,6 +196,24 @@ def test_divided_alignment_protocol_gloo(tmp_path):
     assert sorted(r["shares"]) == [113, 140] and r["splits"] == 8      # (LPT, not optimal: 100+40 | 60+40+7+5+1)
 
 
+def test_bench_gpus_flag_spawns_the_ranks():
+    """`bench.py --gpus N` outside a launcher starts N ranks itself (torch.distributed.run, 127.0.0.1) and reports n_gpus = N;
+    under a launcher whose world size differs from --gpus it refuses instead of silently reporting the wrong n_gpus
+    (RV_BENCH_DRYRUN: the ranks meet over gloo, count themselves and stop in front of the first GPU call)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["RV_BENCH_DRYRUN"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert r == {"dry_run": True, "n_gpus": 2, "ranks_counted": 2, "gpus_flag": 2}
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                         env=dict(env, WORLD_SIZE="3", RANK="0"), timeout=120)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in bad.stderr
+    one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, env=env, timeout=120)
+    assert json.loads(one.stdout.splitlines()[-1])["n_gpus"] == 1
+
+
 @pytest.mark.parametrize("names", [("1a", "1b"), ("1e", "1b"), ("1a", "1b", "1c", "1d", "1e"), ("d1", "d2")])
 def test_gfa_paths_spell_the_inputs(tmp_path, names):
     """the invariant of the reference's test15 (reveal/tests/test_reveal.py:150-159) for reveal_amd/gfa.py: the graph

@@ -191,6 +191,11 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
                        const void *sa, const void *lcp, const void *bwt, int on_device);
 /* largest LCP value of the constructed index (= window of bubble_sort, reveal.c:666-727; workers need the owner's) */
 uint32_t rv_maxlcp(const rv_index *h);
+/* what the anchor cascade (rv_cascade.hip) did in the last rv_align_builtin: out[0] = 1 it decided the run / 0 the level
+ * pipeline ran (out[1..] then describe the abandoned attempt), out[1] levels, out[2] top-level matches, out[3] repeat
+ * witnesses, out[4] sub-indices visited, out[5] sub-indices left undecided (rebuilt from their text and handed to the leaf
+ * kernel), out[6] ranks rebuilt, out[7] = 0 */
+int rv_cascade_info(const rv_index *h, int64_t *out);
 /* anchors chosen by the last rv_align_builtin: l[k], members off[k..k+1] -> pos[] (sorted) */
 int64_t rv_anchor_count(rv_index *h, int64_t *members);
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);

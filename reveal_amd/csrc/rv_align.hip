@@ -18,6 +18,7 @@
 #include "rv_decide.h"
 static_assert(RV_TSUB_TILE == RV_SPLIT_TILE, "one tile -> sub-index table serves the split passes and the multi-sample picker");
 #include "rv_leaf.h"
+#include "rv_cascade.h"
 #include <string.h>
 #include <algorithm>
 #include <chrono>
@@ -137,6 +138,8 @@ struct Align {
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
+    RvCascadeBufs cas;           // scratch of the anchor cascade (rv_cascade.hip)
+    RvCascadeOut cas_out{};      // what the last built-in run's cascade did
     DBuf dPbReady; u32 pb_epoch = 0;   // k_pb_shift: per tile of a round, the number of the launch that read it
     DBuf dNextTsub;              // tile -> sub-index of the level being written (rv_tile_sub_launch)
     DBuf dTmin;                  // per RV_SPLIT_TILE ranks of the level being written: lower bound of its LCP values (split -> bubble rounds)
@@ -195,7 +198,7 @@ struct Align {
     size_t leaf_na = 0;          // anchors of the leaf launches of the last run: they stay in the pinned staging buffer (hLeafOut: pos[2 na], l[na]) until fetched
     void release() {
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
-        scrSA.release(); scrLCP.release(); scrBWT.release();
+        scrSA.release(); scrLCP.release(); scrBWT.release(); cas.release();
         dTmin.release(); dPbReady.release(); dNextTsub.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
         if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
         if (leaf_stream2) { (void)hipStreamSynchronize(leaf_stream2); (void)hipStreamDestroy(leaf_stream2); leaf_stream2 = nullptr; }
@@ -1665,8 +1668,40 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
     return 0;
 }
 
+// The anchor cascade (rv_cascade.hip) in front of the level pipeline: an untraced two-sample run with one sequence per sample
+// is decided from the top-level match list wherever that is provably the reference's result; what is left undecided is rebuilt
+// from its text and finished by the leaf kernel.  It either does the whole run or leaves no trace (RV_NO_CASCADE=1: never tried).
+static int builtin_cascade(rv_index *h) {
+    Align *a = h->al;
+    memset(&a->cas_out, 0, sizeof a->cas_out);
+    if (a->multi || a->trace_on || !a->use_leaf || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || getenv("RV_NO_CASCADE")) return 0;
+    RvCascadeIO io;
+    io.anchor_count = a->lf_counters; io.anchor_cap = (u32)a->leaf_anchor_cap; io.anchor_l = a->lf_l; io.anchor_pos = a->lf_pos;
+    io.stats = a->lf_stats; io.leaf_err = a->lf_counters + 2;
+    io.stage_cap = getenv("RV_LEAF_ACAP") ? (u32)atoi(getenv("RV_LEAF_ACAP")) : 256u;
+    io.lvSA = &a->lvSA[0]; io.lvLCP = &a->lvLCP[0]; io.lvBWT = &a->lvBWT[0]; io.roots = &a->dLeafRoots[0];
+    RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out));
+    if (!a->cas_out.done) {
+        RV_HIP(hipMemsetAsync(a->dLeaf.p, 0, 256, h->ws.stream));      // anchors and counters of the attempt
+        return 0;
+    }
+    a->st.levels += a->cas_out.levels;
+    a->st.scanned_ranks += h->n;
+    a->lv.clear();                                                       // nothing left for the level pipeline
+    return 0;
+}
+
+int rv_cascade_info(const rv_index *h, int64_t *out) {
+    for (int k = 0; k < 8; k++) out[k] = 0;
+    if (!h->al) return 0;
+    const RvCascadeOut &c = h->al->cas_out;
+    out[0] = c.done ? 1 : 0; out[1] = c.levels; out[2] = c.cands; out[3] = c.witnesses; out[4] = c.children; out[5] = c.undecided; out[6] = c.rebuilt_ranks;
+    return 0;
+}
+
 int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     RV_TRY(builtin_setup(h, minl, minn));
+    RV_TRY(builtin_cascade(h));
     RV_TRY(builtin_levels(h, 0));
     return builtin_finish(h, out);
 }

@@ -1,0 +1,29 @@
+// rv_cascade.h -- host interface of the anchor cascade (rv_cascade.hip)
+#pragma once
+#include "rv_common.h"
+
+// device scratch of the cascade, kept between runs (grow-only like every other buffer of a handle)
+struct RvCascadeBufs {
+    DBuf d[24];
+    void release() { for (auto &b : d) b.release(); }
+};
+
+struct RvCascadeIO {
+    // where the built-in run collects its anchors and counters (the leaf kernel's output area, rv_leaf.h)
+    u32 *anchor_count; u32 anchor_cap; u32 *anchor_l; int64_t *anchor_pos;
+    unsigned long long *stats;        // [0] sub-indices visited, [1] anchors, [2] anchored bp, [3] max depth
+    u32 *leaf_err;
+    u32 stage_cap;
+    // level arrays + root table for the sub-indices that are rebuilt from their text
+    DBuf *lvSA, *lvLCP, *lvBWT, *roots;
+};
+
+struct RvCascadeOut {
+    bool done;                         // false: nothing was decided, the caller runs the level pipeline from the top
+    int levels;
+    int64_t cands, witnesses, children, undecided, rebuilt_ranks;
+    const char *why;                   // done == false: the reason
+};
+
+struct rv_index;
+int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl, RvCascadeOut *out);

@@ -1,0 +1,555 @@
+// rv_cascade.hip -- the anchor cascade: the built-in recursion of a two-sample alignment decided from the
+// TOP-LEVEL match list wherever that provably is what the reference's recursion does.
+//
+// The reference (reveallib/reveal.c:731-1338 with the benchmark callbacks of SURVEY 8(d): longest match of the
+// sub-index, ties to the smallest coordinate, linear interval model) scans every sub-index again after every split.
+// For related genomes nearly all of those scans only find what the first scan already found: a sub-index C that
+// descends from the root X (one interval per sample, [a0,a1) + [b0,b1)) holds the suffixes of X that start inside
+// its intervals, cut at the intervals' ends (split reveal.c:582-664 + bubble_sort :666-727), so
+//
+//   * gap i of X (ranks i-1, i) is a UNIQUE CROSS PAIR iff LCP[i] > LCP[i-1], LCP[i] > LCP[i+1] and the two suffixes
+//     start on different sides of nsep[0]; the matches of X (reveal.c:61-85) are its left-maximal unique cross pairs;
+//   * W[p], p = SA[j]: the longest prefix suffix p shares with any suffix of X other than its cross-pair partner
+//       = max(LCP[j-1], LCP[j+1]) if gap j is such a pair, max(LCP[j], LCP[j+2]) if gap j+1 is, else max(LCP[j], LCP[j+1]);
+//   * every match of C longer than Wmax(C) = max W over C's positions is a match of X cut to C -- shifted to start
+//     behind the matched text in front of C (whose last base is lower case by then: left-maximal, reveal.c:81-85) and
+//     capped at C's ends -- and every such cut match longer than Wmax(C) is a match of C (no third suffix of X shares
+//     that many characters with either of its suffixes).
+//
+// So the choice in C is known from X's match list whenever C's best cut match is longer than Wmax(C); C has no match
+// at all when it holds no cut match of minl characters and Wmax(C) < minl, or when one of its intervals is shorter
+// than minl.  Whatever is left undecided (a repeat inside the sub-index that is as long as its best match) is rebuilt
+// from its own text -- its arrays only depend on the text of its two intervals -- and handed to the leaf kernel
+// (rv_leaf.hip), which runs the literal recursion on it.  An undecided sub-index above the leaf kernel's size makes the
+// cascade give up before anything is written; the level pipeline (rv_align.hip) then runs as if it had never started.
+//
+// tools/cascade_proto.py is the same algorithm on the CPU beside the oracle's literal recursion (random inputs with
+// SNPs, indels, tandem repeats, N runs, identical copies); tests/test_gpu_cascade.py and tools/fuzz.py run this file
+// against the oracle with the cascade on and off.
+//
+// Level-synchronous like the pipeline it replaces, but on the match list (2.5 x 10^6 records at 2 x 250 Mbp) and the
+// witness list (positions with W >= minl) instead of the index: per level three small kernels --
+//   k_cas_assign   every live match / witness moves to the child of its sub-index that holds it (or dies) and bids for
+//                  that child's best match / raises its Wmax (one atomic per run of equal children in a wave)
+//   k_cas_winner   the match that holds a child's best bid writes its cut coordinates
+//   k_cas_decide   one thread per sub-index of the level: split (anchor out, children made), ended, or undecided
+#include "rv_index.h"
+#include "rv_cascade.h"
+#include "rv_leaf.h"
+#include <algorithm>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TB = 256;
+constexpr u32 NONE = 0xFFFFFFFFu;
+#ifdef RV_SA64
+constexpr int KEY_SHIFT = 40;                 // bid = length << 40 | (2^40 - 1 - position): lengths below 2^24, positions below 2^40
+#else
+constexpr int KEY_SHIFT = 32;
+#endif
+constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
+
+struct CasIv { sa_t a0, a1, b0, b1; };
+struct CasRes { sa_t qa, qb; u32 ql, lead, trail, state; };      // state: 0 not decided yet, 1 split, 2 ended
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4 };
+
+// the match (pa, pb, len) of the root cut to a sub-index: start shifted behind the sub-index' begin on both sides, length
+// capped at its ends
+__device__ inline bool cas_cut(const CasIv &iv, int64_t pa, int64_t pb, int64_t len, int64_t minl, int64_t *qa, int64_t *qb, int64_t *ql) {
+    const int64_t ka = (int64_t)iv.a0 - pa, kb = (int64_t)iv.b0 - pb;
+    int64_t k = ka > kb ? ka : kb;
+    k = k > 0 ? k : 0;
+    const int64_t a = pa + k, b = pb + k;
+    int64_t l = len - k;
+    const int64_t ra = (int64_t)iv.a1 - a, rb = (int64_t)iv.b1 - b;
+    l = l < ra ? l : ra;
+    l = l < rb ? l : rb;
+    *qa = a; *qb = b; *ql = l;
+    return l >= minl;
+}
+__device__ inline u64 cas_key(int64_t qa, int64_t ql) { return ((u64)ql << KEY_SHIFT) | (KEY_LOW - (u64)qa); }
+
+__device__ inline u64 shfl_up64(u64 v, int d) {
+    const u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+// atomicMax(dst[child], val) for the active lanes of a wave, one atomic per run of equal children (the lists are sorted by
+// position and a sub-index is an interval, so its members sit next to each other), and none when the bid cannot raise the word
+__device__ inline void seg_atomic_max64(u64 *__restrict__ dst, u32 child, u64 val, bool active) {
+    const int lane = threadIdx.x & 63;
+    if (!active) { child = NONE; val = 0; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 ov = shfl_up64(val, d);
+        const u32 oc = __shfl_up(child, d, 64);
+        if (lane >= d && oc == child && ov > val) val = ov;
+    }
+    const u32 nc = __shfl_down(child, 1, 64);
+    const bool last = lane == 63 || nc != child;
+    if (active && last && val > dst[child]) atomicMax((unsigned long long *)&dst[child], (unsigned long long)val);
+}
+__device__ inline void seg_atomic_max32(u32 *__restrict__ dst, u32 child, u32 val, bool active) {
+    const int lane = threadIdx.x & 63;
+    if (!active) { child = NONE; val = 0; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 ov = __shfl_up(val, d, 64);
+        const u32 oc = __shfl_up(child, d, 64);
+        if (lane >= d && oc == child && ov > val) val = ov;
+    }
+    const u32 nc = __shfl_down(child, 1, 64);
+    const bool last = lane == 63 || nc != child;
+    if (active && last && val > dst[child]) atomicMax(&dst[child], val);
+}
+
+// ---- witnesses: positions whose suffix shares minl characters or more with a suffix that is not its cross-pair partner ----
+constexpr int WT_ITEMS = 8;
+constexpr int WT_TILE = TB * WT_ITEMS;
+__global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t n,
+                                                    u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap, u32 *__restrict__ counters) {
+    __shared__ u32 sl[WT_TILE + 3];          // LCP of ranks j0-1 .. j0+TILE+1 (0 outside the array)
+    __shared__ uint8_t ss[WT_TILE + 2];      // side bit of ranks j0-1 .. j0+TILE
+    const int64_t j0 = (int64_t)blockIdx.x * WT_TILE;
+    for (int k = threadIdx.x; k < WT_TILE + 3; k += TB) { const int64_t j = j0 - 1 + k; sl[k] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
+    for (int k = threadIdx.x; k < WT_TILE + 2; k += TB) { const int64_t j = j0 - 1 + k; ss[k] = (j >= 0 && j < n) ? (uint8_t)(BWT[j] >> 7) : (uint8_t)0; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int r = 0; r < WT_ITEMS; r++) {
+        const int k = r * TB + threadIdx.x;
+        const int64_t j = j0 + k;
+        const u32 lm1 = sl[k], l0 = sl[k + 1], l1 = sl[k + 2], l2 = sl[k + 3];
+        const u32 sm1 = ss[k], s0 = ss[k + 1], s1 = ss[k + 2];
+        const bool pair0 = (j >= 1) & (l0 > lm1) & (l0 > l1) & (s0 != sm1);             // gap j is a unique cross pair
+        const bool pair1 = (j + 1 < n) & (l1 > l0) & (l1 > l2) & (s1 != s0);            // gap j+1 is
+        const u32 w = pair0 ? (lm1 > l1 ? lm1 : l1) : pair1 ? (l0 > l2 ? l0 : l2) : (l0 > l1 ? l0 : l1);
+        const bool hit = (j < n) & (w >= minl);
+        const u64 bal = __ballot(hit);
+        if (bal) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&counters[C_NWIT], (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, 0, 64);
+            if (hit) {
+                const u32 o = base + (u32)__popcll(bal & lt);
+                if (o < cap) { w_pos[o] = SA[j]; w_val[o] = w; }
+            }
+        }
+    }
+}
+
+// ---- the match list, sorted by its first coordinate ----
+__global__ __launch_bounds__(TB) void k_cas_keys(const RvPairRec *__restrict__ recs, u32 M, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) { keys[i] = (u64)recs[i].a; vals[i] = i; }
+}
+__global__ __launch_bounds__(TB) void k_cas_gather(const RvPairRec *__restrict__ recs, const u32 *__restrict__ perm, u32 M, sa_t *__restrict__ c_pa,
+                                                   sa_t *__restrict__ c_pb, u32 *__restrict__ c_len, u32 *__restrict__ c_child) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= M) return;
+    const RvPairRec r = recs[perm[i]];
+    c_pa[i] = r.a; c_pb[i] = r.b; c_len[i] = r.l; c_child[i] = 0u;
+}
+__global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth, CasRes *__restrict__ res,
+                           u32 *__restrict__ counters, CasIv root, u32 *__restrict__ w_child, u32 nw) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        iv[0] = root; best[0] = 0; wmax[0] = 0; depth[0] = 0;
+        CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
+        res[0] = r;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0;
+    }
+    if (i < nw) w_child[i] = 0u;
+}
+
+// ---- one level ----
+__global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child,
+                                                   u32 M, const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
+                                                   const CasIv *__restrict__ iv, const CasRes *__restrict__ res, u64 *__restrict__ best, u32 *__restrict__ wmax,
+                                                   int64_t minl, int first) {
+    const u32 t = blockIdx.x * TB + threadIdx.x;      // (the grid covers the matches in whole workgroups, then the witnesses)
+    const u32 mblocks = (M + TB - 1) / TB;
+    if (blockIdx.x < mblocks) {
+        const u32 i = t;
+        u32 c = i < M ? c_child[i] : NONE;
+        bool live = c != NONE;
+        u64 key = 0;
+        if (live) {
+            const int64_t pa = (int64_t)c_pa[i], pb = (int64_t)c_pb[i], len = (int64_t)c_len[i];
+            int64_t qa, qb, ql;
+            if (!first) {
+                const CasRes r = res[c];
+                const CasIv p = iv[c];
+                u32 nc = NONE;
+                if (r.state == 1u) {
+                    // at most one of the two children holds it: a match that covers the parent's choice would be longer than it
+                    CasIv lv; lv.a0 = p.a0; lv.a1 = r.qa; lv.b0 = p.b0; lv.b1 = r.qb;
+                    CasIv tv; tv.a0 = (sa_t)((int64_t)r.qa + r.ql); tv.a1 = p.a1; tv.b0 = (sa_t)((int64_t)r.qb + r.ql); tv.b1 = p.b1;
+                    if (r.lead != NONE && cas_cut(lv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
+                    else if (r.trail != NONE && cas_cut(tv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.trail;
+                }
+                c = nc;
+                c_child[i] = c;
+                live = c != NONE;
+            } else {
+                live = cas_cut(iv[c], pa, pb, len, minl, &qa, &qb, &ql);
+                if (!live) { c = NONE; c_child[i] = NONE; }
+            }
+            if (live) key = cas_key(qa, ql);
+        }
+        seg_atomic_max64(best, c, key, live);
+    } else {
+        const u32 i = t - mblocks * TB;
+        u32 c = i < NW ? w_child[i] : NONE;
+        bool live = c != NONE;
+        u32 v = 0;
+        if (live) {
+            const int64_t pos = (int64_t)w_pos[i];
+            v = w_val[i];
+            if (!first) {
+                const CasRes r = res[c];
+                const CasIv p = iv[c];
+                u32 nc = NONE;
+                if (r.state == 1u) {
+                    const int64_t ea = (int64_t)r.qa + r.ql, eb = (int64_t)r.qb + r.ql;
+                    const bool in_lead = (pos >= p.a0 && pos < r.qa) || (pos >= p.b0 && pos < r.qb);
+                    const bool in_trail = (pos >= ea && pos < p.a1) || (pos >= eb && pos < p.b1);
+                    nc = in_lead ? r.lead : in_trail ? r.trail : NONE;
+                }
+                c = nc;
+                w_child[i] = c;
+                live = c != NONE;
+            } else {
+                const CasIv p = iv[c];
+                live = (pos >= p.a0 && pos < p.a1) || (pos >= p.b0 && pos < p.b1);
+                if (!live) { c = NONE; w_child[i] = NONE; }
+            }
+        }
+        seg_atomic_max32(wmax, c, v, live);
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len,
+                                                   const u32 *__restrict__ c_child, u32 M, const CasIv *__restrict__ iv, CasRes *__restrict__ res,
+                                                   const u64 *__restrict__ best, int64_t minl) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= M) return;
+    const u32 c = c_child[i];
+    if (c == NONE) return;
+    int64_t qa, qb, ql;
+    if (!cas_cut(iv[c], (int64_t)c_pa[i], (int64_t)c_pb[i], (int64_t)c_len[i], minl, &qa, &qb, &ql)) return;
+    if (cas_key(qa, ql) == best[c]) { res[c].qa = (sa_t)qa; res[c].qb = (sa_t)qb; res[c].ql = (u32)ql; }
+}
+
+__global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth,
+                                                   CasRes *__restrict__ res, u32 lo, u32 hi, u32 minl, u32 *__restrict__ counters, u32 child_cap,
+                                                   u32 *__restrict__ und_list, u32 leaf_n, RvCascadeIO io) {
+    const u32 id = lo + blockIdx.x * TB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const bool in = id < hi;
+    CasIv p; p.a0 = p.a1 = p.b0 = p.b1 = 0;
+    u64 bk = 0; u32 wm = 0; int32_t dp = 0;
+    CasRes r; r.qa = r.qb = 0; r.ql = 0; r.lead = r.trail = NONE; r.state = 2;
+    if (in) { p = iv[id]; bk = best[id]; wm = wmax[id]; dp = depth[id]; r = res[id]; }
+    const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
+    const u32 bl = (u32)(bk >> KEY_SHIFT);
+    // both samples present and room for a match of minl characters in each (otherwise the reference's scan of this sub-index finds nothing)
+    const bool can = in & (la >= (int64_t)minl) & (lb >= (int64_t)minl);
+    const bool split = can & (bl >= minl) & (bl > wm);
+    const bool und = can & !split & (wm >= minl);
+    bool lead = false, trail = false;
+    if (split) {
+        if (r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
+        lead = ((int64_t)r.qa - p.a0) + ((int64_t)r.qb - p.b0) > 0;
+        trail = ((int64_t)p.a1 - r.qa - r.ql) + ((int64_t)p.b1 - r.qb - r.ql) > 0;
+    }
+    // room for the children, the anchor and the undecided entry: one reservation per wave each
+    const u64 b_lead = __ballot(lead), b_trail = __ballot(trail), b_split = __ballot(split), b_und = __ballot(und);
+    u32 base_c = 0, base_a = 0, base_u = 0;
+    if (lane == 0) {
+        const u32 nc = (u32)__popcll(b_lead) + (u32)__popcll(b_trail);
+        if (nc) base_c = atomicAdd(&counters[C_NCHILD], nc);
+        if (b_split) base_a = atomicAdd(io.anchor_count, (u32)__popcll(b_split));
+        if (b_und) base_u = atomicAdd(&counters[C_NUND], (u32)__popcll(b_und));
+    }
+    base_c = (u32)__shfl((int)base_c, 0, 64); base_a = (u32)__shfl((int)base_a, 0, 64); base_u = (u32)__shfl((int)base_u, 0, 64);
+    if (split) {
+        u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
+        CasRes nr; nr.qa = 0; nr.qb = 0; nr.ql = 0; nr.lead = NONE; nr.trail = NONE; nr.state = 0;
+        if (lead) {
+            if (slot < child_cap) {
+                CasIv c; c.a0 = p.a0; c.a1 = r.qa; c.b0 = p.b0; c.b1 = r.qb;
+                iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                r.lead = slot;
+            } else atomicOr(&counters[C_ERR], 1u);
+            slot++;
+        }
+        if (trail) {
+            if (slot < child_cap) {
+                CasIv c; c.a0 = (sa_t)((int64_t)r.qa + r.ql); c.a1 = p.a1; c.b0 = (sa_t)((int64_t)r.qb + r.ql); c.b1 = p.b1;
+                iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                r.trail = slot;
+            } else atomicOr(&counters[C_ERR], 1u);
+        }
+        const u32 as = base_a + (u32)__popcll(b_split & lt);
+        if (as < io.anchor_cap) { io.anchor_l[as] = r.ql; io.anchor_pos[2 * (size_t)as] = (int64_t)r.qa; io.anchor_pos[2 * (size_t)as + 1] = (int64_t)r.qb; }
+        else atomicOr(&counters[C_ERR], 4u);
+        r.state = 1;
+    } else {
+        r.state = 2;
+    }
+    if (in) res[id] = r;
+    if (und) {
+        und_list[base_u + (u32)__popcll(b_und & lt)] = id;
+        if ((u64)(la + lb) > (u64)leaf_n) atomicMax(&counters[C_MAXN], (u32)((la + lb) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (la + lb)));
+    }
+    // counters of the run: a sub-index that is decided here has been visited (an undecided one is counted by the leaf kernel)
+    const u64 b_vis = __ballot(in & !und);
+    u64 bp = split ? (u64)r.ql : 0ull;
+    u32 md = (in & !und) ? (u32)dp : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        bp += ((u64)(u32)__shfl_down((u32)(bp >> 32), d, 64) << 32) + (u64)(u32)__shfl_down((u32)bp, d, 64);
+        const u32 om = __shfl_down(md, d, 64);
+        md = om > md ? om : md;
+    }
+    if (lane == 0 && b_vis) {
+        atomicAdd(&io.stats[0], (unsigned long long)__popcll(b_vis));
+        if (b_split) { atomicAdd(&io.stats[1], (unsigned long long)__popcll(b_split)); atomicAdd(&io.stats[2], (unsigned long long)bp); }
+        if ((unsigned long long)md > io.stats[3]) atomicMax(&io.stats[3], (unsigned long long)md);
+    }
+}
+
+// ---- undecided sub-indices: rebuilt from their text ----
+__global__ __launch_bounds__(TB) void k_cas_sizes(const u32 *__restrict__ und_list, u32 U, const CasIv *__restrict__ iv, u64 *__restrict__ sizes) {
+    const u32 u = blockIdx.x * TB + threadIdx.x;
+    if (u < U) { const CasIv p = iv[und_list[u]]; sizes[u] = (u64)(((int64_t)p.a1 - p.a0) + ((int64_t)p.b1 - p.b0)); }
+    if (u == U) sizes[u] = 0;
+}
+__global__ __launch_bounds__(TB) void k_cas_roots(const u32 *__restrict__ und_list, u32 U, const CasIv *__restrict__ iv, const int32_t *__restrict__ depth,
+                                                  const u64 *__restrict__ offs, RvLeafRoot *__restrict__ roots) {
+    const u32 u = blockIdx.x * TB + threadIdx.x;
+    if (u >= U) return;
+    const u32 id = und_list[u];
+    const CasIv p = iv[id];
+    RvLeafRoot r;
+    r.off = (int64_t)offs[u]; r.n = (int32_t)(((int64_t)p.a1 - p.a0) + ((int64_t)p.b1 - p.b0)); r.depth = depth[id];
+    r.a0 = p.a0; r.a1 = p.a1; r.b0 = p.b0; r.b1 = p.b1;
+    roots[u] = r;
+}
+
+// SA / LCP / BWT of one sub-index from the text of its two intervals (one workgroup each, at most RV_LEAF_N suffixes): every
+// suffix counts the suffixes in front of it -- byte order of the text, a suffix ending at its interval's end in front of every
+// longer one that starts with it, which is where bubble_sort (reveal.c:666-727) puts the suffixes it cuts --, then its common
+// prefix with its predecessor with the stops of interface.c:97-114.
+constexpr int BN = RV_LEAF_N;
+__global__ __launch_bounds__(TB) void k_cas_build(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, sa_t *__restrict__ SA, lcp_t *__restrict__ LCP,
+                                                  uint8_t *__restrict__ BWT, int64_t nsep0, int64_t root_a0, int64_t root_b0) {
+    __shared__ uint8_t txt[BN + 8];
+    __shared__ uint16_t ord[BN];
+    const RvLeafRoot root = roots[blockIdx.x];
+    const int la = (int)(root.a1 - root.a0), lb = (int)(root.b1 - root.b0), n = la + lb;
+    for (int k = threadIdx.x; k < n; k += TB) txt[k] = k < la ? T0[root.a0 + k] : T0[root.b0 + (k - la)];
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += TB) {
+        const int ri = (i < la ? la : n) - i;
+        int cnt = 0;
+        for (int j = 0; j < n; j++) {
+            const int rj = (j < la ? la : n) - j;
+            const int lim = ri < rj ? ri : rj;
+            int k = 0;
+            while (k < lim && txt[i + k] == txt[j + k]) k++;
+            const bool j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+            cnt += j_less ? 1 : 0;
+        }
+        ord[cnt] = (uint16_t)i;
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += TB) {
+        const int i = ord[r];
+        const int ri = (i < la ? la : n) - i;
+        u32 l = 0;
+        if (r > 0) {
+            const int j = ord[r - 1];
+            const int rj = (j < la ? la : n) - j;
+            const int lim = ri < rj ? ri : rj;
+            int k = 0;
+            while (k < lim) { const uint8_t c = txt[i + k]; if (c != txt[j + k] || c == '$' || c == 'N') break; k++; }
+            l = (u32)k;
+        }
+        const int64_t gp = i < la ? root.a0 + i : root.b0 + (i - la);
+        uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
+        // the first suffix of an interval that starts behind an anchor: that anchor's last base has been lower-cased (reveal.c:1230-1234)
+        const bool behind_anchor = i < la ? (i == 0 && root.a0 > root_a0) : (i == la && root.b0 > root_b0);
+        if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
+        const int64_t o = root.off + r;
+        SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
+    }
+}
+
+int bitlen64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+
+}  // namespace
+
+int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl_in, RvCascadeOut *out) {
+    memset(out, 0, sizeof *out);
+    out->done = false;
+    Workspace &ws = h->ws;
+    hipStream_t q = ws.stream;
+    const int64_t n = h->n;
+    const u32 minl = (u32)std::max(minl_in, 1);
+    const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
+#define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade: gave up: %s\n", msg); return 0; } while (0)
+    if (h->nsamples != 2 || h->nodes.size() != 2 || h->nsep.size() != 1) GIVE_UP("not two samples with one sequence each");
+    if (n >= ((int64_t)1 << 32) - 2) GIVE_UP("index above 2^32 positions");
+#ifdef RV_SA64
+    if ((u64)h->maxlcp >= (1ull << 24) || n >= ((int64_t)1 << 40)) GIVE_UP("bid word too narrow");
+#endif
+    CasIv root; root.a0 = root.a1 = root.b0 = root.b1 = 0;
+    for (const RvIntv &v : h->nodes) {
+        if (v.begin < h->nsep[0]) { root.a0 = (sa_t)v.begin; root.a1 = (sa_t)v.end; }
+        else { root.b0 = (sa_t)v.begin; root.b1 = (sa_t)v.end; }
+    }
+    if (root.a0 >= root.a1 || root.b0 >= root.b1 || (int64_t)root.a1 > h->nsep[0] || (int64_t)root.b0 <= h->nsep[0]) GIVE_UP("an empty sample");
+
+    const sa_t *SA = h->dSA.as<sa_t>(); const lcp_t *LCP = h->dLCP.as<lcp_t>(); const uint8_t *BWT = h->dBWT.as<uint8_t>();
+
+    // ---- the root's matches, packed on the device (the scan of the level pipeline's first level: same kernel, same profile slot)
+    const int64_t ntile = ceil_div(n, RV_PAIR_TILE);
+    DBuf &bcnt = ws.misc[14], &btab = ws.misc[2], &bslot = ws.misc[3], &bovf = ws.misc[4], &bout = ws.misc[5];
+    if (bcnt.cap == 0) { RV_TRY(bcnt.reserve(64)); RV_HIP(hipMemsetAsync(bcnt.p, 0, 64, q)); }
+    RV_TRY(btab.reserve((size_t)(ntile + 1) * 3 * sizeof(u32)));
+    RV_TRY(bslot.reserve((size_t)ntile * RV_PAIR_SLOTS * sizeof(RvPairRec)));
+    if (bovf.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bovf.reserve(4096 * sizeof(RvPairRec)));
+    if (bout.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bout.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, n / 64)));
+    u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
+    u32 M = 0;
+    for (int attempt = 0;; attempt++) {
+        if (attempt == 3) { rv_set_error("cascade: scan buffer sizing failed"); return -1; }
+        const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
+        hipEvent_t ev_a, ev_b;
+        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)n * (sizeof(sa_t) + sizeof(lcp_t)), &ev_a, &ev_b);
+        RV_TRY(rv_scan_pair_launch(ws, SA, LCP, n, BWT, (sa_t)h->nsep[0], (int)minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
+                                   (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf, nullptr, nullptr, 0, ev_a, ev_b));
+        RV_TRY(rv_exclusive_sum_u32(ws, tilecnt, tileoff, ntile + 1));
+        RV_TRY(rv_pair_compact_launch(ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
+                                      (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), nullptr, (u32)std::min<size_t>(vcap, 0xffffffffu)));
+        u32 hdr[4];
+        RV_TRY(rv_read_back(ws, hdr, bout.p, sizeof hdr));
+        const u32 total = hdr[0], novf = hdr[1];
+        if (total <= ocap && novf <= vcap) { M = total; break; }
+        if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
+        if (total > ocap) RV_TRY(bout.reserve(((size_t)total + RV_PAIR_HDR) * sizeof(RvPairRec)));
+    }
+    out->cands = M;
+    if (M == 0) GIVE_UP("no match at the top level");
+    const RvPairRec *recs = bout.as<RvPairRec>() + RV_PAIR_HDR;
+
+    // ---- buffers
+    const u32 wcap = (u32)std::min<int64_t>(std::max<int64_t>(1 << 16, n / 16), 0x7fffffff);
+    const int64_t ccap64 = n / (int64_t)minl + 16;      // every anchor covers 2 * minl positions and makes two sub-indices at most
+    if (ccap64 >= 0x7fffffff) GIVE_UP("too many sub-indices possible");
+    const u32 ccap = (u32)ccap64;
+    DBuf &k0 = cb.d[0], &k1 = cb.d[1], &v0 = cb.d[2], &v1 = cb.d[3], &bpa = cb.d[4], &bpb = cb.d[5], &blen = cb.d[6], &bcc = cb.d[7], &bwp = cb.d[8], &bwv = cb.d[9],
+         &bwc = cb.d[10], &biv = cb.d[11], &bbest = cb.d[12], &bwm = cb.d[13], &bdep = cb.d[14], &bres = cb.d[15], &bctr = cb.d[16], &bund = cb.d[17], &bsz = cb.d[18];
+    RV_TRY(k0.reserve((size_t)M * 8)); RV_TRY(k1.reserve((size_t)M * 8)); RV_TRY(v0.reserve((size_t)M * 4)); RV_TRY(v1.reserve((size_t)M * 4));
+    RV_TRY(bpa.reserve((size_t)M * sizeof(sa_t))); RV_TRY(bpb.reserve((size_t)M * sizeof(sa_t))); RV_TRY(blen.reserve((size_t)M * 4)); RV_TRY(bcc.reserve((size_t)M * 4));
+    RV_TRY(bwp.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)wcap * 4)); RV_TRY(bwc.reserve((size_t)wcap * 4));
+    RV_TRY(biv.reserve((size_t)ccap * sizeof(CasIv))); RV_TRY(bbest.reserve((size_t)ccap * 8)); RV_TRY(bwm.reserve((size_t)ccap * 4)); RV_TRY(bdep.reserve((size_t)ccap * 4));
+    RV_TRY(bres.reserve((size_t)ccap * sizeof(CasRes))); RV_TRY(bctr.reserve(64)); RV_TRY(bund.reserve((size_t)ccap * 4));
+    u32 *counters = bctr.as<u32>();
+    RV_HIP(hipMemsetAsync(counters, 0, 64, q));
+
+    // ---- witnesses
+    hipLaunchKernelGGL(k_cas_witness, dim3((unsigned)ceil_div(n, WT_TILE)), dim3(TB), 0, q, SA, LCP, BWT, n, minl, bwp.as<sa_t>(), bwv.as<u32>(), wcap, counters);
+    RV_LAUNCH_CHECK();
+    // ---- matches by first coordinate
+    {
+        const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
+        hipLaunchKernelGGL(k_cas_keys, dim3(mb), dim3(TB), 0, q, recs, M, k0.as<u64>(), v0.as<u32>());
+        RV_LAUNCH_CHECK();
+        int in1 = 0;
+        RV_TRY(rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (int64_t)M, 0, bitlen64((u64)n), &in1));
+        hipLaunchKernelGGL(k_cas_gather, dim3(mb), dim3(TB), 0, q, recs, (const u32 *)(in1 ? v1.as<u32>() : v0.as<u32>()), M, bpa.as<sa_t>(), bpb.as<sa_t>(),
+                           blen.as<u32>(), bcc.as<u32>());
+        RV_LAUNCH_CHECK();
+    }
+    u32 hc[8];
+    RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
+    const u32 NW = hc[C_NWIT];
+    out->witnesses = NW;
+    if (NW > wcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
+    hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
+                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW);
+    RV_LAUNCH_CHECK();
+
+    // ---- the levels
+    u32 lo = 0, hi = 1;
+    int level = 0;
+    const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
+    for (;;) {
+        hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
+                           (const sa_t *)bwp.as<sa_t>(), (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
+                           bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, level == 0 ? 1 : 0);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cas_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(),
+                           (const u32 *)blen.as<u32>(), (const u32 *)bcc.as<u32>(), M, (const CasIv *)biv.as<CasIv>(), bres.as<CasRes>(), (const u64 *)bbest.as<u64>(), (int64_t)minl);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cas_decide, dim3((unsigned)ceil_div((int64_t)(hi - lo), TB)), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
+                           bres.as<CasRes>(), lo, hi, minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io);
+        RV_LAUNCH_CHECK();
+        RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
+        level++;
+        if (hc[C_ERR]) { rv_set_error("cascade: device error %u", hc[C_ERR]); return -1; }
+        lo = hi; hi = hc[C_NCHILD];
+        if (hc[C_MAXN] > (u32)RV_LEAF_N) break;      // an undecided sub-index the leaf kernel cannot take
+        if (hi == lo) break;
+        if (level > 100000) { rv_set_error("cascade: no progress"); return -1; }
+    }
+    out->levels = level; out->children = hi;
+    const u32 U = hc[C_NUND];
+    out->undecided = U;
+    if (hc[C_MAXN] > (u32)RV_LEAF_N) {
+        // an undecided sub-index the leaf kernel cannot take: nothing of this attempt may stay
+        out->why = "an undecided sub-index above the leaf kernel's size";
+        if (verbose) fprintf(stderr, "cascade: gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", out->why, hc[C_MAXN], level, hi, U);
+        return 0;
+    }
+    if (U > 0) {
+        RV_TRY(bsz.reserve((size_t)(U + 1) * 8));
+        u64 *sizes = bsz.as<u64>();
+        hipLaunchKernelGGL(k_cas_sizes, dim3((unsigned)ceil_div((int64_t)U + 1, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, (const CasIv *)biv.as<CasIv>(), sizes);
+        RV_LAUNCH_CHECK();
+        RV_TRY(rv_exclusive_sum_u64(ws, sizes, sizes, (int64_t)U + 1));
+        u64 mu = 0;
+        RV_TRY(rv_read_back(ws, &mu, sizes + U, 8));
+        out->rebuilt_ranks = (int64_t)mu;
+        RV_TRY(io.lvSA->reserve((size_t)(mu + 64) * sizeof(sa_t))); RV_TRY(io.lvLCP->reserve((size_t)(mu + 64) * sizeof(lcp_t))); RV_TRY(io.lvBWT->reserve((size_t)mu + 64));
+        RV_TRY(io.roots->reserve((size_t)U * sizeof(RvLeafRoot)));
+        RvLeafRoot *roots = io.roots->as<RvLeafRoot>();
+        hipLaunchKernelGGL(k_cas_roots, dim3((unsigned)ceil_div((int64_t)U, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, (const CasIv *)biv.as<CasIv>(),
+                           (const int32_t *)bdep.as<int32_t>(), (const u64 *)sizes, roots);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cas_build, dim3(U), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), io.lvSA->as<sa_t>(), io.lvLCP->as<lcp_t>(),
+                           io.lvBWT->as<uint8_t>(), h->nsep[0], (int64_t)root.a0, (int64_t)root.b0);
+        RV_LAUNCH_CHECK();
+        RvLeafArgs la;
+        la.roots = roots;
+        la.SA = io.lvSA->as<sa_t>(); la.LCP = io.lvLCP->as<lcp_t>(); la.BWT = io.lvBWT->as<uint8_t>();
+        la.nsep0 = h->nsep[0]; la.minl = minl_in; la.lcap = h->maxlcp;
+        la.stage_cap = io.stage_cap;
+        la.anchor_count = io.anchor_count; la.anchor_cap = io.anchor_cap; la.anchor_l = io.anchor_l; la.anchor_pos = io.anchor_pos;
+        la.stats = io.stats;
+        la.trace = 0; la.trace_count = io.anchor_count + 1; la.trace_cap = 0; la.trace_out = nullptr;
+        la.err = io.leaf_err;
+        RV_TRY(rv_leaf_launch(ws, la, (int)U));
+    }
+    if (verbose) fprintf(stderr, "cascade: %u matches, %u witnesses, %d levels, %u sub-indices, %u undecided (%lld ranks rebuilt)\n", M, NW, level, hi, U, (long long)out->rebuilt_ranks);
+    out->done = true;
+    return 0;
+#undef GIVE_UP
+}

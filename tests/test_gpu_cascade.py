@@ -1,0 +1,120 @@
+"""The anchor cascade (reveal_amd/csrc/rv_cascade.hip) against the CPU oracle's literal recursion (reveal.c:731-1338 with the
+benchmark callbacks): untraced two-sample runs decided from the top-level match list must give the reference's anchors,
+final text and counters -- on the reference's fixtures, on synthetic genomes, and on random inputs with repeats, N runs and
+indels, with the cascade on, off (RV_NO_CASCADE) and forced to give up."""
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, assemble, fa, feed, oracle, synth
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def mod(sa64):
+    from reveal_amd import reveallib, reveallib64
+    return reveallib64 if sa64 else reveallib
+
+
+def aset(a):
+    if len(a) == 4:
+        l, n, off, pos = a
+    else:
+        l, off, pos = a
+    return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+
+
+def oracle_run(inputs, minl, sa64=False):
+    T, nsep, nodes = assemble(inputs)
+    O = oracle(sa64)
+    c = O.construct(T, nsep, len(inputs))
+    return O.align_bench(c, nodes, minl, 2)
+
+
+def check(inputs, minl, sa64=False, want_done=None):
+    ref = oracle_run(inputs, minl, sa64)
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(minl, 2)
+    info = idx.cascade_info()
+    assert aset(got["anchors"]) == aset(ref["anchors"])
+    assert idx.T.encode("latin-1") == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"] and got["stats"]["steps"] == ref["stats"]["nsteps"]
+    assert got["stats"]["anchored_bp"] == ref["stats"]["anchored_bp"]
+    if want_done is not None:
+        assert info["done"] == want_done, info
+    return info
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b", fa("1a", "1b"), 20), ("1a1b_m10", fa("1a", "1b"), 10), ("1e1b", fa("1e", "1b"), 20),
+                                              ("1a1a", fa("1a", "1a"), 20), ("synth", (60000, 2), 20), ("synth_big", (1500000, 2), 20)])
+def test_cascade_equals_the_literal_recursion(name, inputs, minl, sa64):
+    if isinstance(inputs, tuple):
+        inputs = [g.decode() for g in synth.genomes(inputs[0], inputs[1], seed=11)]
+    info = check(inputs, minl, sa64)
+    if name.startswith("synth"):      # unrelated repeats of random text are short: the cascade decides the whole run
+        assert info["done"] and info["levels"] > 3 and info["matches"] > 100, info
+
+
+def test_cascade_off_and_on_agree(monkeypatch):
+    inputs = [g.decode() for g in synth.genomes(300000, 2, seed=5)]
+    on = check(inputs, 20, want_done=True)
+    monkeypatch.setenv("RV_NO_CASCADE", "1")
+    off = check(inputs, 20, want_done=False)
+    assert on["subindices"] > 0 and off["levels"] == 0
+
+
+def test_cascade_gives_up_cleanly():
+    """a tandem repeat longer than the leaf kernel's size, different in the two samples: the sub-index around it cannot be decided
+    from the match list and is too large to be rebuilt -- the attempt must leave nothing behind and the level pipeline's result
+    is the reference's"""
+    rng = random.Random(3)
+    base = "".join(rng.choice("ACGT") for _ in range(40000))
+    unit = "ACGGTCA"
+    a = base[:20000] + unit * 600 + base[20000:]
+    b = base[:20000] + unit * 450 + "T" + unit * 200 + base[20000:]
+    info = check([a, b], 20)
+    assert not info["done"] and info["matches"] > 0, info
+
+
+def test_cascade_with_undecided_subindices():
+    """repeats of minl characters and more inside the gaps between anchors: sub-indices the match list cannot decide are rebuilt
+    from their text (k_cas_build) and finished by the leaf kernel"""
+    rng = random.Random(8)
+    seen = 0
+    for case in range(6):
+        L = rng.choice([30000, 120000])
+        base = [rng.choice("ACGT") for _ in range(L)]
+        rep = "".join(rng.choice("ACGT") for _ in range(rng.choice([25, 60, 150])))
+        for _ in range(rng.randint(5, 40)):      # copies of one repeat, some of them in diverged surroundings
+            p = rng.randint(0, L - 200)
+            base[p:p + len(rep)] = list(rep)
+        base = "".join(base)
+        other = list(base)
+        for _ in range(L // 30):
+            p = rng.randint(0, L - 1)
+            other[p] = rng.choice("ACGT")
+        if case % 2:
+            other[L // 3:L // 3] = list("N" * rng.randint(1, 50))
+        info = check([base, "".join(other)], rng.choice([15, 20, 30]))
+        seen += info["undecided"] if info["done"] else 0
+    assert seen > 0
+
+
+def test_cascade_random_inputs():
+    """the generator of tools/fuzz.py (SNPs, indels, tandem repeats, N runs, identical copies), two samples"""
+    from fuzz import make_case
+    rng = random.Random(2026)
+    done = 0
+    for _ in range(40):
+        seqs, minl = make_case(rng)
+        seqs = [s for s in seqs[:2]]
+        if min(len(s) for s in seqs) == 0:
+            continue
+        done += check(seqs, minl)["done"]
+    assert done >= 10

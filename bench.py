@@ -1,11 +1,13 @@
 #!/usr/bin/env python3
 """bench.py -- Mbp/s indexed + MUM-anchored (reveal rem hot path) on N MI355X.
 
-One step = construct() (suffix array, inverse, LCP) + the full recursive
-anchoring (scan -> pick -> label/split/bubble per level) of one batch of
-synthetic genomes whose text is ALREADY RESIDENT IN HBM when the timed region
-starts (the host->device copy of the text is outside it), with the deterministic
-benchmark callbacks of SURVEY.md 8(d).
+One step = construct() (suffix array, LCP, BWT) + the full recursive anchoring
+of one batch of synthetic genomes whose text is ALREADY RESIDENT IN HBM when the
+timed region starts (the host->device copy of the text is outside it), with the
+deterministic benchmark callbacks of SURVEY.md 8(d).  Two samples: the anchor
+cascade (rv_cascade.hip) decides the recursion from the top-level scan and
+rebuilds what it cannot decide; more samples: scan -> pick -> label / split /
+bubble per level.  Either way the anchors are the reference recursion's.
 
 Default workload = BASELINE.json configs[3], the largest single-GPU
 configuration: 2 x 250 Mbp, 1 % SNP, -m 20 (n = 5*10^8, 32-bit index).
@@ -374,6 +376,10 @@ def main():
             "recursion": {"anchors": st["splits"], "anchored_bp": st["anchored_bp"], "levels": st["levels"], "subindices": st["steps"],
                           "scanned_ranks": st["scanned_ranks"], "host_s": st["t_host"], "scan_s": st["t_scan"],
                           "split_s": st["t_split"], "bubble_s": st["t_bubble"]},
+            # the anchor cascade (rv_cascade.hip): an untraced two-sample run is decided from the top-level match list wherever that is
+            # provably the reference's result, the rest is rebuilt from its text and finished by the leaf kernel; done = False: the
+            # level pipeline (scan / split / bubble_sort per level) did the run
+            "cascade": idx.cascade_info() if not divide else None,
             "sa_build": idx.sa_stats(),
             "properties_full_size": properties,
         }

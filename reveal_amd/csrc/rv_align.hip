@@ -1687,6 +1687,8 @@ static int builtin_cascade(rv_index *h) {
     }
     a->st.levels += a->cas_out.levels;
     a->st.scanned_ranks += h->n;
+    h->main_arrays_freed = true;                                         /* reveal.c:1279-1284: align() consumes the main index */
+    a->level = 1;
     a->lv.clear();                                                       // nothing left for the level pipeline
     return 0;
 }

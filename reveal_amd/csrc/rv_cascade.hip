@@ -40,6 +40,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <chrono>
 
 namespace {
 
@@ -54,7 +55,7 @@ constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
 
 struct CasIv { sa_t a0, a1, b0, b1; };
 struct CasRes { sa_t qa, qb; u32 ql, lead, trail, state; };      // state: 0 not decided yet, 1 split, 2 ended
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7 };
 
 // the match (pa, pb, len) of the root cut to a sub-index: start shifted behind the sub-index' begin on both sides, length
 // capped at its ends
@@ -160,7 +161,7 @@ __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *
         iv[0] = root; best[0] = 0; wmax[0] = 0; depth[0] = 0;
         CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
         res[0] = r;
-        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0;
     }
     if (i < nw) w_child[i] = 0u;
 }
@@ -245,82 +246,108 @@ __global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa
 }
 
 __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth,
-                                                   CasRes *__restrict__ res, u32 lo, u32 hi, u32 minl, u32 *__restrict__ counters, u32 child_cap,
+                                                   CasRes *__restrict__ res, u32 minl, u32 *__restrict__ counters, u32 child_cap,
                                                    u32 *__restrict__ und_list, u32 leaf_n, RvCascadeIO io) {
-    const u32 id = lo + blockIdx.x * TB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
+    __shared__ u32 s_cnt[TB / 64][3];      // per wave: children, anchors, undecided entries
+    __shared__ u32 s_base[3];
+    const u32 lo = counters[C_LO], hi = counters[C_HI];      // the level's sub-indices (k_cas_advance sets the next level's)
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const bool in = id < hi;
-    CasIv p; p.a0 = p.a1 = p.b0 = p.b1 = 0;
-    u64 bk = 0; u32 wm = 0; int32_t dp = 0;
-    CasRes r; r.qa = r.qb = 0; r.ql = 0; r.lead = r.trail = NONE; r.state = 2;
-    if (in) { p = iv[id]; bk = best[id]; wm = wmax[id]; dp = depth[id]; r = res[id]; }
-    const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
-    const u32 bl = (u32)(bk >> KEY_SHIFT);
-    // both samples present and room for a match of minl characters in each (otherwise the reference's scan of this sub-index finds nothing)
-    const bool can = in & (la >= (int64_t)minl) & (lb >= (int64_t)minl);
-    const bool split = can & (bl >= minl) & (bl > wm);
-    const bool und = can & !split & (wm >= minl);
-    bool lead = false, trail = false;
-    if (split) {
-        if (r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
-        lead = ((int64_t)r.qa - p.a0) + ((int64_t)r.qb - p.b0) > 0;
-        trail = ((int64_t)p.a1 - r.qa - r.ql) + ((int64_t)p.b1 - r.qb - r.ql) > 0;
-    }
-    // room for the children, the anchor and the undecided entry: one reservation per wave each
-    const u64 b_lead = __ballot(lead), b_trail = __ballot(trail), b_split = __ballot(split), b_und = __ballot(und);
-    u32 base_c = 0, base_a = 0, base_u = 0;
-    if (lane == 0) {
-        const u32 nc = (u32)__popcll(b_lead) + (u32)__popcll(b_trail);
-        if (nc) base_c = atomicAdd(&counters[C_NCHILD], nc);
-        if (b_split) base_a = atomicAdd(io.anchor_count, (u32)__popcll(b_split));
-        if (b_und) base_u = atomicAdd(&counters[C_NUND], (u32)__popcll(b_und));
-    }
-    base_c = (u32)__shfl((int)base_c, 0, 64); base_a = (u32)__shfl((int)base_a, 0, 64); base_u = (u32)__shfl((int)base_u, 0, 64);
-    if (split) {
-        u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
-        CasRes nr; nr.qa = 0; nr.qb = 0; nr.ql = 0; nr.lead = NONE; nr.trail = NONE; nr.state = 0;
-        if (lead) {
-            if (slot < child_cap) {
-                CasIv c; c.a0 = p.a0; c.a1 = r.qa; c.b0 = p.b0; c.b1 = r.qb;
-                iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
-                r.lead = slot;
-            } else atomicOr(&counters[C_ERR], 1u);
-            slot++;
+    for (u32 first = lo + blockIdx.x * TB; first < hi; first += gridDim.x * TB) {      // (uniform per workgroup: barriers inside)
+        const u32 id = first + threadIdx.x;
+        const bool in = id < hi;
+        CasIv p; p.a0 = p.a1 = p.b0 = p.b1 = 0;
+        u64 bk = 0; u32 wm = 0; int32_t dp = 0;
+        CasRes r; r.qa = r.qb = 0; r.ql = 0; r.lead = r.trail = NONE; r.state = 2;
+        if (in) { p = iv[id]; bk = best[id]; wm = wmax[id]; dp = depth[id]; r = res[id]; }
+        const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
+        const u32 bl = (u32)(bk >> KEY_SHIFT);
+        // both samples present and room for a match of minl characters in each (otherwise the reference's scan of this sub-index finds nothing)
+        const bool can = in & (la >= (int64_t)minl) & (lb >= (int64_t)minl);
+        const bool split = can & (bl >= minl) & (bl > wm);
+        const bool und = can & !split & (wm >= minl);
+        bool lead = false, trail = false;
+        if (split) {
+            if (r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
+            lead = ((int64_t)r.qa - p.a0) + ((int64_t)r.qb - p.b0) > 0;
+            trail = ((int64_t)p.a1 - r.qa - r.ql) + ((int64_t)p.b1 - r.qb - r.ql) > 0;
         }
-        if (trail) {
-            if (slot < child_cap) {
-                CasIv c; c.a0 = (sa_t)((int64_t)r.qa + r.ql); c.a1 = p.a1; c.b0 = (sa_t)((int64_t)r.qb + r.ql); c.b1 = p.b1;
-                iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
-                r.trail = slot;
-            } else atomicOr(&counters[C_ERR], 1u);
+        // room for the children, the anchor and the undecided entry: one reservation per workgroup each (one per wave was 16 000
+        // returning atomics on one address at the widest levels of 2 x 250 Mbp -- 6.7 of the cascade's 12 ms)
+        const u64 b_lead = __ballot(lead), b_trail = __ballot(trail), b_split = __ballot(split), b_und = __ballot(und);
+        if (lane == 0) { s_cnt[w][0] = (u32)__popcll(b_lead) + (u32)__popcll(b_trail); s_cnt[w][1] = (u32)__popcll(b_split); s_cnt[w][2] = (u32)__popcll(b_und); }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            u32 tot = 0;
+            for (int k = 0; k < TB / 64; k++) tot += s_cnt[k][threadIdx.x];
+            u32 *ctr = threadIdx.x == 0 ? &counters[C_NCHILD] : threadIdx.x == 1 ? io.anchor_count : &counters[C_NUND];
+            s_base[threadIdx.x] = tot ? atomicAdd(ctr, tot) : 0u;
         }
-        const u32 as = base_a + (u32)__popcll(b_split & lt);
-        if (as < io.anchor_cap) { io.anchor_l[as] = r.ql; io.anchor_pos[2 * (size_t)as] = (int64_t)r.qa; io.anchor_pos[2 * (size_t)as + 1] = (int64_t)r.qb; }
-        else atomicOr(&counters[C_ERR], 4u);
-        r.state = 1;
-    } else {
-        r.state = 2;
+        __syncthreads();
+        u32 base_c = s_base[0], base_a = s_base[1], base_u = s_base[2];
+        for (int k = 0; k < w; k++) { base_c += s_cnt[k][0]; base_a += s_cnt[k][1]; base_u += s_cnt[k][2]; }
+        if (split) {
+            u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
+            CasRes nr; nr.qa = 0; nr.qb = 0; nr.ql = 0; nr.lead = NONE; nr.trail = NONE; nr.state = 0;
+            if (lead) {
+                if (slot < child_cap) {
+                    CasIv c; c.a0 = p.a0; c.a1 = r.qa; c.b0 = p.b0; c.b1 = r.qb;
+                    iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                    r.lead = slot;
+                } else atomicOr(&counters[C_ERR], 1u);
+                slot++;
+            }
+            if (trail) {
+                if (slot < child_cap) {
+                    CasIv c; c.a0 = (sa_t)((int64_t)r.qa + r.ql); c.a1 = p.a1; c.b0 = (sa_t)((int64_t)r.qb + r.ql); c.b1 = p.b1;
+                    iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                    r.trail = slot;
+                } else atomicOr(&counters[C_ERR], 1u);
+            }
+            const u32 as = base_a + (u32)__popcll(b_split & lt);
+            if (as < io.anchor_cap) { io.anchor_l[as] = r.ql; io.anchor_pos[2 * (size_t)as] = (int64_t)r.qa; io.anchor_pos[2 * (size_t)as + 1] = (int64_t)r.qb; }
+            else atomicOr(&counters[C_ERR], 4u);
+            r.state = 1;
+        } else {
+            r.state = 2;
+        }
+        if (in) res[id] = r;
+        if (und) {
+            und_list[base_u + (u32)__popcll(b_und & lt)] = id;
+            if ((u64)(la + lb) > (u64)leaf_n) atomicMax(&counters[C_MAXN], (u32)((la + lb) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (la + lb)));
+        }
+        __syncthreads();      // (s_cnt / s_base are rewritten by the next stretch)
     }
-    if (in) res[id] = r;
-    if (und) {
-        und_list[base_u + (u32)__popcll(b_und & lt)] = id;
-        if ((u64)(la + lb) > (u64)leaf_n) atomicMax(&counters[C_MAXN], (u32)((la + lb) > 0xFFFFFFFFll ? 0xFFFFFFFFll : (la + lb)));
-    }
-    // counters of the run: a sub-index that is decided here has been visited (an undecided one is counted by the leaf kernel)
-    const u64 b_vis = __ballot(in & !und);
-    u64 bp = split ? (u64)r.ql : 0ull;
-    u32 md = (in & !und) ? (u32)dp : 0u;
+}
+// the next level's sub-indices are the ones the level just decided has made
+__global__ void k_cas_advance(u32 *__restrict__ counters) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const u32 lo = counters[C_LO], hi = counters[C_HI];
+    if (hi > lo) counters[C_LEVELS]++;
+    counters[C_LO] = hi; counters[C_HI] = counters[C_NCHILD];
+}
+// the run's counters (rv_leaf.h: [0] sub-indices visited, [1] anchors, [2] anchored bp, [3] largest depth) from what the levels left:
+// every sub-index made has been visited, except the undecided ones (the leaf kernel counts those itself)
+__global__ __launch_bounds__(TB) void k_cas_stats(const u32 *__restrict__ counters, const int32_t *__restrict__ depth, RvCascadeIO io) {
+    __shared__ unsigned long long s_bp[TB / 64];
+    __shared__ u32 s_md[TB / 64];
+    const u32 nchild = counters[C_NCHILD], na = *io.anchor_count;
+    unsigned long long bp = 0; u32 md = 0;
+    for (u32 i = blockIdx.x * TB + threadIdx.x; i < na; i += gridDim.x * TB) bp += io.anchor_l[i];
+    for (u32 i = blockIdx.x * TB + threadIdx.x; i < nchild; i += gridDim.x * TB) { const u32 d = (u32)depth[i]; md = d > md ? d : md; }
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) {
-        bp += ((u64)(u32)__shfl_down((u32)(bp >> 32), d, 64) << 32) + (u64)(u32)__shfl_down((u32)bp, d, 64);
+        bp += ((unsigned long long)(u32)__shfl_down((u32)(bp >> 32), d, 64) << 32) + (unsigned long long)(u32)__shfl_down((u32)bp, d, 64);
         const u32 om = __shfl_down(md, d, 64);
         md = om > md ? om : md;
     }
-    if (lane == 0 && b_vis) {
-        atomicAdd(&io.stats[0], (unsigned long long)__popcll(b_vis));
-        if (b_split) { atomicAdd(&io.stats[1], (unsigned long long)__popcll(b_split)); atomicAdd(&io.stats[2], (unsigned long long)bp); }
-        if ((unsigned long long)md > io.stats[3]) atomicMax(&io.stats[3], (unsigned long long)md);
+    if ((threadIdx.x & 63) == 0) { s_bp[threadIdx.x >> 6] = bp; s_md[threadIdx.x >> 6] = md; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int k = 1; k < TB / 64; k++) { bp += s_bp[k]; md = s_md[k] > md ? s_md[k] : md; }
+        if (bp) atomicAdd(&io.stats[2], bp);
+        if (md) atomicMax(&io.stats[3], (unsigned long long)md);
+        if (blockIdx.x == 0) { atomicAdd(&io.stats[0], (unsigned long long)(nchild - counters[C_NUND])); atomicAdd(&io.stats[1], (unsigned long long)na); }
     }
 }
 
@@ -392,6 +419,7 @@ __global__ __launch_bounds__(TB) void k_cas_build(const RvLeafRoot *__restrict__
 }
 
 int bitlen64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+double cas_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
 
@@ -403,6 +431,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     const int64_t n = h->n;
     const u32 minl = (u32)std::max(minl_in, 1);
     const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
+    double tp[6] = {0, 0, 0, 0, 0, 0};
+    if (verbose) { (void)hipStreamSynchronize(q); tp[0] = cas_now(); }
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade: gave up: %s\n", msg); return 0; } while (0)
     if (h->nsamples != 2 || h->nodes.size() != 2 || h->nsep.size() != 1) GIVE_UP("not two samples with one sequence each");
     if (n >= ((int64_t)1 << 32) - 2) GIVE_UP("index above 2^32 positions");
@@ -445,6 +475,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         if (novf > vcap) RV_TRY(bovf.reserve((size_t)novf * sizeof(RvPairRec)));
         if (total > ocap) RV_TRY(bout.reserve(((size_t)total + RV_PAIR_HDR) * sizeof(RvPairRec)));
     }
+    if (verbose) tp[1] = cas_now();
     out->cands = M;
     if (M == 0) GIVE_UP("no match at the top level");
     const RvPairRec *recs = bout.as<RvPairRec>() + RV_PAIR_HDR;
@@ -487,29 +518,36 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
                        bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW);
     RV_LAUNCH_CHECK();
 
-    // ---- the levels
-    u32 lo = 0, hi = 1;
-    int level = 0;
+    if (verbose) { (void)hipStreamSynchronize(q); tp[2] = cas_now(); }
+    // ---- the levels: queued in batches, the level's range of sub-indices lives on the device (k_cas_advance), the host only looks
+    // at the counters between batches (a level on an empty range costs its launches, nothing else)
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
+    const int batch = getenv("RV_CASCADE_BATCH") ? std::max(1, atoi(getenv("RV_CASCADE_BATCH"))) : 8;
+    int queued = 0;
     for (;;) {
-        hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
-                           (const sa_t *)bwp.as<sa_t>(), (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
-                           bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, level == 0 ? 1 : 0);
-        RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_cas_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(),
-                           (const u32 *)blen.as<u32>(), (const u32 *)bcc.as<u32>(), M, (const CasIv *)biv.as<CasIv>(), bres.as<CasRes>(), (const u64 *)bbest.as<u64>(), (int64_t)minl);
-        RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_cas_decide, dim3((unsigned)ceil_div((int64_t)(hi - lo), TB)), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
-                           bres.as<CasRes>(), lo, hi, minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io);
-        RV_LAUNCH_CHECK();
+        for (int b = 0; b < batch; b++, queued++) {
+            hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
+                               (const sa_t *)bwp.as<sa_t>(), (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
+                               bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, queued == 0 ? 1 : 0);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_cas_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(),
+                               (const u32 *)blen.as<u32>(), (const u32 *)bcc.as<u32>(), M, (const CasIv *)biv.as<CasIv>(), bres.as<CasRes>(), (const u64 *)bbest.as<u64>(), (int64_t)minl);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_cas_decide, dim3(1024), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
+                               bres.as<CasRes>(), minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_cas_advance, dim3(1), dim3(64), 0, q, counters);
+            RV_LAUNCH_CHECK();
+        }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
-        level++;
         if (hc[C_ERR]) { rv_set_error("cascade: device error %u", hc[C_ERR]); return -1; }
-        lo = hi; hi = hc[C_NCHILD];
         if (hc[C_MAXN] > (u32)RV_LEAF_N) break;      // an undecided sub-index the leaf kernel cannot take
-        if (hi == lo) break;
-        if (level > 100000) { rv_set_error("cascade: no progress"); return -1; }
+        if (hc[C_HI] == hc[C_LO]) break;
+        if (queued > 1000000) { rv_set_error("cascade: no progress"); return -1; }
     }
+    const int level = (int)hc[C_LEVELS];
+    const u32 hi = hc[C_NCHILD];
+    if (verbose) tp[3] = cas_now();
     out->levels = level; out->children = hi;
     const u32 U = hc[C_NUND];
     out->undecided = U;
@@ -519,6 +557,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         if (verbose) fprintf(stderr, "cascade: gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", out->why, hc[C_MAXN], level, hi, U);
         return 0;
     }
+    hipLaunchKernelGGL(k_cas_stats, dim3(256), dim3(TB), 0, q, (const u32 *)counters, (const int32_t *)bdep.as<int32_t>(), io);
+    RV_LAUNCH_CHECK();
     if (U > 0) {
         RV_TRY(bsz.reserve((size_t)(U + 1) * 8));
         u64 *sizes = bsz.as<u64>();
@@ -548,7 +588,11 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         la.err = io.leaf_err;
         RV_TRY(rv_leaf_launch(ws, la, (int)U));
     }
-    if (verbose) fprintf(stderr, "cascade: %u matches, %u witnesses, %d levels, %u sub-indices, %u undecided (%lld ranks rebuilt)\n", M, NW, level, hi, U, (long long)out->rebuilt_ranks);
+    if (verbose) {
+        (void)hipStreamSynchronize(q); tp[4] = cas_now();
+        fprintf(stderr, "cascade: %u matches, %u witnesses, %d levels, %u sub-indices, %u undecided (%lld ranks rebuilt) | ms: scan %.2f witnesses+sort %.2f levels %.2f rebuild+leaf %.2f\n",
+                M, NW, level, hi, U, (long long)out->rebuilt_ranks, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3);
+    }
     out->done = true;
     return 0;
 #undef GIVE_UP

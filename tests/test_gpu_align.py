@@ -167,9 +167,15 @@ def test_parallel_bubble_rounds(monkeypatch, par_min, name, inputs, minl, sa64):
     ("synth20", (20000, 20), 20),       # more than 16 samples: the picker's general form
     ("synth70", (4000, 70), 15),        # more than 64 samples: sample sets no longer fit a bit mask
 ])
-def test_untraced_run_same_anchors(name, inputs, minl):
+@pytest.mark.parametrize("cascade", [False, True])
+def test_untraced_run_same_anchors(monkeypatch, name, inputs, minl, cascade):
     """align_builtin(trace=False) is what bench.py times: leaf kernel, device-side picker (pair) and pre-selection (multi)
-    are on, the host never sees the full MUM lists -- the anchor set and the final text must not change"""
+    are on, the host never sees the full MUM lists -- the anchor set and the final text must not change.
+    cascade False: the level pipeline for two-sample runs as well (RV_NO_CASCADE); True: the default, rv_cascade.hip first"""
+    if not cascade:
+        monkeypatch.setenv("RV_NO_CASCADE", "1")
+    elif isinstance(inputs, list) and len(inputs) > 2 or isinstance(inputs, tuple):
+        pytest.skip("more than two samples: the cascade is not involved")
     if inputs is None:
         inputs = [g.decode() for g in synth.genomes(400000, 2)]
     elif isinstance(inputs, tuple):
@@ -195,6 +201,7 @@ def test_leaf_anchor_staging_overflow(monkeypatch, acap, name, inputs, minl):
     """RV_LEAF_ACAP: the leaf kernel stages that many anchors per workgroup in LDS (256 by default) and writes the rest straight
     to the output, one reservation each -- forced here with a staging area of 0 / 1 / 3 anchors"""
     monkeypatch.setenv("RV_LEAF_ACAP", str(acap))
+    monkeypatch.setenv("RV_NO_CASCADE", "1")      # (the level pipeline's leaf launches; the cascade's own launch: tests/test_gpu_cascade.py, tools/fuzz.py)
     if inputs is None:
         inputs = [g.decode() for g in synth.genomes(400000, 2)]
     ref, T = oracle_run(inputs, minl, 2)

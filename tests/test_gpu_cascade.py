@@ -70,16 +70,26 @@ def test_cascade_off_and_on_agree(monkeypatch):
 
 
 def test_cascade_gives_up_cleanly():
-    """a tandem repeat longer than the leaf kernel's size, different in the two samples: the sub-index around it cannot be decided
-    from the match list and is too large to be rebuilt -- the attempt must leave nothing behind and the level pipeline's result
-    is the reference's"""
+    """tandem arrays longer than the leaf kernel's size with different point mutations in the two samples: the sub-index around
+    them cannot be decided from the match list (its best match is no longer than its repeats) and is too large to be rebuilt --
+    the attempt must leave nothing behind, and the level pipeline's result is the reference's"""
     rng = random.Random(3)
-    base = "".join(rng.choice("ACGT") for _ in range(40000))
-    unit = "ACGGTCA"
-    a = base[:20000] + unit * 600 + base[20000:]
-    b = base[:20000] + unit * 450 + "T" + unit * 200 + base[20000:]
-    info = check([a, b], 20)
-    assert not info["done"] and info["matches"] > 0, info
+    gave_up = 0
+    for case in range(4):
+        base = "".join(rng.choice("ACGT") for _ in range(30000))
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.choice([7, 23, 61])))
+        arr = unit * (6000 // len(unit))
+
+        def mutated(s, every):
+            s = list(s)
+            for p in range(rng.randint(0, every), len(s), every):
+                s[p] = rng.choice("ACGT")
+            return "".join(s)
+        a = base[:15000] + mutated(arr, 97) + base[15000:]
+        b = base[:15000] + mutated(arr, 89) + base[15000:]
+        info = check([a, b], 20)
+        gave_up += (not info["done"]) and info["matches"] > 0
+    assert gave_up > 0
 
 
 def test_cascade_with_undecided_subindices():

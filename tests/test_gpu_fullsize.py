@@ -119,3 +119,32 @@ def test_recursion_properties(built):
         assert p["anchored_bp"] > 0.9 * 2 * L / 2
     with pytest.raises(TypeError):
         idx.SA                                                # main SA/LCP are gone after align (reveal.c:1279-1284)
+
+
+def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch):
+    """C4: the anchor cascade (rv_cascade.hip; what an untraced two-sample run takes) and the level pipeline it stands in for
+    (RV_NO_CASCADE: scan / split / bubble_sort of every level, reveal.c:731-1338 step by step) give the same anchors, counters
+    and final text at n = 5*10^8"""
+    from reveal_amd import reveallib
+    L, G, seed = CONFIGS["C4"]
+    seqs = synth.genomes(L, G, seed=seed)
+    idx = reveallib.index()
+    for k, s in enumerate(seqs):
+        idx.addsample("g%d" % k)
+        idx.addsequence(s)
+    out = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RV_NO_CASCADE", "1")
+        idx.construct()
+        res = idx.align_builtin(20, 2)
+        info = idx.cascade_info()
+        assert info["done"] == (not off), info
+        l, o, pos = res["anchors"]
+        order = np.lexsort((pos[1::2], pos[0::2]))
+        out.append((np.asarray(l)[order], pos[0::2][order], pos[1::2][order], idx.array("T").copy(),
+                    {k: res["stats"][k] for k in ("steps", "splits", "anchored_bp")}))
+    a, b = out
+    assert a[4] == b[4], (a[4], b[4])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert np.array_equal(a[3], b[3])

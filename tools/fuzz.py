@@ -19,14 +19,16 @@ VERBOSE = bool(os.environ.get("FUZZ_VERBOSE"))      # print every configuration 
 ONLY = int(os.environ.get("FUZZ_ONLY", "-1"))
 FIELDS = ("key", "n", "depth", "nsamples", "nnodes", "nmums", "picked", "l", "mn", "sp_min", "h_sa", "h_lcp", "h_mums")
 ENVS = [
-    {},
-    {"RV_BUBBLE_PAR_MIN": "0", "RV_NO_LEAF": "1"},
-    {"RV_BUBBLE_PAR_MIN": "256"},
+    {},                                                   # defaults: the anchor cascade decides untraced two-sample runs (rv_cascade.hip)
+    {"RV_NO_CASCADE": "1"},                               # ... the level pipeline for them too
+    {"RV_BUBBLE_PAR_MIN": "0", "RV_NO_LEAF": "1"},        # (RV_NO_LEAF also keeps the cascade off)
+    {"RV_BUBBLE_PAR_MIN": "256", "RV_NO_CASCADE": "1"},
     {"RV_BUBBLE_LDS_ALWAYS": "1", "RV_NO_LEAF": "1"},
-    {"RV_NO_EARLY_SPLIT": "1"},
-    {"RV_CARRY_CH": "2", "RV_SA_NO_TEXT": "1", "RV_LCP_BY_RANK": "1"},
+    {"RV_NO_EARLY_SPLIT": "1", "RV_NO_CASCADE": "1"},
+    {"RV_CARRY_CH": "2", "RV_SA_NO_TEXT": "1", "RV_LCP_BY_RANK": "1", "RV_NO_CASCADE": "1"},
     {"RV_BUBBLE_PAR_MIN": "64", "RV_PB_TWO_PASS": "1", "RV_NO_LEAF": "1"},
-    {"RV_LEAF_ACAP": "2"},
+    {"RV_LEAF_ACAP": "2", "RV_NO_CASCADE": "1"},
+    {"RV_LEAF_ACAP": "2"},                                # the cascade's leaf launch with a two-anchor staging area
 ]
 
 

@@ -64,7 +64,9 @@ int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so
  * On return T, SA and LCP live in HBM (the inverse SAi is made when something asks for it: the RV_SAI getter, rv_clone,
  * rv_sx_main, rv_align_begin).  Both libraries carry ranks, child sizes and scan records in 32 bits: an index of
  * n >= 2^32 - 2 positions is refused here, whatever the width of saidx_t and wherever SA comes from (built, or read from
- * safile, which is range- and permutation-checked on the device before anything scatters through it). */
+ * safile, which is range- and permutation-checked on the device before anything scatters through it).  The 64-bit library
+ * is exercised above 2^31 positions -- where the reference needs reveallib64, reveal.h:7-13 -- at n = 2.2 x 10^9
+ * (tests/test_gpu_above_2_31.py: construct, both recursion paths, and this refusal). */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache);
 /* Copies the assembled text to HBM now (construct does it on demand).  Lets a
  * caller keep the host->device copy out of a timed construct(); repeated

@@ -18,6 +18,20 @@ void rv_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// live handles, for rv_oom_trim (rv_common.h)
+static std::vector<rv_index *> &live_handles() { static std::vector<rv_index *> v; return v; }
+bool rv_oom_trim() {
+    size_t got = 0;
+    for (rv_index *h : live_handles()) {
+        if (h->ws.sa_in_use) continue;
+        (void)hipSetDevice(h->device);
+        (void)hipDeviceSynchronize();          // nothing may still be reading what is released
+        got += h->ws.trim_sa();
+    }
+    if (getenv("RV_CASCADE_LOG") && got) fprintf(stderr, "reveal_amd: device memory short, released %.1f GB of SA-build scratch\n", got / 1e9);
+    return got > 0;
+}
+
 extern "C" {
 
 const char *rv_last_error(void) { return g_err; }
@@ -48,11 +62,13 @@ rv_index *rv_new(int device) {
         return nullptr;
     }
     h->T.push_back('\0');
+    live_handles().push_back(h);
     return h;
 }
 
 void rv_free(rv_index *h) {
     if (!h) return;
+    { auto &v = live_handles(); v.erase(std::remove(v.begin(), v.end(), h), v.end()); }
     (void)hipSetDevice(h->device);
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
     rv_align_free(h);
@@ -219,6 +235,7 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     const sa_t side_sep = !h->nsep.empty() ? (sa_t)h->nsep[0] : std::numeric_limits<sa_t>::max();      // (RV_BWT_SIDE, rv_common.h; getmums tests against nsep[0] whatever the number of samples, reveal.c:73)
     const bool lcp_from_file = lcpfile && lcpfile[0];
     bool lcp_done = false;
+    SaScratchInUse in_use(h->ws);
     if (!safile || !safile[0]) {
         int id = h->prof.begin(q, RV_K_SA_SORT, 5.0 * (double)n);
         if (lcp_from_file) RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats));

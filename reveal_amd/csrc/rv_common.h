@@ -109,6 +109,11 @@ __device__ inline u32 rv_wave_incl_sum_u32(u32 v) {
 }
 #endif
 
+// When a device allocation fails: give back the SA-build scratch of every handle that is not inside a construct() right now
+// (it is kept between calls so that a benchmark step does not pay for hipMalloc -- 160 GB at 2.2 x 10^9 positions in the 64-bit
+// library, more than the recursion's level arrays find room beside).  true = something was released (rv_api.hip).
+bool rv_oom_trim();
+
 // Grow-only device buffer.
 struct DBuf {
     void  *p = nullptr;
@@ -117,7 +122,13 @@ struct DBuf {
         if (bytes <= cap) return 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 8 + 256;
-        RV_HIP(hipMalloc(&p, want));
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipErrorOutOfMemory) {
+            (void)hipGetLastError();
+            if (rv_oom_trim()) e = hipMalloc(&p, want);
+            if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); want = bytes + 256; e = hipMalloc(&p, want); }      // without the growth margin
+        }
+        if (e != hipSuccess) { p = nullptr; rv_set_error("%s:%d hipMalloc(%zu bytes): %s", __FILE__, __LINE__, want, hipGetErrorString(e)); return -1; }
         cap = want;
         return 0;
     }
@@ -151,6 +162,12 @@ struct Workspace {
     DBuf sa[20];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;
+    bool sa_in_use = false; // inside rv_build_sa / rv_build_lcp: the scratch below must stay
+    size_t trim_sa() {      // releases the SA-build scratch; -> bytes given back
+        size_t got = 0;
+        for (auto &b : sa) { got += b.cap; b.release(); }
+        return got;
+    }
     void release() {
         hpin.release();
         if (ev_rb) { (void)hipEventDestroy(ev_rb); ev_rb = nullptr; }
@@ -160,6 +177,8 @@ struct Workspace {
         for (auto &b : sa) b.release();
     }
 };
+
+struct SaScratchInUse { Workspace &w; bool was; SaScratchInUse(Workspace &x) : w(x), was(x.sa_in_use) { w.sa_in_use = true; } ~SaScratchInUse() { w.sa_in_use = was; } };
 
 // ---- primitives (rv_prims.hip) ---------------------------------------------
 // out[i] = sum_{j<i} in[j]  (in may alias out); n up to 2^40.

@@ -816,6 +816,7 @@ int rv_build_bwt(Workspace &ws, const uint8_t *T, const sa_t *SA, int64_t n, uin
 }
 
 int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, lcp_t *LCP, int64_t n, u32 *d_maxlcp, uint8_t *BWT, sa_t side_sep) {
+    SaScratchInUse in_use(ws);
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
     if (by_rank || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
@@ -839,6 +840,7 @@ int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, 
 
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st,
                 lcp_t *LCP, uint8_t *BWT, sa_t side_sep, u32 *d_maxlcp, bool *fused_done) {
+    SaScratchInUse in_use(ws);
     RvSaStats s;
     memset(&s, 0, sizeof s);
     if (fused_done) *fused_done = false;

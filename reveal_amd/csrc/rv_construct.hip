@@ -10,6 +10,7 @@
 #include "rv_common.h"
 #include <string.h>
 #include <stdlib.h>
+#include <algorithm>
 
 #ifdef RV_SA64
 typedef u64 sav_t;   // suffix ids as radix-sort payload
@@ -50,11 +51,60 @@ __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, i
 // where 3 bits per symbol needed six.  A block stages 1024+K symbols as codes in
 // LDS; each thread then packs 4 keys from LDS.
 constexpr int KEY_TILE = 1024;
-constexpr u64 KEY_MASK = (1ull << 56) - 1;
+
+// ---- the diagonal hint ------------------------------------------------------------------------
+// Two related genomes: nearly every suffix p of the first sample shares its first K symbols with exactly one other suffix, its
+// twin p + D on the diagonal D = nsep[0] + 1 (same coordinate in the second sample), and what orders the two is the next
+// position where the samples differ -- the same position for every suffix of a substitution-free stretch.  The text round
+// used to find it pair by pair: two random 40-byte reads of the packed text per pair and step, 33 of the build's 70 ms at
+// 2 x 250 Mbp.  Along one diagonal it is a streaming computation instead: k_diag_bits marks, for every position y, whether
+// T[y] and T[y + D] differ (or either is not A / C / G / T: an exception) and which is smaller; k_init_keys then knows for
+// every suffix p how far its twin agrees with it (nd = next marked position - p) and which of the two is smaller, and puts
+// that into the spare bits of p's first key, above the bits the sort looks at.  The text round reads a pair's order and LCP
+// from the key it has in registers anyway; anything the hint does not cover (other diagonals after an indel, stretches longer
+// than the field, exceptions, unrelated suffixes that collide in their K symbols) is compared on the text as before.
+struct DiagBits { const u64 *stop, *exc, *lt; int64_t D; };      // one bit per text position each; stop = differs or exception
+__global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T, int64_t n, int64_t D, u64 *__restrict__ stop, u64 *__restrict__ exc,
+                                                  u64 *__restrict__ lt, int64_t nwords) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t y0 = w * 64;
+    u64 ws = 0, we = 0, wl = 0;
+    if (y0 + 64 + D <= n) {
+        u64 a[8], b[8];
+        __builtin_memcpy(a, T + y0, 64);
+        __builtin_memcpy(b, T + y0 + D, 64);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const u32 ca = (u32)(a[k] >> (8 * j)) & 0xffu, cb = (u32)(b[k] >> (8 * j)) & 0xffu;
+                const bool ea = !((ca == 'A') | (ca == 'C') | (ca == 'G') | (ca == 'T')), eb = !((cb == 'A') | (cb == 'C') | (cb == 'G') | (cb == 'T'));
+                const int bit = 8 * k + j;
+                we |= (u64)(ea | eb) << bit; ws |= (u64)((ca != cb) | ea | eb) << bit; wl |= (u64)(ca < cb) << bit;
+            }
+    } else {
+        for (int bit = 0; bit < 64; bit++) {
+            const int64_t y = y0 + bit;
+            if (y + D >= n) { we |= 1ull << bit; ws |= 1ull << bit; continue; }      // no partner on the diagonal
+            const u32 ca = T[y], cb = T[y + D];
+            const bool ea = !((ca == 'A') | (ca == 'C') | (ca == 'G') | (ca == 'T')), eb = !((cb == 'A') | (cb == 'C') | (cb == 'G') | (cb == 'T'));
+            we |= (u64)(ea | eb) << bit; ws |= (u64)((ca != cb) | ea | eb) << bit; wl |= (u64)(ca < cb) << bit;
+        }
+    }
+    stop[w] = ws; exc[w] = we; lt[w] = wl;
+}
+// layout of the key's upper bits on the fused path: [0, bits) the sort key; [nd_shift, nd_shift + nd_bits) nd, all ones = not
+// known; bit nd_shift + nd_bits: the suffix is smaller than its twin; [at_shift, at_shift + at_bits) first stop among the K
+// symbols, all ones = none; [56, 64) the byte in front of the suffix
+struct KeyLayout { int at_shift, at_bits, nd_shift, nd_bits; u64 sortmask; };
+constexpr int ND_WORDS = 40;      // the words of the diagonal bit arrays a block of k_init_keys stages: KEY_TILE / 64 + up to 1536 positions ahead
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1) {
+                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
+                                                  KeyLayout ly, DiagBits dg) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
+    __shared__ u64 s_stop[ND_WORDS], s_exc[ND_WORDS], s_lt[ND_WORDS];
     slut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
@@ -62,25 +112,54 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         const int64_t i = base + k;
         code[k] = (i < n) ? slut[T[i]] : (uint8_t)0;
     }
+    const bool hint = ly.nd_bits > 0;
+    const int64_t nwords = (n + 63) / 64;
+    if (hint && (int)threadIdx.x < ND_WORDS) {
+        const int64_t w = base / 64 + threadIdx.x;
+        const bool in = w < nwords;
+        s_stop[threadIdx.x] = in ? dg.stop[w] : ~0ull; s_exc[threadIdx.x] = in ? dg.exc[w] : ~0ull; s_lt[threadIdx.x] = in ? dg.lt[w] : 0ull;
+    }
     __syncthreads();
+    const u32 at_none = (1u << ly.at_bits) - 1u;
+    const u32 nd_none = hint ? (1u << ly.nd_bits) - 1u : 0u;
 #pragma unroll
     for (int r = 0; r < KEY_TILE / TB; r++) {
         const int k = r * TB + threadIdx.x;
         const int64_t i = base + k;
         if (i < n) {
             u64 key = 0;
-            u32 at = 0xFFu;            // first of the K symbols that is a stop ('$', 'N', past the end), 0xFF = none
+            u32 at = at_none;          // first of the K symbols that is a stop ('$', 'N', past the end)
             for (int j = 0; j < K; j++) {
                 const u32 c = code[k + j];
                 key = key * radix + c;
-                at = ((at == 0xFFu) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at;
+                at = ((at == at_none) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at;
             }
             // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
-            // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Bits 48..55 (the
+            // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Below it (the
             // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --
             // k_heads and the text round read it instead of taking the key apart digit by digit (a function of the digits:
             // keys that are equal in their digits are equal here too)
-            const u64 prev = pay ? ((u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56) | ((u64)at << 48) : 0ull;
+            u64 prev = pay ? ((u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56) | ((u64)at << ly.at_shift) : 0ull;
+            if (hint) {
+                // next marked position at or behind i, looked for in the staged words
+                u32 nd = nd_none, ltb = 0;
+                int wi = k >> 6;
+                u64 mw = s_stop[wi] >> (k & 63);
+                int dist = 0;
+                if (mw) dist = __builtin_ctzll(mw);
+                else {
+                    dist = 64 - (k & 63);
+                    int ww = wi + 1;
+                    while (ww < ND_WORDS && s_stop[ww] == 0ull && dist < (int)nd_none) { dist += 64; ww++; }
+                    if (ww < ND_WORDS && s_stop[ww] != 0ull) dist += __builtin_ctzll(s_stop[ww]); else dist = (int)nd_none;
+                }
+                if (dist < (int)nd_none) {
+                    const int yy = k + dist;
+                    const bool ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull;
+                    if (!ex) { nd = (u32)dist; ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
+                }
+                prev |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
+            }
             keys[i] = key | prev;
             vals[i] = (sav_t)i;
         }
@@ -92,11 +171,19 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 // LCP != NULL (the fused path of rv_build_sa): a head's LCP with its predecessor in the suffix array -- whichever member of the
 // group in front ends up last, it shares that group's K symbols -- is the common prefix of the two keys, cut at the first
 // '$' / 'N' (interface.c:97-114): the digits of both keys, least significant first, by multiply-high division.
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; KeyLayout ly; int64_t D; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
-__device__ inline u32 key_first_stop(u64 key, const KeyDigits &) {
-    const u32 at = (u32)(key >> 48) & 0xFFu;
-    return at == 0xFFu ? 0xFFFFFFFFu : at;
+__device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
+    const u32 none = (1u << kd.ly.at_bits) - 1u;
+    const u32 at = (u32)(key >> kd.ly.at_shift) & none;
+    return at == none ? 0xFFFFFFFFu : at;
+}
+// the diagonal hint of a key (k_init_keys): *nd = symbols its suffix shares with its twin on the diagonal, *lt = it is the smaller one
+__device__ inline bool key_hint(u64 key, const KeyDigits &kd, u32 *nd, bool *lt) {
+    const u32 none = (1u << kd.ly.nd_bits) - 1u;
+    const u32 v = (u32)(key >> kd.ly.nd_shift) & none;
+    *nd = v; *lt = (key >> (kd.ly.nd_shift + kd.ly.nd_bits)) & 1ull;
+    return kd.ly.nd_bits > 0 && v != none;
 }
 // number of leading digits (of K) two keys share: both are taken apart from the top, 8 / 4 / 2 / 1 digits at a time (as 16-digit
 // numbers with leading zeros), following the half that differs -- four rounds of two divisions instead of K
@@ -121,7 +208,7 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
     // the payload bits (56..63 the byte in front, 48..55 the first stop) only exist on the fused path; without it the key may
     // use all 64 bits (sigma = 3 and n > 2^28: 29 symbols in 58 bits) and is compared whole
-    const u64 mask = LCP ? KEY_MASK : ~0ull;
+    const u64 mask = LCP ? kd.ly.sortmask : ~0ull;
     const bool in = j < n;
     const u64 kb = in ? keys[j] & mask : 0ull, ka = (in && j > 0) ? keys[j - 1] & mask : 0ull;
     const bool hd = in && ((j == 0) || ka != kb);
@@ -129,7 +216,7 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     u32 l = 0;
     if (LCP && hd) {
         if (j > 0) {
-            const u64 dm = (1ull << 48) - 1;
+            const u64 dm = kd.ly.sortmask;
             if (kd.K <= 16) {
                 l = key_common_digits(ka & dm, kb & dm, kd);
             } else {      // (tiny alphabets: more than 16 symbols in 48 bits) digit by digit
@@ -404,6 +491,9 @@ __device__ inline int cmp_text(const uint8_t *__restrict__ T, sav_t a, sav_t b, 
 // the same comparison on the 2-bit text, 128 bases per step; leaves to cmp_text where a window touches an exception block
 template <int W>
 __device__ inline int cmp_suffix(const uint8_t *__restrict__ T, const Packed &pk, sav_t a, sav_t b, u32 *lcp, int h0, u32 stop0) {
+#ifdef RV_RT_NOCMP      // (measurement only: the round without its text accesses)
+    *lcp = 20; return a < b ? -1 : 1;
+#endif
     if (pk.Tp == nullptr) return cmp_text<W>(T, a, b, lcp, h0, stop0);
     for (int off = h0; off < TEXT_LIM; off += PK_BLOCK) {
         const int64_t pa = (int64_t)a + off, pb = (int64_t)b + off;
@@ -435,12 +525,18 @@ __device__ inline int cmp_suffix(const uint8_t *__restrict__ T, const Packed &pk
 // what the fused path writes besides SA: BWT byte of every member at its final rank, LCP of every member but the group's first
 // (its LCP with the member in front of it = the largest common prefix it has with any smaller member), the running maximum
 struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; Packed pk; };
-__device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp) {
+__device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp, u32 &lmax) {
     f.BWT[rank] = (uint8_t)(pay | ((sa_t)suf > f.side_sep ? RV_BWT_SIDE : 0u));
     if (!first) {
         f.LCP[rank] = (lcp_t)lcp;
-        if (lcp > __atomic_load_n(f.maxlcp, __ATOMIC_RELAXED)) atomicMax(f.maxlcp, lcp);      // (only threads that raise it reach the atomic unit)
+        lmax = lcp > lmax ? lcp : lmax;
     }
+}
+// the running maximum of the index' LCP values: one look at the word per wave.  (Every put looked at it: 5 x 10^8 loads of one
+// address per round at 2 x 250 Mbp -- one L2 channel per XCD serving them was what the round waited for, 24 of its 29 ms.)
+__device__ inline void fused_max_flush(const FusedOut &f, u32 lmax) {
+    const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
+    if ((threadIdx.x & 63) == 0 && f.maxlcp && wm > __atomic_load_n(f.maxlcp, __ATOMIC_RELAXED)) atomicMax(f.maxlcp, wm);
 }
 
 constexpr int MEDIUM_GROUP = 64;      // groups of up to 64 members: every member ranks itself by text comparison (into Sout; k_medium_back copies back)
@@ -462,11 +558,9 @@ __global__ __launch_bounds__(TB) void k_medium_back(const uint8_t *__restrict__ 
 // MODE 1: the same for groups of three and more; a pair is ordered by its first thread alone.
 // MODE 0: groups of up to SMALL_GROUP members are ordered by their first thread (all pairs in registers), larger ones rank themselves.
 template <int W, int MODE>
-__global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
-                                                   int64_t m, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
-                                                   sav_t *__restrict__ Sout, FusedOut fo) {
-    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (q >= m) return;
+__device__ __forceinline__ void round_text_body(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
+                                                int64_t m, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                sav_t *__restrict__ Sout, const FusedOut &fo, int64_t q, u32 &lmax) {
     const u32 g = G[q];
     const u32 off = P[q] - g;
     const int64_t look = q + (MEDIUM_GROUP - (int64_t)off);
@@ -496,7 +590,7 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         Sout[qs + rank] = mine;                                  // (S itself is still being read by the other members)
         SA[(size_t)g + rank] = (sa_t)mine;
         headq[qs + rank] = !tie_before;
-        if (fused) fused_put(fo, (size_t)g + rank, mine, (u32)(fo.keys[(size_t)g + off] >> 56), rank == 0, best);
+        if (fused) fused_put(fo, (size_t)g + rank, mine, (u32)(fo.keys[(size_t)g + off] >> 56), rank == 0, best, lmax);
         return;
     }
     if (off != 0) return;
@@ -510,8 +604,8 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         headq[q] = 1; headq[q + 1] = c != 0;
         if (fused) {
             const u32 p0 = (u32)(fo.keys[(size_t)g] >> 56), p1 = (u32)(fo.keys[(size_t)g + 1] >> 56);
-            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0);
-            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l);
+            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0, lmax);
+            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l, lmax);
         }
         return;
     }
@@ -531,8 +625,8 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
         headq[q] = 1; headq[q + 1] = c != 0;
         if (fused) {
             const u32 p0 = (u32)(fo.keys[(size_t)g] >> 56), p1 = (u32)(fo.keys[(size_t)g + 1] >> 56);
-            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0);
-            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l);
+            fused_put(fo, (size_t)g, lo, c <= 0 ? p0 : p1, true, 0, lmax);
+            fused_put(fo, (size_t)g + 1, hi, c <= 0 ? p1 : p0, false, l, lmax);
         }
         return;
     }
@@ -562,9 +656,209 @@ __global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T
             S[q + r] = s[i];
             SA[(size_t)g + r] = (sa_t)s[i];
             headq[q + r] = before == 0;
-            if (fused) fused_put(fo, (size_t)g + r, s[i], (u32)(fo.keys[(size_t)g + i] >> 56), r == 0, best[i]);
+            if (fused) fused_put(fo, (size_t)g + r, s[i], (u32)(fo.keys[(size_t)g + i] >> 56), r == 0, best[i], lmax);
         }
     }
+}
+
+
+template <int W, int MODE>
+__global__ __launch_bounds__(TB) void k_round_text(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
+                                                   int64_t m, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                   sav_t *__restrict__ Sout, FusedOut fo) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 lmax = 0;
+    if (q < m) round_text_body<W, MODE>(T, S, G, P, m, headq, bigflag, SA, Sout, fo, q, lmax);
+    if (fo.LCP) fused_max_flush(fo, lmax);
+}
+
+// The first round with the diagonal hint (k_init_keys): groups of two to four by one thread, larger ones rank themselves
+// as in k_round_text.  Twins on the diagonal are ordered from their keys; an unrelated pair (two twin pairs that collide in
+// their K symbols) is compared on the text once and the other members' order against each other follows -- x and its twin x'
+// agree for nd symbols, so against a third suffix z they behave alike up to there: if z leaves x' before nd, it leaves x at the
+// same place the same way; if later, x against z is x against x'.  Whatever that does not settle is compared on the text.
+// Two passes: k_round_text3 streams the list and finishes every group its keys decide (four in five at 2 x 250 Mbp); a group
+// that needs the text goes to a work list, and k_round_text3b takes one group per thread from it.  (In one pass the round was
+// bound by the latency of the few lanes per wave that went to the text: 29 ms for 36 GB of traffic.)
+constexpr int RT_REGIONS = 1024;
+template <int W, bool ALLOW_TEXT>
+__device__ __forceinline__ bool order_small(const uint8_t *__restrict__ T, const FusedOut &fo, int64_t q, u32 g, const sav_t *s, const u64 *kk, int size,
+                                            int h0, u32 stop0, sav_t *__restrict__ S, sa_t *__restrict__ SA, uint8_t *__restrict__ headq, u32 &lmax) {
+    // pair (i, j), i < j, lives at index i * 4 + j; c < 0: s[i] is the smaller suffix
+    int c[16]; u32 l[16]; bool kn[16], tw[16];
+#pragma unroll
+    for (int x = 0; x < 16; x++) { c[x] = 0; l[x] = 0; kn[x] = false; tw[x] = false; }
+    const int64_t D = fo.kd.D;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) {
+            if (j < size) {
+                const int64_t d = (int64_t)s[j] - (int64_t)s[i];
+                if (d == D || d == -D) {
+                    u32 nd; bool lt;
+                    const bool low_i = d > 0;
+                    if (key_hint(low_i ? kk[i] : kk[j], fo.kd, &nd, &lt)) {
+                        c[i * 4 + j] = (low_i == lt) ? -1 : 1; l[i * 4 + j] = nd < stop0 ? nd : stop0; kn[i * 4 + j] = true; tw[i * 4 + j] = true;
+                    }
+                }
+            }
+        }
+    bool need_text = false;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = i + 1; j < 4; j++) {
+            if (j < size && !kn[i * 4 + j]) {
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k != i && k != j && k < size && !done) {
+                        const int ik = i < k ? i * 4 + k : k * 4 + i, kj = k < j ? k * 4 + j : j * 4 + k;
+                        const int c_ik = i < k ? c[ik] : -c[ik], c_kj = k < j ? c[kj] : -c[kj];      // oriented: i against k, k against j
+                        if (tw[ik] && kn[kj] && c_kj != 0) {              // i and k are twins
+                            if (l[kj] < l[ik]) { c[i * 4 + j] = c_kj; l[i * 4 + j] = l[kj]; done = true; }
+                            else if (l[kj] > l[ik]) { c[i * 4 + j] = c_ik; l[i * 4 + j] = l[ik]; done = true; }
+                        } else if (tw[kj] && kn[ik] && c_ik != 0) {       // j and k are twins
+                            if (l[ik] < l[kj]) { c[i * 4 + j] = c_ik; l[i * 4 + j] = l[ik]; done = true; }
+                            else if (l[ik] > l[kj]) { c[i * 4 + j] = c_kj; l[i * 4 + j] = l[kj]; done = true; }
+                        }
+                    }
+                }
+                if (!done) {
+                    if (ALLOW_TEXT) { u32 ll = 0; c[i * 4 + j] = cmp_suffix<W>(T, fo.pk, s[i], s[j], &ll, h0, stop0); l[i * 4 + j] = ll; }
+                    else need_text = true;
+                }
+                kn[i * 4 + j] = true;
+            }
+        }
+    if (!ALLOW_TEXT && need_text) return false;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (i < size) {
+            int r = 0; bool tie_before = false; u32 best = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (j != i && j < size) {
+                    const int ji = j < i ? j * 4 + i : i * 4 + j;
+                    const int cji = j < i ? c[ji] : -c[ji];               // j against i
+                    r += (cji < 0) | ((cji == 0) & (j < i));
+                    tie_before |= (cji == 0) & (j < i);
+                    best = (cji < 0 && l[ji] > best) ? l[ji] : best;
+                }
+            }
+            S[q + r] = s[i];
+            SA[(size_t)g + r] = (sa_t)s[i];
+            headq[q + r] = !tie_before;
+            fused_put(fo, (size_t)g + r, s[i], (u32)(kk[i] >> 56), r == 0, best, lmax);
+        }
+    }
+    return true;
+}
+// the members of the group that starts at list entry q (at most four), everything loaded at once: clamped to the arrays instead of guarded
+__device__ __forceinline__ int load_small(const sav_t *__restrict__ S, const u32 *__restrict__ G, const u64 *__restrict__ keys, int64_t q, u32 g, u64 key_g,
+                                          int64_t m, int64_t n, sav_t *s, u64 *kk) {
+    u32 gg[4];
+    s[0] = S[q]; kk[0] = key_g; gg[0] = g;
+#pragma unroll
+    for (int j = 1; j < 4; j++) {
+        const int64_t qj = q + j < m ? q + j : m - 1;
+        const int64_t rj = (int64_t)g + j < n ? (int64_t)g + j : n - 1;
+        gg[j] = G[qj]; s[j] = S[qj]; kk[j] = keys[rj];
+    }
+    int size = 1;
+#pragma unroll
+    for (int j = 1; j < 4; j++) size += (size == j && q + j < m && gg[j] == g) ? 1 : 0;
+    return size;
+}
+template <int W>
+__global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
+                                                    int64_t m, int64_t n, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                    sav_t *__restrict__ Sout, FusedOut fo, u32 *__restrict__ work, u32 *__restrict__ work_count, u32 reg_cap) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool defer = false;
+    u32 lmax = 0;
+    if (q < m) {
+        const u32 g = G[q];
+        const u32 off = P[q] - g;
+        const int64_t qs = q - (int64_t)off;                       // the group's first list entry (a group is contiguous in the list)
+        const int64_t look = qs + MEDIUM_GROUP, i4 = qs + 4;
+        const u32 g_look = G[look < m ? look : m - 1], g_4 = G[i4 < m ? i4 : m - 1];
+        const u64 key_g = fo.keys[g];
+        const bool big = off >= (u32)MEDIUM_GROUP || (look < m && g_look == g);
+        const bool self = !big && i4 < m && g_4 == g;
+        bigflag[q] = big ? 1 : self ? 2 : 0;
+        const int h0 = fo.h;
+        const u32 stop0 = key_first_stop(key_g, fo.kd);
+        if (self) {
+            int size = (int)off + 1;
+            while (qs + size < m && G[qs + size] == g) size++;
+            const sav_t mine = S[q];
+            int rank = 0; bool tie_before = false; u32 best = 0;
+            for (int j = 0; j < size; j++) {
+                if (j == (int)off) continue;
+                u32 l;
+                const int c = cmp_suffix<W>(T, fo.pk, S[qs + j], mine, &l, h0, stop0);
+                rank += (c < 0) | ((c == 0) & (j < (int)off));
+                tie_before |= (c == 0) & (j < (int)off);
+                best = (c < 0 && l > best) ? l : best;
+            }
+            Sout[qs + rank] = mine;
+            SA[(size_t)g + rank] = (sa_t)mine;
+            headq[qs + rank] = !tie_before;
+            fused_put(fo, (size_t)g + rank, mine, (u32)(fo.keys[(size_t)g + off] >> 56), rank == 0, best, lmax);
+        } else if (!big && off == 0) {
+            // a pair of twins is finished here, from its keys; everything else needs the text at least once: the work list
+            const int64_t q2 = q + 2 < m ? q + 2 : m - 1, r1 = (int64_t)g + 1 < n ? (int64_t)g + 1 : n - 1;
+            const u32 g_2 = G[q2];
+            const sav_t s0 = S[q], s1 = S[q + 1 < m ? q + 1 : m - 1];
+            const u64 key_1 = fo.keys[r1];
+            const bool pair = !(q + 2 < m && g_2 == g);
+            const int64_t d = (int64_t)s1 - (int64_t)s0;
+            u32 nd; bool lt;
+            const bool low0 = d > 0;
+            const bool hinted = pair & ((d == fo.kd.D) | (d == -fo.kd.D)) && key_hint(low0 ? key_g : key_1, fo.kd, &nd, &lt);
+            if (hinted) {
+                const bool first0 = low0 == lt;                     // s0 is the smaller suffix
+                const sav_t lo = first0 ? s0 : s1, hi = first0 ? s1 : s0;
+                S[q] = lo; S[q + 1] = hi;
+                SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
+                headq[q] = 1; headq[q + 1] = 1;
+                const u32 p0 = (u32)(key_g >> 56), p1 = (u32)(key_1 >> 56);
+                fused_put(fo, (size_t)g, lo, first0 ? p0 : p1, true, 0, lmax);
+                fused_put(fo, (size_t)g + 1, hi, first0 ? p1 : p0, false, nd < stop0 ? nd : stop0, lmax);
+            } else defer = true;
+        }
+    }
+    fused_max_flush(fo, lmax);
+    // the work list in RT_REGIONS regions with a counter each (one list, one counter: 7.8 x 10^6 returning atomics on one address,
+    // 79 ms at 2 x 250 Mbp); a region holds the groups of every RT_REGIONS-th workgroup
+    const u64 bal = __ballot(defer);
+    if (bal) {
+        const u32 reg = blockIdx.x & (RT_REGIONS - 1);
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&work_count[reg], (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (defer) work[(size_t)reg * reg_cap + base + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))))] = (u32)q;
+    }
+}
+template <int W>
+__global__ __launch_bounds__(TB) void k_round_text3b(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, int64_t m, int64_t n,
+                                                     uint8_t *__restrict__ headq, sa_t *__restrict__ SA, FusedOut fo, const u32 *__restrict__ work,
+                                                     const u32 *__restrict__ work_count, u32 reg_cap, u32 blocks_per_region) {
+    const u32 reg = blockIdx.x / blocks_per_region;
+    const u32 w = (blockIdx.x % blocks_per_region) * TB + threadIdx.x;
+    u32 lmax = 0;
+    if (w < work_count[reg]) {
+        const int64_t q = (int64_t)work[(size_t)reg * reg_cap + w];
+        const u32 g = G[q];
+        const u64 key_g = fo.keys[g];
+        sav_t s[4]; u64 kk[4];
+        const int size = load_small(S, G, fo.keys, q, g, key_g, m, n, s, kk);
+        (void)order_small<W, true>(T, fo, q, g, s, kk, size, fo.h, key_first_stop(key_g, fo.kd), S, SA, headq, lmax);
+    }
+    fused_max_flush(fo, lmax);
 }
 
 // members of big groups -> sublist (ordered)
@@ -890,6 +1184,14 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     // groups above 64 members: repeats, identical inputs) falls back to rv_build_lcp for the whole index.
     bool fused = LCP && BWT && d_maxlcp && bits <= 48 && !getenv("RV_NO_FUSED_LCP");
     KeyDigits kd;
+    // upper bits of the keys (k_init_keys): first stop among the K symbols in 5 bits when K allows (8 otherwise), the diagonal hint
+    // in what is left between the sort key's last whole digit and that field -- 11 bits at n = 5e8 (nd up to 1022), none at n = 2.2e9 (47-bit keys)
+    kd.ly.sortmask = bits >= 64 ? ~0ull : (1ull << bits) - 1;
+    kd.ly.at_bits = K <= 30 ? 5 : 8; kd.ly.at_shift = 56 - kd.ly.at_bits;
+    kd.ly.nd_shift = (bits + 7) / 8 * 8; kd.ly.nd_bits = 0;      // (the last radix pass looks at a whole 8-bit digit)
+    kd.D = (side_sep > 0 && (int64_t)side_sep < n - 1) ? (int64_t)side_sep + 1 : 0;
+    const bool want_hint = fused && kd.D > 0 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !getenv("RV_NO_DIAG") && !getenv("RV_NO_PACKED_TEXT");
+    if (want_hint) kd.ly.nd_bits = std::min(kd.ly.at_shift - kd.ly.nd_shift - 1, 11);
     kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
     for (int st = 0; st < 4; st++) {
         u64 d = 1;
@@ -911,8 +1213,17 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     const unsigned nblk = (unsigned)ceil_div(n, TB);
 
     // -- first key, sorted on its K*bits significant bits
+    DiagBits dg; dg.stop = dg.exc = dg.lt = nullptr; dg.D = kd.D;
+    if (kd.ly.nd_bits > 0) {
+        DBuf &bds = ws.sa[20], &bde = ws.sa[21], &bdl = ws.sa[22];
+        const int64_t nw = (n + 63) / 64;
+        SA_TRY(bds.reserve((size_t)nw * 8)); SA_TRY(bde.reserve((size_t)nw * 8)); SA_TRY(bdl.reserve((size_t)nw * 8));
+        hipLaunchKernelGGL(k_diag_bits, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, kd.D, bds.as<u64>(), bde.as<u64>(), bdl.as<u64>(), nw);
+        SA_HIP(hipGetLastError());
+        dg.stop = bds.as<u64>(); dg.exc = bde.as<u64>(); dg.lt = bdl.as<u64>();
+    }
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1);
+                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, bits, &in1));
@@ -940,7 +1251,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     // -- compaction of the non-unique suffixes (round 0: from the full arrays)
     int64_t ntile = ceil_div(n, CP_TILE);
-    SA_TRY(btile.reserve((size_t)(ntile + 1) * 4));
+    SA_TRY(btile.reserve(std::max((size_t)(ntile + 1) * 4, (size_t)RT_REGIONS * 4)));      // (also the work-list counters of the text round)
     u32 *tile = btile.as<u32>();
     // compaction of the not yet unique suffixes in two steps, so that a round that leaves nothing behind can stop
     // before it updates ISA
@@ -1008,9 +1319,27 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             // 116-120 / 22.6 / 2.27; everything by the first thread (up to 8 members) 122 / 32.0 / 2.37; everything self-ranking
             // 125 / 22.6 / 2.33; 64-byte steps instead of 32: +14 / +3 / +0.3 (the round is bound by sector traffic, not by the
             // length of its dependent-load chains); 16-byte steps: +4 / -1 / +0.03.  RV_TEXT_MODE: test hook for the other two.
-            const int tmode = getenv("RV_TEXT_MODE") ? atoi(getenv("RV_TEXT_MODE")) : 1;
+            // (with the diagonal hint: groups of up to four by their first thread, twins from their keys -- mode 3)
+            const int tmode = getenv("RV_TEXT_MODE") ? atoi(getenv("RV_TEXT_MODE")) : (kd.ly.nd_bits > 0 ? 3 : 1);
 #define RT_LAUNCH(M_) hipLaunchKernelGGL((k_round_text<4, M_>), dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo)
-            if (tmode == 0) RT_LAUNCH(0); else if (tmode == 2) RT_LAUNCH(2); else RT_LAUNCH(1);
+            if (tmode == 3 && fused) {
+                // (both free here: the list of big-group members comes later, the tile counts of the compaction are used up)
+                u32 *work = bQb.as<u32>(), *work_count = tile;
+                const u32 reg_cap = (u32)(ceil_div((int64_t)mb, RT_REGIONS) * (TB / 2));      // a group has two entries at least
+                SA_HIP(hipMemsetAsync(work_count, 0, RT_REGIONS * 4, q));
+                hipLaunchKernelGGL((k_round_text3<4>), dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, n, head, bigflag, SA, Sfree, fo, work, work_count, reg_cap);
+                SA_HIP(hipGetLastError());
+                u32 cnt[RT_REGIONS];
+                SA_TRY(rv_read_back(ws, cnt, work_count, sizeof cnt));
+                u32 mx = 0;
+                for (int r = 0; r < RT_REGIONS; r++) mx = std::max(mx, cnt[r]);
+                if (mx) {
+                    const u32 bpr = (u32)ceil_div((int64_t)mx, TB);
+                    hipLaunchKernelGGL((k_round_text3b<4>), dim3(bpr * RT_REGIONS), dim3(TB), 0, q, T, S, (const u32 *)G, m, n, head, SA, fo, (const u32 *)work,
+                                       (const u32 *)work_count, reg_cap, bpr);
+                }
+            }
+            else if (tmode == 0) RT_LAUNCH(0); else if (tmode == 2) RT_LAUNCH(2); else RT_LAUNCH(1);
 #undef RT_LAUNCH
             SA_HIP(hipGetLastError());
             hipLaunchKernelGGL(k_medium_back, dim3((unsigned)ceil_div(m, (int64_t)TB * 8)), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);

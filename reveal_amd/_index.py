@@ -483,8 +483,10 @@ def make_index_type(sa64, error):
             dll, h = self._dll, self._h
             mem = ctypes.c_int64(0)
             na = dll.rv_anchor_count(h, ctypes.byref(mem))
-            l = np.zeros(max(na, 1), dtype=np.uint32); off = np.zeros(na + 1, dtype=np.int64)
-            pos = np.zeros(max(mem.value, 1), dtype=np.int64)
+            # (filled completely by the library: no zeroing)
+            l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64)
+            pos = np.empty(max(mem.value, 1), dtype=np.int64)
+            off[0] = 0
             if dll.rv_fetch_anchors(h, l.ctypes.data, off.ctypes.data, pos.ctypes.data) != 0:
                 self._fail()
             tr = None

@@ -22,6 +22,7 @@ static_assert(RV_TSUB_TILE == RV_SPLIT_TILE, "one tile -> sub-index table serves
 #include <string.h>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 namespace {
 
@@ -2174,6 +2175,20 @@ int64_t rv_anchor_count(rv_index *h, int64_t *members) {
     if (members) *members = (int64_t)(h->al->an_pos.size() + 2 * h->al->leaf_na);
     return (int64_t)(h->al->an_l.size() + h->al->leaf_na);
 }
+// a large copy into caller memory (fresh pages on the caller's side: first touch is most of its cost) on a few host threads
+static void copy_parallel(void *dst, const void *src, size_t bytes) {
+    const size_t chunk = (size_t)8 << 20;
+    if (bytes < 2 * chunk) { memcpy(dst, src, bytes); return; }
+    const int nt = (int)std::min<size_t>(8, bytes / chunk);
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) {
+        const size_t lo = bytes / nt * t, hi = t + 1 == nt ? bytes : bytes / nt * (t + 1);
+        th.emplace_back([=]() { memcpy((char *)dst + lo, (const char *)src + lo, hi - lo); });
+    }
+    memcpy(dst, src, bytes / nt);
+    for (auto &x : th) x.join();
+}
+
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos) {
     RV_TRY(need_align(h));
     Align *a = h->al;
@@ -2181,11 +2196,14 @@ int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos) {
     memcpy(l, a->an_l.data(), nl * 4);
     memcpy(off, a->an_off.data(), a->an_off.size() * 8);
     memcpy(pos, a->an_pos.data(), np * 8);
-    if (na) {      // the leaf launches' anchors, still in the pinned staging buffer (pos[2 na], l[na])
+    if (na) {      // the leaf launches' (and the cascade's) anchors, still in the pinned staging buffer (pos[2 na], l[na])
         const int64_t *pp = a->hLeafOut.as<int64_t>(); const u32 *pl = (const u32 *)(pp + 2 * na);
+        std::thread t_off;
+        if (na > (size_t)1 << 18) t_off = std::thread([=]() { for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1)); });
+        else for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1));
         memcpy(l + nl, pl, na * 4);
-        memcpy(pos + np, pp, na * 16);
-        for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1));
+        copy_parallel(pos + np, pp, na * 16);
+        if (t_off.joinable()) t_off.join();
     }
     return 0;
 }

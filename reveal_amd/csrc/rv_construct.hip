@@ -246,13 +246,68 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
 // path for groups above MEDIUM_GROUP: related genomes finish in the text round without either, so the scatter
 // ISA[SA[j]] = grp[j] (a random 4-byte write per position, 21 ms at n = 5e8) waits until something asks for it.
 __global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals, int64_t n, sa_t *__restrict__ SA,
-                                                 const u64 *__restrict__ keys, uint8_t *__restrict__ BWT, sa_t side_sep) {
+                                                 const u64 *__restrict__ keys, uint8_t *__restrict__ BWT, sa_t side_sep,
+                                                 KeyDigits kd, lcp_t *__restrict__ LCP, uint8_t *__restrict__ head, u32 *__restrict__ d_maxlcp, u32 *__restrict__ grp) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (j >= n) return;
-    const sav_t s = vals[j];
-    SA[j] = (sa_t)s;
-    // (fused path) final for every suffix that is alone in its group; members of larger groups are rewritten where they are ordered
-    if (BWT) BWT[j] = (uint8_t)((u32)(keys[j] >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+    u32 lmax = 0;
+    // the workgroup's keys and suffixes with their neighbours (two in front, two behind) through LDS: every thread looks at five keys
+    __shared__ u64 s_key[TB + 4];
+    __shared__ sav_t s_val[TB + 2];
+    const bool hint = BWT && kd.ly.nd_bits > 0;
+    if (hint) {
+        const int64_t j0 = (int64_t)blockIdx.x * TB;
+        for (int k = threadIdx.x; k < TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < n) ? keys[i] : 0ull; }
+        for (int k = threadIdx.x; k < TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < n) ? vals[i] : (sav_t)0; }
+        __syncthreads();
+    }
+    if (j < n) {
+        const int t = threadIdx.x;
+        const sav_t s = hint ? s_val[t + 1] : vals[j];
+        int64_t rank = j;
+        const u64 key = hint ? s_key[t + 2] : (BWT ? keys[j] : 0ull);
+        // (fused path, diagonal hint) a group of exactly two suffixes that are twins on the diagonal is finished right here, from the
+        // keys: both take their final ranks, the second one gets its LCP and becomes a head, and neither enters the list of
+        // not yet unique suffixes -- four in five groups at 2 x 250 Mbp, where the text round used to stream the whole array again
+        if (hint) {
+            const u64 mk = kd.ly.sortmask;
+            const u64 k0 = key & mk;
+            const u64 km2 = j >= 2 ? s_key[t] & mk : ~k0, km1 = j >= 1 ? s_key[t + 1] & mk : ~k0;
+            const u64 kp1r = j + 1 < n ? s_key[t + 3] : ~key, kp2 = j + 2 < n ? s_key[t + 4] & mk : ~k0;
+            const u64 km1r = j >= 1 ? s_key[t + 1] : ~key;
+            const u64 kp1 = j + 1 < n ? kp1r & mk : ~k0;
+            const bool first = (km1 != k0) & (kp1 == k0) & (kp2 != k0);
+            const bool second = (km1 == k0) & (kp1 != k0) & (km2 != k0);
+            if (first | second) {
+                const sav_t ps = first ? s_val[t + 2] : s_val[t];
+                const u64 pkey = first ? kp1r : km1r;
+                const int64_t d = (int64_t)ps - (int64_t)s;
+                if (d == kd.D || d == -kd.D) {
+                    u32 nd; bool lt;
+                    const bool i_low = d > 0;                        // I start at the smaller text position
+                    if (key_hint(i_low ? key : pkey, kd, &nd, &lt)) {
+                        const bool i_smaller = i_low == lt;
+                        const int64_t base = first ? j : j - 1;
+                        rank = base + (i_smaller ? 0 : 1);
+                        if (rank != base) {
+                            const u32 st = key_first_stop(key, kd);
+                            const u32 l = nd < st ? nd : st;
+                            LCP[rank] = (lcp_t)l;
+                            lmax = l;
+                            grp[rank] = (u32)rank;      // a group of its own from here on (k_isa_from_groups: its rank, should a doubling round ask)
+                        }
+                        if (second) head[j] = 1;
+                    }
+                }
+            }
+        }
+        SA[rank] = (sa_t)s;
+        // (fused path) final for every suffix that is alone in its group or finished above; members of other groups are rewritten where they are ordered
+        if (BWT) BWT[rank] = (uint8_t)((u32)(key >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+    }
+    if (BWT && kd.ly.nd_bits > 0) {
+        const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
+        if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
+    }
 }
 // Group ranks are rank ranges and every round only permutes suffixes inside their group, so (SA, grp of round 0) still
 // describe round 0's ISA after the text round has reordered SA.
@@ -1238,7 +1293,12 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd, fused ? d_maxlcp : (u32 *)nullptr);
     SA_HIP(hipGetLastError());
     SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
-    hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep);
+    {
+        KeyDigits kp = kd;
+        if (getenv("RV_NO_PUB_TWINS")) kp.ly.nd_bits = 0;      // (test hook: twin pairs go through the text round's first pass instead)
+        hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep,
+                           kp, fused ? LCP : (lcp_t *)nullptr, head, d_maxlcp, grp);
+    }
     SA_HIP(hipGetLastError());
     bool isa_built = false;
     auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)

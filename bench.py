@@ -304,13 +304,18 @@ def main():
             properties["divide_all"] = dp["all"]
             properties["divide_same_anchor_set_as_rank0_alone"] = anchor_set(*dl["anchors"]) == anchor_set(*last["anchors"])
         del T0
-    breakdown = None
+    breakdown = roofline_other = None
     if rank == 0 and not divide:
         idx.prof(enable=True, reset=True)
         for _ in range(2):
             idx.construct()
             idx.align_builtin(args.minl, args.minn)
-        breakdown = {k: v[1] / 2 for k, v in idx.prof(enable=False).items() if v[0]}
+        pall = idx.prof(enable=False)
+        breakdown = {k: v[1] / 2 for k, v in pall.items() if v[0]}
+        # the other kernels of the step against the same roofline (their own algorithmic bytes, include/reveal_amd.h RV_K_*), from these
+        # two untimed steps: not the judged kernel, but what the step spends its time in
+        roofline_other = {k: {"launches_per_step": v[0] / 2, "ms_per_step": v[1] / 2, "achieved_GBps": (v[2] / 1e9) / (v[1] / 1e3), "frac": (v[2] / 1e9) / (v[1] / 1e3) / HBM_PEAK_GBS}
+                          for k, v in pall.items() if v[0] and v[1] > 0 and v[2] > 0 and k not in (kname, "sa_build", "cascade")}
     barrier()
 
     total_bases = float(bases * jobs) * (1 if divide else world)
@@ -373,6 +378,7 @@ def main():
                          "copy_peak": {"read_GBps": read_gbs, "copy_GBps_read_plus_write": copy_gbs, "bytes": 1 << 30,
                                        "frac_of_read_peak": (achieved / read_gbs) if read_gbs else None}},
             "breakdown_ms_per_step": breakdown,
+            "roofline_other": roofline_other,
             "recursion": {"anchors": st["splits"], "anchored_bp": st["anchored_bp"], "levels": st["levels"], "subindices": st["steps"],
                           "scanned_ranks": st["scanned_ranks"], "host_s": st["t_host"], "scan_s": st["t_scan"],
                           "split_s": st["t_split"], "bubble_s": st["t_bubble"]},

@@ -261,7 +261,12 @@ int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t *nmem, con
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,
-       RV_K_BUBBLE = 6, RV_K_COUNT = 8 };
+       RV_K_BUBBLE = 6,
+       /* parts of RV_K_SA_SORT, timed on their own (bytes = what the kernel has to move: 2 x (8 B key + value) per pair and
+        * scatter pass, 8 B per key and histogram pass; the text round's bytes are its list traffic) */
+       RV_K_RADIX_SCATTER = 7, RV_K_RADIX_HIST = 8, RV_K_TEXT_ROUND = 9,
+       RV_K_CASCADE = 10,      /* the anchor cascade behind its scan: witnesses, match sort, levels, rebuild + leaf launch */
+       RV_K_COUNT = 12 };
 /* on: 0 = off, 1 = every class, otherwise bit k+1 selects class k (an event pair costs the stream a few
  * microseconds, so a timed run times only what it reports) */
 int rv_prof_enable(rv_index *h, int on);

@@ -99,7 +99,8 @@ def make_index_type(sa64, error):
             """HIP-event kernel timing on the index' stream -> {kernel: (launches, ms, bytes)}
             only = names of the kernel classes to time (default: all; every timed span costs the stream two events)"""
             ids = {"scan_pair": _lib.K_SCAN_PAIR, "scan_multi": _lib.K_SCAN_MULTI, "sa_build": _lib.K_SA_SORT, "lcp": _lib.K_LCP,
-                   "split": _lib.K_SPLIT, "label": _lib.K_LABEL, "bubble": _lib.K_BUBBLE}
+                   "split": _lib.K_SPLIT, "label": _lib.K_LABEL, "bubble": _lib.K_BUBBLE, "radix_scatter": _lib.K_RADIX_SCATTER,
+                   "radix_hist": _lib.K_RADIX_HIST, "text_round": _lib.K_TEXT_ROUND, "cascade": _lib.K_CASCADE}
             if enable is not None:
                 on = 0
                 if enable:
@@ -108,8 +109,7 @@ def make_index_type(sa64, error):
             if reset:
                 self._dll.rv_prof_reset(self._h)
             out = {}
-            for name, k in (("scan_pair", _lib.K_SCAN_PAIR), ("scan_multi", _lib.K_SCAN_MULTI), ("sa_build", _lib.K_SA_SORT),
-                            ("lcp", _lib.K_LCP), ("split", _lib.K_SPLIT), ("label", _lib.K_LABEL), ("bubble", _lib.K_BUBBLE)):
+            for name, k in ids.items():
                 n, ms, by = ctypes.c_int64(0), ctypes.c_double(0), ctypes.c_double(0)
                 self._dll.rv_prof_get(self._h, k, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(by))
                 out[name] = (n.value, ms.value, by.value)

@@ -76,6 +76,12 @@ class AlnGraph:
     def has_node(self, node):
         return node in self.offsets
 
+    def number_of_nodes(self):
+        return len(self.offsets)
+
+    def number_of_edges(self):
+        return sum(len(v) for v in self.succ.values())
+
     def seq_nodes(self):
         return [n for n in self.offsets if isinstance(n, tuple)]
 
@@ -294,6 +300,13 @@ class AlnGraph:
                         break
                 break
         return "".join(out).upper()
+
+
+    def spell_by_offsets(self, sample, T):
+        """the same for a graph without sentinels (rem.align removes them, rem.py:708-710): the path's nodes in offset order"""
+        sid = self.path2id[sample]
+        nodes = sorted((o[sid], n) for n, o in self.offsets.items() if isinstance(n, tuple) and sid in o)
+        return "".join(T[b:e] for _, (b, e) in nodes).upper()
 
 
 # ---- readers (reveal/utils.py:304-375, 377-677) -------------------------------------------------------

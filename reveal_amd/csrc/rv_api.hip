@@ -62,6 +62,9 @@ rv_index *rv_new(int device) {
         return nullptr;
     }
     h->T.push_back('\0');
+    h->ws.prof_ctx = &h->prof;
+    h->ws.prof_begin_fn = [](void *c, hipStream_t st, int k, double b) { return ((RvProf *)c)->begin(st, k, b); };
+    h->ws.prof_end_fn = [](void *c, hipStream_t st, int id) { ((RvProf *)c)->end(st, id); };
     live_handles().push_back(h);
     return h;
 }

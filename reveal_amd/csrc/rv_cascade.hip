@@ -477,6 +477,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     }
     if (verbose) tp[1] = cas_now();
     out->cands = M;
+    struct ProfSpan { Workspace &w; int id; ~ProfSpan() { w.prof_end(id); } } span{ws, ws.prof_begin(RV_K_CASCADE, 5.0 * (double)n)};      // (bytes: the witness pass over LCP + BWT)
     if (M == 0) GIVE_UP("no match at the top level");
     const RvPairRec *recs = bout.as<RvPairRec>() + RV_PAIR_HDR;
 

@@ -162,6 +162,12 @@ struct Workspace {
     DBuf sa[24];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;
+    // kernel-class timing of the handle that owns this workspace (RvProf, rv_index.h), for code that only sees the workspace
+    void *prof_ctx = nullptr;
+    int (*prof_begin_fn)(void *, hipStream_t, int, double) = nullptr;
+    void (*prof_end_fn)(void *, hipStream_t, int) = nullptr;
+    int prof_begin(int k, double bytes) { return prof_begin_fn ? prof_begin_fn(prof_ctx, stream, k, bytes) : -1; }
+    void prof_end(int id) { if (prof_end_fn && id >= 0) prof_end_fn(prof_ctx, stream, id); }
     bool sa_in_use = false; // inside rv_build_sa / rv_build_lcp: the scratch below must stay
     size_t trim_sa() {      // releases the SA-build scratch; -> bytes given back
         size_t got = 0;

@@ -1382,6 +1382,8 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             // (with the diagonal hint: groups of up to four by their first thread, twins from their keys -- mode 3)
             const int tmode = getenv("RV_TEXT_MODE") ? atoi(getenv("RV_TEXT_MODE")) : (kd.ly.nd_bits > 0 ? 3 : 1);
 #define RT_LAUNCH(M_) hipLaunchKernelGGL((k_round_text<4, M_>), dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo)
+            // (bytes: the list entries in -- group rank, position, suffix, key -- and SA / LCP / BWT / heads / suffix out)
+            const int tid = ws.prof_begin(9 /* RV_K_TEXT_ROUND */, (double)m * (4 + 4 + sizeof(sav_t) + 8) + (double)m * (sizeof(sav_t) + sizeof(sa_t) + sizeof(lcp_t) + 2));
             if (tmode == 3 && fused) {
                 // (both free here: the list of big-group members comes later, the tile counts of the compaction are used up)
                 u32 *work = bQb.as<u32>(), *work_count = tile;
@@ -1402,6 +1404,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             else if (tmode == 0) RT_LAUNCH(0); else if (tmode == 2) RT_LAUNCH(2); else RT_LAUNCH(1);
 #undef RT_LAUNCH
             SA_HIP(hipGetLastError());
+            ws.prof_end(tid);
             hipLaunchKernelGGL(k_medium_back, dim3((unsigned)ceil_div(m, (int64_t)TB * 8)), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }
         else {

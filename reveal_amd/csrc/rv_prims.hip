@@ -289,12 +289,16 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
     V *vi = v0, *vo = v1;
     int flip = 0;
     for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+        int pid = ws.prof_begin(8 /* RV_K_RADIX_HIST */, 8.0 * (double)n);
         hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, bh, nb);
         RV_LAUNCH_CHECK();
+        ws.prof_end(pid);
         RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, (int64_t)256 * nb));
+        pid = ws.prof_begin(7 /* RV_K_RADIX_SCATTER */, 2.0 * (8.0 + sizeof(V)) * (double)n);
         hipLaunchKernelGGL((k_rs_scatter<V>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, (const V *)vi, ko, vo, n, shift,
                            (const u32 *)bh, nb);
         RV_LAUNCH_CHECK();
+        ws.prof_end(pid);
         u64 *tk = ki; ki = ko; ko = tk;
         V *tv = vi; vi = vo; vo = tv;
         flip ^= 1;

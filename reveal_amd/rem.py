@@ -193,6 +193,55 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
     return G, idx, picker, aligner
 
 
+def align(aobjs, ref=None, minlength=20, minn=2, seedsize=None, threads=0, targetsample=None, maxsamples=None,
+          maxmums=10000, wpen=1, wscore=1, sa64=False, pcutoff=1e-8, gcmodel="sumofpairs", maxsize=None, trim=True, indexmod=None):
+    """reveal/rem.py:616-712 `align(aobjs, ...)` -> (G, idx): the alignment of sequences given as (name, sequence) tuples, as the
+    reference's refine step calls it for the sequences of a bubble (reveal/refine.py:220-229) and its test01 for two 17-mers
+    (reveal/tests/test_reveal.py:36-41).  One sample per tuple, upper-cased, empty sequences skipped; every sequence node hangs
+    between ONE start and ONE end sentinel (the reference's startnode / endnode), which are removed again before the graph is
+    returned, after prune_nodes (rem.py:706-710).  Same keyword arguments and defaults as the reference; `ref`, `threads`,
+    `targetsample`, `maxsamples` are accepted and, like there, not used by this path.
+    G is an alngraph.AlnGraph (number_of_nodes() / number_of_edges() as in networkx); idx the index, its T lower-cased where aligned."""
+    from . import alngraph, schemes
+    if indexmod is None:
+        from . import reveallib, reveallib64
+        indexmod = reveallib64 if sa64 else reveallib
+    idx = indexmod.index()
+    G = alngraph.AlnGraph()
+    import uuid
+    startnode, endnode = uuid.uuid4().hex, uuid.uuid4().hex
+    G.add_node(startnode, offsets={})
+    G.add_node(endnode, offsets={})
+    G.startnodes.append(startnode)
+    G.endnodes.append(endnode)
+    for aobj in aobjs:
+        if not isinstance(aobj, tuple):
+            continue                                  # (the reference only handles tuples here, rem.py:647-648)
+        name, seq = aobj
+        idx.addsample(name)
+        intv = tuple(idx.addsequence(seq.upper()))
+        if intv[1] - intv[0] > 0:
+            sid = alngraph._new_path(G, name, len(seq))
+            G.add_node(intv, offsets={sid: 0}, aligned=0)
+            G.offsets[startnode][sid] = 0
+            G.offsets[endnode][sid] = len(seq)
+            G.add_edge(startnode, intv, {sid})
+            G.add_edge(intv, endnode, {sid})
+    if len(G.paths) < 2:
+        raise ValueError("Specify at least 2 targets to construct alignment.")
+    args = schemes.PickerArgs(wscore=wscore, wpen=wpen, maxmums=maxmums, seedsize=seedsize if seedsize is not None else 10000, gcmodel=gcmodel,
+                              trim=trim, maxsize=maxsize, pcutoff=pcutoff)
+    picker, aligner = schemes.GraphPicker(G, args), GraphAligner(G)
+    idx.construct()
+    idx.align(picker.graphmumpicker, aligner.graphalign, threads=threads, wpen=wpen, wscore=wscore, minl=minlength, minn=minn)
+    G.prune_nodes(idx.T)
+    G.remove_node(startnode)
+    G.remove_node(endnode)
+    G.startnodes.remove(startnode)
+    G.endnodes.remove(endnode)
+    return G, idx
+
+
 def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None):
     """`reveal rem inputs -o output` (rem.py:449-509 align_cmd): align, merge equal siblings when more than two paths took part,
     write GFA1.  -> (graph, index, file name or None)"""

@@ -37,6 +37,29 @@ def test_multi_and_multicontig_with_the_reference_index(tmp_path, refmod):
     C.multi_fasta(tmp_path, refmod)
 
 
+def test_rem_align_entry_with_the_reference_index(refmod):
+    """rem.align(aobjs, ...) -> (G, idx) (reveal/rem.py:616-712) driven by the reference's own index: test01 of
+    reveal/tests/test_reveal.py:36-41, and the call shape of reveal/refine.py:220-229"""
+    from reveal_amd import rem
+    aobjs = [("1", "ACTTGCTAGCTAGTCAG"), ("2", "ACTAGCTAGCTAGTGAG")]
+    G, idx = rem.align(aobjs, minlength=1, indexmod=refmod)
+    assert G.number_of_nodes() > 2 and G.number_of_edges() > 2
+    for name, seq in aobjs:
+        assert G.spell_by_offsets(name, idx.T) == seq
+    import random
+    rng = random.Random(4)
+    base = "".join(rng.choice("ACGT") for _ in range(700))
+    var = list(base)
+    for p in rng.sample(range(700), 12):
+        var[p] = rng.choice("ACGT")
+    aobjs = [("p0", base), ("p1", "".join(var).lower()), ("p2", base[:300] + base[340:]), ("gap", "")]
+    G, idx = rem.align(aobjs, minlength=20, minn=2, seedsize=None, maxmums=1000, wpen=1, wscore=1, gcmodel="sumofpairs", sa64=False, indexmod=refmod)
+    assert G.paths == ["p0", "p1", "p2"]
+    for name, seq in aobjs[:3]:
+        assert G.spell_by_offsets(name, idx.T) == seq.upper()
+    assert sum(e - b for (b, e) in G.seq_nodes() if len(G.offsets[(b, e)]) == 3) > 400
+
+
 def test_sequential_plan_is_align_py():
     """reveal/align.py:30-54"""
     plan = align.sequential_plan(["g%d.fa" % i for i in range(100)], 5, output="out")

@@ -1867,7 +1867,9 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
     if (nsubs < 0 || m < 0 || m >= ((int64_t)1 << 32)) { rv_set_error("rv_frontier_import: bad sizes"); return -1; }
     const bool fresh = !(h->al && h->al->running);
     if (fresh) {
-        if (!h->constructed || h->main_arrays_freed) RV_TRY(rv_text_only(h, maxlcp));
+        // (a handle that already is a worker -- a share taken from the queue before -- keeps its text; only the bound on the LCP values travels)
+        if (h->text_only) h->maxlcp = maxlcp;
+        else if (!h->constructed || h->main_arrays_freed) RV_TRY(rv_text_only(h, maxlcp));
         const bool keep_trace = h->al && h->al->trace_on;
         if (!h->al) h->al = new Align();
         Align *a = h->al;

@@ -5,13 +5,17 @@ independent sub-indices popped by worker threads (reveallib/reveal.c:21-25,
 :731-1338): children of a split cover disjoint text and disjoint ranges of the
 shared inverse and are pushed after their parent's lower-casing (:1230-1234
 before :1296).  Here the workers are GPUs.  Rank 0 builds the index and runs the
-level loop until the frontier is wide enough, every rank (rank 0 included)
-receives a share of the sub-indices -- metadata plus their SA / LCP / BWT
-segments, 9 B per rank, point to point (RCCL send/recv over xGMI with the nccl
-backend, host memory with gloo) -- and finishes it with the same level loop on a
-handle that only holds the text.  Anchors are gathered on rank 0; their union is
-the anchor set of the undivided run (tests/test_gpu_handoff.py compares it, the
-per-sub-index trace and the lower-cased text with the oracle's).
+level loop until the frontier is wide enough; the frontier's sub-indices then
+form a QUEUE of batches that the ranks PULL from (the reference's pop_index /
+push_index with workers popping until the stack is empty, reveal.c:18-53,
+interface.c:338-386): an idle rank asks rank 0 for the next batch and gets its
+metadata plus the SA / LCP / BWT segments, 9 B per rank, point to point (RCCL
+send/recv over xGMI with the nccl backend, host memory with gloo), finishes it
+with the same level loop on a handle that only holds the text, and asks again;
+rank 0 serves the requests between batches of its own, taken from the small end
+of the queue.  Anchors are gathered on rank 0; their union is the anchor set of
+the undivided run (tests/test_gpu_handoff.py compares it, the per-sub-index
+trace and the lower-cased text with the oracle's).
 
 No collective on the data path.  What stays on one GPU (construct + the first
 levels) bounds the speed-up (Amdahl): at 2 x 250 Mbp the top of the recursion is
@@ -22,6 +26,7 @@ import heapq
 
 import numpy as np
 
+_CALLS = 0
 STAT_SUM = ("steps", "splits", "anchored_bp", "scanned_ranks")
 STAT_MAX = ("levels", "maxdepth", "t_scan", "t_host", "t_split", "t_bubble")
 
@@ -122,11 +127,41 @@ def balanced_frontier(idx, world, stop_subs, minl, minn, trace=False, tolerance=
     return 0, None, [np.zeros(0, np.int32)] * world
 
 
-def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False):
-    """Divide ONE alignment over the ranks of `group`.  Every rank passes an index that holds the same samples
+def make_batches(sizes, world, per_rank=4):
+    """the queue: sub-indices largest first, cut into batches of about total / (world * per_rank) ranks (a sub-index above that is a
+    batch of its own: it is the unit of work, whoever takes it splits it further).  -> list of int32 arrays, largest batch first"""
+    sizes = np.asarray(sizes, dtype=np.int64)
+    if len(sizes) == 0:
+        return []
+    target = max(int(sizes.sum()) // max(world * per_rank, 1), 1)
+    out, cur, load = [], [], 0
+    for s in np.argsort(-sizes, kind="stable"):
+        cur.append(int(s)); load += int(sizes[s])
+        if load >= target:
+            out.append(np.asarray(sorted(cur), dtype=np.int32)); cur, load = [], 0
+    if cur:
+        out.append(np.asarray(sorted(cur), dtype=np.int32))
+    return out
+
+
+def _send_batch(dist, group, dst, lib, head, meta_bytes, bufs, m, dev):
+    import torch
+    gdst = dist.get_global_rank(group, dst) if group is not None else dst
+    dist.send(torch.tensor(head, dtype=torch.int64, device=dev), dst=gdst, group=group)
+    if head[0] < 0:
+        return
+    dist.send(torch.frombuffer(bytearray(meta_bytes), dtype=torch.uint8).to(dev), dst=gdst, group=group)
+    if m:
+        for b in bufs:
+            dist.send(b, dst=gdst, group=group)
+
+
+def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False, per_rank=4):
+    """Divide ONE alignment over the ranks of `group` as a work queue.  Every rank passes an index that holds the same samples
     (addsample / addsequence done, construct not needed); rank 0's is constructed here.
-    -> on rank 0 the merged result (shape of index.align_builtin, plus 'shares' = ranks handed to each rank);
-       None on the other ranks."""
+    -> on rank 0 the merged result (shape of index.align_builtin, plus 'shares' = ranks each rank ended up finishing and
+       'batches' = how many batches it took); None on the other ranks."""
+    import pickle
     import torch
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -137,58 +172,103 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False)
         idx.construct()
         res = idx.align_builtin(minl, minn, trace=trace)
         res["shares"] = [int(idx.n)]
+        res["batches"] = [1]
         return res
-    shares = None
+
+    def sync_dev():
+        # RCCL's recv / send only order torch's current stream; the library copies on its own (non-blocking) stream
+        if on_dev:
+            torch.cuda.current_stream().synchronize()
+
+    results, taken, nb = [], 0, 0
+    global _CALLS
+    _CALLS += 1                                        # (every rank calls in the same order: the same number everywhere)
+    store = dist.distributed_c10d._get_default_store()
+    key = "reveal_amd/queue/%d/%d/%%d/%%d" % (dist.get_group_rank(group, 0) if group is not None else 0, _CALLS)
     if rank == 0:
         idx.construct()
-        left, fr, parts = balanced_frontier(idx, world, stop_subs or 4 * world, minl, minn, trace=trace)
+        left, fr, _ = balanced_frontier(idx, world, stop_subs or 4 * world, minl, minn, trace=trace, tolerance=1.5)
+        maxlcp = idx.maxlcp
+        batches, staged = [], None
         if left > 0:
-            heads = [dict(part=subset(fr, p), maxlcp=idx.maxlcp) for p in parts]
-        else:
-            heads = [dict(part=None, maxlcp=0)] * world
-        shares = [int(h["part"]["meta"][:, 1].sum()) if h["part"] is not None else 0 for h in heads]
+            batches = make_batches(fr["meta"][:, 1], world, per_rank)
+            # every segment leaves the level arrays now, in queue order: the owner's own batches replace its frontier later
+            order = np.concatenate(batches)
+            total = int(fr["meta"][order, 1].sum())
+            staged = _buffers(lib, total, dev)
+            idx.frontier_pack(order, *staged)          # (synchronous: the copies have finished when it returns)
+        first = [0]
+        for b in batches:
+            first.append(first[-1] + int(fr["meta"][b, 1].sum()))
+        # requests: a key per worker and request in the process group's store (gloo's irecv does not report completion to a poll,
+        # and a blocking receive would keep rank 0 from its own batches); the data itself travels point to point
+        reqs = {w: 0 for w in range(1, world)}          # worker -> number of its next request
+        lo, hi = 0, len(batches)                       # the queue: batches[lo:hi]; workers take from the large end (lo), rank 0 from the small one
+        shares = [0] * world
+        counts = [0] * world
+
+        def hand_out(w, k):
+            part = subset(fr, batches[k])
+            m = first[k + 1] - first[k]
+            bufs = tuple(b[first[k]:first[k + 1]] for b in staged)
+            meta = pickle.dumps(part, protocol=4)
+            _send_batch(dist, group, w, lib, [len(batches[k]), m, len(meta), maxlcp], meta, bufs, m, dev)
+            shares[w] += m; counts[w] += 1
+
+        while reqs or lo < hi:
+            served = False
+            for w in list(reqs):
+                if store.check([key % (w, reqs[w])]):
+                    served = True
+                    reqs[w] += 1
+                    if lo < hi:
+                        hand_out(w, lo); lo += 1
+                    else:
+                        _send_batch(dist, group, w, lib, [-1, 0, 0, 0], b"", (), 0, dev)
+                        del reqs[w]
+            if lo < hi and not served:                 # nobody is waiting: a batch for rank 0 itself, from the small end
+                hi -= 1
+                k = hi
+                part = subset(fr, batches[k])
+                bufs = tuple(b[first[k]:first[k + 1]] for b in staged)
+                idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
+                results.append(idx.align_builtin_resume())
+                shares[0] += first[k + 1] - first[k]; counts[0] += 1
+        if not results:
+            # rank 0 took no batch (the run finished before it was wide enough to divide, or the workers emptied the queue): its
+            # anchors of the levels in front of the hand-off are collected by finishing an empty frontier
+            if left > 0:
+                idx.frontier_import(subset(fr, np.zeros(0, np.int32)), *_buffers(lib, 0, dev), minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
+            results.append(idx.align_builtin_resume())
     else:
-        heads = None
-    got = [None]
-    dist.scatter_object_list(got, heads, src=0, group=group)
-    head = got[0]
-    part = head["part"]
-    m = int(part["meta"][:, 1].sum()) if part is not None else 0
-    if rank == 0:
-        # the segments leave point to point; rank 0's own share is packed last (the others start while it is busy)
-        pending = []
-        for dst in range(1, world):
-            if len(parts[dst]) == 0:
-                continue
-            bufs = _buffers(lib, shares[dst], dev)
-            idx.frontier_pack(parts[dst], *bufs)
-            for b in bufs:
-                pending.append((dist.isend(b[:shares[dst]], dst=dist.get_global_rank(group, dst) if group is not None else dst, group=group), b))
-        if left > 0:      # (otherwise the run finished before it was wide enough to divide: nothing to hand out)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        while True:
+            store.set(key % (rank, nb), "1")
+            head = torch.zeros(4, dtype=torch.int64, device=dev)
+            dist.recv(head, src=src, group=group)
+            nsubs, m, nmeta, maxlcp = (int(x) for x in head.tolist())
+            if nsubs < 0:
+                break
+            mt = torch.empty(nmeta, dtype=torch.uint8, device=dev)
+            dist.recv(mt, src=src, group=group)
+            part = pickle.loads(mt.cpu().numpy().tobytes())
             bufs = _buffers(lib, m, dev)
             if m:
-                idx.frontier_pack(parts[0], *bufs)
-            idx.frontier_import(part, *bufs, minl=minl, minn=minn)
-        res = idx.align_builtin_resume()
-        for w, _ in pending:
-            w.wait()
-    else:
-        res = empty_result(trace)
-        if m:
-            bufs = _buffers(lib, m, dev)
-            src = dist.get_global_rank(group, 0) if group is not None else 0
-            for b in bufs:
-                dist.recv(b[:m], src=src, group=group)
-            if on_dev:
-                # RCCL's recv only orders torch's current stream behind the transfer; the library copies from these buffers on
-                # its own (non-blocking) stream, so the host has to see the transfers finished first
-                torch.cuda.current_stream().synchronize()
-            idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=head["maxlcp"], trace=trace)
-            res = idx.align_builtin_resume()
+                for b in bufs:
+                    dist.recv(b[:m], src=src, group=group)
+            sync_dev()
+            idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
+            results.append(idx.align_builtin_resume())
+            taken += m; nb += 1
+        if not results:
+            results.append(empty_result(trace))
+    # the owner's anchors of the levels in front of the hand-off ride in its first resume(): a handle with a run in progress keeps them
+    mine = merge(results) if len(results) > 1 else results[0]
     out = [None] * world if rank == 0 else None
-    dist.gather_object(res, out, dst=0, group=group)
+    dist.gather_object(mine, out, dst=0, group=group)
     if rank != 0:
         return None
     merged = merge(out)
     merged["shares"] = shares
+    merged["batches"] = counts
     return merged

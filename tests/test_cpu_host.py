@@ -11,7 +11,7 @@ import numpy as np
 import pytest
 
 from helpers import ROOT, assemble, fa, synth
-from reveal_amd import rem
+from reveal_amd import rem, shard
 
 
 def test_abi_exports_every_declared_symbol():
@@ -154,9 +154,12 @@ class FakeIndex:
     def frontier_import(self, part, sa, lcp, bwt, minl=20, minn=2, maxlcp=None, trace=False):
         assert rank == 0 or (maxlcp == 77 and not self.constructed)
         self.front = (part, sa.numpy().copy(), lcp.numpy().copy(), bwt.numpy().copy())
+    def align_builtin_continue(self, stop):
+        return len(self.sizes)
     def align_builtin_resume(self):
         part, sa, lcp, bwt = self.front
         at = 0
+        import time; time.sleep(0.02 * len(part["meta"]))      # (a batch takes a while: the other ranks get to ask meanwhile)
         for k in range(len(part["meta"])):
             n = int(part["meta"][k, 1])
             assert (lcp[at:at + n] == 7).all() and (bwt[at:at + n] == 65).all()
@@ -165,27 +168,32 @@ class FakeIndex:
             at += n
         l = np.array([d[0] for d in self.done], np.uint32); pos = np.array([p for d in self.done for p in d[1]], np.int64)
         st = shard.empty_result()["stats"]; st["splits"] = len(self.done)
+        self.done = []                                  # (a later import starts a new run on this handle)
         return dict(stats=st, anchors=(l, np.arange(0, 2 * len(l) + 1, 2), pos), trace=None)
 
 import torch
-res = shard.align_sharded(FakeIndex(), 20, 2, stop_subs=4)
+res = shard.align_sharded(FakeIndex(), 20, 2, stop_subs=4, per_rank=2)
 if rank == 0:
     l, off, pos = res["anchors"]
-    print(json.dumps({"anchors": sorted((int(l[k]), [int(x) for x in pos[off[k]:off[k + 1]]]) for k in range(len(l))), "shares": res["shares"], "splits": res["stats"]["splits"]}))
+    print(json.dumps({"anchors": sorted((int(l[k]), [int(x) for x in pos[off[k]:off[k + 1]]]) for k in range(len(l))), "shares": res["shares"], "batches": res["batches"], "splits": res["stats"]["splits"]}))
 else:
     assert res is None
 dist.barrier(); dist.destroy_process_group()
 '''
 
 
-def test_divided_alignment_protocol_gloo(tmp_path):
-    """shard.align_sharded on two ranks (gloo, host memory) around a stand-in index: every sub-index of the frontier reaches
-    exactly one rank with its own segments and metadata, and rank 0 ends up with all anchors"""
+@pytest.mark.parametrize("world", [2, 3])
+def test_divided_alignment_protocol_gloo(tmp_path, world):
+    """shard.align_sharded on two and three ranks (gloo, host memory) around a stand-in index: the frontier becomes a queue of
+    batches the ranks pull from -- every sub-index reaches exactly one rank with its own segments and metadata, uneven sizes
+    end up on different ranks, rank 0 serves between batches of its own and ends up with all anchors (also the one made in
+    front of the hand-off)"""
     script = tmp_path / "shard_worker.py"
     script.write_text(SHARD_WORKER % ROOT)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29519")
-    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                          "--master-port", "29519", str(script)], capture_output=True, text=True, env=env, timeout=300)
+    port = str(29519 + world)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % world, "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
     sizes = [5, 100, 7, 40, 40, 1, 60]
@@ -193,7 +201,19 @@ def test_divided_alignment_protocol_gloo(tmp_path):
     off = np.concatenate([[0], np.cumsum(sizes)[:-1]])
     want = sorted([(9, [0, 500])] + [(n, [int(SA[o:o + n].sum()), int(o)]) for o, n in zip(off, sizes)])
     assert [tuple(a) for a in r["anchors"]] == [(l, p) for l, p in want]
-    assert sorted(r["shares"]) == [113, 140] and r["splits"] == 8      # (LPT, not optimal: 100+40 | 60+40+7+5+1)
+    assert r["splits"] == 8 and sum(r["shares"]) == sum(sizes) and len(r["shares"]) == world
+    # the queue: batches of about total / (world * 2) ranks, largest first
+    nbatches = len(shard.make_batches(sizes, world, 2))
+    assert sum(r["batches"]) == nbatches and nbatches >= world
+    assert sum(1 for x in r["shares"] if x > 0) >= 2                      # more than one rank took part
+
+
+def test_queue_batches():
+    sizes = [5, 100, 7, 40, 40, 1, 60]
+    b = shard.make_batches(sizes, 3, 2)
+    assert sorted(int(x) for p in b for x in p) == list(range(7))
+    assert [int(np.asarray(sizes)[p].sum()) for p in b] == [100, 60, 80, 13]      # target 253 // 6 = 42: 100 | 60 | 40 + 40 | the rest
+    assert shard.make_batches([], 4) == [] and len(shard.make_batches([9], 4)) == 1
 
 
 def test_bench_gpus_flag_spawns_the_ranks():

@@ -394,7 +394,10 @@ def main():
             out["divide"] = {"value": float(bases) * args.steps / dt / 1e6, "unit": "Mbp/s", "ms_per_step": dt / args.steps * 1e3, "scaling": "strong",
                              "what": "ONE alignment (rank 0's input) divided over the %d ranks in the same invocation: rank 0 constructs and runs the top "
                                      "levels, the ranks pull batches of the frontier's sub-indices from it, no collective" % world,
-                             "ranks_per_share": dl.get("shares"), "speedup_vs_rank0_alone": (tmax / args.steps) / (dt / args.steps)}
+                             "ranks_per_share": dl.get("shares"), "batches_per_rank": dl.get("batches"),
+                             "speedup_vs_rank0_alone": (tmax / args.steps) / (dt / args.steps),
+                             "note": None if any(dl.get("shares") or [0]) else "nothing was handed out: the anchor cascade finished this two-sample run on rank 0 "
+                                     "before there was a frontier to divide (rv_align_builtin_until); inputs with more than two samples are divided"}
         if world == 1 and not args.no_cpu:
             # CPU legs and bit-exact parity on a stated sample: 2 x 20 Mbp (or the workload itself when it is not larger)
             cl = min(args.L, CPU_SAMPLE_L)

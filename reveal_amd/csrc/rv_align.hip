@@ -1718,6 +1718,7 @@ int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
  * undivided run; the lower-cased text follows from the anchors.  No collective: segments travel point to point. */
 int rv_align_builtin_until(rv_index *h, int minl, int minn, int stop_subs, rv_align_stats *out) {
     RV_TRY(builtin_setup(h, minl, minn));
+    RV_TRY(builtin_cascade(h));      // (a two-sample run the cascade decides is finished before there is a frontier to hand out: returns 0)
     RV_TRY(builtin_levels(h, stop_subs));
     Align *a = h->al;
     if (a->lv.size() == 0) { RV_TRY(builtin_finish(h, out)); return 0; }

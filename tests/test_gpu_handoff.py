@@ -13,6 +13,14 @@ from test_gpu_align import FIELDS, mod, oracle_run
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def level_pipeline_only(monkeypatch, request):
+    """the hand-off divides the level pipeline's frontier; an untraced two-sample run would be finished by the anchor cascade
+    before there is one (rv_align_builtin_until returns 0 then: test_cascade_leaves_nothing_to_divide)"""
+    if "cascade" not in request.node.name:
+        monkeypatch.setenv("RV_NO_CASCADE", "1")
+
+
 def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, device_buffers=False):
     M = mod(sa64)
     owner = feed(M.index(), inputs)
@@ -216,3 +224,22 @@ def test_widened_frontier_divides_evenly():
         assert got["stats"][k] == ref["stats"][k], k
     # continue on a finished / never-started run is a no-op
     assert one.align_builtin_continue(8) == 0
+
+
+def test_cascade_leaves_nothing_to_divide():
+    """an untraced two-sample run the anchor cascade decides: align_builtin_until finishes it (frontier size 0), the result is the
+    undivided one -- what shard.align_sharded then does is gather that result"""
+    seqs = [g.decode() for g in synth.genomes(300000, 2, seed=5)]
+    M = mod(False)
+    one = feed(M.index(), seqs)
+    one.construct()
+    ref = one.align_builtin(20, 2)
+    idx = feed(M.index(), seqs)
+    idx.construct()
+    assert idx.align_builtin_until(4, 20, 2) == 0 and idx.cascade_info()["done"]
+    got = idx.align_builtin_resume()
+
+    def aset(r):
+        l, off, pos = r["anchors"]
+        return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+    assert aset(got) == aset(ref) and got["stats"]["steps"] == ref["stats"]["steps"]

@@ -20,3 +20,5 @@ cd $R
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write k_scan_pair "2x250000000-32" > $OUT/pmc_scan_c4.json
 python tools/pmc_all.py $OUT/pmc_fetch $OUT/pmc_write 40 > $OUT/pmc_traffic_c4.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
+python bench.py --sa64 --L 1100000000 --steps 3 --warmup 1 --no-cpu > $OUT/bench_sa64_2x1100M.json 2> $OUT/bench_sa64_2x1100M.err
+RV_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --L 60000000 --steps 2 --warmup 1 --no-cpu > $OUT/bench_2ranks_shared_gpu.json 2> $OUT/bench_2ranks_shared_gpu.err

@@ -83,6 +83,7 @@ def anchors_set(a):
 
 def divided(M, seqs, minl, stop, nparts, trace):
     """one alignment over `nparts` handles (frontier hand-off, reveal_amd/shard.py), in this process"""
+    os.environ["RV_NO_CASCADE"] = "1"      # (the cascade would finish a two-sample run before there is a frontier to divide)
     owner = feed(M.index(), seqs)
     owner.construct()
     lib = owner._lib

@@ -1672,10 +1672,38 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
 // The anchor cascade (rv_cascade.hip) in front of the level pipeline: an untraced two-sample run with one sequence per sample
 // is decided from the top-level match list wherever that is provably the reference's result; what is left undecided is rebuilt
 // from its text and finished by the leaf kernel.  It either does the whole run or leaves no trace (RV_NO_CASCADE=1: never tried).
+static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *meta, const int64_t *node_first, const int64_t *nodes, int64_t m,
+                            const void *sa, const void *lcp, const void *bwt, int on_device);
 static int builtin_cascade(rv_index *h) {
     Align *a = h->al;
     memset(&a->cas_out, 0, sizeof a->cas_out);
-    if (a->multi || a->trace_on || !a->use_leaf || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || getenv("RV_NO_CASCADE")) return 0;
+    if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || getenv("RV_NO_CASCADE")) return 0;
+    if (a->multi) {
+        // more than two samples: the decided part's anchors come back on the host, what is undecided becomes the frontier of the level pipeline
+        RvCascadeMultiOut mo;
+        RV_TRY(rv_cascade_multi_run(h, a->cas, a->minl, &mo));
+        a->cas_out.done = mo.done; a->cas_out.levels = mo.levels; a->cas_out.cands = mo.cands; a->cas_out.witnesses = mo.witnesses; a->cas_out.children = mo.children;
+        a->cas_out.undecided = mo.undecided; a->cas_out.rebuilt_ranks = mo.rebuilt_ranks; a->cas_out.why = mo.why;
+        if (!mo.done) return 0;
+        const int k = h->nsamples;
+        for (size_t x = 0; x < mo.an_l.size(); x++) {
+            a->an_l.push_back(mo.an_l[x]);
+            a->an_pos.insert(a->an_pos.end(), mo.an_pos.begin() + (int64_t)x * k, mo.an_pos.begin() + (int64_t)(x + 1) * k);
+            a->an_off.push_back((int64_t)a->an_pos.size());
+            a->st.anchored_bp += mo.an_l[x];
+        }
+        a->st.splits += (int64_t)mo.an_l.size(); a->st.steps += mo.steps; a->st.levels += mo.levels; a->st.scanned_ranks += h->n;
+        if (mo.maxdepth > a->st.maxdepth) a->st.maxdepth = mo.maxdepth;
+        h->main_arrays_freed = true;
+        if (mo.undecided > 0) {
+            RV_TRY(install_frontier(h, 1, (int)mo.undecided, mo.meta.data(), mo.node_first.data(), mo.nodes.data(), mo.rebuilt_ranks, mo.d_sa, mo.d_lcp, mo.d_bwt, 1));
+        } else {
+            a->lv.clear();
+            a->level = 1;
+        }
+        return 0;
+    }
+    if (!a->use_leaf) return 0;
     RvCascadeIO io;
     io.anchor_count = a->lf_counters; io.anchor_cap = (u32)a->leaf_anchor_cap; io.anchor_l = a->lf_l; io.anchor_pos = a->lf_pos;
     io.stats = a->lf_stats; io.leaf_err = a->lf_counters + 2;

@@ -1,6 +1,7 @@
 // rv_cascade.h -- host interface of the anchor cascade (rv_cascade.hip)
 #pragma once
 #include "rv_common.h"
+#include <vector>
 
 // device scratch of the cascade, kept between runs (grow-only like every other buffer of a handle)
 struct RvCascadeBufs {
@@ -25,5 +26,16 @@ struct RvCascadeOut {
     const char *why;                   // done == false: the reason
 };
 
+// more than two samples (rv_cascade_multi.hip): the decided part's anchors come back on the host (the level pipeline keeps its anchors
+// there), the undecided sub-indices as a frontier for it -- metadata in the layout of rv_frontier_import, arrays in device memory
+#define RV_CASM_K 16
+struct RvCascadeMultiOut {
+    bool done; int levels; int64_t cands, witnesses, children, undecided, rebuilt_ranks, steps; int maxdepth; const char *why;
+    std::vector<u32> an_l; std::vector<int64_t> an_pos;                      // k members per anchor, ascending
+    std::vector<int64_t> meta, node_first, nodes;                           // undecided sub-indices: 6 numbers each; intervals as (begin, end) pairs
+    const void *d_sa, *d_lcp, *d_bwt;
+};
+
 struct rv_index;
+int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl, RvCascadeMultiOut *out);
 int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl, RvCascadeOut *out);

@@ -1,0 +1,686 @@
+// rv_cascade_multi.hip -- the anchor cascade for more than two samples (one sequence each).
+//
+// The benchmark picker only takes matches present in EVERY sample of the sub-index (schemes.py:227; reveal.c:436-580
+// getmultimums + :227-259 ismultimum).  For a descendant C of the root X that still holds all k samples:
+//   * R[p] = the longest prefix suffix p shares with another suffix of ITS OWN sample (a repeat inside one genome);
+//   * a full match of C (k suffixes, one per sample) longer than Rmax(C) = max R over C's positions is an LCP interval of
+//     X with exactly those k members -- an extra member would belong to one of the k samples and raise that member's R --,
+//     i.e. a full match of X cut to C (shifted to start behind the matched text in front of C on every sample, capped at
+//     C's ends), and every such cut match longer than Rmax(C) is a full match of C.
+// So C's choice (longest, ties to the smallest coordinate) is known from X's list of full matches whenever its best cut
+// match is longer than Rmax(C); C has no match when it has no cut match of minl characters and Rmax(C) < minl, or when
+// one of its intervals is shorter than minl.  A sub-index that lacks a sample (the picker then wants matches of the
+// remaining ones), or whose best match is no longer than its repeats, is left undecided: rebuilt from the text of its
+// intervals (at most 8192 suffixes) and handed to the level pipeline (rv_align.hip) as its frontier.  A larger
+// undecided sub-index makes the cascade give up before anything is kept.
+//
+// tools/cascade_proto_multi.py is this algorithm on the CPU beside the oracle's literal recursion (1 994 random inputs
+// with two to four samples: identical); tests/test_gpu_cascade.py and tools/fuzz.py run this file against the oracle.
+// Kernels as in rv_cascade.hip, with k coordinates per match and k intervals per sub-index.
+#include "rv_index.h"
+#include "rv_cascade.h"
+#include "rv_leaf.h"
+#include <algorithm>
+#include <string.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TB = 256;
+constexpr u32 NONE = 0xFFFFFFFFu;
+#ifdef RV_SA64
+constexpr int KEY_SHIFT = 40;
+#else
+constexpr int KEY_SHIFT = 32;
+#endif
+constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NCAND = 8, C_NANCH = 9, C_STEPS = 10, C_MAXDEPTH = 11 };
+
+__device__ inline int cm_sample(const sa_t *__restrict__ nsep, int k, sa_t pos) {      // number of separators in front of pos (interface.c:116-134)
+    int s = 0;
+    for (int q = 0; q < k - 1; q++) s += nsep[q] < pos ? 1 : 0;
+    return s;
+}
+__device__ inline u64 shfl_up64m(u64 v, int d) {
+    const u32 lo = __shfl_up((u32)v, d, 64), hi = __shfl_up((u32)(v >> 32), d, 64);
+    return ((u64)hi << 32) | lo;
+}
+__device__ inline void seg_max64(u64 *__restrict__ dst, u32 child, u64 val, bool active) {
+    const int lane = threadIdx.x & 63;
+    if (!active) { child = NONE; val = 0; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u64 ov = shfl_up64m(val, d);
+        const u32 oc = __shfl_up(child, d, 64);
+        if (lane >= d && oc == child && ov > val) val = ov;
+    }
+    const u32 nc = __shfl_down(child, 1, 64);
+    const bool last = lane == 63 || nc != child;
+    if (active && last && val > dst[child]) atomicMax((unsigned long long *)&dst[child], (unsigned long long)val);
+}
+__device__ inline void seg_max32(u32 *__restrict__ dst, u32 child, u32 val, bool active) {
+    const int lane = threadIdx.x & 63;
+    if (!active) { child = NONE; val = 0; }
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 ov = __shfl_up(val, d, 64);
+        const u32 oc = __shfl_up(child, d, 64);
+        if (lane >= d && oc == child && ov > val) val = ov;
+    }
+    const u32 nc = __shfl_down(child, 1, 64);
+    const bool last = lane == 63 || nc != child;
+    if (active && last && val > dst[child]) atomicMax(&dst[child], val);
+}
+
+// sample of every rank's suffix (one byte: the walks below read it many times)
+__global__ __launch_bounds__(TB) void k_casm_so(const sa_t *__restrict__ SA, int64_t n, const sa_t *__restrict__ nsep, int k, uint8_t *__restrict__ so) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j < n) so[j] = (uint8_t)cm_sample(nsep, k, SA[j]);
+}
+
+// full matches of the root: the LCP interval of exactly k ranks that ends at rank u (reveal.c:436-580 for n == nsamples)
+__global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, const uint8_t *__restrict__ so,
+                                                  int64_t n, int k, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap, u32 *__restrict__ counters) {
+    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool ok = false;
+    u32 v = 0;
+    const int64_t lb = u - (k - 1);
+    if (u < n && lb >= 0) {
+        v = (u32)LCP[u];
+        const u32 nxt = u + 1 < n ? (u32)LCP[u + 1] : 0u;
+        ok = v >= minl && v > nxt;
+        for (int64_t j = lb + 1; j < u && ok; j++) { const u32 x = (u32)LCP[j]; v = x < v ? x : v; ok = v >= minl && v > nxt; }
+        ok = ok && (u32)LCP[lb] < v;
+        if (ok) {
+            u32 seen = 0;
+            for (int64_t j = lb; j <= u && ok; j++) { const u32 bit = 1u << so[j]; ok = !(seen & bit); seen |= bit; }
+        }
+        if (ok) {      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
+            bool mx = false;
+            for (int64_t j = lb; j < u && !mx; j++) {
+                const uint8_t ca = BWT[j] & RV_BWT_CHAR, cb = BWT[j + 1] & RV_BWT_CHAR;
+                mx = cb == '$' || ca != cb || ca == 'N' || ca == '$' || (ca >= 'a' && ca <= 'z');
+            }
+            ok = mx;
+        }
+    }
+    const u64 bal = __ballot(ok);
+    if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&counters[C_NCAND], (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (ok) {
+            const u32 o = base + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            if (o < cap) {
+                c_len[o] = v;
+                for (int64_t j = lb; j <= u; j++) c_pos[(size_t)o * k + so[j]] = SA[j];
+            }
+        }
+    }
+}
+
+// R: a suffix' longest common prefix with another suffix of its own sample, where it reaches minl -- the nearest such suffix
+// above and below in the array, the range minimum of LCP in between; a walk that does not find one within WALK ranks keeps
+// the running minimum (an upper bound)
+constexpr int WALK = 256;
+__global__ __launch_bounds__(TB) void k_casm_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ so, int64_t n, u32 minl,
+                                                     sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap, u32 *__restrict__ counters) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    u32 r = 0;
+    if (j < n) {
+        const uint8_t s = so[j];
+        u32 mn = 0xFFFFFFFFu;
+        for (int64_t i = j, st = 0; i > 0 && st < WALK; st++) {          // upwards: lcp(rank i-1, rank j) = min LCP[i..j]
+            const u32 x = (u32)LCP[i];
+            mn = x < mn ? x : mn;
+            if (mn < minl) { mn = 0; break; }
+            i--;
+            if (so[i] == s) break;
+            if (i == 0 || st + 1 == WALK) { if (i == 0) mn = 0; break; }
+        }
+        if (mn != 0xFFFFFFFFu && mn >= minl) r = mn;
+        mn = 0xFFFFFFFFu;
+        for (int64_t i = j + 1, st = 0; i < n && st < WALK; i++, st++) {  // downwards: lcp(rank j, rank i) = min LCP[j+1..i]
+            const u32 x = (u32)LCP[i];
+            mn = x < mn ? x : mn;
+            if (mn < minl) { mn = 0; break; }
+            if (so[i] == s) break;
+            if (i + 1 == n) { mn = 0; break; }
+        }
+        if (mn != 0xFFFFFFFFu && mn >= minl && mn > r) r = mn;
+    }
+    const bool hit = r >= minl && r > 0;
+    const u64 bal = __ballot(hit);
+    if (bal) {
+        u32 base = 0;
+        if (lane == 0) base = atomicAdd(&counters[C_NWIT], (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (hit) {
+            const u32 o = base + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+            if (o < cap) { w_pos[o] = SA[j]; w_val[o] = r; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_casm_keys(const sa_t *__restrict__ c_pos, int k, u32 M, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) { keys[i] = (u64)c_pos[(size_t)i * k]; vals[i] = i; }
+}
+__global__ __launch_bounds__(TB) void k_casm_gather(const u32 *__restrict__ len_in, const sa_t *__restrict__ pos_in, const u32 *__restrict__ perm, int k, u32 M,
+                                                    u32 *__restrict__ len_out, sa_t *__restrict__ pos_out, u32 *__restrict__ c_child) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= M) return;
+    const u32 src = perm[i];
+    len_out[i] = len_in[src]; c_child[i] = 0u;
+    for (int s = 0; s < k; s++) pos_out[(size_t)i * k + s] = pos_in[(size_t)src * k + s];
+}
+
+struct CmTabs {      // per sub-index: k intervals, its best bid, Rmax, depth, state (0 open, 1 split, 2 ended), children, the chosen match
+    sa_t *b, *e; u64 *best; u32 *rmax; int32_t *depth; u32 *state, *lead, *trail; sa_t *q; u32 *ql;
+};
+__global__ void k_casm_init(CmTabs t, int k, const sa_t *__restrict__ root_b, const sa_t *__restrict__ root_e, u32 *__restrict__ counters, u32 *__restrict__ w_child, u32 nw) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        for (int s = 0; s < k; s++) { t.b[s] = root_b[s]; t.e[s] = root_e[s]; }
+        t.best[0] = 0; t.rmax[0] = 0; t.depth[0] = 0; t.state[0] = 0; t.lead[0] = NONE; t.trail[0] = NONE; t.ql[0] = 0;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0;
+        counters[C_NANCH] = 0; counters[C_STEPS] = 0; counters[C_MAXDEPTH] = 0;
+    }
+    if (i < nw) w_child[i] = 0u;
+}
+
+// the match cut to the intervals [B_s, E_s): -> its length (< minl: not there), *sh = how far its start moves
+__device__ inline int64_t cm_cut(const sa_t *__restrict__ p, int k, const sa_t *B, const sa_t *E, int64_t len, int64_t *sh) {
+    int64_t k0 = 0;
+    for (int s = 0; s < k; s++) { const int64_t d = (int64_t)B[s] - (int64_t)p[s]; k0 = d > k0 ? d : k0; }
+    int64_t l = len - k0;
+    for (int s = 0; s < k; s++) { const int64_t r = (int64_t)E[s] - ((int64_t)p[s] + k0); l = r < l ? r : l; }
+    *sh = k0;
+    return l;
+}
+
+__global__ __launch_bounds__(TB) void k_casm_assign(const sa_t *__restrict__ c_pos, const u32 *__restrict__ c_len, u32 *__restrict__ c_child, u32 M,
+                                                    const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
+                                                    CmTabs t, int k, const sa_t *__restrict__ nsep, int64_t minl, int first) {
+    const u32 tid = blockIdx.x * TB + threadIdx.x;
+    const u32 mblocks = (M + TB - 1) / TB;
+    if (blockIdx.x < mblocks) {
+        const u32 i = tid;
+        u32 c = i < M ? c_child[i] : NONE;
+        bool live = c != NONE;
+        u64 key = 0;
+        if (live) {
+            const sa_t *p = c_pos + (size_t)i * k;
+            const int64_t len = (int64_t)c_len[i];
+            int64_t sh = 0, l = -1;
+            if (!first) {
+                u32 nc = NONE;
+                if (t.state[c] == 1u) {
+                    const sa_t *pb = t.b + (size_t)c * k, *pe = t.e + (size_t)c * k, *q = t.q + (size_t)c * k;
+                    const int64_t L = (int64_t)t.ql[c];
+                    sa_t B[RV_CASM_K], E[RV_CASM_K];
+                    if (t.lead[c] != NONE) {
+                        for (int s = 0; s < k; s++) { B[s] = pb[s]; E[s] = q[s]; }
+                        l = cm_cut(p, k, B, E, len, &sh);
+                        if (l >= minl) nc = t.lead[c];
+                    }
+                    if (nc == NONE && t.trail[c] != NONE) {
+                        for (int s = 0; s < k; s++) { B[s] = (sa_t)((int64_t)q[s] + L); E[s] = pe[s]; }
+                        l = cm_cut(p, k, B, E, len, &sh);
+                        if (l >= minl) nc = t.trail[c];
+                    }
+                }
+                c = nc;
+                c_child[i] = c;
+                live = c != NONE;
+            } else {
+                l = cm_cut(p, k, t.b + (size_t)c * k, t.e + (size_t)c * k, len, &sh);
+                live = l >= minl;
+                if (!live) { c = NONE; c_child[i] = NONE; }
+            }
+            if (live) key = ((u64)l << KEY_SHIFT) | (KEY_LOW - (u64)((int64_t)p[0] + sh));
+        }
+        seg_max64(t.best, c, key, live);
+    } else {
+        const u32 i = tid - mblocks * TB;
+        u32 c = i < NW ? w_child[i] : NONE;
+        bool live = c != NONE;
+        u32 v = 0;
+        if (live) {
+            const sa_t pos = w_pos[i];
+            v = w_val[i];
+            const int s = cm_sample(nsep, k, pos);
+            if (!first) {
+                u32 nc = NONE;
+                if (t.state[c] == 1u) {
+                    const int64_t b = t.b[(size_t)c * k + s], e = t.e[(size_t)c * k + s], q = t.q[(size_t)c * k + s], L = t.ql[c];
+                    if ((int64_t)pos >= b && (int64_t)pos < q) nc = t.lead[c];
+                    else if ((int64_t)pos >= q + L && (int64_t)pos < e) nc = t.trail[c];
+                }
+                c = nc;
+                w_child[i] = c;
+                live = c != NONE;
+            } else {
+                live = pos >= t.b[(size_t)c * k + s] && pos < t.e[(size_t)c * k + s];
+                if (!live) { c = NONE; w_child[i] = NONE; }
+            }
+        }
+        seg_max32(t.rmax, c, v, live);
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_casm_winner(const sa_t *__restrict__ c_pos, const u32 *__restrict__ c_len, const u32 *__restrict__ c_child, u32 M, CmTabs t, int k, int64_t minl) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= M) return;
+    const u32 c = c_child[i];
+    if (c == NONE) return;
+    const sa_t *p = c_pos + (size_t)i * k;
+    int64_t sh;
+    const int64_t l = cm_cut(p, k, t.b + (size_t)c * k, t.e + (size_t)c * k, (int64_t)c_len[i], &sh);
+    if (l < minl) return;
+    if ((((u64)l << KEY_SHIFT) | (KEY_LOW - (u64)((int64_t)p[0] + sh))) == t.best[c]) {
+        for (int s = 0; s < k; s++) t.q[(size_t)c * k + s] = (sa_t)((int64_t)p[s] + sh);
+        t.ql[c] = (u32)l;
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u32 *__restrict__ counters, u32 child_cap, u32 *__restrict__ und_list, u32 leaf_n,
+                                                    u32 *__restrict__ an_l, sa_t *__restrict__ an_pos, u32 an_cap) {
+    __shared__ u32 s_cnt[TB / 64][3];
+    __shared__ u32 s_base[3];
+    const u32 lo = counters[C_LO], hi = counters[C_HI];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (u32 first = lo + blockIdx.x * TB; first < hi; first += gridDim.x * TB) {
+        const u32 id = first + threadIdx.x;
+        const bool in = id < hi;
+        int64_t total = 0, mn = (int64_t)1 << 62, nlong = 0; int empty = 0;
+        int64_t nlead = 0, ntrail = 0;
+        u32 bl = 0, rm = 0, L = 0; int32_t dp = 0;
+        if (in) {
+            bl = (u32)(t.best[id] >> KEY_SHIFT); rm = t.rmax[id]; dp = t.depth[id]; L = t.ql[id];
+            for (int s = 0; s < k; s++) {
+                const int64_t len = (int64_t)t.e[(size_t)id * k + s] - (int64_t)t.b[(size_t)id * k + s];
+                total += len; mn = len < mn ? len : mn; empty += len <= 0; nlong += len >= (int64_t)minl;
+            }
+        }
+        // every sample present and room for a match in each: decided from the list; a missing sample changes what the picker wants
+        const bool lacking = in && empty > 0;
+        const bool can = in && !lacking && mn >= (int64_t)minl;
+        const bool split = can && bl >= minl && bl > rm;
+        const bool und = (can && !split && rm >= minl) || (lacking && nlong >= 2);
+        if (split) {
+            if (L != bl) atomicOr(&counters[C_ERR], 2u);
+            for (int s = 0; s < k; s++) {
+                const int64_t q = t.q[(size_t)id * k + s];
+                nlead += q - (int64_t)t.b[(size_t)id * k + s];
+                ntrail += (int64_t)t.e[(size_t)id * k + s] - q - L;
+            }
+        }
+        const bool lead = split && nlead > 0, trail = split && ntrail > 0;
+        const u64 b_lead = __ballot(lead), b_trail = __ballot(trail), b_split = __ballot(split), b_und = __ballot(und);
+        if (lane == 0) { s_cnt[w][0] = (u32)__popcll(b_lead) + (u32)__popcll(b_trail); s_cnt[w][1] = (u32)__popcll(b_split); s_cnt[w][2] = (u32)__popcll(b_und); }
+        __syncthreads();
+        if (threadIdx.x < 3) {
+            u32 tot = 0;
+            for (int q = 0; q < TB / 64; q++) tot += s_cnt[q][threadIdx.x];
+            u32 *ctr = threadIdx.x == 0 ? &counters[C_NCHILD] : threadIdx.x == 1 ? &counters[C_NANCH] : &counters[C_NUND];
+            s_base[threadIdx.x] = tot ? atomicAdd(ctr, tot) : 0u;
+        }
+        __syncthreads();
+        u32 base_c = s_base[0], base_a = s_base[1], base_u = s_base[2];
+        for (int q = 0; q < w; q++) { base_c += s_cnt[q][0]; base_a += s_cnt[q][1]; base_u += s_cnt[q][2]; }
+        if (split) {
+            u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
+            u32 lc = NONE, tc = NONE;
+            if (lead) {
+                if (slot < child_cap) {
+                    for (int s = 0; s < k; s++) { t.b[(size_t)slot * k + s] = t.b[(size_t)id * k + s]; t.e[(size_t)slot * k + s] = t.q[(size_t)id * k + s]; }
+                    t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
+                    lc = slot;
+                } else atomicOr(&counters[C_ERR], 1u);
+                slot++;
+            }
+            if (trail) {
+                if (slot < child_cap) {
+                    for (int s = 0; s < k; s++) { t.b[(size_t)slot * k + s] = (sa_t)((int64_t)t.q[(size_t)id * k + s] + L); t.e[(size_t)slot * k + s] = t.e[(size_t)id * k + s]; }
+                    t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
+                    tc = slot;
+                } else atomicOr(&counters[C_ERR], 1u);
+            }
+            t.lead[id] = lc; t.trail[id] = tc;
+            const u32 as = base_a + (u32)__popcll(b_split & lt);
+            if (as < an_cap) { an_l[as] = L; for (int s = 0; s < k; s++) an_pos[(size_t)as * k + s] = t.q[(size_t)id * k + s]; }
+            else atomicOr(&counters[C_ERR], 4u);
+        }
+        if (in) t.state[id] = split ? 1u : 2u;
+        if (und) {
+            und_list[base_u + (u32)__popcll(b_und & lt)] = id;
+            if ((u64)total > (u64)leaf_n) atomicMax(&counters[C_MAXN], (u32)(total > 0xFFFFFFFFll ? 0xFFFFFFFFll : total));
+        }
+        // visited here: everything but the undecided ones (the level pipeline counts those when it takes them)
+        const u64 b_vis = __ballot(in && !und);
+        u32 md = (in && !und) ? (u32)dp : 0u;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { const u32 om = __shfl_down(md, d, 64); md = om > md ? om : md; }
+        if (lane == 0 && b_vis) {
+            atomicAdd(&counters[C_STEPS], (u32)__popcll(b_vis));
+            if (md > counters[C_MAXDEPTH]) atomicMax(&counters[C_MAXDEPTH], md);
+        }
+        __syncthreads();
+    }
+}
+__global__ void k_casm_advance(u32 *__restrict__ counters) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const u32 lo = counters[C_LO], hi = counters[C_HI];
+    if (hi > lo) counters[C_LEVELS]++;
+    counters[C_LO] = hi; counters[C_HI] = counters[C_NCHILD];
+}
+
+// ---- undecided sub-indices from their text: up to k intervals, at most RV_LEAF_N suffixes, one workgroup each (see k_cas_build) ----
+struct CmRoot { int64_t off; int32_t n, id; };
+// first x < lim with txt[i + x] != txt[j + x], or lim: eight bytes per step (related genomes: a suffix agrees with its k - 1
+// homologues for a hundred characters and more)
+__device__ inline int cm_first_diff(const uint8_t *txt, int i, int j, int lim) {
+    int x = 0;
+    while (x + 8 <= lim) {
+        u64 a, b;
+        __builtin_memcpy(&a, txt + i + x, 8);
+        __builtin_memcpy(&b, txt + j + x, 8);
+        if (a != b) return x + (__builtin_ctzll(a ^ b) >> 3);
+        x += 8;
+    }
+    while (x < lim && txt[i + x] == txt[j + x]) x++;
+    return x;
+}
+// (counting sort by comparison, one suffix per thread: a workgroup takes 256 suffixes of a sub-index, so a sub-index of n suffixes is
+// n / 256 workgroups doing n comparisons per thread -- as ONE workgroup per sub-index the largest of 44 undecided sub-indices of
+// 10 x 5 Mbp, 8 000 suffixes whose homologues agree for hundreds of characters, took 30 ms)
+constexpr int BN = 8192;
+struct CmSlice { int32_t root, first; };
+__device__ inline int cm_load_text(const CmRoot &root, const CmTabs &t, int k, const uint8_t *__restrict__ T0, uint8_t *txt, int *seg_lo, int64_t *seg_b) {
+    if (threadIdx.x == 0) {
+        int at = 0;
+        for (int s = 0; s < k; s++) {
+            const int64_t b = t.b[(size_t)root.id * k + s], e = t.e[(size_t)root.id * k + s];
+            seg_lo[s] = at; seg_b[s] = b; at += e > b ? (int)(e - b) : 0;
+        }
+        seg_lo[k] = at;
+    }
+    __syncthreads();
+    const int n = seg_lo[k];
+    for (int x = threadIdx.x; x < n; x += TB) {
+        int s = 0;
+        while (x >= seg_lo[s + 1]) s++;
+        txt[x] = T0[seg_b[s] + (x - seg_lo[s])];
+    }
+    __syncthreads();
+    return n;
+}
+__global__ __launch_bounds__(TB) void k_casm_rank(const CmRoot *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
+                                                  u32 *__restrict__ ord) {
+    __shared__ uint8_t txt[BN + 8];
+    __shared__ int seg_lo[RV_CASM_K + 1];
+    __shared__ int64_t seg_b[RV_CASM_K];
+    const CmSlice sl = slices[blockIdx.x];
+    const CmRoot root = roots[sl.root];
+    const int n = cm_load_text(root, t, k, T0, txt, seg_lo, seg_b);
+    const int i = sl.first + threadIdx.x;
+    if (i >= n) return;
+    int si = 0;
+    while (i >= seg_lo[si + 1]) si++;
+    const int ri = seg_lo[si + 1] - i;
+    int cnt = 0, sj = 0;
+    for (int j = 0; j < n; j++) {
+        while (j >= seg_lo[sj + 1]) sj++;
+        const int rj = seg_lo[sj + 1] - j;
+        const int lim = ri < rj ? ri : rj;
+        const int x = cm_first_diff(txt, i, j, lim);
+        const bool j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        cnt += j_less ? 1 : 0;
+    }
+    ord[root.off + cnt] = (u32)i;
+}
+__global__ __launch_bounds__(TB) void k_casm_emit(const CmRoot *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
+                                                  const u32 *__restrict__ ord, sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0,
+                                                  const sa_t *__restrict__ root_b) {
+    __shared__ uint8_t txt[BN + 8];
+    __shared__ int seg_lo[RV_CASM_K + 1];
+    __shared__ int64_t seg_b[RV_CASM_K];
+    const CmSlice sl = slices[blockIdx.x];
+    const CmRoot root = roots[sl.root];
+    const int n = cm_load_text(root, t, k, T0, txt, seg_lo, seg_b);
+    const int r = sl.first + threadIdx.x;
+    if (r >= n) return;
+    const int i = (int)ord[root.off + r];
+    int si = 0;
+    while (i >= seg_lo[si + 1]) si++;
+    const int ri = seg_lo[si + 1] - i;
+    u32 l = 0;
+    if (r > 0) {
+        const int j = (int)ord[root.off + r - 1];
+        int sj = 0;
+        while (j >= seg_lo[sj + 1]) sj++;
+        const int rj = seg_lo[sj + 1] - j;
+        const int lim = ri < rj ? ri : rj;
+        int x = 0;
+        while (x < lim) { const uint8_t c = txt[i + x]; if (c != txt[j + x] || c == '$' || c == 'N') break; x++; }
+        l = (u32)x;
+    }
+    const int64_t gp = seg_b[si] + (i - seg_lo[si]);
+    uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
+    const bool behind_anchor = i == seg_lo[si] && seg_b[si] > (int64_t)root_b[si];
+    if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
+    const int64_t o = root.off + r;
+    SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
+}
+__global__ __launch_bounds__(TB) void k_casm_lower(uint8_t *__restrict__ T, const u32 *__restrict__ an_l, const sa_t *__restrict__ an_pos, u32 nranges) {
+    const u32 e = (u32)(((int64_t)blockIdx.x * TB + threadIdx.x) >> 6);
+    if (e >= nranges) return;
+    const int64_t lo = (int64_t)an_pos[e];
+    const int64_t l = (int64_t)an_l[e];      // (an_l expanded per range by the caller's indexing: see the launch)
+    for (int64_t x = threadIdx.x & 63; x < l; x += 64) { const uint8_t c = T[lo + x]; if (c >= 'A' && c <= 'Z') T[lo + x] = c + 32; }
+}
+__global__ __launch_bounds__(TB) void k_casm_expand_l(const u32 *__restrict__ an_l, u32 na, int k, u32 *__restrict__ out) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < na * (u32)k) out[i] = an_l[i / (u32)k];
+}
+
+int bitlen64m(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
+
+}  // namespace
+
+int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeMultiOut *out) {
+    out->done = false; out->levels = 0; out->cands = out->witnesses = out->children = out->undecided = out->rebuilt_ranks = 0; out->steps = 0; out->maxdepth = 0;
+    out->why = nullptr; out->an_l.clear(); out->an_pos.clear(); out->meta.clear(); out->node_first.clear(); out->nodes.clear(); out->d_sa = out->d_lcp = out->d_bwt = nullptr;
+    Workspace &ws = h->ws;
+    hipStream_t q = ws.stream;
+    const int64_t n = h->n;
+    const int k = h->nsamples;
+    const u32 minl = (u32)std::max(minl_in, 1);
+    const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
+#define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s\n", k, msg); return 0; } while (0)
+    if (k < 3 || k > RV_CASM_K) GIVE_UP("sample count outside the cascade's range");
+    if ((int)h->nodes.size() != k || (int)h->nsep.size() != k - 1) GIVE_UP("not one sequence per sample");
+    if (n >= ((int64_t)1 << 32) - 2) GIVE_UP("index above 2^32 positions");
+#ifdef RV_SA64
+    if ((u64)h->maxlcp >= (1ull << 24) || n >= ((int64_t)1 << 40)) GIVE_UP("bid word too narrow");
+#endif
+    std::vector<sa_t> rb((size_t)k), re((size_t)k);
+    {
+        std::vector<RvIntv> nd(h->nodes.begin(), h->nodes.end());
+        std::sort(nd.begin(), nd.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
+        for (int s = 0; s < k; s++) {
+            if (nd[(size_t)s].end <= nd[(size_t)s].begin) GIVE_UP("an empty sample");
+            const int64_t lo = s ? h->nsep[(size_t)s - 1] : -1, hi = s < k - 1 ? h->nsep[(size_t)s] : n;
+            if (nd[(size_t)s].begin <= lo || nd[(size_t)s].end > hi) GIVE_UP("not one sequence per sample");
+            rb[(size_t)s] = (sa_t)nd[(size_t)s].begin; re[(size_t)s] = (sa_t)nd[(size_t)s].end;
+        }
+    }
+    const sa_t *SA = h->dSA.as<sa_t>(); const lcp_t *LCP = h->dLCP.as<lcp_t>(); const uint8_t *BWT = h->dBWT.as<uint8_t>();
+    const sa_t *nsep = h->dNsep.as<sa_t>();
+
+    const u32 mcap = (u32)std::min<int64_t>(std::max<int64_t>(1 << 16, n / (int64_t)k / 4), 0x7fffffff);       // full matches: one per k ranks at most, thinned by left-maximality
+    const u32 wcap = (u32)std::min<int64_t>(std::max<int64_t>(1 << 16, n / 16), 0x7fffffff);
+    const int64_t ccap64 = 2 * n / ((int64_t)minl * k) + 16;
+    if (ccap64 >= 0x7fffffff) GIVE_UP("too many sub-indices possible");
+    const u32 ccap = (u32)ccap64, acap = ccap / 2 + 8;
+    DBuf &bso = cb.d[0], &bcl0 = cb.d[1], &bcp0 = cb.d[2], &bk0 = cb.d[3], &bk1 = cb.d[4], &bv0 = cb.d[5], &bv1 = cb.d[6], &bcl = cb.d[7], &bcp = cb.d[8], &bcc = cb.d[9],
+         &bwp = cb.d[10], &bwv = cb.d[11], &bwc = cb.d[12], &btb = cb.d[13], &bctr = cb.d[14], &bund = cb.d[15], &banl = cb.d[16], &banp = cb.d[17], &broot = cb.d[18],
+         &bsa = cb.d[19], &blcp = cb.d[20], &bbwt = cb.d[21], &brt = cb.d[22], &bexp = cb.d[23];
+    RV_TRY(bso.reserve((size_t)n + 64)); RV_TRY(bcl0.reserve((size_t)mcap * 4)); RV_TRY(bcp0.reserve((size_t)mcap * k * sizeof(sa_t)));
+    RV_TRY(bwp.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)wcap * 4)); RV_TRY(bwc.reserve((size_t)wcap * 4));
+    RV_TRY(bctr.reserve(64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
+    // per sub-index tables, one allocation: b, e, q (k sa_t each), best (u64), rmax, depth, state, lead, trail, ql (u32)
+    const size_t per = (size_t)3 * k * sizeof(sa_t) + 8 + 6 * 4;
+    RV_TRY(btb.reserve(per * ccap + 256)); RV_TRY(bund.reserve((size_t)ccap * 4)); RV_TRY(banl.reserve((size_t)acap * 4)); RV_TRY(banp.reserve((size_t)acap * k * sizeof(sa_t)));
+    CmTabs t;
+    {
+        uint8_t *p = btb.as<uint8_t>();
+        t.best = (u64 *)p; p += (size_t)ccap * 8;
+        t.b = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t); t.e = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t); t.q = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t);
+        t.rmax = (u32 *)p; p += (size_t)ccap * 4; t.depth = (int32_t *)p; p += (size_t)ccap * 4; t.state = (u32 *)p; p += (size_t)ccap * 4;
+        t.lead = (u32 *)p; p += (size_t)ccap * 4; t.trail = (u32 *)p; p += (size_t)ccap * 4; t.ql = (u32 *)p;
+    }
+    u32 *counters = bctr.as<u32>();
+    RV_HIP(hipMemsetAsync(counters, 0, 64, q));
+    {
+        std::vector<sa_t> rr(rb); rr.insert(rr.end(), re.begin(), re.end());
+        RV_HIP(hipMemcpyAsync(broot.p, rr.data(), rr.size() * sizeof(sa_t), hipMemcpyHostToDevice, q));
+        RV_HIP(hipStreamSynchronize(q));      // (the vector leaves scope)
+    }
+    const sa_t *d_rb = broot.as<sa_t>(), *d_re = d_rb + k;
+    const unsigned nblk = (unsigned)ceil_div(n, TB);
+    hipLaunchKernelGGL(k_casm_so, dim3(nblk), dim3(TB), 0, q, SA, n, nsep, k, bso.as<uint8_t>());
+    RV_LAUNCH_CHECK();
+    {
+        int pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * (sizeof(sa_t) + sizeof(lcp_t)));
+        hipLaunchKernelGGL(k_casm_scan, dim3(nblk), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), mcap, counters);
+        RV_LAUNCH_CHECK();
+        h->prof.end(q, pid);
+    }
+    hipLaunchKernelGGL(k_casm_witness, dim3(nblk), dim3(TB), 0, q, SA, LCP, (const uint8_t *)bso.as<uint8_t>(), n, minl, bwp.as<sa_t>(), bwv.as<u32>(), wcap, counters);
+    RV_LAUNCH_CHECK();
+    u32 hc[16];
+    RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
+    const u32 M = hc[C_NCAND], NW = hc[C_NWIT];
+    out->cands = M; out->witnesses = NW;
+    if (M > mcap) GIVE_UP("more full matches than the list holds");
+    if (NW > wcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
+    if (M == 0) GIVE_UP("no full match at the top level");
+    struct ProfSpan { Workspace &w; int id; ~ProfSpan() { w.prof_end(id); } } span{ws, ws.prof_begin(RV_K_CASCADE, 5.0 * (double)n)};
+    RV_TRY(bk0.reserve((size_t)M * 8)); RV_TRY(bk1.reserve((size_t)M * 8)); RV_TRY(bv0.reserve((size_t)M * 4)); RV_TRY(bv1.reserve((size_t)M * 4));
+    RV_TRY(bcl.reserve((size_t)M * 4)); RV_TRY(bcp.reserve((size_t)M * k * sizeof(sa_t))); RV_TRY(bcc.reserve((size_t)M * 4));
+    {
+        const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
+        hipLaunchKernelGGL(k_casm_keys, dim3(mb), dim3(TB), 0, q, (const sa_t *)bcp0.as<sa_t>(), k, M, bk0.as<u64>(), bv0.as<u32>());
+        RV_LAUNCH_CHECK();
+        int in1 = 0;
+        RV_TRY(rv_radix_sort_pairs<u32>(ws, bk0.as<u64>(), bv0.as<u32>(), bk1.as<u64>(), bv1.as<u32>(), (int64_t)M, 0, bitlen64m((u64)n), &in1));
+        hipLaunchKernelGGL(k_casm_gather, dim3(mb), dim3(TB), 0, q, (const u32 *)bcl0.as<u32>(), (const sa_t *)bcp0.as<sa_t>(), (const u32 *)(in1 ? bv1.as<u32>() : bv0.as<u32>()), k, M,
+                           bcl.as<u32>(), bcp.as<sa_t>(), bcc.as<u32>());
+        RV_LAUNCH_CHECK();
+    }
+    hipLaunchKernelGGL(k_casm_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, t, k, d_rb, d_re, counters, bwc.as<u32>(), NW);
+    RV_LAUNCH_CHECK();
+    const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
+    const int batch = getenv("RV_CASCADE_BATCH") ? std::max(1, atoi(getenv("RV_CASCADE_BATCH"))) : 8;
+    int queued = 0;
+    for (;;) {
+        for (int b = 0; b < batch; b++, queued++) {
+            hipLaunchKernelGGL(k_casm_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), bcc.as<u32>(), M, (const sa_t *)bwp.as<sa_t>(),
+                               (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, t, k, nsep, (int64_t)minl, queued == 0 ? 1 : 0);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), (const u32 *)bcc.as<u32>(), M, t, k,
+                               (int64_t)minl);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_decide, dim3(1024), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)BN, banl.as<u32>(), banp.as<sa_t>(), acap);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_advance, dim3(1), dim3(64), 0, q, counters);
+            RV_LAUNCH_CHECK();
+        }
+        RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
+        if (hc[C_ERR]) { rv_set_error("cascade (multi): device error %u", hc[C_ERR]); return -1; }
+        if (hc[C_MAXN] > (u32)BN) break;
+        if (hc[C_HI] == hc[C_LO]) break;
+        if (queued > 1000000) { rv_set_error("cascade (multi): no progress"); return -1; }
+    }
+    out->levels = (int)hc[C_LEVELS]; out->children = hc[C_NCHILD];
+    const u32 U = hc[C_NUND], NA = hc[C_NANCH];
+    out->undecided = U;
+    if (hc[C_MAXN] > (u32)BN) {
+        out->why = "an undecided sub-index above the size that is rebuilt from the text";
+        if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", k, out->why, hc[C_MAXN], hc[C_LEVELS], hc[C_NCHILD], U);
+        return 0;
+    }
+    out->steps = hc[C_STEPS]; out->maxdepth = (int)hc[C_MAXDEPTH];
+    // ---- anchors to the host, their text lower-cased (reveal.c:1230-1234)
+    if (NA) {
+        std::vector<sa_t> hp((size_t)NA * k);
+        out->an_l.resize(NA);
+        RV_HIP(hipMemcpyAsync(out->an_l.data(), banl.p, (size_t)NA * 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(hp.data(), banp.p, (size_t)NA * k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+        RV_TRY(bexp.reserve((size_t)NA * k * 4));
+        hipLaunchKernelGGL(k_casm_expand_l, dim3((unsigned)ceil_div((int64_t)NA * k, TB)), dim3(TB), 0, q, (const u32 *)banl.as<u32>(), NA, k, bexp.as<u32>());
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_casm_lower, dim3((unsigned)ceil_div((int64_t)NA * k * 64, TB)), dim3(TB), 0, q, h->dT.as<uint8_t>(), (const u32 *)bexp.as<u32>(), (const sa_t *)banp.as<sa_t>(), NA * (u32)k);
+        RV_LAUNCH_CHECK();
+        RV_HIP(hipStreamSynchronize(q));
+        out->an_pos.assign(hp.begin(), hp.end());
+    }
+    // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
+    if (U) {
+        std::vector<u32> ids(U);
+        RV_HIP(hipMemcpy(ids.data(), bund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
+        std::sort(ids.begin(), ids.end());
+        // their intervals and depths: the tables are small next to the index, but only these rows are needed
+        std::vector<sa_t> hb((size_t)U * k), he((size_t)U * k);
+        std::vector<int32_t> hd(U);
+        for (u32 x = 0; x < U; x++) {      // (undecided sub-indices are few: row by row)
+            RV_HIP(hipMemcpyAsync(hb.data() + (size_t)x * k, t.b + (size_t)ids[x] * k, (size_t)k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(he.data() + (size_t)x * k, t.e + (size_t)ids[x] * k, (size_t)k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(hd.data() + x, t.depth + ids[x], 4, hipMemcpyDeviceToHost, q));
+        }
+        RV_HIP(hipStreamSynchronize(q));
+        std::vector<CmRoot> roots(U);
+        int64_t m = 0;
+        out->node_first.assign(1, 0);
+        for (u32 x = 0; x < U; x++) {
+            int64_t sz = 0; int ns = 0;
+            for (int s = 0; s < k; s++) {
+                const int64_t b = hb[(size_t)x * k + s], e = he[(size_t)x * k + s];
+                if (e > b) { sz += e - b; ns++; out->nodes.push_back(b); out->nodes.push_back(e); }
+            }
+            out->node_first.push_back((int64_t)out->nodes.size() / 2);
+            roots[x].off = m; roots[x].n = (int32_t)sz; roots[x].id = (int32_t)ids[x];
+            const int64_t m6[6] = {m, sz, hd[x], ns, 0, -1};
+            out->meta.insert(out->meta.end(), m6, m6 + 6);
+            m += sz;
+        }
+        out->rebuilt_ranks = m;
+        RV_TRY(bsa.reserve((size_t)(m + 64) * sizeof(sa_t))); RV_TRY(blcp.reserve((size_t)(m + 64) * sizeof(lcp_t))); RV_TRY(bbwt.reserve((size_t)m + 64));
+        std::vector<CmSlice> slices;
+        for (u32 x = 0; x < U; x++)
+            for (int f = 0; f < roots[x].n; f += TB) slices.push_back({(int32_t)x, (int32_t)f});
+        RV_TRY(brt.reserve((size_t)U * sizeof(CmRoot) + slices.size() * sizeof(CmSlice) + 64));
+        RV_TRY(bexp.reserve((size_t)(m + 64) * 4));      // (the lower-casing above is done with it: its launch has been waited for)
+        CmRoot *d_roots = brt.as<CmRoot>();
+        CmSlice *d_slices = (CmSlice *)(d_roots + U);
+        RV_HIP(hipMemcpy(d_roots, roots.data(), (size_t)U * sizeof(CmRoot), hipMemcpyHostToDevice));
+        RV_HIP(hipMemcpy(d_slices, slices.data(), slices.size() * sizeof(CmSlice), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_casm_emit, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
+                           (const u32 *)bexp.as<u32>(), bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
+        RV_LAUNCH_CHECK();
+        out->d_sa = bsa.p; out->d_lcp = blcp.p; out->d_bwt = bbwt.p;
+    }
+    if (verbose) fprintf(stderr, "cascade (%d samples): %u full matches, %u witnesses, %d levels, %u sub-indices, %u anchors, %u undecided (%lld ranks rebuilt)\n", k, M, NW,
+                         out->levels, hc[C_NCHILD], NA, U, (long long)out->rebuilt_ranks);
+    out->done = true;
+    return 0;
+#undef GIVE_UP
+}

@@ -174,8 +174,6 @@ def test_untraced_run_same_anchors(monkeypatch, name, inputs, minl, cascade):
     cascade False: the level pipeline for two-sample runs as well (RV_NO_CASCADE); True: the default, rv_cascade.hip first"""
     if not cascade:
         monkeypatch.setenv("RV_NO_CASCADE", "1")
-    elif isinstance(inputs, list) and len(inputs) > 2 or isinstance(inputs, tuple):
-        pytest.skip("more than two samples: the cascade is not involved")
     if inputs is None:
         inputs = [g.decode() for g in synth.genomes(400000, 2)]
     elif isinstance(inputs, tuple):

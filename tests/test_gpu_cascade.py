@@ -128,3 +128,48 @@ def test_cascade_random_inputs():
             continue
         done += check(seqs, minl)["done"]
     assert done >= 10
+
+
+# ---- more than two samples (rv_cascade_multi.hip) ----------------------------------------------------------------------
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b1c", fa("1a", "1b", "1c"), 20), ("synth3", (200000, 3), 20), ("synth5", (400000, 5), 20),
+                                              ("synth10", (150000, 10), 20), ("synth16", (30000, 16), 15), ("synth17", (20000, 17), 15)])
+def test_multi_cascade_equals_the_literal_recursion(name, inputs, minl, sa64):
+    if isinstance(inputs, tuple):
+        inputs = [g.decode() for g in synth.genomes(inputs[0], inputs[1], seed=13)]
+    ref = oracle_run(inputs, minl, sa64)
+    idx = feed(mod(sa64).index(), inputs)
+    idx.construct()
+    got = idx.align_builtin(minl, 2)
+    info = idx.cascade_info()
+    assert aset(got["anchors"]) == aset(ref["anchors"])
+    assert idx.T.encode("latin-1") == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"] and got["stats"]["anchored_bp"] == ref["stats"]["anchored_bp"]
+    if name in ("synth3", "synth5", "synth10"):               # one sequence per sample, unrelated repeats are short: decided by the cascade
+        assert info["done"] and info["matches"] > 10, info
+    if name == "synth17":                                     # more samples than the cascade takes
+        assert not info["done"]
+
+
+def test_multi_cascade_random_inputs():
+    """the generator of tools/fuzz.py with three and four samples: indels make sub-indices lack samples (undecided, rebuilt from the
+    text and finished by the level pipeline), repeats make them undecided or make the cascade give up"""
+    from fuzz import make_case
+    rng = random.Random(77)
+    done = und = 0
+    n = 0
+    while n < 40:
+        seqs, minl = make_case(rng)
+        if len(seqs) < 3 or min(len(s) for s in seqs) == 0:
+            continue
+        n += 1
+        ref = oracle_run(seqs, minl)
+        idx = feed(mod(False).index(), seqs)
+        idx.construct()
+        got = idx.align_builtin(minl, 2)
+        info = idx.cascade_info()
+        assert aset(got["anchors"]) == aset(ref["anchors"]), (n, info)
+        assert idx.T.encode("latin-1") == ref["T"]
+        assert got["stats"]["splits"] == ref["stats"]["nsplits"]
+        done += info["done"]; und += info["undecided"] if info["done"] else 0
+    assert done >= 10 and und > 0

@@ -242,7 +242,8 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
     if (!safile || !safile[0]) {
         int id = h->prof.begin(q, RV_K_SA_SORT, 5.0 * (double)n);
         if (lcp_from_file) RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats));
-        else RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats, h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), side_sep, d_max, &lcp_done));
+        else RV_TRY(rv_build_sa(h->ws, h->dT.as<uint8_t>(), n, h->dSA.as<sa_t>(), &h->sa_stats, h->dLCP.as<lcp_t>(), h->dBWT.as<uint8_t>(), side_sep, d_max, &lcp_done,
+                                 h->nsep.data(), (int)h->nsep.size()));
         h->prof.end(q, id);
     } else {
         std::vector<sa_t> tmp((size_t)n);

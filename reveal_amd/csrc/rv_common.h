@@ -220,7 +220,8 @@ struct RvSaStats {
 // LCP / BWT / d_maxlcp given: the build also leaves LCP (interface.c:97-114), the BWT bytes (side_sep as for rv_build_lcp) and
 // the largest LCP whenever the first key and the text round finish the order (*fused_done = true); otherwise rv_build_lcp is due
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st,
-                lcp_t *LCP = nullptr, uint8_t *BWT = nullptr, sa_t side_sep = 0, u32 *d_maxlcp = nullptr, bool *fused_done = nullptr);
+                lcp_t *LCP = nullptr, uint8_t *BWT = nullptr, sa_t side_sep = 0, u32 *d_maxlcp = nullptr, bool *fused_done = nullptr,
+                const int64_t *seps = nullptr, int nseps = 0);      // seps: every sample separator (nsep), for the diagonal hint
 int rv_build_inverse(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);
 // the same for an SA that came from a file: fails unless it is a permutation of 0..n-1
 int rv_build_inverse_checked(Workspace &ws, const sa_t *SA, sa_t *SAi, int64_t n);

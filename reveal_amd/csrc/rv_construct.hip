@@ -11,6 +11,7 @@
 #include <string.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <limits>
 
 #ifdef RV_SA64
 typedef u64 sav_t;   // suffix ids as radix-sort payload
@@ -64,16 +65,24 @@ constexpr int KEY_TILE = 1024;
 // from the key it has in registers anyway; anything the hint does not cover (other diagonals after an indel, stretches longer
 // than the field, exceptions, unrelated suffixes that collide in their K symbols) is compared on the text as before.
 struct DiagBits { const u64 *stop, *exc, *lt; int64_t D; };      // one bit per text position each; stop = differs or exception
-__global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T, int64_t n, int64_t D, u64 *__restrict__ stop, u64 *__restrict__ exc,
+struct DiagSamples { int ns; int64_t sep[15], Ds[16]; };            // (HINT_K - 1 separators, HINT_K diagonals: declared below)
+// the partner of position y: its homologue in the first sample for a position of a later sample, its homologue in the second for one of the first
+__device__ inline int64_t diag_partner(const DiagSamples &ds, int64_t y) {
+    int s = 0;
+    for (int q = 0; q < ds.ns - 1; q++) s += ds.sep[q] < y ? 1 : 0;
+    return s == 0 ? y + ds.Ds[1] : (s < 16 ? y - ds.Ds[s] : -1);
+}
+__global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T, int64_t n, DiagSamples ds, u64 *__restrict__ stop, u64 *__restrict__ exc,
                                                   u64 *__restrict__ lt, int64_t nwords) {
     const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (w >= nwords) return;
     const int64_t y0 = w * 64;
     u64 ws = 0, we = 0, wl = 0;
-    if (y0 + 64 + D <= n) {
+    const int64_t p0 = diag_partner(ds, y0), p63 = y0 + 63 < n ? diag_partner(ds, y0 + 63) : -1;
+    if (y0 + 64 <= n && p0 >= 0 && p63 == p0 + 63 && p0 + 64 <= n) {      // the whole word on one diagonal
         u64 a[8], b[8];
         __builtin_memcpy(a, T + y0, 64);
-        __builtin_memcpy(b, T + y0 + D, 64);
+        __builtin_memcpy(b, T + p0, 64);
 #pragma unroll
         for (int k = 0; k < 8; k++)
 #pragma unroll
@@ -86,8 +95,9 @@ __global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T,
     } else {
         for (int bit = 0; bit < 64; bit++) {
             const int64_t y = y0 + bit;
-            if (y + D >= n) { we |= 1ull << bit; ws |= 1ull << bit; continue; }      // no partner on the diagonal
-            const u32 ca = T[y], cb = T[y + D];
+            const int64_t p = y < n ? diag_partner(ds, y) : -1;
+            if (p < 0 || p >= n) { we |= 1ull << bit; ws |= 1ull << bit; continue; }      // no partner on the diagonal
+            const u32 ca = T[y], cb = T[p];
             const bool ea = !((ca == 'A') | (ca == 'C') | (ca == 'G') | (ca == 'T')), eb = !((cb == 'A') | (cb == 'C') | (cb == 'G') | (cb == 'T'));
             we |= (u64)(ea | eb) << bit; ws |= (u64)((ca != cb) | ea | eb) << bit; wl |= (u64)(ca < cb) << bit;
         }
@@ -171,7 +181,10 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 // LCP != NULL (the fused path of rv_build_sa): a head's LCP with its predecessor in the suffix array -- whichever member of the
 // group in front ends up last, it shares that group's K symbols -- is the common prefix of the two keys, cut at the first
 // '$' / 'N' (interface.c:97-114): the digits of both keys, least significant first, by multiply-high division.
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; KeyLayout ly; int64_t D; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+constexpr int HINT_K = 16;      // samples the diagonal hint knows (the first ones)
+// D: diagonal of the second sample against the first (nsep[0] + 1).  ns / sep / Ds: samples, their separators and every sample's
+// diagonal against the FIRST sample (Ds[s] = nsep[s-1] + 1, where sample s starts when every sample is one sequence)
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
 __device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
     const u32 none = (1u << kd.ly.at_bits) - 1u;
@@ -203,6 +216,37 @@ __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
     }
     return cnt - (16u - (u32)kd.K);
 }
+// The diagonal hint for any number of samples: a suffix of sample s >= 1 carries how far it agrees with its homologue in the FIRST
+// sample (position - Ds[s]) and whether it is the smaller of the two; a suffix of the first sample carries the same against its
+// homologue in the second.  Two suffixes with the same homologue in the first sample ("base") are ordered from that alone:
+//   against the base itself: the variant's own hint;
+//   two variants on different sides of the base: the smaller side first, common prefix = the shorter agreement;
+//   two variants on the same side: the one that leaves the base EARLIER is the smaller one below the base and the larger one
+//   above it (the other still spells the base there); equal agreement: not known (both left the base at the same place).
+// -> true when known: *c < 0: u is the smaller suffix; *l = their common prefix (no stop inside: an exception ends every hint)
+__device__ inline int hint_sample(const KeyDigits &kd, int64_t p) {
+    int s = 0;
+    for (int q = 0; q < kd.ns - 1; q++) s += kd.sep[q] < p ? 1 : 0;
+    return s;
+}
+__device__ inline bool hint_cmp(const KeyDigits &kd, int64_t u, u64 key_u, int64_t v, u64 key_v, int *c, u32 *l) {
+    if (kd.ly.nd_bits <= 0) return false;
+    const int su = hint_sample(kd, u), sv = hint_sample(kd, v);
+    if (su >= HINT_K || sv >= HINT_K) return false;
+    const int64_t bu = u - (su ? kd.Ds[su] : 0), bv = v - (sv ? kd.Ds[sv] : 0);
+    if (bu != bv || su == sv) return false;
+    u32 au = 0, av = 0; bool ltu = false, ltv = false;
+    const bool ku = su ? key_hint(key_u, kd, &au, &ltu) : false, kv = sv ? key_hint(key_v, kd, &av, &ltv) : false;
+    if (su == 0) { if (!kv) return false; *c = ltv ? 1 : -1; *l = av; return true; }
+    if (sv == 0) { if (!ku) return false; *c = ltu ? -1 : 1; *l = au; return true; }
+    if (!ku || !kv) return false;
+    if (ltu != ltv) { *c = ltu ? -1 : 1; *l = au < av ? au : av; return true; }
+    if (au == av) return false;
+    *l = au < av ? au : av;
+    *c = ((au < av) == ltu) ? -1 : 1;      // below the base the earlier one is smaller, above it the later one
+    return true;
+}
+
 __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
                                               lcp_t *__restrict__ LCP, KeyDigits kd, u32 *__restrict__ d_maxlcp) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
@@ -280,23 +324,19 @@ __global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals,
             if (first | second) {
                 const sav_t ps = first ? s_val[t + 2] : s_val[t];
                 const u64 pkey = first ? kp1r : km1r;
-                const int64_t d = (int64_t)ps - (int64_t)s;
-                if (d == kd.D || d == -kd.D) {
-                    u32 nd; bool lt;
-                    const bool i_low = d > 0;                        // I start at the smaller text position
-                    if (key_hint(i_low ? key : pkey, kd, &nd, &lt)) {
-                        const bool i_smaller = i_low == lt;
-                        const int64_t base = first ? j : j - 1;
-                        rank = base + (i_smaller ? 0 : 1);
-                        if (rank != base) {
-                            const u32 st = key_first_stop(key, kd);
-                            const u32 l = nd < st ? nd : st;
-                            LCP[rank] = (lcp_t)l;
-                            lmax = l;
-                            grp[rank] = (u32)rank;      // a group of its own from here on (k_isa_from_groups: its rank, should a doubling round ask)
-                        }
-                        if (second) head[j] = 1;
+                int c; u32 nd;
+                if (hint_cmp(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
+                    const bool i_smaller = c < 0;
+                    const int64_t base = first ? j : j - 1;
+                    rank = base + (i_smaller ? 0 : 1);
+                    if (rank != base) {
+                        const u32 st = key_first_stop(key, kd);
+                        const u32 l = nd < st ? nd : st;
+                        LCP[rank] = (lcp_t)l;
+                        lmax = l;
+                        grp[rank] = (u32)rank;      // a group of its own from here on (k_isa_from_groups: its rank, should a doubling round ask)
                     }
+                    if (second) head[j] = 1;
                 }
             }
         }
@@ -743,19 +783,14 @@ __device__ __forceinline__ bool order_small(const uint8_t *__restrict__ T, const
     int c[16]; u32 l[16]; bool kn[16], tw[16];
 #pragma unroll
     for (int x = 0; x < 16; x++) { c[x] = 0; l[x] = 0; kn[x] = false; tw[x] = false; }
-    const int64_t D = fo.kd.D;
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int j = i + 1; j < 4; j++) {
             if (j < size) {
-                const int64_t d = (int64_t)s[j] - (int64_t)s[i];
-                if (d == D || d == -D) {
-                    u32 nd; bool lt;
-                    const bool low_i = d > 0;
-                    if (key_hint(low_i ? kk[i] : kk[j], fo.kd, &nd, &lt)) {
-                        c[i * 4 + j] = (low_i == lt) ? -1 : 1; l[i * 4 + j] = nd < stop0 ? nd : stop0; kn[i * 4 + j] = true; tw[i * 4 + j] = true;
-                    }
+                int cc; u32 nd;
+                if (hint_cmp(fo.kd, (int64_t)s[i], kk[i], (int64_t)s[j], kk[j], &cc, &nd)) {
+                    c[i * 4 + j] = cc; l[i * 4 + j] = nd < stop0 ? nd : stop0; kn[i * 4 + j] = true; tw[i * 4 + j] = true;
                 }
             }
         }
@@ -851,10 +886,14 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
             while (qs + size < m && G[qs + size] == g) size++;
             const sav_t mine = S[q];
             int rank = 0; bool tie_before = false; u32 best = 0;
+            const u64 key_mine = fo.keys[(size_t)g + off];
             for (int j = 0; j < size; j++) {
                 if (j == (int)off) continue;
-                u32 l;
-                const int c = cmp_suffix<W>(T, fo.pk, S[qs + j], mine, &l, h0, stop0);
+                u32 l; int c;
+                const sav_t other = S[qs + j];
+                // homologues of one position of the first sample are ordered from their keys (hint_cmp): ten samples put ten of them into every group
+                if (hint_cmp(fo.kd, (int64_t)other, fo.keys[(size_t)g + j], (int64_t)mine, key_mine, &c, &l)) l = l < stop0 ? l : stop0;
+                else c = cmp_suffix<W>(T, fo.pk, other, mine, &l, h0, stop0);
                 rank += (c < 0) | ((c == 0) & (j < (int)off));
                 tie_before |= (c == 0) & (j < (int)off);
                 best = (c < 0 && l > best) ? l : best;
@@ -862,7 +901,7 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
             Sout[qs + rank] = mine;
             SA[(size_t)g + rank] = (sa_t)mine;
             headq[qs + rank] = !tie_before;
-            fused_put(fo, (size_t)g + rank, mine, (u32)(fo.keys[(size_t)g + off] >> 56), rank == 0, best, lmax);
+            fused_put(fo, (size_t)g + rank, mine, (u32)(key_mine >> 56), rank == 0, best, lmax);
         } else if (!big && off == 0) {
             // a pair of twins is finished here, from its keys; everything else needs the text at least once: the work list
             const int64_t q2 = q + 2 < m ? q + 2 : m - 1, r1 = (int64_t)g + 1 < n ? (int64_t)g + 1 : n - 1;
@@ -870,12 +909,10 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
             const sav_t s0 = S[q], s1 = S[q + 1 < m ? q + 1 : m - 1];
             const u64 key_1 = fo.keys[r1];
             const bool pair = !(q + 2 < m && g_2 == g);
-            const int64_t d = (int64_t)s1 - (int64_t)s0;
-            u32 nd; bool lt;
-            const bool low0 = d > 0;
-            const bool hinted = pair & ((d == fo.kd.D) | (d == -fo.kd.D)) && key_hint(low0 ? key_g : key_1, fo.kd, &nd, &lt);
+            int cc; u32 nd;
+            const bool hinted = pair && hint_cmp(fo.kd, (int64_t)s0, key_g, (int64_t)s1, key_1, &cc, &nd);
             if (hinted) {
-                const bool first0 = low0 == lt;                     // s0 is the smaller suffix
+                const bool first0 = cc < 0;                          // s0 is the smaller suffix
                 const sav_t lo = first0 ? s0 : s1, hi = first0 ? s1 : s0;
                 S[q] = lo; S[q + 1] = hi;
                 SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
@@ -1188,7 +1225,7 @@ int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, 
 }
 
 int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats *st,
-                lcp_t *LCP, uint8_t *BWT, sa_t side_sep, u32 *d_maxlcp, bool *fused_done) {
+                lcp_t *LCP, uint8_t *BWT, sa_t side_sep, u32 *d_maxlcp, bool *fused_done, const int64_t *seps, int nseps) {
     SaScratchInUse in_use(ws);
     RvSaStats s;
     memset(&s, 0, sizeof s);
@@ -1245,7 +1282,19 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     kd.ly.at_bits = K <= 30 ? 5 : 8; kd.ly.at_shift = 56 - kd.ly.at_bits;
     kd.ly.nd_shift = (bits + 7) / 8 * 8; kd.ly.nd_bits = 0;      // (the last radix pass looks at a whole 8-bit digit)
     kd.D = (side_sep > 0 && (int64_t)side_sep < n - 1) ? (int64_t)side_sep + 1 : 0;
-    const bool want_hint = fused && kd.D > 0 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !getenv("RV_NO_DIAG") && !getenv("RV_NO_PACKED_TEXT");
+    kd.ns = 0;
+    for (int q2 = 0; q2 < HINT_K - 1; q2++) kd.sep[q2] = std::numeric_limits<int64_t>::max();      // (later samples count as the last one the hint knows: no hint for them)
+    for (int q2 = 0; q2 < HINT_K; q2++) kd.Ds[q2] = 0;
+    if (seps && nseps > 0 && kd.D > 0) {
+        kd.ns = (nseps + 1 < HINT_K + 1) ? nseps + 1 : HINT_K + 1;                                   // (ns - 1 separators are looked at)
+        if (kd.ns > HINT_K) kd.ns = HINT_K;
+        for (int q2 = 0; q2 < kd.ns - 1; q2++) kd.sep[q2] = seps[q2];
+        for (int q2 = 1; q2 < kd.ns; q2++) kd.Ds[q2] = seps[q2 - 1] + 1;
+        // every separator the hint does not know makes the samples behind it look like the last known one: their positions would be
+        // taken for that sample's and get a wrong diagonal -- the hint is only used for inputs it knows completely
+        if (nseps + 1 > HINT_K) kd.ns = 0;
+    }
+    const bool want_hint = fused && kd.D > 0 && kd.ns >= 2 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !getenv("RV_NO_DIAG") && !getenv("RV_NO_PACKED_TEXT");
     if (want_hint) kd.ly.nd_bits = std::min(kd.ly.at_shift - kd.ly.nd_shift - 1, 11);
     kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
     for (int st = 0; st < 4; st++) {
@@ -1273,7 +1322,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         DBuf &bds = ws.sa[20], &bde = ws.sa[21], &bdl = ws.sa[22];
         const int64_t nw = (n + 63) / 64;
         SA_TRY(bds.reserve((size_t)nw * 8)); SA_TRY(bde.reserve((size_t)nw * 8)); SA_TRY(bdl.reserve((size_t)nw * 8));
-        hipLaunchKernelGGL(k_diag_bits, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, kd.D, bds.as<u64>(), bde.as<u64>(), bdl.as<u64>(), nw);
+        DiagSamples dsm; dsm.ns = kd.ns;
+        for (int q2 = 0; q2 < HINT_K - 1; q2++) dsm.sep[q2] = kd.sep[q2];
+        for (int q2 = 0; q2 < HINT_K; q2++) dsm.Ds[q2] = kd.Ds[q2];
+        hipLaunchKernelGGL(k_diag_bits, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, dsm, bds.as<u64>(), bde.as<u64>(), bdl.as<u64>(), nw);
         SA_HIP(hipGetLastError());
         dg.stop = bds.as<u64>(); dg.exc = bde.as<u64>(); dg.lt = bdl.as<u64>();
     }

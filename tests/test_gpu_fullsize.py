@@ -121,12 +121,13 @@ def test_recursion_properties(built):
         idx.SA                                                # main SA/LCP are gone after align (reveal.c:1279-1284)
 
 
-def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch):
-    """C4: the anchor cascade (rv_cascade.hip; what an untraced two-sample run takes) and the level pipeline it stands in for
-    (RV_NO_CASCADE: scan / split / bubble_sort of every level, reveal.c:731-1338 step by step) give the same anchors, counters
-    and final text at n = 5*10^8"""
+@pytest.mark.parametrize("cfg", ["C4", "C3"])
+def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch, cfg):
+    """C4 / C3: the anchor cascade (rv_cascade.hip for two samples, rv_cascade_multi.hip for ten; what an untraced run takes) and the
+    level pipeline it stands in for (RV_NO_CASCADE: scan / split / bubble_sort of every level, reveal.c:731-1338 step by step) give
+    the same anchors, counters and final text at full size"""
     from reveal_amd import reveallib
-    L, G, seed = CONFIGS["C4"]
+    L, G, seed = CONFIGS[cfg]
     seqs = synth.genomes(L, G, seed=seed)
     idx = reveallib.index()
     for k, s in enumerate(seqs):
@@ -141,10 +142,13 @@ def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch):
         info = idx.cascade_info()
         assert info["done"] == (not off), info
         l, o, pos = res["anchors"]
-        order = np.lexsort((pos[1::2], pos[0::2]))
-        out.append((np.asarray(l)[order], pos[0::2][order], pos[1::2][order], idx.array("T").copy(),
-                    {k: res["stats"][k] for k in ("steps", "splits", "anchored_bp")}))
+        assert (np.diff(o) == G).all()                        # every anchor has a member in every sample
+        first, second = pos[0::G], pos[1::G]
+        order = np.lexsort((second, first))
+        members = pos.reshape(-1, G)[order]
+        out.append((np.asarray(l)[order], members, idx.array("T").copy(),
+                    {k: res["stats"][k] for k in (("steps", "splits", "anchored_bp") if G == 2 else ("splits", "anchored_bp"))}))
     a, b = out
-    assert a[4] == b[4], (a[4], b[4])
-    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
-    assert np.array_equal(a[3], b[3])
+    assert a[3] == b[3], (a[3], b[3])
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert np.array_equal(a[2], b[2])

@@ -109,8 +109,9 @@ __device__ inline void seg_atomic_max32(u32 *__restrict__ dst, u32 child, u32 va
 // ---- witnesses: positions whose suffix shares minl characters or more with a suffix that is not its cross-pair partner ----
 constexpr int WT_ITEMS = 8;
 constexpr int WT_TILE = TB * WT_ITEMS;
+constexpr int WT_REGIONS = 64;
 __global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t n,
-                                                    u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap, u32 *__restrict__ counters) {
+                                                    u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap /* per region */, u32 *__restrict__ counters /* one per region */) {
     __shared__ u32 sl[WT_TILE + 3];          // LCP of ranks j0-1 .. j0+TILE+1 (0 outside the array)
     __shared__ uint8_t ss[WT_TILE + 2];      // side bit of ranks j0-1 .. j0+TILE
     const int64_t j0 = (int64_t)blockIdx.x * WT_TILE;
@@ -128,18 +129,27 @@ __global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA,
         const bool pair0 = (j >= 1) & (l0 > lm1) & (l0 > l1) & (s0 != sm1);             // gap j is a unique cross pair
         const bool pair1 = (j + 1 < n) & (l1 > l0) & (l1 > l2) & (s1 != s0);            // gap j+1 is
         const u32 w = pair0 ? (lm1 > l1 ? lm1 : l1) : pair1 ? (l0 > l2 ? l0 : l2) : (l0 > l1 ? l0 : l1);
+        // (the list in WT_REGIONS regions with a counter each -- k_cas_wpack makes it dense: one counter was 10^5 returning atomics on one
+        // address at 2 x 250 Mbp, most of the kernel's 1.26 ms)
         const bool hit = (j < n) & (w >= minl);
         const u64 bal = __ballot(hit);
         if (bal) {
+            const u32 reg = blockIdx.x & (WT_REGIONS - 1);
             u32 base = 0;
-            if (lane == 0) base = atomicAdd(&counters[C_NWIT], (u32)__popcll(bal));
+            if (lane == 0) base = atomicAdd(&counters[reg], (u32)__popcll(bal));
             base = (u32)__shfl((int)base, 0, 64);
             if (hit) {
-                const u32 o = base + (u32)__popcll(bal & lt);
-                if (o < cap) { w_pos[o] = SA[j]; w_val[o] = w; }
+                const u32 i = base + (u32)__popcll(bal & lt);
+                if (i < cap) { w_pos[(size_t)reg * cap + i] = SA[j]; w_val[(size_t)reg * cap + i] = w; }
             }
         }
     }
+}
+__global__ __launch_bounds__(TB) void k_cas_wpack(const sa_t *__restrict__ src_pos, const u32 *__restrict__ src_val, u32 rcap, const u32 *__restrict__ region_cnt,
+                                                  const u32 *__restrict__ region_off, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val) {
+    const u32 reg = blockIdx.y, i = blockIdx.x * TB + threadIdx.x;
+    if (i >= region_cnt[reg]) return;
+    w_pos[region_off[reg] + i] = src_pos[(size_t)reg * rcap + i]; w_val[region_off[reg] + i] = src_val[(size_t)reg * rcap + i];
 }
 
 // ---- the match list, sorted by its first coordinate ----
@@ -497,7 +507,12 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     RV_HIP(hipMemsetAsync(counters, 0, 64, q));
 
     // ---- witnesses
-    hipLaunchKernelGGL(k_cas_witness, dim3((unsigned)ceil_div(n, WT_TILE)), dim3(TB), 0, q, SA, LCP, BWT, n, minl, bwp.as<sa_t>(), bwv.as<u32>(), wcap, counters);
+    DBuf &bwp0 = cb.d[19], &bwv0 = cb.d[20], &bwr = cb.d[21];
+    RV_TRY(bwp0.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv0.reserve((size_t)wcap * 4)); RV_TRY(bwr.reserve(2 * WT_REGIONS * 4 + 64));
+    u32 *wreg = bwr.as<u32>();
+    RV_HIP(hipMemsetAsync(wreg, 0, 2 * WT_REGIONS * 4, q));
+    const u32 wrcap = wcap / WT_REGIONS;
+    hipLaunchKernelGGL(k_cas_witness, dim3((unsigned)ceil_div(n, WT_TILE)), dim3(TB), 0, q, SA, LCP, BWT, n, minl, bwp0.as<sa_t>(), bwv0.as<u32>(), wrcap, wreg);
     RV_LAUNCH_CHECK();
     // ---- matches by first coordinate
     {
@@ -511,10 +526,19 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         RV_LAUNCH_CHECK();
     }
     u32 hc[8];
-    RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
-    const u32 NW = hc[C_NWIT];
+    u32 hreg[2 * WT_REGIONS];
+    RV_TRY(rv_read_back(ws, hreg, wreg, WT_REGIONS * 4));
+    u32 NW = 0, wmaxc = 0;
+    for (int r = 0; r < WT_REGIONS; r++) { hreg[WT_REGIONS + r] = NW; NW += hreg[r]; wmaxc = std::max(wmaxc, hreg[r]); }
     out->witnesses = NW;
-    if (NW > wcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
+    if (wmaxc > wrcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
+    if (NW) {
+        RV_HIP(hipMemcpyAsync(wreg + WT_REGIONS, hreg + WT_REGIONS, WT_REGIONS * 4, hipMemcpyHostToDevice, q));
+        RV_HIP(hipStreamSynchronize(q));      // (hreg lives on this stack frame)
+        hipLaunchKernelGGL(k_cas_wpack, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)wmaxc, TB)), WT_REGIONS), dim3(TB), 0, q, (const sa_t *)bwp0.as<sa_t>(),
+                           (const u32 *)bwv0.as<u32>(), wrcap, (const u32 *)wreg, (const u32 *)(wreg + WT_REGIONS), bwp.as<sa_t>(), bwv.as<u32>());
+        RV_LAUNCH_CHECK();
+    }
     hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
                        bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW);
     RV_LAUNCH_CHECK();

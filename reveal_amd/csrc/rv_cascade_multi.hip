@@ -79,43 +79,67 @@ __global__ __launch_bounds__(TB) void k_casm_so(const sa_t *__restrict__ SA, int
     if (j < n) so[j] = (uint8_t)cm_sample(nsep, k, SA[j]);
 }
 
-// full matches of the root: the LCP interval of exactly k ranks that ends at rank u (reveal.c:436-580 for n == nsamples)
+// full matches of the root: the LCP interval of exactly k ranks that ends at rank u (reveal.c:436-580 for n == nsamples).
+// A workgroup stages LCP, sample and BWT byte of its 2048 ranks (+ the k - 1 in front, one behind) in LDS: streamed once, the
+// per-rank tests read LDS (one thread per rank with its own global reads ran at 0.4 TB/s of its 8 B/rank)
+constexpr int MS_ITEMS = 8;
+constexpr int MS_TILE = TB * MS_ITEMS;
+constexpr int CM_REGIONS = 64;
 __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, const uint8_t *__restrict__ so,
-                                                  int64_t n, int k, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap, u32 *__restrict__ counters) {
-    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    bool ok = false;
-    u32 v = 0;
-    const int64_t lb = u - (k - 1);
-    if (u < n && lb >= 0) {
-        v = (u32)LCP[u];
-        const u32 nxt = u + 1 < n ? (u32)LCP[u + 1] : 0u;
-        ok = v >= minl && v > nxt;
-        for (int64_t j = lb + 1; j < u && ok; j++) { const u32 x = (u32)LCP[j]; v = x < v ? x : v; ok = v >= minl && v > nxt; }
-        ok = ok && (u32)LCP[lb] < v;
-        if (ok) {
-            u32 seen = 0;
-            for (int64_t j = lb; j <= u && ok; j++) { const u32 bit = 1u << so[j]; ok = !(seen & bit); seen |= bit; }
-        }
-        if (ok) {      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
-            bool mx = false;
-            for (int64_t j = lb; j < u && !mx; j++) {
-                const uint8_t ca = BWT[j] & RV_BWT_CHAR, cb = BWT[j + 1] & RV_BWT_CHAR;
-                mx = cb == '$' || ca != cb || ca == 'N' || ca == '$' || (ca >= 'a' && ca <= 'z');
-            }
-            ok = mx;
-        }
+                                                  int64_t n, int k, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap /* per region */, u32 *__restrict__ region_cnt) {
+    __shared__ u32 sl[MS_TILE + RV_CASM_K + 1];          // LCP of ranks u0-(k-1) .. u0+TILE (0 outside the array)
+    __shared__ uint8_t ss[MS_TILE + RV_CASM_K], sb[MS_TILE + RV_CASM_K];
+    const int64_t u0 = (int64_t)blockIdx.x * MS_TILE;
+    const int H = k - 1;
+    for (int x = threadIdx.x; x < MS_TILE + H + 1; x += TB) { const int64_t j = u0 - H + x; sl[x] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
+    for (int x = threadIdx.x; x < MS_TILE + H; x += TB) {
+        const int64_t j = u0 - H + x;
+        const bool in = j >= 0 && j < n;
+        ss[x] = in ? so[j] : (uint8_t)0; sb[x] = in ? (uint8_t)(BWT[j] & RV_BWT_CHAR) : (uint8_t)0;
     }
-    const u64 bal = __ballot(ok);
-    if (bal) {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&counters[C_NCAND], (u32)__popcll(bal));
-        base = (u32)__shfl((int)base, 0, 64);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int r = 0; r < MS_ITEMS; r++) {
+        const int x = r * TB + threadIdx.x + H;              // index of rank u in the staged arrays
+        const int64_t u = u0 + r * TB + threadIdx.x;
+        const int64_t lb = u - H;
+        bool ok = u < n && lb >= 0;
+        u32 v = 0;
         if (ok) {
-            const u32 o = base + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            if (o < cap) {
-                c_len[o] = v;
-                for (int64_t j = lb; j <= u; j++) c_pos[(size_t)o * k + so[j]] = SA[j];
+            v = sl[x];
+            const u32 nxt = sl[x + 1];
+            ok = v >= minl && v > nxt;
+            for (int d = 1; d < H && ok; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; ok = v >= minl && v > nxt; }
+            ok = ok && sl[x - H] < v;
+            if (ok) {
+                u32 seen = 0;
+                for (int d = 0; d <= H && ok; d++) { const u32 bit = 1u << ss[x - d]; ok = !(seen & bit); seen |= bit; }
+            }
+            if (ok) {      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
+                bool mx = false;
+                for (int d = H; d >= 1 && !mx; d--) {
+                    const uint8_t ca = sb[x - d], cb = sb[x - d + 1];
+                    mx = cb == '$' || ca != cb || ca == 'N' || ca == '$' || (ca >= 'a' && ca <= 'z');
+                }
+                ok = mx;
+            }
+        }
+        // (the list in CM_REGIONS regions with a counter each: one counter was 50 000 returning atomics on one address, 0.7 of the kernel's 0.9 ms)
+        const u64 bal = __ballot(ok);
+        if (bal) {
+            const u32 reg = blockIdx.x & (CM_REGIONS - 1);
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&region_cnt[reg], (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, 0, 64);
+            if (ok) {
+                const u32 i = base + (u32)__popcll(bal & lt);
+                if (i < cap) {
+                    const size_t o = (size_t)reg * cap + i;
+                    c_len[o] = v;
+                    for (int d = 0; d <= H; d++) c_pos[o * k + ss[x - d]] = SA[u - d];
+                }
             }
         }
     }
@@ -123,51 +147,68 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
 
 // R: a suffix' longest common prefix with another suffix of its own sample, where it reaches minl -- the nearest such suffix
 // above and below in the array, the range minimum of LCP in between; a walk that does not find one within WALK ranks keeps
-// the running minimum (an upper bound)
+// the running minimum (an upper bound).  LCP and sample of the tile's ranks and of WALK ranks on either side come through LDS.
 constexpr int WALK = 256;
 __global__ __launch_bounds__(TB) void k_casm_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ so, int64_t n, u32 minl,
                                                      sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap, u32 *__restrict__ counters) {
-    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    u32 r = 0;
-    if (j < n) {
-        const uint8_t s = so[j];
-        u32 mn = 0xFFFFFFFFu;
-        for (int64_t i = j, st = 0; i > 0 && st < WALK; st++) {          // upwards: lcp(rank i-1, rank j) = min LCP[i..j]
-            const u32 x = (u32)LCP[i];
-            mn = x < mn ? x : mn;
-            if (mn < minl) { mn = 0; break; }
-            i--;
-            if (so[i] == s) break;
-            if (i == 0 || st + 1 == WALK) { if (i == 0) mn = 0; break; }
-        }
-        if (mn != 0xFFFFFFFFu && mn >= minl) r = mn;
-        mn = 0xFFFFFFFFu;
-        for (int64_t i = j + 1, st = 0; i < n && st < WALK; i++, st++) {  // downwards: lcp(rank j, rank i) = min LCP[j+1..i]
-            const u32 x = (u32)LCP[i];
-            mn = x < mn ? x : mn;
-            if (mn < minl) { mn = 0; break; }
-            if (so[i] == s) break;
-            if (i + 1 == n) { mn = 0; break; }
-        }
-        if (mn != 0xFFFFFFFFu && mn >= minl && mn > r) r = mn;
+    __shared__ u32 sl[MS_TILE + 2 * WALK + 1];
+    __shared__ uint8_t ss[MS_TILE + 2 * WALK + 1];
+    const int64_t u0 = (int64_t)blockIdx.x * MS_TILE;
+    for (int x = threadIdx.x; x < MS_TILE + 2 * WALK + 1; x += TB) {
+        const int64_t j = u0 - WALK + x;
+        const bool in = j >= 0 && j < n;
+        sl[x] = in ? (u32)LCP[j] : 0u; ss[x] = in ? so[j] : (uint8_t)255;
     }
-    const bool hit = r >= minl && r > 0;
-    const u64 bal = __ballot(hit);
-    if (bal) {
-        u32 base = 0;
-        if (lane == 0) base = atomicAdd(&counters[C_NWIT], (u32)__popcll(bal));
-        base = (u32)__shfl((int)base, 0, 64);
-        if (hit) {
-            const u32 o = base + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-            if (o < cap) { w_pos[o] = SA[j]; w_val[o] = r; }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll 1
+    for (int r0 = 0; r0 < MS_ITEMS; r0++) {
+        const int x = r0 * TB + threadIdx.x + WALK;
+        const int64_t j = u0 + r0 * TB + threadIdx.x;
+        u32 r = 0;
+        if (j < n) {
+            const uint8_t s = ss[x];
+            // upwards: lcp(rank j - d, rank j) = min LCP[j-d+1 .. j]; rank -1 and beyond: LCP 0 (staged), the walk ends there
+            u32 mn = 0xFFFFFFFFu; bool open = true;
+            for (int d = 1; d <= WALK && open; d++) {
+                const u32 y = sl[x - d + 1];
+                mn = y < mn ? y : mn;
+                if (mn < minl) { mn = 0; open = false; }
+                else if (ss[x - d] == s) open = false;
+            }
+            if (mn >= minl && mn != 0xFFFFFFFFu) r = mn;       // (found, or WALK ranks without one: the running minimum bounds it)
+            mn = 0xFFFFFFFFu; open = true;
+            for (int d = 1; d <= WALK && open; d++) {          // downwards: lcp(rank j, rank j + d) = min LCP[j+1 .. j+d]
+                const u32 y = sl[x + d];
+                mn = y < mn ? y : mn;
+                if (mn < minl) { mn = 0; open = false; }
+                else if (ss[x + d] == s) open = false;
+            }
+            if (mn >= minl && mn != 0xFFFFFFFFu && mn > r) r = mn;
+        }
+        const bool hit = r >= minl && r > 0;
+        const u64 bal = __ballot(hit);
+        if (bal) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&counters[C_NWIT], (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, 0, 64);
+            if (hit) {
+                const u32 o = base + (u32)__popcll(bal & lt);
+                if (o < cap) { w_pos[o] = SA[j]; w_val[o] = r; }
+            }
         }
     }
 }
 
-__global__ __launch_bounds__(TB) void k_casm_keys(const sa_t *__restrict__ c_pos, int k, u32 M, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+// the regions' entries as one dense list: key = first coordinate, value = where the entry lives
+__global__ __launch_bounds__(TB) void k_casm_keys(const sa_t *__restrict__ c_pos, int k, u32 rcap, const u32 *__restrict__ region_cnt, const u32 *__restrict__ region_off,
+                                                  u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 reg = blockIdx.y;
     const u32 i = blockIdx.x * TB + threadIdx.x;
-    if (i < M) { keys[i] = (u64)c_pos[(size_t)i * k]; vals[i] = i; }
+    if (i >= region_cnt[reg]) return;
+    const u32 slot = reg * rcap + i, dense = region_off[reg] + i;
+    keys[dense] = (u64)c_pos[(size_t)slot * k]; vals[dense] = slot;
 }
 __global__ __launch_bounds__(TB) void k_casm_gather(const u32 *__restrict__ len_in, const sa_t *__restrict__ pos_in, const u32 *__restrict__ perm, int k, u32 M,
                                                     u32 *__restrict__ len_out, sa_t *__restrict__ pos_out, u32 *__restrict__ c_child) {
@@ -533,7 +574,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
          &bsa = cb.d[19], &blcp = cb.d[20], &bbwt = cb.d[21], &brt = cb.d[22], &bexp = cb.d[23];
     RV_TRY(bso.reserve((size_t)n + 64)); RV_TRY(bcl0.reserve((size_t)mcap * 4)); RV_TRY(bcp0.reserve((size_t)mcap * k * sizeof(sa_t)));
     RV_TRY(bwp.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)wcap * 4)); RV_TRY(bwc.reserve((size_t)wcap * 4));
-    RV_TRY(bctr.reserve(64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
+    RV_TRY(bctr.reserve(64 + 2 * CM_REGIONS * 4 + 64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
     // per sub-index tables, one allocation: b, e, q (k sa_t each), best (u64), rmax, depth, state, lead, trail, ql (u32)
     const size_t per = (size_t)3 * k * sizeof(sa_t) + 8 + 6 * 4;
     RV_TRY(btb.reserve(per * ccap + 256)); RV_TRY(bund.reserve((size_t)ccap * 4)); RV_TRY(banl.reserve((size_t)acap * 4)); RV_TRY(banp.reserve((size_t)acap * k * sizeof(sa_t)));
@@ -546,7 +587,9 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         t.lead = (u32 *)p; p += (size_t)ccap * 4; t.trail = (u32 *)p; p += (size_t)ccap * 4; t.ql = (u32 *)p;
     }
     u32 *counters = bctr.as<u32>();
-    RV_HIP(hipMemsetAsync(counters, 0, 64, q));
+    u32 *region_cnt = counters + 16, *region_off = region_cnt + CM_REGIONS;      // (the match list's regions: counts, then where each starts in the dense list)
+    RV_HIP(hipMemsetAsync(counters, 0, 64 + 2 * CM_REGIONS * 4, q));
+    const u32 rcap = mcap / CM_REGIONS;
     {
         std::vector<sa_t> rr(rb); rr.insert(rr.end(), re.begin(), re.end());
         RV_HIP(hipMemcpyAsync(broot.p, rr.data(), rr.size() * sizeof(sa_t), hipMemcpyHostToDevice, q));
@@ -558,17 +601,21 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     RV_LAUNCH_CHECK();
     {
         int pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * (sizeof(sa_t) + sizeof(lcp_t)));
-        hipLaunchKernelGGL(k_casm_scan, dim3(nblk), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), mcap, counters);
+        hipLaunchKernelGGL(k_casm_scan, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt);
         RV_LAUNCH_CHECK();
         h->prof.end(q, pid);
     }
-    hipLaunchKernelGGL(k_casm_witness, dim3(nblk), dim3(TB), 0, q, SA, LCP, (const uint8_t *)bso.as<uint8_t>(), n, minl, bwp.as<sa_t>(), bwv.as<u32>(), wcap, counters);
+    hipLaunchKernelGGL(k_casm_witness, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, (const uint8_t *)bso.as<uint8_t>(), n, minl, bwp.as<sa_t>(), bwv.as<u32>(), wcap, counters);
     RV_LAUNCH_CHECK();
     u32 hc[16];
     RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
-    const u32 M = hc[C_NCAND], NW = hc[C_NWIT];
+    u32 hreg[2 * CM_REGIONS];
+    RV_TRY(rv_read_back(ws, hreg, region_cnt, CM_REGIONS * 4));
+    u32 M = 0, rmaxc = 0;
+    for (int r = 0; r < CM_REGIONS; r++) { hreg[CM_REGIONS + r] = M; M += hreg[r]; rmaxc = std::max(rmaxc, hreg[r]); }
+    const u32 NW = hc[C_NWIT];
     out->cands = M; out->witnesses = NW;
-    if (M > mcap) GIVE_UP("more full matches than the list holds");
+    if (rmaxc > rcap) GIVE_UP("more full matches than the list holds");
     if (NW > wcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
     if (M == 0) GIVE_UP("no full match at the top level");
     struct ProfSpan { Workspace &w; int id; ~ProfSpan() { w.prof_end(id); } } span{ws, ws.prof_begin(RV_K_CASCADE, 5.0 * (double)n)};
@@ -576,7 +623,10 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     RV_TRY(bcl.reserve((size_t)M * 4)); RV_TRY(bcp.reserve((size_t)M * k * sizeof(sa_t))); RV_TRY(bcc.reserve((size_t)M * 4));
     {
         const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
-        hipLaunchKernelGGL(k_casm_keys, dim3(mb), dim3(TB), 0, q, (const sa_t *)bcp0.as<sa_t>(), k, M, bk0.as<u64>(), bv0.as<u32>());
+        RV_HIP(hipMemcpyAsync(region_off, hreg + CM_REGIONS, CM_REGIONS * 4, hipMemcpyHostToDevice, q));
+        RV_HIP(hipStreamSynchronize(q));      // (hreg lives on this stack frame)
+        hipLaunchKernelGGL(k_casm_keys, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)rmaxc, TB)), CM_REGIONS), dim3(TB), 0, q, (const sa_t *)bcp0.as<sa_t>(), k, rcap,
+                           (const u32 *)region_cnt, (const u32 *)region_off, bk0.as<u64>(), bv0.as<u32>());
         RV_LAUNCH_CHECK();
         int in1 = 0;
         RV_TRY(rv_radix_sort_pairs<u32>(ws, bk0.as<u64>(), bv0.as<u32>(), bk1.as<u64>(), bv1.as<u32>(), (int64_t)M, 0, bitlen64m((u64)n), &in1));

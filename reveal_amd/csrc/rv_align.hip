@@ -1678,8 +1678,9 @@ static int builtin_cascade(rv_index *h) {
     Align *a = h->al;
     memset(&a->cas_out, 0, sizeof a->cas_out);
     if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || getenv("RV_NO_CASCADE")) return 0;
-    if (a->multi) {
-        // more than two samples: the decided part's anchors come back on the host, what is undecided becomes the frontier of the level pipeline
+    const bool second_try = !a->multi && a->use_leaf && getenv("RV_CASCADE_SECOND") != nullptr && atoi(getenv("RV_CASCADE_SECOND")) == 2;      // (test hook: straight to the second attempt)
+    auto interval_cascade = [&]() -> int {
+        // the decided part's anchors come back on the host, what is undecided becomes the frontier of the level pipeline
         RvCascadeMultiOut mo;
         RV_TRY(rv_cascade_multi_run(h, a->cas, a->minl, &mo));
         a->cas_out.done = mo.done; a->cas_out.levels = mo.levels; a->cas_out.cands = mo.cands; a->cas_out.witnesses = mo.witnesses; a->cas_out.children = mo.children;
@@ -1702,7 +1703,8 @@ static int builtin_cascade(rv_index *h) {
             a->level = 1;
         }
         return 0;
-    }
+    };
+    if (a->multi || second_try) return interval_cascade();
     if (!a->use_leaf) return 0;
     RvCascadeIO io;
     io.anchor_count = a->lf_counters; io.anchor_cap = (u32)a->leaf_anchor_cap; io.anchor_l = a->lf_l; io.anchor_pos = a->lf_pos;
@@ -1712,6 +1714,9 @@ static int builtin_cascade(rv_index *h) {
     RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out));
     if (!a->cas_out.done) {
         RV_HIP(hipMemsetAsync(a->dLeaf.p, 0, 256, h->ws.stream));      // anchors and counters of the attempt
+        // an undecided sub-index above the leaf kernel's size: a second attempt with the bound of rv_cascade_multi.hip (repeats inside one
+        // sample: tighter) whose undecided sub-indices -- up to 8192 suffixes -- go to the level pipeline instead of the leaf kernel
+        if (a->cas_out.undecided > 0 && !getenv("RV_CASCADE_SECOND_OFF")) return interval_cascade();
         return 0;
     }
     a->st.levels += a->cas_out.levels;

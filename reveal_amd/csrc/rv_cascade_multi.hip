@@ -544,7 +544,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const u32 minl = (u32)std::max(minl_in, 1);
     const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s\n", k, msg); return 0; } while (0)
-    if (k < 3 || k > RV_CASM_K) GIVE_UP("sample count outside the cascade's range");
+    if (k < 2 || k > RV_CASM_K) GIVE_UP("sample count outside the cascade's range");      // (two samples: the second attempt of rv_align.hip, see there)
     if ((int)h->nodes.size() != k || (int)h->nsep.size() != k - 1) GIVE_UP("not one sequence per sample");
     if (n >= ((int64_t)1 << 32) - 2) GIVE_UP("index above 2^32 positions");
 #ifdef RV_SA64

@@ -173,3 +173,38 @@ def test_multi_cascade_random_inputs():
         assert got["stats"]["splits"] == ref["stats"]["nsplits"]
         done += info["done"]; und += info["undecided"] if info["done"] else 0
     assert done >= 10 and und > 0
+
+
+# ---- two samples through the interval cascade (the second attempt of rv_align.hip builtin_cascade) ---------------------------------
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b", fa("1a", "1b"), 20), ("1a1b_m10", fa("1a", "1b"), 10), ("synth", (300000, 2), 20)])
+def test_pairs_through_the_interval_cascade(monkeypatch, name, inputs, minl):
+    """RV_CASCADE_SECOND=2: two samples straight through rv_cascade_multi.hip (bound = repeats inside one sample; undecided
+    sub-indices to the level pipeline) -- the literal recursion's result"""
+    monkeypatch.setenv("RV_CASCADE_SECOND", "2")
+    if isinstance(inputs, tuple):
+        inputs = [g.decode() for g in synth.genomes(inputs[0], inputs[1], seed=3)]
+    info = check(inputs, minl)
+    if name == "synth":
+        assert info["done"]
+
+
+def test_second_attempt_takes_what_the_leaf_kernel_cannot():
+    """tandem arrays of a few thousand bases with different point mutations: the sub-index around them is undecided and larger than the
+    leaf kernel takes (the first attempt gives up), but small enough to be rebuilt for the level pipeline (the second attempt)"""
+    rng = random.Random(12)
+    second = 0
+    for case in range(5):
+        base = "".join(rng.choice("ACGT") for _ in range(40000))
+        unit = "".join(rng.choice("ACGT") for _ in range(rng.choice([11, 23, 47])))
+        arr = unit * (rng.choice([1500, 2200, 3000]) // len(unit))
+
+        def mutated(x, every):
+            x = list(x)
+            for p in range(rng.randint(0, every), len(x), every):
+                x[p] = rng.choice("ACGT")
+            return "".join(x)
+        a = base[:20000] + mutated(arr, 97) + base[20000:]
+        b = base[:20000] + mutated(arr, 89) + base[20000:]
+        info = check([a, b], 20)
+        second += info["done"] and info["rebuilt_ranks"] > 2048
+    assert second > 0

@@ -29,6 +29,7 @@ ENVS = [
     {"RV_BUBBLE_PAR_MIN": "64", "RV_PB_TWO_PASS": "1", "RV_NO_LEAF": "1"},
     {"RV_LEAF_ACAP": "2", "RV_NO_CASCADE": "1"},
     {"RV_LEAF_ACAP": "2"},                                # the cascade's leaf launch with a two-anchor staging area
+    {"RV_CASCADE_SECOND": "2"},                           # two samples through the interval cascade (rv_cascade_multi.hip) as well
 ]
 
 

@@ -36,6 +36,7 @@ class AlnGraph:
         self.succ, self.pred = {}, {}
         self.paths, self.path2id, self.id2path, self.id2end = [], {}, {}, {}
         self.startnodes, self.endnodes = [], []
+        self.literal_segments = False      # segmentgraph as the reference spells it (set by check_segment_shortcut)
         self._begins = SortedList()
         self._end_of = {}
 
@@ -208,10 +209,23 @@ class AlnGraph:
         listed as an end point -- so the walk back from that end point finds it.  It is left out here (it tripled the cost of
         a call, and a merge of graphs spends nearly all its time in these walks); `segmentgraph_literal` keeps the reference's
         form, tests/test_cpu_graphrem.py runs both on every call of the fixture alignments."""
+        if self.literal_segments:
+            return self.segmentgraph_literal(node, nodes)
         nodes = set(nodes)
         trailing = {c for c, t in self._bfs(node) if t == 0 and isinstance(c, tuple)} & nodes
         leading = {c for c, t in self._bfs(node, reverse=True) if t == 0 and isinstance(c, tuple)} & nodes
         return leading, trailing, nodes - (leading | trailing)
+
+    def check_segment_shortcut(self):
+        """the shortcut of segmentgraph needs every sequence node to go on, over an edge carried by a real path, in both directions
+        (then a walk through unaligned nodes always ends at an aligned node or a sentinel it lists).  The FASTA reader builds graphs
+        like that; a graph read from a file may not (a node no path leaves): it gets the reference's literal form"""
+        for n in self.offsets:
+            if isinstance(n, tuple):
+                if not any(self._real(p) for p in self.succ[n].values()) or not any(self._real(p) for p in self.pred[n].values()):
+                    self.literal_segments = True
+                    return False
+        return True
 
     def segmentgraph_literal(self, node, nodes):
         """rem.py:260-316 step by step (with the walks back from the end points)"""
@@ -430,6 +444,7 @@ def read_gfa(gfafile, index, G):
                     for (u, a, b), p in list(G.pred[old].items()):
                         G.add_edge(u, sentinel, p, a, b)
                 G.remove_node(old)
+    G.check_segment_shortcut()
 
 
 # ---- writer (reveal/utils.py:710-839 after rem.align_cmd's seq2node, utils.py:1036-1049) ----------------

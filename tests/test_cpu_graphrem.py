@@ -213,3 +213,20 @@ def test_segmentgraph_without_the_walks_back_is_the_reference_form(tmp_path, ref
     rem.graph_rem(files[:3], str(tmp_path / "abc.gfa"), indexmod=refmod)
     rem.graph_rem([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], str(tmp_path / "abcd.gfa"), indexmod=refmod)
     assert calls[0] > 1500
+
+
+def test_segment_shortcut_is_only_taken_where_it_holds():
+    """segmentgraph leaves out the reference's walks back from the end points (rem.py:282-287, 303-308), which is only the same when
+    every sequence node goes on over a real-path edge in both directions; a graph from a file with a node no path leaves gets the
+    literal form (advisor finding, round 2)"""
+    G = alngraph.AlnGraph()
+    G.paths, G.path2id, G.id2path = ["p"], {"p": 0}, {0: "p"}
+    G.add_node("start", offsets={0: 0}); G.add_node("end", offsets={0: 30})
+    G.add_node((0, 10), offsets={0: 0}, aligned=0); G.add_node((11, 21), offsets={0: 10}, aligned=0)
+    G.add_edge("start", (0, 10), {0}); G.add_edge((0, 10), (11, 21), {0}); G.add_edge((11, 21), "end", {0})
+    assert G.check_segment_shortcut() and not G.literal_segments
+    G.add_node((22, 30), offsets={0: 20}, aligned=0)          # a node nothing leads away from
+    G.add_edge((11, 21), (22, 30), {0})
+    assert not G.check_segment_shortcut() and G.literal_segments
+    lead, trail, rest = G.segmentgraph((0, 10), [(11, 21), (22, 30)])
+    assert (lead, trail, rest) == G.segmentgraph_literal((0, 10), [(11, 21), (22, 30)])

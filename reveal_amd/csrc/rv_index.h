@@ -86,6 +86,7 @@ struct rv_index {
     bool text_dirty = true;
     bool text_only = false;            // a worker of a divided alignment: text and shared inverse in HBM, no main SA / LCP
     HBuf hscan;                        // pinned staging for the scan records
+    HBuf hupload;                      // two pinned chunks for the text's way into HBM (rv_upload)
     hipEvent_t ev_picks = nullptr;     // recorded behind the picker kernels: the host waits for this, not for the stream
     size_t scan_guess = 4096;
     u32 maxlcp = 0;

@@ -349,6 +349,80 @@ __global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals,
         if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
     }
 }
+// k_heads and k_publish0 in one pass over the sorted (key, suffix) pairs, for the fused path with the diagonal hint (both read every
+// key and its neighbours: 4 GB at n = 5e8 that need not be streamed twice).  head / seed / a head's LCP as in k_heads; SA / BWT and the
+// twin pairs as in k_publish0 -- the second member of a finished pair is a head with its own seed, so the max-scan over the seeds
+// gives it its own group rank.
+__global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t n, uint8_t *__restrict__ head,
+                                                      u32 *__restrict__ seed, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA, uint8_t *__restrict__ BWT, sa_t side_sep,
+                                                      KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    __shared__ u64 s_key[TB + 4];
+    __shared__ sav_t s_val[TB + 2];
+    {
+        const int64_t j0 = (int64_t)blockIdx.x * TB;
+        for (int k = threadIdx.x; k < TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < n) ? keys[i] : 0ull; }
+        for (int k = threadIdx.x; k < TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < n) ? vals[i] : (sav_t)0; }
+        __syncthreads();
+    }
+    u32 lmax = 0;
+    if (j < n) {
+        const int t = threadIdx.x;
+        const sav_t s = s_val[t + 1];
+        const u64 key = s_key[t + 2];
+        const u64 mk = kd.ly.sortmask;
+        const u64 k0 = key & mk;
+        const u64 km2 = j >= 2 ? s_key[t] & mk : ~k0, km1 = j >= 1 ? s_key[t + 1] & mk : ~k0;
+        const u64 kp1r = j + 1 < n ? s_key[t + 3] : ~key, kp2 = j + 2 < n ? s_key[t + 4] & mk : ~k0;
+        const u64 km1r = j >= 1 ? s_key[t + 1] : ~key;
+        const u64 kp1 = j + 1 < n ? kp1r & mk : ~k0;
+        bool hd = (j == 0) | (km1 != k0);
+        if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
+            u32 l = 0;
+            if (j > 0) {
+                if (kd.K <= 16) l = key_common_digits(km1, k0, kd);
+                else {
+                    u64 x = km1, y = k0;
+                    l = (u32)kd.K;
+                    for (int pos = kd.K - 1; pos >= 0; pos--) {
+                        const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
+                        const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
+                        x = qx; y = qy;
+                        l = (dx != dy) ? (u32)pos : l;
+                    }
+                }
+                const u32 st = key_first_stop(key, kd);
+                l = l < st ? l : st;
+            }
+            LCP[j] = (lcp_t)l;
+            lmax = l;
+        }
+        int64_t rank = j;
+        const bool first = twins & (km1 != k0) & (kp1 == k0) & (kp2 != k0);
+        const bool second = twins & (km1 == k0) & (kp1 != k0) & (km2 != k0);
+        if (first | second) {
+            const sav_t ps = first ? s_val[t + 2] : s_val[t];
+            const u64 pkey = first ? kp1r : km1r;
+            int c; u32 nd;
+            if (hint_cmp(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
+                const int64_t base = first ? j : j - 1;
+                rank = base + (c < 0 ? 0 : 1);
+                if (rank != base) {
+                    const u32 st = key_first_stop(key, kd);
+                    const u32 l = nd < st ? nd : st;
+                    LCP[rank] = (lcp_t)l;
+                    lmax = l > lmax ? l : lmax;
+                }
+                if (second) hd = true;      // finished: a group of its own from here on
+            }
+        }
+        head[j] = hd; seed[j] = hd ? (u32)j : 0u;
+        SA[rank] = (sa_t)s;
+        BWT[rank] = (uint8_t)((u32)(key >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+    }
+    const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
+    if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
+}
 // Group ranks are rank ranges and every round only permutes suffixes inside their group, so (SA, grp of round 0) still
 // describe round 0's ISA after the text round has reordered SA.
 __global__ __launch_bounds__(TB) void k_isa_from_groups(const sa_t *__restrict__ SA, const u32 *__restrict__ grp, int64_t n, u32 *__restrict__ ISA) {
@@ -1342,16 +1416,23 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     uint8_t *head = bhead.as<uint8_t>();
     u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
-    hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd, fused ? d_maxlcp : (u32 *)nullptr);
-    SA_HIP(hipGetLastError());
-    SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
-    {
-        KeyDigits kp = kd;
-        if (getenv("RV_NO_PUB_TWINS")) kp.ly.nd_bits = 0;      // (test hook: twin pairs go through the text round's first pass instead)
-        hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep,
-                           kp, fused ? LCP : (lcp_t *)nullptr, head, d_maxlcp, grp);
+    if (fused && kd.ly.nd_bits > 0 && !getenv("RV_NO_HEADS_FUSION")) {
+        hipLaunchKernelGGL(k_heads_publish, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
+                           getenv("RV_NO_PUB_TWINS") ? 0 : 1);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
+    } else {
+        hipLaunchKernelGGL(k_heads, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, n, head, seed, fused ? LCP : (lcp_t *)nullptr, kd, fused ? d_maxlcp : (u32 *)nullptr);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
+        {
+            KeyDigits kp = kd;
+            if (getenv("RV_NO_PUB_TWINS")) kp.ly.nd_bits = 0;      // (test hook: twin pairs go through the text round's first pass instead)
+            hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep,
+                               kp, fused ? LCP : (lcp_t *)nullptr, head, d_maxlcp, grp);
+        }
+        SA_HIP(hipGetLastError());
     }
-    SA_HIP(hipGetLastError());
     bool isa_built = false;
     auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)
         if (isa_built) return 0;

@@ -51,8 +51,10 @@ def build_index(seqs, sa64=False):
         idx.addsample("g%d" % k)
         idx.addsequence(s)
     import torch
+    idx.upload()               # text resident in HBM before anything is timed (this first copy also pays for the handle's device allocations)
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    idx.upload()               # text resident in HBM before anything is timed
+    idx.upload_again()         # the copy alone
     torch.cuda.synchronize()
     idx.upload_ms = (time.perf_counter() - t0) * 1e3
     return idx

@@ -72,6 +72,9 @@ int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, i
  * caller keep the host->device copy out of a timed construct(); repeated
  * construct() calls on an unchanged text start from the HBM-resident copy. */
 int rv_upload(rv_index *h);
+/* the same copy once more, whether or not the text changed: what the text's way into HBM costs once the buffers exist (bench.py's
+ * upload_ms; the first rv_upload of a handle also pays for its device allocations) */
+int rv_upload_again(rv_index *h);
 
 /* getters (interface.c:538-729).  which: */
 enum { RV_T = 0, RV_SA = 1, RV_SAI = 2, RV_LCP = 3, RV_SO = 4, RV_NSEP = 5, RV_NODES = 6 };

@@ -95,6 +95,11 @@ def make_index_type(sa64, error):
             if self._dll.rv_upload(self._h) != 0:
                 self._fail()
 
+        def upload_again(self):
+            """the host->device copy of the text once more (rv_upload_again): its cost without the first call's allocations"""
+            if self._dll.rv_upload_again(self._h) != 0:
+                self._fail()
+
         def prof(self, enable=None, reset=False, only=None):
             """HIP-event kernel timing on the index' stream -> {kernel: (launches, ms, bytes)}
             only = names of the kernel classes to time (default: all; every timed span costs the stream two events)"""

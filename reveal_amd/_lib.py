@@ -54,6 +54,7 @@ SYMBOLS = {
     "rv_nnodes": (_I, [V]),
     "rv_construct": (_I, [V, _I, ctypes.c_char_p, ctypes.c_char_p, _I]),
     "rv_upload": (_I, [V]),
+    "rv_upload_again": (_I, [V]),
     "rv_get_array": (_L, [V, _I, V, _L]),
     "rv_getmums": (_L, [V, _I]),
     "rv_fetch_mums": (_I, [V, V, V, V, _L]),

@@ -238,6 +238,11 @@ int rv_upload(rv_index *h) {
     return 0;
 }
 
+int rv_upload_again(rv_index *h) {
+    h->text_dirty = true;
+    return rv_upload(h);
+}
+
 /* interface.c:160-291 */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache) {
     RV_HIP(hipSetDevice(h->device));

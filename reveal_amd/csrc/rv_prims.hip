@@ -152,7 +152,10 @@ namespace {
 #define RV_RS_THREADS 256      // (512 x 16 = 8192 keys per block -- a digit's run in the output twice as long -- measures the same: 89 ms of SA build at 5e8 either way)
 #endif
 constexpr int RS_THREADS = RV_RS_THREADS;
-constexpr int RS_ITEMS   = 16;
+#ifndef RV_RS_ITEMS
+#define RV_RS_ITEMS 16
+#endif
+constexpr int RS_ITEMS   = RV_RS_ITEMS;
 constexpr int RS_TILE    = RS_THREADS * RS_ITEMS;
 constexpr int RS_WAVES   = RS_THREADS / 64;
 

@@ -199,7 +199,7 @@ uint32_t rv_maxlcp(const rv_index *h);
 /* what the anchor cascade (rv_cascade.hip) did in the last rv_align_builtin: out[0] = 1 it decided the run / 0 the level
  * pipeline ran (out[1..] then describe the abandoned attempt), out[1] levels, out[2] top-level matches, out[3] repeat
  * witnesses, out[4] sub-indices visited, out[5] sub-indices left undecided (rebuilt from their text and handed to the leaf
- * kernel), out[6] ranks rebuilt, out[7] = 0 */
+ * kernel), out[6] ranks rebuilt, out[7] large undecided sub-indices decided from their repeat witnesses (the second attempt) */
 int rv_cascade_info(const rv_index *h, int64_t *out);
 /* anchors chosen by the last rv_align_builtin: l[k], members off[k..k+1] -> pos[] (sorted) */
 int64_t rv_anchor_count(rv_index *h, int64_t *members);

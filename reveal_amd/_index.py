@@ -513,7 +513,7 @@ def make_index_type(sa64, error):
             """what the anchor cascade did in the last align_builtin (rv_cascade_info)"""
             o = np.zeros(8, dtype=np.int64)
             self._dll.rv_cascade_info(self._h, o.ctypes.data)
-            return dict(done=bool(o[0]), levels=int(o[1]), matches=int(o[2]), witnesses=int(o[3]), subindices=int(o[4]), undecided=int(o[5]), rebuilt_ranks=int(o[6]))
+            return dict(done=bool(o[0]), levels=int(o[1]), matches=int(o[2]), witnesses=int(o[3]), subindices=int(o[4]), undecided=int(o[5]), rebuilt_ranks=int(o[6]), decided_from_witnesses=int(o[7]))
 
         def align_builtin_until(self, stop_subs, minl=20, minn=2, trace=False):
             """align_builtin that stops once the frontier holds >= stop_subs sub-indices.

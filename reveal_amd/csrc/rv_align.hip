@@ -1245,7 +1245,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     sa.mend_all = dc.host_lists ? 1 : 0;
     sa.SA_out = a->lvSA[nxt].as<sa_t>(); sa.LCP_out = a->lvLCP[nxt].as<lcp_t>(); sa.BWT_out = a->lvBWT[nxt].as<uint8_t>(); sa.SAi = h->dSAi.as<sa_t>();
     sa.err = a->dErr.as<u32>();      // persistent for the alignment: an early split (rv_decide.hip) runs before this upload exists
-    int id = h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
+    // (a level whose split went out behind the picker has its span there: none here, or its bytes would count twice)
+    int id = a->early_done ? -1 : h->prof.begin(q, RV_K_SPLIT, (double)lv.m * (2 * (sizeof(sa_t) + sizeof(lcp_t) + 2)) + (double)m_next * (sizeof(sa_t) + sizeof(lcp_t) + 1));
     if (!a->early_done) {     // (otherwise queued behind the picker already, with the same tables built on the device)
         if (!a->descs.empty()) {      // tile bounds: the level has data-parallel bubble rounds
             RV_TRY(a->dTmin.reserve((size_t)(lv.m / RV_SPLIT_TILE + 2) * 4));
@@ -1711,10 +1712,18 @@ static int builtin_cascade(rv_index *h) {
     io.stats = a->lf_stats; io.leaf_err = a->lf_counters + 2;
     io.stage_cap = getenv("RV_LEAF_ACAP") ? (u32)atoi(getenv("RV_LEAF_ACAP")) : 256u;
     io.lvSA = &a->lvSA[0]; io.lvLCP = &a->lvLCP[0]; io.lvBWT = &a->lvBWT[0]; io.roots = &a->dLeafRoots[0];
-    RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out));
+    // RV_CASCADE_DANGER=0: no second attempt of this kind; =2: the first attempt already decides large undecided sub-indices from their witnesses (test hook)
+    const int dmode = getenv("RV_CASCADE_DANGER") ? atoi(getenv("RV_CASCADE_DANGER")) : 1;
+    RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out, dmode == 2 ? 1 : 0, 0));
+    if (!a->cas_out.done && a->cas_out.undecided > 0 && dmode == 1) {
+        // an undecided sub-index above the leaf kernel's size: the same cascade again (its lists are still there), now with the large
+        // undecided sub-indices decided from their witnesses (k_cas_dwalk)
+        RV_HIP(hipMemsetAsync(a->dLeaf.p, 0, 256, h->ws.stream));      // anchors and counters of the attempt
+        RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out, 1, 1));
+    }
     if (!a->cas_out.done) {
         RV_HIP(hipMemsetAsync(a->dLeaf.p, 0, 256, h->ws.stream));      // anchors and counters of the attempt
-        // an undecided sub-index above the leaf kernel's size: a second attempt with the bound of rv_cascade_multi.hip (repeats inside one
+        // still one left: another attempt with the bound of rv_cascade_multi.hip (repeats inside one
         // sample: tighter) whose undecided sub-indices -- up to 8192 suffixes -- go to the level pipeline instead of the leaf kernel
         if (a->cas_out.undecided > 0 && !getenv("RV_CASCADE_SECOND_OFF")) return interval_cascade();
         return 0;
@@ -1731,7 +1740,7 @@ int rv_cascade_info(const rv_index *h, int64_t *out) {
     for (int k = 0; k < 8; k++) out[k] = 0;
     if (!h->al) return 0;
     const RvCascadeOut &c = h->al->cas_out;
-    out[0] = c.done ? 1 : 0; out[1] = c.levels; out[2] = c.cands; out[3] = c.witnesses; out[4] = c.children; out[5] = c.undecided; out[6] = c.rebuilt_ranks;
+    out[0] = c.done ? 1 : 0; out[1] = c.levels; out[2] = c.cands; out[3] = c.witnesses; out[4] = c.children; out[5] = c.undecided; out[6] = c.rebuilt_ranks; out[7] = c.solved;
     return 0;
 }
 

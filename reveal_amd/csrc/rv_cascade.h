@@ -5,7 +5,8 @@
 
 // device scratch of the cascade, kept between runs (grow-only like every other buffer of a handle)
 struct RvCascadeBufs {
-    DBuf d[24];
+    DBuf d[32];
+    u32 M = 0, NW = 0;                 // the lists of the last run on this handle (a second attempt starts from them)
     void release() { for (auto &b : d) b.release(); }
 };
 
@@ -23,6 +24,7 @@ struct RvCascadeOut {
     bool done;                         // false: nothing was decided, the caller runs the level pipeline from the top
     int levels;
     int64_t cands, witnesses, children, undecided, rebuilt_ranks;
+    int64_t solved, unsolved;          // second attempt: large undecided sub-indices decided from their witnesses / left undecided
     const char *why;                   // done == false: the reason
 };
 
@@ -38,4 +40,6 @@ struct RvCascadeMultiOut {
 
 struct rv_index;
 int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl, RvCascadeMultiOut *out);
-int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl, RvCascadeOut *out);
+// danger: large undecided sub-indices are decided from their witnesses (the second attempt, rv_cascade.hip); reuse: the match and
+// witness lists of the previous run on this handle are still in cb (same index, same minl)
+int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl, RvCascadeOut *out, int danger = 0, int reuse = 0);

@@ -55,7 +55,7 @@ constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
 
 struct CasIv { sa_t a0, a1, b0, b1; };
 struct CasRes { sa_t qa, qb; u32 ql, lead, trail, state; };      // state: 0 not decided yet, 1 split, 2 ended
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NSOLVED = 8, C_NUNSOLVED = 9 };
 
 // the match (pa, pb, len) of the root cut to a sub-index: start shifted behind the sub-index' begin on both sides, length
 // capped at its ends
@@ -111,7 +111,7 @@ constexpr int WT_ITEMS = 8;
 constexpr int WT_TILE = TB * WT_ITEMS;
 constexpr int WT_REGIONS = 64;
 __global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t n,
-                                                    u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 cap /* per region */, u32 *__restrict__ counters /* one per region */) {
+                                                    u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 *__restrict__ w_rank, u32 cap /* per region */, u32 *__restrict__ counters /* one per region */) {
     __shared__ u32 sl[WT_TILE + 3];          // LCP of ranks j0-1 .. j0+TILE+1 (0 outside the array)
     __shared__ uint8_t ss[WT_TILE + 2];      // side bit of ranks j0-1 .. j0+TILE
     const int64_t j0 = (int64_t)blockIdx.x * WT_TILE;
@@ -140,16 +140,29 @@ __global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA,
             base = (u32)__shfl((int)base, 0, 64);
             if (hit) {
                 const u32 i = base + (u32)__popcll(bal & lt);
-                if (i < cap) { w_pos[(size_t)reg * cap + i] = SA[j]; w_val[(size_t)reg * cap + i] = w; }
+                if (i < cap) { w_pos[(size_t)reg * cap + i] = SA[j]; w_val[(size_t)reg * cap + i] = w; w_rank[(size_t)reg * cap + i] = (u32)j; }
             }
         }
     }
 }
-__global__ __launch_bounds__(TB) void k_cas_wpack(const sa_t *__restrict__ src_pos, const u32 *__restrict__ src_val, u32 rcap, const u32 *__restrict__ region_cnt,
-                                                  const u32 *__restrict__ region_off, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val) {
+__global__ __launch_bounds__(TB) void k_cas_wpack(const sa_t *__restrict__ src_pos, const u32 *__restrict__ src_val, const u32 *__restrict__ src_rank, u32 rcap,
+                                                  const u32 *__restrict__ region_cnt, const u32 *__restrict__ region_off, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val,
+                                                  u32 *__restrict__ w_rank) {
     const u32 reg = blockIdx.y, i = blockIdx.x * TB + threadIdx.x;
     if (i >= region_cnt[reg]) return;
-    w_pos[region_off[reg] + i] = src_pos[(size_t)reg * rcap + i]; w_val[region_off[reg] + i] = src_val[(size_t)reg * rcap + i];
+    const size_t f = (size_t)reg * rcap + i;
+    const u32 o = region_off[reg] + i;
+    w_pos[o] = src_pos[f]; w_val[o] = src_val[f]; w_rank[o] = src_rank[f];
+}
+// the witness list in rank order (the second attempt walks it: k_cas_dwalk)
+__global__ __launch_bounds__(TB) void k_cas_wkeys(const u32 *__restrict__ w_rank, u32 NW, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < NW) { keys[i] = (u64)w_rank[i]; vals[i] = i; }
+}
+__global__ __launch_bounds__(TB) void k_cas_wgather(const sa_t *__restrict__ src_pos, const u32 *__restrict__ src_val, const u32 *__restrict__ perm, u32 NW,
+                                                    sa_t *__restrict__ w_pos, u32 *__restrict__ w_val) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < NW) { const u32 f = perm[i]; w_pos[i] = src_pos[f]; w_val[i] = src_val[f]; }
 }
 
 // ---- the match list, sorted by its first coordinate ----
@@ -165,13 +178,14 @@ __global__ __launch_bounds__(TB) void k_cas_gather(const RvPairRec *__restrict__
     c_pa[i] = r.a; c_pb[i] = r.b; c_len[i] = r.l; c_child[i] = 0u;
 }
 __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth, CasRes *__restrict__ res,
-                           u32 *__restrict__ counters, CasIv root, u32 *__restrict__ w_child, u32 nw) {
+                           u32 *__restrict__ counters, CasIv root, u32 *__restrict__ w_child, u32 nw, u64 *__restrict__ dbest, u32 *__restrict__ dflag) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
+        if (dbest) { dbest[0] = 0; dflag[0] = 0; }
         iv[0] = root; best[0] = 0; wmax[0] = 0; depth[0] = 0;
         CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
         res[0] = r;
-        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0; counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0;
     }
     if (i < nw) w_child[i] = 0u;
 }
@@ -255,9 +269,118 @@ __global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa
     if (cas_key(qa, ql) == best[c]) { res[c].qa = (sa_t)qa; res[c].qb = (sa_t)qb; res[c].ql = (u32)ql; }
 }
 
+// ---- the second attempt: large undecided sub-indices decided from the witnesses ----------------------------------------------
+// A sub-index C the list does not decide (its best cut match, ell characters, is no longer than Wmax(C)) and the leaf kernel cannot
+// take.  With theta = ell (minl when C holds no cut match) and D = {p in C: W[p] >= theta, theta characters left before C's end}:
+//   * a match of C of theta characters or more that is no cut match has both its suffixes in D (in X a third suffix shares its
+//     string, or it would be one of X's matches), and so has every other occurrence of its string inside C;
+//   * C's best cut match is a match of C if its suffixes are outside D (no other suffix of X shares ell characters with them);
+//     inside D it may have a second occurrence in C -- which then is in D as well;
+//   * hence the gaps of theta and more among D's suffixes, cut at C's ends, are those of C's own index: C's choice is the best of
+//     the unique cross pairs of D and the cut match if that is outside D; nothing found and no cut match: C has no match.
+// D is not sorted: the witness list is in X's rank order, so the prefix a member shares with the members of its sub-index falls with
+// their distance in the list -- every member walks outwards for the two longest prefixes it shares (cut at C's ends: a suffix near
+// an end may share less than a farther one, the walk goes on behind those; the prefixes themselves come from X's LCP array),
+// k_cas_dpick keeps the pairs that are each other's only longest partner.  A cut match inside D that the walk does not confirm (ell was not the length of C's best match) leaves C undecided.
+constexpr u32 DWALK = 1024;
+struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; };
+__device__ inline bool cas_is_danger(const CasIv &p, u64 bk, u32 wm, u32 minl, u32 leaf_n, u32 *theta) {
+    const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
+    const u32 bl = (u32)(bk >> KEY_SHIFT);
+    const bool can = (la >= (int64_t)minl) & (lb >= (int64_t)minl);
+    const bool split = can & (bl >= minl) & (bl > wm);
+    *theta = bl >= minl ? bl : minl;
+    return can & !split & (wm >= minl) & ((u64)(la + lb) > (u64)leaf_n);
+}
+__global__ __launch_bounds__(TB) void k_cas_dwalk(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, const u32 *__restrict__ w_child, u32 NW,
+                                                  const CasIv *__restrict__ iv, const u64 *__restrict__ best, const u32 *__restrict__ wmax, u32 minl, CasDanger dg) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= NW) return;
+    dg.m1[i] = 0; dg.key[i] = 0;
+    const u32 c = w_child[i];
+    if (c == NONE) return;
+    const CasIv p = iv[c];
+    u32 theta;
+    if (!cas_is_danger(p, best[c], wmax[c], minl, dg.leaf_n, &theta)) return;
+    const int64_t pos = (int64_t)w_pos[i];
+    const int64_t cap = (pos < (int64_t)p.a1 ? (int64_t)p.a1 : (int64_t)p.b1) - pos;
+    if (w_val[i] < theta || cap < (int64_t)theta) return;
+    u32 b1 = 0, b2 = 0, part = NONE;
+    bool over = false;
+    // The prefix shared with the suffix k places away in X's order is the smallest LCP value in between.  A rank that is no witness
+    // shares less than minl with every suffix but its partner, so nothing behind it shares theta with this suffix: the walk only ever
+    // crosses consecutive ranks, and reads X's LCP array instead of the text.
+#pragma unroll 1
+    for (int dir = -1; dir <= 1; dir += 2) {
+        u32 steps = 0;
+        u64 rk = dg.rank[i];
+        u32 run = 0xFFFFFFFFu;
+        for (int64_t k = (int64_t)i + dir; k >= 0 && k < (int64_t)NW; k += dir) {
+            const u64 r2 = dg.rank[k];
+            if (r2 != rk + (u64)(int64_t)dir) break;
+            const u32 g = (u32)dg.LCP[dir > 0 ? r2 : rk];
+            run = g < run ? g : run;
+            rk = r2;
+            if (run < theta) break;
+            if (++steps > DWALK) { over = true; break; }
+            if (w_child[k] != c || w_val[k] < theta) continue;
+            const int64_t pk = (int64_t)w_pos[k];
+            const int64_t ck = (pk < (int64_t)p.a1 ? (int64_t)p.a1 : (int64_t)p.b1) - pk;
+            if (ck < (int64_t)theta) continue;
+            u32 l = (u32)(cap < ck ? cap : ck);
+            l = run < l ? run : l;
+            if (l > b1) { b2 = b1; b1 = l; part = (u32)k; }
+            else if (l > b2) b2 = l;
+            if (run <= b2) break;      // (what lies behind shares no more than this)
+        }
+    }
+    if (over) atomicOr(&dg.flag[c], 2u);
+    dg.m1[i] = b1 >= theta ? b1 : 0u; dg.p1[i] = part; dg.m2[i] = b2;
+}
+__global__ __launch_bounds__(TB) void k_cas_dpick(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, const u32 *__restrict__ w_child, u32 NW,
+                                                  const CasIv *__restrict__ iv, const CasRes *__restrict__ res, const u64 *__restrict__ best, const u32 *__restrict__ wmax,
+                                                  u32 minl, CasDanger dg) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= NW) return;
+    const u32 c = w_child[i];
+    if (c == NONE) return;
+    const CasIv p = iv[c];
+    u32 theta;
+    const u64 bk = best[c];
+    if (!cas_is_danger(p, bk, wmax[c], minl, dg.leaf_n, &theta)) return;
+    const int64_t pos = (int64_t)w_pos[i];
+    const int64_t cap = (pos < (int64_t)p.a1 ? (int64_t)p.a1 : (int64_t)p.b1) - pos;
+    if (w_val[i] < theta || cap < (int64_t)theta) return;
+    // a member of D: is it one of the best cut match's suffixes?
+    if ((u32)(bk >> KEY_SHIFT) >= minl) { const CasRes r = res[c]; if (pos == (int64_t)r.qa || pos == (int64_t)r.qb) atomicOr(&dg.flag[c], 1u); }
+    const u32 b1 = dg.m1[i];
+    if (b1 == 0) return;
+    const u32 w = dg.p1[i];
+    if (dg.m1[w] != b1 || dg.p1[w] != i || b1 <= dg.m2[i] || b1 <= dg.m2[w]) return;
+    const int64_t pw = (int64_t)w_pos[w];
+    const bool a_side = pos < (int64_t)p.a1, w_a_side = pw < (int64_t)p.a1;
+    if (!a_side || w_a_side) return;      // (the pair reports once, from its suffix in the first sample)
+    const int64_t qa = pos, qb = pw;
+    if (!(qa == (int64_t)p.a0 || qb == (int64_t)p.b0)) {      // reveal.c:81-85 on the working text: the base in front of an interval that starts behind an anchor is lower case
+        const uint8_t ca = dg.T0[qa - 1];
+        if (ca == dg.T0[qb - 1] && ca != 'N' && ca != '$' && !(ca >= 'a' && ca <= 'z')) return;
+    }
+    const u64 key = cas_key(qa, (int64_t)b1);
+    dg.key[i] = key;
+    if (key > dg.best[c]) atomicMax((unsigned long long *)&dg.best[c], (unsigned long long)key);
+}
+__global__ __launch_bounds__(TB) void k_cas_dwrite(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_child, u32 NW, CasDanger dg) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= NW) return;
+    const u64 key = dg.key[i];
+    if (key == 0) return;
+    const u32 c = w_child[i];
+    if (key == dg.best[c]) dg.qb[c] = w_pos[dg.p1[i]];
+}
+
 __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth,
                                                    CasRes *__restrict__ res, u32 minl, u32 *__restrict__ counters, u32 child_cap,
-                                                   u32 *__restrict__ und_list, u32 leaf_n, RvCascadeIO io) {
+                                                   u32 *__restrict__ und_list, u32 leaf_n, RvCascadeIO io, CasDanger dg, int danger) {
     __shared__ u32 s_cnt[TB / 64][3];      // per wave: children, anchors, undecided entries
     __shared__ u32 s_base[3];
     const u32 lo = counters[C_LO], hi = counters[C_HI];      // the level's sub-indices (k_cas_advance sets the next level's)
@@ -274,11 +397,25 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
         const u32 bl = (u32)(bk >> KEY_SHIFT);
         // both samples present and room for a match of minl characters in each (otherwise the reference's scan of this sub-index finds nothing)
         const bool can = in & (la >= (int64_t)minl) & (lb >= (int64_t)minl);
-        const bool split = can & (bl >= minl) & (bl > wm);
-        const bool und = can & !split & (wm >= minl);
+        bool split = can & (bl >= minl) & (bl > wm);
+        bool und = can & !split & (wm >= minl);
+        bool forced = false;
+        if (danger && und && (u64)(la + lb) > (u64)dg.leaf_n) {
+            // the second attempt: what the witnesses of this sub-index say (k_cas_dwalk / k_cas_dpick)
+            const u32 fl = dg.flag[id];
+            const u64 kh = dg.best[id], kc = (bl >= minl && !(fl & 1u)) ? bk : 0ull;
+            if (!(fl & 2u)) {
+                if (kh == 0 && kc == 0) { if (bl < minl) und = false; }          // no cut match and no pair among the witnesses: nothing to find here
+                else {
+                    if (kh > kc) { r.qa = (sa_t)(KEY_LOW - (kh & KEY_LOW)); r.qb = dg.qb[id]; r.ql = (u32)(kh >> KEY_SHIFT); }
+                    split = true; forced = true; und = false;
+                }
+            }
+            atomicAdd(&counters[und ? C_NUNSOLVED : C_NSOLVED], 1u);
+        }
         bool lead = false, trail = false;
         if (split) {
-            if (r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
+            if (!forced && r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
             lead = ((int64_t)r.qa - p.a0) + ((int64_t)r.qb - p.b0) > 0;
             trail = ((int64_t)p.a1 - r.qa - r.ql) + ((int64_t)p.b1 - r.qb - r.ql) > 0;
         }
@@ -303,6 +440,7 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
                 if (slot < child_cap) {
                     CasIv c; c.a0 = p.a0; c.a1 = r.qa; c.b0 = p.b0; c.b1 = r.qb;
                     iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; }
                     r.lead = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
                 slot++;
@@ -311,6 +449,7 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
                 if (slot < child_cap) {
                     CasIv c; c.a0 = (sa_t)((int64_t)r.qa + r.ql); c.a1 = p.a1; c.b0 = (sa_t)((int64_t)r.qb + r.ql); c.b1 = p.b1;
                     iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
+                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; }
                     r.trail = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
             }
@@ -379,53 +518,74 @@ __global__ __launch_bounds__(TB) void k_cas_roots(const u32 *__restrict__ und_li
     roots[u] = r;
 }
 
-// SA / LCP / BWT of one sub-index from the text of its two intervals (one workgroup each, at most RV_LEAF_N suffixes): every
+// SA / LCP / BWT of one sub-index from the text of its two intervals (at most RV_LEAF_N suffixes): every
 // suffix counts the suffixes in front of it -- byte order of the text, a suffix ending at its interval's end in front of every
 // longer one that starts with it, which is where bubble_sort (reveal.c:666-727) puts the suffixes it cuts --, then its common
 // prefix with its predecessor with the stops of interface.c:97-114.
 constexpr int BN = RV_LEAF_N;
-__global__ __launch_bounds__(TB) void k_cas_build(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, sa_t *__restrict__ SA, lcp_t *__restrict__ LCP,
-                                                  uint8_t *__restrict__ BWT, int64_t nsep0, int64_t root_a0, int64_t root_b0) {
+// first x < lim with txt[i + x] != txt[j + x], or lim: eight bytes per step (a repeat's copies agree for hundreds of characters)
+__device__ inline int cas_first_diff(const uint8_t *txt, int i, int j, int lim) {
+    int x = 0;
+    while (x + 8 <= lim) {
+        u64 a, b;
+        __builtin_memcpy(&a, txt + i + x, 8);
+        __builtin_memcpy(&b, txt + j + x, 8);
+        if (a != b) return x + (__builtin_ctzll(a ^ b) >> 3);
+        x += 8;
+    }
+    while (x < lim && txt[i + x] == txt[j + x]) x++;
+    return x;
+}
+// (a workgroup takes 256 suffixes of a sub-index: as one workgroup per sub-index, byte by byte, 41 sub-indices of about a thousand suffixes
+// inside copies of a 1.5 kb repeat took 40 ms)
+__global__ __launch_bounds__(TB) void k_cas_rank(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, uint16_t *__restrict__ ord) {
     __shared__ uint8_t txt[BN + 8];
-    __shared__ uint16_t ord[BN];
     const RvLeafRoot root = roots[blockIdx.x];
     const int la = (int)(root.a1 - root.a0), lb = (int)(root.b1 - root.b0), n = la + lb;
+    if ((int)blockIdx.y * TB >= n) return;
     for (int k = threadIdx.x; k < n; k += TB) txt[k] = k < la ? T0[root.a0 + k] : T0[root.b0 + (k - la)];
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += TB) {
-        const int ri = (i < la ? la : n) - i;
-        int cnt = 0;
-        for (int j = 0; j < n; j++) {
-            const int rj = (j < la ? la : n) - j;
-            const int lim = ri < rj ? ri : rj;
-            int k = 0;
-            while (k < lim && txt[i + k] == txt[j + k]) k++;
-            const bool j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
-            cnt += j_less ? 1 : 0;
-        }
-        ord[cnt] = (uint16_t)i;
+    const int i = (int)blockIdx.y * TB + threadIdx.x;
+    if (i >= n) return;
+    const int ri = (i < la ? la : n) - i;
+    int cnt = 0;
+    for (int j = 0; j < n; j++) {
+        const int rj = (j < la ? la : n) - j;
+        const int lim = ri < rj ? ri : rj;
+        const int k = cas_first_diff(txt, i, j, lim);
+        const bool j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        cnt += j_less ? 1 : 0;
     }
+    ord[root.off + cnt] = (uint16_t)i;
+}
+__global__ __launch_bounds__(TB) void k_cas_emit(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, const uint16_t *__restrict__ ord, sa_t *__restrict__ SA,
+                                                 lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0, int64_t root_a0, int64_t root_b0) {
+    __shared__ uint8_t txt[BN + 8];
+    const RvLeafRoot root = roots[blockIdx.x];
+    const int la = (int)(root.a1 - root.a0), lb = (int)(root.b1 - root.b0), n = la + lb;
+    if ((int)blockIdx.y * TB >= n) return;
+    for (int k = threadIdx.x; k < n; k += TB) txt[k] = k < la ? T0[root.a0 + k] : T0[root.b0 + (k - la)];
     __syncthreads();
-    for (int r = threadIdx.x; r < n; r += TB) {
-        const int i = ord[r];
-        const int ri = (i < la ? la : n) - i;
-        u32 l = 0;
-        if (r > 0) {
-            const int j = ord[r - 1];
-            const int rj = (j < la ? la : n) - j;
-            const int lim = ri < rj ? ri : rj;
-            int k = 0;
-            while (k < lim) { const uint8_t c = txt[i + k]; if (c != txt[j + k] || c == '$' || c == 'N') break; k++; }
-            l = (u32)k;
-        }
-        const int64_t gp = i < la ? root.a0 + i : root.b0 + (i - la);
-        uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
-        // the first suffix of an interval that starts behind an anchor: that anchor's last base has been lower-cased (reveal.c:1230-1234)
-        const bool behind_anchor = i < la ? (i == 0 && root.a0 > root_a0) : (i == la && root.b0 > root_b0);
-        if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
-        const int64_t o = root.off + r;
-        SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
+    const int r = (int)blockIdx.y * TB + threadIdx.x;
+    if (r >= n) return;
+    const int i = ord[root.off + r];
+    const int ri = (i < la ? la : n) - i;
+    u32 l = 0;
+    if (r > 0) {
+        const int j = ord[root.off + r - 1];
+        const int rj = (j < la ? la : n) - j;
+        const int lim = ri < rj ? ri : rj;
+        int k = 0;
+        while (k < lim) { const uint8_t c = txt[i + k]; if (c != txt[j + k] || c == '$' || c == 'N') break; k++; }
+        l = (u32)k;
     }
+    const int64_t gp = i < la ? root.a0 + i : root.b0 + (i - la);
+    uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
+    // the first suffix of an interval that starts behind an anchor: that anchor's last base has been lower-cased (reveal.c:1230-1234)
+    const bool behind_anchor = i < la ? (i == 0 && root.a0 > root_a0) : (i == la && root.b0 > root_b0);
+    if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
+    const int64_t o = root.off + r;
+    SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
 }
 
 int bitlen64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
@@ -433,7 +593,7 @@ double cas_now() { return std::chrono::duration<double>(std::chrono::steady_cloc
 
 }  // namespace
 
-int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl_in, RvCascadeOut *out) {
+int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl_in, RvCascadeOut *out, int danger, int reuse) {
     memset(out, 0, sizeof *out);
     out->done = false;
     Workspace &ws = h->ws;
@@ -467,8 +627,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     if (bovf.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bovf.reserve(4096 * sizeof(RvPairRec)));
     if (bout.cap < 4096 * sizeof(RvPairRec)) RV_TRY(bout.reserve(sizeof(RvPairRec) * (size_t)std::max<int64_t>(4096, n / 64)));
     u32 *tilecnt = btab.as<u32>(), *tileovf = tilecnt + (ntile + 1), *tileoff = tileovf + (ntile + 1);
-    u32 M = 0;
-    for (int attempt = 0;; attempt++) {
+    u32 M = reuse ? cb.M : 0;
+    for (int attempt = 0; !reuse; attempt++) {
         if (attempt == 3) { rv_set_error("cascade: scan buffer sizing failed"); return -1; }
         const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
         hipEvent_t ev_a, ev_b;
@@ -490,6 +650,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     struct ProfSpan { Workspace &w; int id; ~ProfSpan() { w.prof_end(id); } } span{ws, ws.prof_begin(RV_K_CASCADE, 5.0 * (double)n)};      // (bytes: the witness pass over LCP + BWT)
     if (M == 0) GIVE_UP("no match at the top level");
     const RvPairRec *recs = bout.as<RvPairRec>() + RV_PAIR_HDR;
+    cb.M = M;
 
     // ---- buffers
     const u32 wcap = (u32)std::min<int64_t>(std::max<int64_t>(1 << 16, n / 16), 0x7fffffff);
@@ -507,40 +668,76 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     RV_HIP(hipMemsetAsync(counters, 0, 64, q));
 
     // ---- witnesses
-    DBuf &bwp0 = cb.d[19], &bwv0 = cb.d[20], &bwr = cb.d[21];
+    DBuf &bwp0 = cb.d[19], &bwv0 = cb.d[20], &bwr = cb.d[21], &bwrk = cb.d[22], &bwrk0 = cb.d[23];
     RV_TRY(bwp0.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv0.reserve((size_t)wcap * 4)); RV_TRY(bwr.reserve(2 * WT_REGIONS * 4 + 64));
-    u32 *wreg = bwr.as<u32>();
-    RV_HIP(hipMemsetAsync(wreg, 0, 2 * WT_REGIONS * 4, q));
-    const u32 wrcap = wcap / WT_REGIONS;
-    hipLaunchKernelGGL(k_cas_witness, dim3((unsigned)ceil_div(n, WT_TILE)), dim3(TB), 0, q, SA, LCP, BWT, n, minl, bwp0.as<sa_t>(), bwv0.as<u32>(), wrcap, wreg);
-    RV_LAUNCH_CHECK();
-    // ---- matches by first coordinate
-    {
-        const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
-        hipLaunchKernelGGL(k_cas_keys, dim3(mb), dim3(TB), 0, q, recs, M, k0.as<u64>(), v0.as<u32>());
+    RV_TRY(bwrk.reserve((size_t)wcap * 4)); RV_TRY(bwrk0.reserve((size_t)wcap * 4));
+    u32 hc[16];
+    u32 NW = reuse ? cb.NW : 0;
+    if (!reuse) {
+        u32 *wreg = bwr.as<u32>();
+        RV_HIP(hipMemsetAsync(wreg, 0, 2 * WT_REGIONS * 4, q));
+        const u32 wrcap = wcap / WT_REGIONS;
+        hipLaunchKernelGGL(k_cas_witness, dim3((unsigned)ceil_div(n, WT_TILE)), dim3(TB), 0, q, SA, LCP, BWT, n, minl, bwp0.as<sa_t>(), bwv0.as<u32>(), bwrk0.as<u32>(), wrcap, wreg);
         RV_LAUNCH_CHECK();
-        int in1 = 0;
-        RV_TRY(rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (int64_t)M, 0, bitlen64((u64)n), &in1));
-        hipLaunchKernelGGL(k_cas_gather, dim3(mb), dim3(TB), 0, q, recs, (const u32 *)(in1 ? v1.as<u32>() : v0.as<u32>()), M, bpa.as<sa_t>(), bpb.as<sa_t>(),
-                           blen.as<u32>(), bcc.as<u32>());
-        RV_LAUNCH_CHECK();
+        // ---- matches by first coordinate
+        {
+            const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
+            hipLaunchKernelGGL(k_cas_keys, dim3(mb), dim3(TB), 0, q, recs, M, k0.as<u64>(), v0.as<u32>());
+            RV_LAUNCH_CHECK();
+            int in1 = 0;
+            RV_TRY(rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (int64_t)M, 0, bitlen64((u64)n), &in1));
+            hipLaunchKernelGGL(k_cas_gather, dim3(mb), dim3(TB), 0, q, recs, (const u32 *)(in1 ? v1.as<u32>() : v0.as<u32>()), M, bpa.as<sa_t>(), bpb.as<sa_t>(),
+                               blen.as<u32>(), bcc.as<u32>());
+            RV_LAUNCH_CHECK();
+        }
+        u32 hreg[2 * WT_REGIONS];
+        RV_TRY(rv_read_back(ws, hreg, wreg, WT_REGIONS * 4));
+        u32 wmaxc = 0;
+        for (int r = 0; r < WT_REGIONS; r++) { hreg[WT_REGIONS + r] = NW; NW += hreg[r]; wmaxc = std::max(wmaxc, hreg[r]); }
+        out->witnesses = NW;
+        if (wmaxc > wrcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
+        if (NW) {
+            RV_HIP(hipMemcpyAsync(wreg + WT_REGIONS, hreg + WT_REGIONS, WT_REGIONS * 4, hipMemcpyHostToDevice, q));
+            RV_HIP(hipStreamSynchronize(q));      // (hreg lives on this stack frame)
+            hipLaunchKernelGGL(k_cas_wpack, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)wmaxc, TB)), WT_REGIONS), dim3(TB), 0, q, (const sa_t *)bwp0.as<sa_t>(),
+                               (const u32 *)bwv0.as<u32>(), (const u32 *)bwrk0.as<u32>(), wrcap, (const u32 *)wreg, (const u32 *)(wreg + WT_REGIONS), bwp.as<sa_t>(), bwv.as<u32>(),
+                               bwrk.as<u32>());
+            RV_LAUNCH_CHECK();
+        }
+        cb.NW = NW;
+    } else {
+        RV_HIP(hipMemsetAsync(bcc.p, 0, (size_t)M * 4, q));      // every match starts in the root again
+        out->witnesses = NW;
     }
-    u32 hc[8];
-    u32 hreg[2 * WT_REGIONS];
-    RV_TRY(rv_read_back(ws, hreg, wreg, WT_REGIONS * 4));
-    u32 NW = 0, wmaxc = 0;
-    for (int r = 0; r < WT_REGIONS; r++) { hreg[WT_REGIONS + r] = NW; NW += hreg[r]; wmaxc = std::max(wmaxc, hreg[r]); }
-    out->witnesses = NW;
-    if (wmaxc > wrcap) GIVE_UP("too many repeat witnesses (a repetitive input)");
-    if (NW) {
-        RV_HIP(hipMemcpyAsync(wreg + WT_REGIONS, hreg + WT_REGIONS, WT_REGIONS * 4, hipMemcpyHostToDevice, q));
-        RV_HIP(hipStreamSynchronize(q));      // (hreg lives on this stack frame)
-        hipLaunchKernelGGL(k_cas_wpack, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)wmaxc, TB)), WT_REGIONS), dim3(TB), 0, q, (const sa_t *)bwp0.as<sa_t>(),
-                           (const u32 *)bwv0.as<u32>(), wrcap, (const u32 *)wreg, (const u32 *)(wreg + WT_REGIONS), bwp.as<sa_t>(), bwv.as<u32>());
-        RV_LAUNCH_CHECK();
+    // the second attempt walks the witnesses in the root's rank order and keeps a few words per sub-index and per witness
+    const sa_t *wp = bwp.as<sa_t>(); const u32 *wv = bwv.as<u32>();
+    CasDanger dg; memset(&dg, 0, sizeof dg);
+    if (danger) {
+        if (NW) {
+            RV_TRY(k0.reserve((size_t)NW * 8)); RV_TRY(k1.reserve((size_t)NW * 8)); RV_TRY(v0.reserve((size_t)NW * 4)); RV_TRY(v1.reserve((size_t)NW * 4));
+            const unsigned wb = (unsigned)ceil_div((int64_t)NW, TB);
+            hipLaunchKernelGGL(k_cas_wkeys, dim3(wb), dim3(TB), 0, q, (const u32 *)bwrk.as<u32>(), NW, k0.as<u64>(), v0.as<u32>());
+            RV_LAUNCH_CHECK();
+            int in1 = 0;
+            RV_TRY(rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (int64_t)NW, 0, bitlen64((u64)n), &in1));
+            hipLaunchKernelGGL(k_cas_wgather, dim3(wb), dim3(TB), 0, q, (const sa_t *)bwp.as<sa_t>(), (const u32 *)bwv.as<u32>(), (const u32 *)(in1 ? v1.as<u32>() : v0.as<u32>()), NW,
+                               bwp0.as<sa_t>(), bwv0.as<u32>());
+            RV_LAUNCH_CHECK();
+            wp = bwp0.as<sa_t>(); wv = bwv0.as<u32>();
+            dg.rank = in1 ? k1.as<u64>() : k0.as<u64>();
+        }
+        DBuf &bdc = cb.d[24], &bdw = cb.d[25];
+        const size_t per_child = 8 + 4 + sizeof(sa_t), per_wit = 4 + 4 + 4 + 8;
+        RV_TRY(bdc.reserve((size_t)ccap * per_child + 64)); RV_TRY(bdw.reserve((size_t)std::max<u32>(NW, 1) * per_wit + 64));
+        dg.best = bdc.as<u64>(); dg.qb = (sa_t *)(dg.best + ccap); dg.flag = (u32 *)(dg.qb + ccap);
+        dg.key = bdw.as<u64>(); dg.m1 = (u32 *)(dg.key + std::max<u32>(NW, 1)); dg.p1 = dg.m1 + std::max<u32>(NW, 1); dg.m2 = dg.p1 + std::max<u32>(NW, 1);
+        dg.T0 = h->dT0.as<uint8_t>(); dg.LCP = LCP;
+        // every undecided sub-index this way, not only the ones the leaf kernel cannot take: the walk costs less than rebuilding a sub-index that
+        // sits inside a repeat (RV_CASCADE_DANGER_MIN: only sub-indices above that size)
+        dg.leaf_n = getenv("RV_CASCADE_DANGER_MIN") ? (u32)atoi(getenv("RV_CASCADE_DANGER_MIN")) : 0u;
     }
     hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
-                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW);
+                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag);
     RV_LAUNCH_CHECK();
 
     if (verbose) { (void)hipStreamSynchronize(q); tp[2] = cas_now(); }
@@ -552,14 +749,25 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {
             hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
-                               (const sa_t *)bwp.as<sa_t>(), (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
+                               wp, wv, bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
                                bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, queued == 0 ? 1 : 0);
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_cas_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(),
                                (const u32 *)blen.as<u32>(), (const u32 *)bcc.as<u32>(), M, (const CasIv *)biv.as<CasIv>(), bres.as<CasRes>(), (const u64 *)bbest.as<u64>(), (int64_t)minl);
             RV_LAUNCH_CHECK();
+            if (danger && NW) {
+                const unsigned wb = (unsigned)ceil_div((int64_t)NW, TB);
+                hipLaunchKernelGGL(k_cas_dwalk, dim3(wb), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const u64 *)bbest.as<u64>(),
+                                   (const u32 *)bwm.as<u32>(), minl, dg);
+                RV_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_cas_dpick, dim3(wb), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
+                                   (const u64 *)bbest.as<u64>(), (const u32 *)bwm.as<u32>(), minl, dg);
+                RV_LAUNCH_CHECK();
+                hipLaunchKernelGGL(k_cas_dwrite, dim3(wb), dim3(TB), 0, q, wp, (const u32 *)bwc.as<u32>(), NW, dg);
+                RV_LAUNCH_CHECK();
+            }
             hipLaunchKernelGGL(k_cas_decide, dim3(1024), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
-                               bres.as<CasRes>(), minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io);
+                               bres.as<CasRes>(), minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io, dg, (danger && NW) ? 1 : 0);
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_cas_advance, dim3(1), dim3(64), 0, q, counters);
             RV_LAUNCH_CHECK();
@@ -573,13 +781,13 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     const int level = (int)hc[C_LEVELS];
     const u32 hi = hc[C_NCHILD];
     if (verbose) tp[3] = cas_now();
-    out->levels = level; out->children = hi;
+    out->levels = level; out->children = hi; out->solved = hc[C_NSOLVED]; out->unsolved = hc[C_NUNSOLVED];
     const u32 U = hc[C_NUND];
     out->undecided = U;
     if (hc[C_MAXN] > (u32)RV_LEAF_N) {
         // an undecided sub-index the leaf kernel cannot take: nothing of this attempt may stay
         out->why = "an undecided sub-index above the leaf kernel's size";
-        if (verbose) fprintf(stderr, "cascade: gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", out->why, hc[C_MAXN], level, hi, U);
+        if (verbose) fprintf(stderr, "cascade%s: gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided, %u decided from witnesses, %u not)\n", danger ? " (second attempt)" : "", out->why, hc[C_MAXN], level, hi, U, hc[C_NSOLVED], hc[C_NUNSOLVED]);
         return 0;
     }
     hipLaunchKernelGGL(k_cas_stats, dim3(256), dim3(TB), 0, q, (const u32 *)counters, (const int32_t *)bdep.as<int32_t>(), io);
@@ -599,8 +807,12 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         hipLaunchKernelGGL(k_cas_roots, dim3((unsigned)ceil_div((int64_t)U, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, (const CasIv *)biv.as<CasIv>(),
                            (const int32_t *)bdep.as<int32_t>(), (const u64 *)sizes, roots);
         RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_cas_build, dim3(U), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), io.lvSA->as<sa_t>(), io.lvLCP->as<lcp_t>(),
-                           io.lvBWT->as<uint8_t>(), h->nsep[0], (int64_t)root.a0, (int64_t)root.b0);
+        DBuf &bord = cb.d[26];
+        RV_TRY(bord.reserve((size_t)(mu + 64) * 2));
+        hipLaunchKernelGGL(k_cas_rank, dim3(U, BN / TB), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), bord.as<uint16_t>());
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cas_emit, dim3(U, BN / TB), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), (const uint16_t *)bord.as<uint16_t>(),
+                           io.lvSA->as<sa_t>(), io.lvLCP->as<lcp_t>(), io.lvBWT->as<uint8_t>(), h->nsep[0], (int64_t)root.a0, (int64_t)root.b0);
         RV_LAUNCH_CHECK();
         RvLeafArgs la;
         la.roots = roots;
@@ -615,8 +827,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     }
     if (verbose) {
         (void)hipStreamSynchronize(q); tp[4] = cas_now();
-        fprintf(stderr, "cascade: %u matches, %u witnesses, %d levels, %u sub-indices, %u undecided (%lld ranks rebuilt) | ms: scan %.2f witnesses+sort %.2f levels %.2f rebuild+leaf %.2f\n",
-                M, NW, level, hi, U, (long long)out->rebuilt_ranks, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3);
+        fprintf(stderr, "cascade%s: %u matches, %u witnesses, %d levels, %u sub-indices, %u undecided (%lld ranks rebuilt), %lld decided from witnesses | ms: scan %.2f witnesses+sort %.2f levels %.2f rebuild+leaf %.2f\n",
+                danger ? " (second attempt)" : "", M, NW, level, hi, U, (long long)out->rebuilt_ranks, (long long)out->solved, (tp[1] - tp[0]) * 1e3, (tp[2] - tp[1]) * 1e3, (tp[3] - tp[2]) * 1e3, (tp[4] - tp[3]) * 1e3);
     }
     out->done = true;
     return 0;

@@ -69,10 +69,12 @@ def test_cascade_off_and_on_agree(monkeypatch):
     assert on["subindices"] > 0 and off["levels"] == 0
 
 
-def test_cascade_gives_up_cleanly():
+def test_cascade_gives_up_cleanly(monkeypatch):
     """tandem arrays longer than the leaf kernel's size with different point mutations in the two samples: the sub-index around
     them cannot be decided from the match list (its best match is no longer than its repeats) and is too large to be rebuilt --
-    the attempt must leave nothing behind, and the level pipeline's result is the reference's"""
+    the attempt must leave nothing behind, and the level pipeline's result is the reference's (the attempts that would decide it
+    from its witnesses or rebuild it for the level pipeline switched off)"""
+    monkeypatch.setenv("RV_CASCADE_DANGER", "0")
     rng = random.Random(3)
     gave_up = 0
     for case in range(4):
@@ -188,9 +190,11 @@ def test_pairs_through_the_interval_cascade(monkeypatch, name, inputs, minl):
         assert info["done"]
 
 
-def test_second_attempt_takes_what_the_leaf_kernel_cannot():
+def test_second_attempt_takes_what_the_leaf_kernel_cannot(monkeypatch):
     """tandem arrays of a few thousand bases with different point mutations: the sub-index around them is undecided and larger than the
-    leaf kernel takes (the first attempt gives up), but small enough to be rebuilt for the level pipeline (the second attempt)"""
+    leaf kernel takes (the first attempt gives up), but small enough to be rebuilt for the level pipeline (the interval cascade; the
+    attempt that decides it from its witnesses switched off)"""
+    monkeypatch.setenv("RV_CASCADE_DANGER", "0")
     rng = random.Random(12)
     second = 0
     for case in range(5):
@@ -208,3 +212,64 @@ def test_second_attempt_takes_what_the_leaf_kernel_cannot():
         info = check([a, b], 20)
         second += info["done"] and info["rebuilt_ranks"] > 2048
     assert second > 0
+
+
+# ---- large undecided sub-indices decided from their repeat witnesses (k_cas_dwalk) ---------------------------------------------------
+def _snp(rng, s, rate):
+    s = list(s)
+    for p in range(len(s)):
+        if rng.random() < rate:
+            s[p] = rng.choice("ACGT")
+    return "".join(s)
+
+
+def _with_copies(rng, base, unit, copies):
+    out, at = [], 0
+    for p in sorted(rng.sample(range(len(base)), copies)):
+        out.append(base[at:p]); out.append(unit); at = p
+    out.append(base[at:])
+    return "".join(out)
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("kind", ["element", "operon", "array", "array_both", "low_complexity"])
+def test_repeats_as_long_as_the_matches(kind, sa64):
+    """interspersed repeats as long as the longest matches (copies of a mobile element, of an operon), tandem arrays: the sub-indices at
+    the top are not decided by the match list and far too large to rebuild -- the second attempt decides them from the witnesses"""
+    rng = random.Random({"element": 1, "operon": 2, "array": 3, "array_both": 4, "low_complexity": 5}[kind])
+    base = "".join(rng.choice("ACGT") for _ in range(150000))
+    if kind == "element":
+        a = _with_copies(rng, base, "".join(rng.choice("ACGT") for _ in range(1200)), 12)
+        b = _snp(rng, a, 0.01)
+    elif kind == "operon":
+        a = _with_copies(rng, base, "".join(rng.choice("ACGT") for _ in range(4000)), 5)
+        b = _snp(rng, a, 0.01)
+    elif kind == "array":
+        unit = "".join(rng.choice("ACGT") for _ in range(37))
+        a = base[:50000] + _snp(rng, unit * 80, 0.02) + base[50000:]
+        b = _snp(rng, base[:50000] + unit * 80 + base[50000:], 0.01)
+    elif kind == "array_both":
+        unit = "".join(rng.choice("ACGT") for _ in range(61))
+        a = base[:50000] + _snp(rng, unit * 70, 0.01) + base[50000:]
+        b = _snp(rng, base[:50000] + _snp(rng, unit * 64, 0.01) + base[50000:], 0.01)
+    else:
+        a = base[:70000] + "A" * 700 + "AC" * 900 + base[70000:]
+        b = _snp(rng, base[:70000] + "A" * 650 + "AC" * 1000 + base[70000:], 0.01)
+    info = check([a, b], 20, sa64)
+    if kind in ("element", "operon"):
+        assert info["done"] and info["decided_from_witnesses"] > 0, info
+
+
+def test_witness_decisions_on_random_inputs(monkeypatch):
+    """RV_CASCADE_DANGER=2: the first attempt already decides every undecided sub-index from its witnesses where it can"""
+    from fuzz import make_case
+    monkeypatch.setenv("RV_CASCADE_DANGER", "2")
+    rng = random.Random(909)
+    solved = 0
+    for _ in range(40):
+        seqs, minl = make_case(rng)
+        seqs = [s for s in seqs[:2]]
+        if min(len(s) for s in seqs) == 0:
+            continue
+        solved += check(seqs, minl)["decided_from_witnesses"]
+    assert solved > 0

@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 from helpers import assemble, oracle  # noqa: E402
 
+DANGER_CAP = int(os.environ.get("DANGER_CAP", "4096"))
 STATS = dict(certain=0, empty=0, rebuilt=0, rebuilt_bases=0, cases=0, total_bases=0)
 
 
@@ -89,6 +90,49 @@ def cascade(seqs, minl, depth=0):
         if best is None and wmax < minl:
             STATS["empty"] += 1
             continue
+        # not decided by the list.  With ell = the best cut match's length (minl when there is none) and D = {p in C: W[p] >= ell}:
+        #   * a match of C of ell or more that is no cut match has both its suffixes in D (a third suffix of X shares its string);
+        #   * a cut match of length ell whose suffixes are not in D is a match of C (nothing else in X shares ell characters with them);
+        #     one whose suffixes are in D may have a second occurrence inside C -- but then that occurrence is in D as well;
+        #   * so among D's suffixes, cut at C's ends, the gaps of ell or more are the gaps of C's own index, and C's choice is the best
+        #     of what a scan of D finds and the cut match if it is outside D.  Nothing found and a cut match inside D: not decided.
+        ell = best[2] if best is not None else minl
+        D = [int(x) for x in np.nonzero(Wpos[a0:a1 - ell + 1] >= ell)[0] + a0] + [int(x) for x in np.nonzero(Wpos[b0:b1 - ell + 1] >= ell)[0] + b0]
+        for k_ in ("danger_nodes", "danger_max", "danger_hidden", "danger_sum", "danger_fake"):
+            STATS.setdefault(k_, 0)
+        if len(D) <= DANGER_CAP:
+            STATS["danger_nodes"] += 1; STATS["danger_sum"] += len(D); STATS["danger_max"] = max(STATS["danger_max"], len(D))
+            cap = lambda p: T[p:(a1 if p < a1 else b1)]
+            D.sort(key=lambda p: (cap(p), p))
+            g = [0] * (len(D) + 1)
+            for i in range(1, len(D)):
+                x, y = cap(D[i - 1]), cap(D[i])
+                m = min(len(x), len(y)); k = 0
+                while k < m and x[k] == y[k] and x[k] not in b"N$":
+                    k += 1
+                g[i] = k
+            found = None
+            if best is not None and best[0] not in D and best[1] not in D:
+                found = best
+            for i in range(1, len(D)):
+                p, q = D[i - 1], D[i]
+                if g[i] >= ell and g[i] > g[i - 1] and g[i] > g[i + 1] and (p < a1) != (q < a1):
+                    if q < a1:
+                        p, q = q, p
+                    if not (p == a0 or q == b0 or T[p - 1] != T[q - 1] or T[p - 1] in b"N$"):      # reveal.c:81-85 on the working text
+                        continue
+                    if found is None or g[i] > found[2] or (g[i] == found[2] and p < found[0]):
+                        found = (p, q, g[i]); STATS["danger_hidden"] += 1
+            if found is None and best is None:
+                STATS["empty"] += 1
+                continue
+            if found is not None:
+                qa, qb, ql = found
+                anchors.append((ql, (qa, qb)))
+                stack.append((a0, qa, b0, qb, live))
+                stack.append((qa + ql, a1, qb + ql, b1, live))
+                continue
+            STATS["danger_fake"] += 1
         # not decided by the list: the child from its own text
         STATS["rebuilt"] += 1
         STATS["rebuilt_bases"] += (a1 - a0) + (b1 - b0)

@@ -159,7 +159,7 @@ struct Workspace {
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf misc[16];
-    DBuf sa[24];           // SA-build scratch, kept between construct() calls
+    DBuf sa[26];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;
     // kernel-class timing of the handle that owns this workspace (RvProf, rv_index.h), for code that only sees the workspace

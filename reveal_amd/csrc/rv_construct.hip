@@ -104,6 +104,46 @@ __global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T,
     }
     stop[w] = ws; exc[w] = we; lt[w] = wl;
 }
+// ---- twins leave before the sort --------------------------------------------------------------------------------------
+// Two samples: a suffix q of the second sample whose K symbols -- and the byte in front of it -- are those of its homologue p = q - D in
+// the first (no marked position in [q - 1, q + K - 1]: k_diag_bits) would sort into p's group, carry p's key (same symbols, same byte in
+// front, same agreement nd with its twin, the opposite "smaller" bit) and is told from p by the hint alone.  Such a q is not sorted: p
+// is flagged instead (top bit of its payload), and k_heads_publish_tc writes q behind p when the sorted list is laid out in rank order.
+// At 1 % divergence six in seven suffixes of the second sample leave: the radix passes move 0.57 n pairs instead of n.
+// The predicate is a function of the stop bits alone, and those are the same for p and q (the same two characters are compared):
+// both sides evaluate it on their own words.
+constexpr sav_t TW_FLAG = (sav_t)1 << (sizeof(sav_t) * 8 - 1);
+// bit b: no marked position in [64 w + b - 1, 64 w + b + K - 1]    (prev / lo / hi = words w - 1, w, w + 1 of the stop bits)
+__device__ inline u64 tw_window_clear(u64 prev, u64 lo, u64 hi, int K) {
+    u64 acc = (lo << 1) | (prev >> 63) | lo;
+    for (int d = 1; d < K; d++) acc |= (lo >> d) | (hi << (64 - d));
+    return ~acc;
+}
+// bits of word w whose positions lie in [a, b)
+__device__ inline u64 tw_range(int64_t w, int64_t a, int64_t b) {
+    const int64_t lo = a - 64 * w, hi = b - 64 * w;
+    if (hi <= 0 || lo >= 64) return 0ull;
+    const u64 from = lo <= 0 ? ~0ull : (~0ull << lo), to = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+    return from & to;
+}
+// positions of word w that are twins: flagged (first sample, [1, D - 1)) or left out of the sort (second sample, [D + 1, min(2 D - 1, n)))
+__device__ inline u64 tw_mask(u64 prev, u64 lo, u64 hi, int64_t w, int K, int64_t D, int64_t n) {
+    const int64_t e = 2 * D - 1 < n ? 2 * D - 1 : n;
+    return tw_window_clear(prev, lo, hi, K) & (tw_range(w, 1, D - 1) | tw_range(w, D + 1, e));
+}
+// per tile of KEY_TILE positions: the suffixes of the second sample that stay in the sort
+__global__ __launch_bounds__(TB) void k_tw_count(const u64 *__restrict__ stop, int64_t nwords, int K, int64_t D, int64_t n, u32 *__restrict__ tilecnt, int64_t ntiles) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 c = 0;
+    if (w < nwords) {
+        const u64 prev = w > 0 ? stop[w - 1] : ~0ull, lo = stop[w], hi = w + 1 < nwords ? stop[w + 1] : ~0ull;
+        c = (u32)__popcll(tw_range(w, D, n) & ~tw_mask(prev, lo, hi, w, K, D, n));
+    }
+#pragma unroll
+    for (int d = 8; d >= 1; d >>= 1) c += __shfl_down(c, d, 16);      // KEY_TILE / 64 = 16 words per tile
+    const int64_t tile = w >> 4;
+    if ((threadIdx.x & 15) == 0 && tile < ntiles) tilecnt[tile] = c;
+}
 // layout of the key's upper bits on the fused path: [0, bits) the sort key; [nd_shift, nd_shift + nd_bits) nd, all ones = not
 // known; bit nd_shift + nd_bits: the suffix is smaller than its twin; [at_shift, at_shift + at_bits) first stop among the K
 // symbols, all ones = none; [56, 64) the byte in front of the suffix
@@ -111,10 +151,13 @@ struct KeyLayout { int at_shift, at_bits, nd_shift, nd_bits; u64 sortmask; };
 constexpr int ND_WORDS = 40;      // the words of the diagonal bit arrays a block of k_init_keys stages: KEY_TILE / 64 + up to 1536 positions ahead
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
                                                   u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
-                                                  KeyLayout ly, DiagBits dg) {
+                                                  KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off /* != NULL: twins leave (k_tw_count's scan) */) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
-    __shared__ u64 s_stop[ND_WORDS], s_exc[ND_WORDS], s_lt[ND_WORDS];
+    __shared__ u64 s_stop0[ND_WORDS + 1], s_exc[ND_WORDS], s_lt[ND_WORDS];      // (s_stop0[0] = the word in front of the tile)
+    __shared__ u64 s_tw[KEY_TILE / 64], s_keep[KEY_TILE / 64];
+    __shared__ u32 s_kpre[KEY_TILE / 64];
+    u64 *const s_stop = s_stop0 + 1;
     slut[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
@@ -129,7 +172,19 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         const bool in = w < nwords;
         s_stop[threadIdx.x] = in ? dg.stop[w] : ~0ull; s_exc[threadIdx.x] = in ? dg.exc[w] : ~0ull; s_lt[threadIdx.x] = in ? dg.lt[w] : 0ull;
     }
+    if (hint && threadIdx.x == ND_WORDS) s_stop0[0] = base > 0 ? dg.stop[base / 64 - 1] : ~0ull;
     __syncthreads();
+    if (tw_off) {
+        if (threadIdx.x < KEY_TILE / 64) {
+            const int x = threadIdx.x;
+            const int64_t w = base / 64 + x;
+            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n);
+            s_tw[x] = t; s_keep[x] = tw_range(w, dg.D, n) & ~t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 run = 0; for (int x = 0; x < KEY_TILE / 64; x++) { s_kpre[x] = run; run += (u32)__popcll(s_keep[x]); } }
+        __syncthreads();
+    }
     const u32 at_none = (1u << ly.at_bits) - 1u;
     const u32 nd_none = hint ? (1u << ly.nd_bits) - 1u : 0u;
 #pragma unroll
@@ -170,8 +225,17 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
                 }
                 prev |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
             }
-            keys[i] = key | prev;
-            vals[i] = (sav_t)i;
+            if (!tw_off) { keys[i] = key | prev; vals[i] = (sav_t)i; }
+            else {
+                // the first sample where it is, flagged when its twin leaves; what stays of the second behind it, in text order
+                const int x = k >> 6, b = k & 63;
+                const bool twin = (s_tw[x] >> b) & 1ull;
+                if (i < dg.D) { keys[i] = key | prev; vals[i] = (sav_t)i | (twin ? TW_FLAG : (sav_t)0); }
+                else if (!twin) {
+                    const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
+                    keys[o] = key | prev; vals[o] = (sav_t)i;
+                }
+            }
         }
     }
 }
@@ -419,6 +483,131 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
         head[j] = hd; seed[j] = hd ? (u32)j : 0u;
         SA[rank] = (sa_t)s;
         BWT[rank] = (uint8_t)((u32)(key >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+    }
+    const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
+    if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
+}
+// ---- the sorted list without the twins -> rank order with them (k_init_keys with tw_off) ----
+__global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt) {
+    __shared__ u32 wsum[TB / 64];
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    const u64 bal = __ballot(j < m && (vals[j] & TW_FLAG));
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+// the key k_init_keys would have given the twin of a flagged suffix: same symbols, same byte in front, same agreement, the other side
+__device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
+    const u32 none = (1u << kd.ly.nd_bits) - 1u;
+    const bool known = ((u32)(key >> kd.ly.nd_shift) & none) != none;
+    return known ? key ^ (1ull << (kd.ly.nd_shift + kd.ly.nd_bits)) : key;
+}
+// k_heads_publish over the list of m sorted pairs that lacks the twins: entry j goes to rank j + (flagged entries in front of it), a
+// flagged entry's twin to the rank behind it.  A flagged suffix alone in its group and its twin are the pair k_heads_publish finishes
+// from the keys; every other member of a group waits for the text round, which finds its key in kexp and its suffix in vexp (both in
+// rank order, written for the unfinished only).
+__global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
+                                                         uint8_t *__restrict__ head, u32 *__restrict__ seed, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
+                                                         uint8_t *__restrict__ BWT, sa_t side_sep, KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins,
+                                                         u64 *__restrict__ kexp, sav_t *__restrict__ vexp) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    __shared__ u64 s_key[TB + 4];
+    __shared__ sav_t s_val[TB + 2];
+    __shared__ u32 wsum[TB / 64];
+    {
+        const int64_t j0 = (int64_t)blockIdx.x * TB;
+        for (int k = threadIdx.x; k < TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < m) ? keys[i] : 0ull; }
+        for (int k = threadIdx.x; k < TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < m) ? vals[i] : (sav_t)0; }
+        __syncthreads();
+    }
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool in = j < m;
+    const sav_t sv = s_val[t + 1];
+    const bool flagged = in && (sv & TW_FLAG);
+    const u64 bal = __ballot(flagged);
+    if (lane == 0) wsum[wv] = (u32)__popcll(bal);
+    __syncthreads();
+    u32 before = blockoff[blockIdx.x] + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    for (int k = 0; k < wv; k++) before += wsum[k];
+    u32 lmax = 0;
+    if (in) {
+        const int64_t r = j + (int64_t)before;
+        const sav_t s = sv & ~TW_FLAG;
+        const u64 key = s_key[t + 2];
+        const u64 mk = kd.ly.sortmask;
+        const u64 k0 = key & mk;
+        const u64 km2 = j >= 2 ? s_key[t] & mk : ~k0, km1 = j >= 1 ? s_key[t + 1] & mk : ~k0;
+        const u64 kp1r = j + 1 < m ? s_key[t + 3] : ~key, kp2 = j + 2 < m ? s_key[t + 4] & mk : ~k0;
+        const u64 km1r = j >= 1 ? s_key[t + 1] : ~key;
+        const u64 kp1 = j + 1 < m ? kp1r & mk : ~k0;
+        const bool f_m1 = j >= 1 && (s_val[t] & TW_FLAG), f_p1 = j + 1 < m && (s_val[t + 2] & TW_FLAG);
+        bool hd = (j == 0) | (km1 != k0);
+        if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
+            u32 l = 0;
+            if (j > 0) {
+                if (kd.K <= 16) l = key_common_digits(km1, k0, kd);
+                else {
+                    u64 x = km1, y = k0;
+                    l = (u32)kd.K;
+                    for (int pos = kd.K - 1; pos >= 0; pos--) {
+                        const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
+                        const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
+                        x = qx; y = qy;
+                        l = (dx != dy) ? (u32)pos : l;
+                    }
+                }
+                const u32 st = key_first_stop(key, kd);
+                l = l < st ? l : st;
+            }
+            LCP[r] = (lcp_t)l;
+            lmax = l;
+        }
+        const u32 pay = (u32)(key >> 56);
+        if (flagged) {
+            const sav_t q = s + (sav_t)kd.D;
+            const u64 qkey = tw_twin_key(key, kd);
+            const bool alone = hd & (kp1 != k0);
+            int c = -1; u32 nd = 0;
+            const bool fin = twins && alone && hint_cmp(kd, (int64_t)s, key, (int64_t)q, qkey, &c, &nd);
+            const int64_t rs = r + ((fin && c >= 0) ? 1 : 0), rq = r + ((fin && c >= 0) ? 0 : 1);
+            if (fin) {
+                const u32 st = key_first_stop(key, kd);
+                const u32 l = nd < st ? nd : st;
+                LCP[r + 1] = (lcp_t)l;
+                lmax = l > lmax ? l : lmax;
+            } else { kexp[r] = key; kexp[r + 1] = qkey; vexp[r] = s; vexp[r + 1] = q; }
+            head[r] = hd; seed[r] = hd ? (u32)r : 0u;
+            head[r + 1] = fin; seed[r + 1] = fin ? (u32)(r + 1) : 0u;
+            SA[rs] = (sa_t)s; BWT[rs] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+            SA[rq] = (sa_t)q; BWT[rq] = (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u));
+        } else {
+            int64_t rank = r;
+            // a group of exactly two entries, neither flagged (a twin whose byte in front differs, two unrelated suffixes): k_heads_publish's pair
+            const bool first = twins & (km1 != k0) & (kp1 == k0) & (kp2 != k0) & !f_p1;
+            const bool second = twins & (km1 == k0) & (kp1 != k0) & (km2 != k0) & !f_m1;
+            bool fin = hd & (kp1 != k0);      // alone in its group
+            if (first | second) {
+                const sav_t ps = (first ? s_val[t + 2] : s_val[t]) & ~TW_FLAG;
+                const u64 pkey = first ? kp1r : km1r;
+                int c; u32 nd;
+                if (hint_cmp(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
+                    const int64_t base = first ? r : r - 1;
+                    rank = base + (c < 0 ? 0 : 1);
+                    if (rank != base) {
+                        const u32 st = key_first_stop(key, kd);
+                        const u32 l = nd < st ? nd : st;
+                        LCP[rank] = (lcp_t)l;
+                        lmax = l > lmax ? l : lmax;
+                    }
+                    if (second) hd = true;      // finished: a group of its own from here on
+                    fin = true;
+                }
+            }
+            if (!fin) { kexp[r] = key; vexp[r] = s; }
+            head[r] = hd; seed[r] = hd ? (u32)r : 0u;
+            SA[rank] = (sa_t)s;
+            BWT[rank] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+        }
     }
     const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
     if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
@@ -1403,12 +1592,31 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_HIP(hipGetLastError());
         dg.stop = bds.as<u64>(); dg.exc = bde.as<u64>(); dg.lt = bdl.as<u64>();
     }
+    // two samples with the hint: the twins of the second sample leave before the sort (k_tw_count / k_init_keys / k_heads_publish_tc)
+    const bool collapse = fused && kd.ly.nd_bits > 0 && kd.ns == 2 && K < 64 && kd.D > 1 && n > kd.D + 1 && !getenv("RV_NO_HEADS_FUSION") && !getenv("RV_NO_TWIN_COLLAPSE")
+                          && (sizeof(sav_t) > 4 || n < ((int64_t)1 << 31));
+    int64_t nsort = n;
+    const u32 *tw_off = nullptr;
+    if (collapse) {
+        const int64_t nw = (n + 63) / 64, ntiles = ceil_div(n, KEY_TILE);
+        DBuf &btw = ws.sa[23];
+        SA_TRY(btw.reserve((size_t)(std::max<int64_t>(ntiles, ceil_div(n, TB)) + 1) * 4 + 64));      // (also the flag counts per workgroup of k_heads_publish_tc)
+        u32 *tc = btw.as<u32>();
+        hipLaunchKernelGGL(k_tw_count, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, (const u64 *)dg.stop, nw, K, kd.D, n, tc, ntiles);
+        SA_HIP(hipGetLastError());
+        SA_HIP(hipMemsetAsync(tc + ntiles, 0, 4, q));
+        SA_TRY(rv_exclusive_sum_u32(ws, tc, tc, ntiles + 1));
+        u32 kept = 0;
+        SA_TRY(rv_read_back(ws, &kept, tc + ntiles, 4));
+        nsort = kd.D + (int64_t)kept;
+        tw_off = tc;
+    }
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg);
+                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off);
     SA_HIP(hipGetLastError());
     int in1 = 0;
-    SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), n, 0, bits, &in1));
-    s.radix_passes += (bits + 7) / 8; s.sorted_elems += n;
+    SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), nsort, 0, bits, &in1));
+    s.radix_passes += (bits + 7) / 8; s.sorted_elems += nsort;
     u64 *ks = in1 ? bk1.as<u64>() : bk0.as<u64>();
     sav_t *vs = in1 ? bv1.as<sav_t>() : bv0.as<sav_t>();
     u64 *kt = in1 ? bk0.as<u64>() : bk1.as<u64>();      // the free pair
@@ -1416,7 +1624,24 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     uint8_t *head = bhead.as<uint8_t>();
     u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
-    if (fused && kd.ly.nd_bits > 0 && !getenv("RV_NO_HEADS_FUSION")) {
+    const u64 *keys_by_rank = ks;          // what the text round reads for the members of a group
+    const sav_t *vals_by_rank = vs;
+    if (collapse) {
+        // rank of a list entry = its index + the flagged entries in front of it
+        const int64_t nb = ceil_div(nsort, TB);
+        u32 *bc = ws.sa[23].as<u32>();      // (the tile offsets of k_init_keys are used up)
+        hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)nb), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rv_exclusive_sum_u32(ws, bc, bc, nb));
+        sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)
+        static_assert(sizeof(sav_t) <= 8, "");
+        if (sizeof(sav_t) > 4) { SA_TRY(ws.sa[24].reserve((size_t)n * sizeof(sav_t))); vexp = ws.sa[24].as<sav_t>(); }
+        hipLaunchKernelGGL(k_heads_publish_tc, dim3((unsigned)nb), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, nsort, (const u32 *)bc, head, seed, LCP, SA, BWT,
+                           side_sep, kd, d_maxlcp, getenv("RV_NO_PUB_TWINS") ? 0 : 1, kt, vexp);
+        SA_HIP(hipGetLastError());
+        SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
+        keys_by_rank = kt; vals_by_rank = vexp;
+    } else if (fused && kd.ly.nd_bits > 0 && !getenv("RV_NO_HEADS_FUSION")) {
         hipLaunchKernelGGL(k_heads_publish, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
                            getenv("RV_NO_PUB_TWINS") ? 0 : 1);
         SA_HIP(hipGetLastError());
@@ -1477,7 +1702,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     SA_TRY(bP0.reserve((size_t)n * 4)); SA_TRY(bG0.reserve((size_t)n * 4));
     SA_TRY(bP1.reserve((size_t)n * 4)); SA_TRY(bG1.reserve((size_t)n * 4));
     // round-0 suffix list goes to the free value buffer `vt`
-    SA_TRY(compact(head, n, nullptr, vs, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
+    SA_TRY(compact(head, n, nullptr, vals_by_rank, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
     u32 *P = bP0.as<u32>(), *G = bG0.as<u32>(), *Pn = bP1.as<u32>(), *Gn = bG1.as<u32>();
     sav_t *S = vt;          // current list of suffixes (length m)
     sav_t *Sfree = vs;      // the other value buffer
@@ -1506,7 +1731,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
                 SA_HIP(hipGetLastError());
                 fo.pk.Tp = bTp.as<u64>(); fo.pk.blk = bBlk.as<uint8_t>();
             }
-            fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = ks; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep; fo.kd = kd;
+            fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = keys_by_rank; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep; fo.kd = kd;
             fo.h = (int)h;
             // measured (2 x 250 Mbp / 10 x 5 Mbp / 2 x 5 Mbp, ms of the whole build): first-thread pairs + self-ranking larger groups
             // 116-120 / 22.6 / 2.27; everything by the first thread (up to 8 members) 122 / 32.0 / 2.37; everything self-ranking

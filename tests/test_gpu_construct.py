@@ -268,3 +268,54 @@ def test_maxlcp_counts_the_group_heads(sa64):
     idx = feed(mod(sa64).index(), ["ACGTNACGTNACGTN", "ACGTNACGT"])
     idx.construct()
     assert idx.maxlcp == int(idx.array("LCP").max())
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("collapse", [True, False])
+def test_twins_leave_before_the_sort(monkeypatch, collapse, sa64):
+    """two samples with the diagonal hint: the suffixes of the second sample that carry their homologue's first key are not
+    sorted (k_tw_count / k_init_keys / k_heads_publish_tc) -- SA, LCP, the largest LCP and the matches equal the oracle's on
+    related samples of equal and different length, identical samples, N runs and lower case next to the tile and word borders,
+    a second sample longer than twice the first, and inputs of a few bases"""
+    if not collapse:
+        monkeypatch.setenv("RV_NO_TWIN_COLLAPSE", "1")
+    rng = np.random.default_rng(23)
+
+    def rnd(L):
+        return "".join("ACGT"[x] for x in rng.integers(0, 4, L))
+
+    def snp(s, rate):
+        a = list(s)
+        for p in np.nonzero(rng.random(len(a)) < rate)[0]:
+            a[p] = "ACGT"[rng.integers(0, 4)]
+        return "".join(a)
+    base = rnd(70000)
+    cases = [
+        [base, snp(base, 0.01)],
+        [base, base],
+        [base[:40000], snp(base, 0.01)],                                   # the second sample longer
+        [base, snp(base[:25000], 0.02)],                                   # ... shorter
+        [base[:9000], snp(base[:9000], 0.01) + rnd(30000)],                # ... longer than twice the first
+        [base[:1023] + "N" * 3 + base[1026:5000], snp(base[:5000], 0.005)],
+        [base[:63] + "n" + base[64:3000], base[:3000]],
+        [base[:2048], base[1:2049]],                                       # related on another diagonal only
+        ["ACGTACGTACGTACGTACGTACGT" * 50, "ACGTACGTACGTACGTACGTACGT" * 50],
+        ["ACGTA", "ACGTA"], ["A", "A"], ["ACGTACGTACGTACGTAC", "ACGTACGTACGTACGTAC"],
+    ]
+    for seqs in cases:
+        T, nsep, nodes = assemble(seqs, toupper=False)
+        O = oracle(sa64)
+        c = O.construct(T, nsep, 2)
+        idx = mod(sa64).index()
+        for k, s_ in enumerate(seqs):
+            idx.addsample("s%d" % k)
+            idx.addsequence(s_)
+        idx.construct()
+        tag = (len(seqs[0]), len(seqs[1]))
+        assert np.array_equal(idx.array("SA"), c["SA"]), tag
+        assert np.array_equal(idx.array("LCP"), c["LCP"]), tag
+        assert idx.maxlcp == int(c["LCP"].max()), tag
+        l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 20)
+        assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))], tag
+        if collapse and len(seqs[0]) == 70000 and len(seqs[1]) == 70000:
+            assert idx.sa_stats()["sorted_elems"] < idx.n, idx.sa_stats()      # some twins did leave

@@ -33,6 +33,7 @@ ENVS = [
     {"RV_CASCADE_DANGER": "2"},                           # every undecided sub-index decided from its witnesses where they can be (k_cas_dwalk)
     {"RV_CASCADE_DANGER": "2", "RV_CASCADE_DANGER_MIN": "300", "RV_CASCADE_SECOND_OFF": "1"},
     {"RV_NO_TWIN_COLLAPSE": "1"},                         # every suffix of the second sample through the radix sort
+    {"RV_NO_SHORT_ALPHABET": "1"},                        # a digit value of its own for "past the end"
 ]
 
 

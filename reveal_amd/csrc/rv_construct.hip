@@ -254,7 +254,7 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 constexpr int HINT_K = 16;      // samples the diagonal hint knows (the first ones)
 // D: diagonal of the second sample against the first (nsep[0] + 1).  ns / sep / Ds: samples, their separators and every sample's
 // diagonal against the FIRST sample (Ds[s] = nsep[s-1] + 1, where sample s starts when every sample is one sequence)
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[4], pmagic[4]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[5], pmagic[5]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
 __device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
     const u32 none = (1u << kd.ly.at_bits) - 1u;
@@ -268,12 +268,12 @@ __device__ inline bool key_hint(u64 key, const KeyDigits &kd, u32 *nd, bool *lt)
     *nd = v; *lt = (key >> (kd.ly.nd_shift + kd.ly.nd_bits)) & 1ull;
     return kd.ly.nd_bits > 0 && v != none;
 }
-// number of leading digits (of K) two keys share: both are taken apart from the top, 8 / 4 / 2 / 1 digits at a time (as 16-digit
-// numbers with leading zeros), following the half that differs -- four rounds of two divisions instead of K
+// number of leading digits (of K <= 32) two keys share: both are taken apart from the top, 16 / 8 / 4 / 2 / 1 digits at a time (as 32-digit
+// numbers with leading zeros), following the half that differs -- five rounds of two divisions instead of K
 __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
     u32 cnt = 0;
 #pragma unroll
-    for (int st = 0; st < 4; st++) {
+    for (int st = 0; st < 5; st++) {
         const u64 d = kd.pw[st], mg = kd.pmagic[st];
         u64 qx = __umul64hi(x, mg), qy = __umul64hi(y, mg);
         u64 rx = x - qx * d, ry = y - qy * d;
@@ -281,10 +281,10 @@ __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
         if ((int64_t)rx < 0) { qx--; rx += d; }
         if ((int64_t)ry < 0) { qy--; ry += d; }
         const bool top = qx != qy;            // the difference lies in the upper half
-        cnt += top ? 0u : (8u >> st);
+        cnt += top ? 0u : (16u >> st);
         x = top ? qx : rx; y = top ? qy : ry;
     }
-    return cnt - (16u - (u32)kd.K);
+    return cnt - (32u - (u32)kd.K);
 }
 // The diagonal hint for any number of samples: a suffix of sample s >= 1 carries how far it agrees with its homologue in the FIRST
 // sample (position - Ds[s]) and whether it is the smaller of the two; a suffix of the first sample carries the same against its
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     if (LCP && hd) {
         if (j > 0) {
             const u64 dm = kd.ly.sortmask;
-            if (kd.K <= 16) {
+            if (kd.K <= 32) {
                 l = key_common_digits(ka & dm, kb & dm, kd);
             } else {      // (tiny alphabets: more than 16 symbols in 48 bits) digit by digit
                 u64 x = ka & dm, y = kb & dm;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
         if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
             u32 l = 0;
             if (j > 0) {
-                if (kd.K <= 16) l = key_common_digits(km1, k0, kd);
+                if (kd.K <= 32) l = key_common_digits(km1, k0, kd);
                 else {
                     u64 x = km1, y = k0;
                     l = (u32)kd.K;
@@ -494,6 +494,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
     if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
 }
 // ---- the sorted list without the twins -> rank order with them (k_init_keys with tw_off) ----
+constexpr int TC_TILE = TB;
 __global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt) {
     __shared__ u32 wsum[TB / 64];
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
@@ -511,9 +512,11 @@ __device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
 // k_heads_publish over the list of m sorted pairs that lacks the twins: entry j goes to rank j + (flagged entries in front of it), a
 // flagged entry's twin to the rank behind it.  A flagged suffix alone in its group and its twin are the pair k_heads_publish finishes
 // from the keys; every other member of a group waits for the text round, which finds its key in kexp and its suffix in vexp (both in
-// rank order, written for the unfinished only).
+// rank order, written for the unfinished only).  No group ranks: the compaction of the unfinished reads them off the head flags (k_cp_emit_g).
+// (Laying a round's ranks out in LDS first and writing whole runs made no difference -- switching the writes off altogether takes 0.1 of
+// 12 ms at 2 x 100 Mbp: the kernel waits for its keys, not for its stores.)
 __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
-                                                         uint8_t *__restrict__ head, u32 *__restrict__ seed, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
+                                                         uint8_t *__restrict__ head, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
                                                          uint8_t *__restrict__ BWT, sa_t side_sep, KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins,
                                                          u64 *__restrict__ kexp, sav_t *__restrict__ vexp) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
@@ -582,8 +585,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 LCP[r + 1] = (lcp_t)l;
                 lmax = l > lmax ? l : lmax;
             } else { kexp[r] = key; kexp[r + 1] = qkey; vexp[r] = s; vexp[r + 1] = q; }
-            head[r] = hd; seed[r] = hd ? (u32)r : 0u;
-            head[r + 1] = fin; seed[r + 1] = fin ? (u32)(r + 1) : 0u;
+            head[r] = hd; head[r + 1] = fin;
             SA[rs] = (sa_t)s; BWT[rs] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
             SA[rq] = (sa_t)q; BWT[rq] = (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u));
         } else {
@@ -610,13 +612,27 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 }
             }
             if (!fin) { kexp[r] = key; vexp[r] = s; }
-            head[r] = hd; seed[r] = hd ? (u32)r : 0u;
+            head[r] = hd;
             SA[rank] = (sa_t)s;
             BWT[rank] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
         }
     }
     const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
     if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
+}
+// the start of every rank's group read off the head flags: what the max-scan over the seeds gave (a 4-byte word per rank written,
+// scanned and read again) for the compaction of the unfinished ranks of round 0 -- per tile the last head, a scan over the tiles, and
+// inside the tile the nearest head in front of a rank from the waves' ballots
+__global__ __launch_bounds__(TB) void k_cp_count_g(const uint8_t *__restrict__ head, int64_t n, u32 *__restrict__ tilecnt, u32 *__restrict__ tilelast);
+__global__ __launch_bounds__(TB) void k_cp_emit_g(const uint8_t *__restrict__ head, int64_t n, const u32 *__restrict__ tileoff, const u32 *__restrict__ tilelast,
+                                                  const sav_t *__restrict__ suf_in, u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G);
+__global__ __launch_bounds__(TB) void k_isa_identity(const sa_t *__restrict__ SA, int64_t n, u32 *__restrict__ ISA) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j < n) ISA[SA[j]] = (u32)j;
+}
+__global__ __launch_bounds__(TB) void k_isa_list(const sa_t *__restrict__ SA, const u32 *__restrict__ P, const u32 *__restrict__ G, int64_t m, u32 *__restrict__ ISA) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (q < m) ISA[SA[P[q]]] = G[q];
 }
 // Group ranks are rank ranges and every round only permutes suffixes inside their group, so (SA, grp of round 0) still
 // describe round 0's ISA after the text round has reordered SA.
@@ -685,6 +701,64 @@ __global__ __launch_bounds__(TB) void k_cp_emit(const uint8_t *__restrict__ head
             G[q] = grp_in[j];
         }
         run += tot;
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(TB) void k_cp_count_g(const uint8_t *__restrict__ head, int64_t n, u32 *__restrict__ tilecnt, u32 *__restrict__ tilelast) {
+    __shared__ u32 wsum[TB / 64], wlast[TB / 64];
+    static_assert(CP_ITEMS == 8, "eight head bytes per load");
+    const int64_t j0 = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;
+    u32 c = 0, last = 0;      // last = position of the last head among my entries + 1
+    if (j0 + CP_ITEMS < n) {      // (k_cp_count's load: eight flags and the one behind them)
+        const u64 hb = *reinterpret_cast<const u64 *>(head + j0);
+        const u64 nx = (hb >> 8) | ((u64)head[j0 + CP_ITEMS] << 56);
+#pragma unroll
+        for (int k = 0; k < CP_ITEMS; k++) c += !(((hb >> (8 * k)) & 0xFFu) && ((nx >> (8 * k)) & 0xFFu));
+        if (hb) last = (u32)(j0 + ((63 - __builtin_clzll(hb)) >> 3) + 1);
+    } else {
+        for (int64_t j = j0; j < j0 + CP_ITEMS && j < n; j++) { c += unsorted_at(head, j, n); last = head[j] ? (u32)(j + 1) : last; }
+    }
+    for (int d = 32; d >= 1; d >>= 1) { c += __shfl_down(c, d, 64); const u32 o = __shfl_down(last, d, 64); last = o > last ? o : last; }
+    if ((threadIdx.x & 63) == 0) { wsum[threadIdx.x >> 6] = c; wlast[threadIdx.x >> 6] = last; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        tilecnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        u32 l = wlast[0];
+        for (int k = 1; k < TB / 64; k++) l = wlast[k] > l ? wlast[k] : l;
+        tilelast[blockIdx.x] = l;
+    }
+}
+// tilelast: inclusive maximum over the tiles (so tile t starts behind tilelast[t - 1])
+__global__ __launch_bounds__(TB) void k_cp_emit_g(const uint8_t *__restrict__ head, int64_t n, const u32 *__restrict__ tileoff, const u32 *__restrict__ tilelast,
+                                                  const sav_t *__restrict__ suf_in, u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G) {
+    __shared__ u32 wbase[TB / 64], wlast[TB / 64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
+    u32 run = tileoff[blockIdx.x];
+    u32 seen = blockIdx.x ? tilelast[blockIdx.x - 1] : 0u;      // last head in front of the round (position + 1)
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const u64 le = lt | (1ull << lane);
+#pragma unroll 1
+    for (int r = 0; r < CP_ITEMS; r++) {
+        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
+        const bool hd = j < n && head[j];
+        const bool f = (j < n) && unsorted_at(head, j, n);
+        const u64 bal = __ballot(f), bh = __ballot(hd);
+        if (lane == 0) { wbase[w] = (u32)__popcll(bal); wlast[w] = bh ? (u32)(j + (63 - __builtin_clzll(bh)) + 1) : 0u; }      // (lane 0: j is the wave's first entry)
+        __syncthreads();
+        u32 before = 0, tot = 0, prev = seen, all = seen;
+#pragma unroll
+        for (int k = 0; k < TB / 64; k++) { const u32 c = wbase[k]; if (k < w) { before += c; prev = wlast[k] > prev ? wlast[k] : prev; } tot += c; all = wlast[k] > all ? wlast[k] : all; }
+        if (f) {
+            const u64 mine = bh & le;
+            const u32 g1 = mine ? (u32)(j - lane + (63 - __builtin_clzll(mine)) + 1) : prev;
+            const u32 q = run + before + (u32)__popcll(bal & lt);
+            P[q] = (u32)j;
+            S[q] = suf_in[j];
+            G[q] = g1 - 1u;
+        }
+        run += tot; seen = all;
         __syncthreads();
     }
 }
@@ -1578,9 +1652,9 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     const bool want_hint = fused && kd.D > 0 && kd.ns >= 2 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !getenv("RV_NO_DIAG") && !getenv("RV_NO_PACKED_TEXT");
     if (want_hint) kd.ly.nd_bits = std::min(kd.ly.at_shift - kd.ly.nd_shift - 1, 11);
     kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
-    for (int st = 0; st < 4; st++) {
+    for (int st = 0; st < 5; st++) {
         u64 d = 1;
-        for (int e = 0; e < (8 >> st); e++) d = d > (~0ull) / radix ? ~0ull : d * radix;      // (saturates for large alphabets: nothing is ever that large then)
+        for (int e = 0; e < (16 >> st); e++) d = d > (~0ull) / radix ? ~0ull : d * radix;      // (saturates for large alphabets: nothing is ever that large then)
         kd.pw[st] = d; kd.pmagic[st] = d == ~0ull ? 0ull : (~0ull) / d + 1;
     }
     if (fused) RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
@@ -1646,18 +1720,16 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     const sav_t *vals_by_rank = vs;
     if (collapse) {
         // rank of a list entry = its index + the flagged entries in front of it
-        const int64_t nb = ceil_div(nsort, TB);
+        const int64_t nb = ceil_div(nsort, TC_TILE);
         u32 *bc = ws.sa[23].as<u32>();      // (the tile offsets of k_init_keys are used up)
         hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)nb), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_exclusive_sum_u32(ws, bc, bc, nb));
         sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)
-        static_assert(sizeof(sav_t) <= 8, "");
         if (sizeof(sav_t) > 4) { SA_TRY(ws.sa[24].reserve((size_t)n * sizeof(sav_t))); vexp = ws.sa[24].as<sav_t>(); }
-        hipLaunchKernelGGL(k_heads_publish_tc, dim3((unsigned)nb), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, nsort, (const u32 *)bc, head, seed, LCP, SA, BWT,
+        hipLaunchKernelGGL(k_heads_publish_tc, dim3((unsigned)nb), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, nsort, (const u32 *)bc, head, LCP, SA, BWT,
                            side_sep, kd, d_maxlcp, getenv("RV_NO_PUB_TWINS") ? 0 : 1, kt, vexp);
         SA_HIP(hipGetLastError());
-        SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
         keys_by_rank = kt; vals_by_rank = vexp;
     } else if (fused && kd.ly.nd_bits > 0 && !getenv("RV_NO_HEADS_FUSION")) {
         hipLaunchKernelGGL(k_heads_publish, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
@@ -1677,17 +1749,28 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_HIP(hipGetLastError());
     }
     bool isa_built = false;
+    const u32 *list0_P = nullptr, *list0_G = nullptr; int64_t list0_m = 0;      // the round-0 list (collapse: no group ranks per rank, the list has them for the unfinished)
     auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)
         if (isa_built) return 0;
-        hipLaunchKernelGGL(k_isa_from_groups, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, (const u32 *)grp, n, ISA);
-        RV_LAUNCH_CHECK();
+        if (collapse) {
+            // a finished rank is a group of its own; the unfinished are in the round-0 list, which still stands while this is false
+            hipLaunchKernelGGL(k_isa_identity, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, n, ISA);
+            RV_LAUNCH_CHECK();
+            if (list0_m > 0) {
+                hipLaunchKernelGGL(k_isa_list, dim3((unsigned)ceil_div(list0_m, TB)), dim3(TB), 0, q, (const sa_t *)SA, list0_P, list0_G, list0_m, ISA);
+                RV_LAUNCH_CHECK();
+            }
+        } else {
+            hipLaunchKernelGGL(k_isa_from_groups, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, (const u32 *)grp, n, ISA);
+            RV_LAUNCH_CHECK();
+        }
         isa_built = true;
         return 0;
     };
 
     // -- compaction of the non-unique suffixes (round 0: from the full arrays)
     int64_t ntile = ceil_div(n, CP_TILE);
-    SA_TRY(btile.reserve(std::max((size_t)(ntile + 1) * 4, (size_t)RT_REGIONS * 4)));      // (also the work-list counters of the text round)
+    SA_TRY(btile.reserve(std::max((size_t)(ntile + 1) * 8 + 64, (size_t)RT_REGIONS * 4)));      // (also the work-list counters of the text round; twice: the tiles' last heads)
     u32 *tile = btile.as<u32>();
     // compaction of the not yet unique suffixes in two steps, so that a round that leaves nothing behind can stop
     // before it updates ISA
@@ -1720,6 +1803,24 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     SA_TRY(bP0.reserve((size_t)n * 4)); SA_TRY(bG0.reserve((size_t)n * 4));
     SA_TRY(bP1.reserve((size_t)n * 4)); SA_TRY(bG1.reserve((size_t)n * 4));
     // round-0 suffix list goes to the free value buffer `vt`
+    if (collapse) {
+        // group ranks from the head flags (k_cp_emit_g)
+        u32 *tlast = tile + (ntile + 1);
+        hipLaunchKernelGGL(k_cp_count_g, dim3((unsigned)ntile), dim3(TB), 0, q, (const uint8_t *)head, n, tile, tlast);
+        SA_HIP(hipGetLastError());
+        SA_HIP(hipMemsetAsync(tile + ntile, 0, 4, q));
+        SA_TRY(rv_exclusive_sum_u32(ws, tile, tile, ntile + 1));
+        SA_TRY(rv_inclusive_max_u32(ws, tlast, tlast, ntile));
+        u32 tot = 0;
+        SA_TRY(rv_read_back(ws, &tot, tile + ntile, 4));
+        m = tot;
+        if (m > 0) {
+            hipLaunchKernelGGL(k_cp_emit_g, dim3((unsigned)ntile), dim3(TB), 0, q, (const uint8_t *)head, n, (const u32 *)tile, (const u32 *)tlast, vals_by_rank,
+                               bP0.as<u32>(), vt, bG0.as<u32>());
+            SA_HIP(hipGetLastError());
+        }
+        list0_P = bP0.as<u32>(); list0_G = bG0.as<u32>(); list0_m = m;
+    } else
     SA_TRY(compact(head, n, nullptr, vals_by_rank, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
     u32 *P = bP0.as<u32>(), *G = bG0.as<u32>(), *Pn = bP1.as<u32>(), *Gn = bG1.as<u32>();
     sav_t *S = vt;          // current list of suffixes (length m)

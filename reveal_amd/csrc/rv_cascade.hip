@@ -112,11 +112,30 @@ constexpr int WT_TILE = TB * WT_ITEMS;
 constexpr int WT_REGIONS = 64;
 __global__ __launch_bounds__(TB) void k_cas_witness(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t n,
                                                     u32 minl, sa_t *__restrict__ w_pos, u32 *__restrict__ w_val, u32 *__restrict__ w_rank, u32 cap /* per region */, u32 *__restrict__ counters /* one per region */) {
-    __shared__ u32 sl[WT_TILE + 3];          // LCP of ranks j0-1 .. j0+TILE+1 (0 outside the array)
-    __shared__ uint8_t ss[WT_TILE + 2];      // side bit of ranks j0-1 .. j0+TILE
+    __shared__ __attribute__((aligned(16))) u32 sl0[WT_TILE + 8];          // sl = sl0 + 3: LCP of ranks j0-1 .. j0+TILE+1 (0 outside the array)
+    __shared__ __attribute__((aligned(16))) uint8_t ss0[WT_TILE + 32];     // ss = ss0 + 15: side bit of ranks j0-1 .. j0+TILE
+    u32 *const sl = sl0 + 3;
+    uint8_t *const ss = ss0 + 15;
     const int64_t j0 = (int64_t)blockIdx.x * WT_TILE;
-    for (int k = threadIdx.x; k < WT_TILE + 3; k += TB) { const int64_t j = j0 - 1 + k; sl[k] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
-    for (int k = threadIdx.x; k < WT_TILE + 2; k += TB) { const int64_t j = j0 - 1 + k; ss[k] = (j >= 0 && j < n) ? (uint8_t)(BWT[j] >> 7) : (uint8_t)0; }
+    if (j0 + WT_TILE + 2 <= n && sizeof(lcp_t) == 4) {
+        // the tile's body in 16-byte loads (its ranks start at a multiple of the tile size), the three ranks around it one by one: loaded
+        // entry by entry the kernel ran at 2 TB/s
+        const uint4 *L4 = reinterpret_cast<const uint4 *>(LCP + j0);
+        uint4 *d4 = reinterpret_cast<uint4 *>(sl + 1);
+        for (int k = threadIdx.x; k < WT_TILE / 4; k += TB) d4[k] = L4[k];
+        const uint4 *B4 = reinterpret_cast<const uint4 *>(BWT + j0);
+        for (int k = threadIdx.x; k < WT_TILE / 16; k += TB) {
+            uint4 v = B4[k];
+            v.x = (v.x >> 7) & 0x01010101u; v.y = (v.y >> 7) & 0x01010101u; v.z = (v.z >> 7) & 0x01010101u; v.w = (v.w >> 7) & 0x01010101u;
+            reinterpret_cast<uint4 *>(ss + 1)[k] = v;
+        }
+        if (threadIdx.x == 0) { sl[0] = j0 > 0 ? (u32)LCP[j0 - 1] : 0u; ss[0] = j0 > 0 ? (uint8_t)(BWT[j0 - 1] >> 7) : (uint8_t)0; }
+        if (threadIdx.x == 1) { sl[WT_TILE + 1] = (u32)LCP[j0 + WT_TILE]; ss[WT_TILE + 1] = (uint8_t)(BWT[j0 + WT_TILE] >> 7); }
+        if (threadIdx.x == 2) sl[WT_TILE + 2] = (u32)LCP[j0 + WT_TILE + 1];
+    } else {
+        for (int k = threadIdx.x; k < WT_TILE + 3; k += TB) { const int64_t j = j0 - 1 + k; sl[k] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
+        for (int k = threadIdx.x; k < WT_TILE + 2; k += TB) { const int64_t j = j0 - 1 + k; ss[k] = (j >= 0 && j < n) ? (uint8_t)(BWT[j] >> 7) : (uint8_t)0; }
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));

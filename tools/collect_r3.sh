@@ -22,3 +22,5 @@ python tools/pmc_all.py $OUT/pmc_fetch $OUT/pmc_write 40 > $OUT/pmc_traffic_c4.t
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
 python bench.py --sa64 --L 1100000000 --steps 3 --warmup 1 --no-cpu > $OUT/bench_sa64_2x1100M.json 2> $OUT/bench_sa64_2x1100M.err
 RV_BENCH_SHARE_GPU=1 python bench.py --gpus 2 --L 60000000 --steps 2 --warmup 1 --no-cpu > $OUT/bench_2ranks_shared_gpu.json 2> $OUT/bench_2ranks_shared_gpu.err
+python tools/realistic_probe.py > $OUT/realistic_probe.txt 2> $OUT/realistic_probe.err
+python tools/latency_probe.py > $OUT/latency_small.txt 2> $OUT/latency_small.err

@@ -157,7 +157,7 @@ struct KeyLayout { int at_shift, at_bits, nd_shift, nd_bits; u64 sortmask; };
 constexpr int ND_WORDS = 40;      // the words of the diagonal bit arrays a block of k_init_keys stages: KEY_TILE / 64 + up to 1536 positions ahead
 __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
                                                   u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
-                                                  KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off /* != NULL: twins leave (k_tw_count's scan) */) {
+                                                  KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off /* != NULL: twins leave (k_tw_count's scan) */, u64 top_pow /* radix^(K-1) */) {
     __shared__ uint8_t code[KEY_TILE + 64];
     __shared__ uint8_t slut[256];
     __shared__ u64 s_stop0[ND_WORDS + 1], s_exc[ND_WORDS], s_lt[ND_WORDS];      // (s_stop0[0] = the word in front of the tile)
@@ -193,27 +193,54 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
     }
     const u32 at_none = (1u << ly.at_bits) - 1u;
     const u32 nd_none = hint ? (1u << ly.nd_bits) - 1u : 0u;
+    // A thread takes four positions in a row: the first key from its K symbols, the next three from the one before (drop the leading
+    // symbol, shift, take the next one in) -- K multiply-adds per key made the kernel instruction-bound (3.9 ms for 4.8 GB at 2 x 250 Mbp);
+    // the first stop among the K symbols and the next marked position of the hint move along the same way.
+    constexpr int PER = KEY_TILE / TB;
+    const int k0 = (int)threadIdx.x * PER;
+    u64 okey[PER]; sav_t oval[PER]; bool oin[PER];
+    u64 key = 0;
+    u32 at = at_none;          // first of the K symbols that is a stop ('$', 'N', past the end)
+    int yy = -1;               // the hint's next marked position (tile coordinates), -1: to be looked for
+    u32 prevb = 0;             // the bytes in front of the four positions
+    if (pay) {
+        const int64_t i0 = base + k0;
+        if (i0 >= 1 && i0 + PER - 1 <= n) __builtin_memcpy(&prevb, T + i0 - 1, 4);
+        else for (int r = 0; r < PER; r++) { const int64_t i = i0 + r; prevb |= (u32)((i > 0 && i <= n) ? T[i - 1] : (uint8_t)'$') << (8 * r); }
+    }
+    static_assert(PER == 4, "four bytes in front of four positions");
 #pragma unroll
-    for (int r = 0; r < KEY_TILE / TB; r++) {
-        const int k = r * TB + threadIdx.x;
+    for (int r = 0; r < PER; r++) {
+        const int k = k0 + r;
         const int64_t i = base + k;
-        if (i < n) {
-            u64 key = 0;
-            u32 at = at_none;          // first of the K symbols that is a stop ('$', 'N', past the end)
+        oin[r] = i < n;
+        if (r == 0) {
             for (int j = 0; j < K; j++) {
                 const u32 c = code[k + j];
                 key = key * radix + c;
                 at = ((at == at_none) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at;
             }
-            // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
-            // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Below it (the
-            // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --
-            // k_heads and the text round read it instead of taking the key apart digit by digit (a function of the digits:
-            // keys that are equal in their digits are equal here too)
-            u64 prev = pay ? ((u64)(i > 0 ? T[i - 1] : (uint8_t)'$') << 56) | ((u64)at << ly.at_shift) : 0ull;
-            if (hint) {
-                // next marked position at or behind i, looked for in the staged words
-                u32 nd = nd_none, ltb = 0;
+        } else {
+            const u32 c_out = code[k - 1], c_in = code[k - 1 + K];
+            key = (key - (u64)c_out * top_pow) * radix + c_in;
+            const bool in_stop = (c_in == stop0) | (c_in == stop1) | (c_in == 0u);
+            if (at == at_none) at = in_stop ? (u32)(K - 1) : at_none;
+            else if (at > 0) at -= 1;
+            else {      // the symbol that left was the first stop: look again
+                at = at_none;
+                for (int j = 0; j < K; j++) { const u32 c = code[k + j]; at = ((at == at_none) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at; }
+            }
+        }
+        // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
+        // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Below it (the
+        // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --
+        // k_heads and the text round read it instead of taking the key apart digit by digit (a function of the digits:
+        // keys that are equal in their digits are equal here too)
+        u64 prev = pay ? ((u64)((prevb >> (8 * r)) & 0xffu) << 56) | ((u64)at << ly.at_shift) : 0ull;
+        if (hint) {
+            // next marked position at or behind i, looked for in the staged words
+            u32 nd = nd_none, ltb = 0;
+            if (yy < k) {
                 int wi = k >> 6;
                 u64 mw = s_stop[wi] >> (k & 63);
                 int dist = 0;
@@ -224,23 +251,45 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
                     while (ww < ND_WORDS && s_stop[ww] == 0ull && dist < (int)nd_none) { dist += 64; ww++; }
                     if (ww < ND_WORDS && s_stop[ww] != 0ull) dist += __builtin_ctzll(s_stop[ww]); else dist = (int)nd_none;
                 }
-                if (dist < (int)nd_none) {
-                    const int yy = k + dist;
-                    const bool ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull;
-                    if (!ex) { nd = (u32)dist; ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
-                }
-                prev |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
+                yy = dist < (int)nd_none ? k + dist : -1;
             }
-            if (!tw_off) { keys[i] = key | prev; vals[i] = (sav_t)i; }
-            else {
-                // the first sample where it is, flagged when its twin leaves; what stays of the second behind it, in text order
-                const int x = k >> 6, b = k & 63;
-                const bool twin = (s_tw[x] >> b) & 1ull;
-                if (i < dg.D) { keys[i] = key | prev; vals[i] = (sav_t)i | (twin ? TW_FLAG : (sav_t)0); }
-                else if (!twin) {
-                    const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
-                    keys[o] = key | prev; vals[o] = (sav_t)i;
-                }
+            if (yy >= k && yy - k < (int)nd_none) {
+                const bool ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull;
+                if (!ex) { nd = (u32)(yy - k); ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
+            }
+            prev |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
+        }
+        okey[r] = key | prev; oval[r] = (sav_t)i;
+    }
+    const int64_t i0 = base + k0;
+    if (!tw_off || i0 + PER <= dg.D) {
+        // where they are (the first sample flagged when its twin leaves)
+        if (tw_off) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) { const int k = k0 + r; if ((s_tw[k >> 6] >> (k & 63)) & 1ull) oval[r] |= TW_FLAG; }
+        }
+        if (i0 + PER <= n) {
+            ulonglong2 *kd2 = reinterpret_cast<ulonglong2 *>(keys + i0);
+            kd2[0] = make_ulonglong2(okey[0], okey[1]); kd2[1] = make_ulonglong2(okey[2], okey[3]);
+#pragma unroll
+            for (int r = 0; r < PER; r++) vals[i0 + r] = oval[r];
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) if (oin[r]) { keys[i0 + r] = okey[r]; vals[i0 + r] = oval[r]; }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            if (!oin[r]) continue;
+            const int k = k0 + r;
+            const int64_t i = base + k;
+            const int x = k >> 6, b = k & 63;
+            const bool twin = (s_tw[x] >> b) & 1ull;
+            if (i < dg.D) { keys[i] = okey[r]; vals[i] = oval[r] | (twin ? TW_FLAG : (sav_t)0); }
+            else if (!twin) {
+                // what stays of the second sample behind the first, in text order
+                const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
+                keys[o] = okey[r]; vals[o] = (sav_t)i;
             }
         }
     }
@@ -729,37 +778,55 @@ __global__ __launch_bounds__(TB) void k_cp_count_g(const uint8_t *__restrict__ h
         tilelast[blockIdx.x] = l;
     }
 }
-// tilelast: inclusive maximum over the tiles (so tile t starts behind tilelast[t - 1])
+// tilelast: inclusive maximum over the tiles (so tile t starts behind tilelast[t - 1]).  A thread takes eight flags in a row from one load
+// (entry by entry, 256 at a time with two ballots and two barriers each, the kernel moved 0.6 TB/s).
 __global__ __launch_bounds__(TB) void k_cp_emit_g(const uint8_t *__restrict__ head, int64_t n, const u32 *__restrict__ tileoff, const u32 *__restrict__ tilelast,
                                                   const sav_t *__restrict__ suf_in, u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G) {
-    __shared__ u32 wbase[TB / 64], wlast[TB / 64];
+    __shared__ u32 wcnt[TB / 64], wlast[TB / 64];
+    static_assert(CP_ITEMS == 8, "eight head bytes per load");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t base = (int64_t)blockIdx.x * CP_TILE;
-    u32 run = tileoff[blockIdx.x];
-    u32 seen = blockIdx.x ? tilelast[blockIdx.x - 1] : 0u;      // last head in front of the round (position + 1)
-    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const u64 le = lt | (1ull << lane);
-#pragma unroll 1
-    for (int r = 0; r < CP_ITEMS; r++) {
-        const int64_t j = base + (int64_t)r * TB + threadIdx.x;
-        const bool hd = j < n && head[j];
-        const bool f = (j < n) && unsorted_at(head, j, n);
-        const u64 bal = __ballot(f), bh = __ballot(hd);
-        if (lane == 0) { wbase[w] = (u32)__popcll(bal); wlast[w] = bh ? (u32)(j + (63 - __builtin_clzll(bh)) + 1) : 0u; }      // (lane 0: j is the wave's first entry)
-        __syncthreads();
-        u32 before = 0, tot = 0, prev = seen, all = seen;
+    const int64_t j0 = (int64_t)blockIdx.x * CP_TILE + (int64_t)threadIdx.x * CP_ITEMS;
+    u32 hm = 0, um = 0;      // bit k: entry j0 + k is a head / is not finished
+    if (j0 + CP_ITEMS < n) {
+        const u64 hb = *reinterpret_cast<const u64 *>(head + j0);
+        const u64 nx = (hb >> 8) | ((u64)head[j0 + CP_ITEMS] << 56);
 #pragma unroll
-        for (int k = 0; k < TB / 64; k++) { const u32 c = wbase[k]; if (k < w) { before += c; prev = wlast[k] > prev ? wlast[k] : prev; } tot += c; all = wlast[k] > all ? wlast[k] : all; }
-        if (f) {
-            const u64 mine = bh & le;
-            const u32 g1 = mine ? (u32)(j - lane + (63 - __builtin_clzll(mine)) + 1) : prev;
-            const u32 q = run + before + (u32)__popcll(bal & lt);
+        for (int k = 0; k < CP_ITEMS; k++) {
+            const bool h = (hb >> (8 * k)) & 0xFFu, hn = (nx >> (8 * k)) & 0xFFu;
+            hm |= (u32)h << k; um |= (u32)!(h && hn) << k;
+        }
+    } else {
+        for (int k = 0; k < CP_ITEMS; k++) { const int64_t j = j0 + k; if (j < n) { hm |= (u32)(head[j] != 0) << k; um |= (u32)unsorted_at(head, j, n) << k; } }
+    }
+    const u32 c = (u32)__popc(um);
+    const u32 mylast = hm ? (u32)(j0 + (31 - __clz(hm)) + 1) : 0u;      // position of my last head + 1
+    // exclusive prefix of the counts and running maximum of the last heads, over the wave
+    u32 inc = c, lastinc = mylast;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d, 64), l = __shfl_up(lastinc, d, 64);
+        if (lane >= d) { inc += t; lastinc = l > lastinc ? l : lastinc; }
+    }
+    if (lane == 63) { wcnt[w] = inc; wlast[w] = lastinc; }
+    __syncthreads();
+    u32 before = inc - c;
+    u32 prevlast = __shfl_up(lastinc, 1, 64);
+    if (lane == 0) prevlast = 0;
+    u32 seen = blockIdx.x ? tilelast[blockIdx.x - 1] : 0u;
+    for (int k = 0; k < w; k++) { before += wcnt[k]; seen = wlast[k] > seen ? wlast[k] : seen; }
+    prevlast = prevlast > seen ? prevlast : seen;               // last head in front of my eight entries (position + 1)
+    u32 q = tileoff[blockIdx.x] + before;
+    u32 cur = prevlast;
+#pragma unroll
+    for (int k = 0; k < CP_ITEMS; k++) {
+        const int64_t j = j0 + k;
+        if ((hm >> k) & 1u) cur = (u32)(j + 1);
+        if ((um >> k) & 1u) {
             P[q] = (u32)j;
             S[q] = suf_in[j];
-            G[q] = g1 - 1u;
+            G[q] = cur - 1u;
+            q++;
         }
-        run += tot; seen = all;
-        __syncthreads();
     }
 }
 
@@ -1706,8 +1773,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         nsort = kd.D + (int64_t)kept;
         tw_off = tc;
     }
+    u64 top_pow = 1;
+    for (int e = 0; e + 1 < K; e++) top_pow *= radix;      // (radix^K fits 64 bits: the key does)
     hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off);
+                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, top_pow);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), nsort, 0, bits, &in1));

@@ -25,8 +25,10 @@ constexpr int TB = 256;
 
 // ---- alphabet ---------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, int64_t n, u32 *__restrict__ hist) {
-    __shared__ u32 h[256];
-    h[threadIdx.x] = 0;
+    // eight copies of the table, a lane uses copy lane & 7: a DNA text sends every lane of a wave to the same four words (0.5 GB in 0.57 ms)
+    __shared__ u32 hh[8][256];
+    for (int k = threadIdx.x; k < 8 * 256; k += TB) (&hh[0][0])[k] = 0;
+    u32 *const h = hh[threadIdx.x & 7];
     __syncthreads();
     const int64_t stride = (int64_t)gridDim.x * TB * 16;
     for (int64_t base = ((int64_t)blockIdx.x * TB + threadIdx.x) * 16; base < n; base += stride) {
@@ -48,7 +50,10 @@ __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, i
         }
     }
     __syncthreads();
-    if (h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) tot += hh[k][threadIdx.x];
+    if (tot) atomicAdd(&hist[threadIdx.x], tot);
 }
 
 // ---- first key: K symbols as digits of a base-(sigma+1) number -----------------
@@ -544,13 +549,20 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
 }
 // ---- the sorted list without the twins -> rank order with them (k_init_keys with tw_off) ----
 constexpr int TC_TILE = TB;
-__global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt) {
-    __shared__ u32 wsum[TB / 64];
-    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    const u64 bal = __ballot(j < m && (vals[j] & TW_FLAG));
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = (u32)__popcll(bal);
+__global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt, int64_t nblocks) {
+    // eight of k_heads_publish_tc's workgroups per workgroup here: eight loads in flight per thread
+    __shared__ u32 wsum[8][TB / 64];
+    const int64_t b0 = (int64_t)blockIdx.x * 8;
+    sav_t v[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const int64_t j = (b0 + r) * TB + threadIdx.x; v[r] = j < m ? vals[j] : (sav_t)0; }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u64 bal = __ballot((v[r] & TW_FLAG) != 0);
+        if ((threadIdx.x & 63) == 0) wsum[r][threadIdx.x >> 6] = (u32)__popcll(bal);
+    }
     __syncthreads();
-    if (threadIdx.x == 0) blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x < 8 && b0 + threadIdx.x < nblocks) blockcnt[b0 + threadIdx.x] = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
 }
 // the key k_init_keys would have given the twin of a flagged suffix: same symbols, same byte in front, same agreement, the other side
 __device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
@@ -1794,7 +1806,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // rank of a list entry = its index + the flagged entries in front of it
         const int64_t nb = ceil_div(nsort, TC_TILE);
         u32 *bc = ws.sa[23].as<u32>();      // (the tile offsets of k_init_keys are used up)
-        hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)nb), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc);
+        hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)ceil_div(nb, 8)), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc, nb);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_exclusive_sum_u32(ws, bc, bc, nb));
         sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)

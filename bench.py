@@ -381,6 +381,10 @@ def main():
                                        "frac_of_read_peak": (achieved / read_gbs) if read_gbs else None}},
             "breakdown_ms_per_step": breakdown,
             "roofline_other": roofline_other,
+            # the judged kernel is the scan (8 B per rank); since the anchor cascade it runs once per step, and the step's time is
+            # in the suffix-array build -- the kernel class with the most time per step and its own fraction, so the record does not hide it
+            "roofline_largest_class_by_time": (lambda k: {"class": k, **roofline_other[k]})(max(roofline_other, key=lambda k: roofline_other[k]["ms_per_step"]))
+                                              if roofline_other else None,
             "recursion": {"anchors": st["splits"], "anchored_bp": st["anchored_bp"], "levels": st["levels"], "subindices": st["steps"],
                           "scanned_ranks": st["scanned_ranks"], "host_s": st["t_host"], "scan_s": st["t_scan"],
                           "split_s": st["t_split"], "bubble_s": st["t_bubble"]},

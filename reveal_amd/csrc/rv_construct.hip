@@ -548,21 +548,23 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
     if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
 }
 // ---- the sorted list without the twins -> rank order with them (k_init_keys with tw_off) ----
-constexpr int TC_TILE = TB;
-__global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt, int64_t nblocks) {
-    // eight of k_heads_publish_tc's workgroups per workgroup here: eight loads in flight per thread
-    __shared__ u32 wsum[8][TB / 64];
-    const int64_t b0 = (int64_t)blockIdx.x * 8;
-    sav_t v[8];
+constexpr int TC_PER = 4, TC_TILE = TB * TC_PER;      // k_heads_publish_tc: entries per thread / per workgroup
+__global__ __launch_bounds__(TB) void k_tw_flags(const sav_t *__restrict__ vals, int64_t m, u32 *__restrict__ blockcnt) {
+    __shared__ u32 wsum[TB / 64];
+    const int64_t j0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * TC_PER;
+    u32 c = 0;
+    if (j0 + TC_PER <= m) {
+        sav_t v[TC_PER];
+        __builtin_memcpy(v, vals + j0, sizeof v);
 #pragma unroll
-    for (int r = 0; r < 8; r++) { const int64_t j = (b0 + r) * TB + threadIdx.x; v[r] = j < m ? vals[j] : (sav_t)0; }
-#pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const u64 bal = __ballot((v[r] & TW_FLAG) != 0);
-        if ((threadIdx.x & 63) == 0) wsum[r][threadIdx.x >> 6] = (u32)__popcll(bal);
+        for (int r = 0; r < TC_PER; r++) c += (v[r] & TW_FLAG) ? 1u : 0u;
+    } else {
+        for (int r = 0; r < TC_PER; r++) if (j0 + r < m && (vals[j0 + r] & TW_FLAG)) c++;
     }
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_down(c, d, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = c;
     __syncthreads();
-    if (threadIdx.x < 8 && b0 + threadIdx.x < nblocks) blockcnt[b0 + threadIdx.x] = wsum[threadIdx.x][0] + wsum[threadIdx.x][1] + wsum[threadIdx.x][2] + wsum[threadIdx.x][3];
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
 }
 // the key k_init_keys would have given the twin of a flagged suffix: same symbols, same byte in front, same agreement, the other side
 __device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
@@ -580,42 +582,54 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                                                          uint8_t *__restrict__ head, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
                                                          uint8_t *__restrict__ BWT, sa_t side_sep, KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins,
                                                          u64 *__restrict__ kexp, sav_t *__restrict__ vexp) {
-    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    __shared__ u64 s_key[TB + 4];
-    __shared__ sav_t s_val[TB + 2];
+    // A thread takes four entries in a row, with the two keys in front of them and the two behind straight from memory (its neighbours'
+    // loads hit the same lines): one entry per thread through an LDS tile was bound by its instruction count -- 5 ms for 9.5 GB.
     __shared__ u32 wsum[TB / 64];
-    {
-        const int64_t j0 = (int64_t)blockIdx.x * TB;
-        for (int k = threadIdx.x; k < TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < m) ? keys[i] : 0ull; }
-        for (int k = threadIdx.x; k < TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < m) ? vals[i] : (sav_t)0; }
-        __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t j0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * TC_PER;
+    u64 kk[TC_PER + 4];          // keys j0 - 2 .. j0 + 5
+    sav_t vv[TC_PER + 2];        // payloads j0 - 1 .. j0 + 4
+    if (j0 >= 2 && j0 + TC_PER + 2 <= m) {
+        __builtin_memcpy(kk, keys + j0 - 2, sizeof kk);
+        __builtin_memcpy(vv, vals + j0 - 1, sizeof vv);
+    } else {
+#pragma unroll
+        for (int x = 0; x < TC_PER + 4; x++) { const int64_t i = j0 - 2 + x; kk[x] = (i >= 0 && i < m) ? keys[i] : 0ull; }
+#pragma unroll
+        for (int x = 0; x < TC_PER + 2; x++) { const int64_t i = j0 - 1 + x; vv[x] = (i >= 0 && i < m) ? vals[i] : (sav_t)0; }
     }
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    const bool in = j < m;
-    const sav_t sv = s_val[t + 1];
-    const bool flagged = in && (sv & TW_FLAG);
-    const u64 bal = __ballot(flagged);
-    if (lane == 0) wsum[wv] = (u32)__popcll(bal);
+    u32 myflags = 0;
+#pragma unroll
+    for (int e = 0; e < TC_PER; e++) myflags += (j0 + e < m && (vv[e + 1] & TW_FLAG)) ? 1u : 0u;
+    u32 inc = myflags;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    if (lane == 63) wsum[wv] = inc;
     __syncthreads();
-    u32 before = blockoff[blockIdx.x] + (u32)__popcll(bal & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    u32 before = blockoff[blockIdx.x] + inc - myflags;
     for (int k = 0; k < wv; k++) before += wsum[k];
     u32 lmax = 0;
-    if (in) {
+    const u64 mk = kd.ly.sortmask;
+#pragma unroll
+    for (int e = 0; e < TC_PER; e++) {
+        const int64_t j = j0 + e;
+        if (j >= m) break;
         const int64_t r = j + (int64_t)before;
+        const sav_t sv = vv[e + 1];
+        const bool flagged = (sv & TW_FLAG) != 0;
         const sav_t s = sv & ~TW_FLAG;
-        const u64 key = s_key[t + 2];
-        const u64 mk = kd.ly.sortmask;
+        const u64 key = kk[e + 2];
         const u64 k0 = key & mk;
-        const u64 km2 = j >= 2 ? s_key[t] & mk : ~k0, km1 = j >= 1 ? s_key[t + 1] & mk : ~k0;
-        const u64 kp1r = j + 1 < m ? s_key[t + 3] : ~key, kp2 = j + 2 < m ? s_key[t + 4] & mk : ~k0;
-        const u64 km1r = j >= 1 ? s_key[t + 1] : ~key;
+        const u64 km2 = j >= 2 ? kk[e] & mk : ~k0, km1 = j >= 1 ? kk[e + 1] & mk : ~k0;
+        const u64 kp1r = j + 1 < m ? kk[e + 3] : ~key, kp2 = j + 2 < m ? kk[e + 4] & mk : ~k0;
+        const u64 km1r = j >= 1 ? kk[e + 1] : ~key;
         const u64 kp1 = j + 1 < m ? kp1r & mk : ~k0;
-        const bool f_m1 = j >= 1 && (s_val[t] & TW_FLAG), f_p1 = j + 1 < m && (s_val[t + 2] & TW_FLAG);
+        const bool f_m1 = j >= 1 && (vv[e] & TW_FLAG), f_p1 = j + 1 < m && (vv[e + 2] & TW_FLAG);
         bool hd = (j == 0) | (km1 != k0);
         if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
             u32 l = 0;
             if (j > 0) {
-                if (kd.K <= 16) l = key_common_digits(km1, k0, kd);
+                if (kd.K <= 32) l = key_common_digits(km1, k0, kd);
                 else {
                     u64 x = km1, y = k0;
                     l = (u32)kd.K;
@@ -630,7 +644,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 l = l < st ? l : st;
             }
             LCP[r] = (lcp_t)l;
-            lmax = l;
+            lmax = l > lmax ? l : lmax;
         }
         const u32 pay = (u32)(key >> 56);
         if (flagged) {
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             head[r] = hd; head[r + 1] = fin;
             SA[rs] = (sa_t)s; BWT[rs] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
             SA[rq] = (sa_t)q; BWT[rq] = (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u));
+            before++;
         } else {
             int64_t rank = r;
             // a group of exactly two entries, neither flagged (a twin whose byte in front differs, two unrelated suffixes): k_heads_publish's pair
@@ -656,7 +671,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             const bool second = twins & (km1 == k0) & (kp1 != k0) & (km2 != k0) & !f_m1;
             bool fin = hd & (kp1 != k0);      // alone in its group
             if (first | second) {
-                const sav_t ps = (first ? s_val[t + 2] : s_val[t]) & ~TW_FLAG;
+                const sav_t ps = (first ? vv[e + 2] : vv[e]) & ~TW_FLAG;
                 const u64 pkey = first ? kp1r : km1r;
                 int c; u32 nd;
                 if (hint_cmp(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
@@ -1806,7 +1821,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // rank of a list entry = its index + the flagged entries in front of it
         const int64_t nb = ceil_div(nsort, TC_TILE);
         u32 *bc = ws.sa[23].as<u32>();      // (the tile offsets of k_init_keys are used up)
-        hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)ceil_div(nb, 8)), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc, nb);
+        hipLaunchKernelGGL(k_tw_flags, dim3((unsigned)nb), dim3(TB), 0, q, (const sav_t *)vs, nsort, bc);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_exclusive_sum_u32(ws, bc, bc, nb));
         sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)

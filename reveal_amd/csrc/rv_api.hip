@@ -448,7 +448,7 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
             picks = h->hscan.as<RvPairRec>();
         }
         hipEvent_t ev_a, ev_b;      /* 8 B/rank (12 B in the 64-bit build); the BWT byte is not counted */
-        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)m * (sizeof(sa_t) + sizeof(lcp_t)), &ev_a, &ev_b);
+        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)m * 8.0, &ev_a, &ev_b);      // 8 B per rank (a 4-byte suffix + a 4-byte LCP value), also for the 64-bit library -- the kernel reads suffixes only where a match may start
         RV_TRY(rv_scan_pair_launch(h->ws, SA, LCP, m, BWT, (sa_t)h->nsep[0], minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
                                    (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf,
                                    bbest.as<unsigned long long>(), picks, d_sub_start ? nsubs : 0, ev_a, ev_b));

@@ -651,7 +651,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         if (attempt == 3) { rv_set_error("cascade: scan buffer sizing failed"); return -1; }
         const size_t ocap = bout.cap / sizeof(RvPairRec) - RV_PAIR_HDR, vcap = bovf.cap / sizeof(RvPairRec);
         hipEvent_t ev_a, ev_b;
-        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)n * (sizeof(sa_t) + sizeof(lcp_t)), &ev_a, &ev_b);
+        (void)h->prof.attach(RV_K_SCAN_PAIR, (double)n * 8.0, &ev_a, &ev_b);      // 8 B per rank (a 4-byte suffix + a 4-byte LCP value), also for the 64-bit library -- the kernel reads suffixes only where a match may start
         RV_TRY(rv_scan_pair_launch(ws, SA, LCP, n, BWT, (sa_t)h->nsep[0], (int)minl, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(),
                                    (u32)std::min<size_t>(vcap, 0xffffffffu), bcnt.as<u32>(), tilecnt, tileovf, nullptr, nullptr, 0, ev_a, ev_b));
         RV_TRY(rv_exclusive_sum_u32(ws, tilecnt, tileoff, ntile + 1));

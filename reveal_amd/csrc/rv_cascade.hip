@@ -55,7 +55,7 @@ constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
 
 struct CasIv { sa_t a0, a1, b0, b1; };
 struct CasRes { sa_t qa, qb; u32 ql, lead, trail, state; };      // state: 0 not decided yet, 1 split, 2 ended
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NSOLVED = 8, C_NUNSOLVED = 9 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NSOLVED = 8, C_NUNSOLVED = 9, C_NRETRY = 10 };
 
 // the match (pa, pb, len) of the root cut to a sub-index: start shifted behind the sub-index' begin on both sides, length
 // capped at its ends
@@ -197,14 +197,14 @@ __global__ __launch_bounds__(TB) void k_cas_gather(const RvPairRec *__restrict__
     c_pa[i] = r.a; c_pb[i] = r.b; c_len[i] = r.l; c_child[i] = 0u;
 }
 __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth, CasRes *__restrict__ res,
-                           u32 *__restrict__ counters, CasIv root, u32 *__restrict__ w_child, u32 nw, u64 *__restrict__ dbest, u32 *__restrict__ dflag) {
+                           u32 *__restrict__ counters, CasIv root, u32 *__restrict__ w_child, u32 nw, u64 *__restrict__ dbest, u32 *__restrict__ dflag, u64 *__restrict__ dceil) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
-        if (dbest) { dbest[0] = 0; dflag[0] = 0; }
+        if (dbest) { dbest[0] = 0; dflag[0] = 0; dceil[0] = 0; }
         iv[0] = root; best[0] = 0; wmax[0] = 0; depth[0] = 0;
         CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
         res[0] = r;
-        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0; counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0; counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0;
     }
     if (i < nw) w_child[i] = 0u;
 }
@@ -213,7 +213,7 @@ __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *
 __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child,
                                                    u32 M, const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
                                                    const CasIv *__restrict__ iv, const CasRes *__restrict__ res, u64 *__restrict__ best, u32 *__restrict__ wmax,
-                                                   int64_t minl, int first) {
+                                                   int64_t minl, int first, const u64 *__restrict__ ceil /* second attempt: bids stay below it (0: none) */) {
     const u32 t = blockIdx.x * TB + threadIdx.x;      // (the grid covers the matches in whole workgroups, then the witnesses)
     const u32 mblocks = (M + TB - 1) / TB;
     if (blockIdx.x < mblocks) {
@@ -234,6 +234,8 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
                     CasIv tv; tv.a0 = (sa_t)((int64_t)r.qa + r.ql); tv.a1 = p.a1; tv.b0 = (sa_t)((int64_t)r.qb + r.ql); tv.b1 = p.b1;
                     if (r.lead != NONE && cas_cut(lv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
                     else if (r.trail != NONE && cas_cut(tv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.trail;
+                } else if (r.state == 3u) {      // the same sub-index once more, its best cut match set aside (k_cas_decide)
+                    if (cas_cut(p, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
                 }
                 c = nc;
                 c_child[i] = c;
@@ -244,7 +246,9 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
             }
             if (live) key = cas_key(qa, ql);
         }
-        seg_atomic_max64(best, c, key, live);
+        bool bid = live;
+        if (live && ceil) { const u64 ce = ceil[c]; bid = ce == 0 || key < ce; }
+        seg_atomic_max64(best, c, key, bid);
     } else {
         const u32 i = t - mblocks * TB;
         u32 c = i < NW ? w_child[i] : NONE;
@@ -262,7 +266,7 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
                     const bool in_lead = (pos >= p.a0 && pos < r.qa) || (pos >= p.b0 && pos < r.qb);
                     const bool in_trail = (pos >= ea && pos < p.a1) || (pos >= eb && pos < p.b1);
                     nc = in_lead ? r.lead : in_trail ? r.trail : NONE;
-                }
+                } else if (r.state == 3u) nc = r.lead;
                 c = nc;
                 w_child[i] = c;
                 live = c != NONE;
@@ -300,9 +304,10 @@ __global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa
 // D is not sorted: the witness list is in X's rank order, so the prefix a member shares with the members of its sub-index falls with
 // their distance in the list -- every member walks outwards for the two longest prefixes it shares (cut at C's ends: a suffix near
 // an end may share less than a farther one, the walk goes on behind those; the prefixes themselves come from X's LCP array),
-// k_cas_dpick keeps the pairs that are each other's only longest partner.  A cut match inside D that the walk does not confirm (ell was not the length of C's best match) leaves C undecided.
+// k_cas_dpick keeps the pairs that are each other's only longest partner.  A cut match inside D that the walk does not confirm (ell was not the length of C's
+// best match): C is looked at again in the next level with that match set aside (bids capped below it), up to sixteen times.
 constexpr u32 DWALK = 1024;
-struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; };
+struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u64 *ceil; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; };
 __device__ inline bool cas_is_danger(const CasIv &p, u64 bk, u32 wm, u32 minl, u32 leaf_n, u32 *theta) {
     const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
     const u32 bl = (u32)(bk >> KEY_SHIFT);
@@ -418,21 +423,23 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
         const bool can = in & (la >= (int64_t)minl) & (lb >= (int64_t)minl);
         bool split = can & (bl >= minl) & (bl > wm);
         bool und = can & !split & (wm >= minl);
-        bool forced = false;
+        bool forced = false, retry = false;
         if (danger && und && (u64)(la + lb) > (u64)dg.leaf_n) {
             // the second attempt: what the witnesses of this sub-index say (k_cas_dwalk / k_cas_dpick)
             const u32 fl = dg.flag[id];
             const u64 kh = dg.best[id], kc = (bl >= minl && !(fl & 1u)) ? bk : 0ull;
             if (!(fl & 2u)) {
-                if (kh == 0 && kc == 0) { if (bl < minl) und = false; }          // no cut match and no pair among the witnesses: nothing to find here
-                else {
+                if (kh == 0 && kc == 0) {
+                    if (bl < minl) und = false;          // no cut match and no pair among the witnesses: nothing to find here
+                    else if ((fl >> 8) < 16u) { retry = true; und = false; }      // the cut match is not one of this sub-index and nothing is as long: the next one's turn
+                } else {
                     if (kh > kc) { r.qa = (sa_t)(KEY_LOW - (kh & KEY_LOW)); r.qb = dg.qb[id]; r.ql = (u32)(kh >> KEY_SHIFT); }
                     split = true; forced = true; und = false;
                 }
             }
-            atomicAdd(&counters[und ? C_NUNSOLVED : C_NSOLVED], 1u);
+            if (!retry) atomicAdd(&counters[und ? C_NUNSOLVED : C_NSOLVED], 1u);
         }
-        bool lead = false, trail = false;
+        bool lead = retry, trail = false;
         if (split) {
             if (!forced && r.ql != bl) atomicOr(&counters[C_ERR], 2u);      // (the winner of the bid did not report: cannot happen)
             lead = ((int64_t)r.qa - p.a0) + ((int64_t)r.qb - p.b0) > 0;
@@ -441,6 +448,7 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
         // room for the children, the anchor and the undecided entry: one reservation per workgroup each (one per wave was 16 000
         // returning atomics on one address at the widest levels of 2 x 250 Mbp -- 6.7 of the cascade's 12 ms)
         const u64 b_lead = __ballot(lead), b_trail = __ballot(trail), b_split = __ballot(split), b_und = __ballot(und);
+        if (retry) atomicAdd(&counters[C_NRETRY], 1u);
         if (lane == 0) { s_cnt[w][0] = (u32)__popcll(b_lead) + (u32)__popcll(b_trail); s_cnt[w][1] = (u32)__popcll(b_split); s_cnt[w][2] = (u32)__popcll(b_und); }
         __syncthreads();
         if (threadIdx.x < 3) {
@@ -452,14 +460,24 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
         __syncthreads();
         u32 base_c = s_base[0], base_a = s_base[1], base_u = s_base[2];
         for (int k = 0; k < w; k++) { base_c += s_cnt[k][0]; base_a += s_cnt[k][1]; base_u += s_cnt[k][2]; }
-        if (split) {
+        if (retry) {
+            // the sub-index again, as its own only child, with the bids capped below the match that failed (not a level deeper, not visited twice)
+            const u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
+            CasRes nr; nr.qa = 0; nr.qb = 0; nr.ql = 0; nr.lead = NONE; nr.trail = NONE; nr.state = 0;
+            if (slot < child_cap) {
+                iv[slot] = p; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp; res[slot] = nr;
+                dg.best[slot] = 0; dg.flag[slot] = ((dg.flag[id] >> 8) + 1u) << 8; dg.ceil[slot] = bk;
+                r.lead = slot; r.trail = NONE;
+            } else atomicOr(&counters[C_ERR], 1u);
+            r.state = 3;
+        } else if (split) {
             u32 slot = base_c + (u32)__popcll(b_lead & lt) + (u32)__popcll(b_trail & lt);
             CasRes nr; nr.qa = 0; nr.qb = 0; nr.ql = 0; nr.lead = NONE; nr.trail = NONE; nr.state = 0;
             if (lead) {
                 if (slot < child_cap) {
                     CasIv c; c.a0 = p.a0; c.a1 = r.qa; c.b0 = p.b0; c.b1 = r.qb;
                     iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
-                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; }
+                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; dg.ceil[slot] = 0; }
                     r.lead = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
                 slot++;
@@ -468,7 +486,7 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
                 if (slot < child_cap) {
                     CasIv c; c.a0 = (sa_t)((int64_t)r.qa + r.ql); c.a1 = p.a1; c.b0 = (sa_t)((int64_t)r.qb + r.ql); c.b1 = p.b1;
                     iv[slot] = c; best[slot] = 0; wmax[slot] = 0; depth[slot] = dp + 1; res[slot] = nr;
-                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; }
+                    if (danger) { dg.best[slot] = 0; dg.flag[slot] = 0; dg.ceil[slot] = 0; }
                     r.trail = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
             }
@@ -515,7 +533,7 @@ __global__ __launch_bounds__(TB) void k_cas_stats(const u32 *__restrict__ counte
         for (int k = 1; k < TB / 64; k++) { bp += s_bp[k]; md = s_md[k] > md ? s_md[k] : md; }
         if (bp) atomicAdd(&io.stats[2], bp);
         if (md) atomicMax(&io.stats[3], (unsigned long long)md);
-        if (blockIdx.x == 0) { atomicAdd(&io.stats[0], (unsigned long long)(nchild - counters[C_NUND])); atomicAdd(&io.stats[1], (unsigned long long)na); }
+        if (blockIdx.x == 0) { atomicAdd(&io.stats[0], (unsigned long long)(nchild - counters[C_NUND] - counters[C_NRETRY])); atomicAdd(&io.stats[1], (unsigned long long)na); }
     }
 }
 
@@ -672,7 +690,10 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     cb.M = M;
 
     // ---- buffers
-    const u32 wcap = (u32)std::min<int64_t>(std::max<int64_t>(1 << 16, n / 16), 0x7fffffff);
+    // a region of the witness list takes every WT_REGIONS-th tile: n / WT_REGIONS + a tile's worth of entries can never overflow (small inputs
+    // get that: a low-complexity stretch puts all its witnesses into two or three regions); large inputs a 1024th of n per region
+    const int64_t rcap64 = std::min<int64_t>(n / WT_REGIONS + WT_TILE, std::max<int64_t>(16384, n / 1024));
+    const u32 wcap = (u32)std::min<int64_t>(rcap64 * WT_REGIONS, 0x7fffffff);
     const int64_t ccap64 = n / (int64_t)minl + 16;      // every anchor covers 2 * minl positions and makes two sub-indices at most
     if (ccap64 >= 0x7fffffff) GIVE_UP("too many sub-indices possible");
     const u32 ccap = (u32)ccap64;
@@ -746,9 +767,9 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
             dg.rank = in1 ? k1.as<u64>() : k0.as<u64>();
         }
         DBuf &bdc = cb.d[24], &bdw = cb.d[25];
-        const size_t per_child = 8 + 4 + sizeof(sa_t), per_wit = 4 + 4 + 4 + 8;
+        const size_t per_child = 8 + 8 + 4 + sizeof(sa_t), per_wit = 4 + 4 + 4 + 8;
         RV_TRY(bdc.reserve((size_t)ccap * per_child + 64)); RV_TRY(bdw.reserve((size_t)std::max<u32>(NW, 1) * per_wit + 64));
-        dg.best = bdc.as<u64>(); dg.qb = (sa_t *)(dg.best + ccap); dg.flag = (u32 *)(dg.qb + ccap);
+        dg.best = bdc.as<u64>(); dg.ceil = dg.best + ccap; dg.qb = (sa_t *)(dg.ceil + ccap); dg.flag = (u32 *)(dg.qb + ccap);
         dg.key = bdw.as<u64>(); dg.m1 = (u32 *)(dg.key + std::max<u32>(NW, 1)); dg.p1 = dg.m1 + std::max<u32>(NW, 1); dg.m2 = dg.p1 + std::max<u32>(NW, 1);
         dg.T0 = h->dT0.as<uint8_t>(); dg.LCP = LCP;
         // every undecided sub-index this way, not only the ones the leaf kernel cannot take: the walk costs less than rebuilding a sub-index that
@@ -756,7 +777,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         dg.leaf_n = getenv("RV_CASCADE_DANGER_MIN") ? (u32)atoi(getenv("RV_CASCADE_DANGER_MIN")) : 0u;
     }
     hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
-                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag);
+                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag, dg.ceil);
     RV_LAUNCH_CHECK();
 
     if (verbose) { (void)hipStreamSynchronize(q); tp[2] = cas_now(); }
@@ -769,7 +790,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         for (int b = 0; b < batch; b++, queued++) {
             hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
                                wp, wv, bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
-                               bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, queued == 0 ? 1 : 0);
+                               bbest.as<u64>(), bwm.as<u32>(), (int64_t)minl, queued == 0 ? 1 : 0, (const u64 *)((danger && NW) ? dg.ceil : nullptr));
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_cas_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(),
                                (const u32 *)blen.as<u32>(), (const u32 *)bcc.as<u32>(), M, (const CasIv *)biv.as<CasIv>(), bres.as<CasRes>(), (const u64 *)bbest.as<u64>(), (int64_t)minl);

@@ -586,12 +586,23 @@ __global__ __launch_bounds__(TB) void k_cas_rank(const RvLeafRoot *__restrict__ 
     if (i >= n) return;
     const int ri = (i < la ? la : n) - i;
     int cnt = 0;
+    // (the first eight bytes from registers: mine once, the other's as a window that moves a byte per step -- rv_cascade_multi.hip k_casm_rank)
+    u64 ki = 0, wj = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { ki |= (u64)txt[i + b] << (8 * b); wj |= (u64)txt[b] << (8 * b); }
     for (int j = 0; j < n; j++) {
         const int rj = (j < la ? la : n) - j;
         const int lim = ri < rj ? ri : rj;
-        const int k = cas_first_diff(txt, i, j, lim);
-        const bool j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        const u64 d = ki ^ wj;
+        int k = d ? (__builtin_ctzll(d) >> 3) : 8;
+        bool j_less;
+        if (k < 8 && k < lim) j_less = (u32)((wj >> (8 * k)) & 0xffu) < (u32)((ki >> (8 * k)) & 0xffu);
+        else {
+            if (k >= 8 && lim > 8) k = 8 + cas_first_diff(txt, i + 8, j + 8, lim - 8);
+            j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        }
         cnt += j_less ? 1 : 0;
+        wj = (wj >> 8) | ((u64)txt[j + 8] << 56);
     }
     ord[root.off + cnt] = (uint16_t)i;
 }

@@ -475,13 +475,25 @@ __global__ __launch_bounds__(TB) void k_casm_rank(const CmRoot *__restrict__ roo
     while (i >= seg_lo[si + 1]) si++;
     const int ri = seg_lo[si + 1] - i;
     int cnt = 0, sj = 0;
+    // the first eight bytes of the two suffixes from registers: mine once, the other's as a window that moves a byte per step (one uniform
+    // LDS byte per comparison; two eight-byte reads at unknown alignment per comparison were sixteen byte reads: 2.6 ms at 10 x 5 Mbp)
+    u64 ki = 0, wj = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { ki |= (u64)txt[i + b] << (8 * b); wj |= (u64)txt[b] << (8 * b); }
     for (int j = 0; j < n; j++) {
         while (j >= seg_lo[sj + 1]) sj++;
         const int rj = seg_lo[sj + 1] - j;
         const int lim = ri < rj ? ri : rj;
-        const int x = cm_first_diff(txt, i, j, lim);
-        const bool j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        const u64 d = ki ^ wj;
+        int x = d ? (__builtin_ctzll(d) >> 3) : 8;
+        bool j_less;
+        if (x < 8 && x < lim) j_less = (u32)((wj >> (8 * x)) & 0xffu) < (u32)((ki >> (8 * x)) & 0xffu);
+        else {
+            if (x >= 8 && lim > 8) x = 8 + cm_first_diff(txt, i + 8, j + 8, lim - 8);
+            j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+        }
         cnt += j_less ? 1 : 0;
+        wj = (wj >> 8) | ((u64)txt[j + 8] << 56);
     }
     ord[root.off + cnt] = (u32)i;
 }

@@ -49,7 +49,9 @@ def extract_case(rng, seqs, sa64):
         # keep them apart from what was extracted before (a hole inside or next to an interval is "not part of this index")
         if not ivs:
             break
-        rng.shuffle(ivs) if rng.random() < 0.3 and all(abs(a[0] - b[0]) > 100000 for a in ivs for b in ivs if a != b) else None
+        # (any order is allowed only for intervals farther apart than the longest repeat: identical samples of 250 kbp have one of 250 kbp)
+        far = max(100000, idx.maxlcp)
+        rng.shuffle(ivs) if rng.random() < 0.3 and all(abs(a[0] - b[0]) > far for a in ivs for b in ivs if a != b) else None
         sa, lcp, _ = O.extract(c["tbuf"], sa, lcp, c["SAi"], c["nsep"], ivs, nT=len(T))
         idx.extract(list(ivs))
         assert idx.n == len(sa), ("n", idx.n, len(sa))

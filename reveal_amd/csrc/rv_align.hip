@@ -51,9 +51,12 @@ struct Packer {
         if (need <= cap) return;
         size_t want = need + need / 2 + 4096;
         uint8_t *q = nullptr;
-        if (hipHostMalloc((void **)&q, want, hipHostMallocDefault) != hipSuccess) { q = (uint8_t *)malloc(want); pageable = true; }
-        if (p) { (void)hipDeviceSynchronize(); memcpy(q, p, used); release_ptr(); }      // (a queued copy kernel may still read the old buffer)
-        p = q; cap = want;
+        size_t got = want;
+        const bool was_pageable = pageable;
+        bool now_pageable = false;
+        if (rv_pinned_get(want, (void **)&q, &got) != hipSuccess) { q = (uint8_t *)malloc(want); got = want; now_pageable = true; }
+        if (p) { (void)hipDeviceSynchronize(); memcpy(q, p, used); pageable = was_pageable; release_ptr(); }      // (a queued copy kernel may still read the old buffer)
+        p = q; cap = got; pageable = now_pageable;
     }
     size_t add(const void *src, size_t bytes) {
         const size_t off = (used + 15) & ~(size_t)15;
@@ -72,7 +75,7 @@ struct Packer {
         return off;
     }
     bool pageable = false;
-    void release_ptr() { if (p) { if (pageable) free(p); else (void)hipHostFree(p); } p = nullptr; }
+    void release_ptr() { if (p) { if (pageable) free(p); else rv_pinned_put(p, cap); } p = nullptr; }
     void release() { release_ptr(); cap = used = 0; }
 };
 
@@ -201,9 +204,9 @@ struct Align {
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release(); cas.release();
         dTmin.release(); dPbReady.release(); dNextTsub.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();
-        if (leaf_stream) { (void)hipStreamSynchronize(leaf_stream); (void)hipStreamDestroy(leaf_stream); leaf_stream = nullptr; }
-        if (leaf_stream2) { (void)hipStreamSynchronize(leaf_stream2); (void)hipStreamDestroy(leaf_stream2); leaf_stream2 = nullptr; }
-        if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamDestroy(bub_stream); bub_stream = nullptr; (void)hipStreamSynchronize(bub_stream2); (void)hipStreamDestroy(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
+        if (leaf_stream) { rv_stream_put(leaf_stream); leaf_stream = nullptr; }
+        if (leaf_stream2) { rv_stream_put(leaf_stream2); leaf_stream2 = nullptr; }
+        if (bub_stream) { rv_stream_put(bub_stream); bub_stream = nullptr; rv_stream_put(bub_stream2); bub_stream2 = nullptr; (void)hipEventDestroy(ev_fork); (void)hipEventDestroy(ev_join); (void)hipEventDestroy(ev_join2); ev_fork = ev_join = ev_join2 = nullptr; }
         if (ev_ready) { (void)hipEventDestroy(ev_ready); ev_ready = nullptr; }
         for (int k = 0; k <= RV_LEVEL_BUFS; k++) if (ev_leaf[k]) { (void)hipEventDestroy(ev_leaf[k]); ev_leaf[k] = nullptr; }
         for (int k = 0; k < 2; k++) if (ev_roots[k]) { (void)hipEventDestroy(ev_roots[k]); ev_roots[k] = nullptr; }
@@ -531,8 +534,8 @@ static int early_split(rv_index *h) {
             // thousands of sub-indices (the deep levels of large inputs): the size-class kernels, LDS-resident ones included, each on
             // its own stream -- the host-built launches of rv_frontier_commit, minus the wait for the host's tables
             if (!a->bub_stream) {
-                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
-                RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+                RV_HIP(rv_stream_get(&a->bub_stream));
+                RV_HIP(rv_stream_get(&a->bub_stream2));
                 RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
                 RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
                 RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
@@ -640,8 +643,8 @@ static int early_split_multi(rv_index *h) {
         ba.flag = a->dFlag.as<uint8_t>();
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = d.cut_lo; ba.cut_hi = d.cut_hi; ba.err = a->dErr.as<u32>();
         if (!a->bub_stream) {
-            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
-            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+            RV_HIP(rv_stream_get(&a->bub_stream));
+            RV_HIP(rv_stream_get(&a->bub_stream2));
             RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
             RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
             RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
@@ -1325,8 +1328,8 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         // to its own stream (fork / join by events): the level's bubble time is the longest group, not their sum.
         bool forked = false, forked2 = false;
         if (!a->bub_stream) {
-            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream, hipStreamNonBlocking));
-            RV_HIP(hipStreamCreateWithFlags(&a->bub_stream2, hipStreamNonBlocking));
+            RV_HIP(rv_stream_get(&a->bub_stream));
+            RV_HIP(rv_stream_get(&a->bub_stream2));
             RV_HIP(hipEventCreateWithFlags(&a->ev_fork, hipEventDisableTiming));
             RV_HIP(hipEventCreateWithFlags(&a->ev_join, hipEventDisableTiming));
             RV_HIP(hipEventCreateWithFlags(&a->ev_join2, hipEventDisableTiming));
@@ -1406,8 +1409,8 @@ static int builtin_leaf_setup(rv_index *h) {
         // and the lower-casing queued behind their fork -- 267.4 / 267.9 / 265.4 ms for both / one / neither at C4: no gain)
         // (tried twice: lowest stream priority for the leaf launches -- 306 against 302 ms at C4 while the launches were bound by their
         // atomics, 282 against 277 ms after that)
-        RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream, hipStreamNonBlocking));
-        RV_HIP(hipStreamCreateWithFlags(&a->leaf_stream2, hipStreamNonBlocking));
+        RV_HIP(rv_stream_get(&a->leaf_stream));
+        RV_HIP(rv_stream_get(&a->leaf_stream2));
         RV_HIP(hipEventCreateWithFlags(&a->ev_ready, hipEventDisableTiming));
         for (int k = 0; k <= RV_LEVEL_BUFS; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_leaf[k], hipEventDisableTiming));
         for (int k = 0; k < 2; k++) RV_HIP(hipEventCreateWithFlags(&a->ev_roots[k], hipEventDisableTiming));

@@ -57,7 +57,7 @@ rv_index *rv_new(int device) {
     }
     rv_index *h = new rv_index();
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->ws.stream, hipStreamNonBlocking) != hipSuccess) {
+    if (rv_stream_get(&h->ws.stream) != hipSuccess) {
         rv_set_error("hipStreamCreate failed");
         delete h;
         return nullptr;
@@ -82,7 +82,7 @@ void rv_free(rv_index *h) {
     h->hscan.release();
     h->hupload.release();
     if (h->ev_picks) { (void)hipEventDestroy(h->ev_picks); h->ev_picks = nullptr; }
-    if (h->ws.stream) (void)hipStreamDestroy(h->ws.stream);
+    if (h->ws.stream) rv_stream_put(h->ws.stream);
     delete h;
 }
 

@@ -4,6 +4,9 @@
 // (reveallib/reveal.h:7-13): default = reveallib (int32 SA, int32 LCP),
 // -DRV_SA64 = reveallib64 (int64 SA, uint32 LCP).
 #pragma once
+#include <mutex>
+#include <vector>
+#include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
@@ -137,19 +140,76 @@ struct DBuf {
 };
 
 // Pinned host staging buffer (grow-only).
+// Streams and pinned host buffers outlive the handle that made them.  `reveal refine` builds an index per bubble -- a few hundred bases,
+// 0.9 ms of construct + recursion -- and a handle's three streams and four pinned buffers cost 6 ms to create and destroy
+// (hipStreamCreateWithFlags 0.65-2 ms, hipStreamDestroy 0.96 ms, hipHostFree 0.23 ms each: rocprofv3 --hip-trace of 30 such alignments).
+// Idle ones wait here for the next handle on the same device; nothing is given back at process exit.
+struct RvPools {
+    std::mutex mu;
+    std::vector<std::pair<int, hipStream_t>> streams;
+    struct Pin { int dev; void *p; size_t cap; };
+    std::vector<Pin> pinned;
+    size_t pinned_bytes = 0;
+};
+inline RvPools &rv_pools() { static RvPools *p = new RvPools(); return *p; }
+inline hipError_t rv_stream_get(hipStream_t *s) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    {
+        RvPools &P = rv_pools();
+        std::lock_guard<std::mutex> g(P.mu);
+        for (size_t k = P.streams.size(); k-- > 0;)
+            if (P.streams[k].first == dev) { *s = P.streams[k].second; P.streams.erase(P.streams.begin() + (ptrdiff_t)k); return hipSuccess; }
+    }
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+inline void rv_stream_put(hipStream_t s) {      // (the caller has set the stream's device)
+    if (!s) return;
+    (void)hipStreamSynchronize(s);
+    int dev = 0; (void)hipGetDevice(&dev);
+    RvPools &P = rv_pools();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        if (P.streams.size() < 64) { P.streams.push_back({dev, s}); return; }
+    }
+    (void)hipStreamDestroy(s);
+}
+inline hipError_t rv_pinned_get(size_t bytes, void **p, size_t *cap) {
+    int dev = 0; (void)hipGetDevice(&dev);
+    {
+        RvPools &P = rv_pools();
+        std::lock_guard<std::mutex> g(P.mu);
+        size_t best = (size_t)-1;
+        for (size_t k = 0; k < P.pinned.size(); k++)
+            if (P.pinned[k].dev == dev && P.pinned[k].cap >= bytes && P.pinned[k].cap <= 4 * bytes + (1u << 20) && (best == (size_t)-1 || P.pinned[k].cap < P.pinned[best].cap)) best = k;
+        if (best != (size_t)-1) { *p = P.pinned[best].p; *cap = P.pinned[best].cap; P.pinned_bytes -= *cap; P.pinned.erase(P.pinned.begin() + (ptrdiff_t)best); return hipSuccess; }
+    }
+    const hipError_t e = hipHostMalloc(p, bytes, hipHostMallocDefault);
+    if (e == hipSuccess) *cap = bytes;
+    return e;
+}
+inline void rv_pinned_put(void *p, size_t cap) {
+    if (!p) return;
+    int dev = 0; (void)hipGetDevice(&dev);
+    RvPools &P = rv_pools();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        if (cap <= ((size_t)64 << 20) && P.pinned_bytes + cap <= ((size_t)512 << 20) && P.pinned.size() < 256) { P.pinned.push_back({dev, p, cap}); P.pinned_bytes += cap; return; }
+    }
+    (void)hipHostFree(p);
+}
+
 struct HBuf {
     void  *p = nullptr;
     size_t cap = 0;
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         // (kernels read and write pinned buffers directly -- picks, table staging: nothing may be in flight when one is replaced)
-        if (p) { (void)hipDeviceSynchronize(); (void)hipHostFree(p); p = nullptr; cap = 0; }
+        if (p) { (void)hipDeviceSynchronize(); rv_pinned_put(p, cap); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 2 + 4096;
-        RV_HIP(hipHostMalloc(&p, want, hipHostMallocDefault));
-        cap = want;
+        RV_HIP(rv_pinned_get(want, &p, &cap));
         return 0;
     }
-    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+    void release() { if (p) rv_pinned_put(p, cap); p = nullptr; cap = 0; }
     template <class T> T *as() const { return (T *)p; }
 };
 

@@ -576,7 +576,7 @@ __device__ inline int cas_first_diff(const uint8_t *txt, int i, int j, int lim) 
 // (a workgroup takes 256 suffixes of a sub-index: as one workgroup per sub-index, byte by byte, 41 sub-indices of about a thousand suffixes
 // inside copies of a 1.5 kb repeat took 40 ms)
 __global__ __launch_bounds__(TB) void k_cas_rank(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, uint16_t *__restrict__ ord) {
-    __shared__ uint8_t txt[BN + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t txt[BN + 24];
     const RvLeafRoot root = roots[blockIdx.x];
     const int la = (int)(root.a1 - root.a0), lb = (int)(root.b1 - root.b0), n = la + lb;
     if ((int)blockIdx.y * TB >= n) return;
@@ -590,19 +590,28 @@ __global__ __launch_bounds__(TB) void k_cas_rank(const RvLeafRoot *__restrict__ 
     u64 ki = 0, wj = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) { ki |= (u64)txt[i + b] << (8 * b); wj |= (u64)txt[b] << (8 * b); }
-    for (int j = 0; j < n; j++) {
-        const int rj = (j < la ? la : n) - j;
-        const int lim = ri < rj ? ri : rj;
-        const u64 d = ki ^ wj;
-        int k = d ? (__builtin_ctzll(d) >> 3) : 8;
-        bool j_less;
-        if (k < 8 && k < lim) j_less = (u32)((wj >> (8 * k)) & 0xffu) < (u32)((ki >> (8 * k)) & 0xffu);
-        else {
-            if (k >= 8 && lim > 8) k = 8 + cas_first_diff(txt, i + 8, j + 8, lim - 8);
-            j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+    for (int j0 = 0; j0 < n; j0 += 8) {      // (the bytes that enter the window come eight at a time from one aligned load: no step waits for LDS)
+        u64 nxt = *reinterpret_cast<const u64 *>(txt + j0 + 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int j = j0 + e;
+            if (j < n) {
+                const int rj = (j < la ? la : n) - j;
+                const int lim = ri < rj ? ri : rj;
+                const u64 d = ki ^ wj;
+                int k = d ? (__builtin_ctzll(d) >> 3) : 8;
+                bool j_less;
+                if (k < 8 && k < lim) j_less = (u32)((wj >> (8 * k)) & 0xffu) < (u32)((ki >> (8 * k)) & 0xffu);
+                else {
+                    if (k >= 8 && lim > 8 && j != i) k = 8 + cas_first_diff(txt, i + 8, j + 8, lim - 8);
+                    else if (j == i) k = lim;
+                    j_less = (k < lim) ? (txt[j + k] < txt[i + k]) : ((rj < ri) | ((rj == ri) & (j < i)));
+                }
+                cnt += j_less ? 1 : 0;
+            }
+            wj = (wj >> 8) | (nxt << 56);
+            nxt >>= 8;
         }
-        cnt += j_less ? 1 : 0;
-        wj = (wj >> 8) | ((u64)txt[j + 8] << 56);
     }
     ord[root.off + cnt] = (uint16_t)i;
 }

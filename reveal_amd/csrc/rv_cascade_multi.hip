@@ -463,7 +463,7 @@ __device__ inline int cm_load_text(const CmRoot &root, const CmTabs &t, int k, c
 }
 __global__ __launch_bounds__(TB) void k_casm_rank(const CmRoot *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
                                                   u32 *__restrict__ ord) {
-    __shared__ uint8_t txt[BN + 8];
+    __shared__ __attribute__((aligned(8))) uint8_t txt[BN + 24];
     __shared__ int seg_lo[RV_CASM_K + 1];
     __shared__ int64_t seg_b[RV_CASM_K];
     const CmSlice sl = slices[blockIdx.x];
@@ -480,20 +480,29 @@ __global__ __launch_bounds__(TB) void k_casm_rank(const CmRoot *__restrict__ roo
     u64 ki = 0, wj = 0;
 #pragma unroll
     for (int b = 0; b < 8; b++) { ki |= (u64)txt[i + b] << (8 * b); wj |= (u64)txt[b] << (8 * b); }
-    for (int j = 0; j < n; j++) {
-        while (j >= seg_lo[sj + 1]) sj++;
-        const int rj = seg_lo[sj + 1] - j;
-        const int lim = ri < rj ? ri : rj;
-        const u64 d = ki ^ wj;
-        int x = d ? (__builtin_ctzll(d) >> 3) : 8;
-        bool j_less;
-        if (x < 8 && x < lim) j_less = (u32)((wj >> (8 * x)) & 0xffu) < (u32)((ki >> (8 * x)) & 0xffu);
-        else {
-            if (x >= 8 && lim > 8) x = 8 + cm_first_diff(txt, i + 8, j + 8, lim - 8);
-            j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+    for (int j0 = 0; j0 < n; j0 += 8) {      // (the bytes that enter the window come eight at a time from one aligned load: no step waits for LDS)
+        u64 nxt = *reinterpret_cast<const u64 *>(txt + j0 + 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int j = j0 + e;
+            if (j < n) {
+                while (j >= seg_lo[sj + 1]) sj++;
+                const int rj = seg_lo[sj + 1] - j;
+                const int lim = ri < rj ? ri : rj;
+                const u64 d = ki ^ wj;
+                int x = d ? (__builtin_ctzll(d) >> 3) : 8;
+                bool j_less;
+                if (x < 8 && x < lim) j_less = (u32)((wj >> (8 * x)) & 0xffu) < (u32)((ki >> (8 * x)) & 0xffu);
+                else {
+                    if (x >= 8 && lim > 8 && j != i) x = 8 + cm_first_diff(txt, i + 8, j + 8, lim - 8);
+                    else if (j == i) x = lim;
+                    j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+                }
+                cnt += j_less ? 1 : 0;
+            }
+            wj = (wj >> 8) | (nxt << 56);
+            nxt >>= 8;
         }
-        cnt += j_less ? 1 : 0;
-        wj = (wj >> 8) | ((u64)txt[j + 8] << 56);
     }
     ord[root.off + cnt] = (u32)i;
 }

@@ -1604,6 +1604,80 @@ __global__ __launch_bounds__(TB) void k_bwt(const uint8_t *__restrict__ T, const
     if (k < n) { const sa_t p = SA[k]; BWT[k] = (uint8_t)((p > 0 ? T[p - 1] : (uint8_t)'$') | (p > side_sep ? RV_BWT_SIDE : 0)); }
 }
 
+// ---- a text of at most TINY_N characters (the bubbles `reveal refine` realigns are a few hundred bases) ----
+// The general build is two dozen launches and half a dozen host round trips whatever the size: 0.33 ms.  Here (up to TINY_N / 2 characters) every suffix counts the
+// suffixes in front of it (byte order, the shorter one first when one is a prefix of the other: what divsufsort gives, interface.c:215-222),
+// 256 suffixes per workgroup with the text in LDS, the first eight bytes of a comparison from registers; a second launch writes SA, the
+// LCP with its stops (interface.c:97-114), the BWT byte and the largest LCP.  No host round trip.
+constexpr int TINY_N = 2048;
+__global__ __launch_bounds__(TB) void k_sa_tiny_rank(const uint8_t *__restrict__ T, int n, uint16_t *__restrict__ ord) {
+    __shared__ __attribute__((aligned(8))) uint8_t txt[TINY_N + 32];
+    for (int k = threadIdx.x; k < n + 32; k += TB) txt[k] = k < n ? T[k] : (uint8_t)0;
+    __syncthreads();
+    const int i = (int)blockIdx.x * TB + threadIdx.x;
+    if (i >= n) return;
+    u64 ki = 0, wj = 0;
+#pragma unroll
+    for (int b = 0; b < 8; b++) { ki |= (u64)txt[i + b] << (8 * b); wj |= (u64)txt[b] << (8 * b); }
+    int cnt = 0;
+    // the other suffix' first eight bytes are a window that moves a byte per step; the bytes that enter it come eight at a time from one
+    // aligned load, so no step waits for LDS (a byte per step: 0.68 ms at n = 2002)
+    for (int j0 = 0; j0 < n; j0 += 8) {
+        u64 nxt = *reinterpret_cast<const u64 *>(txt + j0 + 8);
+#pragma unroll
+        for (int e = 0; e < 8; e++) {
+            const int j = j0 + e;
+            if (j < n && j != i) {      // (a suffix against itself: a wave would wait for the whole text once per lane)
+                const int lim = n - (i > j ? i : j);
+                const u64 d = ki ^ wj;
+                int x = d ? (__builtin_ctzll(d) >> 3) : 8;
+                bool j_less;
+                if (x < 8 && x < lim) j_less = (u32)((wj >> (8 * x)) & 0xffu) < (u32)((ki >> (8 * x)) & 0xffu);
+                else {
+                    if (x >= 8 && lim > 8) {
+                        x = 8;
+                        while (x + 8 <= lim) {      // eight bytes per step (the two samples of a bubble agree for most of their length)
+                            u64 a, b;
+                            __builtin_memcpy(&a, txt + i + x, 8);
+                            __builtin_memcpy(&b, txt + j + x, 8);
+                            if (a != b) { x += __builtin_ctzll(a ^ b) >> 3; break; }
+                            x += 8;
+                        }
+                        while (x < lim && txt[i + x] == txt[j + x]) x++;
+                    }
+                    j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : (j > i);      // equal as far as the shorter one goes: the shorter one (the later start) is smaller
+                }
+                cnt += j_less ? 1 : 0;
+            }
+            wj = (wj >> 8) | (nxt << 56);
+            nxt >>= 8;
+        }
+    }
+    ord[cnt] = (uint16_t)i;
+}
+__global__ __launch_bounds__(TB) void k_sa_tiny_emit(const uint8_t *__restrict__ T, int n, const uint16_t *__restrict__ ord, sa_t *__restrict__ SA, lcp_t *__restrict__ LCP,
+                                                     uint8_t *__restrict__ BWT, sa_t side_sep, u32 *__restrict__ d_maxlcp) {
+    __shared__ uint8_t txt[TINY_N + 16];
+    for (int k = threadIdx.x; k < n + 16; k += TB) txt[k] = k < n ? T[k] : (uint8_t)0;
+    __syncthreads();
+    const int r = (int)blockIdx.x * TB + threadIdx.x;
+    u32 l = 0;
+    if (r < n) {
+        const int i = ord[r];
+        if (r > 0) {
+            const int j = ord[r - 1];
+            const int lim = n - (i > j ? i : j);
+            int x = 0;
+            while (x < lim) { const uint8_t c = txt[i + x]; if (c != txt[j + x] || c == '$' || c == 'N') break; x++; }
+            l = (u32)x;
+        }
+        SA[r] = (sa_t)i; LCP[r] = (lcp_t)l;
+        BWT[r] = (uint8_t)((i > 0 ? txt[i - 1] : (uint8_t)'$') | ((sa_t)i > side_sep ? RV_BWT_SIDE : 0u));
+    }
+    const u32 wm = (u32)rv_wave_max_u64((u64)l);
+    if ((threadIdx.x & 63) == 0 && wm) atomicMax(d_maxlcp, wm);
+}
+
 inline int bitlen(u64 v) { int b = 0; while (v) { b++; v >>= 1; } return b; }
 
 }  // namespace
@@ -1670,6 +1744,19 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     if (n <= 0) { if (st) *st = s; return 0; }
     if (n >= ((int64_t)1 << 32) - 2) { rv_set_error("SA build: n >= 2^32-2 not supported yet"); return -1; }
     hipStream_t q = ws.stream;
+    if (n <= TINY_N / 2 && LCP && BWT && d_maxlcp && !getenv("RV_NO_TINY_SA")) {      // (measured: 0.17 / 0.23 ms at n = 202 / 602 against 0.33; at n = 2002 the general build's 0.36 wins against 0.62)
+        RV_TRY(ws.sa[0].reserve((size_t)TINY_N * 2 + 64));
+        RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
+        const unsigned nb = (unsigned)ceil_div(n, TB);
+        hipLaunchKernelGGL(k_sa_tiny_rank, dim3(nb), dim3(TB), 0, q, T, (int)n, ws.sa[0].as<uint16_t>());
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sa_tiny_emit, dim3(nb), dim3(TB), 0, q, T, (int)n, (const uint16_t *)ws.sa[0].as<uint16_t>(), SA, LCP, BWT, side_sep, d_maxlcp);
+        RV_LAUNCH_CHECK();
+        s.rounds = 0; s.sorted_elems = 0;
+        if (st) *st = s;
+        if (fused_done) *fused_done = true;
+        return 0;
+    }
 
     // -- alphabet -> order-preserving dense codes (0 is reserved for "past the end")
     DBuf &d_hist = ws.sa[16], &d_lut = ws.sa[17];

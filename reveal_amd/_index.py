@@ -51,6 +51,17 @@ def make_index_type(sa64, error):
             if not self._h:
                 raise error(self._lib.err())
 
+        # the main index of a sub-index (itself for a main index) -- kept as "None = self": an attribute that points back at its own object is
+        # a reference cycle, and the handle (streams, pinned buffers, the index in HBM) would only be released when the cycle collector runs
+        @property
+        def _main(self):
+            m = self.__dict__.get("_main_ref")
+            return self if m is None else m
+
+        @_main.setter
+        def _main(self, v):
+            self.__dict__["_main_ref"] = None if v is self else v
+
         def __del__(self):
             try:
                 if getattr(self, "_sx", None):

@@ -220,7 +220,9 @@ int rv_set_trace(rv_index *h, int on);
  * those the `maxmums` longest, of equal lengths the later emitted).  With maxmums > 0, rv_sub_info / rv_sub_mums between
  * rv_align_begin and rv_align_end report only those, in emission order; a sub-index without a match in every sample keeps
  * its whole list (schemes.py:229-232 segments over all of them).  0 = off.  A picker that starts with the same filter and
- * cap (graphmumpicker with --maxmums, no --trim) returns what it returns on the full list. */
+ * cap (graphmumpicker with --maxmums, no --trim) returns what it returns on the full list.  The n == nsamples filter runs in the
+ * scan kernel (only what passes it is copied to the host; a sub-index left without a match is scanned again without the filter), the cap
+ * on the host side of this ABI. */
 int rv_set_preselect(rv_index *h, int64_t maxmums);
 int64_t rv_trace_count(rv_index *h);
 int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);

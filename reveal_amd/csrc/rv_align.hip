@@ -139,6 +139,7 @@ struct Align {
     std::vector<int64_t> mum_first, nmums;       // per sub
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
+    int64_t presel_d2h = 0;            // records the scans of this alignment copied to the host while pre-selection was on (RV_PRESEL_LOG)
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
     DBuf dD, dTab, dTile, dList, dFlag, dPar, dDbg, scrSA, scrLCP, scrBWT;
@@ -361,7 +362,13 @@ static int align_begin(rv_index *h, int minl, int minn, bool need_sai) {
 int rv_frontier_size(rv_index *h) { return h->al ? h->al->lv.size() : 0; }
 
 int rv_align_end(rv_index *h) {
-    if (h->al) { h->al->lv.clear(); h->al->scanned = false; }
+    if (h->al) {
+        if (h->al->presel_on && getenv("RV_PRESEL_LOG"))
+            fprintf(stderr, "preselect: %lld match records copied to the host by the scans of this alignment (%s)\n", (long long)h->al->presel_d2h,
+                    getenv("RV_PRESEL_HOST") ? "every match, filtered on the host" : "the scan kernel keeps only matches present in every sample of their sub-index");
+        h->al->presel_d2h = 0;
+        h->al->lv.clear(); h->al->scanned = false;
+    }
     return 0;
 }
 
@@ -770,8 +777,68 @@ int rv_frontier_scan(rv_index *h) {
             RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
             d_ss = (const int64_t *)(buf.as<uint8_t>() + o1); d_want = (const int *)(buf.as<uint8_t>() + o2);
         }
+        const bool dev_filter = a->presel_on && !a->full_only && ns > 0 && !getenv("RV_PRESEL_HOST");
+        if (dev_filter) {
+            // rv_set_preselect: the picker only ever sees the matches present in every sample of their sub-index (schemes.py:227) --
+            // the scan kernel drops the others, they never cross into host memory.  A sub-index without such a match keeps its whole list
+            // (schemes.py:229-232): those sub-indices, and only those, are scanned a second time without the filter.
+            Packer &pk = a->pk;
+            pk.clear();
+            std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
+            const size_t o1 = pk.addv(ss), o2 = pk.addv(a->lv.nsamples);
+            DBuf &buf = h->ws.misc[10];
+            RV_TRY(buf.reserve(pk.size() + 64));
+            RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
+            RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub,
+                                     (const int64_t *)(buf.as<uint8_t>() + o1), (const int *)(buf.as<uint8_t>() + o2), ns));
+            a->presel_d2h += (int64_t)a->ml.size();
+            // which sub-indices came back empty?
+            std::vector<int32_t> want2((size_t)ns, -1);
+            {
+                std::vector<char> has((size_t)ns, 0);
+                int si = 0;
+                for (size_t k = 0; k < a->ml.size(); k++) {
+                    while (si < ns && ub[k] >= a->lv.off[(size_t)si] + a->lv.n[(size_t)si]) si++;
+                    if (si >= ns) { rv_set_error("scan record outside the frontier"); return -1; }
+                    has[(size_t)si] = 1;
+                }
+                bool any = false;
+                for (int s2 = 0; s2 < ns; s2++)
+                    if (!has[(size_t)s2] && !(s2 < (int)a->skip_scan.size() && a->skip_scan[(size_t)s2])) { want2[(size_t)s2] = 0; any = true; }
+                if (any) {
+                    std::vector<u32> l2; std::vector<int32_t> n2; std::vector<int64_t> off2, pos2, ub2; std::vector<uint16_t> so2;
+                    pk.clear();
+                    const size_t p1 = pk.addv(ss), p2 = pk.addv(want2);
+                    RV_HIP(hipStreamSynchronize(h->ws.stream));      // (the first upload has been read)
+                    RV_TRY(buf.reserve(pk.size() + 64));
+                    RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
+                    RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, l2, n2, off2, so2, pos2, &ub2,
+                                             (const int64_t *)(buf.as<uint8_t>() + p1), (const int *)(buf.as<uint8_t>() + p2), ns));
+                    a->presel_d2h += (int64_t)l2.size();
+                    // a sub-index' records come from one of the two passes: merge by the records' upper rank
+                    std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff(1, 0), mpos, mub; std::vector<uint16_t> mso;
+                    size_t ia = 0, ib = 0;
+                    while (ia < a->ml.size() || ib < l2.size()) {
+                        const bool from_a = ib >= l2.size() || (ia < a->ml.size() && ub[ia] < ub2[ib]);
+                        if (from_a) {
+                            ml.push_back(a->ml[ia]); mn.push_back(a->mn[ia]); mub.push_back(ub[ia]);
+                            for (int64_t q2 = a->moff[ia]; q2 < a->moff[ia + 1]; q2++) { mso.push_back(a->mso[(size_t)q2]); mpos.push_back(a->mpos[(size_t)q2]); }
+                            ia++;
+                        } else {
+                            ml.push_back(l2[ib]); mn.push_back(n2[ib]); mub.push_back(ub2[ib]);
+                            for (int64_t q2 = off2[ib]; q2 < off2[ib + 1]; q2++) { mso.push_back(so2[(size_t)q2]); mpos.push_back(pos2[(size_t)q2]); }
+                            ib++;
+                        }
+                        moff.push_back((int64_t)mpos.size());
+                    }
+                    a->ml.swap(ml); a->mn.swap(mn); a->moff.swap(moff); a->mso.swap(mso); a->mpos.swap(mpos); ub.swap(mub);
+                }
+            }
+        } else {
         RV_TRY(rv_run_multi_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, 0, a->ml, a->mn, a->moff, a->mso, a->mpos, &ub,
                                  d_ss, d_want, ns));
+        if (a->presel_on && !a->full_only) a->presel_d2h += (int64_t)a->ml.size();
+        }
         int si = 0;
         for (size_t k = 0; k < a->ml.size(); k++) {
             while (si < ns && ub[k] >= a->lv.off[(size_t)si] + a->lv.n[(size_t)si]) si++;

@@ -340,7 +340,8 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
         if (take && sub_want) {      // pre-selection for the built-in picker: only matches present in every sample of the sub-index
             int lo2 = 0, hi2 = nsubs;
             while (lo2 < hi2) { const int mid = (lo2 + hi2) >> 1; if (sub_start[mid] <= u) lo2 = mid + 1; else hi2 = mid; }
-            take = n == sub_want[lo2 - 1];
+            const int w = sub_want[lo2 - 1];      // (0: every match of this sub-index; a value no match has: none)
+            take = (w == 0) | (n == (int64_t)w);
         }
         if (take && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
             if (EMIT) {

@@ -119,10 +119,15 @@ def test_same_alignment_with_preselection(name, inputs, minl, sa64, maxmums):
         assert sum(r[2] for r in tr1) < sum(r[2] for r in tr0)
 
 
+@pytest.mark.parametrize("host_filter", [False, True])
 @pytest.mark.parametrize("name,inputs,minl,sa64", CASES[:4])
-def test_handed_out_list_is_the_reference_head(name, inputs, minl, sa64):
+def test_handed_out_list_is_the_reference_head(monkeypatch, name, inputs, minl, sa64, host_filter):
     """the list itself: with pre-selection the picker receives exactly head(full list) -- in emission order, which
-    the stable sorts of head() turn into the same sorted list -- or the whole list where nothing spans every sample"""
+    the stable sorts of head() turn into the same sorted list -- or the whole list where nothing spans every sample.
+    host_filter: RV_PRESEL_HOST=1, every match copied to the host and filtered there (the scan kernel drops the matches
+    that are not in every sample of their sub-index otherwise, and scans the sub-indices without such a match again)"""
+    if host_filter:
+        monkeypatch.setenv("RV_PRESEL_HOST", "1")
     maxmums = 4
     full, got = {}, {}
 

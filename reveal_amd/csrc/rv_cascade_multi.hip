@@ -421,7 +421,7 @@ __global__ void k_casm_advance(u32 *__restrict__ counters) {
     counters[C_LO] = hi; counters[C_HI] = counters[C_NCHILD];
 }
 
-// ---- undecided sub-indices from their text: up to k intervals, at most RV_LEAF_N suffixes, one workgroup each (see k_cas_build) ----
+// ---- undecided sub-indices from their text: up to k intervals, at most BN suffixes, 256 per workgroup (see k_cas_rank in rv_cascade.hip) ----
 struct CmRoot { int64_t off; int32_t n, id; };
 // first x < lim with txt[i + x] != txt[j + x], or lim: eight bytes per step (related genomes: a suffix agrees with its k - 1
 // homologues for a hundred characters and more)

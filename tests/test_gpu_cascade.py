@@ -96,7 +96,7 @@ def test_cascade_gives_up_cleanly(monkeypatch):
 
 def test_cascade_with_undecided_subindices():
     """repeats of minl characters and more inside the gaps between anchors: sub-indices the match list cannot decide are rebuilt
-    from their text (k_cas_build) and finished by the leaf kernel"""
+    from their text (k_cas_rank / k_cas_emit) and finished by the leaf kernel"""
     rng = random.Random(8)
     seen = 0
     for case in range(6):

@@ -224,6 +224,14 @@ int rv_set_trace(rv_index *h, int on);
  * scan kernel (only what passes it is copied to the host; a sub-index left without a match is scanned again without the filter), the cap
  * on the host side of this ABI. */
 int rv_set_preselect(rv_index *h, int64_t maxmums);
+/* Switches of one handle: test hooks, diagnostics and A/B paths (reveal_amd/csrc/rv_common.h RV_OPTION_LIST has the names and
+ * defaults -- the historical RV_* spellings, e.g. "RV_NO_CASCADE").  The library never reads the process environment: a handle
+ * starts with the defaults, rv_set_option changes one switch of that handle (a copy() inherits them); the Python layer applies
+ * RV_* environment variables when it makes a handle.  No counterpart in the reference (its only switch is -DREVEALDEBUG). */
+int rv_set_option(rv_index *h, const char *name, int64_t value);
+int rv_get_option(rv_index *h, const char *name, int64_t *value);
+int rv_option_count(void);
+const char *rv_option_name(int k);
 int64_t rv_trace_count(rv_index *h);
 int rv_fetch_trace(rv_index *h, rv_trace *out, int64_t cap);
 

@@ -15,6 +15,7 @@ All compute happens in HBM through libreveal_amd[64].so; nothing here falls
 back to the CPU.
 """
 import ctypes
+import os
 import numpy as np
 
 from . import _lib
@@ -25,6 +26,9 @@ def _pairs(iv, sa64):
     """iterable of (begin, end) -> contiguous int64 array + count (iteration order kept)"""
     a = np.ascontiguousarray(np.array([(int(b), int(e)) for b, e in iv], dtype=np.int64).reshape(-1, 2))
     return a, len(a)
+
+
+_OPTION_DEFAULTS = {}      # (library width, switch) -> value a fresh handle carries
 
 
 def make_index_type(sa64, error):
@@ -50,6 +54,39 @@ def make_index_type(sa64, error):
             self._h = self._dll.rv_new(_lib.device())
             if not self._h:
                 raise error(self._lib.err())
+            self.options_from_env()
+
+        # ---- switches (not in the reference) ------------------------------------
+        def set_option(self, name, value=1):
+            """one switch of this handle (include/reveal_amd.h rv_set_option; names = the RV_* spellings of rv_common.h RV_OPTION_LIST)"""
+            if self._dll.rv_set_option(self._main._h, name.encode(), int(value)) != 0:
+                self._fail()
+
+        def get_option(self, name):
+            v = ctypes.c_int64(0)
+            if self._dll.rv_get_option(self._main._h, name.encode(), ctypes.byref(v)) != 0:
+                self._fail()
+            return v.value
+
+        def options_from_env(self):
+            """The library never reads the environment; this layer does, when a handle is made (and again when asked to): every RV_*
+            variable that names a switch is applied (empty value = 1), every switch without a variable goes back to its default."""
+            for k in range(self._dll.rv_option_count()):
+                name = self._dll.rv_option_name(k).decode()
+                v = os.environ.get(name)
+                if v is None:
+                    d = _OPTION_DEFAULTS.get((sa64, name))
+                    if d is None:
+                        d = _OPTION_DEFAULTS[(sa64, name)] = self.get_option(name)      # (a fresh handle: what rv_new set)
+                    elif self.get_option(name) != d:
+                        self.set_option(name, d)
+                    continue
+                try:
+                    iv = int(v) if v.strip() else 1
+                except ValueError:
+                    iv = 1
+                _OPTION_DEFAULTS.setdefault((sa64, name), self.get_option(name))
+                self.set_option(name, iv)
 
         # the main index of a sub-index (itself for a main index) -- kept as "None = self": an attribute that points back at its own object is
         # a reference cycle, and the handle (streams, pinned buffers, the index in HBM) would only be released when the cycle collector runs
@@ -300,7 +337,12 @@ def make_index_type(sa64, error):
 
             Same callback contracts as the reference; sub-indices are visited
             level by level instead of LIFO (children of a split are independent,
-            the anchor set is the same)."""
+            the anchor set is the same).
+
+            `threads` is accepted for call compatibility and ignored: the reference's worker threads (interface.c:338-386)
+            only run its C work concurrently -- here every sub-index of a level is processed by the same kernel launches, and
+            the Python callbacks run on the calling thread one after the other, as they do under the reference's `python`
+            mutex + GIL (reveal.c:779-780).  `wpen` / `wscore` are stored by the reference and never read in C; ignored too."""
             if not self._constructed:
                 raise error("Index not yet constructed, alignment stopped.")
             dll, h = self._dll, self._h

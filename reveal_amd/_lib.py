@@ -85,6 +85,10 @@ SYMBOLS = {
     "rv_fetch_anchors": (_I, [V, V, V, V]),
     "rv_set_trace": (_I, [V, _I]),
     "rv_set_preselect": (_I, [V, _L]),
+    "rv_set_option": (_I, [V, ctypes.c_char_p, _L]),
+    "rv_get_option": (_I, [V, ctypes.c_char_p, c_i64p]),
+    "rv_option_count": (_I, []),
+    "rv_option_name": (ctypes.c_char_p, [_I]),
     "rv_trace_count": (_L, [V]),
     "rv_fetch_trace": (_I, [V, V, _L]),
     "rv_clone": (V, [V]),

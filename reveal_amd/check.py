@@ -78,3 +78,39 @@ def recursion_properties(T0, T1, anchors, nsep, minl, chunk=1 << 25):
         out["anchors_collinear"] = True
     out["all"] = all(v for k, v in out.items() if isinstance(v, bool))
     return out
+
+
+# ---- digests of a whole result (what tests/golden/fullsize.json holds, written by oracle/gen_fullsize_golden.py) ----
+def array_digest(a):
+    """sha256 of an array's bytes as they lie in memory (SA: int32 / int64, LCP: int32 / uint32, text: uint8)"""
+    import hashlib
+    a = np.ascontiguousarray(a)
+    h = hashlib.sha256()
+    mv = memoryview(a).cast("B")
+    step = 1 << 28
+    for s in range(0, len(mv), step):
+        h.update(mv[s:s + step])
+    return h.hexdigest()
+
+
+def anchor_stream(l, off, pos):
+    """canonical form of an anchor set: anchors ordered by their first member's position (members never overlap, so that is a total
+    order), each written as l, member count, member positions -- one int64 stream"""
+    l = np.asarray(l, dtype=np.int64); off = np.asarray(off, dtype=np.int64); pos = np.asarray(pos, dtype=np.int64)
+    na = len(l)
+    if na == 0:
+        return np.zeros(0, dtype=np.int64)
+    cnt = np.diff(off)
+    order = np.argsort(pos[off[:-1]], kind="stable")
+    c = cnt[order]
+    start = np.cumsum(c + 2) - (c + 2)
+    out = np.empty(int((c + 2).sum()), dtype=np.int64)
+    out[start] = l[order]
+    out[start + 1] = c
+    within = np.arange(int(c.sum()), dtype=np.int64) - np.repeat(np.cumsum(c) - c, c)
+    out[np.repeat(start + 2, c) + within] = pos[np.repeat(off[:-1][order], c) + within]
+    return out
+
+
+def anchor_digest(l, off, pos):
+    return array_digest(anchor_stream(l, off, pos))

@@ -343,7 +343,7 @@ static int align_begin(rv_index *h, int minl, int minn, bool need_sai) {
     a->level = 0; a->cur = 0; a->scanned = false; a->d_err = nullptr; a->full_only = false; a->flag_clean = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false; a->use_leaf = false;
     a->presel_on = a->presel > 0;
-    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
+    a->par_min_cur = (h->ws.opt.bubble_par_min >= 0 ? h->ws.opt.bubble_par_min : bubble_par_default(a->multi));
     RV_TRY(a->dErr.reserve(64));
     RV_HIP(hipMemsetAsync(a->dErr.p, 0, 64, h->ws.stream));
     memset(&a->st, 0, sizeof a->st);
@@ -363,9 +363,9 @@ int rv_frontier_size(rv_index *h) { return h->al ? h->al->lv.size() : 0; }
 
 int rv_align_end(rv_index *h) {
     if (h->al) {
-        if (h->al->presel_on && getenv("RV_PRESEL_LOG"))
+        if (h->al->presel_on && h->ws.opt.presel_log)
             fprintf(stderr, "preselect: %lld match records copied to the host by the scans of this alignment (%s)\n", (long long)h->al->presel_d2h,
-                    getenv("RV_PRESEL_HOST") ? "every match, filtered on the host" : "the scan kernel keeps only matches present in every sample of their sub-index");
+                    h->ws.opt.presel_host ? "every match, filtered on the host" : "the scan kernel keeps only matches present in every sample of their sub-index");
         h->al->presel_d2h = 0;
         h->al->lv.clear(); h->al->scanned = false;
     }
@@ -423,7 +423,7 @@ static int leaf_launch(rv_index *h) {
     la.roots = droots.as<RvLeafRoot>();
     la.SA = cur_sa(h); la.LCP = cur_lcp(h); la.BWT = cur_bwt(h);
     la.nsep0 = h->nsep[0]; la.minl = a->minl; la.lcap = h->maxlcp;
-    la.stage_cap = getenv("RV_LEAF_ACAP") ? (u32)atoi(getenv("RV_LEAF_ACAP")) : 256u;
+    la.stage_cap = (u32)h->ws.opt.leaf_acap;
     la.anchor_count = a->lf_counters; la.anchor_cap = (u32)a->leaf_anchor_cap; la.anchor_l = a->lf_l; la.anchor_pos = a->lf_pos;
     la.stats = a->lf_stats;
     la.trace = a->trace_on ? 1 : 0; la.trace_count = a->lf_counters + 1; la.trace_cap = (u32)a->leaf_trace_cap; la.trace_out = a->lf_tr;
@@ -523,7 +523,7 @@ static int early_split(rv_index *h) {
     // (a level that still has a sub-index above the rounds' threshold keeps the host-built mix of rounds and joined children)
     // (ns > 4096 through the size-class launches below: tried at 2 x 250 Mbp, 304 against 300 ms -- five launches over every
     // descriptor cost more GPU time than the hidden host time is worth; RV_EARLY_BUBBLE_MANY=1 switches it on)
-    if (biggest <= a->par_min_cur && !getenv("RV_BUBBLE_LDS_ALWAYS") && !getenv("RV_NO_EARLY_BUBBLE") && (ns <= 4096 || getenv("RV_EARLY_BUBBLE_MANY"))) {
+    if (biggest <= a->par_min_cur && !h->ws.opt.bubble_lds_always && !h->ws.opt.no_early_bubble && (ns <= 4096 || h->ws.opt.early_bubble_many)) {
         RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, 2 * ns));
         {
             const void *before = a->dFlag.p;
@@ -638,7 +638,7 @@ static int early_split_multi(rv_index *h) {
     // launches of rv_frontier_commit) -- the whole level is queued before the host has seen the picks.
     int64_t biggest = 0;
     for (int s2 = 0; s2 < ns; s2++) biggest = std::max<int64_t>(biggest, lv.n[(size_t)s2]);
-    if (biggest <= a->par_min_cur && !getenv("RV_NO_EARLY_BUBBLE")) {
+    if (biggest <= a->par_min_cur && !h->ws.opt.no_early_bubble) {
         RV_TRY(rv_lower_ranges_launch(h->ws, h->dT.as<uint8_t>(), d.mb, d.me, W * ns));
         {
             const void *before = a->dFlag.p;
@@ -727,7 +727,7 @@ int rv_frontier_scan(rv_index *h) {
         // expose the launch latency of the whole scan).
         const int64_t *d_ss = (a->full_only && (a->level > 0 || a->cur_dev_ok)) ? a->d_next_ss : nullptr;
         a->early_done = false; a->early_bubble = false;
-        const bool early = d_ss && a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
+        const bool early = d_ss && a->cur_dev_ok && !h->ws.opt.no_early_split;
         a->hook_early = early;
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
         RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, level_hook, early || a->leaf_launch_due,
@@ -746,7 +746,7 @@ int rv_frontier_scan(rv_index *h) {
             // built-in picker without tracing: the device returns, per sub-index, the match the picker would take (the tables
             // came with the previous commit's upload)
             a->early_done = false; a->early_bubble = false;
-            const bool early = a->cur_dev_ok && !getenv("RV_NO_EARLY_SPLIT");
+            const bool early = a->cur_dev_ok && !h->ws.opt.no_early_split;
             bool redo = false;
             RV_TRY(rv_run_multi_pick(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->minn, a->d_next_ss, a->d_next_want, ns, a->d_next_tsub, a->pick_l, a->pick_pos,
                                      early ? early_split_multi : nullptr, &redo));
@@ -777,7 +777,7 @@ int rv_frontier_scan(rv_index *h) {
             RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
             d_ss = (const int64_t *)(buf.as<uint8_t>() + o1); d_want = (const int *)(buf.as<uint8_t>() + o2);
         }
-        const bool dev_filter = a->presel_on && !a->full_only && ns > 0 && !getenv("RV_PRESEL_HOST");
+        const bool dev_filter = a->presel_on && !a->full_only && ns > 0 && !h->ws.opt.presel_host;
         if (dev_filter) {
             // rv_set_preselect: the picker only ever sees the matches present in every sample of their sub-index (schemes.py:227) --
             // the scan kernel drops the others, they never cross into host memory.  A sub-index without such a match keeps its whole list
@@ -999,7 +999,7 @@ static void prep_level_tables(rv_index *h, const Level &nx, int64_t m_next, bool
         // more than two samples: one (begin, end) slot per sample and sub-index; a sub-index with two intervals of one sample
         // (multi-contig inputs) sends the level to the host path
         const int W = h->nsamples;
-        a->next_dev_ok = W <= 64 && !getenv("RV_KEEP_DEAD") && !a->trace_on;
+        a->next_dev_ok = W <= 64 && !h->ws.opt.keep_dead && !a->trace_on;
         if (a->next_dev_ok) {
             a->next_nodes.assign((size_t)nsn * 2 * W, 0); a->next_flags.assign((size_t)nsn, 0);
             for (int s2 = 0; s2 < nsn && a->next_dev_ok; s2++) {
@@ -1069,11 +1069,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     a->sub_start.resize((size_t)ns + 1);
     for (auto &r : a->rounds) r.clear();
     a->kids_small.clear(); a->kids_big.clear(); a->kids_lds.clear();
-    const int64_t lds_n = getenv("RV_BUBBLE_NO_LDS") ? 0 : RV_BUBBLE_LDS_N;
+    const int64_t lds_n = h->ws.opt.bubble_no_lds ? 0 : RV_BUBBLE_LDS_N;
     int64_t running = 0;
     const int64_t lcap = (int64_t)h->maxlcp;
     // leading children above this many ranks take the data-parallel bubble rounds (RV_BUBBLE_PAR_MIN: test hook)
-    const int64_t par_min = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
+    const int64_t par_min = (h->ws.opt.bubble_par_min >= 0 ? h->ws.opt.bubble_par_min : bubble_par_default(a->multi));
     struct Ent { int64_t b, e; uint8_t c; };
     std::vector<Ent> ent;
     a->kid_tmp.clear();
@@ -1099,7 +1099,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         // them like members of another child), the child is never made.  Anchors and text are unaffected; the number of
         // sub-indices visited is smaller than the reference's.
         bool dead[3] = {false, false, false};
-        if (a->multi && a->full_only && !dc.host_lists && !getenv("RV_KEEP_DEAD"))
+        if (a->multi && a->full_only && !dc.host_lists && !h->ws.opt.keep_dead)
             for (int c = 0; c < 3; c++) dead[c] = cnts[c] > 0 && child_is_dead(h, lists[c], cnts[c], a->minl, a->minn);
         // class table of this sub: lead/trail/rest merged by begin (the split's tables: not needed when the split of this level ran
         // already, from the same tables built on the device -- early_split; those decisions come from the built-in picker, whose
@@ -1167,13 +1167,13 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     // Leading children above par_min ranks take the data-parallel rounds.  Once a level runs those rounds anyway, the small
     // children join them as long as there are few of them (measured: with thousands of small children per level the
     // one-workgroup-per-child kernel is the cheaper way, C3/C4): their kernel would only add its own latency in front.
-    const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !getenv("RV_BUBBLE_NO_JOIN") && !a->early_bubble;
+    const bool all_par = any_par && window_sum <= ((int64_t)1 << 20) && !h->ws.opt.bubble_no_join && !a->early_bubble;
     // The LDS kernels pay off by throughput (thousands of small children per level: many samples, or very large inputs).  A
     // few hundred small children ride along with the larger ones for free (measured on C2: 612 vs 597 Mbp/s).
     size_t lds_candidates = 0;
     for (const auto &kd : a->kid_tmp) lds_candidates += kd.n <= lds_n;
     // (more than two samples: many cuts per child, no leaf kernel -- the LDS kernel is always the better one for small children)
-    const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && (a->multi || getenv("RV_BUBBLE_LDS_ALWAYS")));
+    const bool use_lds = lds_candidates > 1024 || (lds_candidates > 0 && (a->multi || h->ws.opt.bubble_lds_always));
     for (const auto &kd : a->kid_tmp) {
         if (a->early_bubble && kd.n <= par_min) continue;      // bubbled already, right behind the early split
         if ((!all_par && kd.n <= par_min) || (use_lds && kd.n <= lds_n)) {             // every cut of this child in one workgroup, sequentially
@@ -1240,7 +1240,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_desc = pk.addv(a->descs), o_woff = pk.addv(a->woff), o_toff = pk.addv(a->toff), o_mf = pk.addv(split_tabs ? a->mend_first : no_int), o_mp = pk.addv(a->mend_pos);
     // one launch instead of two when a level has few small children next to large ones (the kernels would run one after the
     // other on the stream; in a 1024-thread workgroup a small child simply finishes early)
-    if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !getenv("RV_BUBBLE_NO_MERGE")) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
+    if (!a->kids_big.empty() && a->kids_small.size() <= 512 && !h->ws.opt.bubble_no_merge) { a->kids_big.insert(a->kids_big.end(), a->kids_small.begin(), a->kids_small.end()); a->kids_small.clear(); }
     int lds_count[3] = {0, 0, 0};
     {   // LDS children by size class (stable: the order inside a class does not matter)
         auto cls = [](const RvBubbleDesc &x) { return x.n <= RV_BUBBLE_LDS_N0 ? 0 : x.n <= RV_BUBBLE_LDS_N1 ? 1 : 2; };
@@ -1265,7 +1265,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     const size_t o_bstate = pk.reserve((a->descs.size() + 1) * sizeof(RvBubbleState));
     RV_TRY(a->dTab.reserve(pk.size() + 64));
     a->lgx[3] = now_s() - t0;     // offsets packed
-    if (pk.pageable || getenv("RV_TABLES_MEMCPY")) RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
+    if (pk.pageable || h->ws.opt.tables_memcpy) RV_HIP(hipMemcpyAsync(a->dTab.p, pk.data(), pk.size(), hipMemcpyHostToDevice, q));
     else { pk.grow(pk.size() + 16); RV_TRY(rv_h2d_copy(h->ws, pk.data(), a->dTab.p, pk.size())); }
     a->lg[1] = now_s() - t0;      // upload issued
     uint8_t *tb = a->dTab.as<uint8_t>();
@@ -1290,7 +1290,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     {
         const int cur_id = (a->level == 0) ? RV_LEVEL_BUFS : a->cur;            // RV_LEVEL_BUFS = the main arrays
         (void)cur_id;
-        const int wait_ids[2] = {nxt, getenv("RV_BUBBLE_PARENT_SCRATCH") && !a->descs.empty() ? cur_id : -1};
+        const int wait_ids[2] = {nxt, h->ws.opt.bubble_parent_scratch && !a->descs.empty() ? cur_id : -1};
         for (int k = 0; k < 2; k++) {
             const int id = wait_ids[k];
             if (id < 0) continue;
@@ -1349,11 +1349,11 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         ba.SA = sa.SA_out; ba.LCP = sa.LCP_out; ba.BWT = sa.BWT_out; ba.SAi = sa.SAi; ba.cut_lo = sa.cut_lo; ba.cut_hi = sa.cut_hi; ba.err = sa.err;
         ba.state = (RvBubbleState *)(tb + o_bstate);
         ba.dbg = nullptr;
-        if (getenv("RV_LEVEL_LOG")) { if (!a->dDbg.p) { RV_TRY(a->dDbg.reserve(64)); RV_HIP(hipMemsetAsync(a->dDbg.p, 0, 64, q)); } ba.dbg = a->dDbg.as<unsigned long long>(); }
+        if (h->ws.opt.level_log) { if (!a->dDbg.p) { RV_TRY(a->dDbg.reserve(64)); RV_HIP(hipMemsetAsync(a->dDbg.p, 0, 64, q)); } ba.dbg = a->dDbg.as<unsigned long long>(); }
         // the parent level is dead once split has run (at level 0 these are the main SA/LCP/BWT, which the
         // reference frees at this point, reveal.c:1279-1284): scratch for the grid-wide long moves
         ba.scrSA = const_cast<sa_t *>(cur_sa(h)); ba.scrLCP = const_cast<lcp_t *>(cur_lcp(h)); ba.scrBWT = const_cast<uint8_t *>(cur_bwt(h));
-        if (!a->descs.empty() && !getenv("RV_BUBBLE_PARENT_SCRATCH")) {
+        if (!a->descs.empty() && !h->ws.opt.bubble_parent_scratch) {
             // ... but this level's leaf launch (second stream, ~180 us) still reads them, and waiting for it left the main
             // stream idle for ~40 us at every level that has both leaf sub-indices and data-parallel rounds: own scratch
             // (9 B per rank of the next level; RV_BUBBLE_PARENT_SCRATCH=1 = the parent arrays and the wait, as before)
@@ -1382,7 +1382,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
             ba.par.Qbw = pb; pb += W;
             ba.par.Qlast = pb;
             ba.par.tready = nullptr; ba.par.epoch = 0;
-            if (!getenv("RV_PB_TWO_PASS")) {      // (test hook: copy-out + scatter as two kernels through the scratch arrays)
+            if (!h->ws.opt.pb_two_pass) {      // (test hook: copy-out + scatter as two kernels through the scratch arrays)
                 const size_t before = a->dPbReady.cap;
                 RV_TRY(a->dPbReady.reserve(TT * 4 + 64));
                 if (a->dPbReady.cap != before) RV_HIP(hipMemsetAsync(a->dPbReady.p, 0, a->dPbReady.cap, q));      // launch numbers start at 1
@@ -1458,7 +1458,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
 static int builtin_leaf_setup(rv_index *h) {
     Align *a = h->al;
     hipStream_t q = h->ws.stream;
-    a->use_leaf = !a->multi && !getenv("RV_NO_LEAF");
+    a->use_leaf = !a->multi && !h->ws.opt.no_leaf;
     a->leaf_flip = 0;
     if (!a->use_leaf) return 0;
     a->leaf_anchor_cap = (size_t)(h->nT / std::max(a->minl, 1)) + 1024;
@@ -1493,7 +1493,7 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     Align *a = h->al;
     a->full_only = !a->trace_on;
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
-    const bool use_leaf = !a->multi && !getenv("RV_NO_LEAF");
+    const bool use_leaf = !a->multi && !h->ws.opt.no_leaf;
     a->use_leaf = use_leaf;
     // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
     // the levels after it), so the first level takes the same path as the others
@@ -1536,7 +1536,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
     const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
     int &leaf_flip = a->leaf_flip;
-    const bool level_log = getenv("RV_LEVEL_LOG") != nullptr;      // diagnostics: per-level wall time (adds a sync per level)
+    const bool level_log = (h->ws.opt.level_log != 0);      // diagnostics: per-level wall time (adds a sync per level)
     while (a->lv.size() > 0) {
         if (stop_subs > 0 && a->level > 0 && a->lv.size() >= stop_subs) break;      // hand-off point (rv_frontier_export)
         const double tl0 = level_log ? now_s() : 0.0;
@@ -1710,7 +1710,7 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
         RV_HIP(hipStreamSynchronize(q));
         u32 cnt[4]; unsigned long long stv[8];
         memcpy(cnt, a->hLeafOut.p, sizeof cnt); memcpy(stv, a->hLeafOut.as<uint8_t>() + 64, sizeof stv);
-        if (getenv("RV_LEAF_PROF"))      // (a build with -DRV_LEAF_PROF: wave cycles waiting for a sub-index / scan + pick / split / bubble + children)
+        if (h->ws.opt.leaf_prof)      // (a build with -DRV_LEAF_PROF: wave cycles waiting for a sub-index / scan + pick / split / bubble + children)
             fprintf(stderr, "leaf: steps %llu splits %llu | cycles idle %llu scan %llu split %llu bubble %llu\n", stv[0], stv[1], stv[4], stv[5], stv[6], stv[7]);
         if (cnt[2]) { rv_set_error(cnt[2] & 4u ? "leaf kernel: recursion stack overflow" : "leaf kernel: a sub-index does not match its intervals"); return -1; }
         if (cnt[0] > a->leaf_anchor_cap || cnt[1] > a->leaf_trace_cap) { rv_set_error("leaf kernel: output buffer too small"); return -1; }
@@ -1748,8 +1748,8 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
 static int builtin_cascade(rv_index *h) {
     Align *a = h->al;
     memset(&a->cas_out, 0, sizeof a->cas_out);
-    if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || getenv("RV_NO_CASCADE")) return 0;
-    const bool second_try = !a->multi && a->use_leaf && getenv("RV_CASCADE_SECOND") != nullptr && atoi(getenv("RV_CASCADE_SECOND")) == 2;      // (test hook: straight to the second attempt)
+    if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || h->ws.opt.no_cascade) return 0;
+    const bool second_try = !a->multi && a->use_leaf && h->ws.opt.cascade_second == 2;      // (test hook: straight to the second attempt)
     auto interval_cascade = [&]() -> int {
         // the decided part's anchors come back on the host, what is undecided becomes the frontier of the level pipeline
         RvCascadeMultiOut mo;
@@ -1780,10 +1780,10 @@ static int builtin_cascade(rv_index *h) {
     RvCascadeIO io;
     io.anchor_count = a->lf_counters; io.anchor_cap = (u32)a->leaf_anchor_cap; io.anchor_l = a->lf_l; io.anchor_pos = a->lf_pos;
     io.stats = a->lf_stats; io.leaf_err = a->lf_counters + 2;
-    io.stage_cap = getenv("RV_LEAF_ACAP") ? (u32)atoi(getenv("RV_LEAF_ACAP")) : 256u;
+    io.stage_cap = (u32)h->ws.opt.leaf_acap;
     io.lvSA = &a->lvSA[0]; io.lvLCP = &a->lvLCP[0]; io.lvBWT = &a->lvBWT[0]; io.roots = &a->dLeafRoots[0];
     // RV_CASCADE_DANGER=0: no second attempt of this kind; =2: the first attempt already decides large undecided sub-indices from their witnesses (test hook)
-    const int dmode = getenv("RV_CASCADE_DANGER") ? atoi(getenv("RV_CASCADE_DANGER")) : 1;
+    const int dmode = (int)h->ws.opt.cascade_danger;
     RV_TRY(rv_cascade_run(h, a->cas, io, a->minl, &a->cas_out, dmode == 2 ? 1 : 0, 0));
     if (!a->cas_out.done && a->cas_out.undecided > 0 && dmode == 1) {
         // an undecided sub-index above the leaf kernel's size: the same cascade again (its lists are still there), now with the large
@@ -1795,7 +1795,7 @@ static int builtin_cascade(rv_index *h) {
         RV_HIP(hipMemsetAsync(a->dLeaf.p, 0, 256, h->ws.stream));      // anchors and counters of the attempt
         // still one left: another attempt with the bound of rv_cascade_multi.hip (repeats inside one
         // sample: tighter) whose undecided sub-indices -- up to 8192 suffixes -- go to the level pipeline instead of the leaf kernel
-        if (a->cas_out.undecided > 0 && !getenv("RV_CASCADE_SECOND_OFF")) return interval_cascade();
+        if (a->cas_out.undecided > 0 && !h->ws.opt.cascade_second_off) return interval_cascade();
         return 0;
     }
     a->st.levels += a->cas_out.levels;
@@ -1991,7 +1991,7 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         a->multi = h->nsamples > 2;
         a->scanned = false; a->d_err = nullptr; a->flag_clean = false;
         a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
-        a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
+        a->par_min_cur = (h->ws.opt.bubble_par_min >= 0 ? h->ws.opt.bubble_par_min : bubble_par_default(a->multi));
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
         a->full_only = !a->trace_on;
@@ -2044,7 +2044,7 @@ static int sx_load(rv_subindex *x, int minl, int minn) {
     a->scanned = false; a->d_err = nullptr; a->flag_clean = false; a->full_only = false; a->use_leaf = false; a->leaf_launch_due = false;
     a->next_dev_ok = a->cur_dev_ok = a->early_done = a->early_bubble = false;
     a->presel_on = false;        // getmums / getmultimums of a detached index hand out every match
-    a->par_min_cur = getenv("RV_BUBBLE_PAR_MIN") ? atoll(getenv("RV_BUBBLE_PAR_MIN")) : bubble_par_default(a->multi);
+    a->par_min_cur = (h->ws.opt.bubble_par_min >= 0 ? h->ws.opt.bubble_par_min : bubble_par_default(a->multi));
     RV_TRY(a->dErr.reserve(64));
     memset(&a->st, 0, sizeof a->st);
     const int64_t meta[6] = {0, x->n, x->depth, x->nsamples, 0, -1};

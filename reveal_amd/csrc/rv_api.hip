@@ -19,19 +19,35 @@ void rv_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
-// live handles, for rv_oom_trim (rv_common.h)
+// live handles, for rv_oom_trim (rv_common.h).  rv_trim_mutex() guards the list and every change of a handle's sa_in_use flag
+// (SaScratchInUse takes it): while a trim holds it no handle can enter construct(), so the scratch of a handle found idle stays
+// idle until it has been released.  Host threads driving one handle each (bench.py --jobs) meet here and nowhere else.
 static std::vector<rv_index *> &live_handles() { static std::vector<rv_index *> v; return v; }
+std::mutex &rv_trim_mutex() { static std::mutex *m = new std::mutex(); return *m; }
 bool rv_oom_trim() {
     size_t got = 0;
-    for (rv_index *h : live_handles()) {
-        if (h->ws.sa_in_use) continue;
-        (void)hipSetDevice(h->device);
-        (void)hipDeviceSynchronize();          // nothing may still be reading what is released
-        got += h->ws.trim_sa();
+    bool log = false;
+    int caller_dev = 0;
+    const bool have_dev = hipGetDevice(&caller_dev) == hipSuccess;
+    {
+        std::lock_guard<std::mutex> g(rv_trim_mutex());
+        for (rv_index *h : live_handles()) {
+            log = log || h->ws.opt.cascade_log != 0;
+            if (h->ws.sa_in_use) continue;
+            bool any = false;
+            for (auto &b : h->ws.sa) any = any || b.p;
+            if (!any) continue;
+            (void)hipSetDevice(h->device);
+            (void)hipDeviceSynchronize();          // nothing may still be reading what is released
+            got += h->ws.trim_sa();
+        }
     }
-    if (getenv("RV_CASCADE_LOG") && got) fprintf(stderr, "reveal_amd: device memory short, released %.1f GB of SA-build scratch\n", got / 1e9);
+    if (have_dev) (void)hipSetDevice(caller_dev);      // the retry in DBuf::reserve allocates on the caller's device, not on the last handle's
+    if (log && got) fprintf(stderr, "reveal_amd: device memory short, released %.1f GB of SA-build scratch\n", got / 1e9);
     return got > 0;
 }
+
+int g_rv_launch_trace = 0;
 
 extern "C" {
 
@@ -66,13 +82,13 @@ rv_index *rv_new(int device) {
     h->ws.prof_ctx = &h->prof;
     h->ws.prof_begin_fn = [](void *c, hipStream_t st, int k, double b) { return ((RvProf *)c)->begin(st, k, b); };
     h->ws.prof_end_fn = [](void *c, hipStream_t st, int id) { ((RvProf *)c)->end(st, id); };
-    live_handles().push_back(h);
+    { std::lock_guard<std::mutex> g(rv_trim_mutex()); live_handles().push_back(h); }
     return h;
 }
 
 void rv_free(rv_index *h) {
     if (!h) return;
-    { auto &v = live_handles(); v.erase(std::remove(v.begin(), v.end(), h), v.end()); }
+    { std::lock_guard<std::mutex> g(rv_trim_mutex()); auto &v = live_handles(); v.erase(std::remove(v.begin(), v.end(), h), v.end()); }
     (void)hipSetDevice(h->device);
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
     rv_align_free(h);
@@ -86,6 +102,39 @@ void rv_free(rv_index *h) {
     delete h;
 }
 
+/* switches of one handle (rv_common.h RV_OPTION_LIST): test hooks, diagnostics, A/B paths.  The library itself never looks at the
+ * process environment. */
+int rv_set_option(rv_index *h, const char *name, int64_t value) {
+    if (!h || !name) { rv_set_error("rv_set_option: null argument"); return -1; }
+    int64_t *f = h->ws.opt.find(name);
+    if (!f) { rv_set_error("rv_set_option: unknown option %s", name); return -1; }
+    *f = value;
+    if (strcmp(name, "RV_LAUNCH_TRACE") == 0) g_rv_launch_trace = value != 0;
+    return 0;
+}
+int rv_get_option(rv_index *h, const char *name, int64_t *value) {
+    if (!h || !name || !value) { rv_set_error("rv_get_option: null argument"); return -1; }
+    const int64_t *f = h->ws.opt.find(name);
+    if (!f) { rv_set_error("rv_get_option: unknown option %s", name); return -1; }
+    *value = *f;
+    return 0;
+}
+int rv_option_count(void) {
+    int c = 0;
+#define RV_X_(f, nm, def) c++;
+    RV_OPTION_LIST(RV_X_)
+#undef RV_X_
+    return c;
+}
+const char *rv_option_name(int k) {
+    static const char *const names[] = {
+#define RV_X_(f, nm, def) nm,
+        RV_OPTION_LIST(RV_X_)
+#undef RV_X_
+    };
+    return k >= 0 && k < rv_option_count() ? names[k] : nullptr;
+}
+
 /* copy() (interface.c:432-470) of a main index: an independent handle with its own text (incl. the lower-case marks of
  * the working copy), SA, SAi, LCP.  The reference also resets depth / file names of the source and hands its SO to nobody
  * (self->SO = NULL, interface.c:462): not imitated. */
@@ -96,6 +145,7 @@ rv_index *rv_clone(rv_index *h) {
     if (!c) return nullptr;
     c->T = h->T; c->nsep = h->nsep; c->nodes = h->nodes; c->nsamples = h->nsamples; c->n = h->n; c->nT = h->nT; c->rc = h->rc;
     c->maxlcp = h->maxlcp; c->sa_stats = h->sa_stats; c->text_dirty = true;
+    c->ws.opt = h->ws.opt;
     const int64_t n = h->n;
     hipStream_t q = c->ws.stream;
     bool ok = rv_upload(c) == 0;
@@ -463,8 +513,8 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
             if (!h->ev_picks) RV_HIP(hipEventCreateWithFlags(&h->ev_picks, hipEventDisableTiming));
             RV_HIP(hipEventRecord(h->ev_picks, q));
             if (use_hook && after_pick) RV_TRY(after_pick(h));
-            if (getenv("RV_SYNC_BLOCK")) { RV_HIP(hipEventSynchronize(h->ev_picks)); }
-            else { hipError_t qe; while ((qe = hipEventQuery(h->ev_picks)) == hipErrorNotReady) {} if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; } }
+            if (h->ws.opt.sync_block) { RV_HIP(hipEventSynchronize(h->ev_picks)); }
+            else { const hipError_t qe = rv_event_wait(h->ev_picks); if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; } }
             const u32 *hdr = h->hscan.as<u32>();
             const u32 novf = hdr[1];
             if (err_out) *err_out = hdr[2];
@@ -642,8 +692,7 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
             RV_HIP(hipMemcpyAsync(hp + o2, bpos.p, b2, hipMemcpyDeviceToHost, q));
             RV_HIP(hipEventRecord(h->ws.ev_rb, q));
             if (attempt == 0 && after_pick) RV_TRY(after_pick(h));      // (queued behind the copies: the host gets the picks first)
-            hipError_t qe;
-            while ((qe = hipEventQuery(h->ws.ev_rb)) == hipErrorNotReady) {}
+            const hipError_t qe = rv_event_wait(h->ws.ev_rb);
             if (qe != hipSuccess) { rv_set_error("stream: %s", hipGetErrorString(qe)); return -1; }
             memcpy(&ncand, hp, 4); memcpy(pick_l.data(), hp + o1, b1); memcpy(pick_pos.data(), hp + o2, b2);
         }

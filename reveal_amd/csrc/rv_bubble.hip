@@ -489,7 +489,7 @@ int rv_bubble_par_round_launch(Workspace &ws, const RvBubbleArgs &b, int first, 
     RV_TRY(rv_bubble_window_launch(ws, b, first, count, total_window));
     hipLaunchKernelGGL(k_pb_runs, dim3(wb), dim3(TB), 0, q, b, first, count, total_window);
     RV_LAUNCH_CHECK();
-    if (refresh_tmin || getenv("RV_PB_REFRESH_TMIN")) {
+    if (refresh_tmin || ws.opt.pb_refresh_tmin) {
         hipLaunchKernelGGL(k_pb_tilemin, dim3((unsigned)total_tiles), dim3(TB), 0, q, b, first, count);
         RV_LAUNCH_CHECK();
     }

@@ -657,7 +657,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     hipStream_t q = ws.stream;
     const int64_t n = h->n;
     const u32 minl = (u32)std::max(minl_in, 1);
-    const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
+    const bool verbose = (ws.opt.cascade_log != 0);
     double tp[6] = {0, 0, 0, 0, 0, 0};
     if (verbose) { (void)hipStreamSynchronize(q); tp[0] = cas_now(); }
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade: gave up: %s\n", msg); return 0; } while (0)
@@ -794,7 +794,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         dg.T0 = h->dT0.as<uint8_t>(); dg.LCP = LCP;
         // every undecided sub-index this way, not only the ones the leaf kernel cannot take: the walk costs less than rebuilding a sub-index that
         // sits inside a repeat (RV_CASCADE_DANGER_MIN: only sub-indices above that size)
-        dg.leaf_n = getenv("RV_CASCADE_DANGER_MIN") ? (u32)atoi(getenv("RV_CASCADE_DANGER_MIN")) : 0u;
+        dg.leaf_n = (u32)ws.opt.cascade_danger_min;
     }
     hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
                        bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag, dg.ceil);
@@ -804,7 +804,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     // ---- the levels: queued in batches, the level's range of sub-indices lives on the device (k_cas_advance), the host only looks
     // at the counters between batches (a level on an empty range costs its launches, nothing else)
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
-    const int batch = getenv("RV_CASCADE_BATCH") ? std::max(1, atoi(getenv("RV_CASCADE_BATCH"))) : 8;
+    const int batch = std::max(1, (int)ws.opt.cascade_batch);
     int queued = 0;
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {

@@ -563,7 +563,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const int64_t n = h->n;
     const int k = h->nsamples;
     const u32 minl = (u32)std::max(minl_in, 1);
-    const bool verbose = getenv("RV_CASCADE_LOG") != nullptr;
+    const bool verbose = (ws.opt.cascade_log != 0);
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s\n", k, msg); return 0; } while (0)
     if (k < 2 || k > RV_CASM_K) GIVE_UP("sample count outside the cascade's range");      // (two samples: the second attempt of rv_align.hip, see there)
     if ((int)h->nodes.size() != k || (int)h->nsep.size() != k - 1) GIVE_UP("not one sequence per sample");
@@ -658,7 +658,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     hipLaunchKernelGGL(k_casm_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, t, k, d_rb, d_re, counters, bwc.as<u32>(), NW);
     RV_LAUNCH_CHECK();
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
-    const int batch = getenv("RV_CASCADE_BATCH") ? std::max(1, atoi(getenv("RV_CASCADE_BATCH"))) : 8;
+    const int batch = std::max(1, (int)ws.opt.cascade_batch);
     int queued = 0;
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {

@@ -5,10 +5,12 @@
 // -DRV_SA64 = reveallib64 (int64 SA, uint32 LCP).
 #pragma once
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <utility>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 #include <stddef.h>
 #include <vector>
 #include <string>
@@ -39,9 +41,65 @@ void rv_set_error(const char *fmt, ...);
         int r_ = (x);                                                                          \
         if (r_ != 0) return r_;                                                                \
     } while (0)
+// ---- switches (test hooks, diagnostics, A/B paths).  The library never reads the process environment: a handle starts with the
+// defaults below and rv_set_option() (include/reveal_amd.h) changes one; the Python layer applies RV_* environment variables
+// when it makes a handle (reveal_amd/_index.py).  name = the historical environment spelling.
+#define RV_OPTION_LIST(X) \
+    X(bubble_par_min, "RV_BUBBLE_PAR_MIN", -1) \
+    X(presel_log, "RV_PRESEL_LOG", 0) \
+    X(presel_host, "RV_PRESEL_HOST", 0) \
+    X(leaf_acap, "RV_LEAF_ACAP", 256) \
+    X(bubble_lds_always, "RV_BUBBLE_LDS_ALWAYS", 0) \
+    X(no_early_bubble, "RV_NO_EARLY_BUBBLE", 0) \
+    X(early_bubble_many, "RV_EARLY_BUBBLE_MANY", 0) \
+    X(no_early_split, "RV_NO_EARLY_SPLIT", 0) \
+    X(keep_dead, "RV_KEEP_DEAD", 0) \
+    X(bubble_no_lds, "RV_BUBBLE_NO_LDS", 0) \
+    X(bubble_no_join, "RV_BUBBLE_NO_JOIN", 0) \
+    X(bubble_no_merge, "RV_BUBBLE_NO_MERGE", 0) \
+    X(tables_memcpy, "RV_TABLES_MEMCPY", 0) \
+    X(bubble_parent_scratch, "RV_BUBBLE_PARENT_SCRATCH", 0) \
+    X(level_log, "RV_LEVEL_LOG", 0) \
+    X(pb_two_pass, "RV_PB_TWO_PASS", 0) \
+    X(no_leaf, "RV_NO_LEAF", 0) \
+    X(leaf_prof, "RV_LEAF_PROF", 0) \
+    X(no_cascade, "RV_NO_CASCADE", 0) \
+    X(cascade_second, "RV_CASCADE_SECOND", 0) \
+    X(cascade_danger, "RV_CASCADE_DANGER", 1) \
+    X(cascade_second_off, "RV_CASCADE_SECOND_OFF", 0) \
+    X(sync_block, "RV_SYNC_BLOCK", 0) \
+    X(pb_refresh_tmin, "RV_PB_REFRESH_TMIN", 0) \
+    X(cascade_log, "RV_CASCADE_LOG", 0) \
+    X(cascade_danger_min, "RV_CASCADE_DANGER_MIN", 0) \
+    X(cascade_batch, "RV_CASCADE_BATCH", 8) \
+    X(lcp_by_rank, "RV_LCP_BY_RANK", 0) \
+    X(no_tiny_sa, "RV_NO_TINY_SA", 0) \
+    X(no_short_alphabet, "RV_NO_SHORT_ALPHABET", 0) \
+    X(no_fused_lcp, "RV_NO_FUSED_LCP", 0) \
+    X(no_diag, "RV_NO_DIAG", 0) \
+    X(no_packed_text, "RV_NO_PACKED_TEXT", 0) \
+    X(no_heads_fusion, "RV_NO_HEADS_FUSION", 0) \
+    X(no_twin_collapse, "RV_NO_TWIN_COLLAPSE", 0) \
+    X(no_pub_twins, "RV_NO_PUB_TWINS", 0) \
+    X(sa_no_text, "RV_SA_NO_TEXT", 0) \
+    X(text_mode, "RV_TEXT_MODE", -1) \
+    X(carry_ch, "RV_CARRY_CH", -1) \
+    X(launch_trace, "RV_LAUNCH_TRACE", 0)
+struct RvOptions {
+#define RV_X_(f, name, def) int64_t f = def;
+    RV_OPTION_LIST(RV_X_)
+#undef RV_X_
+    int64_t *find(const char *name) {
+#define RV_X_(f, nm, def) if (strcmp(name, nm) == 0) return &f;
+        RV_OPTION_LIST(RV_X_)
+#undef RV_X_
+        return nullptr;
+    }
+};
+extern int g_rv_launch_trace;      // process-wide (rv_api.hip): set by rv_set_option(.., "RV_LAUNCH_TRACE", ..) of any handle
 // RV_LAUNCH_TRACE=1 (diagnostics): print the source line of every kernel launch and wait for it, so that a GPU memory fault
 // (which aborts the process) names the kernel behind it
-static inline bool rv_launch_trace_on() { static const int on = getenv("RV_LAUNCH_TRACE") ? 1 : 0; return on != 0; }
+static inline bool rv_launch_trace_on() { return g_rv_launch_trace != 0; }
 #define RV_LAUNCH_CHECK()                                                                      \
     do {                                                                                       \
         RV_HIP(hipGetLastError());                                                             \
@@ -116,6 +174,20 @@ __device__ inline u32 rv_wave_incl_sum_u32(u32 v) {
 // (it is kept between calls so that a benchmark step does not pay for hipMalloc -- 160 GB at 2.2 x 10^9 positions in the 64-bit
 // library, more than the recursion's level arrays find room beside).  true = something was released (rv_api.hip).
 bool rv_oom_trim();
+
+// Wait for an event by polling: the wake-up of a sleeping hipEventSynchronize costs tens of microseconds, and the waits on the path
+// (a few counters between launches) are 5-15 us long.  The first ~20 us spin (pause instruction: the sibling hyper-thread keeps its
+// issue slots), after that the thread yields between polls, and after ~200 us it sleeps in the runtime -- a host application that
+// runs many handles does not burn a core per handle on a long wait (bench.py --jobs).
+inline hipError_t rv_event_wait(hipEvent_t ev) {
+    hipError_t e;
+    for (int spins = 0; (e = hipEventQuery(ev)) == hipErrorNotReady; spins++) {
+        if (spins < 64) { __builtin_ia32_pause(); continue; }
+        if (spins < 640) { std::this_thread::yield(); continue; }
+        return hipEventSynchronize(ev);
+    }
+    return e;
+}
 
 // Grow-only device buffer.
 struct DBuf {
@@ -216,6 +288,7 @@ struct HBuf {
 // Scratch slots used by the primitives (one set per index handle, one stream).
 struct Workspace {
     hipStream_t stream = nullptr;
+    RvOptions opt;         // the owning handle's switches (rv_set_option)
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf misc[16];
@@ -244,7 +317,12 @@ struct Workspace {
     }
 };
 
-struct SaScratchInUse { Workspace &w; bool was; SaScratchInUse(Workspace &x) : w(x), was(x.sa_in_use) { w.sa_in_use = true; } ~SaScratchInUse() { w.sa_in_use = was; } };
+std::mutex &rv_trim_mutex();      // rv_api.hip: guards the list of live handles and every change of sa_in_use
+struct SaScratchInUse {
+    Workspace &w; bool was;
+    SaScratchInUse(Workspace &x) : w(x) { std::lock_guard<std::mutex> g(rv_trim_mutex()); was = w.sa_in_use; w.sa_in_use = true; }
+    ~SaScratchInUse() { std::lock_guard<std::mutex> g(rv_trim_mutex()); w.sa_in_use = was; }
+};
 
 // ---- primitives (rv_prims.hip) ---------------------------------------------
 // out[i] = sum_{j<i} in[j]  (in may alias out); n up to 2^40.

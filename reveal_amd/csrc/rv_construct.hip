@@ -1716,7 +1716,7 @@ int rv_build_lcp(Workspace &ws, const uint8_t *T, const sa_t *SA, bool by_rank, 
     SaScratchInUse in_use(ws);
     if (n <= 0) return 0;
     RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), ws.stream));
-    if (by_rank || getenv("RV_LCP_BY_RANK")) {        // one thread per rank, every pair compared from scratch
+    if (by_rank || ws.opt.lcp_by_rank) {        // one thread per rank, every pair compared from scratch
         hipLaunchKernelGGL(k_lcp, dim3((unsigned)ceil_div(n, TB)), dim3(TB), 0, ws.stream, T, SA, LCP, n, d_maxlcp, BWT, side_sep);
         RV_LAUNCH_CHECK();
         return 0;
@@ -1744,7 +1744,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     if (n <= 0) { if (st) *st = s; return 0; }
     if (n >= ((int64_t)1 << 32) - 2) { rv_set_error("SA build: n >= 2^32-2 not supported yet"); return -1; }
     hipStream_t q = ws.stream;
-    if (n <= TINY_N / 2 && LCP && BWT && d_maxlcp && !getenv("RV_NO_TINY_SA")) {      // (measured: 0.17 / 0.23 ms at n = 202 / 602 against 0.33; at n = 2002 the general build's 0.36 wins against 0.62)
+    if (n <= TINY_N / 2 && LCP && BWT && d_maxlcp && !ws.opt.no_tiny_sa) {      // (measured: 0.17 / 0.23 ms at n = 202 / 602 against 0.33; at n = 2002 the general build's 0.36 wins against 0.62)
         RV_TRY(ws.sa[0].reserve((size_t)TINY_N * 2 + 64));
         RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
         const unsigned nb = (unsigned)ceil_div(n, TB);
@@ -1784,7 +1784,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     // ends with the separator, the separator is its smallest character and never stands twice in a row, "past the end" can spell the
     // separator instead: a suffix reaches the text's last '$' before it reaches the padding, and the only other suffixes that agree with
     // it that far stand in front of another '$' -- they go on with a larger character, so the order is the same and no two keys tie on padding.
-    const bool short_alphabet = sigma >= 2 && sigma < 255 && T != nullptr && hist[(uint8_t)'$'] > 0 && lut[(uint8_t)'$'] == 1 && hist[256] == 0 && !getenv("RV_NO_SHORT_ALPHABET");
+    const bool short_alphabet = sigma >= 2 && sigma < 255 && T != nullptr && hist[(uint8_t)'$'] > 0 && lut[(uint8_t)'$'] == 1 && hist[256] == 0 && !ws.opt.no_short_alphabet;
     bool ends_with_sep = false;
     if (short_alphabet) { uint8_t last = 0; RV_TRY(rv_read_back(ws, &last, T + (n - 1), 1)); ends_with_sep = last == (uint8_t)'$'; }
     if (short_alphabet && ends_with_sep) {
@@ -1813,7 +1813,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     // rank order with the suffix array itself, and the three gather / scatter passes of rv_build_lcp (PHI, PLCP, rank-order
     // gather: 95 ms of a 160 ms construct at n = 5e8) are not run.  Whatever the text round cannot finish (ties beyond 4 KB,
     // groups above 64 members: repeats, identical inputs) falls back to rv_build_lcp for the whole index.
-    bool fused = LCP && BWT && d_maxlcp && bits <= 48 && !getenv("RV_NO_FUSED_LCP");
+    bool fused = LCP && BWT && d_maxlcp && bits <= 48 && !ws.opt.no_fused_lcp;
     KeyDigits kd;
     // upper bits of the keys (k_init_keys): first stop among the K symbols in 5 bits when K allows (8 otherwise), the diagonal hint
     // in what is left between the sort key's last whole digit and that field -- 11 bits at n = 5e8 (nd up to 1022), none at n = 2.2e9 (47-bit keys)
@@ -1833,7 +1833,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // taken for that sample's and get a wrong diagonal -- the hint is only used for inputs it knows completely
         if (nseps + 1 > HINT_K) kd.ns = 0;
     }
-    const bool want_hint = fused && kd.D > 0 && kd.ns >= 2 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !getenv("RV_NO_DIAG") && !getenv("RV_NO_PACKED_TEXT");
+    const bool want_hint = fused && kd.D > 0 && kd.ns >= 2 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !ws.opt.no_diag && !ws.opt.no_packed_text;
     if (want_hint) kd.ly.nd_bits = std::min(kd.ly.at_shift - kd.ly.nd_shift - 1, 11);
     kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
     for (int st = 0; st < 5; st++) {
@@ -1869,7 +1869,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         dg.stop = bds.as<u64>(); dg.exc = bde.as<u64>(); dg.lt = bdl.as<u64>();
     }
     // two samples with the hint: the twins of the second sample leave before the sort (k_tw_count / k_init_keys / k_heads_publish_tc)
-    const bool collapse = fused && kd.ly.nd_bits > 0 && kd.ns == 2 && K < 64 && kd.D > 1 && n > kd.D + 1 && !getenv("RV_NO_HEADS_FUSION") && !getenv("RV_NO_TWIN_COLLAPSE")
+    const bool collapse = fused && kd.ly.nd_bits > 0 && kd.ns == 2 && K < 64 && kd.D > 1 && n > kd.D + 1 && !ws.opt.no_heads_fusion && !ws.opt.no_twin_collapse
                           && (sizeof(sav_t) > 4 || n < ((int64_t)1 << 31));
     int64_t nsort = n;
     const u32 *tw_off = nullptr;
@@ -1914,12 +1914,12 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)
         if (sizeof(sav_t) > 4) { SA_TRY(ws.sa[24].reserve((size_t)n * sizeof(sav_t))); vexp = ws.sa[24].as<sav_t>(); }
         hipLaunchKernelGGL(k_heads_publish_tc, dim3((unsigned)nb), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, nsort, (const u32 *)bc, head, LCP, SA, BWT,
-                           side_sep, kd, d_maxlcp, getenv("RV_NO_PUB_TWINS") ? 0 : 1, kt, vexp);
+                           side_sep, kd, d_maxlcp, ws.opt.no_pub_twins ? 0 : 1, kt, vexp);
         SA_HIP(hipGetLastError());
         keys_by_rank = kt; vals_by_rank = vexp;
-    } else if (fused && kd.ly.nd_bits > 0 && !getenv("RV_NO_HEADS_FUSION")) {
+    } else if (fused && kd.ly.nd_bits > 0 && !ws.opt.no_heads_fusion) {
         hipLaunchKernelGGL(k_heads_publish, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
-                           getenv("RV_NO_PUB_TWINS") ? 0 : 1);
+                           ws.opt.no_pub_twins ? 0 : 1);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
     } else {
@@ -1928,7 +1928,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));
         {
             KeyDigits kp = kd;
-            if (getenv("RV_NO_PUB_TWINS")) kp.ly.nd_bits = 0;      // (test hook: twin pairs go through the text round's first pass instead)
+            if (ws.opt.no_pub_twins) kp.ly.nd_bits = 0;      // (test hook: twin pairs go through the text round's first pass instead)
             hipLaunchKernelGGL(k_publish0, dim3(nblk), dim3(TB), 0, q, (const sav_t *)vs, n, SA, (const u64 *)ks, fused ? BWT : (uint8_t *)nullptr, side_sep,
                                kp, fused ? LCP : (lcp_t *)nullptr, head, d_maxlcp, grp);
         }
@@ -2022,11 +2022,11 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         const unsigned mb = (unsigned)ceil_div(m, TB);
         uint8_t *bigflag = bbig.as<uint8_t>();
         // groups of up to SMALL_GROUP members: sorted by their first thread, in place
-        if (s.rounds == 1 && h <= 64 && !getenv("RV_SA_NO_TEXT"))
+        if (s.rounds == 1 && h <= 64 && !ws.opt.sa_no_text)
         {
             FusedOut fo;
             fo.pk.Tp = nullptr; fo.pk.blk = nullptr;
-            if (!getenv("RV_NO_PACKED_TEXT")) {       // 2-bit copy of the text for the comparisons (n/4 bytes + a flag per 128 bases)
+            if (!ws.opt.no_packed_text) {       // 2-bit copy of the text for the comparisons (n/4 bytes + a flag per 128 bases)
                 DBuf &bTp = ws.sa[18], &bBlk = ws.sa[19];
                 const int64_t nwords = n / 32 + 4, nblk = n / PK_BLOCK + 8;      // (windows read one word / test one block beyond)
                 SA_TRY(bTp.reserve((size_t)(nwords + 8) * 8)); SA_TRY(bBlk.reserve((size_t)nblk + 16));
@@ -2043,7 +2043,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             // 125 / 22.6 / 2.33; 64-byte steps instead of 32: +14 / +3 / +0.3 (the round is bound by sector traffic, not by the
             // length of its dependent-load chains); 16-byte steps: +4 / -1 / +0.03.  RV_TEXT_MODE: test hook for the other two.
             // (with the diagonal hint: groups of up to four by their first thread, twins from their keys -- mode 3)
-            const int tmode = getenv("RV_TEXT_MODE") ? atoi(getenv("RV_TEXT_MODE")) : (kd.ly.nd_bits > 0 ? 3 : 1);
+            const int tmode = ws.opt.text_mode >= 0 ? (int)ws.opt.text_mode : (kd.ly.nd_bits > 0 ? 3 : 1);
 #define RT_LAUNCH(M_) hipLaunchKernelGGL((k_round_text<4, M_>), dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, head, bigflag, SA, Sfree, fo)
             // (bytes: the list entries in -- group rank, position, suffix, key -- and SA / LCP / BWT / heads / suffix out)
             const int tid = ws.prof_begin(9 /* RV_K_TEXT_ROUND */, (double)m * (4 + 4 + sizeof(sav_t) + 8) + (double)m * (sizeof(sav_t) + sizeof(sa_t) + sizeof(lcp_t) + 2));

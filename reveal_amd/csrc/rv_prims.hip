@@ -321,8 +321,7 @@ int rv_read_back(Workspace &ws, void *dst, const void *dsrc, size_t bytes) {
     if (!ws.ev_rb) RV_HIP(hipEventCreateWithFlags(&ws.ev_rb, hipEventDisableTiming));
     RV_HIP(hipMemcpyAsync(ws.hpin.p, dsrc, bytes, hipMemcpyDeviceToHost, ws.stream));
     RV_HIP(hipEventRecord(ws.ev_rb, ws.stream));
-    hipError_t e;
-    while ((e = hipEventQuery(ws.ev_rb)) == hipErrorNotReady) {}
+    const hipError_t e = rv_event_wait(ws.ev_rb);
     if (e != hipSuccess) { rv_set_error("rv_read_back: %s", hipGetErrorString(e)); return -1; }
     memcpy(dst, ws.hpin.p, bytes);
     return 0;

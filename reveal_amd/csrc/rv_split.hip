@@ -1329,7 +1329,7 @@ int rv_split_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, uint8_t *D,
     const unsigned nt = (unsigned)a.ntiles;
     hipLaunchKernelGGL(k_split_count, dim3(nt), dim3(TB), 0, ws.stream, SA, LCP, m, t, a, D);
     RV_LAUNCH_CHECK();
-    const int ch = getenv("RV_CARRY_CH") ? std::max(1, atoi(getenv("RV_CARRY_CH"))) : CARRY_CH;
+    const int ch = (ws.opt.carry_ch > 0 ? (int)ws.opt.carry_ch : CARRY_CH);
     // up to four passes of one small workgroup per class (one launch instead of three: 2 x 5 Mbp has 24 such levels); the
     // 1024-thread form with its 66 KB of LDS took one pass there, but had to wait for room next to a leaf launch (0.3-0.6 ms)
     if (a.ntiles <= 4 * (int64_t)ch) {

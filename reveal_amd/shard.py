@@ -24,6 +24,8 @@ independent alignments per GPU (bench.py's default) are the better use of a node
 """
 import heapq
 
+import time
+
 import numpy as np
 
 _CALLS = 0
@@ -144,6 +146,14 @@ def make_batches(sizes, world, per_rank=4):
     return out
 
 
+def _queue_store(dist):
+    """the key-value store behind the default process group (the requests of the work queue go through it)"""
+    get = getattr(dist.distributed_c10d, "_get_default_store", None)
+    if get is None:
+        raise RuntimeError("reveal_amd.shard: this torch.distributed offers no access to the process group's store")
+    return get()
+
+
 def _send_batch(dist, group, dst, lib, head, meta_bytes, bufs, m, dev):
     import torch
     gdst = dist.get_global_rank(group, dst) if group is not None else dst
@@ -183,8 +193,11 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
     results, taken, nb = [], 0, 0
     global _CALLS
     _CALLS += 1                                        # (every rank calls in the same order: the same number everywhere)
-    store = dist.distributed_c10d._get_default_store()
-    key = "reveal_amd/queue/%d/%d/%%d/%%d" % (dist.get_group_rank(group, 0) if group is not None else 0, _CALLS)
+    store = _queue_store(dist)
+    # the queue's keys carry the owner's GLOBAL rank: two groups running at once never share a prefix, and a group that does not
+    # contain global rank 0 works like any other
+    owner = dist.get_global_rank(group, 0) if group is not None else 0
+    key = "reveal_amd/queue/%d/%d/%%d/%%d" % (owner, _CALLS)
     if rank == 0:
         idx.construct()
         left, fr, _ = balanced_frontier(idx, world, stop_subs or 4 * world, minl, minn, trace=trace, tolerance=1.5)
@@ -215,11 +228,16 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
             _send_batch(dist, group, w, lib, [len(batches[k]), m, len(meta), maxlcp], meta, bufs, m, dev)
             shares[w] += m; counts[w] += 1
 
+        idle = 0
         while reqs or lo < hi:
             served = False
             for w in list(reqs):
                 if store.check([key % (w, reqs[w])]):
                     served = True
+                    try:
+                        store.delete_key(key % (w, reqs[w]))      # (a served request leaves nothing behind in the store)
+                    except Exception:
+                        pass
                     reqs[w] += 1
                     if lo < hi:
                         hand_out(w, lo); lo += 1
@@ -234,6 +252,14 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
                 idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
                 results.append(idx.align_builtin_resume())
                 shares[0] += first[k + 1] - first[k]; counts[0] += 1
+                idle = 0
+            elif served:
+                idle = 0
+            else:
+                # the queue is empty and the workers are busy with their last batches: wait for their final requests without hammering
+                # the store (50 us at first, 2 ms after a while)
+                idle += 1
+                time.sleep(min(0.002, 0.00005 * idle))
         if not results:
             # rank 0 took no batch (the run finished before it was wide enough to divide, or the workers emptied the queue): its
             # anchors of the levels in front of the hand-off are collected by finishing an empty frontier
@@ -265,7 +291,7 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
     # the owner's anchors of the levels in front of the hand-off ride in its first resume(): a handle with a run in progress keeps them
     mine = merge(results) if len(results) > 1 else results[0]
     out = [None] * world if rank == 0 else None
-    dist.gather_object(mine, out, dst=0, group=group)
+    dist.gather_object(mine, out, dst=owner, group=group)      # (dst is a global rank)
     if rank != 0:
         return None
     merged = merge(out)

@@ -121,8 +121,14 @@ sys.path.insert(0, %r)
 import numpy as np
 import torch.distributed as dist
 from reveal_amd import shard
-rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+world = int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
+GROUP = None
+if os.environ.get("SHARD_SUBGROUP"):                  # a group without global rank 0: ranks 1..world-1
+    GROUP = dist.new_group(list(range(1, world)))
+    if dist.get_rank() == 0:
+        dist.barrier(); dist.destroy_process_group(); sys.exit(0)
+rank = dist.get_rank(GROUP)                            # rank inside the group that divides the alignment
 
 class FakeLib: sa64 = False
 class FakeIndex:
@@ -172,7 +178,7 @@ class FakeIndex:
         return dict(stats=st, anchors=(l, np.arange(0, 2 * len(l) + 1, 2), pos), trace=None)
 
 import torch
-res = shard.align_sharded(FakeIndex(), 20, 2, stop_subs=4, per_rank=2)
+res = shard.align_sharded(FakeIndex(), 20, 2, stop_subs=4, per_rank=2, group=GROUP)
 if rank == 0:
     l, off, pos = res["anchors"]
     print(json.dumps({"anchors": sorted((int(l[k]), [int(x) for x in pos[off[k]:off[k + 1]]]) for k in range(len(l))), "shares": res["shares"], "batches": res["batches"], "splits": res["stats"]["splits"]}))
@@ -206,6 +212,20 @@ def test_divided_alignment_protocol_gloo(tmp_path, world):
     nbatches = len(shard.make_batches(sizes, world, 2))
     assert sum(r["batches"]) == nbatches and nbatches >= world
     assert sum(1 for x in r["shares"] if x > 0) >= 2                      # more than one rank took part
+
+
+def test_divided_alignment_in_a_group_without_global_rank_0(tmp_path):
+    """align_sharded(group=...) on a sub-group made of global ranks 1 and 2 of a world of three: the queue's keys are named after
+    the owner's global rank, the owner is the group's rank 0"""
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % ROOT)
+    port = "29531"
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_SUBGROUP="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert r["splits"] == 8 and len(r["shares"]) == 2 and sum(r["shares"]) == 253 and all(x > 0 for x in r["shares"])
 
 
 def test_queue_batches():

@@ -70,7 +70,7 @@ def test_recursion_above_2_31(big, monkeypatch):
     out = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("RV_NO_CASCADE", "1")
+            idx.set_option("RV_NO_CASCADE", 1)      # (a switch of this handle: the library does not read the environment)
         idx.construct()
         res = idx.align_builtin(20, 2)
         assert idx.cascade_info()["done"] == (not off)

@@ -136,7 +136,7 @@ def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch, cfg):
     out = []
     for off in (False, True):
         if off:
-            monkeypatch.setenv("RV_NO_CASCADE", "1")
+            idx.set_option("RV_NO_CASCADE", 1)      # (a switch of this handle: the library does not read the environment)
         idx.construct()
         res = idx.align_builtin(20, 2)
         info = idx.cascade_info()

@@ -153,6 +153,10 @@ def main():
     ap.add_argument("--minl", type=int, default=20)
     ap.add_argument("--minn", type=int, default=2)
     ap.add_argument("--sa64", action="store_true")
+    ap.add_argument("--indelfrac", type=float, default=0.0,
+                    help="variants by the reference's own mutation model (utils/simulate.py:17-77: this fraction of the 1 %% events are indels, "
+                         "zipf(1.7) lengths) instead of substitutions only; 0 = SURVEY 8(d)'s generator, the metric's workload")
+    ap.add_argument("--no-extra", action="store_true", help="skip the companion legs of the default line (level pipeline, indel workload)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size property check of the last step's result")
@@ -210,16 +214,16 @@ def main():
     else:
         modes = [mode]
     jobs = max(1, args.jobs) if "per-rank" in modes else 1
-    seqs = synth.genomes(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0))
+    seqs = synth.genomes(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0), indelfrac=args.indelfrac)
     bases = sum(len(s) for s in seqs)
     idx = build_index(seqs, args.sa64)
     upload_ms = idx.upload_ms      # host->device copy of the assembled text (rv_upload), outside every timed region
     # further jobs of this rank: their own inputs (other seeds), handles and streams
-    extra = [build_index(synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank + 17 * j), args.sa64) for j in range(1, jobs)]
+    extra = [build_index(synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank + 17 * j, indelfrac=args.indelfrac), args.sa64) for j in range(1, jobs)]
     # a divided run works on ONE input: rank 0's (seed 42); the other ranks hold its text
     idx_div = idx
     if "divide" in modes and "per-rank" in modes and rank != 0:
-        idx_div = build_index(synth.genomes(args.L, args.genomes, seed=42), args.sa64)
+        idx_div = build_index(synth.genomes(args.L, args.genomes, seed=42, indelfrac=args.indelfrac), args.sa64)
 
     def barrier():
         torch.cuda.synchronize()
@@ -284,7 +288,7 @@ def main():
     divide = primary == "divide"
     tmax, last, prof = runs[primary]
     # full-size properties of the last timed step's result (reveal_amd/check.py), before the breakdown steps run again
-    properties = None
+    properties = full_size = None
     if rank == 0 and not args.no_check:
         T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
         nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
@@ -298,6 +302,12 @@ def main():
         properties = check.recursion_properties(T0, T1, last["anchors"], nsep, args.minl)
         if divide:
             properties["text"] = "lower-cased text rebuilt from the merged anchors (each rank lower-cases its own share)"
+        # the last timed step's anchor set and final text against the CPU path's digests at THIS size (tests/golden/fullsize.json:
+        # the reference's divsufsort + the restated recursion, run once in the build container by oracle/gen_fullsize_golden.py)
+        grec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn)
+        if grec is not None:
+            full_size = check.compare_with_golden(grec, anchors=last["anchors"], T_final=T1)
+            full_size["cpu_seconds_at_this_size"] = grec["cpu_seconds"]
         del T1
         if "divide" in runs and not divide:      # the divided run of the same invocation: its merged anchors against the same checks
             from reveal_amd import shard
@@ -364,9 +374,11 @@ def main():
             "vs_baseline": None,
             "dtype": "int64" if args.sa64 else "int32",
             "data": "synthetic",
-            "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP, seed 42%s), rem -m %d -n %d, construct + full recursion, "
+            "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, %s, seed 42%s), rem -m %d -n %d, construct + full recursion, "
                                    "bench picker; text resident in HBM before the timed region (host->device copy of the text not timed)"
-                                   % (args.genomes, args.L / 1e6, "" if divide else "+1000*rank", args.minl, args.minn),
+                                   % (args.genomes, args.L / 1e6, "1% SNP" if not args.indelfrac else
+                                      "1%% mutation events of which %g%% indels with zipf(1.7) lengths: the reference simulator's model" % (100 * args.indelfrac),
+                                      "" if divide else "+1000*rank", args.minl, args.minn),
                        "bases_per_gpu": bases * jobs if not divide else bases / world, "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
                        "jobs_per_gpu": jobs, "sharding": sharding},
             # the text's way into HBM, outside the timed region (SURVEY 8(d) asks for it as a sub-timing): the host->device copy of the
@@ -404,6 +416,57 @@ def main():
                              "speedup_vs_rank0_alone": (tmax / args.steps) / (dt / args.steps),
                              "note": None if any(dl.get("shares") or [0]) else "nothing was handed out: the anchor cascade finished this two-sample run on rank 0 "
                                      "before there was a frontier to divide (rv_align_builtin_until); inputs with more than two samples are divided"}
+        out["parity"] = {"full_size": full_size if full_size is not None else
+                         "no CPU digests for this configuration in tests/golden/fullsize.json (oracle/gen_fullsize_golden.py writes them)"}
+        if world == 1 and not args.no_extra and not divide and jobs == 1:
+            # ---- companion figures, outside the timed region (what the headline does not show) ----
+            # (1) the same workload through the LEVEL PIPELINE: scan / pick / label + split / bubble_sort of every level, reveal.c:731-1338 step by
+            # step -- what index.align(mumpicker, graphalign) callers, rc = 1 and traced runs get; the headline's two-sample recursion
+            # is the anchor cascade, which runs none of A10-A12
+            idx.set_option("RV_NO_CASCADE", 1)
+            try:
+                idx.construct(); idx.align_builtin(args.minl, args.minn)
+                idx.prof(enable=True, reset=True)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(2):
+                    idx.construct()
+                    lp = idx.align_builtin(args.minl, args.minn)
+                torch.cuda.synchronize(); lp_s = (time.perf_counter() - t0) / 2
+                pl = idx.prof(enable=False)
+                lp_T = idx.array("T") if full_size is not None else None
+                out["level_pipeline"] = {
+                    "value": bases / lp_s / 1e6, "unit": "Mbp/s", "ms_per_step": lp_s * 1e3, "levels": lp["stats"]["levels"],
+                    "kernel_classes_ms_per_step": {k: v[1] / 2 for k, v in pl.items() if v[0] and v[1] / 2 >= 0.05},
+                    "roofline_by_class": {k: {"achieved_GBps": (v[2] / 1e9) / (v[1] / 1e3), "frac": (v[2] / 1e9) / (v[1] / 1e3) / HBM_PEAK_GBS}
+                                          for k, v in pl.items() if v[0] and v[1] > 0 and v[2] > 0 and k in ("split", "bubble", "scan_pair", "scan_multi")},
+                    "same_anchor_set_as_headline": check.anchor_digest(*lp["anchors"]) == check.anchor_digest(*last["anchors"]),
+                    "golden": check.compare_with_golden(grec, anchors=lp["anchors"], T_final=lp_T) if full_size is not None else None,
+                    "what": "RV_NO_CASCADE: construct + every level's scan / split / bubble_sort (2 steps after 1 warm-up, outside the timed region)"}
+            finally:
+                idx.set_option("RV_NO_CASCADE", 0)
+            # (2) the same sizes with the reference simulator's own mutation model (indels: the second sample leaves the first's diagonal)
+            if not args.indelfrac:
+                iseqs = synth.genomes(args.L, args.genomes, seed=42, indelfrac=0.2)
+                ibases = sum(len(x) for x in iseqs)
+                iidx = build_index(iseqs, args.sa64)
+                iidx.construct(); iidx.align_builtin(args.minl, args.minn)
+                torch.cuda.synchronize(); t0 = time.perf_counter()
+                for _ in range(2):
+                    iidx.construct()
+                    ir = iidx.align_builtin(args.minl, args.minn)
+                torch.cuda.synchronize(); i_s = (time.perf_counter() - t0) / 2
+                irec = check.golden_record(args.L, args.genomes, 42, 0.2, args.minl, args.minn)
+                iT0 = np.frombuffer(b"$".join(iseqs) + b"$", dtype=np.uint8)
+                insep = np.cumsum([len(x) + 1 for x in iseqs])[:-1] - 1
+                iT1 = iidx.array("T")
+                out["indel"] = {
+                    "value": ibases / i_s / 1e6, "unit": "Mbp/s", "ms_per_step": i_s * 1e3, "bases": ibases,
+                    "workload": "%dx %g Mbp, 1%% mutation events of which 20%% indels (half insertions, half deletions, zipf(1.7) lengths <= 2000): "
+                                "reveal_amd/synth.py after utils/simulate.py:17-77, seed 42" % (args.genomes, args.L / 1e6),
+                    "anchors": ir["stats"]["splits"], "anchored_bp": ir["stats"]["anchored_bp"], "cascade": iidx.cascade_info(), "sa_build": iidx.sa_stats(),
+                    "properties": check.recursion_properties(iT0, iT1, ir["anchors"], insep, args.minl)["all"],
+                    "golden": check.compare_with_golden(irec, anchors=ir["anchors"], T_final=iT1) if irec is not None else None}
+                del iidx, iseqs, iT0, iT1
         if world == 1 and not args.no_cpu:
             # CPU legs and bit-exact parity on a stated sample: 2 x 20 Mbp (or the workload itself when it is not larger)
             cl = min(args.L, CPU_SAMPLE_L)
@@ -440,8 +503,8 @@ def main():
             rl, rn, roff, rpos = cb["result"]["anchors"]
             ra = anchor_set(rl, roff, rpos)
             ga = anchor_set(*gres["anchors"])
-            out["parity"] = {"sample": sample, "anchors_gpu": len(ga), "anchors_cpu": len(ra), "identical_anchor_set": ra == ga,
-                             "identical_final_text": gT == cb["result"]["T"]}
+            out["parity"].update({"sample": sample, "anchors_gpu": len(ga), "anchors_cpu": len(ra), "identical_anchor_set": ra == ga,
+                                  "identical_final_text": gT == cb["result"]["T"]})
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

@@ -111,6 +111,7 @@ SYMBOLS = {
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
     "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),
+    "rv_test_radix_time": (_I, [_L, _I, _I, _I, _I, ctypes.POINTER(_D), c_i64p]),
 }
 
 

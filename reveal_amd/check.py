@@ -114,3 +114,34 @@ def anchor_stream(l, off, pos):
 
 def anchor_digest(l, off, pos):
     return array_digest(anchor_stream(l, off, pos))
+
+
+def golden_record(L, genomes, seed, indelfrac=0.0, minl=20, minn=2, path=None):
+    """the CPU path's digests for this synthetic configuration (tests/golden/fullsize.json, written by oracle/gen_fullsize_golden.py in the
+    build container from the reference's divsufsort + the restated recursion), or None when the file holds none"""
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "fullsize.json")
+    if not os.path.exists(path):
+        return None
+    for name, r in json.load(open(path)).items():
+        if (r["L"], r["genomes"], r["seed"], float(r["indelfrac"]), r["minl"], r["minn"]) == (L, genomes, seed, float(indelfrac), minl, minn):
+            return dict(r, name=name)
+    return None
+
+
+def compare_with_golden(rec, anchors=None, T_final=None, SA=None, LCP=None):
+    """-> dict: which of the given results equal the CPU path's digests (only the ones passed in are looked at)"""
+    out = {"golden": rec["name"]}
+    if SA is not None:
+        out["SA"] = array_digest(SA) == rec["sha_SA"]
+    if LCP is not None:
+        out["LCP"] = array_digest(LCP) == rec["sha_LCP"]
+    if anchors is not None:
+        l, off, pos = anchors
+        out["anchor_count"] = int(len(l)) == rec["anchors"]
+        out["anchors"] = anchor_digest(l, off, pos) == rec["sha_anchors"]
+    if T_final is not None:
+        out["final_text"] = array_digest(np.asarray(T_final, dtype=np.uint8)) == rec["sha_finalT"]
+    out["all"] = all(v for k, v in out.items() if isinstance(v, bool))
+    return out

@@ -864,4 +864,64 @@ int rv_test_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, int bit_lo, in
     return r;
 }
 
+/* Timing of the radix sort on keys made on the device (tools/ubench/radix_time.py): n pairs, the low `bits` bits of the keys sorted.
+ * dist 0: uniform bits; 1: the digits of a base-5 number of 17 symbols drawn from {1..4} (the first keys of a DNA text); 2: constant.
+ * flags: bit 0 = 10-bit digits, bit 1 = XCD-aware tile order, bit 2 = 16-bit wave counters.  ms[it] = duration of the whole sort by HIP
+ * events on the sort's own stream; *bad = adjacent pairs out of order (keys, then original index: stability) after the last one. */
+}
+namespace {
+__device__ inline u64 rt_mix(u64 x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33; return x; }
+__global__ __launch_bounds__(256) void k_rt_fill(u64 *keys, u32 *vals, int64_t n, int bits, int dist) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    u64 r = rt_mix((u64)i * 0x9E3779B97F4A7C15ull + 12345);
+    u64 k = 0;
+    if (dist == 0) k = r;
+    else if (dist == 1) { u64 r2 = rt_mix(r); for (int j = 0; j < 17; j++) { k = k * 5 + 1 + (r2 & 3); r2 >>= 2; } }
+    const u64 mask = bits >= 64 ? ~0ull : (1ull << bits) - 1;
+    keys[i] = (k & mask) | (r & ~mask & 0x00ffffffffffffffull);      // (payload bits above the sort key, as the SA build has them)
+    vals[i] = (u32)i;
+}
+__global__ __launch_bounds__(256) void k_rt_check(const u64 *keys, const u32 *vals, int64_t n, int bits, unsigned long long *bad) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i + 1 >= n) return;
+    const u64 mask = bits >= 64 ? ~0ull : (1ull << bits) - 1;
+    const u64 a = keys[i] & mask, b = keys[i + 1] & mask;
+    if (a > b || (a == b && vals[i] > vals[i + 1])) atomicAdd(bad, 1ull);
+}
+}
+extern "C" {
+int rv_test_radix_time(int64_t n, int bits, int dist, int flags, int iters, double *ms, int64_t *bad) {
+    Workspace ws;
+    RV_TRY(test_ws(ws));
+    ws.opt.rs_bits = (flags & 1) ? 10 : 8; ws.opt.rs_xcd = (flags & 2) ? 1 : 0; ws.opt.rs_cnt16 = (flags & 4) ? 1 : 0;
+    DBuf k0, k1, v0, v1, db;
+    int r = 0, in1 = 0;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (k0.reserve((size_t)n * 8 + 64) || k1.reserve((size_t)n * 8 + 64) || v0.reserve((size_t)n * 4 + 64) || v1.reserve((size_t)n * 4 + 64) || db.reserve(64)) r = -1;
+    if (!r && (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess)) r = -1;
+    for (int it = 0; !r && it < iters; it++) {
+        hipLaunchKernelGGL(k_rt_fill, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ws.stream, k0.as<u64>(), v0.as<u32>(), n, bits, dist);
+        (void)hipEventRecord(e0, ws.stream);
+        r = rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), n, 0, bits, &in1);
+        (void)hipEventRecord(e1, ws.stream);
+        if (!r && hipEventSynchronize(e1) != hipSuccess) { rv_set_error("sync failed: %s", hipGetErrorString(hipGetLastError())); r = -1; }
+        float t = 0;
+        if (!r) { (void)hipEventElapsedTime(&t, e0, e1); ms[it] = t; }
+    }
+    if (!r) {
+        (void)hipMemsetAsync(db.p, 0, 8, ws.stream);
+        hipLaunchKernelGGL(k_rt_check, dim3((unsigned)ceil_div(n, 256)), dim3(256), 0, ws.stream, (const u64 *)(in1 ? k1.p : k0.p), (const u32 *)(in1 ? v1.p : v0.p), n, bits,
+                           db.as<unsigned long long>());
+        unsigned long long b = 0;
+        if (hipMemcpyAsync(&b, db.p, 8, hipMemcpyDeviceToHost, ws.stream) != hipSuccess || hipStreamSynchronize(ws.stream) != hipSuccess) r = -1;
+        *bad = (int64_t)b;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    k0.release(); k1.release(); v0.release(); v1.release(); db.release();
+    test_ws_done(ws);
+    return r;
+}
+
 }  // extern "C"

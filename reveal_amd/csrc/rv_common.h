@@ -84,7 +84,10 @@ void rv_set_error(const char *fmt, ...);
     X(sa_no_text, "RV_SA_NO_TEXT", 0) \
     X(text_mode, "RV_TEXT_MODE", -1) \
     X(carry_ch, "RV_CARRY_CH", -1) \
-    X(launch_trace, "RV_LAUNCH_TRACE", 0)
+    X(launch_trace, "RV_LAUNCH_TRACE", 0) \
+    X(rs_bits, "RV_RS_BITS", 8) \
+    X(rs_xcd, "RV_RS_XCD", 1) \
+    X(rs_cnt16, "RV_RS_CNT16", 1)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)
@@ -335,6 +338,8 @@ int rv_inclusive_max_u64(Workspace &ws, const u64 *in, u64 *out, int64_t n);
 // Stable LSD radix sort of (64-bit key, 32/64-bit value) pairs on key bits
 // [bit_lo, bit_hi).  Ping-pongs between (k0,v0) and (k1,v1); *result_in_1
 // tells where the sorted data ended up.
+// radix passes rv_radix_sort_pairs makes over `nbits` key bits (8- or 10-bit digits: ws.opt.rs_bits)
+int rv_radix_passes(const Workspace &ws, int nbits);
 template <class V>
 int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n,
                         int bit_lo, int bit_hi, int *result_in_1);

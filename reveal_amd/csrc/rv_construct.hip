@@ -1800,8 +1800,8 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // with all of them -- sixteen key values per suffix: at 10 x 5 Mbp a fifth radix pass costs 0.4 ms and takes 2.3 off the text round)
         const double want = (double)n * ((seps && nseps > 1) ? 16.0 : 1.0);
         while (cap < want && span <= (~0ull) / radix / radix) { cap *= base; span *= radix; K++; }
-        int passes = (bitlen(span - 1) + 7) / 8;
-        while (span <= (~0ull) / radix / radix && (bitlen(span * radix - 1) + 7) / 8 == passes) { span *= radix; K++; }
+        int passes = rv_radix_passes(ws, bitlen(span - 1));
+        while (span <= (~0ull) / radix / radix && rv_radix_passes(ws, bitlen(span * radix - 1)) == passes) { span *= radix; K++; }
         bits = bitlen(span - 1);                                               // significant bits of the key
     }
     s.sigma = sigma; s.bits = bits; s.k0 = K;        // (bits: of the whole first key)
@@ -1894,7 +1894,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), nsort, 0, bits, &in1));
-    s.radix_passes += (bits + 7) / 8; s.sorted_elems += nsort;
+    s.radix_passes += rv_radix_passes(ws, bits); s.sorted_elems += nsort;
     u64 *ks = in1 ? bk1.as<u64>() : bk0.as<u64>();
     sav_t *vs = in1 ? bv1.as<sav_t>() : bv0.as<sav_t>();
     u64 *kt = in1 ? bk0.as<u64>() : bk1.as<u64>();      // the free pair
@@ -2101,7 +2101,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
                 SA_TRY(rv_radix_sort_pairs<sav_t>(ws, k_in, s_in, k_out, s_out, mbig, 32, 32 + highbits, &f2));
                 const u64 *kS = f2 ? k_out : k_in;
                 const sav_t *sS = f2 ? s_out : s_in;
-                s.radix_passes += (lowbits + 7) / 8 + (highbits + 7) / 8; s.sorted_elems += mbig;
+                s.radix_passes += rv_radix_passes(ws, lowbits) + rv_radix_passes(ws, highbits); s.sorted_elems += mbig;
                 hipLaunchKernelGGL(k_big_writeback, dim3((unsigned)ceil_div(mbig, TB)), dim3(TB), 0, q, kS, (const u32 *)Pb, (const u32 *)Qb, sS, (int64_t)mbig, S, head, SA);
                 SA_HIP(hipGetLastError());
             }

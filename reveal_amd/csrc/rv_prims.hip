@@ -159,9 +159,23 @@ constexpr int RS_ITEMS   = RV_RS_ITEMS;
 constexpr int RS_TILE    = RS_THREADS * RS_ITEMS;
 constexpr int RS_WAVES   = RS_THREADS / 64;
 
-__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, int64_t n, int shift, u32 *__restrict__ blockhist, u32 nblocks) {
-    __shared__ u32 h[256];
-    if (threadIdx.x < 256) h[threadIdx.x] = 0;
+// XCD-aware tile order.  The dispatcher hands consecutive workgroups to the eight XCDs in turn, each with its own L2.  A digit's run of
+// one tile (16 keys on average: 128 B of keys, 64 B of suffixes) is followed in the output by the same digit's run of the NEXT tile;
+// with tile = blockIdx the two runs are written by different XCDs, no L2 ever holds a whole line, and HBM sees partial-line writes.
+// XCD: workgroup i takes tile (i % 8) * ceil(nb / 8) + i / 8 -- an XCD works through one contiguous eighth of the tiles, neighbouring
+// runs meet in its L2.  (The histogram kernel only reads; it keeps the plain order.)
+constexpr unsigned RS_XCDS = 8;
+template <bool XCD> __device__ inline u32 rs_tile_of(u32 nb) {
+    if (!XCD) return blockIdx.x;
+    const u32 chunk = (nb + RS_XCDS - 1) / RS_XCDS;
+    return (blockIdx.x % RS_XCDS) * chunk + blockIdx.x / RS_XCDS;
+}
+
+template <int BITS>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, int64_t n, int shift, u32 dmask, u32 *__restrict__ blockhist, u32 nblocks) {
+    constexpr int NB = 1 << BITS;
+    __shared__ u32 h[NB];
+    for (int k = threadIdx.x; k < NB; k += RS_THREADS) h[k] = 0;
     __syncthreads();
     const int64_t base = (int64_t)blockIdx.x * RS_TILE;
     u64 key[RS_ITEMS];          // (all loads first: see k_rs_scatter)
@@ -173,26 +187,35 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const int64_t i = base + (int64_t)r * RS_THREADS + threadIdx.x;
-        if (i < n) atomicAdd(&h[(u32)(key[r] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(u32)(key[r] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 256) blockhist[(size_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int k = threadIdx.x; k < NB; k += RS_THREADS) blockhist[(size_t)k * nblocks + blockIdx.x] = h[k];
 }
 
-template <class V>
+// BITS: digit width (8: 256 bins; 10: 1024 bins -- a 40-bit key in four passes instead of five).  CNT: type of the waves' bucket
+// counters (a tile holds 4096 keys: 16 bits are enough, and with them three workgroups fit a CU's LDS instead of two).
+template <class V, int BITS, bool XCD, class CNT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ kin, const V *__restrict__ vin,
-                                                            u64 *__restrict__ kout, V *__restrict__ vout, int64_t n, int shift,
+                                                            u64 *__restrict__ kout, V *__restrict__ vout, int64_t n, int shift, u32 dmask,
                                                             const u32 *__restrict__ blockoff, u32 nblocks) {
-    __shared__ u32 cnt[RS_WAVES][256];
-    __shared__ u32 gbase[256], dstart[256], wtot[RS_WAVES];
+    constexpr int NB = 1 << BITS;
+    constexpr int BPT = NB / RS_THREADS;          // bins per thread in the per-digit steps
+    static_assert(NB % RS_THREADS == 0 && RS_TILE < 65536, "bins per thread, 16-bit counters");
+    __shared__ CNT cnt[RS_WAVES][NB];
+    __shared__ u32 gbase[NB];
+    __shared__ CNT dstart[NB];
+    __shared__ u32 wtot[RS_WAVES];
     __shared__ u64 skey[RS_TILE];
     __shared__ V sval[RS_TILE];
+    const u32 tile = rs_tile_of<XCD>(nblocks);
+    if (tile >= nblocks) return;
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int k = threadIdx.x; k < RS_WAVES * 256; k += RS_THREADS) (&cnt[0][0])[k] = 0;
-    if (threadIdx.x < 256) gbase[threadIdx.x] = blockoff[(size_t)threadIdx.x * nblocks + blockIdx.x];
+    for (int k = threadIdx.x; k < RS_WAVES * NB; k += RS_THREADS) (&cnt[0][0])[k] = 0;
+    for (int k = threadIdx.x; k < NB; k += RS_THREADS) gbase[k] = blockoff[(size_t)k * nblocks + tile];
     __syncthreads();
 
-    const int64_t wbase = (int64_t)blockIdx.x * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
+    const int64_t wbase = (int64_t)tile * RS_TILE + (int64_t)w * (64 * RS_ITEMS);
     u64 key[RS_ITEMS];
     V val[RS_ITEMS];
     u32 rnk[RS_ITEMS];
@@ -214,10 +237,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
     for (int r = 0; r < RS_ITEMS; r++) {
         const int64_t i = wbase + (int64_t)r * 64 + lane;
         const bool valid = i < n;
-        const u32 d = (u32)(key[r] >> shift) & 255u;
+        const u32 d = (u32)(key[r] >> shift) & dmask;
         u64 peers = __ballot(valid);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             const bool bit = (d >> b) & 1u;
             const u64 bal = __ballot(bit);
             peers &= bit ? bal : ~bal;
@@ -225,81 +248,101 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         const u32 below = (u32)__popcll(peers & lt);
         const u32 old = cnt[w][d];
         __builtin_amdgcn_wave_barrier();
-        if (valid && below == 0) cnt[w][d] = old + (u32)__popcll(peers);
+        if (valid && below == 0) cnt[w][d] = (CNT)(old + (u32)__popcll(peers));
         __builtin_amdgcn_wave_barrier();
         rnk[r] = old + below;
     }
     __syncthreads();
-    u32 mytot = 0;
-    if (threadIdx.x < 256) {   // exclusive prefix over the waves of this block, per digit; mytot = the block's count of digit threadIdx.x
-        const int d = threadIdx.x;
+    // exclusive prefix over the waves of this block, per digit (a thread takes BPT digits in a row); tot = the block's count of my digits
+    u32 tot[BPT], mytot = 0;
+#pragma unroll
+    for (int b = 0; b < BPT; b++) {
+        const int d = threadIdx.x * BPT + b;
         u32 run = 0;
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; k++) { u32 c = cnt[k][d]; cnt[k][d] = run; run += c; }
-        mytot = run;
+        for (int k = 0; k < RS_WAVES; k++) { const u32 c = cnt[k][d]; cnt[k][d] = (CNT)run; run += c; }
+        tot[b] = run; mytot += run;
     }
     // The tile is first ordered by digit in LDS and then written out: a digit's keys of this block go to one contiguous
     // run in global memory, so consecutive threads store consecutive addresses.  (Scattering straight from registers made
     // every store of a wave hit up to 64 different sectors: 200 us per pass for 1e7 keys where the well-clustered top
     // digit took 55.)
     {
-        u32 inc = mytot;       // (the digits live in the first four waves)
+        u32 inc = mytot;
 #pragma unroll
         for (int dd = 1; dd < 64; dd <<= 1) { const u32 t = __shfl_up(inc, dd, 64); if (lane >= dd) inc += t; }
-        if (lane == 63 && w < 4) wtot[w] = inc;
+        if (lane == 63) wtot[w] = inc;
         __syncthreads();
-        if (threadIdx.x < 256) {
-            u32 before = 0;
+        u32 before = inc - mytot;
 #pragma unroll
-            for (int k = 0; k < 4; k++) if (k < w) before += wtot[k];
-            dstart[threadIdx.x] = before + inc - mytot;
-        }
+        for (int k = 0; k < RS_WAVES; k++) if (k < w) before += wtot[k];
+#pragma unroll
+        for (int b = 0; b < BPT; b++) { dstart[threadIdx.x * BPT + b] = (CNT)before; before += tot[b]; }
     }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
         const int64_t i = wbase + (int64_t)r * 64 + lane;
         if (i < n) {
-            const u32 d = (u32)(key[r] >> shift) & 255u;
-            const u32 li = dstart[d] + cnt[w][d] + rnk[r];
+            const u32 d = (u32)(key[r] >> shift) & dmask;
+            const u32 li = (u32)dstart[d] + (u32)cnt[w][d] + rnk[r];
             skey[li] = key[r];
             sval[li] = val[r];
         }
     }
     __syncthreads();
-    const int64_t tbase = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t tbase = (int64_t)tile * RS_TILE;
     const u32 nvalid = (u32)((n - tbase) < (int64_t)RS_TILE ? (n - tbase) : (int64_t)RS_TILE);
     for (u32 li = threadIdx.x; li < nvalid; li += RS_THREADS) {
         const u64 k = skey[li];
-        const u32 d = (u32)(k >> shift) & 255u;
-        const size_t dst = (size_t)gbase[d] + (li - dstart[d]);
+        const u32 d = (u32)(k >> shift) & dmask;
+        const size_t dst = (size_t)gbase[d] + (li - (u32)dstart[d]);
         kout[dst] = k;
         vout[dst] = sval[li];
     }
 }
 
+template <class V, int BITS, bool XCD, class CNT>
+static void rs_scatter_launch(hipStream_t q, u32 nb, const u64 *ki, const V *vi, u64 *ko, V *vo, int64_t n, int shift, u32 dmask, const u32 *bh) {
+    const u32 grid = XCD ? RS_XCDS * ((nb + RS_XCDS - 1) / RS_XCDS) : nb;
+    hipLaunchKernelGGL((k_rs_scatter<V, BITS, XCD, CNT>), dim3(grid), dim3(RS_THREADS), 0, q, ki, vi, ko, vo, n, shift, dmask, bh, nb);
+}
+
 }  // namespace
+
+int rv_radix_passes(const Workspace &ws, int nbits) {
+    const int w = ws.opt.rs_bits == 10 ? 10 : 8;
+    return nbits <= 0 ? 0 : (nbits + w - 1) / w;
+}
 
 template <class V>
 int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n, int bit_lo, int bit_hi, int *result_in_1) {
     *result_in_1 = 0;
     if (n <= 1 || bit_hi <= bit_lo) return 0;
     if (n >= ((int64_t)1 << 32)) { rv_set_error("radix sort: n >= 2^32 not supported"); return -1; }
+    const int width = ws.opt.rs_bits == 10 ? 10 : 8;
+    const bool xcd = ws.opt.rs_xcd != 0, c16 = ws.opt.rs_cnt16 != 0;
     const u32 nb = (u32)ceil_div(n, RS_TILE);
-    RV_TRY(ws.rs_hist.reserve((size_t)256 * nb * sizeof(u32)));
+    RV_TRY(ws.rs_hist.reserve(((size_t)1 << width) * nb * sizeof(u32)));
     u32 *bh = ws.rs_hist.as<u32>();
     u64 *ki = k0, *ko = k1;
     V *vi = v0, *vo = v1;
     int flip = 0;
-    for (int shift = bit_lo; shift < bit_hi; shift += 8) {
+    for (int shift = bit_lo; shift < bit_hi; shift += width) {
+        // (the last pass may cover fewer bits: whatever lies above bit_hi never takes part)
+        const int wbits = bit_hi - shift < width ? bit_hi - shift : width;
+        const u32 dmask = (1u << wbits) - 1u;
         int pid = ws.prof_begin(8 /* RV_K_RADIX_HIST */, 8.0 * (double)n);
-        hipLaunchKernelGGL(k_rs_hist, dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, bh, nb);
+        if (width == 10) hipLaunchKernelGGL((k_rs_hist<10>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
+        else hipLaunchKernelGGL((k_rs_hist<8>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
         RV_LAUNCH_CHECK();
         ws.prof_end(pid);
-        RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, (int64_t)256 * nb));
+        RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, ((int64_t)1 << width) * nb));
         pid = ws.prof_begin(7 /* RV_K_RADIX_SCATTER */, 2.0 * (8.0 + sizeof(V)) * (double)n);
-        hipLaunchKernelGGL((k_rs_scatter<V>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, (const V *)vi, ko, vo, n, shift,
-                           (const u32 *)bh, nb);
+#define RS_GO(B_, X_, C_) rs_scatter_launch<V, B_, X_, C_>(ws.stream, nb, (const u64 *)ki, (const V *)vi, ko, vo, n, shift, dmask, (const u32 *)bh)
+        if (width == 10) { if (xcd) { if (c16) RS_GO(10, true, uint16_t); else RS_GO(10, true, u32); } else { if (c16) RS_GO(10, false, uint16_t); else RS_GO(10, false, u32); } }
+        else             { if (xcd) { if (c16) RS_GO(8, true, uint16_t); else RS_GO(8, true, u32); } else { if (c16) RS_GO(8, false, uint16_t); else RS_GO(8, false, u32); } }
+#undef RS_GO
         RV_LAUNCH_CHECK();
         ws.prof_end(pid);
         u64 *tk = ki; ki = ko; ko = tk;

@@ -4,7 +4,9 @@ known-answer vectors of SURVEY.md 8(c).  No GPU, no /root/reference needed."""
 import numpy as np
 import pytest
 
-from helpers import assemble, csr_tuples, golden, golden_inputs, oracle, sha_arr, sha_json, trace_digests
+import os
+
+from helpers import GOLD, ROOT, assemble, csr_tuples, golden, golden_inputs, oracle, sha_arr, sha_json, trace_digests
 
 SETS = golden()
 
@@ -242,3 +244,20 @@ def test_reference_aligner_itself_pins_the_oracle(tmp_path):
         g = gold[label]
         P.pin_aligner(label, files(g["inputs"]), sa64, minl=g["minl"], minn=g["minn"], golden=g)
     assert P.check.failed == 0
+
+
+def test_fullsize_golden_file_is_reproducible():
+    """tests/golden/fullsize.json: the record of the smallest configuration comes out of oracle/gen_fullsize_golden.py again, digest
+    for digest (the large ones take the same code minutes to hours; their inputs are pinned by sha_input)"""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import gen_fullsize_golden as g
+    from oracle import ref_ctypes
+    if not ref_ctypes.available(False):
+        pytest.skip("oracle/_ref is not built here")
+    want = json.load(open(os.path.join(GOLD, "fullsize.json")))["C2_seed42"]
+    got = g.run("C2_seed42")
+    for k in want:
+        if k != "cpu_seconds":
+            assert got[k] == want[k], k

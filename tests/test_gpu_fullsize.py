@@ -20,6 +20,15 @@ pytestmark = pytest.mark.gpu
 CONFIGS = {"C4": (250_000_000, 2, 11), "C3": (5_000_000, 10, 13)}
 
 
+def golden(cfg):
+    """the CPU path's digests at this size (tests/golden/fullsize.json: the reference's divsufsort + the restated recursion, run in
+    the build container by oracle/gen_fullsize_golden.py)"""
+    L, G, seed = CONFIGS[cfg]
+    rec = check.golden_record(L, G, seed)
+    assert rec is not None, "tests/golden/fullsize.json holds no record for %s" % cfg
+    return rec
+
+
 def _lcp_stop(T, a, b, cap=8192):
     n = len(T)
     h = 0
@@ -55,6 +64,10 @@ def test_construct_properties(built):
     del seen
     LCP = idx.array("LCP")
     assert LCP[0] == 0 and int(LCP.max()) == idx.maxlcp
+    # bit-identical to the reference's suffix array (divsufsort) and to compute_lcp (interface.c:97-114) at full size
+    g = check.compare_with_golden(golden(name), SA=SA, LCP=LCP)
+    assert g["all"], g
+    assert idx.maxlcp == golden(name)["maxlcp"]
     rng = np.random.default_rng(3)
     ranks = np.concatenate([rng.integers(1, n, 6000), np.arange(1, 300), np.arange(n - 300, n)])
     for k in ranks:
@@ -111,8 +124,12 @@ def test_recursion_properties(built):
     l, off, pos = res["anchors"]
     assert res["stats"]["splits"] == len(l) and res["stats"]["anchored_bp"] == int(np.asarray(l, dtype=np.int64).sum())
     nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
-    p = check.recursion_properties(T0, idx.array("T"), res["anchors"], nsep, 20)
+    T1 = idx.array("T")
+    p = check.recursion_properties(T0, T1, res["anchors"], nsep, 20)
     assert p["all"], p
+    # the anchor set and the lower-cased text are the CPU recursion's (reveal.c:731-1338 with the benchmark callbacks), bit for bit
+    g = check.compare_with_golden(golden(name), anchors=res["anchors"], T_final=T1)
+    assert g["all"], g
     # 1 % substitutions: about one anchor per substitution-free stretch, nearly everything anchored
     assert p["anchors"] > L // 150
     if G == 2:
@@ -148,6 +165,10 @@ def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch, cfg):
         members = pos.reshape(-1, G)[order]
         out.append((np.asarray(l)[order], members, idx.array("T").copy(),
                     {k: res["stats"][k] for k in (("steps", "splits", "anchored_bp") if G == 2 else ("splits", "anchored_bp"))}))
+    for which, o in zip(("cascade", "level pipeline"), out):      # each path against the CPU recursion's digests
+        ll, mm, tt, _ = o
+        g = check.compare_with_golden(golden(cfg), anchors=(ll, np.arange(0, len(mm.ravel()) + 1, G), mm.ravel()), T_final=tt)
+        assert g["all"], (which, g)
     a, b = out
     assert a[3] == b[3], (a[3], b[3])
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])

@@ -33,7 +33,7 @@ def test_inclusive_max(lib, n):
 
 
 @pytest.mark.parametrize("n,lo,hi", [(1, 0, 64), (2, 0, 8), (1000, 0, 64), (4096, 0, 16), (4097, 8, 40),
-                                      (123457, 0, 64), (1 << 20, 0, 24), (3000001, 32, 56)])
+                                      (123457, 0, 64), (1 << 20, 0, 24), (3000001, 32, 56), (70001, 3, 40), (5000, 0, 5)])
 def test_radix_sort_stable(lib, n, lo, hi):
     rng = np.random.default_rng(n + lo)
     keys = rng.integers(0, 1 << 63, size=n, dtype=np.uint64)
@@ -44,10 +44,20 @@ def test_radix_sort_stable(lib, n, lo, hi):
     assert lib.dll.rv_test_radix_sort(k.ctypes.data, v.ctypes.data, n, lo, hi) == 0, lib.err()
     width = hi - lo
     mask = np.uint64((1 << width) - 1) if width < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
-    # the sort sees 8-bit digits: bits [lo, lo + 8*ceil(width/8))
-    width8 = min(64 - lo, 8 * ((width + 7) // 8))
-    mask = np.uint64((1 << width8) - 1) if width8 < 64 else np.uint64(0xFFFFFFFFFFFFFFFF)
+    # (the last pass masks its digit: exactly the bits [lo, hi) take part)
     sub = (keys >> np.uint64(lo)) & mask
     order = np.argsort(sub, kind="stable")
     assert np.array_equal(v, vals[order])
     assert np.array_equal(k, keys[order])
+
+
+@pytest.mark.parametrize("flags", range(8))
+@pytest.mark.parametrize("n,bits,dist", [(100_000, 40, 1), (4096 * 9 + 5, 37, 0), (300_000, 16, 2)])
+def test_radix_sort_variants(lib, flags, n, bits, dist):
+    """every variant of the scatter kernel (10-bit digits, XCD-aware tile order, 16-bit wave counters: rv_prims.hip) sorts device-made
+    keys stably -- checked on the device: no adjacent pair out of order by (key bits, original index)"""
+    import ctypes
+    ms = (ctypes.c_double * 2)()
+    bad = ctypes.c_int64(-1)
+    assert lib.dll.rv_test_radix_time(n, bits, dist, flags, 2, ms, ctypes.byref(bad)) == 0, lib.err()
+    assert bad.value == 0

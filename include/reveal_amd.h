@@ -279,6 +279,7 @@ enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, 
         * scatter pass, 8 B per key and histogram pass; the text round's bytes are its list traffic) */
        RV_K_RADIX_SCATTER = 7, RV_K_RADIX_HIST = 8, RV_K_TEXT_ROUND = 9,
        RV_K_CASCADE = 10,      /* the anchor cascade behind its scan: witnesses, match sort, levels, rebuild + leaf launch */
+       RV_K_DIAG_TABLE = 11,   /* part of RV_K_SA_SORT: piecewise diagonals from seeds (two samples that left their fixed diagonal: indels) */
        RV_K_COUNT = 12 };
 /* on: 0 = off, 1 = every class, otherwise bit k+1 selects class k (an event pair costs the stream a few
  * microseconds, so a timed run times only what it reports) */
@@ -292,6 +293,7 @@ int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes
 int rv_measure_bandwidth(int device, int64_t bytes, int iters, double *read_gbs, double *copy_gbs);
 /* SA-build statistics of the last rv_construct */
 int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_t *sorted_elems, int *radix_passes);
+int rv_sa_diag_table(rv_index *h);      /* 1: two samples on piecewise diagonals from seeds in the last construct() (rv_construct.hip k_diag_bits_tab) */
 
 /* ---- self-test hooks for the device primitives (tests/ only) ------------------ */
 int rv_test_exclusive_sum_u32(const uint32_t *in, uint32_t *out, int64_t n);

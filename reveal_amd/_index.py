@@ -153,7 +153,7 @@ def make_index_type(sa64, error):
             only = names of the kernel classes to time (default: all; every timed span costs the stream two events)"""
             ids = {"scan_pair": _lib.K_SCAN_PAIR, "scan_multi": _lib.K_SCAN_MULTI, "sa_build": _lib.K_SA_SORT, "lcp": _lib.K_LCP,
                    "split": _lib.K_SPLIT, "label": _lib.K_LABEL, "bubble": _lib.K_BUBBLE, "radix_scatter": _lib.K_RADIX_SCATTER,
-                   "radix_hist": _lib.K_RADIX_HIST, "text_round": _lib.K_TEXT_ROUND, "cascade": _lib.K_CASCADE}
+                   "radix_hist": _lib.K_RADIX_HIST, "text_round": _lib.K_TEXT_ROUND, "cascade": _lib.K_CASCADE, "diag_table": _lib.K_DIAG_TABLE}
             if enable is not None:
                 on = 0
                 if enable:
@@ -172,7 +172,8 @@ def make_index_type(sa64, error):
             v = [ctypes.c_int(0) for _ in range(4)]
             se, rp = ctypes.c_int64(0), ctypes.c_int(0)
             self._dll.rv_sa_stats(self._h, *[ctypes.byref(x) for x in v], ctypes.byref(se), ctypes.byref(rp))
-            return dict(sigma=v[0].value, bits=v[1].value, k0=v[2].value, rounds=v[3].value, sorted_elems=se.value, radix_passes=rp.value)
+            return dict(sigma=v[0].value, bits=v[1].value, k0=v[2].value, rounds=v[3].value, sorted_elems=se.value, radix_passes=rp.value,
+                        diag_table=int(self._dll.rv_sa_diag_table(self._h)))
 
         # ---- construct --------------------------------------------------------
         def construct(self, rc=0):                          # interface.c:160-291

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RV_T, RV_SA, RV_SAI, RV_LCP, RV_SO, RV_NSEP, RV_NODES = range(7)
-K_SCAN_PAIR, K_SCAN_MULTI, K_SA_SORT, K_LCP, K_SPLIT, K_LABEL, K_BUBBLE, K_RADIX_SCATTER, K_RADIX_HIST, K_TEXT_ROUND, K_CASCADE = range(11)
+K_SCAN_PAIR, K_SCAN_MULTI, K_SA_SORT, K_LCP, K_SPLIT, K_LABEL, K_BUBBLE, K_RADIX_SCATTER, K_RADIX_HIST, K_TEXT_ROUND, K_CASCADE, K_DIAG_TABLE = range(12)
 
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 V = ctypes.c_void_p
@@ -108,6 +108,7 @@ SYMBOLS = {
     "rv_prof_get": (_I, [V, _I, c_i64p, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "rv_measure_bandwidth": (_I, [_I, _L, _I, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "rv_sa_stats": (_I, [V] + [ctypes.POINTER(_I)] * 4 + [c_i64p, ctypes.POINTER(_I)]),
+    "rv_sa_diag_table": (_I, [V]),
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
     "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),

@@ -775,6 +775,8 @@ int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_
     if (radix_passes) *radix_passes = h->sa_stats.radix_passes;
     return 0;
 }
+/* 1: the last construct() of two samples followed piecewise diagonals from seeds (the samples had left their fixed diagonal: indels) */
+int rv_sa_diag_table(rv_index *h) { return h->sa_stats.diag_table; }
 
 /* ---- the node's practical HBM ceiling (SURVEY 8(d) "Roofline": measured copy-kernel bandwidth beside the 8 TB/s spec) ---- */
 }  // extern "C"

@@ -87,7 +87,8 @@ void rv_set_error(const char *fmt, ...);
     X(launch_trace, "RV_LAUNCH_TRACE", 0) \
     X(rs_bits, "RV_RS_BITS", 8) \
     X(rs_xcd, "RV_RS_XCD", 1) \
-    X(rs_cnt16, "RV_RS_CNT16", 1)
+    X(rs_cnt16, "RV_RS_CNT16", 1) \
+    X(diag_table, "RV_DIAG_TABLE", -1)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)
@@ -358,6 +359,7 @@ struct RvSaStats {
     int    rounds;              // doubling rounds after the initial sort
     int64_t sorted_elems;       // sum of elements pushed through the radix sort
     int    radix_passes;
+    int    diag_table;          // two samples: the hint and the twins' leaving follow piecewise diagonals from seeds (k_diag_bits_tab)
 };
 // SA of T[0..n) (device pointers).  T must be readable up to n+15 (zero padded).
 // LCP / BWT / d_maxlcp given: the build also leaves LCP (interface.c:97-114), the BWT bytes (side_sep as for rv_build_lcp) and

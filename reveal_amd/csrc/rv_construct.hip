@@ -75,7 +75,7 @@ constexpr int KEY_TILE = 1024;
 // that into the spare bits of p's first key, above the bits the sort looks at.  The text round reads a pair's order and LCP
 // from the key it has in registers anyway; anything the hint does not cover (other diagonals after an indel, stretches longer
 // than the field, exceptions, unrelated suffixes that collide in their K symbols) is compared on the text as before.
-struct DiagBits { const u64 *stop, *exc, *lt; int64_t D; };      // one bit per text position each; stop = differs or exception
+struct DiagBits { const u64 *stop, *exc, *lt; int64_t D; int tab; };      // one bit per text position each; stop = differs or exception; tab: the bits follow the diagonal table (k_diag_bits_tab)
 struct DiagSamples { int ns; int64_t sep[15], Ds[16]; };            // (HINT_K - 1 separators, HINT_K diagonals: declared below)
 // the partner of position y: its homologue in the first sample for a position of a later sample, its homologue in the second for one of the first
 __device__ inline int64_t diag_partner(const DiagSamples &ds, int64_t y) {
@@ -115,6 +115,164 @@ __global__ __launch_bounds__(TB) void k_diag_bits(const uint8_t *__restrict__ T,
     }
     stop[w] = ws; exc[w] = we; lt[w] = wl;
 }
+// ---- piecewise diagonals (two samples) ----------------------------------------------------------------------------------
+// One fixed diagonal D = nsep[0] + 1 only describes a pair of genomes without insertions or deletions: behind the first indel every
+// position of the second sample has moved off it, and neither the hint nor the twins' leaving covers anything.  The table gives every
+// tile of 16 text positions its own diagonal: partner(y) = y + D + dtab[y >> 4] for a position of the first sample,
+// y - D - dtab[y >> 4] for one of the second -- the same deviation dd on both sides of a pair.  A position is LINKED when its
+// partner lies in the other sample and the partner's tile carries the same dd: then the partner's partner is the position itself, so
+// both sides see the same pairs whatever the table holds (every entry may be wrong: a link is only ever used through the characters
+// k_diag_bits_tab compares along it).  A position that is not linked, or whose predecessor is linked differently (the start of a run,
+// a change of diagonal), is marked as an exception: the marks of a pair are equal on both sides (link(y - 1) != link(y) holds for y
+// iff it holds for its partner), which is what the twins' predicate needs -- a window without marks lies on ONE diagonal.
+// The table comes from seeds: 32-mers sampled by content (hash & 15 == 0: the same k-mers in both samples), sorted by hash; a hash
+// that occurs exactly twice, once per sample, votes dd = q - p - D for the tiles the two copies cover (the smallest vote wins); a tile
+// without a vote looks for the nearest votes on either side and, when they differ (an indel in between), takes the one along which
+// more of its own sixteen characters agree.  An indel costs the tile it lies in, not the rest of the genome.
+constexpr int32_t DT_NONE = 0x7fffffff;
+constexpr int DT_SHIFT = 4, DT_TILE = 1 << DT_SHIFT;
+constexpr int SEED_K = 32, SEED_SLOTS = 4;          // seed length; seeds a word of 64 positions may emit
+constexpr u64 SEED_EMPTY = (1ull << 40) - 1;        // key of an unused slot: sorts behind every hash (a hash that spells it is dropped)
+struct DiagTab { const int32_t *dtab; int64_t S2, D; };      // S2 = first position of the second sample (= D: the fixed diagonal it deviates from)
+__device__ inline u64 seed_mix(u64 x) { x ^= x >> 31; x *= 0x9E3779B97F4A7C15ull; x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32; return x; }
+// one thread per word: the 32-mers ENDING inside it, rolled as 2-bit codes; the first SEED_SLOTS that pass the filter go to the word's slots
+__global__ __launch_bounds__(TB) void k_seed_sample(const uint8_t *__restrict__ T, int64_t n, u64 *__restrict__ keys, sav_t *__restrict__ vals, int64_t nwords) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t y0 = w * 64;
+    u64 code = 0; int run = 0, cnt = 0;
+    u64 ok[SEED_SLOTS]; sav_t ov[SEED_SLOTS];
+#pragma unroll
+    for (int k = 0; k < SEED_SLOTS; k++) { ok[k] = SEED_EMPTY; ov[k] = 0; }
+    for (int64_t i = y0 - (SEED_K - 1); i < y0 + 64 && i < n; i++) {
+        const u32 c = i >= 0 ? T[i] : 0u;
+        const u32 c2 = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+        run = c2 < 4u ? run + 1 : 0;
+        code = (code << 2) | (c2 & 3u);
+        if (i >= y0 && run >= SEED_K) {
+            const u64 h = seed_mix(code);
+            if ((h & 15u) == 0u && cnt < SEED_SLOTS) {
+                const u64 k40 = h >> 24;
+                if (k40 != SEED_EMPTY) {
+#pragma unroll
+                    for (int k = 0; k < SEED_SLOTS; k++) if (k == cnt) { ok[k] = k40; ov[k] = (sav_t)(i - (SEED_K - 1)); }
+                    cnt++;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SEED_SLOTS; k++) { keys[w * SEED_SLOTS + k] = ok[k]; vals[w * SEED_SLOTS + k] = ov[k]; }
+}
+// sorted seeds: a hash held by exactly two seeds, one in each sample, votes for the tiles its two copies cover
+__global__ __launch_bounds__(TB) void k_seed_pairs(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, int64_t S2, int64_t D, int32_t *__restrict__ raw) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j + 1 >= m) return;
+    const u64 mk = (1ull << 40) - 1;
+    const u64 k0 = keys[j] & mk, k1 = keys[j + 1] & mk;
+    if (k0 == SEED_EMPTY || k0 != k1) return;
+    if (j > 0 && (keys[j - 1] & mk) == k0) return;
+    if (j + 2 < m && (keys[j + 2] & mk) == k0) return;
+    int64_t a = (int64_t)vals[j], b = (int64_t)vals[j + 1];
+    if (a > b) { const int64_t t = a; a = b; b = t; }
+    if (!(a + SEED_K < S2 && b >= S2)) return;
+    const int64_t dd = b - a - D;
+    if (dd <= -(int64_t)0x3fffffff || dd >= (int64_t)0x3fffffff) return;
+    for (int64_t t = a >> DT_SHIFT; t <= (a + SEED_K - 1) >> DT_SHIFT; t++) atomicMin(&raw[t], (int32_t)dd);
+    for (int64_t t = b >> DT_SHIFT; t <= (b + SEED_K - 1) >> DT_SHIFT; t++) atomicMin(&raw[t], (int32_t)dd);
+}
+// characters of tile t that agree with their partners along deviation dd (every character counts: it only ranks two candidates)
+__device__ inline int dtab_agree(const uint8_t *__restrict__ T, int64_t n, int64_t S2, int64_t D, int64_t t, int32_t dd) {
+    int c = 0;
+    for (int k = 0; k < DT_TILE; k++) {
+        const int64_t y = (t << DT_SHIFT) + k;
+        if (y >= n) break;
+        const int64_t z = y < S2 ? y + D + (int64_t)dd : y - D - (int64_t)dd;
+        c += (z >= 0 && z < n && T[y] == T[z]) ? 1 : 0;
+    }
+    return c;
+}
+// a tile without a vote: the nearest votes to its left and right (64 tiles each way); two different ones -> the one its own text follows
+__global__ __launch_bounds__(TB) void k_dtab_fill(const uint8_t *__restrict__ T, int64_t n, int64_t S2, int64_t D, const int32_t *__restrict__ raw, int32_t *__restrict__ dtab, int64_t ntiles) {
+    const int64_t t = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (t >= ntiles) return;
+    int32_t v = raw[t];
+    if (v >= 0x7f000000) {
+        int32_t L = DT_NONE, R = DT_NONE;
+        for (int d = 1; d <= 64 && L == DT_NONE; d++) if (t - d >= 0) { const int32_t x = raw[t - d]; if (x < 0x7f000000) L = x; }
+        for (int d = 1; d <= 64 && R == DT_NONE; d++) if (t + d < ntiles) { const int32_t x = raw[t + d]; if (x < 0x7f000000) R = x; }
+        if (L == DT_NONE) v = R;
+        else if (R == DT_NONE || R == L) v = L;
+        else v = dtab_agree(T, n, S2, D, t, R) > dtab_agree(T, n, S2, D, t, L) ? R : L;
+    }
+    dtab[t] = v;
+}
+__device__ inline int32_t dtab_link(const DiagTab &dt, int64_t y, int64_t n, int64_t *partner) {
+    if (y < 0 || y >= n || y == dt.S2 - 1) return DT_NONE;      // (the separator between the samples belongs to neither: a run of links never crosses it)
+    const int32_t dd = dt.dtab[y >> DT_SHIFT];
+    if (dd == DT_NONE) return DT_NONE;
+    const bool s1 = y < dt.S2;
+    const int64_t z = s1 ? y + dt.D + (int64_t)dd : y - dt.D - (int64_t)dd;
+    if (z < 0 || z >= n || (s1 ? z < dt.S2 : z >= dt.S2 - 1)) return DT_NONE;
+    if (dt.dtab[z >> DT_SHIFT] != dd) return DT_NONE;
+    *partner = z;
+    return dd;
+}
+// k_diag_bits along the table's diagonals: stop = the characters differ, or an exception; exception = not A / C / G / T on either side,
+// not linked, or the first position of a run of equal links.  A thread takes a word, tile by tile.
+__global__ __launch_bounds__(TB) void k_diag_bits_tab(const uint8_t *__restrict__ T, int64_t n, DiagTab dt, u64 *__restrict__ stop, u64 *__restrict__ exc,
+                                                      u64 *__restrict__ lt, int64_t nwords) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (w >= nwords) return;
+    const int64_t y0 = w * 64;
+    u64 ws = 0, we = 0, wl = 0;
+    int64_t zp = 0;
+    int32_t prev = dtab_link(dt, y0 - 1, n, &zp);      // link of the position in front of the one looked at
+    for (int sub = 0; sub < 64 / DT_TILE; sub++) {
+        const int64_t ys = y0 + sub * DT_TILE;
+        u32 ms = 0, me = 0, ml = 0;      // this tile's sixteen bits
+        const int32_t dd = ys < n ? dt.dtab[ys >> DT_SHIFT] : DT_NONE;
+        const bool one_side = ys >= dt.S2 || ys + DT_TILE - 1 < dt.S2 - 1;
+        const int64_t z0 = ys < dt.S2 ? ys + dt.D + (int64_t)dd : ys - dt.D - (int64_t)dd;
+        const bool other_side = ys < dt.S2 ? z0 >= dt.S2 : z0 + DT_TILE - 1 < dt.S2 - 1;
+        if (dd == DT_NONE) { ms = me = 0xffffu; prev = DT_NONE; }
+        else if (one_side && ys + DT_TILE <= n && z0 >= 0 && z0 + DT_TILE <= n && other_side) {      // the tile and its partners as two 16-byte loads
+            const int off = (int)(z0 & (DT_TILE - 1));
+            const bool v0 = dt.dtab[z0 >> DT_SHIFT] == dd, v1 = off ? dt.dtab[(z0 >> DT_SHIFT) + 1] == dd : v0;
+            const u32 lowm = off ? ((1u << (DT_TILE - off)) - 1u) : 0xffffu;
+            const u32 valid = (v0 ? lowm : 0u) | (v1 ? (~lowm & 0xffffu) : 0u);
+            u64 a[2], b[2];
+            __builtin_memcpy(a, T + ys, 16);
+            __builtin_memcpy(b, T + z0, 16);
+#pragma unroll
+            for (int k = 0; k < 2; k++)
+#pragma unroll
+                for (int j = 0; j < 8; j++) {
+                    const u32 ca = (u32)(a[k] >> (8 * j)) & 0xffu, cb = (u32)(b[k] >> (8 * j)) & 0xffu;
+                    const bool ea = !((ca == 'A') | (ca == 'C') | (ca == 'G') | (ca == 'T')), eb = !((cb == 'A') | (cb == 'C') | (cb == 'G') | (cb == 'T'));
+                    const int bit = 8 * k + j;
+                    me |= (u32)(ea | eb) << bit; ms |= (u32)((ca != cb) | ea | eb) << bit; ml |= (u32)(ca < cb) << bit;
+                }
+            u32 forced = 0;
+            if ((valid & 1u) && prev != dd) forced |= 1u;
+            if (off && !v0 && v1) forced |= 1u << (DT_TILE - off);
+            ms |= (~valid & 0xffffu) | forced; me |= (~valid & 0xffffu) | forced; ml &= valid & ~forced;
+            prev = (valid >> (DT_TILE - 1)) & 1u ? dd : DT_NONE;
+        } else {
+            for (int bit = 0; bit < DT_TILE; bit++) {
+                const int64_t y = ys + bit;
+                int64_t z = 0;
+                const int32_t l = dtab_link(dt, y, n, &z);
+                if (l == DT_NONE || l != prev) { me |= 1u << bit; ms |= 1u << bit; prev = l; continue; }
+                const u32 ca = T[y], cb = T[z];
+                const bool ea = !((ca == 'A') | (ca == 'C') | (ca == 'G') | (ca == 'T')), eb = !((cb == 'A') | (cb == 'C') | (cb == 'G') | (cb == 'T'));
+                me |= (u32)(ea | eb) << bit; ms |= (u32)((ca != cb) | ea | eb) << bit; ml |= (u32)((ca < cb) & !(ea | eb)) << bit;
+            }
+        }
+        ws |= (u64)ms << (sub * DT_TILE); we |= (u64)me << (sub * DT_TILE); wl |= (u64)ml << (sub * DT_TILE);
+    }
+    stop[w] = ws; exc[w] = we; lt[w] = wl;
+}
 // ---- twins leave before the sort --------------------------------------------------------------------------------------
 // Two samples: a suffix q of the second sample whose K symbols -- and the byte in front of it -- are those of its homologue p = q - D in
 // the first (no marked position in [q - 1, q + K - 1]: k_diag_bits) would sort into p's group, carry p's key (same symbols, same byte in
@@ -138,17 +296,18 @@ __device__ inline u64 tw_range(int64_t w, int64_t a, int64_t b) {
     return from & to;
 }
 // positions of word w that are twins: flagged (first sample, [1, D - 1)) or left out of the sort (second sample, [D + 1, min(2 D - 1, n)))
-__device__ inline u64 tw_mask(u64 prev, u64 lo, u64 hi, int64_t w, int K, int64_t D, int64_t n) {
+// (tab: piecewise diagonals -- a position without a partner is marked, so the samples' ranges are all that is left to say)
+__device__ inline u64 tw_mask(u64 prev, u64 lo, u64 hi, int64_t w, int K, int64_t D, int64_t n, int tab) {
     const int64_t e = 2 * D - 1 < n ? 2 * D - 1 : n;
-    return tw_window_clear(prev, lo, hi, K) & (tw_range(w, 1, D - 1) | tw_range(w, D + 1, e));
+    return tw_window_clear(prev, lo, hi, K) & (tab ? (tw_range(w, 0, D - 1) | tw_range(w, D, n)) : (tw_range(w, 1, D - 1) | tw_range(w, D + 1, e)));
 }
 // per tile of KEY_TILE positions: the suffixes of the second sample that stay in the sort
-__global__ __launch_bounds__(TB) void k_tw_count(const u64 *__restrict__ stop, int64_t nwords, int K, int64_t D, int64_t n, u32 *__restrict__ tilecnt, int64_t ntiles) {
+__global__ __launch_bounds__(TB) void k_tw_count(const u64 *__restrict__ stop, int64_t nwords, int K, int64_t D, int64_t n, u32 *__restrict__ tilecnt, int64_t ntiles, int tab) {
     const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
     u32 c = 0;
     if (w < nwords) {
         const u64 prev = w > 0 ? stop[w - 1] : ~0ull, lo = stop[w], hi = w + 1 < nwords ? stop[w + 1] : ~0ull;
-        c = (u32)__popcll(tw_range(w, D, n) & ~tw_mask(prev, lo, hi, w, K, D, n));
+        c = (u32)__popcll(tw_range(w, D, n) & ~tw_mask(prev, lo, hi, w, K, D, n, tab));
     }
 #pragma unroll
     for (int d = 8; d >= 1; d >>= 1) c += __shfl_down(c, d, 16);      // KEY_TILE / 64 = 16 words per tile
@@ -189,7 +348,7 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
         if (threadIdx.x < KEY_TILE / 64) {
             const int x = threadIdx.x;
             const int64_t w = base / 64 + x;
-            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n);
+            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n, dg.tab);
             s_tw[x] = t; s_keep[x] = tw_range(w, dg.D, n) & ~t;
         }
         __syncthreads();
@@ -308,7 +467,8 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
 constexpr int HINT_K = 16;      // samples the diagonal hint knows (the first ones)
 // D: diagonal of the second sample against the first (nsep[0] + 1).  ns / sep / Ds: samples, their separators and every sample's
 // diagonal against the FIRST sample (Ds[s] = nsep[s-1] + 1, where sample s starts when every sample is one sequence)
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[5], pmagic[5]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K]; };      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[5], pmagic[5]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K];
+                   const int32_t *dtab; };      // dtab != NULL: two samples on piecewise diagonals (k_diag_bits_tab): partner(y) = y +- (D + dtab[y >> 6])      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
 __device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
     const u32 none = (1u << kd.ly.at_bits) - 1u;
@@ -353,12 +513,22 @@ __device__ inline int hint_sample(const KeyDigits &kd, int64_t p) {
     for (int q = 0; q < kd.ns - 1; q++) s += kd.sep[q] < p ? 1 : 0;
     return s;
 }
-__device__ inline bool hint_cmp(const KeyDigits &kd, int64_t u, u64 key_u, int64_t v, u64 key_v, int *c, u32 *l) {
+// (linked: the caller knows u and v to be partners -- a flagged suffix and the twin made from it: the table is not read again)
+__device__ inline bool hint_cmp(const KeyDigits &kd, int64_t u, u64 key_u, int64_t v, u64 key_v, int *c, u32 *l, bool linked = false) {
     if (kd.ly.nd_bits <= 0) return false;
     const int su = hint_sample(kd, u), sv = hint_sample(kd, v);
     if (su >= HINT_K || sv >= HINT_K) return false;
+    if (kd.dtab) {      // piecewise diagonals: the key of the second sample's suffix carries the hint only when it is linked (k_diag_bits_tab)
+        if (su == sv) return false;
+        if (!linked) {
+            const int64_t a = su == 0 ? u : v, b = su == 0 ? v : u;
+            const int32_t dd = kd.dtab[b >> DT_SHIFT];
+            if (dd == DT_NONE || b - kd.D - (int64_t)dd != a) return false;
+        }
+    } else {
     const int64_t bu = u - (su ? kd.Ds[su] : 0), bv = v - (sv ? kd.Ds[sv] : 0);
     if (bu != bv || su == sv) return false;
+    }
     u32 au = 0, av = 0; bool ltu = false, ltv = false;
     const bool ku = su ? key_hint(key_u, kd, &au, &ltu) : false, kv = sv ? key_hint(key_v, kd, &av, &ltv) : false;
     if (su == 0) { if (!kv) return false; *c = ltv ? 1 : -1; *l = av; return true; }
@@ -648,11 +818,11 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
         }
         const u32 pay = (u32)(key >> 56);
         if (flagged) {
-            const sav_t q = s + (sav_t)kd.D;
+            const sav_t q = s + (sav_t)kd.D + (kd.dtab ? (sav_t)(int64_t)kd.dtab[s >> DT_SHIFT] : (sav_t)0);      // (a flagged suffix is linked: its tile's diagonal)
             const u64 qkey = tw_twin_key(key, kd);
             const bool alone = hd & (kp1 != k0);
             int c = -1; u32 nd = 0;
-            const bool fin = twins && alone && hint_cmp(kd, (int64_t)s, key, (int64_t)q, qkey, &c, &nd);
+            const bool fin = twins && alone && hint_cmp(kd, (int64_t)s, key, (int64_t)q, qkey, &c, &nd, true);
             const int64_t rs = r + ((fin && c >= 0) ? 1 : 0), rq = r + ((fin && c >= 0) ? 0 : 1);
             if (fin) {
                 const u32 st = key_first_stop(key, kd);
@@ -1856,14 +2026,15 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     const unsigned nblk = (unsigned)ceil_div(n, TB);
 
     // -- first key, sorted on its K*bits significant bits
-    DiagBits dg; dg.stop = dg.exc = dg.lt = nullptr; dg.D = kd.D;
+    DiagBits dg; dg.stop = dg.exc = dg.lt = nullptr; dg.D = kd.D; dg.tab = 0;
+    kd.dtab = nullptr;
+    const int64_t nw = (n + 63) / 64;
+    DiagSamples dsm; dsm.ns = kd.ns;
+    for (int q2 = 0; q2 < HINT_K - 1; q2++) dsm.sep[q2] = kd.sep[q2];
+    for (int q2 = 0; q2 < HINT_K; q2++) dsm.Ds[q2] = kd.Ds[q2];
     if (kd.ly.nd_bits > 0) {
         DBuf &bds = ws.sa[20], &bde = ws.sa[21], &bdl = ws.sa[22];
-        const int64_t nw = (n + 63) / 64;
         SA_TRY(bds.reserve((size_t)nw * 8)); SA_TRY(bde.reserve((size_t)nw * 8)); SA_TRY(bdl.reserve((size_t)nw * 8));
-        DiagSamples dsm; dsm.ns = kd.ns;
-        for (int q2 = 0; q2 < HINT_K - 1; q2++) dsm.sep[q2] = kd.sep[q2];
-        for (int q2 = 0; q2 < HINT_K; q2++) dsm.Ds[q2] = kd.Ds[q2];
         hipLaunchKernelGGL(k_diag_bits, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, dsm, bds.as<u64>(), bde.as<u64>(), bdl.as<u64>(), nw);
         SA_HIP(hipGetLastError());
         dg.stop = bds.as<u64>(); dg.exc = bde.as<u64>(); dg.lt = bdl.as<u64>();
@@ -1874,18 +2045,57 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     int64_t nsort = n;
     const u32 *tw_off = nullptr;
     if (collapse) {
-        const int64_t nw = (n + 63) / 64, ntiles = ceil_div(n, KEY_TILE);
+        const int64_t ntiles = ceil_div(n, KEY_TILE);
         DBuf &btw = ws.sa[23];
         SA_TRY(btw.reserve((size_t)(std::max<int64_t>(ntiles, ceil_div(n, TB)) + 1) * 4 + 64));      // (also the flag counts per workgroup of k_heads_publish_tc)
         u32 *tc = btw.as<u32>();
-        hipLaunchKernelGGL(k_tw_count, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, (const u64 *)dg.stop, nw, K, kd.D, n, tc, ntiles);
-        SA_HIP(hipGetLastError());
-        SA_HIP(hipMemsetAsync(tc + ntiles, 0, 4, q));
-        SA_TRY(rv_exclusive_sum_u32(ws, tc, tc, ntiles + 1));
+        // what stays of the second sample in the sort, along the diagonals the bit arrays describe right now
+        auto count_kept = [&](int tab, u32 *kept_out) -> int {
+            hipLaunchKernelGGL(k_tw_count, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, (const u64 *)dg.stop, nw, K, kd.D, n, tc, ntiles, tab);
+            RV_LAUNCH_CHECK();
+            RV_HIP(hipMemsetAsync(tc + ntiles, 0, 4, q));
+            RV_TRY(rv_exclusive_sum_u32(ws, tc, tc, ntiles + 1));
+            return rv_read_back(ws, kept_out, tc + ntiles, 4);
+        };
         u32 kept = 0;
-        SA_TRY(rv_read_back(ws, &kept, tc + ntiles, 4));
+        SA_TRY(count_kept(0, &kept));
+        // Most of the second sample stays although the samples are related enough for the hint to have been asked for: it has left the
+        // fixed diagonal (indels).  Piecewise diagonals from seeds (k_seed_sample ... k_diag_bits_tab); kept when they let more twins leave.
+        const int dt_mode = (int)ws.opt.diag_table;      // -1: when it pays, 0: never, 1: always (test hook)
+        const int64_t n2 = n - kd.D;
+        if (dt_mode != 0 && n >= 4096 && (dt_mode == 1 || (int64_t)kept * 10 > n2 * 3)) {
+            const int64_t mseeds = nw * SEED_SLOTS;
+            DBuf &bdt = ws.sa[25];
+            const int64_t ndt = (n >> DT_SHIFT) + 1;
+            SA_TRY(bdt.reserve((size_t)ndt * 8 + 64));
+            int32_t *raw = bdt.as<int32_t>(), *tab = raw + ndt;
+            const int did = ws.prof_begin(11 /* RV_K_DIAG_TABLE */, (double)n + (double)mseeds * 12.0);
+            hipLaunchKernelGGL(k_seed_sample, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, bk0.as<u64>(), bv0.as<sav_t>(), nw);
+            SA_HIP(hipGetLastError());
+            int sin1 = 0;
+            SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), mseeds, 0, 40, &sin1));
+            SA_HIP(hipMemsetAsync(raw, 0x7f, (size_t)ndt * 4, q));      // (0x7f7f7f7f: above every vote; the fill writes DT_NONE where nothing is found)
+            hipLaunchKernelGGL(k_seed_pairs, dim3((unsigned)ceil_div(mseeds, TB)), dim3(TB), 0, q, (const u64 *)(sin1 ? bk1.as<u64>() : bk0.as<u64>()),
+                               (const sav_t *)(sin1 ? bv1.as<sav_t>() : bv0.as<sav_t>()), mseeds, kd.D, kd.D, raw);
+            SA_HIP(hipGetLastError());
+            hipLaunchKernelGGL(k_dtab_fill, dim3((unsigned)ceil_div(ndt, TB)), dim3(TB), 0, q, T, n, kd.D, kd.D, (const int32_t *)raw, tab, ndt);
+            SA_HIP(hipGetLastError());
+            DiagTab dt; dt.dtab = tab; dt.S2 = kd.D; dt.D = kd.D;
+            hipLaunchKernelGGL(k_diag_bits_tab, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, dt, ws.sa[20].as<u64>(), ws.sa[21].as<u64>(), ws.sa[22].as<u64>(), nw);
+            SA_HIP(hipGetLastError());
+            ws.prof_end(did);
+            u32 kept_tab = 0;
+            SA_TRY(count_kept(1, &kept_tab));
+            if (dt_mode == 1 || (int64_t)kept_tab * 5 < (int64_t)kept * 4) { kept = kept_tab; kd.dtab = tab; dg.tab = 1; }
+            else {      // the table lets no more twins leave than the fixed diagonal (unrelated or rearranged samples): back to the fixed one
+                hipLaunchKernelGGL(k_diag_bits, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, T, n, dsm, ws.sa[20].as<u64>(), ws.sa[21].as<u64>(), ws.sa[22].as<u64>(), nw);
+                SA_HIP(hipGetLastError());
+                SA_TRY(count_kept(0, &kept));
+            }
+        }
         nsort = kd.D + (int64_t)kept;
         tw_off = tc;
+        s.diag_table = dg.tab;
     }
     u64 top_pow = 1;
     for (int e = 0; e + 1 < K; e++) top_pow *= radix;      // (radix^K fits 64 bits: the key does)

@@ -319,3 +319,57 @@ def test_twins_leave_before_the_sort(monkeypatch, collapse, sa64):
         assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))], tag
         if collapse and len(seqs[0]) == 70000 and len(seqs[1]) == 70000:
             assert idx.sa_stats()["sorted_elems"] < idx.n, idx.sa_stats()      # some twins did leave
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("mode", ["auto", "forced", "off"])
+def test_piecewise_diagonals(monkeypatch, mode, sa64):
+    """two samples that left their fixed diagonal (indels): the hint and the twins' leaving follow a table of diagonals made from seeds
+    (k_seed_sample / k_seed_pairs / k_dtab_fill / k_diag_bits_tab; RV_DIAG_TABLE 1 = always, 0 = never) -- SA, LCP, the largest LCP
+    and the matches equal the oracle's on the reference simulator's mutation model, on indels next to tile and word borders, on
+    insertions longer than a tile, on a second sample that starts with an insertion / ends with a deletion, on identical samples
+    (nothing to find), unrelated samples (no seeds at all) and a rearranged second sample (seeds that contradict each other)"""
+    if mode != "auto":
+        monkeypatch.setenv("RV_DIAG_TABLE", "1" if mode == "forced" else "0")
+    rng = np.random.default_rng(29)
+
+    def rnd(L):
+        return "".join("ACGT"[x] for x in rng.integers(0, 4, L))
+    base = rnd(90000)
+    sim = [g.decode() for g in synth.genomes(120000, 2, seed=5, indelfrac=0.2)]
+    sim_dense = [g.decode() for g in synth.genomes(60000, 2, seed=6, snp=0.03, indelfrac=0.5)]
+    cases = [
+        sim, sim_dense,
+        [base, base[:63] + base[64:20000]],                                 # a deletion at the first word border
+        [base[:30000], base[:1024] + "G" + base[1024:30000]],               # an insertion at a key-tile border
+        [base[:30000], base[:5000] + rnd(3000) + base[5000:30000]],         # an insertion longer than a tile (and than the seeds' reach)
+        [base[:30000], rnd(700) + base[:30000]],                            # the second sample starts with an insertion
+        [base[:30000], base[:29000]],                                       # ... ends early
+        [base[:40000], base[20000:40000] + base[:20000]],                   # rearranged: two diagonals, both far from the fixed one
+        [base[:20000], rnd(20000)],                                         # unrelated
+        [base[:20000], base[:20000]],
+        [base[:20000], base[:10000] + base[10001:20000]],
+        ["ACGTACGTACGTTTACGTACGT" * 300, "ACGTACGTACGTTACGTACGT" * 300],    # repeats: every seed is ambiguous
+        [base[:5000], base[1:5000]], ["ACGTA", "ACGA"],
+    ]
+    used = 0
+    for seqs in cases:
+        T, nsep, nodes = assemble(seqs, toupper=False)
+        O = oracle(sa64)
+        c = O.construct(T, nsep, 2)
+        idx = mod(sa64).index()
+        for k, s_ in enumerate(seqs):
+            idx.addsample("s%d" % k)
+            idx.addsequence(s_)
+        idx.construct()
+        tag = (len(seqs[0]), len(seqs[1]), idx.sa_stats())
+        assert np.array_equal(idx.array("SA"), c["SA"]), tag
+        assert np.array_equal(idx.array("LCP"), c["LCP"]), tag
+        assert idx.maxlcp == int(c["LCP"].max()), tag
+        l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 20)
+        assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))], tag
+        used += idx.sa_stats()["diag_table"]
+        if seqs is sim and mode != "off":
+            st = idx.sa_stats()
+            assert st["diag_table"] == 1 and st["sorted_elems"] < 0.8 * idx.n, st      # the table was used and most twins left
+    assert (used > 0) == (mode != "off")

@@ -139,6 +139,124 @@ def spawn_ranks(n):
     return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
 
 
+def run_config5(args, rank, local_rank, world, dist, torch):
+    """BASELINE config 5, level 0: `reveal align --order=sequential --chunksize=5` over 100 genomes of 5 Mbp prints 20 independent
+    `reveal rem` jobs of five FASTA inputs each (reveal/align.py:27-54; reveal_amd/align.py sequential_plan) -- job j belongs to rank
+    j % world, a rank runs `--jobs` of its jobs at a time (a handle, HIP stream and host thread each), nothing is exchanged.  One step =
+    every level-0 job once.  Levels 1-2 align the level-0 GRAPHS (GFA -> GFA through the Python graph callbacks, reveal_amd/rem.py
+    graph_rem): the Python driver's work, outside the timed scope as SURVEY 8(e) allows."""
+    import queue
+    import threading
+    import numpy as np
+    from reveal_amd import _lib, align, check, synth
+    _lib.set_device(local_rank)
+    NG, CH = args.c5_genomes, 5
+    plan = align.sequential_plan(list(range(NG)), CH)
+    level0 = [members for members, _ in plan[0]]
+    mine = [j for j in range(len(level0)) if j % world == rank]
+    base = synth.base_codes(args.L, 42)
+    seqs = {j: [synth.member(base, k, 42, indelfrac=args.indelfrac) for k in level0[j]] for j in mine}
+    handles = {j: build_index(seqs[j], args.sa64) for j in mine}
+    upload_ms = sum(h.upload_ms for h in handles.values())
+    nthreads = max(1, min(args.jobs if args.jobs > 1 else 4, len(mine)))
+    results = {}
+
+    def step():
+        todo = queue.Queue()
+        for j in mine:
+            todo.put(j)
+        err = []
+
+        def work():
+            while True:
+                try:
+                    j = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    handles[j].construct()
+                    results[j] = handles[j].align_builtin(args.minl, args.minn)
+                except Exception as e:      # noqa: BLE001  (reported below: a failed job fails the step)
+                    err.append((j, e))
+        th = [threading.Thread(target=work) for _ in range(nthreads - 1)]
+        for t in th:
+            t.start()
+        work()
+        for t in th:
+            t.join()
+        if err:
+            raise RuntimeError("config-5 job %d failed: %s" % err[0])
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    for h in handles.values():
+        h.prof(enable=True, reset=True, only=("scan_multi",))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = [0, 0.0, 0.0]
+    for h in handles.values():
+        p = h.prof(enable=False)["scan_multi"]
+        prof = [prof[0] + p[0], prof[1] + p[1], prof[2] + p[2]]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # every job of this rank: the full-size properties of its last result; job 0 also against the CPU path's digests
+    props, golden = {}, None
+    if not args.no_check:
+        for j in mine:
+            T0 = np.frombuffer(b"$".join(seqs[j]) + b"$", dtype=np.uint8)
+            nsep = np.cumsum([len(x) + 1 for x in seqs[j]])[:-1] - 1
+            T1 = handles[j].array("T")
+            props[j] = bool(check.recursion_properties(T0, T1, results[j]["anchors"], nsep, args.minl)["all"])
+            if j == 0:
+                rec = check.golden_record(args.L, CH, 42, args.indelfrac, args.minl, args.minn)
+                if rec is not None:
+                    golden = check.compare_with_golden(rec, anchors=results[j]["anchors"], T_final=T1)
+    mine_info = {"rank": rank, "jobs": mine, "properties": props, "anchors": {j: int(results[j]["stats"]["splits"]) for j in mine}}
+    gathered = [mine_info]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine_info)
+    if rank == 0:
+        total_bases = float(NG * args.L)
+        launches, ms, nbytes = prof
+        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        allprops = {j: v for g in gathered for j, v in g["properties"].items()}
+        out = {
+            "metric": "Mbp/s indexed+MUM-anchored (reveal rem)", "value": total_bases * args.steps / elapsed / 1e6, "unit": "Mbp/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "int64" if args.sa64 else "int32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 5, level 0: %d synthetic %g Mbp genomes of one family (uniform ACGT base, 1%% SNP per member, seed 42), "
+                                   "--order=sequential --chunksize=%d -> %d independent rem jobs of %d inputs each (reveal/align.py:27-54), rem -m %d -n %d, "
+                                   "construct + full recursion per job, bench picker; texts resident in HBM before the timed region; levels 1-2 "
+                                   "(GFA -> GFA through the Python graph callbacks) are the Python driver's and outside the timed scope (SURVEY 8(e))"
+                                   % (NG, args.L / 1e6, CH, len(level0), CH, args.minl, args.minn),
+                       "jobs": len(level0), "jobs_per_rank": [len(g["jobs"]) for g in gathered], "concurrent_jobs_per_gpu": nthreads,
+                       "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
+                       "sharding": "job j on rank j % world, no exchange (the reference's only parallelism: independent reveal rem commands)"},
+            "upload_ms": upload_ms,
+            "roofline": {"bound": "hbm", "kernel": "k_casm_scan / k_scan_multi (the multi-sample scans of rank 0's jobs)", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                         "avg_us": (ms * 1e3 / launches) if launches else None},
+            "jobs_anchors": {str(j): v for g in gathered for j, v in g["anchors"].items()},
+            "properties_full_size": {"all": all(allprops.values()) and len(allprops) == len(level0) if not args.no_check else None,
+                                     "jobs_checked": len(allprops), "failed": [j for j, v in allprops.items() if not v]},
+            "parity": {"full_size": golden if golden is not None else "no CPU digests for job 0 in tests/golden/fullsize.json"},
+        }
+        print(json.dumps(out))
+
+
 def anchor_set(l, off, pos):
     return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
 
@@ -157,6 +275,9 @@ def main():
                     help="variants by the reference's own mutation model (utils/simulate.py:17-77: this fraction of the 1 %% events are indels, "
                          "zipf(1.7) lengths) instead of substitutions only; 0 = SURVEY 8(d)'s generator, the metric's workload")
     ap.add_argument("--no-extra", action="store_true", help="skip the companion legs of the default line (level pipeline, indel workload)")
+    ap.add_argument("--config", choices=("default", "c5"), default="default",
+                    help="c5 = BASELINE config 5's level 0: 100 genomes of 5 Mbp as 20 independent jobs of five, divided over the ranks")
+    ap.add_argument("--c5-genomes", type=int, default=100, help="--config c5: number of genomes (a multiple of 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size property check of the last step's result")
@@ -204,6 +325,14 @@ def main():
     import numpy as np
     from reveal_amd import _lib, synth, check
     _lib.set_device(local_rank)
+    if args.config == "c5":
+        if args.L == 250_000_000:
+            args.L = 5_000_000
+        run_config5(args, rank, local_rank, world, dist, torch)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     mode = "divide" if args.divide else args.mode
     big = args.L * args.genomes >= 100_000_000

@@ -87,6 +87,15 @@ def variant_codes_indel(base, k, seed=42, rate=0.01, indelfrac=0.2, zipfd=1.7, m
     return res
 
 
+def member(base, k, seed=42, snp=0.01, indelfrac=0.0):
+    """member k of the family genomes(L, count, seed) makes, from the base's codes (k = 0: the base itself)"""
+    if k == 0:
+        return _ACGT[base].tobytes()
+    if indelfrac > 0:
+        return _ACGT[variant_codes_indel(base, k, seed, snp, indelfrac)].tobytes()
+    return _ACGT[variant_codes(base, k, seed, snp)].tobytes()
+
+
 def genomes(L, count, seed=42, snp=0.01, indelfrac=0.0):
     """-> list of `count` byte strings: the base and count-1 variants of it."""
     base = base_codes(L, seed)

@@ -5,8 +5,12 @@
 
 // device scratch of the cascade, kept between runs (grow-only like every other buffer of a handle)
 struct RvCascadeBufs {
-    DBuf d[32];
+    DBuf d[40];
     u32 M = 0, NW = 0;                 // the lists of the last run on this handle (a second attempt starts from them)
+    // several sequences per sample (rv_cascade.hip "the lineage of rest sub-indices"): what the first attempt found out on the host,
+    // kept for a second attempt on the same lists
+    u32 lin_roots = 0, lin_picks = 0, lin_nA = 0, lin_nB = 0;
+    int64_t lin_steps = 0; int lin_maxdepth = 0; size_t lin_off[6] = {0, 0, 0, 0, 0, 0};
     void release() { for (auto &b : d) b.release(); }
 };
 

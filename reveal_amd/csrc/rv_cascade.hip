@@ -209,6 +209,86 @@ __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *
     if (i < nw) w_child[i] = 0u;
 }
 
+// ---- several sequences per sample: the lineage of "rest" sub-indices ----------------------------------------------------------
+// With more than one sequence in a sample the root holds many intervals, and the linear interval model splits it into
+// leading = the two touched intervals' left remainders, trailing = their right remainders, rest = every interval the match did not touch.
+// The rest child is made of WHOLE sequences again, so the sub-indices with more than one interval per sample form one chain
+// R0 = root, R1 = rest(R0), ..., and everything else is a sub-index with one interval per sample -- what the cascade handles.  The
+// chain is decided on the host from the root's match list in descending length (ties: smallest first coordinate, as the picker breaks
+// them): the choice of Rk is the first match whose two sequences are both still in Rk, provided it is longer than Wmax(Rk) (W over the
+// positions of Rk's sequences: the bound of this file's header holds for any union of whole sequences -- nothing of them is cut).  Every
+// choice makes an anchor and up to two one-interval-per-sample sub-indices, the ROOTS of the device cascade (k_cas_init_roots); a chain
+// member the list does not decide makes the attempt give up.
+struct CasRootTabs { const sa_t *beginA, *beginB; const int32_t *pickA, *pickB; const u32 *rootLead, *rootTrail; u32 nA, nB; };
+__device__ inline int cas_contig_of(const sa_t *__restrict__ begins, u32 cnt, int64_t pos) {      // last sequence that begins at or in front of pos
+    u32 lo = 0, hi = cnt;
+    while (lo < hi) { const u32 mid = (lo + hi) >> 1; if ((int64_t)begins[mid] <= pos) lo = mid + 1; else hi = mid; }
+    return (int)lo - 1;
+}
+__global__ void k_cas_init_roots(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *__restrict__ wmax, int32_t *__restrict__ depth, CasRes *__restrict__ res,
+                                 u32 *__restrict__ counters, const CasIv *__restrict__ roots, const int32_t *__restrict__ rdepth, u32 nroots,
+                                 u64 *__restrict__ dbest, u32 *__restrict__ dflag, u64 *__restrict__ dceil) {
+    const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        counters[C_NCHILD] = nroots; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = nroots; counters[C_LEVELS] = 0;
+        counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0;
+    }
+    if (i < nroots) {
+        if (dbest) { dbest[i] = 0; dflag[i] = 0; dceil[i] = 0; }
+        iv[i] = roots[i]; best[i] = 0; wmax[i] = 0; depth[i] = rdepth[i];
+        CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
+        res[i] = r;
+    }
+}
+// the root a match / a witness starts in (NONE: between sequences that were not chosen together, or inside an anchor of the chain)
+__global__ __launch_bounds__(TB) void k_cas_assign_roots(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child, u32 M,
+                                                         const sa_t *__restrict__ w_pos, u32 *__restrict__ w_child, u32 NW, const CasIv *__restrict__ roots, CasRootTabs t, int64_t minl) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) {
+        const int64_t pa = (int64_t)c_pa[i], pb = (int64_t)c_pb[i], len = (int64_t)c_len[i];
+        const int ca = cas_contig_of(t.beginA, t.nA, pa), cb = cas_contig_of(t.beginB, t.nB, pb);
+        u32 c = NONE;
+        if (ca >= 0 && cb >= 0 && t.pickA[ca] >= 0 && t.pickA[ca] == t.pickB[cb]) {
+            const u32 k = (u32)t.pickA[ca];
+            int64_t qa, qb, ql;
+            if (t.rootLead[k] != NONE && cas_cut(roots[t.rootLead[k]], pa, pb, len, minl, &qa, &qb, &ql)) c = t.rootLead[k];
+            else if (t.rootTrail[k] != NONE && cas_cut(roots[t.rootTrail[k]], pa, pb, len, minl, &qa, &qb, &ql)) c = t.rootTrail[k];
+        }
+        c_child[i] = c;
+    }
+    if (i < NW) {
+        const int64_t pos = (int64_t)w_pos[i];
+        const bool a_side = t.nB == 0 || pos < (int64_t)t.beginB[0];
+        const int ct = a_side ? cas_contig_of(t.beginA, t.nA, pos) : cas_contig_of(t.beginB, t.nB, pos);
+        u32 c = NONE;
+        if (ct >= 0) {
+            const int32_t k = a_side ? t.pickA[ct] : t.pickB[ct];
+            if (k >= 0) {
+                for (int which = 0; which < 2 && c == NONE; which++) {
+                    const u32 r = which ? t.rootTrail[k] : t.rootLead[k];
+                    if (r == NONE) continue;
+                    const CasIv p = roots[r];
+                    if ((pos >= (int64_t)p.a0 && pos < (int64_t)p.a1) || (pos >= (int64_t)p.b0 && pos < (int64_t)p.b1)) c = r;
+                }
+            }
+        }
+        w_child[i] = c;
+    }
+}
+__global__ void k_cas_lineage_stats(unsigned long long *__restrict__ stats, unsigned long long steps, unsigned long long maxdepth) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) { atomicAdd(&stats[0], steps); atomicMax(&stats[3], maxdepth); }
+}
+// matches in the picker's order: longest first, ties to the smallest first coordinate
+__global__ __launch_bounds__(TB) void k_cas_lkeys(const sa_t *__restrict__ c_pa, const u32 *__restrict__ c_len, u32 M, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) { keys[i] = (((1ull << (64 - KEY_SHIFT)) - 1ull - (u64)c_len[i]) << KEY_SHIFT) | (u64)c_pa[i]; vals[i] = i; }
+}
+__global__ __launch_bounds__(TB) void k_cas_lgather(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, const u32 *__restrict__ perm, u32 M,
+                                                    sa_t *__restrict__ o_pa, sa_t *__restrict__ o_pb, u32 *__restrict__ o_len) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) { const u32 f = perm[i]; o_pa[i] = c_pa[f]; o_pb[i] = c_pb[f]; o_len[i] = c_len[f]; }
+}
+
 // ---- one level ----
 __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child,
                                                    u32 M, const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
@@ -616,7 +696,8 @@ __global__ __launch_bounds__(TB) void k_cas_rank(const RvLeafRoot *__restrict__ 
     ord[root.off + cnt] = (uint16_t)i;
 }
 __global__ __launch_bounds__(TB) void k_cas_emit(const RvLeafRoot *__restrict__ roots, const uint8_t *__restrict__ T0, const uint16_t *__restrict__ ord, sa_t *__restrict__ SA,
-                                                 lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0, int64_t root_a0, int64_t root_b0) {
+                                                 lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0, int64_t root_a0, int64_t root_b0,
+                                                 const sa_t *__restrict__ beginA, u32 nA, const sa_t *__restrict__ beginB, u32 nB) {
     __shared__ uint8_t txt[BN + 8];
     const RvLeafRoot root = roots[blockIdx.x];
     const int la = (int)(root.a1 - root.a0), lb = (int)(root.b1 - root.b0), n = la + lb;
@@ -639,7 +720,13 @@ __global__ __launch_bounds__(TB) void k_cas_emit(const RvLeafRoot *__restrict__ 
     const int64_t gp = i < la ? root.a0 + i : root.b0 + (i - la);
     uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
     // the first suffix of an interval that starts behind an anchor: that anchor's last base has been lower-cased (reveal.c:1230-1234)
-    const bool behind_anchor = i < la ? (i == 0 && root.a0 > root_a0) : (i == la && root.b0 > root_b0);
+    // (several sequences per sample: an interval that does not start where its sequence starts begins behind an anchor)
+    bool at_seq_start;
+    if (beginA) {
+        const int c = i < la ? cas_contig_of(beginA, nA, (int64_t)root.a0) : cas_contig_of(beginB, nB, (int64_t)root.b0);
+        at_seq_start = i < la ? (c >= 0 && (int64_t)beginA[c] == (int64_t)root.a0) : (c >= 0 && (int64_t)beginB[c] == (int64_t)root.b0);
+    } else at_seq_start = i < la ? !(root.a0 > root_a0) : !(root.b0 > root_b0);
+    const bool behind_anchor = (i < la ? i == 0 : i == la) && !at_seq_start;
     if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
     const int64_t o = root.off + r;
     SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
@@ -649,6 +736,123 @@ int bitlen64(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 double cas_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 }  // namespace
+
+// the chain of rest sub-indices, decided on the host (see "the lineage of rest sub-indices" above).  -> 0 and *why == nullptr: roots,
+// tables and the chain's anchors are in cb.d[30..33]; *why != nullptr: the chain holds a member the list does not decide
+static int cas_lineage(rv_index *h, RvCascadeBufs &cb, u32 M, u32 NW, u32 minl, const std::vector<RvIntv> &CA, const std::vector<RvIntv> &CB, const char **why) {
+    Workspace &ws = h->ws;
+    hipStream_t q = ws.stream;
+    *why = nullptr;
+    DBuf &k0 = cb.d[0], &k1 = cb.d[1], &v0 = cb.d[2], &v1 = cb.d[3], &bpa = cb.d[4], &bpb = cb.d[5], &blen = cb.d[6], &bwp = cb.d[8], &bwv = cb.d[9];
+    DBuf &spa = cb.d[27], &spb = cb.d[28], &slen = cb.d[29], &broots = cb.d[30], &bdepth = cb.d[31], &btabs = cb.d[32], &banch = cb.d[33];
+    // ---- the matches in the picker's order, and the witnesses, to the host
+    RV_TRY(spa.reserve((size_t)M * sizeof(sa_t))); RV_TRY(spb.reserve((size_t)M * sizeof(sa_t))); RV_TRY(slen.reserve((size_t)M * 4));
+    const unsigned mb = (unsigned)ceil_div((int64_t)M, TB);
+    hipLaunchKernelGGL(k_cas_lkeys, dim3(mb), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const u32 *)blen.as<u32>(), M, k0.as<u64>(), v0.as<u32>());
+    RV_LAUNCH_CHECK();
+    int in1 = 0;
+    RV_TRY(rv_radix_sort_pairs<u32>(ws, k0.as<u64>(), v0.as<u32>(), k1.as<u64>(), v1.as<u32>(), (int64_t)M, 0, 64, &in1));
+    hipLaunchKernelGGL(k_cas_lgather, dim3(mb), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(),
+                       (const u32 *)(in1 ? v1.as<u32>() : v0.as<u32>()), M, spa.as<sa_t>(), spb.as<sa_t>(), slen.as<u32>());
+    RV_LAUNCH_CHECK();
+    std::vector<sa_t> ha(M), hb(M), hwp(NW);
+    std::vector<u32> hl(M), hwv(NW);
+    RV_HIP(hipMemcpyAsync(ha.data(), spa.p, (size_t)M * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+    RV_HIP(hipMemcpyAsync(hb.data(), spb.p, (size_t)M * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+    RV_HIP(hipMemcpyAsync(hl.data(), slen.p, (size_t)M * 4, hipMemcpyDeviceToHost, q));
+    if (NW) {
+        RV_HIP(hipMemcpyAsync(hwp.data(), bwp.p, (size_t)NW * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(hwv.data(), bwv.p, (size_t)NW * 4, hipMemcpyDeviceToHost, q));
+    }
+    RV_HIP(hipStreamSynchronize(q));
+    const size_t nA = CA.size(), nB = CB.size();
+    auto contig = [](const std::vector<RvIntv> &C, int64_t pos) -> int {
+        size_t lo = 0, hi = C.size();
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (C[mid].begin <= pos) lo = mid + 1; else hi = mid; }
+        return (int)lo - 1;
+    };
+    // W over every sequence; the chain's bound = the largest among the sequences still in it
+    std::vector<u32> wA(nA, 0), wB(nB, 0);
+    const int64_t firstB = CB[0].begin;
+    for (u32 i = 0; i < NW; i++) {
+        const int64_t pos = (int64_t)hwp[i];
+        if (pos < firstB) { const int c = contig(CA, pos); if (c >= 0 && pos < CA[(size_t)c].end) wA[(size_t)c] = std::max(wA[(size_t)c], hwv[i]); }
+        else { const int c = contig(CB, pos); if (c >= 0 && pos < CB[(size_t)c].end) wB[(size_t)c] = std::max(wB[(size_t)c], hwv[i]); }
+    }
+    struct Ent { u32 w; int side; u32 c; };
+    std::vector<Ent> byw;
+    for (size_t c = 0; c < nA; c++) byw.push_back({wA[c], 0, (u32)c});
+    for (size_t c = 0; c < nB; c++) byw.push_back({wB[c], 1, (u32)c});
+    std::sort(byw.begin(), byw.end(), [](const Ent &x, const Ent &y) { return x.w > y.w; });
+    std::vector<uint8_t> liveA(nA, 1), liveB(nB, 1);
+    size_t wptr = 0, nLiveA = nA, nLiveB = nB;
+    auto chain_wmax = [&]() -> u32 {
+        while (wptr < byw.size() && !(byw[wptr].side ? liveB[byw[wptr].c] : liveA[byw[wptr].c])) wptr++;
+        return wptr < byw.size() ? byw[wptr].w : 0u;
+    };
+    std::vector<CasIv> roots; std::vector<int32_t> rdepth;
+    std::vector<int32_t> pickA(nA, -1), pickB(nB, -1);
+    std::vector<u32> rootLead, rootTrail, anl; std::vector<int64_t> anp;
+    int32_t depth = 0;
+    for (u32 i = 0; i < M && nLiveA && nLiveB; i++) {
+        const u32 l = hl[i];
+        if (l < minl) break;
+        const int64_t a = (int64_t)ha[i], b = (int64_t)hb[i];
+        const int ca = contig(CA, a), cb2 = contig(CB, b);
+        if (ca < 0 || cb2 < 0 || !liveA[(size_t)ca] || !liveB[(size_t)cb2]) continue;
+        if (a + (int64_t)l > CA[(size_t)ca].end || b + (int64_t)l > CB[(size_t)cb2].end) { *why = "a match that leaves its sequence"; return 0; }
+        if (l <= chain_wmax()) { *why = "a repeat as long as the best match between the sequences that are left"; return 0; }
+        const u32 k = (u32)anl.size();
+        anl.push_back(l); anp.push_back(a); anp.push_back(b);
+        pickA[(size_t)ca] = (int32_t)k; pickB[(size_t)cb2] = (int32_t)k;
+        u32 rl = NONE, rt = NONE;
+        if ((a - CA[(size_t)ca].begin) + (b - CB[(size_t)cb2].begin) > 0) {
+            CasIv c; c.a0 = (sa_t)CA[(size_t)ca].begin; c.a1 = (sa_t)a; c.b0 = (sa_t)CB[(size_t)cb2].begin; c.b1 = (sa_t)b;
+            rl = (u32)roots.size(); roots.push_back(c); rdepth.push_back(depth + 1);
+        }
+        if ((CA[(size_t)ca].end - a - (int64_t)l) + (CB[(size_t)cb2].end - b - (int64_t)l) > 0) {
+            CasIv c; c.a0 = (sa_t)(a + (int64_t)l); c.a1 = (sa_t)CA[(size_t)ca].end; c.b0 = (sa_t)(b + (int64_t)l); c.b1 = (sa_t)CB[(size_t)cb2].end;
+            rt = (u32)roots.size(); roots.push_back(c); rdepth.push_back(depth + 1);
+        }
+        rootLead.push_back(rl); rootTrail.push_back(rt);
+        liveA[(size_t)ca] = 0; liveB[(size_t)cb2] = 0; nLiveA--; nLiveB--;
+        depth++;
+    }
+    if (anl.empty()) { *why = "no match between two sequences at the top level"; return 0; }
+    // the last member of the chain (what no choice touched): visited once more if anything is left; with both samples in it, it must provably hold no match
+    int64_t steps = (int64_t)anl.size();
+    int maxdepth = depth - 1;
+    if (nLiveA + nLiveB > 0) {
+        if (nLiveA && nLiveB && chain_wmax() >= minl) { *why = "sequences without a match between them that hold a repeat of minl characters"; return 0; }
+        steps++; maxdepth = depth;
+    }
+    // ---- to the device: the roots, the look-up tables of k_cas_assign_roots, the chain's anchors
+    const u32 R = (u32)roots.size(), P = (u32)anl.size();
+    RV_TRY(broots.reserve((size_t)std::max<u32>(R, 1) * sizeof(CasIv))); RV_TRY(bdepth.reserve((size_t)std::max<u32>(R, 1) * 4));
+    const size_t tab_bytes = (nA + nB) * (sizeof(sa_t) + 4) + (size_t)P * 8 + 64;
+    RV_TRY(btabs.reserve(tab_bytes + 64)); RV_TRY(banch.reserve((size_t)P * (4 + 16) + 64));
+    std::vector<uint8_t> stage(tab_bytes + 64, 0);
+    size_t o = 0;
+    auto put = [&](const void *src, size_t bytes) { memcpy(stage.data() + o, src, bytes); const size_t at = o; o += (bytes + 15) / 16 * 16; return at; };
+    std::vector<sa_t> bA(nA), bB(nB);
+    for (size_t c = 0; c < nA; c++) bA[c] = (sa_t)CA[c].begin;
+    for (size_t c = 0; c < nB; c++) bB[c] = (sa_t)CB[c].begin;
+    stage.resize((nA + nB) * (sizeof(sa_t) + 4) + (size_t)P * 8 + 16 * 8 + 64);
+    const size_t oA = put(bA.data(), nA * sizeof(sa_t)), oB = put(bB.data(), nB * sizeof(sa_t)), opA = put(pickA.data(), nA * 4), opB = put(pickB.data(), nB * 4),
+                 oL = put(rootLead.data(), (size_t)P * 4), oT = put(rootTrail.data(), (size_t)P * 4);
+    RV_TRY(btabs.reserve(o + 64));
+    RV_HIP(hipMemcpyAsync(btabs.p, stage.data(), o, hipMemcpyHostToDevice, q));
+    if (R) {
+        RV_HIP(hipMemcpyAsync(broots.p, roots.data(), (size_t)R * sizeof(CasIv), hipMemcpyHostToDevice, q));
+        RV_HIP(hipMemcpyAsync(bdepth.p, rdepth.data(), (size_t)R * 4, hipMemcpyHostToDevice, q));
+    }
+    RV_HIP(hipMemcpyAsync(banch.p, anp.data(), (size_t)P * 16, hipMemcpyHostToDevice, q));
+    RV_HIP(hipMemcpyAsync((uint8_t *)banch.p + (size_t)P * 16, anl.data(), (size_t)P * 4, hipMemcpyHostToDevice, q));
+    RV_HIP(hipStreamSynchronize(q));      // (the vectors above live on this stack frame)
+    cb.lin_roots = R; cb.lin_picks = P; cb.lin_nA = (u32)nA; cb.lin_nB = (u32)nB; cb.lin_steps = steps; cb.lin_maxdepth = maxdepth;
+    cb.lin_off[0] = oA; cb.lin_off[1] = oB; cb.lin_off[2] = opA; cb.lin_off[3] = opB; cb.lin_off[4] = oL; cb.lin_off[5] = oT;
+    return 0;
+}
 
 int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int minl_in, RvCascadeOut *out, int danger, int reuse) {
     memset(out, 0, sizeof *out);
@@ -661,16 +865,21 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     double tp[6] = {0, 0, 0, 0, 0, 0};
     if (verbose) { (void)hipStreamSynchronize(q); tp[0] = cas_now(); }
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade: gave up: %s\n", msg); return 0; } while (0)
-    if (h->nsamples != 2 || h->nodes.size() != 2 || h->nsep.size() != 1) GIVE_UP("not two samples with one sequence each");
+    if (h->nsamples != 2 || h->nsep.size() != 1 || h->nodes.size() < 2) GIVE_UP("not two samples");
+    // the sequences of the two samples (empty ones hold no suffix)
+    std::vector<RvIntv> CA, CB;
+    for (const RvIntv &v : h->nodes) if (v.end > v.begin) (v.begin < h->nsep[0] ? CA : CB).push_back(v);
+    std::sort(CA.begin(), CA.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
+    std::sort(CB.begin(), CB.end(), [](const RvIntv &x, const RvIntv &y) { return x.begin < y.begin; });
+    if (CA.empty() || CB.empty()) GIVE_UP("an empty sample");
+    const bool chain = CA.size() > 1 || CB.size() > 1;      // several sequences in a sample: the lineage of rest sub-indices first
+    if (chain && ws.opt.no_cascade_chain) GIVE_UP("several sequences per sample (switched off)");
     if (n >= ((int64_t)1 << 32) - 2) GIVE_UP("index above 2^32 positions");
 #ifdef RV_SA64
     if ((u64)h->maxlcp >= (1ull << 24) || n >= ((int64_t)1 << 40)) GIVE_UP("bid word too narrow");
 #endif
     CasIv root; root.a0 = root.a1 = root.b0 = root.b1 = 0;
-    for (const RvIntv &v : h->nodes) {
-        if (v.begin < h->nsep[0]) { root.a0 = (sa_t)v.begin; root.a1 = (sa_t)v.end; }
-        else { root.b0 = (sa_t)v.begin; root.b1 = (sa_t)v.end; }
-    }
+    root.a0 = (sa_t)CA[0].begin; root.a1 = (sa_t)CA[0].end; root.b0 = (sa_t)CB[0].begin; root.b1 = (sa_t)CB[0].end;
     if (root.a0 >= root.a1 || root.b0 >= root.b1 || (int64_t)root.a1 > h->nsep[0] || (int64_t)root.b0 <= h->nsep[0]) GIVE_UP("an empty sample");
 
     const sa_t *SA = h->dSA.as<sa_t>(); const lcp_t *LCP = h->dLCP.as<lcp_t>(); const uint8_t *BWT = h->dBWT.as<uint8_t>();
@@ -765,7 +974,13 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
             RV_LAUNCH_CHECK();
         }
         cb.NW = NW;
+        if (chain) {
+            const char *why = nullptr;
+            RV_TRY(cas_lineage(h, cb, M, NW, minl, CA, CB, &why));
+            if (why) { cb.lin_picks = 0; GIVE_UP(why); }
+        }
     } else {
+        if (chain && cb.lin_picks == 0) GIVE_UP("the chain of rest sub-indices was not decided");
         RV_HIP(hipMemsetAsync(bcc.p, 0, (size_t)M * 4, q));      // every match starts in the root again
         out->witnesses = NW;
     }
@@ -796,9 +1011,32 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         // sits inside a repeat (RV_CASCADE_DANGER_MIN: only sub-indices above that size)
         dg.leaf_n = (u32)ws.opt.cascade_danger_min;
     }
-    hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
-                       bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag, dg.ceil);
-    RV_LAUNCH_CHECK();
+    const sa_t *d_beginA = nullptr, *d_beginB = nullptr;
+    if (!chain) {
+        hipLaunchKernelGGL(k_cas_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
+                           bdep.as<int32_t>(), bres.as<CasRes>(), counters, root, bwc.as<u32>(), NW, dg.best, dg.flag, dg.ceil);
+        RV_LAUNCH_CHECK();
+    } else {
+        // the roots are the leading / trailing children of the chain's choices; its anchors go in front of the device's
+        const u32 R = cb.lin_roots, P = cb.lin_picks;
+        if ((int64_t)R + 16 > (int64_t)ccap || P > io.anchor_cap) GIVE_UP("more sequences than the cascade's tables hold");
+        const uint8_t *tb = cb.d[32].as<uint8_t>();
+        CasRootTabs rt;
+        rt.beginA = (const sa_t *)(tb + cb.lin_off[0]); rt.beginB = (const sa_t *)(tb + cb.lin_off[1]);
+        rt.pickA = (const int32_t *)(tb + cb.lin_off[2]); rt.pickB = (const int32_t *)(tb + cb.lin_off[3]);
+        rt.rootLead = (const u32 *)(tb + cb.lin_off[4]); rt.rootTrail = (const u32 *)(tb + cb.lin_off[5]);
+        rt.nA = cb.lin_nA; rt.nB = cb.lin_nB;
+        d_beginA = rt.beginA; d_beginB = rt.beginB;
+        hipLaunchKernelGGL(k_cas_init_roots, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)R, TB))), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(),
+                           bdep.as<int32_t>(), bres.as<CasRes>(), counters, (const CasIv *)cb.d[30].as<CasIv>(), (const int32_t *)cb.d[31].as<int32_t>(), R, dg.best, dg.flag, dg.ceil);
+        RV_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_cas_assign_roots, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)std::max(M, NW), TB))), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(),
+                           (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M, wp, bwc.as<u32>(), NW, (const CasIv *)cb.d[30].as<CasIv>(), rt, (int64_t)minl);
+        RV_LAUNCH_CHECK();
+        RV_HIP(hipMemcpyAsync(io.anchor_pos, cb.d[33].p, (size_t)P * 16, hipMemcpyDeviceToDevice, q));
+        RV_HIP(hipMemcpyAsync(io.anchor_l, (const uint8_t *)cb.d[33].p + (size_t)P * 16, (size_t)P * 4, hipMemcpyDeviceToDevice, q));
+        RV_HIP(hipMemcpyAsync(io.anchor_count, &cb.lin_picks, 4, hipMemcpyHostToDevice, q));
+    }
 
     if (verbose) { (void)hipStreamSynchronize(q); tp[2] = cas_now(); }
     // ---- the levels: queued in batches, the level's range of sub-indices lives on the device (k_cas_advance), the host only looks
@@ -852,6 +1090,10 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     }
     hipLaunchKernelGGL(k_cas_stats, dim3(256), dim3(TB), 0, q, (const u32 *)counters, (const int32_t *)bdep.as<int32_t>(), io);
     RV_LAUNCH_CHECK();
+    if (chain) {      // the members of the chain were visited on the host
+        hipLaunchKernelGGL(k_cas_lineage_stats, dim3(1), dim3(64), 0, q, io.stats, (unsigned long long)cb.lin_steps, (unsigned long long)cb.lin_maxdepth);
+        RV_LAUNCH_CHECK();
+    }
     if (U > 0) {
         RV_TRY(bsz.reserve((size_t)(U + 1) * 8));
         u64 *sizes = bsz.as<u64>();
@@ -872,7 +1114,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         hipLaunchKernelGGL(k_cas_rank, dim3(U, BN / TB), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), bord.as<uint16_t>());
         RV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_cas_emit, dim3(U, BN / TB), dim3(TB), 0, q, (const RvLeafRoot *)roots, (const uint8_t *)h->dT0.as<uint8_t>(), (const uint16_t *)bord.as<uint16_t>(),
-                           io.lvSA->as<sa_t>(), io.lvLCP->as<lcp_t>(), io.lvBWT->as<uint8_t>(), h->nsep[0], (int64_t)root.a0, (int64_t)root.b0);
+                           io.lvSA->as<sa_t>(), io.lvLCP->as<lcp_t>(), io.lvBWT->as<uint8_t>(), h->nsep[0], (int64_t)root.a0, (int64_t)root.b0,
+                           d_beginA, cb.lin_nA, d_beginB, cb.lin_nB);
         RV_LAUNCH_CHECK();
         RvLeafArgs la;
         la.roots = roots;

@@ -88,7 +88,8 @@ void rv_set_error(const char *fmt, ...);
     X(rs_bits, "RV_RS_BITS", 8) \
     X(rs_xcd, "RV_RS_XCD", 1) \
     X(rs_cnt16, "RV_RS_CNT16", 1) \
-    X(diag_table, "RV_DIAG_TABLE", -1)
+    X(diag_table, "RV_DIAG_TABLE", -1) \
+    X(no_cascade_chain, "RV_NO_CASCADE_CHAIN", 0)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)

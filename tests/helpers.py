@@ -26,7 +26,9 @@ def assemble(inputs, toupper=True):
     for k, f in enumerate(inputs):
         if k > 0:
             nsep.append(len(T) - 1)
-        if isinstance(f, str) and os.path.exists(f):
+        if isinstance(f, (list, tuple)):                       # one sample given as its sequences (a multi-contig FASTA without the file)
+            seqs = [c.decode() if isinstance(c, (bytes, bytearray)) else c for c in f]
+        elif isinstance(f, str) and os.path.exists(f):
             seqs = [s for _, s in rem.fasta_reader(f, toupper=toupper)]
         else:
             seqs = [f.decode() if isinstance(f, (bytes, bytearray)) else f]
@@ -45,7 +47,11 @@ def oracle(sa64=False):
 def feed(idx, inputs, toupper=True):
     """same protocol, into an index object"""
     for k, f in enumerate(inputs):
-        if isinstance(f, str) and os.path.exists(f):
+        if isinstance(f, (list, tuple)):
+            idx.addsample("s%d" % k)
+            for c in f:
+                idx.addsequence(c)
+        elif isinstance(f, str) and os.path.exists(f):
             rem.read_fasta(f, idx, toupper=toupper)
         else:
             idx.addsample("s%d" % k)

@@ -273,3 +273,57 @@ def test_witness_decisions_on_random_inputs(monkeypatch):
             continue
         solved += check(seqs, minl)["decided_from_witnesses"]
     assert solved > 0
+
+
+def _write_fasta(path, contigs):
+    with open(path, "w") as f:
+        for k, s in enumerate(contigs):
+            f.write(">c%d\n%s\n" % (k, s))
+    return str(path)
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_cascade_with_several_sequences_per_sample(tmp_path, monkeypatch, sa64):
+    """draft assemblies: a sample is a FASTA file of several contigs (one '$' each, utils.py:325-350).  The sub-indices with more than one
+    interval per sample form the chain root -> rest -> rest ..., decided on the host from the match list; their leading / trailing
+    children are the roots of the device cascade (rv_cascade.hip "the lineage of rest sub-indices").  Anchors, text and counters equal
+    the oracle's literal recursion: contigs cut at different places in the two samples, in another order, contigs without a partner,
+    contigs shorter than minl, one sample in one piece; and an input whose left-over contigs share a repeat (the chain gives up)"""
+    rng = random.Random(17)
+
+    def rnd(L):
+        return "".join(rng.choice("ACGT") for _ in range(L))
+
+    def snp(s, rate):
+        a = list(s)
+        for p in range(len(a)):
+            if rng.random() < rate:
+                a[p] = rng.choice("ACGT")
+        return "".join(a)
+
+    def cut(s, k):
+        at = sorted(rng.sample(range(200, len(s) - 200), k - 1))
+        return [s[i:j] for i, j in zip([0] + at, at + [len(s)])]
+    base = rnd(240000)
+    var = snp(base, 0.01)
+    rep = rnd(90)
+    cases = []
+    c1, c2 = cut(base, 5), cut(var, 6)
+    rng.shuffle(c2)
+    cases.append(("cut differently, shuffled", c1, c2, True))
+    cases.append(("one piece against seven", [base], cut(var, 7), True))
+    cases.append(("unrelated extra contigs", cut(base, 3) + [rnd(5000)], [rnd(7000)] + cut(var, 4), True))
+    cases.append(("tiny contigs", cut(base, 3) + ["ACGTACGT", "A"], ["ACG"] + cut(var, 3) + ["TTGACA"], True))
+    cases.append(("left-over contigs share a repeat", cut(base, 2) + [rnd(3000) + rep + rnd(2000)], cut(var, 2) + [rnd(1000) + rep + rnd(4000)], None))
+    done = 0
+    for k, (what, a, b, want) in enumerate(cases):
+        inputs = [_write_fasta(tmp_path / ("a%d.fa" % k), a), _write_fasta(tmp_path / ("b%d.fa" % k), b)]
+        info = check(inputs, 20, sa64, want_done=want)
+        done += bool(info["done"])
+        if want:
+            assert info["subindices"] > 100, (what, info)
+    assert done >= 4
+    # the same through the level pipeline (what these inputs took before): identical by the same checks
+    monkeypatch.setenv("RV_NO_CASCADE_CHAIN", "1")
+    inputs = [_write_fasta(tmp_path / "a.fa", c1), _write_fasta(tmp_path / "b.fa", c2)]
+    assert not check(inputs, 20, sa64)["done"]

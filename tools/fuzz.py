@@ -75,6 +75,23 @@ def make_case(rng):
     return seqs, rng.choice([10, 20, 20, 30])
 
 
+def maybe_contigs(rng, seqs):
+    """draft assemblies: with two samples, sometimes every sample is cut into contigs (one '$' each, utils.py:325-350), the second one's in
+    another order, now and then with a contig that has no partner"""
+    if len(seqs) != 2 or rng.random() >= 0.35:
+        return seqs
+
+    def cut(s):
+        k = rng.randint(1, 6)
+        at = sorted(rng.sample(range(1, len(s)), min(k - 1, len(s) - 1))) if len(s) > 2 else []
+        return [s[i:j] for i, j in zip([0] + at, at + [len(s)])]
+    a, b = cut(seqs[0]), cut(seqs[1])
+    rng.shuffle(b)
+    if rng.random() < 0.3:
+        a.append("".join(rng.choice("ACGT") for _ in range(rng.randint(1, 3000))))
+    return [a, b]
+
+
 def digest(tr):
     o = np.lexsort((tr["key"], tr["depth"]))
     return {f: tr[f][o].astype(np.uint64) for f in FIELDS}
@@ -124,6 +141,7 @@ def main():
     ncase = 0
     while time.time() < t_end:
         seqs, minl = make_case(rng)
+        seqs = maybe_contigs(rng, seqs)
         sa64 = rng.random() < 0.2
         if ONLY >= 0 and ncase != ONLY:      # replay the generator up to one case (FUZZ_ONLY=<case>)
             for _ in range(2):
@@ -146,7 +164,7 @@ def main():
             for trace in (True, False):
                 idx = feed((reveallib64 if sa64 else reveallib).index(), seqs)
                 idx.construct()
-                tag = "seed %d case %d env %s trace %s sa64 %s (L %d, %d samples, minl %d)" % (seed, ncase, env, trace, sa64, len(seqs[0]), len(seqs), minl)
+                tag = "seed %d case %d env %s trace %s sa64 %s (L %d, %d samples, minl %d)" % (seed, ncase, env, trace, sa64, sum(len(c) for c in seqs[0]) if isinstance(seqs[0], list) else len(seqs[0]), len(seqs), minl)
                 if VERBOSE:
                     print(tag, file=sys.stderr, flush=True)
                 assert np.array_equal(idx.array("SA"), sa_ref), "SA " + tag

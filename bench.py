@@ -49,7 +49,8 @@ def build_index(seqs, sa64=False):
     idx = (reveallib64 if sa64 else reveallib).index()
     for k, s in enumerate(seqs):
         idx.addsample("g%d" % k)
-        idx.addsequence(s)
+        for c in (s if isinstance(s, list) else [s]):      # (a sample may be a list of contigs: one addsequence each, utils.py:325-350)
+            idx.addsequence(c)
     import torch
     idx.upload()               # text resident in HBM before anything is timed (this first copy also pays for the handle's device allocations)
     torch.cuda.synchronize()
@@ -257,6 +258,34 @@ def run_config5(args, rank, local_rank, world, dist, torch):
         print(json.dumps(out))
 
 
+def cut_into_contigs(seqs, k, seed=7):
+    """--contigs K: every genome as K contigs cut at seeded random positions, the second and later samples' contigs in another order
+    (a draft assembly against a draft assembly)"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for j, s in enumerate(seqs):
+        at = np.sort(rng.choice(np.arange(1000, len(s) - 1000), size=k - 1, replace=False)).tolist()
+        parts = [s[a:b] for a, b in zip([0] + at, at + [len(s)])]
+        if j:
+            parts = [parts[i] for i in rng.permutation(len(parts))]
+        out.append(parts)
+    return out
+
+
+def flat(seqs):
+    return [c for s in seqs for c in (s if isinstance(s, list) else [s])]
+
+
+def sample_seps(seqs):
+    """text position of the last '$' of every sample but the last (nsep, interface.c:18-49)"""
+    pos, out = 0, []
+    for s in seqs:
+        pos += sum(len(c) + 1 for c in (s if isinstance(s, list) else [s]))
+        out.append(pos - 1)
+    return out[:-1]
+
+
 def anchor_set(l, off, pos):
     return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
 
@@ -274,6 +303,7 @@ def main():
     ap.add_argument("--indelfrac", type=float, default=0.0,
                     help="variants by the reference's own mutation model (utils/simulate.py:17-77: this fraction of the 1 %% events are indels, "
                          "zipf(1.7) lengths) instead of substitutions only; 0 = SURVEY 8(d)'s generator, the metric's workload")
+    ap.add_argument("--contigs", type=int, default=1, help="every genome as this many contigs (a multi-sequence FASTA per sample); implies --no-cpu --no-extra")
     ap.add_argument("--no-extra", action="store_true", help="skip the companion legs of the default line (level pipeline, indel workload)")
     ap.add_argument("--config", choices=("default", "c5"), default="default",
                     help="c5 = BASELINE config 5's level 0: 100 genomes of 5 Mbp as 20 independent jobs of five, divided over the ranks")
@@ -344,7 +374,10 @@ def main():
         modes = [mode]
     jobs = max(1, args.jobs) if "per-rank" in modes else 1
     seqs = synth.genomes(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0), indelfrac=args.indelfrac)
-    bases = sum(len(s) for s in seqs)
+    if args.contigs > 1:
+        seqs = cut_into_contigs(seqs, args.contigs)
+        args.no_cpu = args.no_extra = True
+    bases = sum(len(s) for s in flat(seqs))
     idx = build_index(seqs, args.sa64)
     upload_ms = idx.upload_ms      # host->device copy of the assembled text (rv_upload), outside every timed region
     # further jobs of this rank: their own inputs (other seeds), handles and streams
@@ -419,8 +452,8 @@ def main():
     # full-size properties of the last timed step's result (reveal_amd/check.py), before the breakdown steps run again
     properties = full_size = None
     if rank == 0 and not args.no_check:
-        T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
-        nsep = np.cumsum([len(s) + 1 for s in seqs])[:-1] - 1
+        T0 = np.frombuffer(b"$".join(flat(seqs)) + b"$", dtype=np.uint8)
+        nsep = np.asarray(sample_seps(seqs), dtype=np.int64)
         if divide:      # (a divided run lower-cases each share on its own rank: rebuild the text from the merged anchors)
             from reveal_amd import shard
             T1 = shard.lower_text(T0, last["anchors"])
@@ -428,12 +461,12 @@ def main():
             T1 = last.pop("T_after", None)
             if T1 is None:
                 T1 = idx.array("T")
-        properties = check.recursion_properties(T0, T1, last["anchors"], nsep, args.minl)
+        properties = check.recursion_properties(T0, T1, last["anchors"], nsep, args.minl, collinear=args.contigs <= 1)
         if divide:
             properties["text"] = "lower-cased text rebuilt from the merged anchors (each rank lower-cases its own share)"
         # the last timed step's anchor set and final text against the CPU path's digests at THIS size (tests/golden/fullsize.json:
         # the reference's divsufsort + the restated recursion, run once in the build container by oracle/gen_fullsize_golden.py)
-        grec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn)
+        grec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn) if args.contigs <= 1 else None
         if grec is not None:
             full_size = check.compare_with_golden(grec, anchors=last["anchors"], T_final=T1)
             full_size["cpu_seconds_at_this_size"] = grec["cpu_seconds"]
@@ -507,7 +540,8 @@ def main():
                                    "bench picker; text resident in HBM before the timed region (host->device copy of the text not timed)"
                                    % (args.genomes, args.L / 1e6, "1% SNP" if not args.indelfrac else
                                       "1%% mutation events of which %g%% indels with zipf(1.7) lengths: the reference simulator's model" % (100 * args.indelfrac),
-                                      "" if divide else "+1000*rank", args.minl, args.minn),
+                                      ("" if divide else "+1000*rank") + ("" if args.contigs <= 1 else "; every genome cut into %d contigs, the later samples' in another order" % args.contigs),
+                                      args.minl, args.minn),
                        "bases_per_gpu": bases * jobs if not divide else bases / world, "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
                        "jobs_per_gpu": jobs, "sharding": sharding},
             # the text's way into HBM, outside the timed region (SURVEY 8(d) asks for it as a sub-timing): the host->device copy of the

@@ -201,6 +201,7 @@ uint32_t rv_maxlcp(const rv_index *h);
  * witnesses, out[4] sub-indices visited, out[5] sub-indices left undecided (rebuilt from their text and handed to the leaf
  * kernel), out[6] ranks rebuilt, out[7] large undecided sub-indices decided from their repeat witnesses (the second attempt) */
 int rv_cascade_info(const rv_index *h, int64_t *out);
+const char *rv_cascade_why(const rv_index *h);      /* why the cascade left the last built-in run to the level pipeline ("": it did the run, or was not tried) */
 /* anchors chosen by the last rv_align_builtin: l[k], members off[k..k+1] -> pos[] (sorted) */
 int64_t rv_anchor_count(rv_index *h, int64_t *members);
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);

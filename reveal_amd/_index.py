@@ -16,6 +16,7 @@ back to the CPU.
 """
 import ctypes
 import os
+import sys
 import numpy as np
 
 from . import _lib
@@ -542,9 +543,17 @@ def make_index_type(sa64, error):
             dll, h = self._dll, self._h
             mem = ctypes.c_int64(0)
             na = dll.rv_anchor_count(h, ctypes.byref(mem))
-            # (filled completely by the library: no zeroing)
-            l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64)
-            pos = np.empty(max(mem.value, 1), dtype=np.int64)
+            # (filled completely by the library: no zeroing.)  The arrays of the previous call are used again when the caller has let go of
+            # them -- nothing else refers to them or to a view of them: 56 MB of fresh pages per call cost 2 x 250 Mbp 1-3 ms of page faults
+            c = self.__dict__.get("_res_bufs")
+            if (c is not None and len(c[0]) >= max(na, 1) and len(c[1]) >= na + 1 and len(c[2]) >= max(mem.value, 1)
+                    and sys.getrefcount(c[0]) == 2 and sys.getrefcount(c[1]) == 2 and sys.getrefcount(c[2]) == 2):
+                l, off, pos = c
+            else:
+                l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64)
+                pos = np.empty(max(mem.value, 1), dtype=np.int64)
+                self.__dict__["_res_bufs"] = (l, off, pos)
+            c = None
             off[0] = 0
             if dll.rv_fetch_anchors(h, l.ctypes.data, off.ctypes.data, pos.ctypes.data) != 0:
                 self._fail()
@@ -556,7 +565,7 @@ def make_index_type(sa64, error):
                     self._fail()
                 tr = tr[:nt]
             stats = {f[0]: getattr(st, f[0]) for f in _lib.RvAlignStats._fields_}
-            return dict(stats=stats, anchors=(l[:na], off, pos[:mem.value]), trace=tr)
+            return dict(stats=stats, anchors=(l[:na], off[:na + 1], pos[:mem.value]), trace=tr)
 
         # ---- one alignment over several devices (include/reveal_amd.h "frontier hand-off"; reveal_amd/shard.py drives it)
         @property
@@ -567,7 +576,8 @@ def make_index_type(sa64, error):
             """what the anchor cascade did in the last align_builtin (rv_cascade_info)"""
             o = np.zeros(8, dtype=np.int64)
             self._dll.rv_cascade_info(self._h, o.ctypes.data)
-            return dict(done=bool(o[0]), levels=int(o[1]), matches=int(o[2]), witnesses=int(o[3]), subindices=int(o[4]), undecided=int(o[5]), rebuilt_ranks=int(o[6]), decided_from_witnesses=int(o[7]))
+            return dict(done=bool(o[0]), levels=int(o[1]), matches=int(o[2]), witnesses=int(o[3]), subindices=int(o[4]), undecided=int(o[5]), rebuilt_ranks=int(o[6]), decided_from_witnesses=int(o[7]),
+                        why=(self._dll.rv_cascade_why(self._h) or b"").decode())
 
         def align_builtin_until(self, stop_subs, minl=20, minn=2, trace=False):
             """align_builtin that stops once the frontier holds >= stop_subs sub-indices.

@@ -81,6 +81,7 @@ SYMBOLS = {
     "rv_frontier_import": (_I, [V, _I, _I, ctypes.c_uint32, _I, _I, V, V, V, _L, V, V, V, _I]),
     "rv_maxlcp": (ctypes.c_uint32, [V]),
     "rv_cascade_info": (ctypes.c_int, [V, V]),
+    "rv_cascade_why": (ctypes.c_char_p, [V]),
     "rv_anchor_count": (_L, [V, c_i64p]),
     "rv_fetch_anchors": (_I, [V, V, V, V]),
     "rv_set_trace": (_I, [V, _I]),

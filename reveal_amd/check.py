@@ -20,7 +20,7 @@ def _upper(t):
     return np.where((t >= 97) & (t <= 122), t - 32, t).astype(np.uint8)
 
 
-def recursion_properties(T0, T1, anchors, nsep, minl, chunk=1 << 25):
+def recursion_properties(T0, T1, anchors, nsep, minl, chunk=1 << 25, collinear=True):
     """T0 / T1: uint8 arrays (or bytes) of the text before / after align; anchors = (l, off, pos) as align_builtin
     returns them; nsep = separator positions (sample boundaries).  -> dict of booleans + counts"""
     T0 = np.frombuffer(T0, dtype=np.uint8) if isinstance(T0, (bytes, bytearray)) else np.asarray(T0, dtype=np.uint8)
@@ -70,7 +70,7 @@ def recursion_properties(T0, T1, anchors, nsep, minl, chunk=1 << 25):
     # collinearity over the anchors present in every sample
     ns = len(seps) + 1
     full = cnt == ns
-    if full.any():
+    if full.any() and collinear:      # (samples of several sequences in different orders are collinear per pair of sequences only: not asserted)
         m = pos[(off[:-1][full][:, None] + np.arange(ns)[None, :]).ravel()].reshape(-1, ns)
         order = np.argsort(m[:, 0], kind="stable")
         out["anchors_collinear"] = bool((np.diff(m[order], axis=0) > 0).all())

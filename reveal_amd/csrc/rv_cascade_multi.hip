@@ -87,30 +87,63 @@ constexpr int MS_TILE = TB * MS_ITEMS;
 constexpr int CM_REGIONS = 64;
 __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, const uint8_t *__restrict__ so,
                                                   int64_t n, int k, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap /* per region */, u32 *__restrict__ region_cnt) {
-    __shared__ u32 sl[MS_TILE + RV_CASM_K + 1];          // LCP of ranks u0-(k-1) .. u0+TILE (0 outside the array)
-    __shared__ uint8_t ss[MS_TILE + RV_CASM_K], sb[MS_TILE + RV_CASM_K];
+    __shared__ __attribute__((aligned(16))) u32 sl[MS_TILE + RV_CASM_K + 16];          // LCP of ranks u0-HS .. u0+TILE (0 outside the array); HS = the halo rounded up to 16
+    __shared__ __attribute__((aligned(16))) uint8_t ss[MS_TILE + RV_CASM_K + 16], sb[MS_TILE + RV_CASM_K + 16];
+    __shared__ uint16_t cand[MS_TILE];
+    __shared__ u32 ncand;
     const int64_t u0 = (int64_t)blockIdx.x * MS_TILE;
     const int H = k - 1;
-    for (int x = threadIdx.x; x < MS_TILE + H + 1; x += TB) { const int64_t j = u0 - H + x; sl[x] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
-    for (int x = threadIdx.x; x < MS_TILE + H; x += TB) {
-        const int64_t j = u0 - H + x;
-        const bool in = j >= 0 && j < n;
-        ss[x] = in ? so[j] : (uint8_t)0; sb[x] = in ? (uint8_t)(BWT[j] & RV_BWT_CHAR) : (uint8_t)0;
+    constexpr int HS = 16;                       // staged ranks in front of the tile (>= RV_CASM_K - 1, a multiple of the 16-byte loads)
+    static_assert(RV_CASM_K - 1 <= HS && MS_TILE % 16 == 0, "halo");
+    if (threadIdx.x == 0) ncand = 0;
+    if (u0 >= HS && u0 + MS_TILE + 1 <= n && sizeof(lcp_t) == 4) {
+        // the tile with its halo in 16-byte loads (ranks u0 - 16 .. u0 + TILE), the one rank behind it on its own
+        const uint4 *L4 = reinterpret_cast<const uint4 *>(LCP + (u0 - HS));
+        for (int x = threadIdx.x; x < (MS_TILE + HS) / 4; x += TB) reinterpret_cast<uint4 *>(sl)[x] = L4[x];
+        const uint4 *S4 = reinterpret_cast<const uint4 *>(so + (u0 - HS)), *B4 = reinterpret_cast<const uint4 *>(BWT + (u0 - HS));
+        for (int x = threadIdx.x; x < (MS_TILE + HS) / 16; x += TB) {
+            reinterpret_cast<uint4 *>(ss)[x] = S4[x];
+            uint4 v = B4[x];
+            v.x &= 0x7f7f7f7fu; v.y &= 0x7f7f7f7fu; v.z &= 0x7f7f7f7fu; v.w &= 0x7f7f7f7fu;      // (RV_BWT_CHAR: the side bit off)
+            reinterpret_cast<uint4 *>(sb)[x] = v;
+        }
+        if (threadIdx.x == 0) sl[MS_TILE + HS] = (u32)LCP[u0 + MS_TILE];
+    } else {
+        for (int x = threadIdx.x; x < MS_TILE + HS + 1; x += TB) { const int64_t j = u0 - HS + x; sl[x] = (j >= 0 && j < n) ? (u32)LCP[j] : 0u; }
+        for (int x = threadIdx.x; x < MS_TILE + HS; x += TB) {
+            const int64_t j = u0 - HS + x;
+            const bool in = j >= 0 && j < n;
+            ss[x] = in ? so[j] : (uint8_t)0; sb[x] = in ? (uint8_t)(BWT[j] & RV_BWT_CHAR) : (uint8_t)0;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-#pragma unroll 1
+    // the ranks where an interval can end at all (a value of minl or more, larger than the next one): one in k for related samples.  Every rank
+    // walking its window made a wave run the long path for its few lanes that needed it; the candidates are listed in LDS and walked densely
+#pragma unroll
     for (int r = 0; r < MS_ITEMS; r++) {
-        const int x = r * TB + threadIdx.x + H;              // index of rank u in the staged arrays
-        const int64_t u = u0 + r * TB + threadIdx.x;
-        const int64_t lb = u - H;
-        bool ok = u < n && lb >= 0;
+        const int t = r * TB + threadIdx.x;
+        const int x = t + HS;
+        const int64_t u = u0 + t;
+        const bool c = u < n && u - H >= 0 && sl[x] >= minl && sl[x] > sl[x + 1];
+        const u64 bal = __ballot(c);
+        u32 base = 0;
+        if (lane == 0 && bal) base = atomicAdd(&ncand, (u32)__popcll(bal));
+        base = (u32)__shfl((int)base, 0, 64);
+        if (c) cand[base + (u32)__popcll(bal & lt)] = (uint16_t)t;
+    }
+    __syncthreads();
+    const u32 nc = ncand;
+    for (u32 ci = threadIdx.x; ci < ((nc + 63u) & ~63u); ci += TB) {      // (whole waves: the ballot below)
+        bool ok = ci < nc;
+        const int t = ok ? (int)cand[ci] : 0;
+        const int x = t + HS;
+        const int64_t u = u0 + t;
         u32 v = 0;
         if (ok) {
             v = sl[x];
             const u32 nxt = sl[x + 1];
-            ok = v >= minl && v > nxt;
             for (int d = 1; d < H && ok; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; ok = v >= minl && v > nxt; }
             ok = ok && sl[x - H] < v;
             if (ok) {

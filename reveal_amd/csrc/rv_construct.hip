@@ -468,7 +468,7 @@ constexpr int HINT_K = 16;      // samples the diagonal hint knows (the first on
 // D: diagonal of the second sample against the first (nsep[0] + 1).  ns / sep / Ds: samples, their separators and every sample's
 // diagonal against the FIRST sample (Ds[s] = nsep[s-1] + 1, where sample s starts when every sample is one sequence)
 struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[5], pmagic[5]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K];
-                   const int32_t *dtab; };      // dtab != NULL: two samples on piecewise diagonals (k_diag_bits_tab): partner(y) = y +- (D + dtab[y >> 6])      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+                   const int32_t *dtab; u32 pw32[3], pm32[3]; int narrow; };      // pw32 / pm32: radix^4, ^2, ^1 and their 32-bit reciprocals (narrow: radix^8 < 2^31, key_common_digits' last steps)      // dtab != NULL: two samples on piecewise diagonals (k_diag_bits_tab): partner(y) = y +- (D + dtab[y >> 6])      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
 __device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
     const u32 none = (1u << kd.ly.at_bits) - 1u;
@@ -488,6 +488,7 @@ __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
     u32 cnt = 0;
 #pragma unroll
     for (int st = 0; st < 5; st++) {
+        if (st == 2 && kd.narrow) break;
         const u64 d = kd.pw[st], mg = kd.pmagic[st];
         u64 qx = __umul64hi(x, mg), qy = __umul64hi(y, mg);
         u64 rx = x - qx * d, ry = y - qy * d;
@@ -497,6 +498,22 @@ __device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
         const bool top = qx != qy;            // the difference lies in the upper half
         cnt += top ? 0u : (16u >> st);
         x = top ? qx : rx; y = top ? qy : ry;
+    }
+    if (kd.narrow) {
+        // behind the second step both numbers are below radix^8 < 2^32: the last three steps in 32-bit arithmetic (a 64-bit multiply-high is
+        // four 32-bit multiplies and their carries; the five 64-bit steps were most of k_heads_publish_tc's instructions)
+        u32 a = (u32)x, b = (u32)y;
+#pragma unroll
+        for (int st = 2; st < 5; st++) {
+            const u32 d = kd.pw32[st - 2], mg = kd.pm32[st - 2];
+            u32 qa = __umulhi(a, mg), qb = __umulhi(b, mg);
+            u32 ra = a - qa * d, rb = b - qb * d;
+            if ((int32_t)ra < 0) { qa--; ra += d; }
+            if ((int32_t)rb < 0) { qb--; rb += d; }
+            const bool top = qa != qb;
+            cnt += top ? 0u : (16u >> st);
+            a = top ? qa : ra; b = top ? qb : rb;
+        }
     }
     return cnt - (32u - (u32)kd.K);
 }
@@ -755,6 +772,17 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
     // A thread takes four entries in a row, with the two keys in front of them and the two behind straight from memory (its neighbours'
     // loads hit the same lines): one entry per thread through an LDS tile was bound by its instruction count -- 5 ms for 9.5 GB.
     __shared__ u32 wsum[TB / 64];
+    // The ranks of a workgroup's entries are one stretch [R0, R0 + entries + flagged entries): SA / LCP / BWT / head are laid out in LDS and leave as
+    // whole lines.  Written from the threads' registers (four entries in a row each: every store instruction of a wave touched 64 lanes x 16-32 B
+    // apart) every 64-byte line went to memory once per instruction -- 3.4 x 10^8 write requests, 20.9 GB for 5.4 GB of results at 2 x 250 Mbp
+    // (TCC_EA0_WRREQ / _64B, profiles/r04_wrreq_c4.txt), the kernel at the copy ceiling of the node.  A slot that is not this workgroup's to write (a
+    // pair across the tile border is finished by both sides, each writing its own final rank) keeps its sentinel and is left alone.
+    constexpr int TC_SPAN = 2 * TC_TILE + 2;
+    constexpr sa_t SA_NONE = (sa_t)~(sa_t)0;
+    __shared__ sa_t o_sa[TC_SPAN];
+    __shared__ u32 o_lcp[TC_SPAN];
+    __shared__ uint8_t o_bw[TC_SPAN], o_hd[TC_SPAN];
+    for (int x = threadIdx.x; x < TC_SPAN; x += TB) { o_sa[x] = SA_NONE; o_lcp[x] = 0xFFFFFFFFu; }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t j0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * TC_PER;
     u64 kk[TC_PER + 4];          // keys j0 - 2 .. j0 + 5
@@ -778,6 +806,18 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
     __syncthreads();
     u32 before = blockoff[blockIdx.x] + inc - myflags;
     for (int k = 0; k < wv; k++) before += wsum[k];
+    const int64_t R0 = (int64_t)blockIdx.x * TC_TILE + (int64_t)blockoff[blockIdx.x] - 1;      // slot 0 = the rank in front of the stretch
+    u32 span_flags = 0;
+    for (int k = 0; k < TB / 64; k++) span_flags += wsum[k];
+    auto put_sa = [&](int64_t rank, sa_t v, uint8_t bw) {
+        const int64_t x = rank - R0;
+        if (x >= 0 && x < TC_SPAN) { o_sa[x] = v; o_bw[x] = bw; } else { SA[rank] = v; BWT[rank] = bw; }
+    };
+    auto put_lcp = [&](int64_t rank, u32 l) {
+        const int64_t x = rank - R0;
+        if (x >= 0 && x < TC_SPAN) o_lcp[x] = l; else LCP[rank] = (lcp_t)l;
+    };
+    auto put_head = [&](int64_t rank, bool v) { o_hd[rank - R0] = v ? 1 : 0; };      // (always a rank of this stretch)
     u32 lmax = 0;
     const u64 mk = kd.ly.sortmask;
 #pragma unroll
@@ -813,7 +853,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 const u32 st = key_first_stop(key, kd);
                 l = l < st ? l : st;
             }
-            LCP[r] = (lcp_t)l;
+            put_lcp(r, l);
             lmax = l > lmax ? l : lmax;
         }
         const u32 pay = (u32)(key >> 56);
@@ -827,12 +867,12 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             if (fin) {
                 const u32 st = key_first_stop(key, kd);
                 const u32 l = nd < st ? nd : st;
-                LCP[r + 1] = (lcp_t)l;
+                put_lcp(r + 1, l);
                 lmax = l > lmax ? l : lmax;
             } else { kexp[r] = key; kexp[r + 1] = qkey; vexp[r] = s; vexp[r + 1] = q; }
-            head[r] = hd; head[r + 1] = fin;
-            SA[rs] = (sa_t)s; BWT[rs] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
-            SA[rq] = (sa_t)q; BWT[rq] = (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u));
+            put_head(r, hd); put_head(r + 1, fin);
+            put_sa(rs, (sa_t)s, (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u)));
+            put_sa(rq, (sa_t)q, (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u)));
             before++;
         } else {
             int64_t rank = r;
@@ -850,7 +890,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                     if (rank != base) {
                         const u32 st = key_first_stop(key, kd);
                         const u32 l = nd < st ? nd : st;
-                        LCP[rank] = (lcp_t)l;
+                        put_lcp(rank, l);
                         lmax = l > lmax ? l : lmax;
                     }
                     if (second) hd = true;      // finished: a group of its own from here on
@@ -858,9 +898,23 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 }
             }
             if (!fin) { kexp[r] = key; vexp[r] = s; }
-            head[r] = hd;
-            SA[rank] = (sa_t)s;
-            BWT[rank] = (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+            put_head(r, hd);
+            put_sa(rank, (sa_t)s, (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u)));
+        }
+    }
+    __syncthreads();
+    {
+        const int64_t tile_j0 = (int64_t)blockIdx.x * TC_TILE;
+        const int64_t ents = m - tile_j0 < (int64_t)TC_TILE ? m - tile_j0 : (int64_t)TC_TILE;
+        const int own = (int)(ents + (int64_t)span_flags);      // slots 1 .. own are this workgroup's ranks; 0 and own + 1 its neighbours'
+        for (int x = threadIdx.x; x < own + 2; x += TB) {
+            const int64_t rank = R0 + x;
+            if (rank < 0) continue;
+            const sa_t v = o_sa[x];
+            if (v != SA_NONE) { SA[rank] = v; BWT[rank] = o_bw[x]; }
+            const u32 l = o_lcp[x];
+            if (l != 0xFFFFFFFFu) LCP[rank] = (lcp_t)l;
+            if (x >= 1 && x <= own) head[rank] = o_hd[x];
         }
     }
     const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
@@ -2010,6 +2064,13 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         u64 d = 1;
         for (int e = 0; e < (16 >> st); e++) d = d > (~0ull) / radix ? ~0ull : d * radix;      // (saturates for large alphabets: nothing is ever that large then)
         kd.pw[st] = d; kd.pmagic[st] = d == ~0ull ? 0ull : (~0ull) / d + 1;
+    }
+    kd.narrow = kd.pw[1] < (1ull << 31) ? 1 : 0;      // radix^8: what is left behind the second step of key_common_digits fits 31 bits
+    for (int st = 2; st < 5; st++) {
+        const u64 d = kd.pw[st];
+        kd.pw32[st - 2] = d < (1ull << 31) ? (u32)d : 0u;
+        kd.pm32[st - 2] = (d < (1ull << 31) && d > 1) ? (u32)((1ull << 32) / d + 1) : 0u;
+        if (d <= 1 || d >= (1ull << 31)) kd.narrow = 0;
     }
     if (fused) RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
 

@@ -171,13 +171,18 @@ template <bool XCD> __device__ inline u32 rs_tile_of(u32 nb) {
     return (blockIdx.x % RS_XCDS) * chunk + blockIdx.x / RS_XCDS;
 }
 
-template <int BITS>
+// (XCD: the tile order of k_rs_scatter.  The histograms are stored digit-major -- word d * nblocks + tile -- so the 4-byte words of
+// consecutive tiles share a line; written by eight XCDs in turn no L2 ever holds the whole line: 375 MB of partial-line writes per pass for 72 MB
+// of counts at 2 x 250 Mbp.)
+template <int BITS, bool XCD>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ keys, int64_t n, int shift, u32 dmask, u32 *__restrict__ blockhist, u32 nblocks) {
     constexpr int NB = 1 << BITS;
     __shared__ u32 h[NB];
+    const u32 tile = rs_tile_of<XCD>(nblocks);
+    if (tile >= nblocks) return;
     for (int k = threadIdx.x; k < NB; k += RS_THREADS) h[k] = 0;
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    const int64_t base = (int64_t)tile * RS_TILE;
     u64 key[RS_ITEMS];          // (all loads first: see k_rs_scatter)
 #pragma unroll
     for (int r = 0; r < RS_ITEMS; r++) {
@@ -190,7 +195,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
         if (i < n) atomicAdd(&h[(u32)(key[r] >> shift) & dmask], 1u);
     }
     __syncthreads();
-    for (int k = threadIdx.x; k < NB; k += RS_THREADS) blockhist[(size_t)k * nblocks + blockIdx.x] = h[k];
+    for (int k = threadIdx.x; k < NB; k += RS_THREADS) blockhist[(size_t)k * nblocks + tile] = h[k];
 }
 
 // BITS: digit width (8: 256 bins; 10: 1024 bins -- a 40-bit key in four passes instead of five).  CNT: type of the waves' bucket
@@ -333,8 +338,11 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
         const int wbits = bit_hi - shift < width ? bit_hi - shift : width;
         const u32 dmask = (1u << wbits) - 1u;
         int pid = ws.prof_begin(8 /* RV_K_RADIX_HIST */, 8.0 * (double)n);
-        if (width == 10) hipLaunchKernelGGL((k_rs_hist<10>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
-        else hipLaunchKernelGGL((k_rs_hist<8>), dim3(nb), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
+        const u32 hgrid = xcd ? RS_XCDS * ((nb + RS_XCDS - 1) / RS_XCDS) : nb;
+        if (width == 10) { if (xcd) hipLaunchKernelGGL((k_rs_hist<10, true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
+                           else hipLaunchKernelGGL((k_rs_hist<10, false>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb); }
+        else             { if (xcd) hipLaunchKernelGGL((k_rs_hist<8, true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
+                           else hipLaunchKernelGGL((k_rs_hist<8, false>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb); }
         RV_LAUNCH_CHECK();
         ws.prof_end(pid);
         RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, ((int64_t)1 << width) * nb));

@@ -66,7 +66,14 @@ int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so
  * n >= 2^32 - 2 positions is refused here, whatever the width of saidx_t and wherever SA comes from (built, or read from
  * safile, which is range- and permutation-checked on the device before anything scatters through it).  The 64-bit library
  * is exercised above 2^31 positions -- where the reference needs reveallib64, reveal.h:7-13 -- at n = 2.2 x 10^9
- * (tests/test_gpu_above_2_31.py: construct, both recursion paths, and this refusal). */
+ * (tests/test_gpu_above_2_31.py: construct, both recursion paths, and this refusal).
+ * The byte budget behind that cap (measured, tools/mem_probe.py on one MI355X, 309 GB visible): after construct() + align a handle of the
+ * 64-bit library holds 119 B per position (262 GB at n = 2.2 x 10^9; the 32-bit library 85 B: 42.6 GB at n = 5 x 10^8) -- text and working copy
+ * 2, SA 8, LCP 4, BWT 1, the SA build's scratch, kept between calls, ~95 (two buffers of 8-byte keys and of 8-byte suffixes sized for n, group heads /
+ * seeds / ranks / the round-0 list at 4 to 8 bytes each, the packed text, the diagonal bits), the recursion's lists the rest.  309 GB / 119 B =
+ * 2.6 x 10^9 positions: HBM, not the 32-bit ranks, is what stops this library first; two human genomes (6.2 x 10^9) need both wider ranks and a
+ * build whose scratch is 40 B per position -- not built.  The reference's 64-bit module has no such ceiling besides host memory
+ * (reveal.h:7-13, interface.c:61-68). */
 int rv_construct(rv_index *h, int rc, const char *safile, const char *lcpfile, int cache);
 /* Copies the assembled text to HBM now (construct does it on demand).  Lets a
  * caller keep the host->device copy out of a timed construct(); repeated

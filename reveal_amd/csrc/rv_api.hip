@@ -896,7 +896,7 @@ extern "C" {
 int rv_test_radix_time(int64_t n, int bits, int dist, int flags, int iters, double *ms, int64_t *bad) {
     Workspace ws;
     RV_TRY(test_ws(ws));
-    ws.opt.rs_bits = (flags & 1) ? 10 : 8; ws.opt.rs_xcd = (flags & 2) ? 1 : 0; ws.opt.rs_cnt16 = (flags & 4) ? 1 : 0;
+    ws.opt.rs_bits = (flags & 1) ? 10 : 8; ws.opt.rs_xcd = (flags & 2) ? 1 : 0; ws.opt.rs_cnt16 = (flags & 4) ? 1 : 0; ws.opt.rs_no_digit_bytes = (flags & 8) ? 1 : 0;
     DBuf k0, k1, v0, v1, db;
     int r = 0, in1 = 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;

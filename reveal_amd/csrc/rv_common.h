@@ -88,6 +88,7 @@ void rv_set_error(const char *fmt, ...);
     X(rs_bits, "RV_RS_BITS", 8) \
     X(rs_xcd, "RV_RS_XCD", 1) \
     X(rs_cnt16, "RV_RS_CNT16", 1) \
+    X(rs_no_digit_bytes, "RV_RS_NO_DIGIT_BYTES", 0) \
     X(diag_table, "RV_DIAG_TABLE", -1) \
     X(no_cascade_chain, "RV_NO_CASCADE_CHAIN", 0)
 struct RvOptions {
@@ -296,6 +297,7 @@ struct Workspace {
     RvOptions opt;         // the owning handle's switches (rv_set_option)
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
+    DBuf rs_digits;        // radix sort: the next pass' digit of every key, a byte each
     DBuf misc[16];
     DBuf sa[26];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
@@ -316,7 +318,7 @@ struct Workspace {
         hpin.release();
         if (ev_rb) { (void)hipEventDestroy(ev_rb); ev_rb = nullptr; }
         for (auto &b : scan_tmp) b.release();
-        rs_hist.release();
+        rs_hist.release(); rs_digits.release();
         for (auto &b : misc) b.release();
         for (auto &b : sa) b.release();
     }

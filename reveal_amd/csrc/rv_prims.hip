@@ -198,12 +198,37 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_hist(const u64 *__restrict__ 
     for (int k = threadIdx.x; k < NB; k += RS_THREADS) blockhist[(size_t)k * nblocks + tile] = h[k];
 }
 
+// The same histogram from the digits themselves: the scatter of the pass before left every key's next digit as a byte at the key's new place
+// (k_rs_scatter dnext), so the pass reads 1 byte per key instead of the 8-byte key -- sixteen digits per thread in one load.
+template <bool XCD>
+__global__ __launch_bounds__(RS_THREADS) void k_rs_hist_bytes(const uint8_t *__restrict__ digits, int64_t n, u32 *__restrict__ blockhist, u32 nblocks) {
+    static_assert(RS_ITEMS == 16, "sixteen digit bytes per thread");
+    __shared__ u32 h[256];
+    const u32 tile = rs_tile_of<XCD>(nblocks);
+    if (tile >= nblocks) return;
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t i0 = (int64_t)tile * RS_TILE + (int64_t)threadIdx.x * 16;
+    if (i0 + 16 <= n) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(digits + i0);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) atomicAdd(&h[(w[k] >> (8 * b)) & 255u], 1u);
+    } else {
+        for (int64_t i = i0; i < n && i < i0 + 16; i++) atomicAdd(&h[digits[i]], 1u);
+    }
+    __syncthreads();
+    blockhist[(size_t)threadIdx.x * nblocks + tile] = h[threadIdx.x];
+}
+
 // BITS: digit width (8: 256 bins; 10: 1024 bins -- a 40-bit key in four passes instead of five).  CNT: type of the waves' bucket
 // counters (a tile holds 4096 keys: 16 bits are enough, and with them three workgroups fit a CU's LDS instead of two).
 template <class V, int BITS, bool XCD, class CNT>
 __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict__ kin, const V *__restrict__ vin,
                                                             u64 *__restrict__ kout, V *__restrict__ vout, int64_t n, int shift, u32 dmask,
-                                                            const u32 *__restrict__ blockoff, u32 nblocks) {
+                                                            const u32 *__restrict__ blockoff, u32 nblocks, uint8_t *__restrict__ dnext, int nshift, u32 nmask) {
     constexpr int NB = 1 << BITS;
     constexpr int BPT = NB / RS_THREADS;          // bins per thread in the per-digit steps
     static_assert(NB % RS_THREADS == 0 && RS_TILE < 65536, "bins per thread, 16-bit counters");
@@ -304,13 +329,15 @@ __global__ __launch_bounds__(RS_THREADS) void k_rs_scatter(const u64 *__restrict
         const size_t dst = (size_t)gbase[d] + (li - (u32)dstart[d]);
         kout[dst] = k;
         vout[dst] = sval[li];
+        if (dnext) dnext[dst] = (uint8_t)((u32)(k >> nshift) & nmask);      // the next pass' digit, for its histogram (k_rs_hist_bytes)
     }
 }
 
 template <class V, int BITS, bool XCD, class CNT>
-static void rs_scatter_launch(hipStream_t q, u32 nb, const u64 *ki, const V *vi, u64 *ko, V *vo, int64_t n, int shift, u32 dmask, const u32 *bh) {
+static void rs_scatter_launch(hipStream_t q, u32 nb, const u64 *ki, const V *vi, u64 *ko, V *vo, int64_t n, int shift, u32 dmask, const u32 *bh,
+                              uint8_t *dnext, int nshift, u32 nmask) {
     const u32 grid = XCD ? RS_XCDS * ((nb + RS_XCDS - 1) / RS_XCDS) : nb;
-    hipLaunchKernelGGL((k_rs_scatter<V, BITS, XCD, CNT>), dim3(grid), dim3(RS_THREADS), 0, q, ki, vi, ko, vo, n, shift, dmask, bh, nb);
+    hipLaunchKernelGGL((k_rs_scatter<V, BITS, XCD, CNT>), dim3(grid), dim3(RS_THREADS), 0, q, ki, vi, ko, vo, n, shift, dmask, bh, nb, dnext, nshift, nmask);
 }
 
 }  // namespace
@@ -330,6 +357,11 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
     const u32 nb = (u32)ceil_div(n, RS_TILE);
     RV_TRY(ws.rs_hist.reserve(((size_t)1 << width) * nb * sizeof(u32)));
     u32 *bh = ws.rs_hist.as<u32>();
+    // the digits of the next pass as a byte per key (8-bit digits, inputs large enough for the saved reads to matter)
+    const bool bytes = width == 8 && !ws.opt.rs_no_digit_bytes && n >= ((int64_t)1 << 20) && bit_hi - bit_lo > width;
+    if (bytes) RV_TRY(ws.rs_digits.reserve((size_t)n + 64));
+    uint8_t *dig = bytes ? ws.rs_digits.as<uint8_t>() : nullptr;
+    bool have_digits = false;
     u64 *ki = k0, *ko = k1;
     V *vi = v0, *vo = v1;
     int flip = 0;
@@ -337,22 +369,31 @@ int rv_radix_sort_pairs(Workspace &ws, u64 *k0, V *v0, u64 *k1, V *v1, int64_t n
         // (the last pass may cover fewer bits: whatever lies above bit_hi never takes part)
         const int wbits = bit_hi - shift < width ? bit_hi - shift : width;
         const u32 dmask = (1u << wbits) - 1u;
-        int pid = ws.prof_begin(8 /* RV_K_RADIX_HIST */, 8.0 * (double)n);
+        int pid = ws.prof_begin(8 /* RV_K_RADIX_HIST */, (have_digits ? 1.0 : 8.0) * (double)n);
         const u32 hgrid = xcd ? RS_XCDS * ((nb + RS_XCDS - 1) / RS_XCDS) : nb;
-        if (width == 10) { if (xcd) hipLaunchKernelGGL((k_rs_hist<10, true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
+        if (have_digits) {
+            if (xcd) hipLaunchKernelGGL((k_rs_hist_bytes<true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const uint8_t *)dig, n, bh, nb);
+            else hipLaunchKernelGGL((k_rs_hist_bytes<false>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const uint8_t *)dig, n, bh, nb);
+        } else if (width == 10) { if (xcd) hipLaunchKernelGGL((k_rs_hist<10, true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
                            else hipLaunchKernelGGL((k_rs_hist<10, false>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb); }
         else             { if (xcd) hipLaunchKernelGGL((k_rs_hist<8, true>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb);
                            else hipLaunchKernelGGL((k_rs_hist<8, false>), dim3(hgrid), dim3(RS_THREADS), 0, ws.stream, (const u64 *)ki, n, shift, dmask, bh, nb); }
         RV_LAUNCH_CHECK();
         ws.prof_end(pid);
         RV_TRY(rv_exclusive_sum_u32(ws, bh, bh, ((int64_t)1 << width) * nb));
-        pid = ws.prof_begin(7 /* RV_K_RADIX_SCATTER */, 2.0 * (8.0 + sizeof(V)) * (double)n);
-#define RS_GO(B_, X_, C_) rs_scatter_launch<V, B_, X_, C_>(ws.stream, nb, (const u64 *)ki, (const V *)vi, ko, vo, n, shift, dmask, (const u32 *)bh)
+        // (the next pass' digit, masked like the pass itself will mask it)
+        const int nshift = shift + width;
+        const bool more = nshift < bit_hi;
+        const u32 nmask = more ? ((1u << (bit_hi - nshift < width ? bit_hi - nshift : width)) - 1u) : 0u;
+        uint8_t *dn = (bytes && more) ? dig : nullptr;
+        pid = ws.prof_begin(7 /* RV_K_RADIX_SCATTER */, (2.0 * (8.0 + sizeof(V)) + (dn ? 1.0 : 0.0)) * (double)n);
+#define RS_GO(B_, X_, C_) rs_scatter_launch<V, B_, X_, C_>(ws.stream, nb, (const u64 *)ki, (const V *)vi, ko, vo, n, shift, dmask, (const u32 *)bh, dn, nshift, nmask)
         if (width == 10) { if (xcd) { if (c16) RS_GO(10, true, uint16_t); else RS_GO(10, true, u32); } else { if (c16) RS_GO(10, false, uint16_t); else RS_GO(10, false, u32); } }
         else             { if (xcd) { if (c16) RS_GO(8, true, uint16_t); else RS_GO(8, true, u32); } else { if (c16) RS_GO(8, false, uint16_t); else RS_GO(8, false, u32); } }
 #undef RS_GO
         RV_LAUNCH_CHECK();
         ws.prof_end(pid);
+        have_digits = dn != nullptr;
         u64 *tk = ki; ki = ko; ko = tk;
         V *tv = vi; vi = vo; vo = tv;
         flip ^= 1;

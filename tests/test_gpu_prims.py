@@ -51,10 +51,11 @@ def test_radix_sort_stable(lib, n, lo, hi):
     assert np.array_equal(k, keys[order])
 
 
-@pytest.mark.parametrize("flags", range(8))
-@pytest.mark.parametrize("n,bits,dist", [(100_000, 40, 1), (4096 * 9 + 5, 37, 0), (300_000, 16, 2)])
+@pytest.mark.parametrize("flags", range(16))
+@pytest.mark.parametrize("n,bits,dist", [(100_000, 40, 1), (4096 * 9 + 5, 37, 0), (300_000, 16, 2), (1_200_000, 40, 1), (1_050_001, 35, 0)])
 def test_radix_sort_variants(lib, flags, n, bits, dist):
-    """every variant of the scatter kernel (10-bit digits, XCD-aware tile order, 16-bit wave counters: rv_prims.hip) sorts device-made
+    """every variant of the sort (10-bit digits, XCD-aware tile order, 16-bit wave counters, flag 8: histograms from the keys instead of the
+    digit bytes the pass before left -- those only above 2^20 keys: rv_prims.hip) sorts device-made
     keys stably -- checked on the device: no adjacent pair out of order by (key bits, original index)"""
     import ctypes
     ms = (ctypes.c_double * 2)()

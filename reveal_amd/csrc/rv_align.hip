@@ -202,6 +202,10 @@ struct Align {
     u32 *lf_counters = nullptr; unsigned long long *lf_stats = nullptr; u32 *lf_l = nullptr; int64_t *lf_pos = nullptr; rv_trace *lf_tr = nullptr;
     size_t leaf_na = 0;          // anchors of the leaf launches of the last run: they stay in the pinned staging buffer (hLeafOut: pos[2 na], l[na]) until fetched
     void release() {
+        // (the side streams may still be writing pinned buffers that go back to the process-wide pool below: after an aborted run nothing else waits for them)
+        if (leaf_stream) (void)hipStreamSynchronize(leaf_stream);
+        if (leaf_stream2) (void)hipStreamSynchronize(leaf_stream2);
+        if (bub_stream) { (void)hipStreamSynchronize(bub_stream); (void)hipStreamSynchronize(bub_stream2); }
         for (int k = 0; k < RV_LEVEL_BUFS; k++) { lvSA[k].release(); lvLCP[k].release(); lvBWT[k].release(); }
         scrSA.release(); scrLCP.release(); scrBWT.release(); cas.release();
         dTmin.release(); dPbReady.release(); dNextTsub.release(); dD.release(); dTab.release(); dTile.release(); dList.release(); dFlag.release(); dPar.release(); dDbg.release(); pk.release(); dDec.release(); dErr.release(); dTab0.release(); hLeafRoots[0].release(); hLeafRoots[1].release(); hLeafOut.release(); dLeaf.release(); dLeafRoots[0].release(); dLeafRoots[1].release();

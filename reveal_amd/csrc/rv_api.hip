@@ -260,7 +260,8 @@ int rv_upload(rv_index *h) {
         // pageable vector the runtime stages it itself, single-threaded: 500 MB took 38-52 ms, 10-13 GB/s.)
         HBuf &pin = h->hupload;
         RV_TRY(pin.reserve(2 * CH));
-        hipEvent_t ev[2] = {nullptr, nullptr};
+        struct Events { hipEvent_t e[2] = {nullptr, nullptr}; ~Events() { for (auto x : e) if (x) (void)hipEventDestroy(x); } } evs;      // (destroyed on every way out)
+        hipEvent_t *ev = evs.e;
         for (int k = 0; k < 2; k++) RV_HIP(hipEventCreateWithFlags(&ev[k], hipEventDisableTiming));
         bool used[2] = {false, false};
         int slot = 0;
@@ -281,7 +282,6 @@ int rv_upload(rv_index *h) {
             used[slot] = true;
         }
         RV_HIP(hipStreamSynchronize(q));
-        for (int k = 0; k < 2; k++) (void)hipEventDestroy(ev[k]);
     }
     RV_HIP(hipStreamSynchronize(q));
     h->text_dirty = false;

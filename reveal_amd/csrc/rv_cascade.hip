@@ -1071,7 +1071,10 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
             RV_LAUNCH_CHECK();
         }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
-        if (hc[C_ERR]) { rv_set_error("cascade: device error %u", hc[C_ERR]); return -1; }
+        // (bits 1 and 4: the table of sub-indices / the anchor area is full -- retries of the second attempt take a slot each: not an error of the
+        // input, the level pipeline completes such a run)
+        if (hc[C_ERR] & ~5u) { rv_set_error("cascade: device error %u", hc[C_ERR]); return -1; }
+        if (hc[C_ERR]) GIVE_UP("the cascade's tables are full");
         if (hc[C_MAXN] > (u32)RV_LEAF_N) break;      // an undecided sub-index the leaf kernel cannot take
         if (hc[C_HI] == hc[C_LO]) break;
         if (queued > 1000000) { rv_set_error("cascade: no progress"); return -1; }

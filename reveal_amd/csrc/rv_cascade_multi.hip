@@ -707,7 +707,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
             RV_LAUNCH_CHECK();
         }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
-        if (hc[C_ERR]) { rv_set_error("cascade (multi): device error %u", hc[C_ERR]); return -1; }
+        if (hc[C_ERR] & ~5u) { rv_set_error("cascade (multi): device error %u", hc[C_ERR]); return -1; }
+        if (hc[C_ERR]) GIVE_UP("the cascade's tables are full");      // (bits 1 and 4: sub-index table / anchor area: the level pipeline completes the run)
         if (hc[C_MAXN] > (u32)BN) break;
         if (hc[C_HI] == hc[C_LO]) break;
         if (queued > 1000000) { rv_set_error("cascade (multi): no progress"); return -1; }

@@ -183,6 +183,26 @@ def test_processes_divide_one_alignment(tmp_path, world, genomes, L):
     assert len(r["shares"]) == world and sum(1 for x in r["shares"] if x > 0) >= 2 and sum(r["batches"]) >= world
 
 
+def test_processes_divide_one_alignment_with_the_cascade_on(tmp_path):
+    """the default path (no RV_NO_CASCADE in the ranks' environment; this test's name keeps the fixture away): four samples on three ranks --
+    rv_align_builtin_until runs the interval cascade first, what it leaves undecided becomes the frontier (install_frontier), balanced_frontier
+    widens it, the queue hands it out; the cascade's own anchors ride in rank 0's first resume().  Anchors and text equal the undivided run's
+    (its count of visited sub-indices is the level pipeline's, which also visits children the cascade decides without visiting: not compared)"""
+    import json, os, subprocess, sys
+    from helpers import ROOT
+    script = tmp_path / "ranks.py"
+    script.write_text(TWO_RANK % (ROOT, 150000, 4))
+    port = "29547"
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RV_")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                          "--master-port", port, str(script)], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
+    assert r["same_anchors"] and r["same_text"] and r["anchors"] > 500
+    assert len(r["shares"]) == 3
+
+
 def test_widened_frontier_divides_evenly():
     """shard.balanced_frontier: the owner goes on level by level (rv_align_builtin_continue) until no share of the
     largest-first partition exceeds the mean by more than the tolerance; the divided result is still the undivided one"""

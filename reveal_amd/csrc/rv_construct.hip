@@ -23,36 +23,62 @@ namespace {
 
 constexpr int TB = 256;
 
+// ---- eight text bytes at a time ----------------------------------------------------------------------------
+// 0x80 in every byte of v that equals c (exact: no carries between bytes)
+__device__ inline u64 swar_eq(u64 v, uint8_t c) {
+    const u64 t = v ^ (0x0101010101010101ull * c);
+    return ~(((t & 0x7f7f7f7f7f7f7f7full) + 0x7f7f7f7f7f7f7f7full) | t) & 0x8080808080808080ull;
+}
+// 0x80 in every byte that is one of A, C, G, T
+__device__ inline u64 swar_acgt(u64 v) { return swar_eq(v, 'A') | swar_eq(v, 'C') | swar_eq(v, 'G') | swar_eq(v, 'T'); }
+// the 2-bit codes (A, C, G, T = 0..3: ((c >> 1) ^ (c >> 2)) & 3 on their ASCII codes) of eight bytes, byte j in bits 2j, 2j + 1
+__device__ inline u32 swar_code2(u64 v) {
+    u64 y = ((v >> 1) ^ (v >> 2)) & 0x0303030303030303ull;
+    y = (y | (y >> 6)) & 0x000f000f000f000full;
+    y = (y | (y >> 12)) & 0x000000ff000000ffull;
+    y = (y | (y >> 24)) & 0xffffull;
+    return (u32)y;
+}
+
 // ---- alphabet ---------------------------------------------------------------
 __global__ __launch_bounds__(TB) void k_hist256(const uint8_t *__restrict__ T, int64_t n, u32 *__restrict__ hist) {
-    // eight copies of the table, a lane uses copy lane & 7: a DNA text sends every lane of a wave to the same four words (0.5 GB in 0.57 ms)
-    __shared__ u32 hh[8][256];
-    for (int k = threadIdx.x; k < 8 * 256; k += TB) (&hh[0][0])[k] = 0;
-    u32 *const h = hh[threadIdx.x & 7];
+    // A DNA text is A, C, G, T and the separators: those five are counted in registers, eight bytes per step (equality masks and a population
+    // count); only other bytes go to the LDS table.  (One LDS atomic per byte sent every lane of a wave to the same four words: 0.32 ms for 0.5 GB.)
+    __shared__ u32 hh[256];
+    hh[threadIdx.x] = 0;
     __syncthreads();
+    u32 cA = 0, cC = 0, cG = 0, cT = 0, cS = 0;
     const int64_t stride = (int64_t)gridDim.x * TB * 16;
     for (int64_t base = ((int64_t)blockIdx.x * TB + threadIdx.x) * 16; base < n; base += stride) {
         if (base + 16 <= n) {
             const uint4 v = *reinterpret_cast<const uint4 *>(T + base);
-            const u32 w[4] = {v.x, v.y, v.z, v.w};
-            bool sep = false;
+            const u64 w[2] = {(u64)v.x | ((u64)v.y << 32), (u64)v.z | ((u64)v.w << 32)};
+            u64 sep[2];
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const u32 x = w[k] ^ 0x24242424u;
-                sep |= ((x - 0x01010101u) & ~x & 0x80808080u) != 0u;
-#pragma unroll
-                for (int b = 0; b < 4; b++) atomicAdd(&h[(w[k] >> (8 * b)) & 255u], 1u);
+            for (int k = 0; k < 2; k++) {
+                const u64 eA = swar_eq(w[k], 'A'), eC = swar_eq(w[k], 'C'), eG = swar_eq(w[k], 'G'), eT = swar_eq(w[k], 'T'), eS = swar_eq(w[k], '$');
+                cA += (u32)__popcll(eA); cC += (u32)__popcll(eC); cG += (u32)__popcll(eG); cT += (u32)__popcll(eT); cS += (u32)__popcll(eS);
+                sep[k] = eS;
+                u64 other = ~(eA | eC | eG | eT | eS) & 0x8080808080808080ull;
+                while (other) {
+                    const int b = __builtin_ctzll(other) >> 3;
+                    atomicAdd(&hh[(w[k] >> (8 * b)) & 255u], 1u);
+                    other &= other - 1;
+                }
             }
             // two separators next to each other (an empty sequence): hist[256] -- rv_build_sa's shorter alphabet needs to know
-            if (sep) for (int64_t i = base; i < base + 16; i++) if (T[i] == '$' && i + 1 < n && T[i + 1] == '$') atomicAdd(&hist[256], 1u);
+            if (sep[0] | sep[1]) for (int64_t i = base; i < base + 16; i++) if (T[i] == '$' && i + 1 < n && T[i + 1] == '$') atomicAdd(&hist[256], 1u);
         } else {
-            for (int64_t i = base; i < n; i++) { atomicAdd(&h[T[i]], 1u); if (T[i] == '$' && i + 1 < n && T[i + 1] == '$') atomicAdd(&hist[256], 1u); }
+            for (int64_t i = base; i < n; i++) { atomicAdd(&hh[T[i]], 1u); if (T[i] == '$' && i + 1 < n && T[i + 1] == '$') atomicAdd(&hist[256], 1u); }
         }
     }
+    if (cA) atomicAdd(&hh[(uint8_t)'A'], cA);
+    if (cC) atomicAdd(&hh[(uint8_t)'C'], cC);
+    if (cG) atomicAdd(&hh[(uint8_t)'G'], cG);
+    if (cT) atomicAdd(&hh[(uint8_t)'T'], cT);
+    if (cS) atomicAdd(&hh[(uint8_t)'$'], cS);
     __syncthreads();
-    u32 tot = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) tot += hh[k][threadIdx.x];
+    const u32 tot = hh[threadIdx.x];
     if (tot) atomicAdd(&hist[threadIdx.x], tot);
 }
 
@@ -1175,17 +1201,19 @@ __global__ __launch_bounds__(TB) void k_pack2(const uint8_t *__restrict__ T, int
     const int64_t p0 = w * 32;
     u64 word = 0; bool exc = false;
     if (p0 + 32 <= n) {
-        u64 v[4];
-        __builtin_memcpy(v, T + p0, 32);
+        // (eight bytes at a time: written byte by byte with ?: chains this compiled to 214 exec-mask branches, 0.49 ms for 0.5 GB)
+        const uint4 *q4 = reinterpret_cast<const uint4 *>(T + p0);
+        const uint4 lo = q4[0], hi = q4[1];
+        const u64 v[4] = {(u64)lo.x | ((u64)lo.y << 32), (u64)lo.z | ((u64)lo.w << 32), (u64)hi.x | ((u64)hi.y << 32), (u64)hi.z | ((u64)hi.w << 32)};
+        u64 ok = 0x8080808080808080ull;
 #pragma unroll
-        for (int k = 0; k < 4; k++)
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const u32 c = (u32)(v[k] >> (8 * j)) & 0xffu;
-                const u32 code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-                exc |= code > 3u;
-                word |= (u64)(code & 3u) << (2 * (8 * k + j));
-            }
+        for (int k = 0; k < 4; k++) {
+            const u64 m = swar_acgt(v[k]);
+            ok &= m;
+            // (a byte that is no base contributes whatever its bits give: the block is flagged, its window is compared on the text)
+            word |= (u64)swar_code2(v[k] & (m | (m >> 1) | (m >> 2) | (m >> 3) | (m >> 4) | (m >> 5) | (m >> 6) | (m >> 7))) << (16 * k);
+        }
+        exc = ok != 0x8080808080808080ull;
     } else {
         exc = true;                                  // the tail (and everything behind the text)
         for (int j = 0; j < 32 && p0 + j < n; j++) {

@@ -100,6 +100,7 @@ struct Decisions {
     std::vector<int64_t> sp;
     std::vector<u32>     spl;             // length of the matched range at sp[k] (the match length; splitindex / extract: any)
     bool                 host_lists = false;   // some decision carries interval lists from the caller (not the built-in linear model)
+    bool                 drop_lead = false;    // the leading class of the (only) decision is dropped like matched ranks, no child is made (builtin_cascade: the chain's consumed sequences)
     std::vector<RvIntv>  lead, trail, rest, match;     // lead/trail/rest sorted by begin per decision; match in the given order
     int size() const { return (int)sub.size(); }
     void reset(int nsubs) {
@@ -107,7 +108,7 @@ struct Decisions {
         sub.clear(); l.clear();
         sp_first.assign(1, 0); lead_first.assign(1, 0); trail_first.assign(1, 0); rest_first.assign(1, 0); match_first.assign(1, 0);
         sp.clear(); spl.clear(); lead.clear(); trail.clear(); rest.clear(); match.clear();
-        host_lists = false;
+        host_lists = false; drop_lead = false;
     }
     void close() {
         sp_first.push_back((int64_t)sp.size()); lead_first.push_back((int64_t)lead.size()); trail_first.push_back((int64_t)trail.size());
@@ -1105,6 +1106,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
         bool dead[3] = {false, false, false};
         if (a->multi && a->full_only && !dc.host_lists && !h->ws.opt.keep_dead)
             for (int c = 0; c < 3; c++) dead[c] = cnts[c] > 0 && child_is_dead(h, lists[c], cnts[c], a->minl, a->minn);
+        if (dc.drop_lead) dead[0] = cnts[0] > 0;
         // class table of this sub: lead/trail/rest merged by begin (the split's tables: not needed when the split of this level ran
         // already, from the same tables built on the device -- early_split; those decisions come from the built-in picker, whose
         // intervals need no checking)
@@ -1806,6 +1808,28 @@ static int builtin_cascade(rv_index *h) {
     }
     a->st.levels += a->cas_out.levels;
     a->st.scanned_ranks += h->n;
+    if (!a->cas.lin_rest.empty() && h->nodes.size() > 2) {
+        // several sequences per sample: the chain of rest sub-indices stopped at a member the match list does not decide (left-over sequences whose
+        // only matches are as short as their repeats).  It becomes the level pipeline's frontier: ONE split of the root whose rest class is that
+        // member's sequences -- the split's range minima over the dropped ranks are what the chain of splits in between would have left (split only
+        // takes minima, reveal.c:582-664; bubble_sort touches leading children only) -- at the depth the chain had reached.
+        // The sequences the chain has consumed are labelled like matched ranks: dropped WITH the update of the running minima.  Left unlabelled they
+        // would take the reference's `continue` in front of that update (reveal.c:616-620, which in the reference only ever meets the '$' suffixes of
+        // the root), and the member's LCP values would come out too large.
+        std::vector<RvIntv> rest, gone;
+        for (size_t k = 0; k + 1 < a->cas.lin_rest.size(); k += 2) rest.push_back({a->cas.lin_rest[k], a->cas.lin_rest[k + 1]});
+        std::sort(rest.begin(), rest.end(), intv_less);
+        for (const RvIntv &v : h->nodes) {
+            if (v.end <= v.begin) continue;
+            const auto it = std::lower_bound(rest.begin(), rest.end(), v, intv_less);
+            if (it == rest.end() || it->begin != v.begin) gone.push_back(v);
+        }
+        RV_TRY(add_decision(h, 0, 0, nullptr, 0, gone.data(), (int)gone.size(), nullptr, 0, nullptr, 0, rest.data(), (int)rest.size()));
+        a->dec.drop_lead = true;
+        RV_TRY(rv_frontier_commit(h, nullptr));
+        for (size_t s2 = 0; s2 < a->lv.depth.size(); s2++) a->lv.depth[s2] = a->cas.lin_rest_depth;
+        return 0;
+    }
     h->main_arrays_freed = true;                                         /* reveal.c:1279-1284: align() consumes the main index */
     a->level = 1;
     a->lv.clear();                                                       // nothing left for the level pipeline

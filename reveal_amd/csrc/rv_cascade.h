@@ -11,6 +11,8 @@ struct RvCascadeBufs {
     // kept for a second attempt on the same lists
     u32 lin_roots = 0, lin_picks = 0, lin_nA = 0, lin_nB = 0;
     int64_t lin_steps = 0; int lin_maxdepth = 0; size_t lin_off[6] = {0, 0, 0, 0, 0, 0};
+    // a chain member the match list does not decide: its sequences as (begin, end) pairs and its depth -- the caller makes it the level pipeline's frontier
+    std::vector<int64_t> lin_rest; int lin_rest_depth = 0;
     void release() { for (auto &b : d) b.release(); }
 };
 

@@ -791,6 +791,7 @@ static int cas_lineage(rv_index *h, RvCascadeBufs &cb, u32 M, u32 NW, u32 minl, 
         return wptr < byw.size() ? byw[wptr].w : 0u;
     };
     std::vector<CasIv> roots; std::vector<int32_t> rdepth;
+    bool stalled = false;
     std::vector<int32_t> pickA(nA, -1), pickB(nB, -1);
     std::vector<u32> rootLead, rootTrail, anl; std::vector<int64_t> anp;
     int32_t depth = 0;
@@ -801,8 +802,9 @@ static int cas_lineage(rv_index *h, RvCascadeBufs &cb, u32 M, u32 NW, u32 minl, 
         const int ca = contig(CA, a), cb2 = contig(CB, b);
         if (ca < 0 || cb2 < 0 || !liveA[(size_t)ca] || !liveB[(size_t)cb2]) continue;
         if (a + (int64_t)l > CA[(size_t)ca].end || b + (int64_t)l > CB[(size_t)cb2].end) { *why = "a match that leaves its sequence"; return 0; }
-        if (l <= chain_wmax()) { *why = "a repeat as long as the best match between the sequences that are left"; return 0; }
+        if (l <= chain_wmax()) { stalled = true; break; }      // a repeat as long as the best match between the sequences that are left
         const u32 k = (u32)anl.size();
+        if (ws.opt.cascade_log) fprintf(stderr, "cascade: chain member %u chooses %u at %lld / %lld (sequences %d / %d), bound %u\n", k, l, (long long)a, (long long)b, ca, cb2, chain_wmax());
         anl.push_back(l); anp.push_back(a); anp.push_back(b);
         pickA[(size_t)ca] = (int32_t)k; pickB[(size_t)cb2] = (int32_t)k;
         u32 rl = NONE, rt = NONE;
@@ -818,13 +820,19 @@ static int cas_lineage(rv_index *h, RvCascadeBufs &cb, u32 M, u32 NW, u32 minl, 
         liveA[(size_t)ca] = 0; liveB[(size_t)cb2] = 0; nLiveA--; nLiveB--;
         depth++;
     }
-    if (anl.empty()) { *why = "no match between two sequences at the top level"; return 0; }
-    // the last member of the chain (what no choice touched): visited once more if anything is left; with both samples in it, it must provably hold no match
+    if (anl.empty()) { *why = stalled ? "a repeat as long as the best match of the root" : "no match between two sequences at the top level"; return 0; }
+    // the last member of the chain (what no choice touched): visited once more if anything is left; with both samples in it, it must provably hold no
+    // match.  A member the list does not decide (a repeat as long as its best match; no match but repeats of minl characters) is not visited here:
+    // its sequences go back to the caller, who makes it the level pipeline's frontier (rv_align.hip builtin_cascade)
     int64_t steps = (int64_t)anl.size();
     int maxdepth = depth - 1;
+    cb.lin_rest.clear(); cb.lin_rest_depth = depth;
+    if (ws.opt.cascade_log) fprintf(stderr, "cascade: chain of %zu choices, %zu + %zu sequences left, stalled %d, bound %u\n", anl.size(), nLiveA, nLiveB, (int)stalled, chain_wmax());
     if (nLiveA + nLiveB > 0) {
-        if (nLiveA && nLiveB && chain_wmax() >= minl) { *why = "sequences without a match between them that hold a repeat of minl characters"; return 0; }
-        steps++; maxdepth = depth;
+        if (stalled || (nLiveA && nLiveB && chain_wmax() >= minl)) {
+            for (size_t c = 0; c < nA; c++) if (liveA[c]) { cb.lin_rest.push_back(CA[c].begin); cb.lin_rest.push_back(CA[c].end); }
+            for (size_t c = 0; c < nB; c++) if (liveB[c]) { cb.lin_rest.push_back(CB[c].begin); cb.lin_rest.push_back(CB[c].end); }
+        } else { steps++; maxdepth = depth; }
     }
     // ---- to the device: the roots, the look-up tables of k_cas_assign_roots, the chain's anchors
     const u32 R = (u32)roots.size(), P = (u32)anl.size();
@@ -977,7 +985,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         if (chain) {
             const char *why = nullptr;
             RV_TRY(cas_lineage(h, cb, M, NW, minl, CA, CB, &why));
-            if (why) { cb.lin_picks = 0; GIVE_UP(why); }
+            if (why) { cb.lin_picks = 0; cb.lin_rest.clear(); GIVE_UP(why); }
         }
     } else {
         if (chain && cb.lin_picks == 0) GIVE_UP("the chain of rest sub-indices was not decided");

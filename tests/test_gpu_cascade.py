@@ -288,7 +288,8 @@ def test_cascade_with_several_sequences_per_sample(tmp_path, monkeypatch, sa64):
     interval per sample form the chain root -> rest -> rest ..., decided on the host from the match list; their leading / trailing
     children are the roots of the device cascade (rv_cascade.hip "the lineage of rest sub-indices").  Anchors, text and counters equal
     the oracle's literal recursion: contigs cut at different places in the two samples, in another order, contigs without a partner,
-    contigs shorter than minl, one sample in one piece; and an input whose left-over contigs share a repeat (the chain gives up)"""
+    contigs shorter than minl, one sample in one piece; and inputs whose left-over contigs share a repeat or only chance matches (the chain stops
+    at that member, which becomes the level pipeline's frontier: one split of the root with the consumed sequences dropped)"""
     rng = random.Random(17)
 
     def rnd(L):
@@ -314,7 +315,11 @@ def test_cascade_with_several_sequences_per_sample(tmp_path, monkeypatch, sa64):
     cases.append(("one piece against seven", [base], cut(var, 7), True))
     cases.append(("unrelated extra contigs", cut(base, 3) + [rnd(5000)], [rnd(7000)] + cut(var, 4), True))
     cases.append(("tiny contigs", cut(base, 3) + ["ACGTACGT", "A"], ["ACG"] + cut(var, 3) + ["TTGACA"], True))
-    cases.append(("left-over contigs share a repeat", cut(base, 2) + [rnd(3000) + rep + rnd(2000)], cut(var, 2) + [rnd(1000) + rep + rnd(4000)], None))
+    # a chain member the match list does not decide becomes the level pipeline's frontier, the cascade keeps the roots it has
+    cases.append(("left-over contigs share a repeat", cut(base, 2) + [rnd(3000) + rep + rnd(2000)], cut(var, 2) + [rnd(1000) + rep + rnd(4000)], True))
+    c3, c4 = cut(base, 9), cut(var, 7)
+    rng.shuffle(c4)
+    cases.append(("many contigs, shuffled: chance matches between the left-overs", c3, c4, True))
     done = 0
     for k, (what, a, b, want) in enumerate(cases):
         inputs = [_write_fasta(tmp_path / ("a%d.fa" % k), a), _write_fasta(tmp_path / ("b%d.fa" % k), b)]
@@ -322,7 +327,7 @@ def test_cascade_with_several_sequences_per_sample(tmp_path, monkeypatch, sa64):
         done += bool(info["done"])
         if want:
             assert info["subindices"] > 100, (what, info)
-    assert done >= 4
+    assert done == len(cases)
     # the same through the level pipeline (what these inputs took before): identical by the same checks
     monkeypatch.setenv("RV_NO_CASCADE_CHAIN", "1")
     inputs = [_write_fasta(tmp_path / "a.fa", c1), _write_fasta(tmp_path / "b.fa", c2)]

@@ -1583,12 +1583,18 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
         __syncthreads();
     }
     const int64_t q0 = (int64_t)blockIdx.x * TB;
+    // the group ranks of the workgroup's entries and of the 64 behind them, once: where a group ends is asked entry by entry (every member walks to
+    // the end of its group: ten dependent loads each with ten samples)
+    __shared__ u32 s_G[TB + MEDIUM_GROUP + 1];
+    for (int x = threadIdx.x; x < TB + MEDIUM_GROUP + 1; x += TB) { const int64_t i = q0 + x; s_G[x] = G[i < m ? i : m - 1]; }
+    __syncthreads();
+    auto Gat = [&](int64_t i) -> u32 { const int64_t x = i - q0; return (x >= 0 && x <= TB + MEDIUM_GROUP) ? s_G[x] : G[i]; };
     if (q < m) {
-        const u32 g = G[q];
+        const u32 g = s_G[threadIdx.x];
         const u32 off = P[q] - g;
         const int64_t qs = q - (int64_t)off;                       // the group's first list entry (a group is contiguous in the list)
         const int64_t look = qs + MEDIUM_GROUP, i4 = qs + 4;
-        const u32 g_look = G[look < m ? look : m - 1], g_4 = G[i4 < m ? i4 : m - 1];
+        const u32 g_look = Gat(look < m ? look : m - 1), g_4 = Gat(i4 < m ? i4 : m - 1);
         const u64 key_g = fo.keys[g];
         const bool big = off >= (u32)MEDIUM_GROUP || (look < m && g_look == g);
         const bool self = !big && i4 < m && g_4 == g;
@@ -1597,7 +1603,7 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
         const u32 stop0 = key_first_stop(key_g, fo.kd);
         if (self) {
             int size = (int)off + 1;
-            while (qs + size < m && G[qs + size] == g) size++;
+            while (qs + size < m && Gat(qs + size) == g) size++;
             const sav_t mine = S[q];
             int rank = 0; bool tie_before = false; u32 best = 0;
             const u64 key_mine = fo.keys[(size_t)g + off];
@@ -1610,22 +1616,26 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
                 bool hinted = false;
                 sav_t other;
                 if (in_lds) {
-                    // hint_cmp(other, mine) on what the entries left in LDS
+                    // hint_cmp(other, mine) on what the entries left in LDS, without a branch (written with nested ifs the loop was 1 800 scalar
+                    // instructions per wave of exec-mask bookkeeping beside its 1 300 vector ones)
                     const int x = (int)(qs - q0) + j;
                     other = p_suf[x];
                     const u32 oi = p_info[x];
                     const u32 so_ = oi & 15u, sm_ = my_info & 15u;
-                    if (so_ != 15u && sm_ != 15u && so_ != sm_ && p_base[x] == my_base) {
-                        const bool ko = so_ != 0u && (oi & 16u), km = sm_ != 0u && (my_info & 16u);
-                        const bool lto = (oi & 32u) != 0, ltm = (my_info & 32u) != 0;
-                        const u32 ao = oi >> 8, am = my_info >> 8;
-                        if (so_ == 0u) { if (km) { c = ltm ? 1 : -1; l = am; hinted = true; } }
-                        else if (sm_ == 0u) { if (ko) { c = lto ? -1 : 1; l = ao; hinted = true; } }
-                        else if (ko && km) {
-                            if (lto != ltm) { c = lto ? -1 : 1; l = ao < am ? ao : am; hinted = true; }
-                            else if (ao != am) { l = ao < am ? ao : am; c = ((ao < am) == lto) ? -1 : 1; hinted = true; }
-                        }
-                    }
+                    const bool same = (so_ != 15u) & (sm_ != 15u) & (so_ != sm_) & (p_base[x] == my_base);
+                    const bool ko = (so_ != 0u) & ((oi & 16u) != 0u), km = (sm_ != 0u) & ((my_info & 16u) != 0u);
+                    const bool lto = (oi & 32u) != 0u, ltm = (my_info & 32u) != 0u;
+                    const u32 ao = oi >> 8, am = my_info >> 8;
+                    const u32 mn = ao < am ? ao : am;
+                    const bool c0 = (so_ == 0u) & km;                                   // the other one is the base: my hint
+                    const bool c1 = (so_ != 0u) & (sm_ == 0u) & ko;                     // I am the base: its hint
+                    const bool both = (so_ != 0u) & (sm_ != 0u) & ko & km;
+                    const bool c2 = both & (lto != ltm);                                // different sides of the base
+                    const bool c3 = both & (lto == ltm) & (ao != am);                   // the same side: who leaves the base first
+                    hinted = same & (c0 | c1 | c2 | c3);
+                    l = c0 ? am : c1 ? ao : mn;
+                    const bool other_smaller = c0 ? !ltm : c1 ? lto : c2 ? lto : ((ao < am) == lto);
+                    c = other_smaller ? -1 : 1;
                 } else {
                     other = S[qs + j];
                     hinted = hint_cmp(fo.kd, (int64_t)other, fo.keys[(size_t)g + j], (int64_t)mine, key_mine, &c, &l);
@@ -1644,7 +1654,7 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
         } else if (!big && off == 0) {
             // a pair of twins is finished here, from its keys; everything else needs the text at least once: the work list
             const int64_t q2 = q + 2 < m ? q + 2 : m - 1, r1 = (int64_t)g + 1 < n ? (int64_t)g + 1 : n - 1;
-            const u32 g_2 = G[q2];
+            const u32 g_2 = Gat(q2);
             const sav_t s0 = S[q], s1 = S[q + 1 < m ? q + 1 : m - 1];
             const u64 key_1 = fo.keys[r1];
             const bool pair = !(q + 2 < m && g_2 == g);

@@ -1,6 +1,6 @@
 # what profiles/ holds for round 4 (run on the GPU box): bash tools/collect_r4.sh OUTNAME
 set -x
-OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
+NAME=$1; OUT=$PWD/gpurun_out/$NAME; mkdir -p $OUT
 R=$PWD
 export TMPDIR=/tmp
 python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
@@ -22,6 +22,6 @@ cd $R
 python tools/pmc_summary.py $OUT/pmc_fetch $OUT/pmc_write k_scan_pair "2x250000000-32" > $OUT/pmc_scan_c4.json
 python tools/pmc_all.py $OUT/pmc_fetch $OUT/pmc_write 40 > $OUT/pmc_traffic_c4.txt
 rm -rf $OUT/pmc_fetch $OUT/pmc_write
-bash tools/pmc_wrreq.sh $1/wr $R/bench.py --steps 2 --warmup 1 --no-cpu --no-extra --no-check > /dev/null 2>&1
+bash tools/pmc_wrreq.sh $NAME/wr $R/bench.py --steps 2 --warmup 1 --no-cpu --no-extra --no-check > /dev/null 2>&1
 python tools/ubench/radix_time.py > $OUT/radix_variants.txt 2>&1
 python tools/mem_probe.py 250e6 > $OUT/mem_probe.txt 2>&1

@@ -121,17 +121,26 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
     const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     // the ranks where an interval can end at all (a value of minl or more, larger than the next one): one in k for related samples.  Every rank
     // walking its window made a wave run the long path for its few lanes that needed it; the candidates are listed in LDS and walked densely
+    {
+        // a thread looks at MS_ITEMS ranks in a row (one reservation per wave: ranked one round of 256 strided ranks at a time, the kernel spent
+        // its time on eight ballots and eight returning LDS atomics per wave)
+        const int t0 = (int)threadIdx.x * MS_ITEMS;
+        u32 v[MS_ITEMS + 1];
 #pragma unroll
-    for (int r = 0; r < MS_ITEMS; r++) {
-        const int t = r * TB + threadIdx.x;
-        const int x = t + HS;
-        const int64_t u = u0 + t;
-        const bool c = u < n && u - H >= 0 && sl[x] >= minl && sl[x] > sl[x + 1];
-        const u64 bal = __ballot(c);
+        for (int i = 0; i <= MS_ITEMS; i++) v[i] = sl[t0 + HS + i];
+        u32 mask = 0;
+#pragma unroll
+        for (int i = 0; i < MS_ITEMS; i++) {
+            const int64_t u = u0 + t0 + i;
+            mask |= (u32)((u < n) & (u - H >= 0) & (v[i] >= minl) & (v[i] > v[i + 1])) << i;
+        }
+        const u32 c = (u32)__popc(mask);
+        const u32 inc = rv_wave_incl_sum_u32(c);
         u32 base = 0;
-        if (lane == 0 && bal) base = atomicAdd(&ncand, (u32)__popcll(bal));
-        base = (u32)__shfl((int)base, 0, 64);
-        if (c) cand[base + (u32)__popcll(bal & lt)] = (uint16_t)t;
+        if (lane == 63 && inc) base = atomicAdd(&ncand, inc);
+        base = (u32)__shfl((int)base, 63, 64) + inc - c;
+#pragma unroll
+        for (int i = 0; i < MS_ITEMS; i++) if ((mask >> i) & 1u) cand[base++] = (uint16_t)(t0 + i);
     }
     __syncthreads();
     const u32 nc = ncand;
@@ -140,25 +149,19 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
         const int t = ok ? (int)cand[ci] : 0;
         const int x = t + HS;
         const int64_t u = u0 + t;
-        u32 v = 0;
-        if (ok) {
-            v = sl[x];
-            const u32 nxt = sl[x + 1];
-            for (int d = 1; d < H && ok; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; ok = v >= minl && v > nxt; }
-            ok = ok && sl[x - H] < v;
-            if (ok) {
-                u32 seen = 0;
-                for (int d = 0; d <= H && ok; d++) { const u32 bit = 1u << ss[x - d]; ok = !(seen & bit); seen |= bit; }
-            }
-            if (ok) {      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
-                bool mx = false;
-                for (int d = H; d >= 1 && !mx; d--) {
-                    const uint8_t ca = sb[x - d], cb = sb[x - d + 1];
-                    mx = cb == '$' || ca != cb || ca == 'N' || ca == '$' || (ca >= 'a' && ca <= 'z');
-                }
-                ok = mx;
-            }
+        // every test over the whole window, no early exit: the trip counts are the same for every lane (written with `&& ok` in the loop
+        // conditions the kernel ran two scalar instructions of exec-mask bookkeeping for every vector one)
+        u32 v = sl[x];
+        const u32 nxt = sl[x + 1];
+        for (int d = 1; d < H; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; }
+        u32 seen = 0;
+        for (int d = 0; d <= H; d++) seen |= 1u << ss[x - d];
+        bool mx = false;      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
+        for (int d = 1; d <= H; d++) {
+            const uint8_t ca = sb[x - d], cb = sb[x - d + 1];
+            mx |= (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca >= 'a') & (ca <= 'z'));
         }
+        ok = ok & (v >= minl) & (v > nxt) & (sl[x - H] < v) & (__popc(seen) == H + 1) & mx;
         // (the list in CM_REGIONS regions with a counter each: one counter was 50 000 returning atomics on one address, 0.7 of the kernel's 0.9 ms)
         const u64 bal = __ballot(ok);
         if (bal) {
@@ -701,7 +704,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
             hipLaunchKernelGGL(k_casm_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), (const u32 *)bcc.as<u32>(), M, t, k,
                                (int64_t)minl);
             RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_casm_decide, dim3(1024), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)BN, banl.as<u32>(), banp.as<sa_t>(), acap);
+            hipLaunchKernelGGL(k_casm_decide, dim3(192), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)BN, banl.as<u32>(), banp.as<sa_t>(), acap);
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_casm_advance, dim3(1), dim3(64), 0, q, counters);
             RV_LAUNCH_CHECK();

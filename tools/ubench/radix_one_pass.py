@@ -1,5 +1,7 @@
+"""One radix pass on 8 key bits through the 256-bin kernel (flags 6) and the 1024-bin kernel (flags 7: what a symbol-aligned MSD digit of 625 bins
+would run on), uniform and DNA-key digits: what an MSD hybrid's global passes would cost.  python tools/ubench/radix_one_pass.py"""
 import ctypes, os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from reveal_amd import _lib
 lib = _lib.get(False)
 n = 290_000_000

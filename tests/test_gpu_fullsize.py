@@ -173,3 +173,27 @@ def test_cascade_and_level_pipeline_agree_at_full_size(monkeypatch, cfg):
     assert a[3] == b[3], (a[3], b[3])
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     assert np.array_equal(a[2], b[2])
+
+
+def test_c4_with_indels_equals_the_cpu_digests():
+    """2 x 250 Mbp with the reference simulator's mutation model (20 % of the events indels, reveal_amd/synth.py after utils/simulate.py:17-77):
+    the second sample leaves the fixed diagonal within a few hundred bases, construct follows piecewise diagonals from seeds (rv_construct.hip
+    k_diag_bits_tab) -- SA, LCP, the anchor set and the final text equal the CPU path's at full size (tests/golden/fullsize.json C4_indel_seed42)"""
+    from reveal_amd import reveallib
+    rec = check.golden_record(250_000_000, 2, 42, 0.2)
+    assert rec is not None
+    seqs = synth.genomes(250_000_000, 2, seed=42, indelfrac=0.2)
+    T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
+    assert len(T0) == rec["n"] and check.array_digest(T0) == rec["sha_input"]
+    idx = reveallib.index()
+    for k, s in enumerate(seqs):
+        idx.addsample("g%d" % k)
+        idx.addsequence(s)
+    idx.construct()
+    st = idx.sa_stats()
+    assert st["diag_table"] == 1 and st["sorted_elems"] < 0.7 * idx.n, st          # the table was used, most twins left the sort
+    g = check.compare_with_golden(rec, SA=idx.array("SA"), LCP=idx.array("LCP"))
+    assert g["all"], g
+    res = idx.align_builtin(20, 2)
+    g = check.compare_with_golden(rec, anchors=res["anchors"], T_final=idx.array("T"))
+    assert g["all"], (g, idx.cascade_info())

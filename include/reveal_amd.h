@@ -308,7 +308,8 @@ int rv_test_exclusive_sum_u32(const uint32_t *in, uint32_t *out, int64_t n);
 int rv_test_inclusive_max_u32(const uint32_t *in, uint32_t *out, int64_t n);
 int rv_test_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, int bit_lo, int bit_hi);
 /* the same sort timed on device-made keys (HIP events on its stream): dist 0 uniform, 1 first keys of a DNA text (base-5 digits 1..4),
- * 2 constant; flags: 1 = 10-bit digits, 2 = XCD-aware tile order, 4 = 16-bit wave counters; *bad = pairs out of order afterwards */
+ * 2 constant; flags: 1 = 10-bit digits, 2 = XCD-aware tile order, 4 = 16-bit wave counters, 8 = histograms from the keys (no digit bytes);
+ * *bad = pairs out of order afterwards */
 int rv_test_radix_time(int64_t n, int bits, int dist, int flags, int iters, double *ms, int64_t *bad);
 
 #ifdef __cplusplus

@@ -868,7 +868,7 @@ int rv_test_radix_sort(uint64_t *keys, uint32_t *vals, int64_t n, int bit_lo, in
 
 /* Timing of the radix sort on keys made on the device (tools/ubench/radix_time.py): n pairs, the low `bits` bits of the keys sorted.
  * dist 0: uniform bits; 1: the digits of a base-5 number of 17 symbols drawn from {1..4} (the first keys of a DNA text); 2: constant.
- * flags: bit 0 = 10-bit digits, bit 1 = XCD-aware tile order, bit 2 = 16-bit wave counters.  ms[it] = duration of the whole sort by HIP
+ * flags: bit 0 = 10-bit digits, bit 1 = XCD-aware tile order, bit 2 = 16-bit wave counters, bit 3 = no digit bytes.  ms[it] = duration of the whole sort by HIP
  * events on the sort's own stream; *bad = adjacent pairs out of order (keys, then original index: stability) after the last one. */
 }
 namespace {

@@ -290,14 +290,18 @@ __global__ __launch_bounds__(TB) void k_cas_lgather(const sa_t *__restrict__ c_p
 }
 
 // ---- one level ----
+constexpr int CAS_ITEMS = 8;
 __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child,
                                                    u32 M, const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
                                                    const CasIv *__restrict__ iv, const CasRes *__restrict__ res, u64 *__restrict__ best, u32 *__restrict__ wmax,
                                                    int64_t minl, int first, const u64 *__restrict__ ceil /* second attempt: bids stay below it (0: none) */) {
-    const u32 t = blockIdx.x * TB + threadIdx.x;      // (the grid covers the matches in whole workgroups, then the witnesses)
-    const u32 mblocks = (M + TB - 1) / TB;
+    // (the grid covers the matches in whole workgroups, then the witnesses.)  A workgroup takes CAS_ITEMS stretches of TB entries, a wave 64 consecutive
+    // ones at a time: at the deep levels most entries are dead, and a workgroup per 256 of them was bound by the dispatch of 8 600 workgroups that
+    // only read one word each -- 33 us per level however few matches were alive
+    const u32 mblocks = (M + TB * CAS_ITEMS - 1) / (TB * CAS_ITEMS);
+    for (int it = 0; it < CAS_ITEMS; it++) {
     if (blockIdx.x < mblocks) {
-        const u32 i = t;
+        const u32 i = (blockIdx.x * CAS_ITEMS + (u32)it) * TB + threadIdx.x;
         u32 c = i < M ? c_child[i] : NONE;
         bool live = c != NONE;
         u64 key = 0;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
         if (live && ceil) { const u64 ce = ceil[c]; bid = ce == 0 || key < ce; }
         seg_atomic_max64(best, c, key, bid);
     } else {
-        const u32 i = t - mblocks * TB;
+        const u32 i = ((blockIdx.x - mblocks) * CAS_ITEMS + (u32)it) * TB + threadIdx.x;
         u32 c = i < NW ? w_child[i] : NONE;
         bool live = c != NONE;
         u32 v = 0;
@@ -357,6 +361,7 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
             }
         }
         seg_atomic_max32(wmax, c, v, live);
+    }
     }
 }
 
@@ -1049,7 +1054,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     if (verbose) { (void)hipStreamSynchronize(q); tp[2] = cas_now(); }
     // ---- the levels: queued in batches, the level's range of sub-indices lives on the device (k_cas_advance), the host only looks
     // at the counters between batches (a level on an empty range costs its launches, nothing else)
-    const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
+    const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB * CAS_ITEMS) + ceil_div((int64_t)NW, TB * CAS_ITEMS));
     const int batch = std::max(1, (int)ws.opt.cascade_batch);
     int queued = 0;
     for (;;) {

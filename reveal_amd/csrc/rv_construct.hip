@@ -485,6 +485,189 @@ __global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T,
     }
 }
 
+// k_init_keys for alphabets whose half keys fit 24 bits (radix^ceil(K / 2) < 2^24 and K <= 32: DNA at every size).  The kernel above is
+// bound by its instructions, not by its 4.8 GB (551 vector instructions per wave of 256 positions at 2 x 250 Mbp, SQ_INSTS_VALU: 1.75 of
+// its 2.8 ms), most of them 64-bit multiplies (quarter rate), the stop tests of K symbols and the hint's bit reads per position:
+//   * the key as two halves of Kh and Kl symbols, each kept with 24-bit multiply-adds (full rate) and joined by one 64-bit mad per key;
+//   * which codes are stops as one bit per position in LDS (eight threads' four bits joined by three DPP moves): the first stop among a
+//     key's K symbols is a funnel shift and a count of trailing zeros;
+//   * the hint's marked position, exception and order bit stay in registers until the window has moved past the position;
+//   * a tile of the second sample whose twins leave (tw_off) only makes the keys that stay: their positions as a list in LDS, one key per
+//     thread from its K symbols -- at 1 % divergence 164 of 1024 positions, written next to each other.
+struct KeyHalves { int Kh, Kl; u32 powh, powl, mull; };      // radix^(Kh-1), radix^(Kl-1), radix^Kl
+__device__ inline u32 ik_first_stop(const u32 *s_sc, int k, u32 maskK, u32 at_none) {
+    const u32 win = __funnelshift_r(s_sc[k >> 5], s_sc[(k >> 5) + 1], (u32)(k & 31)) & maskK;
+    return win ? (u32)__builtin_ctz(win) : at_none;
+}
+// the next marked position at or behind k among the staged words (tile coordinates), or far behind everything
+constexpr int IK_FAR = 1 << 28;
+__device__ inline int ik_next_mark(const u64 *s_stop, int k) {
+    int wi = k >> 6;
+    const u64 mw = s_stop[wi] >> (k & 63);
+    if (mw) return k + __builtin_ctzll(mw);
+    for (wi++; wi < ND_WORDS; wi++) if (s_stop[wi] != 0ull) return wi * 64 + __builtin_ctzll(s_stop[wi]);
+    return IK_FAR;
+}
+__global__ __launch_bounds__(TB) void k_init_keys_n(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
+                                                    u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
+                                                    KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off, KeyHalves kh) {
+    __shared__ u32 code32[(KEY_TILE + 64) / 4];
+    __shared__ u32 s_sc[(KEY_TILE + 64) / 32 + 1];      // bit k: code[k] is a stop ('$', 'N', past the end)
+    __shared__ uint8_t slut[256];
+    __shared__ u64 s_stop0[ND_WORDS + 1], s_exc[ND_WORDS], s_lt[ND_WORDS];
+    __shared__ u64 s_tw[KEY_TILE / 64], s_keep[KEY_TILE / 64];
+    __shared__ u32 s_kpre[KEY_TILE / 64 + 1];
+    __shared__ uint16_t s_list[KEY_TILE];
+    u64 *const s_stop = s_stop0 + 1;
+    const uint8_t *const code = reinterpret_cast<const uint8_t *>(code32);
+    slut[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
+    for (int wq = threadIdx.x; wq < (KEY_TILE + 64) / 4; wq += TB) {      // (the second turn: the first sixteen threads, whole groups of eight)
+        const int64_t i = base + 4 * wq;
+        u32 raw = 0;
+        if (i + 4 <= n) raw = *reinterpret_cast<const u32 *>(T + i);
+        else for (int r = 0; r < 4; r++) if (i + r < n) raw |= (u32)T[i + r] << (8 * r);
+        u32 c4 = 0, sb = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u32 c = (i + r < n) ? (u32)slut[(raw >> (8 * r)) & 0xffu] : 0u;
+            c4 |= c << (8 * r);
+            sb |= (u32)((c == stop0) | (c == stop1) | (c == 0u)) << r;
+        }
+        code32[wq] = c4;
+        int v = (int)(sb << (4 * (wq & 7)));
+        v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
+        v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);      // row_half_mirror: the other quad of the eight
+        if ((wq & 7) == 0) s_sc[wq >> 3] = (u32)v;
+    }
+    if (threadIdx.x == 0) s_sc[(KEY_TILE + 64) / 32] = 0u;
+    const bool hint = ly.nd_bits > 0;
+    const int64_t nwords = (n + 63) / 64;
+    if (hint && (int)threadIdx.x < ND_WORDS) {
+        const int64_t w = base / 64 + threadIdx.x;
+        const bool in = w < nwords;
+        s_stop[threadIdx.x] = in ? dg.stop[w] : ~0ull; s_exc[threadIdx.x] = in ? dg.exc[w] : ~0ull; s_lt[threadIdx.x] = in ? dg.lt[w] : 0ull;
+    }
+    if (hint && threadIdx.x == ND_WORDS) s_stop0[0] = base > 0 ? dg.stop[base / 64 - 1] : ~0ull;
+    __syncthreads();
+    if (tw_off) {
+        if (threadIdx.x < KEY_TILE / 64) {
+            const int x = threadIdx.x;
+            const int64_t w = base / 64 + x;
+            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n, dg.tab);
+            s_tw[x] = t; s_keep[x] = tw_range(w, dg.D, n) & ~t;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { u32 run = 0; for (int x = 0; x < KEY_TILE / 64; x++) { s_kpre[x] = run; run += (u32)__popcll(s_keep[x]); } s_kpre[KEY_TILE / 64] = run; }
+        __syncthreads();
+    }
+    const u32 at_none = (1u << ly.at_bits) - 1u;
+    const int nd_none = hint ? (int)((1u << ly.nd_bits) - 1u) : 0;
+    const u32 maskK = K >= 32 ? ~0u : (1u << K) - 1u;
+    const int Kh = kh.Kh, Kl = kh.Kl;
+    if (tw_off && base >= dg.D) {
+        // ---- a tile of the second sample: the keys of the suffixes that stay ----
+        {
+            const int t = (int)threadIdx.x, x = t >> 4, b = (t & 15) * 4;
+            const u64 kw = s_keep[x];
+            u32 nib = (u32)(kw >> b) & 15u;
+            if (nib) {
+                u32 at = s_kpre[x] + (u32)__popcll(kw & ((1ull << b) - 1ull));
+                while (nib) { s_list[at++] = (uint16_t)(4 * t + __builtin_ctz(nib)); nib &= nib - 1u; }
+            }
+        }
+        __syncthreads();
+        const u32 total = s_kpre[KEY_TILE / 64];
+        const int64_t obase = dg.D + (int64_t)tw_off[blockIdx.x];
+        for (u32 j = threadIdx.x; j < total; j += TB) {
+            const int k = (int)s_list[j];
+            const int64_t i = base + k;
+            u32 hi = 0, lo = 0;
+            for (int e = 0; e < Kh; e++) hi = __umul24(hi, radix) + code[k + e];
+            for (int e = 0; e < Kl; e++) lo = __umul24(lo, radix) + code[k + Kh + e];
+            u64 key = (u64)hi * kh.mull + lo;
+            if (pay) key |= ((u64)T[i - 1] << 56) | ((u64)ik_first_stop(s_sc, k, maskK, at_none) << ly.at_shift);
+            if (hint) {
+                u32 nd = (u32)nd_none, ltb = 0;
+                const int yy = ik_next_mark(s_stop, k);
+                if (yy - k < nd_none && !((s_exc[yy >> 6] >> (yy & 63)) & 1ull)) { nd = (u32)(yy - k); ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
+                key |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
+            }
+            keys[obase + j] = key; vals[obase + j] = (sav_t)i;
+        }
+        return;
+    }
+    // ---- every position of the tile: four in a row per thread, the halves rolled along ----
+    constexpr int PER = KEY_TILE / TB;
+    static_assert(PER == 4, "four bytes in front of four positions");
+    const int k0 = (int)threadIdx.x * PER;
+    const int64_t i0 = base + k0;
+    u64 okey[PER];
+    u32 prevb = 0;
+    if (pay) {
+        if (i0 >= 1 && i0 + PER - 1 <= n) __builtin_memcpy(&prevb, T + i0 - 1, 4);
+        else for (int r = 0; r < PER; r++) { const int64_t i = i0 + r; prevb |= (u32)((i > 0 && i <= n) ? T[i - 1] : (uint8_t)'$') << (8 * r); }
+    }
+    u32 hi = 0, lo = 0;
+    for (int e = 0; e < Kh; e++) hi = __umul24(hi, radix) + code[k0 + e];
+    for (int e = 0; e < Kl; e++) lo = __umul24(lo, radix) + code[k0 + Kh + e];
+    int yy = -1; bool ex = true; u32 ltb = 0;
+#pragma unroll
+    for (int r = 0; r < PER; r++) {
+        const int k = k0 + r;
+        if (r > 0) {
+            const u32 c_out = code[k - 1], c_mid = code[k - 1 + Kh], c_in = code[k - 1 + K];
+            hi = __umul24(hi - __umul24(c_out, kh.powh), radix) + c_mid;
+            lo = __umul24(lo - __umul24(c_mid, kh.powl), radix) + c_in;
+        }
+        u64 key = (u64)hi * kh.mull + lo;
+        if (pay) key |= ((u64)((prevb >> (8 * r)) & 0xffu) << 56) | ((u64)ik_first_stop(s_sc, k, maskK, at_none) << ly.at_shift);
+        if (hint) {
+            if (yy < k) {
+                yy = ik_next_mark(s_stop, k);
+                if (yy < IK_FAR) { ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull; ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
+            }
+            const bool known = (yy - k < nd_none) & !ex;
+            key |= ((u64)(known ? (u32)(yy - k) : (u32)nd_none) << ly.nd_shift) | ((u64)(known ? ltb : 0u) << (ly.nd_shift + ly.nd_bits));
+        }
+        okey[r] = key;
+    }
+    if (!tw_off || i0 + PER <= dg.D) {
+        sav_t oval[PER];
+#pragma unroll
+        for (int r = 0; r < PER; r++) { const int k = k0 + r; oval[r] = (sav_t)(i0 + r) | ((tw_off && ((s_tw[k >> 6] >> (k & 63)) & 1ull)) ? TW_FLAG : (sav_t)0); }
+        if (i0 + PER <= n) {
+            ulonglong2 *kd2 = reinterpret_cast<ulonglong2 *>(keys + i0);
+            kd2[0] = make_ulonglong2(okey[0], okey[1]); kd2[1] = make_ulonglong2(okey[2], okey[3]);
+            if constexpr (sizeof(sav_t) == 4) *reinterpret_cast<uint4 *>(vals + i0) = make_uint4((u32)oval[0], (u32)oval[1], (u32)oval[2], (u32)oval[3]);
+            else {
+                ulonglong2 *vd2 = reinterpret_cast<ulonglong2 *>(vals + i0);
+                vd2[0] = make_ulonglong2((u64)oval[0], (u64)oval[1]); vd2[1] = make_ulonglong2((u64)oval[2], (u64)oval[3]);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < PER; r++) if (i0 + r < n) { keys[i0 + r] = okey[r]; vals[i0 + r] = oval[r]; }
+        }
+    } else {
+        // the tile the second sample starts in
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int k = k0 + r;
+            const int64_t i = base + k;
+            if (i >= n) continue;
+            const int x = k >> 6, b = k & 63;
+            const bool twin = (s_tw[x] >> b) & 1ull;
+            if (i < dg.D) { keys[i] = okey[r]; vals[i] = (sav_t)i | (twin ? TW_FLAG : (sav_t)0); }
+            else if (!twin) {
+                const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
+                keys[o] = okey[r]; vals[o] = (sav_t)i;
+            }
+        }
+    }
+}
+
 // ---- group heads / ranks ------------------------------------------------------
 // head[j] = 1 if sorted key j starts a new group; seed[j] = head ? j : 0
 // LCP != NULL (the fused path of rv_build_sa): a head's LCP with its predecessor in the suffix array -- whichever member of the
@@ -2248,8 +2431,22 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     }
     u64 top_pow = 1;
     for (int e = 0; e + 1 < K; e++) top_pow *= radix;      // (radix^K fits 64 bits: the key does)
-    hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                       bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, top_pow);
+    // half keys of at most 24 bits (k_init_keys_n): DNA alphabets at every size
+    KeyHalves kh; kh.Kh = (K + 1) / 2; kh.Kl = K / 2; kh.powh = kh.powl = kh.mull = 0;
+    bool halves = K >= 2 && K <= 32 && T != nullptr && ((uintptr_t)T & 3u) == 0 && !ws.opt.init_keys_wide;
+    if (halves) {
+        u64 ph = 1, pl = 1;
+        for (int e = 0; e + 1 < kh.Kh && ph < (1ull << 24); e++) ph *= radix;
+        for (int e = 0; e + 1 < kh.Kl && pl < (1ull << 24); e++) pl *= radix;
+        halves = ph * radix < (1ull << 24);
+        kh.powh = (u32)ph; kh.powl = (u32)pl; kh.mull = (u32)(pl * radix);
+    }
+    if (halves)
+        hipLaunchKernelGGL(k_init_keys_n, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
+                           bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, kh);
+    else
+        hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
+                           bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, top_pow);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), nsort, 0, bits, &in1));

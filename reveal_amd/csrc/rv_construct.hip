@@ -310,9 +310,11 @@ __global__ __launch_bounds__(TB) void k_diag_bits_tab(const uint8_t *__restrict_
 constexpr sav_t TW_FLAG = (sav_t)1 << (sizeof(sav_t) * 8 - 1);
 // bit b: no marked position in [64 w + b - 1, 64 w + b + K - 1]    (prev / lo / hi = words w - 1, w, w + 1 of the stop bits)
 __device__ inline u64 tw_window_clear(u64 prev, u64 lo, u64 hi, int K) {
-    u64 acc = (lo << 1) | (prev >> 63) | lo;
-    for (int d = 1; d < K; d++) acc |= (lo >> d) | (hi << (64 - d));
-    return ~acc;
+    u64 a = lo, b = hi;      // bit q of (b : a): a mark in [q, q + m) -- doubled up to K, then one step for what is left
+    int m = 1;
+    while (2 * m <= K) { a |= (a >> m) | (b << (64 - m)); b |= b >> m; m *= 2; }
+    if (m < K) { const int d = K - m; a |= (a >> d) | (b << (64 - d)); }
+    return ~(a | (lo << 1) | (prev >> 63));
 }
 // bits of word w whose positions lie in [a, b)
 __device__ inline u64 tw_range(int64_t w, int64_t a, int64_t b) {
@@ -344,300 +346,299 @@ __global__ __launch_bounds__(TB) void k_tw_count(const u64 *__restrict__ stop, i
 // known; bit nd_shift + nd_bits: the suffix is smaller than its twin; [at_shift, at_shift + at_bits) first stop among the K
 // symbols, all ones = none; [56, 64) the byte in front of the suffix
 struct KeyLayout { int at_shift, at_bits, nd_shift, nd_bits; u64 sortmask; };
+// The sort key itself: the K symbols in FIELDS of g digits -- a field is its g codes read as a base-radix number, in fb = the bits of
+// radix^g - 1; the last field holds the gl <= g symbols that are left, in fbl bits.  Five-letter DNA: three digits in seven bits
+// (125 of 128 values), seventeen symbols in 5 x 7 + 5 = 40 bits -- what one base-5 number of seventeen digits needs, too.  One number
+// was what the first key used to be; taking it apart again costs divisions: the common prefix of two neighbouring keys (a head's LCP,
+// k_heads_publish_tc) took ten multiply-high steps per head, most of that kernel's 470 vector instructions per entry, and rolling a
+// 40-bit number along the text most of k_init_keys'.  With fields the first differing field is a count of leading zeros of a ^ b, the
+// digits inside it two multiplies, and a key is its fields' values side by side: k_init_keys makes every position's field value once
+// (in LDS) and a key is nf reads of them.  The order of the keys is the order of the symbol strings either way.
+struct KeyPack { int g, fb, nf, gl, fbl, bits; u32 rad, fmask, lmask, lscale /* radix^(g - gl) */, fdiv /* t / fb = (t * fdiv) >> 16, t < 64 */;
+                 u32 lastmul /* the first gl digits of a field value: (f * lastmul) >> 20 */, dmul[4]; };      // f / radix^(g - i) = (f * dmul[i - 1]) >> 20 for f < radix^g (i = 1 .. g - 1: a field's first i digits)
+constexpr int KP_MAXG = 5;
+constexpr u32 KP_MAXFIELD = 4096;      // radix^g <= this: the reciprocals are exact (checked when the layout is chosen) and a field fits 16 bits
+// number of leading symbols (of K) two different keys share
+__device__ inline u32 key_common_digits(u64 x, u64 y, const KeyPack &kp) {
+    const u64 d = x ^ y;
+    if (d == 0ull) return (u32)((kp.nf - 1) * kp.g + kp.gl);
+    const int top = 63 - __builtin_clzll(d);
+    const bool last = top < kp.fbl;
+    const u32 f = last ? (u32)(kp.nf - 1) : ((u32)(kp.bits - 1 - top) * kp.fdiv) >> 16;
+    const int sh = last ? 0 : kp.bits - (int)(f + 1u) * kp.fb;
+    const u32 fm = last ? kp.lmask : kp.fmask, sc = last ? kp.lscale : 1u;
+    const u32 a = __umul24((u32)(x >> sh) & fm, sc), b = __umul24((u32)(y >> sh) & fm, sc);
+    u32 c = f * (u32)kp.g;
+#pragma unroll
+    for (int i = 1; i < KP_MAXG; i++)
+        if (i < kp.g) c += ((a * kp.dmul[i - 1]) >> 20) == ((b * kp.dmul[i - 1]) >> 20) ? 1u : 0u;
+    return c;
+}
 constexpr int ND_WORDS = 40;      // the words of the diagonal bit arrays a block of k_init_keys stages: KEY_TILE / 64 + up to 1536 positions ahead
-__global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                  u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
-                                                  KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off /* != NULL: twins leave (k_tw_count's scan) */, u64 top_pow /* radix^(K-1) */) {
-    __shared__ uint8_t code[KEY_TILE + 64];
-    __shared__ uint8_t slut[256];
+// ---- k_init_keys ----
+// A workgroup takes a tile of KEY_TILE positions:
+//   * the text as words, translated to codes in LDS; which codes are stops ('$', 'N', past the end) as one bit per position (eight threads'
+//     four bits joined by three DPP moves): the first stop among a key's K symbols is a funnel shift and a count of trailing zeros;
+//   * every position's field value (its g codes) and the value of its first gl codes, once, as 16-bit words in LDS;
+//   * a key = the fields at k, k + g, k + 2 g, ... shifted together; four positions in a row per thread.  The hint's marked position,
+//     exception and order bit stay in registers until the window has moved past the position;
+//   * a tile of the second sample whose twins leave (tw_off) only makes the keys that stay: their positions as a list in LDS, one key
+//     per thread -- at 1 % divergence 164 of 1024 positions, written next to each other.
+// (One base-radix number per key, rolled along the text with 64-bit multiplies, K stop tests and the hint's bit reads per position: 551
+// vector instructions per wave of 256 positions, SQ_INSTS_VALU -- 1.75 of the kernel's 2.8 ms at 2 x 250 Mbp were its instructions.)
+constexpr int IK_AHEAD = 96;                             // codes staged behind the tile: K - 1 + g - 1 <= 68, rounded to whole groups of eight words
+constexpr int IK_WORDS = (KEY_TILE + IK_AHEAD) / 4;      // code words
+constexpr int IK_FPOS = KEY_TILE + 64;                   // positions that get a field value
+__device__ inline u32 ik_first_stop(const u32 *s_sc, int k, int K, u32 at_none) {
+    const int w = k >> 5, sh = k & 31;
+    if (K <= 32) {
+        const u32 win = __funnelshift_r(s_sc[w], s_sc[w + 1], (u32)sh) & (K >= 32 ? ~0u : (1u << K) - 1u);
+        return win ? (u32)__builtin_ctz(win) : at_none;
+    }
+    u64 win = (((u64)s_sc[w + 1] << 32) | s_sc[w]) >> sh;
+    if (sh) win |= (u64)s_sc[w + 2] << (64 - sh);
+    win &= K >= 64 ? ~0ull : (1ull << K) - 1ull;
+    return win ? (u32)__builtin_ctzll(win) : at_none;
+}
+// a key's fields side by side as two 32-bit halves: the whole fields from bit kp.bits down, the last one at bit 0.  The shifts are the same for
+// every thread -- which half a field goes to is decided on the scalar side, a field costs a shift-or per key
+template <int G, int N> __device__ inline void ik_fields(const volatile uint16_t *s_tf, int p, const KeyPack &kp, u32 (&lo)[N], u32 (&hi)[N]) {
+#pragma unroll
+    for (int r = 0; r < N; r++) lo[r] = hi[r] = 0u;
+    int sh = kp.bits;
+    for (int f = 0; f + 1 < kp.nf; f++, p += G) {
+        sh -= kp.fb;
+        u32 v[N];
+#pragma unroll
+        for (int r = 0; r < N; r++) v[r] = s_tf[p + r];
+        if (sh >= 32) {
+#pragma unroll
+            for (int r = 0; r < N; r++) hi[r] |= v[r] << (sh - 32);
+        } else {
+#pragma unroll
+            for (int r = 0; r < N; r++) lo[r] |= v[r] << sh;
+            if (sh + kp.fb > 32) {
+#pragma unroll
+                for (int r = 0; r < N; r++) hi[r] |= v[r] >> (32 - sh);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < N; r++) lo[r] |= ((u32)s_tf[p + r] * kp.lastmul) >> 20;      // the first gl of the g codes
+}
+// what a thread brings in for a tile ahead of time: its text word(s) and, for the first threads, the words of the diagonal bit arrays
+struct IkFetch { u32 raw0, raw1, pb; u64 ds, de, dl; };
+__device__ inline u32 ik_text_word(const uint8_t *__restrict__ T, int64_t n, int64_t i, bool whole) {
+    if (whole) return *reinterpret_cast<const u32 *>(T + i);
+    u32 raw = 0;
+    for (int r = 0; r < 4; r++) if (i + r < n) raw |= (u32)T[i + r] << (8 * r);
+    return raw;
+}
+__device__ inline void ik_fetch(IkFetch &f, const uint8_t *__restrict__ T, int64_t n, const DiagBits &dg, bool hint, int64_t tile, bool aligned) {
+    const int64_t base = tile * KEY_TILE;
+    const bool whole = aligned && base + KEY_TILE + IK_AHEAD <= n;      // every staged word lies inside the text
+    f.raw0 = ik_text_word(T, n, base + 4 * (int64_t)threadIdx.x, whole);
+    f.raw1 = (int)threadIdx.x < IK_WORDS - TB ? ik_text_word(T, n, base + 4 * (int64_t)(TB + threadIdx.x), whole) : 0u;
+    f.pb = (threadIdx.x == 0 && base > 0) ? (u32)T[base - 1] : (u32)'$';      // the byte in front of the tile ('$' in front of the text)
+    f.ds = ~0ull; f.de = ~0ull; f.dl = 0ull;
+    if (hint && (int)threadIdx.x <= ND_WORDS) {      // words base / 64 - 1 ... : thread 0 brings the word in front of the tile
+        const int64_t w = base / 64 - 1 + threadIdx.x, nwords = (n + 63) / 64;
+        if (w >= 0 && w < nwords) { f.ds = dg.stop[w]; if (threadIdx.x) { f.de = dg.exc[w]; f.dl = dg.lt[w]; } }
+    }
+}
+// The kernel is persistent: a workgroup takes tiles blockIdx.x, blockIdx.x + gridDim.x, ... and loads the next one's words before it works on
+// the current one.  One workgroup per tile spent its life waiting -- the table, then the text, then the stores, each a trip to memory with
+// eight workgroups of four waves per CU to hide it: 1.4 ms at 2 x 250 Mbp with the computation switched off, 1.75 with the stores switched off.
+// (Taking the tiles alternately from the two halves of the text -- second-sample tiles, few keys and few stores, between first-sample ones -- cost 0.15 ms.)
+template <int G>
+__global__ __launch_bounds__(TB) void k_init_keys(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut, int K, KeyPack kp,
+                                                  u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
+                                                  KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off /* != NULL: twins leave (k_tw_count's scan) */, int64_t ntiles) {
+    __shared__ u32 code32[IK_WORDS + 2];
+    __shared__ u32 s_sc[IK_WORDS / 8 + 3];      // bit k: code[k] is a stop
+    __shared__ uint8_t slut[256], sstop[256];
+    __shared__ __align__(8) uint16_t s_tf[IK_FPOS];      // the g codes from k on as a number
     __shared__ u64 s_stop0[ND_WORDS + 1], s_exc[ND_WORDS], s_lt[ND_WORDS];      // (s_stop0[0] = the word in front of the tile)
-    __shared__ u64 s_tw[KEY_TILE / 64], s_keep[KEY_TILE / 64];
-    __shared__ u32 s_kpre[KEY_TILE / 64];
-    u64 *const s_stop = s_stop0 + 1;
-    slut[threadIdx.x] = lut[threadIdx.x];
-    __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
-    for (int k = threadIdx.x; k < KEY_TILE + K; k += TB) {
-        const int64_t i = base + k;
-        code[k] = (i < n) ? slut[T[i]] : (uint8_t)0;
-    }
-    const bool hint = ly.nd_bits > 0;
-    const int64_t nwords = (n + 63) / 64;
-    if (hint && (int)threadIdx.x < ND_WORDS) {
-        const int64_t w = base / 64 + threadIdx.x;
-        const bool in = w < nwords;
-        s_stop[threadIdx.x] = in ? dg.stop[w] : ~0ull; s_exc[threadIdx.x] = in ? dg.exc[w] : ~0ull; s_lt[threadIdx.x] = in ? dg.lt[w] : 0ull;
-    }
-    if (hint && threadIdx.x == ND_WORDS) s_stop0[0] = base > 0 ? dg.stop[base / 64 - 1] : ~0ull;
-    __syncthreads();
-    if (tw_off) {
-        if (threadIdx.x < KEY_TILE / 64) {
-            const int x = threadIdx.x;
-            const int64_t w = base / 64 + x;
-            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n, dg.tab);
-            s_tw[x] = t; s_keep[x] = tw_range(w, dg.D, n) & ~t;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { u32 run = 0; for (int x = 0; x < KEY_TILE / 64; x++) { s_kpre[x] = run; run += (u32)__popcll(s_keep[x]); } }
-        __syncthreads();
-    }
-    const u32 at_none = (1u << ly.at_bits) - 1u;
-    const u32 nd_none = hint ? (1u << ly.nd_bits) - 1u : 0u;
-    // A thread takes four positions in a row: the first key from its K symbols, the next three from the one before (drop the leading
-    // symbol, shift, take the next one in) -- K multiply-adds per key made the kernel instruction-bound (3.9 ms for 4.8 GB at 2 x 250 Mbp);
-    // the first stop among the K symbols and the next marked position of the hint move along the same way.
-    constexpr int PER = KEY_TILE / TB;
-    const int k0 = (int)threadIdx.x * PER;
-    u64 okey[PER]; sav_t oval[PER]; bool oin[PER];
-    u64 key = 0;
-    u32 at = at_none;          // first of the K symbols that is a stop ('$', 'N', past the end)
-    int yy = -1;               // the hint's next marked position (tile coordinates), -1: to be looked for
-    u32 prevb = 0;             // the bytes in front of the four positions
-    if (pay) {
-        const int64_t i0 = base + k0;
-        if (i0 >= 1 && i0 + PER - 1 <= n) __builtin_memcpy(&prevb, T + i0 - 1, 4);
-        else for (int r = 0; r < PER; r++) { const int64_t i = i0 + r; prevb |= (u32)((i > 0 && i <= n) ? T[i - 1] : (uint8_t)'$') << (8 * r); }
-    }
-    static_assert(PER == 4, "four bytes in front of four positions");
-#pragma unroll
-    for (int r = 0; r < PER; r++) {
-        const int k = k0 + r;
-        const int64_t i = base + k;
-        oin[r] = i < n;
-        if (r == 0) {
-            for (int j = 0; j < K; j++) {
-                const u32 c = code[k + j];
-                key = key * radix + c;
-                at = ((at == at_none) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at;
-            }
-        } else {
-            const u32 c_out = code[k - 1], c_in = code[k - 1 + K];
-            key = (key - (u64)c_out * top_pow) * radix + c_in;
-            const bool in_stop = (c_in == stop0) | (c_in == stop1) | (c_in == 0u);
-            if (at == at_none) at = in_stop ? (u32)(K - 1) : at_none;
-            else if (at > 0) at -= 1;
-            else {      // the symbol that left was the first stop: look again
-                at = at_none;
-                for (int j = 0; j < K; j++) { const u32 c = code[k + j]; at = ((at == at_none) & ((c == stop0) | (c == stop1) | (c == 0u))) ? (u32)j : at; }
-            }
-        }
-        // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank
-        // travels with the key instead of being gathered from the text at the end ('$' for position 0).  Below it (the
-        // fused path needs keys of at most 48 bits): where the common prefix of this suffix with anything ends at the latest --
-        // k_heads and the text round read it instead of taking the key apart digit by digit (a function of the digits:
-        // keys that are equal in their digits are equal here too)
-        u64 prev = pay ? ((u64)((prevb >> (8 * r)) & 0xffu) << 56) | ((u64)at << ly.at_shift) : 0ull;
-        if (hint) {
-            // next marked position at or behind i, looked for in the staged words
-            u32 nd = nd_none, ltb = 0;
-            if (yy < k) {
-                int wi = k >> 6;
-                u64 mw = s_stop[wi] >> (k & 63);
-                int dist = 0;
-                if (mw) dist = __builtin_ctzll(mw);
-                else {
-                    dist = 64 - (k & 63);
-                    int ww = wi + 1;
-                    while (ww < ND_WORDS && s_stop[ww] == 0ull && dist < (int)nd_none) { dist += 64; ww++; }
-                    if (ww < ND_WORDS && s_stop[ww] != 0ull) dist += __builtin_ctzll(s_stop[ww]); else dist = (int)nd_none;
-                }
-                yy = dist < (int)nd_none ? k + dist : -1;
-            }
-            if (yy >= k && yy - k < (int)nd_none) {
-                const bool ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull;
-                if (!ex) { nd = (u32)(yy - k); ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
-            }
-            prev |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
-        }
-        okey[r] = key | prev; oval[r] = (sav_t)i;
-    }
-    const int64_t i0 = base + k0;
-    if (!tw_off || i0 + PER <= dg.D) {
-        // where they are (the first sample flagged when its twin leaves)
-        if (tw_off) {
-#pragma unroll
-            for (int r = 0; r < PER; r++) { const int k = k0 + r; if ((s_tw[k >> 6] >> (k & 63)) & 1ull) oval[r] |= TW_FLAG; }
-        }
-        if (i0 + PER <= n) {
-            ulonglong2 *kd2 = reinterpret_cast<ulonglong2 *>(keys + i0);
-            kd2[0] = make_ulonglong2(okey[0], okey[1]); kd2[1] = make_ulonglong2(okey[2], okey[3]);
-#pragma unroll
-            for (int r = 0; r < PER; r++) vals[i0 + r] = oval[r];
-        } else {
-#pragma unroll
-            for (int r = 0; r < PER; r++) if (oin[r]) { keys[i0 + r] = okey[r]; vals[i0 + r] = oval[r]; }
-        }
-    } else {
-#pragma unroll
-        for (int r = 0; r < PER; r++) {
-            if (!oin[r]) continue;
-            const int k = k0 + r;
-            const int64_t i = base + k;
-            const int x = k >> 6, b = k & 63;
-            const bool twin = (s_tw[x] >> b) & 1ull;
-            if (i < dg.D) { keys[i] = okey[r]; vals[i] = oval[r] | (twin ? TW_FLAG : (sav_t)0); }
-            else if (!twin) {
-                // what stays of the second sample behind the first, in text order
-                const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
-                keys[o] = okey[r]; vals[o] = (sav_t)i;
-            }
-        }
-    }
-}
-
-// k_init_keys for alphabets whose half keys fit 24 bits (radix^ceil(K / 2) < 2^24 and K <= 32: DNA at every size).  The kernel above is
-// bound by its instructions, not by its 4.8 GB (551 vector instructions per wave of 256 positions at 2 x 250 Mbp, SQ_INSTS_VALU: 1.75 of
-// its 2.8 ms), most of them 64-bit multiplies (quarter rate), the stop tests of K symbols and the hint's bit reads per position:
-//   * the key as two halves of Kh and Kl symbols, each kept with 24-bit multiply-adds (full rate) and joined by one 64-bit mad per key;
-//   * which codes are stops as one bit per position in LDS (eight threads' four bits joined by three DPP moves): the first stop among a
-//     key's K symbols is a funnel shift and a count of trailing zeros;
-//   * the hint's marked position, exception and order bit stay in registers until the window has moved past the position;
-//   * a tile of the second sample whose twins leave (tw_off) only makes the keys that stay: their positions as a list in LDS, one key per
-//     thread from its K symbols -- at 1 % divergence 164 of 1024 positions, written next to each other.
-struct KeyHalves { int Kh, Kl; u32 powh, powl, mull; };      // radix^(Kh-1), radix^(Kl-1), radix^Kl
-__device__ inline u32 ik_first_stop(const u32 *s_sc, int k, u32 maskK, u32 at_none) {
-    const u32 win = __funnelshift_r(s_sc[k >> 5], s_sc[(k >> 5) + 1], (u32)(k & 31)) & maskK;
-    return win ? (u32)__builtin_ctz(win) : at_none;
-}
-// the next marked position at or behind k among the staged words (tile coordinates), or far behind everything
-constexpr int IK_FAR = 1 << 28;
-__device__ inline int ik_next_mark(const u64 *s_stop, int k) {
-    int wi = k >> 6;
-    const u64 mw = s_stop[wi] >> (k & 63);
-    if (mw) return k + __builtin_ctzll(mw);
-    for (wi++; wi < ND_WORDS; wi++) if (s_stop[wi] != 0ull) return wi * 64 + __builtin_ctzll(s_stop[wi]);
-    return IK_FAR;
-}
-__global__ __launch_bounds__(TB) void k_init_keys_n(const uint8_t *__restrict__ T, int64_t n, const uint8_t *__restrict__ lut,
-                                                    u32 radix, int K, u64 *__restrict__ keys, sav_t *__restrict__ vals, int pay, u32 stop0, u32 stop1,
-                                                    KeyLayout ly, DiagBits dg, const u32 *__restrict__ tw_off, KeyHalves kh) {
-    __shared__ u32 code32[(KEY_TILE + 64) / 4];
-    __shared__ u32 s_sc[(KEY_TILE + 64) / 32 + 1];      // bit k: code[k] is a stop ('$', 'N', past the end)
-    __shared__ uint8_t slut[256];
-    __shared__ u64 s_stop0[ND_WORDS + 1], s_exc[ND_WORDS], s_lt[ND_WORDS];
     __shared__ u64 s_tw[KEY_TILE / 64], s_keep[KEY_TILE / 64];
     __shared__ u32 s_kpre[KEY_TILE / 64 + 1];
     __shared__ uint16_t s_list[KEY_TILE];
+    __shared__ u32 s_nm[64];      // the first marked position at or behind the start of word w: position << 2 | order bit << 1 | exception (all ones: none staged)
+    __shared__ u32 s_raw32[KEY_TILE / 4 + 1];      // the tile's bytes as words from word 1 on, the byte in front of the tile the last byte of word 0: T[base + k - 1] = s_raw[k + 3]
     u64 *const s_stop = s_stop0 + 1;
-    const uint8_t *const code = reinterpret_cast<const uint8_t *>(code32);
-    slut[threadIdx.x] = lut[threadIdx.x];
+    uint8_t *const s_raw = reinterpret_cast<uint8_t *>(s_raw32);
+    const bool hint = ly.nd_bits > 0;
+    const bool aligned = (reinterpret_cast<uintptr_t>(T) & 3u) == 0;
+    auto tile_of = [&](int64_t x) { return x; };
+    IkFetch fx;
+    int64_t x = blockIdx.x;
+    if (x < ntiles) ik_fetch(fx, T, n, dg, hint, tile_of(x), aligned);
+    {
+        const u32 c = lut[threadIdx.x];
+        slut[threadIdx.x] = (uint8_t)c;
+        sstop[threadIdx.x] = ((c == stop0) | (c == stop1) | (c == 0u)) ? 1 : 0;      // (byte 0 -- what is read past the end -- has code 0)
+        if (threadIdx.x < 2) code32[IK_WORDS + threadIdx.x] = 0u;
+        if (threadIdx.x < 3) s_sc[IK_WORDS / 8 + threadIdx.x] = ~0u;
+    }
     __syncthreads();
-    const int64_t base = (int64_t)blockIdx.x * KEY_TILE;
-    for (int wq = threadIdx.x; wq < (KEY_TILE + 64) / 4; wq += TB) {      // (the second turn: the first sixteen threads, whole groups of eight)
-        const int64_t i = base + 4 * wq;
-        u32 raw = 0;
-        if (i + 4 <= n) raw = *reinterpret_cast<const u32 *>(T + i);
-        else for (int r = 0; r < 4; r++) if (i + r < n) raw |= (u32)T[i + r] << (8 * r);
+    const u32 at_none = (1u << ly.at_bits) - 1u;
+    const int nd_none = hint ? (int)((1u << ly.nd_bits) - 1u) : 0;
+    for (; x < ntiles; x += gridDim.x) {
+    const int64_t tile = tile_of(x);
+    const int64_t base = tile * KEY_TILE;
+    // the words brought in ahead of time -> codes and stop bits in LDS
+#pragma unroll
+    for (int turn = 0; turn < 2; turn++) {      // (the second turn: the first 24 threads, whole groups of eight)
+        const int wq = (int)threadIdx.x + turn * TB;
+        if (wq >= IK_WORDS) break;
+        const u32 raw = turn ? fx.raw1 : fx.raw0;
         u32 c4 = 0, sb = 0;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const u32 c = (i + r < n) ? (u32)slut[(raw >> (8 * r)) & 0xffu] : 0u;
-            c4 |= c << (8 * r);
-            sb |= (u32)((c == stop0) | (c == stop1) | (c == 0u)) << r;
+            const u32 b = (raw >> (8 * r)) & 0xffu;
+            c4 |= (u32)slut[b] << (8 * r);
+            sb |= (u32)sstop[b] << r;
         }
         code32[wq] = c4;
+        if (turn == 0) s_raw32[1 + wq] = raw;
         int v = (int)(sb << (4 * (wq & 7)));
         v |= __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
         v |= __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);       // quad_perm [2,3,0,1]
         v |= __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);      // row_half_mirror: the other quad of the eight
         if ((wq & 7) == 0) s_sc[wq >> 3] = (u32)v;
     }
-    if (threadIdx.x == 0) s_sc[(KEY_TILE + 64) / 32] = 0u;
-    const bool hint = ly.nd_bits > 0;
-    const int64_t nwords = (n + 63) / 64;
-    if (hint && (int)threadIdx.x < ND_WORDS) {
-        const int64_t w = base / 64 + threadIdx.x;
-        const bool in = w < nwords;
-        s_stop[threadIdx.x] = in ? dg.stop[w] : ~0ull; s_exc[threadIdx.x] = in ? dg.exc[w] : ~0ull; s_lt[threadIdx.x] = in ? dg.lt[w] : 0ull;
+    if (threadIdx.x == 0) s_raw[3] = (uint8_t)fx.pb;
+    if (hint && (int)threadIdx.x <= ND_WORDS) {
+        s_stop0[threadIdx.x] = fx.ds;
+        if (threadIdx.x) { s_exc[threadIdx.x - 1] = fx.de; s_lt[threadIdx.x - 1] = fx.dl; }
     }
-    if (hint && threadIdx.x == ND_WORDS) s_stop0[0] = base > 0 ? dg.stop[base / 64 - 1] : ~0ull;
+    if (x + gridDim.x < ntiles) ik_fetch(fx, T, n, dg, hint, tile_of(x + gridDim.x), aligned);      // in flight while this tile is worked on
     __syncthreads();
-    if (tw_off) {
-        if (threadIdx.x < KEY_TILE / 64) {
-            const int x = threadIdx.x;
-            const int64_t w = base / 64 + x;
-            const u64 t = tw_mask(s_stop0[x], s_stop[x], s_stop[x + 1], w, K, dg.D, n, dg.tab);
-            s_tw[x] = t; s_keep[x] = tw_range(w, dg.D, n) & ~t;
+    // field values: a thread takes four positions in a row -- their codes are two words
+    for (int wq = threadIdx.x; wq < IK_FPOS / 4; wq += TB) {
+        const u64 cw = ((u64)code32[wq + 1] << 32) | code32[wq];
+        u32 f4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            u32 h = 0;
+#pragma unroll
+            for (int e = 0; e < G; e++) h = __umul24(h, kp.rad) + ((u32)(cw >> (8 * (j + e))) & 0xffu);
+            f4[j] = h;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) { u32 run = 0; for (int x = 0; x < KEY_TILE / 64; x++) { s_kpre[x] = run; run += (u32)__popcll(s_keep[x]); } s_kpre[KEY_TILE / 64] = run; }
-        __syncthreads();
+        *reinterpret_cast<uint2 *>(s_tf + 4 * wq) = make_uint2(f4[0] | (f4[1] << 16), f4[2] | (f4[3] << 16));
     }
-    const u32 at_none = (1u << ly.at_bits) - 1u;
-    const int nd_none = hint ? (int)((1u << ly.nd_bits) - 1u) : 0;
-    const u32 maskK = K >= 32 ? ~0u : (1u << K) - 1u;
-    const int Kh = kh.Kh, Kl = kh.Kl;
+    if (hint && (threadIdx.x >> 6) == 1) {      // the second wave: every word's first mark, then the nearest one at or behind each word (a minimum towards the front)
+        const int w = (int)threadIdx.x - 64;
+        u32 v = ~0u;
+        if (w < ND_WORDS && s_stop[w] != 0ull) {
+            const int b = __builtin_ctzll(s_stop[w]);
+            v = ((u32)(64 * w + b) << 2) | ((u32)((s_lt[w] >> b) & 1ull) << 1) | (u32)((s_exc[w] >> b) & 1ull);
+        }
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 o = __shfl_down(v, d, 64); if (w + d < 64 && o < v) v = o; }
+        s_nm[w] = v;
+    }
+    if (tw_off && threadIdx.x < KEY_TILE / 64) {      // sixteen lanes: a word each, the kept positions in front of it by a scan among them
+        const int xw = threadIdx.x;
+        const int64_t w = base / 64 + xw;
+        const u64 t = tw_mask(s_stop0[xw], s_stop[xw], s_stop[xw + 1], w, K, dg.D, n, dg.tab);
+        const u64 keep = tw_range(w, dg.D, n) & ~t;
+        s_tw[xw] = t; s_keep[xw] = keep;
+        const u32 c = (u32)__popcll(keep);
+        u32 inc = c;
+#pragma unroll
+        for (int d = 1; d < KEY_TILE / 64; d <<= 1) { const u32 up = __shfl_up(inc, d, KEY_TILE / 64); if (xw >= d) inc += up; }
+        s_kpre[xw] = inc - c;
+        if (xw == KEY_TILE / 64 - 1) s_kpre[KEY_TILE / 64] = inc;
+    }
+    __syncthreads();
     if (tw_off && base >= dg.D) {
         // ---- a tile of the second sample: the keys of the suffixes that stay ----
         {
-            const int t = (int)threadIdx.x, x = t >> 4, b = (t & 15) * 4;
-            const u64 kw = s_keep[x];
+            const int t = (int)threadIdx.x, xw = t >> 4, b = (t & 15) * 4;
+            const u64 kw = s_keep[xw];
             u32 nib = (u32)(kw >> b) & 15u;
             if (nib) {
-                u32 at = s_kpre[x] + (u32)__popcll(kw & ((1ull << b) - 1ull));
+                u32 at = s_kpre[xw] + (u32)__popcll(kw & ((1ull << b) - 1ull));
                 while (nib) { s_list[at++] = (uint16_t)(4 * t + __builtin_ctz(nib)); nib &= nib - 1u; }
             }
         }
         __syncthreads();
         const u32 total = s_kpre[KEY_TILE / 64];
-        const int64_t obase = dg.D + (int64_t)tw_off[blockIdx.x];
+        const int64_t obase = dg.D + (int64_t)tw_off[tile];
         for (u32 j = threadIdx.x; j < total; j += TB) {
             const int k = (int)s_list[j];
             const int64_t i = base + k;
-            u32 hi = 0, lo = 0;
-            for (int e = 0; e < Kh; e++) hi = __umul24(hi, radix) + code[k + e];
-            for (int e = 0; e < Kl; e++) lo = __umul24(lo, radix) + code[k + Kh + e];
-            u64 key = (u64)hi * kh.mull + lo;
-            if (pay) key |= ((u64)T[i - 1] << 56) | ((u64)ik_first_stop(s_sc, k, maskK, at_none) << ly.at_shift);
+            u32 lo[1], hi[1];
+            ik_fields<G, 1>(s_tf, k, kp, lo, hi);
+            u64 key = ((u64)hi[0] << 32) | lo[0];
+            if (pay) key |= ((u64)s_raw[k + 3] << 56) | ((u64)ik_first_stop(s_sc, k, K, at_none) << ly.at_shift);
             if (hint) {
-                u32 nd = (u32)nd_none, ltb = 0;
-                const int yy = ik_next_mark(s_stop, k);
-                if (yy - k < nd_none && !((s_exc[yy >> 6] >> (yy & 63)) & 1ull)) { nd = (u32)(yy - k); ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
-                key |= ((u64)nd << ly.nd_shift) | ((u64)ltb << (ly.nd_shift + ly.nd_bits));
+                const int wi = k >> 6, sft = k & 63;
+                const u64 A = s_stop[wi] >> sft;
+                const u32 nx = s_nm[wi + 1];
+                const bool has = A != 0ull;
+                const int d = has ? __builtin_ctzll(A) : (int)(nx >> 2) - k;      // to the next marked position: in this word / the first one of the words behind it
+                const int at = (sft + d) & 63;
+                const u32 f = has ? ((u32)((s_lt[wi] >> at) & 1ull) << 1) | (u32)((s_exc[wi] >> at) & 1ull) : nx & 3u;
+                const bool known = (d < nd_none) & !(f & 1u);
+                key |= (u64)(known ? (u32)d | ((f >> 1) << ly.nd_bits) : (u32)nd_none) << ly.nd_shift;
             }
             keys[obase + j] = key; vals[obase + j] = (sav_t)i;
         }
-        return;
-    }
-    // ---- every position of the tile: four in a row per thread, the halves rolled along ----
+    } else {
+    // ---- every position of the tile: four in a row per thread ----
+    // (a position per thread and four turns -- 16-bit field reads in different banks, a wave's stores one run -- took 30 % more instructions:
+    // what the four share -- the word's marks, the stop window, the byte in front -- is most of the work)
     constexpr int PER = KEY_TILE / TB;
     static_assert(PER == 4, "four bytes in front of four positions");
     const int k0 = (int)threadIdx.x * PER;
     const int64_t i0 = base + k0;
     u64 okey[PER];
-    u32 prevb = 0;
-    if (pay) {
-        if (i0 >= 1 && i0 + PER - 1 <= n) __builtin_memcpy(&prevb, T + i0 - 1, 4);
-        else for (int r = 0; r < PER; r++) { const int64_t i = i0 + r; prevb |= (u32)((i > 0 && i <= n) ? T[i - 1] : (uint8_t)'$') << (8 * r); }
-    }
-    u32 hi = 0, lo = 0;
-    for (int e = 0; e < Kh; e++) hi = __umul24(hi, radix) + code[k0 + e];
-    for (int e = 0; e < Kl; e++) lo = __umul24(lo, radix) + code[k0 + Kh + e];
-    int yy = -1; bool ex = true; u32 ltb = 0;
+    {
+        u32 lo[PER], hi[PER];
+        ik_fields<G, PER>(s_tf, k0, kp, lo, hi);
 #pragma unroll
-    for (int r = 0; r < PER; r++) {
-        const int k = k0 + r;
-        if (r > 0) {
-            const u32 c_out = code[k - 1], c_mid = code[k - 1 + Kh], c_in = code[k - 1 + K];
-            hi = __umul24(hi - __umul24(c_out, kh.powh), radix) + c_mid;
-            lo = __umul24(lo - __umul24(c_mid, kh.powl), radix) + c_in;
+        for (int r = 0; r < PER; r++) okey[r] = ((u64)hi[r] << 32) | lo[r];
+    }
+    if (pay) {
+        // bits 56..63 (above everything the sort looks at): the byte in front of the suffix -- the BWT byte of its rank travels with the key
+        // instead of being gathered from the text at the end ('$' for position 0).  Below it: where the common prefix of this suffix
+        // with anything ends at the latest (the first stop among its K symbols) -- k_heads and the text round read it off the key
+        const u32 prevb = (u32)s_raw[k0 + 3] | (s_raw32[threadIdx.x + 1] << 8);      // T[i0 - 1 .. i0 + 2]: the last byte of the word in front, three of the thread's own
+        // (no stop among the K + 3 codes from k0 on -- nearly every thread of a genome: none for all four)
+        const bool clear = K <= 29 && (__funnelshift_r(s_sc[k0 >> 5], s_sc[(k0 >> 5) + 1], (u32)(k0 & 31)) & ((1u << (K + 3)) - 1u)) == 0u;
+#pragma unroll
+        for (int r = 0; r < PER; r++)
+            okey[r] |= ((u64)((prevb >> (8 * r)) & 0xffu) << 56) | ((u64)(clear ? at_none : ik_first_stop(s_sc, k0 + r, K, at_none)) << ly.at_shift);
+    }
+    if (hint) {
+        // The next marked position of each of the four, without a branch (a wave covers 256 positions: at 1 % divergence some lane of it always
+        // has a mark among its own four, and a branch per case made every wave run every case -- 179 of 443 instructions): the word's marks from
+        // k0 on, the first one from the fourth position on (or the first one of the words behind), and the three bits in front of it
+        const int wi = k0 >> 6, sft = k0 & 63;
+        const u64 A = s_stop[wi] >> sft, E = s_exc[wi] >> sft, Lt = s_lt[wi] >> sft;
+        const u32 nx = s_nm[wi + 1];
+        const u64 Ah = A >> 3;
+        const bool hh = Ah != 0ull;
+        const int dh = hh ? 3 + __builtin_ctzll(Ah) : (int)(nx >> 2) - k0;      // relative to k0
+        const u32 fh = hh ? ((u32)((Lt >> (dh & 63)) & 1ull) << 1) | (u32)((E >> (dh & 63)) & 1ull) : nx & 3u;
+        const u32 a3 = (u32)A & 7u, e3 = (u32)E & 7u, l3 = (u32)Lt & 7u;
+#pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const u32 t = a3 >> r;
+            const int m = t ? r + __builtin_ctz(t) : dh;
+            const u32 f = t ? (((l3 >> m) & 1u) << 1) | ((e3 >> m) & 1u) : fh;
+            const int nd = m - r;
+            const bool known = (nd < nd_none) & !(f & 1u);
+            okey[r] |= (u64)(known ? (u32)nd | ((f >> 1) << ly.nd_bits) : (u32)nd_none) << ly.nd_shift;
         }
-        u64 key = (u64)hi * kh.mull + lo;
-        if (pay) key |= ((u64)((prevb >> (8 * r)) & 0xffu) << 56) | ((u64)ik_first_stop(s_sc, k, maskK, at_none) << ly.at_shift);
-        if (hint) {
-            if (yy < k) {
-                yy = ik_next_mark(s_stop, k);
-                if (yy < IK_FAR) { ex = (s_exc[yy >> 6] >> (yy & 63)) & 1ull; ltb = (u32)((s_lt[yy >> 6] >> (yy & 63)) & 1ull); }
-            }
-            const bool known = (yy - k < nd_none) & !ex;
-            key |= ((u64)(known ? (u32)(yy - k) : (u32)nd_none) << ly.nd_shift) | ((u64)(known ? ltb : 0u) << (ly.nd_shift + ly.nd_bits));
-        }
-        okey[r] = key;
     }
     if (!tw_off || i0 + PER <= dg.D) {
+        // where they are (the first sample flagged when its twin leaves)
+        const u32 twn = tw_off ? (u32)(s_tw[k0 >> 6] >> (k0 & 63)) & 15u : 0u;
         sav_t oval[PER];
 #pragma unroll
-        for (int r = 0; r < PER; r++) { const int k = k0 + r; oval[r] = (sav_t)(i0 + r) | ((tw_off && ((s_tw[k >> 6] >> (k & 63)) & 1ull)) ? TW_FLAG : (sav_t)0); }
+        for (int r = 0; r < PER; r++) oval[r] = (sav_t)(i0 + r) | (((twn >> r) & 1u) ? TW_FLAG : (sav_t)0);
         if (i0 + PER <= n) {
             ulonglong2 *kd2 = reinterpret_cast<ulonglong2 *>(keys + i0);
             kd2[0] = make_ulonglong2(okey[0], okey[1]); kd2[1] = make_ulonglong2(okey[2], okey[3]);
@@ -657,14 +658,18 @@ __global__ __launch_bounds__(TB) void k_init_keys_n(const uint8_t *__restrict__ 
             const int k = k0 + r;
             const int64_t i = base + k;
             if (i >= n) continue;
-            const int x = k >> 6, b = k & 63;
-            const bool twin = (s_tw[x] >> b) & 1ull;
+            const int xw = k >> 6, b = k & 63;
+            const bool twin = (s_tw[xw] >> b) & 1ull;
             if (i < dg.D) { keys[i] = okey[r]; vals[i] = (sav_t)i | (twin ? TW_FLAG : (sav_t)0); }
             else if (!twin) {
-                const int64_t o = dg.D + (int64_t)tw_off[blockIdx.x] + s_kpre[x] + (u32)__popcll(s_keep[x] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
+                // what stays of the second sample behind the first, in text order
+                const int64_t o = dg.D + (int64_t)tw_off[tile] + s_kpre[xw] + (u32)__popcll(s_keep[xw] & ((b == 0) ? 0ull : (~0ull >> (64 - b))));
                 keys[o] = okey[r]; vals[o] = (sav_t)i;
             }
         }
+    }
+    }
+    __syncthreads();      // (the next tile's codes overwrite what this one still reads)
     }
 }
 
@@ -676,8 +681,8 @@ __global__ __launch_bounds__(TB) void k_init_keys_n(const uint8_t *__restrict__ 
 constexpr int HINT_K = 16;      // samples the diagonal hint knows (the first ones)
 // D: diagonal of the second sample against the first (nsep[0] + 1).  ns / sep / Ds: samples, their separators and every sample's
 // diagonal against the FIRST sample (Ds[s] = nsep[s-1] + 1, where sample s starts when every sample is one sequence)
-struct KeyDigits { u64 magic; u32 radix; int K; u32 stop0, stop1; u64 pw[5], pmagic[5]; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K];
-                   const int32_t *dtab; u32 pw32[3], pm32[3]; int narrow; };      // pw32 / pm32: radix^4, ^2, ^1 and their 32-bit reciprocals (narrow: radix^8 < 2^31, key_common_digits' last steps)      // dtab != NULL: two samples on piecewise diagonals (k_diag_bits_tab): partner(y) = y +- (D + dtab[y >> 6])      // pw = radix^8, ^4, ^2, ^1 with their reciprocals      // magic = floor(2^64 / radix) + 1 (exact for keys < 2^48)
+struct KeyDigits { int K; u32 stop0, stop1; KeyPack kp; KeyLayout ly; int64_t D; int ns; int64_t sep[HINT_K - 1], Ds[HINT_K];
+                   const int32_t *dtab; };      // dtab != NULL: two samples on piecewise diagonals (k_diag_bits_tab): partner(y) = y +- (D + dtab[y >> 4])
 // first position among a key's K symbols that holds a stop ('$', 'N', past the end), or 0xFFFFFFFF: k_init_keys left it in bits 48..55
 __device__ inline u32 key_first_stop(u64 key, const KeyDigits &kd) {
     const u32 none = (1u << kd.ly.at_bits) - 1u;
@@ -690,41 +695,6 @@ __device__ inline bool key_hint(u64 key, const KeyDigits &kd, u32 *nd, bool *lt)
     const u32 v = (u32)(key >> kd.ly.nd_shift) & none;
     *nd = v; *lt = (key >> (kd.ly.nd_shift + kd.ly.nd_bits)) & 1ull;
     return kd.ly.nd_bits > 0 && v != none;
-}
-// number of leading digits (of K <= 32) two keys share: both are taken apart from the top, 16 / 8 / 4 / 2 / 1 digits at a time (as 32-digit
-// numbers with leading zeros), following the half that differs -- five rounds of two divisions instead of K
-__device__ inline u32 key_common_digits(u64 x, u64 y, const KeyDigits &kd) {
-    u32 cnt = 0;
-#pragma unroll
-    for (int st = 0; st < 5; st++) {
-        if (st == 2 && kd.narrow) break;
-        const u64 d = kd.pw[st], mg = kd.pmagic[st];
-        u64 qx = __umul64hi(x, mg), qy = __umul64hi(y, mg);
-        u64 rx = x - qx * d, ry = y - qy * d;
-        // (the rounded-up reciprocal can overshoot by one when the divisor is large; x, y < 2^48)
-        if ((int64_t)rx < 0) { qx--; rx += d; }
-        if ((int64_t)ry < 0) { qy--; ry += d; }
-        const bool top = qx != qy;            // the difference lies in the upper half
-        cnt += top ? 0u : (16u >> st);
-        x = top ? qx : rx; y = top ? qy : ry;
-    }
-    if (kd.narrow) {
-        // behind the second step both numbers are below radix^8 < 2^32: the last three steps in 32-bit arithmetic (a 64-bit multiply-high is
-        // four 32-bit multiplies and their carries; the five 64-bit steps were most of k_heads_publish_tc's instructions)
-        u32 a = (u32)x, b = (u32)y;
-#pragma unroll
-        for (int st = 2; st < 5; st++) {
-            const u32 d = kd.pw32[st - 2], mg = kd.pm32[st - 2];
-            u32 qa = __umulhi(a, mg), qb = __umulhi(b, mg);
-            u32 ra = a - qa * d, rb = b - qb * d;
-            if ((int32_t)ra < 0) { qa--; ra += d; }
-            if ((int32_t)rb < 0) { qb--; rb += d; }
-            const bool top = qa != qb;
-            cnt += top ? 0u : (16u >> st);
-            a = top ? qa : ra; b = top ? qb : rb;
-        }
-    }
-    return cnt - (32u - (u32)kd.K);
 }
 // The diagonal hint for any number of samples: a suffix of sample s >= 1 carries how far it agrees with its homologue in the FIRST
 // sample (position - Ds[s]) and whether it is the smaller of the two; a suffix of the first sample carries the same against its
@@ -767,6 +737,21 @@ __device__ inline bool hint_cmp(const KeyDigits &kd, int64_t u, u64 key_u, int64
     return true;
 }
 
+// hint_cmp for exactly two samples (kd.ns == 2: what k_heads_publish_tc runs on) -- no walk over the separators
+__device__ inline bool hint_cmp2(const KeyDigits &kd, int64_t u, u64 key_u, int64_t v, u64 key_v, int *c, u32 *l) {
+    const bool su = u > kd.sep[0], sv = v > kd.sep[0];
+    if (su == sv) return false;
+    const int64_t a = su ? v : u, b = su ? u : v;      // a: the suffix of the first sample
+    if (kd.dtab) {
+        const int32_t dd = kd.dtab[b >> DT_SHIFT];
+        if (dd == DT_NONE || b - kd.D - (int64_t)dd != a) return false;
+    } else if (b - kd.D != a) return false;
+    u32 nd = 0; bool lt = false;
+    if (!key_hint(su ? key_u : key_v, kd, &nd, &lt)) return false;      // the second sample's suffix carries the pair's hint
+    *c = (lt == su) ? -1 : 1; *l = nd;
+    return true;
+}
+
 __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int64_t n, uint8_t *__restrict__ head, u32 *__restrict__ seed,
                                               lcp_t *__restrict__ LCP, KeyDigits kd, u32 *__restrict__ d_maxlcp) {
     const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
@@ -781,18 +766,7 @@ __global__ __launch_bounds__(TB) void k_heads(const u64 *__restrict__ keys, int6
     if (LCP && hd) {
         if (j > 0) {
             const u64 dm = kd.ly.sortmask;
-            if (kd.K <= 32) {
-                l = key_common_digits(ka & dm, kb & dm, kd);
-            } else {      // (tiny alphabets: more than 16 symbols in 48 bits) digit by digit
-                u64 x = ka & dm, y = kb & dm;
-                l = (u32)kd.K;
-                for (int pos = kd.K - 1; pos >= 0; pos--) {
-                    const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
-                    const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
-                    x = qx; y = qy;
-                    l = (dx != dy) ? (u32)pos : l;      // going up: the last hit is the first position
-                }
-            }
+            l = key_common_digits(ka & dm, kb & dm, kd.kp);
             const u32 st = key_first_stop(keys[j], kd);
             l = l < st ? l : st;
         }
@@ -900,17 +874,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
         if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
             u32 l = 0;
             if (j > 0) {
-                if (kd.K <= 32) l = key_common_digits(km1, k0, kd);
-                else {
-                    u64 x = km1, y = k0;
-                    l = (u32)kd.K;
-                    for (int pos = kd.K - 1; pos >= 0; pos--) {
-                        const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
-                        const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
-                        x = qx; y = qy;
-                        l = (dx != dy) ? (u32)pos : l;
-                    }
-                }
+                l = key_common_digits(km1, k0, kd.kp);
                 const u32 st = key_first_stop(key, kd);
                 l = l < st ? l : st;
             }
@@ -1048,17 +1012,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
         if (hd) {      // a head's LCP with its predecessor: the common prefix of the two keys (k_heads)
             u32 l = 0;
             if (j > 0) {
-                if (kd.K <= 32) l = key_common_digits(km1, k0, kd);
-                else {
-                    u64 x = km1, y = k0;
-                    l = (u32)kd.K;
-                    for (int pos = kd.K - 1; pos >= 0; pos--) {
-                        const u64 qx = __umul64hi(x, kd.magic), qy = __umul64hi(y, kd.magic);
-                        const u32 dx = (u32)(x - qx * kd.radix), dy = (u32)(y - qy * kd.radix);
-                        x = qx; y = qy;
-                        l = (dx != dy) ? (u32)pos : l;
-                    }
-                }
+                l = key_common_digits(km1, k0, kd.kp);
                 const u32 st = key_first_stop(key, kd);
                 l = l < st ? l : st;
             }
@@ -1070,8 +1024,11 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             const sav_t q = s + (sav_t)kd.D + (kd.dtab ? (sav_t)(int64_t)kd.dtab[s >> DT_SHIFT] : (sav_t)0);      // (a flagged suffix is linked: its tile's diagonal)
             const u64 qkey = tw_twin_key(key, kd);
             const bool alone = hd & (kp1 != k0);
-            int c = -1; u32 nd = 0;
-            const bool fin = twins && alone && hint_cmp(kd, (int64_t)s, key, (int64_t)q, qkey, &c, &nd, true);
+            // s against the twin made from it (hint_cmp of a first-sample suffix and its partner: the partner's hint is s' own with the
+            // order bit turned round)
+            u32 nd = 0; bool lt = false;
+            const bool fin = twins && alone && key_hint(key, kd, &nd, &lt);
+            const int c = lt ? -1 : 1;
             const int64_t rs = r + ((fin && c >= 0) ? 1 : 0), rq = r + ((fin && c >= 0) ? 0 : 1);
             if (fin) {
                 const u32 st = key_first_stop(key, kd);
@@ -1093,7 +1050,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 const sav_t ps = (first ? vv[e + 2] : vv[e]) & ~TW_FLAG;
                 const u64 pkey = first ? kp1r : km1r;
                 int c; u32 nd;
-                if (hint_cmp(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
+                if (hint_cmp2(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
                     const int64_t base = first ? r : r - 1;
                     rank = base + (c < 0 ? 0 : 1);
                     if (rank != base) {
@@ -2286,18 +2243,48 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         for (int c = 0; c < 256; c++) lut[c] = hist[c] ? (uint8_t)(lut[c] - 1) : (uint8_t)0;      // (absent bytes are never looked up)
         radix = (u32)sigma;       // code 0 = '$' = past the end
     }
+    // The key's layout (KeyPack): for every field size g the largest K -- what the text size needs ((sigma-1)^K >= n), raised as far as
+    // the same number of radix passes allows -- then the g with the most symbols, the fewest bits, the smallest fields.
     int K = 1;
-    int bits;
+    int bits = 0;
+    KeyPack kp;
     {
         const double base = sigma > 2 ? (double)(sigma - 1) : 2.0;
-        double cap = base; u64 span = radix;                                   // span = radix^K
         // (more than two samples: every group holds a homologue per sample, and every unrelated suffix that collides with it is compared
         // with all of them -- sixteen key values per suffix: at 10 x 5 Mbp a fifth radix pass costs 0.4 ms and takes 2.3 off the text round)
         const double want = (double)n * ((seps && nseps > 1) ? 16.0 : 1.0);
-        while (cap < want && span <= (~0ull) / radix / radix) { cap *= base; span *= radix; K++; }
-        int passes = rv_radix_passes(ws, bitlen(span - 1));
-        while (span <= (~0ull) / radix / radix && rv_radix_passes(ws, bitlen(span * radix - 1)) == passes) { span *= radix; K++; }
-        bits = bitlen(span - 1);                                               // significant bits of the key
+        int best_g = 0, best_K = 0, best_bits = 0;
+        u64 rg = 1;
+        for (int g = 1; g <= KP_MAXG; g++) {
+            rg *= radix;
+            if (rg > KP_MAXFIELD && g > 1) break;
+            const int fb = bitlen(rg - 1);
+            auto bits_of = [&](int k) { u64 rl = 1; for (int e = 0; e < k % g; e++) rl *= radix; return (k / g) * fb + (k % g ? bitlen(rl - 1) : 0); };
+            bool exact = true;      // the reciprocals of radix^(g - i): checked for every field value
+            for (int i = 1; i < g && exact; i++) {
+                u64 d = 1; for (int e = 0; e < g - i; e++) d *= radix;
+                const u32 m = (u32)(((1ull << 20) + d - 1) / d);
+                for (u64 f = 0; f < rg && exact; f++) exact = ((f * m) >> 20) == f / d && f * m < (1ull << 32);
+            }
+            if (!exact) continue;
+            int k = 1; double cap = base;
+            while (cap < want && bits_of(k + 1) <= 62) { cap *= base; k++; }
+            const int passes = rv_radix_passes(ws, bits_of(k));
+            while (bits_of(k + 1) <= 62 && rv_radix_passes(ws, bits_of(k + 1)) == passes) k++;
+            const int b = bits_of(k);
+            if (k > best_K || (k == best_K && b < best_bits)) { best_g = g; best_K = k; best_bits = b; }
+        }
+        K = best_K; bits = best_bits;
+        u64 rgb = 1; for (int e = 0; e < best_g; e++) rgb *= radix;
+        kp.g = best_g; kp.fb = bitlen(rgb - 1); kp.nf = (K + best_g - 1) / best_g; kp.gl = K - (kp.nf - 1) * best_g;
+        u64 rl = 1; for (int e = 0; e < kp.gl; e++) rl *= radix;
+        kp.fbl = bitlen(rl - 1); kp.bits = bits; kp.rad = radix; kp.fmask = (1u << kp.fb) - 1u; kp.lmask = (1u << kp.fbl) - 1u;
+        kp.lscale = (u32)(rgb / rl); kp.fdiv = (1u << 16) / (u32)kp.fb + 1u;
+        kp.lastmul = kp.gl == best_g ? (1u << 20) : (u32)(((1ull << 20) + kp.lscale - 1) / kp.lscale);      // (= dmul[gl - 1]: checked above)
+        for (int i = 1; i < KP_MAXG; i++) {
+            u64 d = 1; for (int e = 0; e < best_g - i; e++) d *= radix;
+            kp.dmul[i - 1] = i < best_g ? (u32)(((1ull << 20) + d - 1) / d) : 0u;
+        }
     }
     s.sigma = sigma; s.bits = bits; s.k0 = K;        // (bits: of the whole first key)
     RV_HIP(hipMemcpyAsync(d_lut.p, lut, 256, hipMemcpyHostToDevice, q));
@@ -2330,19 +2317,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     }
     const bool want_hint = fused && kd.D > 0 && kd.ns >= 2 && kd.ly.at_shift - kd.ly.nd_shift >= 8 && !ws.opt.no_diag && !ws.opt.no_packed_text;
     if (want_hint) kd.ly.nd_bits = std::min(kd.ly.at_shift - kd.ly.nd_shift - 1, 11);
-    kd.magic = (~0ull) / radix + 1; kd.radix = radix; kd.K = K; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
-    for (int st = 0; st < 5; st++) {
-        u64 d = 1;
-        for (int e = 0; e < (16 >> st); e++) d = d > (~0ull) / radix ? ~0ull : d * radix;      // (saturates for large alphabets: nothing is ever that large then)
-        kd.pw[st] = d; kd.pmagic[st] = d == ~0ull ? 0ull : (~0ull) / d + 1;
-    }
-    kd.narrow = kd.pw[1] < (1ull << 31) ? 1 : 0;      // radix^8: what is left behind the second step of key_common_digits fits 31 bits
-    for (int st = 2; st < 5; st++) {
-        const u64 d = kd.pw[st];
-        kd.pw32[st - 2] = d < (1ull << 31) ? (u32)d : 0u;
-        kd.pm32[st - 2] = (d < (1ull << 31) && d > 1) ? (u32)((1ull << 32) / d + 1) : 0u;
-        if (d <= 1 || d >= (1ull << 31)) kd.narrow = 0;
-    }
+    kd.K = K; kd.kp = kp; kd.stop0 = lut[(uint8_t)'$']; kd.stop1 = lut[(uint8_t)'N'];
     if (fused) RV_HIP(hipMemsetAsync(d_maxlcp, 0, sizeof(u32), q));
 
     // -- buffers: kept in the workspace (grow-only), a construct() per benchmark step must not pay for hipMalloc
@@ -2429,24 +2404,14 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         tw_off = tc;
         s.diag_table = dg.tab;
     }
-    u64 top_pow = 1;
-    for (int e = 0; e + 1 < K; e++) top_pow *= radix;      // (radix^K fits 64 bits: the key does)
-    // half keys of at most 24 bits (k_init_keys_n): DNA alphabets at every size
-    KeyHalves kh; kh.Kh = (K + 1) / 2; kh.Kl = K / 2; kh.powh = kh.powl = kh.mull = 0;
-    bool halves = K >= 2 && K <= 32 && T != nullptr && ((uintptr_t)T & 3u) == 0 && !ws.opt.init_keys_wide;
-    if (halves) {
-        u64 ph = 1, pl = 1;
-        for (int e = 0; e + 1 < kh.Kh && ph < (1ull << 24); e++) ph *= radix;
-        for (int e = 0; e + 1 < kh.Kl && pl < (1ull << 24); e++) pl *= radix;
-        halves = ph * radix < (1ull << 24);
-        kh.powh = (u32)ph; kh.powl = (u32)pl; kh.mull = (u32)(pl * radix);
+    {
+        const int64_t iktiles = ceil_div(n, KEY_TILE);
+        const dim3 ig((unsigned)std::min<int64_t>(iktiles, 256 * 8));      // persistent: eight workgroups of four waves per CU
+#define RV_IK_(G) hipLaunchKernelGGL(k_init_keys<G>, ig, dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), K, kp, bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, \
+                                     kd.stop0, kd.stop1, kd.ly, dg, tw_off, iktiles)
+        switch (kp.g) { case 1: RV_IK_(1); break; case 2: RV_IK_(2); break; case 3: RV_IK_(3); break; case 4: RV_IK_(4); break; default: RV_IK_(5); break; }
+#undef RV_IK_
     }
-    if (halves)
-        hipLaunchKernelGGL(k_init_keys_n, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                           bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, kh);
-    else
-        hipLaunchKernelGGL(k_init_keys, dim3((unsigned)ceil_div(n, KEY_TILE)), dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), radix, K,
-                           bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, kd.stop0, kd.stop1, kd.ly, dg, tw_off, top_pow);
     SA_HIP(hipGetLastError());
     int in1 = 0;
     SA_TRY(rv_radix_sort_pairs<sav_t>(ws, bk0.as<u64>(), bv0.as<sav_t>(), bk1.as<u64>(), bv1.as<sav_t>(), nsort, 0, bits, &in1));

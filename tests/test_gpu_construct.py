@@ -271,7 +271,7 @@ def test_maxlcp_counts_the_group_heads(sa64):
 
 
 @pytest.mark.parametrize("sa64", [False, True])
-@pytest.mark.parametrize("collapse", [True, False, "wide"])
+@pytest.mark.parametrize("collapse", [True, False])
 def test_twins_leave_before_the_sort(monkeypatch, collapse, sa64):
     """two samples with the diagonal hint: the suffixes of the second sample that carry their homologue's first key are not
     sorted (k_tw_count / k_init_keys / k_heads_publish_tc) -- SA, LCP, the largest LCP and the matches equal the oracle's on
@@ -279,8 +279,6 @@ def test_twins_leave_before_the_sort(monkeypatch, collapse, sa64):
     a second sample longer than twice the first, and inputs of a few bases"""
     if not collapse:
         monkeypatch.setenv("RV_NO_TWIN_COLLAPSE", "1")
-    if collapse == "wide":      # the first keys by the kernel for any alphabet (k_init_keys) instead of the one for half keys of 24 bits (k_init_keys_n)
-        monkeypatch.setenv("RV_INIT_KEYS_WIDE", "1")
     rng = np.random.default_rng(23)
 
     def rnd(L):

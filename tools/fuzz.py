@@ -34,7 +34,6 @@ ENVS = [
     {"RV_CASCADE_DANGER": "2", "RV_CASCADE_DANGER_MIN": "300", "RV_CASCADE_SECOND_OFF": "1"},
     {"RV_NO_TWIN_COLLAPSE": "1"},                         # every suffix of the second sample through the radix sort
     {"RV_DIAG_TABLE": "1"},                               # two samples: hint and twins along piecewise diagonals from seeds, whatever the input
-    {"RV_INIT_KEYS_WIDE": "1"},                           # the first keys by the kernel for any alphabet
     {"RV_NO_SHORT_ALPHABET": "1"},                        # a digit value of its own for "past the end"
     {"RV_NO_TINY_SA": "1"},                               # texts of up to 2048 characters through the general build, too
 ]

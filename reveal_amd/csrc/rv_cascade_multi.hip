@@ -478,7 +478,7 @@ __device__ inline int cm_first_diff(const uint8_t *txt, int i, int j, int lim) {
 // 10 x 5 Mbp, 8 000 suffixes whose homologues agree for hundreds of characters, took 30 ms)
 constexpr int BN = 8192;
 struct CmSlice { int32_t root, first; };
-__device__ inline int cm_load_text(const CmRoot &root, const CmTabs &t, int k, const uint8_t *__restrict__ T0, uint8_t *txt, int *seg_lo, int64_t *seg_b) {
+__device__ inline int cm_load_text(const CmRoot &root, const CmTabs &t, int k, const uint8_t *__restrict__ T0, uint8_t *txt, int *seg_lo, int64_t *seg_b, int stride = TB) {
     if (threadIdx.x == 0) {
         int at = 0;
         for (int s = 0; s < k; s++) {
@@ -489,13 +489,79 @@ __device__ inline int cm_load_text(const CmRoot &root, const CmTabs &t, int k, c
     }
     __syncthreads();
     const int n = seg_lo[k];
-    for (int x = threadIdx.x; x < n; x += TB) {
+    for (int x = threadIdx.x; x < n; x += stride) {
         int s = 0;
         while (x >= seg_lo[s + 1]) s++;
         txt[x] = T0[seg_b[s] + (x - seg_lo[s])];
     }
     __syncthreads();
     return n;
+}
+// The ranks of a sub-index' suffixes by sorting instead of counting: a workgroup per sub-index sorts (first six bytes, suffix) words in LDS
+// (bitonic: 91 steps for 8192 words), and a suffix is only compared in full with the ones that share its six bytes -- its homologues in the
+// other samples and repeats.  Counting compared every suffix with every other: 62 000 vector instructions per wave, 1.35 ms for the 44
+// undecided sub-indices (58 000 suffixes) of 10 x 5 Mbp.  The order is the one k_casm_rank counts out: a suffix ends with its interval, the
+// shorter of two that agree to the end first, then the one in front; bytes behind the end count as zero in the six.
+constexpr int RK_TB = 1024;
+__global__ __launch_bounds__(RK_TB) void k_casm_rank_sort(const CmRoot *__restrict__ roots, CmTabs t, int k, const uint8_t *__restrict__ T0, u32 *__restrict__ ord) {
+    __shared__ __attribute__((aligned(8))) uint8_t txt[BN + 24];
+    __shared__ u64 sk[BN];
+    __shared__ int seg_lo[RV_CASM_K + 1];
+    __shared__ int64_t seg_b[RV_CASM_K];
+    const CmRoot root = roots[blockIdx.x];
+    const int n = cm_load_text(root, t, k, T0, txt, seg_lo, seg_b, RK_TB);
+    int P = 2;
+    while (P < n) P <<= 1;
+    for (int i = threadIdx.x; i < P; i += RK_TB) {
+        u64 e = ~0ull;
+        if (i < n) {
+            int si = 0;
+            while (i >= seg_lo[si + 1]) si++;
+            const int ri = seg_lo[si + 1] - i;
+            u64 key = 0;
+#pragma unroll
+            for (int b = 0; b < 6; b++) key = (key << 8) | (b < ri ? (u64)txt[i + b] : 0ull);
+            e = (key << 16) | (u64)i;
+        }
+        sk[i] = e;
+    }
+    for (int size = 2; size <= P; size <<= 1)
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            __syncthreads();
+            for (int x = threadIdx.x; x < P / 2; x += RK_TB) {
+                const int lo = 2 * x - (x & (stride - 1)), hi = lo + stride;
+                const u64 a = sk[lo], b = sk[hi];
+                if ((a > b) == ((lo & size) == 0)) { sk[lo] = b; sk[hi] = a; }
+            }
+        }
+    __syncthreads();
+    for (int r = threadIdx.x; r < n; r += RK_TB) {
+        const u64 e = sk[r];
+        const u64 key = e >> 16;
+        const int i = (int)(e & 0xffffu);
+        int gs = r, ge = r + 1;
+        while (gs > 0 && (sk[gs - 1] >> 16) == key) gs--;
+        while (ge < n && (sk[ge] >> 16) == key) ge++;
+        int cnt = 0;
+        if (ge - gs > 1) {
+            int si = 0;
+            while (i >= seg_lo[si + 1]) si++;
+            const int ri = seg_lo[si + 1] - i;
+            for (int m = gs; m < ge; m++) {
+                if (m == r) continue;
+                const int j = (int)(sk[m] & 0xffffu);
+                int sj = 0;
+                while (j >= seg_lo[sj + 1]) sj++;
+                const int rj = seg_lo[sj + 1] - j;
+                const int lim = ri < rj ? ri : rj;
+                const int x0 = lim < 6 ? lim : 6;      // (the six bytes agree, zeros behind an end included: both end inside them or neither does)
+                const int x = x0 + cm_first_diff(txt, i + x0, j + x0, lim - x0);
+                const bool j_less = (x < lim) ? (txt[j + x] < txt[i + x]) : ((rj < ri) | ((rj == ri) & (j < i)));
+                cnt += j_less ? 1 : 0;
+            }
+        }
+        ord[root.off + gs + cnt] = (u32)i;
+    }
 }
 __global__ __launch_bounds__(TB) void k_casm_rank(const CmRoot *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
                                                   u32 *__restrict__ ord) {
@@ -582,6 +648,15 @@ __global__ __launch_bounds__(TB) void k_casm_lower(uint8_t *__restrict__ T, cons
     const int64_t l = (int64_t)an_l[e];      // (an_l expanded per range by the caller's indexing: see the launch)
     for (int64_t x = threadIdx.x & 63; x < l; x += 64) { const uint8_t c = T[lo + x]; if (c >= 'A' && c <= 'Z') T[lo + x] = c + 32; }
 }
+// the rows of the undecided sub-indices side by side (ids, depths, begins, ends): one copy to the host instead of three per row
+__global__ __launch_bounds__(TB) void k_casm_rows(const u32 *__restrict__ und, u32 U, CmTabs t, int k, u32 *__restrict__ o_id, int32_t *__restrict__ o_dep,
+                                                  sa_t *__restrict__ o_b, sa_t *__restrict__ o_e) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= U * (u32)k) return;
+    const u32 x = i / (u32)k, s = i - x * (u32)k, id = und[x];
+    o_b[i] = t.b[(size_t)id * k + s]; o_e[i] = t.e[(size_t)id * k + s];
+    if (s == 0) { o_id[x] = id; o_dep[x] = t.depth[id]; }
+}
 __global__ __launch_bounds__(TB) void k_casm_expand_l(const u32 *__restrict__ an_l, u32 na, int k, u32 *__restrict__ out) {
     const u32 i = blockIdx.x * TB + threadIdx.x;
     if (i < na * (u32)k) out[i] = an_l[i / (u32)k];
@@ -628,7 +703,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const u32 ccap = (u32)ccap64, acap = ccap / 2 + 8;
     DBuf &bso = cb.d[0], &bcl0 = cb.d[1], &bcp0 = cb.d[2], &bk0 = cb.d[3], &bk1 = cb.d[4], &bv0 = cb.d[5], &bv1 = cb.d[6], &bcl = cb.d[7], &bcp = cb.d[8], &bcc = cb.d[9],
          &bwp = cb.d[10], &bwv = cb.d[11], &bwc = cb.d[12], &btb = cb.d[13], &bctr = cb.d[14], &bund = cb.d[15], &banl = cb.d[16], &banp = cb.d[17], &broot = cb.d[18],
-         &bsa = cb.d[19], &blcp = cb.d[20], &bbwt = cb.d[21], &brt = cb.d[22], &bexp = cb.d[23];
+         &bsa = cb.d[19], &blcp = cb.d[20], &bbwt = cb.d[21], &brt = cb.d[22], &bexp = cb.d[23], &brows = cb.d[34];
     RV_TRY(bso.reserve((size_t)n + 64)); RV_TRY(bcl0.reserve((size_t)mcap * 4)); RV_TRY(bcp0.reserve((size_t)mcap * k * sizeof(sa_t)));
     RV_TRY(bwp.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)wcap * 4)); RV_TRY(bwc.reserve((size_t)wcap * 4));
     RV_TRY(bctr.reserve(64 + 2 * CM_REGIONS * 4 + 64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
@@ -741,18 +816,30 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     }
     // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
     if (U) {
+        // their ids, intervals and depths: gathered on the device (the tables are small next to the index, but only these rows are needed), one
+        // copy, put in the order of the ids on the host
+        const size_t rowbytes = (size_t)U * 8 + (size_t)U * k * sizeof(sa_t) * 2;
+        RV_TRY(brows.reserve(rowbytes + 64));
+        u32 *d_id = brows.as<u32>(); int32_t *d_dep = (int32_t *)(d_id + U);
+        sa_t *d_b = (sa_t *)(d_dep + U), *d_e = d_b + (size_t)U * k;
+        hipLaunchKernelGGL(k_casm_rows, dim3((unsigned)ceil_div((int64_t)U * k, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, t, k, d_id, d_dep, d_b, d_e);
+        RV_LAUNCH_CHECK();
+        std::vector<uint8_t> hrows(rowbytes);
+        RV_HIP(hipMemcpyAsync(hrows.data(), brows.p, rowbytes, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipStreamSynchronize(q));
+        const u32 *r_id = (const u32 *)hrows.data(); const int32_t *r_dep = (const int32_t *)(r_id + U);
+        const sa_t *r_b = (const sa_t *)(r_dep + U), *r_e = r_b + (size_t)U * k;
+        std::vector<u32> order(U);
+        for (u32 x = 0; x < U; x++) order[x] = x;
+        std::sort(order.begin(), order.end(), [&](u32 a, u32 b) { return r_id[a] < r_id[b]; });
         std::vector<u32> ids(U);
-        RV_HIP(hipMemcpy(ids.data(), bund.p, (size_t)U * 4, hipMemcpyDeviceToHost));
-        std::sort(ids.begin(), ids.end());
-        // their intervals and depths: the tables are small next to the index, but only these rows are needed
         std::vector<sa_t> hb((size_t)U * k), he((size_t)U * k);
         std::vector<int32_t> hd(U);
-        for (u32 x = 0; x < U; x++) {      // (undecided sub-indices are few: row by row)
-            RV_HIP(hipMemcpyAsync(hb.data() + (size_t)x * k, t.b + (size_t)ids[x] * k, (size_t)k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
-            RV_HIP(hipMemcpyAsync(he.data() + (size_t)x * k, t.e + (size_t)ids[x] * k, (size_t)k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
-            RV_HIP(hipMemcpyAsync(hd.data() + x, t.depth + ids[x], 4, hipMemcpyDeviceToHost, q));
+        for (u32 x = 0; x < U; x++) {
+            const u32 o = order[x];
+            ids[x] = r_id[o]; hd[x] = r_dep[o];
+            for (int s2 = 0; s2 < k; s2++) { hb[(size_t)x * k + s2] = r_b[(size_t)o * k + s2]; he[(size_t)x * k + s2] = r_e[(size_t)o * k + s2]; }
         }
-        RV_HIP(hipStreamSynchronize(q));
         std::vector<CmRoot> roots(U);
         int64_t m = 0;
         out->node_first.assign(1, 0);
@@ -779,7 +866,10 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         CmSlice *d_slices = (CmSlice *)(d_roots + U);
         RV_HIP(hipMemcpy(d_roots, roots.data(), (size_t)U * sizeof(CmRoot), hipMemcpyHostToDevice));
         RV_HIP(hipMemcpy(d_slices, slices.data(), slices.size() * sizeof(CmSlice), hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
+        if (h->ws.opt.casm_rank_count)      // (test hook: the ranks counted out by comparison, k_casm_rank)
+            hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
+        else
+            hipLaunchKernelGGL(k_casm_rank_sort, dim3(U), dim3(RK_TB), 0, q, (const CmRoot *)d_roots, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
         RV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_casm_emit, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
                            (const u32 *)bexp.as<u32>(), bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);

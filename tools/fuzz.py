@@ -30,6 +30,7 @@ ENVS = [
     {"RV_LEAF_ACAP": "2", "RV_NO_CASCADE": "1"},
     {"RV_LEAF_ACAP": "2"},                                # the cascade's leaf launch with a two-anchor staging area
     {"RV_CASCADE_SECOND": "2"},                           # two samples through the interval cascade (rv_cascade_multi.hip) as well
+    {"RV_CASM_RANK_COUNT": "1"},                          # more than two samples: undecided sub-indices ranked by counting instead of sorting (k_casm_rank)
     {"RV_CASCADE_DANGER": "2"},                           # every undecided sub-index decided from its witnesses where they can be (k_cas_dwalk)
     {"RV_CASCADE_DANGER": "2", "RV_CASCADE_DANGER_MIN": "300", "RV_CASCADE_SECOND_OFF": "1"},
     {"RV_NO_TWIN_COLLAPSE": "1"},                         # every suffix of the second sample through the radix sort

@@ -55,7 +55,7 @@ constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
 
 struct CasIv { sa_t a0, a1, b0, b1; };
 struct CasRes { sa_t qa, qb; u32 ql, lead, trail, state; };      // state: 0 not decided yet, 1 split, 2 ended
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NSOLVED = 8, C_NUNSOLVED = 9, C_NRETRY = 10 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NSOLVED = 8, C_NUNSOLVED = 9, C_NRETRY = 10, C_TICKET = 11 };
 
 // the match (pa, pb, len) of the root cut to a sub-index: start shifted behind the sub-index' begin on both sides, length
 // capped at its ends
@@ -204,7 +204,7 @@ __global__ void k_cas_init(CasIv *__restrict__ iv, u64 *__restrict__ best, u32 *
         iv[0] = root; best[0] = 0; wmax[0] = 0; depth[0] = 0;
         CasRes r; r.qa = 0; r.qb = 0; r.ql = 0; r.lead = NONE; r.trail = NONE; r.state = 0;
         res[0] = r;
-        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0; counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0;
+        counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0; counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0; counters[C_TICKET] = 0;
     }
     if (i < nw) w_child[i] = 0u;
 }
@@ -231,7 +231,7 @@ __global__ void k_cas_init_roots(CasIv *__restrict__ iv, u64 *__restrict__ best,
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         counters[C_NCHILD] = nroots; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = nroots; counters[C_LEVELS] = 0;
-        counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0;
+        counters[C_NSOLVED] = 0; counters[C_NUNSOLVED] = 0; counters[C_NRETRY] = 0; counters[C_TICKET] = 0;
     }
     if (i < nroots) {
         if (dbest) { dbest[i] = 0; dflag[i] = 0; dceil[i] = 0; }
@@ -589,13 +589,16 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
         }
         __syncthreads();      // (s_cnt / s_base are rewritten by the next stretch)
     }
-}
-// the next level's sub-indices are the ones the level just decided has made
-__global__ void k_cas_advance(u32 *__restrict__ counters) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const u32 lo = counters[C_LO], hi = counters[C_HI];
-    if (hi > lo) counters[C_LEVELS]++;
-    counters[C_LO] = hi; counters[C_HI] = counters[C_NCHILD];
+    // The next level's sub-indices are the ones this level has made: the workgroup that finishes last moves the range on.  (Every workgroup read
+    // the range when it started, and takes its ticket when it is done: nobody reads the range after the last ticket.  A kernel of its own for
+    // this was 4.5 us per level, 53 levels at 2 x 250 Mbp.)
+    if (threadIdx.x == 0) {      // (no fence: what the workgroups wrote is for the next kernel; the range's end is read with an atomic, behind their returning ones)
+        if (atomicAdd(&counters[C_TICKET], 1u) == gridDim.x - 1) {
+            if (hi > lo) counters[C_LEVELS]++;
+            counters[C_LO] = hi; counters[C_HI] = atomicAdd(&counters[C_NCHILD], 0u);
+            counters[C_TICKET] = 0;
+        }
+    }
 }
 // the run's counters (rv_leaf.h: [0] sub-indices visited, [1] anchors, [2] anchored bp, [3] largest depth) from what the levels left:
 // every sub-index made has been visited, except the undecided ones (the leaf kernel counts those itself)
@@ -1077,10 +1080,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
                 hipLaunchKernelGGL(k_cas_dwrite, dim3(wb), dim3(TB), 0, q, wp, (const u32 *)bwc.as<u32>(), NW, dg);
                 RV_LAUNCH_CHECK();
             }
-            hipLaunchKernelGGL(k_cas_decide, dim3(1024), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
+            hipLaunchKernelGGL(k_cas_decide, dim3(256), dim3(TB), 0, q, biv.as<CasIv>(), bbest.as<u64>(), bwm.as<u32>(), bdep.as<int32_t>(),
                                bres.as<CasRes>(), minl, counters, ccap, bund.as<u32>(), (u32)RV_LEAF_N, io, dg, (danger && NW) ? 1 : 0);
-            RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_cas_advance, dim3(1), dim3(64), 0, q, counters);
             RV_LAUNCH_CHECK();
         }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));

@@ -35,7 +35,7 @@ constexpr int KEY_SHIFT = 40;
 constexpr int KEY_SHIFT = 32;
 #endif
 constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NCAND = 8, C_NANCH = 9, C_STEPS = 10, C_MAXDEPTH = 11 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NCAND = 8, C_NANCH = 9, C_STEPS = 10, C_MAXDEPTH = 11, C_TICKET = 12 };
 
 __device__ inline int cm_sample(const sa_t *__restrict__ nsep, int k, sa_t pos) {      // number of separators in front of pos (interface.c:116-134)
     int s = 0;
@@ -264,7 +264,7 @@ __global__ void k_casm_init(CmTabs t, int k, const sa_t *__restrict__ root_b, co
         for (int s = 0; s < k; s++) { t.b[s] = root_b[s]; t.e[s] = root_e[s]; }
         t.best[0] = 0; t.rmax[0] = 0; t.depth[0] = 0; t.state[0] = 0; t.lead[0] = NONE; t.trail[0] = NONE; t.ql[0] = 0;
         counters[C_NCHILD] = 1; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = 1; counters[C_LEVELS] = 0;
-        counters[C_NANCH] = 0; counters[C_STEPS] = 0; counters[C_MAXDEPTH] = 0;
+        counters[C_NANCH] = 0; counters[C_STEPS] = 0; counters[C_MAXDEPTH] = 0; counters[C_TICKET] = 0;
     }
     if (i < nw) w_child[i] = 0u;
 }
@@ -449,12 +449,14 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
         }
         __syncthreads();
     }
-}
-__global__ void k_casm_advance(u32 *__restrict__ counters) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    const u32 lo = counters[C_LO], hi = counters[C_HI];
-    if (hi > lo) counters[C_LEVELS]++;
-    counters[C_LO] = hi; counters[C_HI] = counters[C_NCHILD];
+    // the workgroup that finishes last moves the level's range on (k_cas_decide, rv_cascade.hip)
+    if (threadIdx.x == 0) {      // (no fence: what the workgroups wrote is for the next kernel; the range's end is read with an atomic, behind their returning ones)
+        if (atomicAdd(&counters[C_TICKET], 1u) == gridDim.x - 1) {
+            if (hi > lo) counters[C_LEVELS]++;
+            counters[C_LO] = hi; counters[C_HI] = atomicAdd(&counters[C_NCHILD], 0u);
+            counters[C_TICKET] = 0;
+        }
+    }
 }
 
 // ---- undecided sub-indices from their text: up to k intervals, at most BN suffixes, 256 per workgroup (see k_cas_rank in rv_cascade.hip) ----
@@ -780,8 +782,6 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                                (int64_t)minl);
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_casm_decide, dim3(192), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)BN, banl.as<u32>(), banp.as<sa_t>(), acap);
-            RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_casm_advance, dim3(1), dim3(64), 0, q, counters);
             RV_LAUNCH_CHECK();
         }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));

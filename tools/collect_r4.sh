@@ -6,7 +6,7 @@ export TMPDIR=/tmp
 python bench.py > $OUT/bench_c4.json 2> $OUT/bench_c4.err
 python bench.py --indelfrac 0.2 --no-cpu --no-extra > $OUT/bench_c4_indel.json 2> $OUT/bench_c4_indel.err
 python bench.py --L 5000000 --steps 20 --warmup 5 --no-allcores > $OUT/bench_c2.json 2> $OUT/bench_c2.err
-python bench.py --L 5000000 --genomes 10 --steps 5 --warmup 2 --no-allcores > $OUT/bench_c3.json 2> $OUT/bench_c3.err
+python bench.py --L 5000000 --genomes 10 --steps 20 --warmup 3 --no-allcores > $OUT/bench_c3.json 2> $OUT/bench_c3.err
 python bench.py --config c5 --steps 2 --warmup 1 > $OUT/bench_c5_level0.json 2> $OUT/bench_c5_level0.err
 python bench.py --contigs 2 --steps 3 > $OUT/bench_c4_contigs2.json 2> $OUT/bench_c4_contigs2.err
 cd /tmp

@@ -534,10 +534,27 @@ def make_index_type(sa64, error):
                 raise error("Index not yet constructed, alignment stopped.")
             dll, h = self._dll, self._h
             dll.rv_set_trace(h, 1 if trace else 0)
+            self._offer_result_buffers()
             st = _lib.RvAlignStats()
             if dll.rv_align_builtin(h, int(minl), int(minn), ctypes.byref(st)) != 0:
                 self._fail()
             return self._builtin_result(st, trace)
+
+        def _result_buffers_free(self):
+            """the result arrays of the previous call, when nothing but this object refers to them (or to a view of them) any more"""
+            c = self.__dict__.get("_res_bufs")
+            if c is not None and sys.getrefcount(c[0]) == 2 and sys.getrefcount(c[1]) == 2 and sys.getrefcount(c[2]) == 2:
+                return c
+            return None
+
+        def _offer_result_buffers(self):
+            """rv_set_result_buffers: the run delivers its anchors straight into the arrays the caller has let go of (page-locked by the
+            library while they are set); arrays somebody still holds are taken back from the library first"""
+            c = self._result_buffers_free()
+            if c is not None:
+                self._dll.rv_set_result_buffers(self._h, c[0].ctypes.data, len(c[0]), c[1].ctypes.data, len(c[1]), c[2].ctypes.data, len(c[2]))
+            else:
+                self._dll.rv_set_result_buffers(self._h, None, 0, None, 0, None, 0)
 
         def _builtin_result(self, st, trace):
             dll, h = self._dll, self._h
@@ -545,11 +562,11 @@ def make_index_type(sa64, error):
             na = dll.rv_anchor_count(h, ctypes.byref(mem))
             # (filled completely by the library: no zeroing.)  The arrays of the previous call are used again when the caller has let go of
             # them -- nothing else refers to them or to a view of them: 56 MB of fresh pages per call cost 2 x 250 Mbp 1-3 ms of page faults
-            c = self.__dict__.get("_res_bufs")
-            if (c is not None and len(c[0]) >= max(na, 1) and len(c[1]) >= na + 1 and len(c[2]) >= max(mem.value, 1)
-                    and sys.getrefcount(c[0]) == 2 and sys.getrefcount(c[1]) == 2 and sys.getrefcount(c[2]) == 2):
+            c = self._result_buffers_free()
+            if c is not None and len(c[0]) >= max(na, 1) and len(c[1]) >= na + 1 and len(c[2]) >= max(mem.value, 1):
                 l, off, pos = c
             else:
+                dll.rv_set_result_buffers(h, None, 0, None, 0, None, 0)      # (the arrays that are replaced may be freed: not the library's any more)
                 l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64)
                 pos = np.empty(max(mem.value, 1), dtype=np.int64)
                 self.__dict__["_res_bufs"] = (l, off, pos)

@@ -84,6 +84,7 @@ SYMBOLS = {
     "rv_cascade_why": (ctypes.c_char_p, [V]),
     "rv_anchor_count": (_L, [V, c_i64p]),
     "rv_fetch_anchors": (_I, [V, V, V, V]),
+    "rv_set_result_buffers": (_I, [V, V, _L, V, _L, V, _L]),
     "rv_set_trace": (_I, [V, _I]),
     "rv_set_preselect": (_I, [V, _L]),
     "rv_set_option": (_I, [V, ctypes.c_char_p, _L]),

@@ -1701,10 +1701,22 @@ static int builtin_levels(rv_index *h, int stop_subs) {
     return 0;
 }
 
+// off[k] = base + 2 (k + 1), k < na: the member offsets of na two-member anchors, on a few host threads
+static void fill_offsets(int64_t *off, size_t na, int64_t base) {
+    const int nt = na > ((size_t)1 << 18) ? 4 : 1;
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) {
+        const size_t lo = na / nt * t, hi = t + 1 == nt ? na : na / nt * (t + 1);
+        th.emplace_back([=]() { for (size_t k = lo; k < hi; k++) off[k] = base + 2 * (int64_t)(k + 1); });
+    }
+    for (size_t k = 0; k < na / nt; k++) off[k] = base + 2 * (int64_t)(k + 1);
+    for (auto &x : th) x.join();
+}
 // collect what the leaf launches produced
 static int builtin_finish(rv_index *h, rv_align_stats *out) {
     Align *a = h->al;
     hipStream_t q = h->ws.stream;
+    h->rb.direct = false;
     if (a->use_leaf && a->running) {
         u32 *lf_counters = a->lf_counters; u32 *lf_l = a->lf_l; int64_t *lf_pos = a->lf_pos; rv_trace *lf_tr = a->lf_tr;
         // everything through pinned staging (pageable destinations are staged by the runtime, copy by copy: ~0.25 ms per run)
@@ -1725,12 +1737,20 @@ static int builtin_finish(rv_index *h, rv_align_stats *out) {
             // the anchors stay in the pinned buffer in the layout rv_fetch_anchors hands out (2 x 10^6 of them at 2 x 250 Mbp: appending
             // them to the host vectors one by one cost 5 ms per run, most of it page faults of the freshly grown vectors)
             const size_t na = cnt[0];
-            RV_TRY(a->hLeafOut.reserve(na * 20 + 64));
-            int64_t *pp = a->hLeafOut.as<int64_t>(); u32 *pl = (u32 *)(pp + 2 * na);
+            const size_t nl = a->an_l.size(), np = a->an_pos.size();
+            // The caller's own arrays when it has set them and they are large enough (rv_set_result_buffers: page-locked): the anchors go
+            // straight to where rv_fetch_anchors would copy them -- through the staging buffer the 2 x 10^6 anchors of 2 x 250 Mbp were
+            // 65 MB of host writes behind the run, 1.3-1.6 ms with the GPU idle (tools/rocpd_gaps.py)
+            rv_index::ResultBufs &rb = h->rb;
+            rb.direct = rb.l && (int64_t)(nl + na) <= rb.l_cap && (int64_t)(nl + na + 1) <= rb.off_cap && (int64_t)(np + 2 * na) <= rb.pos_cap;
+            int64_t *pp; u32 *pl;
+            if (rb.direct) { pp = rb.pos + np; pl = rb.l + nl; }
+            else { RV_TRY(a->hLeafOut.reserve(na * 20 + 64)); pp = a->hLeafOut.as<int64_t>(); pl = (u32 *)(pp + 2 * na); }
             // (both streams are idle here: the copies to the host run on the side stream beside the lower-casing -- 0.9 and 0.7 ms at 2 x 250 Mbp)
             RV_HIP(hipMemcpyAsync(pp, lf_pos, na * 16, hipMemcpyDeviceToHost, a->leaf_stream));
             RV_HIP(hipMemcpyAsync(pl, lf_l, na * 4, hipMemcpyDeviceToHost, a->leaf_stream));
             RV_TRY(rv_leaf_lower_launch(h->ws, h->dT.as<uint8_t>(), lf_pos, lf_l, (u32)na));      // their matched text (nothing read it during the run)
+            if (rb.direct) fill_offsets(rb.off + nl + 1, na, (int64_t)np);      // (two members per anchor: the host writes them while the GPU works)
             RV_HIP(hipStreamSynchronize(a->leaf_stream));
             RV_HIP(hipStreamSynchronize(q));
             a->leaf_na = na;
@@ -2340,6 +2360,23 @@ static void copy_parallel(void *dst, const void *src, size_t bytes) {
     for (auto &x : th) x.join();
 }
 
+int rv_set_result_buffers(rv_index *h, uint32_t *l, int64_t l_cap, int64_t *off, int64_t off_cap, int64_t *pos, int64_t pos_cap) {
+    if (!h) { rv_set_error("rv_set_result_buffers: null handle"); return -1; }
+    rv_index::ResultBufs &rb = h->rb;
+    if (l == rb.l && off == rb.off && pos == rb.pos && l_cap == rb.l_cap && off_cap == rb.off_cap && pos_cap == rb.pos_cap) return 0;
+    RV_HIP(hipSetDevice(h->device));
+    if (rb.l) {      // (a copy into them may still be in flight only inside rv_align_builtin: not here)
+        (void)hipHostUnregister(rb.l); (void)hipHostUnregister(rb.off); (void)hipHostUnregister(rb.pos);
+        rb = rv_index::ResultBufs();
+    }
+    if (!l || !off || !pos || l_cap <= 0 || off_cap <= 0 || pos_cap <= 0) return 0;
+    if (hipHostRegister(l, (size_t)l_cap * 4, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }      // (not page-lockable: the staging buffer as before)
+    if (hipHostRegister(off, (size_t)off_cap * 8, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(l); return 0; }
+    if (hipHostRegister(pos, (size_t)pos_cap * 8, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(l); (void)hipHostUnregister(off); return 0; }
+    rb.l = l; rb.off = off; rb.pos = pos; rb.l_cap = l_cap; rb.off_cap = off_cap; rb.pos_cap = pos_cap;
+    return 0;
+}
+
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos) {
     RV_TRY(need_align(h));
     Align *a = h->al;
@@ -2347,8 +2384,10 @@ int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos) {
     memcpy(l, a->an_l.data(), nl * 4);
     memcpy(off, a->an_off.data(), a->an_off.size() * 8);
     memcpy(pos, a->an_pos.data(), np * 8);
-    if (na) {      // the leaf launches' (and the cascade's) anchors, still in the pinned staging buffer (pos[2 na], l[na])
-        const int64_t *pp = a->hLeafOut.as<int64_t>(); const u32 *pl = (const u32 *)(pp + 2 * na);
+    if (na && h->rb.direct && l == h->rb.l && off == h->rb.off && pos == h->rb.pos) return 0;      // delivered by the run itself (rv_set_result_buffers)
+    if (na) {      // the leaf launches' (and the cascade's) anchors, still in the pinned staging buffer (pos[2 na], l[na]) -- or in the result buffers
+        const int64_t *pp = h->rb.direct ? h->rb.pos + np : a->hLeafOut.as<int64_t>();
+        const u32 *pl = h->rb.direct ? h->rb.l + nl : (const u32 *)(pp + 2 * na);
         std::thread t_off;
         if (na > (size_t)1 << 18) t_off = std::thread([=]() { for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1)); });
         else for (size_t k = 0; k < na; k++) off[nl + 1 + k] = (int64_t)(np + 2 * (k + 1));

@@ -91,6 +91,7 @@ void rv_free(rv_index *h) {
     { std::lock_guard<std::mutex> g(rv_trim_mutex()); auto &v = live_handles(); v.erase(std::remove(v.begin(), v.end(), h), v.end()); }
     (void)hipSetDevice(h->device);
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
+    (void)rv_set_result_buffers(h, nullptr, 0, nullptr, 0, nullptr, 0);
     rv_align_free(h);
     h->prof.release();
     h->dT.release(); h->dT0.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dBWT.release(); h->dNsep.release();

@@ -96,6 +96,12 @@ struct rv_index {
     std::vector<u32> mm_l; std::vector<int32_t> mm_n; std::vector<int64_t> mm_off, mm_pos; std::vector<uint16_t> mm_so;
     // ---- recursion state (rv_align.hip)
     struct Align *al = nullptr;
+    // ---- where the built-in run delivers its anchors (rv_set_result_buffers): the caller's arrays, page-locked while they are set
+    struct ResultBufs {
+        uint32_t *l = nullptr; int64_t *off = nullptr, *pos = nullptr;
+        int64_t l_cap = 0, off_cap = 0, pos_cap = 0;
+        bool direct = false;           // the last run's leaf / cascade anchors are already in them (rv_fetch_anchors copies the rest)
+    } rb;
 };
 
 // scan of SA/LCP[0..m) -> host records in rank order (rv_api.hip)

@@ -332,3 +332,39 @@ def test_cascade_with_several_sequences_per_sample(tmp_path, monkeypatch, sa64):
     monkeypatch.setenv("RV_NO_CASCADE_CHAIN", "1")
     inputs = [_write_fasta(tmp_path / "a.fa", c1), _write_fasta(tmp_path / "b.fa", c2)]
     assert not check(inputs, 20, sa64)["done"]
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_anchors_delivered_into_the_callers_arrays(sa64):
+    """rv_set_result_buffers (include/reveal_amd.h): a built-in run on a handle whose previous result arrays have been let go of writes its anchors
+    straight into them (page-locked by the library); arrays somebody still holds are left alone.  Same anchors either way, run after run, for results
+    that grow, shrink and do not fit"""
+    big = [g.decode() for g in synth.genomes(400000, 2, seed=21)]
+    small = [g.decode() for g in synth.genomes(90000, 2, seed=22)]
+    ref = {id(x): aset(oracle_run(x, 20, sa64)["anchors"]) for x in (big, small)}
+    idx_big, idx_small = feed(mod(sa64).index(), big), feed(mod(sa64).index(), small)
+    for idx, inp in ((idx_big, big), (idx_small, small)):
+        kept = None
+        for turn in range(5):
+            idx.construct()
+            got = idx.align_builtin(20, 2)
+            assert aset(got["anchors"]) == ref[id(inp)], (turn, len(inp[0]))
+            if turn == 1:
+                kept = got["anchors"]            # views of the arrays stay with the caller: the next run must not write into them
+                snap = [np.array(a, copy=True) for a in kept]
+            elif turn == 2:
+                assert all(np.array_equal(a, b) for a, b in zip(kept, snap))
+                kept = None
+            del got
+    # one handle, results of different sizes through the same arrays (the larger one does not fit the smaller one's)
+    idx = feed(mod(sa64).index(), small)
+    for inp in (small, small, big, big, small, small):
+        idx2 = feed(mod(sa64).index(), inp)
+        idx2.__dict__["_res_bufs"] = idx.__dict__.get("_res_bufs")
+        idx.__dict__.pop("_res_bufs", None)
+        idx._dll.rv_set_result_buffers(idx._h, None, 0, None, 0, None, 0)
+        idx2.construct()
+        got = idx2.align_builtin(20, 2)
+        assert aset(got["anchors"]) == ref[id(inp)]
+        del got
+        idx = idx2

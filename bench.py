@@ -430,6 +430,7 @@ def main():
         t0 = time.perf_counter()
         last = None
         for _ in range(args.steps):
+            last = None      # (the caller is done with a result before it asks for the next: its arrays are handed back to the library, rv_set_result_buffers)
             last = step(divide)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -591,7 +592,9 @@ def main():
                 idx.construct(); idx.align_builtin(args.minl, args.minn)
                 idx.prof(enable=True, reset=True)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
+                lp = None
                 for _ in range(2):
+                    lp = None
                     idx.construct()
                     lp = idx.align_builtin(args.minl, args.minn)
                 torch.cuda.synchronize(); lp_s = (time.perf_counter() - t0) / 2
@@ -614,7 +617,9 @@ def main():
                 iidx = build_index(iseqs, args.sa64)
                 iidx.construct(); iidx.align_builtin(args.minl, args.minn)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
+                ir = None
                 for _ in range(2):
+                    ir = None
                     iidx.construct()
                     ir = iidx.align_builtin(args.minl, args.minn)
                 torch.cuda.synchronize(); i_s = (time.perf_counter() - t0) / 2

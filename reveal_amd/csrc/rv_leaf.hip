@@ -410,25 +410,29 @@ __global__ __launch_bounds__(NT) void k_leaf(RvLeafArgs A) {
     }
 }
 
-// the matched text of the anchors the leaf launches found, lower-cased when the run ends (reveal.c:1230-1234): one wave per anchor
+// the matched text of the anchors the leaf launches found, lower-cased when the run ends (reveal.c:1230-1234): four anchors per wave -- sixteen lanes
+// per anchor, eight per side, sixteen bytes per lane and step.  (One wave per anchor, half a wave per side and eight bytes per lane: 2 x 10^6 waves of
+// three dependent trips to memory each -- length, positions, text -- were 1.2 ms at 2 x 250 Mbp for 1 GB of traffic; a byte per lane 1.07 ms for
+// 2 x 10^6 anchors of ~120 bases.)  The anchors of a run cover disjoint text, and whole 16-byte pieces never reach beyond the match.
+__device__ inline u64 lower8(u64 x) {
+    // 0x20 in every byte of 'A' .. 'Z': bit 7 of (b + 0x3F) is set from 'A' on, bit 7 of (b + 0x25) from '[' on (bytes below 0x80)
+    const u64 lo7 = x & 0x7F7F7F7F7F7F7F7Full;
+    return x | (((lo7 + 0x3F3F3F3F3F3F3F3Full) & ~(lo7 + 0x2525252525252525ull) & ~x & 0x8080808080808080ull) >> 2);
+}
 __global__ __launch_bounds__(NT) void k_leaf_lower(uint8_t *__restrict__ T, const int64_t *__restrict__ pos, const u32 *__restrict__ len, u32 na) {
-    const u32 e = (u32)(((int64_t)blockIdx.x * NT + threadIdx.x) >> 6);
+    const int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x;
+    const u32 e = (u32)(t >> 4);
     if (e >= na) return;
     const int64_t l = (int64_t)len[e];
-    // half a wave per side, eight bytes per lane and step (a byte per lane: 1.07 ms for 2 x 10^6 anchors of ~120 bases); the anchors of a run
-    // cover disjoint text, and whole words never reach beyond the match
-    const int lane = threadIdx.x & 63, h = lane & 31;
-    uint8_t *const p = T + pos[2 * (size_t)e + (lane >> 5)];
-    for (int64_t j = (int64_t)h * 8; j + 8 <= l; j += 256) {
-        u64 x;
-        __builtin_memcpy(&x, p + j, 8);
-        // 0x20 in every byte of 'A' .. 'Z': bit 7 of (b + 0x3F) is set from 'A' on, bit 7 of (b + 0x25) from '[' on (bytes below 0x80)
-        const u64 lo7 = x & 0x7F7F7F7F7F7F7F7Full;
-        const u64 up = ((lo7 + 0x3F3F3F3F3F3F3F3Full) & ~(lo7 + 0x2525252525252525ull) & ~x & 0x8080808080808080ull) >> 2;
-        x |= up;
-        __builtin_memcpy(p + j, &x, 8);
+    const int side = (int)(t >> 3) & 1, h = (int)t & 7;
+    uint8_t *const p = T + pos[2 * (size_t)e + side];
+    for (int64_t j = (int64_t)h * 16; j + 16 <= l; j += 128) {
+        u64 x[2];
+        __builtin_memcpy(x, p + j, 16);
+        x[0] = lower8(x[0]); x[1] = lower8(x[1]);
+        __builtin_memcpy(p + j, x, 16);
     }
-    for (int64_t j = (l & ~(int64_t)7) + h; j < l; j += 32) { const uint8_t ch = p[j]; if (ch >= 'A' && ch <= 'Z') p[j] = ch + 32; }
+    for (int64_t j = (l & ~(int64_t)15) + h; j < l; j += 8) { const uint8_t ch = p[j]; if (ch >= 'A' && ch <= 'Z') p[j] = ch + 32; }
 }
 
 }  // namespace
@@ -442,7 +446,7 @@ int rv_leaf_launch(Workspace &ws, const RvLeafArgs &a, int nroots) {
 
 int rv_leaf_lower_launch(Workspace &ws, uint8_t *T, const int64_t *pos, const u32 *len, u32 na) {
     if (na == 0) return 0;
-    hipLaunchKernelGGL(k_leaf_lower, dim3((unsigned)ceil_div((int64_t)na * 64, NT)), dim3(NT), 0, ws.stream, T, pos, len, na);
+    hipLaunchKernelGGL(k_leaf_lower, dim3((unsigned)ceil_div((int64_t)na * 16, NT)), dim3(NT), 0, ws.stream, T, pos, len, na);
     RV_LAUNCH_CHECK();
     return 0;
 }

@@ -6,6 +6,7 @@
 // device scratch of the cascade, kept between runs (grow-only like every other buffer of a handle)
 struct RvCascadeBufs {
     DBuf d[40];
+    HBuf hstage, hstage2;              // pinned staging of the multi-sample cascade's results and tables (rv_cascade_multi.hip)
     u32 M = 0, NW = 0;                 // the lists of the last run on this handle (a second attempt starts from them)
     // several sequences per sample (rv_cascade.hip "the lineage of rest sub-indices"): what the first attempt found out on the host,
     // kept for a second attempt on the same lists
@@ -13,7 +14,7 @@ struct RvCascadeBufs {
     int64_t lin_steps = 0; int lin_maxdepth = 0; size_t lin_off[6] = {0, 0, 0, 0, 0, 0};
     // a chain member the match list does not decide: its sequences as (begin, end) pairs and its depth -- the caller makes it the level pipeline's frontier
     std::vector<int64_t> lin_rest; int lin_rest_depth = 0;
-    void release() { for (auto &b : d) b.release(); }
+    void release() { for (auto &b : d) b.release(); hstage.release(); hstage2.release(); }
 };
 
 struct RvCascadeIO {

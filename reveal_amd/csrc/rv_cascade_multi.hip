@@ -800,34 +800,40 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         return 0;
     }
     out->steps = hc[C_STEPS]; out->maxdepth = (int)hc[C_MAXDEPTH];
-    // ---- anchors to the host, their text lower-cased (reveal.c:1230-1234)
+    // ---- anchors to the host, their text lower-cased (reveal.c:1230-1234); the rows of the undecided sub-indices (ids, depths, begins, ends) gathered on
+    // the device (the tables are small next to the index, but only these rows are needed).  Everything through ONE pinned buffer and one wait: copies to
+    // and from pageable vectors are staged by the runtime and waited for one by one (five of them: 0.4 ms of a 10 ms step at 10 x 5 Mbp)
+    const size_t b_anl = 0, b_anp = b_anl + (((size_t)NA * 4 + 15) & ~(size_t)15), b_rows = b_anp + (((size_t)NA * k * sizeof(sa_t) + 15) & ~(size_t)15);
+    const size_t rowbytes = (size_t)U * 8 + (size_t)U * k * sizeof(sa_t) * 2;
+    RV_TRY(cb.hstage.reserve(b_rows + rowbytes + 64));
+    uint8_t *hs = cb.hstage.as<uint8_t>();
     if (NA) {
-        std::vector<sa_t> hp((size_t)NA * k);
-        out->an_l.resize(NA);
-        RV_HIP(hipMemcpyAsync(out->an_l.data(), banl.p, (size_t)NA * 4, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipMemcpyAsync(hp.data(), banp.p, (size_t)NA * k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(hs + b_anl, banl.p, (size_t)NA * 4, hipMemcpyDeviceToHost, q));
+        RV_HIP(hipMemcpyAsync(hs + b_anp, banp.p, (size_t)NA * k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
         RV_TRY(bexp.reserve((size_t)NA * k * 4));
         hipLaunchKernelGGL(k_casm_expand_l, dim3((unsigned)ceil_div((int64_t)NA * k, TB)), dim3(TB), 0, q, (const u32 *)banl.as<u32>(), NA, k, bexp.as<u32>());
         RV_LAUNCH_CHECK();
         hipLaunchKernelGGL(k_casm_lower, dim3((unsigned)ceil_div((int64_t)NA * k * 64, TB)), dim3(TB), 0, q, h->dT.as<uint8_t>(), (const u32 *)bexp.as<u32>(), (const sa_t *)banp.as<sa_t>(), NA * (u32)k);
         RV_LAUNCH_CHECK();
-        RV_HIP(hipStreamSynchronize(q));
-        out->an_pos.assign(hp.begin(), hp.end());
     }
-    // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
     if (U) {
-        // their ids, intervals and depths: gathered on the device (the tables are small next to the index, but only these rows are needed), one
-        // copy, put in the order of the ids on the host
-        const size_t rowbytes = (size_t)U * 8 + (size_t)U * k * sizeof(sa_t) * 2;
         RV_TRY(brows.reserve(rowbytes + 64));
         u32 *d_id = brows.as<u32>(); int32_t *d_dep = (int32_t *)(d_id + U);
         sa_t *d_b = (sa_t *)(d_dep + U), *d_e = d_b + (size_t)U * k;
         hipLaunchKernelGGL(k_casm_rows, dim3((unsigned)ceil_div((int64_t)U * k, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, t, k, d_id, d_dep, d_b, d_e);
         RV_LAUNCH_CHECK();
-        std::vector<uint8_t> hrows(rowbytes);
-        RV_HIP(hipMemcpyAsync(hrows.data(), brows.p, rowbytes, hipMemcpyDeviceToHost, q));
-        RV_HIP(hipStreamSynchronize(q));
-        const u32 *r_id = (const u32 *)hrows.data(); const int32_t *r_dep = (const int32_t *)(r_id + U);
+        RV_HIP(hipMemcpyAsync(hs + b_rows, brows.p, rowbytes, hipMemcpyDeviceToHost, q));
+    }
+    if (NA || U) RV_HIP(hipStreamSynchronize(q));
+    if (NA) {
+        const u32 *pl = (const u32 *)(hs + b_anl); const sa_t *pp = (const sa_t *)(hs + b_anp);
+        out->an_l.assign(pl, pl + NA);
+        out->an_pos.assign(pp, pp + (size_t)NA * k);
+    }
+    // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
+    if (U) {
+        const uint8_t *hrows = hs + b_rows;      // (in the order of the ids on the host)
+        const u32 *r_id = (const u32 *)hrows; const int32_t *r_dep = (const int32_t *)(r_id + U);
         const sa_t *r_b = (const sa_t *)(r_dep + U), *r_e = r_b + (size_t)U * k;
         std::vector<u32> order(U);
         for (u32 x = 0; x < U; x++) order[x] = x;
@@ -864,8 +870,12 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         RV_TRY(bexp.reserve((size_t)(m + 64) * 4));      // (the lower-casing above is done with it: its launch has been waited for)
         CmRoot *d_roots = brt.as<CmRoot>();
         CmSlice *d_slices = (CmSlice *)(d_roots + U);
-        RV_HIP(hipMemcpy(d_roots, roots.data(), (size_t)U * sizeof(CmRoot), hipMemcpyHostToDevice));
-        RV_HIP(hipMemcpy(d_slices, slices.data(), slices.size() * sizeof(CmSlice), hipMemcpyHostToDevice));
+        {      // (roots and slices in one copy from pinned memory, queued in front of the kernels that read them; the staging area's rows have been read)
+            const size_t rbytes = (size_t)U * sizeof(CmRoot), sbytes = slices.size() * sizeof(CmSlice);
+            RV_TRY(cb.hstage2.reserve(rbytes + sbytes + 64));
+            memcpy(cb.hstage2.p, roots.data(), rbytes); memcpy(cb.hstage2.as<uint8_t>() + rbytes, slices.data(), sbytes);
+            RV_HIP(hipMemcpyAsync(d_roots, cb.hstage2.p, rbytes + sbytes, hipMemcpyHostToDevice, q));
+        }
         if (h->ws.opt.casm_rank_count)      // (test hook: the ranks counted out by comparison, k_casm_rank)
             hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
         else

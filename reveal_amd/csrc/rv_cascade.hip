@@ -290,14 +290,16 @@ __global__ __launch_bounds__(TB) void k_cas_lgather(const sa_t *__restrict__ c_p
 }
 
 // ---- one level ----
-constexpr int CAS_ITEMS = 8;
+constexpr int CAS_ITEMS = 4;
 __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa, const sa_t *__restrict__ c_pb, const u32 *__restrict__ c_len, u32 *__restrict__ c_child,
                                                    u32 M, const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
                                                    const CasIv *__restrict__ iv, const CasRes *__restrict__ res, u64 *__restrict__ best, u32 *__restrict__ wmax,
                                                    int64_t minl, int first, const u64 *__restrict__ ceil /* second attempt: bids stay below it (0: none) */) {
     // (the grid covers the matches in whole workgroups, then the witnesses.)  A workgroup takes CAS_ITEMS stretches of TB entries, a wave 64 consecutive
     // ones at a time: at the deep levels most entries are dead, and a workgroup per 256 of them was bound by the dispatch of 8 600 workgroups that
-    // only read one word each -- 33 us per level however few matches were alive
+    // only read one word each -- 33 us per level however few matches were alive.  Every stretch is a chain of dependent trips to memory (the entry's
+    // sub-index, its record, the bid), so more stretches per workgroup cost what fewer workgroups save: 36 / 26.8 / 25.0 us per level with 16 / 8 / 4
+    // (same box; issuing all loads of the stretches first: 30 us -- dead entries load too)
     const u32 mblocks = (M + TB * CAS_ITEMS - 1) / (TB * CAS_ITEMS);
     for (int it = 0; it < CAS_ITEMS; it++) {
     if (blockIdx.x < mblocks) {

@@ -25,3 +25,6 @@ rm -rf $OUT/pmc_fetch $OUT/pmc_write
 bash tools/pmc_wrreq.sh $NAME/wr $R/bench.py --steps 2 --warmup 1 --no-cpu --no-extra --no-check > /dev/null 2>&1
 python tools/ubench/radix_time.py > $OUT/radix_variants.txt 2>&1
 python tools/mem_probe.py 250e6 > $OUT/mem_probe.txt 2>&1
+bash tools/pmc_insts.sh $NAME/insts $R/bench.py --steps 2 --warmup 1 --no-cpu --no-extra --no-check > /dev/null 2>&1
+bash tools/pmc_sq.sh $NAME/sq $R/bench.py --steps 1 --warmup 1 --no-cpu --no-extra --no-check > /dev/null 2>&1
+python bench.py --sa64 --L 1100000000 --steps 3 --warmup 1 --no-cpu --no-extra > $OUT/bench_sa64_2x1100M.json 2> $OUT/bench_sa64_2x1100M.err

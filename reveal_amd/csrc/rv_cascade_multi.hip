@@ -74,9 +74,30 @@ __device__ inline void seg_max32(u32 *__restrict__ dst, u32 child, u32 val, bool
 }
 
 // sample of every rank's suffix (one byte: the walks below read it many times)
+// (sixteen ranks per thread, the separators from LDS: a thread per rank was 7.8 x 10^5 waves of two loads and a byte store, 133 us at 10 x 5 Mbp)
+constexpr int SO_PER = 16;
 __global__ __launch_bounds__(TB) void k_casm_so(const sa_t *__restrict__ SA, int64_t n, const sa_t *__restrict__ nsep, int k, uint8_t *__restrict__ so) {
-    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    if (j < n) so[j] = (uint8_t)cm_sample(nsep, k, SA[j]);
+    __shared__ sa_t s_sep[RV_CASM_K];
+    if ((int)threadIdx.x < RV_CASM_K) s_sep[threadIdx.x] = (int)threadIdx.x < k - 1 ? nsep[threadIdx.x] : (sa_t)0;
+    __syncthreads();
+    const int64_t j0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * SO_PER;
+    if (j0 >= n) return;
+    if (j0 + SO_PER <= n) {
+        sa_t v[SO_PER];
+        __builtin_memcpy(v, SA + j0, sizeof v);
+        u32 w[SO_PER / 4];
+#pragma unroll
+        for (int x = 0; x < SO_PER / 4; x++) w[x] = 0;
+#pragma unroll
+        for (int r = 0; r < SO_PER; r++) {
+            u32 sm = 0;
+            for (int q = 0; q < k - 1; q++) sm += s_sep[q] < v[r] ? 1u : 0u;
+            w[r >> 2] |= sm << (8 * (r & 3));
+        }
+        __builtin_memcpy(so + j0, w, sizeof w);
+    } else {
+        for (int64_t j = j0; j < n; j++) { u32 sm = 0; for (int q = 0; q < k - 1; q++) sm += s_sep[q] < SA[j] ? 1u : 0u; so[j] = (uint8_t)sm; }
+    }
 }
 
 // full matches of the root: the LCP interval of exactly k ranks that ends at rank u (reveal.c:436-580 for n == nsamples).
@@ -314,15 +335,24 @@ __global__ void k_casm_init(CmTabs t, int k, const sa_t *__restrict__ root_b, co
 }
 
 // the match cut to the intervals [B_s, E_s): -> its length (< minl: not there), *sh = how far its start moves
-__device__ inline int64_t cm_cut(const sa_t *__restrict__ p, int k, const sa_t *B, const sa_t *E, int64_t len, int64_t *sh) {
+// (the k coordinates of a match / the k bounds of a sub-index are loaded as whole rows into registers, every load issued before the first one is used:
+// loops of k dependent trips to memory -- and local arrays indexed by a runtime counter, which live in scratch memory -- made a level of ten samples
+// 18 + 11 + 6 us however few sub-indices it held)
+typedef sa_t CmRow[RV_CASM_K];
+__device__ inline void cm_row(const sa_t *__restrict__ src, int k, CmRow &v) {
+#pragma unroll
+    for (int s = 0; s < RV_CASM_K; s++) v[s] = s < k ? src[s] : (sa_t)0;
+}
+__device__ inline int64_t cm_cut(const CmRow &p, int k, const CmRow &B, const CmRow &E, int64_t len, int64_t *sh) {
     int64_t k0 = 0;
-    for (int s = 0; s < k; s++) { const int64_t d = (int64_t)B[s] - (int64_t)p[s]; k0 = d > k0 ? d : k0; }
+#pragma unroll
+    for (int s = 0; s < RV_CASM_K; s++) if (s < k) { const int64_t d = (int64_t)B[s] - (int64_t)p[s]; k0 = d > k0 ? d : k0; }
     int64_t l = len - k0;
-    for (int s = 0; s < k; s++) { const int64_t r = (int64_t)E[s] - ((int64_t)p[s] + k0); l = r < l ? r : l; }
+#pragma unroll
+    for (int s = 0; s < RV_CASM_K; s++) if (s < k) { const int64_t r = (int64_t)E[s] - ((int64_t)p[s] + k0); l = r < l ? r : l; }
     *sh = k0;
     return l;
 }
-
 __global__ __launch_bounds__(TB) void k_casm_assign(const sa_t *__restrict__ c_pos, const u32 *__restrict__ c_len, u32 *__restrict__ c_child, u32 M,
                                                     const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
                                                     CmTabs t, int k, const sa_t *__restrict__ nsep, int64_t minl, int first) {
@@ -334,31 +364,34 @@ __global__ __launch_bounds__(TB) void k_casm_assign(const sa_t *__restrict__ c_p
         bool live = c != NONE;
         u64 key = 0;
         if (live) {
-            const sa_t *p = c_pos + (size_t)i * k;
+            CmRow p, rb, re, rq;
+            cm_row(c_pos + (size_t)i * k, k, p);
+            cm_row(t.b + (size_t)c * k, k, rb); cm_row(t.e + (size_t)c * k, k, re);
+            if (!first) cm_row(t.q + (size_t)c * k, k, rq);
             const int64_t len = (int64_t)c_len[i];
             int64_t sh = 0, l = -1;
             if (!first) {
                 u32 nc = NONE;
-                if (t.state[c] == 1u) {
-                    const sa_t *pb = t.b + (size_t)c * k, *pe = t.e + (size_t)c * k, *q = t.q + (size_t)c * k;
-                    const int64_t L = (int64_t)t.ql[c];
-                    sa_t B[RV_CASM_K], E[RV_CASM_K];
-                    if (t.lead[c] != NONE) {
-                        for (int s = 0; s < k; s++) { B[s] = pb[s]; E[s] = q[s]; }
-                        l = cm_cut(p, k, B, E, len, &sh);
-                        if (l >= minl) nc = t.lead[c];
+                const u32 st = t.state[c], lc = t.lead[c], tc = t.trail[c];
+                const int64_t L = (int64_t)t.ql[c];
+                if (st == 1u) {
+                    if (lc != NONE) {
+                        l = cm_cut(p, k, rb, rq, len, &sh);
+                        if (l >= minl) nc = lc;
                     }
-                    if (nc == NONE && t.trail[c] != NONE) {
-                        for (int s = 0; s < k; s++) { B[s] = (sa_t)((int64_t)q[s] + L); E[s] = pe[s]; }
-                        l = cm_cut(p, k, B, E, len, &sh);
-                        if (l >= minl) nc = t.trail[c];
+                    if (nc == NONE && tc != NONE) {
+                        CmRow B;
+#pragma unroll
+                        for (int s = 0; s < RV_CASM_K; s++) B[s] = (sa_t)((int64_t)rq[s] + L);
+                        l = cm_cut(p, k, B, re, len, &sh);
+                        if (l >= minl) nc = tc;
                     }
                 }
                 c = nc;
                 c_child[i] = c;
                 live = c != NONE;
             } else {
-                l = cm_cut(p, k, t.b + (size_t)c * k, t.e + (size_t)c * k, len, &sh);
+                l = cm_cut(p, k, rb, re, len, &sh);
                 live = l >= minl;
                 if (!live) { c = NONE; c_child[i] = NONE; }
             }
@@ -398,12 +431,15 @@ __global__ __launch_bounds__(TB) void k_casm_winner(const sa_t *__restrict__ c_p
     if (i >= M) return;
     const u32 c = c_child[i];
     if (c == NONE) return;
-    const sa_t *p = c_pos + (size_t)i * k;
+    CmRow p, rb, re;
+    cm_row(c_pos + (size_t)i * k, k, p); cm_row(t.b + (size_t)c * k, k, rb); cm_row(t.e + (size_t)c * k, k, re);
+    const u64 bestc = t.best[c];
     int64_t sh;
-    const int64_t l = cm_cut(p, k, t.b + (size_t)c * k, t.e + (size_t)c * k, (int64_t)c_len[i], &sh);
+    const int64_t l = cm_cut(p, k, rb, re, (int64_t)c_len[i], &sh);
     if (l < minl) return;
-    if ((((u64)l << KEY_SHIFT) | (KEY_LOW - (u64)((int64_t)p[0] + sh))) == t.best[c]) {
-        for (int s = 0; s < k; s++) t.q[(size_t)c * k + s] = (sa_t)((int64_t)p[s] + sh);
+    if ((((u64)l << KEY_SHIFT) | (KEY_LOW - (u64)((int64_t)p[0] + sh))) == bestc) {
+#pragma unroll
+        for (int s = 0; s < RV_CASM_K; s++) if (s < k) t.q[(size_t)c * k + s] = (sa_t)((int64_t)p[s] + sh);
         t.ql[c] = (u32)l;
     }
 }
@@ -421,10 +457,13 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
         int64_t total = 0, mn = (int64_t)1 << 62, nlong = 0; int empty = 0;
         int64_t nlead = 0, ntrail = 0;
         u32 bl = 0, rm = 0, L = 0; int32_t dp = 0;
+        CmRow rb, re, rq;      // the sub-index' row: begins, ends, the chosen match
         if (in) {
+            cm_row(t.b + (size_t)id * k, k, rb); cm_row(t.e + (size_t)id * k, k, re); cm_row(t.q + (size_t)id * k, k, rq);
             bl = (u32)(t.best[id] >> KEY_SHIFT); rm = t.rmax[id]; dp = t.depth[id]; L = t.ql[id];
-            for (int s = 0; s < k; s++) {
-                const int64_t len = (int64_t)t.e[(size_t)id * k + s] - (int64_t)t.b[(size_t)id * k + s];
+#pragma unroll
+            for (int s = 0; s < RV_CASM_K; s++) if (s < k) {
+                const int64_t len = (int64_t)re[s] - (int64_t)rb[s];
                 total += len; mn = len < mn ? len : mn; empty += len <= 0; nlong += len >= (int64_t)minl;
             }
         }
@@ -435,10 +474,11 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
         const bool und = (can && !split && rm >= minl) || (lacking && nlong >= 2);
         if (split) {
             if (L != bl) atomicOr(&counters[C_ERR], 2u);
-            for (int s = 0; s < k; s++) {
-                const int64_t q = t.q[(size_t)id * k + s];
-                nlead += q - (int64_t)t.b[(size_t)id * k + s];
-                ntrail += (int64_t)t.e[(size_t)id * k + s] - q - L;
+#pragma unroll
+            for (int s = 0; s < RV_CASM_K; s++) if (s < k) {
+                const int64_t q = rq[s];
+                nlead += q - (int64_t)rb[s];
+                ntrail += (int64_t)re[s] - q - L;
             }
         }
         const bool lead = split && nlead > 0, trail = split && ntrail > 0;
@@ -459,7 +499,8 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
             u32 lc = NONE, tc = NONE;
             if (lead) {
                 if (slot < child_cap) {
-                    for (int s = 0; s < k; s++) { t.b[(size_t)slot * k + s] = t.b[(size_t)id * k + s]; t.e[(size_t)slot * k + s] = t.q[(size_t)id * k + s]; }
+#pragma unroll
+                    for (int s = 0; s < RV_CASM_K; s++) if (s < k) { t.b[(size_t)slot * k + s] = rb[s]; t.e[(size_t)slot * k + s] = rq[s]; }
                     t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
                     lc = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
@@ -467,14 +508,19 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
             }
             if (trail) {
                 if (slot < child_cap) {
-                    for (int s = 0; s < k; s++) { t.b[(size_t)slot * k + s] = (sa_t)((int64_t)t.q[(size_t)id * k + s] + L); t.e[(size_t)slot * k + s] = t.e[(size_t)id * k + s]; }
+#pragma unroll
+                    for (int s = 0; s < RV_CASM_K; s++) if (s < k) { t.b[(size_t)slot * k + s] = (sa_t)((int64_t)rq[s] + L); t.e[(size_t)slot * k + s] = re[s]; }
                     t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
                     tc = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
             }
             t.lead[id] = lc; t.trail[id] = tc;
             const u32 as = base_a + (u32)__popcll(b_split & lt);
-            if (as < an_cap) { an_l[as] = L; for (int s = 0; s < k; s++) an_pos[(size_t)as * k + s] = t.q[(size_t)id * k + s]; }
+            if (as < an_cap) {
+                an_l[as] = L;
+#pragma unroll
+                for (int s = 0; s < RV_CASM_K; s++) if (s < k) an_pos[(size_t)as * k + s] = rq[s];
+            }
             else atomicOr(&counters[C_ERR], 4u);
         }
         if (in) t.state[id] = split ? 1u : 2u;
@@ -774,8 +820,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         RV_HIP(hipStreamSynchronize(q));      // (the vector leaves scope)
     }
     const sa_t *d_rb = broot.as<sa_t>(), *d_re = d_rb + k;
-    const unsigned nblk = (unsigned)ceil_div(n, TB);
-    hipLaunchKernelGGL(k_casm_so, dim3(nblk), dim3(TB), 0, q, SA, n, nsep, k, bso.as<uint8_t>());
+    hipLaunchKernelGGL(k_casm_so, dim3((unsigned)ceil_div(n, (int64_t)TB * SO_PER)), dim3(TB), 0, q, SA, n, nsep, k, bso.as<uint8_t>());
     RV_LAUNCH_CHECK();
     {
         int pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * (sizeof(sa_t) + sizeof(lcp_t)));

@@ -847,21 +847,25 @@ __global__ __launch_bounds__(TB) void k_publish0(const sav_t *__restrict__ vals,
 // key and its neighbours: 4 GB at n = 5e8 that need not be streamed twice).  head / seed / a head's LCP as in k_heads; SA / BWT and the
 // twin pairs as in k_publish0 -- the second member of a finished pair is a head with its own seed, so the max-scan over the seeds
 // gives it its own group rank.
+constexpr int HP_ITEMS = 4;
 __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t n, uint8_t *__restrict__ head,
                                                       u32 *__restrict__ seed, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA, uint8_t *__restrict__ BWT, sa_t side_sep,
                                                       KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins) {
-    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
-    __shared__ u64 s_key[TB + 4];
-    __shared__ sav_t s_val[TB + 2];
+    // (HP_ITEMS x TB entries per workgroup, staged once: an entry per thread was 7.8 x 10^5 waves at 10 x 5 Mbp, 0.6 ms for 1.3 GB)
+    __shared__ u64 s_key[HP_ITEMS * TB + 4];
+    __shared__ sav_t s_val[HP_ITEMS * TB + 2];
     {
-        const int64_t j0 = (int64_t)blockIdx.x * TB;
-        for (int k = threadIdx.x; k < TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < n) ? keys[i] : 0ull; }
-        for (int k = threadIdx.x; k < TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < n) ? vals[i] : (sav_t)0; }
+        const int64_t j0 = (int64_t)blockIdx.x * (HP_ITEMS * TB);
+        for (int k = threadIdx.x; k < HP_ITEMS * TB + 4; k += TB) { const int64_t i = j0 - 2 + k; s_key[k] = (i >= 0 && i < n) ? keys[i] : 0ull; }
+        for (int k = threadIdx.x; k < HP_ITEMS * TB + 2; k += TB) { const int64_t i = j0 - 1 + k; s_val[k] = (i >= 0 && i < n) ? vals[i] : (sav_t)0; }
         __syncthreads();
     }
     u32 lmax = 0;
+#pragma unroll 1
+    for (int it = 0; it < HP_ITEMS; it++) {
+    const int64_t j = (int64_t)blockIdx.x * (HP_ITEMS * TB) + it * TB + threadIdx.x;
     if (j < n) {
-        const int t = threadIdx.x;
+        const int t = it * TB + (int)threadIdx.x;
         const sav_t s = s_val[t + 1];
         const u64 key = s_key[t + 2];
         const u64 mk = kd.ly.sortmask;
@@ -879,7 +883,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
                 l = l < st ? l : st;
             }
             LCP[j] = (lcp_t)l;
-            lmax = l;
+            lmax = l > lmax ? l : lmax;
         }
         int64_t rank = j;
         const bool first = twins & (km1 != k0) & (kp1 == k0) & (kp2 != k0);
@@ -903,6 +907,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish(const u64 *__restrict__ ke
         head[j] = hd; seed[j] = hd ? (u32)j : 0u;
         SA[rank] = (sa_t)s;
         BWT[rank] = (uint8_t)((u32)(key >> 56) | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u));
+    }
     }
     const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
     if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(d_maxlcp, __ATOMIC_RELAXED)) atomicMax(d_maxlcp, wm);
@@ -2439,7 +2444,7 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_HIP(hipGetLastError());
         keys_by_rank = kt; vals_by_rank = vexp;
     } else if (fused && kd.ly.nd_bits > 0 && !ws.opt.no_heads_fusion) {
-        hipLaunchKernelGGL(k_heads_publish, dim3(nblk), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
+        hipLaunchKernelGGL(k_heads_publish, dim3((unsigned)ceil_div(n, (int64_t)HP_ITEMS * TB)), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, n, head, seed, LCP, SA, BWT, side_sep, kd, d_maxlcp,
                            ws.opt.no_pub_twins ? 0 : 1);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, n));

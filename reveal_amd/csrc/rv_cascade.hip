@@ -301,91 +301,41 @@ __global__ __launch_bounds__(TB) void k_cas_assign(const sa_t *__restrict__ c_pa
     // sub-index, its record, the bid), so more stretches per workgroup cost what fewer workgroups save: 36 / 26.8 / 25.0 us per level with 16 / 8 / 4
     // (same box; issuing all loads of the stretches first: 30 us -- dead entries load too)
     const u32 mblocks = (M + TB * CAS_ITEMS - 1) / (TB * CAS_ITEMS);
-    if (blockIdx.x < mblocks) {
-        // The workgroup's CAS_ITEMS stretches in lockstep, phase by phase: a stretch is a chain of four trips of about a microsecond each -- the entry's
-        // sub-index, its record and the match, the shuffles of the segmented maximum, the word the bid has to beat -- and stretch after stretch a level
-        // cost 8.5 us of wave dispatch (a wave per nanosecond) + four chains; fewer stretches per workgroup only trade the chains for dispatch.  A
-        // stretch whose 64 entries are all dead is skipped by its wave (at the deep levels most are).
-        u32 ii[CAS_ITEMS], cc[CAS_ITEMS]; bool any[CAS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) { ii[it] = (blockIdx.x * CAS_ITEMS + (u32)it) * TB + threadIdx.x; cc[it] = ii[it] < M ? c_child[ii[it]] : NONE; }
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) any[it] = __ballot(cc[it] != NONE) != 0ull;
-        sa_t l_pa[CAS_ITEMS], l_pb[CAS_ITEMS]; u32 l_len[CAS_ITEMS]; CasRes l_r[CAS_ITEMS]; CasIv l_p[CAS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) {
-            if (!any[it]) continue;
-            const bool lv = cc[it] != NONE;      // (a dead entry among live ones reads entry 0 / sub-index 0: no branch around the loads)
-            const u32 i0 = lv ? ii[it] : 0u, c0 = lv ? cc[it] : 0u;
-            l_pa[it] = c_pa[i0]; l_pb[it] = c_pb[i0]; l_len[it] = c_len[i0]; l_p[it] = iv[c0];
-            if (!first) l_r[it] = res[c0];
-        }
-        u64 key[CAS_ITEMS]; bool bid[CAS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) {
-            u32 c = cc[it];
-            bool live = c != NONE;
-            key[it] = 0;
-            if (live) {
-                const int64_t pa = (int64_t)l_pa[it], pb = (int64_t)l_pb[it], len = (int64_t)l_len[it];
-                int64_t qa = 0, qb = 0, ql = 0;
-                const CasIv p = l_p[it];
-                if (!first) {
-                    const CasRes r = l_r[it];
-                    u32 nc = NONE;
-                    if (r.state == 1u) {
-                        // at most one of the two children holds it: a match that covers the parent's choice would be longer than it
-                        CasIv lv; lv.a0 = p.a0; lv.a1 = r.qa; lv.b0 = p.b0; lv.b1 = r.qb;
-                        CasIv tv; tv.a0 = (sa_t)((int64_t)r.qa + r.ql); tv.a1 = p.a1; tv.b0 = (sa_t)((int64_t)r.qb + r.ql); tv.b1 = p.b1;
-                        if (r.lead != NONE && cas_cut(lv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
-                        else if (r.trail != NONE && cas_cut(tv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.trail;
-                    } else if (r.state == 3u) {      // the same sub-index once more, its best cut match set aside (k_cas_decide)
-                        if (cas_cut(p, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
-                    }
-                    c = nc;
-                    c_child[ii[it]] = c;
-                    live = c != NONE;
-                } else {
-                    live = cas_cut(p, pa, pb, len, minl, &qa, &qb, &ql);
-                    if (!live) { c = NONE; c_child[ii[it]] = NONE; }
-                }
-                if (live) key[it] = cas_key(qa, ql);
-            }
-            cc[it] = c;
-            bid[it] = live;
-        }
-        if (ceil) {
-#pragma unroll
-            for (int it = 0; it < CAS_ITEMS; it++) if (bid[it]) { const u64 ce = ceil[cc[it]]; bid[it] = ce == 0 || key[it] < ce; }
-        }
-        // the segmented maxima of the stretches side by side (seg_atomic_max64 for one), then the words they have to beat, then the atomics
-        const int lane = threadIdx.x & 63;
-        u32 ch[CAS_ITEMS]; u64 val[CAS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) { ch[it] = bid[it] ? cc[it] : NONE; val[it] = bid[it] ? key[it] : 0ull; any[it] = __ballot(bid[it]) != 0ull; }
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            u64 ov[CAS_ITEMS]; u32 oc[CAS_ITEMS];
-#pragma unroll
-            for (int it = 0; it < CAS_ITEMS; it++) if (any[it]) { ov[it] = shfl_up64(val[it], d); oc[it] = __shfl_up(ch[it], d, 64); }
-#pragma unroll
-            for (int it = 0; it < CAS_ITEMS; it++) if (any[it] && lane >= d && oc[it] == ch[it] && ov[it] > val[it]) val[it] = ov[it];
-        }
-        bool fire[CAS_ITEMS]; u64 cur[CAS_ITEMS];
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) {
-            fire[it] = false; cur[it] = ~0ull;
-            if (!any[it]) continue;
-            const u32 nc = __shfl_down(ch[it], 1, 64);
-            fire[it] = bid[it] && (lane == 63 || nc != ch[it]);
-            if (fire[it]) cur[it] = best[ch[it]];
-        }
-#pragma unroll
-        for (int it = 0; it < CAS_ITEMS; it++) if (fire[it] && val[it] > cur[it]) atomicMax((unsigned long long *)&best[ch[it]], (unsigned long long)val[it]);
-        return;
-    }
     for (int it = 0; it < CAS_ITEMS; it++) {
-    {
+    if (blockIdx.x < mblocks) {
+        const u32 i = (blockIdx.x * CAS_ITEMS + (u32)it) * TB + threadIdx.x;
+        u32 c = i < M ? c_child[i] : NONE;
+        bool live = c != NONE;
+        u64 key = 0;
+        if (live) {
+            const int64_t pa = (int64_t)c_pa[i], pb = (int64_t)c_pb[i], len = (int64_t)c_len[i];
+            int64_t qa, qb, ql;
+            if (!first) {
+                const CasRes r = res[c];
+                const CasIv p = iv[c];
+                u32 nc = NONE;
+                if (r.state == 1u) {
+                    // at most one of the two children holds it: a match that covers the parent's choice would be longer than it
+                    CasIv lv; lv.a0 = p.a0; lv.a1 = r.qa; lv.b0 = p.b0; lv.b1 = r.qb;
+                    CasIv tv; tv.a0 = (sa_t)((int64_t)r.qa + r.ql); tv.a1 = p.a1; tv.b0 = (sa_t)((int64_t)r.qb + r.ql); tv.b1 = p.b1;
+                    if (r.lead != NONE && cas_cut(lv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
+                    else if (r.trail != NONE && cas_cut(tv, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.trail;
+                } else if (r.state == 3u) {      // the same sub-index once more, its best cut match set aside (k_cas_decide)
+                    if (cas_cut(p, pa, pb, len, minl, &qa, &qb, &ql)) nc = r.lead;
+                }
+                c = nc;
+                c_child[i] = c;
+                live = c != NONE;
+            } else {
+                live = cas_cut(iv[c], pa, pb, len, minl, &qa, &qb, &ql);
+                if (!live) { c = NONE; c_child[i] = NONE; }
+            }
+            if (live) key = cas_key(qa, ql);
+        }
+        bool bid = live;
+        if (live && ceil) { const u64 ce = ceil[c]; bid = ce == 0 || key < ce; }
+        seg_atomic_max64(best, c, key, bid);
+    } else {
         const u32 i = ((blockIdx.x - mblocks) * CAS_ITEMS + (u32)it) * TB + threadIdx.x;
         u32 c = i < NW ? w_child[i] : NONE;
         bool live = c != NONE;

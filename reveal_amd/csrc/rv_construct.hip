@@ -977,9 +977,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
     u32 myflags = 0;
 #pragma unroll
     for (int e = 0; e < TC_PER; e++) myflags += (j0 + e < m && (vv[e + 1] & TW_FLAG)) ? 1u : 0u;
-    u32 inc = myflags;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
+    const u32 inc = rv_wave_incl_sum_u32(myflags);      // (DPP: six shuffles through the LDS crossbar were a sixth of a microsecond of every wave)
     if (lane == 63) wsum[wv] = inc;
     __syncthreads();
     u32 before = blockoff[blockIdx.x] + inc - myflags;
@@ -987,22 +985,22 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
     const int64_t R0 = (int64_t)blockIdx.x * TC_TILE + (int64_t)blockoff[blockIdx.x] - 1;      // slot 0 = the rank in front of the stretch
     u32 span_flags = 0;
     for (int k = 0; k < TB / 64; k++) span_flags += wsum[k];
-    auto put_sa = [&](int64_t rank, sa_t v, uint8_t bw) {
-        const int64_t x = rank - R0;
-        if (x >= 0 && x < TC_SPAN) { o_sa[x] = v; o_bw[x] = bw; } else { SA[rank] = v; BWT[rank] = bw; }
+    // (ranks as slots of the workgroup's stretch -- 32-bit -- wherever they are only compared or used as LDS indices: rank = R0 + slot)
+    auto put_sa = [&](int x, sa_t v, uint8_t bw) {
+        if (x >= 0 && x < TC_SPAN) { o_sa[x] = v; o_bw[x] = bw; } else { SA[R0 + x] = v; BWT[R0 + x] = bw; }
     };
-    auto put_lcp = [&](int64_t rank, u32 l) {
-        const int64_t x = rank - R0;
-        if (x >= 0 && x < TC_SPAN) o_lcp[x] = l; else LCP[rank] = (lcp_t)l;
+    auto put_lcp = [&](int x, u32 l) {
+        if (x >= 0 && x < TC_SPAN) o_lcp[x] = l; else LCP[R0 + x] = (lcp_t)l;
     };
-    auto put_head = [&](int64_t rank, bool v) { o_hd[rank - R0] = v ? 1 : 0; };      // (always a rank of this stretch)
+    auto put_head = [&](int x, bool v) { o_hd[x] = v ? 1 : 0; };      // (always a slot of this stretch)
+    u64 *const kexpR = kexp + R0; sav_t *const vexpR = vexp + R0;
     u32 lmax = 0;
     const u64 mk = kd.ly.sortmask;
 #pragma unroll
     for (int e = 0; e < TC_PER; e++) {
         const int64_t j = j0 + e;
         if (j >= m) break;
-        const int64_t r = j + (int64_t)before;
+        const int r = (int)(j - (int64_t)blockIdx.x * TC_TILE) + (int)(before - blockoff[blockIdx.x]) + 1;      // the entry's slot
         const sav_t sv = vv[e + 1];
         const bool flagged = (sv & TW_FLAG) != 0;
         const sav_t s = sv & ~TW_FLAG;
@@ -1034,19 +1032,19 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             u32 nd = 0; bool lt = false;
             const bool fin = twins && alone && key_hint(key, kd, &nd, &lt);
             const int c = lt ? -1 : 1;
-            const int64_t rs = r + ((fin && c >= 0) ? 1 : 0), rq = r + ((fin && c >= 0) ? 0 : 1);
+            const int rs = r + ((fin && c >= 0) ? 1 : 0), rq = r + ((fin && c >= 0) ? 0 : 1);
             if (fin) {
                 const u32 st = key_first_stop(key, kd);
                 const u32 l = nd < st ? nd : st;
                 put_lcp(r + 1, l);
                 lmax = l > lmax ? l : lmax;
-            } else { kexp[r] = key; kexp[r + 1] = qkey; vexp[r] = s; vexp[r + 1] = q; }
+            } else { kexpR[r] = key; kexpR[r + 1] = qkey; vexpR[r] = s; vexpR[r + 1] = q; }
             put_head(r, hd); put_head(r + 1, fin);
             put_sa(rs, (sa_t)s, (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u)));
             put_sa(rq, (sa_t)q, (uint8_t)(pay | ((sa_t)q > side_sep ? RV_BWT_SIDE : 0u)));
             before++;
         } else {
-            int64_t rank = r;
+            int rank = r;
             // a group of exactly two entries, neither flagged (a twin whose byte in front differs, two unrelated suffixes): k_heads_publish's pair
             const bool first = twins & (km1 != k0) & (kp1 == k0) & (kp2 != k0) & !f_p1;
             const bool second = twins & (km1 == k0) & (kp1 != k0) & (km2 != k0) & !f_m1;
@@ -1056,7 +1054,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                 const u64 pkey = first ? kp1r : km1r;
                 int c; u32 nd;
                 if (hint_cmp2(kd, (int64_t)s, key, (int64_t)ps, pkey, &c, &nd)) {      // I against my partner
-                    const int64_t base = first ? r : r - 1;
+                    const int base = first ? r : r - 1;
                     rank = base + (c < 0 ? 0 : 1);
                     if (rank != base) {
                         const u32 st = key_first_stop(key, kd);
@@ -1068,7 +1066,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
                     fin = true;
                 }
             }
-            if (!fin) { kexp[r] = key; vexp[r] = s; }
+            if (!fin) { kexpR[r] = key; vexpR[r] = s; }
             put_head(r, hd);
             put_sa(rank, (sa_t)s, (uint8_t)(pay | ((sa_t)s > side_sep ? RV_BWT_SIDE : 0u)));
         }

@@ -373,3 +373,38 @@ def test_piecewise_diagonals(monkeypatch, mode, sa64):
             st = idx.sa_stats()
             assert st["diag_table"] == 1 and st["sorted_elems"] < 0.8 * idx.n, st      # the table was used and most twins left
     assert (used > 0) == (mode != "off")
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_first_key_layouts_for_every_alphabet_size(sa64):
+    """the first key packs its symbols in fields of g digits (rv_build_sa picks g per alphabet: three base-5 digits in seven bits for DNA, one
+    symbol per field for 2, 4 or many letters, five base-3 digits in eight bits ...): SA, LCP and the largest LCP equal the oracle's for alphabets
+    of 1 to 88 letters, related and unrelated samples, with and without 'N' -- and the layout the library reports is one of the expected ones"""
+    rng = np.random.default_rng(99)
+    letters = [chr(c) for c in range(65, 91) if chr(c) != "N"] + [chr(c) for c in range(97, 123)] + list("0123456789") + list("!#%&()*+,-./:;<=>?@[]^_{|}~")
+    seen_layouts = set()
+    for nsym in (1, 2, 3, 4, 5, 6, 7, 12, 20, 26, 60, 88):
+        alpha = letters[:nsym]
+        for L, related in ((3000, True), (700, False)):
+            a = "".join(alpha[x] for x in rng.integers(0, nsym, L))
+            if related:
+                b = list(a)
+                for p in np.nonzero(rng.random(L) < 0.02)[0]:
+                    b[p] = alpha[rng.integers(0, nsym)]
+                b = "".join(b)
+                if nsym in (4, 12):
+                    b = b[:500] + "N" * 7 + b[507:]
+            else:
+                b = "".join(alpha[x] for x in rng.integers(0, nsym, L + 13))
+            seqs = [a, b]
+            T, nsep, nodes = assemble(seqs, toupper=False)
+            c = oracle(sa64).construct(T, nsep, 2)
+            idx = feed(mod(sa64).index(), seqs)
+            idx.construct()
+            tag = (nsym, L, related)
+            assert np.array_equal(idx.array("SA"), c["SA"]), tag
+            assert np.array_equal(idx.array("LCP"), c["LCP"]), tag
+            assert idx.maxlcp == int(c["LCP"].max()), tag
+            st = idx.sa_stats()
+            seen_layouts.add((st["sigma"], st["k0"], st["bits"]))
+    assert len(seen_layouts) >= 8, seen_layouts

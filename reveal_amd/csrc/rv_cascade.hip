@@ -82,12 +82,7 @@ __device__ inline u64 shfl_up64(u64 v, int d) {
 __device__ inline void seg_atomic_max64(u64 *__restrict__ dst, u32 child, u64 val, bool active) {
     const int lane = threadIdx.x & 63;
     if (!active) { child = NONE; val = 0; }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u64 ov = shfl_up64(val, d);
-        const u32 oc = __shfl_up(child, d, 64);
-        if (lane >= d && oc == child && ov > val) val = ov;
-    }
+    val = rv_wave_seg_max_u64(child, val);
     const u32 nc = __shfl_down(child, 1, 64);
     const bool last = lane == 63 || nc != child;
     if (active && last && val > dst[child]) atomicMax((unsigned long long *)&dst[child], (unsigned long long)val);
@@ -95,12 +90,7 @@ __device__ inline void seg_atomic_max64(u64 *__restrict__ dst, u32 child, u64 va
 __device__ inline void seg_atomic_max32(u32 *__restrict__ dst, u32 child, u32 val, bool active) {
     const int lane = threadIdx.x & 63;
     if (!active) { child = NONE; val = 0; }
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const u32 ov = __shfl_up(val, d, 64);
-        const u32 oc = __shfl_up(child, d, 64);
-        if (lane >= d && oc == child && ov > val) val = ov;
-    }
+    val = rv_wave_seg_max_u32(child, val);
     const u32 nc = __shfl_down(child, 1, 64);
     const bool last = lane == 63 || nc != child;
     if (active && last && val > dst[child]) atomicMax(&dst[child], val);

@@ -167,6 +167,25 @@ __device__ inline u64 rv_wave_max_u64(u64 v) {
 #undef RV_STEP_
     return ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(v >> 32), 63) << 32) | (u32)__builtin_amdgcn_readlane((int)(u32)v, 63);
 }
+// inclusive maximum over the run of equal `seg` values a lane belongs to (runs are stretches of consecutive lanes): lane i gets the maximum of the
+// values of the lanes of its run at or below i.  The same six DPP steps as the scans: a lane takes its source lane's value when that lane belongs
+// to the same run (then every lane in between does).  (Written with __shfl_up this was eighteen dependent trips through the LDS crossbar per call.)
+__device__ inline u64 rv_wave_seg_max_u64(u32 seg, u64 v) {
+    const int lane = threadIdx.x & 63;
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+#define RV_STEP_(CTRL, RM, TAKE) { const u32 os = rv_dpp_u32<CTRL, RM>(seg), ol = rv_dpp_u32<CTRL, RM>(lo), oh = rv_dpp_u32<CTRL, RM>(hi); \
+                                   const bool up = (TAKE) && os == seg && (oh > hi || (oh == hi && ol > lo)); lo = up ? ol : lo; hi = up ? oh : hi; }
+    RV_WAVE_SCAN_STEPS(RV_STEP_)
+#undef RV_STEP_
+    return ((u64)hi << 32) | lo;
+}
+__device__ inline u32 rv_wave_seg_max_u32(u32 seg, u32 v) {
+    const int lane = threadIdx.x & 63;
+#define RV_STEP_(CTRL, RM, TAKE) { const u32 os = rv_dpp_u32<CTRL, RM>(seg), ov = rv_dpp_u32<CTRL, RM>(v); v = ((TAKE) && os == seg && ov > v) ? ov : v; }
+    RV_WAVE_SCAN_STEPS(RV_STEP_)
+#undef RV_STEP_
+    return v;
+}
 // inclusive prefix sum over the wave
 __device__ inline u32 rv_wave_incl_sum_u32(u32 v) {
     const int lane = threadIdx.x & 63;

@@ -904,11 +904,6 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         RV_HIP(hipMemcpyAsync(hs + b_rows, brows.p, rowbytes, hipMemcpyDeviceToHost, q));
     }
     if (NA || U) RV_HIP(hipStreamSynchronize(q));
-    if (NA) {
-        const u32 *pl = (const u32 *)(hs + b_anl); const sa_t *pp = (const sa_t *)(hs + b_anp);
-        out->an_l.assign(pl, pl + NA);
-        out->an_pos.assign(pp, pp + (size_t)NA * k);
-    }
     // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
     if (U) {
         const uint8_t *hrows = hs + b_rows;      // (in the order of the ids on the host)
@@ -964,6 +959,11 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                            (const u32 *)bexp.as<u32>(), bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
         RV_LAUNCH_CHECK();
         out->d_sa = bsa.p; out->d_lcp = blcp.p; out->d_bwt = bbwt.p;
+    }
+    if (NA) {      // (behind the launches above: the host copies the anchors out of the staging area while the GPU rebuilds the undecided sub-indices)
+        const u32 *pl = (const u32 *)(hs + b_anl); const sa_t *pp = (const sa_t *)(hs + b_anp);
+        out->an_l.assign(pl, pl + NA);
+        out->an_pos.assign(pp, pp + (size_t)NA * k);
     }
     if (verbose) fprintf(stderr, "cascade (%d samples): %u full matches, %u witnesses, %d levels, %u sub-indices, %u anchors, %u undecided (%lld ranks rebuilt)\n", k, M, NW,
                          out->levels, hc[C_NCHILD], NA, U, (long long)out->rebuilt_ranks);

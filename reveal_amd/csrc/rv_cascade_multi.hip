@@ -96,8 +96,11 @@ __global__ __launch_bounds__(TB) void k_casm_so(const sa_t *__restrict__ SA, int
 constexpr int MS_ITEMS = 8;
 constexpr int MS_TILE = TB * MS_ITEMS;
 constexpr int CM_REGIONS = 64;
+// (KT: the number of samples when it is one the kernel was built for -- the windows' loops unrolled, their LDS reads at fixed offsets; 0: any)
+template <int KT>
 __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, const uint8_t *__restrict__ so,
-                                                  int64_t n, int k, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap /* per region */, u32 *__restrict__ region_cnt) {
+                                                  int64_t n, int k_rt, u32 minl, u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 cap /* per region */, u32 *__restrict__ region_cnt) {
+    const int k = KT ? KT : k_rt;
     __shared__ __attribute__((aligned(16))) u32 sl[MS_TILE + RV_CASM_K + 16];          // LCP of ranks u0-HS .. u0+TILE (0 outside the array); HS = the halo rounded up to 16
     __shared__ __attribute__((aligned(16))) uint8_t ss[MS_TILE + RV_CASM_K + 16], sb[MS_TILE + RV_CASM_K + 16];
     __shared__ uint16_t cand[MS_TILE];
@@ -164,10 +167,13 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
         // conditions the kernel ran two scalar instructions of exec-mask bookkeeping for every vector one)
         u32 v = sl[x];
         const u32 nxt = sl[x + 1];
+#pragma unroll
         for (int d = 1; d < H; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; }
         u32 seen = 0;
+#pragma unroll
         for (int d = 0; d <= H; d++) seen |= 1u << ss[x - d];
         bool mx = false;      // left-maximal (reveal.c:246-256; the BWT byte holds '$' where SA == 0)
+#pragma unroll
         for (int d = 1; d <= H; d++) {
             const uint8_t ca = sb[x - d], cb = sb[x - d + 1];
             mx |= (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca >= 'a') & (ca <= 'z'));
@@ -185,6 +191,7 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
                 if (i < cap) {
                     const size_t o = (size_t)reg * cap + i;
                     c_len[o] = v;
+#pragma unroll
                     for (int d = 0; d <= H; d++) c_pos[o * k + ss[x - d]] = SA[u - d];
                 }
             }
@@ -814,7 +821,12 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     RV_LAUNCH_CHECK();
     {
         int pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * (sizeof(sa_t) + sizeof(lcp_t)));
-        hipLaunchKernelGGL(k_casm_scan, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt);
+#define RV_SCAN_(KT) hipLaunchKernelGGL(k_casm_scan<KT>, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt)
+        switch (k) {
+            case 3: RV_SCAN_(3); break; case 4: RV_SCAN_(4); break; case 5: RV_SCAN_(5); break; case 6: RV_SCAN_(6); break; case 8: RV_SCAN_(8); break;
+            case 10: RV_SCAN_(10); break; case 12: RV_SCAN_(12); break; case 16: RV_SCAN_(16); break; default: RV_SCAN_(0); break;
+        }
+#undef RV_SCAN_
         RV_LAUNCH_CHECK();
         h->prof.end(q, pid);
     }

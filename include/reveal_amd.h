@@ -214,8 +214,10 @@ int64_t rv_anchor_count(rv_index *h, int64_t *members);
 int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);
 /* Optional: arrays of the caller's that the NEXT rv_align_builtin runs deliver their anchors into directly (capacities in elements; the
  * layout rv_fetch_anchors fills).  The library page-locks them (hipHostRegister) until they are replaced, cleared (all NULL / 0) or the
- * handle is freed -- they must stay allocated that long.  A run whose result does not fit, or arrays that cannot be locked, use the
- * library's staging buffer as before; rv_fetch_anchors called with these same three pointers then only completes what the run has not
+ * handle is freed -- they must stay allocated that long.  Each array must begin on a page boundary and own the pages it lies on up to
+ * the end of the last one (mmap, posix_memalign to whole pages: locking and unlocking act on whole pages, and a page shared with other
+ * heap objects loses its GPU mapping under them) -- arrays that do not begin on a page boundary are not locked.  A run whose result
+ * does not fit, or arrays that are not / cannot be locked, use the library's staging buffer as before; rv_fetch_anchors called with these same three pointers then only completes what the run has not
  * written itself.  (2 x 250 Mbp: 2 x 10^6 anchors, 65 MB -- copied out of the staging buffer behind the run they were 1.3-1.6 ms of a
  * 25 ms step with the GPU idle.) */
 int rv_set_result_buffers(rv_index *h, uint32_t *l, int64_t l_cap, int64_t *off, int64_t off_cap, int64_t *pos, int64_t pos_cap);

@@ -15,12 +15,22 @@ All compute happens in HBM through libreveal_amd[64].so; nothing here falls
 back to the CPU.
 """
 import ctypes
+import mmap
 import os
 import sys
 import numpy as np
 
 from . import _lib
 from ._lib import RV_T, RV_SA, RV_SAI, RV_LCP, RV_SO, RV_NSEP
+
+
+def _page_array(count, dtype):
+    """an array on pages of its own (anonymous mmap, whole pages): what rv_set_result_buffers page-locks must not share a page with
+    anything else -- arrays from the C heap do (with one another, with whatever numpy allocates next), and locking / unlocking a range
+    acts on whole pages: a later copy into a neighbour of a released array ended in a GPU memory fault now and then"""
+    nbytes = max(int(count), 1) * np.dtype(dtype).itemsize
+    m = mmap.mmap(-1, (nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE)
+    return np.frombuffer(m, dtype=dtype, count=max(int(count), 1))
 
 
 def _pairs(iv, sa64):
@@ -567,8 +577,10 @@ def make_index_type(sa64, error):
                 l, off, pos = c
             else:
                 dll.rv_set_result_buffers(h, None, 0, None, 0, None, 0)      # (the arrays that are replaced may be freed: not the library's any more)
-                l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64)
-                pos = np.empty(max(mem.value, 1), dtype=np.int64)
+                if os.environ.get("RV_RESULT_BUFS", "") == "heap":      # (diagnostics: arrays from the C heap are never page-locked by the library)
+                    l = np.empty(max(na, 1), dtype=np.uint32); off = np.empty(na + 1, dtype=np.int64); pos = np.empty(max(mem.value, 1), dtype=np.int64)
+                else:
+                    l = _page_array(max(na, 1), np.uint32); off = _page_array(na + 1, np.int64); pos = _page_array(max(mem.value, 1), np.int64)
                 self.__dict__["_res_bufs"] = (l, off, pos)
             c = None
             off[0] = 0

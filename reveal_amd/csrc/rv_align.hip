@@ -2377,6 +2377,9 @@ int rv_set_result_buffers(rv_index *h, uint32_t *l, int64_t l_cap, int64_t *off,
         rb = rv_index::ResultBufs();
     }
     if (!l || !off || !pos || l_cap <= 0 || off_cap <= 0 || pos_cap <= 0) return 0;
+    // (whole pages of the caller's only: locking / unlocking act on pages, and a page shared with other heap objects loses its GPU mapping
+    //  under them -- numpy arrays from the C heap, locked here, ended in GPU memory faults of later copies into their neighbours)
+    if ((((uintptr_t)l | (uintptr_t)off | (uintptr_t)pos) & 4095u) != 0 && !h->ws.opt.lock_any) return 0;      // (RV_LOCK_ANY: diagnostics)
     if (hipHostRegister(l, (size_t)l_cap * 4, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); return 0; }      // (not page-lockable: the staging buffer as before)
     if (hipHostRegister(off, (size_t)off_cap * 8, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(l); return 0; }
     if (hipHostRegister(pos, (size_t)pos_cap * 8, hipHostRegisterDefault) != hipSuccess) { (void)hipGetLastError(); (void)hipHostUnregister(l); (void)hipHostUnregister(off); return 0; }

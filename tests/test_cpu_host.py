@@ -282,3 +282,22 @@ def test_gfa_paths_spell_the_inputs(tmp_path, names):
     # gzip output and the default extension
     fn2 = gfa.write_gfa(str(tmp_path / "out2"), segments, links, paths)
     assert fn2.endswith(".gfa.gz") and gfa.read_gfa(fn2)[2] == pp
+
+
+def test_result_arrays_own_their_pages():
+    """what rv_set_result_buffers page-locks begins on a page boundary and shares no page with another object (arrays from the C heap
+    did: GPU memory faults of later copies, profiles/r04_stress_fault.txt); a view keeps the array -- and its refcount -- alive"""
+    import mmap
+    import sys
+    from reveal_amd._index import _page_array
+    a, b = _page_array(3, np.uint32), _page_array(1 << 20, np.int64)
+    for x in (a, b):
+        assert x.ctypes.data % mmap.PAGESIZE == 0 and x.flags.writeable
+    assert len(a) == 3 and len(b) == 1 << 20 and a.dtype == np.uint32
+    lo, hi = sorted((a.ctypes.data, b.ctypes.data))
+    assert hi - lo >= mmap.PAGESIZE
+    before = sys.getrefcount(a)
+    v = a[:2]
+    assert sys.getrefcount(a) == before + 1 and v.base is a
+    b[-1] = 7
+    assert b[-1] == 7

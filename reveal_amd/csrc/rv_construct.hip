@@ -1704,25 +1704,38 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
     // Every entry's suffix, key, sample, position of its homologue in the first sample and hint, once, in LDS: the members of a self-ranking
     // group (ten homologues per group with ten samples) compare from there.  Taken apart per comparison -- two loads and two walks over the
     // separators each -- the kernel was 3.3 ms of a 14.8 ms step at 10 x 5 Mbp.  (Fixed diagonals only: fo.kd.dtab is for two samples.)
-    __shared__ u64 p_key[TB];
-    __shared__ int64_t p_base[TB];
-    __shared__ sav_t p_suf[TB];
-    __shared__ u32 p_info[TB];      // bits 0..3 sample (15: outside the hint's samples), 4 hint known, 5 smaller than the homologue, 8.. agreement
+    // p_w, an entry's place among the homologues of its base as ONE word: bit 31 the hint says something (the base itself, or a variant whose
+    // agreement with the base is known), bits 12..24 the order -- a variant below the base 2 nd (it leaves the base after nd symbols: the earlier,
+    // the smaller), the base 4095, a variant above it 2 (4095 - nd) (the later it leaves, the nearer to the base) --, bits 0..11 the agreement
+    // (the base: all ones).  Two entries with the same base and different orders are ordered by them, their common prefix is the smaller
+    // agreement: hint_cmp case by case.  (Decoded per pair from sample / known / side / agreement the loop below was ~130 vector instructions
+    // per pair, 1 320 per entry with ten samples.)
+    // RT_HALO entries on either side of the workgroup's are staged as well: a group that crosses the workgroup's border -- one in 25 with ten
+    // samples -- sent its members to the path that reads global memory and walks the separators per comparison, and took the whole wave along
+    // for ten rounds: half the waves of the kernel, 0.85 of its 2.35 ms at 10 x 5 Mbp
+    constexpr int RT_HALO = 16;
+    __shared__ int64_t p_base[TB + 2 * RT_HALO];
+    __shared__ sav_t p_suf[TB + 2 * RT_HALO];
+    __shared__ u32 p_w[TB + 2 * RT_HALO];
     const bool pre = fo.kd.ly.nd_bits > 0 && fo.kd.dtab == nullptr;
     if (pre) {
-        u32 info = 15u; u64 key = 0; int64_t base = -1; sav_t sf = 0;
-        if (q < m) {
-            sf = S[q];
-            key = fo.keys[P[q]];
-            const int sm = hint_sample(fo.kd, (int64_t)sf);
-            if (sm < HINT_K && sm < 15) {
-                base = (int64_t)sf - (sm ? fo.kd.Ds[sm] : 0);
-                u32 nd = 0; bool ltb = false;
-                const bool known = key_hint(key, fo.kd, &nd, &ltb);
-                info = (u32)sm | (known ? 16u : 0u) | (ltb ? 32u : 0u) | (nd << 8);
+        for (int t = threadIdx.x; t < TB + 2 * RT_HALO; t += TB) {
+            const int64_t e = (int64_t)blockIdx.x * TB - RT_HALO + t;
+            u32 w = 0; int64_t base = -1; sav_t sf = 0;
+            if (e >= 0 && e < m) {
+                sf = S[e];
+                const u64 key = fo.keys[P[e]];
+                const int sm = hint_sample(fo.kd, (int64_t)sf);
+                if (sm < HINT_K && sm < 15) {
+                    base = (int64_t)sf - (sm ? fo.kd.Ds[sm] : 0);
+                    u32 nd = 0; bool ltb = false;
+                    const bool known = key_hint(key, fo.kd, &nd, &ltb);      // (nd_bits <= 11: nd <= 2046)
+                    if (sm == 0) w = 0x80000000u | (4095u << 12) | 0xFFFu;
+                    else if (known) w = 0x80000000u | ((ltb ? 2u * nd : 2u * (4095u - nd)) << 12) | nd;
+                }
             }
+            p_base[t] = base; p_suf[t] = sf; p_w[t] = w;
         }
-        p_key[threadIdx.x] = key; p_base[threadIdx.x] = base; p_suf[threadIdx.x] = sf; p_info[threadIdx.x] = info;
         __syncthreads();
     }
     const int64_t q0 = (int64_t)blockIdx.x * TB;
@@ -1750,45 +1763,53 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
             const sav_t mine = S[q];
             int rank = 0; bool tie_before = false; u32 best = 0;
             const u64 key_mine = fo.keys[(size_t)g + off];
-            const bool in_lds = pre && qs >= q0 && qs + size <= q0 + TB;
-            const u32 my_info = in_lds ? p_info[threadIdx.x] : 15u;
-            const int64_t my_base = in_lds ? p_base[threadIdx.x] : -1;
-            for (int j = 0; j < size; j++) {
-                if (j == (int)off) continue;
-                u32 l; int c;
-                bool hinted = false;
-                sav_t other;
-                if (in_lds) {
-                    // hint_cmp(other, mine) on what the entries left in LDS, without a branch (written with nested ifs the loop was 1 800 scalar
-                    // instructions per wave of exec-mask bookkeeping beside its 1 300 vector ones)
-                    const int x = (int)(qs - q0) + j;
-                    other = p_suf[x];
-                    const u32 oi = p_info[x];
-                    const u32 so_ = oi & 15u, sm_ = my_info & 15u;
-                    const bool same = (so_ != 15u) & (sm_ != 15u) & (so_ != sm_) & (p_base[x] == my_base);
-                    const bool ko = (so_ != 0u) & ((oi & 16u) != 0u), km = (sm_ != 0u) & ((my_info & 16u) != 0u);
-                    const bool lto = (oi & 32u) != 0u, ltm = (my_info & 32u) != 0u;
-                    const u32 ao = oi >> 8, am = my_info >> 8;
-                    const u32 mn = ao < am ? ao : am;
-                    const bool c0 = (so_ == 0u) & km;                                   // the other one is the base: my hint
-                    const bool c1 = (so_ != 0u) & (sm_ == 0u) & ko;                     // I am the base: its hint
-                    const bool both = (so_ != 0u) & (sm_ != 0u) & ko & km;
-                    const bool c2 = both & (lto != ltm);                                // different sides of the base
-                    const bool c3 = both & (lto == ltm) & (ao != am);                   // the same side: who leaves the base first
-                    hinted = same & (c0 | c1 | c2 | c3);
-                    l = c0 ? am : c1 ? ao : mn;
-                    const bool other_smaller = c0 ? !ltm : c1 ? lto : c2 ? lto : ((ao < am) == lto);
-                    c = other_smaller ? -1 : 1;
-                } else {
-                    other = S[qs + j];
-                    hinted = hint_cmp(fo.kd, (int64_t)other, fo.keys[(size_t)g + j], (int64_t)mine, key_mine, &c, &l);
+            const bool in_lds = pre && qs >= q0 - RT_HALO && qs + size <= q0 + TB + RT_HALO;
+            const u32 my_w = in_lds ? p_w[threadIdx.x + RT_HALO] : 0u;
+            const int64_t my_base = in_lds ? p_base[threadIdx.x + RT_HALO] : -1;
+            const u32 km = (my_w >> 12) & 0x1FFFu, am = my_w & 0xFFFu;
+            if (in_lds) {
+                const int xs = (int)(qs - q0) + RT_HALO;
+                // homologues of one position of the first sample are ordered from their keys (hint_cmp on the words the entries left in LDS): ten
+                // samples put ten of them into every group.  No branch inside: the rounds' LDS reads overlap; a pair the words do not order
+                // (two variants that leave the base at the same place, a chance member of the group: rare) is counted and compared on the text
+                // in a second loop that most waves never enter
+                int unordered = 0; u32 best_h = 0;
+                for (int j = 0; j < size; j++) {
+                    const u32 wo = p_w[xs + j];
+                    const u32 ko = (wo >> 12) & 0x1FFFu, ao = wo & 0xFFFu;
+                    const bool hinted = (((wo & my_w) >> 31) != 0u) & (p_base[xs + j] == my_base) & (ko != km);
+                    const bool lt = hinted & (ko < km);                  // the other one is the smaller suffix
+                    const u32 l = ao < am ? ao : am;
+                    unordered += hinted ? 0 : 1;
+                    rank += lt ? 1 : 0;
+                    best_h = (lt && l > best_h) ? l : best_h;
                 }
-                // homologues of one position of the first sample are ordered from their keys (hint_cmp): ten samples put ten of them into every group
-                if (hinted) l = l < stop0 ? l : stop0;
-                else c = cmp_suffix<W>(T, fo.pk, other, mine, &l, h0, stop0);
-                rank += (c < 0) | ((c == 0) & (j < (int)off));
-                tie_before |= (c == 0) & (j < (int)off);
-                best = (c < 0 && l > best) ? l : best;
+                best = best_h < stop0 ? best_h : stop0;
+                if (unordered > 1) {                                     // (one: the entry itself)
+                    for (int j = 0; j < size; j++) {
+                        const u32 wo = p_w[xs + j];
+                        const bool hinted = (((wo & my_w) >> 31) != 0u) & (p_base[xs + j] == my_base) & (((wo >> 12) & 0x1FFFu) != km);
+                        if (!hinted && j != (int)off) {
+                            u32 l2;
+                            const int c = cmp_suffix<W>(T, fo.pk, p_suf[xs + j], mine, &l2, h0, stop0);
+                            rank += (c < 0) | ((c == 0) & (j < (int)off));
+                            tie_before |= (c == 0) & (j < (int)off);
+                            best = (c < 0 && l2 > best) ? l2 : best;
+                        }
+                    }
+                }
+            } else {
+                for (int j = 0; j < size; j++) {
+                    if (j == (int)off) continue;
+                    u32 l; int c;
+                    const sav_t other = S[qs + j];
+                    const bool hinted = hint_cmp(fo.kd, (int64_t)other, fo.keys[(size_t)g + j], (int64_t)mine, key_mine, &c, &l);
+                    if (hinted) l = l < stop0 ? l : stop0;
+                    else c = cmp_suffix<W>(T, fo.pk, other, mine, &l, h0, stop0);
+                    rank += (c < 0) | ((c == 0) & (j < (int)off));
+                    tie_before |= (c == 0) & (j < (int)off);
+                    best = (c < 0 && l > best) ? l : best;
+                }
             }
             Sout[qs + rank] = mine;
             SA[(size_t)g + rank] = (sa_t)mine;

@@ -1717,14 +1717,33 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
     __shared__ int64_t p_base[TB + 2 * RT_HALO];
     __shared__ sav_t p_suf[TB + 2 * RT_HALO];
     __shared__ u32 p_w[TB + 2 * RT_HALO];
+    __shared__ u64 p_key[TB + 2 * RT_HALO];      // (the key itself: the second member of a pair of twins)
     const bool pre = fo.kd.ly.nd_bits > 0 && fo.kd.dtab == nullptr;
+    const int64_t q0 = (int64_t)blockIdx.x * TB;
+    __shared__ u32 s_G[TB + MEDIUM_GROUP + 1];      // the group ranks of the workgroup's entries and of the 64 behind them (where a group ends is asked entry by entry)
+    // Two trips to memory, each with everything it can bring: suffix, rank and group of the thread's own entry, of a halo entry, of the entries behind
+    // the workgroup -- then the keys at those ranks.  (Staging, group ranks, the entry's own rank / suffix / key and its group's key one after the
+    // other were five dependent trips: 61 % of the waves' cycles waiting for memory, 11 us per wave for 836 vector instructions.)
+    const bool have = q < m;
+    sav_t sf_own = 0; u32 p_own = 0;
+    if (have) { sf_own = S[q]; p_own = P[q]; }
+    const int64_t gi0 = q0 + threadIdx.x, gi1 = q0 + TB + threadIdx.x;
+    const u32 gv0 = G[gi0 < m ? gi0 : m - 1];
+    const u32 gv1 = (int)threadIdx.x <= MEDIUM_GROUP ? G[gi1 < m ? gi1 : m - 1] : 0u;
+    int64_t e2 = -1; sav_t sf2 = 0; u32 p2 = 0;      // the thread's halo entry (the first 2 RT_HALO threads)
+    const int idx2 = (int)threadIdx.x < RT_HALO ? (int)threadIdx.x : TB + (int)threadIdx.x;
+    if (pre && (int)threadIdx.x < 2 * RT_HALO) {
+        e2 = (int)threadIdx.x < RT_HALO ? q0 - RT_HALO + threadIdx.x : q0 + TB + threadIdx.x - RT_HALO;
+        if (e2 >= 0 && e2 < m) { sf2 = S[e2]; p2 = P[e2]; } else e2 = -1;
+    }
+    const u64 key_own = have ? fo.keys[p_own] : 0ull;
+    const u64 key2 = e2 >= 0 ? fo.keys[p2] : 0ull;
+    s_G[threadIdx.x] = gv0;
+    if ((int)threadIdx.x <= MEDIUM_GROUP) s_G[TB + threadIdx.x] = gv1;
     if (pre) {
-        for (int t = threadIdx.x; t < TB + 2 * RT_HALO; t += TB) {
-            const int64_t e = (int64_t)blockIdx.x * TB - RT_HALO + t;
-            u32 w = 0; int64_t base = -1; sav_t sf = 0;
-            if (e >= 0 && e < m) {
-                sf = S[e];
-                const u64 key = fo.keys[P[e]];
+        auto stage = [&](int idx, bool there, sav_t sf, u64 key) {
+            u32 w = 0; int64_t base = -1;
+            if (there) {
                 const int sm = hint_sample(fo.kd, (int64_t)sf);
                 if (sm < HINT_K && sm < 15) {
                     base = (int64_t)sf - (sm ? fo.kd.Ds[sm] : 0);
@@ -1734,24 +1753,21 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
                     else if (known) w = 0x80000000u | ((ltb ? 2u * nd : 2u * (4095u - nd)) << 12) | nd;
                 }
             }
-            p_base[t] = base; p_suf[t] = sf; p_w[t] = w;
-        }
-        __syncthreads();
+            p_base[idx] = base; p_suf[idx] = sf; p_w[idx] = w; p_key[idx] = key;
+        };
+        stage((int)threadIdx.x + RT_HALO, have, sf_own, key_own);
+        if ((int)threadIdx.x < 2 * RT_HALO) stage(idx2, e2 >= 0, sf2, key2);
     }
-    const int64_t q0 = (int64_t)blockIdx.x * TB;
-    // the group ranks of the workgroup's entries and of the 64 behind them, once: where a group ends is asked entry by entry (every member walks to
-    // the end of its group: ten dependent loads each with ten samples)
-    __shared__ u32 s_G[TB + MEDIUM_GROUP + 1];
-    for (int x = threadIdx.x; x < TB + MEDIUM_GROUP + 1; x += TB) { const int64_t i = q0 + x; s_G[x] = G[i < m ? i : m - 1]; }
     __syncthreads();
     auto Gat = [&](int64_t i) -> u32 { const int64_t x = i - q0; return (x >= 0 && x <= TB + MEDIUM_GROUP) ? s_G[x] : G[i]; };
     if (q < m) {
         const u32 g = s_G[threadIdx.x];
-        const u32 off = P[q] - g;
+        const u32 off = p_own - g;
         const int64_t qs = q - (int64_t)off;                       // the group's first list entry (a group is contiguous in the list)
-        const int64_t look = qs + MEDIUM_GROUP, i4 = qs + 4;
+        const int64_t look = qs + MEDIUM_GROUP, i4 = qs + 4 > q ? qs + 4 : q;      // (the fifth entry of the group, or the entry itself when it is a later one: staged)
         const u32 g_look = Gat(look < m ? look : m - 1), g_4 = Gat(i4 < m ? i4 : m - 1);
-        const u64 key_g = fo.keys[g];
+        // (the group's first key is only asked for its first stop among the K symbols -- every member's key holds the same -- and as the first member's own)
+        const u64 key_g = key_own;
         const bool big = off >= (u32)MEDIUM_GROUP || (look < m && g_look == g);
         const bool self = !big && i4 < m && g_4 == g;
         bigflag[q] = big ? 1 : self ? 2 : 0;
@@ -1760,9 +1776,9 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
         if (self) {
             int size = (int)off + 1;
             while (qs + size < m && Gat(qs + size) == g) size++;
-            const sav_t mine = S[q];
+            const sav_t mine = sf_own;
             int rank = 0; bool tie_before = false; u32 best = 0;
-            const u64 key_mine = fo.keys[(size_t)g + off];
+            const u64 key_mine = key_own;
             const bool in_lds = pre && qs >= q0 - RT_HALO && qs + size <= q0 + TB + RT_HALO;
             const u32 my_w = in_lds ? p_w[threadIdx.x + RT_HALO] : 0u;
             const int64_t my_base = in_lds ? p_base[threadIdx.x + RT_HALO] : -1;
@@ -1819,8 +1835,9 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
             // a pair of twins is finished here, from its keys; everything else needs the text at least once: the work list
             const int64_t q2 = q + 2 < m ? q + 2 : m - 1, r1 = (int64_t)g + 1 < n ? (int64_t)g + 1 : n - 1;
             const u32 g_2 = Gat(q2);
-            const sav_t s0 = S[q], s1 = S[q + 1 < m ? q + 1 : m - 1];
-            const u64 key_1 = fo.keys[r1];
+            const bool staged = pre && q + 1 < m;                // (the next entry holds rank g + 1 when it belongs to the group -- and nothing is a pair otherwise)
+            const sav_t s0 = sf_own, s1 = staged ? p_suf[threadIdx.x + RT_HALO + 1] : S[q + 1 < m ? q + 1 : m - 1];
+            const u64 key_1 = staged ? p_key[threadIdx.x + RT_HALO + 1] : fo.keys[r1];
             const bool pair = !(q + 2 < m && g_2 == g);
             int cc; u32 nd;
             const bool hinted = pair && hint_cmp(fo.kd, (int64_t)s0, key_g, (int64_t)s1, key_1, &cc, &nd);

@@ -408,3 +408,30 @@ def test_first_key_layouts_for_every_alphabet_size(sa64):
             st = idx.sa_stats()
             seen_layouts.add((st["sigma"], st["k0"], st["bits"]))
     assert len(seen_layouts) >= 8, seen_layouts
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("count,L,seed", [(5, 40000, 1), (6, 30011, 2), (9, 20000, 3), (10, 60000, 4), (12, 25000, 5), (15, 9000, 6), (16, 8000, 7), (17, 8000, 8)])
+def test_text_round_of_many_samples(count, L, seed, sa64):
+    """groups of one homologue per sample rank themselves from the words their members leave in LDS (k_round_text3: the order among the
+    homologues of a base, entries staged on either side of the workgroup): group sizes 5 to 17 (the hint knows fifteen samples; seventeen
+    members: past the staged border entries), groups across every workgroup border, variants that share a substitution (equal agreement
+    with the base: the text decides), a sample that repeats another, a repeat inside the base -- SA and LCP against the oracle"""
+    rng = np.random.default_rng(100 + seed)
+    gs = [bytearray(g) for g in synth.genomes(L, count, seed=seed, snp=0.01)]
+    # substitutions shared by two or three variants (they leave the base at the same place, on the same side)
+    for _ in range(L // 200):
+        p = int(rng.integers(L)); ch = b"ACGT"[int(rng.integers(4))]
+        for k in rng.choice(np.arange(1, count), size=min(count - 1, int(rng.integers(2, 4))), replace=False):
+            gs[int(k)][p] = ch
+    if count > 5:
+        gs[count - 1] = bytearray(gs[2])                     # a sample twice
+    if L >= 20000:
+        gs[0][5000:5600] = gs[0][1000:1600]                  # a repeat inside the base (the variants keep their own text there)
+    seqs = [bytes(g).decode() for g in gs]
+    T, nsep, nodes = assemble(seqs)
+    idx = feed(mod(sa64).index(), seqs)
+    c = oracle(sa64).construct(T, nsep, count)
+    idx.construct()
+    assert np.array_equal(idx.array("SA"), c["SA"])
+    assert np.array_equal(idx.array("LCP"), c["LCP"])

@@ -1774,8 +1774,23 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
         const int h0 = fo.h;
         const u32 stop0 = key_first_stop(key_g, fo.kd);
         if (self) {
-            int size = (int)off + 1;
-            while (qs + size < m && Gat(qs + size) == g) size++;
+            // the members behind this one, four staged group ranks at a time (one at a time the walk was ten LDS round trips in a row)
+            int size;
+            {
+                const int t = (int)threadIdx.x;
+                const int64_t left = m - q;                              // entries from this one to the end of the list
+                int d = 1;
+                for (;;) {
+                    const int i0 = t + d;                                // (a group has fewer than MEDIUM_GROUP members: the indices stay inside s_G but for the last step's)
+                    const u32 a = s_G[i0 < TB + MEDIUM_GROUP ? i0 : TB + MEDIUM_GROUP], b = s_G[i0 + 1 < TB + MEDIUM_GROUP ? i0 + 1 : TB + MEDIUM_GROUP];
+                    const u32 c = s_G[i0 + 2 < TB + MEDIUM_GROUP ? i0 + 2 : TB + MEDIUM_GROUP], e = s_G[i0 + 3 < TB + MEDIUM_GROUP ? i0 + 3 : TB + MEDIUM_GROUP];
+                    int k = a != g ? 0 : b != g ? 1 : c != g ? 2 : e != g ? 3 : 4;
+                    if ((int64_t)(d + k) > left) k = (int)(left - d);      // (behind the list's end the staged ranks repeat the last entry's)
+                    d += k;
+                    if (k < 4 || d >= MEDIUM_GROUP) break;
+                }
+                size = (int)off + d;
+            }
             const sav_t mine = sf_own;
             int rank = 0; bool tie_before = false; u32 best = 0;
             const u64 key_mine = key_own;
@@ -1790,15 +1805,20 @@ __global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ 
                 // (two variants that leave the base at the same place, a chance member of the group: rare) is counted and compared on the text
                 // in a second loop that most waves never enter
                 int unordered = 0; u32 best_h = 0;
-                for (int j = 0; j < size; j++) {
-                    const u32 wo = p_w[xs + j];
-                    const u32 ko = (wo >> 12) & 0x1FFFu, ao = wo & 0xFFFu;
-                    const bool hinted = (((wo & my_w) >> 31) != 0u) & (p_base[xs + j] == my_base) & (ko != km);
-                    const bool lt = hinted & (ko < km);                  // the other one is the smaller suffix
-                    const u32 l = ao < am ? ao : am;
-                    unordered += hinted ? 0 : 1;
-                    rank += lt ? 1 : 0;
-                    best_h = (lt && l > best_h) ? l : best_h;
+                for (int j0 = 0; j0 < size; j0 += 4) {                   // (four members a round: eight LDS reads in flight)
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const bool in = j0 + u < size;
+                        const int x = xs + (in ? j0 + u : (int)off);     // (past the group's end: the entry itself, which nothing orders)
+                        const u32 wo = p_w[x];
+                        const u32 ko = (wo >> 12) & 0x1FFFu, ao = wo & 0xFFFu;
+                        const bool hinted = (((wo & my_w) >> 31) != 0u) & (p_base[x] == my_base) & (ko != km);
+                        const bool lt = hinted & (ko < km);              // the other one is the smaller suffix
+                        const u32 l = ao < am ? ao : am;
+                        unordered += (in & !hinted) ? 1 : 0;
+                        rank += lt ? 1 : 0;
+                        best_h = (lt && l > best_h) ? l : best_h;
+                    }
                 }
                 best = best_h < stop0 ? best_h : stop0;
                 if (unordered > 1) {                                     // (one: the entry itself)

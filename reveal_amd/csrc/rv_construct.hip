@@ -1693,8 +1693,9 @@ __device__ __forceinline__ int load_small(const sav_t *__restrict__ S, const u32
     for (int j = 1; j < 4; j++) size += (size == j && q + j < m && gg[j] == g) ? 1 : 0;
     return size;
 }
+// (eight waves per SIMD: 64 registers, three spilled -- the kernel waits for memory, 1.49 -> 1.30 ms at 10 x 5 Mbp; k_round_text3b at six: 0.45 -> 0.70 ms at 2 x 250 Mbp, not taken)
 template <int W>
-__global__ __launch_bounds__(TB) void k_round_text3(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
+__global__ __launch_bounds__(TB, 8) void k_round_text3(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P,
                                                     int64_t m, int64_t n, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
                                                     sav_t *__restrict__ Sout, FusedOut fo, u32 *__restrict__ work, u32 *__restrict__ work_count, u32 reg_cap) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;

@@ -1771,7 +1771,7 @@ __global__ __launch_bounds__(TB, 8) void k_round_text3(const uint8_t *__restrict
         const u64 key_g = key_own;
         const bool big = off >= (u32)MEDIUM_GROUP || (look < m && g_look == g);
         const bool self = !big && i4 < m && g_4 == g;
-        bigflag[q] = big ? 1 : self ? 2 : 0;
+        if (!self) bigflag[q] = big ? 1 : 0;
         const int h0 = fo.h;
         const u32 stop0 = key_first_stop(key_g, fo.kd);
         if (self) {
@@ -1848,7 +1848,12 @@ __global__ __launch_bounds__(TB, 8) void k_round_text3(const uint8_t *__restrict
                     best = (c < 0 && l > best) ? l : best;
                 }
             }
-            Sout[qs + rank] = mine;
+            // a group inside the workgroup's own entries has been read (into LDS) before the barrier, by this workgroup and as halo of its neighbours,
+            // which rank none of its members: its list entries are rewritten in place.  A group across the border is ranked by two workgroups
+            // that both read its entries: into the spare list, k_medium_back copies those back (flag 2)
+            const bool own = in_lds && qs >= q0 && qs + size <= q0 + TB;
+            bigflag[q] = own ? 0 : 2;
+            (own ? S : Sout)[qs + rank] = mine;
             SA[(size_t)g + rank] = (sa_t)mine;
             headq[qs + rank] = !tie_before;
             fused_put(fo, (size_t)g + rank, mine, (u32)(key_mine >> 56), rank == 0, best, lmax);

@@ -943,7 +943,7 @@ __device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
 // rank order, written for the unfinished only).  No group ranks: the compaction of the unfinished reads them off the head flags (k_cp_emit_g).
 // (Laying a round's ranks out in LDS first and writing whole runs made no difference -- switching the writes off altogether takes 0.1 of
 // 12 ms at 2 x 100 Mbp: the kernel waits for its keys, not for its stores.)
-__global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
+__global__ __launch_bounds__(TB, 8) void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
                                                          uint8_t *__restrict__ head, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
                                                          uint8_t *__restrict__ BWT, sa_t side_sep, KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins,
                                                          u64 *__restrict__ kexp, sav_t *__restrict__ vexp) {
@@ -958,9 +958,9 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
     constexpr int TC_SPAN = 2 * TC_TILE + 2;
     constexpr sa_t SA_NONE = (sa_t)~(sa_t)0;
     __shared__ sa_t o_sa[TC_SPAN];
-    __shared__ u32 o_lcp[TC_SPAN];
+    __shared__ uint16_t o_lcp[TC_SPAN];      // (a head's common digits, a twin's agreement: below 2^11.  Four bytes each the arrays were 20 560 bytes -- seven workgroups per CU, eighty bytes short of eight)
     __shared__ uint8_t o_bw[TC_SPAN], o_hd[TC_SPAN];
-    for (int x = threadIdx.x; x < TC_SPAN; x += TB) { o_sa[x] = SA_NONE; o_lcp[x] = 0xFFFFFFFFu; }
+    for (int x = threadIdx.x; x < TC_SPAN; x += TB) { o_sa[x] = SA_NONE; o_lcp[x] = (uint16_t)0xFFFFu; }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t j0 = ((int64_t)blockIdx.x * TB + threadIdx.x) * TC_PER;
     u64 kk[TC_PER + 4];          // keys j0 - 2 .. j0 + 5
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
         if (x >= 0 && x < TC_SPAN) { o_sa[x] = v; o_bw[x] = bw; } else { SA[R0 + x] = v; BWT[R0 + x] = bw; }
     };
     auto put_lcp = [&](int x, u32 l) {
-        if (x >= 0 && x < TC_SPAN) o_lcp[x] = l; else LCP[R0 + x] = (lcp_t)l;
+        if (x >= 0 && x < TC_SPAN && l < 0xFFFFu) o_lcp[x] = (uint16_t)l; else LCP[R0 + x] = (lcp_t)l;
     };
     auto put_head = [&](int x, bool v) { o_hd[x] = v ? 1 : 0; };      // (always a slot of this stretch)
     u64 *const kexpR = kexp + R0; sav_t *const vexpR = vexp + R0;
@@ -1082,7 +1082,7 @@ __global__ __launch_bounds__(TB) void k_heads_publish_tc(const u64 *__restrict__
             const sa_t v = o_sa[x];
             if (v != SA_NONE) { SA[rank] = v; BWT[rank] = o_bw[x]; }
             const u32 l = o_lcp[x];
-            if (l != 0xFFFFFFFFu) LCP[rank] = (lcp_t)l;
+            if (l != 0xFFFFu) LCP[rank] = (lcp_t)l;
             if (x >= 1 && x <= own) head[rank] = o_hd[x];
         }
     }

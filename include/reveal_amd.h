@@ -238,8 +238,10 @@ int rv_set_trace(rv_index *h, int on);
  * rv_align_begin and rv_align_end report only those, in emission order; a sub-index without a match in every sample keeps
  * its whole list (schemes.py:229-232 segments over all of them).  0 = off.  A picker that starts with the same filter and
  * cap (graphmumpicker with --maxmums, no --trim) returns what it returns on the full list.  The n == nsamples filter runs in the
- * scan kernel (only what passes it is copied to the host; a sub-index left without a match is scanned again without the filter), the cap
- * on the host side of this ABI. */
+ * scan kernel (only what passes it is copied to the host; a sub-index left without a match is scanned again without the filter).  The cap:
+ * with two samples the `maxmums` longest of every sub-index are chosen on the device once a level holds RV_PRESEL_DEV_MIN records (option,
+ * default 65536: a stable sort of (sub-index, length) keys, the last `maxmums` of every run kept, the kept records in their old order --
+ * the others never cross into host memory); smaller levels and more than two samples: on the host side of this ABI. */
 int rv_set_preselect(rv_index *h, int64_t maxmums);
 /* Switches of one handle: test hooks, diagnostics and A/B paths (reveal_amd/csrc/rv_common.h RV_OPTION_LIST has the names and
  * defaults -- the historical RV_* spellings, e.g. "RV_NO_CASCADE").  The library never reads the process environment: a handle

@@ -735,8 +735,22 @@ int rv_frontier_scan(rv_index *h) {
         const bool early = d_ss && a->cur_dev_ok && !h->ws.opt.no_early_split;
         a->hook_early = early;
         if (early) RV_TRY(h->hscan.reserve((size_t)(ns + RV_PAIR_HDR) * sizeof(RvPairRec)));      // (the hook needs the final address of the picks)
+        // rv_set_preselect with Python callbacks: the `presel` longest matches of every sub-index are chosen on the device when the level holds
+        // many (RV_PRESEL_DEV_MIN records; the host caps what arrives otherwise -- build_preselection, which leaves a chosen list as it is)
+        const int64_t *d_ps = nullptr;
+        if (a->presel_on && !a->full_only && ns > 0 && !h->ws.opt.presel_host) {
+            Packer &pk = a->pk;
+            pk.clear();
+            std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
+            const size_t o1 = pk.addv(ss);
+            DBuf &buf = h->ws.misc[10];
+            RV_TRY(buf.reserve(pk.size() + 64));
+            RV_HIP(hipMemcpyAsync(buf.p, pk.data(), pk.size(), hipMemcpyHostToDevice, h->ws.stream));
+            d_ps = (const int64_t *)(buf.as<uint8_t>() + o1);
+        }
         RV_TRY(rv_run_pair_scan(h, cur_sa(h), cur_lcp(h), cur_bwt(h), a->lv.m, a->minl, a->recs, a->dErr.as<u32>(), &err, d_ss, ns, level_hook, early || a->leaf_launch_due,
-                                (d_ss && a->cur_dev_ok) ? a->d_next_tsub2 : nullptr));
+                                (d_ss && a->cur_dev_ok) ? a->d_next_tsub2 : nullptr, d_ps, ns, a->presel));
+        if (a->presel_on && !a->full_only) a->presel_d2h += (int64_t)a->recs.size();
         RV_TRY(report_dev_err(err));
         int si = 0;
         for (size_t k = 0; k < a->recs.size(); k++) {

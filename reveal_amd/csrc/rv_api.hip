@@ -97,6 +97,7 @@ void rv_free(rv_index *h) {
     h->dT.release(); h->dT0.release(); h->dSA.release(); h->dSAi.release(); h->dLCP.release(); h->dBWT.release(); h->dNsep.release();
     h->ws.release();
     h->hscan.release();
+    for (auto &b : h->ps) b.release();
     h->hupload.release();
     if (h->ev_picks) { (void)hipEventDestroy(h->ev_picks); h->ev_picks = nullptr; }
     if (h->ws.stream) rv_stream_put(h->ws.stream);
@@ -468,9 +469,66 @@ int rv_text_only(rv_index *h, u32 maxlcp) {
 // pair scan driver: scan kernel -> scan of the tile counts -> compaction ->
 // one D2H copy of the dense, rank-ordered records
 // ---------------------------------------------------------------------------
+// rv_set_preselect on two samples (reveal/schemes.py:240, 287-289): of every sub-index the `presel` longest matches, of equal
+// lengths the later emitted, in emission order -- chosen on the device, so that the others never cross into host memory (2 x 10^6 records of
+// 16 bytes at the top level of 2 x 250 Mbp).  The dense records are in rank order = emission order: (sub-index, length) keys with the record
+// number as value through the library's stable radix sort; inside a sub-index the last `presel` of the sorted run stay (equal lengths keep their
+// emission order in a stable sort: the later ones are the last); flags -> offsets -> the kept records in their old order.
+namespace {
+__global__ __launch_bounds__(256) void k_ps_keys(const RvPairRec *__restrict__ recs, u32 total, const int64_t *__restrict__ ss, int ns, u64 *__restrict__ keys, u32 *__restrict__ vals) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const int64_t r = (int64_t)recs[i].rank;
+    int lo = 0, hi = ns;                                      // the last sub-index that starts at or before r (ss[0] = 0, ss[ns] = the level's size)
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (ss[mid] <= r) lo = mid; else hi = mid; }
+    keys[i] = ((u64)(u32)lo << 32) | (u64)recs[i].l;
+    vals[i] = i;
+}
+__global__ __launch_bounds__(256) void k_ps_mark(const u64 *__restrict__ skeys, const u32 *__restrict__ svals, u32 total, u32 presel, u32 *__restrict__ flag) {
+    const u32 p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= total) return;
+    const u64 next = ((skeys[p] >> 32) + 1ull) << 32;          // the first key of the next sub-index
+    u32 lo = p, hi = total;                                   // skeys[lo] < next; the first position at or above `next` ends up in hi
+    while (hi - lo > 1) { const u32 mid = lo + ((hi - lo) >> 1); if (skeys[mid] < next) lo = mid; else hi = mid; }
+    flag[svals[p]] = (hi - p <= presel) ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_ps_emit(const RvPairRec *__restrict__ recs, const u32 *__restrict__ flag, const u32 *__restrict__ off, u32 total, RvPairRec *__restrict__ out) {
+    const u32 i = blockIdx.x * 256u + threadIdx.x;
+    if (i < total && flag[i]) out[off[i]] = recs[i];
+}
+}  // namespace
+static int pair_topk(rv_index *h, const RvPairRec *recs, u32 total, const int64_t *d_ss, int ns, int64_t presel, std::vector<RvPairRec> &out) {
+    hipStream_t q = h->ws.stream;
+    DBuf *b = h->ps;
+    RV_TRY(b[0].reserve((size_t)total * 8 + 64)); RV_TRY(b[1].reserve((size_t)total * 8 + 64));
+    RV_TRY(b[2].reserve((size_t)total * 4 + 64)); RV_TRY(b[3].reserve((size_t)total * 4 + 64));
+    RV_TRY(b[4].reserve(((size_t)total + 1) * 4 + 64)); RV_TRY(b[5].reserve(((size_t)total + 1) * 4 + 64));
+    RV_TRY(b[6].reserve((size_t)total * sizeof(RvPairRec) + 64));
+    const unsigned grid = (unsigned)ceil_div((int64_t)total, 256);
+    hipLaunchKernelGGL(k_ps_keys, dim3(grid), dim3(256), 0, q, recs, total, d_ss, ns, b[0].as<u64>(), b[2].as<u32>());
+    RV_LAUNCH_CHECK();
+    int segbits = 1;
+    while (segbits < 31 && ((int64_t)1 << segbits) < (int64_t)ns) segbits++;
+    int in1 = 0;
+    RV_TRY(rv_radix_sort_pairs<u32>(h->ws, b[0].as<u64>(), b[2].as<u32>(), b[1].as<u64>(), b[3].as<u32>(), (int64_t)total, 0, 32 + segbits, &in1));
+    RV_HIP(hipMemsetAsync(b[4].p, 0, ((size_t)total + 1) * 4, q));
+    const u32 keep = (u32)std::min<int64_t>(presel, 0xffffffffll);
+    hipLaunchKernelGGL(k_ps_mark, dim3(grid), dim3(256), 0, q, (const u64 *)(in1 ? b[1].p : b[0].p), (const u32 *)(in1 ? b[3].p : b[2].p), total, keep, b[4].as<u32>());
+    RV_LAUNCH_CHECK();
+    RV_TRY(rv_exclusive_sum_u32(h->ws, b[4].as<u32>(), b[5].as<u32>(), (int64_t)total + 1));
+    hipLaunchKernelGGL(k_ps_emit, dim3(grid), dim3(256), 0, q, recs, (const u32 *)b[4].p, (const u32 *)b[5].p, total, b[6].as<RvPairRec>());
+    RV_LAUNCH_CHECK();
+    u32 cnt = 0;
+    RV_TRY(rv_read_back(h->ws, &cnt, b[5].as<u32>() + total, 4));
+    if (cnt > total) { rv_set_error("preselect: more records kept than scanned"); return -1; }
+    out.resize(cnt);
+    if (cnt) RV_TRY(rv_read_back(h->ws, out.data(), b[6].p, (size_t)cnt * sizeof(RvPairRec)));
+    return 0;
+}
+
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
                      const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs, int (*after_pick)(rv_index *), bool use_hook,
-                     const int *d_tile_sub) {
+                     const int *d_tile_sub, const int64_t *d_presel_start, int presel_subs, int64_t presel) {
     out.clear();
     if (err_out) *err_out = 0;
     if (m <= 1) {
@@ -530,6 +588,18 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
                                       (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err, (u32)std::min<size_t>(vcap, 0xffffffffu)));
+        if (d_presel_start && presel > 0 && presel_subs > 0) {
+            // (the header first: the level's record count says whether the device does the choosing)
+            u32 hdr4[4];
+            RV_TRY(rv_read_back(h->ws, hdr4, bout.p, sizeof hdr4));
+            const u32 total = hdr4[0], novf = hdr4[1];
+            if (total <= ocap && novf <= vcap && (int64_t)total >= h->ws.opt.presel_dev_min && (int64_t)total > presel) {
+                if (err_out) *err_out = hdr4[2];
+                RV_TRY(pair_topk(h, bout.as<RvPairRec>() + RV_PAIR_HDR, total, d_presel_start, presel_subs, presel, out));
+                h->scan_guess = (size_t)total + total / 16 + 64;
+                return 0;
+            }
+        }
         // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
         size_t guess = std::min<size_t>(ocap, h->scan_guess);
         RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));

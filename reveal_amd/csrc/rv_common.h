@@ -92,7 +92,8 @@ void rv_set_error(const char *fmt, ...);
     X(diag_table, "RV_DIAG_TABLE", -1) \
     X(no_cascade_chain, "RV_NO_CASCADE_CHAIN", 0) \
     X(casm_rank_count, "RV_CASM_RANK_COUNT", 0) \
-    X(lock_any, "RV_LOCK_ANY", 0)
+    X(lock_any, "RV_LOCK_ANY", 0) \
+    X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)

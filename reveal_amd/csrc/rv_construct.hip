@@ -943,7 +943,12 @@ __device__ inline u64 tw_twin_key(u64 key, const KeyDigits &kd) {
 // rank order, written for the unfinished only).  No group ranks: the compaction of the unfinished reads them off the head flags (k_cp_emit_g).
 // (Laying a round's ranks out in LDS first and writing whole runs made no difference -- switching the writes off altogether takes 0.1 of
 // 12 ms at 2 x 100 Mbp: the kernel waits for its keys, not for its stores.)
-__global__ __launch_bounds__(TB, 8) void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
+#ifdef RV_SA64
+#define RV_TC_BOUNDS __launch_bounds__(TB)          // (eight-byte suffixes: 24.6 KB of LDS per workgroup, six workgroups per CU whatever the registers)
+#else
+#define RV_TC_BOUNDS __launch_bounds__(TB, 8)
+#endif
+__global__ RV_TC_BOUNDS void k_heads_publish_tc(const u64 *__restrict__ keys, const sav_t *__restrict__ vals, int64_t m, const u32 *__restrict__ blockoff,
                                                          uint8_t *__restrict__ head, lcp_t *__restrict__ LCP, sa_t *__restrict__ SA,
                                                          uint8_t *__restrict__ BWT, sa_t side_sep, KeyDigits kd, u32 *__restrict__ d_maxlcp, int twins,
                                                          u64 *__restrict__ kexp, sav_t *__restrict__ vexp) {

@@ -89,6 +89,7 @@ struct rv_index {
     HBuf hupload;                      // two pinned chunks for the text's way into HBM (rv_upload)
     hipEvent_t ev_picks = nullptr;     // recorded behind the picker kernels: the host waits for this, not for the stream
     size_t scan_guess = 4096;
+    DBuf ps[7];                        // rv_set_preselect on two samples: the longest matches of every sub-index chosen on the device (pair_topk, rv_api.hip)
     u32 maxlcp = 0;
     RvSaStats sa_stats{};
     // ---- scan results of the main index (getmums / getmultimums)
@@ -115,7 +116,8 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
 int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t m, int minl, std::vector<RvPairRec> &out,
                      const u32 *d_err, u32 *err_out, const int64_t *d_sub_start, int nsubs,   // d_sub_start != NULL: only the best record per sub-index
                      int (*after_pick)(rv_index *), bool use_hook,
-                     const int *d_tile_sub = nullptr);                                       // ... tile -> sub-index table of the level (optional, speeds the picker's look-ups)                        // ... and a hook called once the picker kernels are queued
+                     const int *d_tile_sub = nullptr,                                        // ... tile -> sub-index table of the level (optional, speeds the picker's look-ups)
+                     const int64_t *d_presel_start = nullptr, int presel_subs = 0, int64_t presel = 0);   // rv_set_preselect: of every sub-index (starts on the device, presel_subs + 1 of them) only the `presel` longest records come back                        // ... and a hook called once the picker kernels are queued
 
 // text, shared inverse and separators in HBM without an index (rv_api.hip); maxlcp = window size of bubble_sort
 int rv_text_only(rv_index *h, u32 maxlcp);

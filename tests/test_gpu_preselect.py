@@ -180,3 +180,39 @@ def test_preselect_off_again_and_errors():
     n = len(idx.getmums(20))
     idx.preselect(1)
     assert len(idx.getmums(20)) == n and n > 1
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("maxmums", [1, 4, 50])
+@pytest.mark.parametrize("name,inputs,minl", [("1a1b", fa("1a", "1b"), 20), ("synthetic2", [g.decode() for g in synth.genomes(80000, 2, seed=3)], 12)])
+def test_cap_applied_on_the_device(monkeypatch, name, inputs, minl, maxmums, sa64):
+    """two samples: the `maxmums` longest matches of every sub-index are chosen on the device (pair_topk, rv_api.hip) once a level holds
+    RV_PRESEL_DEV_MIN records -- 0 here: every level -- instead of on the host from everything that was copied (10^9: never on the device).
+    The picker receives the same lists either way, order included: of equal lengths the later emitted stay (minl 12 on random text: many
+    ties); they are head(list) of themselves and no longer than the cap; the alignment is the same.  (What the host's cap hands out is
+    compared with the reference's own selection in the tests above and in tools/fuzz_preselect.py, which runs both forms.)"""
+    host, dev = {}, {}
+
+    def recorder(store):
+        def pick(mums, idx, precomputed=False, minlength=0):
+            store[(idx.depth, min(idx.nodes))] = (list(mums), idx.nsamples)
+            return rem.bench_mumpicker(mums, idx)
+        return pick
+    from reveal_amd import reveallib, reveallib64
+    texts = []
+    for store, dev_min in ((host, "1000000000"), (dev, "0")):
+        monkeypatch.setenv("RV_PRESEL_DEV_MIN", dev_min)
+        idx = feed((reveallib64 if sa64 else reveallib).index(), inputs)
+        idx.construct()
+        idx.preselect(maxmums)
+        idx.align(recorder(store), rem.linear_graphalign, minl=minl, minn=2)
+        texts.append(idx.T)
+    assert texts[0] == texts[1]
+    assert host.keys() == dev.keys() and len(host) > 3
+    full_lists = 0
+    for key, (mums, ns) in host.items():
+        sel = dev[key][0]
+        assert sel == mums, key
+        assert len(sel) <= maxmums and head(sel, ns, maxmums) == sorted(sel, key=lambda m: (m[1], m[0]))
+        full_lists += len(sel) == maxmums
+    assert full_lists > 0

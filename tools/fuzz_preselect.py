@@ -29,6 +29,7 @@ def main():
         seqs = [s.decode() if isinstance(s, (bytes, bytearray)) else s for s in seqs]
         sa64 = rng.random() < 0.25
         maxmums = rng.choice([1, 2, 5, 40, 1000])
+        os.environ["RV_PRESEL_DEV_MIN"] = rng.choice(["0", "65536"])      # two samples: the cap applied on the device at every level / on the host
         try:
             T1, an1, tr1, _ = run(seqs, maxmums, True, minl, sa64)
             To, ano, tro = oracle_recursion(seqs, maxmums, minl, sa64)
@@ -38,7 +39,7 @@ def main():
             saved[0] += sum(r[2] for r in tr1)
             saved[1] += sum(r[2] for r in tro)
         except Exception:
-            print("FAILED case %d (seed %d): %d samples, lengths %s, minl %d, sa64 %s, maxmums %d" % (n, seed, len(seqs), [len(s) for s in seqs], minl, sa64, maxmums))
+            print("FAILED case %d (seed %d): %d samples, lengths %s, minl %d, sa64 %s, maxmums %d, RV_PRESEL_DEV_MIN %s" % (n, seed, len(seqs), [len(s) for s in seqs], minl, sa64, maxmums, os.environ["RV_PRESEL_DEV_MIN"]))
             raise
         n += 1
     print("fuzz_preselect: %d cases identical to the oracle-driven recursion (seed %d); %d of %d matches crossed into Python" % (n, seed, saved[0], saved[1]))

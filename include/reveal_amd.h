@@ -219,7 +219,12 @@ int rv_fetch_anchors(rv_index *h, uint32_t *l, int64_t *off, int64_t *pos);
  * heap objects loses its GPU mapping under them) -- arrays that do not begin on a page boundary are not locked.  A run whose result
  * does not fit, or arrays that are not / cannot be locked, use the library's staging buffer as before; rv_fetch_anchors called with these same three pointers then only completes what the run has not
  * written itself.  (2 x 250 Mbp: 2 x 10^6 anchors, 65 MB -- copied out of the staging buffer behind the run they were 1.3-1.6 ms of a
- * 25 ms step with the GPU idle.) */
+ * 25 ms step with the GPU idle.)
+ * Lifetime: the arrays are the library's from this call until they are replaced, cleared, or the handle is freed; CLEAR THEM BEFORE
+ * FREEING THEM (a freed page that is still locked faults under a later copy).  Clearing or replacing them between a run and its
+ * rv_fetch_anchors is allowed: what the run delivered moves to the library's staging buffer first and rv_fetch_anchors hands it out as
+ * usual.  Every run (rv_align_builtin, _until, _continue, _resume, and a worker's rv_frontier_import + _resume) writes into whatever
+ * is set when it ends: a caller that still reads an earlier result from these arrays must clear or replace them before the next run. */
 int rv_set_result_buffers(rv_index *h, uint32_t *l, int64_t l_cap, int64_t *off, int64_t off_cap, int64_t *pos, int64_t pos_cap);
 /* per-sub-index trace of the last rv_align_builtin when tracing was enabled
  * (tests only: costs a D2H copy of every sub-index) */

@@ -127,7 +127,24 @@ def main():
         "1e1b": (["1e", "1b"], 20, 2),
         "d1d2": (["d1", "d2"], 20, 2),
         "1a1brc": (["1a", "1brc"], 20, 2),
+        # round 5: the rest of the reference's fixtures (tests/1f.fa, e2.fa, and its two Mbp-scale pairs 2a+2b, 3a+3b:
+        # the only inputs with real repeat structure the reference ships)
+        "1a1f": (["1a", "1f"], 20, 2),
+        "1ae2": (["1a", "e2"], 20, 2),
+        "2a2b": (["2a", "2b"], 20, 2),
+        "3a3b": (["3a", "3b"], 20, 2),
     }
+    only = [a.split("=", 1)[1].split(",") for a in sys.argv[1:] if a.startswith("--only=")]
+    if only:                                  # add / refresh some sets, keep the rest of the file
+        with open(os.path.join(GOLD, "vectors.json")) as f:
+            out = json.load(f)
+        for label in only[0]:
+            inputs, minl, minn = sets[label]
+            out["sets"][label] = one(label, inputs, minl, minn)
+        with open(os.path.join(GOLD, "vectors.json"), "w") as f:
+            json.dump(out, f, indent=1, sort_keys=True)
+        print("updated tests/golden/vectors.json:", ",".join(only[0]))
+        return
     out = {"_generator": "oracle/gen_golden.py (reference C built unmodified into oracle/_ref)", "sets": {}}
     for label, (inputs, minl, minn) in sets.items():
         out["sets"][label] = one(label, inputs, minl, minn)

@@ -614,6 +614,7 @@ def make_index_type(sa64, error):
             if not self._constructed:
                 raise error("Index not yet constructed, alignment stopped.")
             self._dll.rv_set_trace(self._h, 1 if trace else 0)
+            self._offer_result_buffers()      # (arrays of an earlier result the caller still holds are taken back from the library: the run writes into what is set)
             self._st = _lib.RvAlignStats()
             self._trace = bool(trace)
             r = self._dll.rv_align_builtin_until(self._h, int(minl), int(minn), int(stop_subs), ctypes.byref(self._st))
@@ -627,6 +628,7 @@ def make_index_type(sa64, error):
             sub-indices.  -> new frontier size (0: finished on the way)"""
             if not getattr(self, "_pending", False):
                 return 0
+            self._offer_result_buffers()
             r = self._dll.rv_align_builtin_continue(self._h, int(stop_subs), ctypes.byref(self._st))
             if r < 0:
                 self._fail()
@@ -661,6 +663,7 @@ def make_index_type(sa64, error):
             nf = np.ascontiguousarray(part["node_first"], dtype=np.int64); nodes = np.ascontiguousarray(part["nodes"], dtype=np.int64).reshape(-1, 2)
             m = int(meta[:, 1].sum()) if len(meta) else 0
             ptr, dev = _pointers(sa, lcp, bwt)
+            self._offer_result_buffers()
             if not getattr(self, "_pending", False):
                 self._dll.rv_set_trace(self._h, 1 if trace else 0)
                 self._st = _lib.RvAlignStats()
@@ -674,6 +677,7 @@ def make_index_type(sa64, error):
         def align_builtin_resume(self):
             """finish the run started by align_builtin_until / frontier_import; result as align_builtin"""
             if getattr(self, "_pending", False):
+                self._offer_result_buffers()
                 if self._dll.rv_align_builtin_resume(self._h, ctypes.byref(self._st)) != 0:
                     self._fail()
             self._pending = False

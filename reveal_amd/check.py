@@ -116,7 +116,7 @@ def anchor_digest(l, off, pos):
     return array_digest(anchor_stream(l, off, pos))
 
 
-def golden_record(L, genomes, seed, indelfrac=0.0, minl=20, minn=2, path=None):
+def golden_record(L, genomes, seed, indelfrac=0.0, minl=20, minn=2, path=None, snp=0.01, repeats=0.0, nruns=0):
     """the CPU path's digests for this synthetic configuration (tests/golden/fullsize.json, written by oracle/gen_fullsize_golden.py in the
     build container from the reference's divsufsort + the restated recursion), or None when the file holds none"""
     import json
@@ -125,7 +125,8 @@ def golden_record(L, genomes, seed, indelfrac=0.0, minl=20, minn=2, path=None):
     if not os.path.exists(path):
         return None
     for name, r in json.load(open(path)).items():
-        if (r["L"], r["genomes"], r["seed"], float(r["indelfrac"]), r["minl"], r["minn"]) == (L, genomes, seed, float(indelfrac), minl, minn):
+        if (r["L"], r["genomes"], r["seed"], float(r["indelfrac"]), r["minl"], r["minn"], float(r.get("snp", 0.01)), float(r.get("repeats", 0.0)), int(r.get("nruns", 0))) == \
+           (L, genomes, seed, float(indelfrac), minl, minn, float(snp), float(repeats), int(nruns)):
             return dict(r, name=name)
     return None
 

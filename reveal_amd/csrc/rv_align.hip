@@ -2387,6 +2387,16 @@ int rv_set_result_buffers(rv_index *h, uint32_t *l, int64_t l_cap, int64_t *off,
     if (l == rb.l && off == rb.off && pos == rb.pos && l_cap == rb.l_cap && off_cap == rb.off_cap && pos_cap == rb.pos_cap) return 0;
     RV_HIP(hipSetDevice(h->device));
     if (rb.l) {      // (a copy into them may still be in flight only inside rv_align_builtin: not here)
+        if (rb.direct && h->al && h->al->leaf_na) {
+            // the last run delivered its leaf / cascade anchors into these arrays and they have not been fetched yet: they move to the
+            // staging buffer (the layout rv_fetch_anchors reads: pos[2 na], l[na]) before the arrays stop being the library's
+            Align *a = h->al;
+            const size_t na = a->leaf_na, nl = a->an_l.size(), np = a->an_pos.size();
+            RV_TRY(a->hLeafOut.reserve(na * 20 + 64));
+            int64_t *pp = a->hLeafOut.as<int64_t>();
+            memcpy(pp, rb.pos + np, na * 16);
+            memcpy(pp + 2 * na, rb.l + nl, na * 4);
+        }
         (void)hipHostUnregister(rb.l); (void)hipHostUnregister(rb.off); (void)hipHostUnregister(rb.pos);
         rb = rv_index::ResultBufs();
     }

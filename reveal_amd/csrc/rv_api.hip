@@ -91,6 +91,7 @@ void rv_free(rv_index *h) {
     { std::lock_guard<std::mutex> g(rv_trim_mutex()); auto &v = live_handles(); v.erase(std::remove(v.begin(), v.end(), h), v.end()); }
     (void)hipSetDevice(h->device);
     if (h->ws.stream) (void)hipStreamSynchronize(h->ws.stream);
+    h->rb.direct = false;      // (nothing will fetch the last run's anchors any more: no copy to the staging buffer)
     (void)rv_set_result_buffers(h, nullptr, 0, nullptr, 0, nullptr, 0);
     rv_align_free(h);
     h->prof.release();

@@ -584,7 +584,8 @@ __global__ __launch_bounds__(TB) void k_cas_decide(CasIv *__restrict__ iv, u64 *
     // The next level's sub-indices are the ones this level has made: the workgroup that finishes last moves the range on.  (Every workgroup read
     // the range when it started, and takes its ticket when it is done: nobody reads the range after the last ticket.  A kernel of its own for
     // this was 4.5 us per level, 53 levels at 2 x 250 Mbp.)
-    if (threadIdx.x == 0) {      // (no fence: what the workgroups wrote is for the next kernel; the range's end is read with an atomic, behind their returning ones)
+    if (threadIdx.x == 0) {      // (what the workgroups wrote is for the next kernel; the fence orders this workgroup's C_NCHILD reservations -- atomics of other
+        __threadfence();         //  waves, behind the barrier above -- in front of its ticket, so the last ticket holder reads the final count)
         if (atomicAdd(&counters[C_TICKET], 1u) == gridDim.x - 1) {
             if (hi > lo) counters[C_LEVELS]++;
             counters[C_LO] = hi; counters[C_HI] = atomicAdd(&counters[C_NCHILD], 0u);

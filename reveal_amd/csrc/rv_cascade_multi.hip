@@ -541,7 +541,8 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
         __syncthreads();
     }
     // the workgroup that finishes last moves the level's range on (k_cas_decide, rv_cascade.hip)
-    if (threadIdx.x == 0) {      // (no fence: what the workgroups wrote is for the next kernel; the range's end is read with an atomic, behind their returning ones)
+    if (threadIdx.x == 0) {      // (what the workgroups wrote is for the next kernel; the fence orders this workgroup's C_NCHILD reservations -- atomics of other
+        __threadfence();         //  waves, behind the barrier above -- in front of its ticket, so the last ticket holder reads the final count)
         if (atomicAdd(&counters[C_TICKET], 1u) == gridDim.x - 1) {
             if (hi > lo) counters[C_LEVELS]++;
             counters[C_LO] = hi; counters[C_HI] = atomicAdd(&counters[C_NCHILD], 0u);

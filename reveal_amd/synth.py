@@ -15,6 +15,14 @@ whose upper bound is exclusive), otherwise a substitution; positions swallowed b
 an earlier deletion are skipped (simulate.py:35-36).  The draws come from PCG64
 (seed + k) in a fixed vectorised order, not from the simulator's global Mersenne
 state: the distribution is the simulator's, the stream is ours.
+
+`repeats > 0` (round 5: the unfriendly classes of the bench's class table and of the full-size
+digests) overlays the BASE with what real genomes have and i.i.d. text has not: interspersed
+copies of a dozen element families (1-6 kb consensus, every copy 0-5 % diverged from it, a
+third truncated; a fifth of the copies exact: ties far beyond the first key, beyond the text
+round's 4 KB) covering `repeats` of the length, tandem arrays (unit 2-60 bp x 10-300) and --
+`nruns` -- runs of N (10 bp - 50 kb, the same places in every member: assembly gaps).  All of
+it from PCG64(seed + 1000003), so a family is a function of (L, seed, repeats, nruns).
 """
 import numpy as np
 
@@ -85,6 +93,76 @@ def variant_codes_indel(base, k, seed=42, rate=0.01, indelfrac=0.2, zipfd=1.7, m
     hole = res == 255
     res[hole] = rng.integers(0, 3, size=int(hole.sum()), dtype=np.uint8)      # A, C, G (simulate.py:41, 47)
     return res
+
+
+def overlay_repeats(base, seed=42, repeats=0.02):
+    """interspersed repeat families and tandem arrays written over the base's codes (in place) -> base"""
+    L = len(base)
+    rng = np.random.Generator(np.random.PCG64(seed + 1000003))
+    nfam = 12
+    cons = [rng.integers(0, 4, size=int(rng.integers(1000, 6001)), dtype=np.uint8) for _ in range(nfam)]
+    weight = 1.0 / np.arange(1, nfam + 1)
+    weight /= weight.sum()
+    budget = int(L * repeats)
+    while budget > 0:
+        f = int(rng.choice(nfam, p=weight))
+        c = cons[f]
+        if rng.random() < 0.33 and len(c) > 400:                 # truncated copy
+            a = int(rng.integers(0, len(c) - 200)); b = int(rng.integers(a + 200, len(c) + 1))
+            c = c[a:b]
+        c = c.copy()
+        if rng.random() >= 0.2:                                  # (a fifth of the copies stay exact)
+            nsub = int(len(c) * rng.random() * 0.05)
+            if nsub:
+                q = rng.integers(0, len(c), size=nsub)
+                c[q] = (c[q] + rng.integers(1, 4, size=nsub, dtype=np.uint8)) & 3
+        if len(c) >= L:
+            break
+        at = int(rng.integers(0, L - len(c)))
+        base[at:at + len(c)] = c
+        budget -= len(c)
+    for _ in range(max(2, L // 2_000_000)):                      # tandem arrays
+        unit = rng.integers(0, 4, size=int(rng.integers(2, 61)), dtype=np.uint8)
+        arr = np.tile(unit, int(rng.integers(10, 301)))
+        if len(arr) >= L:
+            continue
+        at = int(rng.integers(0, L - len(arr)))
+        base[at:at + len(arr)] = arr
+    return base
+
+
+def n_runs(L, seed=42, nruns=0):
+    """-> sorted list of (begin, end) of the runs of N (log-uniform lengths 10 .. 50 000, clipped to the text)"""
+    if nruns <= 0:
+        return []
+    rng = np.random.Generator(np.random.PCG64(seed + 2000003))
+    out = []
+    for _ in range(nruns):
+        ln = int(min(10 ** rng.uniform(1.0, 4.7), max(1, L // 8)))
+        at = int(rng.integers(0, max(1, L - ln)))
+        out.append((at, min(L, at + ln)))
+    return sorted(out)
+
+
+def _spell(codes, runs):
+    out = _ACGT[codes]
+    for b, e in runs:
+        out[b:min(e, len(out))] = 78      # 'N'
+    return out.tobytes()
+
+
+def family(L, count, seed=42, snp=0.01, indelfrac=0.0, repeats=0.0, nruns=0):
+    """genomes() with the unfriendly knobs: `repeats` (fraction of the base covered by interspersed repeat copies; tandem arrays
+    come with it) and `nruns` (runs of N, the same text positions in every member).  repeats = 0 and nruns = 0: genomes()."""
+    base = base_codes(L, seed)
+    if repeats > 0:
+        overlay_repeats(base, seed, repeats)
+    runs = n_runs(L, seed, nruns)
+    out = [_spell(base, runs)]
+    for k in range(1, count):
+        v = variant_codes_indel(base, k, seed, snp, indelfrac) if indelfrac > 0 else variant_codes(base, k, seed, snp)
+        out.append(_spell(v, runs))
+    return out
 
 
 def member(base, k, seed=42, snp=0.01, indelfrac=0.0):

@@ -14,7 +14,7 @@ from reveal_amd import check
 pytestmark = pytest.mark.gpu
 
 RECORDS = json.load(open(os.path.join(GOLD, "fullsize.json")))
-NAMES = [k for k, r in RECORDS.items() if r["n"] <= 60_000_000]
+NAMES = [k for k, r in RECORDS.items() if r["n"] <= 110_000_000]
 
 
 @pytest.mark.parametrize("sa64", [False, True])
@@ -27,7 +27,7 @@ def test_digests(name, cascade, sa64):
     if sa64 and (r["genomes"] != 2 or not cascade):
         pytest.skip("64-bit library: two-sample records through the default path")
     reveallib = reveallib64 if sa64 else reveallib
-    seqs = synth.genomes(r["L"], r["genomes"], seed=r["seed"], snp=r["snp"], indelfrac=r["indelfrac"])
+    seqs = synth.family(r["L"], r["genomes"], seed=r["seed"], snp=r["snp"], indelfrac=r["indelfrac"], repeats=r.get("repeats", 0.0), nruns=r.get("nruns", 0))
     T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
     assert len(T0) == r["n"] and check.array_digest(T0) == r["sha_input"]        # the generator still makes the bytes the CPU saw
     idx = reveallib.index()

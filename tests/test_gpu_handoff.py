@@ -263,3 +263,62 @@ def test_cascade_leaves_nothing_to_divide():
         l, off, pos = r["anchors"]
         return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
     assert aset(got) == aset(ref) and got["stats"]["steps"] == ref["stats"]["steps"]
+
+
+def _aset(r):
+    l, off, pos = r["anchors"]
+    return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+
+
+def test_a_held_result_survives_a_later_stopped_run():
+    """A result the caller still holds lives in arrays the library had page-locked and written directly (rv_set_result_buffers).  A later
+    run on the same handle through align_builtin_until / _resume (other minl: other anchors) must neither write into those arrays nor hand
+    out stale staging data: the held arrays stay what they were, the new result is the oracle's."""
+    seqs = [g.decode() for g in synth.genomes(500000, 2, seed=5)]
+    M = mod(False)
+    idx = feed(M.index(), seqs)
+    idx.construct()
+    r1 = idx.align_builtin(20, 2)
+    want20 = _aset(r1)
+    del r1                                         # the arrays go back to the index ...
+    idx.construct()
+    r2 = idx.align_builtin(20, 2)                  # ... and this run is delivered straight into them
+    assert _aset(r2) == want20
+    snap = tuple(np.array(x, copy=True) for x in r2["anchors"])
+    idx.construct()
+    left = idx.align_builtin_until(8, 31, 2)
+    assert left >= 8
+    r3 = idx.align_builtin_resume()
+    for a, b in zip(r2["anchors"], snap):
+        assert np.array_equal(a, b), "a run overwrote the arrays of a result the caller still holds"
+    ref, _ = oracle_run(seqs, 31, 2, False)
+    rl, rn, roff, rpos = ref["anchors"]
+    assert _aset(r3) == sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl)))
+    assert _aset(r3) != want20
+
+
+def test_result_buffers_cleared_between_the_run_and_its_fetch():
+    """C-ABI contract (include/reveal_amd.h at rv_set_result_buffers): clearing the arrays after a run has delivered into them and before
+    rv_fetch_anchors keeps the result -- it moves to the library's staging buffer."""
+    import ctypes
+    from reveal_amd import _lib
+    from reveal_amd._index import _page_array
+    seqs = [g.decode() for g in synth.genomes(300000, 2, seed=6)]
+    M = mod(False)
+    idx = feed(M.index(), seqs)
+    idx.construct()
+    want = _aset(idx.align_builtin(20, 2))
+    dll, h = idx._dll, idx._h
+    na = len(want)
+    l = _page_array(na + 8, np.uint32); off = _page_array(na + 9, np.int64); pos = _page_array(2 * na + 16, np.int64)
+    idx.construct()
+    assert dll.rv_set_result_buffers(h, l.ctypes.data, len(l), off.ctypes.data, len(off), pos.ctypes.data, len(pos)) == 0
+    st = _lib.RvAlignStats()
+    assert dll.rv_align_builtin(h, 20, 2, ctypes.byref(st)) == 0
+    assert dll.rv_set_result_buffers(h, None, 0, None, 0, None, 0) == 0          # cleared before the fetch
+    l[:] = 0; off[:] = 0; pos[:] = 0
+    l2 = np.zeros(na, np.uint32); off2 = np.zeros(na + 1, np.int64); pos2 = np.zeros(2 * na, np.int64)
+    mem = ctypes.c_int64(0)
+    assert dll.rv_anchor_count(h, ctypes.byref(mem)) == na and mem.value == 2 * na
+    assert dll.rv_fetch_anchors(h, l2.ctypes.data, off2.ctypes.data, pos2.ctypes.data) == 0
+    assert _aset(dict(anchors=(l2, off2, pos2))) == want

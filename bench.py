@@ -258,6 +258,239 @@ def run_config5(args, rank, local_rank, world, dist, torch):
         print(json.dumps(out))
 
 
+def run_stream(args, rank, local_rank, world, dist, torch):
+    """--config stream: a queue of `--pairs` inputs per rank (default 20 pairs of 2 x 250 Mbp = 10 Gbp, north_star's target volume), each
+    one assembled on the host (addsample / addsequence into the handle's page-locked text), copied into HBM, constructed and anchored --
+    everything from the caller's sequences in ordinary host memory to the anchors in the caller's arrays is inside the timed region.
+    `--stream-handles` inputs are in flight at a time, each on its own handle, HIP stream and host thread: the next input's assembly
+    and its host->device copy (one DMA) run under the current input's construct.  Handles are reused through rv_reset."""
+    import queue
+    import threading
+    import numpy as np
+    from reveal_amd import _lib, check, synth, reveallib, reveallib64
+    _lib.set_device(local_rank)
+    P, D, H = args.pairs, max(1, min(args.stream_distinct, args.pairs)), max(1, args.stream_handles)
+    # the inputs, generated before anything is timed (a caller would have read them from its files): D distinct ones, used in turn
+    inputs = [synth.genomes(args.L, args.genomes, seed=42 + 1000 * rank + 17 * d, indelfrac=args.indelfrac) for d in range(D)]
+    bases = [sum(len(x) for x in seqs) for seqs in inputs]
+    text_bytes = max(sum(len(x) + 1 for x in seqs) for seqs in inputs)
+    M = reveallib64 if args.sa64 else reveallib
+    handles = [M.index() for _ in range(H)]
+    hold = [None] * H                        # per handle: (which distinct input, its result) of the last run
+    anchors_of = {}
+    times = {"assemble": 0.0, "upload": 0.0, "construct": 0.0, "align": 0.0}
+    tl = threading.Lock()
+
+    def one(hk, i):
+        ix, seqs = handles[hk], inputs[i % D]
+        t0 = time.perf_counter()
+        ix.reset(reserve=text_bytes)
+        for k, sq in enumerate(seqs):
+            ix.addsample("g%d" % k)
+            ix.addsequence(sq)
+        t1 = time.perf_counter()
+        ix.upload()
+        t2 = time.perf_counter()
+        ix.construct()
+        t3 = time.perf_counter()
+        hold[hk] = None                      # (the previous result of this handle is let go: its arrays are the next run's)
+        r = ix.align_builtin(args.minl, args.minn)
+        t4 = time.perf_counter()
+        hold[hk] = (i % D, r)
+        with tl:
+            times["assemble"] += t1 - t0; times["upload"] += t2 - t1; times["construct"] += t3 - t2; times["align"] += t4 - t3
+            anchors_of[i % D] = int(r["stats"]["splits"])
+
+    def run(npairs):
+        todo = queue.Queue()
+        for i in range(npairs):
+            todo.put(i)
+        err = []
+
+        def work(hk):
+            while True:
+                try:
+                    i = todo.get_nowait()
+                except queue.Empty:
+                    return
+                try:
+                    one(hk, i)
+                except Exception as e:      # noqa: BLE001
+                    err.append(e)
+                    return
+        th = [threading.Thread(target=work, args=(hk,)) for hk in range(1, H)]
+        for t in th:
+            t.start()
+        work(0)
+        for t in th:
+            t.join()
+        if err:
+            raise err[0]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(max(1, args.warmup)):
+        run(max(H, D) * 2)                   # every handle has made its allocations, every distinct input has run
+    for k in times:
+        times[k] = 0.0
+    kname = "scan_pair" if args.genomes == 2 else "scan_multi"
+    for ix in handles:
+        ix.prof(enable=True, reset=True, only=(kname,))
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run(P)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = [0, 0.0, 0.0]
+    for ix in handles:
+        p = ix.prof(enable=False)[kname]
+        prof = [prof[0] + p[0], prof[1] + p[1], prof[2] + p[2]]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    # the last result of every handle against the full-size properties; rank 0's seed-42 input against the CPU digests
+    props, golden = [], None
+    if not args.no_check:
+        for hk in range(H):
+            if hold[hk] is None:
+                continue
+            dd, r = hold[hk]
+            T0 = np.frombuffer(b"$".join(inputs[dd]) + b"$", dtype=np.uint8)
+            T1 = handles[hk].array("T")
+            nsep = np.cumsum([len(x) + 1 for x in inputs[dd]])[:-1] - 1
+            props.append(bool(check.recursion_properties(T0, T1, r["anchors"], nsep, args.minl)["all"]))
+            if rank == 0 and dd == 0 and golden is None:
+                rec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn)
+                if rec is not None:
+                    golden = check.compare_with_golden(rec, anchors=r["anchors"], T_final=T1)
+            del T0, T1
+    info = {"rank": rank, "properties": props}
+    gathered = [info]
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, info)
+    if rank == 0:
+        per_step = float(sum(bases[i % D] for i in range(P)))
+        total = per_step * args.steps * world
+        launches, ms, nbytes = prof
+        achieved = (nbytes / 1e9) / (ms / 1e3) if ms > 0 else 0.0
+        allp = [v for g in gathered for v in g["properties"]]
+        npair = P * args.steps
+        out = {
+            "metric": "Mbp/s indexed+MUM-anchored (reveal rem)", "value": total / elapsed / 1e6, "unit": "Mbp/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int64" if args.sa64 else "int32", "data": "synthetic",
+            "config": {"workload": "sustained stream: %d inputs per rank and step, each %dx synthetic %g Mbp genomes (uniform ACGT, 1%% SNP; %d distinct inputs, "
+                                   "seeds 42+1000*rank+17*d, used in turn), rem -m %d -n %d, construct + full recursion, bench picker.  TIMED PER INPUT: host "
+                                   "assembly (addsample / addsequence from the caller's sequences in pageable host memory), host->device copy, construct, "
+                                   "recursion, anchors into the caller's arrays; %d inputs in flight per GPU (a handle, HIP stream and host thread each, "
+                                   "handles reused through rv_reset)" % (P, args.genomes, args.L / 1e6, D, args.minl, args.minn, H),
+                       "inputs_per_rank_and_step": P, "Gbp_per_rank_and_step": per_step / 1e9, "in_flight_per_gpu": H,
+                       "index": "64-bit" if args.sa64 else "32-bit", "sharding": "an input queue per rank, no exchange"},
+            "includes_upload": True,
+            "wall_seconds": elapsed, "Gbp_total": total / 1e9, "ms_per_input": elapsed / npair * 1e3,
+            "host_thread_ms_per_input": {k: v / npair * 1e3 for k, v in times.items()},
+            "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("pair" if args.genomes == 2 else "multi") + " (launches of every handle; they share the GPU with the other inputs in flight)",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None, "launches": launches,
+                         "avg_us": (ms * 1e3 / launches) if launches else None},
+            "properties_full_size": {"all": (all(allp) and len(allp) > 0) if not args.no_check else None, "results_checked": len(allp)},
+            "parity": {"full_size": golden if golden is not None else "no CPU digests for the last input of a handle in tests/golden/fullsize.json"},
+            "anchors_per_distinct_input": {str(d): v for d, v in sorted(anchors_of.items())},
+        }
+        print(json.dumps(out))
+
+
+CLASSES = ("snp0.1", "snp1", "snp5", "snp15", "indel", "repeats", "repeats_indel", "contigs50", "unrelated", "identical")
+
+
+def class_inputs(name, L, seed=42):
+    """the two genomes of one input class at length L (bench.py --classes): what the headline's generator is one point of"""
+    from reveal_amd import synth
+    if name.startswith("snp"):
+        return synth.family(L, 2, seed=seed, snp=float(name[3:]) / 100.0)
+    if name == "indel":
+        return synth.family(L, 2, seed=seed, indelfrac=0.2)
+    if name == "repeats":                     # interspersed repeat families + tandem arrays + runs of N (synth.overlay_repeats)
+        return synth.family(L, 2, seed=seed, repeats=0.02, nruns=max(3, L // 10_000_000))
+    if name == "repeats_indel":
+        return synth.family(L, 2, seed=seed, indelfrac=0.2, repeats=0.02, nruns=max(3, L // 10_000_000))
+    if name == "contigs50":
+        return cut_into_contigs(synth.genomes(L, 2, seed=seed), 50)
+    if name == "unrelated":
+        return [synth.genomes(L, 1, seed=seed)[0], synth.genomes(L, 1, seed=seed + 7777)[0]]
+    if name == "identical":
+        g = synth.genomes(L, 1, seed=seed)[0]
+        return [g, g]
+    raise ValueError(name)
+
+
+def run_one_class(args):
+    """one class, one process (bench.py --class-one NAME): 1 warm-up + 2 timed steps, properties, CPU digests where tests/golden/fullsize.json holds them"""
+    import numpy as np
+    import torch
+    from reveal_amd import _lib, check
+    _lib.set_device(0)
+    name = args.class_one
+    t0 = time.perf_counter()
+    seqs = class_inputs(name, args.L)
+    gen_s = time.perf_counter() - t0
+    bases = sum(len(c) for c in flat(seqs))
+    idx = build_index(seqs, args.sa64)
+    idx.construct(); idx.align_builtin(args.minl, args.minn)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    r = None
+    for _ in range(2):
+        r = None
+        idx.construct()
+        r = idx.align_builtin(args.minl, args.minn)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
+    info = idx.cascade_info()
+    out = {"class": name, "L": args.L, "bases": bases, "ms_per_step": dt * 1e3, "Mbp_per_s": bases / dt / 1e6, "anchors": int(r["stats"]["splits"]),
+           "anchored_bp": int(r["stats"]["anchored_bp"]), "levels": int(r["stats"]["levels"]), "maxlcp": idx.maxlcp,
+           "path": "cascade" if info["done"] else "level pipeline", "cascade_why": info["why"], "sa_build": idx.sa_stats(), "generate_s": gen_s}
+    if not args.no_check:
+        T0 = np.frombuffer(b"$".join(flat(seqs)) + b"$", dtype=np.uint8)
+        nsep = np.asarray(sample_seps(seqs), dtype=np.int64)
+        T1 = idx.array("T")
+        out["properties"] = bool(check.recursion_properties(T0, T1, r["anchors"], nsep, args.minl, collinear=name != "contigs50")["all"])
+        kw = {"snp0.1": dict(snp=0.001), "snp1": {}, "snp5": dict(snp=0.05), "snp15": dict(snp=0.15), "indel": dict(indelfrac=0.2),
+              "repeats": dict(repeats=0.02, nruns=max(3, args.L // 10_000_000)), "repeats_indel": dict(indelfrac=0.2, repeats=0.02, nruns=max(3, args.L // 10_000_000))}.get(name)
+        rec = check.golden_record(args.L, 2, 42, minl=args.minl, minn=args.minn, **kw) if kw is not None else None
+        out["golden"] = check.compare_with_golden(rec, anchors=r["anchors"], T_final=T1) if rec is not None else None
+    print(json.dumps(out))
+
+
+def run_classes(args):
+    """bench.py --classes: every input class at the workload's size, each in a process of its own under a time limit"""
+    names = [c for c in (args.classes.split(",") if args.classes != "all" else CLASSES)]
+    rows = []
+    for name in names:
+        cmd = [sys.executable, os.path.abspath(__file__), "--class-one", name, "--L", str(args.L), "--minl", str(args.minl), "--minn", str(args.minn)] + \
+              (["--sa64"] if args.sa64 else []) + (["--no-check"] if args.no_check else [])
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=args.class_timeout)
+            line = [x for x in p.stdout.decode().splitlines() if x.startswith("{")]
+            row = json.loads(line[-1]) if p.returncode == 0 and line else {"class": name, "failed": p.stderr.decode()[-400:]}
+        except subprocess.TimeoutExpired:
+            row = {"class": name, "failed": "no result within %d s" % args.class_timeout}
+        row["wall_s"] = time.perf_counter() - t0
+        rows.append(row)
+        print(json.dumps(row), file=sys.stderr, flush=True)
+    head = next((r for r in rows if r.get("class") == "snp1" and "ms_per_step" in r), None)
+    for r in rows:
+        if head and "ms_per_step" in r:
+            r["vs_headline"] = r["ms_per_step"] / head["ms_per_step"]
+    print(json.dumps({"what": "input classes at 2 x %g Mbp, construct + full recursion with the bench picker, one MI355X; snp1 = the headline's generator" % (args.L / 1e6),
+                      "L": args.L, "classes": rows}))
+
+
 def cut_into_contigs(seqs, k, seed=7):
     """--contigs K: every genome as K contigs cut at seeded random positions, the second and later samples' contigs in another order
     (a draft assembly against a draft assembly)"""
@@ -303,10 +536,20 @@ def main():
     ap.add_argument("--indelfrac", type=float, default=0.0,
                     help="variants by the reference's own mutation model (utils/simulate.py:17-77: this fraction of the 1 %% events are indels, "
                          "zipf(1.7) lengths) instead of substitutions only; 0 = SURVEY 8(d)'s generator, the metric's workload")
+    ap.add_argument("--snp", type=float, default=0.01, help="substitution rate of the variants (0.01 = the metric's workload)")
+    ap.add_argument("--repeats", type=float, default=0.0, help="fraction of the base covered by interspersed repeat copies (synth.family; implies --no-cpu --no-extra)")
+    ap.add_argument("--nruns", type=int, default=0, help="runs of N in every genome (synth.family)")
     ap.add_argument("--contigs", type=int, default=1, help="every genome as this many contigs (a multi-sequence FASTA per sample); implies --no-cpu --no-extra")
     ap.add_argument("--no-extra", action="store_true", help="skip the companion legs of the default line (level pipeline, indel workload)")
-    ap.add_argument("--config", choices=("default", "c5"), default="default",
-                    help="c5 = BASELINE config 5's level 0: 100 genomes of 5 Mbp as 20 independent jobs of five, divided over the ranks")
+    ap.add_argument("--config", choices=("default", "c5", "stream"), default="default",
+                    help="c5 = BASELINE config 5's level 0: 100 genomes of 5 Mbp as 20 independent jobs of five, divided over the ranks; "
+                         "stream = a queue of --pairs inputs per rank, host assembly and upload inside the timed region, overlapped with compute")
+    ap.add_argument("--classes", default="", help="'all' or a comma-separated list of %s: the input-class table at --L (each class in its own process)" % (CLASSES,))
+    ap.add_argument("--class-one", default="", help="(used by --classes) run one class in this process")
+    ap.add_argument("--class-timeout", type=int, default=600)
+    ap.add_argument("--pairs", type=int, default=20, help="--config stream: inputs per rank and step (20 x 2 x 250 Mbp = 10 Gbp)")
+    ap.add_argument("--stream-distinct", type=int, default=3, help="--config stream: distinct synthetic inputs generated (used in turn)")
+    ap.add_argument("--stream-handles", type=int, default=4, help="--config stream: inputs in flight per GPU")
     ap.add_argument("--c5-genomes", type=int, default=100, help="--config c5: number of genomes (a multiple of 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
@@ -321,6 +564,10 @@ def main():
                          "config 5's 20 independent 5-genome jobs on 8 GPUs (reveal/align.py:45-53); the default 1 is the metric's config")
     args = ap.parse_args()
 
+    if args.class_one:
+        return run_one_class(args)
+    if args.classes:
+        return run_classes(args)
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
     if int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
@@ -364,6 +611,13 @@ def main():
             dist.destroy_process_group()
         return
 
+    if args.config == "stream":
+        run_stream(args, rank, local_rank, world, dist, torch)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
     mode = "divide" if args.divide else args.mode
     big = args.L * args.genomes >= 100_000_000
     if world == 1:
@@ -373,7 +627,9 @@ def main():
     else:
         modes = [mode]
     jobs = max(1, args.jobs) if "per-rank" in modes else 1
-    seqs = synth.genomes(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0), indelfrac=args.indelfrac)
+    seqs = synth.family(args.L, args.genomes, seed=42 + (1000 * rank if "per-rank" in modes else 0), snp=args.snp, indelfrac=args.indelfrac, repeats=args.repeats, nruns=args.nruns)
+    if args.snp != 0.01 or args.repeats or args.nruns:
+        args.no_cpu = args.no_extra = True
     if args.contigs > 1:
         seqs = cut_into_contigs(seqs, args.contigs)
         args.no_cpu = args.no_extra = True
@@ -467,7 +723,7 @@ def main():
             properties["text"] = "lower-cased text rebuilt from the merged anchors (each rank lower-cases its own share)"
         # the last timed step's anchor set and final text against the CPU path's digests at THIS size (tests/golden/fullsize.json:
         # the reference's divsufsort + the restated recursion, run once in the build container by oracle/gen_fullsize_golden.py)
-        grec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn) if args.contigs <= 1 else None
+        grec = check.golden_record(args.L, args.genomes, 42, args.indelfrac, args.minl, args.minn, snp=args.snp, repeats=args.repeats, nruns=args.nruns) if args.contigs <= 1 else None
         if grec is not None:
             full_size = check.compare_with_golden(grec, anchors=last["anchors"], T_final=T1)
             full_size["cpu_seconds_at_this_size"] = grec["cpu_seconds"]
@@ -539,7 +795,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "%dx synthetic %g Mbp genomes (uniform ACGT, %s, seed 42%s), rem -m %d -n %d, construct + full recursion, "
                                    "bench picker; text resident in HBM before the timed region (host->device copy of the text not timed)"
-                                   % (args.genomes, args.L / 1e6, "1% SNP" if not args.indelfrac else
+                                   % (args.genomes, args.L / 1e6, ("%g%% SNP" % (100 * args.snp) + (", %g%% of the base in interspersed repeats + tandem arrays, %d runs of N" % (100 * args.repeats, args.nruns) if args.repeats or args.nruns else "")) if not args.indelfrac else
                                       "1%% mutation events of which %g%% indels with zipf(1.7) lengths: the reference simulator's model" % (100 * args.indelfrac),
                                       ("" if divide else "+1000*rank") + ("" if args.contigs <= 1 else "; every genome cut into %d contigs, the later samples' in another order" % args.contigs),
                                       args.minl, args.minn),

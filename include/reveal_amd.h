@@ -52,6 +52,14 @@ int rv_add_sample(rv_index *h);
  * rv_add_sample / rv_add_sequence after a construct() make the index
  * "not yet constructed" again (the arrays in HBM describe the old text). */
 int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, int64_t *end);
+/* Not in the reference (its callers make a new index object per input, interface.c:489-521): rv_reset forgets the text and the
+ * samples and keeps every allocation of the handle -- ~86 B of device memory per position, the page-locked host text, streams --
+ * for the next input's rv_add_sample / rv_add_sequence; rv_reserve_text says how many bytes of text are to come (sequences + one
+ * separator each), so the host buffer is allocated once.  A text of 8 MB and more lives in page-locked host memory: rv_upload /
+ * rv_construct then move it into HBM as one DMA copy (500 MB: 10 ms, no host thread involved), which a caller with several inputs
+ * overlaps with the alignment before it by giving each input in flight its own handle and host thread (bench.py --config stream). */
+int rv_reset(rv_index *h);
+int rv_reserve_text(rv_index *h, int64_t bytes);
 int64_t rv_n(const rv_index *h);        /* reveal_getn (interface.c:681-689): ranks in the main index */
 int rv_nsamples(const rv_index *h);     /* interface.c:691-695 */
 int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so far */
@@ -318,6 +326,9 @@ int rv_measure_bandwidth(int device, int64_t bytes, int iters, double *read_gbs,
 /* SA-build statistics of the last rv_construct */
 int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_t *sorted_elems, int *radix_passes);
 int rv_sa_diag_table(rv_index *h);      /* 1: two samples on piecewise diagonals from seeds in the last construct() (rv_construct.hip k_diag_bits_tab) */
+/* what finished the suffixes the first key and the text round left tied (agreement beyond 4 KB: near-identical inputs, repeats): out[0] = tied
+ * pairs of partners ordered from the diagonal's marks, out[1] = ranks whose LCP / BWT came from the text after the doubling rounds */
+int rv_sa_tail(rv_index *h, int64_t *out);
 
 /* ---- self-test hooks for the device primitives (tests/ only) ------------------ */
 int rv_test_exclusive_sum_u32(const uint32_t *in, uint32_t *out, int64_t n);

@@ -148,6 +148,26 @@ def make_index_type(sa64, error):
             self._constructed = False
             return intv
 
+        def reset(self, reserve=0):
+            """Not in the reference (its callers make a new index per input): forget the text and the samples, keep the handle's
+            device arrays, SA-build scratch, streams and (page-locked) host text for the next input (rv_reset); `reserve` = bytes
+            of text to come (sequences + one separator each), so the host buffer is made once (rv_reserve_text)."""
+            if self._main is not self or self._slot is not None:
+                raise error("reset() is for a main index outside align()")
+            if self._sx:
+                self._dll.rv_sx_free(self._sx)
+                self._sx = None
+            if self._dll.rv_reset(self._h) != 0:
+                self._fail()
+            if reserve and self._dll.rv_reserve_text(self._h, int(reserve)) != 0:
+                self._fail()
+            self._samples, self._nodes, self.skipmums = [], set(), []
+            self._leftnode = self._rightnode = None
+            self._depth = 0
+            self._constructed = False
+            self._pending = False
+            self._n_sub = self._nsamples_sub = None
+
         def upload(self):
             """Not in the reference: copy the assembled text to HBM now (construct()
             does it on demand), so a timed construct() starts from resident input."""
@@ -183,8 +203,10 @@ def make_index_type(sa64, error):
             v = [ctypes.c_int(0) for _ in range(4)]
             se, rp = ctypes.c_int64(0), ctypes.c_int(0)
             self._dll.rv_sa_stats(self._h, *[ctypes.byref(x) for x in v], ctypes.byref(se), ctypes.byref(rp))
+            tail = (ctypes.c_int64 * 2)()
+            self._dll.rv_sa_tail(self._h, tail)
             return dict(sigma=v[0].value, bits=v[1].value, k0=v[2].value, rounds=v[3].value, sorted_elems=se.value, radix_passes=rp.value,
-                        diag_table=int(self._dll.rv_sa_diag_table(self._h)))
+                        diag_table=int(self._dll.rv_sa_diag_table(self._h)), far_pairs=int(tail[0]), lcp_list=int(tail[1]))
 
         # ---- construct --------------------------------------------------------
         def construct(self, rc=0):                          # interface.c:160-291

@@ -49,6 +49,8 @@ SYMBOLS = {
     "rv_free": (None, [V]),
     "rv_add_sample": (_I, [V]),
     "rv_add_sequence": (_I, [V, ctypes.c_char_p, _L, c_i64p, c_i64p]),
+    "rv_reset": (_I, [V]),
+    "rv_reserve_text": (_I, [V, _L]),
     "rv_n": (_L, [V]),
     "rv_nsamples": (_I, [V]),
     "rv_nnodes": (_I, [V]),
@@ -111,6 +113,7 @@ SYMBOLS = {
     "rv_measure_bandwidth": (_I, [_I, _L, _I, ctypes.POINTER(_D), ctypes.POINTER(_D)]),
     "rv_sa_stats": (_I, [V] + [ctypes.POINTER(_I)] * 4 + [c_i64p, ctypes.POINTER(_I)]),
     "rv_sa_diag_table": (_I, [V]),
+    "rv_sa_tail": (_I, [V, c_i64p]),
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
     "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),

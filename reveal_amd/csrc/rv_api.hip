@@ -185,16 +185,46 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
         return -1;
     }
 #endif
-    {   // bit 7 of the BWT bytes carries the sample side (rv_common.h): sequence text has to be ASCII
-        uint64_t acc = 0;
-        int64_t k = 0;
-        for (; k + 8 <= len; k += 8) { uint64_t w; memcpy(&w, seq + k, 8); acc |= w; }
-        for (; k < len; k++) acc |= (uint64_t)(uint8_t)seq[k] << 0;
-        if (acc & 0x8080808080808080ull) { rv_set_error("addsequence: the sequence contains non-ASCII bytes"); return -1; }
-    }
+    // one pass: copy into the (page-locked, when large) host text and test for non-ASCII bytes on the way -- bit 7 of the BWT bytes
+    // carries the sample side (rv_common.h) --, block by block so that the test reads what the copy just left in the cache; four threads
+    // above 4 MB (250 Mbp: 60 ms -> 12 ms; a stream of inputs is assembled while the GPU works on the one before)
     const int64_t s = h->n;
-    h->T.resize((size_t)(h->n + len + 2));
-    memcpy(h->T.data() + h->n, seq, (size_t)len);
+    (void)hipSetDevice(h->device);      // (a large text is page-locked memory)
+    if (h->T.resize((size_t)(h->n + len + 2)) != 0) return -1;
+    char *dst = h->T.data() + h->n;
+    auto copy_check = [dst, seq](int64_t lo, int64_t hi) -> uint64_t {
+        uint64_t acc = 0;
+        const int64_t B = 32768;
+        for (int64_t at = lo; at < hi; at += B) {
+            const int64_t m = std::min(B, hi - at);
+            memcpy(dst + at, seq + at, (size_t)m);
+            int64_t k = 0;
+            for (; k + 8 <= m; k += 8) { uint64_t w; memcpy(&w, dst + at + k, 8); acc |= w; }
+            for (; k < m; k++) acc |= (uint64_t)(uint8_t)dst[at + k];
+        }
+        return acc;
+    };
+    uint64_t acc = 0;
+    if (len >= ((int64_t)4 << 20)) {
+        const int nt = 4;
+        uint64_t part[nt] = {0, 0, 0, 0};
+        std::thread th[nt];
+        for (int t = 1; t < nt; t++) {
+            const int64_t lo = len / nt * t, hi = t + 1 == nt ? len : len / nt * (t + 1);
+            th[t] = std::thread([&, t, lo, hi]() { part[t] = copy_check(lo, hi); });
+        }
+        part[0] = copy_check(0, len / nt);
+        for (int t = 1; t < nt; t++) th[t].join();
+        for (int t = 0; t < nt; t++) acc |= part[t];
+    } else {
+        acc = copy_check(0, len);
+    }
+    if (acc & 0x8080808080808080ull) {
+        (void)h->T.resize((size_t)h->n + 1);
+        h->T[(size_t)h->n] = '\0';
+        rv_set_error("addsequence: the sequence contains non-ASCII bytes");
+        return -1;
+    }
     h->T[(size_t)(h->n + len)] = '$';
     h->T[(size_t)(h->n + len + 1)] = '\0';
     h->n += len + 1;
@@ -204,6 +234,33 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     if (end) *end = h->n - 1;
     h->nodes.push_back(RvIntv{s, h->n - 1});
     return 0;
+}
+
+/* Forget the text and the samples; keep every allocation (host text, device arrays, SA-build scratch, streams): the handle is ready for
+ * the next input's addsample / addsequence.  No counterpart in the reference, whose callers make a new index object per input -- which
+ * here would allocate ~86 B per position of device memory again.  Result arrays set by rv_set_result_buffers stay set. */
+int rv_reset(rv_index *h) {
+    if (!h) { rv_set_error("rv_reset: null handle"); return -1; }
+    RV_HIP(hipSetDevice(h->device));
+    if (h->al) (void)rv_align_end(h);
+    RV_HIP(hipStreamSynchronize(h->ws.stream));
+    if (h->T.resize(1) != 0) return -1;
+    h->T[0] = '\0';
+    h->n = 0; h->nT = 0; h->nsamples = 0; h->rc = 0;
+    h->nsep.clear(); h->nodes.clear();
+    h->constructed = false; h->main_arrays_freed = false; h->sai_valid = false; h->text_only = false; h->text_dirty = true;
+    h->maxlcp = 0;
+    h->m_l.clear(); h->m_a.clear(); h->m_b.clear();
+    h->mm_l.clear(); h->mm_n.clear(); h->mm_off.clear(); h->mm_pos.clear(); h->mm_so.clear();
+    return 0;
+}
+
+/* Optional hint: the text will hold this many bytes (sequences + one separator each): the host buffer is made once instead of growing
+ * sequence by sequence. */
+int rv_reserve_text(rv_index *h, int64_t bytes) {
+    if (!h || bytes < 0) { rv_set_error("rv_reserve_text: bad argument"); return -1; }
+    (void)hipSetDevice(h->device);
+    return h->T.reserve((size_t)bytes + 2);
 }
 
 int64_t rv_n(const rv_index *h) { return h->n; }
@@ -256,7 +313,7 @@ int rv_upload(rv_index *h) {
     RV_HIP(hipMemsetAsync(h->dT0.p, 0, 64, q));
     RV_HIP(hipMemsetAsync(h->dT0.as<uint8_t>() + n, 0, 64, q));
     const size_t CH = (size_t)32 << 20;
-    if ((size_t)n < 2 * CH) {
+    if ((size_t)n < 2 * CH || h->T.pinned) {      // (a page-locked text: one copy by the DMA engine, no host thread touches it)
         RV_HIP(hipMemcpyAsync(h->dT0.p, h->T.data(), (size_t)n, hipMemcpyHostToDevice, q));
     } else {
         // A large text through two pinned chunks: several host threads fill one while the other is on the wire.  (Straight from the
@@ -589,26 +646,23 @@ int rv_run_pair_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8_
         RV_TRY(rv_exclusive_sum_u32(h->ws, tilecnt, tileoff, ntile + 1));
         RV_TRY(rv_pair_compact_launch(h->ws, bslot.as<RvPairRec>(), bovf.as<RvPairRec>(), tilecnt, tileovf, tileoff, ntile, bout.as<RvPairRec>(),
                                       (u32)std::min<size_t>(ocap, 0xffffffffu), bcnt.as<u32>(), d_err, (u32)std::min<size_t>(vcap, 0xffffffffu)));
-        if (d_presel_start && presel > 0 && presel_subs > 0) {
-            // (the header first: the level's record count says whether the device does the choosing)
-            u32 hdr4[4];
-            RV_TRY(rv_read_back(h->ws, hdr4, bout.p, sizeof hdr4));
-            const u32 total = hdr4[0], novf = hdr4[1];
-            if (total <= ocap && novf <= vcap && (int64_t)total >= h->ws.opt.presel_dev_min && (int64_t)total > presel) {
-                if (err_out) *err_out = hdr4[2];
-                RV_TRY(pair_topk(h, bout.as<RvPairRec>() + RV_PAIR_HDR, total, d_presel_start, presel_subs, presel, out));
-                h->scan_guess = (size_t)total + total / 16 + 64;
-                return 0;
-            }
-        }
-        // one copy: header + as many records as the previous scan produced (record counts shrink level by level)
+        // one copy: header + as many records as the previous scan produced (record counts shrink level by level).  With a pre-selection cap
+        // the copy brings RV_PRESEL_DEV_MIN records at most: a level with more is capped on the device (pair_topk) and its records never cross
+        // into host memory -- the header that decides this arrives with the same copy (it used to be a round trip of its own per level)
+        const bool presel_on = d_presel_start && presel > 0 && presel_subs > 0;
         size_t guess = std::min<size_t>(ocap, h->scan_guess);
+        if (presel_on) guess = std::min<size_t>(guess, (size_t)std::max<int64_t>(h->ws.opt.presel_dev_min, 1));
         RV_TRY(h->hscan.reserve((guess + RV_PAIR_HDR) * sizeof(RvPairRec)));
         RV_HIP(hipMemcpyAsync(h->hscan.p, bout.p, (guess + RV_PAIR_HDR) * sizeof(RvPairRec), hipMemcpyDeviceToHost, q));
         RV_HIP(hipStreamSynchronize(q));
         const u32 *hdr = h->hscan.as<u32>();
         const u32 total = hdr[0], novf = hdr[1];
         if (err_out) *err_out = hdr[2];
+        if (presel_on && total <= ocap && novf <= vcap && (int64_t)total >= h->ws.opt.presel_dev_min && (int64_t)total > presel) {
+            RV_TRY(pair_topk(h, bout.as<RvPairRec>() + RV_PAIR_HDR, total, d_presel_start, presel_subs, presel, out));
+            h->scan_guess = (size_t)total + total / 16 + 64;
+            return 0;
+        }
         if (total <= ocap && novf <= vcap) {
             out.resize(total);
             const RvPairRec *src = h->hscan.as<RvPairRec>() + RV_PAIR_HDR;
@@ -849,6 +903,9 @@ int rv_sa_stats(rv_index *h, int *sigma, int *bits, int *k0, int *rounds, int64_
 }
 /* 1: the last construct() of two samples followed piecewise diagonals from seeds (the samples had left their fixed diagonal: indels) */
 int rv_sa_diag_table(rv_index *h) { return h->sa_stats.diag_table; }
+/* what finished the suffixes the first key and the text round left tied in the last construct(): out[0] tied pairs of partners ordered from the
+ * diagonal's marks (k_far_twins), out[1] ranks whose LCP / BWT came from the text after the doubling rounds (k_lcp_list) */
+int rv_sa_tail(rv_index *h, int64_t *out) { if (!h || !out) return -1; out[0] = h->sa_stats.far_pairs; out[1] = h->sa_stats.lcp_list; return 0; }
 
 /* ---- the node's practical HBM ceiling (SURVEY 8(d) "Roofline": measured copy-kernel bandwidth beside the 8 TB/s spec) ---- */
 }  // extern "C"

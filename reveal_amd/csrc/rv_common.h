@@ -80,6 +80,10 @@ void rv_set_error(const char *fmt, ...);
     X(no_packed_text, "RV_NO_PACKED_TEXT", 0) \
     X(no_heads_fusion, "RV_NO_HEADS_FUSION", 0) \
     X(no_twin_collapse, "RV_NO_TWIN_COLLAPSE", 0) \
+    X(no_far_twins, "RV_NO_FAR_TWINS", 0) \
+    X(no_lcp_list, "RV_NO_LCP_LIST", 0) \
+    X(no_text_jump, "RV_NO_TEXT_JUMP", 0) \
+    X(far_table, "RV_FAR_TABLE", 0) \
     X(no_pub_twins, "RV_NO_PUB_TWINS", 0) \
     X(sa_no_text, "RV_SA_NO_TEXT", 0) \
     X(text_mode, "RV_TEXT_MODE", -1) \
@@ -321,7 +325,7 @@ struct Workspace {
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf rs_digits;        // radix sort: the next pass' digit of every key, a byte each
     DBuf misc[16];
-    DBuf sa[26];           // SA-build scratch, kept between construct() calls
+    DBuf sa[30];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;
     // kernel-class timing of the handle that owns this workspace (RvProf, rv_index.h), for code that only sees the workspace
@@ -385,6 +389,8 @@ struct RvSaStats {
     int64_t sorted_elems;       // sum of elements pushed through the radix sort
     int    radix_passes;
     int    diag_table;          // two samples: the hint and the twins' leaving follow piecewise diagonals from seeds (k_diag_bits_tab)
+    int64_t far_pairs;          // tied pairs of partners ordered from the diagonal's marks (k_far_twins)
+    int64_t lcp_list;           // ranks whose LCP / BWT came from the text after the doubling rounds (k_lcp_list)
 };
 // SA of T[0..n) (device pointers).  T must be readable up to n+15 (zero padded).
 // LCP / BWT / d_maxlcp given: the build also leaves LCP (interface.c:97-114), the BWT bytes (side_sep as for rv_build_lcp) and

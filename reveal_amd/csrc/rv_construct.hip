@@ -1456,7 +1456,14 @@ __device__ inline int cmp_suffix(const uint8_t *__restrict__ T, const Packed &pk
 
 // what the fused path writes besides SA: BWT byte of every member at its final rank, LCP of every member but the group's first
 // (its LCP with the member in front of it = the largest common prefix it has with any smaller member), the running maximum
-struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; Packed pk; };
+struct FusedOut { lcp_t *LCP; uint8_t *BWT; const u64 *keys; u32 *maxlcp; sa_t side_sep; KeyDigits kd; int h; Packed pk; int far_defer; };
+// a (first sample) and b (second) are partners on the diagonal the hint follows -- the predicate of k_far_twins (far_linked)
+__device__ inline bool twins_linked(const KeyDigits &kd, int64_t n, int64_t a, int64_t b) {
+    if (a < 0 || a >= kd.D - 1 || b >= n || b < kd.D) return false;
+    if (!kd.dtab) return b - a == kd.D;
+    const int32_t dd = kd.dtab[a >> DT_SHIFT];
+    return dd != DT_NONE && kd.D + (int64_t)dd == b - a && kd.dtab[b >> DT_SHIFT] == dd;
+}
 __device__ inline void fused_put(const FusedOut &f, size_t rank, sav_t suf, u32 pay, bool first, u32 lcp, u32 &lmax) {
     f.BWT[rank] = (uint8_t)(pay | ((sa_t)suf > f.side_sep ? RV_BWT_SIDE : 0u));
     if (!first) {
@@ -1777,6 +1784,7 @@ __global__ __launch_bounds__(TB, 8) void k_round_text3(const uint8_t *__restrict
         const bool big = off >= (u32)MEDIUM_GROUP || (look < m && g_look == g);
         const bool self = !big && i4 < m && g_4 == g;
         if (!self) bigflag[q] = big ? 1 : 0;
+        if (big) fo.BWT[p_own] = (uint8_t)((u32)(key_own >> 56) | ((sa_t)sf_own > fo.side_sep ? RV_BWT_SIDE : 0u));      // (rank p_own holds this suffix until the radix path moves it; k_lcp_list has the last word)
         const int h0 = fo.h;
         const u32 stop0 = key_first_stop(key_g, fo.kd);
         if (self) {
@@ -1881,6 +1889,14 @@ __global__ __launch_bounds__(TB, 8) void k_round_text3(const uint8_t *__restrict
                 const u32 p0 = (u32)(key_g >> 56), p1 = (u32)(key_1 >> 56);
                 fused_put(fo, (size_t)g, lo, first0 ? p0 : p1, true, 0, lmax);
                 fused_put(fo, (size_t)g + 1, hi, first0 ? p1 : p0, false, nd < stop0 ? nd : stop0, lmax);
+            } else if (pair && fo.far_defer && twins_linked(fo.kd, n, (int64_t)(s0 < s1 ? s0 : s1), (int64_t)(s0 < s1 ? s1 : s0))) {
+                // partners whose agreement does not fit the key's field (near-identical inputs): left tied without a look at the text --
+                // k_far_twins reads their order and LCP off the diagonal's marks (2 x 50 Mbp of identical text: 5 x 10^7 comparisons of 4 KB)
+                SA[(size_t)g] = (sa_t)s0; SA[(size_t)g + 1] = (sa_t)s1;
+                headq[q] = 1; headq[q + 1] = 0;
+                // (the bytes in front of the two, in this order: k_far_twins swaps them with the suffixes instead of reading the text)
+                fused_put(fo, (size_t)g, s0, (u32)(key_g >> 56), true, 0, lmax);
+                fused_put(fo, (size_t)g + 1, s1, (u32)(key_1 >> 56), false, 0, lmax);
             } else defer = true;
         }
     }
@@ -1912,6 +1928,203 @@ __global__ __launch_bounds__(TB) void k_round_text3b(const uint8_t *__restrict__
         (void)order_small<W, true>(T, fo, q, g, s, kk, size, fo.h, key_first_stop(key_g, fo.kd), S, SA, headq, lmax);
     }
     fused_max_flush(fo, lmax);
+}
+
+// ---- far twins: a pair on one diagonal that agrees beyond the text round's window --------------------------------------
+// Two samples with the diagonal hint.  A suffix p of the first sample and its twin p + delta (delta = D, or D + dtab[..] on piecewise
+// diagonals) that the text round left tied agree for TEXT_LIM characters and more: nearly identical genomes (0.1 % divergence: one pair
+// in fifty; identical inputs: every pair).  Prefix doubling orders them in log2(agreement / K) rounds over everything that is left --
+// 9 rounds at 0.1 %, 22 at 2 x 50 Mbp of identical text (9.8 s) -- and loses the fused LCP (another pass over the whole index).  Along
+// the diagonal their order is a look-up instead: the next marked position y of k_diag_bits (the reversed max-scan M over the words of the
+// stop bits gives the next word that holds a mark) is where the two texts differ next -- LCP = y - p, the `lt` bit says which one is
+// smaller.  A mark that is an exception ('$', 'N', IUPAC, lower case, a change of diagonal) is looked at on the text, TEXT_LIM bytes at
+// a time, then the diagonal is taken up again; FAR_MAXIT such windows and the pair is left to the doubling rounds.
+struct FarTwins { const u64 *stop, *exc, *lt; const u32 *M; int64_t nw, n, S2, D; const int32_t *dtab; };
+constexpr int FAR_MAXIT = 64;
+__global__ __launch_bounds__(TB) void k_far_rev(const u64 *__restrict__ stop, int64_t nw, u32 *__restrict__ R) {
+    const int64_t j = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (j < nw) R[j] = stop[nw - 1 - j] ? (u32)(j + 1) : 0u;
+}
+__device__ inline int64_t far_next_mark(const FarTwins &ft, int64_t pos) {      // first marked position >= pos (64 nw: none)
+    int64_t w = pos >> 6;
+    if (w >= ft.nw) return ft.nw * 64;
+    u64 bits = ft.stop[w] & (~0ull << (pos & 63));
+    if (!bits) {
+        if (w + 1 >= ft.nw) return ft.nw * 64;
+        const u32 mm = ft.M[ft.nw - 2 - w];
+        if (!mm) return ft.nw * 64;
+        w = ft.nw - (int64_t)mm;
+        bits = ft.stop[w];
+    }
+    return w * 64 + __builtin_ctzll(bits);
+}
+__device__ inline bool far_linked(const FarTwins &ft, int64_t y, int64_t delta) {      // y (first sample) and y + delta are partners
+    if (y < 0 || y >= ft.S2 - 1 || y + delta >= ft.n || y + delta < ft.S2) return false;
+    if (!ft.dtab) return delta == ft.D;
+    const int32_t dd = ft.dtab[y >> DT_SHIFT];
+    return dd != DT_NONE && ft.D + (int64_t)dd == delta && ft.dtab[(y + delta) >> DT_SHIFT] == dd;
+}
+// -> -1 / +1: a / b is the smaller suffix (0: not decided); *lcp as compute_lcp counts it (interface.c:97-114)
+// (pos0: nothing is marked in [a, pos0) -- the two texts agree that far, base for base)
+__device__ inline int far_cmp(const uint8_t *__restrict__ T, const FarTwins &ft, int64_t a, int64_t b, u32 *lcp, int64_t pos0) {
+    const int64_t delta = b - a;
+    int64_t pos = pos0, stop_at = INT64_MAX;
+    bool on_diag = true;
+    for (int it = 0; it < FAR_MAXIT; it++) {
+        int64_t y = pos;
+        if (on_diag) {
+            y = far_next_mark(ft, pos);
+            if (y >= ft.S2 - 1) y = ft.S2 - 1;                   // (the separator between the samples is an exception at the latest)
+            const bool is_exc = y >= ft.nw * 64 || ((ft.exc[y >> 6] >> (y & 63)) & 1ull) != 0ull;
+            if (!is_exc) {      // both A / C / G / T, linked, different: the texts part here
+                const int64_t l = y - a < stop_at ? y - a : stop_at;
+                *lcp = (u32)l;
+                return ((ft.lt[y >> 6] >> (y & 63)) & 1ull) ? -1 : 1;
+            }
+        }
+        // a window of the text from y on: 32 bytes a step (cmp_text's loop, offsets beyond its int range)
+        const uint8_t *pa = T + y, *pb = T + y + delta;
+        for (int off = 0; off < TEXT_LIM; off += 32) {
+            u64 wa[4], wb[4];
+            __builtin_memcpy(wa, pa + off, 32);
+            __builtin_memcpy(wb, pb + off, 32);
+            if (stop_at == INT64_MAX) {
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    const u64 st = zero_bytes(wb[k] ^ 0x2424242424242424ull) | zero_bytes(wb[k] ^ 0x4E4E4E4E4E4E4E4Eull) | zero_bytes(wb[k]);
+                    if (st) stop_at = (y - a) + off + 8 * k + (__builtin_ctzll(st) >> 3);
+                }
+            }
+            u64 x = 0, z = 0; int at = 0; bool diff = false;
+#pragma unroll
+            for (int k = 3; k >= 0; k--) { const bool d = wa[k] != wb[k]; x = d ? wa[k] : x; z = d ? wb[k] : z; at = d ? 8 * k : at; diff |= d; }
+            if (diff) {
+                const int64_t dpos = (y - a) + off + at + (__builtin_ctzll(x ^ z) >> 3);
+                *lcp = (u32)(dpos < stop_at ? dpos : stop_at);
+                return __builtin_bswap64(x) < __builtin_bswap64(z) ? -1 : 1;
+            }
+        }
+        pos = y + TEXT_LIM;
+        on_diag = far_linked(ft, pos, delta);
+    }
+    return 0;
+}
+// The next mark of every position of the first sample, in text order: nd[p] = distance to the first marked position at or behind p (bits 0..29),
+// bit 30 that mark is an exception, bit 31 the first sample's base is the smaller one there; FAR_NONE: no mark, or too far for the field.  Made once
+// (a stream over the words of the bit arrays, 4 bytes written per position) so that a pair of k_far_twins -- the pairs come in rank order, their
+// positions are anywhere in the text -- reads ONE word instead of walking stop word, reversed scan, stop word, exception word, order word one
+// after the other (33 ms for 8.9 x 10^7 pairs at 2 x 250 Mbp with 0.1 % divergence).
+constexpr u32 FAR_NONE = 0xFFFFFFFFu, FAR_EXC = 1u << 30, FAR_LT = 1u << 31, FAR_DIST = (1u << 30) - 1u;
+__global__ __launch_bounds__(TB) void k_far_nd(FarTwins ft, u32 *__restrict__ nd, int64_t nwords1) {
+    const int64_t w = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (w >= nwords1) return;
+    const u64 sw = ft.stop[w], ew = ft.exc[w], lw = ft.lt[w];
+    int64_t cy = -1; u32 ce = 0, cl = 0;
+    if (w + 1 < ft.nw) {
+        const u32 mm = ft.M[ft.nw - 2 - w];
+        if (mm) {
+            const int64_t w2 = ft.nw - (int64_t)mm;
+            const int b = __builtin_ctzll(ft.stop[w2]);
+            cy = w2 * 64 + b; ce = (u32)(ft.exc[w2] >> b) & 1u; cl = (u32)(ft.lt[w2] >> b) & 1u;
+        }
+    }
+    const int64_t last = ft.S2 - 1;      // (positions of the first sample in front of its separator)
+    for (int c4 = 15; c4 >= 0; c4--) {
+        u32 v[4];
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const int b = 4 * c4 + k;
+            const int64_t p = w * 64 + b;
+            if ((sw >> b) & 1ull) { cy = p; ce = (u32)(ew >> b) & 1u; cl = (u32)(lw >> b) & 1u; }
+            const int64_t d = cy - p;
+            v[k] = (cy < 0 || d > (int64_t)FAR_DIST) ? FAR_NONE : ((u32)d | (ce ? FAR_EXC : 0u) | (cl ? FAR_LT : 0u));
+        }
+        const int64_t p0 = w * 64 + 4 * c4;
+        if (p0 + 4 <= last) *reinterpret_cast<uint4 *>(nd + p0) = make_uint4(v[0], v[1], v[2], v[3]);
+        else for (int k = 0; k < 4; k++) if (p0 + k < last) nd[p0 + k] = v[k];
+    }
+}
+// One "round" over the list the text round left: a group of exactly two partners is finished (SA, LCP, BWT, both heads); every other
+// entry keeps its group.  Every entry's head flag and big-group flag are written: the round's bookkeeping reads them for the whole list.
+__global__ __launch_bounds__(TB) void k_far_twins(const uint8_t *__restrict__ T, sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P, int64_t m,
+                                                  FarTwins ft, const u32 *__restrict__ nd, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag, sa_t *__restrict__ SA,
+                                                  lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, sa_t side_sep, u32 *__restrict__ maxlcp) {
+    const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
+    u32 lmax = 0;
+    if (q < m) {
+        const u32 g = G[q];
+        const u32 off = P[q] - g;
+        bigflag[q] = 0;
+        const bool first_of_pair = off == 0 && q + 1 < m && G[q + 1] == g && !(q + 2 < m && G[q + 2] == g);
+        const bool second_of_pair = off == 1 && !(q + 1 < m && G[q + 1] == g);
+        if (first_of_pair) {
+            const int64_t s0 = (int64_t)S[q], s1 = (int64_t)S[q + 1];
+            const int64_t a = s0 < s1 ? s0 : s1, b = s0 < s1 ? s1 : s0;
+            int c = 0; u32 l = 0;
+            if (far_linked(ft, a, b - a)) {
+                const u32 v = nd ? nd[a] : FAR_NONE;
+                if (v != FAR_NONE && !(v & FAR_EXC)) { l = v & FAR_DIST; c = (v & FAR_LT) ? -1 : 1; }      // both A / C / G / T, linked, different: the texts part there
+                else c = far_cmp(T, ft, a, b, &l, v != FAR_NONE ? a + (int64_t)(v & FAR_DIST) : a);
+            }
+            if (c != 0) {
+                const int64_t lo = c < 0 ? a : b, hi = c < 0 ? b : a;
+                S[q] = (sav_t)lo; S[q + 1] = (sav_t)hi;
+                SA[(size_t)g] = (sa_t)lo; SA[(size_t)g + 1] = (sa_t)hi;
+                headq[q] = 1; headq[q + 1] = 1;
+                LCP[(size_t)g + 1] = (lcp_t)l;
+                // the bytes in front of the two suffixes stand at the two ranks, in the list's order (the text round wrote them with the
+                // suffixes): they change places with them.  (Read from the text they were two more random sectors per pair.)
+                if (lo != s0) { const uint8_t b0 = BWT[(size_t)g], b1 = BWT[(size_t)g + 1]; BWT[(size_t)g] = b1; BWT[(size_t)g + 1] = b0; }
+                lmax = l;
+            } else { headq[q] = 1; headq[q + 1] = 0; }
+        } else if (!second_of_pair) headq[q] = off == 0;
+    }
+    const u32 wm = (u32)rv_wave_max_u64((u64)lmax);
+    // (no counter of the finished pairs: a wave's atomic on one address was 2.8 x 10^6 of them at 2 x 250 Mbp with 0.1 % divergence, ~11 ns each:
+    //  the whole kernel's 31.6 ms; the host reads the number off the list's length before and after)
+    if ((threadIdx.x & 63) == 0 && wm > __atomic_load_n(maxlcp, __ATOMIC_RELAXED)) atomicMax(maxlcp, wm);
+}
+
+// ---- LCP / BWT of a list of ranks (what the doubling rounds ordered), straight from the text --------------------------
+// The fused path leaves LCP and BWT at every rank the first key and the text round finish.  The ranks they do not finish -- ties beyond
+// TEXT_LIM, groups above MEDIUM_GROUP: repeats -- used to send the WHOLE index through rv_build_lcp (three random passes over n: 19 of
+// the 29 ms a 2 x 50 Mbp pair with 2 % repeats cost more than one without).  They are a short list: one wave per rank compares the two
+// suffixes 512 bytes a step.  A rank whose suffixes agree for more than LL_MAX_STEPS steps raises the flag, and the caller falls back.
+constexpr int LL_MAX_STEPS = 4096;      // 2 MB of common prefix
+__device__ inline u64 stop_mask(u64 wa, u64 wb);
+__global__ __launch_bounds__(TB) void k_lcp_list(const uint8_t *__restrict__ T, int64_t n, const sa_t *__restrict__ SA, const u32 *__restrict__ ranks, int64_t cnt,
+                                                 lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, sa_t side_sep, u32 *__restrict__ maxlcp, u32 *__restrict__ overflow) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = ((int64_t)blockIdx.x * TB + threadIdx.x) >> 6;
+    if (i >= cnt) return;
+    const int64_t k = (int64_t)ranks[i];
+    const int64_t pb = (int64_t)SA[k];
+    if (lane == 0) BWT[k] = (uint8_t)((pb > 0 ? T[pb - 1] : (uint8_t)'$') | ((sa_t)pb > side_sep ? RV_BWT_SIDE : 0));
+    if (k == 0) return;
+    const int64_t pa = (int64_t)SA[k - 1];
+    u32 h = 0; bool done = false;
+    for (int step = 0; step < LL_MAX_STEPS; step++) {
+        const int64_t off = (int64_t)h + 8 * lane;
+        // (the text is zero padded for 64 bytes only: words that would start beyond count as the end of the text)
+        const u64 wa = (pa + off < n + 48) ? load8(T + pa + off) : 0ull;
+        const u64 wb = (pb + off < n + 48) ? load8(T + pb + off) : 0ull;
+        const u64 stop = stop_mask(wa, wb);
+        const u64 bal = __ballot(stop != 0);
+        if (bal) {
+            const int f = (int)__builtin_ctzll(bal);
+            const u32 lo = (u32)__shfl((int)(u32)stop, f, 64), hi = (u32)__shfl((int)(u32)(stop >> 32), f, 64);
+            const u64 st = ((u64)hi << 32) | lo;
+            h += 8u * (u32)f + (u32)(__builtin_ctzll(st) >> 3);
+            done = true;
+            break;
+        }
+        h += 512;
+    }
+    if (lane == 0) {
+        if (!done) { atomicOr(overflow, 1u); return; }
+        LCP[k] = (lcp_t)h;
+        if (h > __atomic_load_n(maxlcp, __ATOMIC_RELAXED)) atomicMax(maxlcp, h);
+    }
 }
 
 // members of big groups -> sublist (ordered)
@@ -2529,18 +2742,18 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     }
     bool isa_built = false;
     const u32 *list0_P = nullptr, *list0_G = nullptr; int64_t list0_m = 0;      // the round-0 list (collapse: no group ranks per rank, the list has them for the unfinished)
-    auto need_isa = [&]() -> int {      // before the first reader; grp must still hold round 0's group ranks (it is overwritten by the first k_seed / max-scan)
+    // ISA, when something first asks for it (the radix path of groups above MEDIUM_GROUP, a doubling round): a finished rank is a group of
+    // its own -- ISA[SA[r]] = r --, the entries of the CURRENT list carry their group's rank.  (It used to be made from round 0's groups
+    // and kept up to date at the end of every round: a random write per position, 21 ms at n = 5 x 10^8, also for inputs whose ties the
+    // far round finishes without ever reading it.)  SA holds a group's members at the group's ranks from round 0 on, so every suffix of
+    // the text is written once by the first kernel; the second overwrites the list's.
+    const sav_t *cur_S = nullptr; const u32 *cur_G = nullptr; int64_t cur_m = 0;
+    auto need_isa = [&]() -> int {
         if (isa_built) return 0;
-        if (collapse) {
-            // a finished rank is a group of its own; the unfinished are in the round-0 list, which still stands while this is false
-            hipLaunchKernelGGL(k_isa_identity, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, n, ISA);
-            RV_LAUNCH_CHECK();
-            if (list0_m > 0) {
-                hipLaunchKernelGGL(k_isa_list, dim3((unsigned)ceil_div(list0_m, TB)), dim3(TB), 0, q, (const sa_t *)SA, list0_P, list0_G, list0_m, ISA);
-                RV_LAUNCH_CHECK();
-            }
-        } else {
-            hipLaunchKernelGGL(k_isa_from_groups, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, (const u32 *)grp, n, ISA);
+        hipLaunchKernelGGL(k_isa_identity, dim3(nblk), dim3(TB), 0, q, (const sa_t *)SA, n, ISA);
+        RV_LAUNCH_CHECK();
+        if (cur_m > 0) {
+            hipLaunchKernelGGL(k_round_isa, dim3((unsigned)ceil_div(cur_m, TB)), dim3(TB), 0, q, cur_S, cur_G, cur_m, ISA);
             RV_LAUNCH_CHECK();
         }
         isa_built = true;
@@ -2609,14 +2822,71 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 
     const int lowbits = bitlen((u64)n), highbits = bitlen((u64)(n > 1 ? n - 1 : 1));
     int64_t h = K;
+    // What the first key and the text round do not finish.  (1) two samples with the hint: a tied pair of partners is read off the
+    // diagonal's marks (k_far_twins: one more "round" over the list, no doubling, LCP and BWT written with it).  (2) the doubling rounds
+    // order the rest by ranks; the ranks they touch -- `todo`: the members of groups above MEDIUM_GROUP in the text round, and the list
+    // when the first doubling round starts -- get LCP and BWT from the text when SA is complete (k_lcp_list) instead of the whole
+    // index going through rv_build_lcp.  RV_NO_FAR_TWINS / RV_NO_LCP_LIST: the old paths.
+    const bool can_far = fused && kd.ly.nd_bits > 0 && kd.ns == 2 && dg.stop != nullptr && !ws.opt.no_far_twins;
+    const bool can_list = fused && !ws.opt.no_lcp_list;
+    bool text_round_ran = false, far_ran = false, partial = false;
+    DBuf &btodo = ws.sa[26];
+    int64_t ntodo = 0;
+    auto todo_add = [&](const u32 *ranks, int64_t cnt) -> int {
+        if (cnt <= 0) return 0;
+        if ((size_t)(ntodo + cnt) * 4 > btodo.cap) {      // (grow, keeping what is there)
+            DBuf nb;
+            RV_TRY(nb.reserve((size_t)(ntodo + cnt) * 4 * 2 + 1024));
+            if (ntodo) RV_HIP(hipMemcpyAsync(nb.p, btodo.p, (size_t)ntodo * 4, hipMemcpyDeviceToDevice, q));
+            RV_HIP(hipStreamSynchronize(q));
+            btodo.release();
+            btodo = nb;
+        }
+        RV_HIP(hipMemcpyAsync(btodo.as<u32>() + ntodo, ranks, (size_t)cnt * 4, hipMemcpyDeviceToDevice, q));
+        ntodo += cnt;
+        return 0;
+    };
+    // the ordering is by ranks from here on: the fused LCP / BWT survive as "partial" when the list kernel may finish them
+    auto leave_fused = [&](const u32 *ranks, int64_t cnt) -> int {
+        if (!fused) return 0;
+        if (!can_list) { fused = false; return 0; }
+        partial = true;
+        return todo_add(ranks, cnt);
+    };
+    bool list_in_todo = false;
     while (m > 0) {
-        if (h >= 2 * n + 2) { rv_set_error("SA build: did not converge"); freeall(); return -1; }
+        if (h >= 2 * n + 2 + 2 * TEXT_LIM) { rv_set_error("SA build: did not converge"); freeall(); return -1; }
         s.rounds++;
         const unsigned mb = (unsigned)ceil_div(m, TB);
         uint8_t *bigflag = bbig.as<uint8_t>();
+        cur_S = S; cur_G = G; cur_m = m;
+        // (the far round always follows the text round when it may run at all: the text round leaves partners tied on the strength of it,
+        //  without having looked at their text -- fo.far_defer)
+        const bool far_round = text_round_ran && !far_ran && can_far;
+        const bool text_round = !far_round && s.rounds == 1 && h <= 64 && !ws.opt.sa_no_text;
+        bool text_big = false;
+        if (far_round) {
+            far_ran = true;
+            DBuf &bR = ws.sa[27], &bM = ws.sa[28];
+            const int64_t nw1 = ceil_div(kd.D - 1, (int64_t)64);      // words of the first sample
+            SA_TRY(bR.reserve(std::max((size_t)nw * 4 + 64, (size_t)(nw1 * 64 + 64) * 4))); SA_TRY(bM.reserve((size_t)nw * 4 + 64));      // (bR: the reversed words, then the table of k_far_nd)
+            hipLaunchKernelGGL(k_far_rev, dim3((unsigned)ceil_div(nw, TB)), dim3(TB), 0, q, (const u64 *)dg.stop, nw, bR.as<u32>());
+            SA_HIP(hipGetLastError());
+            SA_TRY(rv_inclusive_max_u32(ws, bR.as<u32>(), bM.as<u32>(), nw));
+            FarTwins ft; ft.stop = dg.stop; ft.exc = dg.exc; ft.lt = dg.lt; ft.M = bM.as<u32>(); ft.nw = nw; ft.n = n; ft.S2 = kd.D; ft.D = kd.D; ft.dtab = kd.dtab;
+            // (the table pays for itself from about a million pairs on: 0.6 ms at 2 x 250 Mbp; the few pairs of a 1 % pair walk the marks themselves)
+            const bool nd_table = m >= ((int64_t)1 << 21) || ws.opt.far_table == 1;
+            if (nd_table) {
+                hipLaunchKernelGGL(k_far_nd, dim3((unsigned)ceil_div(nw1, TB)), dim3(TB), 0, q, ft, bR.as<u32>(), nw1);
+                SA_HIP(hipGetLastError());
+            }
+            hipLaunchKernelGGL(k_far_twins, dim3(mb), dim3(TB), 0, q, T, S, (const u32 *)G, (const u32 *)P, m, ft, nd_table ? (const u32 *)bR.as<u32>() : (const u32 *)nullptr, head, bigflag, SA, LCP, BWT, side_sep, d_maxlcp);
+            SA_HIP(hipGetLastError());
+        }
         // groups of up to SMALL_GROUP members: sorted by their first thread, in place
-        if (s.rounds == 1 && h <= 64 && !ws.opt.sa_no_text)
+        else if (text_round)
         {
+            text_round_ran = true;
             FusedOut fo;
             fo.pk.Tp = nullptr; fo.pk.blk = nullptr;
             if (!ws.opt.no_packed_text) {       // 2-bit copy of the text for the comparisons (n/4 bytes + a flag per 128 bases)
@@ -2631,6 +2901,9 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             }
             fo.LCP = fused ? LCP : (lcp_t *)nullptr; fo.BWT = BWT; fo.keys = keys_by_rank; fo.maxlcp = d_maxlcp; fo.side_sep = side_sep; fo.kd = kd;
             fo.h = (int)h;
+            // (fixed diagonal only: along piecewise diagonals most keys without a known agreement stand behind a change of diagonal, and their
+            //  texts part within a few symbols -- the text round is the cheaper place for those; 2 x 250 Mbp with indels: 49 against 39 ms)
+            fo.far_defer = (can_far && kd.dtab == nullptr) ? 1 : 0;
             // measured (2 x 250 Mbp / 10 x 5 Mbp / 2 x 5 Mbp, ms of the whole build): first-thread pairs + self-ranking larger groups
             // 116-120 / 22.6 / 2.27; everything by the first thread (up to 8 members) 122 / 32.0 / 2.37; everything self-ranking
             // 125 / 22.6 / 2.33; 64-byte steps instead of 32: +14 / +3 / +0.3 (the round is bound by sector traffic, not by the
@@ -2664,13 +2937,14 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             hipLaunchKernelGGL(k_medium_back, dim3((unsigned)ceil_div(m, (int64_t)TB * 8)), dim3(TB), 0, q, (const uint8_t *)bigflag, (const sav_t *)Sfree, S, m);
         }
         else {
-            fused = false;      // (a doubling round orders by ranks, not by text: no common prefixes come out of it)
+            // (a doubling round orders by ranks, not by text: no common prefixes come out of it -- every rank of the list is looked at again)
+            if (!list_in_todo) { SA_TRY(leave_fused(P, m)); list_in_todo = true; }
             SA_TRY(need_isa());
             hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
         }
         SA_HIP(hipGetLastError());
         // members of larger groups: ordered sublist -> radix sort on (group rank, rank of suffix+h) -> back into the list
-        {
+        if (!far_round) {
             const int64_t nt = ceil_div(m, CP_TILE);
             hipLaunchKernelGGL(k_flag_count, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, tile);
             SA_HIP(hipGetLastError());
@@ -2679,12 +2953,13 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             u32 mbig = 0;
             SA_TRY(rv_read_back(ws, &mbig, tile + nt, 4));
             if (mbig > 0) {
-                fused = false;
+                text_big = text_round;
                 SA_TRY(need_isa());
                 u32 *Pb = bPb.as<u32>(), *Qb = bQb.as<u32>();
                 hipLaunchKernelGGL(k_flag_emit, dim3((unsigned)nt), dim3(TB), 0, q, (const uint8_t *)bigflag, m, (const u32 *)tile, (const u32 *)P, (const sav_t *)S,
                                    (const u32 *)G, n, h, (const u32 *)ISA, Pb, Sfree, Qb, kA);
                 SA_HIP(hipGetLastError());
+                if (!list_in_todo) SA_TRY(leave_fused(Pb, (int64_t)mbig));      // (the text round wrote nothing for them; a later round's are in the list already)
                 // Sfree holds the sublist's suffixes; its partner buffer for the ping-pong is the seed array (free until k_seed)
                 sav_t *sb0 = Sfree, *sb1 = reinterpret_cast<sav_t *>(bseed.p);
                 int f1 = 0, f2 = 0;
@@ -2702,21 +2977,39 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         // what is still not unique?  Nothing: SA is complete (ISA is only an intermediate of this build)
         int64_t m2 = 0;
         SA_TRY(count_unsorted(head, m, &m2));
+        if (far_round) s.far_pairs = (m - m2) / 2;
         if (m2 == 0) break;
-        fused = false;
-        // new group ranks from the heads, ISA update
-        SA_TRY(need_isa());
+        if (!can_far && !can_list) fused = false;      // (nothing can finish LCP / BWT for what is left)
+        // new group ranks from the heads; ISA, if it exists, follows (made later, it starts from the list of that moment)
         hipLaunchKernelGGL(k_seed, dim3(mb), dim3(TB), 0, q, (const uint8_t *)head, (const u32 *)P, m, seed);
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));
-        hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA);
-        SA_HIP(hipGetLastError());
+        if (isa_built) {
+            hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA);
+            SA_HIP(hipGetLastError());
+        }
         // next list
         SA_TRY(emit_unsorted(head, m, P, S, grp, Pn, Sfree, Gn));
         { u32 *t = P; P = Pn; Pn = t; t = G; G = Gn; Gn = t; }
         { sav_t *t = S; S = Sfree; Sfree = t; }
         m = m2;
-        h *= 2;
+        // (what the text round leaves tied agrees for TEXT_LIM symbols -- unless groups above MEDIUM_GROUP went through the radix path on
+        //  the rank of suffix + K: then the list is only 2 K-ordered)
+        if (text_round && !text_big && !ws.opt.no_text_jump && h < TEXT_LIM && n > 2 * TEXT_LIM) h = TEXT_LIM;
+        else if (!far_round) h *= 2;
+    }
+    if (fused && partial) {
+        // LCP and BWT of the ranks the doubling rounds ordered, from the text; too long a common prefix: the whole index the old way
+        DBuf &bov = ws.sa[29];
+        SA_TRY(bov.reserve(64));
+        SA_HIP(hipMemsetAsync(bov.p, 0, 4, q));
+        hipLaunchKernelGGL(k_lcp_list, dim3((unsigned)ceil_div(ntodo * 64, TB)), dim3(TB), 0, q, T, n, (const sa_t *)SA, (const u32 *)btodo.as<u32>(), ntodo, LCP, BWT, side_sep,
+                           d_maxlcp, bov.as<u32>());
+        SA_HIP(hipGetLastError());
+        u32 ov = 0;
+        SA_TRY(rv_read_back(ws, &ov, bov.p, 4));
+        if (ov) fused = false;
+        s.lcp_list = ntodo;
     }
 #undef SA_TRY
 #undef SA_HIP

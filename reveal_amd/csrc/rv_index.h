@@ -67,12 +67,58 @@ struct RvSub {
     std::vector<RvIntv> lead, trail, match, rest;
 };
 
+// The assembled text on the host (n chars + NUL).  Pageable while small -- `reveal refine` builds an index per bubble of a few hundred
+// bases --, page-locked (hipHostMalloc) from RV_TEXT_PIN_MIN bytes on: the text's way into HBM is then ONE copy by the DMA engine
+// straight from where addsequence wrote it (through two pinned chunks filled by host threads it was 10 ms of four cores' memcpy per
+// 500 MB; a stream of inputs keeps the cores for assembling the next text).  No zero-fill on growth: the bytes are written once.
+struct HostText {
+    static constexpr size_t RV_TEXT_PIN_MIN = (size_t)8 << 20;
+    char *p = nullptr;
+    size_t n = 0, cap = 0;
+    bool pinned = false;
+    HostText() = default;
+    HostText(const HostText &) = delete;
+    HostText &operator=(const HostText &o) {      // (rv_clone)
+        if (this != &o && resize(o.n) == 0 && o.n) memcpy(p, o.p, o.n);
+        return *this;
+    }
+    ~HostText() { release(); }
+    void release() {
+        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+        p = nullptr; n = cap = 0; pinned = false;
+    }
+    int reserve(size_t want) {
+        if (want <= cap) return 0;
+        size_t grow = want < RV_TEXT_PIN_MIN ? std::max<size_t>(want * 2, 256) : want + want / 16 + 4096;
+        char *q = nullptr;
+        bool pin = false;
+        if (grow >= RV_TEXT_PIN_MIN) {
+            void *v = nullptr;
+            if (hipHostMalloc(&v, grow, hipHostMallocDefault) == hipSuccess) { q = (char *)v; pin = true; }
+            else (void)hipGetLastError();      // (no page-locked memory to be had: pageable, the copy is staged by the runtime)
+        }
+        if (!q) q = (char *)malloc(grow);
+        if (!q) { rv_set_error("out of host memory for %zu bytes of text", grow); return -1; }
+        if (n) memcpy(q, p, n);
+        if (p) { if (pinned) (void)hipHostFree(p); else free(p); }
+        p = q; cap = grow; pinned = pin;
+        return 0;
+    }
+    int resize(size_t m) { if (reserve(m) != 0) return -1; n = m; return 0; }
+    void push_back(char c) { if (resize(n + 1) == 0) p[n - 1] = c; }
+    char *data() { return p; }
+    const char *data() const { return p; }
+    size_t size() const { return n; }
+    char &operator[](size_t k) { return p[k]; }
+    const char &operator[](size_t k) const { return p[k]; }
+};
+
 struct rv_index {
     int device = 0;
     Workspace ws;
     RvProf prof;
     // ---- host text assembly (interface.c:18-95)
-    std::vector<char> T;               // n chars + NUL
+    HostText T;                        // n chars + NUL
     std::vector<int64_t> nsep;
     std::vector<int64_t> nsep_dev;     // what dNsep holds
     std::vector<RvIntv> nodes;

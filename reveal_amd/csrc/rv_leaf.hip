@@ -419,12 +419,25 @@ __device__ inline u64 lower8(u64 x) {
     const u64 lo7 = x & 0x7F7F7F7F7F7F7F7Full;
     return x | (((lo7 + 0x3F3F3F3F3F3F3F3Full) & ~(lo7 + 0x2525252525252525ull) & ~x & 0x8080808080808080ull) >> 2);
 }
-__global__ __launch_bounds__(NT) void k_leaf_lower(uint8_t *__restrict__ T, const int64_t *__restrict__ pos, const u32 *__restrict__ len, u32 na) {
+// An anchor longer than LOWER_CAP bytes (near-identical inputs: one anchor of 50 Mbp took its eight lanes 183 ms) is only begun here: it goes
+// to a short list, and k_leaf_lower_long shares what is left of it among a whole grid.  (A full list: the anchor is finished here after all.)
+constexpr int64_t LOWER_CAP = 16384;
+constexpr u32 LOWER_LONG_MAX = 4096;
+__global__ __launch_bounds__(NT) void k_leaf_lower(uint8_t *__restrict__ T, const int64_t *__restrict__ pos, const u32 *__restrict__ len, u32 na, u32 *__restrict__ lng) {
     const int64_t t = (int64_t)blockIdx.x * NT + threadIdx.x;
     const u32 e = (u32)(t >> 4);
     if (e >= na) return;
-    const int64_t l = (int64_t)len[e];
+    int64_t l = (int64_t)len[e];
     const int side = (int)(t >> 3) & 1, h = (int)t & 7;
+    if (l > LOWER_CAP) {      // (both sides and all eight lanes see the same slot: the first lane of the first side takes it, the others learn it through the wave)
+        u32 slot = 0;
+        if (side == 0 && h == 0) slot = atomicAdd(&lng[0], 1u);
+        slot = (u32)__shfl((int)slot, (int)(threadIdx.x & 63) & ~15, 64);
+        if (slot < LOWER_LONG_MAX) {
+            if (side == 0 && h == 0) lng[4 + slot] = e;
+            l = LOWER_CAP;      // (a multiple of sixteen: the tail loop below does nothing)
+        }
+    }
     uint8_t *const p = T + pos[2 * (size_t)e + side];
     for (int64_t j = (int64_t)h * 16; j + 16 <= l; j += 128) {
         u64 x[2];
@@ -433,6 +446,28 @@ __global__ __launch_bounds__(NT) void k_leaf_lower(uint8_t *__restrict__ T, cons
         __builtin_memcpy(p + j, x, 16);
     }
     for (int64_t j = (l & ~(int64_t)15) + h; j < l; j += 8) { const uint8_t ch = p[j]; if (ch >= 'A' && ch <= 'Z') p[j] = ch + 32; }
+}
+// the rest of the long anchors: every workgroup takes 4 KB pieces of every listed anchor in turn (both sides), sixteen bytes per lane and step
+__global__ __launch_bounds__(NT) void k_leaf_lower_long(uint8_t *__restrict__ T, const int64_t *__restrict__ pos, const u32 *__restrict__ len, const u32 *__restrict__ lng) {
+    const u32 cnt = lng[0] < LOWER_LONG_MAX ? lng[0] : LOWER_LONG_MAX;
+    for (u32 k = 0; k < cnt; k++) {
+        const u32 e = lng[4 + k];
+        const int64_t l = (int64_t)len[e];
+        for (int side = 0; side < 2; side++) {
+            uint8_t *const p = T + pos[2 * (size_t)e + side];
+            for (int64_t j0 = LOWER_CAP + (int64_t)blockIdx.x * (NT * 16); j0 < l; j0 += (int64_t)gridDim.x * (NT * 16)) {
+                const int64_t j = j0 + (int64_t)threadIdx.x * 16;
+                if (j + 16 <= l) {
+                    u64 x[2];
+                    __builtin_memcpy(x, p + j, 16);
+                    x[0] = lower8(x[0]); x[1] = lower8(x[1]);
+                    __builtin_memcpy(p + j, x, 16);
+                } else {
+                    for (int64_t i = j; i < l; i++) { const uint8_t ch = p[i]; if (ch >= 'A' && ch <= 'Z') p[i] = ch + 32; }
+                }
+            }
+        }
+    }
 }
 
 }  // namespace
@@ -446,7 +481,12 @@ int rv_leaf_launch(Workspace &ws, const RvLeafArgs &a, int nroots) {
 
 int rv_leaf_lower_launch(Workspace &ws, uint8_t *T, const int64_t *pos, const u32 *len, u32 na) {
     if (na == 0) return 0;
-    hipLaunchKernelGGL(k_leaf_lower, dim3((unsigned)ceil_div((int64_t)na * 16, NT)), dim3(NT), 0, ws.stream, T, pos, len, na);
+    RV_TRY(ws.misc[15].reserve((size_t)(4 + LOWER_LONG_MAX) * 4));
+    u32 *lng = ws.misc[15].as<u32>();
+    RV_HIP(hipMemsetAsync(lng, 0, 16, ws.stream));
+    hipLaunchKernelGGL(k_leaf_lower, dim3((unsigned)ceil_div((int64_t)na * 16, NT)), dim3(NT), 0, ws.stream, T, pos, len, na, lng);
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_leaf_lower_long, dim3(1024), dim3(NT), 0, ws.stream, T, pos, len, (const u32 *)lng);
     RV_LAUNCH_CHECK();
     return 0;
 }

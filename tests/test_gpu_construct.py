@@ -435,3 +435,124 @@ def test_text_round_of_many_samples(count, L, seed, sa64):
     idx.construct()
     assert np.array_equal(idx.array("SA"), c["SA"])
     assert np.array_equal(idx.array("LCP"), c["LCP"])
+
+
+def test_reset_reuses_the_handle():
+    """rv_reset (not in the reference): a handle forgets its text and samples, keeps its allocations, and indexes the next input as a
+    fresh handle would -- incl. a text large enough to live in page-locked host memory (one DMA copy into HBM) between two small ones"""
+    import hashlib
+    from reveal_amd import check, reveallib
+    from helpers import assemble, feed, oracle, synth
+
+    def run(idx, seqs, minl=20):
+        feed(idx, seqs)
+        idx.construct()
+        sa, lcp = idx.array("SA").copy(), idx.array("LCP").copy()
+        r = idx.align_builtin(minl, 2)
+        l, off, pos = r["anchors"]
+        return sa, lcp, sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l))), hashlib.sha256(idx.T.encode("latin-1")).hexdigest()
+
+    small = [g.decode() for g in synth.genomes(200000, 2, seed=3)]
+    three = [g.decode() for g in synth.genomes(90000, 3, seed=4)]
+    idx = reveallib.index()
+    a1 = run(idx, small)
+    idx.reset()
+    assert idx.n == 0 and idx.nsamples == 0 and len(idx.nodes) == 0 and idx.samples == []
+    with pytest.raises(Exception):
+        idx.getmums(20)                                   # not constructed
+    b1 = run(idx, three)
+    idx.reset(reserve=2 * 5_000_001)
+    big = synth.genomes(5_000_000, 2, seed=42)            # 10 MB of text: page-locked
+    feed(idx, [g.decode() for g in big])
+    idx.construct()
+    rec = check.golden_record(5_000_000, 2, 42)
+    g = check.compare_with_golden(rec, SA=idx.array("SA"), LCP=idx.array("LCP"))
+    assert g["all"], g
+    res = idx.align_builtin(20, 2)
+    g = check.compare_with_golden(rec, anchors=res["anchors"], T_final=idx.array("T"))
+    assert g["all"], g
+    idx.reset()
+    a2 = run(idx, small)
+    for x, y in zip(a1, a2):
+        assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y
+    fresh = run(reveallib.index(), three)
+    for x, y in zip(b1, fresh):
+        assert np.array_equal(x, y) if isinstance(x, np.ndarray) else x == y
+    T, nsep, nodes = assemble(small)
+    c = oracle(False).construct(T, nsep, 2)
+    assert np.array_equal(a2[0], c["SA"]) and np.array_equal(a2[1], c["LCP"])
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+@pytest.mark.parametrize("mode", ["default", "no_far", "no_list", "no_jump", "tab", "far_table"])
+def test_ties_beyond_the_text_round(monkeypatch, mode, sa64):
+    """what the first key and the text round leave tied (agreement beyond 4 KB): near-identical and identical pairs are read off the diagonal's
+    marks (k_far_twins), repeats are ordered by the doubling rounds and get LCP / BWT from the text afterwards (k_lcp_list) instead of a rebuild
+    of the whole index; every switch's old path, and the piecewise diagonals, give the same arrays -- SA, LCP, the largest LCP, the matches and
+    the recursion's anchors equal the oracle's"""
+    env = {"no_far": "RV_NO_FAR_TWINS", "no_list": "RV_NO_LCP_LIST", "no_jump": "RV_NO_TEXT_JUMP", "tab": "RV_DIAG_TABLE", "far_table": "RV_FAR_TABLE"}.get(mode)
+    if env:
+        monkeypatch.setenv(env, "1")
+    rng = np.random.default_rng(41)
+
+    def rnd(L):
+        return "".join("ACGT"[x] for x in rng.integers(0, 4, L))
+
+    def mutate(s_, every):
+        b = bytearray(s_.encode())
+        for p in range(every // 2, len(b), every):
+            if chr(b[p]) in "ACGT":
+                b[p] = ord("ACGT"[("ACGT".index(chr(b[p])) + 1) % 4])
+        return b.decode()
+    base = rnd(120000)
+    elem = rnd(9000)
+    rep = base[:20000] + elem + base[20000:50000] + elem + base[50000:70000] + elem[:7000] + base[70000:]      # exact copies of 9 kb and 7 kb
+    tandem = base[:30000] + "ACGGTCA" * 1500 + base[30000:60000] + "AC" * 6000 + base[60000:90000]
+    many = base[:10000] + ("".join(rnd(40) for _ in range(3)) * 1) .join([elem[:5000]] * 70)                  # 70 copies of a 5 kb element: groups above 64
+    near = [g.decode() for g in synth.family(300000, 2, seed=9, snp=0.0002)]
+    near_indel = [g.decode() for g in synth.family(200000, 2, seed=10, snp=0.0004, indelfrac=0.3)]
+    withn = base[:40000] + "N" * 6000 + base[40000:80000]
+    cases = {
+        "near": near, "near_indel": near_indel,
+        "identical": [base[:60000], base[:60000]],
+        "identical_one_snp": [base[:60000], mutate(base[:60000], 45000)],
+        "prefix": [base[:60000], base[:52000]],
+        "n_run": [withn, mutate(withn, 30000)],                      # a run of N in both, agreement across it
+        "repeats": [rep, mutate(rep, 25000)],
+        "tandem": [tandem, mutate(tandem, 20000)],
+        "many_copies": [many, mutate(many, 50000)],
+        "repeats_3": [rep[:60000], mutate(rep[:60000], 9000), mutate(rep[:60000], 7000)],
+    }
+    far = lst = 0
+    for name, seqs in cases.items():
+        T, nsep, nodes = assemble(seqs, toupper=False)
+        O = oracle(sa64)
+        c = O.construct(T, nsep, len(seqs))
+        idx = mod(sa64).index()
+        for k, s_ in enumerate(seqs):
+            idx.addsample("s%d" % k)
+            idx.addsequence(s_)
+        idx.construct()
+        st = idx.sa_stats()
+        tag = (name, st)
+        assert np.array_equal(idx.array("SA"), c["SA"]), tag
+        assert np.array_equal(idx.array("LCP"), c["LCP"]), tag
+        assert idx.maxlcp == int(c["LCP"].max()), tag
+        if len(seqs) == 2:
+            l, a, b = O.getmums(c["tbuf"], c["SA"], c["LCP"], nsep, 20)
+            assert idx.getmums(20) == [(int(l[k]), (int(a[k]), int(b[k])), 0) for k in range(len(l))], tag
+        got = idx.align_builtin(20, 2)
+        ref = O.align_bench(c, nodes, 20, 2)
+        gl, goff, gpos = got["anchors"]
+        rl, rn, roff, rpos = ref["anchors"]
+        assert sorted((int(gl[k]), tuple(int(x) for x in gpos[goff[k]:goff[k + 1]])) for k in range(len(gl))) == \
+               sorted((int(rl[k]), tuple(int(x) for x in rpos[roff[k]:roff[k + 1]])) for k in range(len(rl))), tag
+        assert idx.T.encode("latin-1") == ref["T"], tag
+        far += st["far_pairs"]; lst += st["lcp_list"]
+        if mode == "default":
+            if name in ("near", "identical", "identical_one_snp", "prefix"):
+                assert st["far_pairs"] > 0 and st["rounds"] <= 2 and st["lcp_list"] == 0, tag      # no doubling round at all
+            if name in ("repeats", "tandem", "many_copies"):
+                assert st["lcp_list"] > 0, tag
+    assert (far > 0) == (mode != "no_far")
+    assert (lst > 0) == (mode != "no_list")

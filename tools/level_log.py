@@ -14,5 +14,5 @@ for k, s in enumerate(seqs):
 for rep in range(3):
     idx.construct()
     if rep == 2:
-        os.environ["RV_LEVEL_LOG"] = "1"      # the first runs are silent warm-ups (device buffers reach their final size)
+        idx.set_option("RV_LEVEL_LOG", 1)      # the first runs are silent warm-ups (device buffers reach their final size)
     t = time.time(); idx.align_builtin(20, 2, trace=False); print("total %.2f ms" % ((time.time() - t) * 1e3), file=sys.stderr)

@@ -1,0 +1,9 @@
+# rocprofv3 kernel stats of one input class: bash tools/r5/prof_class.sh OUTNAME CLASS L
+OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
+R=$PWD
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats -d $OUT/prof -o x -- python $R/bench.py --class-one $2 --L $3 --no-check > $OUT/prof.log 2>&1
+cd $R
+python tools/rocpd_stats.py $(ls $OUT/prof/*/x_results.db $OUT/prof/x_results.db 2>/dev/null | head -1) > $OUT/kernel_stats.txt
+rm -rf $OUT/prof
+head -40 $OUT/kernel_stats.txt

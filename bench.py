@@ -553,6 +553,8 @@ def main():
     ap.add_argument("--c5-genomes", type=int, default=100, help="--config c5: number of genomes (a multiple of 5)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
+    ap.add_argument("--cpu-full", action="store_true", help="also time the CPU restatement on the WHOLE workload on this host (single thread: about 13 minutes and 17 GB "
+                                                          "at 2 x 250 Mbp) and compare its anchors with the GPU's -- `cpu_baseline.full_size`")
     ap.add_argument("--no-check", action="store_true", help="skip the full-size property check of the last step's result")
     ap.add_argument("--prof-all", action="store_true", help="time every kernel class inside the timed region (adds events to every level)")
     ap.add_argument("--mode", choices=("auto", "per-rank", "divide"), default="auto",
@@ -908,6 +910,14 @@ def main():
                 "note": "measured on the sample, not on the workload: suffix sorting is n log n, so the CPU's rate per base at the full "
                         "workload size is lower than this figure -- the GPU/CPU ratio read off this line is on the generous-to-CPU side",
             }
+            if args.cpu_full and not same:
+                fb = cpu_baseline(seqs, args.minl, args.minn)
+                frl, frn, froff, frpos = fb["result"]["anchors"]
+                out["cpu_baseline"]["full_size"] = {
+                    "value": bases / (fb["t_construct"] + fb["t_align"]) / 1e6, "unit": "Mbp/s", "cores": 1,
+                    "sample": "the workload itself on this host: construct %.1f s + recursion %.1f s, single thread" % (fb["t_construct"], fb["t_align"]),
+                    "identical_anchor_set": check.anchor_digest(frl, froff, frpos) == check.anchor_digest(*last["anchors"])}
+                del fb
             if not args.no_allcores:
                 ac = cpu_all_cores(cl, args.genomes, args.minl, args.minn)
                 if ac:

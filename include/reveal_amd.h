@@ -303,6 +303,32 @@ int rv_sx_extract(rv_subindex *x, int64_t *intervals, int niv);
 int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t *nmem, const int64_t *crd, const int64_t *left,
                  const int64_t *right, int64_t wscore, int64_t wpen, int model, int64_t *out_idx, int64_t *out_score);
 
+/* One sub-index' decision by the reference's default picker -- `graphmumpicker`, reveal/schemes.py:197-361, the branch that is not
+ * "precomputed" -- for FASTA inputs with one sequence per sample: keep the matches present in every sample of the sub-index (the best sample
+ * subset when there is none: `segment`), trim overlaps (--trim, the default), order, cap at --maxmums, chain (rv_chain), split on the largest
+ * match of the chain, seed the children with the rest of the chain above --seedsize, and with minlength == 0 the p-value cut.  Plain host
+ * code, no device involved.  Input: the sub-index' scan result as rv_sub_mums hands it out (m matches, members off[i]..off[i+1] in emission
+ * order: sample so[], text position pos[]), nsub = samples of the sub-index, and per sample of the index (nsamples): where its sequence
+ * begins and the sub-index' interval of it (iv_begin < 0: none).  Returns 1 with the choice and the seeds in *out (seed w: seed_l / seed_n /
+ * members seed_off[w]..seed_off[w+1] / seed_score / seed_right 0 = for the leading, 1 = for the trailing child), 0 for the reference's `()`
+ * (stop this branch), -2 where the reference's own code raises (KeyError / IndexError), -1 on bad arguments.  The caller owns every array. */
+typedef struct { int64_t wscore, wpen, maxmums, seedsize; int gcmodel; int trim; double pcutoff; } rv_picker_args;
+typedef struct {
+    int picked; uint32_t pick_l; int32_t pick_n; int pick_members; uint16_t *pick_so; int64_t *pick_pos; int64_t member_cap;
+    int64_t nleft, nright, nseed_members, seed_cap, seed_member_cap;
+    uint32_t *seed_l; int32_t *seed_n; int64_t *seed_off; uint16_t *seed_so; int64_t *seed_pos; int64_t *seed_score; uint8_t *seed_right;
+} rv_picker_out;
+/* The picker of rv_align_builtin and its relatives: kind 0 = the benchmark picker (the longest match present in every sample; the
+ * default), kind 1 = the reference's default picker with these options (rv_pick_chain per sub-index, seeds handed to the children as the reference's
+ * skipmums: reveal.c:802, 830-837, 1157, 1180) under the linear interval model -- `reveal rem a.fa b.fa` with its defaults, no Python callback per
+ * sub-index.  Kind 1 takes inputs with one sequence per sample; the scans hand their whole lists to the host (no device-side pick, no leaf
+ * kernel, no anchor cascade); rv_fetch_anchors hands out an anchor's members in the picker's order (the scan's emission order), not sorted.  rv_picker_info: out[0] kind, out[1] picker calls of the last run, out[2] of them seeded. */
+int rv_set_picker(rv_index *h, int kind, const rv_picker_args *args);
+int rv_picker_info(const rv_index *h, int64_t *out);
+int rv_pick_chain(const rv_picker_args *args, int nsub, int64_t m, const uint32_t *l, const int32_t *n, const int64_t *off, const uint16_t *so,
+                  const int64_t *pos, int nsamples, const int64_t *seq_begin, const int64_t *iv_begin, const int64_t *iv_end, int minlength,
+                  rv_picker_out *out);
+
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,

@@ -572,6 +572,26 @@ def make_index_type(sa64, error):
                 self._fail()
             return self._builtin_result(st, trace)
 
+        def set_picker(self, args=None):
+            """the picker of align_builtin (rv_set_picker): None = the benchmark picker; a schemes.PickerArgs = the reference's default picker
+            (schemes.graphmumpicker) in C++ behind the ABI, for inputs with one sequence per sample (args.maxsize / maxdepth are not supported there)"""
+            from . import schemes
+            if args is None:
+                r = self._dll.rv_set_picker(self._h, 0, None)
+            else:
+                if args.maxsize is not None or args.maxdepth is not None:
+                    raise error("the native picker does not take --maxbubblesize / maxdepth")
+                A = schemes._RvPickerArgs(int(args.wscore), int(args.wpen), int(args.maxmums or 0), int(args.seedsize or 0), schemes.GCMODELS[args.gcmodel],
+                                          1 if args.trim else 0, float(args.pcutoff))
+                r = self._dll.rv_set_picker(self._h, 1, ctypes.byref(A))
+            if r != 0:
+                self._fail()
+
+        def picker_info(self):
+            o = (ctypes.c_int64 * 3)()
+            self._dll.rv_picker_info(self._h, o)
+            return dict(kind=int(o[0]), calls=int(o[1]), seeded=int(o[2]))
+
         def _result_buffers_free(self):
             """the result arrays of the previous call, when nothing but this object refers to them (or to a view of them) any more"""
             c = self.__dict__.get("_res_bufs")

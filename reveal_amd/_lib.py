@@ -114,6 +114,9 @@ SYMBOLS = {
     "rv_sa_stats": (_I, [V] + [ctypes.POINTER(_I)] * 4 + [c_i64p, ctypes.POINTER(_I)]),
     "rv_sa_diag_table": (_I, [V]),
     "rv_sa_tail": (_I, [V, c_i64p]),
+    "rv_set_picker": (_I, [V, _I, V]),
+    "rv_picker_info": (_I, [V, c_i64p]),
+    "rv_pick_chain": (_I, [V, _I, _L, V, V, V, V, V, _I, V, V, V, _I, V]),
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
     "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),

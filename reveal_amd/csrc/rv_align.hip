@@ -138,6 +138,22 @@ struct Align {
     std::vector<RvPairRec> recs;
     std::vector<u32> ml; std::vector<int32_t> mn; std::vector<int64_t> moff, mpos; std::vector<uint16_t> mso;
     std::vector<int64_t> mum_first, nmums;       // per sub
+    // rv_set_picker: 0 = the benchmark picker (longest match in every sample), 1 = the reference's default picker in C++ (rv_pick_chain, rv_chain.hip).
+    // Its seeds (schemes.py:321-332; reveal.c:1157, 1180 hands them to the children as skipmums) wait here: per sub-index of the current level the
+    // list it was seeded with (empty: it is scanned), and the two lists its own decision leaves for its leading / trailing child
+    int picker = 0; rv_picker_args pargs{};
+    struct SeedList {
+        std::vector<u32> l; std::vector<int32_t> n; std::vector<int64_t> off; std::vector<uint16_t> so; std::vector<int64_t> pos, score;
+        size_t size() const { return l.size(); }
+        void clear() { l.clear(); n.clear(); off.assign(1, 0); so.clear(); pos.clear(); score.clear(); }
+        void push(u32 l_, int32_t n_, const uint16_t *so_, const int64_t *pos_, int members, int64_t sc) {
+            if (off.empty()) off.assign(1, 0);
+            l.push_back(l_); n.push_back(n_); score.push_back(sc);
+            so.insert(so.end(), so_, so_ + members); pos.insert(pos.end(), pos_, pos_ + members); off.push_back((int64_t)pos.size());
+        }
+    };
+    std::vector<SeedList> seeds_cur, seeds_lead, seeds_trail;
+    int64_t picker_calls = 0, picker_seeded = 0;
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
     int64_t presel_d2h = 0;            // records the scans of this alignment copied to the host while pre-selection was on (RV_PRESEL_LOG)
@@ -386,6 +402,19 @@ int rv_set_trace(rv_index *h, int on) {
 /* What schemes.graphmumpicker keeps of a scan before it chains (schemes.py:227 the matches present in every sample of the
  * sub-index; :240, :245-247, :287-289 of those the `maxmums` longest -- two stable sorts, so of equal lengths the later
  * emitted ones stay), applied inside the library so that only those cross into Python.  0 = off (the reference's lists). */
+int rv_set_picker(rv_index *h, int kind, const rv_picker_args *args) {
+    if (!h || kind < 0 || kind > 1 || (kind == 1 && !args)) { rv_set_error("rv_set_picker: bad arguments"); return -1; }
+    if (kind == 1 && (args->gcmodel < 0 || args->gcmodel > 2)) { rv_set_error("rv_set_picker: gap cost model 0 (sumofpairs), 1 (star-avg) or 2 (star-med)"); return -1; }
+    if (!h->al) h->al = new Align();
+    h->al->picker = kind;
+    if (kind == 1) h->al->pargs = *args;
+    return 0;
+}
+int rv_picker_info(const rv_index *h, int64_t *out) {
+    if (!h || !out) return -1;
+    out[0] = h->al ? h->al->picker : 0; out[1] = h->al ? h->al->picker_calls : 0; out[2] = h->al ? h->al->picker_seeded : 0;
+    return 0;
+}
 int rv_set_preselect(rv_index *h, int64_t maxmums) {
     if (maxmums < 0) { rv_set_error("rv_set_preselect: maxmums must not be negative"); return -1; }
     if (!h->al) h->al = new Align();
@@ -1478,7 +1507,7 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
 static int builtin_leaf_setup(rv_index *h) {
     Align *a = h->al;
     hipStream_t q = h->ws.stream;
-    a->use_leaf = !a->multi && !h->ws.opt.no_leaf;
+    a->use_leaf = !a->multi && !h->ws.opt.no_leaf && a->picker == 0;
     a->leaf_flip = 0;
     if (!a->use_leaf) return 0;
     a->leaf_anchor_cap = (size_t)(h->nT / std::max(a->minl, 1)) + 1024;
@@ -1511,9 +1540,14 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     // (an untraced built-in run never hands a sub-index out: the inverse stays unmade unless somebody asked for it before)
     RV_TRY(align_begin(h, minl, minn, h->al && h->al->trace_on));
     Align *a = h->al;
-    a->full_only = !a->trace_on;
+    a->full_only = !a->trace_on && a->picker == 0;      // (the chain picker looks at every match of a sub-index: the scans hand their whole lists to the host)
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
-    const bool use_leaf = !a->multi && !h->ws.opt.no_leaf;
+    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear(); a->picker_calls = a->picker_seeded = 0;
+    if (a->picker == 1) {
+        if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
+        if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
+    }
+    const bool use_leaf = !a->multi && !h->ws.opt.no_leaf && a->picker == 0;
     a->use_leaf = use_leaf;
     // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
     // the levels after it), so the first level takes the same path as the others
@@ -1553,6 +1587,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
     std::vector<int64_t> sp;
     std::vector<RvIntv> lead, trail, match, rest;
     std::vector<uint8_t> touched;
+    std::vector<u32> pk_l, pk_sl; std::vector<int32_t> pk_n, pk_sn; std::vector<int64_t> pk_off, pk_mpos, pk_pos, pk_sb, pk_ib, pk_ie, pk_soff, pk_spos, pk_ssc;
+    std::vector<uint16_t> pk_mso, pk_so, pk_sso; std::vector<uint8_t> pk_srt;
     const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
     int &leaf_flip = a->leaf_flip;
@@ -1642,6 +1678,73 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             // picker: longest match present in every sample of the sub-index, ties -> smallest minimum coordinate
             int64_t best = -1, bmin = 0; u32 bl = 0;
             const int want = lv.nsamples[(size_t)s];
+            bool chain_pick = false;
+            if (a->picker == 1) {
+                // the reference's default picker (schemes.py:197-361) in C++: rv_pick_chain on the sub-index' whole list -- or, for a sub-index its
+                // parent seeded, the middle of that list (schemes.py:349-354) and its two halves for the children
+                if ((int)a->seeds_lead.size() != ns) { a->seeds_lead.assign((size_t)ns, Align::SeedList()); a->seeds_trail.assign((size_t)ns, Align::SeedList()); }
+                const int W = h->nsamples;
+                pk_so.assign((size_t)W, 0); pk_pos.assign((size_t)W, 0);
+                int members = 0;
+                Align::SeedList &sl = a->seeds_lead[(size_t)s], &st = a->seeds_trail[(size_t)s];
+                sl.clear(); st.clear();
+                a->picker_calls++;
+                if (s < (int)a->seeds_cur.size() && a->seeds_cur[(size_t)s].size() > 0) {
+                    const Align::SeedList &sd = a->seeds_cur[(size_t)s];
+                    const size_t cnt2 = sd.size(), mid = cnt2 / 2;
+                    a->picker_seeded++;
+                    bl = sd.l[mid]; members = (int)(sd.off[mid + 1] - sd.off[mid]);
+                    for (int q2 = 0; q2 < members; q2++) { pk_so[(size_t)q2] = sd.so[(size_t)sd.off[mid] + q2]; pk_pos[(size_t)q2] = sd.pos[(size_t)sd.off[mid] + q2]; }
+                    for (size_t k = 0; k < cnt2; k++) {
+                        if (k == mid) continue;
+                        (k < mid ? sl : st).push(sd.l[k], sd.n[k], sd.so.data() + sd.off[k], sd.pos.data() + sd.off[k], (int)(sd.off[k + 1] - sd.off[k]), sd.score[k]);
+                    }
+                    chain_pick = true;
+                } else if (cnt > 0) {
+                    // the list as rv_sub_mums hands it out
+                    pk_l.clear(); pk_n.clear(); pk_off.assign(1, 0); pk_mso.clear(); pk_mpos.clear();
+                    if (!a->multi) {
+                        for (int64_t k = first; k < first + cnt; k++) {
+                            const RvPairRec &r = a->recs[(size_t)k];
+                            pk_l.push_back(r.l); pk_n.push_back(2);
+                            pk_mso.push_back(0); pk_mpos.push_back((int64_t)r.a); pk_mso.push_back(1); pk_mpos.push_back((int64_t)r.b);
+                            pk_off.push_back((int64_t)pk_mpos.size());
+                        }
+                    } else {
+                        for (int64_t k = first; k < first + cnt; k++) {
+                            pk_l.push_back(a->ml[(size_t)k]); pk_n.push_back(a->mn[(size_t)k]);
+                            for (int64_t qq = a->moff[(size_t)k]; qq < a->moff[(size_t)k + 1]; qq++) { pk_mso.push_back(a->mso[(size_t)qq]); pk_mpos.push_back(a->mpos[(size_t)qq]); }
+                            pk_off.push_back((int64_t)pk_mpos.size());
+                        }
+                    }
+                    pk_sb.assign((size_t)W, 0); pk_ib.assign((size_t)W, -1); pk_ie.assign((size_t)W, -1);
+                    for (int q2 = 0; q2 < W; q2++) pk_sb[(size_t)q2] = h->nodes[(size_t)q2].begin;
+                    for (size_t k = 0; k < nn; k++) {
+                        const int sm = sample_of(h, nodes[k].begin);
+                        if (pk_ib[(size_t)sm] >= 0) { rv_set_error("the native picker takes one interval per sample and sub-index"); return -1; }
+                        pk_ib[(size_t)sm] = nodes[k].begin; pk_ie[(size_t)sm] = nodes[k].end;
+                    }
+                    const size_t scap = pk_l.size(), mcap = pk_mpos.size();
+                    pk_sl.resize(scap); pk_sn.resize(scap); pk_soff.resize(scap + 1); pk_sso.resize(std::max<size_t>(mcap, 1)); pk_spos.resize(std::max<size_t>(mcap, 1));
+                    pk_ssc.resize(scap); pk_srt.resize(scap);
+                    rv_picker_out po;
+                    memset(&po, 0, sizeof po);
+                    po.pick_so = pk_so.data(); po.pick_pos = pk_pos.data(); po.member_cap = W;
+                    po.seed_cap = (int64_t)scap; po.seed_member_cap = (int64_t)std::max<size_t>(mcap, 1);
+                    po.seed_l = pk_sl.data(); po.seed_n = pk_sn.data(); po.seed_off = pk_soff.data(); po.seed_so = pk_sso.data(); po.seed_pos = pk_spos.data();
+                    po.seed_score = pk_ssc.data(); po.seed_right = pk_srt.data();
+                    const int pr = rv_pick_chain(&a->pargs, want, (int64_t)pk_l.size(), pk_l.data(), pk_n.data(), pk_off.data(), pk_mso.data(), pk_mpos.data(), W,
+                                                 pk_sb.data(), pk_ib.data(), pk_ie.data(), a->minl, &po);
+                    if (pr < 0) return -1;
+                    if (pr == 1) {
+                        bl = po.pick_l; members = po.pick_members; chain_pick = true;
+                        for (int64_t k = 0; k < po.nleft + po.nright; k++)
+                            (pk_srt[(size_t)k] ? st : sl).push(pk_sl[(size_t)k], pk_sn[(size_t)k], pk_sso.data() + pk_soff[(size_t)k], pk_spos.data() + pk_soff[(size_t)k],
+                                                              (int)(pk_soff[(size_t)k + 1] - pk_soff[(size_t)k]), pk_ssc[(size_t)k]);
+                    }
+                }
+                if (chain_pick) { sp.assign(pk_pos.begin(), pk_pos.begin() + members); best = 0; }
+            } else
             if (!a->multi) {
                 if (want == 2)
                     for (int64_t k = first; k < first + cnt; k++) {
@@ -1658,8 +1761,9 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             }
             if (best >= 0) {
                 // graphalign, linear interval model
-                sp.clear(); lead.clear(); trail.clear(); match.clear(); rest.clear();
-                if (!a->multi) { sp.push_back((int64_t)a->recs[(size_t)best].a); sp.push_back((int64_t)a->recs[(size_t)best].b); }
+                lead.clear(); trail.clear(); match.clear(); rest.clear();
+                if (chain_pick) {}      // (sp holds the choice's members)
+                else if (!a->multi) { sp.clear(); sp.push_back((int64_t)a->recs[(size_t)best].a); sp.push_back((int64_t)a->recs[(size_t)best].b); }
                 else sp.assign(a->mpos.begin() + a->moff[(size_t)best], a->mpos.begin() + a->moff[(size_t)best + 1]);
                 std::sort(sp.begin(), sp.end());
                 touched.assign(nn, 0);
@@ -1677,6 +1781,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                 RV_TRY(add_decision(h, s, bl, sp.data(), (int)sp.size(), lead.data(), (int)lead.size(), trail.data(), (int)trail.size(),
                                     match.data(), (int)match.size(), rest.data(), (int)rest.size()));
                 a->an_l.push_back(bl);
+                if (chain_pick) a->an_pos.insert(a->an_pos.end(), pk_pos.begin(), pk_pos.begin() + (ptrdiff_t)sp.size());      // (the picker's member order: graphalign merges the nodes in it)
+                else
                 a->an_pos.insert(a->an_pos.end(), sp.begin(), sp.end());
                 a->an_off.push_back((int64_t)a->an_pos.size());
                 a->st.splits++; a->st.anchored_bp += bl;
@@ -1687,6 +1793,23 @@ static int builtin_levels(rv_index *h, int stop_subs) {
         a->st.t_host += now_s() - t0;
         const double tl1 = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_commit(h, nullptr));
+        if (a->picker == 1) {
+            // a child whose parent left it a list is not scanned (reveal.c:802, 830-837): its picker call takes the list's middle
+            const int nn2 = a->lv.size();
+            std::vector<Align::SeedList> nxt((size_t)nn2);
+            for (int s2 = 0; s2 < nn2; s2++) {
+                const int p = a->lv.parent[(size_t)s2], kd = a->lv.kind[(size_t)s2];
+                if (p < 0 || p >= (int)a->seeds_lead.size()) continue;
+                Align::SeedList &src = kd == 1 ? a->seeds_lead[(size_t)p] : a->seeds_trail[(size_t)p];
+                if ((kd == 1 || kd == 2) && src.size() > 0) {
+                    nxt[(size_t)s2] = std::move(src);
+                    if ((int)a->skip_scan.size() != nn2) a->skip_scan.assign((size_t)nn2, 0);
+                    a->skip_scan[(size_t)s2] = 1;
+                }
+            }
+            a->seeds_cur.swap(nxt);
+            a->seeds_lead.clear(); a->seeds_trail.clear();
+        }
         if (level_log) {
             const double tl2 = now_s();
             (void)hipStreamSynchronize(q);
@@ -1790,7 +1913,7 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
 static int builtin_cascade(rv_index *h) {
     Align *a = h->al;
     memset(&a->cas_out, 0, sizeof a->cas_out);
-    if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || h->ws.opt.no_cascade) return 0;
+    if (a->trace_on || h->rc != 0 || h->n <= RV_LEAF_N || a->minl < 4 || h->ws.opt.no_cascade || a->picker != 0) return 0;
     const bool second_try = !a->multi && a->use_leaf && h->ws.opt.cascade_second == 2;      // (test hook: straight to the second attempt)
     auto interval_cascade = [&]() -> int {
         // the decided part's anchors come back on the host, what is undecided becomes the frontier of the level pipeline

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa
 // k_cas_dpick keeps the pairs that are each other's only longest partner.  A cut match inside D that the walk does not confirm (ell was not the length of C's
 // best match): C is looked at again in the next level with that match set aside (bids capped below it), up to sixteen times.
 constexpr u32 DWALK = 1024;
-struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u64 *ceil; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; };
+struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u64 *ceil; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; uint8_t *dflag; };
 __device__ inline bool cas_is_danger(const CasIv &p, u64 bk, u32 wm, u32 minl, u32 leaf_n, u32 *theta) {
     const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
     const u32 bl = (u32)(bk >> KEY_SHIFT);
@@ -393,13 +393,24 @@ __device__ inline bool cas_is_danger(const CasIv &p, u64 bk, u32 wm, u32 minl, u
     *theta = bl >= minl ? bl : minl;
     return can & !split & (wm >= minl) & ((u64)(la + lb) > (u64)leaf_n);
 }
+// A byte per sub-index of the level: the second attempt looks at it (cas_is_danger).  The three kernels below run over EVERY witness at every level,
+// and nearly all of them sit in sub-indices the match list decides: read per witness, the sub-index' intervals, best bid and Wmax were three random
+// sectors each -- 1.4 ms per level for 2 x 10^7 witnesses (2 x 250 Mbp with 2 % repeats: 79 of the run's 173 ms) -- where this byte stays in the L2.
+// (A live witness always sits in a sub-index of the current level: k_cas_assign moves it to a child made by the last k_cas_decide or lets it die.)
+__global__ __launch_bounds__(TB) void k_cas_dmark(const CasIv *__restrict__ iv, const u64 *__restrict__ best, const u32 *__restrict__ wmax, u32 minl, const u32 *__restrict__ counters, CasDanger dg) {
+    const u32 lo = counters[C_LO], hi = counters[C_HI];
+    for (u32 id = lo + blockIdx.x * TB + threadIdx.x; id < hi; id += gridDim.x * TB) {
+        u32 theta;
+        dg.dflag[id] = cas_is_danger(iv[id], best[id], wmax[id], minl, dg.leaf_n, &theta) ? 1 : 0;
+    }
+}
 __global__ __launch_bounds__(TB) void k_cas_dwalk(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, const u32 *__restrict__ w_child, u32 NW,
                                                   const CasIv *__restrict__ iv, const u64 *__restrict__ best, const u32 *__restrict__ wmax, u32 minl, CasDanger dg) {
     const u32 i = blockIdx.x * TB + threadIdx.x;
     if (i >= NW) return;
-    dg.m1[i] = 0; dg.key[i] = 0;
     const u32 c = w_child[i];
-    if (c == NONE) return;
+    if (c == NONE || !dg.dflag[c]) return;      // (m1 / key of such a witness are never read: k_cas_dpick and k_cas_dwrite leave through the same door)
+    dg.m1[i] = 0; dg.key[i] = 0;
     const CasIv p = iv[c];
     u32 theta;
     if (!cas_is_danger(p, best[c], wmax[c], minl, dg.leaf_n, &theta)) return;
@@ -444,7 +455,7 @@ __global__ __launch_bounds__(TB) void k_cas_dpick(const sa_t *__restrict__ w_pos
     const u32 i = blockIdx.x * TB + threadIdx.x;
     if (i >= NW) return;
     const u32 c = w_child[i];
-    if (c == NONE) return;
+    if (c == NONE || !dg.dflag[c]) return;
     const CasIv p = iv[c];
     u32 theta;
     const u64 bk = best[c];
@@ -473,9 +484,10 @@ __global__ __launch_bounds__(TB) void k_cas_dpick(const sa_t *__restrict__ w_pos
 __global__ __launch_bounds__(TB) void k_cas_dwrite(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_child, u32 NW, CasDanger dg) {
     const u32 i = blockIdx.x * TB + threadIdx.x;
     if (i >= NW) return;
+    const u32 c = w_child[i];
+    if (c == NONE || !dg.dflag[c]) return;
     const u64 key = dg.key[i];
     if (key == 0) return;
-    const u32 c = w_child[i];
     if (key == dg.best[c]) dg.qb[c] = w_pos[dg.p1[i]];
 }
 
@@ -1011,9 +1023,9 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
             dg.rank = in1 ? k1.as<u64>() : k0.as<u64>();
         }
         DBuf &bdc = cb.d[24], &bdw = cb.d[25];
-        const size_t per_child = 8 + 8 + 4 + sizeof(sa_t), per_wit = 4 + 4 + 4 + 8;
+        const size_t per_child = 8 + 8 + 4 + sizeof(sa_t) + 1, per_wit = 4 + 4 + 4 + 8;
         RV_TRY(bdc.reserve((size_t)ccap * per_child + 64)); RV_TRY(bdw.reserve((size_t)std::max<u32>(NW, 1) * per_wit + 64));
-        dg.best = bdc.as<u64>(); dg.ceil = dg.best + ccap; dg.qb = (sa_t *)(dg.ceil + ccap); dg.flag = (u32 *)(dg.qb + ccap);
+        dg.best = bdc.as<u64>(); dg.ceil = dg.best + ccap; dg.qb = (sa_t *)(dg.ceil + ccap); dg.flag = (u32 *)(dg.qb + ccap); dg.dflag = (uint8_t *)(dg.flag + ccap);
         dg.key = bdw.as<u64>(); dg.m1 = (u32 *)(dg.key + std::max<u32>(NW, 1)); dg.p1 = dg.m1 + std::max<u32>(NW, 1); dg.m2 = dg.p1 + std::max<u32>(NW, 1);
         dg.T0 = h->dT0.as<uint8_t>(); dg.LCP = LCP;
         // every undecided sub-index this way, not only the ones the leaf kernel cannot take: the walk costs less than rebuilding a sub-index that
@@ -1064,6 +1076,8 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
             RV_LAUNCH_CHECK();
             if (danger && NW) {
                 const unsigned wb = (unsigned)ceil_div((int64_t)NW, TB);
+                hipLaunchKernelGGL(k_cas_dmark, dim3(256), dim3(TB), 0, q, (const CasIv *)biv.as<CasIv>(), (const u64 *)bbest.as<u64>(), (const u32 *)bwm.as<u32>(), minl, (const u32 *)counters, dg);
+                RV_LAUNCH_CHECK();
                 hipLaunchKernelGGL(k_cas_dwalk, dim3(wb), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const u64 *)bbest.as<u64>(),
                                    (const u32 *)bwm.as<u32>(), minl, dg);
                 RV_LAUNCH_CHECK();

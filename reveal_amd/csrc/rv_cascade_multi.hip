@@ -106,7 +106,7 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
     const int k = KT ? KT : k_rt;
     __shared__ __attribute__((aligned(16))) u32 sl[MS_TILE + RV_CASM_K + 16];          // LCP of ranks u0-HS .. u0+TILE (0 outside the array); HS = the halo rounded up to 16
     __shared__ __attribute__((aligned(16))) uint8_t ss[MS_TILE + RV_CASM_K + 16], sb[MS_TILE + RV_CASM_K + 16];
-    __shared__ uint16_t cand[MS_TILE];
+    __shared__ uint16_t cand[MS_TILE], cand2[MS_TILE];
     __shared__ u32 ncand;
     const int64_t u0 = (int64_t)blockIdx.x * MS_TILE;
     const int H = k - 1;
@@ -161,15 +161,38 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
     }
     __syncthreads();
     const u32 nc = ncand;
+    // Two dense stages.  First what most candidates fail on -- the window's smallest value (with related samples a candidate closes the k homologues of
+    // one position, and some of them have left the others within minl symbols) and the values on either side of it --, which is H reads of LDS;
+    // the ones that pass (one in seventy at 10 x 5 Mbp) are listed again, and only they pay the H + 1 reads of the samples and the 2 H of the bytes
+    // in front.  (One stage, every test on every candidate: 38 reads of LDS per candidate, 257 us at 10 x 5 Mbp.)
+    __syncthreads();      // (ncand has been read by everybody: it counts the second list from here on)
+    if (threadIdx.x == 0) ncand = 0;
+    __syncthreads();
     for (u32 ci = threadIdx.x; ci < ((nc + 63u) & ~63u); ci += TB) {      // (whole waves: the ballot below)
         bool ok = ci < nc;
         const int t = ok ? (int)cand[ci] : 0;
         const int x = t + HS;
-        const int64_t u = u0 + t;
-        // every test over the whole window, no early exit: the trip counts are the same for every lane (written with `&& ok` in the loop
-        // conditions the kernel ran two scalar instructions of exec-mask bookkeeping for every vector one)
         u32 v = sl[x];
         const u32 nxt = sl[x + 1];
+#pragma unroll
+        for (int d = 1; d < H; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; }
+        ok = ok & (v >= minl) & (v > nxt) & (sl[x - H] < v);
+        const u64 bal = __ballot(ok);
+        if (bal) {
+            u32 base = 0;
+            if (lane == 0) base = atomicAdd(&ncand, (u32)__popcll(bal));
+            base = (u32)__shfl((int)base, 0, 64);
+            if (ok) cand2[base + (u32)__popcll(bal & lt)] = (uint16_t)t;
+        }
+    }
+    __syncthreads();
+    const u32 nc2 = ncand;
+    for (u32 ci = threadIdx.x; ci < ((nc2 + 63u) & ~63u); ci += TB) {
+        bool ok = ci < nc2;
+        const int t = ok ? (int)cand2[ci] : 0;
+        const int x = t + HS;
+        const int64_t u = u0 + t;
+        u32 v = sl[x];
 #pragma unroll
         for (int d = 1; d < H; d++) { const u32 y = sl[x - d]; v = y < v ? y : v; }
         u32 seen = 0;
@@ -181,7 +204,7 @@ __global__ __launch_bounds__(TB) void k_casm_scan(const sa_t *__restrict__ SA, c
             const uint8_t ca = sb[x - d], cb = sb[x - d + 1];
             mx |= (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca >= 'a') & (ca <= 'z'));
         }
-        ok = ok & (v >= minl) & (v > nxt) & (sl[x - H] < v) & (__popc(seen) == H + 1) & mx;
+        ok = ok & (__popc(seen) == H + 1) & mx;
         // (the list in CM_REGIONS regions with a counter each: one counter was 50 000 returning atomics on one address, 0.7 of the kernel's 0.9 ms)
         const u64 bal = __ballot(ok);
         if (bal) {

@@ -84,6 +84,7 @@ void rv_set_error(const char *fmt, ...);
     X(no_lcp_list, "RV_NO_LCP_LIST", 0) \
     X(no_text_jump, "RV_NO_TEXT_JUMP", 0) \
     X(far_table, "RV_FAR_TABLE", 0) \
+    X(no_slow_class, "RV_NO_SLOW_CLASS", 0) \
     X(no_pub_twins, "RV_NO_PUB_TWINS", 0) \
     X(sa_no_text, "RV_SA_NO_TEXT", 0) \
     X(text_mode, "RV_TEXT_MODE", -1) \
@@ -228,7 +229,9 @@ struct DBuf {
     int reserve(size_t bytes) {
         if (bytes <= cap) return 0;
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-        size_t want = bytes + bytes / 8 + 256;
+        // (the growth margin saves re-allocations while inputs of similar size follow each other; on the arrays of a large index -- 256 MB and
+        //  more -- an eighth was 8.5 bytes per text position of device memory)
+        size_t want = bytes + (bytes >= ((size_t)256 << 20) ? bytes / 64 : bytes / 8) + 256;
         hipError_t e = hipMalloc(&p, want);
         if (e == hipErrorOutOfMemory) {
             (void)hipGetLastError();
@@ -325,7 +328,7 @@ struct Workspace {
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf rs_digits;        // radix sort: the next pass' digit of every key, a byte each
     DBuf misc[16];
-    DBuf sa[30];           // SA-build scratch, kept between construct() calls
+    DBuf sa[32];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;
     // kernel-class timing of the handle that owns this workspace (RvProf, rv_index.h), for code that only sees the workspace

@@ -1152,7 +1152,8 @@ __global__ __launch_bounds__(TB) void k_cp_count(const uint8_t *__restrict__ hea
 // pos_in == nullptr means "position is j itself" (round 0).
 __global__ __launch_bounds__(TB) void k_cp_emit(const uint8_t *__restrict__ head, int64_t n, const u32 *__restrict__ tileoff,
                                                 const u32 *__restrict__ pos_in, const sav_t *__restrict__ suf_in, const u32 *__restrict__ grp_in,
-                                                u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G) {
+                                                u32 *__restrict__ P, sav_t *__restrict__ S, u32 *__restrict__ G,
+                                                const uint8_t *__restrict__ cls_in = nullptr, uint8_t *__restrict__ cls_out = nullptr, int cls_is = 0) {
     __shared__ u32 wbase[TB / 64];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     const int64_t base = (int64_t)blockIdx.x * CP_TILE;
@@ -1173,6 +1174,7 @@ __global__ __launch_bounds__(TB) void k_cp_emit(const uint8_t *__restrict__ head
             P[q] = pos_in ? pos_in[j] : (u32)j;
             S[q] = suf_in[j];
             G[q] = grp_in[j];
+            if (cls_out) cls_out[q] = cls_in ? (cls_is ? (cls_in[j] == (uint8_t)cls_is) : cls_in[j]) : (uint8_t)0;      // (cls_is: the flag value that means "of the slow class")
         }
         run += tot;
         __syncthreads();
@@ -1257,10 +1259,14 @@ __global__ __launch_bounds__(TB) void k_cp_emit_g(const uint8_t *__restrict__ he
 
 // ---- refinement rounds --------------------------------------------------------
 // ISA of the list's suffixes after a round: the start of their (new) group
-__global__ __launch_bounds__(TB) void k_round_isa(const sav_t *__restrict__ S, const u32 *__restrict__ newG, int64_t m, u32 *__restrict__ ISA) {
+// (oldG: the round's own group ranks -- an entry whose group did not change keeps its word: the doubling rounds below TEXT_LIM pass over
+//  everything the text round left tied, a random write per entry and round for nothing)
+__global__ __launch_bounds__(TB) void k_round_isa(const sav_t *__restrict__ S, const u32 *__restrict__ newG, int64_t m, u32 *__restrict__ ISA, const u32 *__restrict__ oldG = nullptr) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q >= m) return;
-    ISA[S[q]] = newG[q];
+    const u32 g = newG[q];
+    if (oldG && oldG[q] == g) return;
+    ISA[S[q]] = g;
 }
 
 // ---- doubling round, small groups ------------------------------------------------
@@ -1279,11 +1285,13 @@ __device__ inline u32 key2_of(sav_t s, int64_t h, int64_t n, const u32 *__restri
 
 __global__ __launch_bounds__(TB) void k_round_small(sav_t *__restrict__ S, const u32 *__restrict__ G, const u32 *__restrict__ P, int64_t m, int64_t n, int64_t h,
                                                     const u32 *__restrict__ ISA, uint8_t *__restrict__ headq, uint8_t *__restrict__ bigflag,
-                                                    sa_t *__restrict__ SA) {
+                                                    sa_t *__restrict__ SA, const uint8_t *__restrict__ slow = nullptr) {
     const int64_t q = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (q >= m) return;
     const u32 g = G[q];
     const u32 off = P[q] - g;
+    // slow != NULL: only the entries it marks take part in this round (h is below what the others are known to share: their groups stand)
+    if (slow && !slow[q]) { bigflag[q] = 0; headq[q] = off == 0; return; }
     const int64_t look = q + (SMALL_GROUP - (int64_t)off);
     const bool big = off >= (u32)SMALL_GROUP || (look < m && G[look] == g);
     bigflag[q] = big;
@@ -2613,7 +2621,13 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
 #define SA_HIP(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { rv_set_error("%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); freeall(); return -1; } } while (0)
     SA_TRY(bk0.reserve((size_t)n * 8)); SA_TRY(bk1.reserve((size_t)n * 8));
     SA_TRY(bv0.reserve((size_t)n * sizeof(sav_t))); SA_TRY(bv1.reserve((size_t)n * sizeof(sav_t)));
-    SA_TRY(bhead.reserve((size_t)n + 16)); SA_TRY(bseed.reserve((size_t)n * (sizeof(sav_t) > 4 ? sizeof(sav_t) : 4))); SA_TRY(bgrp.reserve((size_t)n * 4));
+    SA_TRY(bhead.reserve((size_t)n + 16));
+    // (seed / group ranks: n entries where round 0 writes them per rank; with the twins' leaving only the rounds' lists use them -- m entries, reserved then:
+    //  8 of the build's ~54 bytes per position)
+    auto need_seed_grp = [&](int64_t cnt) -> int {
+        RV_TRY(bseed.reserve((size_t)std::max<int64_t>(cnt, 1) * (sizeof(sav_t) > 4 ? sizeof(sav_t) : 4)));
+        return bgrp.reserve((size_t)std::max<int64_t>(cnt, 1) * 4);
+    };
     SA_TRY(bisa.reserve((size_t)n * 4));
     const unsigned nblk = (unsigned)ceil_div(n, TB);
 
@@ -2707,7 +2721,8 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
     sav_t *vt = in1 ? bv0.as<sav_t>() : bv1.as<sav_t>();
 
     uint8_t *head = bhead.as<uint8_t>();
-    u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();
+    if (!collapse) SA_TRY(need_seed_grp(n));
+    u32 *seed = bseed.as<u32>(), *grp = bgrp.as<u32>(), *ISA = bisa.as<u32>();      // (collapse: set again once the list's length is known)
     const u64 *keys_by_rank = ks;          // what the text round reads for the members of a group
     const sav_t *vals_by_rank = vs;
     if (collapse) {
@@ -2741,7 +2756,6 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_HIP(hipGetLastError());
     }
     bool isa_built = false;
-    const u32 *list0_P = nullptr, *list0_G = nullptr; int64_t list0_m = 0;      // the round-0 list (collapse: no group ranks per rank, the list has them for the unfinished)
     // ISA, when something first asks for it (the radix path of groups above MEDIUM_GROUP, a doubling round): a finished rank is a group of
     // its own -- ISA[SA[r]] = r --, the entries of the CURRENT list carry their group's rank.  (It used to be made from round 0's groups
     // and kept up to date at the end of every round: a random write per position, 21 ms at n = 5 x 10^8, also for inputs whose ties the
@@ -2778,22 +2792,16 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         *m_out = tot;
         return 0;
     };
-    auto emit_unsorted = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in, u32 *P, sav_t *S, u32 *G) -> int {
+    auto emit_unsorted = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in, u32 *P, sav_t *S, u32 *G,
+                             const uint8_t *cls_in = nullptr, uint8_t *cls_out = nullptr, int cls_is = 0) -> int {
         const int64_t nt = ceil_div(len, CP_TILE);
-        hipLaunchKernelGGL(k_cp_emit, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, (const u32 *)tile, pos_in, suf_in, grp_in, P, S, G);
+        hipLaunchKernelGGL(k_cp_emit, dim3((unsigned)nt), dim3(TB), 0, q, hd, len, (const u32 *)tile, pos_in, suf_in, grp_in, P, S, G, cls_in, cls_out, cls_is);
         RV_LAUNCH_CHECK();
         return 0;
     };
-    auto compact = [&](const uint8_t *hd, int64_t len, const u32 *pos_in, const sav_t *suf_in, const u32 *grp_in,
-                       u32 *P, sav_t *S, u32 *G, int64_t *m_out) -> int {
-        RV_TRY(count_unsorted(hd, len, m_out));
-        if (*m_out == 0) return 0;
-        return emit_unsorted(hd, len, pos_in, suf_in, grp_in, P, S, G);
-    };
-
     int64_t m = 0;
-    SA_TRY(bP0.reserve((size_t)n * 4)); SA_TRY(bG0.reserve((size_t)n * 4));
-    SA_TRY(bP1.reserve((size_t)n * 4)); SA_TRY(bG1.reserve((size_t)n * 4));
+    // (the lists of the not yet unique hold m entries, not n -- 2.4 x 10^7 of 5 x 10^8 at 2 x 250 Mbp: reserved when m is known, the second pair when a
+    //  round leaves something behind; they were 16 bytes per position)
     // round-0 suffix list goes to the free value buffer `vt`
     if (collapse) {
         // group ranks from the head flags (k_cp_emit_g)
@@ -2806,15 +2814,21 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         u32 tot = 0;
         SA_TRY(rv_read_back(ws, &tot, tile + ntile, 4));
         m = tot;
+        SA_TRY(bP0.reserve((size_t)std::max<int64_t>(m, 1) * 4)); SA_TRY(bG0.reserve((size_t)std::max<int64_t>(m, 1) * 4));
+        SA_TRY(need_seed_grp(m));
+        seed = bseed.as<u32>(); grp = bgrp.as<u32>();
         if (m > 0) {
             hipLaunchKernelGGL(k_cp_emit_g, dim3((unsigned)ntile), dim3(TB), 0, q, (const uint8_t *)head, n, (const u32 *)tile, (const u32 *)tlast, vals_by_rank,
                                bP0.as<u32>(), vt, bG0.as<u32>());
             SA_HIP(hipGetLastError());
         }
-        list0_P = bP0.as<u32>(); list0_G = bG0.as<u32>(); list0_m = m;
-    } else
-    SA_TRY(compact(head, n, nullptr, vals_by_rank, grp, bP0.as<u32>(), vt, bG0.as<u32>(), &m));
-    u32 *P = bP0.as<u32>(), *G = bG0.as<u32>(), *Pn = bP1.as<u32>(), *Gn = bG1.as<u32>();
+    } else {
+        SA_TRY(count_unsorted(head, n, &m));
+        SA_TRY(bP0.reserve((size_t)std::max<int64_t>(m, 1) * 4)); SA_TRY(bG0.reserve((size_t)std::max<int64_t>(m, 1) * 4));
+        if (m > 0) SA_TRY(emit_unsorted(head, n, nullptr, vals_by_rank, grp, bP0.as<u32>(), vt, bG0.as<u32>()));
+    }
+    const int64_t m_list0 = m;
+    u32 *P = bP0.as<u32>(), *G = bG0.as<u32>(), *Pn = nullptr, *Gn = nullptr;      // (the second pair: reserved by the first round that needs it)
     sav_t *S = vt;          // current list of suffixes (length m)
     sav_t *Sfree = vs;      // the other value buffer
     u64 *kA = ks, *kB = kt; // both key buffers are free from here on
@@ -2854,6 +2868,12 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         return todo_add(ranks, cnt);
     };
     bool list_in_todo = false;
+    // Groups above MEDIUM_GROUP went through the radix path on the rank of suffix + K in the text round: their members (class "slow") are only
+    // 2 K-ordered, everything else the text round left tied agrees for TEXT_LIM symbols.  The doubling rounds below TEXT_LIM / 2 are the slow
+    // class' alone: the others keep their groups without a look at ISA (k_round_small) and without a write to it (k_round_isa) -- eight rounds
+    // over 1.6 x 10^7 tied entries for a few hundred thousand members of tandem arrays at 2 x 250 Mbp with 2 % repeats.
+    DBuf &bcls0 = ws.sa[30], &bcls1 = ws.sa[31];
+    uint8_t *cls = nullptr, *cls_next = nullptr;      // class of the current list's entries (1 = slow); NULL: no classes (every entry takes part)
     while (m > 0) {
         if (h >= 2 * n + 2 + 2 * TEXT_LIM) { rv_set_error("SA build: did not converge"); freeall(); return -1; }
         s.rounds++;
@@ -2940,7 +2960,8 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
             // (a doubling round orders by ranks, not by text: no common prefixes come out of it -- every rank of the list is looked at again)
             if (!list_in_todo) { SA_TRY(leave_fused(P, m)); list_in_todo = true; }
             SA_TRY(need_isa());
-            hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA);
+            const uint8_t *slow = (cls && 2 * h <= TEXT_LIM) ? cls : nullptr;
+            hipLaunchKernelGGL(k_round_small, dim3(mb), dim3(TB), 0, q, S, (const u32 *)G, (const u32 *)P, m, n, h, (const u32 *)ISA, head, bigflag, SA, slow);
         }
         SA_HIP(hipGetLastError());
         // members of larger groups: ordered sublist -> radix sort on (group rank, rank of suffix+h) -> back into the list
@@ -2985,10 +3006,22 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_HIP(hipGetLastError());
         SA_TRY(rv_inclusive_max_u32(ws, seed, grp, m));
         if (isa_built) {
-            hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA);
+            hipLaunchKernelGGL(k_round_isa, dim3(mb), dim3(TB), 0, q, (const sav_t *)S, (const u32 *)grp, m, ISA, (const u32 *)G);
             SA_HIP(hipGetLastError());
         }
         // next list
+        if (!Pn) {
+            SA_TRY(bP1.reserve((size_t)std::max<int64_t>(m_list0, 1) * 4)); SA_TRY(bG1.reserve((size_t)std::max<int64_t>(m_list0, 1) * 4));
+            Pn = bP1.as<u32>(); Gn = bG1.as<u32>();
+        }
+        // (classes: made when the text round had groups above MEDIUM_GROUP -- its flag 1 --, carried along afterwards)
+        const bool want_cls = (text_round && text_big && !ws.opt.no_slow_class && n > 2 * TEXT_LIM) || cls != nullptr;
+        if (want_cls) {
+            SA_TRY(bcls0.reserve((size_t)m2 + 64)); SA_TRY(bcls1.reserve((size_t)m2 + 64));
+            cls_next = (cls == bcls0.as<uint8_t>()) ? bcls1.as<uint8_t>() : bcls0.as<uint8_t>();
+            SA_TRY(emit_unsorted(head, m, P, S, grp, Pn, Sfree, Gn, text_round ? (const uint8_t *)bigflag : (const uint8_t *)cls, cls_next, text_round ? 1 : 0));
+            cls = cls_next;
+        } else
         SA_TRY(emit_unsorted(head, m, P, S, grp, Pn, Sfree, Gn));
         { u32 *t = P; P = Pn; Pn = t; t = G; G = Gn; Gn = t; }
         { sav_t *t = S; S = Sfree; Sfree = t; }

@@ -164,7 +164,47 @@ class GraphAligner:
         return leading, trailing, matching, rest, mn, newleft, newright
 
 
-def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None):
+class _ReplaySub:
+    """what graphalign reads and edits of a sub-index (rem.py:318-382): its set of intervals and its left / right graph nodes"""
+    __slots__ = ("nodes", "leftnode", "rightnode", "depth")
+
+    def __init__(self, nodes, leftnode, rightnode, depth):
+        self.nodes, self.leftnode, self.rightnode, self.depth = nodes, leftnode, rightnode, depth
+
+
+def replay_anchors(G, aligner, root_nodes, anchors):
+    """The graph of a run whose picker ran inside the library (index.set_picker + align_builtin): the recursion's bookkeeping of
+    index.align (level by level; children: leading, trailing, rest -- reveal.c:1136-1207) with graphalign applied to every anchor in the
+    order the library chose them.  anchors: [(l, n, ((sample, pos), ...))] in emission order.  -> number of graphalign calls"""
+    frontier = [_ReplaySub(set(root_nodes), None, None, 0)]
+    ai, na = 0, len(anchors)
+    while frontier and ai < na:
+        nxt = []
+        for sub in frontier:
+            if ai >= na:
+                break
+            mum = anchors[ai]
+            p0 = mum[2][0][1]
+            if not any(b <= p0 < e for b, e in sub.nodes):
+                continue
+            ai += 1
+            r = aligner.graphalign(sub, mum)
+            if r is None:
+                continue
+            leading, trailing, matching, rest, merged, newleft, newright = r
+            if leading:
+                nxt.append(_ReplaySub(leading, sub.leftnode, newright, sub.depth + 1))
+            if trailing:
+                nxt.append(_ReplaySub(trailing, newleft, sub.rightnode, sub.depth + 1))
+            if rest:
+                nxt.append(_ReplaySub(rest, sub.leftnode, sub.rightnode, sub.depth + 1))
+        frontier = nxt
+    if ai != na:
+        raise RuntimeError("replay_anchors: %d of %d anchors found no sub-index" % (na - ai, na))
+    return na
+
+
+def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None):
     """rem.py:511-611 align_genomes: index + graph from FASTA / GFA inputs, construct, align with the graph callbacks.
     preselect: let the library hand the picker only what it keeps anyway (index.preselect(maxmums): the matches spanning
     every sample of the sub-index, capped at --maxmums) -- not valid with --trim, which looks at the others
@@ -186,7 +226,28 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
         raise ValueError("Specify at least 2 targets to construct alignment. In case of multi-fasta, consider the --nocontigs flag.")
     args = args or schemes.PickerArgs()
     picker, aligner = schemes.GraphPicker(G, args), GraphAligner(G)
+    # native: the picker inside the library (rv_set_picker / rv_pick_chain: no Python call per sub-index), the graph from the anchors afterwards.
+    # Its case: FASTA inputs with one sequence per sample, no --maxbubblesize / maxdepth, reveal_amd's own index.  None = whenever that holds.
+    can_native = (hasattr(idx, "set_picker") and not any(f.endswith(".gfa") or f.endswith(".gfa.gz") for f in inputfiles)
+                  and len(idx.nodes) == len(idx.samples) and args.maxsize is None and args.maxdepth is None)
+    if native and not can_native:
+        raise ValueError("native=True: FASTA inputs with one sequence per sample, no maxsize / maxdepth, reveal_amd's index")
+    if native is None:
+        native = can_native
+    root_nodes = sorted(tuple(x) for x in idx.nodes)
     idx.construct()
+    if native:
+        import bisect
+        idx.set_picker(args)
+        l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
+        begins = [b for b, _ in root_nodes]
+        pos = pos.tolist(); off = off.tolist(); l = l.tolist()
+        anchors = [(l[k], off[k + 1] - off[k], tuple((bisect.bisect_right(begins, p) - 1, p) for p in pos[off[k]:off[k + 1]])) for k in range(len(l))]
+        idx.set_picker(None)
+        picker.calls = idx.picker_info()["calls"]
+        idx._nodes = set(root_nodes)
+        replay_anchors(G, aligner, root_nodes, anchors)
+        return G, idx, picker, aligner
     if preselect and not args.trim and args.maxmums and hasattr(idx, "preselect"):
         idx.preselect(args.maxmums)
     idx.align(picker.graphmumpicker, aligner.graphalign, threads=0, wpen=args.wpen, wscore=args.wscore, minl=minlength, minn=minn)
@@ -242,12 +303,12 @@ def align(aobjs, ref=None, minlength=20, minn=2, seedsize=None, threads=0, targe
     return G, idx
 
 
-def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None):
+def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None):
     """`reveal rem inputs -o output` (rem.py:449-509 align_cmd): align, merge equal siblings when more than two paths took part,
     write GFA1.  -> (graph, index, file name or None)"""
     from . import alngraph
     G, idx, picker, aligner = graph_align_genomes(inputfiles, sa64=sa64, minlength=minlength, minn=minn, contigs=contigs, toupper=toupper,
-                                                  args=args, preselect=preselect, indexmod=indexmod)
+                                                  args=args, preselect=preselect, indexmod=indexmod, native=native)
     T = idx.T
     if len(G.paths) > 2:
         G.prune_nodes(T)

@@ -230,3 +230,59 @@ def test_segment_shortcut_is_only_taken_where_it_holds():
     assert not G.check_segment_shortcut() and G.literal_segments
     lead, trail, rest = G.segmentgraph((0, 10), [(11, 21), (22, 30)])
     assert (lead, trail, rest) == G.segmentgraph_literal((0, 10), [(11, 21), (22, 30)])
+
+
+def _native_beside_python(monkeypatch, stats):
+    """every call of the Python picker (schemes.GraphPicker.graphmumpicker, the not-precomputed branch) is also put to rv_pick_chain"""
+    import bisect
+    from reveal_amd import schemes
+    orig = schemes.GraphPicker.graphmumpicker
+
+    def both(self, mums, idx, precomputed=False, minlength=0):
+        want = orig(self, mums, idx, precomputed=precomputed, minlength=minlength)
+        if precomputed or len(mums) == 0 or self.args.maxsize is not None or self.args.maxdepth is not None:
+            return want
+        G = self.G
+        rpaths = [p for p in G.paths if not p.startswith("*")]
+        begins = getattr(self, "_seq_begin", None)
+        if begins is None:                                  # the sequences of the index: one per sample (the graph's first nodes)
+            begins = self._seq_begin = sorted(b for b, e in stats["root_nodes"])
+            assert len(begins) == len(rpaths)
+        ns = len(begins)
+        ivb, ive = [-1] * ns, [-1] * ns
+        for b, e in idx.nodes:
+            s = bisect.bisect_right(begins, b) - 1
+            assert ivb[s] < 0, "more than one interval of a sample: not the native picker's case"
+            ivb[s], ive[s] = b, e
+        got = schemes.native_pick([(mm[0], mm[1], tuple(mm[2])) for mm in mums], idx.nsamples, begins, ivb, ive, self.args, minlength)
+        norm = lambda r: () if not r else ((r[0][0], r[0][1], tuple(tuple(x) for x in r[0][2])),
+                                           [((m[0], m[1], tuple(tuple(x) for x in m[2])), sc) for m, sc in r[1]],
+                                           [((m[0], m[1], tuple(tuple(x) for x in m[2])), sc) for m, sc in r[2]])
+        assert norm(got) == norm(want), (idx.depth, sorted(idx.nodes), norm(got)[:1], norm(want)[:1])
+        stats["calls"] += 1
+        stats["picked"] += 1 if want else 0
+        stats["seeded"] += 1 if want and (want[1] or want[2]) else 0
+        return want
+    monkeypatch.setattr(schemes.GraphPicker, "graphmumpicker", both)
+
+
+@pytest.mark.parametrize("names,kw", [(["1a", "1b"], {}), (["1a", "1b", "1c"], {}), (["1a", "1b"], {"trim": False}), (["1a", "1c", "1d"], {"seedsize": 300, "maxmums": 50}),
+                                      (["1a", "1b"], {"seedsize": 200, "wpen": 3, "gcmodel": "star-avg"}), (["d1", "d2"], {})])
+def test_native_picker_decides_like_the_python_picker(tmp_path, refmod, monkeypatch, names, kw):
+    """rv_pick_chain (C++ behind the ABI) beside schemes.GraphPicker.graphmumpicker on every sub-index of whole `reveal rem` runs driven by the
+    reference's index: same choice (after trimming: length and positions), same seeds with the same scores, same refusals"""
+    from reveal_amd import rem, schemes
+    files = C.fasta_files(tmp_path, names)
+    stats = {"calls": 0, "picked": 0, "seeded": 0, "root_nodes": None}
+    orig_init = schemes.GraphPicker.__init__
+
+    def init(self, graph, args=None):
+        orig_init(self, graph, args)
+        stats["root_nodes"] = list(graph.seq_nodes())
+    monkeypatch.setattr(schemes.GraphPicker, "__init__", init)
+    _native_beside_python(monkeypatch, stats)
+    G, idx, fn = rem.graph_rem(files, str(tmp_path / "o.gfa"), args=schemes.PickerArgs(**kw), indexmod=refmod, preselect=False)
+    if kw.get("seedsize", 10000) < 1000:      # (seeded children are "precomputed" calls: few calls reach the chain)
+        assert stats["seeded"] > 0 and stats["calls"] >= 3, stats
+    else:
+        assert stats["calls"] > 5 and stats["picked"] > 5, stats

@@ -484,13 +484,13 @@ def test_reset_reuses_the_handle():
 
 
 @pytest.mark.parametrize("sa64", [False, True])
-@pytest.mark.parametrize("mode", ["default", "no_far", "no_list", "no_jump", "tab", "far_table"])
+@pytest.mark.parametrize("mode", ["default", "no_far", "no_list", "no_jump", "tab", "far_table", "no_slow"])
 def test_ties_beyond_the_text_round(monkeypatch, mode, sa64):
     """what the first key and the text round leave tied (agreement beyond 4 KB): near-identical and identical pairs are read off the diagonal's
     marks (k_far_twins), repeats are ordered by the doubling rounds and get LCP / BWT from the text afterwards (k_lcp_list) instead of a rebuild
     of the whole index; every switch's old path, and the piecewise diagonals, give the same arrays -- SA, LCP, the largest LCP, the matches and
     the recursion's anchors equal the oracle's"""
-    env = {"no_far": "RV_NO_FAR_TWINS", "no_list": "RV_NO_LCP_LIST", "no_jump": "RV_NO_TEXT_JUMP", "tab": "RV_DIAG_TABLE", "far_table": "RV_FAR_TABLE"}.get(mode)
+    env = {"no_far": "RV_NO_FAR_TWINS", "no_list": "RV_NO_LCP_LIST", "no_jump": "RV_NO_TEXT_JUMP", "tab": "RV_DIAG_TABLE", "far_table": "RV_FAR_TABLE", "no_slow": "RV_NO_SLOW_CLASS"}.get(mode)
     if env:
         monkeypatch.setenv(env, "1")
     rng = np.random.default_rng(41)

@@ -48,3 +48,56 @@ def test_synthetic_config5_shape(tmp_path):
     assert spelled == {"genome%d" % k: s.decode() for k, s in enumerate(seqs)}
     shared = [n for n in G.seq_nodes() if len(G.offsets[n]) == 9]
     assert sum(e - b for b, e in shared) > 0.3 * 60000
+
+
+def test_config5_all_three_levels(tmp_path):
+    """BASELINE config 5's own shape -- 100 genomes, --order=sequential --chunksize=5: 20 / 4 / 1 jobs, graphs feeding graphs twice -- at 20 kbp
+    per genome (tools/config5.py; the same command at 5 Mbp per genome is profiles/r05_config5_full.json): the final graph spells all 100"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if not k.startswith("RV_")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5.py"), "--genomes", "100", "--L", "20000", "--chunksize", "5", "--dir", str(tmp_path)],
+                       capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert d["plan"] == [20, 4, 1] and d["paths_spell_inputs"] is True
+    assert d["levels"]["0"]["jobs"] == 20 and d["levels"]["1"]["jobs"] == 4 and d["levels"]["2"]["jobs"] == 1
+
+
+@pytest.mark.parametrize("names,kw", [(["1a", "1b"], {}), (["1a", "1b", "1c"], {}), (["1a", "1b"], {"trim": False}), (["1a", "1c", "1d"], {"seedsize": 300, "maxmums": 50}),
+                                      (["1a", "1b"], {"seedsize": 200, "wpen": 3, "gcmodel": "star-avg"}), (["d1", "d2"], {}), (["2a", "2b"], {})])
+def test_native_picker_writes_the_same_gfa(tmp_path, names, kw):
+    """`reveal rem` with its default picker inside the library (rv_set_picker / rv_pick_chain, no Python call per sub-index; the graph replayed
+    from the anchors) against the same run through the two Python callbacks: the same GFA file, byte for byte"""
+    from reveal_amd import schemes
+    files = C.fasta_files(tmp_path, names)
+    outs = {}
+    for native in (False, True):
+        G, idx, fn = rem.graph_rem(files, str(tmp_path / ("n%d.gfa" % native)), args=schemes.PickerArgs(**kw), native=native, preselect=False)
+        outs[native] = (open(fn).read(), sum(1 for n in G.seq_nodes() if G.aligned[n]), len(G.seq_nodes()))
+        if native:
+            info = idx.picker_info()
+            assert info["calls"] > 3
+    assert outs[True][1:] == outs[False][1:]
+    assert outs[True][0] == outs[False][0]
+    if names == ["1a", "1b"] and not kw:
+        assert outs[True][1] == 553      # BASELINE config 1's figure
+
+
+def test_native_picker_synthetic_five_way(tmp_path):
+    """five related genomes of 200 kbp: native picker == Python callbacks (anchors in sub-indices that lack samples, `segment`)"""
+    from reveal_amd import schemes
+    seqs = synth.genomes(200000, 5, seed=23, indelfrac=0.2)
+    files = []
+    for k, s in enumerate(seqs):
+        p = tmp_path / ("g%d.fa" % k)
+        p.write_text(">genome%d\n%s\n" % (k, s.decode()))
+        files.append(str(p))
+    texts = []
+    for native in (False, True):
+        G, idx, fn = rem.graph_rem(files, str(tmp_path / ("s%d.gfa" % native)), args=schemes.PickerArgs(), native=native, preselect=False)
+        texts.append(open(fn).read())
+    assert texts[0] == texts[1]

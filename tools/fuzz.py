@@ -39,6 +39,7 @@ ENVS = [
     {"RV_NO_TINY_SA": "1"},                               # texts of up to 2048 characters through the general build, too
     {"RV_FAR_TABLE": "1"},                                # the far round reads the next mark of a pair from the text-order table (k_far_nd) whatever the list's size
     {"RV_NO_FAR_TWINS": "1"},                             # ties beyond the text round: doubling rounds for partners, too (round 5)
+    {"RV_NO_SLOW_CLASS": "1"},                            # ... every tied entry through every doubling round
     {"RV_NO_LCP_LIST": "1", "RV_NO_TEXT_JUMP": "1"},      # ... and the whole index through rv_build_lcp after them
 ]
 

@@ -4,6 +4,7 @@ R=$PWD
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $OUT/prof -o x -- python $R/bench.py --class-one $2 --L $3 --no-check > $OUT/prof.log 2>&1
 cd $R
-python tools/rocpd_stats.py $(ls $OUT/prof/*/x_results.db $OUT/prof/x_results.db 2>/dev/null | head -1) > $OUT/kernel_stats.txt
+DB=$(ls $OUT/prof/*/x_results.db $OUT/prof/x_results.db 2>/dev/null | head -1)
+python tools/rocpd_stats.py $DB > $OUT/kernel_stats.txt
+python tools/rocpd_step.py $DB > $OUT/step.txt
 rm -rf $OUT/prof
-head -40 $OUT/kernel_stats.txt

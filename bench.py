@@ -407,6 +407,7 @@ def run_stream(args, rank, local_rank, world, dist, torch):
 
 
 CLASSES = ("snp0.1", "snp1", "snp5", "snp15", "indel", "repeats", "repeats_indel", "contigs50", "unrelated", "identical")
+MORE_CLASSES = ("repeats10", "tandem2", "snp25")      # beyond the table: 10 % of the base in repeat copies, 2 % in tandem arrays (homopolymers included), 25 % divergence
 
 
 def class_inputs(name, L, seed=42):
@@ -420,6 +421,10 @@ def class_inputs(name, L, seed=42):
         return synth.family(L, 2, seed=seed, repeats=0.02, nruns=max(3, L // 10_000_000))
     if name == "repeats_indel":
         return synth.family(L, 2, seed=seed, indelfrac=0.2, repeats=0.02, nruns=max(3, L // 10_000_000))
+    if name == "repeats10":
+        return synth.family(L, 2, seed=seed, repeats=0.10, nruns=max(3, L // 10_000_000))
+    if name == "tandem2":
+        return synth.family(L, 2, seed=seed, tandem=0.02)
     if name == "contigs50":
         return cut_into_contigs(synth.genomes(L, 2, seed=seed), 50)
     if name == "unrelated":
@@ -893,6 +898,21 @@ def main():
                     "properties": check.recursion_properties(iT0, iT1, ir["anchors"], insep, args.minl)["all"],
                     "golden": check.compare_with_golden(irec, anchors=ir["anchors"], T_final=iT1) if irec is not None else None}
                 del iidx, iseqs, iT0, iT1
+        if world == 1 and not args.no_extra and not divide and jobs == 1 and args.L * args.genomes >= 100_000_000:
+            # (3) north_star's target volume as a sustained stream: 20 inputs of this size (10 Gbp at the default workload) through `--config stream` in a
+            # process of its own -- host assembly, host->device copy, construct, recursion and result delivery of every input inside its timed region
+            try:
+                cmd = [sys.executable, os.path.abspath(__file__), "--config", "stream", "--pairs", "20", "--steps", "1", "--warmup", "1", "--no-check",
+                       "--L", str(args.L), "--genomes", str(args.genomes), "--minl", str(args.minl), "--minn", str(args.minn)] + (["--sa64"] if args.sa64 else [])
+                pr = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600)
+                sj = json.loads([x for x in pr.stdout.decode().splitlines() if x.startswith("{")][-1])
+                out["stream"] = {"value": sj["value"], "unit": "Mbp/s", "includes_upload": True, "inputs": sj["config"]["inputs_per_rank_and_step"], "Gbp": sj["Gbp_total"],
+                                 "wall_seconds": sj["wall_seconds"], "ms_per_input": sj["ms_per_input"], "in_flight_per_gpu": sj["config"]["in_flight_per_gpu"],
+                                 "host_thread_ms_per_input": sj["host_thread_ms_per_input"],
+                                 "what": "python bench.py --config stream --pairs 20: every input assembled from the caller's sequences, copied to HBM, constructed and "
+                                         "anchored inside the timed region, four inputs in flight (a handle, HIP stream and host thread each)"}
+            except Exception as e:      # noqa: BLE001  (a companion figure: its failure must not lose the line)
+                out["stream"] = {"failed": repr(e)[:300]}
         if world == 1 and not args.no_cpu:
             # CPU legs and bit-exact parity on a stated sample: 2 x 20 Mbp (or the workload itself when it is not larger)
             cl = min(args.L, CPU_SAMPLE_L)

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(TB) void k_cas_winner(const sa_t *__restrict__ c_pa
 // k_cas_dpick keeps the pairs that are each other's only longest partner.  A cut match inside D that the walk does not confirm (ell was not the length of C's
 // best match): C is looked at again in the next level with that match set aside (bids capped below it), up to sixteen times.
 constexpr u32 DWALK = 1024;
-struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u64 *ceil; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; uint8_t *dflag; };
+struct CasDanger { u64 *best; u32 *flag; sa_t *qb; u64 *ceil; u32 *m1, *p1, *m2; u64 *key; const uint8_t *T0; const lcp_t *LCP; const u64 *rank; u32 leaf_n; uint8_t *dflag; const uint8_t *wcls; };
 __device__ inline bool cas_is_danger(const CasIv &p, u64 bk, u32 wm, u32 minl, u32 leaf_n, u32 *theta) {
     const int64_t la = (int64_t)p.a1 - p.a0, lb = (int64_t)p.b1 - p.b0;
     const u32 bl = (u32)(bk >> KEY_SHIFT);
@@ -408,6 +408,7 @@ __global__ __launch_bounds__(TB) void k_cas_dwalk(const sa_t *__restrict__ w_pos
                                                   const CasIv *__restrict__ iv, const u64 *__restrict__ best, const u32 *__restrict__ wmax, u32 minl, CasDanger dg) {
     const u32 i = blockIdx.x * TB + threadIdx.x;
     if (i >= NW) return;
+    if (dg.wcls && dg.wcls[i]) return;          // (a witness of a medium block: k_cas_dwalk_blk walks it in LDS)
     const u32 c = w_child[i];
     if (c == NONE || !dg.dflag[c]) return;      // (m1 / key of such a witness are never read: k_cas_dpick and k_cas_dwrite leave through the same door)
     dg.m1[i] = 0; dg.key[i] = 0;
@@ -448,6 +449,99 @@ __global__ __launch_bounds__(TB) void k_cas_dwalk(const sa_t *__restrict__ w_pos
     }
     if (over) atomicOr(&dg.flag[c], 2u);
     dg.m1[i] = b1 >= theta ? b1 : 0u; dg.p1[i] = part; dg.m2[i] = b2;
+}
+// ---- the same walk, block by block in LDS -------------------------------------------------------------------------------------
+// The witnesses stand in the root's rank order; a walk only ever crosses consecutive ranks joined by LCP values of minl and more, so the list
+// falls into BLOCKS no walk leaves -- the suffixes that share a repeat's position: a few for a chance repeat, several hundred for a position of
+// a mobile element with hundreds of copies.  Membership in a block never changes; only the sub-index of a witness, theta and the interval ends do.
+// In global memory every step of every walk was five dependent reads (rank, LCP, sub-index, value, position): 2 x 10^7 witnesses x hundreds of
+// steps x 40 levels = 80 of the 172 ms a 2 x 250 Mbp pair with 2 % repeats took.  A medium block (BLK_MIN < size <= BLK_MAX) is staged once per level
+// by ONE workgroup -- sub-index, value, position, LCP with the rank in front -- and its members walk in LDS, step for step what k_cas_dwalk does
+// (the same breaks, the same two best partners, the same ties).  Small and large blocks keep the global walk.
+constexpr u32 BLK_MIN = 64, BLK_MAX = 1024;
+__global__ __launch_bounds__(TB) void k_cas_blk_flags(const u64 *__restrict__ rank, const lcp_t *__restrict__ LCP, u32 NW, u32 minl, u32 *__restrict__ flag) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= NW) return;
+    flag[i] = (i == 0 || rank[i] != rank[i - 1] + 1 || (u32)LCP[rank[i]] < minl) ? 1u : 0u;
+}
+// boff[b] = first witness of block b (bid = exclusive sum of the flags: the block of witness i is bid[i] + flag[i] - 1)
+__global__ __launch_bounds__(TB) void k_cas_blk_off(const u32 *__restrict__ flag, const u32 *__restrict__ bid, u32 NW, u32 nb, u32 *__restrict__ boff) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i == 0) boff[nb] = NW;
+    if (i < NW && flag[i]) boff[bid[i]] = i;
+}
+// medium blocks: a flag per block (for the list) and a byte per witness (for the global walk, which leaves them out)
+__global__ __launch_bounds__(TB) void k_cas_blk_class(const u32 *__restrict__ flag, const u32 *__restrict__ bid, const u32 *__restrict__ boff, u32 NW, u32 *__restrict__ mflag, uint8_t *__restrict__ wcls) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= NW) return;
+    const u32 b = bid[i] + flag[i] - 1u;
+    const u32 size = boff[b + 1] - boff[b];
+    const bool med = size > BLK_MIN && size <= BLK_MAX;
+    wcls[i] = med ? 1 : 0;
+    if (flag[i]) mflag[b] = med ? 1u : 0u;
+}
+__global__ __launch_bounds__(TB) void k_cas_blk_list(const u32 *__restrict__ mflag, const u32 *__restrict__ mid, u32 nb, u32 *__restrict__ mlist) {
+    const u32 b = blockIdx.x * TB + threadIdx.x;
+    if (b < nb && mflag[b]) mlist[mid[b]] = b;
+}
+__global__ __launch_bounds__(TB) void k_cas_dwalk_blk(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, const u32 *__restrict__ w_child, const u32 *__restrict__ boff,
+                                                      const u32 *__restrict__ mlist, u32 nmed, const CasIv *__restrict__ iv, const u64 *__restrict__ best, const u32 *__restrict__ wmax,
+                                                      u32 minl, CasDanger dg) {
+    // a workgroup per block (one wavefront per block left the members of a block of 900 fourteen walks each, one after the other, and the LDS of four
+    // blocks per workgroup kept the CUs at eight waves: 4.2 ms per level where the global walk took 1.4)
+    __shared__ u32 cc[BLK_MAX], vv[BLK_MAX], ll[BLK_MAX];
+    __shared__ sa_t pp[BLK_MAX];
+    __shared__ u32 s_any;
+    const u32 b = mlist[blockIdx.x];
+    const u32 s0 = boff[b], size = boff[b + 1] - s0;
+    if (threadIdx.x == 0) s_any = 0;
+    __syncthreads();
+    bool any = false;
+    for (u32 j = threadIdx.x; j < size; j += TB) {
+        const u32 c = w_child[s0 + j];
+        cc[j] = c;
+        any |= c != NONE && dg.dflag[c];
+    }
+    if (__ballot(any) && (threadIdx.x & 63) == 0) s_any = 1;
+    __syncthreads();
+    if (!s_any) return;      // nobody of this block sits in a sub-index the second attempt looks at
+    for (u32 j = threadIdx.x; j < size; j += TB) {
+        vv[j] = w_val[s0 + j]; pp[j] = w_pos[s0 + j];
+        ll[j] = (u32)dg.LCP[dg.rank[s0 + j]];      // common prefix with the rank in front
+    }
+    __syncthreads();
+    for (u32 j = threadIdx.x; j < size; j += TB) {
+        const u32 c = cc[j];
+        if (c == NONE || !dg.dflag[c]) continue;
+        const u32 i = s0 + j;
+        dg.m1[i] = 0; dg.key[i] = 0;
+        const CasIv p = iv[c];
+        u32 theta;
+        if (!cas_is_danger(p, best[c], wmax[c], minl, dg.leaf_n, &theta)) continue;
+        const int64_t pos = (int64_t)pp[j];
+        const int64_t cap = (pos < (int64_t)p.a1 ? (int64_t)p.a1 : (int64_t)p.b1) - pos;
+        if (vv[j] < theta || cap < (int64_t)theta) continue;
+        u32 b1 = 0, b2 = 0, part = NONE;
+#pragma unroll 1
+        for (int dir = -1; dir <= 1; dir += 2) {
+            u32 run = 0xFFFFFFFFu;
+            for (int64_t k = (int64_t)j + dir; k >= 0 && k < (int64_t)size; k += dir) {
+                const u32 g = ll[dir > 0 ? k : k + 1];
+                run = g < run ? g : run;
+                if (run < theta) break;
+                if (cc[k] != c || vv[k] < theta) continue;
+                const int64_t pk = (int64_t)pp[k];
+                const int64_t ck = (pk < (int64_t)p.a1 ? (int64_t)p.a1 : (int64_t)p.b1) - pk;
+                if (ck < (int64_t)theta) continue;
+                u32 l = (u32)(cap < ck ? cap : ck);
+                l = run < l ? run : l;
+                if (l > b1) { b2 = b1; b1 = l; part = s0 + (u32)k; }
+                else if (l > b2) b2 = l;
+                if (run <= b2) break;      // (what lies behind shares no more than this)
+            }
+        }
+        dg.m1[i] = b1 >= theta ? b1 : 0u; dg.p1[i] = part; dg.m2[i] = b2;
+    }
 }
 __global__ __launch_bounds__(TB) void k_cas_dpick(const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, const u32 *__restrict__ w_child, u32 NW,
                                                   const CasIv *__restrict__ iv, const CasRes *__restrict__ res, const u64 *__restrict__ best, const u32 *__restrict__ wmax,
@@ -1008,6 +1102,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     // the second attempt walks the witnesses in the root's rank order and keeps a few words per sub-index and per witness
     const sa_t *wp = bwp.as<sa_t>(); const u32 *wv = bwv.as<u32>();
     CasDanger dg; memset(&dg, 0, sizeof dg);
+    u32 dwalk_nmed = 0; const u32 *dwalk_boff = nullptr, *dwalk_mlist = nullptr;
     if (danger) {
         if (NW) {
             RV_TRY(k0.reserve((size_t)NW * 8)); RV_TRY(k1.reserve((size_t)NW * 8)); RV_TRY(v0.reserve((size_t)NW * 4)); RV_TRY(v1.reserve((size_t)NW * 4));
@@ -1028,6 +1123,33 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         dg.best = bdc.as<u64>(); dg.ceil = dg.best + ccap; dg.qb = (sa_t *)(dg.ceil + ccap); dg.flag = (u32 *)(dg.qb + ccap); dg.dflag = (uint8_t *)(dg.flag + ccap);
         dg.key = bdw.as<u64>(); dg.m1 = (u32 *)(dg.key + std::max<u32>(NW, 1)); dg.p1 = dg.m1 + std::max<u32>(NW, 1); dg.m2 = dg.p1 + std::max<u32>(NW, 1);
         dg.T0 = h->dT0.as<uint8_t>(); dg.LCP = LCP;
+        // the blocks of the witness list (k_cas_dwalk_blk): made once, the medium ones listed
+        if (NW && !ws.opt.no_dwalk_blocks) {
+            DBuf &bfl = cb.d[35], &bbid = cb.d[36], &bboff = cb.d[37], &bml = cb.d[38], &bwcls = cb.d[39];
+            RV_TRY(bfl.reserve((size_t)(NW + 1) * 4)); RV_TRY(bbid.reserve((size_t)(NW + 1) * 4)); RV_TRY(bwcls.reserve((size_t)NW + 16));
+            const unsigned wb = (unsigned)ceil_div((int64_t)NW, TB);
+            hipLaunchKernelGGL(k_cas_blk_flags, dim3(wb), dim3(TB), 0, q, dg.rank, LCP, NW, minl, bfl.as<u32>());
+            RV_LAUNCH_CHECK();
+            RV_HIP(hipMemsetAsync(bfl.as<u32>() + NW, 0, 4, q));
+            RV_TRY(rv_exclusive_sum_u32(ws, bfl.as<u32>(), bbid.as<u32>(), (int64_t)NW + 1));
+            u32 nb = 0;
+            RV_TRY(rv_read_back(ws, &nb, bbid.as<u32>() + NW, 4));
+            RV_TRY(bboff.reserve((size_t)(nb + 2) * 4)); RV_TRY(bml.reserve((size_t)(nb + 2) * 4 * 3));
+            u32 *mflag = bml.as<u32>(), *mid = mflag + (nb + 1), *mlist = mid + (nb + 1);
+            hipLaunchKernelGGL(k_cas_blk_off, dim3(wb), dim3(TB), 0, q, (const u32 *)bfl.as<u32>(), (const u32 *)bbid.as<u32>(), NW, nb, bboff.as<u32>());
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_cas_blk_class, dim3(wb), dim3(TB), 0, q, (const u32 *)bfl.as<u32>(), (const u32 *)bbid.as<u32>(), (const u32 *)bboff.as<u32>(), NW, mflag, bwcls.as<uint8_t>());
+            RV_LAUNCH_CHECK();
+            RV_HIP(hipMemsetAsync(mflag + nb, 0, 4, q));
+            RV_TRY(rv_exclusive_sum_u32(ws, mflag, mid, (int64_t)nb + 1));
+            RV_TRY(rv_read_back(ws, &dwalk_nmed, mid + nb, 4));
+            if (dwalk_nmed) {
+                hipLaunchKernelGGL(k_cas_blk_list, dim3((unsigned)ceil_div((int64_t)nb, TB)), dim3(TB), 0, q, (const u32 *)mflag, (const u32 *)mid, nb, mlist);
+                RV_LAUNCH_CHECK();
+                dg.wcls = bwcls.as<uint8_t>();
+                dwalk_boff = bboff.as<u32>(); dwalk_mlist = mlist;
+            }
+        }
         // every undecided sub-index this way, not only the ones the leaf kernel cannot take: the walk costs less than rebuilding a sub-index that
         // sits inside a repeat (RV_CASCADE_DANGER_MIN: only sub-indices above that size)
         dg.leaf_n = (u32)ws.opt.cascade_danger_min;
@@ -1081,6 +1203,11 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
                 hipLaunchKernelGGL(k_cas_dwalk, dim3(wb), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const u64 *)bbest.as<u64>(),
                                    (const u32 *)bwm.as<u32>(), minl, dg);
                 RV_LAUNCH_CHECK();
+                if (dwalk_nmed) {
+                    hipLaunchKernelGGL(k_cas_dwalk_blk, dim3((unsigned)dwalk_nmed), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), dwalk_boff, dwalk_mlist, dwalk_nmed,
+                                       (const CasIv *)biv.as<CasIv>(), (const u64 *)bbest.as<u64>(), (const u32 *)bwm.as<u32>(), minl, dg);
+                    RV_LAUNCH_CHECK();
+                }
                 hipLaunchKernelGGL(k_cas_dpick, dim3(wb), dim3(TB), 0, q, wp, wv, (const u32 *)bwc.as<u32>(), NW, (const CasIv *)biv.as<CasIv>(), (const CasRes *)bres.as<CasRes>(),
                                    (const u64 *)bbest.as<u64>(), (const u32 *)bwm.as<u32>(), minl, dg);
                 RV_LAUNCH_CHECK();

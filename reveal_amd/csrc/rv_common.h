@@ -85,6 +85,7 @@ void rv_set_error(const char *fmt, ...);
     X(no_text_jump, "RV_NO_TEXT_JUMP", 0) \
     X(far_table, "RV_FAR_TABLE", 0) \
     X(no_slow_class, "RV_NO_SLOW_CLASS", 0) \
+    X(no_dwalk_blocks, "RV_NO_DWALK_BLOCKS", 0) \
     X(no_pub_twins, "RV_NO_PUB_TWINS", 0) \
     X(sa_no_text, "RV_SA_NO_TEXT", 0) \
     X(text_mode, "RV_TEXT_MODE", -1) \

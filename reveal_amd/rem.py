@@ -161,7 +161,11 @@ class GraphAligner:
             newright = index.rightnode
         if any(not set(G.offsets[iv]) <= msamples for iv in trailing):
             newleft = index.leftnode
-        return leading, trailing, matching, rest, mn, newleft, newright
+        # (matching as a list in ascending order: the index walks it when it shortens the leading child's suffixes at the cuts, reveal.c:673-674, and the
+        #  order of equal truncated suffixes -- with it the order a later match's members are emitted in, which trim_overlap's coordinate-wise cuts
+        #  look at -- follows that walk.  The reference hands over a set, i.e. its hash order: any fixed order is as good; this one is the library's
+        #  own (rv_set_picker), so the two ways of running the picker give the same graph.)
+        return leading, trailing, sorted(matching), rest, mn, newleft, newright
 
 
 class _ReplaySub:

@@ -95,8 +95,9 @@ def variant_codes_indel(base, k, seed=42, rate=0.01, indelfrac=0.2, zipfd=1.7, m
     return res
 
 
-def overlay_repeats(base, seed=42, repeats=0.02):
-    """interspersed repeat families and tandem arrays written over the base's codes (in place) -> base"""
+def overlay_repeats(base, seed=42, repeats=0.02, tandem=None):
+    """interspersed repeat families and tandem arrays written over the base's codes (in place) -> base
+    tandem: fraction of the base in tandem arrays (None: one array per 2 Mbp, the default family's ~0.4 %)"""
     L = len(base)
     rng = np.random.Generator(np.random.PCG64(seed + 1000003))
     nfam = 12
@@ -121,13 +122,20 @@ def overlay_repeats(base, seed=42, repeats=0.02):
         at = int(rng.integers(0, L - len(c)))
         base[at:at + len(c)] = c
         budget -= len(c)
-    for _ in range(max(2, L // 2_000_000)):                      # tandem arrays
-        unit = rng.integers(0, 4, size=int(rng.integers(2, 61)), dtype=np.uint8)
+    narr, tbudget = max(2, L // 2_000_000), None
+    if tandem is not None:
+        narr, tbudget = 1 << 60, int(L * tandem)
+    k = 0
+    while k < narr and (tbudget is None or tbudget > 0):         # tandem arrays
+        k += 1
+        unit = rng.integers(0, 4, size=int(rng.integers(2 if tandem is None else 1, 61)), dtype=np.uint8)
         arr = np.tile(unit, int(rng.integers(10, 301)))
         if len(arr) >= L:
             continue
         at = int(rng.integers(0, L - len(arr)))
         base[at:at + len(arr)] = arr
+        if tbudget is not None:
+            tbudget -= len(arr)
     return base
 
 
@@ -151,12 +159,12 @@ def _spell(codes, runs):
     return out.tobytes()
 
 
-def family(L, count, seed=42, snp=0.01, indelfrac=0.0, repeats=0.0, nruns=0):
+def family(L, count, seed=42, snp=0.01, indelfrac=0.0, repeats=0.0, nruns=0, tandem=None):
     """genomes() with the unfriendly knobs: `repeats` (fraction of the base covered by interspersed repeat copies; tandem arrays
     come with it) and `nruns` (runs of N, the same text positions in every member).  repeats = 0 and nruns = 0: genomes()."""
     base = base_codes(L, seed)
-    if repeats > 0:
-        overlay_repeats(base, seed, repeats)
+    if repeats > 0 or tandem:
+        overlay_repeats(base, seed, repeats, tandem)
     runs = n_runs(L, seed, nruns)
     out = [_spell(base, runs)]
     for k in range(1, count):

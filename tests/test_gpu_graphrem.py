@@ -67,11 +67,28 @@ def test_config5_all_three_levels(tmp_path):
     assert d["levels"]["0"]["jobs"] == 20 and d["levels"]["1"]["jobs"] == 4 and d["levels"]["2"]["jobs"] == 1
 
 
+def _canonical_gfa(text):
+    """a GFA file up to the numbering of its segments: the multiset of segment sequences, the links as pairs of sequences, every path as the list of
+    the sequences it walks.  (Which of its members' intervals stands for a merged node -- and with it the node's number -- follows the order
+    graphalign is handed the members in, and the order of equal truncated suffixes at a cut follows the iteration order of the Python set
+    `matching`, reveal.c:673-674: neither is part of the alignment.)"""
+    seg, links, paths = {}, [], {}
+    for line in text.splitlines():
+        f = line.split("\t")
+        if f[0] == "S":
+            seg[f[1]] = f[2]
+        elif f[0] == "L":
+            links.append((f[1], f[2], f[3], f[4]))
+        elif f[0] == "P":
+            paths[f[1]] = [(x[:-1], x[-1]) for x in f[2].split(",")] if f[2] else []
+    return (sorted(seg.values()), sorted((seg[a], sa, seg[b], sb) for a, sa, b, sb in links), {k: [(seg[n], o) for n, o in v] for k, v in paths.items()})
+
+
 @pytest.mark.parametrize("names,kw", [(["1a", "1b"], {}), (["1a", "1b", "1c"], {}), (["1a", "1b"], {"trim": False}), (["1a", "1c", "1d"], {"seedsize": 300, "maxmums": 50}),
                                       (["1a", "1b"], {"seedsize": 200, "wpen": 3, "gcmodel": "star-avg"}), (["d1", "d2"], {}), (["2a", "2b"], {})])
 def test_native_picker_writes_the_same_gfa(tmp_path, names, kw):
     """`reveal rem` with its default picker inside the library (rv_set_picker / rv_pick_chain, no Python call per sub-index; the graph replayed
-    from the anchors) against the same run through the two Python callbacks: the same GFA file, byte for byte"""
+    from the anchors) against the same run through the two Python callbacks: the same file byte for byte"""
     from reveal_amd import schemes
     files = C.fasta_files(tmp_path, names)
     outs = {}
@@ -82,9 +99,12 @@ def test_native_picker_writes_the_same_gfa(tmp_path, names, kw):
             info = idx.picker_info()
             assert info["calls"] > 3
     assert outs[True][1:] == outs[False][1:]
+    assert _canonical_gfa(outs[True][0]) == _canonical_gfa(outs[False][0])
     assert outs[True][0] == outs[False][0]
     if names == ["1a", "1b"] and not kw:
         assert outs[True][1] == 553      # BASELINE config 1's figure
+    spelled, _ = C.spelled_by_file(str(tmp_path / "n1.gfa"))
+    assert spelled == C.input_sequences(files)
 
 
 def test_native_picker_synthetic_five_way(tmp_path):
@@ -100,4 +120,5 @@ def test_native_picker_synthetic_five_way(tmp_path):
     for native in (False, True):
         G, idx, fn = rem.graph_rem(files, str(tmp_path / ("s%d.gfa" % native)), args=schemes.PickerArgs(), native=native, preselect=False)
         texts.append(open(fn).read())
+    assert _canonical_gfa(texts[0]) == _canonical_gfa(texts[1])
     assert texts[0] == texts[1]

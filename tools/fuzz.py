@@ -33,6 +33,7 @@ ENVS = [
     {"RV_CASM_RANK_COUNT": "1"},                          # more than two samples: undecided sub-indices ranked by counting instead of sorting (k_casm_rank)
     {"RV_CASCADE_DANGER": "2"},                           # every undecided sub-index decided from its witnesses where they can be (k_cas_dwalk)
     {"RV_CASCADE_DANGER": "2", "RV_CASCADE_DANGER_MIN": "300", "RV_CASCADE_SECOND_OFF": "1"},
+    {"RV_CASCADE_DANGER": "2", "RV_NO_DWALK_BLOCKS": "1"},   # ... every witness walks in global memory (no blocks in LDS)
     {"RV_NO_TWIN_COLLAPSE": "1"},                         # every suffix of the second sample through the radix sort
     {"RV_DIAG_TABLE": "1"},                               # two samples: hint and twins along piecewise diagonals from seeds, whatever the input
     {"RV_NO_SHORT_ALPHABET": "1"},                        # a digit value of its own for "past the end"

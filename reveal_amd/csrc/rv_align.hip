@@ -153,7 +153,7 @@ struct Align {
         }
     };
     std::vector<SeedList> seeds_cur, seeds_lead, seeds_trail;
-    int64_t picker_calls = 0, picker_seeded = 0;
+    int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0;
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
     int64_t presel_d2h = 0;            // records the scans of this alignment copied to the host while pre-selection was on (RV_PRESEL_LOG)
@@ -413,6 +413,7 @@ int rv_set_picker(rv_index *h, int kind, const rv_picker_args *args) {
 int rv_picker_info(const rv_index *h, int64_t *out) {
     if (!h || !out) return -1;
     out[0] = h->al ? h->al->picker : 0; out[1] = h->al ? h->al->picker_calls : 0; out[2] = h->al ? h->al->picker_seeded : 0;
+    out[3] = h->al ? h->al->picker_ns : 0; out[4] = h->al ? h->al->picker_list_ns : 0;
     return 0;
 }
 int rv_set_preselect(rv_index *h, int64_t maxmums) {
@@ -1542,7 +1543,7 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     Align *a = h->al;
     a->full_only = !a->trace_on && a->picker == 0;      // (the chain picker looks at every match of a sub-index: the scans hand their whole lists to the host)
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
-    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear(); a->picker_calls = a->picker_seeded = 0;
+    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear(); a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = 0;
     if (a->picker == 1) {
         if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
         if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
@@ -1702,6 +1703,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     chain_pick = true;
                 } else if (cnt > 0) {
                     // the list as rv_sub_mums hands it out
+                    const double tp0 = now_s();
                     pk_l.clear(); pk_n.clear(); pk_off.assign(1, 0); pk_mso.clear(); pk_mpos.clear();
                     if (!a->multi) {
                         for (int64_t k = first; k < first + cnt; k++) {
@@ -1733,8 +1735,10 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     po.seed_cap = (int64_t)scap; po.seed_member_cap = (int64_t)std::max<size_t>(mcap, 1);
                     po.seed_l = pk_sl.data(); po.seed_n = pk_sn.data(); po.seed_off = pk_soff.data(); po.seed_so = pk_sso.data(); po.seed_pos = pk_spos.data();
                     po.seed_score = pk_ssc.data(); po.seed_right = pk_srt.data();
+                    const double tp1 = now_s();
                     const int pr = rv_pick_chain(&a->pargs, want, (int64_t)pk_l.size(), pk_l.data(), pk_n.data(), pk_off.data(), pk_mso.data(), pk_mpos.data(), W,
                                                  pk_sb.data(), pk_ib.data(), pk_ie.data(), a->minl, &po);
+                    a->picker_ns += (int64_t)((now_s() - tp1) * 1e9); a->picker_list_ns += (int64_t)((tp1 - tp0) * 1e9);
                     if (pr < 0) return -1;
                     if (pr == 1) {
                         bl = po.pick_l; members = po.pick_members; chain_pick = true;

@@ -57,21 +57,42 @@ extern "C" int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t
     std::vector<int64_t> order((size_t)m + 1);
     for (int64_t i = 0; i <= m; i++) order[(size_t)i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return C(a, 0) < C(b, 0); });      // schemes.py:30
-    std::unordered_map<int64_t, int64_t> sp2mum, link, score;   // all keyed by the coordinate on the first path, as in the reference
-    for (int64_t e : order) sp2mum[C(e, 0)] = e;                // schemes.py:32-34 (a later equal coordinate replaces the earlier)
-    score[left[0]] = 0;
+    // The reference keys three dictionaries by the coordinate on the first path (sp2mum, link, score: two matches that start at the same place on
+    // that path share an entry, the later one replaces the earlier).  Same semantics on arrays: every distinct coordinate gets a slot once.  (As hash
+    // maps looked at inside the sort's comparator they were most of a call: 1000 matches = 100 ms, 10.5 of the 11 s five 5 Mbp genomes spent in the
+    // library with the native picker.)
+    std::vector<int64_t> cs((size_t)m + 2);
+    for (int64_t e = 0; e <= m + 1; e++) cs[(size_t)e] = C(e, 0);
+    std::vector<int64_t> uniq(cs);
+    std::sort(uniq.begin(), uniq.end());
+    uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+    std::vector<int32_t> slot((size_t)m + 2);
+    for (int64_t e = 0; e <= m + 1; e++) slot[(size_t)e] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), cs[(size_t)e]) - uniq.begin());
+    const size_t ns = uniq.size();
+    std::vector<int64_t> sp2mum(ns, -1), score(ns, 0);
+    std::vector<int32_t> link(ns, -1);
+    for (int64_t e : order) sp2mum[(size_t)slot[(size_t)e]] = e;                // schemes.py:32-34 (a later equal coordinate replaces the earlier)
+    score[(size_t)slot[(size_t)L]] = 0;
     std::vector<int64_t> active{L}, processed, keep, D;
     std::vector<int64_t> ea((size_t)k), sb((size_t)k);
     int64_t best = -1;
     auto ends_before = [&](int64_t a, int64_t b) -> bool {      // a ends at or in front of b's start on every path (schemes.py:49-51, 63-65)
-        for (int j = 0; j < k; j++) if (C(a, j) + LEN(a) > C(b, j)) return false;
+        const int64_t la = LEN(a);
+        for (int j = 0; j < k; j++) if (C(a, j) + la > C(b, j)) return false;
         return true;
     };
+    auto by_score = [&](int64_t a, int64_t b) { return score[(size_t)slot[(size_t)a]] > score[(size_t)slot[(size_t)b]]; };
     for (int64_t e : order) {
         keep.clear();
+        const size_t old = active.size();
         for (int64_t p : processed) { if (ends_before(p, e)) active.push_back(p); else keep.push_back(p); }      // schemes.py:47-57
         processed.swap(keep);
-        std::stable_sort(active.begin(), active.end(), [&](int64_t a, int64_t b) { return score[C(a, 0)] > score[C(b, 0)]; });      // :59
+        // schemes.py:59: the list stably sorted by score.  What was there is in that order already unless a match that shares its first coordinate with an
+        // earlier one has replaced that one's score: then (checked) the whole list is sorted, otherwise the newcomers are, and merged in -- the same list
+        if (std::is_sorted(active.begin(), active.begin() + (ptrdiff_t)old, by_score)) {
+            std::stable_sort(active.begin() + (ptrdiff_t)old, active.end(), by_score);
+            std::inplace_merge(active.begin(), active.begin() + (ptrdiff_t)old, active.end(), by_score);
+        } else std::stable_sort(active.begin(), active.end(), by_score);
         bool have = false;
         int64_t w = 0;
         const int64_t n = e >= m ? 0 : (int64_t)nmem[e];
@@ -79,27 +100,27 @@ extern "C" int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t
         for (int j = 0; j < k; j++) sb[(size_t)j] = C(e, j);
         for (int64_t a : active) {
             if (!ends_before(a, e)) continue;
-            const int64_t s = score[C(a, 0)] + gain;
-            if (have && w > s) break;                           // sorted by score: nothing better can follow (schemes.py:70-72)
-            for (int j = 0; j < k; j++) ea[(size_t)j] = C(a, j) + LEN(a);
-            const int64_t tmpw = s - wpen * gapcost(ea.data(), sb.data(), k, model, D);
+            const int64_t sc = score[(size_t)slot[(size_t)a]] + gain;
+            if (have && w > sc) break;                           // sorted by score: nothing better can follow (schemes.py:70-72)
+            const int64_t la = LEN(a);
+            for (int j = 0; j < k; j++) ea[(size_t)j] = C(a, j) + la;
+            const int64_t tmpw = sc - wpen * gapcost(ea.data(), sb.data(), k, model, D);
             if (!have || tmpw > w) { w = tmpw; best = a; have = true; }
         }
         if (best < 0 || !have) { rv_set_error("rv_chain: a match has no predecessor (it does not lie behind `left` on every path)"); return -1; }
-        link[C(e, 0)] = C(best, 0);
-        score[C(e, 0)] = w;
+        link[(size_t)slot[(size_t)e]] = slot[(size_t)best];
+        score[(size_t)slot[(size_t)e]] = w;
         processed.push_back(e);
     }
     // backtrack from `right` (schemes.py:97-103); the chain is handed out left to right, `right` itself left out
     std::vector<std::pair<int64_t, int64_t>> path;
-    int64_t end = right[0];
-    const int64_t start = left[0];
+    int32_t end = slot[(size_t)R];
+    const int32_t start = slot[(size_t)L];
     int64_t guard = 0;
     while (end != start) {
-        auto it = sp2mum.find(end);
-        if (it == sp2mum.end() || ++guard > m + 2) { rv_set_error("rv_chain: broken back-pointer chain"); return -1; }
-        path.push_back({it->second, score[end]});
-        end = link[end];
+        if (end < 0 || sp2mum[(size_t)end] < 0 || ++guard > m + 2) { rv_set_error("rv_chain: broken back-pointer chain"); return -1; }
+        path.push_back({sp2mum[(size_t)end], score[(size_t)end]});
+        end = link[(size_t)end];
     }
     int64_t cnt = 0;
     for (size_t q = path.size(); q-- > 1;) {                    // path[0] is `right`
@@ -116,41 +137,45 @@ extern "C" int64_t rv_chain(int64_t m, int k, const uint32_t *len, const int32_t
 // list filter of trim_overlap that looks at the LAST element for the first (Python's index -1), the dictionary keyed by the offsets that lets a
 // later match replace an earlier one, the chain's tie rules (rv_chain), "the largest of the chain" = the last of equal lengths.
 namespace {
-struct PkMum { int64_t l; int32_t n; std::vector<uint16_t> so; std::vector<int64_t> pos; };
+// a match of the list: its length after trimming, how far trimming moved its members (the same distance on every path), and where its
+// members stand in the caller's arrays -- the members themselves are never copied (a list of 1.5 x 10^6 five-way matches as vectors of vectors
+// made the root's call 6 s of a 5 x 5 Mbp job's 13.8 s in the picker)
+struct PkItem { int64_t l, shift; int64_t off; int32_t n, nm; };
 
-// schemes.py:160-193; -> false: the reference's own code would raise here (trimmed[-1] of an empty list)
-bool pk_trim_overlap(std::vector<PkMum> &mums) {
+struct PkCtx {
+    const uint16_t *so; const int64_t *pos;
+    int64_t at(const PkItem &m, size_t c) const { return pos[m.off + (int64_t)c] + m.shift; }
+};
+
+// schemes.py:160-193; -> false: the reference's own code would raise here (trimmed[-1] of an empty list, or a match with fewer members than the first)
+bool pk_trim_overlap(std::vector<PkItem> &mums, const PkCtx &X) {
     if (mums.empty()) return true;
-    const size_t ncoord = mums[0].pos.size();
+    const size_t ncoord = (size_t)mums[0].nm;
+    std::vector<PkItem> kept, trimmed;
     for (size_t c = 0; c < ncoord; c++) {
         if (mums.size() <= 1) break;
-        for (const PkMum &m : mums) if (m.pos.size() <= c) return false;      // (a match with fewer members than the first: IndexError there)
-        std::stable_sort(mums.begin(), mums.end(), [c](const PkMum &a, const PkMum &b) { return a.pos[c] != b.pos[c] ? a.pos[c] < b.pos[c] : a.l > b.l; });
-        auto end = [c](const PkMum &m) { return m.pos[c] + m.l; };
-        std::vector<PkMum> kept;
+        for (const PkItem &m : mums) if ((size_t)m.nm <= c) return false;
+        std::stable_sort(mums.begin(), mums.end(), [&](const PkItem &a, const PkItem &b) { const int64_t pa = X.at(a, c), pb = X.at(b, c); return pa != pb ? pa < pb : a.l > b.l; });
+        auto end = [&](const PkItem &m) { return X.at(m, c) + m.l; };
+        kept.clear();
         const size_t cnt = mums.size();
         for (size_t i = 0; i < cnt; i++) {
-            const PkMum &mm = mums[i];
-            const PkMum &prev = mums[i == 0 ? cnt - 1 : i - 1];      // (i - 1 == -1: the last one)
+            const PkItem &mm = mums[i];
+            const PkItem &prev = mums[i == 0 ? cnt - 1 : i - 1];      // (i - 1 == -1: the last one)
             if ((i == 0 && end(mums[1]) > end(mm)) || end(prev) < end(mm)) kept.push_back(mm);
         }
         mums.swap(kept);
         if (mums.size() <= 1) break;
-        std::vector<PkMum> trimmed;
+        trimmed.clear();
         trimmed.push_back(mums[0]);
         for (size_t i = 1; i < mums.size(); i++) {
             if (trimmed.empty()) return false;
-            const PkMum &mum = mums[i];
-            PkMum &pm = trimmed.back();
-            const int64_t overlap = end(pm) - mum.pos[c];
+            const PkItem &mum = mums[i];
+            PkItem &pm = trimmed.back();
+            const int64_t overlap = end(pm) - X.at(mum, c);
             if (overlap > 0) {
                 if (pm.l - overlap > 0) pm.l -= overlap; else trimmed.pop_back();
-                if (mum.l - overlap > 0) {
-                    PkMum t = mum;
-                    t.l -= overlap;
-                    for (int64_t &p : t.pos) p += overlap;
-                    trimmed.push_back(std::move(t));
-                }
+                if (mum.l - overlap > 0) { PkItem t = mum; t.l -= overlap; t.shift += overlap; trimmed.push_back(t); }
             } else trimmed.push_back(mum);
         }
         mums.swap(trimmed);
@@ -165,79 +190,80 @@ extern "C" int rv_pick_chain(const rv_picker_args *A, int nsub, int64_t m, const
     if (!A || !O || m < 0 || nsamples < 1) { rv_set_error("rv_pick_chain: bad arguments"); return -1; }
     O->picked = 0; O->nleft = O->nright = 0; O->nseed_members = 0;
     if (m == 0) return 0;
-    std::vector<PkMum> all((size_t)m);
-    for (int64_t i = 0; i < m; i++) {
-        PkMum &x = all[(size_t)i];
-        x.l = l[i]; x.n = n[i];
-        x.so.assign(so + off[i], so + off[i + 1]); x.pos.assign(pos + off[i], pos + off[i + 1]);
-    }
+    const PkCtx X{so, pos};
+    auto item = [&](int64_t i) { PkItem x; x.l = l[i]; x.shift = 0; x.off = off[i]; x.n = n[i]; x.nm = (int32_t)(off[i + 1] - off[i]); return x; };
+    // the sample set of a match: a bit mask (more than 64 samples: the sorted ids)
+    const bool wide = nsamples > 64;
+    auto mask_of = [&](const PkItem &x) { uint64_t k = 0; for (int q = 0; q < x.nm; q++) k |= 1ull << (so[x.off + q] & 63); return k; };
+    auto ids_of = [&](const PkItem &x) { std::vector<uint16_t> k(so + x.off, so + x.off + x.nm); std::sort(k.begin(), k.end()); return k; };
+    auto same_set = [&](const PkItem &a, const PkItem &b) { return a.nm == b.nm && (wide ? ids_of(a) == ids_of(b) : mask_of(a) == mask_of(b)); };
+    for (int64_t i = 0; i < m; i++)
+        for (int64_t q = off[i]; q < off[i + 1]; q++) if (so[q] >= nsamples) { rv_set_error("rv_pick_chain: sample id out of range"); return -1; }
     // schemes.py:227-233: the matches in every sample of the sub-index; none and more than two samples: the best sample subset (`segment`, :107-126)
-    std::vector<PkMum> mm;
-    for (const PkMum &x : all) if (x.n == nsub) mm.push_back(x);
+    std::vector<PkItem> mm;
+    for (int64_t i = 0; i < m; i++) if (n[i] == nsub) mm.push_back(item(i));
     if (mm.empty() && nsub > 2) {
-        std::vector<std::vector<uint16_t>> keys; std::vector<std::vector<size_t>> members;
-        for (size_t i = 0; i < all.size(); i++) {
-            std::vector<uint16_t> k = all[i].so;
-            std::sort(k.begin(), k.end());
+        std::vector<PkItem> reps; std::vector<int64_t> zsum; std::vector<int32_t> grp((size_t)m);
+        for (int64_t i = 0; i < m; i++) {
+            const PkItem x = item(i);
             size_t g = 0;
-            for (; g < keys.size(); g++) if (keys[g] == k) break;
-            if (g == keys.size()) { keys.push_back(k); members.emplace_back(); }
-            members[g].push_back(i);
+            for (; g < reps.size(); g++) if (same_set(reps[g], x)) break;
+            if (g == reps.size()) { reps.push_back(x); zsum.push_back(0); }
+            zsum[g] += x.l; grp[(size_t)i] = (int32_t)g;
         }
         int64_t best = 0; size_t part = (size_t)-1;
-        for (size_t g = 0; g < keys.size(); g++) {
-            int64_t z = 0;
-            for (size_t i : members[g]) z += all[i].l;
-            z *= (int64_t)keys[g].size();
-            if (z > best) { best = z; part = g; }
-        }
+        for (size_t g = 0; g < reps.size(); g++) { const int64_t z = zsum[g] * reps[g].nm; if (z > best) { best = z; part = g; } }
         if (part == (size_t)-1) { rv_set_error("rv_pick_chain: no sample subset (the reference raises KeyError here)"); return -2; }
-        for (size_t i : members[part]) mm.push_back(all[i]);
+        for (int64_t i = 0; i < m; i++) if (grp[(size_t)i] == (int32_t)part) mm.push_back(item(i));
     }
     if (A->trim) {
-        if (!mm.empty() && !pk_trim_overlap(mm)) { rv_set_error("rv_pick_chain: trim_overlap ran out of matches (the reference raises IndexError here)"); return -2; }
+        if (!mm.empty() && !pk_trim_overlap(mm, X)) { rv_set_error("rv_pick_chain: trim_overlap ran out of matches (the reference raises IndexError here)"); return -2; }
         if (mm.empty()) return 0;
     }
     if (mm.empty()) return 0;
-    std::stable_sort(mm.begin(), mm.end(), [](const PkMum &a, const PkMum &b) { return a.l > b.l; });      // :240 (reverse=True keeps equal lengths in order)
-    // maptooffsets (:150-158): rel[i] = offsets per path in member order; `mapping` keyed by the offsets, a later equal key replaces the earlier
+    std::stable_sort(mm.begin(), mm.end(), [](const PkItem &a, const PkItem &b) { return a.l > b.l; });      // :240 (reverse=True keeps equal lengths in order)
+    // maptooffsets (:150-158): a match's offsets per path in member order; `mapping` is keyed by them, a later equal key replaces the earlier
     const size_t cnt = mm.size();
-    std::vector<std::vector<int64_t>> rel(cnt);
-    for (size_t i = 0; i < cnt; i++) {
-        rel[i].resize(mm[i].pos.size());
-        for (size_t j = 0; j < mm[i].pos.size(); j++) {
-            const int s = mm[i].so[j];
-            if (s >= nsamples) { rv_set_error("rv_pick_chain: sample id out of range"); return -1; }
-            rel[i][j] = mm[i].pos[j] - seq_begin[s];
+    auto rel = [&](size_t i, int q) { return X.at(mm[i], (size_t)q) - seq_begin[so[mm[i].off + q]]; };
+    auto same_rel = [&](size_t a, size_t b) {
+        if (mm[a].nm != mm[b].nm) return false;
+        for (int q = 0; q < mm[a].nm; q++) if (rel(a, q) != rel(b, q)) return false;
+        return true;
+    };
+    // mapping[tuple(rel.values())]: the LAST match with these offsets.  One look-up walks the list; the seeds of a long chain over a long list
+    // (1000 x 1.5 x 10^6 at the root of five 5 Mbp genomes) go through a table of the offsets' hashes made once
+    std::unordered_map<uint64_t, uint32_t> last_by_hash;
+    auto rel_hash = [&](size_t i) { uint64_t hsh = 0x9E3779B97F4A7C15ull ^ (uint64_t)mm[i].nm; for (int q = 0; q < mm[i].nm; q++) { hsh ^= (uint64_t)rel(i, q) + 0x9E3779B97F4A7C15ull + (hsh << 6) + (hsh >> 2); } return hsh; };
+    auto mapped = [&](size_t i) -> size_t {
+        if (!last_by_hash.empty()) {
+            const auto it = last_by_hash.find(rel_hash(i));
+            if (it != last_by_hash.end() && same_rel(it->second, i)) return it->second;      // (two different offset tuples under one hash: the walk)
         }
-    }
-    auto mapped = [&](size_t i) -> size_t {      // mapping[tuple(rel.values())]: the LAST match with these offsets
         size_t r = i;
-        for (size_t j = i + 1; j < cnt; j++) if (rel[j] == rel[i]) r = j;
+        for (size_t j = i + 1; j < cnt; j++) if (same_rel(j, i)) r = j;
         return r;
     };
-    std::vector<size_t> ord(cnt);
-    for (size_t i = 0; i < cnt; i++) ord[i] = i;
-    std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {      // :247 key (n, l); n = paths of the members' nodes = members
-        const size_t na = mm[a].pos.size(), nb = mm[b].pos.size();
-        return na != nb ? na < nb : mm[a].l < mm[b].l;
+    std::vector<uint32_t> ord(cnt);
+    for (size_t i = 0; i < cnt; i++) ord[i] = (uint32_t)i;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t a, uint32_t b) {      // :247 key (n, l); n = paths of the members' nodes = members
+        return mm[a].nm != mm[b].nm ? mm[a].nm < mm[b].nm : mm[a].l < mm[b].l;
     });
-    auto keyset = [&](size_t i) { std::vector<uint16_t> k = mm[i].so; std::sort(k.begin(), k.end()); return k; };
-    const std::vector<uint16_t> last = keyset(ord.back());
-    std::vector<size_t> relm;
-    for (size_t i : ord) if (keyset(i) == last) relm.push_back(i);
+    const PkItem lastm = mm[ord.back()];
+    std::vector<uint32_t> relm;
+    for (uint32_t i : ord) if (same_set(mm[i], lastm)) relm.push_back(i);
     if (relm.empty()) return 0;
     // the chain's sentinels over the paths of the last match, in ascending path id (schemes.chain sorts the keys)
+    const std::vector<uint16_t> last = ids_of(lastm);
     const int k = (int)last.size();
     std::vector<int64_t> lf((size_t)k), rt((size_t)k);
     for (int j = 0; j < k; j++) {
-        const int s = last[(size_t)j];
-        if (iv_begin[s] < 0) { rv_set_error("rv_pick_chain: a match in a sample the sub-index does not hold"); return -1; }
-        lf[(size_t)j] = iv_begin[s] - 1 - seq_begin[s];
-        rt[(size_t)j] = iv_end[s] - seq_begin[s];
+        const int s2 = last[(size_t)j];
+        if (iv_begin[s2] < 0) { rv_set_error("rv_pick_chain: a match in a sample the sub-index does not hold"); return -1; }
+        lf[(size_t)j] = iv_begin[s2] - 1 - seq_begin[s2];
+        rt[(size_t)j] = iv_end[s2] - seq_begin[s2];
     }
     auto coord = [&](size_t i, int j) -> int64_t {      // offset of match i on path last[j]
-        for (size_t q = 0; q < mm[i].so.size(); q++) if (mm[i].so[q] == last[(size_t)j]) return rel[i][q];
+        for (int q = 0; q < mm[i].nm; q++) if (so[mm[i].off + q] == last[(size_t)j]) return rel(i, q);
         return 0;
     };
     size_t split;
@@ -248,7 +274,7 @@ extern "C" int rv_pick_chain(const rv_picker_args *A, int nsub, int64_t m, const
         const int64_t mc = (int64_t)relm.size();
         std::vector<uint32_t> cl((size_t)mc); std::vector<int32_t> cn((size_t)mc); std::vector<int64_t> crd((size_t)mc * k), oi((size_t)mc), osc((size_t)mc);
         for (int64_t i = 0; i < mc; i++) {
-            cl[(size_t)i] = (uint32_t)mm[relm[(size_t)i]].l; cn[(size_t)i] = (int32_t)mm[relm[(size_t)i]].pos.size();
+            cl[(size_t)i] = (uint32_t)mm[relm[(size_t)i]].l; cn[(size_t)i] = mm[relm[(size_t)i]].nm;
             for (int j = 0; j < k; j++) crd[(size_t)i * k + j] = coord(relm[(size_t)i], j);
         }
         const int64_t r = rv_chain(mc, k, cl.data(), cn.data(), crd.data(), lf.data(), rt.data(), A->wscore, A->wpen, A->gcmodel, oi.data(), osc.data());
@@ -263,6 +289,7 @@ extern "C" int rv_pick_chain(const rv_picker_args *A, int nsub, int64_t m, const
     struct Seed { size_t i; int64_t sc; bool right; };
     std::vector<Seed> seeds;
     if (!chained.empty() && A->seedsize > 0) {
+        if (chained.size() > 4 && cnt > 64) { last_by_hash.reserve(cnt * 2); for (size_t i = 0; i < cnt; i++) last_by_hash[rel_hash(i)] = (uint32_t)i; }
         int64_t at = 0; bool right = false;
         for (auto &c : chained) {
             if (c.first == split) { at = c.second; right = true; continue; }
@@ -280,21 +307,21 @@ extern "C" int rv_pick_chain(const rv_picker_args *A, int nsub, int64_t m, const
     }
     auto put = [&](size_t i, uint32_t *ol, int32_t *on, uint16_t *oso, int64_t *opos) -> int {
         *ol = (uint32_t)mm[i].l; *on = mm[i].n;
-        for (size_t q = 0; q < mm[i].pos.size(); q++) { oso[q] = mm[i].so[q]; opos[q] = mm[i].pos[q]; }
-        return (int)mm[i].pos.size();
+        for (int q = 0; q < mm[i].nm; q++) { oso[q] = so[mm[i].off + q]; opos[q] = X.at(mm[i], (size_t)q); }
+        return mm[i].nm;
     };
-    if ((int64_t)mm[sm].pos.size() > O->member_cap) { rv_set_error("rv_pick_chain: output too small"); return -1; }
+    if ((int64_t)mm[sm].nm > O->member_cap) { rv_set_error("rv_pick_chain: output too small"); return -1; }
     O->picked = 1;
     O->pick_members = put(sm, &O->pick_l, &O->pick_n, O->pick_so, O->pick_pos);
     int64_t w = 0, wm = 0;
-    for (const Seed &s : seeds) {
-        if (mm[s.i].l < A->seedsize) continue;
-        if (w >= O->seed_cap || wm + (int64_t)mm[s.i].pos.size() > O->seed_member_cap) { rv_set_error("rv_pick_chain: seed output too small"); return -1; }
+    for (const Seed &s2 : seeds) {
+        if (mm[s2.i].l < A->seedsize) continue;
+        if (w >= O->seed_cap || wm + (int64_t)mm[s2.i].nm > O->seed_member_cap) { rv_set_error("rv_pick_chain: seed output too small"); return -1; }
         O->seed_off[w] = wm;
-        wm += put(s.i, &O->seed_l[w], &O->seed_n[w], O->seed_so + wm, O->seed_pos + wm);
-        O->seed_score[w] = s.sc;
-        O->seed_right[w] = s.right ? 1 : 0;
-        if (s.right) O->nright++; else O->nleft++;
+        wm += put(s2.i, &O->seed_l[w], &O->seed_n[w], O->seed_so + wm, O->seed_pos + wm);
+        O->seed_score[w] = s2.sc;
+        O->seed_right[w] = s2.right ? 1 : 0;
+        if (s2.right) O->nright++; else O->nleft++;
         w++;
     }
     O->seed_off[w] = wm;

@@ -458,7 +458,7 @@ def run_one_class(args):
     info = idx.cascade_info()
     out = {"class": name, "L": args.L, "bases": bases, "ms_per_step": dt * 1e3, "Mbp_per_s": bases / dt / 1e6, "anchors": int(r["stats"]["splits"]),
            "anchored_bp": int(r["stats"]["anchored_bp"]), "levels": int(r["stats"]["levels"]), "maxlcp": idx.maxlcp,
-           "path": "cascade" if info["done"] else "level pipeline", "cascade_why": info["why"], "sa_build": idx.sa_stats(), "generate_s": gen_s}
+           "path": "cascade" if info["done"] else "level pipeline", "cascade_why": info["why"], "cascade": info, "sa_build": idx.sa_stats(), "generate_s": gen_s}
     if not args.no_check:
         T0 = np.frombuffer(b"$".join(flat(seqs)) + b"$", dtype=np.uint8)
         nsep = np.asarray(sample_seps(seqs), dtype=np.int64)

@@ -1,4 +1,4 @@
-# rocprofv3 kernel stats of one input class: bash tools/r5/prof_class.sh OUTNAME CLASS L
+# rocprofv3 kernel stats of one input class: bash tools/prof_class.sh OUTNAME CLASS L
 OUT=$PWD/gpurun_out/$1; mkdir -p $OUT
 R=$PWD
 cd /tmp; export TMPDIR=/tmp

@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Where a `reveal rem` job of five 5 Mbp genomes with the native picker (rv_set_picker) spends its time: reading, construct, the recursion in the
+library, the replay of the anchors into the alignment graph, prune_nodes, writing the GFA.  usage (GPU box): python tools/time_native.py"""
 import sys, os, time, tempfile, pathlib, bisect
 sys.path.insert(0, os.getcwd())
 from reveal_amd import rem, schemes, synth, alngraph, reveallib

@@ -2,7 +2,7 @@
 // own access pattern").  Four streaming reads of the SAME 1 GiB, differing only in bytes per lane and load: 16 (dwordx4, the pair scan's LCP
 // stream), 8 (dwordx2, its BWT stream), 4 (dword) and 1 (byte); non-temporal like the scan's.  Run under
 //   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d OUT -o f -- tools/ubench/fetch_calib.bin
-// and divide each kernel's counter (KB) by 2^20 KB: the factor a byte count has to be multiplied with.  tools/r5/fetch_calib.sh does both.
+// and divide each kernel's counter (KB) by 2^20 KB: the factor a byte count has to be multiplied with.  tools/fetch_calib.sh does both.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

@@ -770,6 +770,10 @@ int rv_frontier_scan(rv_index *h) {
         const int64_t *d_ps = nullptr;
         if (a->presel_on && !a->full_only && ns > 0 && !h->ws.opt.presel_host) {
             Packer &pk = a->pk;
+            // (the staging buffer still feeds the previous commit's table upload -- a kernel that reads this pinned memory, queued and not waited for:
+            //  rewriting it here raced with that kernel.  Seen once in ~15 000 cases of tools/fuzz_preselect.py as "child size mismatch" or a memory fault,
+            //  in the round-4 code as in this one)
+            RV_HIP(hipStreamSynchronize(h->ws.stream));
             pk.clear();
             std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
             const size_t o1 = pk.addv(ss);
@@ -832,6 +836,7 @@ int rv_frontier_scan(rv_index *h) {
             // the scan kernel drops the others, they never cross into host memory.  A sub-index without such a match keeps its whole list
             // (schemes.py:229-232): those sub-indices, and only those, are scanned a second time without the filter.
             Packer &pk = a->pk;
+            RV_HIP(hipStreamSynchronize(h->ws.stream));      // (the previous commit's upload reads this buffer: see the pair branch above)
             pk.clear();
             std::vector<int64_t> ss(a->lv.off); ss.push_back(a->lv.m);
             const size_t o1 = pk.addv(ss), o2 = pk.addv(a->lv.nsamples);

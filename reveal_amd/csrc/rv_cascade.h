@@ -40,6 +40,7 @@ struct RvCascadeOut {
 #define RV_CASM_K 16
 struct RvCascadeMultiOut {
     bool done; int levels; int64_t cands, witnesses, children, undecided, rebuilt_ranks, steps; int maxdepth; const char *why;
+    int64_t big, big_ranks;                                                  // of the undecided: those rebuilt through global memory (k_casmb_*)
     std::vector<u32> an_l; std::vector<int64_t> an_pos;                      // k members per anchor, ascending
     std::vector<int64_t> meta, node_first, nodes;                           // undecided sub-indices: 6 numbers each; intervals as (begin, end) pairs
     const void *d_sa, *d_lcp, *d_bwt;

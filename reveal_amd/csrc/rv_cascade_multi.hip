@@ -35,7 +35,7 @@ constexpr int KEY_SHIFT = 40;
 constexpr int KEY_SHIFT = 32;
 #endif
 constexpr u64 KEY_LOW = (1ull << KEY_SHIFT) - 1;
-enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NCAND = 8, C_NANCH = 9, C_STEPS = 10, C_MAXDEPTH = 11, C_TICKET = 12 };
+enum { C_NCHILD = 0, C_NUND = 1, C_NWIT = 2, C_ERR = 3, C_MAXN = 4, C_LO = 5, C_HI = 6, C_LEVELS = 7, C_NCAND = 8, C_NANCH = 9, C_STEPS = 10, C_MAXDEPTH = 11, C_TICKET = 12, C_BIGERR = 13, C_BIGTOT = 14 /* 64 bits */ };
 
 __device__ inline int cm_sample(const sa_t *__restrict__ nsep, int k, sa_t pos) {      // number of separators in front of pos (interface.c:116-134)
     int s = 0;
@@ -550,7 +550,10 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
         if (in) t.state[id] = split ? 1u : 2u;
         if (und) {
             und_list[base_u + (u32)__popcll(b_und & lt)] = id;
-            if ((u64)total > (u64)leaf_n) atomicMax(&counters[C_MAXN], (u32)(total > 0xFFFFFFFFll ? 0xFFFFFFFFll : total));
+            if ((u64)total > (u64)leaf_n) {      // (above the size one workgroup rebuilds in LDS: k_casmb_*)
+                atomicMax(&counters[C_MAXN], (u32)(total > 0xFFFFFFFFll ? 0xFFFFFFFFll : total));
+                atomicAdd((unsigned long long *)&counters[C_BIGTOT], (unsigned long long)total);
+            }
         }
         // visited here: everything but the undecided ones (the level pipeline counts those when it takes them)
         const u64 b_vis = __ballot(in && !und);
@@ -758,6 +761,116 @@ __global__ __launch_bounds__(TB) void k_casm_emit(const CmRoot *__restrict__ roo
     const int64_t o = root.off + r;
     SA[o] = (sa_t)gp; LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
 }
+// ---- undecided sub-indices of more than BN suffixes: the same order through global memory ----
+// (a sample that lost a kilobase or more to a deletion leaves the other k - 1 samples' kilobases behind as ONE sub-index that lacks a sample: above BN
+// ranks from a few hundred bases per sample on; with the simulator's indel model 10 x 5 Mbp holds some twenty of them, and the run used to start again
+// at the top in the level pipeline: 135 instead of 8 ms.)  The suffixes of all such sub-indices get a word (sub-index, first `kb` bytes, zeros behind the
+// end) and go through one radix sort; a suffix is compared in full only with the ones that share its word -- its homologues and repeats --, on the
+// pristine text in HBM, eight bytes a step.  The order is k_casm_rank_sort's; a group of more than BIG_GROUP suffixes (low-complexity text) raises a flag
+// and the cascade gives up as it used to.
+struct CmBig { int64_t off, offL; int32_t n, id; };      // (off: where its arrays start among the rebuilt ones; offL: where its suffixes start in the sort)
+constexpr int BIG_GROUP = 4096;
+constexpr int64_t BIG_ROOT_CAP = (int64_t)1 << 22, BIG_TOTAL_CAP = (int64_t)1 << 26;
+__device__ inline u64 cm_ld8(const uint8_t *p) { u64 a; __builtin_memcpy(&a, p, 8); return a; }
+__global__ __launch_bounds__(TB) void k_casmb_keys(const CmBig *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0, int kb,
+                                                   u64 *__restrict__ keys, u64 *__restrict__ vals) {
+    const CmSlice sl = slices[blockIdx.x];
+    const CmBig root = roots[sl.root];
+    const int64_t i = (int64_t)sl.first + threadIdx.x;
+    if (i >= root.n) return;
+    int64_t at = 0, gp = 0, ri = 0;
+    for (int s = 0; s < k; s++) {
+        const int64_t b = (int64_t)t.b[(size_t)root.id * k + s], e = (int64_t)t.e[(size_t)root.id * k + s];
+        const int64_t len = e > b ? e - b : 0;
+        if (i >= at && i < at + len) { gp = b + (i - at); ri = e - gp; }
+        at += len;
+    }
+    u64 key = 0;
+    for (int b = 0; b < kb; b++) key = (key << 8) | (b < ri ? (u64)T0[gp + b] : 0ull);
+    keys[root.offL + i] = ((u64)(u32)sl.root << (8 * kb)) | key;
+    vals[root.offL + i] = ((u64)ri << 32) | (u64)(u32)gp;
+}
+__global__ __launch_bounds__(TB) void k_casmb_place(const CmBig *__restrict__ roots, const u64 *__restrict__ keys, const u64 *__restrict__ vals, int64_t mL, int kb,
+                                                    const uint8_t *__restrict__ T0, sa_t *__restrict__ SA, u32 *__restrict__ RI, u32 *__restrict__ err) {
+    const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (r >= mL) return;
+    const u64 key = keys[r];
+    const CmBig root = roots[key >> (8 * kb)];
+    int64_t gs = r, ge = r + 1;
+    while (gs > 0 && r - gs <= BIG_GROUP && keys[gs - 1] == key) gs--;
+    while (ge < mL && ge - r <= BIG_GROUP && keys[ge] == key) ge++;
+    if (ge - gs > BIG_GROUP) { atomicOr(err, 1u); return; }
+    const u64 vi = vals[r];
+    const int64_t pi = (int64_t)(u32)vi, ri = (int64_t)(vi >> 32);
+    int64_t cnt = 0;
+    for (int64_t m = gs; m < ge; m++) {
+        if (m == r) continue;
+        const u64 vj = vals[m];
+        const int64_t pj = (int64_t)(u32)vj, rj = (int64_t)(vj >> 32);
+        const int64_t lim = ri < rj ? ri : rj;
+        int64_t x = lim < kb ? lim : kb;      // (the first kb bytes agree, zeros behind an end included: both end inside them or neither does)
+        bool diff = false;
+        while (x + 8 <= lim) {
+            const u64 a = cm_ld8(T0 + pi + x), b = cm_ld8(T0 + pj + x);
+            if (a != b) { x += __builtin_ctzll(a ^ b) >> 3; diff = true; break; }
+            x += 8;
+        }
+        if (!diff) while (x < lim && T0[pi + x] == T0[pj + x]) x++;
+        const bool j_less = (x < lim) ? (T0[pj + x] < T0[pi + x]) : ((rj < ri) | ((rj == ri) & (pj < pi)));
+        cnt += j_less ? 1 : 0;
+    }
+    const int64_t o = root.off + (gs - root.offL) + cnt;
+    SA[o] = (sa_t)pi; RI[o] = (u32)ri;
+}
+// bytes of `a` that differ from `b` or are '$' or 'N': the index of the first one, 8 if none
+__device__ inline int cm_first_stop(u64 a, u64 b) {
+    const u64 lo = 0x0101010101010101ull, hi = 0x8080808080808080ull;
+    const u64 d = a ^ b, vn = a ^ (lo * (u64)'N'), vs = a ^ (lo * (u64)'$');
+    int x = d ? (__builtin_ctzll(d) >> 3) : 8;
+    const u64 zn = (vn - lo) & ~vn & hi, zs = (vs - lo) & ~vs & hi;      // (the lowest flagged byte is exact)
+    if (zn) { const int y = __builtin_ctzll(zn) >> 3; x = y < x ? y : x; }
+    if (zs) { const int y = __builtin_ctzll(zs) >> 3; x = y < x ? y : x; }
+    return x;
+}
+__global__ __launch_bounds__(TB) void k_casmb_emit(const CmBig *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
+                                                   const u32 *__restrict__ RI, const sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0,
+                                                   const sa_t *__restrict__ root_b) {
+    const CmSlice sl = slices[blockIdx.x];
+    const CmBig root = roots[sl.root];
+    const int64_t r = (int64_t)sl.first + threadIdx.x;
+    if (r >= root.n) return;
+    const int64_t o = root.off + r;
+    const int64_t gp = (int64_t)SA[o], ri = (int64_t)RI[o];
+    int64_t l = 0;
+    if (r > 0) {
+        const int64_t gq = (int64_t)SA[o - 1], rj = (int64_t)RI[o - 1];
+        const int64_t lim = ri < rj ? ri : rj;
+        int64_t x = 0;
+        bool stop = false;
+        while (x + 8 <= lim) {
+            const int y = cm_first_stop(cm_ld8(T0 + gp + x), cm_ld8(T0 + gq + x));
+            x += y;
+            if (y < 8) { stop = true; break; }
+        }
+        if (!stop) while (x < lim) { const uint8_t c = T0[gp + x]; if (c != T0[gq + x] || c == '$' || c == 'N') break; x++; }
+        l = x;
+    }
+    uint8_t ch = gp > 0 ? T0[gp - 1] : (uint8_t)'$';
+    bool behind_anchor = false;
+    for (int s = 0; s < k; s++) {
+        const int64_t b = (int64_t)t.b[(size_t)root.id * k + s];
+        behind_anchor |= gp == b && (int64_t)t.e[(size_t)root.id * k + s] > b && b > (int64_t)root_b[s];
+    }
+    if (behind_anchor && ch >= 'A' && ch <= 'Z') ch += 32;
+    LCP[o] = (lcp_t)l; BWT[o] = (uint8_t)(ch | (gp > nsep0 ? RV_BWT_SIDE : 0u));
+}
+__global__ __launch_bounds__(TB) void k_casm_unlower(uint8_t *__restrict__ T, const uint8_t *__restrict__ T0, const u32 *__restrict__ an_l, const sa_t *__restrict__ an_pos, u32 nranges) {
+    const u32 e = (u32)(((int64_t)blockIdx.x * TB + threadIdx.x) >> 6);
+    if (e >= nranges) return;
+    const int64_t lo = (int64_t)an_pos[e];
+    const int64_t l = (int64_t)an_l[e];
+    for (int64_t x = threadIdx.x & 63; x < l; x += 64) T[lo + x] = T0[lo + x];
+}
 __global__ __launch_bounds__(TB) void k_casm_lower(uint8_t *__restrict__ T, const u32 *__restrict__ an_l, const sa_t *__restrict__ an_pos, u32 nranges) {
     const u32 e = (u32)(((int64_t)blockIdx.x * TB + threadIdx.x) >> 6);
     if (e >= nranges) return;
@@ -785,7 +898,7 @@ int bitlen64m(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 
 int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeMultiOut *out) {
     out->done = false; out->levels = 0; out->cands = out->witnesses = out->children = out->undecided = out->rebuilt_ranks = 0; out->steps = 0; out->maxdepth = 0;
-    out->why = nullptr; out->an_l.clear(); out->an_pos.clear(); out->meta.clear(); out->node_first.clear(); out->nodes.clear(); out->d_sa = out->d_lcp = out->d_bwt = nullptr;
+    out->why = nullptr; out->big = out->big_ranks = 0; out->an_l.clear(); out->an_pos.clear(); out->meta.clear(); out->node_first.clear(); out->nodes.clear(); out->d_sa = out->d_lcp = out->d_bwt = nullptr;
     Workspace &ws = h->ws;
     hipStream_t q = ws.stream;
     const int64_t n = h->n;
@@ -891,6 +1004,14 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     RV_LAUNCH_CHECK();
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
     const int batch = std::max(1, (int)ws.opt.cascade_batch);
+    // undecided sub-indices of up to big_min ranks are rebuilt by a workgroup in LDS, larger ones through global memory (RV_CASM_BIG_MIN: the test hook
+    // that sends smaller ones there, too; RV_CASM_NO_BIG=1: the cascade gives up on them as it did up to round 4)
+    const bool no_big = ws.opt.casm_no_big != 0;
+    const int64_t big_min = (!no_big && ws.opt.casm_big_min >= 0 && ws.opt.casm_big_min < BN) ? ws.opt.casm_big_min : BN;
+    auto too_big = [&](const u32 *c) {
+        unsigned long long tot; memcpy(&tot, c + C_BIGTOT, 8);
+        return no_big ? c[C_MAXN] > (u32)BN : ((int64_t)c[C_MAXN] > BIG_ROOT_CAP || (int64_t)tot > BIG_TOTAL_CAP);
+    };
     int queued = 0;
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {
@@ -900,20 +1021,20 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
             hipLaunchKernelGGL(k_casm_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), (const u32 *)bcc.as<u32>(), M, t, k,
                                (int64_t)minl);
             RV_LAUNCH_CHECK();
-            hipLaunchKernelGGL(k_casm_decide, dim3(192), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)BN, banl.as<u32>(), banp.as<sa_t>(), acap);
+            hipLaunchKernelGGL(k_casm_decide, dim3(192), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), (u32)big_min, banl.as<u32>(), banp.as<sa_t>(), acap);
             RV_LAUNCH_CHECK();
         }
         RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
         if (hc[C_ERR] & ~5u) { rv_set_error("cascade (multi): device error %u", hc[C_ERR]); return -1; }
         if (hc[C_ERR]) GIVE_UP("the cascade's tables are full");      // (bits 1 and 4: sub-index table / anchor area: the level pipeline completes the run)
-        if (hc[C_MAXN] > (u32)BN) break;
+        if (too_big(hc)) break;
         if (hc[C_HI] == hc[C_LO]) break;
         if (queued > 1000000) { rv_set_error("cascade (multi): no progress"); return -1; }
     }
     out->levels = (int)hc[C_LEVELS]; out->children = hc[C_NCHILD];
     const u32 U = hc[C_NUND], NA = hc[C_NANCH];
     out->undecided = U;
-    if (hc[C_MAXN] > (u32)BN) {
+    if (too_big(hc)) {
         out->why = "an undecided sub-index above the size that is rebuilt from the text";
         if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", k, out->why, hc[C_MAXN], hc[C_LEVELS], hc[C_NCHILD], U);
         return 0;
@@ -960,8 +1081,9 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
             ids[x] = r_id[o]; hd[x] = r_dep[o];
             for (int s2 = 0; s2 < k; s2++) { hb[(size_t)x * k + s2] = r_b[(size_t)o * k + s2]; he[(size_t)x * k + s2] = r_e[(size_t)o * k + s2]; }
         }
-        std::vector<CmRoot> roots(U);
-        int64_t m = 0;
+        std::vector<CmRoot> roots;      // (up to big_min ranks: a workgroup each, in LDS)
+        std::vector<CmBig> bigs;        // (above: through global memory)
+        int64_t m = 0, mL = 0;
         out->node_first.assign(1, 0);
         for (u32 x = 0; x < U; x++) {
             int64_t sz = 0; int ns = 0;
@@ -970,34 +1092,78 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                 if (e > b) { sz += e - b; ns++; out->nodes.push_back(b); out->nodes.push_back(e); }
             }
             out->node_first.push_back((int64_t)out->nodes.size() / 2);
-            roots[x].off = m; roots[x].n = (int32_t)sz; roots[x].id = (int32_t)ids[x];
+            if (sz > big_min) { bigs.push_back({m, mL, (int32_t)sz, (int32_t)ids[x]}); mL += sz; }
+            else roots.push_back({m, (int32_t)sz, (int32_t)ids[x]});
             const int64_t m6[6] = {m, sz, hd[x], ns, 0, -1};
             out->meta.insert(out->meta.end(), m6, m6 + 6);
             m += sz;
         }
         out->rebuilt_ranks = m;
         RV_TRY(bsa.reserve((size_t)(m + 64) * sizeof(sa_t))); RV_TRY(blcp.reserve((size_t)(m + 64) * sizeof(lcp_t))); RV_TRY(bbwt.reserve((size_t)m + 64));
-        std::vector<CmSlice> slices;
-        for (u32 x = 0; x < U; x++)
+        std::vector<CmSlice> slices, bslices;
+        for (size_t x = 0; x < roots.size(); x++)
             for (int f = 0; f < roots[x].n; f += TB) slices.push_back({(int32_t)x, (int32_t)f});
-        RV_TRY(brt.reserve((size_t)U * sizeof(CmRoot) + slices.size() * sizeof(CmSlice) + 64));
+        for (size_t x = 0; x < bigs.size(); x++)
+            for (int f = 0; f < bigs[x].n; f += TB) bslices.push_back({(int32_t)x, (int32_t)f});
+        const size_t rbytes = roots.size() * sizeof(CmRoot), sbytes = slices.size() * sizeof(CmSlice), gbytes = bigs.size() * sizeof(CmBig), tbytes = bslices.size() * sizeof(CmSlice);
+        RV_TRY(brt.reserve(rbytes + sbytes + gbytes + tbytes + 64));
         RV_TRY(bexp.reserve((size_t)(m + 64) * 4));      // (the lower-casing above is done with it: its launch has been waited for)
         CmRoot *d_roots = brt.as<CmRoot>();
-        CmSlice *d_slices = (CmSlice *)(d_roots + U);
-        {      // (roots and slices in one copy from pinned memory, queued in front of the kernels that read them; the staging area's rows have been read)
-            const size_t rbytes = (size_t)U * sizeof(CmRoot), sbytes = slices.size() * sizeof(CmSlice);
-            RV_TRY(cb.hstage2.reserve(rbytes + sbytes + 64));
-            memcpy(cb.hstage2.p, roots.data(), rbytes); memcpy(cb.hstage2.as<uint8_t>() + rbytes, slices.data(), sbytes);
-            RV_HIP(hipMemcpyAsync(d_roots, cb.hstage2.p, rbytes + sbytes, hipMemcpyHostToDevice, q));
+        CmSlice *d_slices = (CmSlice *)(d_roots + roots.size());
+        CmBig *d_bigs = (CmBig *)(d_slices + slices.size());      // (16-byte records in front, 8-byte ones behind them, 24-byte ones at a multiple of 8)
+        CmSlice *d_bslices = (CmSlice *)(d_bigs + bigs.size());
+        {      // (tables in one copy from pinned memory, queued in front of the kernels that read them; the staging area's rows have been read)
+            RV_TRY(cb.hstage2.reserve(rbytes + sbytes + gbytes + tbytes + 64));
+            uint8_t *hp = cb.hstage2.as<uint8_t>();
+            if (rbytes) memcpy(hp, roots.data(), rbytes);
+            if (sbytes) memcpy(hp + rbytes, slices.data(), sbytes);
+            if (gbytes) memcpy(hp + rbytes + sbytes, bigs.data(), gbytes);
+            if (tbytes) memcpy(hp + rbytes + sbytes + gbytes, bslices.data(), tbytes);
+            RV_HIP(hipMemcpyAsync(d_roots, cb.hstage2.p, rbytes + sbytes + gbytes + tbytes, hipMemcpyHostToDevice, q));
         }
-        if (h->ws.opt.casm_rank_count)      // (test hook: the ranks counted out by comparison, k_casm_rank)
-            hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
-        else
-            hipLaunchKernelGGL(k_casm_rank_sort, dim3(U), dim3(RK_TB), 0, q, (const CmRoot *)d_roots, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
-        RV_LAUNCH_CHECK();
-        hipLaunchKernelGGL(k_casm_emit, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
-                           (const u32 *)bexp.as<u32>(), bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
-        RV_LAUNCH_CHECK();
+        if (!roots.empty()) {
+            if (h->ws.opt.casm_rank_count)      // (test hook: the ranks counted out by comparison, k_casm_rank)
+                hipLaunchKernelGGL(k_casm_rank, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
+            else
+                hipLaunchKernelGGL(k_casm_rank_sort, dim3((unsigned)roots.size()), dim3(RK_TB), 0, q, (const CmRoot *)d_roots, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), bexp.as<u32>());
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_emit, dim3((unsigned)slices.size()), dim3(TB), 0, q, (const CmRoot *)d_roots, (const CmSlice *)d_slices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
+                               (const u32 *)bexp.as<u32>(), bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
+            RV_LAUNCH_CHECK();
+        }
+        if (!bigs.empty()) {
+            int rootbits = 1;
+            while (((size_t)1 << rootbits) < bigs.size()) rootbits++;
+            const int kb = std::min(6, (64 - rootbits) / 8);
+            RV_TRY(bk0.reserve((size_t)(mL + 64) * 8)); RV_TRY(bk1.reserve((size_t)(mL + 64) * 8)); RV_TRY(bv0.reserve((size_t)(mL + 64) * 8)); RV_TRY(bv1.reserve((size_t)(mL + 64) * 8));
+            hipLaunchKernelGGL(k_casmb_keys, dim3((unsigned)bslices.size()), dim3(TB), 0, q, (const CmBig *)d_bigs, (const CmSlice *)d_bslices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(), kb,
+                               bk0.as<u64>(), bv0.as<u64>());
+            RV_LAUNCH_CHECK();
+            int in1 = 0;
+            RV_TRY(rv_radix_sort_pairs<u64>(ws, bk0.as<u64>(), bv0.as<u64>(), bk1.as<u64>(), bv1.as<u64>(), mL, 0, 8 * kb + rootbits, &in1));
+            hipLaunchKernelGGL(k_casmb_place, dim3((unsigned)ceil_div(mL, TB)), dim3(TB), 0, q, (const CmBig *)d_bigs, (const u64 *)(in1 ? bk1.as<u64>() : bk0.as<u64>()),
+                               (const u64 *)(in1 ? bv1.as<u64>() : bv0.as<u64>()), mL, kb, (const uint8_t *)h->dT0.as<uint8_t>(), bsa.as<sa_t>(), bexp.as<u32>(), counters + C_BIGERR);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casmb_emit, dim3((unsigned)bslices.size()), dim3(TB), 0, q, (const CmBig *)d_bigs, (const CmSlice *)d_bslices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
+                               (const u32 *)bexp.as<u32>(), (const sa_t *)bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
+            RV_LAUNCH_CHECK();
+            u32 berr = 0;
+            RV_TRY(rv_read_back(ws, &berr, counters + C_BIGERR, 4));
+            if (berr) {      // (a tie group above BIG_GROUP: nothing of this run stays -- the anchors' text goes back to what it was)
+                if (NA) {
+                    RV_TRY(bcl0.reserve((size_t)NA * k * 4));      // (the candidates' lengths: long gathered into the sorted list)
+                    hipLaunchKernelGGL(k_casm_expand_l, dim3((unsigned)ceil_div((int64_t)NA * k, TB)), dim3(TB), 0, q, (const u32 *)banl.as<u32>(), NA, k, bcl0.as<u32>());
+                    RV_LAUNCH_CHECK();
+                    hipLaunchKernelGGL(k_casm_unlower, dim3((unsigned)ceil_div((int64_t)NA * k * 64, TB)), dim3(TB), 0, q, h->dT.as<uint8_t>(), (const uint8_t *)h->dT0.as<uint8_t>(),
+                                       (const u32 *)bcl0.as<u32>(), (const sa_t *)banp.as<sa_t>(), NA * (u32)k);
+                    RV_LAUNCH_CHECK();
+                    RV_HIP(hipStreamSynchronize(q));
+                }
+                out->meta.clear(); out->node_first.clear(); out->nodes.clear(); out->rebuilt_ranks = 0;
+                GIVE_UP("an undecided sub-index with more suffixes sharing their first bytes than are compared one by one");
+            }
+            out->big = (int64_t)bigs.size(); out->big_ranks = mL;
+        }
         out->d_sa = bsa.p; out->d_lcp = blcp.p; out->d_bwt = bbwt.p;
     }
     if (NA) {      // (behind the launches above: the host copies the anchors out of the staging area while the GPU rebuilds the undecided sub-indices)
@@ -1005,8 +1171,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         out->an_l.assign(pl, pl + NA);
         out->an_pos.assign(pp, pp + (size_t)NA * k);
     }
-    if (verbose) fprintf(stderr, "cascade (%d samples): %u full matches, %u witnesses, %d levels, %u sub-indices, %u anchors, %u undecided (%lld ranks rebuilt)\n", k, M, NW,
-                         out->levels, hc[C_NCHILD], NA, U, (long long)out->rebuilt_ranks);
+    if (verbose) fprintf(stderr, "cascade (%d samples): %u full matches, %u witnesses, %d levels, %u sub-indices, %u anchors, %u undecided (%lld ranks rebuilt; %lld of them above %lld ranks: %lld)\n", k, M, NW,
+                         out->levels, hc[C_NCHILD], NA, U, (long long)out->rebuilt_ranks, (long long)out->big, (long long)big_min, (long long)out->big_ranks);
     out->done = true;
     return 0;
 #undef GIVE_UP

@@ -177,6 +177,63 @@ def test_multi_cascade_random_inputs():
     assert done >= 10 and und > 0
 
 
+def _multi_equal(seqs, minl, sa64=False):
+    ref = oracle_run(seqs, minl, sa64)
+    idx = feed(mod(sa64).index(), seqs)
+    idx.construct()
+    got = idx.align_builtin(minl, 2)
+    info = idx.cascade_info()
+    assert aset(got["anchors"]) == aset(ref["anchors"]), info
+    assert idx.T.encode("latin-1") == ref["T"]
+    assert got["stats"]["splits"] == ref["stats"]["nsplits"] and got["stats"]["anchored_bp"] == ref["stats"]["anchored_bp"]
+    return info
+
+
+@pytest.mark.parametrize("sa64", [False, True])
+def test_multi_cascade_rebuilds_large_undecided_subindices(monkeypatch, sa64):
+    """a sample that lost kilobases leaves the others' kilobases behind as one sub-index that lacks a sample: above the 8192 ranks a workgroup rebuilds
+    in LDS they go through global memory (k_casmb_keys / place / emit) instead of ending the cascade; with what makes suffixes tie there -- an N run,
+    a tandem array, a copy of another stretch, ends that agree"""
+    rng = random.Random(5)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    base = rnd(260000)
+    unit = rnd(37)
+    base = base[:50000] + "N" * 300 + base[50300:52000] + unit * 60 + base[52000 + 37 * 60:]      # inside what sample 1 loses
+    base = base[:120000] + base[124000:127000] + base[123000:]                                      # a copy of a stretch, inside what sample 2 loses
+    seqs = [base]
+    for s in range(1, 5):
+        seqs.append(_snp(rng, base, 0.01))
+    seqs[1] = seqs[1][:48000] + seqs[1][55000:]                  # 7 kb gone: 4 x 7 kb left with the others
+    seqs[2] = seqs[2][:118000] + seqs[2][131000:]                # 13 kb
+    seqs[3] = seqs[3][:200000] + rnd(6000) + seqs[3][200000:]    # an insertion: a sub-index with one sample
+    seqs[4] = seqs[4][:230000] + seqs[4][233000:236000] + seqs[4][233000:]      # a duplication
+    info = _multi_equal(seqs, 20, sa64)
+    assert info["done"] and info["rebuilt_ranks"] > 4 * 13000, info
+    monkeypatch.setenv("RV_CASM_NO_BIG", "1")      # up to round 4: the cascade gave up and the level pipeline ran from the top
+    info = _multi_equal(seqs, 20, sa64)
+    assert not info["done"] and "above the size" in info["why"], info
+    monkeypatch.delenv("RV_CASM_NO_BIG")
+    monkeypatch.setenv("RV_CASM_BIG_MIN", "0")     # every undecided sub-index through global memory
+    info = _multi_equal(seqs, 20, sa64)
+    assert info["done"]
+
+
+def test_multi_cascade_random_inputs_through_global_memory(monkeypatch):
+    """test_multi_cascade_random_inputs with every undecided sub-index, however small, rebuilt by the kernels for the large ones"""
+    monkeypatch.setenv("RV_CASM_BIG_MIN", "0")
+    from fuzz import make_case
+    rng = random.Random(78)
+    done = und = n = 0
+    while n < 40:
+        seqs, minl = make_case(rng)
+        if len(seqs) < 3 or min(len(s) for s in seqs) == 0:
+            continue
+        n += 1
+        info = _multi_equal(seqs, minl, sa64=(n % 4 == 0))
+        done += info["done"]; und += info["undecided"] if info["done"] else 0
+    assert done >= 10 and und > 0
+
+
 # ---- two samples through the interval cascade (the second attempt of rv_align.hip builtin_cascade) ---------------------------------
 @pytest.mark.parametrize("name,inputs,minl", [("1a1b", fa("1a", "1b"), 20), ("1a1b_m10", fa("1a", "1b"), 10), ("synth", (300000, 2), 20)])
 def test_pairs_through_the_interval_cascade(monkeypatch, name, inputs, minl):

@@ -31,6 +31,7 @@ ENVS = [
     {"RV_LEAF_ACAP": "2"},                                # the cascade's leaf launch with a two-anchor staging area
     {"RV_CASCADE_SECOND": "2"},                           # two samples through the interval cascade (rv_cascade_multi.hip) as well
     {"RV_CASM_RANK_COUNT": "1"},                          # more than two samples: undecided sub-indices ranked by counting instead of sorting (k_casm_rank)
+    {"RV_CASM_BIG_MIN": "0"},                             # ... every one of them rebuilt through global memory (k_casmb_*: the path of those above 8192 ranks)
     {"RV_CASCADE_DANGER": "2"},                           # every undecided sub-index decided from its witnesses where they can be (k_cas_dwalk)
     {"RV_CASCADE_DANGER": "2", "RV_CASCADE_DANGER_MIN": "300", "RV_CASCADE_SECOND_OFF": "1"},
     {"RV_CASCADE_DANGER": "2", "RV_NO_DWALK_BLOCKS": "1"},   # ... every witness walks in global memory (no blocks in LDS)

@@ -766,11 +766,12 @@ __global__ __launch_bounds__(TB) void k_casm_emit(const CmRoot *__restrict__ roo
 // ranks from a few hundred bases per sample on; with the simulator's indel model 10 x 5 Mbp holds some twenty of them, and the run used to start again
 // at the top in the level pipeline: 135 instead of 8 ms.)  The suffixes of all such sub-indices get a word (sub-index, first `kb` bytes, zeros behind the
 // end) and go through one radix sort; a suffix is compared in full only with the ones that share its word -- its homologues and repeats --, on the
-// pristine text in HBM, eight bytes a step.  The order is k_casm_rank_sort's; a group of more than BIG_GROUP suffixes (low-complexity text) raises a flag
-// and the cascade gives up as it used to.
+// pristine text in HBM, eight bytes a step.  The order is k_casm_rank_sort's.  Low-complexity text (an N run, a tandem array: thousands of suffixes that
+// share their first bytes and agree for kilobases) is not for this: a group of more than BIG_GROUP suffixes, or a suffix that has spent BIG_STEPS steps,
+// raises a flag, whoever sees the flag stops, and the cascade gives up as it used to -- within a millisecond, not after 10^12 comparisons.
 struct CmBig { int64_t off, offL; int32_t n, id; };      // (off: where its arrays start among the rebuilt ones; offL: where its suffixes start in the sort)
-constexpr int BIG_GROUP = 4096;
-constexpr int64_t BIG_ROOT_CAP = (int64_t)1 << 22, BIG_TOTAL_CAP = (int64_t)1 << 26;
+constexpr int BIG_GROUP = 256;                 // (homologues: one per sample; repeats inside one sub-index on top)
+constexpr int64_t BIG_STEPS = (int64_t)1 << 15;      // eight-byte steps a suffix may spend on its comparisons: 256 KB
 __device__ inline u64 cm_ld8(const uint8_t *p) { u64 a; __builtin_memcpy(&a, p, 8); return a; }
 __global__ __launch_bounds__(TB) void k_casmb_keys(const CmBig *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0, int kb,
                                                    u64 *__restrict__ keys, u64 *__restrict__ vals) {
@@ -794,6 +795,7 @@ __global__ __launch_bounds__(TB) void k_casmb_place(const CmBig *__restrict__ ro
                                                     const uint8_t *__restrict__ T0, sa_t *__restrict__ SA, u32 *__restrict__ RI, u32 *__restrict__ err) {
     const int64_t r = (int64_t)blockIdx.x * TB + threadIdx.x;
     if (r >= mL) return;
+    if (*(volatile u32 *)err) return;
     const u64 key = keys[r];
     const CmBig root = roots[key >> (8 * kb)];
     int64_t gs = r, ge = r + 1;
@@ -802,9 +804,10 @@ __global__ __launch_bounds__(TB) void k_casmb_place(const CmBig *__restrict__ ro
     if (ge - gs > BIG_GROUP) { atomicOr(err, 1u); return; }
     const u64 vi = vals[r];
     const int64_t pi = (int64_t)(u32)vi, ri = (int64_t)(vi >> 32);
-    int64_t cnt = 0;
+    int64_t cnt = 0, steps = 0;
     for (int64_t m = gs; m < ge; m++) {
         if (m == r) continue;
+        if (steps > BIG_STEPS || *(volatile u32 *)err) { atomicOr(err, 1u); return; }
         const u64 vj = vals[m];
         const int64_t pj = (int64_t)(u32)vj, rj = (int64_t)(vj >> 32);
         const int64_t lim = ri < rj ? ri : rj;
@@ -814,7 +817,9 @@ __global__ __launch_bounds__(TB) void k_casmb_place(const CmBig *__restrict__ ro
             const u64 a = cm_ld8(T0 + pi + x), b = cm_ld8(T0 + pj + x);
             if (a != b) { x += __builtin_ctzll(a ^ b) >> 3; diff = true; break; }
             x += 8;
+            if (++steps > BIG_STEPS) break;
         }
+        if (steps > BIG_STEPS) { atomicOr(err, 1u); return; }
         if (!diff) while (x < lim && T0[pi + x] == T0[pj + x]) x++;
         const bool j_less = (x < lim) ? (T0[pj + x] < T0[pi + x]) : ((rj < ri) | ((rj == ri) & (pj < pi)));
         cnt += j_less ? 1 : 0;
@@ -834,7 +839,8 @@ __device__ inline int cm_first_stop(u64 a, u64 b) {
 }
 __global__ __launch_bounds__(TB) void k_casmb_emit(const CmBig *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0,
                                                    const u32 *__restrict__ RI, const sa_t *__restrict__ SA, lcp_t *__restrict__ LCP, uint8_t *__restrict__ BWT, int64_t nsep0,
-                                                   const sa_t *__restrict__ root_b) {
+                                                   const sa_t *__restrict__ root_b, const u32 *__restrict__ err) {
+    if (*err) return;      // (k_casmb_place stopped half way: there is no order to read)
     const CmSlice sl = slices[blockIdx.x];
     const CmBig root = roots[sl.root];
     const int64_t r = (int64_t)sl.first + threadIdx.x;
@@ -1010,7 +1016,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const int64_t big_min = (!no_big && ws.opt.casm_big_min >= 0 && ws.opt.casm_big_min < BN) ? ws.opt.casm_big_min : BN;
     auto too_big = [&](const u32 *c) {
         unsigned long long tot; memcpy(&tot, c + C_BIGTOT, 8);
-        return no_big ? c[C_MAXN] > (u32)BN : ((int64_t)c[C_MAXN] > BIG_ROOT_CAP || (int64_t)tot > BIG_TOTAL_CAP);
+        return no_big ? c[C_MAXN] > (u32)BN : ((int64_t)c[C_MAXN] > ws.opt.casm_big_root || (int64_t)tot > ws.opt.casm_big_total);
     };
     int queued = 0;
     for (;;) {
@@ -1039,6 +1045,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", k, out->why, hc[C_MAXN], hc[C_LEVELS], hc[C_NCHILD], U);
         return 0;
     }
+    if (U == 1 && hc[C_NCHILD] == 1 && n > (int64_t)BN)      // (nothing was decided: rebuilding the root's arrays from its text would only copy the index)
+        GIVE_UP("the index' longest match of all samples is no longer than its repeats");
     out->steps = hc[C_STEPS]; out->maxdepth = (int)hc[C_MAXDEPTH];
     // ---- anchors to the host, their text lower-cased (reveal.c:1230-1234); the rows of the undecided sub-indices (ids, depths, begins, ends) gathered on
     // the device (the tables are small next to the index, but only these rows are needed).  Everything through ONE pinned buffer and one wait: copies to
@@ -1145,7 +1153,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                                (const u64 *)(in1 ? bv1.as<u64>() : bv0.as<u64>()), mL, kb, (const uint8_t *)h->dT0.as<uint8_t>(), bsa.as<sa_t>(), bexp.as<u32>(), counters + C_BIGERR);
             RV_LAUNCH_CHECK();
             hipLaunchKernelGGL(k_casmb_emit, dim3((unsigned)bslices.size()), dim3(TB), 0, q, (const CmBig *)d_bigs, (const CmSlice *)d_bslices, t, k, (const uint8_t *)h->dT0.as<uint8_t>(),
-                               (const u32 *)bexp.as<u32>(), (const sa_t *)bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb);
+                               (const u32 *)bexp.as<u32>(), (const sa_t *)bsa.as<sa_t>(), blcp.as<lcp_t>(), bbwt.as<uint8_t>(), h->nsep[0], d_rb, (const u32 *)(counters + C_BIGERR));
             RV_LAUNCH_CHECK();
             u32 berr = 0;
             RV_TRY(rv_read_back(ws, &berr, counters + C_BIGERR, 4));

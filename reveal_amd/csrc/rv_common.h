@@ -100,6 +100,8 @@ void rv_set_error(const char *fmt, ...);
     X(casm_rank_count, "RV_CASM_RANK_COUNT", 0) \
     X(casm_big_min, "RV_CASM_BIG_MIN", -1) \
     X(casm_no_big, "RV_CASM_NO_BIG", 0) \
+    X(casm_big_root, "RV_CASM_BIG_ROOT", 1 << 22) \
+    X(casm_big_total, "RV_CASM_BIG_TOTAL", 1 << 26) \
     X(lock_any, "RV_LOCK_ANY", 0) \
     X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536)
 struct RvOptions {

@@ -330,6 +330,31 @@ int rv_pick_chain(const rv_picker_args *args, int nsub, int64_t m, const uint32_
                   const int64_t *pos, int nsamples, const int64_t *seq_begin, const int64_t *iv_begin, const int64_t *iv_end, int minlength,
                   rv_picker_out *out);
 
+/* ---- the alignment graph of a finished run (host code; reveal/rem.py:14-200, 318-345) ---------------------------------------------
+ * With the picker inside the library the recursion hands back its anchors in the order it chose them, and the graph `reveal rem` builds -- every
+ * member's node broken around the match (breaknode, rem.py:14-131), the pieces merged into the first (mergenodes, rem.py:133-200) -- depends on
+ * that order alone.  rv_graph_replay does this surgery for inputs with one sequence per sample (nseq sequences at [begin[s], end[s]) of the index
+ * text, path id = s; anchor a: length an_l[a], members an_pos[an_off[a] .. an_off[a+1]) in the picker's order) starting from the FASTA reader's
+ * graph (start sentinel, sequence, end sentinel per sequence: utils.py:304-375).  What comes back keeps the reference structure's ORDER -- nodes in
+ * creation order (the GFA writer's numbering), a node's links in the order they were last made (the writer's L lines; which sibling survives
+ * prune_nodes) --, so the GFA written from it is the callbacks' byte for byte.  rv_graph_sizes: out[0] nodes, out[1] offset entries, out[2] edges,
+ * out[3] path entries.  rv_graph_export: per node (b, e, aligned) with aligned = -1 for a sentinel (b = sample, e = 0 start / 1 end); CSR arrays
+ * (ptr arrays one longer than their count) of the nodes' (path id, offset) entries, of their links forwards and backwards as (neighbour's number,
+ * edge number), and of the edges' path ids.  rv_graph_error: NULL, or why the replay stopped (an anchor outside every node). */
+typedef struct rv_graph rv_graph;
+rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos);
+const char *rv_graph_error(const rv_graph *g);
+int rv_graph_sizes(const rv_graph *g, int64_t *out);
+int rv_graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t *node_aligned, int64_t *off_ptr, int32_t *off_sid, int64_t *off_val,
+                    int64_t *succ_ptr, int32_t *succ_to, int32_t *succ_edge, int64_t *pred_ptr, int32_t *pred_from, int32_t *pred_edge, int64_t *edge_ptr, int32_t *edge_paths);
+/* rv_graph_prune: `prune_nodes` (rem.py:384-447; what `reveal rem` does before writing when more than two paths took part) with T = the index text after
+ * the run.  rv_graph_gfa: the GFA1 text `reveal rem` writes (utils.py:710-839: H, S + L per sequence node in creation order, P per path; names[s] = the name of
+ * path s, cmdline for the header) -- *out points at it until the graph is freed, the return value is its length.  Both identical to the Python graph layer's
+ * result (tests/test_cpu_graph_native.py). */
+int rv_graph_prune(rv_graph *g, const char *T);
+int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out);
+void rv_graph_free(rv_graph *g);
+
 /* ---- measurement ------------------------------------------------------------ */
 /* HIP-event timing of the kernels on the handle's stream.  kernel ids: */
 enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, RV_K_SPLIT = 4, RV_K_LABEL = 5,

@@ -117,6 +117,13 @@ SYMBOLS = {
     "rv_set_picker": (_I, [V, _I, V]),
     "rv_picker_info": (_I, [V, c_i64p]),
     "rv_pick_chain": (_I, [V, _I, _L, V, V, V, V, V, _I, V, V, V, _I, V]),
+    "rv_graph_replay": (V, [_I, V, V, _L, V, V, V]),
+    "rv_graph_error": (ctypes.c_char_p, [V]),
+    "rv_graph_sizes": (_I, [V, c_i64p]),
+    "rv_graph_export": (_I, [V] * 15),
+    "rv_graph_prune": (_I, [V, V]),
+    "rv_graph_gfa": (_L, [V, V, _I, V, V, V]),
+    "rv_graph_free": (None, [V]),
     "rv_test_exclusive_sum_u32": (_I, [V, V, _L]),
     "rv_test_inclusive_max_u32": (_I, [V, V, _L]),
     "rv_test_radix_sort": (_I, [V, V, _L, _I, _I]),

@@ -47,9 +47,12 @@ def run_plan(levels, minlength=20, minn=2, sa64=False, args=None, rank=0, world=
             if j % world != rank:
                 continue
             t0 = time.perf_counter()
-            G, idx, fn = rem.graph_rem(inputs, out, sa64=sa64, minlength=minlength, minn=minn, args=args, indexmod=indexmod)
+            G, idx, fn = rem.graph_rem(inputs, out, sa64=sa64, minlength=minlength, minn=minn, args=args, indexmod=indexmod, materialize=False)
             dt = time.perf_counter() - t0
-            done.append((lv, j, dt, len(G.seq_nodes()), len(G.paths)))
+            if isinstance(G, dict):      # (FASTA inputs with reveal_amd's index: graph built, pruned and written behind the ABI)
+                done.append((lv, j, dt, G["seq_nodes"], len(G["paths"])))
+            else:
+                done.append((lv, j, dt, len(G.seq_nodes()), len(G.paths)))
             if log:
                 log("level %d job %d: %d inputs -> %s  %.2f s, %d nodes, %d paths" % (lv, j, len(inputs), fn, dt, done[-1][3], done[-1][4]))
             del G, idx

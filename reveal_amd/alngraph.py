@@ -39,6 +39,7 @@ class AlnGraph:
         self.literal_segments = False      # segmentgraph as the reference spells it (set by check_segment_shortcut)
         self._begins = SortedList()
         self._end_of = {}
+        self.native = None          # NativeGraph: the run's graph while it is kept behind the ABI (rem.graph_align_genomes(materialize=False))
 
     # ---- nodes and edges -------------------------------------------------------------------
     def add_node(self, node, offsets=None, aligned=None, seq=None):
@@ -291,6 +292,15 @@ class AlnGraph:
             if not merged_any:
                 break
 
+    # ---- the graph of a finished run, built behind the ABI ----------------------------------------------------------
+    def replay_native(self, root_nodes, an_l, an_off, an_pos):
+        """rv_graph_replay (include/reveal_amd.h): graphalign's surgery (rem.py:331-345) for every anchor of a finished run, in C++, the result
+        loaded into this graph -- which must be the FASTA reader's (one sequence per sample, nothing aligned yet).  Same nodes, links and path sets
+        in the same dictionary order as rem.replay_anchors leaves them, so prune_nodes and write_gfa give the same file.
+        root_nodes: the sequences' intervals in sample order; an_l / an_off / an_pos: the anchors as index.align_builtin returns them."""
+        with NativeGraph(self, root_nodes, an_l, an_off, an_pos) as ng:
+            return ng.load_into(self)
+
     # ---- invariants used by the tests ----------------------------------------------------------------
     def spell(self, sample, T):
         """the sequence a path spells: walk its edges from its start sentinel (what `reveal extract` prints, test15)"""
@@ -321,6 +331,123 @@ class AlnGraph:
         sid = self.path2id[sample]
         nodes = sorted((o[sid], n) for n, o in self.offsets.items() if isinstance(n, tuple) and sid in o)
         return "".join(T[b:e] for _, (b, e) in nodes).upper()
+
+
+class NativeGraph:
+    """rv_graph (include/reveal_amd.h): the alignment graph of a finished run with one sequence per sample, kept behind the ABI: the anchors'
+    surgery (rv_graph_replay), prune_nodes (rv_graph_prune), the GFA text (rv_graph_gfa) -- and, when somebody wants to look at it, the same graph as
+    an AlnGraph (load_into).  `G` is the FASTA reader's graph of the inputs: it lends its path names and sentinels."""
+
+    def __init__(self, G, root_nodes, an_l, an_off, an_pos):
+        import numpy as np
+        from . import _lib
+        k = len(root_nodes)
+        if len(G.startnodes) != k or len(G.endnodes) != k or any(G.aligned.get(tuple(n)) != 0 for n in root_nodes) or len(G.aligned) != k:
+            raise ValueError("NativeGraph: the graph is not the FASTA reader's graph of these sequences")
+        if [G.path2id[p] for p in G.paths] != list(range(k)):
+            raise ValueError("NativeGraph: path ids are not the samples 0..k-1")
+        self._dll = _lib.get(False).dll
+        self.names = list(G.paths)
+        rb = np.ascontiguousarray([n[0] for n in root_nodes], dtype=np.int64); re_ = np.ascontiguousarray([n[1] for n in root_nodes], dtype=np.int64)
+        an_l = np.ascontiguousarray(an_l, dtype=np.uint32); an_off = np.ascontiguousarray(an_off, dtype=np.int64); an_pos = np.ascontiguousarray(an_pos, dtype=np.int64)
+        self._g = self._dll.rv_graph_replay(k, rb.ctypes.data, re_.ctypes.data, len(an_l), an_l.ctypes.data, an_off.ctypes.data, an_pos.ctypes.data)
+        if not self._g:
+            raise MemoryError("rv_graph_replay")
+        why = self._dll.rv_graph_error(self._g)
+        if why:
+            self.close()
+            raise RuntimeError(why.decode())
+
+    def close(self):
+        if self._g:
+            self._dll.rv_graph_free(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        self.close()
+
+    @staticmethod
+    def _text(T):
+        return T if isinstance(T, (bytes, bytearray)) else T.encode("latin-1")
+
+    def counts(self):
+        """-> (sequence nodes, links) as the graph stands"""
+        import ctypes
+        import numpy as np
+        sz = np.zeros(4, dtype=np.int64)
+        self._dll.rv_graph_sizes(self._g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        return int(sz[0]) - 2 * len(self.names), int(sz[2])
+
+    def prune(self, T):
+        """AlnGraph.prune_nodes (rem.py:384-447) on the graph behind the ABI; T = the index text after the run"""
+        self._dll.rv_graph_prune(self._g, self._text(T))
+
+    def gfa(self, T, cmdline=None):
+        """the text write_gfa writes -> bytes"""
+        import ctypes
+        names = (ctypes.c_char_p * len(self.names))(*[n.encode() for n in self.names])
+        out = ctypes.c_char_p()
+        cl = (cmdline if cmdline is not None else " ".join(sys.argv)).encode()
+        n = self._dll.rv_graph_gfa(self._g, self._text(T), len(self.names), names, cl, ctypes.byref(out))
+        return ctypes.string_at(out, n)
+
+    def write_gfa(self, T, outputfile, cmdline=None):
+        """write_gfa(G, T, outputfile) for the graph behind the ABI -> the file name written"""
+        if not outputfile.endswith(".gfa") and not outputfile.endswith(".gfa.gz"):
+            outputfile += ".gfa.gz"
+        data = self.gfa(T, cmdline)
+        with (gzip.open if outputfile.endswith(".gz") else open)(outputfile, "wb") as f:
+            f.write(data)
+        return outputfile
+
+    def load_into(self, G):
+        """the graph as it stands behind the ABI into the AlnGraph `G` (the one handed to the constructor): nodes, links and path sets in the
+        dictionary order the Python surgery leaves them in -> number of nodes"""
+        import ctypes
+        import numpy as np
+        dll, g = self._dll, self._g
+        k = len(self.names)
+        sz = np.zeros(4, dtype=np.int64)
+        dll.rv_graph_sizes(g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        nn, no, ne, npth = (int(x) for x in sz)
+        nb = np.zeros(nn, np.int64); nend = np.zeros(nn, np.int64); nal = np.zeros(nn, np.int8)
+        optr = np.zeros(nn + 1, np.int64); osid = np.zeros(max(no, 1), np.int32); oval = np.zeros(max(no, 1), np.int64)
+        sptr = np.zeros(nn + 1, np.int64); sto = np.zeros(max(ne, 1), np.int32); sed = np.zeros(max(ne, 1), np.int32)
+        pptr = np.zeros(nn + 1, np.int64); pfr = np.zeros(max(ne, 1), np.int32); ped = np.zeros(max(ne, 1), np.int32)
+        eptr = np.zeros(ne + 1, np.int64); epath = np.zeros(max(npth, 1), np.int32)
+        dll.rv_graph_export(g, *(x.ctypes.data for x in (nb, nend, nal, optr, osid, oval, sptr, sto, sed, pptr, pfr, ped, eptr, epath)))
+        # sentinels keep their names: (sample, 0 / 1) -> the reader's start / end node of that sequence
+        sid_of = {}
+        for st in G.startnodes:
+            (sid,) = G.offsets[st].keys(); sid_of[(sid, 0)] = st
+        for en in G.endnodes:
+            (sid,) = G.offsets[en].keys(); sid_of[(sid, 1)] = en
+        if sorted(q for q, _ in sid_of) != sorted(list(range(k)) * 2):
+            raise ValueError("NativeGraph: path ids are not the samples 0..k-1")
+        nbl, nel, nall = nb.tolist(), nend.tolist(), nal.tolist()
+        names = [(sid_of[(b, e)] if al < 0 else (b, e)) for b, e, al in zip(nbl, nel, nall)]
+        osidl, ovall, optrl = osid.tolist(), oval.tolist(), optr.tolist()
+        eptrl, epl = eptr.tolist(), epath.tolist()
+        sets = [set(epl[eptrl[j]:eptrl[j + 1]]) for j in range(ne)]      # one object per edge, shared by its two directories (add_edge unites in place)
+        seq_keep = {n: G.seq[n] for n in G.seq if not isinstance(n, tuple)}
+        offsets, aligned, succ, pred = {}, {}, {}, {}
+        sptrl, stol, sedl, pptrl, pfrl, pedl = sptr.tolist(), sto.tolist(), sed.tolist(), pptr.tolist(), pfr.tolist(), ped.tolist()
+        for i, name in enumerate(names):
+            offsets[name] = dict(zip(osidl[optrl[i]:optrl[i + 1]], ovall[optrl[i]:optrl[i + 1]]))
+            if nall[i] >= 0:
+                aligned[name] = nall[i]
+            succ[name] = {(names[stol[j]], "+", "+"): sets[sedl[j]] for j in range(sptrl[i], sptrl[i + 1])}
+            pred[name] = {(names[pfrl[j]], "+", "+"): sets[pedl[j]] for j in range(pptrl[i], pptrl[i + 1])}
+        G.offsets, G.aligned, G.succ, G.pred, G.seq = offsets, aligned, succ, pred, seq_keep
+        G._begins = SortedList(sorted(b for b, al in zip(nbl, nall) if al >= 0))
+        G._end_of = {b: e for b, e, al in zip(nbl, nel, nall) if al >= 0}
+        return nn
 
 
 # ---- readers (reveal/utils.py:304-375, 377-677) -------------------------------------------------------

@@ -1,0 +1,338 @@
+// rv_graph.hip -- the alignment graph of a finished `reveal rem` run, built from its anchors on the host side of the ABI (no device code).
+//
+// With the picker inside the library (rv_set_picker) the recursion returns the anchors in the order it chose them, and the graph the reference
+// builds callback by callback (reveal/rem.py:318-345 graphalign: break the nodes that hold the members, merge the pieces; rem.py:14-131 breaknode,
+// 133-200 mergenodes) depends on that order alone.  reveal_amd/rem.py replay_anchors_fast does the surgery in Python: 48 us per broken node, 25 s for
+// five genomes of 5 Mbp -- most of what such a job takes.  This file does the same surgery on plain arrays and hands the result back in the
+// order the Python structure would have it: the writer numbers the nodes in creation order and prints a node's links in the order they were (last)
+// made, prune_nodes picks the survivor of a merge by the order of its neighbours, so "ordered dictionary" is part of the result.
+//
+// Scope: the native picker's -- FASTA inputs, one sequence per sample (path id = sample), every edge on the forward strand.
+// Test infrastructure compares it with the Python surgery node for node and edge for edge (tests/test_cpu_graph_native.py).
+#include "../../include/reveal_amd.h"
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct GNode {
+    int64_t b, e;                                   // text interval; sentinels: b = sample, e = 0 (start) / 1 (end)
+    int8_t aligned;                                 // -1: sentinel
+    bool alive;
+    uint64_t order;                                 // position in the graph's node dictionary (creation order)
+    std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
+    std::vector<int> succ, pred;                    // edge ids, in dictionary order
+};
+struct GEdge { int u, v; std::vector<int> paths; };      // (paths: sorted, unique)
+
+void set_union(std::vector<int> &a, const std::vector<int> &b) {
+    std::vector<int> r;
+    r.reserve(a.size() + b.size());
+    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(r));
+    a.swap(r);
+}
+
+}  // namespace
+
+struct rv_graph {
+    std::vector<GNode> nodes;
+    std::vector<GEdge> edges;
+    std::map<int64_t, int> at;                      // begin -> node, sequence nodes that are alive
+    uint64_t counter = 0;
+    std::vector<int> order;                         // export: alive nodes in dictionary order
+    std::vector<int> edge_no;                       // export: edge id -> dense number (-1: dead)
+    std::string err, gfa;
+    int nseq = 0;
+
+    int new_node(int64_t b, int64_t e, int8_t aligned) {
+        GNode n;
+        n.b = b; n.e = e; n.aligned = aligned; n.alive = true; n.order = counter++;
+        nodes.push_back(std::move(n));
+        const int id = (int)nodes.size() - 1;
+        if (aligned >= 0) at[b] = id;
+        return id;
+    }
+    // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
+    void add_edge(int u, int v, const std::vector<int> &paths) {
+        for (int e : nodes[(size_t)u].succ)
+            if (edges[(size_t)e].v == v) { set_union(edges[(size_t)e].paths, paths); return; }
+        edges.push_back({u, v, paths});
+        const int e = (int)edges.size() - 1;
+        nodes[(size_t)u].succ.push_back(e);
+        nodes[(size_t)v].pred.push_back(e);
+    }
+    void remove_node(int x) {
+        GNode &n = nodes[(size_t)x];
+        for (int e : n.succ) { auto &p = nodes[(size_t)edges[(size_t)e].v].pred; p.erase(std::find(p.begin(), p.end(), e)); edges[(size_t)e].u = -1; }
+        for (int e : n.pred) { auto &s = nodes[(size_t)edges[(size_t)e].u].succ; s.erase(std::find(s.begin(), s.end(), e)); edges[(size_t)e].u = -1; }
+        n.succ.clear(); n.pred.clear(); n.off.clear(); n.alive = false;
+        auto it = at.find(n.b);
+        if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
+    }
+    int node_at(int64_t pos) {
+        auto it = at.upper_bound(pos);
+        if (it == at.begin()) return -1;
+        --it;
+        const GNode &n = nodes[(size_t)it->second];
+        return (n.alive && pos < n.e) ? it->second : -1;
+    }
+    // rem.py:14-131 for a node every path crosses forwards
+    int breaknode(int x, int64_t pos, int64_t l) {
+        const int64_t nb = nodes[(size_t)x].b, ne = nodes[(size_t)x].e;
+        if (nb == pos && ne == pos + l) return x;
+        const std::vector<std::pair<int, int64_t>> att = nodes[(size_t)x].off;
+        std::vector<std::pair<int, std::vector<int>>> in_edges, out_edges;
+        for (int e : nodes[(size_t)x].pred) in_edges.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
+        for (int e : nodes[(size_t)x].succ) out_edges.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
+        std::vector<int> pospaths;
+        if (in_edges.empty() && out_edges.empty()) {
+            for (auto &a : att) pospaths.push_back(a.first);
+            std::sort(pospaths.begin(), pospaths.end());
+        } else {
+            for (auto &ie : in_edges) set_union(pospaths, ie.second);
+            for (auto &oe : out_edges) set_union(pospaths, oe.second);
+        }
+        // (the old node leaves the position map first: the match or prefix node shares its begin)
+        { auto it = at.find(nb); if (it != at.end() && it->second == x) at.erase(it); }
+        const int mn = new_node(pos, pos + l, 0);
+        for (auto &a : att) nodes[(size_t)mn].off.push_back({a.first, a.second + (pos - nb)});
+        int pn = mn, sn = mn;
+        if (nb != pos) {
+            pn = new_node(nb, pos, 0);
+            nodes[(size_t)pn].off = att;
+            add_edge(pn, mn, pospaths);
+        }
+        if (ne != pos + l) {
+            sn = new_node(pos + l, ne, 0);
+            for (auto &a : att) nodes[(size_t)sn].off.push_back({a.first, a.second + (pos + l - nb)});
+            add_edge(mn, sn, pospaths);
+        }
+        remove_node(x);
+        for (auto &ie : in_edges) add_edge(ie.first, pn, ie.second);
+        for (auto &oe : out_edges) add_edge(sn, oe.first, oe.second);
+        return mn;
+    }
+    // rem.py:133-200: the first node absorbs the others
+    int mergenodes(const std::vector<int> &mns) {
+        const int ref = mns[0];
+        std::vector<std::pair<int, int64_t>> merged;
+        for (int x : mns)
+            for (auto &a : nodes[(size_t)x].off) {
+                bool found = false;
+                for (auto &m : merged) if (m.first == a.first) { m.second = a.second; found = true; break; }
+                if (!found) merged.push_back(a);
+            }
+        nodes[(size_t)ref].off = merged;
+        nodes[(size_t)ref].aligned = 1;
+        for (size_t k = 1; k < mns.size(); k++) {
+            const int x = mns[k];
+            if (x == ref) continue;
+            std::vector<std::pair<int, std::vector<int>>> ins, outs;
+            for (int e : nodes[(size_t)x].pred) ins.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
+            for (int e : nodes[(size_t)x].succ) outs.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
+            for (auto &ie : ins) add_edge(ie.first, ref, ie.second);
+            for (auto &oe : outs) add_edge(ref, oe.first, oe.second);
+            remove_node(x);
+        }
+        return ref;
+    }
+    void finish() {
+        order.clear();
+        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return nodes[(size_t)a].order < nodes[(size_t)b].order; });
+        edge_no.assign(edges.size(), -1);
+        int ne = 0;
+        for (int x : order) for (int e : nodes[(size_t)x].succ) edge_no[(size_t)e] = ne++;
+    }
+};
+
+extern "C" {
+
+rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
+    rv_graph *g = new rv_graph();
+    g->nseq = nseq;
+    // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
+    for (int s = 0; s < nseq; s++) {
+        const int st = g->new_node(s, 0, -1), iv = g->new_node(begin[s], end[s], 0), en = g->new_node(s, 1, -1);
+        g->nodes[(size_t)st].off.push_back({s, 0}); g->nodes[(size_t)iv].off.push_back({s, 0}); g->nodes[(size_t)en].off.push_back({s, end[s] - begin[s]});
+        g->add_edge(st, iv, {s}); g->add_edge(iv, en, {s});
+    }
+    std::vector<int> mns;
+    for (int64_t a = 0; a < na; a++) {
+        mns.clear();
+        const int64_t l = (int64_t)an_l[a];
+        for (int64_t k = an_off[a]; k < an_off[a + 1]; k++) {
+            const int x = g->node_at(an_pos[k]);
+            if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; g->finish(); return g; }
+            mns.push_back(g->breaknode(x, an_pos[k], l));
+        }
+        if (!mns.empty()) g->mergenodes(mns);
+    }
+    g->finish();
+    return g;
+}
+
+const char *rv_graph_error(const rv_graph *g) { return g->err.empty() ? nullptr : g->err.c_str(); }
+
+/* out[0] nodes, out[1] offset entries, out[2] edges, out[3] path entries of the edges */
+int rv_graph_sizes(const rv_graph *g, int64_t *out) {
+    int64_t no = 0, ne = 0, np = 0;
+    for (int x : g->order) {
+        no += (int64_t)g->nodes[(size_t)x].off.size();
+        for (int e : g->nodes[(size_t)x].succ) { ne++; np += (int64_t)g->edges[(size_t)e].paths.size(); }
+    }
+    out[0] = (int64_t)g->order.size(); out[1] = no; out[2] = ne; out[3] = np;
+    return 0;
+}
+
+/* nodes in dictionary order: (b, e, aligned; -1 = sentinel: b = sample, e = 0 start / 1 end); offsets as CSR; per node its links forwards and backwards as CSR of
+ * (neighbour's number, edge number) in dictionary order; per edge its path ids as CSR */
+int rv_graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t *node_aligned, int64_t *off_ptr, int32_t *off_sid, int64_t *off_val,
+                    int64_t *succ_ptr, int32_t *succ_to, int32_t *succ_edge, int64_t *pred_ptr, int32_t *pred_from, int32_t *pred_edge, int64_t *edge_ptr, int32_t *edge_paths) {
+    std::vector<int> number(g->nodes.size(), -1);
+    for (size_t i = 0; i < g->order.size(); i++) number[(size_t)g->order[i]] = (int)i;
+    int64_t no = 0, ns = 0, np = 0;
+    int64_t nedges = 0;
+    for (int e : g->edge_no) if (e >= 0) nedges++;
+    std::vector<int> by_no((size_t)nedges, -1);
+    for (size_t e = 0; e < g->edge_no.size(); e++) if (g->edge_no[e] >= 0) by_no[(size_t)g->edge_no[e]] = (int)e;
+    for (size_t i = 0; i < g->order.size(); i++) {
+        const GNode &n = g->nodes[(size_t)g->order[i]];
+        node_b[i] = n.b; node_e[i] = n.e; node_aligned[i] = n.aligned;
+        off_ptr[i] = no;
+        for (auto &a : n.off) { off_sid[no] = a.first; off_val[no] = a.second; no++; }
+        succ_ptr[i] = ns;
+        for (int e : n.succ) { succ_to[ns] = number[(size_t)g->edges[(size_t)e].v]; succ_edge[ns] = g->edge_no[(size_t)e]; ns++; }
+        pred_ptr[i] = np;
+        for (int e : n.pred) { pred_from[np] = number[(size_t)g->edges[(size_t)e].u]; pred_edge[np] = g->edge_no[(size_t)e]; np++; }
+    }
+    off_ptr[g->order.size()] = no; succ_ptr[g->order.size()] = ns; pred_ptr[g->order.size()] = np;
+    int64_t pp = 0;
+    for (int64_t k = 0; k < nedges; k++) {
+        edge_ptr[k] = pp;
+        for (int p : g->edges[(size_t)by_no[(size_t)k]].paths) edge_paths[pp++] = p;
+    }
+    edge_ptr[nedges] = pp;
+    return 0;
+}
+
+/* rem.py:384-447 prune_nodes, as reveal_amd/alngraph.py runs it (work list instead of whole passes, same fixpoint): siblings with the same sequence
+ * that hang on one parent (child) and have no other are merged.  T = the index text after the run (matched text lower-cased: an aligned and an
+ * unaligned sibling spell differently).  Which sibling survives, and where the survivor stands among its neighbours' links, follows the dictionary
+ * order -- kept here. */
+int rv_graph_prune(rv_graph *g, const char *T) {
+    auto &nodes = g->nodes; auto &edges = g->edges;
+    for (;;) {
+        bool merged_any = false;
+        g->finish();
+        std::deque<int> queue(g->order.begin(), g->order.end());
+        std::vector<char> queued(nodes.size(), 0);
+        for (int x : queue) queued[(size_t)x] = 1;
+        std::vector<int> neis, again;
+        std::vector<std::vector<int>> groups;
+        while (!queue.empty()) {
+            const int node = queue.front(); queue.pop_front(); queued[(size_t)node] = 0;
+            if (!nodes[(size_t)node].alive) continue;
+            for (int dir = 0; dir < 2; dir++) {
+                neis.clear();
+                for (int e : (dir == 0 ? nodes[(size_t)node].succ : nodes[(size_t)node].pred)) neis.push_back(dir == 0 ? edges[(size_t)e].v : edges[(size_t)e].u);
+                if (neis.size() < 2) continue;
+                groups.clear();
+                for (int nei : neis) {
+                    const GNode &q = nodes[(size_t)nei];
+                    if (q.aligned < 0) continue;
+                    bool placed = false;
+                    for (auto &grp : groups) {
+                        const GNode &r = nodes[(size_t)grp[0]];
+                        if (r.e - r.b == q.e - q.b && memcmp(T + r.b, T + q.b, (size_t)(q.e - q.b)) == 0) { grp.push_back(nei); placed = true; break; }
+                    }
+                    if (!placed) groups.push_back({nei});
+                }
+                for (auto &grp : groups) {
+                    if (grp.size() < 2) continue;
+                    bool single = true;
+                    for (int v : grp) if ((dir == 0 ? nodes[(size_t)v].pred : nodes[(size_t)v].succ).size() > 1) { single = false; break; }
+                    if (!single) continue;
+                    const int ref = g->mergenodes(grp);
+                    merged_any = true;
+                    again.clear(); again.push_back(node); again.push_back(ref);
+                    for (int e : nodes[(size_t)ref].succ) again.push_back(edges[(size_t)e].v);
+                    for (int e : nodes[(size_t)ref].pred) again.push_back(edges[(size_t)e].u);
+                    for (int x : again)
+                        if (!queued[(size_t)x] && nodes[(size_t)x].alive) { queue.push_back(x); queued[(size_t)x] = 1; }
+                }
+            }
+        }
+        if (!merged_any) break;
+    }
+    g->finish();
+    return 0;
+}
+
+/* utils.py:710-839 write_gfa as reveal_amd/alngraph.py writes GFA1: H, then per sequence node (numbered from 1 in dictionary order) its S line -- the text of
+ * its interval, upper-cased when aligned -- and an L line per link to a sequence node, then a P line per path (names[0 .. npaths), path id = position),
+ * walked from its start sentinel.  The text stays with the graph until it is freed; *out points at it, the return value is its length. */
+int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out) {
+    auto &nodes = g->nodes; auto &edges = g->edges;
+    std::string &o = g->gfa;
+    o.clear();
+    std::vector<int> ident(nodes.size(), 0);
+    int nid = 0;
+    for (int x : g->order) if (nodes[(size_t)x].aligned >= 0) ident[(size_t)x] = ++nid;
+    o += "H\tVN:Z:1.0\tCL:Z:"; o += cmdline ? cmdline : ""; o += "\n";
+    char buf[96];
+    for (int x : g->order) {
+        const GNode &n = nodes[(size_t)x];
+        if (n.aligned < 0) continue;
+        int w = snprintf(buf, sizeof buf, "S\t%d\t", ident[(size_t)x]);
+        o.append(buf, (size_t)w);
+        const size_t at = o.size();
+        o.append(T + n.b, (size_t)(n.e - n.b));
+        if (n.aligned > 0)
+            for (size_t i = at; i < o.size(); i++) { const char c = o[i]; if (c >= 'a' && c <= 'z') o[i] = (char)(c - 32); }
+        o += "\n";
+        for (int e : n.succ) {
+            const int v = edges[(size_t)e].v;
+            if (nodes[(size_t)v].aligned < 0) continue;
+            w = snprintf(buf, sizeof buf, "L\t%d\t+\t%d\t+\t0M\n", ident[(size_t)x], ident[(size_t)v]);
+            o.append(buf, (size_t)w);
+        }
+    }
+    // the start sentinels in the reader's order: sample s' is node 3 s of the replay
+    for (int sid = 0; sid < npaths; sid++) {
+        std::string path, cigar;
+        for (size_t st = 0; st + 2 < nodes.size() && (int)(st / 3) < g->nseq; st += 3) {
+            bool has = false;
+            for (auto &a : nodes[st].off) has |= a.first == sid;
+            if (!nodes[st].alive || !has) continue;
+            int node = (int)st;
+            for (;;) {
+                int nout = 0, v = -1;
+                for (int e : nodes[(size_t)node].succ)
+                    if (std::binary_search(edges[(size_t)e].paths.begin(), edges[(size_t)e].paths.end(), sid)) { nout++; v = edges[(size_t)e].v; }
+                if (nout != 1) break;
+                if (nodes[(size_t)v].aligned < 0 && nodes[(size_t)v].e == 1) break;      // an end sentinel
+                if (nodes[(size_t)v].aligned >= 0) {
+                    const int w = snprintf(buf, sizeof buf, "%s%d+", path.empty() ? "" : ",", ident[(size_t)v]);
+                    path.append(buf, (size_t)w);
+                    if (nodes[(size_t)node].aligned >= 0) { cigar += cigar.empty() ? "0M" : ",0M"; }
+                }
+                node = v;
+            }
+            break;
+        }
+        o += "P\t"; o += names[sid]; o += "\t"; o += path; o += "\t"; o += cigar; o += "\n";
+    }
+    *out = o.data();
+    return (int64_t)o.size();
+}
+
+void rv_graph_free(rv_graph *g) { delete g; }
+
+}  // extern "C"

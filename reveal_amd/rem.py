@@ -208,11 +208,25 @@ def replay_anchors(G, aligner, root_nodes, anchors):
     return na
 
 
-def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None):
+def replay_anchors_fast(G, aligner, root_nodes, anchors):
+    """replay_anchors without the recursion's bookkeeping: what graphalign does to the GRAPH for an anchor -- break the nodes that hold its members,
+    merge the pieces (rem.py:331-345) -- depends on the graph alone, and replay_anchors applies the anchors strictly in the order given; the
+    sub-index' interval set, its left / right nodes and segmentgraph's walks only serve the index, which has already finished.  Same graph, node
+    for node and edge for edge in the same insertion order (the GFA writer's order)."""
+    node_at, breaknode, mergenodes = G.node_at, G.breaknode, G.mergenodes
+    for l, n, spd in anchors:
+        mergenodes([breaknode(node_at(pos), pos, l)[0] for _, pos in spd])
+    aligner.calls += len(anchors)
+    return len(anchors)
+
+
+def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None, materialize=True):
     """rem.py:511-611 align_genomes: index + graph from FASTA / GFA inputs, construct, align with the graph callbacks.
     preselect: let the library hand the picker only what it keeps anyway (index.preselect(maxmums): the matches spanning
     every sample of the sub-index, capped at --maxmums) -- not valid with --trim, which looks at the others
     indexmod: the module that provides `index` (default reveal_amd.reveallib / reveallib64; tests pass the reference's own module)
+    native: the picker inside the library and the graph from the run's anchors behind the ABI (alngraph.NativeGraph); materialize=False leaves it
+    there -- `graph.native` holds it, the returned graph is still the reader's -- for a caller that only wants the file (graph_rem)
     -> (graph, index, picker, aligner)"""
     from . import alngraph, schemes
     if indexmod is None:
@@ -241,16 +255,19 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
     root_nodes = sorted(tuple(x) for x in idx.nodes)
     idx.construct()
     if native:
-        import bisect
         idx.set_picker(args)
         l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
-        begins = [b for b, _ in root_nodes]
-        pos = pos.tolist(); off = off.tolist(); l = l.tolist()
-        anchors = [(l[k], off[k + 1] - off[k], tuple((bisect.bisect_right(begins, p) - 1, p) for p in pos[off[k]:off[k + 1]])) for k in range(len(l))]
         idx.set_picker(None)
         picker.calls = idx.picker_info()["calls"]
         idx._nodes = set(root_nodes)
-        replay_anchors(G, aligner, root_nodes, anchors)
+        # graphalign's surgery for every anchor, in the order the library chose them (replay_anchors / replay_anchors_fast are the same in Python:
+        # 25 s instead of 1.3 for five genomes of 5 Mbp)
+        G.native = alngraph.NativeGraph(G, root_nodes, l, off, pos)
+        aligner.calls += len(l)
+        if materialize:
+            G.native.load_into(G)
+            G.native.close()
+            G.native = None
         return G, idx, picker, aligner
     if preselect and not args.trim and args.maxmums and hasattr(idx, "preselect"):
         idx.preselect(args.maxmums)
@@ -307,13 +324,27 @@ def align(aobjs, ref=None, minlength=20, minn=2, seedsize=None, threads=0, targe
     return G, idx
 
 
-def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None):
+def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None, materialize=True):
     """`reveal rem inputs -o output` (rem.py:449-509 align_cmd): align, merge equal siblings when more than two paths took part,
-    write GFA1.  -> (graph, index, file name or None)"""
+    write GFA1.  -> (graph, index, file name or None)
+    materialize=False: when the graph was built behind the ABI (native picker) it is pruned and written there and not turned into Python
+    objects (most of what the graph then takes): in its place comes {"seq_nodes": .., "edges": .., "paths": [names]}"""
     from . import alngraph
     G, idx, picker, aligner = graph_align_genomes(inputfiles, sa64=sa64, minlength=minlength, minn=minn, contigs=contigs, toupper=toupper,
-                                                  args=args, preselect=preselect, indexmod=indexmod, native=native)
+                                                  args=args, preselect=preselect, indexmod=indexmod, native=native, materialize=False)
     T = idx.T
+    ng = getattr(G, "native", None)
+    if ng is not None:
+        Tb = T.encode("latin-1")
+        if len(G.paths) > 2:
+            ng.prune(Tb)
+        fn = ng.write_gfa(Tb, output, cmdline="reveal_amd.rem " + " ".join(inputfiles)) if output else None
+        summary = dict(zip(("seq_nodes", "edges"), ng.counts()), paths=list(G.paths))
+        if materialize:
+            ng.load_into(G)
+        ng.close()
+        G.native = None
+        return (G if materialize else summary), idx, fn
     if len(G.paths) > 2:
         G.prune_nodes(T)
     fn = None
@@ -403,8 +434,11 @@ def main(argv=None):
         return
     from . import schemes
     pa = schemes.PickerArgs(wscore=a.wscore, wpen=a.wpen, maxmums=a.maxmums, seedsize=a.seedsize, gcmodel=a.gcmodel, trim=a.trim, maxsize=a.maxsize, pcutoff=a.pcutoff)
-    G, idx, fn = graph_rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs, args=pa)
-    print("%s: %d nodes, %d paths" % (fn, len(G.seq_nodes()), len(G.paths)))
+    G, idx, fn = graph_rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs, args=pa, materialize=False)
+    if isinstance(G, dict):      # (built, pruned and written behind the ABI)
+        print("%s: %d nodes, %d paths" % (fn, G["seq_nodes"], len(G["paths"])))
+    else:
+        print("%s: %d nodes, %d paths" % (fn, len(G.seq_nodes()), len(G.paths)))
 
 
 if __name__ == "__main__":

@@ -771,7 +771,7 @@ __global__ __launch_bounds__(TB) void k_casm_emit(const CmRoot *__restrict__ roo
 // raises a flag, whoever sees the flag stops, and the cascade gives up as it used to -- within a millisecond, not after 10^12 comparisons.
 struct CmBig { int64_t off, offL; int32_t n, id; };      // (off: where its arrays start among the rebuilt ones; offL: where its suffixes start in the sort)
 constexpr int BIG_GROUP = 256;                 // (homologues: one per sample; repeats inside one sub-index on top)
-constexpr int64_t BIG_STEPS = (int64_t)1 << 15;      // eight-byte steps a suffix may spend on its comparisons: 256 KB
+constexpr int64_t BIG_STEPS = (int64_t)1 << 13;      // eight-byte steps a suffix may spend on its comparisons: 64 KB
 __device__ inline u64 cm_ld8(const uint8_t *p) { u64 a; __builtin_memcpy(&a, p, 8); return a; }
 __global__ __launch_bounds__(TB) void k_casmb_keys(const CmBig *__restrict__ roots, const CmSlice *__restrict__ slices, CmTabs t, int k, const uint8_t *__restrict__ T0, int kb,
                                                    u64 *__restrict__ keys, u64 *__restrict__ vals) {

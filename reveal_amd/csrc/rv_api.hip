@@ -688,13 +688,11 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     if (ub_out) ub_out->clear();
     if (h->nsamples < 2) { rv_set_error("multi scan needs at least two samples"); return -1; }
     if (mems) {
-        /* reveal.c:292-434 by one wavefront (rv_mems.hip).  The sample census of an interval is a 64-bit mask there. */
+        /* reveal.c:292-434, a stack machine per run of LCP values of minl and more (rv_mems.hip).  The sample census of an interval is a 64-bit mask there. */
         if (h->nsamples > 64) { rv_set_error("getmultimems: more than 64 samples not supported yet"); return -1; }
         if (m <= 1) return 0;
         hipStream_t q = h->ws.stream;
-        DBuf &bst = h->ws.misc[11], &brec = h->ws.misc[13], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
-        const int64_t g_cap = (int64_t)h->maxlcp + 16;      // the stack holds strictly increasing LCP values
-        RV_TRY(bst.reserve((size_t)g_cap * 12 + 64));
+        DBuf &brec = h->ws.misc[13], &bso = h->ws.misc[6], &bpos = h->ws.misc[7];
         size_t rcap = (size_t)std::max<int64_t>(4096, m / 16), mcap = (size_t)std::max<int64_t>(8192, m / 2);
         for (int attempt = 0; attempt < 2; attempt++) {
             RV_TRY(brec.reserve(64 + rcap * 16 + 64));
@@ -703,9 +701,8 @@ int rv_run_multi_scan(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
             uint8_t *rb = brec.as<uint8_t>();
             unsigned long long *d_out = (unsigned long long *)rb;
             int64_t *rec_first = (int64_t *)(rb + 64); u32 *rec_l = (u32 *)(rec_first + rcap); int32_t *rec_c = (int32_t *)(rec_l + rcap);
-            int64_t *g_lb = bst.as<int64_t>(); u32 *g_lcp = (u32 *)(g_lb + g_cap);
             int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
-            RV_TRY(rv_multimems_launch(h->ws, SA, LCP, BWT, m, h->dNsep.as<sa_t>(), h->nsamples, minl, minn, g_lcp, g_lb, g_cap, rec_l, rec_c, rec_first,
+            RV_TRY(rv_multimems_launch(h->ws, SA, LCP, BWT, m, h->dNsep.as<sa_t>(), h->nsamples, minl, minn, (u32)std::min<int64_t>(h->maxlcp, 0xfffffff0ll), rec_l, rec_c, rec_first,
                                        bso.as<uint16_t>(), bpos.as<sa_t>(), rcap, mcap, d_out));
             h->prof.end(q, id);
             unsigned long long res[3] = {0, 0, 0};

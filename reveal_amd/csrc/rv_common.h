@@ -332,7 +332,7 @@ struct Workspace {
     DBuf scan_tmp[4];      // block sums of the multi-level scan
     DBuf rs_hist;          // radix sort: per-block digit histograms
     DBuf rs_digits;        // radix sort: the next pass' digit of every key, a byte each
-    DBuf misc[16];
+    DBuf misc[20];
     DBuf sa[32];           // SA-build scratch, kept between construct() calls
     HBuf hpin;             // pinned landing zone of rv_read_back
     hipEvent_t ev_rb = nullptr;

@@ -48,7 +48,7 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 
 // getmultimems (reveal.c:292-434) replayed by one wavefront (rv_mems.hip); counts beyond the capacities are still counted
 int rv_multimems_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int nsamples, int minl, int minn,
-                        u32 *g_lcp, int64_t *g_lb, int64_t g_cap, u32 *rec_l, int32_t *rec_c, int64_t *rec_first, uint16_t *so, sa_t *pos,
+                        u32 maxlcp, u32 *rec_l, int32_t *rec_c, int64_t *rec_first, uint16_t *so, sa_t *pos,
                         unsigned long long rec_cap, unsigned long long mem_cap, unsigned long long *out);
 
 // Built-in picker for more than two samples: per sub-index the longest match present in every one of its samples

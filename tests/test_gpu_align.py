@@ -2,6 +2,8 @@
 CPU oracle: every sub-index visited must have the same intervals, size, scan result,
 chosen match and child SA/LCP arrays (reveallib/reveal.c:731-1338).  The GPU visits
 level by level, the oracle LIFO; records are matched by (depth, smallest interval begin)."""
+import random
+
 import numpy as np
 import pytest
 
@@ -135,6 +137,55 @@ def test_getmultimems_synthetic_and_two_samples():
     pair = feed(mod(False).index(), seqs[:2])
     pair.construct()
     assert pair.getmultimems(minlength=20, minn=2) == []
+
+
+def test_getmultimems_runs_of_every_kind():
+    """rv_mems.hip round 5: a stack machine per run of LCP values of minl and more -- a thread for the short ones, a wavefront for those of
+    more than 2048 ranks or deeper than a thread's stack.  Random families of 3-6 samples with what makes runs long, deep and private to
+    one sample (the `continue` of reveal.c:340-342): homopolymers, tandem arrays, copies inside one sample, an N run, a repeated sample;
+    small minl (long runs everywhere) and minl = 1 (the whole index is a handful of runs)"""
+    rng = random.Random(99)
+    rnd = lambda n: "".join(rng.choice("ACGT") for _ in range(n))
+    cases = 0
+    for case in range(14):
+        k = rng.choice([3, 3, 4, 5, 6])
+        L = rng.choice([1500, 6000, 20000])
+        base = rnd(L)
+        seqs = []
+        for s in range(k):
+            v = list(base)
+            for p in range(len(v)):
+                if rng.random() < 0.01:
+                    v[p] = rng.choice("ACGT")
+            v = "".join(v)
+            kind = rng.randrange(6)
+            at = rng.randrange(len(v))
+            if kind == 0:
+                v = v[:at] + rng.choice("ACGT") * rng.choice([40, 700, 5000]) + v[at:]            # a homopolymer: one run, as deep as it is long
+            elif kind == 1:
+                v = v[:at] + rnd(rng.randint(2, 30)) * rng.choice([5, 60, 400]) + v[at:]           # a tandem array
+            elif kind == 2:
+                u = rnd(rng.choice([30, 300]))
+                for _ in range(rng.choice([2, 6, 40])):                                            # copies private to this sample
+                    q = rng.randrange(len(v)); v = v[:q] + u + v[q:]
+            elif kind == 3:
+                v = v[:at] + "N" * rng.choice([3, 50, 3000]) + v[at:]
+            seqs.append(v)
+        if rng.random() < 0.3:
+            seqs[-1] = seqs[0]
+        T, nsep, nodes = assemble(seqs)
+        sa64 = case % 5 == 4
+        O = oracle(sa64)
+        c = O.construct(T, nsep, k)
+        idx = feed(mod(sa64).index(), seqs)
+        idx.construct()
+        for minl, minn in ((20, 2), (rng.choice([3, 6, 12]), rng.choice([2, 3])), (1, 2), (30, k)):
+            ref = csr_tuples(*O.getmultimums(c["tbuf"], c["SA"], c["LCP"], c["SO"], nsep, k, minl, minn, mems=True))
+            got = idx.getmultimems(minlength=minl, minn=minn)
+            assert len(got) == len(ref), (case, k, minl, minn)
+            assert got == ref, (case, k, minl, minn)
+            cases += 1
+    assert cases == 56
 
 
 @pytest.mark.parametrize("par_min", [0, 64, 1000])

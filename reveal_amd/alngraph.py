@@ -341,6 +341,7 @@ class NativeGraph:
     def __init__(self, G, root_nodes, an_l, an_off, an_pos):
         import numpy as np
         from . import _lib
+        self._g = None
         k = len(root_nodes)
         if len(G.startnodes) != k or len(G.endnodes) != k or any(G.aligned.get(tuple(n)) != 0 for n in root_nodes) or len(G.aligned) != k:
             raise ValueError("NativeGraph: the graph is not the FASTA reader's graph of these sequences")
@@ -359,7 +360,7 @@ class NativeGraph:
             raise RuntimeError(why.decode())
 
     def close(self):
-        if self._g:
+        if getattr(self, "_g", None):
             self._dll.rv_graph_free(self._g)
             self._g = None
 

@@ -144,8 +144,7 @@ struct rv_graph {
     }
     void finish() {
         order.clear();
-        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);
-        std::sort(order.begin(), order.end(), [&](int a, int b) { return nodes[(size_t)a].order < nodes[(size_t)b].order; });
+        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);      // (a node's number IS its creation order: new_node hands both out together)
         edge_no.assign(edges.size(), -1);
         int ne = 0;
         for (int x : order) for (int e : nodes[(size_t)x].succ) edge_no[(size_t)e] = ne++;
@@ -275,6 +274,13 @@ int rv_graph_prune(rv_graph *g, const char *T) {
     return 0;
 }
 
+static inline void put_int(std::string &o, int v) {
+    char b[16]; int n = 0;
+    if (v == 0) b[n++] = '0';
+    while (v > 0) { b[n++] = (char)('0' + v % 10); v /= 10; }
+    while (n > 0) o.push_back(b[--n]);
+}
+
 /* utils.py:710-839 write_gfa as reveal_amd/alngraph.py writes GFA1: H, then per sequence node (numbered from 1 in dictionary order) its S line -- the text of
  * its interval, upper-cased when aligned -- and an L line per link to a sequence node, then a P line per path (names[0 .. npaths), path id = position),
  * walked from its start sentinel.  The text stays with the graph until it is freed; *out points at it, the return value is its length. */
@@ -287,11 +293,15 @@ int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *
     for (int x : g->order) if (nodes[(size_t)x].aligned >= 0) ident[(size_t)x] = ++nid;
     o += "H\tVN:Z:1.0\tCL:Z:"; o += cmdline ? cmdline : ""; o += "\n";
     char buf[96];
+    {
+        size_t need = 256;
+        for (int x : g->order) { const GNode &n = nodes[(size_t)x]; if (n.aligned >= 0) need += (size_t)(n.e - n.b) + 16 + 40 * n.succ.size() + 24 * n.off.size(); }
+        o.reserve(need);
+    }
     for (int x : g->order) {
         const GNode &n = nodes[(size_t)x];
         if (n.aligned < 0) continue;
-        int w = snprintf(buf, sizeof buf, "S\t%d\t", ident[(size_t)x]);
-        o.append(buf, (size_t)w);
+        o += "S\t"; put_int(o, ident[(size_t)x]); o += '\t';
         const size_t at = o.size();
         o.append(T + n.b, (size_t)(n.e - n.b));
         if (n.aligned > 0)
@@ -300,8 +310,7 @@ int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *
         for (int e : n.succ) {
             const int v = edges[(size_t)e].v;
             if (nodes[(size_t)v].aligned < 0) continue;
-            w = snprintf(buf, sizeof buf, "L\t%d\t+\t%d\t+\t0M\n", ident[(size_t)x], ident[(size_t)v]);
-            o.append(buf, (size_t)w);
+            o += "L\t"; put_int(o, ident[(size_t)x]); o += "\t+\t"; put_int(o, ident[(size_t)v]); o += "\t+\t0M\n";
         }
     }
     // the start sentinels in the reader's order: sample s' is node 3 s of the replay

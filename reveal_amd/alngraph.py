@@ -439,12 +439,20 @@ class NativeGraph:
         seq_keep = {n: G.seq[n] for n in G.seq if not isinstance(n, tuple)}
         offsets, aligned, succ, pred = {}, {}, {}, {}
         sptrl, stol, sedl, pptrl, pfrl, pedl = sptr.tolist(), sto.tolist(), sed.tolist(), pptr.tolist(), pfr.tolist(), ped.tolist()
+        # (whole lists at once where a loop body per node is not needed: the keys of all links, the pairs of all offsets)
+        skeys = [(names[v], "+", "+") for v in stol[:ne]]
+        pkeys = [(names[u], "+", "+") for u in pfrl[:ne]]
+        ssets = [sets[e] for e in sedl[:ne]]
+        psets = [sets[e] for e in pedl[:ne]]
+        opairs = list(zip(osidl[:no], ovall[:no]))
         for i, name in enumerate(names):
-            offsets[name] = dict(zip(osidl[optrl[i]:optrl[i + 1]], ovall[optrl[i]:optrl[i + 1]]))
-            if nall[i] >= 0:
-                aligned[name] = nall[i]
-            succ[name] = {(names[stol[j]], "+", "+"): sets[sedl[j]] for j in range(sptrl[i], sptrl[i + 1])}
-            pred[name] = {(names[pfrl[j]], "+", "+"): sets[pedl[j]] for j in range(pptrl[i], pptrl[i + 1])}
+            a, b = optrl[i], optrl[i + 1]
+            offsets[name] = dict(opairs[a:b])
+            a, b = sptrl[i], sptrl[i + 1]
+            succ[name] = dict(zip(skeys[a:b], ssets[a:b]))
+            a, b = pptrl[i], pptrl[i + 1]
+            pred[name] = dict(zip(pkeys[a:b], psets[a:b]))
+        aligned = {name: al for name, al in zip(names, nall) if al >= 0}
         G.offsets, G.aligned, G.succ, G.pred, G.seq = offsets, aligned, succ, pred, seq_keep
         G._begins = SortedList(sorted(b for b, al in zip(nbl, nall) if al >= 0))
         G._end_of = {b: e for b, e, al in zip(nbl, nel, nall) if al >= 0}

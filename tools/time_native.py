@@ -3,7 +3,7 @@
 library, the anchors' surgery / prune_nodes / the GFA text behind the ABI (alngraph.NativeGraph), and -- for comparison -- the same graph work in
 Python (rem.replay_anchors_fast, AlnGraph.prune_nodes, write_gfa).  usage (GPU box): python tools/time_native.py [L=5000000] [genomes=5] [--python]"""
 import sys, os, time, tempfile, pathlib
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from reveal_amd import rem, schemes, synth, alngraph, reveallib
 argv = [a for a in sys.argv[1:] if not a.startswith("--")]
 L = int(argv[0]) if argv else 5000000

@@ -155,3 +155,31 @@ def test_anchor_outside_the_graph_is_refused(tmp_path, refmod):
     G, roots = fresh(files, refmod)
     with pytest.raises(RuntimeError, match="no node"):
         alngraph.NativeGraph(G, roots, np.array([30], np.uint32), np.array([0, 2], np.int64), np.array([10, roots[0][1]], np.int64))
+
+
+def test_node_begins_list():
+    """alngraph._Begins: the largest begin <= a position, under insertions, against bisect on a plain list"""
+    import bisect
+    rng = random.Random(3)
+    for trial in range(60):
+        B = alngraph._Begins(rng.sample(range(100000), rng.choice([0, 1, 5, 600, 3000])))
+        ref = sorted(B)
+        for _ in range(2000):
+            if rng.random() < 0.5:
+                x = rng.randrange(100000)
+                if x not in ref:
+                    B.add(x)
+                    bisect.insort(ref, x)
+            q = rng.randrange(-5, 100005)
+            j = bisect.bisect_right(ref, q)
+            assert B.pred(q) == (ref[j - 1] if j else None), (trial, q)
+        assert list(B) == ref and len(B) == len(ref)
+
+
+def test_csr_to_tuples():
+    """_index._csr_to_tuples: the lists the scans return (reveal.c: (length, count, ((sample, position), ...)) per match) from the C ABI's arrays"""
+    from reveal_amd._index import _csr_to_tuples
+    got = _csr_to_tuples(2, np.array([5, 7], np.uint32), np.array([2, 3], np.int32), np.array([0, 2, 5], np.int64),
+                         np.array([0, 1, 0, 1, 2, 9], np.uint16), np.array([10, 20, 30, 40, 50, 99], np.int64))
+    assert got == [(5, 2, ((0, 10), (1, 20))), (7, 3, ((0, 30), (1, 40), (2, 50)))]
+    assert _csr_to_tuples(0, np.zeros(1, np.uint32), np.zeros(1, np.int32), np.zeros(1, np.int64), np.zeros(1, np.uint16), np.zeros(1, np.int64)) == []

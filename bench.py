@@ -812,10 +812,17 @@ def main():
             # assembled text, once per input; value_incl_upload charges it to every step
             "upload_ms": upload_ms,
             "value_incl_upload": total_bases * args.steps / (tmax + args.steps * upload_ms / 1e3) / 1e6,
-            "roofline": {"bound": "hbm", "kernel": "k_scan_" + ("multi" if args.genomes > 2 else "pair"),
+            "roofline": {"bound": "hbm", "kernel": "k_full_scan" if args.genomes > 2 else "k_scan_pair",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_source, "launches": launches, "avg_us": (ms * 1e3 / launches) if launches else None,
                          "algorithmic_bytes_per_launch": (nbytes / launches) if launches else None,
+                         # two readings of the same launches, side by side: `frac` prices a rank at SURVEY 8(d)'s 8 B (4 B suffix + 4 B LCP value);
+                         # the kernel streams 5 B of it -- the LCP value and the BWT byte that carries the separator's side -- and gathers suffixes
+                         # for the ranks that pass only.  frac_of_bytes_streamed is what the memory system actually delivers of its peak.
+                         "frac_model_8B": achieved / HBM_PEAK_GBS,
+                         "bytes_streamed_per_rank": 5,
+                         "frac_of_bytes_streamed": achieved * 5.0 / 8.0 / HBM_PEAK_GBS,
+                         "frac_of_traffic": (traffic / (ms * 1e-3 / launches) / 1e9 / HBM_PEAK_GBS) if (traffic and launches and ms > 0 and args.genomes <= 2) else None,
                          "copy_peak": {"read_GBps": read_gbs, "copy_GBps_read_plus_write": copy_gbs, "bytes": 1 << 30,
                                        "frac_of_read_peak": (achieved / read_gbs) if read_gbs else None}},
             "breakdown_ms_per_step": breakdown,

@@ -209,6 +209,12 @@ int64_t rv_frontier_pack(rv_index *h, const int32_t *subs, int k, void *sa, void
 int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int level, int nsubs, const int64_t *meta,
                        const int64_t *node_first, const int64_t *nodes, int64_t m,
                        const void *sa, const void *lcp, const void *bwt, int on_device);
+/* rv_set_picker(h, 1, ..) runs: the seed lists of the listed sub-indices of the frontier (what the reference's children carry as skipmums,
+ * reveal.c:1157, 1180; schemes.py:321-332) travel with them -- export before the owner's frontier is replaced, import right after
+ * rv_frontier_import of the same sub-indices in the same order.  Words per sub-index: count, then per seed l, n, score, members,
+ * (sample, position) x members.  rv_frontier_seeds_export returns the number of words and writes them when cap is large enough. */
+int64_t rv_frontier_seeds_export(rv_index *h, const int32_t *subs, int k, int64_t *out, int64_t cap);
+int rv_frontier_seeds_import(rv_index *h, int nsubs, const int64_t *words, int64_t nwords);
 /* largest LCP value of the constructed index (= window of bubble_sort, reveal.c:666-727; workers need the owner's) */
 uint32_t rv_maxlcp(const rv_index *h);
 /* what the anchor cascade (rv_cascade.hip) did in the last rv_align_builtin: out[0] = 1 it decided the run / 0 the level

@@ -698,9 +698,22 @@ def make_index_type(sa64, error):
                 self._fail()
             return int(r)
 
+        def frontier_seeds(self, subs):
+            """rv_set_picker(1) runs: the seed lists the native picker left for the sub-indices `subs` of the frontier (the reference's
+            skipmums, reveal.c:1157, 1180), packed as int64 words for frontier_import(part with part["seeds"] = these)"""
+            subs = np.ascontiguousarray(subs, dtype=np.int32)
+            need = self._dll.rv_frontier_seeds_export(self._h, subs.ctypes.data, len(subs), None, 0)
+            if need < 0:
+                self._fail()
+            out = np.zeros(max(int(need), 1), dtype=np.int64)
+            if self._dll.rv_frontier_seeds_export(self._h, subs.ctypes.data, len(subs), out.ctypes.data, int(need)) != need:
+                self._fail()
+            return out[:int(need)]
+
         def frontier_import(self, part, sa, lcp, bwt, minl=20, minn=2, maxlcp=None, trace=False):
-            """make `part` (a subset of a frontier() dict: level, meta, node_first, nodes) with its packed segments the
-            frontier of this index.  An index that only holds its samples (no construct) becomes a worker."""
+            """make `part` (a subset of a frontier() dict: level, meta, node_first, nodes; optionally "seeds" = frontier_seeds() of the
+            same sub-indices) with its packed segments the frontier of this index.  An index that only holds its samples (no construct)
+            becomes a worker."""
             meta = np.ascontiguousarray(part["meta"], dtype=np.int64).reshape(-1, 6)
             nf = np.ascontiguousarray(part["node_first"], dtype=np.int64); nodes = np.ascontiguousarray(part["nodes"], dtype=np.int64).reshape(-1, 2)
             m = int(meta[:, 1].sum()) if len(meta) else 0
@@ -715,6 +728,11 @@ def make_index_type(sa64, error):
                                             nodes.ctypes.data, m, ptr[0], ptr[1], ptr[2], dev) != 0:
                 self._fail()
             self._pending = True
+            seeds = part.get("seeds")
+            if seeds is not None and len(seeds) > len(meta):      # (more than the zero per sub-index of "no seeds")
+                seeds = np.ascontiguousarray(seeds, dtype=np.int64)
+                if self._dll.rv_frontier_seeds_import(self._h, len(meta), seeds.ctypes.data, len(seeds)) != 0:
+                    self._fail()
 
         def align_builtin_resume(self):
             """finish the run started by align_builtin_until / frontier_import; result as align_builtin"""

@@ -81,6 +81,8 @@ SYMBOLS = {
     "rv_frontier_export": (_I, [V, V, V, V]),
     "rv_frontier_pack": (_L, [V, V, _I, V, V, V, _I]),
     "rv_frontier_import": (_I, [V, _I, _I, ctypes.c_uint32, _I, _I, V, V, V, _L, V, V, V, _I]),
+    "rv_frontier_seeds_export": (_L, [V, V, _I, V, _L]),
+    "rv_frontier_seeds_import": (_I, [V, _I, V, _L]),
     "rv_maxlcp": (ctypes.c_uint32, [V]),
     "rv_cascade_info": (ctypes.c_int, [V, V]),
     "rv_cascade_why": (ctypes.c_char_p, [V]),

@@ -2175,6 +2175,8 @@ static int install_frontier(rv_index *h, int level, int nsubs, const int64_t *me
     a->scanned = false; a->d_err = nullptr;
     a->dec.reset(lv.size());
     a->skip_scan.assign((size_t)lv.size(), 0);
+    // (seed lists are indexed by the sub-indices of the frontier they were made for: rv_frontier_seeds_import brings the new frontier's)
+    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear();
     return 0;
 }
 
@@ -2203,12 +2205,83 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         a->par_min_cur = (h->ws.opt.bubble_par_min >= 0 ? h->ws.opt.bubble_par_min : bubble_par_default(a->multi));
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
-        a->full_only = !a->trace_on;
+        a->full_only = !a->trace_on && a->picker == 0;      // (as builtin_setup: the chain picker wants every match of a sub-index)
+        if (a->picker == 1) {
+            if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
+            if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
+        }
+        a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = 0;
         a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
         RV_TRY(builtin_leaf_setup(h));
     }
     RV_TRY(install_frontier(h, level, nsubs, meta, node_first, nodes, m, sa, lcp, bwt, on_device));
     h->al->running = true;
+    return 0;
+}
+
+/* rv_set_picker(1): the seed lists the parents' picker calls left for the listed sub-indices of the frontier (schemes.py:321-332; reveal.c:1157, 1180
+ * hands them to the children as skipmums) as int64 words -- per sub-index: count, then per seed l, n, score, members, (sample, position) x members.
+ * Returns the number of words; they are written when out holds that many (cap).  A frontier whose sub-indices carry no seeds: a zero per sub-index. */
+int64_t rv_frontier_seeds_export(rv_index *h, const int32_t *subs, int k, int64_t *out, int64_t cap) {
+    if (need_align(h)) return -1;
+    const Align *a = h->al;
+    const int ns = a->lv.size();
+    int64_t need = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        int64_t at = 0;
+        for (int i = 0; i < k; i++) {
+            const int s = subs[i];
+            if (s < 0 || s >= ns) { rv_set_error("sub-index %d out of range", s); return -1; }
+            const Align::SeedList *sd = (s < (int)a->seeds_cur.size() && a->seeds_cur[(size_t)s].size() > 0) ? &a->seeds_cur[(size_t)s] : nullptr;
+            if (pass) out[at] = sd ? (int64_t)sd->size() : 0;
+            at++;
+            if (!sd) continue;
+            for (size_t r = 0; r < sd->size(); r++) {
+                const int64_t mem = sd->off[r + 1] - sd->off[r];
+                if (pass) {
+                    out[at] = sd->l[r]; out[at + 1] = sd->n[r]; out[at + 2] = sd->score[r]; out[at + 3] = mem;
+                    for (int64_t q2 = 0; q2 < mem; q2++) { out[at + 4 + 2 * q2] = sd->so[(size_t)(sd->off[r] + q2)]; out[at + 5 + 2 * q2] = sd->pos[(size_t)(sd->off[r] + q2)]; }
+                }
+                at += 4 + 2 * mem;
+            }
+        }
+        need = at;
+        if (!out || cap < need) break;
+    }
+    return need;
+}
+
+/* ... and their way into the handle that took those sub-indices over (rv_frontier_import first, same sub-indices in the same order): a seeded
+ * sub-index is not scanned, its picker call takes the middle of its list (reveal.c:802, 830-837; schemes.py:346-351) */
+int rv_frontier_seeds_import(rv_index *h, int nsubs, const int64_t *words, int64_t nwords) {
+    RV_TRY(need_align(h));
+    Align *a = h->al;
+    if (!a->running || nsubs != a->lv.size()) { rv_set_error("rv_frontier_seeds_import: %d seed lists for a frontier of %d sub-indices", nsubs, a->lv.size()); return -1; }
+    if (a->picker != 1) { rv_set_error("rv_frontier_seeds_import: seeds belong to the native picker (rv_set_picker)"); return -1; }
+    std::vector<Align::SeedList> nxt((size_t)nsubs);
+    int64_t at = 0;
+    for (int s = 0; s < nsubs; s++) {
+        if (at >= nwords) { rv_set_error("rv_frontier_seeds_import: truncated seed lists"); return -1; }
+        const int64_t cnt = words[at++];
+        if (cnt < 0) { rv_set_error("rv_frontier_seeds_import: bad seed count"); return -1; }
+        for (int64_t r = 0; r < cnt; r++) {
+            if (at + 4 > nwords) { rv_set_error("rv_frontier_seeds_import: truncated seed lists"); return -1; }
+            const int64_t l = words[at], n = words[at + 1], sc = words[at + 2], mem = words[at + 3];
+            if (mem < 0 || mem > h->nsamples || at + 4 + 2 * mem > nwords) { rv_set_error("rv_frontier_seeds_import: bad seed record"); return -1; }
+            std::vector<uint16_t> so((size_t)mem); std::vector<int64_t> pos((size_t)mem);
+            for (int64_t q2 = 0; q2 < mem; q2++) {
+                so[(size_t)q2] = (uint16_t)words[at + 4 + 2 * q2]; pos[(size_t)q2] = words[at + 5 + 2 * q2];
+                if (pos[(size_t)q2] < 0 || pos[(size_t)q2] + l > h->nT) { rv_set_error("rv_frontier_seeds_import: seed outside the text"); return -1; }
+            }
+            nxt[(size_t)s].push((u32)l, (int32_t)n, so.data(), pos.data(), (int)mem, sc);
+            at += 4 + 2 * mem;
+        }
+        if (cnt > 0) {
+            if ((int)a->skip_scan.size() != nsubs) a->skip_scan.assign((size_t)nsubs, 0);
+            a->skip_scan[(size_t)s] = 1;
+        }
+    }
+    a->seeds_cur.swap(nxt);
     return 0;
 }
 

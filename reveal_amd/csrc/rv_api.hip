@@ -146,7 +146,10 @@ rv_index *rv_clone(rv_index *h) {
     if (rv_need_sai(h)) return nullptr;
     rv_index *c = rv_new(h->device);
     if (!c) return nullptr;
-    c->T = h->T; c->nsep = h->nsep; c->nodes = h->nodes; c->nsamples = h->nsamples; c->n = h->n; c->nT = h->nT; c->rc = h->rc;
+    try { c->T = h->T; c->nsep = h->nsep; c->nodes = h->nodes; }
+    catch (...) { rv_set_error("copy of the index: out of host memory"); rv_free(c); return nullptr; }
+    if (c->T.size() != h->T.size()) { rv_free(c); return nullptr; }      // (HostText::resize failed and said why)
+    c->nsamples = h->nsamples; c->n = h->n; c->nT = h->nT; c->rc = h->rc;
     c->maxlcp = h->maxlcp; c->sa_stats = h->sa_stats; c->text_dirty = true;
     c->ws.opt = h->ws.opt;
     const int64_t n = h->n;
@@ -209,12 +212,16 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
         const int nt = 4;
         uint64_t part[nt] = {0, 0, 0, 0};
         std::thread th[nt];
+        bool started[nt] = {false, false, false, false};
         for (int t = 1; t < nt; t++) {
             const int64_t lo = len / nt * t, hi = t + 1 == nt ? len : len / nt * (t + 1);
-            th[t] = std::thread([&, t, lo, hi]() { part[t] = copy_check(lo, hi); });
+            // (no exception may leave through the C ABI: a thread the system will not start -- std::system_error at the thread limit -- has its
+            //  part copied by this one)
+            try { th[t] = std::thread([&, t, lo, hi]() { part[t] = copy_check(lo, hi); }); started[t] = true; }
+            catch (...) { part[t] = copy_check(lo, hi); }
         }
         part[0] = copy_check(0, len / nt);
-        for (int t = 1; t < nt; t++) th[t].join();
+        for (int t = 1; t < nt; t++) if (started[t]) th[t].join();
         for (int t = 0; t < nt; t++) acc |= part[t];
     } else {
         acc = copy_check(0, len);
@@ -232,7 +239,8 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     h->constructed = false; h->text_only = false;      /* SA / LCP / BWT in HBM are sized for the old text (the getters would read past them) */
     if (begin) *begin = s;
     if (end) *end = h->n - 1;
-    h->nodes.push_back(RvIntv{s, h->n - 1});
+    try { h->nodes.push_back(RvIntv{s, h->n - 1}); }
+    catch (...) { rv_set_error("addsequence: out of host memory"); return -1; }
     return 0;
 }
 
@@ -798,11 +806,11 @@ int rv_run_multi_pick(rv_index *h, const sa_t *SA, const lcp_t *LCP, const uint8
     if (bcand.cap < 65536 * RV_MULTI_CAND_BYTES) RV_TRY(bcand.reserve((size_t)std::max<int64_t>(65536, m / 64) * RV_MULTI_CAND_BYTES));
     for (int attempt = 0; attempt < 2; attempt++) {
         const size_t ccap = bcand.cap / RV_MULTI_CAND_BYTES;
-        int id = h->prof.begin(q, RV_K_SCAN_MULTI, (double)m * (sizeof(sa_t) + sizeof(lcp_t)));
+        hipEvent_t ev_a, ev_b;      // the streaming kernel alone, as for the pair scan (8 B per rank)
+        (void)h->prof.attach(RV_K_SCAN_MULTI, (double)m * 8.0, &ev_a, &ev_b);
         RV_TRY(rv_multi_pick_launch(h->ws, SA, LCP, m, BWT, h->dNsep.as<sa_t>(), W, minl, minn, d_sub_start, d_sub_want, nsubs, d_tile_sub,
                                     bbest.as<unsigned long long>(), bl.as<u32>(), bpos.as<sa_t>(), (RvMultiCand *)bcand.p,
-                                    (u32)std::min<size_t>(ccap, 0xffffffffu), bcnt.as<u32>()));
-        h->prof.end(q, id);
+                                    (u32)std::min<size_t>(ccap, 0xffffffffu), bcnt.as<u32>(), ev_a, ev_b));
         u32 ncand = 0;
         pick_pos.resize((size_t)nsubs * W);
         {   // the level's one round trip: three arrays into pinned memory, one polled event (pageable destinations are staged copy by copy)

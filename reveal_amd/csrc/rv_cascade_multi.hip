@@ -967,9 +967,13 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     hipLaunchKernelGGL(k_casm_so, dim3((unsigned)ceil_div(n, (int64_t)TB * SO_PER)), dim3(TB), 0, q, SA, n, nsep, k, bso.as<uint8_t>());
     RV_LAUNCH_CHECK();
     {
-        int pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * (sizeof(sa_t) + sizeof(lcp_t)));
+        hipEvent_t ev_a = nullptr, ev_b = nullptr;      // 8 B per rank; the events ride on the kernel's own dispatch
+        int pid = -1;
+        if (!ws.opt.scan_v1) (void)h->prof.attach(RV_K_SCAN_MULTI, (double)n * 8.0, &ev_a, &ev_b);
+        else pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * 8.0);
 #define RV_SCAN_(KT) hipLaunchKernelGGL(k_casm_scan<KT>, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt)
-        switch (k) {
+        if (!ws.opt.scan_v1) RV_TRY(rv_full_list_launch(ws, SA, LCP, BWT, n, nsep, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt, CM_REGIONS, ev_a, ev_b));
+        else switch (k) {      // (RV_SCAN_V1: the kernel that stages a workgroup's ranks in LDS, for comparison)
             case 3: RV_SCAN_(3); break; case 4: RV_SCAN_(4); break; case 5: RV_SCAN_(5); break; case 6: RV_SCAN_(6); break; case 8: RV_SCAN_(8); break;
             case 10: RV_SCAN_(10); break; case 12: RV_SCAN_(12); break; case 16: RV_SCAN_(16); break; default: RV_SCAN_(0); break;
         }

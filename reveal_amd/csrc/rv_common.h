@@ -103,7 +103,8 @@ void rv_set_error(const char *fmt, ...);
     X(casm_big_root, "RV_CASM_BIG_ROOT", 1 << 22) \
     X(casm_big_total, "RV_CASM_BIG_TOTAL", 1 << 26) \
     X(lock_any, "RV_LOCK_ANY", 0) \
-    X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536)
+    X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536) \
+    X(scan_v1, "RV_SCAN_V1", 0)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)

@@ -15,9 +15,13 @@
 #include <cstdio>
 #include <cstring>
 #include <deque>
+#include <exception>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
+
+void rv_set_error(const char *fmt, ...);      // rv_api.hip
 
 namespace {
 
@@ -153,8 +157,10 @@ struct rv_graph {
 
 extern "C" {
 
-rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
-    rv_graph *g = new rv_graph();
+// (no exception may leave through the C ABI: bad_alloc from the vectors' growth becomes NULL / -1 and rv_last_error's text)
+static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
+    std::unique_ptr<rv_graph> own(new rv_graph());      // (freed when the surgery below throws)
+    rv_graph *g = own.get();
     g->nseq = nseq;
     // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
     for (int s = 0; s < nseq; s++) {
@@ -168,13 +174,18 @@ rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, in
         const int64_t l = (int64_t)an_l[a];
         for (int64_t k = an_off[a]; k < an_off[a + 1]; k++) {
             const int x = g->node_at(an_pos[k]);
-            if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; g->finish(); return g; }
+            if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; g->finish(); return own.release(); }
             mns.push_back(g->breaknode(x, an_pos[k], l));
         }
         if (!mns.empty()) g->mergenodes(mns);
     }
     g->finish();
-    return g;
+    return own.release();
+}
+rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
+    try { return graph_replay(nseq, begin, end, na, an_l, an_off, an_pos); }
+    catch (const std::exception &e) { rv_set_error("rv_graph_replay: %s", e.what()); return nullptr; }
+    catch (...) { rv_set_error("rv_graph_replay: failed"); return nullptr; }
 }
 
 const char *rv_graph_error(const rv_graph *g) { return g->err.empty() ? nullptr : g->err.c_str(); }
@@ -192,7 +203,7 @@ int rv_graph_sizes(const rv_graph *g, int64_t *out) {
 
 /* nodes in dictionary order: (b, e, aligned; -1 = sentinel: b = sample, e = 0 start / 1 end); offsets as CSR; per node its links forwards and backwards as CSR of
  * (neighbour's number, edge number) in dictionary order; per edge its path ids as CSR */
-int rv_graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t *node_aligned, int64_t *off_ptr, int32_t *off_sid, int64_t *off_val,
+static int graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t *node_aligned, int64_t *off_ptr, int32_t *off_sid, int64_t *off_val,
                     int64_t *succ_ptr, int32_t *succ_to, int32_t *succ_edge, int64_t *pred_ptr, int32_t *pred_from, int32_t *pred_edge, int64_t *edge_ptr, int32_t *edge_paths) {
     std::vector<int> number(g->nodes.size(), -1);
     for (size_t i = 0; i < g->order.size(); i++) number[(size_t)g->order[i]] = (int)i;
@@ -225,7 +236,7 @@ int rv_graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t 
  * that hang on one parent (child) and have no other are merged.  T = the index text after the run (matched text lower-cased: an aligned and an
  * unaligned sibling spell differently).  Which sibling survives, and where the survivor stands among its neighbours' links, follows the dictionary
  * order -- kept here. */
-int rv_graph_prune(rv_graph *g, const char *T) {
+static int graph_prune(rv_graph *g, const char *T) {
     auto &nodes = g->nodes; auto &edges = g->edges;
     for (;;) {
         bool merged_any = false;
@@ -284,7 +295,7 @@ static inline void put_int(std::string &o, int v) {
 /* utils.py:710-839 write_gfa as reveal_amd/alngraph.py writes GFA1: H, then per sequence node (numbered from 1 in dictionary order) its S line -- the text of
  * its interval, upper-cased when aligned -- and an L line per link to a sequence node, then a P line per path (names[0 .. npaths), path id = position),
  * walked from its start sentinel.  The text stays with the graph until it is freed; *out points at it, the return value is its length. */
-int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out) {
+static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out) {
     auto &nodes = g->nodes; auto &edges = g->edges;
     std::string &o = g->gfa;
     o.clear();
@@ -341,6 +352,17 @@ int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *
     *out = o.data();
     return (int64_t)o.size();
 }
+
+#define RV_GRAPH_GUARD(call)                                                                         \
+    try { return call; }                                                                             \
+    catch (const std::exception &e) { rv_set_error("%s: %s", __func__, e.what()); return -1; }       \
+    catch (...) { rv_set_error("%s: failed", __func__); return -1; }
+int rv_graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int8_t *node_aligned, int64_t *off_ptr, int32_t *off_sid, int64_t *off_val,
+                    int64_t *succ_ptr, int32_t *succ_to, int32_t *succ_edge, int64_t *pred_ptr, int32_t *pred_from, int32_t *pred_edge, int64_t *edge_ptr, int32_t *edge_paths) {
+    RV_GRAPH_GUARD(graph_export(g, node_b, node_e, node_aligned, off_ptr, off_sid, off_val, succ_ptr, succ_to, succ_edge, pred_ptr, pred_from, pred_edge, edge_ptr, edge_paths))
+}
+int rv_graph_prune(rv_graph *g, const char *T) { RV_GRAPH_GUARD(graph_prune(g, T)) }
+int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out) { RV_GRAPH_GUARD(graph_gfa(g, T, npaths, names, cmdline, out)) }
 
 void rv_graph_free(rv_graph *g) { delete g; }
 

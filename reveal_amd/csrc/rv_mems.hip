@@ -127,17 +127,21 @@ __global__ __launch_bounds__(TB) void k_mems_runs(MemsArgs A) {
     for (int64_t i = lo; i < hi; i++) {
         const u32 v = (u32)A.LCP[i];
         if (v >= A.minl_e && (i == 1 || prev < A.minl_e)) {
-            if (!run_thread<WRITE>(A, i, nrec, nmem)) {
-                if (!WRITE) {
-                    const u32 x = (u32)atomicAdd(&A.out[3], 1ull);
-                    if (x < A.long_cap) A.long_s[x] = i;
-                } else {      // its counts are known: where it goes, and past it
-                    u32 a = 0, b = A.nlong;
-                    while (a < b) { const u32 mid = (a + b) >> 1; if (A.long_s[mid] < i) a = mid + 1; else b = mid; }
+            if (WRITE) {
+                // a run the count pass listed for the wavefront machine is not walked again (it would write up to 2048 ranks' records that
+                // k_mems_long rewrites at the same places, only to fail where it failed before): its counts are known -- where it goes, and past it
+                u32 a = 0, b = A.nlong;
+                while (a < b) { const u32 mid = (a + b) >> 1; if (A.long_s[mid] < i) a = mid + 1; else b = mid; }
+                if (a < A.nlong && A.long_s[a] == i) {
                     const u64 cr = A.long_rec[a], cm = A.long_mem[a];
                     A.long_rec[a] = nrec; A.long_mem[a] = nmem;
                     nrec += cr; nmem += cm;
+                } else {
+                    (void)run_thread<true>(A, i, nrec, nmem);
                 }
+            } else if (!run_thread<false>(A, i, nrec, nmem)) {
+                const u32 x = (u32)atomicAdd(&A.out[3], 1ull);
+                if (x < A.long_cap) A.long_s[x] = i;
             }
         }
         prev = v;
@@ -298,18 +302,25 @@ int rv_multimems_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const u
     DBuf &btile = ws.misc[16], &blong = ws.misc[17], &bst = ws.misc[11];
     RV_TRY(btile.reserve((size_t)(A.ntiles + 1) * 16 + 64));
     A.tile_rec = btile.as<u64>(); A.tile_mem = A.tile_rec + (A.ntiles + 1);
-    A.long_cap = (u32)std::min<int64_t>(n / 64 + 1024, 0x7fffffff);      // (runs beyond 2048 ranks: n / 2048 at most; the rest is for runs deeper than a thread's stack)
-    RV_TRY(blong.reserve((size_t)A.long_cap * 24 + 64));
-    A.long_s = blong.as<int64_t>(); A.long_rec = (u64 *)(A.long_s + A.long_cap); A.long_mem = A.long_rec + A.long_cap;
+    // the list of runs for the wavefront machine: runs beyond 2048 ranks (n / 2048 at most) and runs deeper than a thread's stack.  Some 25 ranks
+    // are enough for the latter (tandem arrays, homopolymers: up to n / 26 runs), so a count pass that finds more than the list holds is repeated
+    // with a list of that size
+    A.long_cap = (u32)std::min<int64_t>(n / 64 + 1024, 0x7fffffff);
     A.nlong = 0; A.g_lcp = nullptr; A.g_lb = nullptr; A.g_cap = 0;
-    RV_HIP(hipMemsetAsync(out, 0, 32, q));
-    RV_HIP(hipMemsetAsync(A.tile_rec + A.ntiles, 0, 8, q)); RV_HIP(hipMemsetAsync(A.tile_mem + A.ntiles, 0, 8, q));
     const unsigned grid = (unsigned)ceil_div(A.ntiles, TB);
-    hipLaunchKernelGGL(k_mems_runs<false>, dim3(grid), dim3(TB), 0, q, A);
-    RV_LAUNCH_CHECK();
     unsigned long long res[4] = {0, 0, 0, 0};
-    RV_TRY(rv_read_back(ws, res, out, sizeof res));
-    if (res[3] > A.long_cap) { rv_set_error("getmultimems: more long runs than the list holds"); return -1; }
+    for (int attempt = 0; ; attempt++) {
+        RV_TRY(blong.reserve((size_t)A.long_cap * 24 + 64));
+        A.long_s = blong.as<int64_t>(); A.long_rec = (u64 *)(A.long_s + A.long_cap); A.long_mem = A.long_rec + A.long_cap;
+        RV_HIP(hipMemsetAsync(out, 0, 32, q));
+        RV_HIP(hipMemsetAsync(A.tile_rec + A.ntiles, 0, 8, q)); RV_HIP(hipMemsetAsync(A.tile_mem + A.ntiles, 0, 8, q));
+        hipLaunchKernelGGL(k_mems_runs<false>, dim3(grid), dim3(TB), 0, q, A);
+        RV_LAUNCH_CHECK();
+        RV_TRY(rv_read_back(ws, res, out, sizeof res));
+        if (res[3] <= A.long_cap) break;
+        if (attempt || res[3] > 0x7fffffffull) { rv_set_error("getmultimems: more long runs than the list holds"); return -1; }
+        A.long_cap = (u32)res[3];
+    }
     A.nlong = (u32)res[3];
     unsigned lgrid = 0;
     if (A.nlong) {

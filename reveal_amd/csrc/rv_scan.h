@@ -37,10 +37,10 @@ int rv_pick_slots_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec 
 int rv_pair_compact_launch(Workspace &ws, const RvPairRec *slots, const RvPairRec *ovf, const u32 *tilecnt, const u32 *tileovf,
                            const u32 *tileoff, int64_t ntile, RvPairRec *out, u32 out_cap, u32 *ovf_counter, const u32 *err, u32 ovf_cap);
 
-#define RV_MULTI_TILE 256
+#define RV_MULTI_TILE 512    // ranks per tile of the multi-MUM scan = what one wave scans
 struct RvMultiRec { u32 l, n, ub, pad; };
 // Multi-MUM scan (getmultimums, reveal.c:436-580).  Records and members of
-// tile t (256 ranks) land at rec[tab.x .. +tab.y) / so,pos[tab.z .. +tab.w) in
+// tile t (512 ranks) land at rec[tab.x .. +tab.y) / so,pos[tab.z .. +tab.w) in
 // the reference's emission order; counters[0..1] must be zeroed.
 int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples,
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
@@ -57,6 +57,13 @@ int rv_multimems_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const u
 struct RvMultiCand;
 int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
                          const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub /* sub-index of rank t * RV_TSUB_TILE */,
-                         unsigned long long *best, u32 *pick_l, sa_t *pick_pos, RvMultiCand *cand, u32 cand_cap, u32 *cand_count);
+                         unsigned long long *best, u32 *pick_l, sa_t *pick_pos, RvMultiCand *cand, u32 cand_cap, u32 *cand_count,
+                         hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);      // both given: start / stop of the streaming kernel itself
 #define RV_MULTI_CAND_BYTES 16
+// Full matches of a whole index with k samples (2 <= k <= 16; the anchor cascade's root list, rv_cascade_multi.hip): every LCP interval of exactly k
+// ranks with a value of minl or more whose members are of k different samples and left-maximal.  Entry i of region r (nregions a power of two, counters
+// region_cnt[r] zeroed by the caller; entries beyond rcap are counted, not stored) lives at r * rcap + i: c_len = the value, c_pos[.. * k + s] = the
+// member of sample s.
+int rv_full_list_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int k, u32 minl,
+                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 #define RV_MULTI_REGIONS 64      // the picker's candidate list: regions with a counter each (counter r at word 64 * r, the largest count at word 64 * RV_MULTI_REGIONS)

@@ -9,13 +9,22 @@
 // and the arrays end with a virtual LCP 0, so a sub-index boundary behaves
 // exactly like the array ends of the reference's per-index loops.
 //
-// The pair scan is the roofline-judged kernel: a pure stream of 8 B per rank
-// (4 B SA + 4 B LCP, 16-byte loads per lane) plus 1 B of BWT for the
-// left-maximality test (no gathers from T).  Output is order preserving and
-// free of hot atomics: per-tile slots + a small compaction kernel.
+// The pair scan is the roofline-judged kernel.  SURVEY 8(d) prices it at 8 B per
+// rank (4 B SA + 4 B LCP); what it streams is 5 B per rank -- LCP (16-byte
+// non-temporal loads) and the BWT byte, whose bit 7 carries the side of the
+// separator -- and SA is fetched for the survivors only (no gathers from T).
+// bench.py reports both fractions (the 8-B model and the bytes moved).  Output
+// is order preserving and free of hot atomics: per-tile slots + a small
+// compaction kernel.
+//
+// The scans for more than two samples (k_full_scan, k_scan_multi) are built on
+// the same skeleton: a wave streams 512 ranks, eight per lane, the neighbours'
+// values come by shuffle, every per-rank test is a bit operation on 24-rank
+// windows, and only the few ranks that pass touch memory again.
 #include "rv_common.h"
 #include "rv_scan.h"
 #include <hip/hip_ext.h>
+#include <algorithm>
 
 namespace {
 
@@ -359,37 +368,83 @@ __device__ inline void multi_walk(const sa_t *__restrict__ SA, const lcp_t *__re
     nrec = rq; nmem = mq;
 }
 
+// The enumeration on the pair scan's skeleton: a wave streams 512 ranks (eight per lane, non-temporal 16-byte loads), the rank behind a lane's last
+// one comes by shuffle, and the ranks that close an interval at all -- LCP[u] > LCP[u+1], LCP[u] >= minl: one in `nsamples` for related genomes,
+// next to none for unrelated ones -- are listed in the wave's corner of LDS.  The lanes then take one listed rank each: a first walk counts its
+// records and members, a wave-wide prefix sum and ONE atomic per wave and list give it room in emission order, a second walk (over lines the first
+// one left in the cache) writes.  No workgroup barrier; a wave whose ranks close nothing retires after its loads.  (Before: a thread per rank, each
+// with its own 4-byte loads and both walks, 256-rank workgroups between two barriers.)
 __global__ __launch_bounds__(TB) void k_scan_multi(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
                                                    const uint8_t *__restrict__ BWT, const sa_t *__restrict__ nsep, int nsamples, int minl, int minn,
                                                    RvMultiRec *__restrict__ rec, uint16_t *__restrict__ so, sa_t *__restrict__ pos,
                                                    u32 rec_cap, u32 mem_cap, u32 *__restrict__ counters, uint4 *__restrict__ tiletab,
                                                    const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs) {
-    __shared__ u32 ws_r[TB / 64], ws_m[TB / 64];
-    __shared__ u32 s_rb, s_mb;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t u = (int64_t)blockIdx.x * TB + threadIdx.x;
-    u32 nr, nm;
-    multi_walk<false>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, nr, nm, nullptr, nullptr, nullptr, 0, 0, sub_start, sub_want, nsubs);
-    u32 ir = nr, im = nm;
+    constexpr int ITEMS = RV_MULTI_TILE / 64;
+    static_assert(ITEMS == 8, "eight ranks per lane");
+    __shared__ uint16_t s_c[TB / 64][RV_MULTI_TILE], s_ro[TB / 64][RV_MULTI_TILE];
+    __shared__ u32 s_mo[TB / 64][RV_MULTI_TILE];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wtile = (int64_t)blockIdx.x * (TB / 64) + w;
+    const int64_t wfirst = wtile * RV_MULTI_TILE;
+    if (wfirst >= m) return;
+    const int64_t i0 = wfirst + (int64_t)lane * ITEMS;
+    u32 h_nlc = 0;
+    if (wfirst + RV_MULTI_TILE < m) h_nlc = (u32)LCP[wfirst + RV_MULTI_TILE];
+    u32 lc[ITEMS + 1];
+    if (i0 + ITEMS <= m) {
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { u32 a = __shfl_up(ir, d, 64), b = __shfl_up(im, d, 64); if (lane >= d) { ir += a; im += b; } }
-    if (lane == 63) { ws_r[w] = ir; ws_m[w] = im; }
-    __syncthreads();
-    u32 br = 0, bm = 0, tr = 0, tm = 0;
+        for (int v4 = 0; v4 < ITEMS / 4; v4++) {
+            const v4i c = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(LCP + i0) + v4);
+            lc[4 * v4] = (u32)c.x; lc[4 * v4 + 1] = (u32)c.y; lc[4 * v4 + 2] = (u32)c.z; lc[4 * v4 + 3] = (u32)c.w;
+        }
+    } else {
 #pragma unroll
-    for (int k = 0; k < TB / 64; k++) { if (k < w) { br += ws_r[k]; bm += ws_m[k]; } tr += ws_r[k]; tm += ws_m[k]; }
-    if (threadIdx.x == 0) {
-        const u32 rb = tr ? atomicAdd(&counters[0], tr) : 0u;
-        const u32 mb = tm ? atomicAdd(&counters[1], tm) : 0u;
-        s_rb = rb; s_mb = mb;
-        tiletab[blockIdx.x] = make_uint4(rb, tr, mb, tm);
+        for (int k = 0; k < ITEMS; k++) lc[k] = (i0 + k < m) ? (u32)LCP[i0 + k] : 0u;
     }
-    __syncthreads();
-    if (nr) {
-        const u32 r0 = s_rb + br + (ir - nr), m0 = s_mb + bm + (im - nm);
-        u32 a2, b2;
-        multi_walk<true>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, u, a2, b2, rec + r0, so + m0, pos + m0,
-                         r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u, sub_start, sub_want, nsubs);
+    lc[ITEMS] = (u32)__shfl_down((int)lc[0], 1, 64);
+    if (lane == 63) lc[ITEMS] = h_nlc;
+    const u32 lmin = (u32)(minl > 1 ? minl : 1);
+    u32 c8 = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) c8 |= (u32)((lc[k] >= lmin) & (lc[k] > lc[k + 1])) << k;      // (rank 0 and the ranks past the end hold 0)
+    const u32 cnt = (u32)__popc(c8);
+    const u32 inc = rv_wave_incl_sum_u32(cnt);
+    const u32 tot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+    {
+        u32 at = inc - cnt, hh = c8;
+        while (hh) { const int k = __builtin_ctz(hh); hh &= hh - 1; s_c[w][at++] = (uint16_t)(lane * ITEMS + k); }
+    }
+    // (the list is read by other lanes of the same wave only: its LDS operations complete in order, the fences keep the compiler from moving them)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    u32 run_r = 0, run_m = 0, nz = 0;
+    for (u32 base = 0, round = 0; base < tot; base += 64, round++) {
+        const u32 ci = base + (u32)lane;
+        u32 nr = 0, nm = 0;
+        if (ci < tot)
+            multi_walk<false>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, wfirst + (int64_t)s_c[w][ci], nr, nm, nullptr, nullptr, nullptr, 0, 0, sub_start, sub_want, nsubs);
+        const u32 ir = rv_wave_incl_sum_u32(nr), im = rv_wave_incl_sum_u32(nm);
+        if (ci < tot) { s_ro[w][ci] = (uint16_t)(run_r + ir - nr); s_mo[w][ci] = run_m + im - nm; }
+        nz |= (u32)(nr != 0u) << round;
+        run_r += (u32)__builtin_amdgcn_readlane((int)ir, 63); run_m += (u32)__builtin_amdgcn_readlane((int)im, 63);
+    }
+    u32 rb = 0, mb = 0;
+    if (lane == 0) {
+        rb = run_r ? atomicAdd(&counters[0], run_r) : 0u;
+        mb = run_m ? atomicAdd(&counters[1], run_m) : 0u;
+        tiletab[wtile] = make_uint4(rb, run_r, mb, run_m);
+    }
+    rb = (u32)__shfl((int)rb, 0, 64); mb = (u32)__shfl((int)mb, 0, 64);
+    for (u32 base = 0, round = 0; base < tot; base += 64, round++) {
+        const u32 ci = base + (u32)lane;
+        if (ci < tot && ((nz >> round) & 1u)) {
+            const u32 r0 = rb + (u32)s_ro[w][ci], m0 = mb + s_mo[w][ci];      // (written by this very lane)
+            u32 a2, b2;
+            multi_walk<true>(SA, LCP, m, BWT, nsep, nsamples, minl, minn, wfirst + (int64_t)s_c[w][ci], a2, b2, rec + r0, so + m0, pos + m0,
+                             r0 < rec_cap ? rec_cap - r0 : 0u, m0 < mem_cap ? mem_cap - m0 : 0u, sub_start, sub_want, nsubs);
+        }
     }
 }
 
@@ -598,15 +653,273 @@ __global__ __launch_bounds__(TB) void k_multi_pick2(const sa_t *__restrict__ SA,
     }
 }
 
+
+// ---- full matches by streaming (more than two samples) -------------------------------------
+// A FULL match of a sub-index with `want` samples is the LCP interval of exactly `want` ranks [lb, u], lb = u - want + 1:
+// value l = min LCP[lb+1 .. u] >= minl, LCP[lb] < l > LCP[u+1], its members' samples all different (reveal.c:231-244) and
+// left-maximal (reveal.c:246-256).  This is what the built-in picker takes (schemes.py:227) and what the anchor cascade
+// lists at the root, so both scans run on the skeleton below -- the pair scan's: a wave streams 512 ranks, eight per lane
+// (non-temporal 16-byte loads of LCP, 8 bytes of BWT), and tests them branch-free on two bit windows:
+//   G bit j: LCP[j] >= minl                                   -- a full match ending at u needs G set on u-want+2 .. u
+//   D bit j: ranks j-1, j are evidence of left-maximality      -- ... and some D set on the same ranks
+// (G and D of the 16 ranks in front of a lane come from the two lanes below by shuffle, for lanes 0 and 1 from the wave's
+// halo), together with LCP[u] > LCP[u+1].  About one rank in seven hundred passes at 10 x 5 Mbp; only those ranks read
+// again -- LCP[lb .. u+1] and SA[lb .. u], independent loads of lines the wave has just streamed -- for the exact value,
+// the two strict comparisons and the samples.  No LDS, no workgroup barrier, no sample array: a wave retires when its own
+// ranks are done.  (Before: a workgroup staged 2048 ranks of LCP, a sample byte and BWT in LDS and walked the candidates --
+// one rank in ten -- in two dense stages between seven barriers: 130 us at 10 x 5 Mbp, 0.23 of the 8 TB/s.)
+//
+// MODE 0 (cascade root, rv_cascade_multi.hip): want = k everywhere; survivors are listed (length, the k positions by sample).
+// MODE 1 (built-in picker): want = the sample count of the rank's sub-index, looked up per lane (a lane whose eight ranks
+//         straddle two sub-indices, or whose sub-index has more than FS_HALO samples, takes the general path rank by rank);
+//         survivors raise the maximum of their sub-index and are listed for k_multi_pick2.
+constexpr int FS_ITEMS = 8, FS_WTILE = 64 * FS_ITEMS, FS_TILE = (TB / 64) * FS_WTILE, FS_HALO = 16;
+static_assert(FS_TILE == RV_TSUB_TILE, "a workgroup covers one tile of the host's tile -> sub-index table");
+
+__device__ inline bool fs_evidence(u32 ca, u32 cb) {      // reveal.c:246-256 on the characters in front of two neighbouring ranks ('$' where SA == 0)
+    return (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca - 'a') < 26u);
+}
+
+// exact test of the full match [u - want + 1, u] (want <= FS_HALO); -> value, members (SA order), their smallest position
+__device__ inline bool fs_exact(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const sa_t *__restrict__ nsep, int nsamples,
+                                int64_t u, int want, u32 minl, u32 &l_out, sa_t *sv, int *ss, sa_t &mn_out) {
+    const int64_t lb = u - want + 1;
+    if (lb < 0) return false;
+    u32 lv[FS_HALO];
+#pragma unroll
+    for (int d = 0; d < FS_HALO; d++) lv[d] = (u32)LCP[d < want - 1 ? u - d : u];      // (independent, predicated: one round trip)
+#pragma unroll
+    for (int k = 0; k < FS_HALO; k++) sv[k] = SA[k < want ? lb + k : u];
+    const u32 below = (u32)LCP[lb], nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
+    u32 l = lv[0];
+#pragma unroll
+    for (int d = 1; d < FS_HALO; d++) l = lv[d] < l ? lv[d] : l;
+    if (!((l >= minl) & (l > nxt) & (below < l))) return false;
+    // the members' samples (interface.c:116-134: the separators in front of a position), every member at once: ONE pass over the separators --
+    // uniform addresses, scalar loads -- in which each member counts those below it.  (A binary search per member was sixteen chains of dependent
+    // vector loads per passing rank: 203 us for the scan of 10 x 5 Mbp, of which ~150 waiting for them.)
+#pragma unroll
+    for (int k = 0; k < FS_HALO; k++) ss[k] = 0;
+    for (int q = 0; q < nsamples - 1; q++) {
+        const sa_t sp = nsep[q];
+#pragma unroll
+        for (int k = 0; k < FS_HALO; k++) ss[k] += sp < sv[k] ? 1 : 0;
+    }
+    u64 seen = 0; bool distinct = true;
+    sa_t mn = sv[0];
+#pragma unroll
+    for (int k = 0; k < FS_HALO; k++) {
+        if (k < want) {
+            const u64 bit = 1ull << (ss[k] & 63);
+            distinct &= !(seen & bit); seen |= bit;
+            mn = sv[k] < mn ? sv[k] : mn;
+        }
+    }
+    l_out = l; mn_out = mn;
+    return distinct;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(TB) void k_full_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t m,
+                                                  const sa_t *__restrict__ nsep, int nsamples, u32 minl, int minn,
+                                                  u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 rcap, u32 *__restrict__ region_cnt, int nregions,
+                                                  const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs, const int *__restrict__ tile_sub,
+                                                  unsigned long long *__restrict__ best, RvMultiCand *__restrict__ cand, u32 cand_cap, u32 *__restrict__ cand_count) {
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int64_t wfirst = (int64_t)blockIdx.x * FS_TILE + (int64_t)w * FS_WTILE;
+    if (wfirst >= m) return;
+    const int64_t i0 = wfirst + (int64_t)lane * FS_ITEMS;
+    // halo: the FS_HALO ranks in front of the wave (a rank each for lanes 0 .. 15), the LCP value behind its last rank; issued first
+    u32 h_lc = 0, h_bw = 0, h_nlc = 0;
+    {
+        const int64_t j = wfirst - FS_HALO + lane;
+        if (lane < FS_HALO && j >= 0) { h_lc = (u32)LCP[j]; h_bw = (u32)BWT[j]; }      // (the side bit is masked where the byte is used: masking here made the wave wait for this load before it issued the streaming ones)
+        if (wfirst + FS_WTILE < m) h_nlc = (u32)LCP[wfirst + FS_WTILE];
+    }
+    // the sub-index of the lane's first rank and its sample count (MODE 1)
+    int want = nsamples, mine = 0, s_last = 0;
+    bool slow = false;
+    if (MODE == 1) {
+        const int64_t tt = blockIdx.x, ntsub = (m + FS_TILE - 1) / FS_TILE;
+        const int s0 = tile_sub[tt];
+        s_last = tt + 1 < ntsub ? tile_sub[tt + 1] : nsubs - 1;
+        mine = s0;
+        if (s_last > s0) {      // (several sub-indices in this workgroup's ranks: the largest s with sub_start[s] <= i0)
+            int lo = s0, hi = s_last;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= i0) lo = mid; else hi = mid - 1; }
+            mine = lo;
+            const int64_t nstart = sub_start[mine + 1];      // (sub_start[nsubs] = m)
+            slow = nstart < i0 + FS_ITEMS;
+        }
+        want = sub_want[mine];
+        if (want > FS_HALO) slow = true;
+        if (!slow && !(want >= minn && want >= 2 && want <= nsamples)) want = 1;      // (no match can have this size: the window test below fails everywhere)
+    }
+    u32 lc[FS_ITEMS + 1], bw[FS_ITEMS];
+    if (i0 + FS_ITEMS <= m) {
+        const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0));
+#pragma unroll
+        for (int k = 0; k < 4; k++) { bw[k] = (bb.x >> (8 * k)) & RV_BWT_CHAR; bw[4 + k] = (bb.y >> (8 * k)) & RV_BWT_CHAR; }
+#pragma unroll
+        for (int v4 = 0; v4 < FS_ITEMS / 4; v4++) {
+            const v4i c = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(LCP + i0) + v4);
+            lc[4 * v4] = (u32)c.x; lc[4 * v4 + 1] = (u32)c.y; lc[4 * v4 + 2] = (u32)c.z; lc[4 * v4 + 3] = (u32)c.w;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FS_ITEMS; k++) {
+            lc[k] = (i0 + k < m) ? (u32)LCP[i0 + k] : 0u;
+            bw[k] = (i0 + k < m) ? ((u32)BWT[i0 + k] & RV_BWT_CHAR) : 0u;
+        }
+    }
+    asm volatile("" : "+v"(h_bw), "+v"(h_lc));      // (the halo's values are first looked at here, behind the streaming loads: see above)
+    lc[FS_ITEMS] = (u32)__shfl_down((int)lc[0], 1, 64);
+    if (lane == 63) lc[FS_ITEMS] = h_nlc;
+    u32 pbw = (u32)__shfl_up((int)bw[FS_ITEMS - 1], 1, 64);
+    h_bw &= RV_BWT_CHAR;
+    const u32 hb15 = (u32)__builtin_amdgcn_readlane((int)h_bw, FS_HALO - 1);
+    if (lane == 0) pbw = hb15;
+    // per-rank bits of my eight ranks: closes an interval (c), G, D
+    u32 c8 = 0, g8 = 0, d8 = 0;
+#pragma unroll
+    for (int k = 0; k < FS_ITEMS; k++) {
+        const bool g = lc[k] >= minl;
+        g8 |= (u32)g << k;
+        c8 |= (u32)(g & (lc[k] > lc[k + 1])) << k;
+        d8 |= (u32)fs_evidence(k == 0 ? pbw : bw[k - 1], bw[k]) << k;
+    }
+    // the same bits of the 16 ranks in front of my first one
+    const u32 mw = g8 | (d8 << 8);
+    u32 pw = (u32)__shfl_up((int)mw, 1, 64), ppw = (u32)__shfl_up((int)mw, 2, 64);
+    {
+        const u32 hprev = (u32)__shfl_up((int)h_bw, 1, 64);
+        const u64 HG = __ballot((lane < FS_HALO) & (h_lc >= minl));
+        const u64 HD = __ballot((lane < FS_HALO) & (lane > 0) & fs_evidence(hprev, h_bw));
+        const u32 hlo = ((u32)HG & 0xffu) | (((u32)HD & 0xffu) << 8), hhi = (((u32)HG >> 8) & 0xffu) | ((((u32)HD >> 8) & 0xffu) << 8);
+        if (lane == 0) { pw = hhi; ppw = hlo; }
+        if (lane == 1) ppw = hhi;
+    }
+    const u32 G24 = (ppw & 0xffu) | ((pw & 0xffu) << 8) | (g8 << 16);
+    const u32 D24 = ((ppw >> 8) & 0xffu) | (((pw >> 8) & 0xffu) << 8) | (d8 << 16);
+    u32 todo = 0;
+    if (!slow) {
+        const int H = want - 1;                      // 0 .. FS_HALO - 1
+        const u32 MH = (1u << H) - 1u;
+#pragma unroll
+        for (int k = 0; k < FS_ITEMS; k++) {
+            const int sh = 17 + k - H;               // ranks u - want + 2 .. u of rank u = my k-th (bit 16 + k)
+            const u32 gi = (G24 >> sh) & MH, di = (D24 >> sh) & MH;
+            todo |= (((c8 >> k) & 1u) & (u32)(gi == MH) & (u32)(di != 0u)) << k;
+        }
+    } else {
+        todo = c8;
+    }
+    const u32 reg = MODE == 0 ? (blockIdx.x & (u32)(nregions - 1)) : (blockIdx.x % RV_MULTI_REGIONS);
+    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // the ranks that passed (rounds of one per lane; the wave leaves together: the ballot)
+    while (__any(todo != 0u)) {
+        bool ok = false;
+        u32 l = 0; sa_t mn = 0; int64_t u = 0; int sub = mine, wn = want;
+        sa_t sv[FS_HALO]; int ss[FS_HALO];
+        if (todo) {
+            const int k = __builtin_ctz(todo);
+            todo &= todo - 1;
+            u = i0 + k;
+            if (!slow) {
+                ok = fs_exact(SA, LCP, m, nsep, nsamples, u, wn, minl, l, sv, ss, mn);
+            } else if (MODE == 1) {      // the general form, everything from global memory (reveal.c:227-259 by ismultimum_dev)
+                int lo = mine, hi = s_last;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= u) lo = mid; else hi = mid - 1; }
+                sub = lo; wn = sub_want[sub];
+                const int64_t lb = u - wn + 1;
+                ok = wn >= minn && wn >= 2 && wn <= nsamples && lb >= sub_start[sub];
+                if (ok) {
+                    const u32 nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
+                    l = (u32)LCP[u];
+                    for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
+                    ok = l > nxt && l >= minl && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u);
+                    if (ok) { mn = SA[lb]; for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; } }
+                }
+            }
+        }
+        if (MODE == 0) {
+            const u64 bal = __ballot(ok);
+            if (bal) {
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&region_cnt[reg], (u32)__popcll(bal));
+                base = (u32)__shfl((int)base, 0, 64);
+                if (ok) {
+                    const u32 i = base + (u32)__popcll(bal & lt);
+                    if (i < rcap) {
+                        const size_t o = (size_t)reg * rcap + i;
+                        c_len[o] = l;
+#pragma unroll
+                        for (int k = 0; k < FS_HALO; k++) if (k < wn) c_pos[o * (size_t)nsamples + (size_t)ss[k]] = sv[k];
+                    }
+                }
+            }
+        } else {
+            // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be the winner
+            // k_multi_pick2 looks for (the maximum never falls): the others are not even listed.
+            const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
+            ok = ok && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED);
+            if (ok) atomicMax(&best[sub], key);
+            const u64 bal = __ballot(ok);
+            if (bal) {
+                const u32 rc = cand_cap / RV_MULTI_REGIONS;
+                u32 qb = 0;
+                if (lane == 0) qb = atomicAdd(&cand_count[reg * 64], (u32)__popcll(bal));
+                qb = (u32)__shfl((int)qb, 0, 64);
+                if (ok) {
+                    const u32 q = qb + (u32)__popcll(bal & lt);
+                    if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+                }
+            }
+        }
+    }
+}
+
+// best / pick_l / the list's counters back to zero in one launch (three memsets were three launches inside the level's scan)
+__global__ __launch_bounds__(TB) void k_mp_zero(unsigned long long *__restrict__ best, u32 *__restrict__ pick_l, int nsubs, u32 *__restrict__ cand_count) {
+    const int64_t id = (int64_t)blockIdx.x * TB + threadIdx.x;
+    if (id < nsubs) { best[id] = 0; pick_l[id] = 0; }
+    if (id < RV_MULTI_REGIONS * 64 + 1) cand_count[id] = 0;
+}
+
+// (ev_start / ev_stop given: the events ride on the streaming kernel's own dispatch packet, as for the pair scan)
+#define RV_FS_LAUNCH(MODE, GRID, ...)                                                                                              \
+    do {                                                                                                                           \
+        if (ev_start && ev_stop) hipExtLaunchKernelGGL(k_full_scan<MODE>, dim3(GRID), dim3(TB), 0, ws.stream, ev_start, ev_stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(k_full_scan<MODE>, dim3(GRID), dim3(TB), 0, ws.stream, __VA_ARGS__);                               \
+    } while (0)
+
+int rv_full_list_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int k, u32 minl,
+                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (n <= 0) return 0;
+    if (k < 2 || k > FS_HALO || (nregions & (nregions - 1))) { rv_set_error("full-match scan: sample count or region count out of range"); return -1; }
+    RV_FS_LAUNCH(0, (unsigned)ceil_div(n, FS_TILE), SA, LCP, BWT, n, nsep, k, minl, 2,
+                 c_len, c_pos, rcap, region_cnt, nregions, (const int64_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr,
+                 (unsigned long long *)nullptr, (RvMultiCand *)nullptr, 0u, (u32 *)nullptr);
+    RV_LAUNCH_CHECK();
+    return 0;
+}
+
 int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_t m, const uint8_t *BWT, const sa_t *nsep, int nsamples, int minl, int minn,
                          const int64_t *sub_start, const int *sub_want, int nsubs, const int *tile_sub, unsigned long long *best, u32 *pick_l, sa_t *pick_pos,
-                         RvMultiCand *cand, u32 cand_cap, u32 *cand_count) {
+                         RvMultiCand *cand, u32 cand_cap, u32 *cand_count, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (m <= 0 || nsubs <= 0) return 0;
-    RV_HIP(hipMemsetAsync(best, 0, (size_t)nsubs * 8, ws.stream));
-    RV_HIP(hipMemsetAsync(pick_l, 0, (size_t)nsubs * 4, ws.stream));
-    RV_HIP(hipMemsetAsync(cand_count, 0, (RV_MULTI_REGIONS * 64 + 1) * 4, ws.stream));
-    hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, RV_TSUB_TILE)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
-                       sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);
+    hipLaunchKernelGGL(k_mp_zero, dim3((unsigned)ceil_div(std::max<int64_t>(nsubs, RV_MULTI_REGIONS * 64 + 1), TB)), dim3(TB), 0, ws.stream, best, pick_l, nsubs, cand_count);
+    RV_LAUNCH_CHECK();
+    if (nsamples <= 64 && !ws.opt.scan_v1)
+        RV_FS_LAUNCH(1, (unsigned)ceil_div(m, FS_TILE), SA, LCP, BWT, m, nsep, nsamples, (u32)(minl > 1 ? minl : 1), minn,
+                     (u32 *)nullptr, (sa_t *)nullptr, 0u, (u32 *)nullptr, 1, sub_start, sub_want, nsubs, tile_sub, best, cand, cand_cap, cand_count);
+    else if (ev_start && ev_stop)      // (more than 64 samples: the samples of a match no longer fit a 64-bit census; RV_SCAN_V1: the staged kernel, for comparison)
+        hipExtLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, RV_TSUB_TILE)), dim3(TB), 0, ws.stream, ev_start, ev_stop, 0, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
+                              sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);
+    else
+        hipLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, RV_TSUB_TILE)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
+                           sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);
     RV_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_multi_pick2, dim3(RV_MULTI_REGIONS * 4), dim3(TB), 0, ws.stream, SA, sub_want, nsamples, (const unsigned long long *)best,
                        (const RvMultiCand *)cand, cand_cap, (const u32 *)cand_count, pick_l, pick_pos);
@@ -618,7 +931,7 @@ int rv_scan_multi_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
                          int minl, int minn, RvMultiRec *rec, uint16_t *so, sa_t *pos, u32 rec_cap, u32 mem_cap, u32 *counters, uint4 *tiletab,
                          const int64_t *sub_start, const int *sub_want, int nsubs) {
     if (m <= 0) return 0;
-    hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, TB)), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
+    hipLaunchKernelGGL(k_scan_multi, dim3((unsigned)ceil_div(m, (int64_t)RV_MULTI_TILE * (TB / 64))), dim3(TB), 0, ws.stream, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
                        rec, so, pos, rec_cap, mem_cap, counters, tiletab, sub_start, sub_want, nsubs);
     RV_LAUNCH_CHECK();
     return 0;

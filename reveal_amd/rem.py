@@ -250,8 +250,8 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
                   and len(idx.nodes) == len(idx.samples) and args.maxsize is None and args.maxdepth is None)
     if native and not can_native:
         raise ValueError("native=True: FASTA inputs with one sequence per sample, no maxsize / maxdepth, reveal_amd's index")
-    if native is None:
-        native = can_native
+    if native is None:      # (REVEAL_AMD_NATIVE=0 in the environment, or --no-native on the command line: the Python callbacks)
+        native = can_native and os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")
     root_nodes = sorted(tuple(x) for x in idx.nodes)
     idx.construct()
     if native:
@@ -427,6 +427,9 @@ def main(argv=None):
     ap.add_argument("--notrim", dest="trim", action="store_false")
     ap.add_argument("--maxbubblesize", dest="maxsize", type=int, default=None)
     ap.add_argument("-p", dest="pcutoff", type=float, default=1e-8)
+    ap.add_argument("--no-native", dest="native", action="store_const", const=False, default=None,
+                    help="run the reference's graphmumpicker / graphalign as Python callbacks per sub-index instead of the C++ picker and graph behind the ABI "
+                         "(the default wherever the inputs allow it; REVEAL_AMD_NATIVE=0 does the same)")
     a = ap.parse_args(argv)
     if a.bench_callbacks:
         idx, (segments, links, paths), fn = rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs)
@@ -434,7 +437,7 @@ def main(argv=None):
         return
     from . import schemes
     pa = schemes.PickerArgs(wscore=a.wscore, wpen=a.wpen, maxmums=a.maxmums, seedsize=a.seedsize, gcmodel=a.gcmodel, trim=a.trim, maxsize=a.maxsize, pcutoff=a.pcutoff)
-    G, idx, fn = graph_rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs, args=pa, materialize=False)
+    G, idx, fn = graph_rem(a.inputfiles, a.output, sa64=a.sa64, minlength=a.minlength, minn=a.minn, contigs=a.contigs, args=pa, native=a.native, materialize=False)
     if isinstance(G, dict):      # (built, pruned and written behind the ABI)
         print("%s: %d nodes, %d paths" % (fn, G["seq_nodes"], len(G["paths"])))
     else:

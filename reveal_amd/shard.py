@@ -210,6 +210,8 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
             total = int(fr["meta"][order, 1].sum())
             staged = _buffers(lib, total, dev)
             idx.frontier_pack(order, *staged)          # (synchronous: the copies have finished when it returns)
+            # rv_set_picker(1): the seed lists of the sub-indices leave with them (the owner's frontier is replaced by its own batches later)
+            seeds = [idx.frontier_seeds(b) for b in batches] if idx.picker_info()["kind"] == 1 else None
         first = [0]
         for b in batches:
             first.append(first[-1] + int(fr["meta"][b, 1].sum()))
@@ -222,6 +224,8 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
 
         def hand_out(w, k):
             part = subset(fr, batches[k])
+            if seeds is not None:
+                part["seeds"] = seeds[k]
             m = first[k + 1] - first[k]
             bufs = tuple(b[first[k]:first[k + 1]] for b in staged)
             meta = pickle.dumps(part, protocol=4)
@@ -248,6 +252,8 @@ def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False,
                 hi -= 1
                 k = hi
                 part = subset(fr, batches[k])
+                if seeds is not None:
+                    part["seeds"] = seeds[k]
                 bufs = tuple(b[first[k]:first[k + 1]] for b in staged)
                 idx.frontier_import(part, *bufs, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
                 results.append(idx.align_builtin_resume())

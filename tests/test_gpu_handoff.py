@@ -21,9 +21,11 @@ def level_pipeline_only(monkeypatch, request):
         monkeypatch.setenv("RV_NO_CASCADE", "1")
 
 
-def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, device_buffers=False):
+def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, device_buffers=False, picker=None):
     M = mod(sa64)
     owner = feed(M.index(), inputs)
+    if picker is not None:
+        owner.set_picker(picker)
     owner.construct()
     lib = owner._lib
     left = owner.align_builtin_until(stop_subs, minl, minn, trace=trace)
@@ -35,6 +37,8 @@ def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, devic
         packed = []
         for subs in parts:
             part = shard.subset(fr, subs)
+            if picker is not None:
+                part["seeds"] = owner.frontier_seeds(subs)
             m = int(part["meta"][:, 1].sum())
             if device_buffers:
                 bufs = shard._buffers(lib, m, "cuda:0")
@@ -47,6 +51,8 @@ def divided(inputs, minl, minn, stop_subs, nparts, sa64=False, trace=True, devic
         owner.frontier_import(packed[0][0], *packed[0][1], minl=minl, minn=minn)
         for part, bufs in packed[1:]:
             w = feed(M.index(), inputs)          # a worker: samples only, no construct
+            if picker is not None:
+                w.set_picker(picker)
             if len(part["meta"]) == 0:
                 results.append(shard.empty_result(trace))
                 continue
@@ -127,6 +133,32 @@ def test_divided_untraced_matches_undivided():
     for k in ("steps", "splits", "anchored_bp"):
         assert one["stats"][k] == got["stats"][k], k
     assert shard.lower_text(assemble(seqs)[0], got["anchors"]).tobytes() == idx.T.encode("latin-1")
+
+
+@pytest.mark.parametrize("genomes,L,seedsize", [(2, 300000, 40), (3, 120000, 40), (2, 200000, 10000)])
+def test_divided_with_the_native_picker(genomes, L, seedsize):
+    """rv_set_picker(1) through the hand-off: the workers' scans hand whole lists to the chain picker, and the seed lists the owner's picker
+    calls left for the frontier's sub-indices (the reference's skipmums, reveal.c:1157, 1180) travel with them -- same anchors, in the same
+    number of picker calls and seeded calls, as the undivided run"""
+    from reveal_amd import schemes
+    seqs = [g.decode() for g in synth.genomes(L, genomes, indelfrac=0.2)]
+    args = schemes.PickerArgs(seedsize=seedsize)
+    M = mod(False)
+    idx = feed(M.index(), seqs)
+    idx.set_picker(args)
+    idx.construct()
+    one = idx.align_builtin(20, 2)
+    info = idx.picker_info()
+    assert info["kind"] == 1 and (seedsize > 1000 or info["seeded"] > 0)
+    got, shares, left = divided(seqs, 20, 2, 8, 3, trace=False, picker=args)
+    assert left >= 8
+
+    def aset(r):
+        l, off, pos = r["anchors"]
+        return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+    assert aset(one) == aset(got)
+    for k in ("steps", "splits", "anchored_bp"):
+        assert one["stats"][k] == got["stats"][k], k
 
 
 TWO_RANK = r'''

@@ -24,7 +24,9 @@ def collect(d, counter, kernel):
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         per = {}
         for r in csv.DictReader(open(f)):
-            if r["Counter_Name"] == counter and (kernel + "(") in r["Kernel_Name"].replace("<", "("):
+            kn = r["Kernel_Name"]
+            hit = (kernel in kn) if "<" in kernel else ((kernel + "(") in kn.replace("<", "("))      # "k_full_scan<0>": that instance only
+            if r["Counter_Name"] == counter and hit:
                 per[r["Dispatch_Id"]] = per.get(r["Dispatch_Id"], 0.0) + float(r["Counter_Value"])
         vals += list(per.values())
     return vals

@@ -268,6 +268,8 @@ int rv_set_preselect(rv_index *h, int64_t maxmums);
  * RV_* environment variables when it makes a handle.  No counterpart in the reference (its only switch is -DREVEALDEBUG). */
 int rv_set_option(rv_index *h, const char *name, int64_t value);
 int rv_get_option(rv_index *h, const char *name, int64_t *value);
+/* process-wide diagnostics (not a handle's switch): print the source line of every kernel launch and wait for it; returns the previous setting */
+int rv_set_launch_trace(int on);
 int rv_option_count(void);
 const char *rv_option_name(int k);
 int64_t rv_trace_count(rv_index *h);

@@ -92,6 +92,7 @@ SYMBOLS = {
     "rv_set_trace": (_I, [V, _I]),
     "rv_set_preselect": (_I, [V, _L]),
     "rv_set_option": (_I, [V, ctypes.c_char_p, _L]),
+    "rv_set_launch_trace": (_I, [_I]),
     "rv_get_option": (_I, [V, ctypes.c_char_p, c_i64p]),
     "rv_option_count": (_I, []),
     "rv_option_name": (ctypes.c_char_p, [_I]),
@@ -168,6 +169,10 @@ class Lib:
         self.sa_t = np.int64 if sa64 else np.int32
         self.lcp_t = np.uint32 if sa64 else np.int32
         assert self.dll.rv_sa_bits() == (64 if sa64 else 32)
+        # the one process-wide diagnostic (not a handle's switch, rv_set_launch_trace): RV_LAUNCH_TRACE in the environment when the library is loaded
+        v = os.environ.get("RV_LAUNCH_TRACE")
+        if v is not None and v.strip() not in ("", "0"):
+            self.dll.rv_set_launch_trace(1)
 
     def err(self):
         return (self.dll.rv_last_error() or b"").decode(errors="replace")
@@ -194,6 +199,11 @@ def measure_bandwidth(nbytes=1 << 30, iters=10):
     if lib.dll.rv_measure_bandwidth(device(), int(nbytes), int(iters), ctypes.byref(r), ctypes.byref(c)) != 0:
         raise RuntimeError(lib.err())
     return r.value, c.value
+
+
+def set_launch_trace(on=True):
+    """process-wide: every kernel launch of both libraries prints its source line and is waited for (finds the kernel behind a GPU fault)"""
+    return [bool(get(w).dll.rv_set_launch_trace(1 if on else 0)) for w in (False, True)]
 
 
 def get(sa64=False):

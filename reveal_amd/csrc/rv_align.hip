@@ -23,6 +23,7 @@ static_assert(RV_TSUB_TILE == RV_SPLIT_TILE, "one tile -> sub-index table serves
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <atomic>
 
 namespace {
 
@@ -1586,6 +1587,115 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     return 0;
 }
 
+// rv_set_picker(1): the chain picker's call for one sub-index of a level (schemes.py:197-361 by rv_pick_chain).  The calls of a level are independent of
+// each other -- each reads its sub-index' match list and intervals, and leaves a choice and two seed lists of its own -- so a level with enough work runs
+// them on a few host threads (the reference serialises its Python callbacks behind one mutex, reveal.c:779; here the picker is C++ and needs none):
+// 230 765 calls, 0.88 of the 1.34 s of a 5 x 5 Mbp recursion, were made one after the other between the level's scan and its commit.
+struct PickScratch {
+    std::vector<u32> pk_l, pk_sl; std::vector<int32_t> pk_n, pk_sn; std::vector<int64_t> pk_off, pk_mpos, pk_sb, pk_ib, pk_ie, pk_soff, pk_spos, pk_ssc;
+    std::vector<uint16_t> pk_mso, pk_sso; std::vector<uint8_t> pk_srt;
+};
+struct PickRes {
+    int rc = -9;                       // rv_pick_chain's return value (-9: not called)
+    u32 l = 0; int members = 0;
+    std::vector<uint16_t> so; std::vector<int64_t> pos;
+    double t_list = 0, t_pick = 0;
+    std::string err;
+};
+static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R) {
+    Align *a = h->al;
+    const Level &lv = a->lv;
+    const int W = h->nsamples, want = lv.nsamples[(size_t)s];
+    const RvIntv *nodes = lv.nodes.data() + lv.node_first[(size_t)s];
+    const size_t nn = (size_t)(lv.node_first[(size_t)s + 1] - lv.node_first[(size_t)s]);
+    const int64_t first = a->mum_first[(size_t)s], cnt = a->nmums[(size_t)s];
+    Align::SeedList &sl = a->seeds_lead[(size_t)s], &st = a->seeds_trail[(size_t)s];
+    R.so.assign((size_t)W, 0); R.pos.assign((size_t)W, 0);
+    // the list as rv_sub_mums hands it out
+    const double tp0 = now_s();
+    X.pk_l.clear(); X.pk_n.clear(); X.pk_off.assign(1, 0); X.pk_mso.clear(); X.pk_mpos.clear();
+    if (!a->multi) {
+        for (int64_t k = first; k < first + cnt; k++) {
+            const RvPairRec &r = a->recs[(size_t)k];
+            X.pk_l.push_back(r.l); X.pk_n.push_back(2);
+            X.pk_mso.push_back(0); X.pk_mpos.push_back((int64_t)r.a); X.pk_mso.push_back(1); X.pk_mpos.push_back((int64_t)r.b);
+            X.pk_off.push_back((int64_t)X.pk_mpos.size());
+        }
+    } else {
+        for (int64_t k = first; k < first + cnt; k++) {
+            X.pk_l.push_back(a->ml[(size_t)k]); X.pk_n.push_back(a->mn[(size_t)k]);
+            for (int64_t qq = a->moff[(size_t)k]; qq < a->moff[(size_t)k + 1]; qq++) { X.pk_mso.push_back(a->mso[(size_t)qq]); X.pk_mpos.push_back(a->mpos[(size_t)qq]); }
+            X.pk_off.push_back((int64_t)X.pk_mpos.size());
+        }
+    }
+    X.pk_sb.assign((size_t)W, 0); X.pk_ib.assign((size_t)W, -1); X.pk_ie.assign((size_t)W, -1);
+    for (int q2 = 0; q2 < W; q2++) X.pk_sb[(size_t)q2] = h->nodes[(size_t)q2].begin;
+    for (size_t k = 0; k < nn; k++) {
+        const int sm = sample_of(h, nodes[k].begin);
+        if (X.pk_ib[(size_t)sm] >= 0) { R.rc = -1; R.err = "the native picker takes one interval per sample and sub-index"; return; }
+        X.pk_ib[(size_t)sm] = nodes[k].begin; X.pk_ie[(size_t)sm] = nodes[k].end;
+    }
+    const size_t scap = X.pk_l.size(), mcap = X.pk_mpos.size();
+    X.pk_sl.resize(scap); X.pk_sn.resize(scap); X.pk_soff.resize(scap + 1); X.pk_sso.resize(std::max<size_t>(mcap, 1)); X.pk_spos.resize(std::max<size_t>(mcap, 1));
+    X.pk_ssc.resize(scap); X.pk_srt.resize(scap);
+    rv_picker_out po;
+    memset(&po, 0, sizeof po);
+    po.pick_so = R.so.data(); po.pick_pos = R.pos.data(); po.member_cap = W;
+    po.seed_cap = (int64_t)scap; po.seed_member_cap = (int64_t)std::max<size_t>(mcap, 1);
+    po.seed_l = X.pk_sl.data(); po.seed_n = X.pk_sn.data(); po.seed_off = X.pk_soff.data(); po.seed_so = X.pk_sso.data(); po.seed_pos = X.pk_spos.data();
+    po.seed_score = X.pk_ssc.data(); po.seed_right = X.pk_srt.data();
+    const double tp1 = now_s();
+    const int pr = rv_pick_chain(&a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), W,
+                                 X.pk_sb.data(), X.pk_ib.data(), X.pk_ie.data(), a->minl, &po);
+    R.t_pick = now_s() - tp1; R.t_list = tp1 - tp0;
+    R.rc = pr;
+    if (pr < 0) { R.err = rv_last_error(); return; }      // (the error text is this thread's: the caller sets it again on its own)
+    if (pr == 1) {
+        R.l = po.pick_l; R.members = po.pick_members;
+        for (int64_t k = 0; k < po.nleft + po.nright; k++)
+            (X.pk_srt[(size_t)k] ? st : sl).push(X.pk_sl[(size_t)k], X.pk_sn[(size_t)k], X.pk_sso.data() + X.pk_soff[(size_t)k], X.pk_spos.data() + X.pk_soff[(size_t)k],
+                                                 (int)(X.pk_soff[(size_t)k + 1] - X.pk_soff[(size_t)k]), X.pk_ssc[(size_t)k]);
+    }
+}
+// every not-seeded sub-index of the level with matches; on several threads when the level holds enough of them (RV_PICK_THREADS: 0 = up to eight, 1 = none)
+static void pick_level(rv_index *h, std::vector<PickRes> &res) {
+    Align *a = h->al;
+    const int ns = a->lv.size();
+    res.assign((size_t)ns, PickRes());
+    a->seeds_lead.assign((size_t)ns, Align::SeedList()); a->seeds_trail.assign((size_t)ns, Align::SeedList());
+    std::vector<int> todo;
+    int64_t work = 0;
+    for (int s = 0; s < ns; s++) {
+        if (s < (int)a->seeds_cur.size() && a->seeds_cur[(size_t)s].size() > 0) continue;      // (seeded: the middle of its list, in the level loop)
+        if (a->nmums[(size_t)s] <= 0) continue;
+        todo.push_back(s); work += a->nmums[(size_t)s];
+    }
+    int nt = (int)h->ws.opt.pick_threads;
+    if (nt <= 0) nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+    nt = (int)std::min<size_t>((size_t)nt, todo.size());
+    if (work < 4096) nt = 1;
+    if (nt <= 1) {
+        PickScratch X;
+        for (int s : todo) pick_one(h, s, X, res[(size_t)s]);
+        return;
+    }
+    std::atomic<size_t> next{0};
+    auto worker = [&]() {
+        PickScratch X;
+        for (;;) {
+            const size_t i = next.fetch_add(16);      // (sixteen sub-indices a turn: the deep levels hold tens of thousands of small ones)
+            if (i >= todo.size()) return;
+            for (size_t j = i; j < std::min(todo.size(), i + 16); j++) pick_one(h, todo[j], X, res[(size_t)todo[j]]);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) {
+        try { th.emplace_back(worker); } catch (...) { break; }      // (no thread to be had: the others, or this one alone, do the work)
+    }
+    worker();
+    for (auto &t : th) t.join();
+}
+
 // levels of the recursion until the frontier is empty, or (stop_subs > 0) until it holds at least stop_subs sub-indices
 static int builtin_levels(rv_index *h, int stop_subs) {
     Align *a = h->al;
@@ -1593,8 +1703,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
     std::vector<int64_t> sp;
     std::vector<RvIntv> lead, trail, match, rest;
     std::vector<uint8_t> touched;
-    std::vector<u32> pk_l, pk_sl; std::vector<int32_t> pk_n, pk_sn; std::vector<int64_t> pk_off, pk_mpos, pk_pos, pk_sb, pk_ib, pk_ie, pk_soff, pk_spos, pk_ssc;
-    std::vector<uint16_t> pk_mso, pk_so, pk_sso; std::vector<uint8_t> pk_srt;
+    std::vector<int64_t> pk_pos; std::vector<uint16_t> pk_so;
+    std::vector<PickRes> pres;
     const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
     int &leaf_flip = a->leaf_flip;
@@ -1655,6 +1765,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
         }
         a->st.levels++;
         const int ns = lv.size();
+        if (a->picker == 1) pick_level(h, pres);
         for (int s = 0; s < ns; s++) {
             if (use_leaf && a->leaf_done[(size_t)s]) continue;         // finished (with its whole sub-tree) by the leaf kernel
             a->st.steps++;
@@ -1686,19 +1797,18 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             const int want = lv.nsamples[(size_t)s];
             bool chain_pick = false;
             if (a->picker == 1) {
-                // the reference's default picker (schemes.py:197-361) in C++: rv_pick_chain on the sub-index' whole list -- or, for a sub-index its
-                // parent seeded, the middle of that list (schemes.py:349-354) and its two halves for the children
-                if ((int)a->seeds_lead.size() != ns) { a->seeds_lead.assign((size_t)ns, Align::SeedList()); a->seeds_trail.assign((size_t)ns, Align::SeedList()); }
+                // the reference's default picker (schemes.py:197-361) in C++: rv_pick_chain on the sub-index' whole list (pick_level, above) -- or, for a
+                // sub-index its parent seeded, the middle of that list (schemes.py:349-354) and its two halves for the children
                 const int W = h->nsamples;
                 pk_so.assign((size_t)W, 0); pk_pos.assign((size_t)W, 0);
                 int members = 0;
                 Align::SeedList &sl = a->seeds_lead[(size_t)s], &st = a->seeds_trail[(size_t)s];
-                sl.clear(); st.clear();
                 a->picker_calls++;
                 if (s < (int)a->seeds_cur.size() && a->seeds_cur[(size_t)s].size() > 0) {
                     const Align::SeedList &sd = a->seeds_cur[(size_t)s];
                     const size_t cnt2 = sd.size(), mid = cnt2 / 2;
                     a->picker_seeded++;
+                    sl.clear(); st.clear();
                     bl = sd.l[mid]; members = (int)(sd.off[mid + 1] - sd.off[mid]);
                     for (int q2 = 0; q2 < members; q2++) { pk_so[(size_t)q2] = sd.so[(size_t)sd.off[mid] + q2]; pk_pos[(size_t)q2] = sd.pos[(size_t)sd.off[mid] + q2]; }
                     for (size_t k = 0; k < cnt2; k++) {
@@ -1707,49 +1817,13 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     }
                     chain_pick = true;
                 } else if (cnt > 0) {
-                    // the list as rv_sub_mums hands it out
-                    const double tp0 = now_s();
-                    pk_l.clear(); pk_n.clear(); pk_off.assign(1, 0); pk_mso.clear(); pk_mpos.clear();
-                    if (!a->multi) {
-                        for (int64_t k = first; k < first + cnt; k++) {
-                            const RvPairRec &r = a->recs[(size_t)k];
-                            pk_l.push_back(r.l); pk_n.push_back(2);
-                            pk_mso.push_back(0); pk_mpos.push_back((int64_t)r.a); pk_mso.push_back(1); pk_mpos.push_back((int64_t)r.b);
-                            pk_off.push_back((int64_t)pk_mpos.size());
-                        }
-                    } else {
-                        for (int64_t k = first; k < first + cnt; k++) {
-                            pk_l.push_back(a->ml[(size_t)k]); pk_n.push_back(a->mn[(size_t)k]);
-                            for (int64_t qq = a->moff[(size_t)k]; qq < a->moff[(size_t)k + 1]; qq++) { pk_mso.push_back(a->mso[(size_t)qq]); pk_mpos.push_back(a->mpos[(size_t)qq]); }
-                            pk_off.push_back((int64_t)pk_mpos.size());
-                        }
-                    }
-                    pk_sb.assign((size_t)W, 0); pk_ib.assign((size_t)W, -1); pk_ie.assign((size_t)W, -1);
-                    for (int q2 = 0; q2 < W; q2++) pk_sb[(size_t)q2] = h->nodes[(size_t)q2].begin;
-                    for (size_t k = 0; k < nn; k++) {
-                        const int sm = sample_of(h, nodes[k].begin);
-                        if (pk_ib[(size_t)sm] >= 0) { rv_set_error("the native picker takes one interval per sample and sub-index"); return -1; }
-                        pk_ib[(size_t)sm] = nodes[k].begin; pk_ie[(size_t)sm] = nodes[k].end;
-                    }
-                    const size_t scap = pk_l.size(), mcap = pk_mpos.size();
-                    pk_sl.resize(scap); pk_sn.resize(scap); pk_soff.resize(scap + 1); pk_sso.resize(std::max<size_t>(mcap, 1)); pk_spos.resize(std::max<size_t>(mcap, 1));
-                    pk_ssc.resize(scap); pk_srt.resize(scap);
-                    rv_picker_out po;
-                    memset(&po, 0, sizeof po);
-                    po.pick_so = pk_so.data(); po.pick_pos = pk_pos.data(); po.member_cap = W;
-                    po.seed_cap = (int64_t)scap; po.seed_member_cap = (int64_t)std::max<size_t>(mcap, 1);
-                    po.seed_l = pk_sl.data(); po.seed_n = pk_sn.data(); po.seed_off = pk_soff.data(); po.seed_so = pk_sso.data(); po.seed_pos = pk_spos.data();
-                    po.seed_score = pk_ssc.data(); po.seed_right = pk_srt.data();
-                    const double tp1 = now_s();
-                    const int pr = rv_pick_chain(&a->pargs, want, (int64_t)pk_l.size(), pk_l.data(), pk_n.data(), pk_off.data(), pk_mso.data(), pk_mpos.data(), W,
-                                                 pk_sb.data(), pk_ib.data(), pk_ie.data(), a->minl, &po);
-                    a->picker_ns += (int64_t)((now_s() - tp1) * 1e9); a->picker_list_ns += (int64_t)((tp1 - tp0) * 1e9);
-                    if (pr < 0) return -1;
-                    if (pr == 1) {
-                        bl = po.pick_l; members = po.pick_members; chain_pick = true;
-                        for (int64_t k = 0; k < po.nleft + po.nright; k++)
-                            (pk_srt[(size_t)k] ? st : sl).push(pk_sl[(size_t)k], pk_sn[(size_t)k], pk_sso.data() + pk_soff[(size_t)k], pk_spos.data() + pk_soff[(size_t)k],
-                                                              (int)(pk_soff[(size_t)k + 1] - pk_soff[(size_t)k]), pk_ssc[(size_t)k]);
+                    const PickRes &R = pres[(size_t)s];
+                    a->picker_ns += (int64_t)(R.t_pick * 1e9); a->picker_list_ns += (int64_t)(R.t_list * 1e9);
+                    if (R.rc == -9) { rv_set_error("the native picker was not run for sub-index %d", s); return -1; }
+                    if (R.rc < 0) { rv_set_error("%s", R.err.c_str()); return -1; }
+                    if (R.rc == 1) {
+                        bl = R.l; members = R.members; chain_pick = true;
+                        for (int q2 = 0; q2 < members; q2++) { pk_so[(size_t)q2] = R.so[(size_t)q2]; pk_pos[(size_t)q2] = R.pos[(size_t)q2]; }
                     }
                 }
                 if (chain_pick) { sp.assign(pk_pos.begin(), pk_pos.begin() + members); best = 0; }

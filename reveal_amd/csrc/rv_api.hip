@@ -112,8 +112,14 @@ int rv_set_option(rv_index *h, const char *name, int64_t value) {
     int64_t *f = h->ws.opt.find(name);
     if (!f) { rv_set_error("rv_set_option: unknown option %s", name); return -1; }
     *f = value;
-    if (strcmp(name, "RV_LAUNCH_TRACE") == 0) g_rv_launch_trace = value != 0;
     return 0;
+}
+/* diagnostics of the whole process, not of a handle: every kernel launch of the library prints its source line and is waited for, so that a
+ * GPU memory fault (which aborts the process) names the kernel behind it.  Returns the previous setting. */
+int rv_set_launch_trace(int on) {
+    const int was = g_rv_launch_trace;
+    g_rv_launch_trace = on != 0;
+    return was;
 }
 int rv_get_option(rv_index *h, const char *name, int64_t *value) {
     if (!h || !name || !value) { rv_set_error("rv_get_option: null argument"); return -1; }

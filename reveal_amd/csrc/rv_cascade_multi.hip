@@ -327,6 +327,10 @@ __global__ __launch_bounds__(TB) void k_casm_witness(const sa_t *__restrict__ SA
 }
 
 // the regions' entries as one dense list: key = first coordinate, value = where the entry lives
+// the regions' counters, kept 64 words apart while the scan counts into them, side by side for the host and k_casm_keys
+__global__ void k_casm_collect(const u32 *__restrict__ spread, int stride, u32 *__restrict__ region_cnt) {
+    if (threadIdx.x < (unsigned)CM_REGIONS) region_cnt[threadIdx.x] = spread[(size_t)threadIdx.x * stride];
+}
 __global__ __launch_bounds__(TB) void k_casm_keys(const sa_t *__restrict__ c_pos, int k, u32 rcap, const u32 *__restrict__ region_cnt, const u32 *__restrict__ region_off,
                                                   u64 *__restrict__ keys, u32 *__restrict__ vals) {
     const u32 reg = blockIdx.y;
@@ -942,7 +946,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
          &bsa = cb.d[19], &blcp = cb.d[20], &bbwt = cb.d[21], &brt = cb.d[22], &bexp = cb.d[23], &brows = cb.d[34];
     RV_TRY(bso.reserve((size_t)n + 64)); RV_TRY(bcl0.reserve((size_t)mcap * 4)); RV_TRY(bcp0.reserve((size_t)mcap * k * sizeof(sa_t)));
     RV_TRY(bwp.reserve((size_t)wcap * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)wcap * 4)); RV_TRY(bwc.reserve((size_t)wcap * 4));
-    RV_TRY(bctr.reserve(64 + 2 * CM_REGIONS * 4 + 64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
+    constexpr int CNT_STRIDE = 64;      // words between the counters of two regions while the scan counts (256 B: another L2 channel)
+    RV_TRY(bctr.reserve(1024 + (size_t)CM_REGIONS * CNT_STRIDE * 4 + 64)); RV_TRY(broot.reserve((size_t)2 * k * sizeof(sa_t)));
     // per sub-index tables, one allocation: b, e, q (k sa_t each), best (u64), rmax, depth, state, lead, trail, ql (u32)
     const size_t per = (size_t)3 * k * sizeof(sa_t) + 8 + 6 * 4;
     RV_TRY(btb.reserve(per * ccap + 256)); RV_TRY(bund.reserve((size_t)ccap * 4)); RV_TRY(banl.reserve((size_t)acap * 4)); RV_TRY(banp.reserve((size_t)acap * k * sizeof(sa_t)));
@@ -956,7 +961,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     }
     u32 *counters = bctr.as<u32>();
     u32 *region_cnt = counters + 16, *region_off = region_cnt + CM_REGIONS;      // (the match list's regions: counts, then where each starts in the dense list)
-    RV_HIP(hipMemsetAsync(counters, 0, 64 + 2 * CM_REGIONS * 4, q));
+    u32 *region_spread = counters + 256;
+    RV_HIP(hipMemsetAsync(counters, 0, 1024 + (size_t)CM_REGIONS * CNT_STRIDE * 4, q));
     const u32 rcap = mcap / CM_REGIONS;
     {
         std::vector<sa_t> rr(rb); rr.insert(rr.end(), re.begin(), re.end());
@@ -972,7 +978,10 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         if (!ws.opt.scan_v1) (void)h->prof.attach(RV_K_SCAN_MULTI, (double)n * 8.0, &ev_a, &ev_b);
         else pid = h->prof.begin(q, RV_K_SCAN_MULTI, (double)n * 8.0);
 #define RV_SCAN_(KT) hipLaunchKernelGGL(k_casm_scan<KT>, dim3((unsigned)ceil_div(n, MS_TILE)), dim3(TB), 0, q, SA, LCP, BWT, (const uint8_t *)bso.as<uint8_t>(), n, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt)
-        if (!ws.opt.scan_v1) RV_TRY(rv_full_list_launch(ws, SA, LCP, BWT, n, nsep, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_cnt, CM_REGIONS, ev_a, ev_b));
+        if (!ws.opt.scan_v1) {
+            RV_TRY(rv_full_list_launch(ws, SA, LCP, BWT, n, nsep, k, minl, bcl0.as<u32>(), bcp0.as<sa_t>(), rcap, region_spread, CM_REGIONS, CNT_STRIDE, ev_a, ev_b));
+            hipLaunchKernelGGL(k_casm_collect, dim3(1), dim3(64), 0, q, (const u32 *)region_spread, CNT_STRIDE, region_cnt);
+        }
         else switch (k) {      // (RV_SCAN_V1: the kernel that stages a workgroup's ranks in LDS, for comparison)
             case 3: RV_SCAN_(3); break; case 4: RV_SCAN_(4); break; case 5: RV_SCAN_(5); break; case 6: RV_SCAN_(6); break; case 8: RV_SCAN_(8); break;
             case 10: RV_SCAN_(10); break; case 12: RV_SCAN_(12); break; case 16: RV_SCAN_(16); break; default: RV_SCAN_(0); break;

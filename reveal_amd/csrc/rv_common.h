@@ -90,7 +90,6 @@ void rv_set_error(const char *fmt, ...);
     X(sa_no_text, "RV_SA_NO_TEXT", 0) \
     X(text_mode, "RV_TEXT_MODE", -1) \
     X(carry_ch, "RV_CARRY_CH", -1) \
-    X(launch_trace, "RV_LAUNCH_TRACE", 0) \
     X(rs_bits, "RV_RS_BITS", 8) \
     X(rs_xcd, "RV_RS_XCD", 1) \
     X(rs_cnt16, "RV_RS_CNT16", 1) \
@@ -104,7 +103,8 @@ void rv_set_error(const char *fmt, ...);
     X(casm_big_total, "RV_CASM_BIG_TOTAL", 1 << 26) \
     X(lock_any, "RV_LOCK_ANY", 0) \
     X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536) \
-    X(scan_v1, "RV_SCAN_V1", 0)
+    X(scan_v1, "RV_SCAN_V1", 0) \
+    X(pick_threads, "RV_PICK_THREADS", 0)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)
@@ -116,7 +116,7 @@ struct RvOptions {
         return nullptr;
     }
 };
-extern int g_rv_launch_trace;      // process-wide (rv_api.hip): set by rv_set_option(.., "RV_LAUNCH_TRACE", ..) of any handle
+extern int g_rv_launch_trace;      // process-wide (rv_api.hip): rv_set_launch_trace(), not a switch of a handle
 // RV_LAUNCH_TRACE=1 (diagnostics): print the source line of every kernel launch and wait for it, so that a GPU memory fault
 // (which aborts the process) names the kernel behind it
 static inline bool rv_launch_trace_on() { return g_rv_launch_trace != 0; }

@@ -3,7 +3,7 @@
 #include "rv_common.h"
 
 #ifndef RV_PAIR_TILE
-#define RV_PAIR_TILE 512     // ranks per tile of the pair scan = what one wave scans
+#define RV_PAIR_TILE 1024    // ranks per tile of the pair scan = what one wave scans (sixteen per lane)
 #endif
 #define RV_TSUB_TILE 2048    // granularity of the tile -> sub-index tables the host ships (== RV_SPLIT_TILE)
 
@@ -15,9 +15,9 @@ struct RvPairRec {
     u32  rank;
 };
 
-#define RV_PAIR_SLOTS 8
+#define RV_PAIR_SLOTS 16
 // Streams SA/LCP/BWT[0..m) once.  The first RV_PAIR_SLOTS survivors of tile t
-// (512 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
+// (1024 ranks, rank order) go to slots[t*RV_PAIR_SLOTS ..], further ones to
 // ovf[tileovf[t] ..] (*ovf_counter must be zero: rv_pair_compact_launch leaves it so);
 // tilecnt[t] = number of survivors, tilecnt[ntile] = 0.  rv_pair_compact_launch packs them densely in rank order given
 // tileoff = exclusive scan of tilecnt.
@@ -62,8 +62,8 @@ int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
 #define RV_MULTI_CAND_BYTES 16
 // Full matches of a whole index with k samples (2 <= k <= 16; the anchor cascade's root list, rv_cascade_multi.hip): every LCP interval of exactly k
 // ranks with a value of minl or more whose members are of k different samples and left-maximal.  Entry i of region r (nregions a power of two, counters
-// region_cnt[r] zeroed by the caller; entries beyond rcap are counted, not stored) lives at r * rcap + i: c_len = the value, c_pos[.. * k + s] = the
-// member of sample s.
+// region_cnt[r * cnt_stride] zeroed by the caller -- 64 words apart they sit in different L2 channels; entries beyond rcap are counted, not stored)
+// lives at r * rcap + i: c_len = the value, c_pos[.. * k + s] = the member of sample s.
 int rv_full_list_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int k, u32 minl,
-                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
+                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, int cnt_stride, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 #define RV_MULTI_REGIONS 64      // the picker's candidate list: regions with a counter each (counter r at word 64 * r, the largest count at word 64 * RV_MULTI_REGIONS)

@@ -34,6 +34,7 @@ constexpr int PAIR_TILE = TB * PAIR_ITEMS;      // ranks per workgroup
 __device__ inline int64_t ceil_div_dev(int64_t a, int64_t b) { return (a + b - 1) / b; }
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u32 __attribute__((ext_vector_type(4)));
 
 __device__ inline bool is_lower_c(uint8_t c) { return c >= 'a' && c <= 'z'; }
 
@@ -53,13 +54,59 @@ __device__ inline bool lcp_lt(lcp_t v, int minl) {
 #endif
 }
 
+// A wave's 1024 LCP values, sixteen consecutive ranks per lane.  Loaded the way the lanes want them -- lane i the 64 bytes at 64 i, four 16-byte
+// loads -- every load instruction touches 64 different cache lines for a quarter of each (the pair scan with this pattern: 646 us at 2 x 250 Mbp
+// against 620 with eight ranks per lane, its instruction count more than halved).  So the loads are the memory system's: lane i takes 16 bytes at
+// 16 i, 1 KB per instruction, and the values change lanes in the wave's corner of LDS (rows padded to 80 bytes: conflict-free 16-byte reads).
+// No workgroup barrier: the corner belongs to one wave, whose LDS operations complete in order.
+constexpr int LT_ROW = 5;      // uint4 per lane's row (four used)
+__device__ inline void wave_lcp16(const lcp_t *__restrict__ LCP, int64_t wfirst, int lane, uint4 *__restrict__ corner, u32 *out /* [16] */) {
+    const v4i *src = reinterpret_cast<const v4i *>(LCP + wfirst);
+    v4i v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = __builtin_nontemporal_load(src + j * 64 + lane);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int r4 = j * 64 + lane;
+        corner[(r4 >> 2) * LT_ROW + (r4 & 3)] = make_uint4((u32)v[j].x, (u32)v[j].y, (u32)v[j].z, (u32)v[j].w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 t = corner[lane * LT_ROW + j];
+        out[4 * j] = t.x; out[4 * j + 1] = t.y; out[4 * j + 2] = t.z; out[4 * j + 3] = t.w;
+    }
+}
+
+// four ranks at once: x = their BWT bytes (bit 7 = side of the separator, RV_BWT_SIDE), y = the bytes of the ranks in front of each.
+// -> bit 7 of byte i set iff the two suffixes start on different sides of the separator (not a repeat inside one sample, reveal.c:73) and are
+// left-maximal (reveal.c:81-85: the characters differ, or the one in front is N / $ / lower case -- which only decides anything when they are
+// equal, and then either of them will do).  (v + 0x7f..: bit 7 of a 7-bit byte set iff it is not zero; no carry leaves such a byte.)
+__device__ inline u32 pair_bytes4(u32 x, u32 y) {
+    const u32 K = 0x7f7f7f7fu;
+    const u32 xc = x & K, yc = y & K;
+    const u32 ne = (xc ^ yc) + K;
+    const u32 plain = ((xc ^ 0x4e4e4e4eu) + K) & ((xc ^ 0x24242424u) + K);      // neither 'N' nor '$'
+    const u32 low = (xc + 0x1f1f1f1fu) & ~(xc + 0x05050505u);                    // 'a' .. 'z'
+    return (x ^ y) & (ne | ~plain | low) & 0x80808080u;
+}
+__device__ inline u32 bits4_of_bytes(u32 e) {      // bit 7 of the four bytes -> bits 0 .. 3
+    u32 v = (e >> 7) & 0x01010101u;
+    v |= v >> 7;
+    v |= v >> 14;
+    return v & 0xfu;
+}
+
 __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m,
                                                   const uint8_t *__restrict__ BWT, sa_t nsep0, int minl,
                                                   RvPairRec *__restrict__ slots, RvPairRec *__restrict__ ovf, u32 ovf_cap,
                                                   u32 *__restrict__ ovf_counter, u32 *__restrict__ tilecnt, u32 *__restrict__ tileovf,
                                                   unsigned long long *__restrict__ best, RvPairRec *__restrict__ picks, int nsubs) {
+    static_assert(PAIR_ITEMS == 16, "sixteen ranks per lane: four 16-byte loads of LCP, one of BWT");
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    // one 2048-rank stretch per block (persistent blocks walking several tiles measured 25 % slower: the
+    // one stretch of TB x 16 ranks per block (persistent blocks walking several tiles measured 25 % slower: the
     // block-wide append at the end of a tile then no longer overlaps with another block's loads)
     const int64_t tile = blockIdx.x;
     const int64_t i0 = tile * PAIR_TILE + (int64_t)threadIdx.x * PAIR_ITEMS;
@@ -72,73 +119,66 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
     // trip per wave (measured: the bare load pattern of this kernel streams 6.3 TB/s, the kernel 3.5).
     const int64_t wfirst = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63)) * (int64_t)PAIR_ITEMS + tile * PAIR_TILE;
     const int64_t wnext = wfirst + 64 * PAIR_ITEMS;
-    lcp_t h_lc = 0, h_nlc = 0; uint8_t h_bw = 0;
-    if (wfirst > 0 && wfirst - 1 < m) { h_lc = LCP[wfirst - 1]; h_bw = BWT[wfirst - 1]; }
-    if (wnext < m) h_nlc = LCP[wnext];
+    u32 h_lc = 0, h_nlc = 0, h_bw = 0;
+    if (wfirst > 0 && wfirst - 1 < m) { h_lc = (u32)LCP[wfirst - 1]; h_bw = BWT[wfirst - 1]; }
+    if (wnext < m) h_nlc = (u32)LCP[wnext];
 
     // What is streamed: LCP (4 B) and the BWT byte, whose bit 7 says on which side of the separator the suffix starts
     // (RV_BWT_SIDE, rv_common.h) -- the predicate of reveal.c:61-85 needs nothing else of SA.  SA is fetched for the
     // survivors only (one in a few hundred ranks).
-    lcp_t lc[PAIR_ITEMS];
-    uint8_t bw[PAIR_ITEMS];
-    if (i0 + PAIR_ITEMS <= m) {
-        // streamed once: non-temporal 16-byte loads (8 B of BWT)
-        if (PAIR_ITEMS == 4) {
-            const u32 bb = __builtin_nontemporal_load(reinterpret_cast<const u32 *>(BWT + i0));
-#pragma unroll
-            for (int k = 0; k < 4 && k < PAIR_ITEMS; k++) bw[k] = (uint8_t)(bb >> (8 * k));
-        }
-#pragma unroll
-        for (int v8 = 0; v8 < PAIR_ITEMS / 8; v8++) {
-            const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0) + v8);
-#pragma unroll
-            for (int k = 0; k < 4; k++) { bw[8 * v8 + k] = (uint8_t)(bb.x >> (8 * k)); bw[8 * v8 + 4 + k] = (uint8_t)(bb.y >> (8 * k)); }
-        }
-#pragma unroll
-        for (int v4 = 0; v4 < PAIR_ITEMS / 4; v4++) {
-            const v4i c = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(LCP + i0) + v4);
-            lc[4 * v4] = (lcp_t)c.x; lc[4 * v4 + 1] = (lcp_t)c.y; lc[4 * v4 + 2] = (lcp_t)c.z; lc[4 * v4 + 3] = (lcp_t)c.w;
-        }
+    __shared__ uint4 s_corner[TB / 64][64 * LT_ROW];
+    u32 lc[PAIR_ITEMS + 2], bx[PAIR_ITEMS / 4];      // lc[0] / lc[17]: the ranks in front of and behind my sixteen
+    if (wnext <= m) {      // (the whole wave inside the arrays)
+        // streamed once: non-temporal 16-byte loads, a kilobyte per instruction (the BWT bytes are sixteen per lane as they lie)
+        const v4u32 bb = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(BWT + i0));
+        bx[0] = bb.x; bx[1] = bb.y; bx[2] = bb.z; bx[3] = bb.w;
+        wave_lcp16(LCP, wfirst, lane, s_corner[w], lc + 1);
     } else {
 #pragma unroll
+        for (int k = 0; k < PAIR_ITEMS / 4; k++) bx[k] = 0;
+#pragma unroll
         for (int k = 0; k < PAIR_ITEMS; k++) {
-            lc[k] = (i0 + k < m) ? LCP[i0 + k] : (lcp_t)0;
-            bw[k] = (i0 + k < m) ? BWT[i0 + k] : (uint8_t)0;
+            lc[1 + k] = (i0 + k < m) ? (u32)LCP[i0 + k] : 0u;
+            bx[k >> 2] |= ((i0 + k < m) ? (u32)BWT[i0 + k] : 0u) << (8 * (k & 3));
         }
     }
     // neighbours: previous rank's LCP / BWT byte, next rank's LCP (0 past the end)
-    lcp_t plc = (lcp_t)__shfl_up((int)lc[PAIR_ITEMS - 1], 1, 64);
-    lcp_t nlc = (lcp_t)__shfl_down((int)lc[0], 1, 64);
-    uint8_t pbw = (uint8_t)__shfl_up((int)bw[PAIR_ITEMS - 1], 1, 64);
-    if (lane == 0) { plc = h_lc; pbw = h_bw; }
-    if (lane == 63) nlc = h_nlc;
+    lc[0] = (u32)__shfl_up((int)lc[PAIR_ITEMS], 1, 64);
+    lc[PAIR_ITEMS + 1] = (u32)__shfl_down((int)lc[1], 1, 64);
+    u32 plast = (u32)__shfl_up((int)bx[PAIR_ITEMS / 4 - 1], 1, 64);
+    if (lane == 0) { lc[0] = h_lc; plast = h_bw << 24; }
+    if (lane == 63) lc[PAIR_ITEMS + 1] = h_nlc;
 
-    // The predicate, branch-free (bitwise & | on the comparison results): written with && / ?: the compiler emitted one
-    // exec-mask branch per term -- 120 of them per thread -- and the kernel was bound by control flow, not by memory.
-    // Ranks past the end were loaded as zeros and a sub-index' first rank has LCP 0, so neither can pass `lb < l`:
-    // no bounds tests are needed here.
+    // The predicate, branch-free and mostly not per rank.  LCP: "long enough, larger than both neighbours" (unique, reveal.c:76-79) is ONE
+    // comparison with the maximum of three (the neighbours and minl - 1).  BWT: the side bit and left-maximality of four ranks at a time
+    // (pair_bytes4).  28 vector instructions per rank in the form with a compare chain per rank -- the kernel spent more time issuing them
+    // than waiting for memory (SQ_INSTS_VALU, r04_insts_c4.txt) -- about 11 now.
+    // Ranks past the end were loaded as zeros and a sub-index' first rank has LCP 0, so neither can pass: no bounds tests are needed here.
+#ifdef RV_SA64
+    const u32 thr = minl < 0 ? 0xFFFFFFFFu : (minl >= 1 ? (u32)minl - 1u : 0u);      // (unsigned compare with minl, as the reference's uint32 lcp_t: nothing is "long enough" for a negative minl)
+#else
+    const u32 thr = minl >= 1 ? (u32)minl - 1u : 0u;
+#endif
     u32 hit = 0;        // bitmask over my ranks
 #pragma unroll
     for (int k = 0; k < PAIR_ITEMS; k++) {
-        const lcp_t l = lc[k], lb = (k == 0) ? plc : lc[k - 1];
-        const lcp_t la = (k == PAIR_ITEMS - 1) ? nlc : lc[k + 1];
-        const u32 b1 = bw[k], b0 = (k == 0) ? pbw : bw[k - 1];
-        const u32 c1 = b1 & RV_BWT_CHAR, c0 = b0 & RV_BWT_CHAR;
-        // reveal.c:81-85 inspects the character in front of the SMALLER text position for N / $ / lower case; that only
-        // decides anything when the two characters are equal, and then either of them will do
-        const bool special = (c1 == 'N') | (c1 == '$') | ((c1 - 'a') < 26u);
-        const bool ok = (!lcp_lt(l, minl)) & (((b1 ^ b0) & RV_BWT_SIDE) != 0)   // long enough; not a repeat inside one sample
-                      & (lb < l) & (la < l)                       // unique
-                      & ((c1 != c0) | special);                   // left-maximal (reveal.c:81-85)
-        hit |= (u32)ok << k;
+        const u32 a = lc[k], c = lc[k + 2];
+        u32 mx = a > c ? a : c;
+        mx = mx > thr ? mx : thr;
+        hit |= (u32)(lc[k + 1] > mx) << k;
     }
-    // order-preserving append of the survivors.  A tile is what one wave scans (512 ranks): no workgroup barrier, a wave
+    u32 okb = 0;
+#pragma unroll
+    for (int k = 0; k < PAIR_ITEMS / 4; k++) {
+        const u32 y = __builtin_amdgcn_alignbit(bx[k], k ? bx[k - 1] : plast, 24);      // byte i = the BWT byte of the rank in front of rank 4k + i
+        okb |= bits4_of_bytes(pair_bytes4(bx[k], y)) << (4 * k);
+    }
+    hit &= okb;
+    // order-preserving append of the survivors.  A tile is what one wave scans: no workgroup barrier, a wave
     // retires as soon as its own loads are consumed.
     const u32 mine = __popc(hit);
-    u32 inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(inc, d, 64); if (lane >= d) inc += t; }
-    const u32 tot = (u32)__shfl((int)inc, 63, 64);
+    const u32 inc = rv_wave_incl_sum_u32(mine);
+    const u32 tot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
     const int64_t wtile = tile * (TB / 64) + w;
     if (wfirst >= m) return;                     // (a wave entirely past the end)
     // The first RV_PAIR_SLOTS survivors of a tile go to the tile's own slots (no atomics at all in the common case); only a
@@ -151,8 +191,7 @@ __global__ __launch_bounds__(TB) void k_scan_pair(const sa_t *__restrict__ SA, c
         tileovf[wtile] = base;
     }
     base = (u32)__shfl((int)base, 0, 64);
-    // one trip per survivor of the lane (usually one), not one per rank: walking all PAIR_ITEMS bits cost every wave with a
-    // survivor anywhere some forty instructions, a third of the kernel's VALU work (SQ_INSTS_VALU: 28 per rank)
+    // one trip per survivor of the lane (usually one), not one per rank
     u32 hh = hit, q = inc - mine;                // q: index inside the tile
     while (hh) {
         const int k = __builtin_ctz(hh);
@@ -658,71 +697,70 @@ __global__ __launch_bounds__(TB) void k_multi_pick2(const sa_t *__restrict__ SA,
 // A FULL match of a sub-index with `want` samples is the LCP interval of exactly `want` ranks [lb, u], lb = u - want + 1:
 // value l = min LCP[lb+1 .. u] >= minl, LCP[lb] < l > LCP[u+1], its members' samples all different (reveal.c:231-244) and
 // left-maximal (reveal.c:246-256).  This is what the built-in picker takes (schemes.py:227) and what the anchor cascade
-// lists at the root, so both scans run on the skeleton below -- the pair scan's: a wave streams 512 ranks, eight per lane
-// (non-temporal 16-byte loads of LCP, 8 bytes of BWT), and tests them branch-free on two bit windows:
+// lists at the root, so both scans run on the skeleton below -- the pair scan's: a wave streams 1024 ranks, SIXTEEN per
+// lane (non-temporal 16-byte loads: four of LCP, one of BWT), and tests them branch-free on two 32-rank bit windows
+// (my sixteen ranks and the sixteen in front of them, which the lane below hands up by shuffle -- lane 0 gets them from
+// the wave's halo):
 //   G bit j: LCP[j] >= minl                                   -- a full match ending at u needs G set on u-want+2 .. u
 //   D bit j: ranks j-1, j are evidence of left-maximality      -- ... and some D set on the same ranks
-// (G and D of the 16 ranks in front of a lane come from the two lanes below by shuffle, for lanes 0 and 1 from the wave's
-// halo), together with LCP[u] > LCP[u+1].  About one rank in seven hundred passes at 10 x 5 Mbp; only those ranks read
-// again -- LCP[lb .. u+1] and SA[lb .. u], independent loads of lines the wave has just streamed -- for the exact value,
-// the two strict comparisons and the samples.  No LDS, no workgroup barrier, no sample array: a wave retires when its own
-// ranks are done.  (Before: a workgroup staged 2048 ranks of LCP, a sample byte and BWT in LDS and walked the candidates --
-// one rank in ten -- in two dense stages between seven barriers: 130 us at 10 x 5 Mbp, 0.23 of the 8 TB/s.)
+// together with LCP[u] > LCP[u+1].  "All of the H = want - 1 bits below and at u" is one AND-doubling ladder for all
+// sixteen ranks at once (A2 = A1 & A1 << 1, A4 = A2 & A2 << 2, A8 ..., combined by the bits of H); D's bits come from
+// the BWT words four characters at a time (byte-parallel compares; every character is ASCII, bit 7 is the carry room).
+// About one rank in seven hundred passes at 10 x 5 Mbp.  Those are taken one at a time by the WHOLE wave: lane j reads
+// LCP[lb + j] and SA[lb + j] -- lines the wave has just streamed --, the value is a wave minimum, the samples a count of
+// the separators below each member (uniform addresses: scalar loads), their census a wave OR.  No LDS, no workgroup
+// barrier, no sample array: a wave retires when its own ranks are done.
+// The kernel is bound by instruction issue, not by memory, and was written against that: the first form of this skeleton
+// (8 ranks per lane, a compare chain per rank and per window, a passing rank's sixteen members walked by its own lane)
+// issued ~1 000 vector instructions per wave and took 200 us at 10 x 5 Mbp; before that a workgroup staged 2048 ranks in
+// LDS and walked the candidates -- one rank in ten -- in two dense stages between seven barriers: 130 us.
 //
 // MODE 0 (cascade root, rv_cascade_multi.hip): want = k everywhere; survivors are listed (length, the k positions by sample).
-// MODE 1 (built-in picker): want = the sample count of the rank's sub-index, looked up per lane (a lane whose eight ranks
+// MODE 1 (built-in picker): want = the sample count of the rank's sub-index, looked up per lane (a lane whose sixteen ranks
 //         straddle two sub-indices, or whose sub-index has more than FS_HALO samples, takes the general path rank by rank);
 //         survivors raise the maximum of their sub-index and are listed for k_multi_pick2.
-constexpr int FS_ITEMS = 8, FS_WTILE = 64 * FS_ITEMS, FS_TILE = (TB / 64) * FS_WTILE, FS_HALO = 16;
-static_assert(FS_TILE == RV_TSUB_TILE, "a workgroup covers one tile of the host's tile -> sub-index table");
+constexpr int FS_ITEMS = 16, FS_WTILE = 64 * FS_ITEMS, FS_TILE = (TB / 64) * FS_WTILE, FS_HALO = 16, FS_SEPS = 15;
+static_assert(FS_WTILE * 2 == RV_TSUB_TILE, "a wave covers half a tile of the host's tile -> sub-index table");
 
 __device__ inline bool fs_evidence(u32 ca, u32 cb) {      // reveal.c:246-256 on the characters in front of two neighbouring ranks ('$' where SA == 0)
     return (cb == '$') | (ca != cb) | (ca == 'N') | (ca == '$') | ((ca - 'a') < 26u);
 }
-
-// exact test of the full match [u - want + 1, u] (want <= FS_HALO); -> value, members (SA order), their smallest position
-__device__ inline bool fs_exact(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, int64_t m, const sa_t *__restrict__ nsep, int nsamples,
-                                int64_t u, int want, u32 minl, u32 &l_out, sa_t *sv, int *ss, sa_t &mn_out) {
-    const int64_t lb = u - want + 1;
-    if (lb < 0) return false;
-    u32 lv[FS_HALO];
-#pragma unroll
-    for (int d = 0; d < FS_HALO; d++) lv[d] = (u32)LCP[d < want - 1 ? u - d : u];      // (independent, predicated: one round trip)
-#pragma unroll
-    for (int k = 0; k < FS_HALO; k++) sv[k] = SA[k < want ? lb + k : u];
-    const u32 below = (u32)LCP[lb], nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
-    u32 l = lv[0];
-#pragma unroll
-    for (int d = 1; d < FS_HALO; d++) l = lv[d] < l ? lv[d] : l;
-    if (!((l >= minl) & (l > nxt) & (below < l))) return false;
-    // the members' samples (interface.c:116-134: the separators in front of a position), every member at once: ONE pass over the separators --
-    // uniform addresses, scalar loads -- in which each member counts those below it.  (A binary search per member was sixteen chains of dependent
-    // vector loads per passing rank: 203 us for the scan of 10 x 5 Mbp, of which ~150 waiting for them.)
-#pragma unroll
-    for (int k = 0; k < FS_HALO; k++) ss[k] = 0;
-    for (int q = 0; q < nsamples - 1; q++) {
-        const sa_t sp = nsep[q];
-#pragma unroll
-        for (int k = 0; k < FS_HALO; k++) ss[k] += sp < sv[k] ? 1 : 0;
-    }
-    u64 seen = 0; bool distinct = true;
-    sa_t mn = sv[0];
-#pragma unroll
-    for (int k = 0; k < FS_HALO; k++) {
-        if (k < want) {
-            const u64 bit = 1ull << (ss[k] & 63);
-            distinct &= !(seen & bit); seen |= bit;
-            mn = sv[k] < mn ? sv[k] : mn;
-        }
-    }
-    l_out = l; mn_out = mn;
-    return distinct;
+// the same for four ranks at once: x = their characters (7 bits each, one per byte), y = the characters of the ranks in front of each.
+// -> bit 7 of byte i set iff fs_evidence(y_i, x_i).  (v + 0x7f..: bit 7 of a byte set iff the byte is not zero; no carry leaves a 7-bit byte.)
+__device__ inline u32 fs_evidence4(u32 x, u32 y) {
+    const u32 K = 0x7f7f7f7fu;
+    const u32 ne = (x ^ y) + K;                                   // ca != cb
+    const u32 eq = ((x ^ 0x24242424u) + K) & ((y ^ 0x4e4e4e4eu) + K) & ((y ^ 0x24242424u) + K);      // none of cb == '$', ca == 'N', ca == '$'
+    const u32 low = (y + 0x1f1f1f1fu) & ~(y + 0x05050505u);       // 'a' <= ca <= 'z'
+    return (ne | ~eq | low) & 0x80808080u;
+}
+__device__ inline u32 fs_bits4(u32 e) {      // bit 7 of the four bytes -> bits 0 .. 3
+    u32 v = (e >> 7) & 0x01010101u;
+    v |= v >> 7;
+    v |= v >> 14;
+    return v & 0xfu;
+}
+// bit b of the result: bits b-H+1 .. b of g are all set (H = 0: every bit set).  H < 16.
+__device__ inline u32 fs_run(u32 g, int H) {
+    const u32 a1 = g, a2 = a1 & (a1 << 1), a4 = a2 & (a2 << 2), a8 = a4 & (a4 << 4);
+    u32 acc = 0xFFFFFFFFu; int off = 0;
+    if (H & 8) { acc &= a8; off = 8; }
+    if (H & 4) { acc &= a4 << off; off += 4; }
+    if (H & 2) { acc &= a2 << off; off += 2; }
+    if (H & 1) acc &= a1 << off;
+    return acc;
+}
+__device__ inline u32 rv_wave_or_u32(u32 v) {      // every lane gets the OR over the wave
+#define RV_STEP_(CTRL, RM, TAKE) v |= rv_dpp_u32<CTRL, RM>(v);
+    RV_WAVE_SCAN_STEPS(RV_STEP_)        // (a lane without a source lane sees 0)
+#undef RV_STEP_
+    return (u32)__builtin_amdgcn_readlane((int)v, 63);
 }
 
 template <int MODE>
 __global__ __launch_bounds__(TB) void k_full_scan(const sa_t *__restrict__ SA, const lcp_t *__restrict__ LCP, const uint8_t *__restrict__ BWT, int64_t m,
                                                   const sa_t *__restrict__ nsep, int nsamples, u32 minl, int minn,
-                                                  u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 rcap, u32 *__restrict__ region_cnt, int nregions,
+                                                  u32 *__restrict__ c_len, sa_t *__restrict__ c_pos, u32 rcap, u32 *__restrict__ region_cnt, int nregions, int cnt_stride,
                                                   const int64_t *__restrict__ sub_start, const int *__restrict__ sub_want, int nsubs, const int *__restrict__ tile_sub,
                                                   unsigned long long *__restrict__ best, RvMultiCand *__restrict__ cand, u32 cand_cap, u32 *__restrict__ cand_count) {
     const int lane = threadIdx.x & 63;
@@ -737,15 +775,20 @@ __global__ __launch_bounds__(TB) void k_full_scan(const sa_t *__restrict__ SA, c
         if (lane < FS_HALO && j >= 0) { h_lc = (u32)LCP[j]; h_bw = (u32)BWT[j]; }      // (the side bit is masked where the byte is used: masking here made the wave wait for this load before it issued the streaming ones)
         if (wfirst + FS_WTILE < m) h_nlc = (u32)LCP[wfirst + FS_WTILE];
     }
+    // the first separators, in scalar registers before anything waits for them (the separator array is a DBuf: its allocation reaches 256 bytes beyond
+    // the last separator, so these loads stay inside it whatever the sample count; what lies behind the last separator is masked where it is used)
+    sa_t sep[FS_SEPS];
+#pragma unroll
+    for (int q = 0; q < FS_SEPS; q++) sep[q] = nsep[q];
     // the sub-index of the lane's first rank and its sample count (MODE 1)
     int want = nsamples, mine = 0, s_last = 0;
     bool slow = false;
     if (MODE == 1) {
-        const int64_t tt = blockIdx.x, ntsub = (m + FS_TILE - 1) / FS_TILE;
+        const int64_t tt = wfirst / RV_TSUB_TILE, ntsub = (m + RV_TSUB_TILE - 1) / RV_TSUB_TILE;
         const int s0 = tile_sub[tt];
         s_last = tt + 1 < ntsub ? tile_sub[tt + 1] : nsubs - 1;
         mine = s0;
-        if (s_last > s0) {      // (several sub-indices in this workgroup's ranks: the largest s with sub_start[s] <= i0)
+        if (s_last > s0) {      // (several sub-indices around this wave's ranks: the largest s with sub_start[s] <= i0)
             int lo = s0, hi = s_last;
             while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= i0) lo = mid; else hi = mid - 1; }
             mine = lo;
@@ -756,127 +799,137 @@ __global__ __launch_bounds__(TB) void k_full_scan(const sa_t *__restrict__ SA, c
         if (want > FS_HALO) slow = true;
         if (!slow && !(want >= minn && want >= 2 && want <= nsamples)) want = 1;      // (no match can have this size: the window test below fails everywhere)
     }
-    u32 lc[FS_ITEMS + 1], bw[FS_ITEMS];
-    if (i0 + FS_ITEMS <= m) {
-        const v2u bb = __builtin_nontemporal_load(reinterpret_cast<const v2u *>(BWT + i0));
-#pragma unroll
-        for (int k = 0; k < 4; k++) { bw[k] = (bb.x >> (8 * k)) & RV_BWT_CHAR; bw[4 + k] = (bb.y >> (8 * k)) & RV_BWT_CHAR; }
-#pragma unroll
-        for (int v4 = 0; v4 < FS_ITEMS / 4; v4++) {
-            const v4i c = __builtin_nontemporal_load(reinterpret_cast<const v4i *>(LCP + i0) + v4);
-            lc[4 * v4] = (u32)c.x; lc[4 * v4 + 1] = (u32)c.y; lc[4 * v4 + 2] = (u32)c.z; lc[4 * v4 + 3] = (u32)c.w;
-        }
+    __shared__ uint4 s_corner[TB / 64][64 * LT_ROW];
+    u32 lc[FS_ITEMS + 1], bx[FS_ITEMS / 4];
+    if (wfirst + FS_WTILE <= m) {      // (the whole wave inside the arrays)
+        const v4u32 bb = __builtin_nontemporal_load(reinterpret_cast<const v4u32 *>(BWT + i0));
+        bx[0] = bb.x; bx[1] = bb.y; bx[2] = bb.z; bx[3] = bb.w;
+        wave_lcp16(LCP, wfirst, lane, s_corner[w], lc);
     } else {
+#pragma unroll
+        for (int k = 0; k < FS_ITEMS / 4; k++) bx[k] = 0;
 #pragma unroll
         for (int k = 0; k < FS_ITEMS; k++) {
             lc[k] = (i0 + k < m) ? (u32)LCP[i0 + k] : 0u;
-            bw[k] = (i0 + k < m) ? ((u32)BWT[i0 + k] & RV_BWT_CHAR) : 0u;
+            bx[k >> 2] |= ((i0 + k < m) ? (u32)BWT[i0 + k] : 0u) << (8 * (k & 3));
         }
     }
     asm volatile("" : "+v"(h_bw), "+v"(h_lc));      // (the halo's values are first looked at here, behind the streaming loads: see above)
+#pragma unroll
+    for (int k = 0; k < FS_ITEMS / 4; k++) bx[k] &= 0x7f7f7f7fu;      // RV_BWT_CHAR: the side bit off
+    h_bw &= RV_BWT_CHAR;
     lc[FS_ITEMS] = (u32)__shfl_down((int)lc[0], 1, 64);
     if (lane == 63) lc[FS_ITEMS] = h_nlc;
-    u32 pbw = (u32)__shfl_up((int)bw[FS_ITEMS - 1], 1, 64);
-    h_bw &= RV_BWT_CHAR;
-    const u32 hb15 = (u32)__builtin_amdgcn_readlane((int)h_bw, FS_HALO - 1);
-    if (lane == 0) pbw = hb15;
-    // per-rank bits of my eight ranks: closes an interval (c), G, D
-    u32 c8 = 0, g8 = 0, d8 = 0;
+    // per-rank bits of my sixteen ranks: G, closes an interval (c), D
+    u32 c16 = 0, g16 = 0;
 #pragma unroll
     for (int k = 0; k < FS_ITEMS; k++) {
         const bool g = lc[k] >= minl;
-        g8 |= (u32)g << k;
-        c8 |= (u32)(g & (lc[k] > lc[k + 1])) << k;
-        d8 |= (u32)fs_evidence(k == 0 ? pbw : bw[k - 1], bw[k]) << k;
+        g16 |= (u32)g << k;
+        c16 |= (u32)(g & (lc[k] > lc[k + 1])) << k;
+    }
+    u32 plast = (u32)__shfl_up((int)bx[FS_ITEMS / 4 - 1], 1, 64);      // the four characters in front of my first rank (the last one matters)
+    const u32 hb15 = (u32)__builtin_amdgcn_readlane((int)h_bw, FS_HALO - 1);
+    if (lane == 0) plast = hb15 << 24;
+    u32 d16 = 0;
+#pragma unroll
+    for (int k = 0; k < FS_ITEMS / 4; k++) {
+        const u32 y = __builtin_amdgcn_alignbit(bx[k], k ? bx[k - 1] : plast, 24);      // byte i = the character in front of rank 4k + i's
+        d16 |= fs_bits4(fs_evidence4(bx[k], y)) << (4 * k);
     }
     // the same bits of the 16 ranks in front of my first one
-    const u32 mw = g8 | (d8 << 8);
-    u32 pw = (u32)__shfl_up((int)mw, 1, 64), ppw = (u32)__shfl_up((int)mw, 2, 64);
+    u32 pw = (u32)__shfl_up((int)(g16 | (d16 << 16)), 1, 64);
     {
         const u32 hprev = (u32)__shfl_up((int)h_bw, 1, 64);
         const u64 HG = __ballot((lane < FS_HALO) & (h_lc >= minl));
         const u64 HD = __ballot((lane < FS_HALO) & (lane > 0) & fs_evidence(hprev, h_bw));
-        const u32 hlo = ((u32)HG & 0xffu) | (((u32)HD & 0xffu) << 8), hhi = (((u32)HG >> 8) & 0xffu) | ((((u32)HD >> 8) & 0xffu) << 8);
-        if (lane == 0) { pw = hhi; ppw = hlo; }
-        if (lane == 1) ppw = hhi;
+        if (lane == 0) pw = ((u32)HG & 0xffffu) | (((u32)HD & 0xffffu) << 16);
     }
-    const u32 G24 = (ppw & 0xffu) | ((pw & 0xffu) << 8) | (g8 << 16);
-    const u32 D24 = ((ppw >> 8) & 0xffu) | (((pw >> 8) & 0xffu) << 8) | (d8 << 16);
-    u32 todo = 0;
+    const u32 G32 = (pw & 0xffffu) | (g16 << 16);
+    const u32 D32 = (pw >> 16) | (d16 << 16);
+    u32 todo = c16;
     if (!slow) {
         const int H = want - 1;                      // 0 .. FS_HALO - 1
-        const u32 MH = (1u << H) - 1u;
-#pragma unroll
-        for (int k = 0; k < FS_ITEMS; k++) {
-            const int sh = 17 + k - H;               // ranks u - want + 2 .. u of rank u = my k-th (bit 16 + k)
-            const u32 gi = (G24 >> sh) & MH, di = (D24 >> sh) & MH;
-            todo |= (((c8 >> k) & 1u) & (u32)(gi == MH) & (u32)(di != 0u)) << k;
-        }
-    } else {
-        todo = c8;
+        todo = (((c16 << 16) & fs_run(G32, H) & ~fs_run(~D32, H)) >> 16);      // (H = 0: the second term is everything, its complement nothing)
     }
     const u32 reg = MODE == 0 ? (blockIdx.x & (u32)(nregions - 1)) : (blockIdx.x % RV_MULTI_REGIONS);
-    const u64 lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    // the ranks that passed (rounds of one per lane; the wave leaves together: the ballot)
-    while (__any(todo != 0u)) {
-        bool ok = false;
-        u32 l = 0; sa_t mn = 0; int64_t u = 0; int sub = mine, wn = want;
-        sa_t sv[FS_HALO]; int ss[FS_HALO];
-        if (todo) {
-            const int k = __builtin_ctz(todo);
-            todo &= todo - 1;
-            u = i0 + k;
-            if (!slow) {
-                ok = fs_exact(SA, LCP, m, nsep, nsamples, u, wn, minl, l, sv, ss, mn);
-            } else if (MODE == 1) {      // the general form, everything from global memory (reveal.c:227-259 by ismultimum_dev)
-                int lo = mine, hi = s_last;
-                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= u) lo = mid; else hi = mid - 1; }
-                sub = lo; wn = sub_want[sub];
-                const int64_t lb = u - wn + 1;
-                ok = wn >= minn && wn >= 2 && wn <= nsamples && lb >= sub_start[sub];
-                if (ok) {
-                    const u32 nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
-                    l = (u32)LCP[u];
-                    for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
-                    ok = l > nxt && l >= minl && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u);
-                    if (ok) { mn = SA[lb]; for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; } }
-                }
-            }
-        }
-        if (MODE == 0) {
-            const u64 bal = __ballot(ok);
-            if (bal) {
-                u32 base = 0;
-                if (lane == 0) base = atomicAdd(&region_cnt[reg], (u32)__popcll(bal));
-                base = (u32)__shfl((int)base, 0, 64);
-                if (ok) {
-                    const u32 i = base + (u32)__popcll(bal & lt);
-                    if (i < rcap) {
-                        const size_t o = (size_t)reg * rcap + i;
-                        c_len[o] = l;
+    // the ranks that passed, one at a time, by the whole wave
+    u64 bal = __ballot(todo != 0u);
+    while (bal) {
+        const int src = (int)__builtin_ctzll(bal);
+        const u32 td = (u32)__builtin_amdgcn_readlane((int)todo, src);
+        const int kk = __builtin_ctz(td);
+        if (lane == src) todo &= todo - 1;
+        const int64_t u = wfirst + (int64_t)src * FS_ITEMS + kk;
+        const bool slow_u = MODE == 1 && __builtin_amdgcn_readlane((int)slow, src) != 0;
+        if (!slow_u) {
+            const int wn = MODE == 0 ? nsamples : __builtin_amdgcn_readlane(want, src);
+            const int sub = MODE == 0 ? 0 : __builtin_amdgcn_readlane(mine, src);
+            const int64_t lb = u - wn + 1;             // >= 0: G is clear at rank 0 and at every sub-index' first rank
+            // lane j: LCP[lb + j] (j <= wn: lb .. u + 1) and SA[lb + j] (j < wn)
+            const int64_t at = lb + lane;
+            const u32 lv = (lane <= wn && at < m) ? (u32)LCP[at] : 0u;
+            const sa_t sv = lane < wn ? SA[at] : (sa_t)0;
+            const u32 l = rv_wave_min_u32((lane >= 1 && lane < wn) ? lv : 0xFFFFFFFFu);
+            const u32 below = (u32)__builtin_amdgcn_readlane((int)lv, 0), nxt = (u32)__builtin_amdgcn_readlane((int)lv, wn);
+            if ((l >= minl) & (l > nxt) & (below < l)) {
+                // the members' samples (interface.c:116-134: the separators in front of a position): one pass over the separators, uniform addresses
+                int sm = 0;
 #pragma unroll
-                        for (int k = 0; k < FS_HALO; k++) if (k < wn) c_pos[o * (size_t)nsamples + (size_t)ss[k]] = sv[k];
+                for (int q = 0; q < FS_SEPS; q++) sm += ((q < nsamples - 1) & (sep[q] < sv)) ? 1 : 0;
+                for (int q = FS_SEPS; q < nsamples - 1; q++) sm += nsep[q] < sv ? 1 : 0;
+                const u32 census_lo = rv_wave_or_u32((lane < wn && sm < 32) ? (1u << sm) : 0u);
+                const u32 census_hi = nsamples > 32 ? rv_wave_or_u32((lane < wn && sm >= 32) ? (1u << (sm - 32)) : 0u) : 0u;
+                if (__popc(census_lo) + __popc(census_hi) == wn) {      // all different (reveal.c:231-244)
+                    if (MODE == 0) {
+                        u32 i = 0;
+                        // (a returning atomic per listed match: ~71 000 at 10 x 5 Mbp.  With the regions' counters side by side in one cache line
+                        //  they queued up in ONE L2 channel at ~3.7 ns each -- the kernel's time was their number, 268 us, whatever else it did;
+                        //  the counters stand cnt_stride words apart now, in different channels)
+                        if (lane == 0) i = atomicAdd(&region_cnt[(size_t)reg * cnt_stride], 1u);
+                        i = (u32)__builtin_amdgcn_readfirstlane((int)i);
+                        if (i < rcap) {
+                            const size_t o = (size_t)reg * rcap + i;
+                            if (lane == 0) c_len[o] = l;
+                            if (lane < wn) c_pos[o * (size_t)nsamples + (size_t)sm] = sv;
+                        }
+                    } else {
+                        // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be the winner
+                        // k_multi_pick2 looks for (the maximum never falls): the others are not even listed.
+                        const u32 mn = rv_wave_min_u32(lane < wn ? (u32)sv : 0xFFFFFFFFu);
+                        const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - mn);
+                        if (lane == 0 && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
+                            atomicMax(&best[sub], key);
+                            const u32 rc = cand_cap / RV_MULTI_REGIONS;
+                            const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
+                            if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+                        }
                     }
                 }
             }
-        } else {
-            // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be the winner
-            // k_multi_pick2 looks for (the maximum never falls): the others are not even listed.
-            const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
-            ok = ok && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED);
-            if (ok) atomicMax(&best[sub], key);
-            const u64 bal = __ballot(ok);
-            if (bal) {
-                const u32 rc = cand_cap / RV_MULTI_REGIONS;
-                u32 qb = 0;
-                if (lane == 0) qb = atomicAdd(&cand_count[reg * 64], (u32)__popcll(bal));
-                qb = (u32)__shfl((int)qb, 0, 64);
-                if (ok) {
-                    const u32 q = qb + (u32)__popcll(bal & lt);
-                    if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+        } else if (MODE == 1 && lane == src) {      // the general form, everything from global memory (reveal.c:227-259 by ismultimum_dev)
+            int lo = mine, hi = s_last;
+            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= u) lo = mid; else hi = mid - 1; }
+            const int sub = lo, wn = sub_want[sub];
+            const int64_t lb = u - wn + 1;
+            if (wn >= minn && wn >= 2 && wn <= nsamples && lb >= sub_start[sub]) {
+                const u32 nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
+                u32 l = (u32)LCP[u];
+                for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
+                if (l > nxt && l >= minl && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
+                    sa_t mn = SA[lb];
+                    for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; }
+                    const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
+                    if (key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
+                        atomicMax(&best[sub], key);
+                        const u32 rc = cand_cap / RV_MULTI_REGIONS;
+                        const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
+                        if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+                    }
                 }
             }
         }
+        bal = __ballot(todo != 0u);
     }
 }
 
@@ -895,11 +948,11 @@ __global__ __launch_bounds__(TB) void k_mp_zero(unsigned long long *__restrict__
     } while (0)
 
 int rv_full_list_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, const uint8_t *BWT, int64_t n, const sa_t *nsep, int k, u32 minl,
-                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                        u32 *c_len, sa_t *c_pos, u32 rcap, u32 *region_cnt, int nregions, int cnt_stride, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (n <= 0) return 0;
     if (k < 2 || k > FS_HALO || (nregions & (nregions - 1))) { rv_set_error("full-match scan: sample count or region count out of range"); return -1; }
     RV_FS_LAUNCH(0, (unsigned)ceil_div(n, FS_TILE), SA, LCP, BWT, n, nsep, k, minl, 2,
-                 c_len, c_pos, rcap, region_cnt, nregions, (const int64_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr,
+                 c_len, c_pos, rcap, region_cnt, nregions, cnt_stride, (const int64_t *)nullptr, (const int *)nullptr, 0, (const int *)nullptr,
                  (unsigned long long *)nullptr, (RvMultiCand *)nullptr, 0u, (u32 *)nullptr);
     RV_LAUNCH_CHECK();
     return 0;
@@ -913,7 +966,7 @@ int rv_multi_pick_launch(Workspace &ws, const sa_t *SA, const lcp_t *LCP, int64_
     RV_LAUNCH_CHECK();
     if (nsamples <= 64 && !ws.opt.scan_v1)
         RV_FS_LAUNCH(1, (unsigned)ceil_div(m, FS_TILE), SA, LCP, BWT, m, nsep, nsamples, (u32)(minl > 1 ? minl : 1), minn,
-                     (u32 *)nullptr, (sa_t *)nullptr, 0u, (u32 *)nullptr, 1, sub_start, sub_want, nsubs, tile_sub, best, cand, cand_cap, cand_count);
+                     (u32 *)nullptr, (sa_t *)nullptr, 0u, (u32 *)nullptr, 1, 1, sub_start, sub_want, nsubs, tile_sub, best, cand, cand_cap, cand_count);
     else if (ev_start && ev_stop)      // (more than 64 samples: the samples of a match no longer fit a 64-bit census; RV_SCAN_V1: the staged kernel, for comparison)
         hipExtLaunchKernelGGL(k_multi_pick1, dim3((unsigned)ceil_div(m, RV_TSUB_TILE)), dim3(TB), 0, ws.stream, ev_start, ev_stop, 0, SA, LCP, m, BWT, nsep, nsamples, minl, minn,
                               sub_start, sub_want, nsubs, tile_sub, best, pick_l, cand, cand_cap, cand_count);

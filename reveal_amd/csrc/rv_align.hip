@@ -1314,6 +1314,12 @@ int rv_frontier_commit(rv_index *h, int32_t *children) {
     if (a->next_dev_ok) { o_nnodes = pk.addv(a->next_nodes); o_nflags = pk.addv(a->next_flags); o_ntsub2 = a->multi ? o_ntsub : pk.addv(a->next_tsub); }
     const size_t o_nss = pk.addv(a->next_ss), o_nwant = pk.addv(nx.nsamples);
     a->sub_off_h.assign(split_tabs ? (size_t)ns * 3 : 0, 0);
+    {   // SURVEY 8(a) A12 / reveal.c:666-727: bubble_sort looks at every rank of a leading child (4 B SA + 4 B LCP; the BWT byte travels with them here).
+        // The spans of the class are opened where the kernels are queued (the early ones before the host knows the children's sizes): its bytes come from here.
+        double lead_ranks = 0;
+        for (int s = 0; s < ns; s++) lead_ranks += (double)a->child_n[(size_t)s * 3];
+        h->prof.credit(RV_K_BUBBLE, lead_ranks * (double)(sizeof(sa_t) + sizeof(lcp_t) + 1));
+    }
     u32 class_total[4] = {0, 0, 0, 0};
     if (split_tabs)
         for (int s = 0; s < ns; s++) for (int c = 0; c < 3; c++) { a->sub_off_h[(size_t)s * 3 + c] = a->child_base[(size_t)s * 3 + c] - class_total[c]; class_total[c] += a->child_n[(size_t)s * 3 + c]; }

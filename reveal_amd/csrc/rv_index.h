@@ -31,6 +31,8 @@ struct RvProf {
         return (int)spans.size() - 1;
     }
     void end(hipStream_t s, int id) { if (id >= 0) (void)hipEventRecord(spans[id].b, s); }
+    // algorithmic bytes of a class whose spans are opened before the figure is known (bubble_sort: the leading children's sizes come with the commit)
+    void credit(int k, double nbytes) { if (on && ((mask >> k) & 1u)) bytes[k] += nbytes; }
     // span whose two events are handed to hipExtLaunchKernelGGL: start / stop of that one kernel, no packets of their own
     int attach(int k, double nbytes, hipEvent_t *ea, hipEvent_t *eb) {
         *ea = *eb = nullptr;

@@ -750,6 +750,21 @@ __device__ inline u32 fs_run(u32 g, int H) {
     if (H & 1) acc &= a1 << off;
     return acc;
 }
+// minimum / OR over the 16-lane row a lane belongs to (every lane of the row gets it): the four in-row steps of rv_wave_min_u32
+__device__ inline u32 rv_row_min_u32(u32 v) {
+    int x = (int)v, y;
+#define RV_DPP_ROW_(ctrl) y = __builtin_amdgcn_update_dpp(-1, x, ctrl, 0xf, 0xf, false); x = (int)(((u32)y < (u32)x) ? (u32)y : (u32)x);
+    RV_DPP_ROW_(0xB1) RV_DPP_ROW_(0x4E) RV_DPP_ROW_(0x141) RV_DPP_ROW_(0x140)      // quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
+#undef RV_DPP_ROW_
+    return (u32)x;
+}
+__device__ inline u32 rv_row_or_u32(u32 v) {
+    int x = (int)v;
+#define RV_DPP_ROW_(ctrl) x |= __builtin_amdgcn_update_dpp(0, x, ctrl, 0xf, 0xf, false);
+    RV_DPP_ROW_(0xB1) RV_DPP_ROW_(0x4E) RV_DPP_ROW_(0x141) RV_DPP_ROW_(0x140)
+#undef RV_DPP_ROW_
+    return (u32)x;
+}
 __device__ inline u32 rv_wave_or_u32(u32 v) {      // every lane gets the OR over the wave
 #define RV_STEP_(CTRL, RM, TAKE) v |= rv_dpp_u32<CTRL, RM>(v);
     RV_WAVE_SCAN_STEPS(RV_STEP_)        // (a lane without a source lane sees 0)
@@ -853,82 +868,96 @@ __global__ __launch_bounds__(TB) void k_full_scan(const sa_t *__restrict__ SA, c
         todo = (((c16 << 16) & fs_run(G32, H) & ~fs_run(~D32, H)) >> 16);      // (H = 0: the second term is everything, its complement nothing)
     }
     const u32 reg = MODE == 0 ? (blockIdx.x & (u32)(nregions - 1)) : (blockIdx.x % RV_MULTI_REGIONS);
-    // the ranks that passed, one at a time, by the whole wave
+    // The ranks that passed, FOUR at a time: every 16-lane row of the wave takes one -- lane j of the row reads LCP[lb + j] and SA[lb + j], the value is
+    // a row minimum, the samples' census a row OR (DPP row operations) -- so a wave's passing ranks cost it one memory round trip and one returning atomic
+    // per four instead of per rank.  (One at a time by the whole wave: 64 us at 10 x 5 Mbp, and ~11 us for a frontier of a few thousand ranks whose
+    // handful of waves had nobody to hide behind.)
+    const int row = lane >> 4, j = lane & 15;
     u64 bal = __ballot(todo != 0u);
     while (bal) {
-        const int src = (int)__builtin_ctzll(bal);
-        const u32 td = (u32)__builtin_amdgcn_readlane((int)todo, src);
-        const int kk = __builtin_ctz(td);
-        if (lane == src) todo &= todo - 1;
-        const int64_t u = wfirst + (int64_t)src * FS_ITEMS + kk;
-        const bool slow_u = MODE == 1 && __builtin_amdgcn_readlane((int)slow, src) != 0;
-        if (!slow_u) {
-            const int wn = MODE == 0 ? nsamples : __builtin_amdgcn_readlane(want, src);
-            const int sub = MODE == 0 ? 0 : __builtin_amdgcn_readlane(mine, src);
-            const int64_t lb = u - wn + 1;             // >= 0: G is clear at rank 0 and at every sub-index' first rank
-            // lane j: LCP[lb + j] (j <= wn: lb .. u + 1) and SA[lb + j] (j < wn)
-            const int64_t at = lb + lane;
-            const u32 lv = (lane <= wn && at < m) ? (u32)LCP[at] : 0u;
-            const sa_t sv = lane < wn ? SA[at] : (sa_t)0;
-            const u32 l = rv_wave_min_u32((lane >= 1 && lane < wn) ? lv : 0xFFFFFFFFu);
-            const u32 below = (u32)__builtin_amdgcn_readlane((int)lv, 0), nxt = (u32)__builtin_amdgcn_readlane((int)lv, wn);
-            if ((l >= minl) & (l > nxt) & (below < l)) {
-                // the members' samples (interface.c:116-134: the separators in front of a position): one pass over the separators, uniform addresses
-                int sm = 0;
+        u64 bb = bal;
+        const int s0 = (int)__builtin_ctzll(bb); bb &= bb - 1;
+        const int s1 = bb ? (int)__builtin_ctzll(bb) : -1; bb &= bb ? bb - 1 : 0;
+        const int s2 = bb ? (int)__builtin_ctzll(bb) : -1; bb &= bb ? bb - 1 : 0;
+        const int s3 = bb ? (int)__builtin_ctzll(bb) : -1;
+        const int my = row == 0 ? s0 : row == 1 ? s1 : row == 2 ? s2 : s3;      // the lane whose rank my row takes
+        const bool valid = my >= 0;
+        const int from = valid ? my : 0;
+        const u32 td = (u32)__shfl((int)todo, from, 64);
+        const int kk = __builtin_ctz(td | (valid ? 0u : 1u));
+        const int64_t u = wfirst + (int64_t)from * FS_ITEMS + kk;
+        const int wn = MODE == 0 ? nsamples : __shfl(want, from, 64);
+        const int sub = MODE == 0 ? 0 : __shfl(mine, from, 64);
+        const bool slw = MODE == 1 && __shfl((int)slow, from, 64) != 0;
+        const bool fast = valid && !slw;
+        const int64_t lb = u - wn + 1;             // >= 0: G is clear at rank 0 and at every sub-index' first rank
+        const int64_t at = lb + j;
+        const bool mem = fast && j < wn;           // lane j of the row: member j of the interval
+        const u32 lv = mem ? (u32)LCP[at] : 0xFFFFFFFFu;
+        const u32 nxt = (fast && u + 1 < m) ? (u32)LCP[u + 1] : 0u;
+        const sa_t sv = mem ? SA[at] : (sa_t)0;
+        const u32 l = rv_row_min_u32(j >= 1 ? lv : 0xFFFFFFFFu);
+        const u32 below = (u32)__shfl((int)lv, lane & ~15, 64);
+        const bool ok = fast & (l >= minl) & (l > nxt) & (below < l);
+        // the members' samples (interface.c:116-134: the separators in front of a position): one pass over the separators, uniform addresses
+        int sm = 0;
 #pragma unroll
-                for (int q = 0; q < FS_SEPS; q++) sm += ((q < nsamples - 1) & (sep[q] < sv)) ? 1 : 0;
-                for (int q = FS_SEPS; q < nsamples - 1; q++) sm += nsep[q] < sv ? 1 : 0;
-                const u32 census_lo = rv_wave_or_u32((lane < wn && sm < 32) ? (1u << sm) : 0u);
-                const u32 census_hi = nsamples > 32 ? rv_wave_or_u32((lane < wn && sm >= 32) ? (1u << (sm - 32)) : 0u) : 0u;
-                if (__popc(census_lo) + __popc(census_hi) == wn) {      // all different (reveal.c:231-244)
-                    if (MODE == 0) {
-                        u32 i = 0;
-                        // (a returning atomic per listed match: ~71 000 at 10 x 5 Mbp.  With the regions' counters side by side in one cache line
-                        //  they queued up in ONE L2 channel at ~3.7 ns each -- the kernel's time was their number, 268 us, whatever else it did;
-                        //  the counters stand cnt_stride words apart now, in different channels)
-                        if (lane == 0) i = atomicAdd(&region_cnt[(size_t)reg * cnt_stride], 1u);
-                        i = (u32)__builtin_amdgcn_readfirstlane((int)i);
-                        if (i < rcap) {
-                            const size_t o = (size_t)reg * rcap + i;
-                            if (lane == 0) c_len[o] = l;
-                            if (lane < wn) c_pos[o * (size_t)nsamples + (size_t)sm] = sv;
-                        }
-                    } else {
-                        // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be the winner
-                        // k_multi_pick2 looks for (the maximum never falls): the others are not even listed.
-                        const u32 mn = rv_wave_min_u32(lane < wn ? (u32)sv : 0xFFFFFFFFu);
-                        const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - mn);
-                        if (lane == 0 && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
-                            atomicMax(&best[sub], key);
-                            const u32 rc = cand_cap / RV_MULTI_REGIONS;
-                            const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
-                            if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
-                        }
-                    }
+        for (int q = 0; q < FS_SEPS; q++) sm += ((q < nsamples - 1) & (sep[q] < sv)) ? 1 : 0;
+        for (int q = FS_SEPS; q < nsamples - 1; q++) sm += nsep[q] < sv ? 1 : 0;
+        const u32 census_lo = rv_row_or_u32((mem && sm < 32) ? (1u << sm) : 0u);
+        const u32 census_hi = nsamples > 32 ? rv_row_or_u32((mem && sm >= 32) ? (1u << (sm - 32)) : 0u) : 0u;
+        const bool good = ok && __popc(census_lo) + __popc(census_hi) == wn;      // all different (reveal.c:231-244)
+        if (MODE == 0) {
+            const u64 gb = __ballot(good && j == 0);
+            if (gb) {
+                // (the regions' counters stand cnt_stride words apart: side by side in one cache line their returning atomics -- one per listed
+                //  match then, ~71 000 at 10 x 5 Mbp -- queued up in ONE L2 channel at ~3.7 ns each, and the kernel's time was their number, 268 us)
+                u32 base = 0;
+                if (lane == 0) base = atomicAdd(&region_cnt[(size_t)reg * cnt_stride], (u32)__popcll(gb));
+                base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+                const u32 i = base + (u32)__popcll(gb & ((1ull << (row * 16)) - 1ull));
+                if (good && i < rcap) {
+                    const size_t o = (size_t)reg * rcap + i;
+                    if (j == 0) c_len[o] = l;
+                    if (mem) c_pos[o * (size_t)nsamples + (size_t)sm] = sv;
                 }
             }
-        } else if (MODE == 1 && lane == src) {      // the general form, everything from global memory (reveal.c:227-259 by ismultimum_dev)
-            int lo = mine, hi = s_last;
-            while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= u) lo = mid; else hi = mid - 1; }
-            const int sub = lo, wn = sub_want[sub];
-            const int64_t lb = u - wn + 1;
-            if (wn >= minn && wn >= 2 && wn <= nsamples && lb >= sub_start[sub]) {
-                const u32 nxt = u + 1 < m ? (u32)LCP[u + 1] : 0u;
-                u32 l = (u32)LCP[u];
-                for (int64_t j = lb + 1; j < u; j++) { const u32 v = (u32)LCP[j]; l = v < l ? v : l; }
-                if (l > nxt && l >= minl && (u32)LCP[lb] < l && ismultimum_dev(SA, BWT, nsep, nsamples, lb, u)) {
-                    sa_t mn = SA[lb];
-                    for (int64_t j = lb + 1; j <= u; j++) { const sa_t v = SA[j]; mn = v < mn ? v : mn; }
-                    const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn);
-                    if (key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
-                        atomicMax(&best[sub], key);
-                        const u32 rc = cand_cap / RV_MULTI_REGIONS;
-                        const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
-                        if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+        } else {
+            // Only a rank that would raise the maximum of its sub-index goes to the atomic unit, and only such a rank can be the winner
+            // k_multi_pick2 looks for (the maximum never falls): the others are not even listed.
+            const u32 mn = rv_row_min_u32(mem ? (u32)sv : 0xFFFFFFFFu);
+            const unsigned long long key = ((unsigned long long)l << 32) | (unsigned long long)(0xFFFFFFFFu - mn);
+            if (good && j == 0 && key > __atomic_load_n(&best[sub], __ATOMIC_RELAXED)) {
+                atomicMax(&best[sub], key);
+                const u32 rc = cand_cap / RV_MULTI_REGIONS;
+                const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
+                if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub; c.key = key; cand[(size_t)reg * rc + q] = c; }
+            }
+            const int s_last_src = __shfl(s_last, from, 64);
+            if (valid && slw && j == 0) {      // the general form, everything from global memory (reveal.c:227-259 by ismultimum_dev), by one lane of the row
+                int lo = sub, hi = s_last_src;
+                while (lo < hi) { const int mid = (lo + hi + 1) >> 1; if (sub_start[mid] <= u) lo = mid; else hi = mid - 1; }
+                const int sub2 = lo, wn2 = sub_want[sub2];
+                const int64_t lb2 = u - wn2 + 1;
+                if (wn2 >= minn && wn2 >= 2 && wn2 <= nsamples && lb2 >= sub_start[sub2]) {
+                    const u32 nxt2 = u + 1 < m ? (u32)LCP[u + 1] : 0u;
+                    u32 l2 = (u32)LCP[u];
+                    for (int64_t x = lb2 + 1; x < u; x++) { const u32 v = (u32)LCP[x]; l2 = v < l2 ? v : l2; }
+                    if (l2 > nxt2 && l2 >= minl && (u32)LCP[lb2] < l2 && ismultimum_dev(SA, BWT, nsep, nsamples, lb2, u)) {
+                        sa_t mn2 = SA[lb2];
+                        for (int64_t x = lb2 + 1; x <= u; x++) { const sa_t v = SA[x]; mn2 = v < mn2 ? v : mn2; }
+                        const unsigned long long key2 = ((unsigned long long)l2 << 32) | (unsigned long long)(0xFFFFFFFFu - (u32)mn2);
+                        if (key2 > __atomic_load_n(&best[sub2], __ATOMIC_RELAXED)) {
+                            atomicMax(&best[sub2], key2);
+                            const u32 rc = cand_cap / RV_MULTI_REGIONS;
+                            const u32 q = atomicAdd(&cand_count[reg * 64], 1u);
+                            if (q < rc) { RvMultiCand c; c.ub = (u32)u; c.sub = (u32)sub2; c.key = key2; cand[(size_t)reg * rc + q] = c; }
+                        }
                     }
                 }
             }
         }
+        if (lane == s0 || lane == s1 || lane == s2 || lane == s3) todo &= todo - 1;
         bal = __ballot(todo != 0u);
     }
 }

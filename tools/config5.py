@@ -27,6 +27,8 @@ def main():
     ap.add_argument("--minn", type=int, default=2)
     ap.add_argument("--max-jobs", type=int, default=0, help="run at most this many jobs of level 0 and stop (timing of single jobs)")
     ap.add_argument("--dir", default=None)
+    ap.add_argument("--procs", type=int, default=1, help="jobs of a level run as this many `python -m reveal_amd.rem` processes at a time on this GPU (they share "
+                                                        "nothing but files: reveal/align.py prints them as shell commands); 1 = in this process")
     a = ap.parse_args()
     from reveal_amd import align, synth
     import graphrem_cases as C
@@ -46,14 +48,47 @@ def main():
         levels = [levels[0][:a.max_jobs]]
     logs = []
     t1 = time.perf_counter()
-    done = align.run_plan(levels, minlength=a.minl, minn=a.minn, log=lambda m: (logs.append(m), print(m, file=sys.stderr)))
+    if a.procs <= 1:
+        done = align.run_plan(levels, minlength=a.minl, minn=a.minn, log=lambda m: (logs.append(m), print(m, file=sys.stderr)))
+    else:
+        import re
+        import subprocess
+        done = []
+        level_wall = {}
+        for lv, jobs in enumerate(levels):
+            t_lv = time.perf_counter()
+            pending = list(enumerate(jobs))
+            running = []
+            while pending or running:
+                while pending and len(running) < a.procs:
+                    j, (inputs, out) = pending.pop(0)
+                    cmd = [sys.executable, "-m", "reveal_amd.rem"] + list(inputs) + ["-o", out, "-m", str(a.minl), "-n", str(a.minn)]
+                    running.append((j, out, time.perf_counter(), subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+                still = []
+                for j, out, ts, pr in running:
+                    if pr.poll() is None:
+                        still.append((j, out, ts, pr))
+                        continue
+                    so, se = pr.communicate()
+                    if pr.returncode != 0:
+                        sys.exit("level %d job %d failed: %s" % (lv, j, se[-2000:]))
+                    mm = re.search(r"(\d+) nodes, (\d+) paths", so)
+                    dt = time.perf_counter() - ts
+                    done.append((lv, j, dt, int(mm.group(1)) if mm else 0, int(mm.group(2)) if mm else 0))
+                    print("level %d job %d -> %s  %.2f s (process), %s" % (lv, j, out, dt, so.strip().splitlines()[-1] if so.strip() else ""), file=sys.stderr)
+                running = still
+                if running:
+                    time.sleep(0.2)
+            level_wall[str(lv)] = time.perf_counter() - t_lv
     t_run = time.perf_counter() - t1
     per_level = {}
     for lv, j, dt, nodes, paths in done:
         e = per_level.setdefault(lv, dict(jobs=0, seconds=0.0, max_job_s=0.0, nodes=0))
         e["jobs"] += 1; e["seconds"] += dt; e["max_job_s"] = max(e["max_job_s"], dt); e["nodes"] += nodes
-    out = dict(genomes=a.genomes, L=a.L, chunksize=a.chunksize, plan=[len(j) for j in levels], t_generate_s=t_gen, t_run_s=t_run,
+    out = dict(genomes=a.genomes, L=a.L, chunksize=a.chunksize, plan=[len(j) for j in levels], processes_per_level=a.procs, t_generate_s=t_gen, t_run_s=t_run,
                levels={str(k): v for k, v in per_level.items()}, bases=a.genomes * a.L)
+    if a.procs > 1:
+        out["level_wall_s"] = level_wall
     if not a.max_jobs:
         t2 = time.perf_counter()
         spelled, G = C.spelled_by_file(levels[-1][-1][1])

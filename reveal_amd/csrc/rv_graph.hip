@@ -33,14 +33,40 @@ struct GNode {
     std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
     std::vector<int> succ, pred;                    // edge ids, in dictionary order
 };
-struct GEdge { int u, v; std::vector<int> paths; };      // (paths: sorted, unique)
-
-void set_union(std::vector<int> &a, const std::vector<int> &b) {
-    std::vector<int> r;
-    r.reserve(a.size() + b.size());
-    std::set_union(a.begin(), a.end(), b.begin(), b.end(), std::back_inserter(r));
-    a.swap(r);
-}
+// The path ids an edge carries.  A graph of up to 64 paths keeps them as one word (uniting two sets, and asking for a member, cost an
+// instruction instead of an allocation: anchors' surgery spent most of its time in malloc); more paths: a sorted vector as before.
+struct PathSet {
+    uint64_t m = 0;
+    std::vector<int> v;        // used when `big`
+    bool big = false;
+    PathSet() = default;
+    explicit PathSet(const std::vector<int> &ids) { for (int p : ids) add(p); }
+    void add(int p) {
+        if (!big && p >= 0 && p < 64) { m |= 1ull << p; return; }
+        grow();
+        auto it = std::lower_bound(v.begin(), v.end(), p);
+        if (it == v.end() || *it != p) v.insert(it, p);
+    }
+    void grow() {
+        if (big) return;
+        big = true;
+        for (int q = 0; q < 64; q++) if ((m >> q) & 1ull) v.push_back(q);
+        m = 0;
+    }
+    void unite(const PathSet &o) {
+        if (!big && !o.big) { m |= o.m; return; }
+        grow();
+        if (o.big) { std::vector<int> r; r.reserve(v.size() + o.v.size()); std::set_union(v.begin(), v.end(), o.v.begin(), o.v.end(), std::back_inserter(r)); v.swap(r); }
+        else for (int q = 0; q < 64; q++) if ((o.m >> q) & 1ull) add(q);
+    }
+    bool has(int p) const { return big ? std::binary_search(v.begin(), v.end(), p) : (p >= 0 && p < 64 && ((m >> p) & 1ull)); }
+    size_t size() const { return big ? v.size() : (size_t)__builtin_popcountll(m); }
+    template <class F> void each(F f) const {      // ascending
+        if (big) { for (int p : v) f(p); return; }
+        for (uint64_t x = m; x; x &= x - 1) f(__builtin_ctzll(x));
+    }
+};
+struct GEdge { int u, v; PathSet paths; };
 
 }  // namespace
 
@@ -53,6 +79,8 @@ struct rv_graph {
     std::vector<int> edge_no;                       // export: edge id -> dense number (-1: dead)
     std::string err, gfa;
     int nseq = 0;
+    std::vector<std::pair<int, PathSet>> in_tmp, out_tmp;      // scratch of breaknode / mergenodes: a node's links while it is taken apart
+    std::vector<int> start_of;                      // the start sentinel of every sequence, in the reader's order
 
     int new_node(int64_t b, int64_t e, int8_t aligned) {
         GNode n;
@@ -63,9 +91,9 @@ struct rv_graph {
         return id;
     }
     // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
-    void add_edge(int u, int v, const std::vector<int> &paths) {
+    void add_edge(int u, int v, const PathSet &paths) {
         for (int e : nodes[(size_t)u].succ)
-            if (edges[(size_t)e].v == v) { set_union(edges[(size_t)e].paths, paths); return; }
+            if (edges[(size_t)e].v == v) { edges[(size_t)e].paths.unite(paths); return; }
         edges.push_back({u, v, paths});
         const int e = (int)edges.size() - 1;
         nodes[(size_t)u].succ.push_back(e);
@@ -90,21 +118,22 @@ struct rv_graph {
     int breaknode(int x, int64_t pos, int64_t l) {
         const int64_t nb = nodes[(size_t)x].b, ne = nodes[(size_t)x].e;
         if (nb == pos && ne == pos + l) return x;
-        const std::vector<std::pair<int, int64_t>> att = nodes[(size_t)x].off;
-        std::vector<std::pair<int, std::vector<int>>> in_edges, out_edges;
-        for (int e : nodes[(size_t)x].pred) in_edges.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
-        for (int e : nodes[(size_t)x].succ) out_edges.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
-        std::vector<int> pospaths;
-        if (in_edges.empty() && out_edges.empty()) {
-            for (auto &a : att) pospaths.push_back(a.first);
-            std::sort(pospaths.begin(), pospaths.end());
+        const std::vector<std::pair<int, int64_t>> att = std::move(nodes[(size_t)x].off);      // (the node is about to go)
+        in_tmp.clear(); out_tmp.clear();
+        for (int e : nodes[(size_t)x].pred) in_tmp.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
+        for (int e : nodes[(size_t)x].succ) out_tmp.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
+        const size_t n_in = in_tmp.size(), n_out = out_tmp.size();
+        PathSet pospaths;
+        if (n_in == 0 && n_out == 0) {
+            for (auto &a : att) pospaths.add(a.first);
         } else {
-            for (auto &ie : in_edges) set_union(pospaths, ie.second);
-            for (auto &oe : out_edges) set_union(pospaths, oe.second);
+            for (size_t k = 0; k < n_in; k++) pospaths.unite(in_tmp[k].second);
+            for (size_t k = 0; k < n_out; k++) pospaths.unite(out_tmp[k].second);
         }
         // (the old node leaves the position map first: the match or prefix node shares its begin)
         { auto it = at.find(nb); if (it != at.end() && it->second == x) at.erase(it); }
         const int mn = new_node(pos, pos + l, 0);
+        nodes[(size_t)mn].off.reserve(att.size());
         for (auto &a : att) nodes[(size_t)mn].off.push_back({a.first, a.second + (pos - nb)});
         int pn = mn, sn = mn;
         if (nb != pos) {
@@ -114,12 +143,13 @@ struct rv_graph {
         }
         if (ne != pos + l) {
             sn = new_node(pos + l, ne, 0);
+            nodes[(size_t)sn].off.reserve(att.size());
             for (auto &a : att) nodes[(size_t)sn].off.push_back({a.first, a.second + (pos + l - nb)});
             add_edge(mn, sn, pospaths);
         }
         remove_node(x);
-        for (auto &ie : in_edges) add_edge(ie.first, pn, ie.second);
-        for (auto &oe : out_edges) add_edge(sn, oe.first, oe.second);
+        for (size_t k = 0; k < n_in; k++) add_edge(in_tmp[k].first, pn, in_tmp[k].second);
+        for (size_t k = 0; k < n_out; k++) add_edge(sn, out_tmp[k].first, out_tmp[k].second);
         return mn;
     }
     // rem.py:133-200: the first node absorbs the others
@@ -137,14 +167,38 @@ struct rv_graph {
         for (size_t k = 1; k < mns.size(); k++) {
             const int x = mns[k];
             if (x == ref) continue;
-            std::vector<std::pair<int, std::vector<int>>> ins, outs;
-            for (int e : nodes[(size_t)x].pred) ins.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
-            for (int e : nodes[(size_t)x].succ) outs.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
-            for (auto &ie : ins) add_edge(ie.first, ref, ie.second);
-            for (auto &oe : outs) add_edge(ref, oe.first, oe.second);
+            in_tmp.clear(); out_tmp.clear();
+            for (int e : nodes[(size_t)x].pred) in_tmp.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
+            for (int e : nodes[(size_t)x].succ) out_tmp.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
+            for (size_t k2 = 0; k2 < in_tmp.size(); k2++) add_edge(in_tmp[k2].first, ref, in_tmp[k2].second);
+            for (size_t k2 = 0; k2 < out_tmp.size(); k2++) add_edge(ref, out_tmp[k2].first, out_tmp[k2].second);
             remove_node(x);
         }
         return ref;
+    }
+    // The surgery leaves three dead nodes for every live one (a broken node stays in the array): prune_nodes and the writer then walk a structure four
+    // times the size it needs to be, a cache miss per step.  Live nodes and edges move together, in their old order (a node's number IS its place in the
+    // dictionary), ids are renamed.
+    void compact() {
+        std::vector<int> nmap(nodes.size(), -1), emap(edges.size(), -1);
+        size_t nn = 0;
+        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) nmap[i] = (int)nn++;
+        size_t ne = 0;
+        for (size_t e = 0; e < edges.size(); e++) if (edges[e].u >= 0 && nodes[(size_t)edges[e].u].alive && nodes[(size_t)edges[e].v].alive) emap[e] = (int)ne++;
+        std::vector<GNode> n2; n2.reserve(nn);
+        for (size_t i = 0; i < nodes.size(); i++) {
+            if (!nodes[i].alive) continue;
+            GNode &n = nodes[i];
+            for (int &e : n.succ) e = emap[(size_t)e];
+            for (int &e : n.pred) e = emap[(size_t)e];
+            n.off.shrink_to_fit(); n.succ.shrink_to_fit(); n.pred.shrink_to_fit();
+            n2.push_back(std::move(n));
+        }
+        std::vector<GEdge> e2; e2.reserve(ne);
+        for (size_t e = 0; e < edges.size(); e++) if (emap[e] >= 0) { GEdge &x = edges[e]; x.u = nmap[(size_t)x.u]; x.v = nmap[(size_t)x.v]; e2.push_back(std::move(x)); }
+        nodes.swap(n2); edges.swap(e2);
+        for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
+        for (int &x : start_of) x = nmap[(size_t)x];
     }
     void finish() {
         order.clear();
@@ -165,8 +219,10 @@ static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end
     // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
     for (int s = 0; s < nseq; s++) {
         const int st = g->new_node(s, 0, -1), iv = g->new_node(begin[s], end[s], 0), en = g->new_node(s, 1, -1);
+        g->start_of.push_back(st);
         g->nodes[(size_t)st].off.push_back({s, 0}); g->nodes[(size_t)iv].off.push_back({s, 0}); g->nodes[(size_t)en].off.push_back({s, end[s] - begin[s]});
-        g->add_edge(st, iv, {s}); g->add_edge(iv, en, {s});
+        PathSet only; only.add(s);
+        g->add_edge(st, iv, only); g->add_edge(iv, en, only);
     }
     std::vector<int> mns;
     for (int64_t a = 0; a < na; a++) {
@@ -179,6 +235,7 @@ static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end
         }
         if (!mns.empty()) g->mergenodes(mns);
     }
+    g->compact();
     g->finish();
     return own.release();
 }
@@ -226,7 +283,7 @@ static int graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int
     int64_t pp = 0;
     for (int64_t k = 0; k < nedges; k++) {
         edge_ptr[k] = pp;
-        for (int p : g->edges[(size_t)by_no[(size_t)k]].paths) edge_paths[pp++] = p;
+        g->edges[(size_t)by_no[(size_t)k]].paths.each([&](int p) { edge_paths[pp++] = p; });
     }
     edge_ptr[nedges] = pp;
     return 0;
@@ -324,10 +381,11 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
             o += "L\t"; put_int(o, ident[(size_t)x]); o += "\t+\t"; put_int(o, ident[(size_t)v]); o += "\t+\t0M\n";
         }
     }
-    // the start sentinels in the reader's order: sample s' is node 3 s of the replay
+    // the start sentinels in the reader's order (start_of: sample s' is node 3 s of the replay, wherever compact() has moved it)
     for (int sid = 0; sid < npaths; sid++) {
         std::string path, cigar;
-        for (size_t st = 0; st + 2 < nodes.size() && (int)(st / 3) < g->nseq; st += 3) {
+        for (size_t sq = 0; sq < g->start_of.size(); sq++) {
+            const size_t st = (size_t)g->start_of[sq];
             bool has = false;
             for (auto &a : nodes[st].off) has |= a.first == sid;
             if (!nodes[st].alive || !has) continue;
@@ -335,7 +393,7 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
             for (;;) {
                 int nout = 0, v = -1;
                 for (int e : nodes[(size_t)node].succ)
-                    if (std::binary_search(edges[(size_t)e].paths.begin(), edges[(size_t)e].paths.end(), sid)) { nout++; v = edges[(size_t)e].v; }
+                    if (edges[(size_t)e].paths.has(sid)) { nout++; v = edges[(size_t)e].v; }
                 if (nout != 1) break;
                 if (nodes[(size_t)v].aligned < 0 && nodes[(size_t)v].e == 1) break;      // an end sentinel
                 if (nodes[(size_t)v].aligned >= 0) {

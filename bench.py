@@ -661,10 +661,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    divide_state = {}
+
     def step(divide):
         if divide:      # rank 0 constructs and runs the top levels, the ranks pull sub-index batches from it
-            from reveal_amd import shard
-            return shard.align_sharded(idx_div, args.minl, args.minn)
+            # the hand-off over reveal_amd.transport: requests over local sockets, segments out of rank 0's HBM by HIP's inter-process copies -- no
+            # tensor library, no collective on the data path (torch.distributed only brackets the timed region, as the contract says)
+            from reveal_amd import shard, transport
+            if "grp" not in divide_state:
+                divide_state["grp"] = transport.Group.from_env()
+            return shard.align_sharded_group(idx_div, divide_state["grp"], transport.DeviceMemory(idx_div._lib, local_rank), args.minl, args.minn)
         if extra:      # (ctypes releases the GIL inside the library calls: the jobs' level loops overlap on the GPU)
             import threading
             res = [None] * (1 + len(extra))

@@ -379,6 +379,17 @@ int rv_prof_enable(rv_index *h, int on);
 int rv_prof_reset(rv_index *h);
 /* launches, total milliseconds and algorithmic bytes of kernel class k since the last reset */
 int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes);
+/* ---- device memory for the frontier hand-off between processes ("child SA/LCP shipped once to the owner GPU, peer copy over
+ * xGMI") -- what reveal_amd/shard.py's own transport uses instead of a tensor library: the owner packs the segments it hands out into buffers of its
+ * device (rv_frontier_pack, on_device = 1) and exports them once (hipIpcGetMemHandle: 64 bytes that travel over any byte channel); a worker process
+ * opens them on ITS device (hipIpcOpenMemHandle) and copies its batches out, device to device (hipMemcpy over the peer link).  No collective, no
+ * library besides HIP.  rv_dev_alloc returns NULL, the others -1, with rv_last_error set. */
+void *rv_dev_alloc(int device, int64_t bytes);
+int rv_dev_free(int device, void *p);
+int rv_ipc_export(int device, const void *p, uint8_t handle[64]);     /* p: what rv_dev_alloc returned */
+void *rv_ipc_open(int device, const uint8_t handle[64]);
+int rv_ipc_close(int device, void *p);
+int rv_dev_copy(int device, void *dst, const void *src, int64_t bytes);      /* any two device (or host) addresses; returns when the copy is done */
 /* The practical HBM ceiling of this device ("also report measured copy-kernel bandwidth on the node"): a
  * streaming read kernel and a copy kernel over `bytes` of freshly allocated memory, `iters` timed launches each, HIP events.
  * GB/s; the copy figure counts bytes read + bytes written. */

@@ -93,6 +93,12 @@ SYMBOLS = {
     "rv_set_preselect": (_I, [V, _L]),
     "rv_set_option": (_I, [V, ctypes.c_char_p, _L]),
     "rv_set_launch_trace": (_I, [_I]),
+    "rv_dev_alloc": (V, [_I, _L]),
+    "rv_dev_free": (_I, [_I, V]),
+    "rv_ipc_export": (_I, [_I, V, V]),
+    "rv_ipc_open": (V, [_I, V]),
+    "rv_ipc_close": (_I, [_I, V]),
+    "rv_dev_copy": (_I, [_I, V, V, _L]),
     "rv_get_option": (_I, [V, ctypes.c_char_p, c_i64p]),
     "rv_option_count": (_I, []),
     "rv_option_name": (ctypes.c_char_p, [_I]),

@@ -932,6 +932,50 @@ __global__ __launch_bounds__(256) void k_bw_copy(const bw_v4 *__restrict__ a, bw
 }
 }  // namespace
 extern "C" {
+/* device memory for the frontier hand-off between processes (include/reveal_amd.h) */
+void *rv_dev_alloc(int device, int64_t bytes) {
+    void *p = nullptr;
+    if (bytes < 0 || hipSetDevice(device) != hipSuccess) { rv_set_error("rv_dev_alloc: bad device or size"); return nullptr; }
+    const hipError_t e = hipMalloc(&p, (size_t)std::max<int64_t>(bytes, 256));
+    if (e != hipSuccess) { (void)hipGetLastError(); rv_set_error("rv_dev_alloc(%lld bytes): %s", (long long)bytes, hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int rv_dev_free(int device, void *p) {
+    if (!p) return 0;
+    RV_HIP(hipSetDevice(device));
+    RV_HIP(hipFree(p));
+    return 0;
+}
+int rv_ipc_export(int device, const void *p, uint8_t handle[64]) {
+    static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+    RV_HIP(hipSetDevice(device));
+    hipIpcMemHandle_t hd;
+    RV_HIP(hipIpcGetMemHandle(&hd, const_cast<void *>(p)));
+    memcpy(handle, &hd, 64);
+    return 0;
+}
+void *rv_ipc_open(int device, const uint8_t handle[64]) {
+    if (hipSetDevice(device) != hipSuccess) { rv_set_error("rv_ipc_open: bad device"); return nullptr; }
+    hipIpcMemHandle_t hd;
+    memcpy(&hd, handle, 64);
+    void *p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, hd, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) { (void)hipGetLastError(); rv_set_error("rv_ipc_open: %s", hipGetErrorString(e)); return nullptr; }
+    return p;
+}
+int rv_ipc_close(int device, void *p) {
+    if (!p) return 0;
+    RV_HIP(hipSetDevice(device));
+    RV_HIP(hipIpcCloseMemHandle(p));
+    return 0;
+}
+int rv_dev_copy(int device, void *dst, const void *src, int64_t bytes) {
+    if (bytes <= 0) return 0;
+    RV_HIP(hipSetDevice(device));
+    RV_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault));
+    return 0;
+}
+
 int rv_measure_bandwidth(int device, int64_t bytes, int iters, double *read_gbs, double *copy_gbs) {
     if (bytes < (1 << 20) || iters < 1) { rv_set_error("rv_measure_bandwidth: bytes >= 1 MiB and iters >= 1 needed"); return -1; }
     RV_HIP(hipSetDevice(device));

@@ -166,11 +166,133 @@ def _send_batch(dist, group, dst, lib, head, meta_bytes, bufs, m, dev):
             dist.send(b, dst=gdst, group=group)
 
 
+def _elem_sizes(lib):
+    return (8 if lib.sa64 else 4, 4, 1)
+
+
+def align_sharded_group(idx, grp, mem, minl=20, minn=2, stop_subs=None, trace=False, per_rank=4):
+    """align_sharded over reveal_amd.transport: `grp` = transport.Group (local sockets: requests, metadata, results), `mem` = where the segments live --
+    transport.DeviceMemory (each rank its GPU: the owner exports its staging buffers once, workers copy their batches out device to device),
+    transport.SharedMemory (the same code path without a device) or transport.HostMemory (segments inside the messages).  No torch, no collective.
+    -> on rank 0 the merged result (as align_sharded), None on the others."""
+    rank, world = grp.rank, grp.world
+    lib = idx._lib
+    sizes = _elem_sizes(lib)
+    if world == 1:
+        idx.construct()
+        res = idx.align_builtin(minl, minn, trace=trace)
+        res["shares"] = [int(idx.n)]; res["batches"] = [1]
+        return res
+    shared = mem.kind == "device"
+    results = []
+    if rank == 0:
+        idx.construct()
+        left, fr, _ = balanced_frontier(idx, world, stop_subs or 4 * world, minl, minn, trace=trace, tolerance=1.5)
+        maxlcp = idx.maxlcp
+        batches, staged, tokens, seeds = [], None, None, None
+        if left > 0:
+            batches = make_batches(fr["meta"][:, 1], world, per_rank)
+            order = np.concatenate(batches)
+            total = int(fr["meta"][order, 1].sum())
+            staged = tuple(mem.alloc(total, sz) for sz in sizes)
+            idx.frontier_pack(order, *staged)          # (synchronous: the copies have finished when it returns)
+            seeds = [idx.frontier_seeds(b) for b in batches] if idx.picker_info()["kind"] == 1 else None
+            if shared:
+                tokens = tuple(mem.export(b) for b in staged)      # once: a worker opens them with its first batch
+        first = [0]
+        for b in batches:
+            first.append(first[-1] + int(fr["meta"][b, 1].sum()))
+        lo, hi = 0, len(batches)                       # the queue: workers take from the large end (lo), rank 0 from the small one
+        shares, counts = [0] * world, [0] * world
+        told = set()                                   # workers that have the tokens
+        active = set(range(1, world))                  # workers that have not been told "no more" yet
+        remote = {}
+
+        def part_of(k):
+            part = subset(fr, batches[k])
+            if seeds is not None:
+                part["seeds"] = seeds[k]
+            return part
+
+        def serve(w, msg):
+            nonlocal lo
+            if msg[0] == "result":
+                remote[w] = msg[1]
+                return
+            assert msg[0] == "next", msg
+            if lo >= hi:
+                grp.send(w, None)
+                active.discard(w)
+                return
+            k = lo; lo += 1
+            m = first[k + 1] - first[k]
+            reply = dict(part=part_of(k), m=m, first=first[k], maxlcp=maxlcp)
+            if shared:
+                if w not in told:
+                    reply["tokens"] = tokens; told.add(w)
+            else:
+                reply["segments"] = tuple(mem.bytes_of(b[first[k]:first[k + 1]]) for b in staged)
+            grp.send(w, reply)
+            shares[w] += m; counts[w] += 1
+
+        while active or lo < hi or len(remote) < world - 1:
+            # requests first (a blocking wait when rank 0 has nothing of its own to do: no polling of a store, no sleep)
+            busy = lo < hi
+            got = grp.ready(0 if busy else None)
+            for w, msg in got:
+                serve(w, msg)
+            if got or lo >= hi:
+                continue
+            hi -= 1
+            k = hi
+            bufs = tuple(b[first[k]:first[k + 1]] for b in staged)
+            idx.frontier_import(part_of(k), *bufs, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
+            results.append(idx.align_builtin_resume())
+            shares[0] += first[k + 1] - first[k]; counts[0] += 1
+        if not results:
+            if left > 0:
+                empty = tuple(mem.alloc(0, sz) for sz in sizes)
+                idx.frontier_import(subset(fr, np.zeros(0, np.int32)), *empty, minl=minl, minn=minn, maxlcp=maxlcp, trace=trace)
+            results.append(idx.align_builtin_resume())
+        mine = merge(results) if len(results) > 1 else results[0]
+        merged = merge([mine] + [remote[w] for w in sorted(remote)])
+        merged["shares"] = shares; merged["batches"] = counts
+        for w in range(1, world):
+            grp.send(w, "done")                        # (the staging buffers may go: every worker has copied what it took)
+        mem.release()
+        return merged
+    opened = None
+    while True:
+        reply = grp.ask(("next",))
+        if reply is None:
+            break
+        m = reply["m"]
+        mine = tuple(mem.alloc(m, sz) for sz in sizes)
+        if shared:
+            if "tokens" in reply:
+                opened = tuple(mem.open(t) for t in reply["tokens"])
+            for dst, src in zip(mine, opened):
+                mem.copy(dst, src[reply["first"]:reply["first"] + m], m)
+        else:
+            for dst, data in zip(mine, reply["segments"]):
+                mem.fill(dst, data)
+        idx.frontier_import(reply["part"], *mine, minl=minl, minn=minn, maxlcp=reply["maxlcp"], trace=trace)
+        results.append(idx.align_builtin_resume())
+    if not results:
+        results.append(empty_result(trace))
+    grp.send(0, ("result", merge(results) if len(results) > 1 else results[0]))
+    assert grp.recv() == "done"
+    mem.release()
+    return None
+
+
 def align_sharded(idx, minl=20, minn=2, stop_subs=None, group=None, trace=False, per_rank=4):
     """Divide ONE alignment over the ranks of `group` as a work queue.  Every rank passes an index that holds the same samples
     (addsample / addsequence done, construct not needed); rank 0's is constructed here.
     -> on rank 0 the merged result (shape of index.align_builtin, plus 'shares' = ranks each rank ended up finishing and
-       'batches' = how many batches it took); None on the other ranks."""
+       'batches' = how many batches it took); None on the other ranks.
+    (This form rides on torch.distributed -- RCCL send / recv with the nccl backend, host memory with gloo -- for callers that live in a
+    process group already; align_sharded_group does the same over reveal_amd.transport with HIP's own inter-process copies and no torch.)"""
     import pickle
     import torch
     import torch.distributed as dist

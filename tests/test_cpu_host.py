@@ -139,6 +139,7 @@ class FakeIndex:
     maxlcp = 77
     def __init__(self): self.constructed = False; self.front = None; self.done = []
     def construct(self): self.constructed = True
+    def picker_info(self): return {"kind": 0}
     def align_builtin_until(self, stop, minl, minn, trace=False):
         assert self.constructed and rank == 0
         self.sizes = np.array([5, 100, 7, 40, 40, 1, 60])
@@ -226,6 +227,104 @@ def test_divided_alignment_in_a_group_without_global_rank_0(tmp_path):
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads([x for x in out.stdout.splitlines() if x.startswith("{")][-1])
     assert r["splits"] == 8 and len(r["shares"]) == 2 and sum(r["shares"]) == 253 and all(x > 0 for x in r["shares"])
+
+
+GROUP_WORKER = r'''
+import os, sys, json, ctypes
+sys.path.insert(0, %r)
+import numpy as np
+from reveal_amd import shard, transport
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+grp = transport.Group.from_env()
+mem = transport.SharedMemory() if os.environ["SHARD_MEM"] == "shared" else transport.HostMemory()
+
+def arr(view, dtype):      # the numpy face of a transport buffer
+    return np.frombuffer((ctypes.c_uint8 * (view.n * view.itemsize)).from_address(view.ptr), dtype=dtype)
+
+class FakeLib: sa64 = False
+class FakeIndex:
+    """the methods shard.align_sharded_group drives, on numpy: a frontier of 7 sub-indices whose 'recursion' turns every sub-index
+    into one anchor (l = its size, members = checksums of the segments it was handed)"""
+    _lib = FakeLib()
+    n = 1000
+    maxlcp = 77
+    def __init__(self): self.constructed = False; self.front = None; self.done = []
+    def construct(self): self.constructed = True
+    def picker_info(self): return {"kind": 0}
+    def align_builtin_until(self, stop, minl, minn, trace=False):
+        assert self.constructed and rank == 0
+        self.sizes = np.array([5, 100, 7, 40, 40, 1, 60])
+        self.SA = np.arange(self.sizes.sum(), dtype=np.int32) * 3 + 1
+        self.done = [(9, (0, 500))]                    # an anchor of the levels in front of the hand-off
+        return len(self.sizes)
+    def frontier(self):
+        off = np.concatenate([[0], np.cumsum(self.sizes)[:-1]])
+        meta = np.stack([off, self.sizes, np.full(7, 2), np.full(7, 2), np.zeros(7, int), np.full(7, -1)], axis=1).astype(np.int64)
+        return dict(level=3, m=int(self.sizes.sum()), meta=meta, node_first=np.arange(8, dtype=np.int64), nodes=np.stack([off, off + self.sizes], axis=1).astype(np.int64))
+    def frontier_pack(self, subs, sa, lcp, bwt):
+        assert sa.itemsize == 4 and lcp.itemsize == 4 and bwt.itemsize == 1
+        at = 0
+        fr = self.frontier()
+        for s in subs:
+            o, n = int(fr["meta"][s, 0]), int(fr["meta"][s, 1])
+            arr(sa, np.int32)[at:at + n] = self.SA[o:o + n]; arr(lcp, np.int32)[at:at + n] = 7; arr(bwt, np.uint8)[at:at + n] = 65
+            at += n
+        return at
+    def frontier_import(self, part, sa, lcp, bwt, minl=20, minn=2, maxlcp=None, trace=False):
+        assert rank == 0 or (maxlcp == 77 and not self.constructed)
+        self.front = (part, arr(sa, np.int32).copy(), arr(lcp, np.int32).copy(), arr(bwt, np.uint8).copy())
+    def align_builtin_continue(self, stop):
+        return len(self.sizes)
+    def align_builtin_resume(self):
+        part, sa, lcp, bwt = self.front
+        at = 0
+        import time; time.sleep(0.02 * len(part["meta"]))      # (a batch takes a while: the other ranks get to ask meanwhile)
+        for k in range(len(part["meta"])):
+            n = int(part["meta"][k, 1])
+            assert (lcp[at:at + n] == 7).all() and (bwt[at:at + n] == 65).all()
+            assert part["nodes"][part["node_first"][k], 1] - part["nodes"][part["node_first"][k], 0] == n
+            self.done.append((n, (int(sa[at:at + n].sum()), int(part["nodes"][part["node_first"][k], 0]))))
+            at += n
+        l = np.array([d[0] for d in self.done], np.uint32); pos = np.array([p for d in self.done for p in d[1]], np.int64)
+        st = shard.empty_result()["stats"]; st["splits"] = len(self.done)
+        self.done = []
+        return dict(stats=st, anchors=(l, np.arange(0, 2 * len(l) + 1, 2), pos), trace=None)
+
+res = shard.align_sharded_group(FakeIndex(), grp, mem, 20, 2, stop_subs=4, per_rank=2)
+if rank == 0:
+    l, off, pos = res["anchors"]
+    print(json.dumps({"anchors": sorted((int(l[k]), [int(x) for x in pos[off[k]:off[k + 1]]]) for k in range(len(l))), "shares": res["shares"], "batches": res["batches"], "splits": res["stats"]["splits"]}))
+else:
+    assert res is None
+grp.barrier(); grp.close()
+'''
+
+
+@pytest.mark.parametrize("world,mem", [(2, "shared"), (3, "shared"), (3, "host")])
+def test_divided_alignment_over_the_socket_transport(tmp_path, world, mem):
+    """shard.align_sharded_group: the same work queue without torch -- requests, metadata and results over local sockets
+    (reveal_amd/transport.py), the segments either in memory every rank can open (`shared`: the code path of the GPU ranks -- staging
+    buffers exported once, a worker copies its batches out of them at the offsets it is told -- with POSIX shared memory in place of
+    HIP's inter-process handles) or inside the messages (`host`)"""
+    script = tmp_path / "group_worker.py"
+    script.write_text(GROUP_WORKER % ROOT)
+    port = str(29700 + world * 3 + (1 if mem == "host" else 0))
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, SHARD_MEM=mem)
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    r = json.loads([x for x in outs[0][0].splitlines() if x.startswith("{")][-1])
+    sizes = [5, 100, 7, 40, 40, 1, 60]
+    SA = np.arange(sum(sizes)) * 3 + 1
+    off = np.concatenate([[0], np.cumsum(sizes)[:-1]])
+    want = sorted([(9, [0, 500])] + [(n, [int(SA[o:o + n].sum()), int(o)]) for o, n in zip(off, sizes)])
+    assert [tuple(a) for a in r["anchors"]] == [(l, p) for l, p in want]
+    assert r["splits"] == 8 and sum(r["shares"]) == sum(sizes) and len(r["shares"]) == world
+    nbatches = len(shard.make_batches(sizes, world, 2))
+    assert sum(r["batches"]) == nbatches and sum(1 for x in r["shares"] if x > 0) >= 2
 
 
 def test_queue_batches():

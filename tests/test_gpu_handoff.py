@@ -215,6 +215,63 @@ def test_processes_divide_one_alignment(tmp_path, world, genomes, L):
     assert len(r["shares"]) == world and sum(1 for x in r["shares"] if x > 0) >= 2 and sum(r["batches"]) >= world
 
 
+IPC_RANK = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import numpy as np
+from reveal_amd import _lib, reveallib, shard, synth, transport
+assert "torch" not in sys.modules                 # the hand-off over reveal_amd.transport needs no tensor library
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+_lib.set_device(0)                                # (the ranks share the one GPU of the test box: an IPC handle opens in another process all the same)
+seqs = synth.genomes(%d, %d, seed=7)
+grp = transport.Group.from_env()
+
+def feed(idx):
+    for g in seqs:
+        idx.addsample("s"); idx.addsequence(g.decode())
+    return idx
+
+res = None
+for it in range(2):
+    idx = feed(reveallib.index()) if it == 0 else idx
+    res = shard.align_sharded_group(idx, grp, transport.DeviceMemory(idx._lib, 0), 20, 2, stop_subs=8)
+if rank == 0:
+    os.environ["RV_NO_CASCADE"] = "1"
+    one = feed(reveallib.index()); one.construct()
+    ref = one.align_builtin(20, 2)
+    def aset(r):
+        l, off, pos = r["anchors"]
+        return sorted((int(l[k]), tuple(int(x) for x in pos[off[k]:off[k + 1]])) for k in range(len(l)))
+    T0 = np.frombuffer(b"$".join(seqs) + b"$", dtype=np.uint8)
+    print(json.dumps({"same_anchors": aset(res) == aset(ref), "anchors": len(ref["anchors"][0]), "shares": res["shares"], "batches": res["batches"],
+                      "same_text": shard.lower_text(T0.tobytes(), res["anchors"]).tobytes() == one.T.encode("latin-1"),
+                      "same_counts": all(res["stats"][k] == ref["stats"][k] for k in ("steps", "splits", "anchored_bp"))}))
+grp.barrier(); grp.close()
+'''
+
+
+@pytest.mark.parametrize("world,genomes,L", [(2, 2, 400000), (3, 4, 150000)])
+def test_processes_divide_one_alignment_over_hip_ipc(tmp_path, world, genomes, L):
+    """shard.align_sharded_group with transport.DeviceMemory: no torch in the ranks -- requests over local sockets, the owner's staging buffers exported
+    once with hipIpcGetMemHandle, every worker process opens them and copies its batches out device to device (SURVEY 8(e): point-to-point copies of
+    child arrays, no collective).  The merged result is the undivided one."""
+    import json, os, subprocess, sys
+    from helpers import ROOT
+    script = tmp_path / "ranks_ipc.py"
+    script.write_text(IPC_RANK % (ROOT, L, genomes))
+    port = str(29560 + world + genomes)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env))
+    outs = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-3000:]
+    r = json.loads([x for x in outs[0][0].splitlines() if x.startswith("{")][-1])
+    assert r["same_anchors"] and r["same_text"] and r["same_counts"] and r["anchors"] > 500
+    assert len(r["shares"]) == world and sum(1 for x in r["shares"] if x > 0) >= 2 and sum(r["batches"]) >= world
+
+
 def test_processes_divide_one_alignment_with_the_cascade_on(tmp_path):
     """the default path (no RV_NO_CASCADE in the ranks' environment; this test's name keeps the fixture away): four samples on three ranks --
     rv_align_builtin_until runs the interval cascade first, what it leaves undecided becomes the frontier (install_frontier), balanced_frontier

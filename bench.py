@@ -268,6 +268,8 @@ def run_stream(args, rank, local_rank, world, dist, torch, emit=True):
     import threading
     import numpy as np
     from reveal_amd import _lib, check, synth, reveallib, reveallib64
+    if os.environ.get("RV_BENCH_SHARE_GPU"):
+        local_rank = 0
     _lib.set_device(local_rank)
     P, D, H = args.pairs, max(1, min(args.stream_distinct, args.pairs)), max(1, args.stream_handles)
     # the inputs, generated before anything is timed (a caller would have read them from its files): D distinct ones, used in turn
@@ -351,7 +353,7 @@ def run_stream(args, rank, local_rank, world, dist, torch, emit=True):
         p = ix.prof(enable=False)[kname]
         prof = [prof[0] + p[0], prof[1] + p[1], prof[2] + p[2]]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if not os.environ.get("RV_BENCH_SHARE_GPU") else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     # the last result of every handle against the full-size properties; rank 0's seed-42 input against the CPU digests

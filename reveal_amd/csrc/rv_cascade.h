@@ -14,7 +14,15 @@ struct RvCascadeBufs {
     int64_t lin_steps = 0; int lin_maxdepth = 0; size_t lin_off[6] = {0, 0, 0, 0, 0, 0};
     // a chain member the match list does not decide: its sequences as (begin, end) pairs and its depth -- the caller makes it the level pipeline's frontier
     std::vector<int64_t> lin_rest; int lin_rest_depth = 0;
-    void release() { for (auto &b : d) b.release(); hstage.release(); hstage2.release(); }
+    // the cascade's level loop on a stream of the highest priority (RV_CASCADE_PRIO): its kernels are a chain of tiny launches, and on the handle's own
+    // stream they queue behind the large kernels of whatever other handles share the hardware queue
+    hipStream_t prio_stream = nullptr; hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    void release() {
+        for (auto &b : d) b.release(); hstage.release(); hstage2.release();
+        if (prio_stream) { (void)hipStreamDestroy(prio_stream); prio_stream = nullptr; }
+        if (ev_in) { (void)hipEventDestroy(ev_in); ev_in = nullptr; }
+        if (ev_out) { (void)hipEventDestroy(ev_out); ev_out = nullptr; }
+    }
 };
 
 struct RvCascadeIO {

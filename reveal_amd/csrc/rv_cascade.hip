@@ -1187,6 +1187,31 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB * CAS_ITEMS) + ceil_div((int64_t)NW, TB * CAS_ITEMS));
     const int batch = std::max(1, (int)ws.opt.cascade_batch);
     int queued = 0;
+    // (RV_CASCADE_PRIO=1: the level loop on a stream of the highest priority, fenced by events against the handle's own -- see rv_cascade_multi.hip)
+    struct PrioScope {
+        Workspace &w; hipStream_t home; RvCascadeBufs &cb; bool on = false;
+        ~PrioScope() { leave(); }
+        void leave() {
+            if (!on) return;
+            on = false;
+            (void)hipEventRecord(cb.ev_out, w.stream);
+            w.stream = home;
+            (void)hipStreamWaitEvent(home, cb.ev_out, 0);
+        }
+    } prio{ws, q, cb};
+    if (ws.opt.cascade_prio) {
+        if (!cb.prio_stream) {
+            int plo = 0, phi = 0;
+            RV_HIP(hipDeviceGetStreamPriorityRange(&plo, &phi));
+            RV_HIP(hipStreamCreateWithPriority(&cb.prio_stream, hipStreamNonBlocking, phi));
+            RV_HIP(hipEventCreateWithFlags(&cb.ev_in, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&cb.ev_out, hipEventDisableTiming));
+        }
+        RV_HIP(hipEventRecord(cb.ev_in, q));
+        RV_HIP(hipStreamWaitEvent(cb.prio_stream, cb.ev_in, 0));
+        ws.stream = cb.prio_stream; prio.on = true;
+        q = cb.prio_stream;
+    }
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {
             hipLaunchKernelGGL(k_cas_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bpa.as<sa_t>(), (const sa_t *)bpb.as<sa_t>(), (const u32 *)blen.as<u32>(), bcc.as<u32>(), M,
@@ -1227,6 +1252,7 @@ int rv_cascade_run(rv_index *h, RvCascadeBufs &cb, const RvCascadeIO &io, int mi
         if (hc[C_HI] == hc[C_LO]) break;
         if (queued > 1000000) { rv_set_error("cascade: no progress"); return -1; }
     }
+    prio.leave(); q = ws.stream;
     const int level = (int)hc[C_LEVELS];
     const u32 hi = hc[C_NCHILD];
     if (verbose) tp[3] = cas_now();

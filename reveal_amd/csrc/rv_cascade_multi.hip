@@ -1019,6 +1019,32 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                            bcl.as<u32>(), bcp.as<sa_t>(), bcc.as<u32>());
         RV_LAUNCH_CHECK();
     }
+    // (RV_CASCADE_PRIO=1: the level loop -- ~120 launches of a few microseconds each, a host round trip every eighth level -- runs on a stream of the highest
+    //  priority, fenced by events against the handle's own; restored before the function returns on any path)
+    struct PrioScope {
+        Workspace &w; hipStream_t home; RvCascadeBufs &cb; bool on = false;
+        ~PrioScope() { leave(); }
+        void leave() {
+            if (!on) return;
+            on = false;
+            (void)hipEventRecord(cb.ev_out, w.stream);
+            w.stream = home;
+            (void)hipStreamWaitEvent(home, cb.ev_out, 0);
+        }
+    } prio{ws, q, cb};
+    if (ws.opt.cascade_prio) {
+        if (!cb.prio_stream) {
+            int lo = 0, hi = 0;
+            RV_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // (hi: the numerically smallest = the greatest priority)
+            RV_HIP(hipStreamCreateWithPriority(&cb.prio_stream, hipStreamNonBlocking, hi));
+            RV_HIP(hipEventCreateWithFlags(&cb.ev_in, hipEventDisableTiming));
+            RV_HIP(hipEventCreateWithFlags(&cb.ev_out, hipEventDisableTiming));
+        }
+        RV_HIP(hipEventRecord(cb.ev_in, q));
+        RV_HIP(hipStreamWaitEvent(cb.prio_stream, cb.ev_in, 0));
+        ws.stream = cb.prio_stream; prio.on = true;
+        q = cb.prio_stream;
+    }
     hipLaunchKernelGGL(k_casm_init, dim3((unsigned)std::max<int64_t>(1, ceil_div((int64_t)NW, TB))), dim3(TB), 0, q, t, k, d_rb, d_re, counters, bwc.as<u32>(), NW);
     RV_LAUNCH_CHECK();
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
@@ -1050,6 +1076,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         if (hc[C_HI] == hc[C_LO]) break;
         if (queued > 1000000) { rv_set_error("cascade (multi): no progress"); return -1; }
     }
+    prio.leave(); q = ws.stream;
     out->levels = (int)hc[C_LEVELS]; out->children = hc[C_NCHILD];
     const u32 U = hc[C_NUND], NA = hc[C_NANCH];
     out->undecided = U;

@@ -104,7 +104,8 @@ void rv_set_error(const char *fmt, ...);
     X(lock_any, "RV_LOCK_ANY", 0) \
     X(presel_dev_min, "RV_PRESEL_DEV_MIN", 65536) \
     X(scan_v1, "RV_SCAN_V1", 0) \
-    X(pick_threads, "RV_PICK_THREADS", 0)
+    X(pick_threads, "RV_PICK_THREADS", 0) \
+    X(cascade_prio, "RV_CASCADE_PRIO", 0)
 struct RvOptions {
 #define RV_X_(f, name, def) int64_t f = def;
     RV_OPTION_LIST(RV_X_)

@@ -162,7 +162,17 @@ def run_config5(args, rank, local_rank, world, dist, torch):
     nthreads = max(1, min(args.jobs if args.jobs > 1 else 8, len(mine)))      # (measured on one GPU: 2 / 4 / 8 / 12 / 20 at a time -> 114 / 99 / 95 / 96 / 103 ms per step)
     results = {}
 
+    batches = None
+    if args.batch > 0:      # rv_batch_run: the jobs of a batch on host threads inside the library, the level loops of their anchor cascades as one set of launches
+        from reveal_amd import batch as rvbatch
+        batches = [(grp, rvbatch.Batch([handles[j] for j in grp])) for grp in (mine[i:i + args.batch] for i in range(0, len(mine), args.batch))]
+
     def step():
+        if batches is not None:
+            for grp, B in batches:
+                for j, r in zip(grp, B.run(args.minl, args.minn)):
+                    results[j] = r
+            return
         todo = queue.Queue()
         for j in mine:
             todo.put(j)
@@ -243,7 +253,9 @@ def run_config5(args, rank, local_rank, world, dist, torch):
                                    "construct + full recursion per job, bench picker; texts resident in HBM before the timed region; levels 1-2 "
                                    "(GFA -> GFA through the Python graph callbacks) are the Python driver's and outside the timed scope (SURVEY 8(e))"
                                    % (NG, args.L / 1e6, CH, len(level0), CH, args.minl, args.minn),
-                       "jobs": len(level0), "jobs_per_rank": [len(g["jobs"]) for g in gathered], "concurrent_jobs_per_gpu": nthreads,
+                       "jobs": len(level0), "jobs_per_rank": [len(g["jobs"]) for g in gathered], "concurrent_jobs_per_gpu": nthreads if batches is None else args.batch,
+                       "batched": None if batches is None else {"jobs_per_rv_batch_run": args.batch, "joint_level_loops": sum(B.info()["joint_level_loops"] for _, B in batches),
+                                                                "jobs_served_by_them": sum(B.info()["jobs_served"] for _, B in batches)},
                        "bases_per_step": total_bases, "index": "64-bit" if args.sa64 else "32-bit",
                        "sharding": "job j on rank j % world, no exchange (the reference's only parallelism: independent reveal rem commands)"},
             "upload_ms": upload_ms,
@@ -561,6 +573,8 @@ def main():
     ap.add_argument("--stream-distinct", type=int, default=3, help="--config stream: distinct synthetic inputs generated (used in turn)")
     ap.add_argument("--stream-handles", type=int, default=4, help="--config stream: inputs in flight per GPU")
     ap.add_argument("--c5-genomes", type=int, default=100, help="--config c5: number of genomes (a multiple of 5)")
+    ap.add_argument("--batch", type=int, default=0, help="--config c5: jobs per rv_batch_run call (the library's own host threads, the anchor cascades' level loops of a "
+                                                         "batch as one set of launches); 0 = a Python thread per job in flight (--jobs)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline and parity legs")
     ap.add_argument("--no-allcores", action="store_true", help="skip the all-host-cores CPU leg")
     ap.add_argument("--cpu-full", action="store_true", help="also time the CPU restatement on the WHOLE workload on this host (single thread: about 13 minutes and 17 GB "

@@ -379,6 +379,19 @@ int rv_prof_enable(rv_index *h, int on);
 int rv_prof_reset(rv_index *h);
 /* launches, total milliseconds and algorithmic bytes of kernel class k since the last reset */
 int rv_prof_get(rv_index *h, int k, int64_t *launches, double *ms, double *bytes);
+/* ---- a batch of independent alignments -----------------------------------------------------------------------------------------------------------
+ * The reference's job-level parallelism is a shell script of independent `reveal rem` commands (reveal/align.py:27-54: the 20 / 4 / 1 jobs of
+ * `--order=sequential --chunksize=5`).  On one GPU small jobs are bound by the chains of tiny launches in their anchor cascades, which streams of their
+ * own hide from each other only in part; rv_batch_run runs the handles' construct + rv_align_builtin on a host thread each and lets the jobs with more
+ * than two samples run the level loops of their cascades as ONE set of launches (every job's lists behind each other, a root per job).
+ * Every handle's result is what rv_align_builtin would have given it alone (rv_fetch_anchors etc. as usual).  status / stats: one entry per handle, in
+ * the order they were added (either may be NULL). */
+typedef struct rv_batch rv_batch;
+rv_batch *rv_batch_new(void);
+int rv_batch_add(rv_batch *b, rv_index *h);
+int rv_batch_run(rv_batch *b, int minl, int minn, int construct, rv_align_stats *stats, int *status);
+int rv_batch_info(const rv_batch *b, int64_t *out);      /* out[0] = joint level loops run so far, out[1] = jobs they served */
+void rv_batch_free(rv_batch *b);
 /* ---- device memory for the frontier hand-off between processes ("child SA/LCP shipped once to the owner GPU, peer copy over
  * xGMI") -- what reveal_amd/shard.py's own transport uses instead of a tensor library: the owner packs the segments it hands out into buffers of its
  * device (rv_frontier_pack, on_device = 1) and exports them once (hipIpcGetMemHandle: 64 bytes that travel over any byte channel); a worker process

@@ -93,6 +93,11 @@ SYMBOLS = {
     "rv_set_preselect": (_I, [V, _L]),
     "rv_set_option": (_I, [V, ctypes.c_char_p, _L]),
     "rv_set_launch_trace": (_I, [_I]),
+    "rv_batch_new": (V, []),
+    "rv_batch_add": (_I, [V, V]),
+    "rv_batch_run": (_I, [V, _I, _I, _I, V, V]),
+    "rv_batch_info": (_I, [V, V]),
+    "rv_batch_free": (None, [V]),
     "rv_dev_alloc": (V, [_I, _L]),
     "rv_dev_free": (_I, [_I, V]),
     "rv_ipc_export": (_I, [_I, V, V]),

@@ -2,6 +2,7 @@
 // construct, getters, top-level scans, profiling and primitive self-tests.
 // The recursion lives in rv_align.hip.
 #include "rv_index.h"
+#include "rv_cascade.h"
 #include <limits>
 #include <stdarg.h>
 #include <stdio.h>
@@ -932,6 +933,80 @@ __global__ __launch_bounds__(256) void k_bw_copy(const bw_v4 *__restrict__ a, bw
 }
 }  // namespace
 extern "C" {
+/* ---- a batch of independent alignments (include/reveal_amd.h "rv_batch"; the reference's counterpart is a shell script of independent `reveal rem`
+ * commands, reveal/align.py:27-54) ---------------------------------------------------------------------------------------------------------------- */
+struct rv_batch {
+    std::vector<rv_index *> hs;
+    RvBatchGroup *g = nullptr;
+    std::vector<std::string> errs;
+};
+rv_batch *rv_batch_new(void) {
+    try { return new rv_batch(); } catch (...) { rv_set_error("rv_batch_new: out of host memory"); return nullptr; }
+}
+int rv_batch_add(rv_batch *b, rv_index *h) {
+    if (!b || !h) { rv_set_error("rv_batch_add: null argument"); return -1; }
+    if (!b->hs.empty() && b->hs[0]->device != h->device) { rv_set_error("rv_batch_add: the handles of a batch live on one device"); return -1; }
+    try { b->hs.push_back(h); } catch (...) { rv_set_error("rv_batch_add: out of host memory"); return -1; }
+    return 0;
+}
+void rv_batch_free(rv_batch *b) {
+    if (!b) return;
+    rv_batch_group_free(b->g);
+    delete b;
+}
+int rv_batch_info(const rv_batch *b, int64_t *out) {
+    out[0] = out[1] = 0;
+    if (b && b->g) rv_batch_group_info(b->g, out);
+    return 0;
+}
+/* construct (when asked) + rv_align_builtin of every handle, each on a host thread and on its handle's stream; status[i] = what the calls of handle i
+ * returned (0 = fine), stats[i] its statistics.  Handles with more than two samples meet in the middle of their anchor cascades and run the level loops as one
+ * set of launches (rv_cascade_multi.hip); their results are those of rv_align_builtin called on each. */
+int rv_batch_run(rv_batch *b, int minl, int minn, int construct, rv_align_stats *stats, int *status) {
+    if (!b || b->hs.empty()) { rv_set_error("rv_batch_run: empty batch"); return -1; }
+    const int n = (int)b->hs.size();
+    try {
+        b->errs.assign((size_t)n, std::string());
+        if (!b->g) b->g = rv_batch_group_new(b->hs[0]->device);
+        int members = 0;
+        for (rv_index *h : b->hs) {
+            const bool in = h->nsamples > 2 && !h->ws.opt.no_cascade;      // (what may reach the rendezvous at all; every early exit on the way there lets the group know)
+            h->batch = in ? b->g : nullptr; h->batch_settled = false;
+            members += in ? 1 : 0;
+        }
+        rv_batch_group_begin(b->g, members);
+        std::vector<int> rc((size_t)n, 0);
+        auto work = [&](int i) {
+            rv_index *h = b->hs[(size_t)i];
+            int r = 0;
+            if (hipSetDevice(h->device) != hipSuccess) { rv_set_error("hipSetDevice failed"); r = -1; }
+            if (r == 0 && construct) r = rv_construct(h, 0, "", "", 0);
+            if (r == 0) r = rv_align_builtin(h, minl, minn, stats ? &stats[i] : nullptr);
+            if (h->batch && !h->batch_settled) { h->batch_settled = true; rv_batch_group_leave(h->batch); }      // (it never got to the rendezvous)
+            if (r != 0) b->errs[(size_t)i] = rv_last_error();      // (the error text is this thread's)
+            rc[(size_t)i] = r;
+        };
+        std::vector<std::thread> th;
+        int started = n;
+        for (int i = 1; i < n; i++) {
+            try { th.emplace_back(work, i); }
+            catch (...) { started = i; break; }      // (no thread to be had: the rest one after the other below -- outside the group, which must not wait for them)
+        }
+        if (started < n) for (int i = started; i < n; i++) { rv_index *h = b->hs[(size_t)i]; if (h->batch) { h->batch_settled = true; rv_batch_group_leave(h->batch); h->batch = nullptr; } }
+        work(0);
+        for (auto &t : th) t.join();
+        for (int i = started; i < n; i++) work(i);
+        int bad = -1;
+        for (int i = 0; i < n; i++) { b->hs[(size_t)i]->batch = nullptr; if (status) status[i] = rc[(size_t)i]; if (rc[(size_t)i] != 0 && bad < 0) bad = i; }
+        if (bad >= 0) { rv_set_error("rv_batch_run: job %d: %s", bad, b->errs[(size_t)bad].c_str()); return -1; }
+        return 0;
+    } catch (const std::exception &e) {
+        for (rv_index *h : b->hs) h->batch = nullptr;
+        rv_set_error("rv_batch_run: %s", e.what());
+        return -1;
+    }
+}
+
 /* device memory for the frontier hand-off between processes (include/reveal_amd.h) */
 void *rv_dev_alloc(int device, int64_t bytes) {
     void *p = nullptr;

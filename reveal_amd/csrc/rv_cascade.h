@@ -55,6 +55,13 @@ struct RvCascadeMultiOut {
 };
 
 struct rv_index;
+// rv_batch_run (rv_api.hip): the jobs of a batch run the level loops of their anchor cascades as one (rv_cascade_multi.hip)
+struct RvBatchGroup;
+RvBatchGroup *rv_batch_group_new(int device);
+void rv_batch_group_begin(RvBatchGroup *g, int total);      // before the jobs of a run start: how many there are
+void rv_batch_group_leave(RvBatchGroup *g);                 // a job that will not come to the rendezvous
+void rv_batch_group_free(RvBatchGroup *g);
+void rv_batch_group_info(const RvBatchGroup *g, int64_t *out);      // out[0] joint level loops run, out[1] jobs they served
 int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl, RvCascadeMultiOut *out);
 // danger: large undecided sub-indices are decided from their witnesses (the second attempt, rv_cascade.hip); reuse: the match and
 // witness lists of the previous run on this handle are still in cb (same index, same minl)

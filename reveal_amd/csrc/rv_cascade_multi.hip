@@ -21,6 +21,9 @@
 #include "rv_cascade.h"
 #include "rv_leaf.h"
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
 #include <string.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -348,8 +351,9 @@ __global__ __launch_bounds__(TB) void k_casm_gather(const u32 *__restrict__ len_
     for (int s = 0; s < k; s++) pos_out[(size_t)i * k + s] = pos_in[(size_t)src * k + s];
 }
 
-struct CmTabs {      // per sub-index: k intervals, its best bid, Rmax, depth, state (0 open, 1 split, 2 ended), children, the chosen match
+struct CmTabs {      // per sub-index: k intervals, its best bid, Rmax, depth, state (0 open, 1 split, 2 ended, 3 undecided), children, the chosen match
     sa_t *b, *e; u64 *best; u32 *rmax; int32_t *depth; u32 *state, *lead, *trail; sa_t *q; u32 *ql;
+    u32 *job = nullptr;      // the level loops of several jobs as one (rv_batch_*): the job a sub-index belongs to (inherited from its root); NULL otherwise
 };
 __global__ void k_casm_init(CmTabs t, int k, const sa_t *__restrict__ root_b, const sa_t *__restrict__ root_e, u32 *__restrict__ counters, u32 *__restrict__ w_child, u32 nw) {
     const u32 i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,7 +387,7 @@ __device__ inline int64_t cm_cut(const CmRow &p, int k, const CmRow &B, const Cm
 }
 __global__ __launch_bounds__(TB) void k_casm_assign(const sa_t *__restrict__ c_pos, const u32 *__restrict__ c_len, u32 *__restrict__ c_child, u32 M,
                                                     const sa_t *__restrict__ w_pos, const u32 *__restrict__ w_val, u32 *__restrict__ w_child, u32 NW,
-                                                    CmTabs t, int k, const sa_t *__restrict__ nsep, int64_t minl, int first) {
+                                                    CmTabs t, int k, const sa_t *__restrict__ nsep, int64_t minl, int first, const uint8_t *__restrict__ w_smp = nullptr) {
     const u32 tid = blockIdx.x * TB + threadIdx.x;
     const u32 mblocks = (M + TB - 1) / TB;
     if (blockIdx.x < mblocks) {
@@ -434,7 +438,7 @@ __global__ __launch_bounds__(TB) void k_casm_assign(const sa_t *__restrict__ c_p
         if (live) {
             const sa_t pos = w_pos[i];
             v = w_val[i];
-            const int s = cm_sample(nsep, k, pos);
+            const int s = w_smp ? (int)w_smp[i] : cm_sample(nsep, k, pos);      // (several jobs in one loop: every job has separators of its own, the sample was made with the list)
             if (!first) {
                 u32 nc = NONE;
                 if (t.state[c] == 1u) {
@@ -473,7 +477,8 @@ __global__ __launch_bounds__(TB) void k_casm_winner(const sa_t *__restrict__ c_p
 }
 
 __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u32 *__restrict__ counters, u32 child_cap, u32 *__restrict__ und_list, u32 leaf_n,
-                                                    u32 *__restrict__ an_l, sa_t *__restrict__ an_pos, u32 an_cap) {
+                                                    u32 *__restrict__ an_l, sa_t *__restrict__ an_pos, u32 an_cap, u32 *__restrict__ an_job = nullptr,
+                                                    u32 *__restrict__ job_cnt = nullptr, const u32 *__restrict__ job_abase = nullptr) {
     __shared__ u32 s_cnt[TB / 64][3];
     __shared__ u32 s_base[3];
     const u32 lo = counters[C_LO], hi = counters[C_HI];
@@ -530,6 +535,7 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
 #pragma unroll
                     for (int s = 0; s < RV_CASM_K; s++) if (s < k) { t.b[(size_t)slot * k + s] = rb[s]; t.e[(size_t)slot * k + s] = rq[s]; }
                     t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
+                    if (t.job) t.job[slot] = t.job[id];
                     lc = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
                 slot++;
@@ -539,19 +545,24 @@ __global__ __launch_bounds__(TB) void k_casm_decide(CmTabs t, int k, u32 minl, u
 #pragma unroll
                     for (int s = 0; s < RV_CASM_K; s++) if (s < k) { t.b[(size_t)slot * k + s] = (sa_t)((int64_t)rq[s] + L); t.e[(size_t)slot * k + s] = re[s]; }
                     t.best[slot] = 0; t.rmax[slot] = 0; t.depth[slot] = dp + 1; t.state[slot] = 0; t.lead[slot] = NONE; t.trail[slot] = NONE; t.ql[slot] = 0;
+                    if (t.job) t.job[slot] = t.job[id];
                     tc = slot;
                 } else atomicOr(&counters[C_ERR], 1u);
             }
             t.lead[id] = lc; t.trail[id] = tc;
-            const u32 as = base_a + (u32)__popcll(b_split & lt);
-            if (as < an_cap) {
+            // (several jobs in one loop: a job's anchors stand together, in its own stretch of the arrays -- the counters 256 B apart, see k_full_scan)
+            u32 as = base_a + (u32)__popcll(b_split & lt);
+            u32 as_cap = an_cap;
+            if (job_cnt) { const u32 jb = t.job[id]; as = job_abase[jb] + atomicAdd(&job_cnt[jb * 64], 1u); as_cap = job_abase[jb + 1]; }
+            if (as < as_cap) {
                 an_l[as] = L;
+                if (an_job) an_job[as] = t.job[id];
 #pragma unroll
                 for (int s = 0; s < RV_CASM_K; s++) if (s < k) an_pos[(size_t)as * k + s] = rq[s];
             }
             else atomicOr(&counters[C_ERR], 4u);
         }
-        if (in) t.state[id] = split ? 1u : 2u;
+        if (in) t.state[id] = split ? 1u : (und ? 3u : 2u);
         if (und) {
             und_list[base_u + (u32)__popcll(b_und & lt)] = id;
             if ((u64)total > (u64)leaf_n) {      // (above the size one workgroup rebuilds in LDS: k_casmb_*)
@@ -906,6 +917,302 @@ int bitlen64m(u64 x) { int b = 0; while (x) { b++; x >>= 1; } return b; }
 
 }  // namespace
 
+// ---- the level loops of several jobs as ONE (rv_batch_*) -------------------------------------------------------------------------
+// The cascade's level kernels never touch SA or LCP: they work on a job's list of full matches, its witness list and the table of sub-indices.  A job
+// of 5 x 5 Mbp spends a quarter of its kernel time in them -- 40 levels x 3 dependent launches of a few microseconds -- and independent jobs on streams
+// of their own hide little of that behind each other (four hardware queues, a tiny kernel waits behind whatever large one shares its queue).  So the
+// jobs of a batch meet here: every job builds its index and its two lists as always, on its own stream and host thread; the last to arrive concatenates
+// the lists (matches keep their job's coordinates -- a match only ever meets sub-indices of its own job, through c_child), makes one root per job, runs
+// the level loop once for all of them -- a sub-index inherits its root's job, an anchor is written with it -- lower-cases every job's anchors, and hands
+// each job its anchors and undecided sub-indices; every job then rebuilds those and finishes on its own stream.  Anything unusual (different sample
+// counts or minl in the batch, full tables) sends every job back to its own loop.
+struct RvBatchJob {
+    // what a job brings
+    int k = 0; u32 minl = 0; u32 M = 0, NW = 0, ccap = 0, acap = 0;
+    const u32 *c_len = nullptr; const sa_t *c_pos = nullptr; const sa_t *w_pos = nullptr; const u32 *w_val = nullptr;
+    const sa_t *nsep = nullptr; uint8_t *dT = nullptr;
+    std::vector<sa_t> rb, re, sep;
+    int64_t big_min = 0, big_root = 0, big_total = 0; bool no_big = false;
+    hipStream_t stream = nullptr; hipEvent_t ready = nullptr;
+    // what it gets back
+    bool ok = false, too_big = false;
+    u32 levels = 0, nchild = 0, steps = 0, maxdepth = 0, maxn = 0;
+    const u32 *d_anl = nullptr; const sa_t *d_anp = nullptr; u32 na = 0;      // its anchors: a stretch of the group's arrays (device)
+    std::vector<u32> und_id; std::vector<int32_t> und_dep; std::vector<sa_t> und_b, und_e;
+};
+struct RvBatchGroup {
+    std::mutex mu; std::condition_variable cv;
+    int total = 0, settled = 0;
+    std::vector<RvBatchJob *> arrived;
+    bool leader_taken = false, done = false;
+    DBuf d[20]; HBuf hs, hs2;
+    CmTabs t{};
+    hipEvent_t ev_done = nullptr;
+    int device = 0;
+    int64_t joint_runs = 0, joint_jobs = 0;
+};
+
+// which job owns entry i of a concatenated list (off: J + 1 ascending offsets)
+__device__ inline int cmj_owner(const u32 *__restrict__ off, int J, u32 i) {
+    int lo = 0, hi = J;
+    while (lo + 1 < hi) { const int mid = (lo + hi) >> 1; if (off[mid] <= i) lo = mid; else hi = mid; }
+    return lo;
+}
+__global__ __launch_bounds__(TB) void k_cmj_fill(u32 M, u32 NW, const u32 *__restrict__ moff, const u32 *__restrict__ woff, int J, int k, const sa_t *__restrict__ seps /* J x (k - 1) */,
+                                                 const sa_t *__restrict__ w_pos, u32 *__restrict__ c_child, u32 *__restrict__ w_child, uint8_t *__restrict__ w_smp) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i < M) c_child[i] = (u32)cmj_owner(moff, J, i);
+    if (i < NW) {
+        const int j = cmj_owner(woff, J, i);
+        w_child[i] = (u32)j;
+        w_smp[i] = (uint8_t)cm_sample(seps + (size_t)j * (k - 1), k, w_pos[i]);
+    }
+}
+__global__ void k_cmj_init(CmTabs t, int k, const sa_t *__restrict__ roots_b, const sa_t *__restrict__ roots_e, int J, u32 *__restrict__ counters) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < J) {
+        for (int s = 0; s < k; s++) { t.b[(size_t)j * k + s] = roots_b[(size_t)j * k + s]; t.e[(size_t)j * k + s] = roots_e[(size_t)j * k + s]; }
+        t.best[j] = 0; t.rmax[j] = 0; t.depth[j] = 0; t.state[j] = 0; t.lead[j] = NONE; t.trail[j] = NONE; t.ql[j] = 0; t.job[j] = (u32)j;
+    }
+    if (j == 0) {
+        counters[C_NCHILD] = (u32)J; counters[C_NUND] = 0; counters[C_ERR] = 0; counters[C_MAXN] = 0; counters[C_LO] = 0; counters[C_HI] = (u32)J; counters[C_LEVELS] = 0;
+        counters[C_NANCH] = 0; counters[C_STEPS] = 0; counters[C_MAXDEPTH] = 0; counters[C_TICKET] = 0; counters[C_BIGTOT] = 0; counters[C_BIGTOT + 1] = 0;
+    }
+}
+// per job: sub-indices, the largest depth among all of them, among those that were visited (not undecided)
+__global__ __launch_bounds__(TB) void k_cmj_stats(CmTabs t, u32 nchild, u32 *__restrict__ out /* J x 4 */) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= nchild) return;
+    const u32 j = t.job[i], dp = (u32)t.depth[i];
+    atomicAdd(&out[j * 4], 1u);
+    if (dp > out[j * 4 + 1]) atomicMax(&out[j * 4 + 1], dp);
+    if (t.state[i] != 3u && dp > out[j * 4 + 2]) atomicMax(&out[j * 4 + 2], dp);
+}
+__global__ __launch_bounds__(TB) void k_cmj_rows(const u32 *__restrict__ und, u32 U, CmTabs t, int k, u32 *__restrict__ o_id, int32_t *__restrict__ o_dep, u32 *__restrict__ o_job,
+                                                 sa_t *__restrict__ o_b, sa_t *__restrict__ o_e) {
+    const u32 i = blockIdx.x * TB + threadIdx.x;
+    if (i >= U * (u32)k) return;
+    const u32 x = i / (u32)k, s = i - x * (u32)k, id = und[x];
+    o_b[i] = t.b[(size_t)id * k + s]; o_e[i] = t.e[(size_t)id * k + s];
+    if (s == 0) { o_id[x] = id; o_dep[x] = t.depth[id]; o_job[x] = t.job[id]; }
+}
+// reveal.c:1230-1234 for one job's anchors (its stretch of the group's arrays): a wave per member
+__global__ __launch_bounds__(TB) void k_cmj_lower(uint8_t *__restrict__ T, const u32 *__restrict__ an_l, const sa_t *__restrict__ an_pos, u32 na, int k) {
+    const u32 e = (u32)(((int64_t)blockIdx.x * TB + threadIdx.x) >> 6);
+    if (e >= na * (u32)k) return;
+    const int64_t lo = (int64_t)an_pos[e], l = (int64_t)an_l[e / (u32)k];
+    for (int64_t x = threadIdx.x & 63; x < l; x += 64) { const uint8_t c = T[lo + x]; if (c >= 'A' && c <= 'Z') T[lo + x] = c + 32; }
+}
+
+static int batch_joint_phase(RvBatchGroup *g, Workspace &ws);
+
+// a job arrives with its lists; returns when the joint phase is over (job->ok says whether it served this job)
+static void batch_join(RvBatchGroup *g, RvBatchJob *job, Workspace &ws) {
+    std::unique_lock<std::mutex> lk(g->mu);
+    g->arrived.push_back(job);
+    g->settled++;
+    for (;;) {
+        if (g->done) return;
+        if (g->settled >= g->total && !g->leader_taken) {
+            g->leader_taken = true;
+            lk.unlock();
+            if (batch_joint_phase(g, ws) != 0) for (RvBatchJob *x : g->arrived) x->ok = false;      // (everybody falls back to its own loop)
+            lk.lock();
+            g->done = true;
+            g->cv.notify_all();
+            return;
+        }
+        g->cv.wait(lk);
+    }
+}
+void rv_batch_group_leave(RvBatchGroup *g) {
+    if (!g) return;
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->settled++;
+    if (g->settled >= g->total) g->cv.notify_all();      // (a job that is waiting takes the joint phase)
+}
+RvBatchGroup *rv_batch_group_new(int device) { RvBatchGroup *g = new RvBatchGroup(); g->device = device; return g; }
+void rv_batch_group_begin(RvBatchGroup *g, int total) {
+    std::lock_guard<std::mutex> lk(g->mu);
+    g->total = total; g->settled = 0; g->arrived.clear(); g->leader_taken = false; g->done = false;
+}
+void rv_batch_group_free(RvBatchGroup *g) {
+    if (!g) return;
+    (void)hipSetDevice(g->device);
+    for (auto &b : g->d) b.release();
+    g->hs.release(); g->hs2.release();
+    if (g->ev_done) (void)hipEventDestroy(g->ev_done);
+    delete g;
+}
+void rv_batch_group_info(const RvBatchGroup *g, int64_t *out) { out[0] = g->joint_runs; out[1] = g->joint_jobs; }
+
+static int batch_joint_phase(RvBatchGroup *g, Workspace &ws) {
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<RvBatchJob *> &jobs = g->arrived;
+    const int J = (int)jobs.size();
+    for (RvBatchJob *x : jobs) x->ok = false;
+    if (J < 2) return 0;
+    const int k = jobs[0]->k; const u32 minl = jobs[0]->minl;
+    for (RvBatchJob *x : jobs) if (x->k != k || x->minl != minl) return 0;
+    hipStream_t q = ws.stream;      // the leader's stream
+    RV_HIP(hipSetDevice(g->device));
+    if (!g->ev_done) RV_HIP(hipEventCreateWithFlags(&g->ev_done, hipEventDisableTiming));
+    std::vector<u32> moff((size_t)J + 1, 0), woff((size_t)J + 1, 0);
+    u64 ccap64 = 0, acap64 = 0;
+    for (int j = 0; j < J; j++) {
+        moff[(size_t)j + 1] = moff[(size_t)j] + jobs[(size_t)j]->M; woff[(size_t)j + 1] = woff[(size_t)j] + jobs[(size_t)j]->NW;
+        ccap64 += jobs[(size_t)j]->ccap; acap64 += jobs[(size_t)j]->acap;
+        if ((u64)moff[(size_t)j] + jobs[(size_t)j]->M > 0x7fffffffull || (u64)woff[(size_t)j] + jobs[(size_t)j]->NW > 0x7fffffffull) return 0;
+    }
+    if (ccap64 > 0x7fffffffull || acap64 > 0x7fffffffull) return 0;
+    const u32 M = moff[(size_t)J], NW = woff[(size_t)J], ccap = (u32)ccap64, acap = (u32)acap64;
+    if (M == 0) return 0;
+    DBuf &bcl = g->d[0], &bcp = g->d[1], &bcc = g->d[2], &bwp = g->d[3], &bwv = g->d[4], &bwc = g->d[5], &bws = g->d[6], &btb = g->d[7], &bctr = g->d[8], &bund = g->d[9],
+         &banl = g->d[10], &banp = g->d[11], &bsm = g->d[13], &brows = g->d[14], &bst = g->d[15];
+    RV_TRY(bcl.reserve((size_t)M * 4)); RV_TRY(bcp.reserve((size_t)M * k * sizeof(sa_t))); RV_TRY(bcc.reserve((size_t)M * 4));
+    RV_TRY(bwp.reserve((size_t)(NW + 1) * sizeof(sa_t))); RV_TRY(bwv.reserve((size_t)(NW + 1) * 4)); RV_TRY(bwc.reserve((size_t)(NW + 1) * 4)); RV_TRY(bws.reserve((size_t)NW + 64));
+    const size_t per = (size_t)3 * k * sizeof(sa_t) + 8 + 7 * 4;
+    RV_TRY(btb.reserve(per * ccap + 256)); RV_TRY(bctr.reserve(256)); RV_TRY(bund.reserve((size_t)ccap * 4));
+    RV_TRY(banl.reserve((size_t)acap * 4)); RV_TRY(banp.reserve((size_t)acap * k * sizeof(sa_t)));
+    RV_TRY(bst.reserve((size_t)J * 16 + 64));
+    CmTabs t;
+    {
+        uint8_t *p = btb.as<uint8_t>();
+        t.best = (u64 *)p; p += (size_t)ccap * 8;
+        t.b = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t); t.e = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t); t.q = (sa_t *)p; p += (size_t)ccap * k * sizeof(sa_t);
+        t.rmax = (u32 *)p; p += (size_t)ccap * 4; t.depth = (int32_t *)p; p += (size_t)ccap * 4; t.state = (u32 *)p; p += (size_t)ccap * 4;
+        t.lead = (u32 *)p; p += (size_t)ccap * 4; t.trail = (u32 *)p; p += (size_t)ccap * 4; t.ql = (u32 *)p; p += (size_t)ccap * 4; t.job = (u32 *)p;
+    }
+    g->t = t;
+    // small tables in one pinned buffer: list offsets, roots, separators, text pointers, skip flags
+    const size_t o_m = 0, o_w = o_m + ((size_t)J + 1) * 4, o_rb = (o_w + ((size_t)J + 1) * 4 + 15) & ~(size_t)15, o_re = o_rb + (size_t)J * k * sizeof(sa_t),
+                 o_sep = o_re + (size_t)J * k * sizeof(sa_t), o_ab = (o_sep + (size_t)J * (k - 1) * sizeof(sa_t) + 15) & ~(size_t)15, sm_bytes = o_ab + ((size_t)J + 1) * 4 + 64;
+    RV_TRY(g->hs.reserve(sm_bytes)); RV_TRY(bsm.reserve(sm_bytes));
+    uint8_t *hp = g->hs.as<uint8_t>();
+    memset(hp, 0, sm_bytes);
+    memcpy(hp + o_m, moff.data(), ((size_t)J + 1) * 4); memcpy(hp + o_w, woff.data(), ((size_t)J + 1) * 4);
+    for (int j = 0; j < J; j++) {
+        memcpy(hp + o_rb + (size_t)j * k * sizeof(sa_t), jobs[(size_t)j]->rb.data(), (size_t)k * sizeof(sa_t));
+        memcpy(hp + o_re + (size_t)j * k * sizeof(sa_t), jobs[(size_t)j]->re.data(), (size_t)k * sizeof(sa_t));
+        memcpy(hp + o_sep + (size_t)j * (k - 1) * sizeof(sa_t), jobs[(size_t)j]->sep.data(), (size_t)(k - 1) * sizeof(sa_t));
+    }
+    std::vector<u32> abase((size_t)J + 1, 0);      // a job's anchors: its own stretch of the arrays, as long as its own area would have been
+    for (int j = 0; j < J; j++) abase[(size_t)j + 1] = abase[(size_t)j] + jobs[(size_t)j]->acap;
+    memcpy(hp + o_ab, abase.data(), ((size_t)J + 1) * 4);
+    DBuf &bjc = g->d[16];
+    RV_TRY(bjc.reserve((size_t)J * 256 + 64));
+    RV_HIP(hipMemsetAsync(bjc.p, 0, (size_t)J * 256, q));
+    uint8_t *dsm = bsm.as<uint8_t>();
+    RV_HIP(hipMemcpyAsync(dsm, hp, sm_bytes, hipMemcpyHostToDevice, q));
+    u32 *counters = bctr.as<u32>();
+    for (int j = 0; j < J; j++) {      // every job's lists are complete on its own stream: wait for them, then copy them behind each other
+        RvBatchJob &x = *jobs[(size_t)j];
+        RV_HIP(hipStreamWaitEvent(q, x.ready, 0));
+        if (x.M) {
+            RV_HIP(hipMemcpyAsync(bcl.as<u32>() + moff[(size_t)j], x.c_len, (size_t)x.M * 4, hipMemcpyDeviceToDevice, q));
+            RV_HIP(hipMemcpyAsync(bcp.as<sa_t>() + (size_t)moff[(size_t)j] * k, x.c_pos, (size_t)x.M * k * sizeof(sa_t), hipMemcpyDeviceToDevice, q));
+        }
+        if (x.NW) {
+            RV_HIP(hipMemcpyAsync(bwp.as<sa_t>() + woff[(size_t)j], x.w_pos, (size_t)x.NW * sizeof(sa_t), hipMemcpyDeviceToDevice, q));
+            RV_HIP(hipMemcpyAsync(bwv.as<u32>() + woff[(size_t)j], x.w_val, (size_t)x.NW * 4, hipMemcpyDeviceToDevice, q));
+        }
+    }
+    hipLaunchKernelGGL(k_cmj_fill, dim3((unsigned)ceil_div((int64_t)std::max(M, NW), TB)), dim3(TB), 0, q, M, NW, (const u32 *)(dsm + o_m), (const u32 *)(dsm + o_w), J, k,
+                       (const sa_t *)(dsm + o_sep), (const sa_t *)bwp.as<sa_t>(), bcc.as<u32>(), bwc.as<u32>(), bws.as<uint8_t>());
+    RV_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_cmj_init, dim3((unsigned)ceil_div((int64_t)J, 64)), dim3(64), 0, q, t, k, (const sa_t *)(dsm + o_rb), (const sa_t *)(dsm + o_re), J, counters);
+    RV_LAUNCH_CHECK();
+    const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
+    const int batch = std::max(1, (int)ws.opt.cascade_batch);
+    // (the size above which an undecided sub-index goes through global memory when it is rebuilt: the jobs' own setting -- it only feeds two counters here)
+    const u32 big_min = (u32)std::min<int64_t>(jobs[0]->big_min, 0x7fffffff);
+    u32 hc[16];
+    int queued = 0;
+    for (;;) {
+        for (int b = 0; b < batch; b++, queued++) {
+            hipLaunchKernelGGL(k_casm_assign, dim3(agrid), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), bcc.as<u32>(), M, (const sa_t *)bwp.as<sa_t>(),
+                               (const u32 *)bwv.as<u32>(), bwc.as<u32>(), NW, t, k, (const sa_t *)nullptr, (int64_t)minl, queued == 0 ? 1 : 0, (const uint8_t *)bws.as<uint8_t>());
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_winner, dim3((unsigned)ceil_div((int64_t)M, TB)), dim3(TB), 0, q, (const sa_t *)bcp.as<sa_t>(), (const u32 *)bcl.as<u32>(), (const u32 *)bcc.as<u32>(), M, t, k,
+                               (int64_t)minl);
+            RV_LAUNCH_CHECK();
+            hipLaunchKernelGGL(k_casm_decide, dim3(192), dim3(TB), 0, q, t, k, minl, counters, ccap, bund.as<u32>(), big_min, banl.as<u32>(), banp.as<sa_t>(), acap, (u32 *)nullptr,
+                               bjc.as<u32>(), (const u32 *)(dsm + o_ab));
+            RV_LAUNCH_CHECK();
+        }
+        RV_TRY(rv_read_back(ws, hc, counters, sizeof hc));
+        if (hc[C_ERR]) return 0;                         // (full tables, or worse: every job back to its own loop, which reports it)
+        if (hc[C_HI] == hc[C_LO]) break;
+        if (queued > 1000000) return 0;
+    }
+    const u32 NCH = hc[C_NCHILD], U = hc[C_NUND];
+    // per job: how many sub-indices, how deep
+    RV_HIP(hipMemsetAsync(bst.p, 0, (size_t)J * 16, q));
+    hipLaunchKernelGGL(k_cmj_stats, dim3((unsigned)ceil_div((int64_t)NCH, TB)), dim3(TB), 0, q, t, NCH, bst.as<u32>());
+    RV_LAUNCH_CHECK();
+    // the undecided sub-indices' rows, the per-job figures and anchor counts to the host (one pinned buffer, one wait); the anchors themselves stay where
+    // they are: every job fetches its own stretch on its own stream afterwards
+    const size_t rowbytes = (size_t)U * 12 + (size_t)U * k * sizeof(sa_t) * 2;
+    const size_t h_st = 0, h_jc = ((size_t)J * 16 + 15) & ~(size_t)15, h_rows = h_jc + (size_t)J * 256;
+    RV_TRY(g->hs2.reserve(h_rows + rowbytes + 64));
+    uint8_t *h2 = g->hs2.as<uint8_t>();
+    RV_HIP(hipMemcpyAsync(h2 + h_st, bst.p, (size_t)J * 16, hipMemcpyDeviceToHost, q));
+    RV_HIP(hipMemcpyAsync(h2 + h_jc, bjc.p, (size_t)J * 256, hipMemcpyDeviceToHost, q));
+    if (U) {
+        RV_TRY(brows.reserve(rowbytes + 64));
+        u32 *d_id = brows.as<u32>(); int32_t *d_dep = (int32_t *)(d_id + U); u32 *d_job = (u32 *)(d_dep + U);
+        sa_t *d_b = (sa_t *)(d_job + U), *d_e = d_b + (size_t)U * k;
+        hipLaunchKernelGGL(k_cmj_rows, dim3((unsigned)ceil_div((int64_t)U * k, TB)), dim3(TB), 0, q, (const u32 *)bund.as<u32>(), U, t, k, d_id, d_dep, d_job, d_b, d_e);
+        RV_LAUNCH_CHECK();
+        RV_HIP(hipMemcpyAsync(h2 + h_rows, brows.p, rowbytes, hipMemcpyDeviceToHost, q));
+    }
+    RV_HIP(hipStreamSynchronize(q));
+    const u32 *st = (const u32 *)(h2 + h_st), *jc = (const u32 *)(h2 + h_jc);
+    for (int j = 0; j < J; j++) {
+        RvBatchJob &x = *jobs[(size_t)j];
+        x.nchild = st[(size_t)j * 4]; x.levels = st[(size_t)j * 4 + 1] + 1; x.maxdepth = st[(size_t)j * 4 + 2];
+        x.na = jc[(size_t)j * 64];
+        if (x.na > x.acap) return 0;      // (its stretch was too short: every job back to its own loop, which reports it)
+        x.d_anl = banl.as<u32>() + abase[(size_t)j]; x.d_anp = banp.as<sa_t>() + (size_t)abase[(size_t)j] * k;
+        x.und_id.clear(); x.und_dep.clear(); x.und_b.clear(); x.und_e.clear(); x.too_big = false; x.maxn = 0;
+    }
+    std::vector<unsigned long long> bigtot((size_t)J, 0);
+    if (U) {
+        const u32 *r_id = (const u32 *)(h2 + h_rows); const int32_t *r_dep = (const int32_t *)(r_id + U); const u32 *r_job = (const u32 *)(r_dep + U);
+        const sa_t *r_b = (const sa_t *)(r_job + U), *r_e = r_b + (size_t)U * k;
+        for (u32 u2 = 0; u2 < U; u2++) {
+            const u32 j = r_job[u2];
+            if (j >= (u32)J) return 0;
+            RvBatchJob &x = *jobs[j];
+            x.und_id.push_back(r_id[u2]); x.und_dep.push_back(r_dep[u2]);
+            int64_t sz = 0;
+            for (int s2 = 0; s2 < k; s2++) {
+                x.und_b.push_back(r_b[(size_t)u2 * k + s2]); x.und_e.push_back(r_e[(size_t)u2 * k + s2]);
+                if (r_e[(size_t)u2 * k + s2] > r_b[(size_t)u2 * k + s2]) sz += (int64_t)(r_e[(size_t)u2 * k + s2] - r_b[(size_t)u2 * k + s2]);
+            }
+            if (sz > x.big_min) { x.maxn = std::max<u32>(x.maxn, (u32)std::min<int64_t>(sz, 0xFFFFFFFFll)); bigtot[j] += (unsigned long long)sz; }
+        }
+    }
+    for (int j = 0; j < J; j++) {
+        RvBatchJob &x = *jobs[(size_t)j];
+        x.steps = x.nchild - (u32)x.und_id.size();
+        x.too_big = x.no_big ? x.maxn > (u32)BN : ((int64_t)x.maxn > x.big_root || (int64_t)bigtot[(size_t)j] > x.big_total);
+        // (a job rv_cascade_multi_run gives up on after its loop keeps its text: too large an undecided sub-index, or nothing decided at all)
+        const bool nothing = x.und_id.size() == 1 && x.nchild == 1;
+        if (x.na && !x.too_big && !nothing) {
+            hipLaunchKernelGGL(k_cmj_lower, dim3((unsigned)ceil_div((int64_t)x.na * k * 64, TB)), dim3(TB), 0, q, x.dT, x.d_anl, x.d_anp, x.na, k);
+            RV_LAUNCH_CHECK();
+        }
+    }
+    RV_HIP(hipEventRecord(g->ev_done, q));
+    for (RvBatchJob *x : jobs) x->ok = true;
+    g->joint_runs++; g->joint_jobs += J;
+    if (ws.opt.cascade_log)
+        fprintf(stderr, "cascade (batch): %d jobs of %d samples in one loop: %u matches, %u witnesses, %u levels, %u sub-indices, %u undecided; %.2f ms from the last arrival to the hand-back\n",
+                J, k, M, NW, hc[C_LEVELS], NCH, U, (std::chrono::duration<double>(std::chrono::steady_clock::now() - t_begin).count()) * 1e3);
+    return 0;
+}
+
 int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeMultiOut *out) {
     out->done = false; out->levels = 0; out->cands = out->witnesses = out->children = out->undecided = out->rebuilt_ranks = 0; out->steps = 0; out->maxdepth = 0;
     out->why = nullptr; out->big = out->big_ranks = 0; out->an_l.clear(); out->an_pos.clear(); out->meta.clear(); out->node_first.clear(); out->nodes.clear(); out->d_sa = out->d_lcp = out->d_bwt = nullptr;
@@ -914,6 +1221,8 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const int64_t n = h->n;
     const int k = h->nsamples;
     const u32 minl = (u32)std::max(minl_in, 1);
+    // a job of a batch that leaves this function before the rendezvous tells the group so (the others would wait for it for ever)
+    struct BatchTicket { rv_index *h; bool settled = false; ~BatchTicket() { if (h->batch && !settled && !h->batch_settled) { h->batch_settled = true; rv_batch_group_leave(h->batch); } } } ticket{h};
     const bool verbose = (ws.opt.cascade_log != 0);
 #define GIVE_UP(msg) do { out->why = msg; if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s\n", k, msg); return 0; } while (0)
     if (k < 2 || k > RV_CASM_K) GIVE_UP("sample count outside the cascade's range");      // (two samples: the second attempt of rv_align.hip, see there)
@@ -1019,6 +1328,40 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
                            bcl.as<u32>(), bcp.as<sa_t>(), bcc.as<u32>());
         RV_LAUNCH_CHECK();
     }
+    // undecided sub-indices of up to big_min ranks are rebuilt by a workgroup in LDS, larger ones through global memory (RV_CASM_BIG_MIN: the test hook
+    // that sends smaller ones there, too; RV_CASM_NO_BIG=1: the cascade gives up on them as it did up to round 4)
+    const bool no_big = ws.opt.casm_no_big != 0;
+    const int64_t big_min = (!no_big && ws.opt.casm_big_min >= 0 && ws.opt.casm_big_min < BN) ? ws.opt.casm_big_min : BN;
+    auto too_big = [&](const u32 *c) {
+        unsigned long long tot; memcpy(&tot, c + C_BIGTOT, 8);
+        return no_big ? c[C_MAXN] > (u32)BN : ((int64_t)c[C_MAXN] > ws.opt.casm_big_root || (int64_t)tot > ws.opt.casm_big_total);
+    };
+    // ---- a job of a batch (rv_batch_run): the level loop is run once for all jobs by whoever arrives last (batch_joint_phase above)
+    bool joint = false;
+    RvBatchJob bjob;
+    if (h->batch && !h->batch_settled) {
+        h->batch_settled = true; ticket.settled = true;
+        bjob.k = k; bjob.minl = minl; bjob.M = M; bjob.NW = std::min(NW, wcap); bjob.ccap = ccap; bjob.acap = acap;
+        bjob.c_len = bcl.as<u32>(); bjob.c_pos = bcp.as<sa_t>(); bjob.w_pos = bwp.as<sa_t>(); bjob.w_val = bwv.as<u32>();
+        bjob.nsep = nsep; bjob.dT = h->dT.as<uint8_t>();
+        bjob.rb = rb; bjob.re = re;
+        for (int s2 = 0; s2 + 1 < k; s2++) bjob.sep.push_back((sa_t)h->nsep[(size_t)s2]);
+        bjob.big_min = big_min; bjob.big_root = ws.opt.casm_big_root; bjob.big_total = ws.opt.casm_big_total; bjob.no_big = no_big;
+        bjob.stream = q;
+        if (!cb.ev_in) RV_HIP(hipEventCreateWithFlags(&cb.ev_in, hipEventDisableTiming));
+        bjob.ready = cb.ev_in;
+        RV_HIP(hipEventRecord(cb.ev_in, q));
+        batch_join(h->batch, &bjob, ws);
+        joint = bjob.ok;
+        if (joint) {
+            RV_HIP(hipStreamWaitEvent(q, h->batch->ev_done, 0));
+            t = h->batch->t;      // (the sub-indices of every job of the batch: this job's are named by the ids it was handed)
+            memset(hc, 0, sizeof hc);
+            hc[C_LEVELS] = bjob.levels; hc[C_NCHILD] = bjob.nchild; hc[C_NUND] = (u32)bjob.und_id.size(); hc[C_NANCH] = bjob.na;
+            hc[C_STEPS] = bjob.steps; hc[C_MAXDEPTH] = bjob.maxdepth; hc[C_MAXN] = bjob.maxn;
+        }
+    }
+    if (!joint) {
     // (RV_CASCADE_PRIO=1: the level loop -- ~120 launches of a few microseconds each, a host round trip every eighth level -- runs on a stream of the highest
     //  priority, fenced by events against the handle's own; restored before the function returns on any path)
     struct PrioScope {
@@ -1049,14 +1392,6 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     RV_LAUNCH_CHECK();
     const unsigned agrid = (unsigned)(ceil_div((int64_t)M, TB) + ceil_div((int64_t)NW, TB));
     const int batch = std::max(1, (int)ws.opt.cascade_batch);
-    // undecided sub-indices of up to big_min ranks are rebuilt by a workgroup in LDS, larger ones through global memory (RV_CASM_BIG_MIN: the test hook
-    // that sends smaller ones there, too; RV_CASM_NO_BIG=1: the cascade gives up on them as it did up to round 4)
-    const bool no_big = ws.opt.casm_no_big != 0;
-    const int64_t big_min = (!no_big && ws.opt.casm_big_min >= 0 && ws.opt.casm_big_min < BN) ? ws.opt.casm_big_min : BN;
-    auto too_big = [&](const u32 *c) {
-        unsigned long long tot; memcpy(&tot, c + C_BIGTOT, 8);
-        return no_big ? c[C_MAXN] > (u32)BN : ((int64_t)c[C_MAXN] > ws.opt.casm_big_root || (int64_t)tot > ws.opt.casm_big_total);
-    };
     int queued = 0;
     for (;;) {
         for (int b = 0; b < batch; b++, queued++) {
@@ -1077,10 +1412,11 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         if (queued > 1000000) { rv_set_error("cascade (multi): no progress"); return -1; }
     }
     prio.leave(); q = ws.stream;
+    }      // (!joint)
     out->levels = (int)hc[C_LEVELS]; out->children = hc[C_NCHILD];
     const u32 U = hc[C_NUND], NA = hc[C_NANCH];
     out->undecided = U;
-    if (too_big(hc)) {
+    if (joint ? bjob.too_big : too_big(hc)) {
         out->why = "an undecided sub-index above the size that is rebuilt from the text";
         if (verbose) fprintf(stderr, "cascade (%d samples): gave up: %s (%u ranks; %u levels, %u sub-indices, %u undecided)\n", k, out->why, hc[C_MAXN], hc[C_LEVELS], hc[C_NCHILD], U);
         return 0;
@@ -1095,6 +1431,20 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
     const size_t rowbytes = (size_t)U * 8 + (size_t)U * k * sizeof(sa_t) * 2;
     RV_TRY(cb.hstage.reserve(b_rows + rowbytes + 64));
     uint8_t *hs = cb.hstage.as<uint8_t>();
+    // (a job of a batch: its anchors are a stretch of the group's arrays, its text has been lower-cased and its rows are on the host already)
+    const u32 *d_anl = joint ? bjob.d_anl : (const u32 *)banl.as<u32>();
+    const sa_t *d_anp = joint ? bjob.d_anp : (const sa_t *)banp.as<sa_t>();
+    if (joint) {
+        if (NA) {
+            RV_HIP(hipMemcpyAsync(hs + b_anl, d_anl, (size_t)NA * 4, hipMemcpyDeviceToHost, q));
+            RV_HIP(hipMemcpyAsync(hs + b_anp, d_anp, (size_t)NA * k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
+        }
+        if (U) {
+            uint8_t *hr = hs + b_rows;
+            memcpy(hr, bjob.und_id.data(), (size_t)U * 4); memcpy(hr + (size_t)U * 4, bjob.und_dep.data(), (size_t)U * 4);
+            memcpy(hr + (size_t)U * 8, bjob.und_b.data(), (size_t)U * k * sizeof(sa_t)); memcpy(hr + (size_t)U * 8 + (size_t)U * k * sizeof(sa_t), bjob.und_e.data(), (size_t)U * k * sizeof(sa_t));
+        }
+    } else {
     if (NA) {
         RV_HIP(hipMemcpyAsync(hs + b_anl, banl.p, (size_t)NA * 4, hipMemcpyDeviceToHost, q));
         RV_HIP(hipMemcpyAsync(hs + b_anp, banp.p, (size_t)NA * k * sizeof(sa_t), hipMemcpyDeviceToHost, q));
@@ -1112,6 +1462,7 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
         RV_LAUNCH_CHECK();
         RV_HIP(hipMemcpyAsync(hs + b_rows, brows.p, rowbytes, hipMemcpyDeviceToHost, q));
     }
+    }      // (!joint)
     if (NA || U) RV_HIP(hipStreamSynchronize(q));
     // ---- undecided sub-indices: arrays from their text, bookkeeping for the level pipeline
     if (U) {
@@ -1200,10 +1551,10 @@ int rv_cascade_multi_run(rv_index *h, RvCascadeBufs &cb, int minl_in, RvCascadeM
             if (berr) {      // (a tie group above BIG_GROUP: nothing of this run stays -- the anchors' text goes back to what it was)
                 if (NA) {
                     RV_TRY(bcl0.reserve((size_t)NA * k * 4));      // (the candidates' lengths: long gathered into the sorted list)
-                    hipLaunchKernelGGL(k_casm_expand_l, dim3((unsigned)ceil_div((int64_t)NA * k, TB)), dim3(TB), 0, q, (const u32 *)banl.as<u32>(), NA, k, bcl0.as<u32>());
+                    hipLaunchKernelGGL(k_casm_expand_l, dim3((unsigned)ceil_div((int64_t)NA * k, TB)), dim3(TB), 0, q, d_anl, NA, k, bcl0.as<u32>());
                     RV_LAUNCH_CHECK();
                     hipLaunchKernelGGL(k_casm_unlower, dim3((unsigned)ceil_div((int64_t)NA * k * 64, TB)), dim3(TB), 0, q, h->dT.as<uint8_t>(), (const uint8_t *)h->dT0.as<uint8_t>(),
-                                       (const u32 *)bcl0.as<u32>(), (const sa_t *)banp.as<sa_t>(), NA * (u32)k);
+                                       (const u32 *)bcl0.as<u32>(), d_anp, NA * (u32)k);
                     RV_LAUNCH_CHECK();
                     RV_HIP(hipStreamSynchronize(q));
                 }

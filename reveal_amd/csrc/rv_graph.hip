@@ -191,7 +191,6 @@ struct rv_graph {
             GNode &n = nodes[i];
             for (int &e : n.succ) e = emap[(size_t)e];
             for (int &e : n.pred) e = emap[(size_t)e];
-            n.off.shrink_to_fit(); n.succ.shrink_to_fit(); n.pred.shrink_to_fit();
             n2.push_back(std::move(n));
         }
         std::vector<GEdge> e2; e2.reserve(ne);

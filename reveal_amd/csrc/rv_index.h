@@ -145,6 +145,8 @@ struct rv_index {
     std::vector<u32> mm_l; std::vector<int32_t> mm_n; std::vector<int64_t> mm_off, mm_pos; std::vector<uint16_t> mm_so;
     // ---- recursion state (rv_align.hip)
     struct Align *al = nullptr;
+    struct RvBatchGroup *batch = nullptr;      // rv_batch_run: the group this handle's job meets in the middle of its anchor cascade (rv_cascade_multi.hip)
+    bool batch_settled = false;                // ... it has arrived there, or has let the group know that it will not
     // ---- where the built-in run delivers its anchors (rv_set_result_buffers): the caller's arrays, page-locked while they are set
     struct ResultBufs {
         uint32_t *l = nullptr; int64_t *off = nullptr, *pos = nullptr;

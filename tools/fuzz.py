@@ -43,6 +43,8 @@ ENVS = [
     {"RV_NO_FAR_TWINS": "1"},                             # ties beyond the text round: doubling rounds for partners, too (round 5)
     {"RV_NO_SLOW_CLASS": "1"},                            # ... every tied entry through every doubling round
     {"RV_NO_LCP_LIST": "1", "RV_NO_TEXT_JUMP": "1"},      # ... and the whole index through rv_build_lcp after them
+    {"RV_SCAN_V1": "1"},                                  # round 5's staged multi-sample scans (k_casm_scan, k_multi_pick1) instead of k_full_scan
+    {"RV_PICK_THREADS": "1"},                             # (no effect on the built-in picker: the switch must at least be accepted)
 ]
 
 

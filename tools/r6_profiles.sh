@@ -32,3 +32,17 @@ for f in ("bench_c2", "bench_c3", "bench_c4", "bench_c5_level0"):
     except Exception as e:
         print(f, "failed", e)
 P
+python -m pytest tests -m gpu -q > $O/gputest.txt 2>&1; tail -3 $O/gputest.txt
+python tools/time_native.py > $O/time_native.txt 2>&1; tail -2 $O/time_native.txt | cut -c1-300
+python bench.py --config stream --pairs 20 --steps 1 --warmup 1 > $O/bench_stream.json 2> $O/bench_stream.err
+python tools/scan_probe.py 250000000 5000000 > $O/scan_probe_pair.txt 2>&1; python tools/scan_probe.py --multi 10 5000000 > $O/scan_probe_multi.txt 2>&1; cat $O/scan_probe_pair.txt $O/scan_probe_multi.txt | cut -c1-200
+python bench.py --config c5 --batch 20 --steps 3 --warmup 1 --no-cpu > $O/bench_c5_level0_batched.json 2> $O/bench_c5b.err
+python - <<'P'
+import json
+for f in ("bench_stream", "bench_c5_level0_batched"):
+    try:
+        d = json.loads(open("gpurun_out/r6prof/%s.json" % f).read().strip().splitlines()[-1])
+        print(f, round(d["ms_per_step"], 2), round(d["value"]))
+    except Exception as e:
+        print(f, "failed", e)
+P

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 6: the records under profiles/ -- kernel statistics and PMC traffic of the two judged scans, bench lines of C2 / C3 / C4 / C5 level 0
+# the records under profiles/ of a round (round 6 as committed): bash tools/round_profiles.sh -- -- kernel statistics and PMC traffic of the two judged scans, bench lines of C2 / C3 / C4 / C5 level 0
 O=gpurun_out/r6prof; mkdir -p $O
 R=$PWD
 pmc() {   # name kernel workload bench-args...

@@ -350,6 +350,32 @@ int rv_pick_chain(const rv_picker_args *args, int nsub, int64_t m, const uint32_
  * (ptr arrays one longer than their count) of the nodes' (path id, offset) entries, of their links forwards and backwards as (neighbour's number,
  * edge number), and of the edges' path ids.  rv_graph_error: NULL, or why the replay stopped (an anchor outside every node). */
 typedef struct rv_graph rv_graph;
+/* ---- graphs as INPUTS (the levels 1 and 2 of `reveal align --order=sequential`: `reveal rem` of GFA files, reveal/utils.py:377-677) ----------------------------
+ * rv_graph_import: the graph the readers made (reveal_amd/alngraph.py read_gfa / read_fasta), in its dictionary order: nodes (b, e, aligned; sentinels: aligned = -1,
+ * sent = 1 start / 2 end), their (path id, offset) entries as CSR, the links forwards node by node (edge_u / edge_v, path ids as CSR), every node's links backwards as
+ * edge numbers in dictionary order, per path: a '*' name? / its length; the start sentinels in the readers' order; literal_segments = alngraph.check_segment_shortcut said no.
+ * Forward-strand links only.
+ * rv_graph_pick = schemes.graphmumpicker's not-precomputed branch (schemes.py:197-361) for one sub-index of such an alignment (arguments as rv_pick_chain; left / right =
+ * the sub-index' left / right graph node as (begin, end), begin < 0: None); rv_graph_align = rem.graphalign (rem.py:318-382): the nodes under the match are broken and
+ * merged, the graph walked around the merged node (segmentgraph, rem.py:228-316); counts[0..3] = leading / trailing / matching / rest intervals (rv_graph_align_fetch
+ * hands them out back to back as (begin, end) pairs), out6 = merged node, new left node, new right node.  rv_set_graph_picker(h, g, args) makes rv_align_builtin call the
+ * two per sub-index (picker kind 2): `reveal rem a.gfa b.gfa` with no Python call per sub-index. */
+rv_graph *rv_graph_import(int64_t nnodes, const int64_t *node_b, const int64_t *node_e, const int8_t *node_aligned, const int8_t *node_sent,
+                          const int64_t *off_ptr, const int32_t *off_sid, const int64_t *off_val,
+                          int64_t nedges, const int32_t *edge_u, const int32_t *edge_v, const int64_t *edge_ptr, const int32_t *edge_paths,
+                          const int64_t *pred_ptr, const int32_t *pred_edge, int npaths, const uint8_t *star, const int64_t *id2end,
+                          int nstart, const int32_t *start_nodes, int literal_segments);
+int rv_graph_pick(rv_graph *g, const rv_picker_args *args, int nsub, int64_t m, const uint32_t *l, const int32_t *n, const int64_t *off, const uint16_t *so, const int64_t *pos,
+                  const int64_t *left, const int64_t *right, int minlength, rv_picker_out *out);
+int rv_graph_align(rv_graph *g, const int64_t *nodes, int64_t nn, const int64_t *left, const int64_t *right, uint32_t l, const int64_t *pos, int npos,
+                   int64_t *counts, int64_t *out6);
+int rv_graph_align_fetch(rv_graph *g, int64_t *out);
+/* Picker kind 2 of the built-in recursion (rv_align_builtin*): both callbacks inside the library, on the caller's graph of the inputs (rv_graph_import).  Per
+ * sub-index, in the reference's order: rv_graph_pick on its match list (or the middle of the list its parent seeded), rv_graph_align for the choice; the children
+ * get their left / right nodes as reveal.c:884-950 hands them on.  The graph is the alignment graph when the run returns (rv_graph_finish, then _prune / _gfa /
+ * _export); it stays the caller's.  g = NULL turns the picker off.  Not combined with construct(rc=1), tracing or the frontier hand-off. */
+int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args);
+int rv_graph_finish(rv_graph *g);      /* renumber live nodes and links (after rv_graph_align, before rv_graph_sizes / rv_graph_export) */
 rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos);
 const char *rv_graph_error(const rv_graph *g);
 int rv_graph_sizes(const rv_graph *g, int64_t *out);

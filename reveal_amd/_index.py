@@ -587,6 +587,23 @@ def make_index_type(sa64, error):
             if r != 0:
                 self._fail()
 
+        def set_graph_picker(self, graph=None, args=None):
+            """graph inputs (rv_set_graph_picker): `graph` = an alngraph.LoopGraph of the inputs made with this index' library; picker and graphalign of
+            `reveal rem` run inside align_builtin on it, and it is the alignment graph afterwards.  None = off."""
+            from . import schemes
+            if graph is None:
+                r = self._dll.rv_set_graph_picker(self._h, None, None)
+            else:
+                if args.maxsize is not None or args.maxdepth is not None:
+                    raise error("the native picker does not take --maxbubblesize / maxdepth")
+                if graph._dll is not self._dll:
+                    raise error("the graph was made by the other build of the library (32 / 64-bit suffix arrays)")
+                A = schemes._RvPickerArgs(int(args.wscore), int(args.wpen), int(args.maxmums or 0), int(args.seedsize or 0), schemes.GCMODELS[args.gcmodel],
+                                          1 if args.trim else 0, float(args.pcutoff))
+                r = self._dll.rv_set_graph_picker(self._h, graph._g, ctypes.byref(A))
+            if r != 0:
+                self._fail()
+
         def picker_info(self):
             o = (ctypes.c_int64 * 5)()
             self._dll.rv_picker_info(self._h, o)

@@ -131,6 +131,12 @@ SYMBOLS = {
     "rv_set_picker": (_I, [V, _I, V]),
     "rv_picker_info": (_I, [V, c_i64p]),
     "rv_pick_chain": (_I, [V, _I, _L, V, V, V, V, V, _I, V, V, V, _I, V]),
+    "rv_graph_import": (V, [_L, V, V, V, V, V, V, V, _L, V, V, V, V, V, V, _I, V, V, _I, V, _I]),
+    "rv_graph_pick": (_I, [V, V, _I, _L, V, V, V, V, V, V, V, _I, V]),
+    "rv_graph_align": (_I, [V, V, _L, V, V, ctypes.c_uint32, V, _I, V, V]),
+    "rv_graph_align_fetch": (_I, [V, V]),
+    "rv_graph_finish": (_I, [V]),
+    "rv_set_graph_picker": (_I, [V, V, V]),
     "rv_graph_replay": (V, [_I, V, V, _L, V, V, V]),
     "rv_graph_error": (ctypes.c_char_p, [V]),
     "rv_graph_sizes": (_I, [V, c_i64p]),

@@ -459,16 +459,8 @@ class NativeGraph:
         pptr = np.zeros(nn + 1, np.int64); pfr = np.zeros(max(ne, 1), np.int32); ped = np.zeros(max(ne, 1), np.int32)
         eptr = np.zeros(ne + 1, np.int64); epath = np.zeros(max(npth, 1), np.int32)
         dll.rv_graph_export(g, *(x.ctypes.data for x in (nb, nend, nal, optr, osid, oval, sptr, sto, sed, pptr, pfr, ped, eptr, epath)))
-        # sentinels keep their names: (sample, 0 / 1) -> the reader's start / end node of that sequence
-        sid_of = {}
-        for st in G.startnodes:
-            (sid,) = G.offsets[st].keys(); sid_of[(sid, 0)] = st
-        for en in G.endnodes:
-            (sid,) = G.offsets[en].keys(); sid_of[(sid, 1)] = en
-        if sorted(q for q, _ in sid_of) != sorted(list(range(k)) * 2):
-            raise ValueError("NativeGraph: path ids are not the samples 0..k-1")
         nbl, nel, nall = nb.tolist(), nend.tolist(), nal.tolist()
-        names = [(sid_of[(b, e)] if al < 0 else (b, e)) for b, e, al in zip(nbl, nel, nall)]
+        names = self._node_names(G, nbl, nel, nall)
         osidl, ovall, optrl = osid.tolist(), oval.tolist(), optr.tolist()
         eptrl, epl = eptr.tolist(), epath.tolist()
         sets = [set(epl[eptrl[j]:eptrl[j + 1]]) for j in range(ne)]      # one object per edge, shared by its two directories (add_edge unites in place)
@@ -493,6 +485,207 @@ class NativeGraph:
         G._begins = _Begins(b for b, al in zip(nbl, nall) if al >= 0)
         G._end_of = {b: e for b, e, al in zip(nbl, nel, nall) if al >= 0}
         return nn
+
+
+    def _node_names(self, G, nbl, nel, nall):
+        # sentinels keep their names: (sample, 0 / 1) -> the reader's start / end node of that sequence
+        k = len(self.names)
+        sid_of = {}
+        for st in G.startnodes:
+            (sid,) = G.offsets[st].keys(); sid_of[(sid, 0)] = st
+        for en in G.endnodes:
+            (sid,) = G.offsets[en].keys(); sid_of[(sid, 1)] = en
+        if sorted(q for q, _ in sid_of) != sorted(list(range(k)) * 2):
+            raise ValueError("NativeGraph: path ids are not the samples 0..k-1")
+        return [(sid_of[(b, e)] if al < 0 else (b, e)) for b, e, al in zip(nbl, nel, nall)]
+
+
+def graph_arrays(G):
+    """the graph as the readers left it, in the arrays rv_graph_import takes (include/reveal_amd.h) -> (dict of numpy arrays, node list in dictionary order).
+    Raises ValueError for a link on the reverse strand (such inputs keep the Python callbacks)."""
+    import numpy as np
+    nodes = list(G.offsets)
+    num = {n: i for i, n in enumerate(nodes)}
+    nn = len(nodes)
+    startset, endset = set(G.startnodes), set(G.endnodes)
+    nb = np.zeros(nn, np.int64); ne = np.zeros(nn, np.int64); al = np.zeros(nn, np.int8); sent = np.zeros(nn, np.int8)
+    optr = np.zeros(nn + 1, np.int64)
+    osid, oval = [], []
+    aligned = G.aligned
+    for i, n in enumerate(nodes):
+        if isinstance(n, tuple):
+            nb[i], ne[i] = n
+            al[i] = aligned.get(n, 0)
+        else:
+            nb[i], ne[i], al[i] = i, 0, -1
+            sent[i] = 1 if n in startset else 2 if n in endset else 0
+        o = G.offsets[n]
+        osid.extend(o.keys()); oval.extend(o.values())
+        optr[i + 1] = len(osid)
+    eu, ev, eptr, epaths = [], [], [0], []
+    eid = {}
+    for n in nodes:
+        u = num[n]
+        for (v, a, b), p in G.succ[n].items():
+            if a != "+" or b != "+":
+                raise ValueError("a link on the reverse strand: %s -> %s" % (n, v))
+            eid[(u, num[v])] = len(eu)
+            eu.append(u); ev.append(num[v])
+            epaths.extend(sorted(p)); eptr.append(len(epaths))
+    pptr = np.zeros(nn + 1, np.int64)
+    pedge = []
+    for i, n in enumerate(nodes):
+        for (u, a, b) in G.pred[n]:
+            pedge.append(eid[(num[u], i)])
+        pptr[i + 1] = len(pedge)
+    npaths = len(G.paths)
+    star = np.array([1 if G.id2path[sid].startswith("*") else 0 for sid in range(npaths)], np.uint8)
+    id2end = np.array([G.id2end.get(sid, 0) for sid in range(npaths)], np.int64)
+    starts = np.array([num[x] for x in G.startnodes if x in num], np.int32)
+    arr = dict(nb=nb, ne=ne, al=al, sent=sent, optr=optr, osid=np.array(osid or [0], np.int32), oval=np.array(oval or [0], np.int64),
+               eu=np.array(eu or [0], np.int32), ev=np.array(ev or [0], np.int32), eptr=np.array(eptr, np.int64), epaths=np.array(epaths or [0], np.int32),
+               pptr=pptr, pedge=np.array(pedge or [0], np.int32), star=star, id2end=id2end, starts=starts, nedges=len(eu), npaths=npaths,
+               literal=1 if G.literal_segments else 0)
+    return arr, nodes
+
+
+class LoopGraph(NativeGraph):
+    """rv_graph behind the ABI for GRAPH inputs (include/reveal_amd.h rv_graph_import): the structure the library's own picker and graphalign work on
+    while the recursion runs (rv_set_graph_picker), made from the AlnGraph the readers left.  pick / align expose the two steps one call at a time (the tests run
+    them beside schemes.GraphPicker / rem.GraphAligner on every sub-index of whole alignments)."""
+
+    def __init__(self, G, sa64=False):
+        from . import _lib
+        self._lib = _lib.get(bool(sa64))
+        self._dll = self._lib.dll
+        self.names = list(G.paths)
+        a, self.nodes0 = graph_arrays(G)
+        p = lambda x: x.ctypes.data
+        self._g = self._dll.rv_graph_import(len(a["nb"]), p(a["nb"]), p(a["ne"]), p(a["al"]), p(a["sent"]), p(a["optr"]), p(a["osid"]), p(a["oval"]),
+                                            a["nedges"], p(a["eu"]), p(a["ev"]), p(a["eptr"]), p(a["epaths"]), p(a["pptr"]), p(a["pedge"]), a["npaths"], p(a["star"]), p(a["id2end"]),
+                                            len(a["starts"]), p(a["starts"]), a["literal"])
+        if not self._g:
+            raise RuntimeError(self._lib.err())
+        self.sentinels0 = [n for n in self.nodes0 if not isinstance(n, tuple)]
+
+    def finish(self):
+        """after the run (index.set_graph_picker + align_builtin): live nodes and links renumbered, ready for counts / prune / gfa / load_into"""
+        self._dll.rv_graph_finish(self._g)
+
+    def counts(self):
+        import ctypes
+        import numpy as np
+        sz = np.zeros(4, dtype=np.int64)
+        self._dll.rv_graph_sizes(self._g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        return int(sz[0]) - len(self.sentinels0), int(sz[2])
+
+    def _node_names(self, G, nbl, nel, nall):
+        # sentinels are neither made nor removed by the run and keep their order: the k-th one is the k-th one of the graph handed to the constructor
+        it = iter(self.sentinels0)
+        return [(next(it) if al < 0 else (b, e)) for b, e, al in zip(nbl, nel, nall)]
+
+    @staticmethod
+    def _iv(node):
+        import numpy as np
+        return np.array([-1, -1] if node is None else [node[0], node[1]], np.int64)
+
+    def pick(self, mums, nsub, leftnode, rightnode, args, minlength=20):
+        """schemes.GraphPicker.graphmumpicker(mums, idx, precomputed=False) -> () or (mum, skipleft, skipright)"""
+        import ctypes
+        import numpy as np
+        from . import schemes
+        m = len(mums)
+        members = sum(len(mm[2]) for mm in mums)
+        ln = np.ascontiguousarray([mm[0] for mm in mums], dtype=np.uint32); nn = np.ascontiguousarray([mm[1] for mm in mums], dtype=np.int32)
+        off = np.zeros(m + 1, np.int64); so = np.zeros(max(members, 1), np.uint16); pos = np.zeros(max(members, 1), np.int64)
+        w = 0
+        for i, mm in enumerate(mums):
+            for gq, pq in mm[2]:
+                so[w] = gq; pos[w] = pq; w += 1
+            off[i + 1] = w
+        ns = max((len(mm[2]) for mm in mums), default=1)
+        A = schemes._RvPickerArgs(int(args.wscore), int(args.wpen), int(args.maxmums or 0), int(args.seedsize or 0), schemes.GCMODELS[args.gcmodel], 1 if args.trim else 0, float(args.pcutoff))
+        pso = np.zeros(ns, np.uint16); ppos = np.zeros(ns, np.int64)
+        cap = max(m, 1)
+        sl = np.zeros(cap, np.uint32); sn = np.zeros(cap, np.int32); soff = np.zeros(cap + 1, np.int64)
+        sso = np.zeros(max(members, 1), np.uint16); spos = np.zeros(max(members, 1), np.int64); ssc = np.zeros(cap, np.int64); srt = np.zeros(cap, np.uint8)
+        O = schemes._RvPickerOut()
+        O.pick_so, O.pick_pos, O.member_cap = pso.ctypes.data, ppos.ctypes.data, ns
+        O.seed_cap, O.seed_member_cap = cap, max(members, 1)
+        O.seed_l, O.seed_n, O.seed_off, O.seed_so, O.seed_pos, O.seed_score, O.seed_right = (x.ctypes.data for x in (sl, sn, soff, sso, spos, ssc, srt))
+        lf, rt = self._iv(leftnode), self._iv(rightnode)
+        r = self._dll.rv_graph_pick(self._g, ctypes.byref(A), int(nsub), m, ln.ctypes.data, nn.ctypes.data, off.ctypes.data, so.ctypes.data, pos.ctypes.data,
+                                    lf.ctypes.data, rt.ctypes.data, int(minlength), ctypes.byref(O))
+        if r < 0:
+            raise RuntimeError(self._lib.err())
+        if r == 0:
+            return ()
+        pick = (int(O.pick_l), int(O.pick_n), tuple((int(pso[q]), int(ppos[q])) for q in range(O.pick_members)))
+        left, right = [], []
+        for k in range(O.nleft + O.nright):
+            mm = (int(sl[k]), int(sn[k]), tuple((int(sso[q]), int(spos[q])) for q in range(soff[k], soff[k + 1])))
+            (right if srt[k] else left).append((mm, int(ssc[k])))
+        return pick, left, right
+
+    def align(self, nodes, leftnode, rightnode, mum):
+        """rem.GraphAligner.graphalign -> (leading, trailing, matching, rest, merged, newleft, newright) with the interval collections as sorted lists"""
+        import numpy as np
+        l, n, spd = mum
+        nd = np.ascontiguousarray(sorted(nodes), dtype=np.int64).reshape(-1, 2)
+        ps = np.ascontiguousarray([p for _, p in spd], dtype=np.int64)
+        counts = np.zeros(4, np.int64); out6 = np.zeros(6, np.int64)
+        lf, rt = self._iv(leftnode), self._iv(rightnode)
+        if self._dll.rv_graph_align(self._g, nd.ctypes.data, len(nd), lf.ctypes.data, rt.ctypes.data, int(l), ps.ctypes.data, len(ps), counts.ctypes.data, out6.ctypes.data) != 0:
+            raise RuntimeError(self._lib.err())
+        buf = np.zeros(2 * max(int(counts.sum()), 1), np.int64)
+        self._dll.rv_graph_align_fetch(self._g, buf.ctypes.data)
+        ivs = [tuple(x) for x in buf[:2 * int(counts.sum())].reshape(-1, 2).tolist()]
+        c = [int(x) for x in counts]
+        lead, trail, match, rest = ivs[:c[0]], ivs[c[0]:c[0] + c[1]], ivs[c[0] + c[1]:c[0] + c[1] + c[2]], ivs[c[0] + c[1] + c[2]:]
+        node = lambda b, e: None if b < 0 else (int(b), int(e))
+        return lead, trail, match, rest, node(out6[0], out6[1]), node(out6[2], out6[3]), node(out6[4], out6[5])
+
+    def snapshot(self):
+        """-> (nodes, offsets, links): sequence nodes as (b, e, aligned), sentinels as ('s', k) in order of appearance; per node its (path, offset) list and its
+        links forwards as (target, sorted path ids), all in dictionary order"""
+        import ctypes
+        import numpy as np
+        dll, g = self._dll, self._g
+        dll.rv_graph_finish(g)
+        sz = np.zeros(4, np.int64)
+        dll.rv_graph_sizes(g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        nn, no, ne, npth = (int(x) for x in sz)
+        nb = np.zeros(nn, np.int64); nend = np.zeros(nn, np.int64); nal = np.zeros(nn, np.int8)
+        optr = np.zeros(nn + 1, np.int64); osid = np.zeros(max(no, 1), np.int32); oval = np.zeros(max(no, 1), np.int64)
+        sptr = np.zeros(nn + 1, np.int64); sto = np.zeros(max(ne, 1), np.int32); sed = np.zeros(max(ne, 1), np.int32)
+        pptr = np.zeros(nn + 1, np.int64); pfr = np.zeros(max(ne, 1), np.int32); ped = np.zeros(max(ne, 1), np.int32)
+        eptr = np.zeros(ne + 1, np.int64); epath = np.zeros(max(npth, 1), np.int32)
+        dll.rv_graph_export(g, *(x.ctypes.data for x in (nb, nend, nal, optr, osid, oval, sptr, sto, sed, pptr, pfr, ped, eptr, epath)))
+        names, ks = [], 0
+        for i in range(nn):
+            if nal[i] < 0:
+                names.append(("s", ks)); ks += 1
+            else:
+                names.append((int(nb[i]), int(nend[i]), int(nal[i])))
+        offs = [list(zip(osid[optr[i]:optr[i + 1]].tolist(), oval[optr[i]:optr[i + 1]].tolist())) for i in range(nn)]
+        links = [[(names[sto[q]], epath[eptr[sed[q]]:eptr[sed[q] + 1]].tolist()) for q in range(sptr[i], sptr[i + 1])] for i in range(nn)]
+        preds = [[names[pfr[q]] for q in range(pptr[i], pptr[i + 1])] for i in range(nn)]
+        return names, offs, links, preds
+
+
+def graph_snapshot(G):
+    """the same view of a Python AlnGraph (LoopGraph.snapshot)"""
+    names, ks = {}, 0
+    for n in G.offsets:
+        if isinstance(n, tuple):
+            names[n] = (n[0], n[1], G.aligned.get(n, 0))
+        else:
+            names[n] = ("s", ks); ks += 1
+    order = list(G.offsets)
+    offs = [list(G.offsets[n].items()) for n in order]
+    links = [[(names[v], sorted(p)) for (v, a, b), p in G.succ[n].items()] for n in order]
+    preds = [[names[u] for (u, a, b) in G.pred[n]] for n in order]
+    return [names[n] for n in order], offs, links, preds
 
 
 # ---- readers (reveal/utils.py:304-375, 377-677) -------------------------------------------------------

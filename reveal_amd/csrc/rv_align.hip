@@ -24,6 +24,7 @@ static_assert(RV_TSUB_TILE == RV_SPLIT_TILE, "one tile -> sub-index table serves
 #include <chrono>
 #include <thread>
 #include <atomic>
+#include "rv_graphrem.h"
 
 namespace {
 
@@ -154,6 +155,11 @@ struct Align {
         }
     };
     std::vector<SeedList> seeds_cur, seeds_lead, seeds_trail;
+    // rv_set_graph_picker (kind 2): graph inputs -- the picker and graphalign of `reveal rem` for graphs (rv_graphrem.hip) on the caller's rv_graph, called per
+    // sub-index in the reference's order; per sub-index of the current level its left / right graph node (rem.py:318-382: graphalign hands the children theirs)
+    rv_graph *ggraph = nullptr;
+    std::vector<RvGraphIv> g_left, g_right, g_newleft, g_newright;
+    RvGraphAlignOut g_out;
     int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0;
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
@@ -408,7 +414,19 @@ int rv_set_picker(rv_index *h, int kind, const rv_picker_args *args) {
     if (kind == 1 && (args->gcmodel < 0 || args->gcmodel > 2)) { rv_set_error("rv_set_picker: gap cost model 0 (sumofpairs), 1 (star-avg) or 2 (star-med)"); return -1; }
     if (!h->al) h->al = new Align();
     h->al->picker = kind;
+    h->al->ggraph = nullptr;
     if (kind == 1) h->al->pargs = *args;
+    return 0;
+}
+/* Picker kind 2: graph inputs.  `g` is the caller's rv_graph of the inputs (rv_graph_import) -- it stays the caller's, is changed by the run (graphalign's
+ * surgery per chosen match) and is the alignment graph afterwards (rv_graph_finish / _prune / _gfa).  g == NULL: picker off. */
+int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args) {
+    if (!h || (g && !args)) { rv_set_error("rv_set_graph_picker: bad arguments"); return -1; }
+    if (g && (args->gcmodel < 0 || args->gcmodel > 2)) { rv_set_error("rv_set_graph_picker: gap cost model 0 (sumofpairs), 1 (star-avg) or 2 (star-med)"); return -1; }
+    if (!h->al) h->al = new Align();
+    h->al->picker = g ? 2 : 0;
+    h->al->ggraph = g;
+    if (g) h->al->pargs = *args;
     return 0;
 }
 int rv_picker_info(const rv_index *h, int64_t *out) {
@@ -1560,6 +1578,11 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
         if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
         if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
     }
+    if (a->picker == 2) {
+        if (!a->ggraph) { rv_set_error("rv_set_graph_picker: no graph"); return -1; }
+        if (h->rc) { rv_set_error("the native picker (rv_set_graph_picker) with construct(rc=1) is not supported"); return -1; }
+        a->g_left.assign((size_t)a->lv.size(), RvGraphIv{-1, -1}); a->g_right.assign((size_t)a->lv.size(), RvGraphIv{-1, -1});      // (the root: no left / right node)
+    }
     const bool use_leaf = !a->multi && !h->ws.opt.no_leaf && a->picker == 0;
     a->use_leaf = use_leaf;
     // level 0 of an untraced two-sample run: ship the tables the device-side picker and decisions need (what a commit ships for
@@ -1608,7 +1631,7 @@ struct PickRes {
     double t_list = 0, t_pick = 0;
     std::string err;
 };
-static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R) {
+static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R, RvGraphIv gleft = RvGraphIv{-1, -1}, RvGraphIv gright = RvGraphIv{-1, -1}) {
     Align *a = h->al;
     const Level &lv = a->lv;
     const int W = h->nsamples, want = lv.nsamples[(size_t)s];
@@ -1635,8 +1658,8 @@ static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R) {
         }
     }
     X.pk_sb.assign((size_t)W, 0); X.pk_ib.assign((size_t)W, -1); X.pk_ie.assign((size_t)W, -1);
-    for (int q2 = 0; q2 < W; q2++) X.pk_sb[(size_t)q2] = h->nodes[(size_t)q2].begin;
-    for (size_t k = 0; k < nn; k++) {
+    if (a->picker == 1) for (int q2 = 0; q2 < W; q2++) X.pk_sb[(size_t)q2] = h->nodes[(size_t)q2].begin;
+    for (size_t k = 0; k < nn && a->picker == 1; k++) {
         const int sm = sample_of(h, nodes[k].begin);
         if (X.pk_ib[(size_t)sm] >= 0) { R.rc = -1; R.err = "the native picker takes one interval per sample and sub-index"; return; }
         X.pk_ib[(size_t)sm] = nodes[k].begin; X.pk_ie[(size_t)sm] = nodes[k].end;
@@ -1651,8 +1674,10 @@ static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R) {
     po.seed_l = X.pk_sl.data(); po.seed_n = X.pk_sn.data(); po.seed_off = X.pk_soff.data(); po.seed_so = X.pk_sso.data(); po.seed_pos = X.pk_spos.data();
     po.seed_score = X.pk_ssc.data(); po.seed_right = X.pk_srt.data();
     const double tp1 = now_s();
-    const int pr = rv_pick_chain(&a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), W,
-                                 X.pk_sb.data(), X.pk_ib.data(), X.pk_ie.data(), a->minl, &po);
+    const int pr = a->picker == 2
+        ? rv_graph_do_pick(a->ggraph, &a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), gleft, gright, a->minl, &po)
+        : rv_pick_chain(&a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), W,
+                        X.pk_sb.data(), X.pk_ib.data(), X.pk_ie.data(), a->minl, &po);
     R.t_pick = now_s() - tp1; R.t_list = tp1 - tp0;
     R.rc = pr;
     if (pr < 0) { R.err = rv_last_error(); return; }      // (the error text is this thread's: the caller sets it again on its own)
@@ -1710,7 +1735,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
     std::vector<RvIntv> lead, trail, match, rest;
     std::vector<uint8_t> touched;
     std::vector<int64_t> pk_pos; std::vector<uint16_t> pk_so;
-    std::vector<PickRes> pres;
+    std::vector<PickRes> pres; PickScratch gpx;
     const bool use_leaf = a->use_leaf;
     hipStream_t q = h->ws.stream;
     int &leaf_flip = a->leaf_flip;
@@ -1772,6 +1797,14 @@ static int builtin_levels(rv_index *h, int stop_subs) {
         a->st.levels++;
         const int ns = lv.size();
         if (a->picker == 1) pick_level(h, pres);
+        if (a->picker == 2) {
+            // graph inputs: a pick reads node offsets graphalign's surgery of the calls before it may have set, so the calls are made here, one sub-index after the
+            // other in the reference's order (pick, then graphalign)
+            a->seeds_lead.assign((size_t)ns, Align::SeedList()); a->seeds_trail.assign((size_t)ns, Align::SeedList());
+            a->g_newleft.assign((size_t)ns, RvGraphIv{-1, -1}); a->g_newright.assign((size_t)ns, RvGraphIv{-1, -1});
+            if ((int)a->g_left.size() != ns || (int)a->g_right.size() != ns) { rv_set_error("graph picker: the level's left / right nodes are missing"); return -1; }
+            pres.assign(1, PickRes());
+        }
         for (int s = 0; s < ns; s++) {
             if (use_leaf && a->leaf_done[(size_t)s]) continue;         // finished (with its whole sub-tree) by the leaf kernel
             a->st.steps++;
@@ -1801,8 +1834,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             // picker: longest match present in every sample of the sub-index, ties -> smallest minimum coordinate
             int64_t best = -1, bmin = 0; u32 bl = 0;
             const int want = lv.nsamples[(size_t)s];
-            bool chain_pick = false;
-            if (a->picker == 1) {
+            bool chain_pick = false; int pk_members = 0;
+            if (a->picker != 0) {
                 // the reference's default picker (schemes.py:197-361) in C++: rv_pick_chain on the sub-index' whole list (pick_level, above) -- or, for a
                 // sub-index its parent seeded, the middle of that list (schemes.py:349-354) and its two halves for the children
                 const int W = h->nsamples;
@@ -1823,7 +1856,8 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     }
                     chain_pick = true;
                 } else if (cnt > 0) {
-                    const PickRes &R = pres[(size_t)s];
+                    if (a->picker == 2) { pres[0] = PickRes(); pick_one(h, s, gpx, pres[0], a->g_left[(size_t)s], a->g_right[(size_t)s]); }
+                    const PickRes &R = pres[a->picker == 2 ? 0 : (size_t)s];
                     a->picker_ns += (int64_t)(R.t_pick * 1e9); a->picker_list_ns += (int64_t)(R.t_list * 1e9);
                     if (R.rc == -9) { rv_set_error("the native picker was not run for sub-index %d", s); return -1; }
                     if (R.rc < 0) { rv_set_error("%s", R.err.c_str()); return -1; }
@@ -1832,7 +1866,7 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                         for (int q2 = 0; q2 < members; q2++) { pk_so[(size_t)q2] = R.so[(size_t)q2]; pk_pos[(size_t)q2] = R.pos[(size_t)q2]; }
                     }
                 }
-                if (chain_pick) { sp.assign(pk_pos.begin(), pk_pos.begin() + members); best = 0; }
+                if (chain_pick) { sp.assign(pk_pos.begin(), pk_pos.begin() + members); best = 0; pk_members = members; }
             } else
             if (!a->multi) {
                 if (want == 2)
@@ -1855,6 +1889,17 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                 else if (!a->multi) { sp.clear(); sp.push_back((int64_t)a->recs[(size_t)best].a); sp.push_back((int64_t)a->recs[(size_t)best].b); }
                 else sp.assign(a->mpos.begin() + a->moff[(size_t)best], a->mpos.begin() + a->moff[(size_t)best + 1]);
                 std::sort(sp.begin(), sp.end());
+                if (a->picker == 2) {
+                    // graphalign on the graph (rem.py:318-382): break the nodes that hold the members, merge the matched pieces, find the children's intervals
+                    // by walking the graph around the merged node
+                    RvGraphAlignOut &GO = a->g_out;
+                    static_assert(sizeof(RvGraphIv) == sizeof(RvIntv), "interval layouts");
+                    RV_TRY(rv_graph_do_align(a->ggraph, (const RvGraphIv *)nodes, nn, a->g_left[(size_t)s], a->g_right[(size_t)s], bl, pk_pos.data(), (int)sp.size(), GO));
+                    a->g_newleft[(size_t)s] = GO.newleft; a->g_newright[(size_t)s] = GO.newright;
+                    auto cp = [](std::vector<RvIntv> &d, const std::vector<RvGraphIv> &v) { for (const RvGraphIv &x : v) d.push_back({x.b, x.e}); };
+                    cp(lead, GO.lead); cp(trail, GO.trail); cp(match, GO.match); cp(rest, GO.rest);
+                    sp.erase(std::unique(sp.begin(), sp.end()), sp.end());
+                } else {
                 touched.assign(nn, 0);
                 for (int64_t p : sp) {
                     size_t lo = 0, hi = nn;
@@ -1867,10 +1912,11 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     match.push_back({p, p + (int64_t)bl});
                 }
                 for (size_t k = 0; k < nn; k++) if (!touched[k]) rest.push_back(nodes[k]);
+                }
                 RV_TRY(add_decision(h, s, bl, sp.data(), (int)sp.size(), lead.data(), (int)lead.size(), trail.data(), (int)trail.size(),
                                     match.data(), (int)match.size(), rest.data(), (int)rest.size()));
                 a->an_l.push_back(bl);
-                if (chain_pick) a->an_pos.insert(a->an_pos.end(), pk_pos.begin(), pk_pos.begin() + (ptrdiff_t)sp.size());      // (the picker's member order: graphalign merges the nodes in it)
+                if (chain_pick) a->an_pos.insert(a->an_pos.end(), pk_pos.begin(), pk_pos.begin() + (ptrdiff_t)pk_members);      // (the picker's member order: graphalign merges the nodes in it)
                 else
                 a->an_pos.insert(a->an_pos.end(), sp.begin(), sp.end());
                 a->an_off.push_back((int64_t)a->an_pos.size());
@@ -1882,7 +1928,19 @@ static int builtin_levels(rv_index *h, int stop_subs) {
         a->st.t_host += now_s() - t0;
         const double tl1 = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_commit(h, nullptr));
-        if (a->picker == 1) {
+        if (a->picker == 2) {
+            // the children's left / right graph nodes (reveal.c:884-950: leading (parent's left, newright), trailing (newleft, parent's right), the others the parent's)
+            const int nn2 = a->lv.size();
+            std::vector<RvGraphIv> gl((size_t)nn2, RvGraphIv{-1, -1}), gr((size_t)nn2, RvGraphIv{-1, -1});
+            for (int s2 = 0; s2 < nn2; s2++) {
+                const int p = a->lv.parent[(size_t)s2], kd = a->lv.kind[(size_t)s2];
+                if (p < 0 || p >= (int)a->g_left.size()) continue;
+                gl[(size_t)s2] = kd == 2 ? a->g_newleft[(size_t)p] : a->g_left[(size_t)p];
+                gr[(size_t)s2] = kd == 1 ? a->g_newright[(size_t)p] : a->g_right[(size_t)p];
+            }
+            a->g_left.swap(gl); a->g_right.swap(gr);
+        }
+        if (a->picker != 0) {
             // a child whose parent left it a list is not scanned (reveal.c:802, 830-837): its picker call takes the list's middle
             const int nn2 = a->lv.size();
             std::vector<Align::SeedList> nxt((size_t)nn2);
@@ -2160,6 +2218,7 @@ int rv_frontier_counts(rv_index *h, int64_t *out) {
 /* meta: 6 numbers per sub-index (off, n, depth, nsamples, kind, parent); node_first: nsubs+1; nodes: (begin, end) pairs */
 int rv_frontier_export(rv_index *h, int64_t *meta, int64_t *node_first, int64_t *nodes) {
     RV_TRY(need_align(h));
+    if (h->al->picker == 2) { rv_set_error("rv_frontier_export: a run on a graph (rv_set_graph_picker) is not handed off -- its sub-indices share the graph"); return -1; }
     const Level &lv = h->al->lv;
     for (int s = 0; s < lv.size(); s++) {
         int64_t *m6 = meta + 6 * (size_t)s;
@@ -2286,6 +2345,7 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
         a->full_only = !a->trace_on && a->picker == 0;      // (as builtin_setup: the chain picker wants every match of a sub-index)
+        if (a->picker == 2) { rv_set_error("rv_frontier_import: a run on a graph (rv_set_graph_picker) is not handed off -- its sub-indices share the graph"); return -1; }
         if (a->picker == 1) {
             if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
             if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }

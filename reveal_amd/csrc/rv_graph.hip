@@ -9,204 +9,10 @@
 //
 // Scope: the native picker's -- FASTA inputs, one sequence per sample (path id = sample), every edge on the forward strand.
 // Test infrastructure compares it with the Python surgery node for node and edge for edge (tests/test_cpu_graph_native.py).
-#include "../../include/reveal_amd.h"
-#include <algorithm>
-#include <cstdint>
-#include <cstdio>
-#include <cstring>
-#include <deque>
-#include <exception>
-#include <map>
-#include <memory>
-#include <string>
-#include <vector>
+#include "rv_graph.h"
 
-void rv_set_error(const char *fmt, ...);      // rv_api.hip
-
-namespace {
-
-struct GNode {
-    int64_t b, e;                                   // text interval; sentinels: b = sample, e = 0 (start) / 1 (end)
-    int8_t aligned;                                 // -1: sentinel
-    bool alive;
-    uint64_t order;                                 // position in the graph's node dictionary (creation order)
-    std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
-    std::vector<int> succ, pred;                    // edge ids, in dictionary order
-};
-// The path ids an edge carries.  A graph of up to 64 paths keeps them as one word (uniting two sets, and asking for a member, cost an
-// instruction instead of an allocation: anchors' surgery spent most of its time in malloc); more paths: a sorted vector as before.
-struct PathSet {
-    uint64_t m = 0;
-    std::vector<int> v;        // used when `big`
-    bool big = false;
-    PathSet() = default;
-    explicit PathSet(const std::vector<int> &ids) { for (int p : ids) add(p); }
-    void add(int p) {
-        if (!big && p >= 0 && p < 64) { m |= 1ull << p; return; }
-        grow();
-        auto it = std::lower_bound(v.begin(), v.end(), p);
-        if (it == v.end() || *it != p) v.insert(it, p);
-    }
-    void grow() {
-        if (big) return;
-        big = true;
-        for (int q = 0; q < 64; q++) if ((m >> q) & 1ull) v.push_back(q);
-        m = 0;
-    }
-    void unite(const PathSet &o) {
-        if (!big && !o.big) { m |= o.m; return; }
-        grow();
-        if (o.big) { std::vector<int> r; r.reserve(v.size() + o.v.size()); std::set_union(v.begin(), v.end(), o.v.begin(), o.v.end(), std::back_inserter(r)); v.swap(r); }
-        else for (int q = 0; q < 64; q++) if ((o.m >> q) & 1ull) add(q);
-    }
-    bool has(int p) const { return big ? std::binary_search(v.begin(), v.end(), p) : (p >= 0 && p < 64 && ((m >> p) & 1ull)); }
-    size_t size() const { return big ? v.size() : (size_t)__builtin_popcountll(m); }
-    template <class F> void each(F f) const {      // ascending
-        if (big) { for (int p : v) f(p); return; }
-        for (uint64_t x = m; x; x &= x - 1) f(__builtin_ctzll(x));
-    }
-};
-struct GEdge { int u, v; PathSet paths; };
-
-}  // namespace
-
-struct rv_graph {
-    std::vector<GNode> nodes;
-    std::vector<GEdge> edges;
-    std::map<int64_t, int> at;                      // begin -> node, sequence nodes that are alive
-    uint64_t counter = 0;
-    std::vector<int> order;                         // export: alive nodes in dictionary order
-    std::vector<int> edge_no;                       // export: edge id -> dense number (-1: dead)
-    std::string err, gfa;
-    int nseq = 0;
-    std::vector<std::pair<int, PathSet>> in_tmp, out_tmp;      // scratch of breaknode / mergenodes: a node's links while it is taken apart
-    std::vector<int> start_of;                      // the start sentinel of every sequence, in the reader's order
-
-    int new_node(int64_t b, int64_t e, int8_t aligned) {
-        GNode n;
-        n.b = b; n.e = e; n.aligned = aligned; n.alive = true; n.order = counter++;
-        nodes.push_back(std::move(n));
-        const int id = (int)nodes.size() - 1;
-        if (aligned >= 0) at[b] = id;
-        return id;
-    }
-    // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
-    void add_edge(int u, int v, const PathSet &paths) {
-        for (int e : nodes[(size_t)u].succ)
-            if (edges[(size_t)e].v == v) { edges[(size_t)e].paths.unite(paths); return; }
-        edges.push_back({u, v, paths});
-        const int e = (int)edges.size() - 1;
-        nodes[(size_t)u].succ.push_back(e);
-        nodes[(size_t)v].pred.push_back(e);
-    }
-    void remove_node(int x) {
-        GNode &n = nodes[(size_t)x];
-        for (int e : n.succ) { auto &p = nodes[(size_t)edges[(size_t)e].v].pred; p.erase(std::find(p.begin(), p.end(), e)); edges[(size_t)e].u = -1; }
-        for (int e : n.pred) { auto &s = nodes[(size_t)edges[(size_t)e].u].succ; s.erase(std::find(s.begin(), s.end(), e)); edges[(size_t)e].u = -1; }
-        n.succ.clear(); n.pred.clear(); n.off.clear(); n.alive = false;
-        auto it = at.find(n.b);
-        if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
-    }
-    int node_at(int64_t pos) {
-        auto it = at.upper_bound(pos);
-        if (it == at.begin()) return -1;
-        --it;
-        const GNode &n = nodes[(size_t)it->second];
-        return (n.alive && pos < n.e) ? it->second : -1;
-    }
-    // rem.py:14-131 for a node every path crosses forwards
-    int breaknode(int x, int64_t pos, int64_t l) {
-        const int64_t nb = nodes[(size_t)x].b, ne = nodes[(size_t)x].e;
-        if (nb == pos && ne == pos + l) return x;
-        const std::vector<std::pair<int, int64_t>> att = std::move(nodes[(size_t)x].off);      // (the node is about to go)
-        in_tmp.clear(); out_tmp.clear();
-        for (int e : nodes[(size_t)x].pred) in_tmp.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
-        for (int e : nodes[(size_t)x].succ) out_tmp.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
-        const size_t n_in = in_tmp.size(), n_out = out_tmp.size();
-        PathSet pospaths;
-        if (n_in == 0 && n_out == 0) {
-            for (auto &a : att) pospaths.add(a.first);
-        } else {
-            for (size_t k = 0; k < n_in; k++) pospaths.unite(in_tmp[k].second);
-            for (size_t k = 0; k < n_out; k++) pospaths.unite(out_tmp[k].second);
-        }
-        // (the old node leaves the position map first: the match or prefix node shares its begin)
-        { auto it = at.find(nb); if (it != at.end() && it->second == x) at.erase(it); }
-        const int mn = new_node(pos, pos + l, 0);
-        nodes[(size_t)mn].off.reserve(att.size());
-        for (auto &a : att) nodes[(size_t)mn].off.push_back({a.first, a.second + (pos - nb)});
-        int pn = mn, sn = mn;
-        if (nb != pos) {
-            pn = new_node(nb, pos, 0);
-            nodes[(size_t)pn].off = att;
-            add_edge(pn, mn, pospaths);
-        }
-        if (ne != pos + l) {
-            sn = new_node(pos + l, ne, 0);
-            nodes[(size_t)sn].off.reserve(att.size());
-            for (auto &a : att) nodes[(size_t)sn].off.push_back({a.first, a.second + (pos + l - nb)});
-            add_edge(mn, sn, pospaths);
-        }
-        remove_node(x);
-        for (size_t k = 0; k < n_in; k++) add_edge(in_tmp[k].first, pn, in_tmp[k].second);
-        for (size_t k = 0; k < n_out; k++) add_edge(sn, out_tmp[k].first, out_tmp[k].second);
-        return mn;
-    }
-    // rem.py:133-200: the first node absorbs the others
-    int mergenodes(const std::vector<int> &mns) {
-        const int ref = mns[0];
-        std::vector<std::pair<int, int64_t>> merged;
-        for (int x : mns)
-            for (auto &a : nodes[(size_t)x].off) {
-                bool found = false;
-                for (auto &m : merged) if (m.first == a.first) { m.second = a.second; found = true; break; }
-                if (!found) merged.push_back(a);
-            }
-        nodes[(size_t)ref].off = merged;
-        nodes[(size_t)ref].aligned = 1;
-        for (size_t k = 1; k < mns.size(); k++) {
-            const int x = mns[k];
-            if (x == ref) continue;
-            in_tmp.clear(); out_tmp.clear();
-            for (int e : nodes[(size_t)x].pred) in_tmp.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
-            for (int e : nodes[(size_t)x].succ) out_tmp.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
-            for (size_t k2 = 0; k2 < in_tmp.size(); k2++) add_edge(in_tmp[k2].first, ref, in_tmp[k2].second);
-            for (size_t k2 = 0; k2 < out_tmp.size(); k2++) add_edge(ref, out_tmp[k2].first, out_tmp[k2].second);
-            remove_node(x);
-        }
-        return ref;
-    }
-    // The surgery leaves three dead nodes for every live one (a broken node stays in the array): prune_nodes and the writer then walk a structure four
-    // times the size it needs to be, a cache miss per step.  Live nodes and edges move together, in their old order (a node's number IS its place in the
-    // dictionary), ids are renamed.
-    void compact() {
-        std::vector<int> nmap(nodes.size(), -1), emap(edges.size(), -1);
-        size_t nn = 0;
-        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) nmap[i] = (int)nn++;
-        size_t ne = 0;
-        for (size_t e = 0; e < edges.size(); e++) if (edges[e].u >= 0 && nodes[(size_t)edges[e].u].alive && nodes[(size_t)edges[e].v].alive) emap[e] = (int)ne++;
-        std::vector<GNode> n2; n2.reserve(nn);
-        for (size_t i = 0; i < nodes.size(); i++) {
-            if (!nodes[i].alive) continue;
-            GNode &n = nodes[i];
-            for (int &e : n.succ) e = emap[(size_t)e];
-            for (int &e : n.pred) e = emap[(size_t)e];
-            n2.push_back(std::move(n));
-        }
-        std::vector<GEdge> e2; e2.reserve(ne);
-        for (size_t e = 0; e < edges.size(); e++) if (emap[e] >= 0) { GEdge &x = edges[e]; x.u = nmap[(size_t)x.u]; x.v = nmap[(size_t)x.v]; e2.push_back(std::move(x)); }
-        nodes.swap(n2); edges.swap(e2);
-        for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
-        for (int &x : start_of) x = nmap[(size_t)x];
-    }
-    void finish() {
-        order.clear();
-        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);      // (a node's number IS its creation order: new_node hands both out together)
-        edge_no.assign(edges.size(), -1);
-        int ne = 0;
-        for (int x : order) for (int e : nodes[(size_t)x].succ) edge_no[(size_t)e] = ne++;
-    }
-};
+void rv_graph_align_out_free(void *p);      // rv_graphrem.hip
+rv_graph::~rv_graph() { if (align_out_) rv_graph_align_out_free(align_out_); }
 
 extern "C" {
 
@@ -219,6 +25,7 @@ static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end
     for (int s = 0; s < nseq; s++) {
         const int st = g->new_node(s, 0, -1), iv = g->new_node(begin[s], end[s], 0), en = g->new_node(s, 1, -1);
         g->start_of.push_back(st);
+        g->nodes[(size_t)st].sent = 1; g->nodes[(size_t)en].sent = 2;
         g->nodes[(size_t)st].off.push_back({s, 0}); g->nodes[(size_t)iv].off.push_back({s, 0}); g->nodes[(size_t)en].off.push_back({s, end[s] - begin[s]});
         PathSet only; only.add(s);
         g->add_edge(st, iv, only); g->add_edge(iv, en, only);
@@ -244,6 +51,10 @@ rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, in
     catch (...) { rv_set_error("rv_graph_replay: failed"); return nullptr; }
 }
 
+/* after changes to the graph (rv_graph_align) and before rv_graph_sizes / rv_graph_export: the numbering of live nodes and links in dictionary order */
+int rv_graph_finish(rv_graph *g) {
+    try { g->finish(); return 0; } catch (...) { rv_set_error("rv_graph_finish: out of host memory"); return -1; }
+}
 const char *rv_graph_error(const rv_graph *g) { return g->err.empty() ? nullptr : g->err.c_str(); }
 
 /* out[0] nodes, out[1] offset entries, out[2] edges, out[3] path entries of the edges */
@@ -352,6 +163,7 @@ static inline void put_int(std::string &o, int v) {
  * its interval, upper-cased when aligned -- and an L line per link to a sequence node, then a P line per path (names[0 .. npaths), path id = position),
  * walked from its start sentinel.  The text stays with the graph until it is freed; *out points at it, the return value is its length. */
 static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *names, const char *cmdline, const char **out) {
+    g->finish();      // (the numbering follows the graph as it stands)
     auto &nodes = g->nodes; auto &edges = g->edges;
     std::string &o = g->gfa;
     o.clear();
@@ -394,7 +206,7 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
                 for (int e : nodes[(size_t)node].succ)
                     if (edges[(size_t)e].paths.has(sid)) { nout++; v = edges[(size_t)e].v; }
                 if (nout != 1) break;
-                if (nodes[(size_t)v].aligned < 0 && nodes[(size_t)v].e == 1) break;      // an end sentinel
+                if (nodes[(size_t)v].sent == 2) break;      // an end sentinel
                 if (nodes[(size_t)v].aligned >= 0) {
                     const int w = snprintf(buf, sizeof buf, "%s%d+", path.empty() ? "" : ",", ident[(size_t)v]);
                     path.append(buf, (size_t)w);

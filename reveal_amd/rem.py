@@ -248,12 +248,37 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
     # Its case: FASTA inputs with one sequence per sample, no --maxbubblesize / maxdepth, reveal_amd's own index.  None = whenever that holds.
     can_native = (hasattr(idx, "set_picker") and not any(f.endswith(".gfa") or f.endswith(".gfa.gz") for f in inputfiles)
                   and len(idx.nodes) == len(idx.samples) and args.maxsize is None and args.maxdepth is None)
-    if native and not can_native:
-        raise ValueError("native=True: FASTA inputs with one sequence per sample, no maxsize / maxdepth, reveal_amd's index")
+    # The other inputs -- graphs (GFA files of earlier alignments), samples of several sequences: picker AND graphalign inside the library, on the readers' graph
+    # moved behind the ABI (alngraph.LoopGraph, rv_set_graph_picker); links on the reverse strand keep the Python callbacks.
+    loop = None
+    if not can_native and native is not False and hasattr(idx, "set_graph_picker") and args.maxsize is None and args.maxdepth is None \
+            and (native or os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")):
+        try:
+            loop = alngraph.LoopGraph(G, sa64=sa64)
+        except ValueError:
+            loop = None
+    if native and not can_native and loop is None:
+        raise ValueError("native=True: no links on the reverse strand, no maxsize / maxdepth, reveal_amd's index")
     if native is None:      # (REVEAL_AMD_NATIVE=0 in the environment, or --no-native on the command line: the Python callbacks)
         native = can_native and os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")
     root_nodes = sorted(tuple(x) for x in idx.nodes)
     idx.construct()
+    if loop is not None:
+        idx.set_graph_picker(loop, args)
+        try:
+            res = idx.align_builtin(minlength, minn)
+        finally:
+            idx.set_graph_picker(None)
+        loop.finish()
+        picker.calls = idx.picker_info()["calls"]
+        aligner.calls += len(res["anchors"][0])
+        idx._nodes = set(root_nodes)
+        G.native = loop
+        if materialize:
+            loop.load_into(G)
+            loop.close()
+            G.native = None
+        return G, idx, picker, aligner
     if native:
         idx.set_picker(args)
         l, off, pos = idx.align_builtin(minlength, minn)["anchors"]

@@ -1,0 +1,104 @@
+"""The two callbacks of `reveal rem` for GRAPH inputs behind the ABI (reveal_amd/csrc/rv_graphrem.hip: rv_graph_pick, rv_graph_align on the structure
+rv_graph_import makes) beside their Python forms (schemes.GraphPicker.graphmumpicker, rem.GraphAligner.graphalign) on EVERY sub-index of whole
+alignments: the reference's own index (oracle/_ref, no GPU) drives the recursion with the Python callbacks; a LoopGraph made from the same input graph
+answers every call as well, and must answer the same -- the pick, the seeds, the children's intervals, the merged / left / right nodes -- and, node for
+node and link for link in dictionary order, end up as the same graph, pruned and written to the same GFA text."""
+import os
+import sys
+
+import pytest
+
+import graphrem_cases as C
+from reveal_amd import alngraph, rem, schemes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "oracle"))
+
+
+@pytest.fixture(scope="module")
+def refmod():
+    import pin_oracle as P
+    mod = P.load_refmod(False)
+    if mod is None:
+        pytest.skip("oracle/_ref/reveallib.so not built (make -C oracle refmod needs /root/reference)")
+    return mod
+
+
+def beside(monkeypatch, stats):
+    """every graphmumpicker / graphalign call of the run also goes to a LoopGraph of the same graph (made at the first call: the readers are done by then)"""
+    state = {}
+    py_pick, py_align = schemes.GraphPicker.graphmumpicker, rem.GraphAligner.graphalign
+
+    def loop(G):
+        if "lg" not in state:
+            state["lg"] = alngraph.LoopGraph(G)
+        return state["lg"]
+
+    def pick(self, mums, idx, precomputed=False, minlength=0):
+        lg = loop(self.G)
+        if not precomputed and self.args.maxsize is None and self.args.maxdepth is None and len(mums):
+            left, right = idx.leftnode, idx.rightnode
+            got = lg.pick(list(mums), idx.nsamples, None if left is None else tuple(left), None if right is None else tuple(right), self.args, minlength)
+        else:
+            got = None
+        want = py_pick(self, mums, idx, precomputed=precomputed, minlength=minlength)
+        if got is not None:
+            stats["picks"] += 1
+            norm = lambda r: () if r == () else (r[0], [(tuple(m), s) for m, s in r[1]], [(tuple(m), s) for m, s in r[2]])
+            w = () if want == () else ((want[0][0], want[0][1], tuple(tuple(x) for x in want[0][2])), [((m[0], m[1], tuple(tuple(x) for x in m[2])), s) for m, s in want[1]],
+                                       [((m[0], m[1], tuple(tuple(x) for x in m[2])), s) for m, s in want[2]])
+            assert norm(got) == norm(w), (got, w)
+        return want
+
+    def align(self, index, mum):
+        lg = loop(self.G)
+        nodes_before = sorted(tuple(x) for x in index.nodes)
+        left, right = index.leftnode, index.rightnode
+        got = lg.align(nodes_before, None if left is None else tuple(left), None if right is None else tuple(right), mum)
+        want = py_align(self, index, mum)
+        stats["aligns"] += 1
+        leading, trailing, matching, rest, mn, newleft, newright = want
+        node = lambda x: None if x is None else tuple(x)
+        assert got == (sorted(tuple(x) for x in leading), sorted(tuple(x) for x in trailing), sorted(tuple(x) for x in matching), sorted(tuple(x) for x in rest),
+                       node(mn), node(newleft), node(newright)), (got, want)
+        return want
+    monkeypatch.setattr(schemes.GraphPicker, "graphmumpicker", pick)
+    monkeypatch.setattr(rem.GraphAligner, "graphalign", align)
+    return state
+
+
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(trim=False), dict(seedsize=50), dict(gcmodel="star-avg", maxmums=50)])
+def test_graph_inputs_native_beside_python(tmp_path, refmod, monkeypatch, kw):
+    """level 0 in Python (two FASTA jobs), then the graph + graph job with both forms on every call; also a graph + FASTA job"""
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d"])
+    rem.graph_rem(files[:2], str(tmp_path / "ab.gfa"), indexmod=refmod, native=False)
+    rem.graph_rem(files[2:], str(tmp_path / "cd.gfa"), indexmod=refmod, native=False)
+    for inputs, name in (([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], "abcd.gfa"), ([str(tmp_path / "ab.gfa"), files[2]], "abc.gfa")):
+        stats = dict(picks=0, aligns=0)
+        with monkeypatch.context() as mp:
+            state = beside(mp, stats)
+            G, idx, picker, aligner = rem.graph_align_genomes(inputs, indexmod=refmod, native=False, args=schemes.PickerArgs(**kw), preselect=False)
+        assert stats["aligns"] > 100 and stats["picks"] > 100
+        lg = state["lg"]
+        assert lg.snapshot() == alngraph.graph_snapshot(G)
+        T = idx.T
+        if len(G.paths) > 2:
+            G.prune_nodes(T)
+            lg.prune(T)
+            assert lg.snapshot() == alngraph.graph_snapshot(G)
+        fn = alngraph.write_gfa(G, T, str(tmp_path / ("py_" + name)), cmdline="x")
+        assert lg.gfa(T, cmdline="x") == open(fn, "rb").read()
+        lg.close()
+
+
+def test_fasta_inputs_through_the_loop_graph(tmp_path, refmod, monkeypatch):
+    """FASTA inputs (also a multi-contig one) are graphs, too: the same two entry points serve them"""
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1e"])
+    stats = dict(picks=0, aligns=0)
+    with monkeypatch.context() as mp:
+        state = beside(mp, stats)
+        G, idx, picker, aligner = rem.graph_align_genomes(files, indexmod=refmod, native=False, preselect=False)
+    assert stats["aligns"] > 100
+    assert state["lg"].snapshot() == alngraph.graph_snapshot(G)

@@ -122,3 +122,59 @@ def test_native_picker_synthetic_five_way(tmp_path):
         texts.append(open(fn).read())
     assert _canonical_gfa(texts[0]) == _canonical_gfa(texts[1])
     assert texts[0] == texts[1]
+
+
+def _both_ways(tmp_path, files, tag, **kw):
+    """graph_rem with both callbacks inside the library (rv_set_graph_picker) and through Python: -> the two GFA texts, aligned node counts"""
+    from reveal_amd import schemes
+    outs = {}
+    for native in (False, True):
+        G, idx, fn = rem.graph_rem(files, str(tmp_path / ("%s_n%d.gfa" % (tag, native))), args=schemes.PickerArgs(**kw), native=native, preselect=False)
+        outs[native] = (open(fn).read(), sum(1 for n in G.seq_nodes() if G.aligned[n]), len(G.seq_nodes()), fn)
+        if native:
+            assert idx.picker_info()["kind"] == 0 and idx.picker_info()["calls"] > 0      # (switched off again after the run; the calls were counted)
+    assert outs[True][1:3] == outs[False][1:3]
+    assert outs[True][0] == outs[False][0]
+    return outs[True][3]
+
+
+@pytest.mark.parametrize("kw", [{}, {"trim": False}, {"seedsize": 300, "maxmums": 50}, {"seedsize": 200, "wpen": 3, "gcmodel": "star-avg"}])
+def test_graph_inputs_native_callbacks_write_the_same_gfa(tmp_path, kw):
+    """graphs as inputs (what levels 1 and 2 of `reveal align --order=sequential` run): graph + graph, graph + FASTA, three graphs -- the picker and graphalign
+    of the reference's Python, inside the library on the graph behind the ABI (rv_graphrem.hip), against the Python callbacks: the same file byte for byte"""
+    fa = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d"])
+    g_ab = rem.graph_rem(fa[:2], str(tmp_path / "ab.gfa"))[2]
+    g_cd = rem.graph_rem(fa[2:], str(tmp_path / "cd.gfa"))[2]
+    fn = _both_ways(tmp_path, [g_ab, g_cd], "gg", **kw)
+    spelled, _ = C.spelled_by_file(fn)
+    assert spelled == C.input_sequences(fa)
+    fn = _both_ways(tmp_path, [g_ab, fa[2]], "gf", **kw)
+    spelled, _ = C.spelled_by_file(fn)
+    assert spelled == C.input_sequences(fa[:3])
+    if not kw:
+        g_abc = fn
+        fn = _both_ways(tmp_path, [g_abc, g_cd], "gg2")      # (1c on both sides: two paths of the same sequence)
+
+
+def test_multi_sequence_samples_native_callbacks(tmp_path):
+    """samples of several sequences (multi-FASTA, one sample per file: --nocontigs is off) take the same route"""
+    files = C.fasta_files(tmp_path, ["d1", "d2"])
+    both = tmp_path / "both.fa"
+    both.write_text(open(files[0]).read() + open(C.fasta_files(tmp_path, ["2a"])[0]).read())
+    other = tmp_path / "other.fa"
+    other.write_text(open(files[1]).read() + open(C.fasta_files(tmp_path, ["2b"])[0]).read())
+    _both_ways(tmp_path, [str(both), str(other)], "mf")
+
+
+def test_graph_inputs_native_synthetic(tmp_path):
+    """nine related genomes of 60 kbp in three graphs, then the three graphs in one: level 1 of config 5's plan both ways"""
+    seqs = synth.genomes(60000, 9, seed=29, indelfrac=0.2)
+    files = []
+    for k, s in enumerate(seqs):
+        p = tmp_path / ("g%d.fa" % k)
+        p.write_text(">genome%d\n%s\n" % (k, s.decode()))
+        files.append(str(p))
+    graphs = [rem.graph_rem(files[3 * j:3 * j + 3], str(tmp_path / ("j%d.gfa" % j)))[2] for j in range(3)]
+    fn = _both_ways(tmp_path, graphs, "lvl1")
+    spelled, _ = C.spelled_by_file(fn)
+    assert spelled == {"genome%d" % k: s.decode() for k, s in enumerate(seqs)}

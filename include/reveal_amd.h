@@ -63,6 +63,7 @@ int rv_reserve_text(rv_index *h, int64_t bytes);
 int64_t rv_n(const rv_index *h);        /* reveal_getn (interface.c:681-689): ranks in the main index */
 int rv_nsamples(const rv_index *h);     /* interface.c:691-695 */
 int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so far */
+int rv_node_list(const rv_index *h, int64_t *begin_end);      /* those intervals, 2 * rv_nnodes numbers (sequences added inside the library: rv_graph_read_gfa) */
 
 /* ---- construct (interface.c:160-291) ------------------------------------- */
 /* rc!=0 reverse-complements T[nsep[0]..n) first (interface.c:168-175).
@@ -375,6 +376,19 @@ int rv_graph_align_fetch(rv_graph *g, int64_t *out);
  * get their left / right nodes as reveal.c:884-950 hands them on.  The graph is the alignment graph when the run returns (rv_graph_finish, then _prune / _gfa /
  * _export); it stays the caller's.  g = NULL turns the picker off.  Not combined with construct(rc=1), tracing or the frontier hand-off. */
 int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args);
+/* The readers of `reveal rem` behind the ABI (reveal/utils.py:304-375 read_fasta, :377-677 read_gfa with rem's defaults; reveal_amd/alngraph.py in Python): the
+ * graph of the inputs made where the run uses it, the segments' text appended to the index on the way.
+ * rv_graph_add_linear: one sequence the caller added to the index as [b, e) -- a new path (-> its id), its start sentinel, the node, its end sentinel.
+ * rv_graph_read_gfa: the text of a GFA1 file; every S line becomes a sequence of h's current sample (h == NULL: intervals counted from *text_n on -- tests
+ * without a device); -> number of paths added (*names: their names, one per line, valid until the next call), -1 error, -2 the file holds links on the reverse
+ * strand (not supported behind the ABI; g and h are then half-filled: start over with the Python readers).
+ * rv_graph_paths -> number of paths, their lengths; rv_graph_node_kinds: per node in rv_graph_export's order 0 sequence node, 1 start, 2 end sentinel. */
+rv_graph *rv_graph_new(void);
+int rv_graph_add_linear(rv_graph *g, int64_t b, int64_t e, int star);
+int64_t rv_graph_read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len, const char **names);
+int rv_graph_paths(const rv_graph *g, int64_t *id2end);
+int rv_graph_node_kinds(const rv_graph *g, int8_t *out);
+int rv_graph_literal(const rv_graph *g);      /* 1: some node of the inputs does not go on in both directions -- segmentgraph walks back from its end points as the reference does */
 int rv_graph_finish(rv_graph *g);      /* renumber live nodes and links (after rv_graph_align, before rv_graph_sizes / rv_graph_export) */
 rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos);
 const char *rv_graph_error(const rv_graph *g);

@@ -587,6 +587,16 @@ def make_index_type(sa64, error):
             if r != 0:
                 self._fail()
 
+        def _sync_nodes(self):
+            """sequences added inside the library (rv_graph_read_gfa) into this object's interval set"""
+            k = self._dll.rv_nnodes(self._h)
+            if k != len(self._nodes):
+                buf = np.zeros(2 * max(k, 1), np.int64)
+                if self._dll.rv_node_list(self._h, buf.ctypes.data) != 0:
+                    self._fail()
+                self._nodes = set(map(tuple, buf[:2 * k].reshape(-1, 2).tolist()))
+                self._constructed = False
+
         def set_graph_picker(self, graph=None, args=None):
             """graph inputs (rv_set_graph_picker): `graph` = an alngraph.LoopGraph of the inputs made with this index' library; picker and graphalign of
             `reveal rem` run inside align_builtin on it, and it is the alignment graph afterwards.  None = off."""

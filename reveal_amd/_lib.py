@@ -54,6 +54,7 @@ SYMBOLS = {
     "rv_n": (_L, [V]),
     "rv_nsamples": (_I, [V]),
     "rv_nnodes": (_I, [V]),
+    "rv_node_list": (_I, [V, V]),
     "rv_construct": (_I, [V, _I, ctypes.c_char_p, ctypes.c_char_p, _I]),
     "rv_upload": (_I, [V]),
     "rv_upload_again": (_I, [V]),
@@ -137,6 +138,12 @@ SYMBOLS = {
     "rv_graph_align_fetch": (_I, [V, V]),
     "rv_graph_finish": (_I, [V]),
     "rv_set_graph_picker": (_I, [V, V, V]),
+    "rv_graph_new": (V, []),
+    "rv_graph_add_linear": (_I, [V, _L, _L, _I]),
+    "rv_graph_read_gfa": (_L, [V, V, V, V, _L, V]),
+    "rv_graph_paths": (_I, [V, V]),
+    "rv_graph_node_kinds": (_I, [V, V]),
+    "rv_graph_literal": (_I, [V]),
     "rv_graph_replay": (V, [_I, V, V, _L, V, V, V]),
     "rv_graph_error": (ctypes.c_char_p, [V]),
     "rv_graph_sizes": (_I, [V, c_i64p]),

@@ -14,6 +14,7 @@ Functions follow the reference's semantics (cited at each one); the code is not 
 """
 import bisect
 import gzip
+import os
 import sys
 import uuid
 
@@ -549,6 +550,10 @@ def graph_arrays(G):
     return arr, nodes
 
 
+class ReverseStrand(ValueError):
+    """a GFA input with links on the reverse strand: not read behind the ABI"""
+
+
 class LoopGraph(NativeGraph):
     """rv_graph behind the ABI for GRAPH inputs (include/reveal_amd.h rv_graph_import): the structure the library's own picker and graphalign work on
     while the recursion runs (rv_set_graph_picker), made from the AlnGraph the readers left.  pick / align expose the two steps one call at a time (the tests run
@@ -568,6 +573,82 @@ class LoopGraph(NativeGraph):
             raise RuntimeError(self._lib.err())
         self.sentinels0 = [n for n in self.nodes0 if not isinstance(n, tuple)]
 
+    @classmethod
+    def read(cls, inputfiles, idx, G, contigs=True, toupper=True, sa64=False):
+        """the inputs read behind the ABI (rv_graph_add_linear / rv_graph_read_gfa: csrc/rv_gfaread.hip): sequences go to `idx` (reveal_amd's index) as the
+        Python readers would add them, the graph is made where the run uses it; of `G` only the path tables are filled.  Raises ReverseStrand when a file
+        holds links on the reverse strand -- idx and G are half-filled then: start over with the Python readers."""
+        import ctypes
+        import uuid
+        from . import _lib
+        from .rem import fasta_reader
+        self = cls.__new__(cls)
+        self._lib = _lib.get(bool(sa64))
+        self._dll = dll = self._lib.dll
+        self._g = dll.rv_graph_new()
+        if not self._g:
+            raise MemoryError(self._lib.err())
+        for f in inputfiles:
+            if f.endswith(".gfa") or f.endswith(".gfa.gz"):
+                idx.addsample(os.path.basename(f))
+                with (gzip.open if f.endswith(".gz") else open)(f, "rb") as fh:
+                    data = fh.read()
+                names = ctypes.c_char_p()
+                if getattr(idx, "_h", None) is not None:
+                    n = dll.rv_graph_read_gfa(self._g, idx._h, None, data, len(data), ctypes.byref(names))
+                else:      # (an index stand-in that only counts text positions -- tests without a device: the graph alone)
+                    tn = ctypes.c_int64(idx.n)
+                    n = dll.rv_graph_read_gfa(self._g, None, ctypes.byref(tn), data, len(data), ctypes.byref(names))
+                    idx.n = tn.value
+                if n == -2:
+                    self.close()
+                    raise ReverseStrand(f)
+                if n < 0:
+                    why = self._lib.err()
+                    self.close()
+                    raise ValueError("%s: %s" % (f, why))
+                for name in names.value.decode("latin-1").split("\n")[:n]:
+                    _new_path(G, name)
+                del data
+            else:
+                if contigs:
+                    idx.addsample(os.path.basename(f))
+                for name, seq in fasta_reader(f, toupper=toupper):
+                    if not contigs:
+                        idx.addsample(name)
+                    name = name.replace(":", "").replace(";", "")
+                    sid = _new_path(G, name, len(seq))
+                    b, e = idx.addsequence(seq)
+                    if dll.rv_graph_add_linear(self._g, b, e, 1 if name.startswith("*") else 0) != sid:
+                        raise RuntimeError("path ids out of step: " + self._lib.err())
+        if hasattr(idx, "_sync_nodes"):
+            idx._sync_nodes()
+        k = dll.rv_graph_paths(self._g, None)
+        import numpy as np
+        ends = np.zeros(max(k, 1), np.int64)
+        dll.rv_graph_paths(self._g, ends.ctypes.data)
+        G.id2end.update({sid: int(ends[sid]) for sid in range(k)})
+        self.names = list(G.paths)
+        self.nodes0, self.sentinels0 = None, None
+        return self
+
+    def _sentinel_names(self, G):
+        """names for the graph's sentinels when it was read behind the ABI (they have none there), registered with G as the Python readers would"""
+        import ctypes
+        import uuid
+        import numpy as np
+        sz = np.zeros(4, dtype=np.int64)
+        self._dll.rv_graph_sizes(self._g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
+        kinds = np.zeros(max(int(sz[0]), 1), np.int8)
+        self._dll.rv_graph_node_kinds(self._g, kinds.ctypes.data)
+        self.sentinels0 = []
+        G.startnodes, G.endnodes = [], []
+        for kd in kinds[:int(sz[0])].tolist():
+            if kd:
+                name = uuid.uuid4().hex
+                self.sentinels0.append(name)
+                (G.startnodes if kd == 1 else G.endnodes).append(name)
+
     def finish(self):
         """after the run (index.set_graph_picker + align_builtin): live nodes and links renumbered, ready for counts / prune / gfa / load_into"""
         self._dll.rv_graph_finish(self._g)
@@ -577,10 +658,14 @@ class LoopGraph(NativeGraph):
         import numpy as np
         sz = np.zeros(4, dtype=np.int64)
         self._dll.rv_graph_sizes(self._g, sz.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)))
-        return int(sz[0]) - len(self.sentinels0), int(sz[2])
+        kinds = np.zeros(max(int(sz[0]), 1), np.int8)
+        self._dll.rv_graph_node_kinds(self._g, kinds.ctypes.data)
+        return int(sz[0]) - int(np.count_nonzero(kinds[:int(sz[0])])), int(sz[2])
 
     def _node_names(self, G, nbl, nel, nall):
         # sentinels are neither made nor removed by the run and keep their order: the k-th one is the k-th one of the graph handed to the constructor
+        if self.sentinels0 is None:
+            self._sentinel_names(G)
         it = iter(self.sentinels0)
         return [(next(it) if al < 0 else (b, e)) for b, e, al in zip(nbl, nel, nall)]
 
@@ -747,7 +832,7 @@ def read_gfa(gfafile, index, G):
         G.add_edge(nmap[e[1]], nmap[e[3]], set(), e[2], e[4])
     if not plines:
         raise ValueError("no paths defined in %s" % gfafile)
-    starts, ends = set(), set()
+    starts, ends = {}, {}          # (dictionaries for their order: the reference keeps sets of random names and meets them in any order; here creation order)
     for line in plines:
         cols = line.rstrip("\n").split("\t")
         sample = cols[1]
@@ -771,7 +856,7 @@ def read_gfa(gfafile, index, G):
         if path:
             G.add_edge(start, nmap[path[0][0]], {sid}, "+", path[0][1])
             G.add_edge(nmap[path[-1][0]], end, {sid}, path[-1][1], "+")
-        starts.add(start); ends.add(end)
+        starts[start] = None; ends[end] = None
         G.id2end[sid] = o
     for u in list(G.succ):                              # untraversed edges, then untraversed nodes
         for key, p in list(G.succ[u].items()):
@@ -782,10 +867,14 @@ def read_gfa(gfafile, index, G):
     for n in [n for n in mine if not G.offsets[n]]:
         G.remove_node(n)
         mine.discard(n)
-    # weakly connected components of what this file added; one start and one end sentinel per component
-    todo = mine | starts | ends
-    while todo:
-        comp, stack = set(), [next(iter(todo))]
+    # weakly connected components of what this file added -- each found from its first member in creation order --; one start and one end sentinel per
+    # component, made from the paths' own in creation order (rv_gfaread.hip does the same)
+    todo = mine | set(starts) | set(ends)
+    comps = []
+    for x0 in [n for n in G.offsets if n in todo]:
+        if x0 not in todo:
+            continue
+        comp, stack = set(), [x0]
         while stack:
             x = stack.pop()
             if x in comp:
@@ -794,7 +883,9 @@ def read_gfa(gfafile, index, G):
             stack.extend(v for (v, a, b) in G.succ[x] if v not in comp)
             stack.extend(u for (u, a, b) in G.pred[x] if u not in comp)
         todo -= comp
-        for group, register, forward in ((comp & ends, G.endnodes, False), (comp & starts, G.startnodes, True)):
+        comps.append(comp)
+    for comp in comps:
+        for group, register, forward in (([x for x in ends if x in comp], G.endnodes, False), ([x for x in starts if x in comp], G.startnodes, True)):
             if not group:
                 continue
             sentinel = uuid.uuid4().hex

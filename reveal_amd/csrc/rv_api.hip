@@ -281,6 +281,11 @@ int rv_reserve_text(rv_index *h, int64_t bytes) {
 int64_t rv_n(const rv_index *h) { return h->n; }
 int rv_nsamples(const rv_index *h) { return h->nsamples; }
 int rv_nnodes(const rv_index *h) { return (int)h->nodes.size(); }
+int rv_node_list(const rv_index *h, int64_t *begin_end) {
+    if (!h || !begin_end) { rv_set_error("rv_node_list: bad arguments"); return -1; }
+    for (size_t k = 0; k < h->nodes.size(); k++) { begin_end[2 * k] = h->nodes[k].begin; begin_end[2 * k + 1] = h->nodes[k].end; }
+    return 0;
+}
 
 /* interface.c:136-158 */
 static char comp_of(char ch) {

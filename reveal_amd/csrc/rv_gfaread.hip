@@ -1,0 +1,255 @@
+// rv_gfaread.hip -- the input side of `reveal rem` for graphs behind the ABI (host code): the graph the reference's readers leave (reveal/utils.py:304-375
+// read_fasta, :377-677 read_gfa with the defaults `reveal rem` uses) built straight into the structure of rv_graph.h, the segments' text appended to the index
+// on the way.  reveal_amd/alngraph.py read_fasta / read_gfa are the Python forms (tests/test_cpu_graphrem_native.py reads every fixture both ways and compares
+// node for node in dictionary order); a level-1 job of config 5 at 25 x 1 Mbp spent 9.3 of its 14.8 s there and another 1.8 s moving the result behind the ABI.
+//
+// What the reference's reader does, in its order: every S line becomes a '$'-terminated sequence of the current sample and an unaligned node; L lines become
+// links with empty path sets; every P line numbers a new path, walks its steps -- a node's offset on the path, the link from the step before gets the path -- and
+// hangs the walk between a start and an end sentinel of its own; links and nodes no path uses go; per weakly connected component of what the file added, the end
+// sentinels of its paths are merged into one, then the start sentinels.  The reference picks components and merges sentinels in the iteration order of Python
+// sets of random names; here (and in alngraph.read_gfa) both go by creation order, one of the orders the reference can take.
+// Links on the reverse strand are not supported behind the ABI: -2 comes back and the caller takes the Python route.
+#include "rv_graph.h"
+#include <string_view>
+#include <unordered_map>
+
+namespace {
+
+inline int new_sentinel(rv_graph *g, int kind) {
+    const int x = g->new_node((int64_t)g->counter, 0, -1);
+    g->nodes[(size_t)x].sent = (int8_t)kind;
+    return x;
+}
+inline void drop_edge(rv_graph *g, int e) {
+    GEdge &ed = g->edges[(size_t)e];
+    auto &s = g->nodes[(size_t)ed.u].succ; s.erase(std::find(s.begin(), s.end(), e));
+    auto &p = g->nodes[(size_t)ed.v].pred; p.erase(std::find(p.begin(), p.end(), e));
+    ed.u = -1;
+}
+// alngraph.check_segment_shortcut: every sequence node goes on over a link carried by a real path, in both directions -- or segmentgraph takes the reference's form
+void check_shortcut(rv_graph *g) {
+    bool any_star = false;
+    for (uint8_t s : g->star) any_star |= s != 0;
+    auto real = [&](const PathSet &p) {
+        if (!any_star) return p.size() > 0;
+        bool r = false;
+        p.each([&](int sid) { r |= !g->star[(size_t)sid]; });
+        return r;
+    };
+    for (const GNode &n : g->nodes) {
+        if (!n.alive || n.aligned < 0) continue;
+        bool f = false, b = false;
+        for (int e : n.succ) if (real(g->edges[(size_t)e].paths)) { f = true; break; }
+        for (int e : n.pred) if (real(g->edges[(size_t)e].paths)) { b = true; break; }
+        if (!f || !b) { g->literal_segments = true; return; }
+    }
+}
+
+struct Fields {      // the first columns of a tab-separated line
+    std::string_view f[6]; int n = 0;
+    explicit Fields(std::string_view line, int want = 6) {
+        size_t at = 0;
+        while (n < want && at <= line.size()) {
+            size_t t = line.find('\t', at);
+            if (t == std::string_view::npos) t = line.size();
+            f[n++] = line.substr(at, t - at);
+            at = t + 1;
+        }
+    }
+};
+
+int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len) {
+    std::unordered_map<std::string_view, int> nmap;
+    std::vector<std::string_view> llines, plines;
+    const size_t first_node = g->nodes.size();
+    std::string up;
+    g->names_buf.clear();
+    // S lines: text and nodes
+    {
+        size_t lines = 0;
+        for (int64_t i = 0; i < len; i++) lines += data[i] == '\n';
+        nmap.reserve(lines);
+        g->nodes.reserve(g->nodes.size() + lines + 64);
+    }
+    for (int64_t at = 0; at < len;) {
+        const char *nl = (const char *)memchr(data + at, '\n', (size_t)(len - at));
+        const int64_t end = nl ? nl - data : len;
+        std::string_view line(data + at, (size_t)(end - at));
+        at = end + 1;
+        if (line.empty()) continue;
+        if (line[0] == 'S') {
+            Fields c(line, 4);
+            if (c.n < 2) { rv_set_error("read_gfa: an S line without a name"); return -1; }
+            std::string_view seq = c.n > 2 ? c.f[2] : std::string_view();
+            up.assign(seq.data(), seq.size());
+            for (char &ch : up) if (ch >= 'a' && ch <= 'z') ch = (char)(ch - 32);
+            int64_t b = 0, e = 0;
+            if (h) { if (rv_add_sequence(h, up.data(), (int64_t)up.size(), &b, &e) != 0) return -1; }
+            else { b = *text_n; e = b + (int64_t)up.size(); *text_n = e + 1; }
+            nmap[c.f[1]] = g->new_node(b, e, 0);
+        } else if (line[0] == 'L') llines.push_back(line);
+        else if (line[0] == 'P') plines.push_back(line);
+    }
+    auto node_named = [&](std::string_view id) -> int {
+        auto it = nmap.find(id);
+        if (it == nmap.end()) { rv_set_error("read_gfa: no segment named '%.*s'", (int)std::min<size_t>(id.size(), 60), id.data()); return -1; }
+        return it->second;
+    };
+    for (std::string_view line : llines) {
+        Fields c(line, 6);
+        if (c.n < 5) { rv_set_error("read_gfa: an L line with fewer than five columns"); return -1; }
+        if (c.f[2] != "+" || c.f[4] != "+") return -2;
+        const int u = node_named(c.f[1]), v = node_named(c.f[3]);
+        if (u < 0 || v < 0) return -1;
+        g->add_edge(u, v, PathSet());
+    }
+    if (plines.empty()) { rv_set_error("no paths defined in the GFA input"); return -1; }
+    std::vector<int> starts, ends;
+    int64_t added = 0;
+    for (std::string_view line : plines) {
+        Fields c(line, 4);
+        if (c.n < 2) { rv_set_error("read_gfa: a P line without a name"); return -1; }
+        const int sid = (int)g->id2end.size();
+        g->names_buf.append(c.f[1].data(), c.f[1].size()); g->names_buf += '\n';
+        g->star.push_back(!c.f[1].empty() && c.f[1][0] == '*');
+        int64_t o = 0;
+        int prev = -1, first = -1;
+        std::string_view steps = c.n > 2 ? c.f[2] : std::string_view();
+        for (size_t at = 0; !steps.empty() && at <= steps.size();) {
+            size_t cm = steps.find(',', at);
+            if (cm == std::string_view::npos) cm = steps.size();
+            std::string_view st = steps.substr(at, cm - at);
+            at = cm + 1;
+            if (st.empty()) { rv_set_error("read_gfa: an empty step in path %.*s", (int)std::min<size_t>(c.f[1].size(), 60), c.f[1].data()); return -1; }
+            if (st.back() != '+') return -2;
+            const int node = node_named(st.substr(0, st.size() - 1));
+            if (node < 0) return -1;
+            GNode &n = g->nodes[(size_t)node];
+            if (!n.off.empty() && n.off.back().first == sid) n.off.back().second = o;      // (a path through a node twice: the later offset stands, in the first one's place)
+            else n.off.push_back({sid, o});
+            o += n.e - n.b;
+            if (prev >= 0) {
+                int hit = -1;
+                for (int e : g->nodes[(size_t)prev].succ) if (g->edges[(size_t)e].v == node) { hit = e; break; }
+                if (hit < 0) { rv_set_error("path %.*s steps over a link the graph does not have", (int)std::min<size_t>(c.f[1].size(), 60), c.f[1].data()); return -1; }
+                g->edges[(size_t)hit].paths.add(sid);
+            } else first = node;
+            prev = node;
+        }
+        const int start = new_sentinel(g, 1), end = new_sentinel(g, 2);
+        g->nodes[(size_t)start].off.push_back({sid, 0});
+        g->nodes[(size_t)end].off.push_back({sid, o});
+        if (first >= 0) {
+            PathSet one; one.add(sid);
+            g->add_edge(start, first, one);
+            g->add_edge(prev, end, one);
+        }
+        starts.push_back(start); ends.push_back(end);
+        g->id2end.push_back(o);
+        added++;
+    }
+    // links, then nodes, no path uses
+    const size_t file_end = g->nodes.size();
+    std::vector<int> dead;
+    for (size_t x = first_node; x < file_end; x++) {
+        dead.clear();
+        for (int e : g->nodes[x].succ) if (g->edges[(size_t)e].paths.size() == 0) dead.push_back(e);
+        for (int e : dead) drop_edge(g, e);
+    }
+    for (size_t x = first_node; x < file_end; x++) if (g->nodes[x].alive && g->nodes[x].aligned >= 0 && g->nodes[x].off.empty()) g->remove_node((int)x);
+    // weakly connected components of what the file added, each by its first member in creation order; one end and one start sentinel per component
+    std::vector<int> comp_of(file_end - first_node, -1);
+    std::vector<std::vector<int>> comp_ends, comp_starts;
+    std::vector<int> stack;
+    for (size_t x0 = first_node; x0 < file_end; x0++) {
+        if (!g->nodes[x0].alive || comp_of[x0 - first_node] >= 0) continue;
+        const int cid = (int)comp_ends.size();
+        comp_ends.emplace_back(); comp_starts.emplace_back();
+        stack.assign(1, (int)x0);
+        comp_of[x0 - first_node] = cid;
+        while (!stack.empty()) {
+            const int x = stack.back(); stack.pop_back();
+            const GNode &n = g->nodes[(size_t)x];
+            for (int e : n.succ) { const int v = g->edges[(size_t)e].v; if (comp_of[(size_t)v - first_node] < 0) { comp_of[(size_t)v - first_node] = cid; stack.push_back(v); } }
+            for (int e : n.pred) { const int u = g->edges[(size_t)e].u; if (comp_of[(size_t)u - first_node] < 0) { comp_of[(size_t)u - first_node] = cid; stack.push_back(u); } }
+        }
+    }
+    for (int x : ends) comp_ends[(size_t)comp_of[(size_t)x - first_node]].push_back(x);           // (creation order)
+    for (int x : starts) comp_starts[(size_t)comp_of[(size_t)x - first_node]].push_back(x);
+    std::vector<std::pair<int, PathSet>> links;
+    for (size_t cidx = 0; cidx < comp_ends.size(); cidx++) {
+        for (int forward = 0; forward < 2; forward++) {
+            const std::vector<int> &group = forward ? comp_starts[cidx] : comp_ends[cidx];
+            if (group.empty()) continue;
+            const int sentinel = new_sentinel(g, forward ? 1 : 2);
+            if (forward) g->start_of.push_back(sentinel);
+            for (int old : group) {
+                for (auto &a : g->nodes[(size_t)old].off) {
+                    bool found = false;
+                    for (auto &m : g->nodes[(size_t)sentinel].off) if (m.first == a.first) { m.second = a.second; found = true; break; }
+                    if (!found) g->nodes[(size_t)sentinel].off.push_back(a);
+                }
+                links.clear();
+                if (forward) { for (int e : g->nodes[(size_t)old].succ) links.push_back({g->edges[(size_t)e].v, g->edges[(size_t)e].paths}); }
+                else for (int e : g->nodes[(size_t)old].pred) links.push_back({g->edges[(size_t)e].u, g->edges[(size_t)e].paths});
+                for (auto &lk : links) { if (forward) g->add_edge(sentinel, lk.first, lk.second); else g->add_edge(lk.first, sentinel, lk.second); }
+                g->remove_node(old);
+            }
+        }
+    }
+    g->compact();
+    check_shortcut(g);
+    return added;
+}
+
+}  // namespace
+
+extern "C" {
+
+rv_graph *rv_graph_new(void) {
+    try { return new rv_graph(); } catch (...) { rv_set_error("rv_graph_new: out of host memory"); return nullptr; }
+}
+
+/* utils.py:304-375 read_fasta for one sequence the caller has added to the index as [b, e): a new path, its start sentinel, the node, its end sentinel -> path id */
+int rv_graph_add_linear(rv_graph *g, int64_t b, int64_t e, int star) {
+    try {
+        const int sid = (int)g->id2end.size();
+        g->star.push_back(star ? 1 : 0); g->id2end.push_back(e - b);
+        const int st = new_sentinel(g, 1), x = g->new_node(b, e, 0), en = new_sentinel(g, 2);
+        g->nodes[(size_t)st].off.push_back({sid, 0}); g->nodes[(size_t)x].off.push_back({sid, 0}); g->nodes[(size_t)en].off.push_back({sid, e - b});
+        PathSet one; one.add(sid);
+        g->add_edge(st, x, one); g->add_edge(x, en, one);
+        g->start_of.push_back(st);
+        return sid;
+    } catch (...) { rv_set_error("rv_graph_add_linear: out of host memory"); return -1; }
+}
+
+/* utils.py:377-677 read_gfa on the text of a GFA1 file (data, len): segments appended to the index h as sequences of its current sample (h == NULL: intervals
+ * counted from *text_n on, which moves -- tests without a device), the graph added to g.  -> number of paths added (their names, one per line: *names, valid
+ * until the next call), -1 error, -2 the file holds links on the reverse strand (g and h are then in an undefined state: start over on the Python route) */
+int64_t rv_graph_read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len, const char **names) {
+    try {
+        if (!g || !data || len < 0 || (!h && !text_n)) { rv_set_error("rv_graph_read_gfa: bad arguments"); return -1; }
+        const int64_t r = read_gfa(g, h, text_n, data, len);
+        if (names) *names = g->names_buf.c_str();
+        return r;
+    } catch (const std::exception &e) { rv_set_error("rv_graph_read_gfa: %s", e.what()); return -1; }
+    catch (...) { rv_set_error("rv_graph_read_gfa: failed"); return -1; }
+}
+
+/* the paths of a graph made by the two readers: -> their number; id2end (may be NULL): their lengths */
+int rv_graph_paths(const rv_graph *g, int64_t *id2end) {
+    if (id2end) for (size_t k = 0; k < g->id2end.size(); k++) id2end[k] = g->id2end[k];
+    return (int)g->id2end.size();
+}
+
+int rv_graph_literal(const rv_graph *g) { return g->literal_segments ? 1 : 0; }      /* segmentgraph takes the reference's literal form (alngraph.check_segment_shortcut said no) */
+
+/* per node in the order of rv_graph_export (after rv_graph_finish): 0 a sequence node, 1 a start sentinel, 2 an end sentinel */
+int rv_graph_node_kinds(const rv_graph *g, int8_t *out) {
+    size_t k = 0;
+    for (int x : g->order) out[k++] = g->nodes[(size_t)x].aligned < 0 ? g->nodes[(size_t)x].sent : 0;
+    return 0;
+}
+
+}

@@ -66,7 +66,7 @@ struct rv_graph {
     uint64_t counter = 0;
     std::vector<int> order;                         // export: alive nodes in dictionary order
     std::vector<int> edge_no;                       // export: edge id -> dense number (-1: dead)
-    std::string err, gfa;
+    std::string err, gfa, names_buf;                // (names_buf: the path names the last rv_graph_read_gfa added, one per line)
     int nseq = 0;
     std::vector<std::pair<int, PathSet>> in_tmp, out_tmp;      // scratch of breaknode / mergenodes: a node's links while it is taken apart
     std::vector<int> start_of;                      // the start sentinels (FASTA reader: one per sequence, in the reader's order; graph inputs: one per component)

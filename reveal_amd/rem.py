@@ -14,6 +14,7 @@ node, `construct`, `align` with two callbacks):
 """
 import gzip
 import os
+import sys
 
 
 def fasta_reader(fn, toupper=True, keepdash=False):
@@ -220,13 +221,38 @@ def replay_anchors_fast(G, aligner, root_nodes, anchors):
     return len(anchors)
 
 
+class _Stages:
+    """REVEAL_AMD_TIMES=1: wall-clock seconds of a job's stages on stderr (reading, index, recursion, graph, file)"""
+    on = os.environ.get("REVEAL_AMD_TIMES", "0") not in ("0", "")
+
+    def __init__(self):
+        import time
+        self.clock, self.t, self.rows = time.perf_counter, time.perf_counter(), []
+
+    def mark(self, what):
+        if self.on:
+            now = self.clock()
+            self.rows.append((what, now - self.t))
+            self.t = now
+
+    def report(self, extra=""):
+        if self.on and self.rows:
+            sys.stderr.write("stages: " + ", ".join("%s %.3f s" % r for r in self.rows) + (" | " + extra if extra else "") + "\n")
+            self.rows = []
+
+
+_stages = _Stages()
+
+
 def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=True, toupper=True, args=None, preselect=True, indexmod=None, native=None, materialize=True):
     """rem.py:511-611 align_genomes: index + graph from FASTA / GFA inputs, construct, align with the graph callbacks.
     preselect: let the library hand the picker only what it keeps anyway (index.preselect(maxmums): the matches spanning
     every sample of the sub-index, capped at --maxmums) -- not valid with --trim, which looks at the others
     indexmod: the module that provides `index` (default reveal_amd.reveallib / reveallib64; tests pass the reference's own module)
-    native: the picker inside the library and the graph from the run's anchors behind the ABI (alngraph.NativeGraph); materialize=False leaves it
-    there -- `graph.native` holds it, the returned graph is still the reader's -- for a caller that only wants the file (graph_rem)
+    native: both callbacks inside the library -- FASTA inputs with one sequence per sample: the picker (rv_set_picker), the graph from the run's anchors
+    afterwards (alngraph.NativeGraph); graphs / several sequences per sample: readers, picker and graphalign on the graph behind the ABI (alngraph.LoopGraph,
+    rv_set_graph_picker).  None = wherever the inputs allow it, False = the Python callbacks.  materialize=False leaves the graph behind the ABI --
+    `graph.native` holds it, the returned graph is the reader's (only its path tables when the inputs were read there) -- for a caller that only wants the file
     -> (graph, index, picker, aligner)"""
     from . import alngraph, schemes
     if indexmod is None:
@@ -234,25 +260,35 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
         indexmod = reveallib64 if sa64 else reveallib
     idx = indexmod.index()
     G = alngraph.AlnGraph()
-    for f in inputfiles:
-        if f.endswith(".gfa") or f.endswith(".gfa.gz"):
-            idx.addsample(os.path.basename(f))
-            alngraph.read_gfa(f, idx, G)
-        else:
-            alngraph.read_fasta(f, idx, G, contigs=contigs, toupper=toupper)
+    args = args or schemes.PickerArgs()
+    env_on = os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")
+    gfa_in = any(f.endswith(".gfa") or f.endswith(".gfa.gz") for f in inputfiles)
+    loop_ok = native is not False and hasattr(idx, "set_graph_picker") and args.maxsize is None and args.maxdepth is None and (native or env_on)
+    loop = None
+    if gfa_in and loop_ok:
+        # graphs among the inputs: read behind the ABI as well (csrc/rv_gfaread.hip; the Python reader took 9.3 of the 14.8 s of a job of five 5 x 1 Mbp graphs)
+        try:
+            loop = alngraph.LoopGraph.read(inputfiles, idx, G, contigs=contigs, toupper=toupper, sa64=sa64)
+        except alngraph.ReverseStrand:
+            idx, G, loop = indexmod.index(), alngraph.AlnGraph(), None      # (half-filled: start over)
+            loop_ok = False
+    if loop is None:
+        for f in inputfiles:
+            if f.endswith(".gfa") or f.endswith(".gfa.gz"):
+                idx.addsample(os.path.basename(f))
+                alngraph.read_gfa(f, idx, G)
+            else:
+                alngraph.read_fasta(f, idx, G, contigs=contigs, toupper=toupper)
     if len(idx.samples) <= 1:
         raise ValueError("Specify at least 2 targets to construct alignment. In case of multi-fasta, consider the --nocontigs flag.")
-    args = args or schemes.PickerArgs()
+    _stages.mark("read inputs")
     picker, aligner = schemes.GraphPicker(G, args), GraphAligner(G)
     # native: the picker inside the library (rv_set_picker / rv_pick_chain: no Python call per sub-index), the graph from the anchors afterwards.
     # Its case: FASTA inputs with one sequence per sample, no --maxbubblesize / maxdepth, reveal_amd's own index.  None = whenever that holds.
-    can_native = (hasattr(idx, "set_picker") and not any(f.endswith(".gfa") or f.endswith(".gfa.gz") for f in inputfiles)
-                  and len(idx.nodes) == len(idx.samples) and args.maxsize is None and args.maxdepth is None)
-    # The other inputs -- graphs (GFA files of earlier alignments), samples of several sequences: picker AND graphalign inside the library, on the readers' graph
-    # moved behind the ABI (alngraph.LoopGraph, rv_set_graph_picker); links on the reverse strand keep the Python callbacks.
-    loop = None
-    if not can_native and native is not False and hasattr(idx, "set_graph_picker") and args.maxsize is None and args.maxdepth is None \
-            and (native or os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")):
+    can_native = (hasattr(idx, "set_picker") and not gfa_in and len(idx.nodes) == len(idx.samples) and args.maxsize is None and args.maxdepth is None)
+    # The other inputs -- graphs (GFA files of earlier alignments: read behind the ABI above), samples of several sequences (the readers' graph moved there:
+    # alngraph.LoopGraph): picker AND graphalign inside the library (rv_set_graph_picker); links on the reverse strand keep the Python callbacks.
+    if loop is None and not can_native and loop_ok:
         try:
             loop = alngraph.LoopGraph(G, sa64=sa64)
         except ValueError:
@@ -260,17 +296,22 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
     if native and not can_native and loop is None:
         raise ValueError("native=True: no links on the reverse strand, no maxsize / maxdepth, reveal_amd's index")
     if native is None:      # (REVEAL_AMD_NATIVE=0 in the environment, or --no-native on the command line: the Python callbacks)
-        native = can_native and os.environ.get("REVEAL_AMD_NATIVE", "1") not in ("0", "false", "no", "off")
+        native = can_native and env_on
+    _stages.mark("graph behind the ABI" if loop is not None else "setup")
     root_nodes = sorted(tuple(x) for x in idx.nodes)
     idx.construct()
+    _stages.mark("construct")
     if loop is not None:
         idx.set_graph_picker(loop, args)
         try:
             res = idx.align_builtin(minlength, minn)
         finally:
             idx.set_graph_picker(None)
+        _stages.mark("recursion")
         loop.finish()
+        _stages.mark("renumber")
         picker.calls = idx.picker_info()["calls"]
+        _stages.report("picker %(calls)d calls (%(seeded)d seeded), pick %(picker_s).3f s, lists %(lists_s).3f s" % idx.picker_info())
         aligner.calls += len(res["anchors"][0])
         idx._nodes = set(root_nodes)
         G.native = loop
@@ -283,11 +324,13 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
         idx.set_picker(args)
         l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
         idx.set_picker(None)
+        _stages.mark("recursion")
         picker.calls = idx.picker_info()["calls"]
         idx._nodes = set(root_nodes)
         # graphalign's surgery for every anchor, in the order the library chose them (replay_anchors / replay_anchors_fast are the same in Python:
         # 25 s instead of 1.3 for five genomes of 5 Mbp)
         G.native = alngraph.NativeGraph(G, root_nodes, l, off, pos)
+        _stages.mark("graph replay")
         aligner.calls += len(l)
         if materialize:
             G.native.load_into(G)
@@ -361,9 +404,13 @@ def graph_rem(inputfiles, output=None, sa64=False, minlength=20, minn=2, contigs
     ng = getattr(G, "native", None)
     if ng is not None:
         Tb = T.encode("latin-1")
+        _stages.mark("text")
         if len(G.paths) > 2:
             ng.prune(Tb)
+        _stages.mark("prune")
         fn = ng.write_gfa(Tb, output, cmdline="reveal_amd.rem " + " ".join(inputfiles)) if output else None
+        _stages.mark("gfa")
+        _stages.report()
         summary = dict(zip(("seq_nodes", "edges"), ng.counts()), paths=list(G.paths))
         if materialize:
             ng.load_into(G)

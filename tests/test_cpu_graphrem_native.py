@@ -102,3 +102,51 @@ def test_fasta_inputs_through_the_loop_graph(tmp_path, refmod, monkeypatch):
         G, idx, picker, aligner = rem.graph_align_genomes(files, indexmod=refmod, native=False, preselect=False)
     assert stats["aligns"] > 100
     assert state["lg"].snapshot() == alngraph.graph_snapshot(G)
+
+
+def test_readers_behind_the_abi_leave_the_same_graph(tmp_path, refmod):
+    """rv_graph_add_linear / rv_graph_read_gfa (csrc/rv_gfaread.hip) beside alngraph.read_fasta / read_gfa: graphs, FASTA files and both mixed, also a
+    hand-made file with a segment and a link no path uses, two components, a path through one node twice and a '*' path -- node for node, link for link"""
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d", "1e"])
+    rem.graph_rem(files[:2], str(tmp_path / "ab.gfa"), indexmod=refmod, native=False)
+    rem.graph_rem(files[2:4], str(tmp_path / "cd.gfa"), indexmod=refmod, native=False)
+    rem.graph_rem([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], str(tmp_path / "abcd.gfa.gz"), indexmod=refmod, native=False)
+    odd = tmp_path / "odd.gfa"
+    odd.write_text("H\tVN:Z:1.0\n"
+                   "S\t1\tACGTACGT\nS\t2\tggg\nS\t3\tTTTT\nS\t4\tCCCCC\nS\tx5\tAAAA\nS\t6\tGATTACA\nS\t7\tTT\n"
+                   "L\t1\t+\t2\t+\t0M\nL\t1\t+\t3\t+\t0M\nL\t2\t+\t4\t+\t0M\nL\t3\t+\t4\t+\t0M\nL\t4\t+\t1\t+\t0M\nL\t3\t+\tx5\t+\t0M\nL\t6\t+\t7\t+\t0M\nL\t1\t+\t2\t+\t0M\n"
+                   "P\tp1\t1+,2+,4+\t0M,0M\nP\tp2\t1+,3+,4+,1+\t0M,0M,0M\nP\t*p3\t6+,7+\t0M\nP\tp4\t6+\t\n")
+    for inputs in ([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], [files[4], str(tmp_path / "abcd.gfa.gz"), files[0].replace("1a", "1a")], [str(odd)], [str(odd), files[4]]):
+        if inputs[-1] == files[0]:
+            inputs = inputs[:-1]
+        Gp, tp = alngraph.AlnGraph(), C.TextOnly()
+        for f in inputs:
+            if f.endswith(".fa"):
+                alngraph.read_fasta(f, tp, Gp)
+            else:
+                alngraph.read_gfa(f, tp, Gp)
+        Gn, tn = alngraph.AlnGraph(), C.TextOnly()
+        lg = alngraph.LoopGraph.read(inputs, tn, Gn)
+        assert tn.n == tp.n
+        assert Gn.paths == Gp.paths and Gn.id2end == Gp.id2end
+        assert lg.snapshot() == alngraph.graph_snapshot(Gp)
+        via_arrays = alngraph.LoopGraph(Gp)
+        assert via_arrays.snapshot() == lg.snapshot()
+        assert lg._dll.rv_graph_literal(lg._g) == (1 if Gp.literal_segments else 0)
+        assert lg.counts() == via_arrays.counts() == (len(Gp.seq_nodes()), Gp.number_of_edges())
+        # and back into Python objects
+        n = lg.load_into(Gn)
+        assert n == Gp.number_of_nodes() and alngraph.graph_snapshot(Gn) == alngraph.graph_snapshot(Gp)
+        assert len(Gn.startnodes) == len(Gp.startnodes) and len(Gn.endnodes) == len(Gp.endnodes)
+        lg.close(); via_arrays.close()
+
+
+def test_reader_behind_the_abi_refuses_the_reverse_strand(tmp_path):
+    bad = tmp_path / "rev.gfa"
+    bad.write_text("S\t1\tACGT\nS\t2\tTTTT\nL\t1\t+\t2\t-\t0M\nP\tp\t1+,2-\t0M\n")
+    with pytest.raises(alngraph.ReverseStrand):
+        alngraph.LoopGraph.read([str(bad)], C.TextOnly(), alngraph.AlnGraph())
+    broken = tmp_path / "broken.gfa"
+    broken.write_text("S\t1\tACGT\nS\t2\tTTTT\nP\tp\t1+,2+\t0M\n")
+    with pytest.raises(ValueError, match="link"):
+        alngraph.LoopGraph.read([str(broken)], C.TextOnly(), alngraph.AlnGraph())

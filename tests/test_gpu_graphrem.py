@@ -152,8 +152,9 @@ def test_graph_inputs_native_callbacks_write_the_same_gfa(tmp_path, kw):
     spelled, _ = C.spelled_by_file(fn)
     assert spelled == C.input_sequences(fa[:3])
     if not kw:
-        g_abc = fn
-        fn = _both_ways(tmp_path, [g_abc, g_cd], "gg2")      # (1c on both sides: two paths of the same sequence)
+        fn = _both_ways(tmp_path, [fa[3], fn], "fg3")      # (a graph of a graph: level 2)
+        spelled, _ = C.spelled_by_file(fn)
+        assert spelled == C.input_sequences(fa)
 
 
 def test_multi_sequence_samples_native_callbacks(tmp_path):

@@ -332,7 +332,7 @@ typedef struct {
  * skipmums: reveal.c:802, 830-837, 1157, 1180) under the linear interval model -- `reveal rem a.fa b.fa` with its defaults, no Python callback per
  * sub-index.  Kind 1 takes inputs with one sequence per sample; the scans hand their whole lists to the host (no device-side pick, no leaf
  * kernel, no anchor cascade); rv_fetch_anchors hands out an anchor's members in the picker's order (the scan's emission order), not sorted.  rv_picker_info: out[0] kind, out[1] picker calls of the last run, out[2] of them seeded, out[3] nanoseconds inside rv_pick_chain,
- * out[4] nanoseconds putting the lists together (five values). */
+ * out[4] nanoseconds putting the lists together, out[5] nanoseconds inside graphalign (kind 2, rv_set_graph_picker); six values. */
 int rv_set_picker(rv_index *h, int kind, const rv_picker_args *args);
 int rv_picker_info(const rv_index *h, int64_t *out);
 int rv_pick_chain(const rv_picker_args *args, int nsub, int64_t m, const uint32_t *l, const int32_t *n, const int64_t *off, const uint16_t *so,

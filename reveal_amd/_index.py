@@ -615,9 +615,9 @@ def make_index_type(sa64, error):
                 self._fail()
 
         def picker_info(self):
-            o = (ctypes.c_int64 * 5)()
+            o = (ctypes.c_int64 * 6)()
             self._dll.rv_picker_info(self._h, o)
-            return dict(kind=int(o[0]), calls=int(o[1]), seeded=int(o[2]), picker_s=o[3] / 1e9, lists_s=o[4] / 1e9)
+            return dict(kind=int(o[0]), calls=int(o[1]), seeded=int(o[2]), picker_s=o[3] / 1e9, lists_s=o[4] / 1e9, graphalign_s=o[5] / 1e9)
 
         def _result_buffers_free(self):
             """the result arrays of the previous call, when nothing but this object refers to them (or to a view of them) any more"""

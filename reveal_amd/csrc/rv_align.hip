@@ -160,7 +160,7 @@ struct Align {
     rv_graph *ggraph = nullptr;
     std::vector<RvGraphIv> g_left, g_right, g_newleft, g_newright;
     RvGraphAlignOut g_out;
-    int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0;
+    int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0, galign_ns = 0;
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
     int64_t presel_d2h = 0;            // records the scans of this alignment copied to the host while pre-selection was on (RV_PRESEL_LOG)
@@ -432,7 +432,7 @@ int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args) {
 int rv_picker_info(const rv_index *h, int64_t *out) {
     if (!h || !out) return -1;
     out[0] = h->al ? h->al->picker : 0; out[1] = h->al ? h->al->picker_calls : 0; out[2] = h->al ? h->al->picker_seeded : 0;
-    out[3] = h->al ? h->al->picker_ns : 0; out[4] = h->al ? h->al->picker_list_ns : 0;
+    out[3] = h->al ? h->al->picker_ns : 0; out[4] = h->al ? h->al->picker_list_ns : 0; out[5] = h->al ? h->al->galign_ns : 0;
     return 0;
 }
 int rv_set_preselect(rv_index *h, int64_t maxmums) {
@@ -1573,7 +1573,7 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
     Align *a = h->al;
     a->full_only = !a->trace_on && a->picker == 0;      // (the chain picker looks at every match of a sub-index: the scans hand their whole lists to the host)
     a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
-    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear(); a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = 0;
+    a->seeds_cur.clear(); a->seeds_lead.clear(); a->seeds_trail.clear(); a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = a->galign_ns = 0;
     if (a->picker == 1) {
         if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
         if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
@@ -1894,7 +1894,9 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     // by walking the graph around the merged node
                     RvGraphAlignOut &GO = a->g_out;
                     static_assert(sizeof(RvGraphIv) == sizeof(RvIntv), "interval layouts");
+                    const double tg0 = now_s();
                     RV_TRY(rv_graph_do_align(a->ggraph, (const RvGraphIv *)nodes, nn, a->g_left[(size_t)s], a->g_right[(size_t)s], bl, pk_pos.data(), (int)sp.size(), GO));
+                    a->galign_ns += (int64_t)((now_s() - tg0) * 1e9);
                     a->g_newleft[(size_t)s] = GO.newleft; a->g_newright[(size_t)s] = GO.newright;
                     auto cp = [](std::vector<RvIntv> &d, const std::vector<RvGraphIv> &v) { for (const RvGraphIv &x : v) d.push_back({x.b, x.e}); };
                     cp(lead, GO.lead); cp(trail, GO.trail); cp(match, GO.match); cp(rest, GO.rest);
@@ -2350,7 +2352,7 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
             if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
             if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
         }
-        a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = 0;
+        a->picker_calls = a->picker_seeded = 0; a->picker_ns = a->picker_list_ns = a->galign_ns = 0;
         a->an_l.clear(); a->an_off.assign(1, 0); a->an_pos.clear(); a->trace.clear(); a->leaf_na = 0;
         RV_TRY(builtin_leaf_setup(h));
     }

@@ -81,7 +81,18 @@ static int node_of(rv_graph *g, int64_t b, int64_t e, const char *what) {
 int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv left, RvGraphIv right, uint32_t l, const int64_t *pos, int npos, RvGraphAlignOut &O) {
     O.lead.clear(); O.trail.clear(); O.match.clear(); O.rest.clear();
     std::vector<int> mine; mine.reserve(nn + 2 * (size_t)npos);
-    for (size_t i = 0; i < nn; i++) { const int x = node_of(g, nodes[i].b, nodes[i].e, "interval of the sub-index"); if (x < 0) return -1; mine.push_back(x); }
+    {   // (the intervals come sorted, and neighbours in the sub-index are mostly neighbours in the graph's position map: the next entry is tried before a search from
+        //  the root -- 4 x 10^5 searches per level were most of graphalign's time in a merge of five graphs of 8 x 10^4 nodes)
+        auto it = g->at.end();
+        for (size_t i = 0; i < nn; i++) {
+            if (it != g->at.end()) { ++it; if (it != g->at.end() && it->first != nodes[i].b) it = g->at.end(); }
+            if (it == g->at.end()) it = g->at.find(nodes[i].b);
+            if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[i].e) {
+                rv_set_error("graph: interval of the sub-index [%lld,%lld) is not a node of the graph", (long long)nodes[i].b, (long long)nodes[i].e); return -1;
+            }
+            mine.push_back(it->second);
+        }
+    }
     std::vector<int> mns;
     for (int q = 0; q < npos; q++) {
         O.match.push_back({pos[q], pos[q] + (int64_t)l});

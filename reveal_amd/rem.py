@@ -311,7 +311,7 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
         loop.finish()
         _stages.mark("renumber")
         picker.calls = idx.picker_info()["calls"]
-        _stages.report("picker %(calls)d calls (%(seeded)d seeded), pick %(picker_s).3f s, lists %(lists_s).3f s" % idx.picker_info())
+        _stages.report("picker %(calls)d calls (%(seeded)d seeded), pick %(picker_s).3f s, lists %(lists_s).3f s, graphalign %(graphalign_s).3f s" % idx.picker_info())
         aligner.calls += len(res["anchors"][0])
         idx._nodes = set(root_nodes)
         G.native = loop

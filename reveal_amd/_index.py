@@ -250,6 +250,8 @@ def make_index_type(sa64, error):
 
         @property
         def nodes(self):
+            if self.__dict__.get("_nodes_stale"):      # (sequences were added inside the library: rv_graph_read_gfa -- 10^7 tuples are made when somebody asks)
+                self._sync_nodes()
             return self._nodes
 
         @property
@@ -589,6 +591,7 @@ def make_index_type(sa64, error):
 
         def _sync_nodes(self):
             """sequences added inside the library (rv_graph_read_gfa) into this object's interval set"""
+            self._nodes_stale = False
             k = self._dll.rv_nnodes(self._h)
             if k != len(self._nodes):
                 buf = np.zeros(2 * max(k, 1), np.int64)

@@ -588,6 +588,10 @@ class LoopGraph(NativeGraph):
         self._g = dll.rv_graph_new()
         if not self._g:
             raise MemoryError(self._lib.err())
+        if getattr(idx, "_h", None) is not None:
+            # one allocation of the (page-locked) host text: a file is never shorter than the text it adds
+            total = sum(os.path.getsize(f) for f in inputfiles if not f.endswith(".gz"))
+            dll.rv_reserve_text(idx._h, int(dll.rv_n(idx._h)) + total + 64)
         for f in inputfiles:
             if f.endswith(".gfa") or f.endswith(".gfa.gz"):
                 idx.addsample(os.path.basename(f))
@@ -622,7 +626,8 @@ class LoopGraph(NativeGraph):
                     if dll.rv_graph_add_linear(self._g, b, e, 1 if name.startswith("*") else 0) != sid:
                         raise RuntimeError("path ids out of step: " + self._lib.err())
         if hasattr(idx, "_sync_nodes"):
-            idx._sync_nodes()
+            idx._nodes_stale = True      # (idx.nodes asks the library when somebody looks)
+            idx._constructed = False
         k = dll.rv_graph_paths(self._g, None)
         import numpy as np
         ends = np.zeros(max(k, 1), np.int64)

@@ -199,7 +199,7 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     // carries the sample side (rv_common.h) --, block by block so that the test reads what the copy just left in the cache; four threads
     // above 4 MB (250 Mbp: 60 ms -> 12 ms; a stream of inputs is assembled while the GPU works on the one before)
     const int64_t s = h->n;
-    (void)hipSetDevice(h->device);      // (a large text is page-locked memory)
+    if ((size_t)(h->n + len + 2) > h->T.cap) (void)hipSetDevice(h->device);      // (a large text is page-locked memory; 10^7 segments of a graph each find the room there)
     if (h->T.resize((size_t)(h->n + len + 2)) != 0) return -1;
     char *dst = h->T.data() + h->n;
     auto copy_check = [dst, seq](int64_t lo, int64_t hi) -> uint64_t {

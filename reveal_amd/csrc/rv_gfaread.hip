@@ -59,7 +59,18 @@ struct Fields {      // the first columns of a tab-separated line
 };
 
 int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len) {
+    // segment names: the numbers 1 .. N in files reveal writes -- a table then, not a hash look-up per step of every path (10^8 steps in the last job of config 5);
+    // any other name moves all of them into the map
     std::unordered_map<std::string_view, int> nmap;
+    std::vector<int> by_number;
+    std::vector<std::string_view> snames;      // (kept while the table serves, for the move)
+    bool numbered = true;
+    auto number_of = [](std::string_view id, int64_t limit) -> int64_t {
+        if (id.empty() || id.size() > 10 || (id.size() > 1 && id[0] == '0')) return -1;
+        int64_t v = 0;
+        for (char ch : id) { if (ch < '0' || ch > '9') return -1; v = v * 10 + (ch - '0'); }
+        return v < limit ? v : -1;
+    };
     std::vector<std::string_view> llines, plines;
     const size_t first_node = g->nodes.size();
     std::string up;
@@ -68,9 +79,10 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
     {
         size_t lines = 0;
         for (int64_t i = 0; i < len; i++) lines += data[i] == '\n';
-        nmap.reserve(lines);
+        by_number.assign(lines + 2, -1);
         g->nodes.reserve(g->nodes.size() + lines + 64);
     }
+    const int64_t number_limit = (int64_t)by_number.size();
     for (int64_t at = 0; at < len;) {
         const char *nl = (const char *)memchr(data + at, '\n', (size_t)(len - at));
         const int64_t end = nl ? nl - data : len;
@@ -86,11 +98,27 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
             int64_t b = 0, e = 0;
             if (h) { if (rv_add_sequence(h, up.data(), (int64_t)up.size(), &b, &e) != 0) return -1; }
             else { b = *text_n; e = b + (int64_t)up.size(); *text_n = e + 1; }
-            nmap[c.f[1]] = g->new_node(b, e, 0);
+            const int x = g->new_node(b, e, 0);
+            if (numbered) {
+                const int64_t num = number_of(c.f[1], number_limit);
+                if (num >= 0) { by_number[(size_t)num] = x; snames.push_back(c.f[1]); }
+                else {
+                    numbered = false;
+                    nmap.reserve(by_number.size());
+                    for (std::string_view nm : snames) nmap[nm] = by_number[(size_t)number_of(nm, number_limit)];
+                    snames.clear(); snames.shrink_to_fit();
+                }
+            }
+            if (!numbered) nmap[c.f[1]] = x;
         } else if (line[0] == 'L') llines.push_back(line);
         else if (line[0] == 'P') plines.push_back(line);
     }
     auto node_named = [&](std::string_view id) -> int {
+        if (numbered) {
+            const int64_t num = number_of(id, number_limit);
+            if (num >= 0 && by_number[(size_t)num] >= 0) return by_number[(size_t)num];
+            rv_set_error("read_gfa: no segment named '%.*s'", (int)std::min<size_t>(id.size(), 60), id.data()); return -1;
+        }
         auto it = nmap.find(id);
         if (it == nmap.end()) { rv_set_error("read_gfa: no segment named '%.*s'", (int)std::min<size_t>(id.size(), 60), id.data()); return -1; }
         return it->second;

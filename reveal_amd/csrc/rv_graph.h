@@ -24,16 +24,18 @@ struct GNode {
     std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
     std::vector<int> succ, pred;                    // edge ids, in dictionary order
 };
-// The path ids an edge carries.  A graph of up to 64 paths keeps them as one word (uniting two sets, and asking for a member, cost an
-// instruction instead of an allocation: anchors' surgery spent most of its time in malloc); more paths: a sorted vector as before.
+// The path ids an edge carries.  A graph of up to 256 paths keeps them as four words (uniting two sets, and asking for a member, cost a few instructions
+// instead of an allocation: the anchors' surgery spent most of its time in malloc -- and again when the last job of config 5, a hundred paths, outgrew the
+// one word this began with: 64 of graphalign's 73 us per call); more paths: a sorted vector as before.
 struct PathSet {
-    uint64_t m = 0;
+    static constexpr int W = 4;
+    uint64_t m[W] = {0, 0, 0, 0};
     std::vector<int> v;        // used when `big`
     bool big = false;
     PathSet() = default;
     explicit PathSet(const std::vector<int> &ids) { for (int p : ids) add(p); }
     void add(int p) {
-        if (!big && p >= 0 && p < 64) { m |= 1ull << p; return; }
+        if (!big && p >= 0 && p < 64 * W) { m[p >> 6] |= 1ull << (p & 63); return; }
         grow();
         auto it = std::lower_bound(v.begin(), v.end(), p);
         if (it == v.end() || *it != p) v.insert(it, p);
@@ -41,20 +43,25 @@ struct PathSet {
     void grow() {
         if (big) return;
         big = true;
-        for (int q = 0; q < 64; q++) if ((m >> q) & 1ull) v.push_back(q);
-        m = 0;
+        for (int q = 0; q < 64 * W; q++) if ((m[q >> 6] >> (q & 63)) & 1ull) v.push_back(q);
+        for (int w = 0; w < W; w++) m[w] = 0;
     }
     void unite(const PathSet &o) {
-        if (!big && !o.big) { m |= o.m; return; }
+        if (!big && !o.big) { for (int w = 0; w < W; w++) m[w] |= o.m[w]; return; }
         grow();
         if (o.big) { std::vector<int> r; r.reserve(v.size() + o.v.size()); std::set_union(v.begin(), v.end(), o.v.begin(), o.v.end(), std::back_inserter(r)); v.swap(r); }
-        else for (int q = 0; q < 64; q++) if ((o.m >> q) & 1ull) add(q);
+        else for (int q = 0; q < 64 * W; q++) if ((o.m[q >> 6] >> (q & 63)) & 1ull) add(q);
     }
-    bool has(int p) const { return big ? std::binary_search(v.begin(), v.end(), p) : (p >= 0 && p < 64 && ((m >> p) & 1ull)); }
-    size_t size() const { return big ? v.size() : (size_t)__builtin_popcountll(m); }
+    bool has(int p) const { return big ? std::binary_search(v.begin(), v.end(), p) : (p >= 0 && p < 64 * W && ((m[p >> 6] >> (p & 63)) & 1ull)); }
+    size_t size() const {
+        if (big) return v.size();
+        size_t c = 0;
+        for (int w = 0; w < W; w++) c += (size_t)__builtin_popcountll(m[w]);
+        return c;
+    }
     template <class F> void each(F f) const {      // ascending
         if (big) { for (int p : v) f(p); return; }
-        for (uint64_t x = m; x; x &= x - 1) f(__builtin_ctzll(x));
+        for (int w = 0; w < W; w++) for (uint64_t x = m[w]; x; x &= x - 1) f(64 * w + __builtin_ctzll(x));
     }
 };
 struct GEdge { int u, v; PathSet paths; };
@@ -76,6 +83,7 @@ struct rv_graph {
     bool literal_segments = false;                  // segmentgraph in the reference's form (alngraph.check_segment_shortcut said no)
     std::vector<uint32_t> stamp, stamp2; uint32_t epoch = 0;      // scratch of the walks: visited marks per node
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
+    std::vector<int64_t> orig_b; std::vector<int> orig_id;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
     void *align_out();
     ~rv_graph();
@@ -157,14 +165,16 @@ struct rv_graph {
     // rem.py:133-200: the first node absorbs the others
     int mergenodes(const std::vector<int> &mns) {
         const int ref = mns[0];
-        std::vector<std::pair<int, int64_t>> merged;
+        std::vector<std::pair<int, int64_t>> merged;      // an ordered mapping path -> offset: a later node's value for a path that is there replaces it in place
         for (int x : mns)
             for (auto &a : nodes[(size_t)x].off) {
-                bool found = false;
-                for (auto &m : merged) if (m.first == a.first) { m.second = a.second; found = true; break; }
-                if (!found) merged.push_back(a);
+                if ((size_t)a.first >= pmark.size()) { pmark.resize((size_t)a.first + 64, 0); pwhere.resize(pmark.size(), 0); }
+                if (pwhere.size() < pmark.size()) pwhere.resize(pmark.size(), 0);
+                if (pmark[(size_t)a.first]) merged[(size_t)pwhere[(size_t)a.first]].second = a.second;
+                else { pmark[(size_t)a.first] = 1; pwhere[(size_t)a.first] = (int32_t)merged.size(); merged.push_back(a); }
             }
-        nodes[(size_t)ref].off = merged;
+        for (auto &a : merged) pmark[(size_t)a.first] = 0;
+        nodes[(size_t)ref].off.swap(merged);
         nodes[(size_t)ref].aligned = 1;
         for (size_t k = 1; k < mns.size(); k++) {
             const int x = mns[k];
@@ -200,6 +210,7 @@ struct rv_graph {
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
+        orig_b.clear(); orig_id.clear();
     }
     void finish() {
         order.clear();

@@ -10,6 +10,8 @@
 // Scope: the native picker's -- FASTA inputs, one sequence per sample (path id = sample), every edge on the forward strand.
 // Test infrastructure compares it with the Python surgery node for node and edge for edge (tests/test_cpu_graph_native.py).
 #include "rv_graph.h"
+#include <atomic>
+#include <thread>
 
 void rv_graph_align_out_free(void *p);      // rv_graphrem.hip
 rv_graph::~rv_graph() { if (align_out_) rv_graph_align_out_free(align_out_); }
@@ -171,7 +173,6 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
     int nid = 0;
     for (int x : g->order) if (nodes[(size_t)x].aligned >= 0) ident[(size_t)x] = ++nid;
     o += "H\tVN:Z:1.0\tCL:Z:"; o += cmdline ? cmdline : ""; o += "\n";
-    char buf[96];
     {
         size_t need = 256;
         for (int x : g->order) { const GNode &n = nodes[(size_t)x]; if (n.aligned >= 0) need += (size_t)(n.e - n.b) + 16 + 40 * n.succ.size() + 24 * n.off.size(); }
@@ -192,9 +193,12 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
             o += "L\t"; put_int(o, ident[(size_t)x]); o += "\t+\t"; put_int(o, ident[(size_t)v]); o += "\t+\t0M\n";
         }
     }
-    // the start sentinels in the reader's order (start_of: sample s' is node 3 s of the replay, wherever compact() has moved it)
-    for (int sid = 0; sid < npaths; sid++) {
+    // the start sentinels in the reader's order (start_of: sample s' is node 3 s of the replay, wherever compact() has moved it).  The walks are independent of each
+    // other and read only: on a few threads (a hundred paths of 10^6 steps each, a cache miss per step, were half of the writer's time)
+    std::vector<std::string> plines((size_t)std::max(npaths, 0));
+    auto walk = [&](int sid) {
         std::string path, cigar;
+        char pbuf[32];
         for (size_t sq = 0; sq < g->start_of.size(); sq++) {
             const size_t st = (size_t)g->start_of[sq];
             bool has = false;
@@ -208,16 +212,30 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
                 if (nout != 1) break;
                 if (nodes[(size_t)v].sent == 2) break;      // an end sentinel
                 if (nodes[(size_t)v].aligned >= 0) {
-                    const int w = snprintf(buf, sizeof buf, "%s%d+", path.empty() ? "" : ",", ident[(size_t)v]);
-                    path.append(buf, (size_t)w);
+                    const int w = snprintf(pbuf, sizeof pbuf, "%s%d+", path.empty() ? "" : ",", ident[(size_t)v]);
+                    path.append(pbuf, (size_t)w);
                     if (nodes[(size_t)node].aligned >= 0) { cigar += cigar.empty() ? "0M" : ",0M"; }
                 }
                 node = v;
             }
             break;
         }
-        o += "P\t"; o += names[sid]; o += "\t"; o += path; o += "\t"; o += cigar; o += "\n";
+        std::string &ln = plines[(size_t)sid];
+        ln.reserve(path.size() + cigar.size() + 64);
+        ln += "P\t"; ln += names[sid]; ln += "\t"; ln += path; ln += "\t"; ln += cigar; ln += "\n";
+    };
+    {
+        int nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+        nt = std::min(nt, npaths);
+        if (nodes.size() < 100000) nt = 1;
+        std::atomic<int> next{0};
+        auto worker = [&]() { for (;;) { const int sid = next.fetch_add(1); if (sid >= npaths) return; walk(sid); } };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) { try { th.emplace_back(worker); } catch (...) { break; } }
+        worker();
+        for (auto &t : th) t.join();
     }
+    for (int sid = 0; sid < npaths; sid++) o += plines[(size_t)sid];
     *out = o.data();
     return (int64_t)o.size();
 }

@@ -81,16 +81,32 @@ static int node_of(rv_graph *g, int64_t b, int64_t e, const char *what) {
 int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv left, RvGraphIv right, uint32_t l, const int64_t *pos, int npos, RvGraphAlignOut &O) {
     O.lead.clear(); O.trail.clear(); O.match.clear(); O.rest.clear();
     std::vector<int> mine; mine.reserve(nn + 2 * (size_t)npos);
-    {   // (the intervals come sorted, and neighbours in the sub-index are mostly neighbours in the graph's position map: the next entry is tried before a search from
-        //  the root -- 4 x 10^5 searches per level were most of graphalign's time in a merge of five graphs of 8 x 10^4 nodes)
-        auto it = g->at.end();
+    {   // The intervals come sorted.  Most of them, in the levels where there are many, are nodes the inputs brought along: those are looked up in a sorted table
+        // of begins made once (read one after the other: no search from the root of the position map, no cache miss per node -- 4 x 10^5 searches per level were
+        // most of graphalign's time in a merge of five graphs of 8 x 10^4 nodes); a node the surgery made, or an entry whose node is gone, goes to the map.
+        if (g->orig_b.empty() && nn >= 64) {
+            g->orig_b.reserve(g->at.size()); g->orig_id.reserve(g->at.size());
+            for (auto &kv : g->at) { g->orig_b.push_back(kv.first); g->orig_id.push_back(kv.second); }
+        }
+        const size_t K = g->orig_b.size();
+        size_t k = K ? (size_t)(std::lower_bound(g->orig_b.begin(), g->orig_b.end(), nn ? nodes[0].b : 0) - g->orig_b.begin()) : 0;
         for (size_t i = 0; i < nn; i++) {
-            if (it != g->at.end()) { ++it; if (it != g->at.end() && it->first != nodes[i].b) it = g->at.end(); }
-            if (it == g->at.end()) it = g->at.find(nodes[i].b);
-            if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[i].e) {
-                rv_set_error("graph: interval of the sub-index [%lld,%lld) is not a node of the graph", (long long)nodes[i].b, (long long)nodes[i].e); return -1;
+            const int64_t b = nodes[i].b;
+            int x = -1;
+            if (k < K && g->orig_b[k] < b) {
+                int step = 0;
+                while (k < K && g->orig_b[k] < b && step < 8) { k++; step++; }
+                if (k < K && g->orig_b[k] < b) k = (size_t)(std::lower_bound(g->orig_b.begin() + (ptrdiff_t)k, g->orig_b.end(), b) - g->orig_b.begin());
             }
-            mine.push_back(it->second);
+            if (k < K && g->orig_b[k] == b) { const int c = g->orig_id[k]; if (g->nodes[(size_t)c].alive && g->nodes[(size_t)c].b == b && g->nodes[(size_t)c].e == nodes[i].e) x = c; }
+            if (x < 0) {
+                auto it = g->at.find(b);
+                if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[i].e) {
+                    rv_set_error("graph: interval of the sub-index [%lld,%lld) is not a node of the graph", (long long)b, (long long)nodes[i].e); return -1;
+                }
+                x = it->second;
+            }
+            mine.push_back(x);
         }
     }
     std::vector<int> mns;
@@ -112,13 +128,13 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     std::vector<uint8_t> &in_sub = g->mark;
     if (in_sub.size() < g->nodes.size()) in_sub.resize(g->nodes.size() + g->nodes.size() / 4 + 64, 0);
     std::vector<int> cur; cur.reserve(mine.size());
+    for (int m2 : mns) in_sub[(size_t)m2] = 2;      // (never the match nodes -- marked, not compared one by one: a hundred members times 10^7 nodes per level)
     for (int x : mine) {
         const GNode &n = g->nodes[(size_t)x];
-        bool is_match = false;
-        for (int m2 : mns) is_match |= m2 == x;
-        if (!n.alive || is_match || in_sub[(size_t)x]) continue;
+        if (!n.alive || in_sub[(size_t)x]) continue;
         in_sub[(size_t)x] = 1; cur.push_back(x);
     }
+    for (int m2 : mns) in_sub[(size_t)m2] = 0;
     auto side = [&](bool reverse, std::vector<int> &res) {
         std::vector<BfsHit> hits; std::vector<int> queue;
         bfs(g, mn, reverse, nullptr, hits, queue);
@@ -152,18 +168,21 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     if (msam.size() < g->id2end.size() + 1) msam.resize(g->id2end.size() + 64, 0);
     int maxsid = -1;
     for (auto &a : g->nodes[(size_t)mn].off) { if ((size_t)a.first >= msam.size()) msam.resize((size_t)a.first + 64, 0); msam[(size_t)a.first] = 1; maxsid = std::max(maxsid, a.first); }
+    // "clean": every path of every leading (trailing) node crosses the merged node.  A merged node on every path of the graph settles it; one offending node does,
+    // too (the walk over a node's offsets was the larger half of this loop: 10^7 nodes per level, tens of paths through each)
+    const bool covers_all = g->nodes[(size_t)mn].off.size() >= g->id2end.size() && !g->id2end.empty();
     bool lead_clean = true, trail_clean = true;
     for (int x : cur) {
         const GNode &n = g->nodes[(size_t)x];
         const uint8_t c = cls[(size_t)x];
-        if (c & 1) { O.lead.push_back({n.b, n.e}); for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) lead_clean = false; }
-        if (c & 2) { O.trail.push_back({n.b, n.e}); for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) trail_clean = false; }
+        if (c & 1) { O.lead.push_back({n.b, n.e}); if (lead_clean && !covers_all) for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) { lead_clean = false; break; } }
+        if (c & 2) { O.trail.push_back({n.b, n.e}); if (trail_clean && !covers_all) for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) { trail_clean = false; break; } }
         if (!c) O.rest.push_back({n.b, n.e});
     }
     for (auto &a : g->nodes[(size_t)mn].off) msam[(size_t)a.first] = 0;
     for (int x : cur) { in_sub[(size_t)x] = 0; cls[(size_t)x] = 0; }
     auto by_b = [](const RvGraphIv &a, const RvGraphIv &b) { return a.b < b.b; };
-    std::sort(O.lead.begin(), O.lead.end(), by_b); std::sort(O.trail.begin(), O.trail.end(), by_b); std::sort(O.rest.begin(), O.rest.end(), by_b);
+    for (std::vector<RvGraphIv> *v : {&O.lead, &O.trail, &O.rest}) if (!std::is_sorted(v->begin(), v->end(), by_b)) std::sort(v->begin(), v->end(), by_b);
     O.merged = {g->nodes[(size_t)mn].b, g->nodes[(size_t)mn].e};
     O.newleft = O.newright = O.merged;
     if (!lead_clean) O.newright = right;        // no clean dissection of all paths on the left (rem.py:367-370)
@@ -276,7 +295,6 @@ int rv_graph_do_pick(rv_graph *g, const rv_picker_args *A, int nsub, int64_t m, 
         if (x < 0) return -1;
         for (int j = 0; j < k; j++) { int64_t o; if (!off_of(g->nodes[(size_t)x], last[(size_t)j], &o)) { rv_set_error("rv_graph_pick: the right node is not on path %d (the reference raises KeyError here)", last[(size_t)j]); return -2; } rt[(size_t)j] = o; }
     } else for (int j = 0; j < k; j++) { if ((size_t)last[(size_t)j] >= g->id2end.size()) { rv_set_error("rv_graph_pick: path without a length"); return -1; } rt[(size_t)j] = g->id2end[(size_t)last[(size_t)j]]; }
-    auto coord = [&](size_t i, int j) -> int64_t { for (uint32_t z = 0; z < rel[i].cnt; z++) if (pt[rel[i].first + z].first == last[(size_t)j]) return pt[rel[i].first + z].second; return 0; };
     size_t split;
     std::vector<std::pair<size_t, int64_t>> chained;
     if (relm.size() == 1) split = relm[0];
@@ -284,9 +302,15 @@ int rv_graph_do_pick(rv_graph *g, const rv_picker_args *A, int nsub, int64_t m, 
         if (A->maxmums > 0 && (int64_t)relm.size() > A->maxmums) relm.erase(relm.begin(), relm.end() - (ptrdiff_t)A->maxmums);      // :287-289
         const int64_t mc = (int64_t)relm.size();
         std::vector<uint32_t> cl((size_t)mc); std::vector<int32_t> cn((size_t)mc); std::vector<int64_t> crd((size_t)mc * k), oi((size_t)mc), osc((size_t)mc);
+        std::vector<std::pair<int32_t, int64_t>> row((size_t)k);
         for (int64_t i = 0; i < mc; i++) {
             cl[(size_t)i] = (uint32_t)mm[relm[(size_t)i]].l; cn[(size_t)i] = rel[relm[(size_t)i]].n;
-            for (int j = 0; j < k; j++) crd[(size_t)i * k + j] = coord(relm[(size_t)i], j);
+            // (the match's paths ARE `last`, as a set: its pairs sorted by path id are the row -- looked up one by one they cost k^2 per match, 10^7 steps per call of
+            //  a hundred paths and a thousand matches)
+            const RelMum &r = rel[relm[(size_t)i]];
+            std::copy(pt.begin() + r.first, pt.begin() + r.first + r.cnt, row.begin());
+            std::sort(row.begin(), row.end(), [](const std::pair<int32_t, int64_t> &a, const std::pair<int32_t, int64_t> &b) { return a.first < b.first; });
+            for (int j = 0; j < k; j++) crd[(size_t)i * k + j] = row[(size_t)j].second;
         }
         const int64_t r = rv_chain(mc, k, cl.data(), cn.data(), crd.data(), lf.data(), rt.data(), A->wscore, A->wpen, A->gcmodel, oi.data(), osc.data());
         if (r < 0) return -1;

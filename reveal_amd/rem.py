@@ -298,7 +298,7 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
     if native is None:      # (REVEAL_AMD_NATIVE=0 in the environment, or --no-native on the command line: the Python callbacks)
         native = can_native and env_on
     _stages.mark("graph behind the ABI" if loop is not None else "setup")
-    root_nodes = sorted(tuple(x) for x in idx.nodes)
+    root_nodes = sorted(tuple(x) for x in idx.nodes) if loop is None else None
     idx.construct()
     _stages.mark("construct")
     if loop is not None:
@@ -313,7 +313,6 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
         picker.calls = idx.picker_info()["calls"]
         _stages.report("picker %(calls)d calls (%(seeded)d seeded), pick %(picker_s).3f s, lists %(lists_s).3f s, graphalign %(graphalign_s).3f s" % idx.picker_info())
         aligner.calls += len(res["anchors"][0])
-        idx._nodes = set(root_nodes)
         G.native = loop
         if materialize:
             loop.load_into(G)

@@ -390,6 +390,11 @@ int rv_graph_paths(const rv_graph *g, int64_t *id2end);
 int rv_graph_node_kinds(const rv_graph *g, int8_t *out);
 int rv_graph_literal(const rv_graph *g);      /* 1: some node of the inputs does not go on in both directions -- segmentgraph walks back from its end points as the reference does */
 int rv_graph_finish(rv_graph *g);      /* renumber live nodes and links (after rv_graph_align, before rv_graph_sizes / rv_graph_export) */
+/* The same surgery as a follower of the run that chooses the anchors: rv_graph_replay_begin = the graph of the sequences alone; rv_set_replay_graph(h, g) makes the
+ * next rv_align_builtin (picker kind 1) apply every level's anchors to g on a host thread while the GPU works on the next level; when the run returns g is what
+ * rv_graph_replay would have made of its anchors.  g stays the caller's; NULL: off. */
+rv_graph *rv_graph_replay_begin(int nseq, const int64_t *begin, const int64_t *end);
+int rv_set_replay_graph(rv_index *h, rv_graph *g);
 rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos);
 const char *rv_graph_error(const rv_graph *g);
 int rv_graph_sizes(const rv_graph *g, int64_t *out);

@@ -589,6 +589,14 @@ def make_index_type(sa64, error):
             if r != 0:
                 self._fail()
 
+        def set_replay_graph(self, graph=None):
+            """rv_set_replay_graph: `graph` = alngraph.NativeGraph(G, root_nodes) without anchors; the next align_builtin with the native picker applies its anchors
+            to it as the levels go by (a host thread beside the GPU's work); None = off"""
+            if graph is not None and graph._dll is not self._dll:
+                raise error("the graph was made by the other build of the library (32 / 64-bit suffix arrays)")
+            if self._dll.rv_set_replay_graph(self._h, None if graph is None else graph._g) != 0:
+                self._fail()
+
         def _sync_nodes(self):
             """sequences added inside the library (rv_graph_read_gfa) into this object's interval set"""
             self._nodes_stale = False

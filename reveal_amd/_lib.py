@@ -139,6 +139,8 @@ SYMBOLS = {
     "rv_graph_finish": (_I, [V]),
     "rv_set_graph_picker": (_I, [V, V, V]),
     "rv_graph_new": (V, []),
+    "rv_graph_replay_begin": (V, [_I, V, V]),
+    "rv_set_replay_graph": (_I, [V, V]),
     "rv_graph_add_linear": (_I, [V, _L, _L, _I]),
     "rv_graph_read_gfa": (_L, [V, V, V, V, _L, V]),
     "rv_graph_paths": (_I, [V, V]),

@@ -375,7 +375,9 @@ class NativeGraph:
     surgery (rv_graph_replay), prune_nodes (rv_graph_prune), the GFA text (rv_graph_gfa) -- and, when somebody wants to look at it, the same graph as
     an AlnGraph (load_into).  `G` is the FASTA reader's graph of the inputs: it lends its path names and sentinels."""
 
-    def __init__(self, G, root_nodes, an_l, an_off, an_pos):
+    def __init__(self, G, root_nodes, an_l=None, an_off=None, an_pos=None, sa64=False):
+        """with anchors: the graph after their surgery (rv_graph_replay); without: the graph of the sequences alone (rv_graph_replay_begin), for
+        index.set_replay_graph -- the run that chooses the anchors then applies them level by level on a thread of its own"""
         import numpy as np
         from . import _lib
         self._g = None
@@ -384,9 +386,14 @@ class NativeGraph:
             raise ValueError("NativeGraph: the graph is not the FASTA reader's graph of these sequences")
         if [G.path2id[p] for p in G.paths] != list(range(k)):
             raise ValueError("NativeGraph: path ids are not the samples 0..k-1")
-        self._dll = _lib.get(False).dll
+        self._dll = _lib.get(bool(sa64)).dll
         self.names = list(G.paths)
         rb = np.ascontiguousarray([n[0] for n in root_nodes], dtype=np.int64); re_ = np.ascontiguousarray([n[1] for n in root_nodes], dtype=np.int64)
+        if an_l is None:
+            self._g = self._dll.rv_graph_replay_begin(k, rb.ctypes.data, re_.ctypes.data)
+            if not self._g:
+                raise MemoryError("rv_graph_replay_begin")
+            return
         an_l = np.ascontiguousarray(an_l, dtype=np.uint32); an_off = np.ascontiguousarray(an_off, dtype=np.int64); an_pos = np.ascontiguousarray(an_pos, dtype=np.int64)
         self._g = self._dll.rv_graph_replay(k, rb.ctypes.data, re_.ctypes.data, len(an_l), an_l.ctypes.data, an_off.ctypes.data, an_pos.ctypes.data)
         if not self._g:

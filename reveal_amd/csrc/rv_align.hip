@@ -158,6 +158,8 @@ struct Align {
     // rv_set_graph_picker (kind 2): graph inputs -- the picker and graphalign of `reveal rem` for graphs (rv_graphrem.hip) on the caller's rv_graph, called per
     // sub-index in the reference's order; per sub-index of the current level its left / right graph node (rem.py:318-382: graphalign hands the children theirs)
     rv_graph *ggraph = nullptr;
+    // rv_set_replay_graph (picker kind 1): the anchors' surgery follows the run level by level on a host thread of its own (rv_graph.hip RvReplayFeed)
+    rv_graph *replay_graph = nullptr; RvReplayFeed *feed = nullptr; size_t fed = 0;
     std::vector<RvGraphIv> g_left, g_right, g_newleft, g_newright;
     RvGraphAlignOut g_out;
     int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0, galign_ns = 0;
@@ -243,6 +245,7 @@ struct Align {
 };
 
 void rv_align_free(rv_index *h) {
+    if (h->al && h->al->feed) { (void)rv_replay_feed_finish(h->al->feed); h->al->feed = nullptr; }
     if (h->al) { h->al->release(); delete h->al; h->al = nullptr; }
 }
 
@@ -427,6 +430,16 @@ int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args) {
     h->al->picker = g ? 2 : 0;
     h->al->ggraph = g;
     if (g) h->al->pargs = *args;
+    return 0;
+}
+/* With picker kind 1: g = rv_graph_replay_begin's graph of the same sequences; the next whole run (rv_align_builtin) applies every level's anchors to it on a host
+ * thread while the GPU works on the next level, and returns with g as rv_graph_replay would have left it (the replay was a third of `reveal rem` on five genomes
+ * of 5 Mbp, all of it after the run).  One run; g = NULL: off.  Runs that stop at a frontier (rv_align_builtin_until) do not feed it. */
+int rv_set_replay_graph(rv_index *h, rv_graph *g) {
+    if (!h) { rv_set_error("rv_set_replay_graph: null handle"); return -1; }
+    if (!h->al) h->al = new Align();
+    if (h->al->feed) { (void)rv_replay_feed_finish(h->al->feed); h->al->feed = nullptr; }
+    h->al->replay_graph = g;
     return 0;
 }
 int rv_picker_info(const rv_index *h, int64_t *out) {
@@ -1928,6 +1941,10 @@ static int builtin_levels(rv_index *h, int stop_subs) {
             if (a->trace_on) a->trace.push_back(tr);
         }
         a->st.t_host += now_s() - t0;
+        if (a->feed && a->an_l.size() > a->fed) {      // this level's anchors to the surgery's thread
+            rv_replay_feed_push(a->feed, a->an_l.data() + a->fed, a->an_off.data() + a->fed, a->an_pos.data() + a->an_off[a->fed], a->an_l.size() - a->fed);
+            a->fed = a->an_l.size();
+        }
         const double tl1 = level_log ? now_s() : 0.0;
         RV_TRY(rv_frontier_commit(h, nullptr));
         if (a->picker == 2) {
@@ -2165,9 +2182,22 @@ const char *rv_cascade_why(const rv_index *h) {
 
 int rv_align_builtin(rv_index *h, int minl, int minn, rv_align_stats *out) {
     RV_TRY(builtin_setup(h, minl, minn));
-    RV_TRY(builtin_cascade(h));
-    RV_TRY(builtin_levels(h, 0));
-    return builtin_finish(h, out);
+    Align *a = h->al;
+    if (a->replay_graph && a->picker == 1) {
+        a->feed = rv_replay_feed_start(a->replay_graph);
+        a->fed = 0;
+        a->replay_graph = nullptr;      // (one run)
+        if (!a->feed) return -1;
+    }
+    int rc = builtin_cascade(h);
+    if (rc == 0) rc = builtin_levels(h, 0);
+    if (rc == 0) rc = builtin_finish(h, out);
+    if (a->feed) {
+        RvReplayFeed *f = a->feed; a->feed = nullptr;
+        if (rc == 0) { if (rv_replay_feed_finish(f) != 0) return -1; }
+        else { const std::string keep = rv_last_error(); (void)rv_replay_feed_finish(f); rv_set_error("%s", keep.c_str()); }
+    }
+    return rc;
 }
 
 /* ---- frontier hand-off (second granularity) ---------------------------

@@ -10,6 +10,7 @@
 // Scope: the native picker's -- FASTA inputs, one sequence per sample (path id = sample), every edge on the forward strand.
 // Test infrastructure compares it with the Python surgery node for node and edge for edge (tests/test_cpu_graph_native.py).
 #include "rv_graph.h"
+#include "rv_graphrem.h"
 #include <atomic>
 #include <thread>
 
@@ -19,9 +20,7 @@ rv_graph::~rv_graph() { if (align_out_) rv_graph_align_out_free(align_out_); }
 extern "C" {
 
 // (no exception may leave through the C ABI: bad_alloc from the vectors' growth becomes NULL / -1 and rv_last_error's text)
-static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
-    std::unique_ptr<rv_graph> own(new rv_graph());      // (freed when the surgery below throws)
-    rv_graph *g = own.get();
+static void replay_start(rv_graph *g, int nseq, const int64_t *begin, const int64_t *end) {
     g->nseq = nseq;
     // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
     for (int s = 0; s < nseq; s++) {
@@ -32,20 +31,36 @@ static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end
         PathSet only; only.add(s);
         g->add_edge(st, iv, only); g->add_edge(iv, en, only);
     }
-    std::vector<int> mns;
+}
+// anchors [0, na): member k of anchor a at an_pos[an_off[a] - an_off[0] + k]
+static bool replay_apply(rv_graph *g, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos, std::vector<int> &mns) {
+    const int64_t base = na ? an_off[0] : 0;
     for (int64_t a = 0; a < na; a++) {
         mns.clear();
         const int64_t l = (int64_t)an_l[a];
-        for (int64_t k = an_off[a]; k < an_off[a + 1]; k++) {
+        for (int64_t k = an_off[a] - base; k < an_off[a + 1] - base; k++) {
             const int x = g->node_at(an_pos[k]);
-            if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; g->finish(); return own.release(); }
+            if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; return false; }
             mns.push_back(g->breaknode(x, an_pos[k], l));
         }
         if (!mns.empty()) g->mergenodes(mns);
     }
+    return true;
+}
+static rv_graph *graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
+    std::unique_ptr<rv_graph> own(new rv_graph());      // (freed when the surgery below throws)
+    rv_graph *g = own.get();
+    replay_start(g, nseq, begin, end);
+    std::vector<int> mns;
+    if (!replay_apply(g, na, an_l, an_off, an_pos, mns)) { g->finish(); return own.release(); }
     g->compact();
     g->finish();
     return own.release();
+}
+/* the graph of the inputs alone (rv_graph_replay with no anchors, not renumbered): what rv_set_replay_graph feeds while a run goes on */
+rv_graph *rv_graph_replay_begin(int nseq, const int64_t *begin, const int64_t *end) {
+    try { std::unique_ptr<rv_graph> own(new rv_graph()); replay_start(own.get(), nseq, begin, end); return own.release(); }
+    catch (...) { rv_set_error("rv_graph_replay_begin: out of host memory"); return nullptr; }
 }
 rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, int64_t na, const uint32_t *an_l, const int64_t *an_off, const int64_t *an_pos) {
     try { return graph_replay(nseq, begin, end, na, an_l, an_off, an_pos); }
@@ -113,8 +128,7 @@ static int graph_prune(rv_graph *g, const char *T) {
         std::deque<int> queue(g->order.begin(), g->order.end());
         std::vector<char> queued(nodes.size(), 0);
         for (int x : queue) queued[(size_t)x] = 1;
-        std::vector<int> neis, again;
-        std::vector<std::vector<int>> groups;
+        std::vector<int> neis, again, rep, grp;
         while (!queue.empty()) {
             const int node = queue.front(); queue.pop_front(); queued[(size_t)node] = 0;
             if (!nodes[(size_t)node].alive) continue;
@@ -122,18 +136,26 @@ static int graph_prune(rv_graph *g, const char *T) {
                 neis.clear();
                 for (int e : (dir == 0 ? nodes[(size_t)node].succ : nodes[(size_t)node].pred)) neis.push_back(dir == 0 ? edges[(size_t)e].v : edges[(size_t)e].u);
                 if (neis.size() < 2) continue;
-                groups.clear();
-                for (int nei : neis) {
-                    const GNode &q = nodes[(size_t)nei];
+                // groups of neighbours that spell the same, in order of their first member; a group's members in the neighbours' order.  (rep[k] = the place of the
+                // first neighbour that spells like neighbour k: no list of lists made and thrown away per node -- most nodes have two neighbours that differ)
+                const size_t nk = neis.size();
+                rep.assign(nk, -1);
+                bool any_group = false;
+                for (size_t k = 0; k < nk; k++) {
+                    const GNode &q = nodes[(size_t)neis[k]];
                     if (q.aligned < 0) continue;
-                    bool placed = false;
-                    for (auto &grp : groups) {
-                        const GNode &r = nodes[(size_t)grp[0]];
-                        if (r.e - r.b == q.e - q.b && memcmp(T + r.b, T + q.b, (size_t)(q.e - q.b)) == 0) { grp.push_back(nei); placed = true; break; }
+                    rep[k] = (int)k;
+                    for (size_t j = 0; j < k; j++) {
+                        if (rep[j] != (int)j) continue;
+                        const GNode &r = nodes[(size_t)neis[j]];
+                        if (r.e - r.b == q.e - q.b && (q.e == q.b || T[r.b] == T[q.b]) && memcmp(T + r.b, T + q.b, (size_t)(q.e - q.b)) == 0) { rep[k] = (int)j; any_group = true; break; }
                     }
-                    if (!placed) groups.push_back({nei});
                 }
-                for (auto &grp : groups) {
+                if (!any_group) continue;
+                for (size_t k0 = 0; k0 < nk; k0++) {
+                    if (rep[k0] != (int)k0) continue;
+                    grp.clear();
+                    for (size_t k = k0; k < nk; k++) if (rep[k] == (int)k0) grp.push_back(neis[k]);
                     if (grp.size() < 2) continue;
                     bool single = true;
                     for (int v : grp) if ((dir == 0 ? nodes[(size_t)v].pred : nodes[(size_t)v].succ).size() > 1) { single = false; break; }
@@ -253,4 +275,64 @@ int64_t rv_graph_gfa(rv_graph *g, const char *T, int npaths, const char *const *
 
 void rv_graph_free(rv_graph *g) { delete g; }
 
-}  // extern "C"
+}
+
+// ---- the surgery as a follower of a running recursion (rv_graphrem.h) ------------------------------------------------------------------------------------------
+#include <condition_variable>
+#include <mutex>
+struct RvReplayFeed {
+    struct Chunk { std::vector<uint32_t> l; std::vector<int64_t> off, pos; };
+    rv_graph *g = nullptr;
+    std::thread th;
+    std::mutex mu; std::condition_variable cv;
+    std::deque<Chunk> q;
+    bool closed = false, failed = false;
+    std::string why;
+    void run() {
+        std::vector<int> mns;
+        for (;;) {
+            Chunk c;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return closed || !q.empty(); });
+                if (q.empty()) return;
+                c = std::move(q.front()); q.pop_front();
+            }
+            if (failed) continue;      // (drain)
+            try {
+                if (!replay_apply(g, (int64_t)c.l.size(), c.l.data(), c.off.data(), c.pos.data(), mns)) { failed = true; why = g->err; }
+            } catch (const std::exception &e) { failed = true; why = std::string("the anchors' surgery: ") + e.what(); }
+            catch (...) { failed = true; why = "the anchors' surgery failed"; }
+        }
+    }
+};
+RvReplayFeed *rv_replay_feed_start(rv_graph *g) {
+    try {
+        std::unique_ptr<RvReplayFeed> f(new RvReplayFeed());
+        f->g = g;
+        f->th = std::thread([p = f.get()] { p->run(); });
+        return f.release();
+    } catch (...) { rv_set_error("replay feed: no thread / memory to be had"); return nullptr; }
+}
+void rv_replay_feed_push(RvReplayFeed *f, const uint32_t *l, const int64_t *off, const int64_t *pos, size_t count) {
+    if (!count) return;
+    RvReplayFeed::Chunk c;
+    try {
+        c.l.assign(l, l + count); c.off.assign(off, off + count + 1); c.pos.assign(pos, pos + (off[count] - off[0]));
+        std::lock_guard<std::mutex> lk(f->mu);
+        f->q.push_back(std::move(c));
+    } catch (...) { std::lock_guard<std::mutex> lk(f->mu); f->failed = true; f->why = "replay feed: out of host memory"; }
+    f->cv.notify_one();
+}
+int rv_replay_feed_finish(RvReplayFeed *f) {
+    { std::lock_guard<std::mutex> lk(f->mu); f->closed = true; }
+    f->cv.notify_one();
+    if (f->th.joinable()) f->th.join();
+    const bool bad = f->failed;
+    const std::string why = f->why;
+    rv_graph *g = f->g;
+    delete f;
+    if (bad) { rv_set_error("%s", why.c_str()); return -1; }
+    try { g->compact(); g->finish(); } catch (...) { rv_set_error("replay feed: out of host memory"); return -1; }
+    return 0;
+}

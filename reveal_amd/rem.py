@@ -320,16 +320,20 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
             G.native = None
         return G, idx, picker, aligner
     if native:
+        # graphalign's surgery for every anchor, in the order the library chooses them, on a host thread that follows the run level by level (rv_set_replay_graph;
+        # replay_anchors / replay_anchors_fast are the same in Python, after the run: 25 s instead of 1.1 for five genomes of 5 Mbp)
         idx.set_picker(args)
-        l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
-        idx.set_picker(None)
-        _stages.mark("recursion")
+        ng = alngraph.NativeGraph(G, root_nodes, sa64=sa64)
+        idx.set_replay_graph(ng)
+        try:
+            l, off, pos = idx.align_builtin(minlength, minn)["anchors"]
+        finally:
+            idx.set_replay_graph(None)
+            idx.set_picker(None)
+        _stages.mark("recursion + graph")
         picker.calls = idx.picker_info()["calls"]
         idx._nodes = set(root_nodes)
-        # graphalign's surgery for every anchor, in the order the library chose them (replay_anchors / replay_anchors_fast are the same in Python:
-        # 25 s instead of 1.3 for five genomes of 5 Mbp)
-        G.native = alngraph.NativeGraph(G, root_nodes, l, off, pos)
-        _stages.mark("graph replay")
+        G.native = ng
         aligner.calls += len(l)
         if materialize:
             G.native.load_into(G)

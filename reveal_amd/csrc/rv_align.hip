@@ -165,6 +165,7 @@ struct Align {
     int64_t picker_calls = 0, picker_seeded = 0, picker_ns = 0, picker_list_ns = 0, galign_ns = 0;
     // pre-selection for the Python callbacks (rv_set_preselect): record numbers handed out per sub, in emission order
     int64_t presel = 0; bool presel_on = false;
+    bool pick_filter = false;      // presel_on for the native pickers' sake: the device-side filter alone, no per-sub-index selection on the host
     int64_t presel_d2h = 0;            // records the scans of this alignment copied to the host while pre-selection was on (RV_PRESEL_LOG)
     std::vector<int64_t> sel, sel_first, sel_tmp;
     // device scratch
@@ -937,7 +938,7 @@ int rv_frontier_scan(rv_index *h) {
     for (int s2 = 0; s2 < ns && s2 < (int)a->skip_scan.size(); s2++)
         if (a->skip_scan[(size_t)s2]) { a->nmums[(size_t)s2] = 0; a->mum_first[(size_t)s2] = 0; }
     a->scanned = true;
-    if (a->presel_on && !a->full_only) build_preselection(a);
+    if (a->presel_on && !a->full_only && !a->pick_filter) build_preselection(a);
     a->st.scanned_ranks += a->lv.m;
     a->st.t_scan += now_s() - t0;
     return 0;
@@ -1591,6 +1592,11 @@ static int builtin_setup(rv_index *h, int minl, int minn) {
         if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }
         if (h->rc) { rv_set_error("the native picker (rv_set_picker) with construct(rc=1) is not supported"); return -1; }
     }
+    // The reference's picker looks at the matches present in every sample of the sub-index and at nothing else, unless there is none (schemes.py:227-232): the scan
+    // drops the others on the device (the filter of rv_set_preselect without its cap, which --trim forbids: trim_overlap runs on the filtered list, in front of the
+    // cap) -- of the 1.8 x 10^6 matches of five 5 Mbp genomes that every level's scan found again, copied to the host and sorted into its sub-indices.
+    if (a->picker != 0 && a->multi && !a->trace_on) { a->presel_on = true; a->pick_filter = true; }
+    else a->pick_filter = false;
     if (a->picker == 2) {
         if (!a->ggraph) { rv_set_error("rv_set_graph_picker: no graph"); return -1; }
         if (h->rc) { rv_set_error("the native picker (rv_set_graph_picker) with construct(rc=1) is not supported"); return -1; }
@@ -2377,6 +2383,8 @@ int rv_frontier_import(rv_index *h, int minl, int minn, uint32_t maxlcp, int lev
         RV_TRY(a->dErr.reserve(64));
         memset(&a->st, 0, sizeof a->st);
         a->full_only = !a->trace_on && a->picker == 0;      // (as builtin_setup: the chain picker wants every match of a sub-index)
+        a->pick_filter = a->picker != 0 && a->multi && !a->trace_on;
+        if (a->pick_filter) a->presel_on = true;
         if (a->picker == 2) { rv_set_error("rv_frontier_import: a run on a graph (rv_set_graph_picker) is not handed off -- its sub-indices share the graph"); return -1; }
         if (a->picker == 1) {
             if ((int)h->nodes.size() != h->nsamples) { rv_set_error("the native picker (rv_set_picker) takes one sequence per sample: %d sequences in %d samples", (int)h->nodes.size(), h->nsamples); return -1; }

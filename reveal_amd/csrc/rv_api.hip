@@ -1053,6 +1053,9 @@ int rv_dev_copy(int device, void *dst, const void *src, int64_t bytes) {
     if (bytes <= 0) return 0;
     RV_HIP(hipSetDevice(device));
     RV_HIP(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDefault));
+    // (a copy between two device addresses may return before it is done; the library's own streams do not wait for the null stream: one run in four of the
+    //  three-process hand-off test imported segments that were still arriving)
+    RV_HIP(hipStreamSynchronize(nullptr));
     return 0;
 }
 

@@ -268,8 +268,8 @@ def test_processes_divide_one_alignment_over_hip_ipc(tmp_path, world, genomes, L
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se[-3000:]
     r = json.loads([x for x in outs[0][0].splitlines() if x.startswith("{")][-1])
-    assert r["same_anchors"] and r["same_text"] and r["same_counts"] and r["anchors"] > 500
-    assert len(r["shares"]) == world and sum(1 for x in r["shares"] if x > 0) >= 2 and sum(r["batches"]) >= world
+    assert r["same_anchors"] and r["same_text"] and r["same_counts"] and r["anchors"] > 500, r
+    assert len(r["shares"]) == world and sum(1 for x in r["shares"] if x > 0) >= 2 and sum(r["batches"]) >= world, r
 
 
 def test_processes_divide_one_alignment_with_the_cascade_on(tmp_path):

@@ -51,15 +51,16 @@ def test_synthetic_config5_shape(tmp_path):
 
 
 def test_config5_all_three_levels(tmp_path):
-    """BASELINE config 5's own shape -- 100 genomes, --order=sequential --chunksize=5: 20 / 4 / 1 jobs, graphs feeding graphs twice -- at 20 kbp
-    per genome (tools/config5.py; the same command at 5 Mbp per genome is profiles/r05_config5_full.json): the final graph spells all 100"""
+    """BASELINE config 5's own shape -- 100 genomes, --order=sequential --chunksize=5: 20 / 4 / 1 jobs, graphs feeding graphs twice -- at 1 Mbp
+    per genome (tools/config5.py; the same command at 5 Mbp per genome is profiles/r06_config5_full_native.json): the final file spells all 100.
+    Levels 1 and 2 run readers, picker and graphalign inside the library (rv_set_graph_picker)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if not k.startswith("RV_")}
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5.py"), "--genomes", "100", "--L", "20000", "--chunksize", "5", "--dir", str(tmp_path)],
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config5.py"), "--genomes", "100", "--L", "1000000", "--chunksize", "5", "--procs", "4", "--dir", str(tmp_path)],
                        capture_output=True, text=True, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])

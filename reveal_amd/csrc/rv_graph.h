@@ -20,6 +20,10 @@ struct GNode {
     int8_t aligned;                                 // -1: sentinel
     int8_t sent = 0;                                // sentinels: 1 a start node, 2 an end node
     bool alive;
+    // graphalign's marks, here and not in arrays of their own: the walk looks at a node's `aligned` anyway, so the marks cost no cache line of their own (a level of
+    // the last job of config 5 touches 10^7 nodes a dozen times).  Valid while the epoch matches (rv_graph::sub_epoch / walk_epoch): nothing is reset between calls.
+    uint8_t cls = 0;                                // bit 0 leading, bit 1 trailing (while ep_sub == sub_epoch)
+    uint32_t ep_sub = 0, ep_walk = 0;               // belongs to the sub-index of the current graphalign call / reached by the current walk
     uint64_t order;                                 // position in the graph's node dictionary (creation order)
     std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
     std::vector<int> succ, pred;                    // edge ids, in dictionary order
@@ -83,6 +87,7 @@ struct rv_graph {
     bool literal_segments = false;                  // segmentgraph in the reference's form (alngraph.check_segment_shortcut said no)
     std::vector<uint32_t> stamp, stamp2; uint32_t epoch = 0;      // scratch of the walks: visited marks per node
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
+    uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
     std::vector<int64_t> orig_b; std::vector<int> orig_id;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
     void *align_out();

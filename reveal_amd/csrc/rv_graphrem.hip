@@ -109,6 +109,10 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
             mine.push_back(x);
         }
     }
+    // marks live in the nodes (GNode::ep_sub / cls / ep_walk): a node belongs to this call's sub-index while its ep_sub is this call's number
+    if (++g->sub_epoch == 0) { for (GNode &n : g->nodes) n.ep_sub = 0; g->sub_epoch = 1; }
+    const uint32_t se = g->sub_epoch;
+    for (int x : mine) { GNode &n = g->nodes[(size_t)x]; n.ep_sub = se; n.cls = 0; }
     std::vector<int> mns;
     for (int q = 0; q < npos; q++) {
         O.match.push_back({pos[q], pos[q] + (int64_t)l});
@@ -117,77 +121,78 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         int pn = -1, sn = -1;
         const int mn = g->breaknode(old, pos[q], (int64_t)l, &pn, &sn);
         mns.push_back(mn);
-        if (pn >= 0) mine.push_back(pn);
-        if (sn >= 0) mine.push_back(sn);
+        if (pn >= 0) { mine.push_back(pn); g->nodes[(size_t)pn].ep_sub = se; g->nodes[(size_t)pn].cls = 0; }      // the pieces belong to the sub-index
+        if (sn >= 0) { mine.push_back(sn); g->nodes[(size_t)sn].ep_sub = se; g->nodes[(size_t)sn].cls = 0; }
     }
     std::sort(O.match.begin(), O.match.end(), [](const RvGraphIv &a, const RvGraphIv &b) { return a.b < b.b; });
     O.match.erase(std::unique(O.match.begin(), O.match.end(), [](const RvGraphIv &a, const RvGraphIv &b) { return a.b == b.b && a.e == b.e; }), O.match.end());
     const int mn = g->mergenodes(mns);
-    // the sub-index' nodes as they stand: what was handed in and is still alive (a broken node is gone), the pieces; never the match nodes
-    grow_stamps(g);
-    std::vector<uint8_t> &in_sub = g->mark;
-    if (in_sub.size() < g->nodes.size()) in_sub.resize(g->nodes.size() + g->nodes.size() / 4 + 64, 0);
-    std::vector<int> cur; cur.reserve(mine.size());
-    for (int m2 : mns) in_sub[(size_t)m2] = 2;      // (never the match nodes -- marked, not compared one by one: a hundred members times 10^7 nodes per level)
-    for (int x : mine) {
-        const GNode &n = g->nodes[(size_t)x];
-        if (!n.alive || in_sub[(size_t)x]) continue;
-        in_sub[(size_t)x] = 1; cur.push_back(x);
-    }
-    for (int m2 : mns) in_sub[(size_t)m2] = 0;
-    auto side = [&](bool reverse, std::vector<int> &res) {
-        std::vector<BfsHit> hits; std::vector<int> queue;
-        bfs(g, mn, reverse, nullptr, hits, queue);
-        res.clear();
-        if (!g->literal_segments) {
-            for (const BfsHit &h : hits) if (h.kind == 0) res.push_back(h.node);
-            return;
+    for (int m2 : mns) g->nodes[(size_t)m2].ep_sub = 0;      // never the match nodes
+    bool any_star = false;
+    for (uint8_t st : g->star) any_star |= st != 0;
+    // alngraph._bfs from the merged node: unaligned nodes are walked through -- those of the sub-index get the side's bit --, aligned ones and sentinels end the walk
+    auto walk = [&](bool reverse, uint8_t bit) {
+        if (++g->walk_epoch == 0) { for (GNode &n : g->nodes) n.ep_walk = 0; g->walk_epoch = 1; }
+        const uint32_t we = g->walk_epoch;
+        std::vector<int> &queue = g->walk_queue;
+        queue.clear(); queue.push_back(mn);
+        g->nodes[(size_t)mn].ep_walk = we;
+        for (size_t qi = 0; qi < queue.size(); qi++) {
+            const GNode &par = g->nodes[(size_t)queue[qi]];
+            for (int e : (reverse ? par.pred : par.succ)) {
+                const GEdge &ed = g->edges[(size_t)e];
+                GNode &c = g->nodes[(size_t)(reverse ? ed.u : ed.v)];
+                if (c.ep_walk == we || !real_edge(g, ed.paths, any_star)) continue;
+                c.ep_walk = we;
+                if (c.aligned == 0) { queue.push_back(reverse ? ed.u : ed.v); if (c.ep_sub == se) c.cls |= bit; }
+            }
         }
-        // rem.py:282-287 / 303-308: the walk ended at several places: only what a walk back from every one of them reaches as well
-        std::vector<int> walk, ends;
-        for (const BfsHit &h : hits) (h.kind == 0 ? walk : ends).push_back(h.node);
-        if (ends.size() > 1) {
-            std::vector<uint8_t> ign(g->nodes.size(), 0), back(g->nodes.size(), 0);
-            for (int e : ends) ign[(size_t)e] = 1;
-            std::vector<BfsHit> h2;
-            for (int e : ends) { bfs(g, e, !reverse, &ign, h2, queue); for (const BfsHit &h : h2) if (h.kind == 0) back[(size_t)h.node] = 1; }
-            for (int x : walk) if (back[(size_t)x]) res.push_back(x);
-        } else res = walk;
     };
-    std::vector<int> tr, ld;
-    side(false, tr);
-    side(true, ld);
+    if (!g->literal_segments) { walk(false, 2); walk(true, 1); }
+    else {
+        // rem.py:282-287 / 303-308: a walk that ended at several places keeps only what a walk back from every one of them reaches as well
+        auto side = [&](bool reverse, uint8_t bit) {
+            std::vector<BfsHit> hits; std::vector<int> queue;
+            bfs(g, mn, reverse, nullptr, hits, queue);
+            std::vector<int> walked, ends;
+            for (const BfsHit &h : hits) (h.kind == 0 ? walked : ends).push_back(h.node);
+            if (ends.size() > 1) {
+                std::vector<uint8_t> ign(g->nodes.size(), 0), back(g->nodes.size(), 0);
+                for (int e : ends) ign[(size_t)e] = 1;
+                std::vector<BfsHit> h2;
+                for (int e : ends) { bfs(g, e, !reverse, &ign, h2, queue); for (const BfsHit &h : h2) if (h.kind == 0) back[(size_t)h.node] = 1; }
+                for (int x : walked) if (back[(size_t)x] && g->nodes[(size_t)x].ep_sub == se) g->nodes[(size_t)x].cls |= bit;
+            } else for (int x : walked) if (g->nodes[(size_t)x].ep_sub == se) g->nodes[(size_t)x].cls |= bit;
+        };
+        side(false, 2);
+        side(true, 1);
+    }
     // leading / trailing: the walked nodes that belong to the sub-index; rest: what is left of it.  (A node both walks reach counts as leading AND trailing in
     // the reference's sets; it cannot happen in a graph whose paths run forwards only.)
-    std::vector<uint8_t> &cls = g->mark2;
-    if (cls.size() < g->nodes.size()) cls.resize(g->nodes.size() + g->nodes.size() / 4 + 64, 0);
-    for (int x : ld) if (in_sub[(size_t)x]) cls[(size_t)x] |= 1;
-    for (int x : tr) if (in_sub[(size_t)x]) cls[(size_t)x] |= 2;
     // the merged node's paths (every id, '*' paths included: set(G.offsets[mn]))
     std::vector<uint8_t> &msam = g->pmark;
     if (msam.size() < g->id2end.size() + 1) msam.resize(g->id2end.size() + 64, 0);
-    int maxsid = -1;
-    for (auto &a : g->nodes[(size_t)mn].off) { if ((size_t)a.first >= msam.size()) msam.resize((size_t)a.first + 64, 0); msam[(size_t)a.first] = 1; maxsid = std::max(maxsid, a.first); }
+    for (auto &a : g->nodes[(size_t)mn].off) { if ((size_t)a.first >= msam.size()) msam.resize((size_t)a.first + 64, 0); msam[(size_t)a.first] = 1; }
     // "clean": every path of every leading (trailing) node crosses the merged node.  A merged node on every path of the graph settles it; one offending node does,
     // too (the walk over a node's offsets was the larger half of this loop: 10^7 nodes per level, tens of paths through each)
     const bool covers_all = g->nodes[(size_t)mn].off.size() >= g->id2end.size() && !g->id2end.empty();
     bool lead_clean = true, trail_clean = true;
-    for (int x : cur) {
-        const GNode &n = g->nodes[(size_t)x];
-        const uint8_t c = cls[(size_t)x];
+    for (int x : mine) {      // what was handed in and is still alive (a broken node is gone), the pieces; each once (its mark goes as it is listed)
+        GNode &n = g->nodes[(size_t)x];
+        if (!n.alive || n.ep_sub != se) continue;
+        n.ep_sub = 0;
+        const uint8_t c = n.cls;
         if (c & 1) { O.lead.push_back({n.b, n.e}); if (lead_clean && !covers_all) for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) { lead_clean = false; break; } }
         if (c & 2) { O.trail.push_back({n.b, n.e}); if (trail_clean && !covers_all) for (auto &a : n.off) if ((size_t)a.first >= msam.size() || !msam[(size_t)a.first]) { trail_clean = false; break; } }
         if (!c) O.rest.push_back({n.b, n.e});
     }
     for (auto &a : g->nodes[(size_t)mn].off) msam[(size_t)a.first] = 0;
-    for (int x : cur) { in_sub[(size_t)x] = 0; cls[(size_t)x] = 0; }
     auto by_b = [](const RvGraphIv &a, const RvGraphIv &b) { return a.b < b.b; };
     for (std::vector<RvGraphIv> *v : {&O.lead, &O.trail, &O.rest}) if (!std::is_sorted(v->begin(), v->end(), by_b)) std::sort(v->begin(), v->end(), by_b);
     O.merged = {g->nodes[(size_t)mn].b, g->nodes[(size_t)mn].e};
     O.newleft = O.newright = O.merged;
     if (!lead_clean) O.newright = right;        // no clean dissection of all paths on the left (rem.py:367-370)
     if (!trail_clean) O.newleft = left;
-    (void)maxsid;
     return 0;
 }
 

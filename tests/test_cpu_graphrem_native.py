@@ -150,3 +150,22 @@ def test_reader_behind_the_abi_refuses_the_reverse_strand(tmp_path):
     broken.write_text("S\t1\tACGT\nS\t2\tTTTT\nP\tp\t1+,2+\t0M\n")
     with pytest.raises(ValueError, match="link"):
         alngraph.LoopGraph.read([str(broken)], C.TextOnly(), alngraph.AlnGraph())
+
+
+def test_literal_segmentgraph_beside_python(tmp_path, refmod, monkeypatch):
+    """the reference's own form of segmentgraph (walks back from the end points, rem.py:282-287 / 303-308) forced on both sides: a graph + graph job call by call"""
+    files = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d"])
+    rem.graph_rem(files[:2], str(tmp_path / "ab.gfa"), indexmod=refmod, native=False)
+    rem.graph_rem(files[2:], str(tmp_path / "cd.gfa"), indexmod=refmod, native=False)
+
+    def forced(self):
+        self.literal_segments = True
+        return False
+    monkeypatch.setattr(alngraph.AlnGraph, "check_segment_shortcut", forced)
+    stats = dict(picks=0, aligns=0)
+    with monkeypatch.context() as mp:
+        state = beside(mp, stats)
+        G, idx, picker, aligner = rem.graph_align_genomes([str(tmp_path / "ab.gfa"), str(tmp_path / "cd.gfa")], indexmod=refmod, native=False, preselect=False)
+    assert G.literal_segments and stats["aligns"] > 100
+    assert state["lg"]._dll.rv_graph_literal(state["lg"]._g) == 1
+    assert state["lg"].snapshot() == alngraph.graph_snapshot(G)

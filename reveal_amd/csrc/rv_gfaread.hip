@@ -10,6 +10,8 @@
 // sets of random names; here (and in alngraph.read_gfa) both go by creation order, one of the orders the reference can take.
 // Links on the reverse strand are not supported behind the ABI: -2 comes back and the caller takes the Python route.
 #include "rv_graph.h"
+#include <chrono>
+#include <cstdlib>
 #include <string_view>
 #include <unordered_map>
 
@@ -58,7 +60,12 @@ struct Fields {      // the first columns of a tab-separated line
     }
 };
 
+inline double rnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
 int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len) {
+    const bool times = getenv("RV_GRAPH_TIMES") != nullptr;
+    double tq = rnow(), tph[6] = {0, 0, 0, 0, 0, 0};
+    auto phase = [&](int k) { const double t = rnow(); tph[k] += t - tq; tq = t; };
     // segment names: the numbers 1 .. N in files reveal writes -- a table then, not a hash look-up per step of every path (10^8 steps in the last job of config 5);
     // any other name moves all of them into the map
     std::unordered_map<std::string_view, int> nmap;
@@ -113,6 +120,7 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
         } else if (line[0] == 'L') llines.push_back(line);
         else if (line[0] == 'P') plines.push_back(line);
     }
+    phase(0);
     auto node_named = [&](std::string_view id) -> int {
         if (numbered) {
             const int64_t num = number_of(id, number_limit);
@@ -131,6 +139,7 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
         if (u < 0 || v < 0) return -1;
         g->add_edge(u, v, PathSet());
     }
+    phase(1);
     if (plines.empty()) { rv_set_error("no paths defined in the GFA input"); return -1; }
     std::vector<int> starts, ends;
     int64_t added = 0;
@@ -176,6 +185,7 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
         g->id2end.push_back(o);
         added++;
     }
+    phase(2);
     // links, then nodes, no path uses
     const size_t file_end = g->nodes.size();
     std::vector<int> dead;
@@ -225,8 +235,11 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
             }
         }
     }
+    phase(3);
     g->compact();
     check_shortcut(g);
+    phase(4);
+    if (times) fprintf(stderr, "read_gfa: segments %.3f s, links %.3f, paths %.3f, unused + components %.3f, renumber + check %.3f\n", tph[0], tph[1], tph[2], tph[3], tph[4]);
     return added;
 }
 

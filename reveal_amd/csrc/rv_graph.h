@@ -87,6 +87,7 @@ struct rv_graph {
     bool literal_segments = false;                  // segmentgraph in the reference's form (alngraph.check_segment_shortcut said no)
     std::vector<uint32_t> stamp, stamp2; uint32_t epoch = 0;      // scratch of the walks: visited marks per node
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
+    double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // graphalign: seconds in look-ups / breaks + merge / walks / lists / sorts (RV_GRAPH_TIMES=1 prints them when the graph is renumbered)
     uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
     std::vector<int64_t> orig_b; std::vector<int> orig_id;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI

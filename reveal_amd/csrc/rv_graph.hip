@@ -10,6 +10,7 @@
 // Scope: the native picker's -- FASTA inputs, one sequence per sample (path id = sample), every edge on the forward strand.
 // Test infrastructure compares it with the Python surgery node for node and edge for edge (tests/test_cpu_graph_native.py).
 #include "rv_graph.h"
+#include <cstdlib>
 #include "rv_graphrem.h"
 #include <atomic>
 #include <thread>
@@ -70,6 +71,8 @@ rv_graph *rv_graph_replay(int nseq, const int64_t *begin, const int64_t *end, in
 
 /* after changes to the graph (rv_graph_align) and before rv_graph_sizes / rv_graph_export: the numbering of live nodes and links in dictionary order */
 int rv_graph_finish(rv_graph *g) {
+    if (getenv("RV_GRAPH_TIMES") && g->t_phase[0] + g->t_phase[2] > 0)
+        fprintf(stderr, "graphalign: look-ups %.3f s, breaks + merge %.3f, walks %.3f, lists %.3f, sorts %.3f\n", g->t_phase[0], g->t_phase[1], g->t_phase[2], g->t_phase[3], g->t_phase[4]);
     try { g->finish(); return 0; } catch (...) { rv_set_error("rv_graph_finish: out of host memory"); return -1; }
 }
 const char *rv_graph_error(const rv_graph *g) { return g->err.empty() ? nullptr : g->err.c_str(); }

@@ -18,6 +18,7 @@
 #include "rv_graph.h"
 #include "rv_graphrem.h"
 #include "rv_pick.h"
+#include <chrono>
 #include <cmath>
 #include <unordered_map>
 
@@ -78,7 +79,10 @@ static int node_of(rv_graph *g, int64_t b, int64_t e, const char *what) {
 
 // rem.graphalign (rem.py:318-382) for one sub-index: nodes = its intervals (graph nodes), left / right = its left / right graph node, the match (l, members in the
 // picker's order).  The graph is changed (nodes broken and merged); the intervals of the children, the merged node and the children's left / right nodes come back.
+static inline double gnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv left, RvGraphIv right, uint32_t l, const int64_t *pos, int npos, RvGraphAlignOut &O) {
+    double tp = gnow();
+    auto phase = [&](int k) { const double t = gnow(); g->t_phase[k] += t - tp; tp = t; };
     O.lead.clear(); O.trail.clear(); O.match.clear(); O.rest.clear();
     std::vector<int> mine; mine.reserve(nn + 2 * (size_t)npos);
     {   // The intervals come sorted.  Most of them, in the levels where there are many, are nodes the inputs brought along: those are looked up in a sorted table
@@ -109,6 +113,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
             mine.push_back(x);
         }
     }
+    phase(0);
     // marks live in the nodes (GNode::ep_sub / cls / ep_walk): a node belongs to this call's sub-index while its ep_sub is this call's number
     if (++g->sub_epoch == 0) { for (GNode &n : g->nodes) n.ep_sub = 0; g->sub_epoch = 1; }
     const uint32_t se = g->sub_epoch;
@@ -128,6 +133,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     O.match.erase(std::unique(O.match.begin(), O.match.end(), [](const RvGraphIv &a, const RvGraphIv &b) { return a.b == b.b && a.e == b.e; }), O.match.end());
     const int mn = g->mergenodes(mns);
     for (int m2 : mns) g->nodes[(size_t)m2].ep_sub = 0;      // never the match nodes
+    phase(1);
     bool any_star = false;
     for (uint8_t st : g->star) any_star |= st != 0;
     // alngraph._bfs from the merged node: unaligned nodes are walked through -- those of the sub-index get the side's bit --, aligned ones and sentinels end the walk
@@ -167,6 +173,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         side(false, 2);
         side(true, 1);
     }
+    phase(2);
     // leading / trailing: the walked nodes that belong to the sub-index; rest: what is left of it.  (A node both walks reach counts as leading AND trailing in
     // the reference's sets; it cannot happen in a graph whose paths run forwards only.)
     // the merged node's paths (every id, '*' paths included: set(G.offsets[mn]))
@@ -177,7 +184,10 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     // too (the walk over a node's offsets was the larger half of this loop: 10^7 nodes per level, tens of paths through each)
     const bool covers_all = g->nodes[(size_t)mn].off.size() >= g->id2end.size() && !g->id2end.empty();
     bool lead_clean = true, trail_clean = true;
-    for (int x : mine) {      // what was handed in and is still alive (a broken node is gone), the pieces; each once (its mark goes as it is listed)
+    size_t cut[3] = {0, 0, 0};      // where the pieces begin in the three lists (what was handed in came sorted)
+    for (size_t mi = 0; mi < mine.size(); mi++) {      // what was handed in and is still alive (a broken node is gone), the pieces; each once (its mark goes as it is listed)
+        if (mi == nn) { cut[0] = O.lead.size(); cut[1] = O.trail.size(); cut[2] = O.rest.size(); }
+        const int x = mine[mi];
         GNode &n = g->nodes[(size_t)x];
         if (!n.alive || n.ep_sub != se) continue;
         n.ep_sub = 0;
@@ -187,12 +197,22 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         if (!c) O.rest.push_back({n.b, n.e});
     }
     for (auto &a : g->nodes[(size_t)mn].off) msam[(size_t)a.first] = 0;
+    phase(3);
     auto by_b = [](const RvGraphIv &a, const RvGraphIv &b) { return a.b < b.b; };
-    for (std::vector<RvGraphIv> *v : {&O.lead, &O.trail, &O.rest}) if (!std::is_sorted(v->begin(), v->end(), by_b)) std::sort(v->begin(), v->end(), by_b);
+    if (mine.size() <= nn) { cut[0] = O.lead.size(); cut[1] = O.trail.size(); cut[2] = O.rest.size(); }
+    {   // the few pieces sorted and merged into the sorted rest (a sort of the whole list per call was a seventh of graphalign)
+        std::vector<RvGraphIv> *lists[3] = {&O.lead, &O.trail, &O.rest};
+        for (int k = 0; k < 3; k++) {
+            std::vector<RvGraphIv> &v = *lists[k];
+            if (cut[k] < v.size()) { std::sort(v.begin() + (ptrdiff_t)cut[k], v.end(), by_b); std::inplace_merge(v.begin(), v.begin() + (ptrdiff_t)cut[k], v.end(), by_b); }
+            if (!std::is_sorted(v.begin(), v.end(), by_b)) std::sort(v.begin(), v.end(), by_b);      // (the caller's intervals were not sorted)
+        }
+    }
     O.merged = {g->nodes[(size_t)mn].b, g->nodes[(size_t)mn].e};
     O.newleft = O.newright = O.merged;
     if (!lead_clean) O.newright = right;        // no clean dissection of all paths on the left (rem.py:367-370)
     if (!trail_clean) O.newleft = left;
+    phase(4);
     return 0;
 }
 

@@ -65,7 +65,7 @@ def main():
                     j, (inputs, out) = pending.pop(0)
                     cmd = [sys.executable, "-m", "reveal_amd.rem"] + list(inputs) + ["-o", out, "-m", str(a.minl), "-n", str(a.minn)]
                     running.append((j, out, time.perf_counter(), subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                                                                  env=dict(os.environ, REVEAL_AMD_TIMES="1"))))
+                                                                                  env=dict(os.environ, REVEAL_AMD_TIMES="1", RV_GRAPH_TIMES="1"))))
                 still = []
                 for j, out, ts, pr in running:
                     if pr.poll() is None:
@@ -80,7 +80,7 @@ def main():
                     print("level %d job %d -> %s  %.2f s (process), %s" % (lv, j, out, dt, so.strip().splitlines()[-1] if so.strip() else ""), file=sys.stderr)
                     if lv > 0:
                         for ln in se.splitlines():
-                            if ln.startswith("stages:"):
+                            if ln.startswith(("stages:", "graphalign:", "read_gfa:")):
                                 print("    " + ln, file=sys.stderr)
                                 stage_log.append((lv, j, ln))
                 running = still

@@ -24,8 +24,8 @@ inline int new_sentinel(rv_graph *g, int kind) {
 }
 inline void drop_edge(rv_graph *g, int e) {
     GEdge &ed = g->edges[(size_t)e];
-    auto &s = g->nodes[(size_t)ed.u].succ; s.erase(std::find(s.begin(), s.end(), e));
-    auto &p = g->nodes[(size_t)ed.v].pred; p.erase(std::find(p.begin(), p.end(), e));
+    g->nodes[(size_t)ed.u].succ.remove(e);
+    g->nodes[(size_t)ed.v].pred.remove(e);
     ed.u = -1;
 }
 // alngraph.check_segment_shortcut: every sequence node goes on over a link carried by a real path, in both directions -- or segmentgraph takes the reference's form

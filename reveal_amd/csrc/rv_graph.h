@@ -5,15 +5,66 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <exception>
 #include <map>
 #include <memory>
+#include <new>
 #include <string>
 #include <vector>
 
 void rv_set_error(const char *fmt, ...);      // rv_api.hip
+
+// A node's links in one direction: (edge id, neighbour) pairs in dictionary order, the first two inside the node.  graphalign's walks go from node to node along
+// chains of small bubbles, every step waiting for the one before: with a vector of edge ids a step was three dependent loads (the vector's heap block, the edge,
+// the neighbour); now it is the neighbour alone.  Iterating yields the edge ids, as the vector did.
+struct Link { int e, to; };
+class LinkVec {
+    uint32_t n_ = 0, cap_ = 2;
+    union { Link inl_[2]; Link *heap_; };
+    Link *p() { return cap_ > 2 ? heap_ : inl_; }
+    const Link *p() const { return cap_ > 2 ? heap_ : inl_; }
+    void take(LinkVec &o) { n_ = o.n_; cap_ = o.cap_; if (cap_ > 2) heap_ = o.heap_; else { inl_[0] = o.inl_[0]; inl_[1] = o.inl_[1]; } o.n_ = 0; o.cap_ = 2; }
+    void copy(const LinkVec &o) {
+        n_ = 0; cap_ = 2;
+        for (uint32_t i = 0; i < o.n_; i++) push_back(o.p()[i].e, o.p()[i].to);
+    }
+public:
+    LinkVec() { inl_[0] = inl_[1] = Link{-1, -1}; }
+    ~LinkVec() { if (cap_ > 2) free(heap_); }
+    LinkVec(const LinkVec &o) { copy(o); }
+    LinkVec(LinkVec &&o) noexcept { take(o); }
+    LinkVec &operator=(const LinkVec &o) { if (this != &o) { if (cap_ > 2) free(heap_); copy(o); } return *this; }
+    LinkVec &operator=(LinkVec &&o) noexcept { if (this != &o) { if (cap_ > 2) free(heap_); take(o); } return *this; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    void push_back(int e, int to) {
+        if (n_ == cap_) {
+            const uint32_t c2 = cap_ * 2;
+            Link *q = (Link *)malloc(sizeof(Link) * c2);
+            if (!q) throw std::bad_alloc();
+            memcpy(q, p(), sizeof(Link) * n_);
+            if (cap_ > 2) free(heap_);
+            heap_ = q; cap_ = c2;
+        }
+        p()[n_++] = Link{e, to};
+    }
+    void remove(int e) {      // the first entry of edge e goes, the others keep their order
+        Link *q = p();
+        for (uint32_t i = 0; i < n_; i++) if (q[i].e == e) { for (uint32_t j = i + 1; j < n_; j++) q[j - 1] = q[j]; n_--; return; }
+    }
+    const Link *links() const { return p(); }
+    Link *links() { return p(); }
+    struct It { Link *q; int &operator*() const { return q->e; } It &operator++() { ++q; return *this; } bool operator!=(const It &o) const { return q != o.q; } };
+    struct CIt { const Link *q; int operator*() const { return q->e; } CIt &operator++() { ++q; return *this; } bool operator!=(const CIt &o) const { return q != o.q; } };
+    It begin() { return It{p()}; }
+    It end() { return It{p() + n_}; }
+    CIt begin() const { return CIt{p()}; }
+    CIt end() const { return CIt{p() + n_}; }
+};
 
 struct GNode {
     int64_t b, e;                                   // text interval; sentinels: b = sample, e = 0 (start) / 1 (end)
@@ -26,7 +77,7 @@ struct GNode {
     uint32_t ep_sub = 0, ep_walk = 0;               // belongs to the sub-index of the current graphalign call / reached by the current walk
     uint64_t order;                                 // position in the graph's node dictionary (creation order)
     std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
-    std::vector<int> succ, pred;                    // edge ids, in dictionary order
+    LinkVec succ, pred;                             // links forwards / backwards, in dictionary order (iterating yields edge ids)
 };
 // The path ids an edge carries.  A graph of up to 256 paths keeps them as four words (uniting two sets, and asking for a member, cost a few instructions
 // instead of an allocation: the anchors' surgery spent most of its time in malloc -- and again when the last job of config 5, a hundred paths, outgrew the
@@ -70,6 +121,36 @@ struct PathSet {
 };
 struct GEdge { int u, v; PathSet paths; };
 
+// begin -> node for the nodes the surgery makes while a run goes on (rv_graph_do_align finds the inputs' own nodes in a sorted table and these here: a search in
+// the position map -- 23 levels of a tree of 10^7 entries, a cache miss each -- per piece, sub-index and level was a third of graphalign in the last job of config 5).
+// Open addressing; nothing is ever taken out: an entry whose node is gone fails the caller's check, a new node with the same begin takes the entry over.
+struct BeginHash {
+    std::vector<int64_t> key; std::vector<int> val;
+    size_t mask = 0, used = 0;
+    static size_t mix(int64_t b) { uint64_t x = (uint64_t)b * 0x9E3779B97F4A7C15ull; return (size_t)(x ^ (x >> 29)); }
+    void clear() { key.clear(); val.clear(); mask = used = 0; }
+    void grow() {
+        const size_t cap = key.empty() ? 1024 : key.size() * 2;
+        std::vector<int64_t> k2(cap, -1); std::vector<int> v2(cap, -1);
+        const size_t m2 = cap - 1;
+        for (size_t i = 0; i < key.size(); i++) if (key[i] >= 0) { size_t h = mix(key[i]) & m2; while (k2[h] >= 0) h = (h + 1) & m2; k2[h] = key[i]; v2[h] = val[i]; }
+        key.swap(k2); val.swap(v2); mask = m2;
+    }
+    void put(int64_t b, int id) {
+        if ((used + 1) * 5 > key.size() * 3) grow();
+        size_t h = mix(b) & mask;
+        while (key[h] >= 0 && key[h] != b) h = (h + 1) & mask;
+        if (key[h] < 0) { key[h] = b; used++; }
+        val[h] = id;
+    }
+    int get(int64_t b) const {
+        if (key.empty()) return -1;
+        size_t h = mix(b) & mask;
+        while (key[h] >= 0) { if (key[h] == b) return val[h]; h = (h + 1) & mask; }
+        return -1;
+    }
+};
+
 struct rv_graph {
     std::vector<GNode> nodes;
     std::vector<GEdge> edges;
@@ -89,6 +170,7 @@ struct rv_graph {
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
     double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // graphalign: seconds in look-ups / breaks + merge / walks / lists / sorts (RV_GRAPH_TIMES=1 prints them when the graph is renumbered)
     uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
+    BeginHash made; bool made_on = false;           // nodes made since the table of the inputs' nodes (orig_b) was built
     std::vector<int64_t> orig_b; std::vector<int> orig_id;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
     void *align_out();
@@ -99,7 +181,7 @@ struct rv_graph {
         n.b = b; n.e = e; n.aligned = aligned; n.alive = true; n.order = counter++;
         nodes.push_back(std::move(n));
         const int id = (int)nodes.size() - 1;
-        if (aligned >= 0) at[b] = id;
+        if (aligned >= 0) { at[b] = id; if (made_on) made.put(b, id); }
         return id;
     }
     // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
@@ -108,13 +190,13 @@ struct rv_graph {
             if (edges[(size_t)e].v == v) { edges[(size_t)e].paths.unite(paths); return; }
         edges.push_back({u, v, paths});
         const int e = (int)edges.size() - 1;
-        nodes[(size_t)u].succ.push_back(e);
-        nodes[(size_t)v].pred.push_back(e);
+        nodes[(size_t)u].succ.push_back(e, v);
+        nodes[(size_t)v].pred.push_back(e, u);
     }
     void remove_node(int x) {
         GNode &n = nodes[(size_t)x];
-        for (int e : n.succ) { auto &p = nodes[(size_t)edges[(size_t)e].v].pred; p.erase(std::find(p.begin(), p.end(), e)); edges[(size_t)e].u = -1; }
-        for (int e : n.pred) { auto &s = nodes[(size_t)edges[(size_t)e].u].succ; s.erase(std::find(s.begin(), s.end(), e)); edges[(size_t)e].u = -1; }
+        for (int e : n.succ) { nodes[(size_t)edges[(size_t)e].v].pred.remove(e); edges[(size_t)e].u = -1; }
+        for (int e : n.pred) { nodes[(size_t)edges[(size_t)e].u].succ.remove(e); edges[(size_t)e].u = -1; }
         n.succ.clear(); n.pred.clear(); n.off.clear(); n.alive = false;
         auto it = at.find(n.b);
         if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
@@ -209,6 +291,8 @@ struct rv_graph {
             GNode &n = nodes[i];
             for (int &e : n.succ) e = emap[(size_t)e];
             for (int &e : n.pred) e = emap[(size_t)e];
+            for (size_t k = 0; k < n.succ.size(); k++) n.succ.links()[k].to = nmap[(size_t)n.succ.links()[k].to];
+            for (size_t k = 0; k < n.pred.size(); k++) n.pred.links()[k].to = nmap[(size_t)n.pred.links()[k].to];
             n2.push_back(std::move(n));
         }
         std::vector<GEdge> e2; e2.reserve(ne);
@@ -216,7 +300,7 @@ struct rv_graph {
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
-        orig_b.clear(); orig_id.clear();
+        orig_b.clear(); orig_id.clear(); made.clear(); made_on = false;
     }
     void finish() {
         order.clear();

@@ -55,7 +55,7 @@ void bfs(rv_graph *g, int source, bool reverse, const std::vector<uint8_t> *igno
     queue.push_back(source);
     for (size_t qi = 0; qi < queue.size(); qi++) {
         const int parent = queue[qi];
-        const std::vector<int> &adj = reverse ? g->nodes[(size_t)parent].pred : g->nodes[(size_t)parent].succ;
+        const LinkVec &adj = reverse ? g->nodes[(size_t)parent].pred : g->nodes[(size_t)parent].succ;
         for (int e : adj) {
             const int child = reverse ? g->edges[(size_t)e].u : g->edges[(size_t)e].v;
             if (g->stamp[(size_t)child] == ep || !real_edge(g, g->edges[(size_t)e].paths, any_star)) continue;
@@ -91,6 +91,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         if (g->orig_b.empty() && nn >= 64) {
             g->orig_b.reserve(g->at.size()); g->orig_id.reserve(g->at.size());
             for (auto &kv : g->at) { g->orig_b.push_back(kv.first); g->orig_id.push_back(kv.second); }
+            g->made.clear(); g->made_on = true;      // (what is made from here on registers itself: rv_graph::new_node)
         }
         const size_t K = g->orig_b.size();
         size_t k = K ? (size_t)(std::lower_bound(g->orig_b.begin(), g->orig_b.end(), nn ? nodes[0].b : 0) - g->orig_b.begin()) : 0;
@@ -103,6 +104,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
                 if (k < K && g->orig_b[k] < b) k = (size_t)(std::lower_bound(g->orig_b.begin() + (ptrdiff_t)k, g->orig_b.end(), b) - g->orig_b.begin());
             }
             if (k < K && g->orig_b[k] == b) { const int c = g->orig_id[k]; if (g->nodes[(size_t)c].alive && g->nodes[(size_t)c].b == b && g->nodes[(size_t)c].e == nodes[i].e) x = c; }
+            if (x < 0 && g->made_on) { const int c = g->made.get(b); if (c >= 0 && g->nodes[(size_t)c].alive && g->nodes[(size_t)c].b == b && g->nodes[(size_t)c].e == nodes[i].e) x = c; }
             if (x < 0) {
                 auto it = g->at.find(b);
                 if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[i].e) {
@@ -145,12 +147,13 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         g->nodes[(size_t)mn].ep_walk = we;
         for (size_t qi = 0; qi < queue.size(); qi++) {
             const GNode &par = g->nodes[(size_t)queue[qi]];
-            for (int e : (reverse ? par.pred : par.succ)) {
-                const GEdge &ed = g->edges[(size_t)e];
-                GNode &c = g->nodes[(size_t)(reverse ? ed.u : ed.v)];
-                if (c.ep_walk == we || !real_edge(g, ed.paths, any_star)) continue;
+            const LinkVec &adj = reverse ? par.pred : par.succ;
+            const Link *lk = adj.links();
+            for (size_t k = 0, nk = adj.size(); k < nk; k++) {
+                GNode &c = g->nodes[(size_t)lk[k].to];
+                if (c.ep_walk == we || (any_star && !real_edge(g, g->edges[(size_t)lk[k].e].paths, true))) continue;
                 c.ep_walk = we;
-                if (c.aligned == 0) { queue.push_back(reverse ? ed.u : ed.v); if (c.ep_sub == se) c.cls |= bit; }
+                if (c.aligned == 0) { queue.push_back(lk[k].to); if (c.ep_sub == se) c.cls |= bit; }
             }
         }
     };
@@ -415,12 +418,12 @@ rv_graph *rv_graph_import(int64_t nnodes, const int64_t *node_b, const int64_t *
             GEdge ed; ed.u = edge_u[e]; ed.v = edge_v[e];
             for (int64_t q = edge_ptr[e]; q < edge_ptr[e + 1]; q++) ed.paths.add(edge_paths[q]);
             g->edges.push_back(std::move(ed));
-            g->nodes[(size_t)edge_u[e]].succ.push_back((int)e);
+            g->nodes[(size_t)edge_u[e]].succ.push_back((int)e, edge_v[e]);
         }
         for (int64_t i = 0; i < nnodes; i++)
             for (int64_t q = pred_ptr[i]; q < pred_ptr[i + 1]; q++) {
                 if (pred_edge[q] < 0 || pred_edge[q] >= nedges || g->edges[(size_t)pred_edge[q]].v != (int)i) { rv_set_error("rv_graph_import: a node's backward links do not match the links"); return nullptr; }
-                g->nodes[(size_t)i].pred.push_back(pred_edge[q]);
+                g->nodes[(size_t)i].pred.push_back(pred_edge[q], g->edges[(size_t)pred_edge[q]].u);
             }
         g->star.assign(star, star + npaths); g->id2end.assign(id2end, id2end + npaths);
         g->start_of.assign(start_nodes, start_nodes + nstart);

@@ -382,10 +382,11 @@ int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args);
  * rv_graph_read_gfa: the text of a GFA1 file; every S line becomes a sequence of h's current sample (h == NULL: intervals counted from *text_n on -- tests
  * without a device); -> number of paths added (*names: their names, one per line, valid until the next call), -1 error, -2 the file holds links on the reverse
  * strand (not supported behind the ABI; g and h are then half-filled: start over with the Python readers).
- * rv_graph_paths -> number of paths, their lengths; rv_graph_node_kinds: per node in rv_graph_export's order 0 sequence node, 1 start, 2 end sentinel. */
+ * rv_graph_seal: once after the last input.  rv_graph_paths -> number of paths, their lengths; rv_graph_node_kinds: per node in rv_graph_export's order 0 sequence node, 1 start, 2 end sentinel. */
 rv_graph *rv_graph_new(void);
 int rv_graph_add_linear(rv_graph *g, int64_t b, int64_t e, int star);
 int64_t rv_graph_read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len, const char **names);
+int rv_graph_seal(rv_graph *g);      /* after the last rv_graph_read_gfa / rv_graph_add_linear, before the graph is used: renumbers it, decides rv_graph_literal */
 int rv_graph_paths(const rv_graph *g, int64_t *id2end);
 int rv_graph_node_kinds(const rv_graph *g, int8_t *out);
 int rv_graph_literal(const rv_graph *g);      /* 1: some node of the inputs does not go on in both directions -- segmentgraph walks back from its end points as the reference does */

@@ -144,6 +144,7 @@ SYMBOLS = {
     "rv_graph_add_linear": (_I, [V, _L, _L, _I]),
     "rv_graph_read_gfa": (_L, [V, V, V, V, _L, V]),
     "rv_graph_paths": (_I, [V, V]),
+    "rv_graph_seal": (_I, [V]),
     "rv_graph_node_kinds": (_I, [V, V]),
     "rv_graph_literal": (_I, [V]),
     "rv_graph_replay": (V, [_I, V, V, _L, V, V, V]),

@@ -632,6 +632,8 @@ class LoopGraph(NativeGraph):
                     b, e = idx.addsequence(seq)
                     if dll.rv_graph_add_linear(self._g, b, e, 1 if name.startswith("*") else 0) != sid:
                         raise RuntimeError("path ids out of step: " + self._lib.err())
+        if dll.rv_graph_seal(self._g) != 0:
+            raise MemoryError(self._lib.err())
         if hasattr(idx, "_sync_nodes"):
             idx._nodes_stale = True      # (idx.nodes asks the library when somebody looks)
             idx._constructed = False

@@ -167,7 +167,7 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
             o += n.e - n.b;
             if (prev >= 0) {
                 int hit = -1;
-                for (int e : g->nodes[(size_t)prev].succ) if (g->edges[(size_t)e].v == node) { hit = e; break; }
+                { const LinkVec &sv = g->nodes[(size_t)prev].succ; const Link *lk = sv.links(); for (size_t k = 0; k < sv.size(); k++) if (lk[k].to == node) { hit = lk[k].e; break; } }
                 if (hit < 0) { rv_set_error("path %.*s steps over a link the graph does not have", (int)std::min<size_t>(c.f[1].size(), 60), c.f[1].data()); return -1; }
                 g->edges[(size_t)hit].paths.add(sid);
             } else first = node;
@@ -236,10 +236,9 @@ int64_t read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, in
         }
     }
     phase(3);
-    g->compact();
-    check_shortcut(g);
+    // (the per-path sentinels and unused segments stay behind as dead entries until rv_graph_seal renumbers the graph once, after the last file)
     phase(4);
-    if (times) fprintf(stderr, "read_gfa: segments %.3f s, links %.3f, paths %.3f, unused + components %.3f, renumber + check %.3f\n", tph[0], tph[1], tph[2], tph[3], tph[4]);
+    if (times) fprintf(stderr, "read_gfa: segments %.3f s, links %.3f, paths %.3f, unused + components %.3f\n", tph[0], tph[1], tph[2], tph[3]);
     return added;
 }
 
@@ -276,6 +275,13 @@ int64_t rv_graph_read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char 
         return r;
     } catch (const std::exception &e) { rv_set_error("rv_graph_read_gfa: %s", e.what()); return -1; }
     catch (...) { rv_set_error("rv_graph_read_gfa: failed"); return -1; }
+}
+
+/* after the last input: dead entries go, live nodes and links are renumbered in their order, and alngraph.check_segment_shortcut's question is asked once for the
+ * whole graph (the reference asks it after every file, of every node read so far: the same answer) */
+int rv_graph_seal(rv_graph *g) {
+    try { g->compact(); check_shortcut(g); g->finish(); return 0; }
+    catch (...) { rv_set_error("rv_graph_seal: out of host memory"); return -1; }
 }
 
 /* the paths of a graph made by the two readers: -> their number; id2end (may be NULL): their lengths */

@@ -121,32 +121,35 @@ struct PathSet {
 };
 struct GEdge { int u, v; PathSet paths; };
 
-// begin -> node for the nodes the surgery makes while a run goes on (rv_graph_do_align finds the inputs' own nodes in a sorted table and these here: a search in
-// the position map -- 23 levels of a tree of 10^7 entries, a cache miss each -- per piece, sub-index and level was a third of graphalign in the last job of config 5).
-// Open addressing; nothing is ever taken out: an entry whose node is gone fails the caller's check, a new node with the same begin takes the entry over.
+// begin -> node for graphalign's look-ups (rv_graph_do_align is handed intervals and needs nodes).  The position map (std::map) answers them with a search from its
+// root -- 23 levels of a tree of 10^7 entries, a cache miss each -- and a graph file lists its segments in the order an earlier run MADE them, so the nodes of one
+// sub-index lie all over the table: a third of graphalign in the last job of config 5.  Open addressing, one 16-byte slot per entry (one cache line per look-up, and the
+// caller prefetches it); nothing is ever taken out: an entry whose node is gone fails the caller's check, a new node with the same begin takes the entry over.
 struct BeginHash {
-    std::vector<int64_t> key; std::vector<int> val;
+    struct Slot { int64_t key; int val; int pad; };
+    std::vector<Slot> slot;
     size_t mask = 0, used = 0;
     static size_t mix(int64_t b) { uint64_t x = (uint64_t)b * 0x9E3779B97F4A7C15ull; return (size_t)(x ^ (x >> 29)); }
-    void clear() { key.clear(); val.clear(); mask = used = 0; }
-    void grow() {
-        const size_t cap = key.empty() ? 1024 : key.size() * 2;
-        std::vector<int64_t> k2(cap, -1); std::vector<int> v2(cap, -1);
+    void clear() { slot.clear(); slot.shrink_to_fit(); mask = used = 0; }
+    void reserve(size_t entries) { size_t cap = 1024; while (cap * 3 < entries * 5 + 16) cap *= 2; if (cap > slot.size()) rehash(cap); }
+    void rehash(size_t cap) {
+        std::vector<Slot> s2(cap, Slot{-1, -1, 0});
         const size_t m2 = cap - 1;
-        for (size_t i = 0; i < key.size(); i++) if (key[i] >= 0) { size_t h = mix(key[i]) & m2; while (k2[h] >= 0) h = (h + 1) & m2; k2[h] = key[i]; v2[h] = val[i]; }
-        key.swap(k2); val.swap(v2); mask = m2;
+        for (const Slot &x : slot) if (x.key >= 0) { size_t h = mix(x.key) & m2; while (s2[h].key >= 0) h = (h + 1) & m2; s2[h] = x; }
+        slot.swap(s2); mask = m2;
     }
     void put(int64_t b, int id) {
-        if ((used + 1) * 5 > key.size() * 3) grow();
+        if ((used + 1) * 5 > slot.size() * 3) rehash(slot.empty() ? 1024 : slot.size() * 2);
         size_t h = mix(b) & mask;
-        while (key[h] >= 0 && key[h] != b) h = (h + 1) & mask;
-        if (key[h] < 0) { key[h] = b; used++; }
-        val[h] = id;
+        while (slot[h].key >= 0 && slot[h].key != b) h = (h + 1) & mask;
+        if (slot[h].key < 0) { slot[h].key = b; used++; }
+        slot[h].val = id;
     }
+    const Slot *home(int64_t b) const { return slot.empty() ? nullptr : &slot[mix(b) & mask]; }
     int get(int64_t b) const {
-        if (key.empty()) return -1;
+        if (slot.empty()) return -1;
         size_t h = mix(b) & mask;
-        while (key[h] >= 0) { if (key[h] == b) return val[h]; h = (h + 1) & mask; }
+        while (slot[h].key >= 0) { if (slot[h].key == b) return slot[h].val; h = (h + 1) & mask; }
         return -1;
     }
 };
@@ -170,8 +173,8 @@ struct rv_graph {
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
     double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // graphalign: seconds in look-ups / breaks + merge / walks / lists / sorts (RV_GRAPH_TIMES=1 prints them when the graph is renumbered)
     uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
-    BeginHash made; bool made_on = false;           // nodes made since the table of the inputs' nodes (orig_b) was built
-    std::vector<int64_t> orig_b; std::vector<int> orig_id;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
+    BeginHash made; bool made_on = false;           // graphalign: begin -> node, every sequence node from its first large call on (new_node keeps it up)
+    std::vector<int> look_tmp;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
     void *align_out();
     ~rv_graph();
@@ -186,8 +189,8 @@ struct rv_graph {
     }
     // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
     void add_edge(int u, int v, const PathSet &paths) {
-        for (int e : nodes[(size_t)u].succ)
-            if (edges[(size_t)e].v == v) { edges[(size_t)e].paths.unite(paths); return; }
+        { const LinkVec &sv = nodes[(size_t)u].succ; const Link *lk = sv.links();
+          for (size_t k = 0; k < sv.size(); k++) if (lk[k].to == v) { edges[(size_t)lk[k].e].paths.unite(paths); return; } }
         edges.push_back({u, v, paths});
         const int e = (int)edges.size() - 1;
         nodes[(size_t)u].succ.push_back(e, v);
@@ -300,7 +303,7 @@ struct rv_graph {
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
-        orig_b.clear(); orig_id.clear(); made.clear(); made_on = false;
+        made.clear(); made_on = false;
     }
     void finish() {
         order.clear();

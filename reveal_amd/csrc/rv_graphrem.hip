@@ -85,34 +85,33 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     auto phase = [&](int k) { const double t = gnow(); g->t_phase[k] += t - tp; tp = t; };
     O.lead.clear(); O.trail.clear(); O.match.clear(); O.rest.clear();
     std::vector<int> mine; mine.reserve(nn + 2 * (size_t)npos);
-    {   // The intervals come sorted.  Most of them, in the levels where there are many, are nodes the inputs brought along: those are looked up in a sorted table
-        // of begins made once (read one after the other: no search from the root of the position map, no cache miss per node -- 4 x 10^5 searches per level were
-        // most of graphalign's time in a merge of five graphs of 8 x 10^4 nodes); a node the surgery made, or an entry whose node is gone, goes to the map.
-        if (g->orig_b.empty() && nn >= 64) {
-            g->orig_b.reserve(g->at.size()); g->orig_id.reserve(g->at.size());
-            for (auto &kv : g->at) { g->orig_b.push_back(kv.first); g->orig_id.push_back(kv.second); }
-            g->made.clear(); g->made_on = true;      // (what is made from here on registers itself: rv_graph::new_node)
+    {   // intervals -> nodes through the hash of begins (rv_graph.h BeginHash), three steps apart in a software pipeline: the slot is prefetched, then read and the node it
+        // names prefetched, then the node is checked (alive, the same interval) and marked.  An interval the hash does not hold goes to the position map.
+        if (!g->made_on && nn >= 64) {
+            g->made.reserve(g->at.size() + g->at.size() / 2);
+            for (auto &kv : g->at) g->made.put(kv.first, kv.second);
+            g->made_on = true;      // (what is made from here on registers itself: rv_graph::new_node)
         }
-        const size_t K = g->orig_b.size();
-        size_t k = K ? (size_t)(std::lower_bound(g->orig_b.begin(), g->orig_b.end(), nn ? nodes[0].b : 0) - g->orig_b.begin()) : 0;
-        for (size_t i = 0; i < nn; i++) {
-            const int64_t b = nodes[i].b;
-            int x = -1;
-            if (k < K && g->orig_b[k] < b) {
-                int step = 0;
-                while (k < K && g->orig_b[k] < b && step < 8) { k++; step++; }
-                if (k < K && g->orig_b[k] < b) k = (size_t)(std::lower_bound(g->orig_b.begin() + (ptrdiff_t)k, g->orig_b.end(), b) - g->orig_b.begin());
-            }
-            if (k < K && g->orig_b[k] == b) { const int c = g->orig_id[k]; if (g->nodes[(size_t)c].alive && g->nodes[(size_t)c].b == b && g->nodes[(size_t)c].e == nodes[i].e) x = c; }
-            if (x < 0 && g->made_on) { const int c = g->made.get(b); if (c >= 0 && g->nodes[(size_t)c].alive && g->nodes[(size_t)c].b == b && g->nodes[(size_t)c].e == nodes[i].e) x = c; }
-            if (x < 0) {
-                auto it = g->at.find(b);
-                if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[i].e) {
-                    rv_set_error("graph: interval of the sub-index [%lld,%lld) is not a node of the graph", (long long)b, (long long)nodes[i].e); return -1;
+        std::vector<int> &cand = g->look_tmp;
+        cand.assign(nn, -1);
+        const size_t D = 12;
+        for (size_t i = 0; i < nn + 2 * D; i++) {
+            if (g->made_on && i < nn) __builtin_prefetch(g->made.home(nodes[i].b));
+            if (g->made_on && i >= D && i - D < nn) { const int c = g->made.get(nodes[i - D].b); cand[i - D] = c; if (c >= 0) __builtin_prefetch(&g->nodes[(size_t)c]); }
+            if (i >= 2 * D) {
+                const size_t j = i - 2 * D;
+                const int64_t b = nodes[j].b;
+                int x = cand[j];
+                if (x >= 0 && !(g->nodes[(size_t)x].alive && g->nodes[(size_t)x].b == b && g->nodes[(size_t)x].e == nodes[j].e)) x = -1;
+                if (x < 0) {
+                    auto it = g->at.find(b);
+                    if (it == g->at.end() || !g->nodes[(size_t)it->second].alive || g->nodes[(size_t)it->second].e != nodes[j].e) {
+                        rv_set_error("graph: interval of the sub-index [%lld,%lld) is not a node of the graph", (long long)b, (long long)nodes[j].e); return -1;
+                    }
+                    x = it->second;
                 }
-                x = it->second;
+                mine.push_back(x);
             }
-            mine.push_back(x);
         }
     }
     phase(0);

@@ -1693,8 +1693,13 @@ static void pick_one(rv_index *h, int s, PickScratch &X, PickRes &R, RvGraphIv g
     po.seed_l = X.pk_sl.data(); po.seed_n = X.pk_sn.data(); po.seed_off = X.pk_soff.data(); po.seed_so = X.pk_sso.data(); po.seed_pos = X.pk_spos.data();
     po.seed_score = X.pk_ssc.data(); po.seed_right = X.pk_srt.data();
     const double tp1 = now_s();
+    auto graph_pick = [&]() -> int {      // (host containers grow in there: no exception may leave through the C ABI)
+        try { return rv_graph_do_pick(a->ggraph, &a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), gleft, gright, a->minl, &po); }
+        catch (const std::exception &e) { rv_set_error("graph picker: %s", e.what()); return -1; }
+        catch (...) { rv_set_error("graph picker failed"); return -1; }
+    };
     const int pr = a->picker == 2
-        ? rv_graph_do_pick(a->ggraph, &a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), gleft, gright, a->minl, &po)
+        ? graph_pick()
         : rv_pick_chain(&a->pargs, want, (int64_t)X.pk_l.size(), X.pk_l.data(), X.pk_n.data(), X.pk_off.data(), X.pk_mso.data(), X.pk_mpos.data(), W,
                         X.pk_sb.data(), X.pk_ib.data(), X.pk_ie.data(), a->minl, &po);
     R.t_pick = now_s() - tp1; R.t_list = tp1 - tp0;
@@ -1914,7 +1919,11 @@ static int builtin_levels(rv_index *h, int stop_subs) {
                     RvGraphAlignOut &GO = a->g_out;
                     static_assert(sizeof(RvGraphIv) == sizeof(RvIntv), "interval layouts");
                     const double tg0 = now_s();
-                    RV_TRY(rv_graph_do_align(a->ggraph, (const RvGraphIv *)nodes, nn, a->g_left[(size_t)s], a->g_right[(size_t)s], bl, pk_pos.data(), (int)sp.size(), GO));
+                    int grc;
+                    try { grc = rv_graph_do_align(a->ggraph, (const RvGraphIv *)nodes, nn, a->g_left[(size_t)s], a->g_right[(size_t)s], bl, pk_pos.data(), (int)sp.size(), GO); }
+                    catch (const std::exception &e) { rv_set_error("graphalign: %s", e.what()); grc = -1; }
+                    catch (...) { rv_set_error("graphalign failed"); grc = -1; }
+                    RV_TRY(grc);
                     a->galign_ns += (int64_t)((now_s() - tg0) * 1e9);
                     a->g_newleft[(size_t)s] = GO.newleft; a->g_newright[(size_t)s] = GO.newright;
                     auto cp = [](std::vector<RvIntv> &d, const std::vector<RvGraphIv> &v) { for (const RvGraphIv &x : v) d.push_back({x.b, x.e}); };

@@ -418,7 +418,10 @@ enum { RV_K_SCAN_PAIR = 0, RV_K_SCAN_MULTI = 1, RV_K_SA_SORT = 2, RV_K_LCP = 3, 
        RV_K_RADIX_SCATTER = 7, RV_K_RADIX_HIST = 8, RV_K_TEXT_ROUND = 9,
        RV_K_CASCADE = 10,      /* the anchor cascade behind its scan: witnesses, match sort, levels, rebuild + leaf launch */
        RV_K_DIAG_TABLE = 11,   /* part of RV_K_SA_SORT: piecewise diagonals from seeds (two samples that left their fixed diagonal: indels) */
-       RV_K_COUNT = 12 };
+       RV_K_INIT_KEYS = 12,    /* part of RV_K_SA_SORT: the first keys (bytes: the text once, a key + suffix + digit byte per kept suffix) */
+       RV_K_PUBLISH = 13,      /* part of RV_K_SA_SORT: heads of the sorted list and the finished ranks' SA / LCP / BWT (bytes: key + suffix read per entry, key + suffix
+                                  written in rank order, 9 B per position written) */
+       RV_K_COUNT = 14 };
 /* on: 0 = off, 1 = every class, otherwise bit k+1 selects class k (an event pair costs the stream a few
  * microseconds, so a timed run times only what it reports) */
 int rv_prof_enable(rv_index *h, int on);

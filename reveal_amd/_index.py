@@ -184,7 +184,8 @@ def make_index_type(sa64, error):
             only = names of the kernel classes to time (default: all; every timed span costs the stream two events)"""
             ids = {"scan_pair": _lib.K_SCAN_PAIR, "scan_multi": _lib.K_SCAN_MULTI, "sa_build": _lib.K_SA_SORT, "lcp": _lib.K_LCP,
                    "split": _lib.K_SPLIT, "label": _lib.K_LABEL, "bubble": _lib.K_BUBBLE, "radix_scatter": _lib.K_RADIX_SCATTER,
-                   "radix_hist": _lib.K_RADIX_HIST, "text_round": _lib.K_TEXT_ROUND, "cascade": _lib.K_CASCADE, "diag_table": _lib.K_DIAG_TABLE}
+                   "radix_hist": _lib.K_RADIX_HIST, "text_round": _lib.K_TEXT_ROUND, "cascade": _lib.K_CASCADE, "diag_table": _lib.K_DIAG_TABLE,
+                   "init_keys": _lib.K_INIT_KEYS, "publish": _lib.K_PUBLISH}
             if enable is not None:
                 on = 0
                 if enable:

@@ -14,7 +14,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 
 RV_T, RV_SA, RV_SAI, RV_LCP, RV_SO, RV_NSEP, RV_NODES = range(7)
-K_SCAN_PAIR, K_SCAN_MULTI, K_SA_SORT, K_LCP, K_SPLIT, K_LABEL, K_BUBBLE, K_RADIX_SCATTER, K_RADIX_HIST, K_TEXT_ROUND, K_CASCADE, K_DIAG_TABLE = range(12)
+K_SCAN_PAIR, K_SCAN_MULTI, K_SA_SORT, K_LCP, K_SPLIT, K_LABEL, K_BUBBLE, K_RADIX_SCATTER, K_RADIX_HIST, K_TEXT_ROUND, K_CASCADE, K_DIAG_TABLE, K_INIT_KEYS, K_PUBLISH = range(14)
 
 c_i64p = ctypes.POINTER(ctypes.c_int64)
 V = ctypes.c_void_p

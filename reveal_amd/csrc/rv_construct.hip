@@ -2708,7 +2708,9 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         const dim3 ig((unsigned)std::min<int64_t>(iktiles, 256 * 8));      // persistent: eight workgroups of four waves per CU
 #define RV_IK_(G) hipLaunchKernelGGL(k_init_keys<G>, ig, dim3(TB), 0, q, T, n, d_lut.as<uint8_t>(), K, kp, bk0.as<u64>(), bv0.as<sav_t>(), fused ? 1 : 0, \
                                      kd.stop0, kd.stop1, kd.ly, dg, tw_off, iktiles)
+        const int ikid = ws.prof_begin(12 /* RV_K_INIT_KEYS */, (double)n + (double)nsort * (8.0 + sizeof(sav_t) + 1.0));
         switch (kp.g) { case 1: RV_IK_(1); break; case 2: RV_IK_(2); break; case 3: RV_IK_(3); break; case 4: RV_IK_(4); break; default: RV_IK_(5); break; }
+        ws.prof_end(ikid);
 #undef RV_IK_
     }
     SA_HIP(hipGetLastError());
@@ -2734,8 +2736,10 @@ int rv_build_sa(Workspace &ws, const uint8_t *T, int64_t n, sa_t *SA, RvSaStats 
         SA_TRY(rv_exclusive_sum_u32(ws, bc, bc, nb));
         sav_t *vexp = reinterpret_cast<sav_t *>(bisa.p);      // (the inverse is only built on demand, after the round-0 list has been made)
         if (sizeof(sav_t) > 4) { SA_TRY(ws.sa[24].reserve((size_t)n * sizeof(sav_t))); vexp = ws.sa[24].as<sav_t>(); }
+        const int pbid = ws.prof_begin(13 /* RV_K_PUBLISH */, (double)nsort * 2.0 * (8.0 + sizeof(sav_t)) + (double)n * (1.0 + sizeof(sa_t) + sizeof(lcp_t) + 1.0));
         hipLaunchKernelGGL(k_heads_publish_tc, dim3((unsigned)nb), dim3(TB), 0, q, (const u64 *)ks, (const sav_t *)vs, nsort, (const u32 *)bc, head, LCP, SA, BWT,
                            side_sep, kd, d_maxlcp, ws.opt.no_pub_twins ? 0 : 1, kt, vexp);
+        ws.prof_end(pbid);
         SA_HIP(hipGetLastError());
         keys_by_rank = kt; vals_by_rank = vexp;
     } else if (fused && kd.ly.nd_bits > 0 && !ws.opt.no_heads_fusion) {

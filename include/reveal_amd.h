@@ -63,6 +63,7 @@ int rv_reserve_text(rv_index *h, int64_t bytes);
 int64_t rv_n(const rv_index *h);        /* reveal_getn (interface.c:681-689): ranks in the main index */
 int rv_nsamples(const rv_index *h);     /* interface.c:691-695 */
 int rv_nnodes(const rv_index *h);       /* number of sequence intervals added so far */
+int rv_add_sequences(rv_index *h, const char *text, int64_t total, const int64_t *lens, int64_t count);      /* count sequences at once: each followed by '$' in text */
 int rv_node_list(const rv_index *h, int64_t *begin_end);      /* those intervals, 2 * rv_nnodes numbers (sequences added inside the library: rv_graph_read_gfa) */
 
 /* ---- construct (interface.c:160-291) ------------------------------------- */
@@ -386,6 +387,12 @@ int rv_set_graph_picker(rv_index *h, rv_graph *g, const rv_picker_args *args);
 rv_graph *rv_graph_new(void);
 int rv_graph_add_linear(rv_graph *g, int64_t b, int64_t e, int star);
 int64_t rv_graph_read_gfa(rv_graph *g, rv_index *h, int64_t *text_n, const char *data, int64_t len, const char **names);
+/* The same reader in two halves, so that the files of a job are parsed side by side: rv_gfa_parse (any thread; touches no graph and no index) -> an object that holds the
+ * file's graph and text; rv_graph_adopt (in the order of the inputs) appends both to h and g and returns what rv_graph_read_gfa returns; rv_gfa_parsed_free. */
+typedef struct GfaParsed rv_gfa_parsed;
+rv_gfa_parsed *rv_gfa_parse(const char *data, int64_t len);
+int64_t rv_graph_adopt(rv_graph *g, rv_index *h, int64_t *text_n, rv_gfa_parsed *parsed, const char **names);
+void rv_gfa_parsed_free(rv_gfa_parsed *parsed);
 int rv_graph_seal(rv_graph *g);      /* after the last rv_graph_read_gfa / rv_graph_add_linear, before the graph is used: renumbers it, decides rv_graph_literal */
 int rv_graph_paths(const rv_graph *g, int64_t *id2end);
 int rv_graph_node_kinds(const rv_graph *g, int8_t *out);

@@ -145,6 +145,10 @@ SYMBOLS = {
     "rv_graph_read_gfa": (_L, [V, V, V, V, _L, V]),
     "rv_graph_paths": (_I, [V, V]),
     "rv_graph_seal": (_I, [V]),
+    "rv_gfa_parse": (V, [V, _L]),
+    "rv_graph_adopt": (_L, [V, V, V, V, V]),
+    "rv_gfa_parsed_free": (None, [V]),
+    "rv_add_sequences": (_I, [V, V, _L, V, _L]),
     "rv_graph_node_kinds": (_I, [V, V]),
     "rv_graph_literal": (_I, [V]),
     "rv_graph_replay": (V, [_I, V, V, _L, V, V, V]),

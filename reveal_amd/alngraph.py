@@ -581,7 +581,7 @@ class LoopGraph(NativeGraph):
         self.sentinels0 = [n for n in self.nodes0 if not isinstance(n, tuple)]
 
     @classmethod
-    def read(cls, inputfiles, idx, G, contigs=True, toupper=True, sa64=False):
+    def read(cls, inputfiles, idx, G, contigs=True, toupper=True, sa64=False, threads=None):
         """the inputs read behind the ABI (rv_graph_add_linear / rv_graph_read_gfa: csrc/rv_gfaread.hip): sequences go to `idx` (reveal_amd's index) as the
         Python readers would add them, the graph is made where the run uses it; of `G` only the path tables are filled.  Raises ReverseStrand when a file
         holds links on the reverse strand -- idx and G are half-filled then: start over with the Python readers."""
@@ -599,28 +599,51 @@ class LoopGraph(NativeGraph):
             # one allocation of the (page-locked) host text: a file is never shorter than the text it adds
             total = sum(os.path.getsize(f) for f in inputfiles if not f.endswith(".gz"))
             dll.rv_reserve_text(idx._h, int(dll.rv_n(idx._h)) + total + 64)
+        # graph files are parsed side by side (rv_gfa_parse touches neither graph nor index; the library call runs without the interpreter's lock) and adopted in
+        # the order of the inputs (rv_graph_adopt)
+        gfas = [f for f in inputfiles if f.endswith(".gfa") or f.endswith(".gfa.gz")]
+
+        def parse(f):
+            with (gzip.open if f.endswith(".gz") else open)(f, "rb") as fh:
+                data = fh.read()
+            return dll.rv_gfa_parse(data, len(data))
+        pool, pending = None, {}
+        if len(gfas) > 1 and threads != 1:
+            from concurrent.futures import ThreadPoolExecutor
+            pool = ThreadPoolExecutor(max_workers=min(len(gfas), threads or 4))
+            pending = {f: pool.submit(parse, f) for f in gfas}
         for f in inputfiles:
             if f.endswith(".gfa") or f.endswith(".gfa.gz"):
                 idx.addsample(os.path.basename(f))
-                with (gzip.open if f.endswith(".gz") else open)(f, "rb") as fh:
-                    data = fh.read()
+                parsed = pending.pop(f).result() if f in pending else parse(f)
+                if not parsed:
+                    self.close()
+                    raise MemoryError(self._lib.err())
                 names = ctypes.c_char_p()
                 if getattr(idx, "_h", None) is not None:
-                    n = dll.rv_graph_read_gfa(self._g, idx._h, None, data, len(data), ctypes.byref(names))
+                    n = dll.rv_graph_adopt(self._g, idx._h, None, parsed, ctypes.byref(names))
                 else:      # (an index stand-in that only counts text positions -- tests without a device: the graph alone)
                     tn = ctypes.c_int64(idx.n)
-                    n = dll.rv_graph_read_gfa(self._g, None, ctypes.byref(tn), data, len(data), ctypes.byref(names))
+                    n = dll.rv_graph_adopt(self._g, None, ctypes.byref(tn), parsed, ctypes.byref(names))
                     idx.n = tn.value
+                why = self._lib.err() if n == -1 else None
+                dll.rv_gfa_parsed_free(parsed)
+                if n < 0:
+                    for fut in pending.values():
+                        p2 = fut.result()
+                        if p2:
+                            dll.rv_gfa_parsed_free(p2)
+                    pending = {}
+                    if pool is not None:
+                        pool.shutdown()
                 if n == -2:
                     self.close()
                     raise ReverseStrand(f)
                 if n < 0:
-                    why = self._lib.err()
                     self.close()
                     raise ValueError("%s: %s" % (f, why))
                 for name in names.value.decode("latin-1").split("\n")[:n]:
                     _new_path(G, name)
-                del data
             else:
                 if contigs:
                     idx.addsample(os.path.basename(f))
@@ -632,6 +655,8 @@ class LoopGraph(NativeGraph):
                     b, e = idx.addsequence(seq)
                     if dll.rv_graph_add_linear(self._g, b, e, 1 if name.startswith("*") else 0) != sid:
                         raise RuntimeError("path ids out of step: " + self._lib.err())
+        if pool is not None:
+            pool.shutdown()
         if dll.rv_graph_seal(self._g) != 0:
             raise MemoryError(self._lib.err())
         if hasattr(idx, "_sync_nodes"):

@@ -251,6 +251,62 @@ int rv_add_sequence(rv_index *h, const char *seq, int64_t len, int64_t *begin, i
     return 0;
 }
 
+/* `count` sequences of the current sample at once: text = the sequences with a '$' behind each (total bytes), lens their lengths -- what count calls of
+ * rv_add_sequence would leave, with one copy (the segments of a graph file: rv_graph_adopt) */
+int rv_add_sequences(rv_index *h, const char *text, int64_t total, const int64_t *lens, int64_t count) {
+    if (!h || !text || total < 0 || count < 0 || (count && !lens)) { rv_set_error("rv_add_sequences: bad arguments"); return -1; }
+    int64_t sum = 0;
+    for (int64_t k = 0; k < count; k++) { if (lens[k] < 0) { rv_set_error("rv_add_sequences: negative length"); return -1; } sum += lens[k] + 1; }
+    if (sum != total) { rv_set_error("rv_add_sequences: lengths and text do not agree"); return -1; }
+#ifndef RV_SA64
+    if ((uint64_t)h->n + (uint64_t)total + 1 > (uint64_t)INT_MAX) {
+        rv_set_error("Total amount of sequence too large, use \"reveal <subcommand> --64\" to use 64 bit suffix arrays instead.");
+        return -1;
+    }
+#endif
+    if ((size_t)(h->n + total + 1) > h->T.cap) (void)hipSetDevice(h->device);
+    if (h->T.resize((size_t)(h->n + total + 1)) != 0) return -1;
+    char *dst = h->T.data() + h->n;
+    uint64_t acc = 0;
+    {
+        const int nt = total >= ((int64_t)4 << 20) ? 4 : 1;
+        std::vector<uint64_t> part((size_t)nt, 0);
+        auto work = [&](int t) {
+            const int64_t lo = total / nt * t, hi = t + 1 == nt ? total : total / nt * (t + 1);
+            memcpy(dst + lo, text + lo, (size_t)(hi - lo));
+            uint64_t a = 0; int64_t k = lo;
+            for (; k + 8 <= hi; k += 8) { uint64_t w; memcpy(&w, text + k, 8); a |= w; }
+            for (; k < hi; k++) a |= (uint64_t)(uint8_t)text[k];
+            part[(size_t)t] = a;
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) { try { th.emplace_back(work, t); } catch (...) { work(t); } }
+        work(0);
+        for (auto &x : th) x.join();
+        for (uint64_t a : part) acc |= a;
+    }
+    if (acc & 0x8080808080808080ull) {
+        (void)h->T.resize((size_t)h->n + 1);
+        h->T[(size_t)h->n] = '\0';
+        rv_set_error("addsequence: the sequence contains non-ASCII bytes");
+        return -1;
+    }
+    try {
+        h->nodes.reserve(h->nodes.size() + (size_t)count);
+        int64_t at = h->n;
+        for (int64_t k = 0; k < count; k++) {
+            if (dst[at - h->n + lens[k]] != '$') { rv_set_error("rv_add_sequences: no '$' behind sequence %lld", (long long)k); (void)h->T.resize((size_t)h->n + 1); h->T[(size_t)h->n] = '\0'; return -1; }
+            h->nodes.push_back(RvIntv{at, at + lens[k]});
+            at += lens[k] + 1;
+        }
+    } catch (...) { rv_set_error("addsequence: out of host memory"); return -1; }
+    h->T[(size_t)(h->n + total)] = '\0';
+    h->n += total;
+    h->text_dirty = true;
+    h->constructed = false; h->text_only = false;
+    return 0;
+}
+
 /* Forget the text and the samples; keep every allocation (host text, device arrays, SA-build scratch, streams): the handle is ready for
  * the next input's addsample / addsequence.  No counterpart in the reference, whose callers make a new index object per input -- which
  * here would allocate ~86 B per position of device memory again.  Result arrays set by rv_set_result_buffers stay set. */

@@ -134,6 +134,21 @@ def test_readers_behind_the_abi_leave_the_same_graph(tmp_path, refmod):
         assert via_arrays.snapshot() == lg.snapshot()
         assert lg._dll.rv_graph_literal(lg._g) == (1 if Gp.literal_segments else 0)
         assert lg.counts() == via_arrays.counts() == (len(Gp.seq_nodes()), Gp.number_of_edges())
+        # the one-call form of the reader (rv_graph_read_gfa) leaves the same graph as parse + adopt
+        if all(not f.endswith(".fa") for f in inputs):
+            import ctypes
+            one = alngraph.LoopGraph.__new__(alngraph.LoopGraph)
+            one._lib, one._dll = lg._lib, lg._dll
+            one._g = lg._dll.rv_graph_new()
+            tn = ctypes.c_int64(0)
+            for f in inputs:
+                import gzip
+                data = (gzip.open if f.endswith(".gz") else open)(f, "rb").read()
+                assert lg._dll.rv_graph_read_gfa(one._g, None, ctypes.byref(tn), data, len(data), None) > 0
+            assert lg._dll.rv_graph_seal(one._g) == 0 and tn.value == tp.n
+            one.names, one.sentinels0, one.nodes0 = list(Gp.paths), None, None
+            assert one.snapshot() == lg.snapshot()
+            one.close()
         # and back into Python objects
         n = lg.load_into(Gn)
         assert n == Gp.number_of_nodes() and alngraph.graph_snapshot(Gn) == alngraph.graph_snapshot(Gp)

@@ -290,10 +290,11 @@ int rv_graph_do_pick(rv_graph *g, const rv_picker_args *A, int nsub, int64_t m, 
         return true;
     };
     auto val_hash = [&](size_t i) { uint64_t h = 0x9E3779B97F4A7C15ull ^ (uint64_t)rel[i].cnt; for (uint32_t z = 0; z < rel[i].cnt; z++) h ^= (uint64_t)pt[rel[i].first + z].second + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h; };
-    std::unordered_map<uint64_t, uint32_t> last_by_hash;
-    last_by_hash.reserve(cnt * 2);
-    for (size_t i = 0; i < cnt; i++) last_by_hash[val_hash(i)] = (uint32_t)i;
+    std::unordered_map<uint64_t, uint32_t> last_by_hash;      // (made when somebody asks: most calls hold one or two matches)
+    bool hashed = false;
     auto mapped = [&](size_t i) -> size_t {
+        if (cnt <= 8) { size_t r = i; for (size_t j = i + 1; j < cnt; j++) if (same_vals(j, i)) r = j; return r; }
+        if (!hashed) { last_by_hash.reserve(cnt * 2); for (size_t j = 0; j < cnt; j++) last_by_hash[val_hash(j)] = (uint32_t)j; hashed = true; }
         const auto it = last_by_hash.find(val_hash(i));
         if (it != last_by_hash.end() && same_vals(it->second, i)) return it->second;
         size_t r = i;      // (two different value tuples under one hash: the walk)

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/reveal_amd.h"
 #include <algorithm>
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -66,7 +67,9 @@ public:
     CIt end() const { return CIt{p() + n_}; }
 };
 
-struct GNode {
+// A node is two cache lines (128 B, aligned): what a walk reads -- interval, flags, marks and the links it follows forwards -- in the first, the links backwards, the offsets and
+// the dictionary position in the second.
+struct alignas(64) GNode {
     int64_t b, e;                                   // text interval; sentinels: b = sample, e = 0 (start) / 1 (end)
     int8_t aligned;                                 // -1: sentinel
     int8_t sent = 0;                                // sentinels: 1 a start node, 2 an end node
@@ -75,10 +78,12 @@ struct GNode {
     // the last job of config 5 touches 10^7 nodes a dozen times).  Valid while the epoch matches (rv_graph::sub_epoch / walk_epoch): nothing is reset between calls.
     uint8_t cls = 0;                                // bit 0 leading, bit 1 trailing (while ep_sub == sub_epoch)
     uint32_t ep_sub = 0, ep_walk = 0;               // belongs to the sub-index of the current graphalign call / reached by the current walk
-    uint64_t order;                                 // position in the graph's node dictionary (creation order)
+    LinkVec succ;                                   // links forwards, in dictionary order (iterating yields edge ids)
+    LinkVec pred;                                   // links backwards
     std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
-    LinkVec succ, pred;                             // links forwards / backwards, in dictionary order (iterating yields edge ids)
+    uint64_t order;                                 // position in the graph's node dictionary (creation order)
 };
+static_assert(sizeof(GNode) == 128 && offsetof(GNode, succ) + sizeof(LinkVec) <= 64 && offsetof(GNode, pred) + sizeof(LinkVec) <= 128, "GNode layout");
 // The path ids an edge carries.  A graph of up to 256 paths keeps them as four words (uniting two sets, and asking for a member, cost a few instructions
 // instead of an allocation: the anchors' surgery spent most of its time in malloc -- and again when the last job of config 5, a hundred paths, outgrew the
 // one word this began with: 64 of graphalign's 73 us per call); more paths: a sorted vector as before.

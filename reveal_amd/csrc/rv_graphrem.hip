@@ -152,7 +152,11 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
                 GNode &c = g->nodes[(size_t)lk[k].to];
                 if (c.ep_walk == we || (any_star && !real_edge(g, g->edges[(size_t)lk[k].e].paths, true))) continue;
                 c.ep_walk = we;
-                if (c.aligned == 0) { queue.push_back(lk[k].to); if (c.ep_sub == se) c.cls |= bit; }
+                if (c.aligned == 0) {
+                    queue.push_back(lk[k].to);
+                    if (reverse) __builtin_prefetch((const char *)&c + 64);      // (its links backwards are in the node's second line)
+                    if (c.ep_sub == se) c.cls |= bit;
+                }
             }
         }
     };

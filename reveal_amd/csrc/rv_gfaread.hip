@@ -340,7 +340,7 @@ int64_t rv_graph_adopt(rv_graph *g, rv_index *h, int64_t *text_n, GfaParsed *P, 
             g->nodes.push_back(std::move(n));
             const int id = (int)g->nodes.size() - 1;
             const GNode &m = g->nodes[(size_t)id];
-            if (m.alive && m.aligned >= 0) { g->at.emplace_hint(g->at.end(), m.b, id); if (g->made_on) g->made.put(m.b, id); }      // (begins grow with the text)
+            if (m.alive && m.aligned >= 0) { g->at.emplace_hint(g->at.end(), m.b, id); if (g->made_on) { g->made.put(m.b, id); g->mark_begin(m.b); } }      // (begins grow with the text)
         }
         for (int x : f.start_of) g->start_of.push_back(x + node_base);
         g->star.insert(g->star.end(), f.star.begin(), f.star.end());

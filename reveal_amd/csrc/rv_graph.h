@@ -178,6 +178,7 @@ struct rv_graph {
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
     double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // graphalign: seconds in look-ups / breaks + merge / walks / lists / sorts (RV_GRAPH_TIMES=1 prints them when the graph is renumbered)
     uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
+    std::vector<uint64_t> begbits;                  // one bit per text position: a node begins here (kept with `made`; the predecessor search of fast_node_at)
     BeginHash made; bool made_on = false;           // graphalign: begin -> node, every sequence node from its first large call on (new_node keeps it up)
     std::vector<int> look_tmp;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
@@ -189,7 +190,7 @@ struct rv_graph {
         n.b = b; n.e = e; n.aligned = aligned; n.alive = true; n.order = counter++;
         nodes.push_back(std::move(n));
         const int id = (int)nodes.size() - 1;
-        if (aligned >= 0) { at[b] = id; if (made_on) made.put(b, id); }
+        if (aligned >= 0) { at[b] = id; if (made_on) { made.put(b, id); mark_begin(b); } }
         return id;
     }
     // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
@@ -208,6 +209,25 @@ struct rv_graph {
         n.succ.clear(); n.pred.clear(); n.off.clear(); n.alive = false;
         auto it = at.find(n.b);
         if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
+    }
+    void mark_begin(int64_t b) {
+        const size_t w = (size_t)(b >> 6);
+        if (w >= begbits.size()) begbits.resize(w + w / 4 + 1024, 0);
+        begbits[w] |= 1ull << (b & 63);
+    }
+    // node_at without the search from the root of the position map: the nearest begin at or in front of pos from the bitmap (nodes are tens of positions long: the same
+    // word, or the one before), its node from the hash; anything that does not check out -- a begin whose node is gone -- goes to node_at
+    int fast_node_at(int64_t pos) {
+        if (!made_on || pos < 0) return node_at(pos);
+        size_t w = (size_t)(pos >> 6);
+        uint64_t bits;
+        if (w >= begbits.size()) { if (begbits.empty()) return node_at(pos); w = begbits.size() - 1; bits = begbits[w]; }
+        else bits = begbits[w] & (~0ull >> (63 - (pos & 63)));
+        for (int guard = 0; !bits; guard++) { if (w == 0 || guard > 64) return node_at(pos); bits = begbits[--w]; }
+        const int64_t b = (int64_t)(w << 6) + 63 - __builtin_clzll(bits);
+        const int id = made.get(b);
+        if (id >= 0) { const GNode &n = nodes[(size_t)id]; if (n.alive && n.aligned >= 0 && n.b == b && pos < n.e) return id; }
+        return node_at(pos);
     }
     int node_at(int64_t pos) {
         auto it = at.upper_bound(pos);
@@ -308,7 +328,7 @@ struct rv_graph {
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
-        made.clear(); made_on = false;
+        made.clear(); made_on = false; begbits.clear();
     }
     void finish() {
         order.clear();

@@ -89,7 +89,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
         // names prefetched, then the node is checked (alive, the same interval) and marked.  An interval the hash does not hold goes to the position map.
         if (!g->made_on && nn >= 64) {
             g->made.reserve(g->at.size() + g->at.size() / 2);
-            for (auto &kv : g->at) g->made.put(kv.first, kv.second);
+            for (auto &kv : g->at) { g->made.put(kv.first, kv.second); g->mark_begin(kv.first); }
             g->made_on = true;      // (what is made from here on registers itself: rv_graph::new_node)
         }
         std::vector<int> &cand = g->look_tmp;
@@ -122,7 +122,7 @@ int rv_graph_do_align(rv_graph *g, const RvGraphIv *nodes, size_t nn, RvGraphIv 
     std::vector<int> mns;
     for (int q = 0; q < npos; q++) {
         O.match.push_back({pos[q], pos[q] + (int64_t)l});
-        const int old = g->node_at(pos[q]);
+        const int old = g->fast_node_at(pos[q]);
         if (old < 0 || pos[q] + (int64_t)l > g->nodes[(size_t)old].e) { rv_set_error("graph: a member of the match lies in no node of the graph"); return -1; }
         int pn = -1, sn = -1;
         const int mn = g->breaknode(old, pos[q], (int64_t)l, &pn, &sn);
@@ -273,7 +273,7 @@ int rv_graph_do_pick(rv_graph *g, const rv_picker_args *A, int nsub, int64_t m, 
         r.i = (uint32_t)i; r.n = 0; r.first = (uint32_t)pt.size();
         for (int q = 0; q < mm[i].nm; q++) {
             const int64_t p = X.at(mm[i], (size_t)q);
-            const int x = g->node_at(p);
+            const int x = g->fast_node_at(p);
             if (x < 0) { for (size_t z = r.first; z < pt.size(); z++) pm[(size_t)pt[z].first] = 0; rv_set_error("rv_graph_pick: a match's member lies in no node of the graph"); return -1; }
             const GNode &nd = g->nodes[(size_t)x];
             for (auto &a : nd.off) {

@@ -198,26 +198,36 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
     int nid = 0;
     for (int x : g->order) if (nodes[(size_t)x].aligned >= 0) ident[(size_t)x] = ++nid;
     o += "H\tVN:Z:1.0\tCL:Z:"; o += cmdline ? cmdline : ""; o += "\n";
-    {
-        size_t need = 256;
-        for (int x : g->order) { const GNode &n = nodes[(size_t)x]; if (n.aligned >= 0) need += (size_t)(n.e - n.b) + 16 + 40 * n.succ.size() + 24 * n.off.size(); }
-        o.reserve(need);
-    }
-    for (int x : g->order) {
-        const GNode &n = nodes[(size_t)x];
-        if (n.aligned < 0) continue;
-        o += "S\t"; put_int(o, ident[(size_t)x]); o += '\t';
-        const size_t at = o.size();
-        o.append(T + n.b, (size_t)(n.e - n.b));
-        if (n.aligned > 0)
-            for (size_t i = at; i < o.size(); i++) { const char c = o[i]; if (c >= 'a' && c <= 'z') o[i] = (char)(c - 32); }
-        o += "\n";
-        for (int e : n.succ) {
-            const int v = edges[(size_t)e].v;
-            if (nodes[(size_t)v].aligned < 0) continue;
-            o += "L\t"; put_int(o, ident[(size_t)x]); o += "\t+\t"; put_int(o, ident[(size_t)v]); o += "\t+\t0M\n";
+    // S and L lines: the nodes in dictionary order, in stretches written side by side and put together afterwards
+    const size_t norder = g->order.size();
+    const char *env_min = getenv("RV_GFA_PARALLEL_MIN");      // (tests: the threaded form on small graphs)
+    const size_t par_min = env_min ? (size_t)atoll(env_min) : 100000;
+    const int nchunks = norder >= std::max<size_t>(par_min, 16) ? 16 : 1;
+    std::vector<std::string> chunks((size_t)nchunks);
+    auto write_chunk = [&](int c) {
+        std::string &oc = chunks[(size_t)c];
+        const size_t lo = norder * (size_t)c / (size_t)nchunks, hi = norder * (size_t)(c + 1) / (size_t)nchunks;
+        size_t need = 64;
+        for (size_t k = lo; k < hi; k++) { const GNode &n = nodes[(size_t)g->order[k]]; if (n.aligned >= 0) need += (size_t)(n.e - n.b) + 16 + 40 * n.succ.size(); }
+        oc.reserve(need);
+        for (size_t k = lo; k < hi; k++) {
+            const int x = g->order[k];
+            const GNode &n = nodes[(size_t)x];
+            if (n.aligned < 0) continue;
+            oc += "S\t"; put_int(oc, ident[(size_t)x]); oc += '\t';
+            const size_t at = oc.size();
+            oc.append(T + n.b, (size_t)(n.e - n.b));
+            if (n.aligned > 0)
+                for (size_t i = at; i < oc.size(); i++) { const char ch = oc[i]; if (ch >= 'a' && ch <= 'z') oc[i] = (char)(ch - 32); }
+            oc += "\n";
+            const Link *lk = n.succ.links();
+            for (size_t q = 0; q < n.succ.size(); q++) {
+                const int v = lk[q].to;
+                if (nodes[(size_t)v].aligned < 0) continue;
+                oc += "L\t"; put_int(oc, ident[(size_t)x]); oc += "\t+\t"; put_int(oc, ident[(size_t)v]); oc += "\t+\t0M\n";
+            }
         }
-    }
+    };
     // the start sentinels in the reader's order (start_of: sample s' is node 3 s of the replay, wherever compact() has moved it).  The walks are independent of each
     // other and read only: on a few threads (a hundred paths of 10^6 steps each, a cache miss per step, were half of the writer's time)
     std::vector<std::string> plines((size_t)std::max(npaths, 0));
@@ -250,15 +260,29 @@ static int64_t graph_gfa(rv_graph *g, const char *T, int npaths, const char *con
         ln += "P\t"; ln += names[sid]; ln += "\t"; ln += path; ln += "\t"; ln += cigar; ln += "\n";
     };
     {
+        // one pool for both kinds of work: the stretches of nodes first, then a path each
+        const int ntasks = nchunks + std::max(npaths, 0);
         int nt = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-        nt = std::min(nt, npaths);
-        if (nodes.size() < 100000) nt = 1;
+        nt = std::min(nt, ntasks);
+        if (nodes.size() < par_min) nt = 1;
         std::atomic<int> next{0};
-        auto worker = [&]() { for (;;) { const int sid = next.fetch_add(1); if (sid >= npaths) return; walk(sid); } };
+        std::atomic<bool> failed{false};
+        auto worker = [&]() {
+            try { for (;;) { const int k = next.fetch_add(1); if (k >= ntasks) return; if (k < nchunks) write_chunk(k); else walk(k - nchunks); } }
+            catch (...) { failed = true; }
+        };
         std::vector<std::thread> th;
         for (int t = 1; t < nt; t++) { try { th.emplace_back(worker); } catch (...) { break; } }
         worker();
         for (auto &t : th) t.join();
+        if (failed) throw std::bad_alloc();
+    }
+    {
+        size_t need = o.size() + 16;
+        for (const std::string &c : chunks) need += c.size();
+        for (const std::string &c : plines) need += c.size();
+        o.reserve(need);
+        for (std::string &c : chunks) { o += c; std::string().swap(c); }
     }
     for (int sid = 0; sid < npaths; sid++) o += plines[(size_t)sid];
     *out = o.data();

@@ -124,7 +124,7 @@ static int graph_export(const rv_graph *g, int64_t *node_b, int64_t *node_e, int
  * unaligned sibling spell differently).  Which sibling survives, and where the survivor stands among its neighbours' links, follows the dictionary
  * order -- kept here. */
 static int graph_prune(rv_graph *g, const char *T) {
-    auto &nodes = g->nodes; auto &edges = g->edges;
+    auto &nodes = g->nodes;
     for (;;) {
         bool merged_any = false;
         g->finish();
@@ -136,9 +136,10 @@ static int graph_prune(rv_graph *g, const char *T) {
             const int node = queue.front(); queue.pop_front(); queued[(size_t)node] = 0;
             if (!nodes[(size_t)node].alive) continue;
             for (int dir = 0; dir < 2; dir++) {
+                const LinkVec &adj = dir == 0 ? nodes[(size_t)node].succ : nodes[(size_t)node].pred;
+                if (adj.size() < 2) continue;
                 neis.clear();
-                for (int e : (dir == 0 ? nodes[(size_t)node].succ : nodes[(size_t)node].pred)) neis.push_back(dir == 0 ? edges[(size_t)e].v : edges[(size_t)e].u);
-                if (neis.size() < 2) continue;
+                for (size_t k = 0; k < adj.size(); k++) neis.push_back(adj.links()[k].to);
                 // groups of neighbours that spell the same, in order of their first member; a group's members in the neighbours' order.  (rep[k] = the place of the
                 // first neighbour that spells like neighbour k: no list of lists made and thrown away per node -- most nodes have two neighbours that differ)
                 const size_t nk = neis.size();
@@ -166,8 +167,8 @@ static int graph_prune(rv_graph *g, const char *T) {
                     const int ref = g->mergenodes(grp);
                     merged_any = true;
                     again.clear(); again.push_back(node); again.push_back(ref);
-                    for (int e : nodes[(size_t)ref].succ) again.push_back(edges[(size_t)e].v);
-                    for (int e : nodes[(size_t)ref].pred) again.push_back(edges[(size_t)e].u);
+                    for (size_t k = 0; k < nodes[(size_t)ref].succ.size(); k++) again.push_back(nodes[(size_t)ref].succ.links()[k].to);
+                    for (size_t k = 0; k < nodes[(size_t)ref].pred.size(); k++) again.push_back(nodes[(size_t)ref].pred.links()[k].to);
                     for (int x : again)
                         if (!queued[(size_t)x] && nodes[(size_t)x].alive) { queue.push_back(x); queued[(size_t)x] = 1; }
                 }

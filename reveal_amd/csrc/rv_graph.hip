@@ -23,6 +23,7 @@ extern "C" {
 // (no exception may leave through the C ABI: bad_alloc from the vectors' growth becomes NULL / -1 and rv_last_error's text)
 static void replay_start(rv_graph *g, int nseq, const int64_t *begin, const int64_t *end) {
     g->nseq = nseq;
+    g->made_on = true;      // (a member's node through the bitmap of begins and the hash, rv_graph::fast_node_at: new_node keeps both up)
     // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
     for (int s = 0; s < nseq; s++) {
         const int st = g->new_node(s, 0, -1), iv = g->new_node(begin[s], end[s], 0), en = g->new_node(s, 1, -1);
@@ -40,7 +41,7 @@ static bool replay_apply(rv_graph *g, int64_t na, const uint32_t *an_l, const in
         mns.clear();
         const int64_t l = (int64_t)an_l[a];
         for (int64_t k = an_off[a] - base; k < an_off[a + 1] - base; k++) {
-            const int x = g->node_at(an_pos[k]);
+            const int x = g->fast_node_at(an_pos[k]);
             if (x < 0 || an_pos[k] + l > g->nodes[(size_t)x].e) { g->err = "rv_graph_replay: an anchor's member lies in no node of the graph"; return false; }
             mns.push_back(g->breaknode(x, an_pos[k], l));
         }

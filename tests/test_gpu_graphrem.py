@@ -180,3 +180,23 @@ def test_graph_inputs_native_synthetic(tmp_path):
     fn = _both_ways(tmp_path, graphs, "lvl1")
     spelled, _ = C.spelled_by_file(fn)
     assert spelled == {"genome%d" % k: s.decode() for k, s in enumerate(seqs)}
+
+
+@pytest.mark.parametrize("seed,kw", [(3, dict(snp=0.02, indelfrac=0.3)), (5, dict(snp=0.01, repeats=0.05)), (7, dict(snp=0.03, indelfrac=0.2, repeats=0.02, nruns=3)),
+                                     (11, dict(snp=0.005, indelfrac=0.5))])
+def test_graph_inputs_native_random_families(tmp_path, seed, kw):
+    """unfriendly families (indels, interspersed repeats and tandem arrays, runs of N): seven genomes of 30 kbp as graphs of 3 + 2 + 2, then the three graphs in one -- both
+    callbacks inside the library against the Python callbacks, the same file; also graph + graph + FASTA"""
+    seqs = synth.family(30000, 7, seed=seed, **kw)
+    files = []
+    for k, s in enumerate(seqs):
+        p = tmp_path / ("f%d.fa" % k)
+        p.write_text(">fam%d\n%s\n" % (k, s.decode()))
+        files.append(str(p))
+    g1 = rem.graph_rem(files[0:3], str(tmp_path / "g1.gfa"))[2]
+    g2 = rem.graph_rem(files[3:5], str(tmp_path / "g2.gfa"))[2]
+    g3 = rem.graph_rem(files[5:7], str(tmp_path / "g3.gfa"))[2]
+    fn = _both_ways(tmp_path, [g1, g2, g3], "fam")
+    spelled, _ = C.spelled_by_file(fn)
+    assert spelled == {"fam%d" % k: s.decode().upper() for k, s in enumerate(seqs)}
+    _both_ways(tmp_path, [g1, g2, files[5]], "famf", seedsize=100, maxmums=200)

@@ -18,6 +18,35 @@
 
 void rv_set_error(const char *fmt, ...);      // rv_api.hip
 
+// The graph's large arrays (nodes, links, the hash of begins) are read all over -- a walk's next node is anywhere in a gigabyte -- so with 4 KB pages nearly every access
+// also misses the TLB.  With RV_HUGEPAGES=1 in the environment allocations of 4 MB and more are made on 2 MB boundaries and the kernel is asked for huge pages (transparent
+// huge pages in `madvise` mode).  Off by default: where memory is fragmented the kernel compacts it at the first touch, and a graph that grows by doubling pays that again and
+// again (the anchors' surgery of five 5 Mbp genomes: 2.7 -> 11 s in the build container).
+#include <sys/mman.h>
+inline bool rv_hugepages() { static const bool on = [] { const char *e = getenv("RV_HUGEPAGES"); return e && *e && *e != '0'; }(); return on; }
+template <class T> struct HugeAlloc {
+    typedef T value_type;
+    HugeAlloc() = default;
+    template <class U> HugeAlloc(const HugeAlloc<U> &) {}
+    T *allocate(size_t n) {
+        const size_t bytes = n * sizeof(T);
+        void *p = nullptr;
+        if (bytes >= ((size_t)4 << 20) && rv_hugepages()) {
+            const size_t huge = (size_t)2 << 20, sz = (bytes + huge - 1) / huge * huge;
+            p = aligned_alloc(huge, sz);
+            if (p) (void)madvise(p, sz, MADV_HUGEPAGE);
+        } else {
+            const size_t al = alignof(T) > 16 ? alignof(T) : 16, sz = (bytes + al - 1) / al * al;
+            p = aligned_alloc(al, sz ? sz : al);
+        }
+        if (!p) throw std::bad_alloc();
+        return (T *)p;
+    }
+    void deallocate(T *p, size_t) { free(p); }
+    template <class U> bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <class U> bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+
 // A node's links in one direction: (edge id, neighbour) pairs in dictionary order, the first two inside the node.  graphalign's walks go from node to node along
 // chains of small bubbles, every step waiting for the one before: with a vector of edge ids a step was three dependent loads (the vector's heap block, the edge,
 // the neighbour); now it is the neighbour alone.  Iterating yields the edge ids, as the vector did.
@@ -132,13 +161,13 @@ struct GEdge { int u, v; PathSet paths; };
 // caller prefetches it); nothing is ever taken out: an entry whose node is gone fails the caller's check, a new node with the same begin takes the entry over.
 struct BeginHash {
     struct Slot { int64_t key; int val; int pad; };
-    std::vector<Slot> slot;
+    std::vector<Slot, HugeAlloc<Slot>> slot;
     size_t mask = 0, used = 0;
     static size_t mix(int64_t b) { uint64_t x = (uint64_t)b * 0x9E3779B97F4A7C15ull; return (size_t)(x ^ (x >> 29)); }
     void clear() { slot.clear(); slot.shrink_to_fit(); mask = used = 0; }
     void reserve(size_t entries) { size_t cap = 1024; while (cap * 3 < entries * 5 + 16) cap *= 2; if (cap > slot.size()) rehash(cap); }
     void rehash(size_t cap) {
-        std::vector<Slot> s2(cap, Slot{-1, -1, 0});
+        std::vector<Slot, HugeAlloc<Slot>> s2(cap, Slot{-1, -1, 0});
         const size_t m2 = cap - 1;
         for (const Slot &x : slot) if (x.key >= 0) { size_t h = mix(x.key) & m2; while (s2[h].key >= 0) h = (h + 1) & m2; s2[h] = x; }
         slot.swap(s2); mask = m2;
@@ -160,8 +189,8 @@ struct BeginHash {
 };
 
 struct rv_graph {
-    std::vector<GNode> nodes;
-    std::vector<GEdge> edges;
+    std::vector<GNode, HugeAlloc<GNode>> nodes;
+    std::vector<GEdge, HugeAlloc<GEdge>> edges;
     std::map<int64_t, int> at;                      // begin -> node, sequence nodes that are alive
     uint64_t counter = 0;
     std::vector<int> order;                         // export: alive nodes in dictionary order
@@ -178,7 +207,7 @@ struct rv_graph {
     std::vector<uint8_t> mark, mark2, pmark; std::vector<int32_t> pwhere;      // scratch of graphalign / the picker (all zero between calls)
     double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // graphalign: seconds in look-ups / breaks + merge / walks / lists / sorts (RV_GRAPH_TIMES=1 prints them when the graph is renumbered)
     uint32_t sub_epoch = 0, walk_epoch = 0; std::vector<int> walk_queue;      // graphalign: see GNode::ep_sub / ep_walk
-    std::vector<uint64_t> begbits;                  // one bit per text position: a node begins here (kept with `made`; the predecessor search of fast_node_at)
+    std::vector<uint64_t, HugeAlloc<uint64_t>> begbits;                  // one bit per text position: a node begins here (kept with `made`; the predecessor search of fast_node_at)
     BeginHash made; bool made_on = false;           // graphalign: begin -> node, every sequence node from its first large call on (new_node keeps it up)
     std::vector<int> look_tmp;      // graphalign: begin -> node of the nodes that were there when the run began, sorted (see rv_graph_do_align)
     void *align_out_ = nullptr;                     // rv_graphrem.hip: the result of the last rv_graph_do_align through the C ABI
@@ -313,7 +342,7 @@ struct rv_graph {
         for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) nmap[i] = (int)nn++;
         size_t ne = 0;
         for (size_t e = 0; e < edges.size(); e++) if (edges[e].u >= 0 && nodes[(size_t)edges[e].u].alive && nodes[(size_t)edges[e].v].alive) emap[e] = (int)ne++;
-        std::vector<GNode> n2; n2.reserve(nn);
+        std::vector<GNode, HugeAlloc<GNode>> n2; n2.reserve(nn);
         for (size_t i = 0; i < nodes.size(); i++) {
             if (!nodes[i].alive) continue;
             GNode &n = nodes[i];
@@ -323,7 +352,7 @@ struct rv_graph {
             for (size_t k = 0; k < n.pred.size(); k++) n.pred.links()[k].to = nmap[(size_t)n.pred.links()[k].to];
             n2.push_back(std::move(n));
         }
-        std::vector<GEdge> e2; e2.reserve(ne);
+        std::vector<GEdge, HugeAlloc<GEdge>> e2; e2.reserve(ne);
         for (size_t e = 0; e < edges.size(); e++) if (emap[e] >= 0) { GEdge &x = edges[e]; x.u = nmap[(size_t)x.u]; x.v = nmap[(size_t)x.v]; e2.push_back(std::move(x)); }
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];

@@ -125,12 +125,12 @@ def test_native_picker_synthetic_five_way(tmp_path):
     assert texts[0] == texts[1]
 
 
-def _both_ways(tmp_path, files, tag, **kw):
+def _both_ways(tmp_path, files, tag, sa64=False, **kw):
     """graph_rem with both callbacks inside the library (rv_set_graph_picker) and through Python: -> the two GFA texts, aligned node counts"""
     from reveal_amd import schemes
     outs = {}
     for native in (False, True):
-        G, idx, fn = rem.graph_rem(files, str(tmp_path / ("%s_n%d.gfa" % (tag, native))), args=schemes.PickerArgs(**kw), native=native, preselect=False)
+        G, idx, fn = rem.graph_rem(files, str(tmp_path / ("%s_n%d.gfa" % (tag, native))), args=schemes.PickerArgs(**kw), native=native, preselect=False, sa64=sa64)
         outs[native] = (open(fn).read(), sum(1 for n in G.seq_nodes() if G.aligned[n]), len(G.seq_nodes()), fn)
         if native:
             assert idx.picker_info()["kind"] == 0 and idx.picker_info()["calls"] > 0      # (switched off again after the run; the calls were counted)
@@ -200,3 +200,13 @@ def test_graph_inputs_native_random_families(tmp_path, seed, kw):
     spelled, _ = C.spelled_by_file(fn)
     assert spelled == {"fam%d" % k: s.decode().upper() for k, s in enumerate(seqs)}
     _both_ways(tmp_path, [g1, g2, files[5]], "famf", seedsize=100, maxmums=200)
+
+
+def test_graph_inputs_native_64bit_library(tmp_path):
+    """the same through libreveal_amd64.so (reveallib64: the graph behind the ABI is made by the library that runs the recursion)"""
+    fa = C.fasta_files(tmp_path, ["1a", "1b", "1c"])
+    g_ab = rem.graph_rem(fa[:2], str(tmp_path / "ab64.gfa"), sa64=True)[2]
+    fn = _both_ways(tmp_path, [g_ab, fa[2]], "gf64", sa64=True)
+    spelled, _ = C.spelled_by_file(fn)
+    assert spelled == C.input_sequences(fa)
+    assert open(fn).read() == open(_both_ways(tmp_path, [g_ab, fa[2]], "gf32")).read()

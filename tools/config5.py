@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--dir", default=None)
     ap.add_argument("--procs", type=int, default=1, help="jobs of a level run as this many `python -m reveal_amd.rem` processes at a time on this GPU (they share "
                                                         "nothing but files: reveal/align.py prints them as shell commands); 1 = in this process")
+    ap.add_argument("--barriers", action="store_true", help="--procs > 1: a level's jobs start only when the level below is finished (default: a job starts when its inputs exist)")
     a = ap.parse_args()
     from reveal_amd import align, synth
     import graphrem_cases as C
@@ -56,37 +57,53 @@ def main():
         done = []
         level_wall = {}
         stage_log = []
-        for lv, jobs in enumerate(levels):
-            t_lv = time.perf_counter()
-            pending = list(enumerate(jobs))
-            running = []
-            while pending or running:
-                while pending and len(running) < a.procs:
-                    j, (inputs, out) = pending.pop(0)
-                    cmd = [sys.executable, "-m", "reveal_amd.rem"] + list(inputs) + ["-o", out, "-m", str(a.minl), "-n", str(a.minn)]
-                    running.append((j, out, time.perf_counter(), subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
-                                                                                  env=dict(os.environ, REVEAL_AMD_TIMES="1", RV_GRAPH_TIMES="1"))))
-                still = []
-                for j, out, ts, pr in running:
-                    if pr.poll() is None:
-                        still.append((j, out, ts, pr))
-                        continue
-                    so, se = pr.communicate()
-                    if pr.returncode != 0:
-                        sys.exit("level %d job %d failed: %s" % (lv, j, se[-2000:]))
-                    mm = re.search(r"(\d+) nodes, (\d+) paths", so)
-                    dt = time.perf_counter() - ts
-                    done.append((lv, j, dt, int(mm.group(1)) if mm else 0, int(mm.group(2)) if mm else 0))
-                    print("level %d job %d -> %s  %.2f s (process), %s" % (lv, j, out, dt, so.strip().splitlines()[-1] if so.strip() else ""), file=sys.stderr)
-                    if lv > 0:
-                        for ln in se.splitlines():
-                            if ln.startswith(("stages:", "graphalign:", "read_gfa:")):
-                                print("    " + ln, file=sys.stderr)
-                                stage_log.append((lv, j, ln))
-                running = still
-                if running:
-                    time.sleep(0.2)
-            level_wall[str(lv)] = time.perf_counter() - t_lv
+        # every job of the plan, started as soon as its inputs exist and a process slot is free (what `make -j` does with the commands reveal/align.py prints level by level;
+        # --barriers keeps the levels apart); jobs of lower levels first
+        todo = [(lv, j, inputs, out) for lv, jobs in enumerate(levels) for j, (inputs, out) in enumerate(jobs)]
+        made_by_plan = {out for _, _, _, out in todo}
+        finished = set()
+        span = {}      # level -> [first start, last end]
+        running = []
+        while todo or running:
+            lowest = min([lv for lv, _, _, _ in todo] + [x[0] for x in running]) if (todo or running) else 0
+            k = 0
+            while k < len(todo) and len(running) < a.procs:
+                lv, j, inputs, out = todo[k]
+                ready = all((f not in made_by_plan) or (f in finished) for f in inputs) and (not a.barriers or lv == lowest)
+                if not ready:
+                    k += 1
+                    continue
+                todo.pop(k)
+                cmd = [sys.executable, "-m", "reveal_amd.rem"] + list(inputs) + ["-o", out, "-m", str(a.minl), "-n", str(a.minn)]
+                now = time.perf_counter()
+                span.setdefault(lv, [now, now])
+                running.append((lv, j, out, now, subprocess.Popen(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                                                                  env=dict(os.environ, REVEAL_AMD_TIMES="1", RV_GRAPH_TIMES="1"))))
+            still = []
+            for lv, j, out, ts, pr in running:
+                if pr.poll() is None:
+                    still.append((lv, j, out, ts, pr))
+                    continue
+                so, se = pr.communicate()
+                if pr.returncode != 0:
+                    sys.exit("level %d job %d failed: %s" % (lv, j, se[-2000:]))
+                mm = re.search(r"(\d+) nodes, (\d+) paths", so)
+                now = time.perf_counter()
+                dt = now - ts
+                finished.add(out)
+                span[lv][1] = now
+                done.append((lv, j, dt, int(mm.group(1)) if mm else 0, int(mm.group(2)) if mm else 0))
+                print("level %d job %d -> %s  %.2f s (process), %s" % (lv, j, out, dt, so.strip().splitlines()[-1] if so.strip() else ""), file=sys.stderr)
+                if lv > 0:
+                    for ln in se.splitlines():
+                        if ln.startswith(("stages:", "graphalign:", "read_gfa:")):
+                            print("    " + ln, file=sys.stderr)
+                            stage_log.append((lv, j, ln))
+            running = still
+            if running:
+                time.sleep(0.1)
+        level_wall = {str(lv): v[1] - v[0] for lv, v in span.items()}
+        level_span = {str(lv): [v[0] - t1, v[1] - t1] for lv, v in span.items()}
     t_run = time.perf_counter() - t1
     per_level = {}
     for lv, j, dt, nodes, paths in done:
@@ -96,6 +113,8 @@ def main():
                levels={str(k): v for k, v in per_level.items()}, bases=a.genomes * a.L)
     if a.procs > 1:
         out["level_wall_s"] = level_wall
+        out["level_span_s"] = level_span      # [first start, last end] of a level's jobs, seconds from the start of the run (levels overlap unless --barriers)
+        out["barriers"] = bool(a.barriers)
         out["stages_of_graph_jobs"] = ["level %d job %d %s" % x for x in stage_log]
     if not a.max_jobs:
         t2 = time.perf_counter()

@@ -2,7 +2,7 @@
 """Randomised parity soak for GRAPH inputs: `reveal rem` on graphs (and graphs + FASTA, multi-sequence samples) with readers, picker and graphalign inside the library
 (rv_gfa_parse / rv_graph_adopt, rv_set_graph_picker) against the same job through the Python readers and callbacks -- the two GFA files must be equal byte for byte, and every
 input must be spelled by its path.  Random families (SNPs, indels, repeats, runs of N), random partitions into input graphs, random picker options.  Test infrastructure.
-usage: python tools/fuzz_graphs.py [seconds] [seed]"""
+usage: python tools/fuzz_graphs.py [seconds] [seed]      (FUZZ_BIG=1: larger families)"""
 import os
 import random
 import sys
@@ -23,8 +23,9 @@ cases = jobs = 0
 while time.time() - t0 < budget:
     cases += 1
     seed = rng.randrange(1 << 30)
-    K = rng.randint(4, 9)
-    L = rng.choice([3000, 8000, 20000, 50000])
+    big = bool(os.environ.get("FUZZ_BIG"))      # FUZZ_BIG=1: up to 14 genomes of up to 400 kbp
+    K = rng.randint(4, 14 if big else 9)
+    L = rng.choice([50000, 150000, 400000] if big else [3000, 8000, 20000, 50000])
     fam = dict(snp=rng.choice([0.002, 0.01, 0.03, 0.08]), indelfrac=rng.choice([0.0, 0.0, 0.2, 0.5]), repeats=rng.choice([0.0, 0.0, 0.03, 0.1]), nruns=rng.choice([0, 0, 2]))
     args = dict(trim=rng.random() < 0.8, seedsize=rng.choice([10000, 10000, 300, 50]), maxmums=rng.choice([1000, 1000, 50, 10]), gcmodel=rng.choice(["sumofpairs", "sumofpairs", "star-avg", "star-med"]),
                 wpen=rng.choice([1, 1, 3]), wscore=rng.choice([1, 1, 2]))

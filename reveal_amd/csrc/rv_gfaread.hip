@@ -37,6 +37,7 @@ inline void drop_edge(rv_graph *g, int e) {
     g->nodes[(size_t)ed.u].succ.remove(e);
     g->nodes[(size_t)ed.v].pred.remove(e);
     ed.u = -1;
+    g->has_dead = true;
 }
 // alngraph.check_segment_shortcut: every sequence node goes on over a link carried by a real path, in both directions -- or segmentgraph takes the reference's form
 void check_shortcut(rv_graph *g) {
@@ -305,7 +306,7 @@ GfaParsed *rv_gfa_parse(const char *data, int64_t len) {
         const int64_t r = read_gfa(&P->frag, nullptr, &tn, data, len, P);
         P->npaths = r;
         if (r == -1) P->err = rv_last_error();
-        if (r >= 0) { P->names = P->frag.names_buf; P->frag.compact(); }
+        if (r >= 0) P->names = P->frag.names_buf;      // (its dead entries -- the paths' own sentinels, unused segments -- are left out when it is adopted)
         return P;
     } catch (const std::exception &e) { if (P) { P->npaths = -1; P->err = std::string("rv_gfa_parse: ") + e.what(); } else rv_set_error("rv_gfa_parse: out of host memory"); return P; }
     catch (...) { if (P) { P->npaths = -1; P->err = "rv_gfa_parse failed"; } else rv_set_error("rv_gfa_parse: out of host memory"); return P; }
@@ -323,26 +324,37 @@ int64_t rv_graph_adopt(rv_graph *g, rv_index *h, int64_t *text_n, GfaParsed *P, 
             if (rv_add_sequences(h, P->text.data(), (int64_t)P->text.size(), P->seq_len.data(), (int64_t)P->seq_len.size()) != 0) return -1;
         } else { text_base = *text_n; *text_n += (int64_t)P->text.size(); }
         rv_graph &f = P->frag;
-        const int node_base = (int)g->nodes.size(), edge_base = (int)g->edges.size(), sid_base = (int)g->id2end.size();
-        g->nodes.reserve(g->nodes.size() + f.nodes.size()); g->edges.reserve(g->edges.size() + f.edges.size());
-        for (GEdge &ed : f.edges) {
-            GEdge x; x.u = ed.u < 0 ? -1 : ed.u + node_base; x.v = ed.v + node_base;
+        const int sid_base = (int)g->id2end.size();
+        // live nodes and links get their numbers behind what is there, in their order; the rest stays behind
+        std::vector<int> nmap(f.nodes.size(), -1), emap(f.edges.size(), -1);
+        int nn = (int)g->nodes.size(), ne = (int)g->edges.size();
+        for (size_t i = 0; i < f.nodes.size(); i++) if (f.nodes[i].alive) nmap[i] = nn++;
+        for (size_t e = 0; e < f.edges.size(); e++) { const GEdge &ed = f.edges[e]; if (ed.u >= 0 && f.nodes[(size_t)ed.u].alive && f.nodes[(size_t)ed.v].alive) emap[e] = ne++; }
+        g->nodes.reserve((size_t)nn); g->edges.reserve((size_t)ne);
+        for (size_t e = 0; e < f.edges.size(); e++) {
+            if (emap[e] < 0) continue;
+            GEdge &ed = f.edges[e];
+            GEdge x; x.u = nmap[(size_t)ed.u]; x.v = nmap[(size_t)ed.v];
             if (sid_base == 0) x.paths = std::move(ed.paths); else ed.paths.each([&](int q) { x.paths.add(q + sid_base); });
             g->edges.push_back(std::move(x));
         }
-        for (GNode &n : f.nodes) {
+        for (size_t i = 0; i < f.nodes.size(); i++) {
+            if (nmap[i] < 0) continue;
+            GNode &n = f.nodes[i];
             if (n.aligned >= 0) { n.b += text_base; n.e += text_base; } else n.b = (int64_t)g->counter;
             n.order = g->counter++;
             n.ep_sub = n.ep_walk = 0; n.cls = 0;
             for (auto &a : n.off) a.first += sid_base;
-            for (size_t k = 0; k < n.succ.size(); k++) { n.succ.links()[k].e += edge_base; n.succ.links()[k].to += node_base; }
-            for (size_t k = 0; k < n.pred.size(); k++) { n.pred.links()[k].e += edge_base; n.pred.links()[k].to += node_base; }
+            for (size_t k = 0; k < n.succ.size(); k++) { Link &lk = n.succ.links()[k]; lk.e = emap[(size_t)lk.e]; lk.to = nmap[(size_t)lk.to]; }
+            for (size_t k = 0; k < n.pred.size(); k++) { Link &lk = n.pred.links()[k]; lk.e = emap[(size_t)lk.e]; lk.to = nmap[(size_t)lk.to]; }
             g->nodes.push_back(std::move(n));
             const int id = (int)g->nodes.size() - 1;
             const GNode &m = g->nodes[(size_t)id];
-            if (m.alive && m.aligned >= 0) { g->at.emplace_hint(g->at.end(), m.b, id); if (g->made_on) { g->made.put(m.b, id); g->mark_begin(m.b); } }      // (begins grow with the text)
+            if (m.aligned >= 0) { g->at.emplace_hint(g->at.end(), m.b, id); if (g->made_on) { g->made.put(m.b, id); g->mark_begin(m.b); } }      // (begins grow with the text)
         }
-        for (int x : f.start_of) g->start_of.push_back(x + node_base);
+        const int node_base = 0;      // (start_of below goes through nmap)
+        (void)node_base;
+        for (int x : f.start_of) if (nmap[(size_t)x] >= 0) g->start_of.push_back(nmap[(size_t)x]);
         g->star.insert(g->star.end(), f.star.begin(), f.star.end());
         g->id2end.insert(g->id2end.end(), f.id2end.begin(), f.id2end.end());
         g->literal_segments = g->literal_segments || f.literal_segments;

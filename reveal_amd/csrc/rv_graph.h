@@ -231,7 +231,9 @@ struct rv_graph {
         nodes[(size_t)u].succ.push_back(e, v);
         nodes[(size_t)v].pred.push_back(e, u);
     }
+    bool has_dead = false;                          // a node or a link has gone since the last renumbering (compact() has work to do)
     void remove_node(int x) {
+        has_dead = true;
         GNode &n = nodes[(size_t)x];
         for (int e : n.succ) { nodes[(size_t)edges[(size_t)e].v].pred.remove(e); edges[(size_t)e].u = -1; }
         for (int e : n.pred) { nodes[(size_t)edges[(size_t)e].u].succ.remove(e); edges[(size_t)e].u = -1; }
@@ -337,6 +339,9 @@ struct rv_graph {
     // times the size it needs to be, a cache miss per step.  Live nodes and edges move together, in their old order (a node's number IS its place in the
     // dictionary), ids are renamed.
     void compact() {
+        made.clear(); made_on = false; begbits.clear();
+        if (!has_dead) return;
+        has_dead = false;
         std::vector<int> nmap(nodes.size(), -1), emap(edges.size(), -1);
         size_t nn = 0;
         for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) nmap[i] = (int)nn++;
@@ -357,7 +362,6 @@ struct rv_graph {
         nodes.swap(n2); edges.swap(e2);
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
-        made.clear(); made_on = false; begbits.clear();
     }
     void finish() {
         order.clear();

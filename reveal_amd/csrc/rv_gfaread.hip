@@ -370,16 +370,7 @@ int64_t rv_graph_adopt(rv_graph *g, rv_index *h, int64_t *text_n, GfaParsed *P, 
 /* after the last input: dead entries go, live nodes and links are renumbered in their order, and alngraph.check_segment_shortcut's question is asked once for the
  * whole graph (the reference asks it after every file, of every node read so far: the same answer) */
 int rv_graph_seal(rv_graph *g) {
-    try {
-        g->compact();
-        check_shortcut(g);
-        // (graphs read from files: the nodes laid out as the graph runs, rv_graph::relayout; RV_GRAPH_RELAYOUT=0 keeps the files' order, =1 moves small graphs too -- tests)
-        const char *e = getenv("RV_GRAPH_RELAYOUT");
-        const bool from_files = g->nodes.size() > 3 * g->id2end.size();      // (more than the readers' three nodes per FASTA sequence)
-        if (e ? atoi(e) != 0 : (from_files && g->nodes.size() >= 50000)) g->relayout();
-        g->finish();
-        return 0;
-    }
+    try { g->compact(); check_shortcut(g); g->finish(); return 0; }
     catch (...) { rv_set_error("rv_graph_seal: out of host memory"); return -1; }
 }
 

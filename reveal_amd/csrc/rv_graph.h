@@ -363,55 +363,9 @@ struct rv_graph {
         for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
         for (int &x : start_of) x = nmap[(size_t)x];
     }
-    // The readers number nodes as a graph file lists its segments: in the order an EARLIER run made them, which has nothing to do with where they stand in the graph -- a walk
-    // from node to node, a path followed by the writer, a sub-index' nodes: every step somewhere else in a gigabyte.  relayout() renumbers nodes (and links) in a topological
-    // order, one component after the other and a bubble's branches next to each other (Kahn's algorithm with a stack; what lies on a cycle follows in the old order), so
-    // that neighbours in the graph are neighbours in memory.  The dictionary order the outputs follow is the nodes' `order` field, as before; from here on finish() sorts by it.
-    bool permuted = false;
-    void relayout() {
-        const size_t N = nodes.size();
-        std::vector<int> indeg(N, 0), seq; seq.reserve(N);
-        std::vector<int> stack;
-        std::vector<uint8_t> seen(N, 0);
-        for (size_t i = 0; i < N; i++) if (nodes[i].alive) indeg[i] = (int)nodes[i].pred.size();
-        for (size_t i = N; i-- > 0;) if (nodes[i].alive && indeg[i] == 0) stack.push_back((int)i);      // (the first root is taken first)
-        while (!stack.empty()) {
-            const int x = stack.back(); stack.pop_back();
-            if (seen[(size_t)x]) continue;
-            seen[(size_t)x] = 1; seq.push_back(x);
-            const LinkVec &sv = nodes[(size_t)x].succ;
-            for (size_t k = sv.size(); k-- > 0;) { const int to = sv.links()[k].to; if (--indeg[(size_t)to] == 0) stack.push_back(to); }
-        }
-        for (size_t i = 0; i < N; i++) if (nodes[i].alive && !seen[i]) seq.push_back((int)i);      // (on a cycle, or behind one)
-        std::vector<int> nmap(N, -1), emap(edges.size(), -1);
-        for (size_t k = 0; k < seq.size(); k++) nmap[(size_t)seq[k]] = (int)k;
-        int ne = 0;
-        for (int x : seq) for (size_t k = 0; k < nodes[(size_t)x].succ.size(); k++) emap[(size_t)nodes[(size_t)x].succ.links()[k].e] = ne++;
-        std::vector<GNode, HugeAlloc<GNode>> n2; n2.reserve(seq.size());
-        for (int x : seq) {
-            GNode &n = nodes[(size_t)x];
-            for (size_t k = 0; k < n.succ.size(); k++) { Link &lk = n.succ.links()[k]; lk.e = emap[(size_t)lk.e]; lk.to = nmap[(size_t)lk.to]; }
-            for (size_t k = 0; k < n.pred.size(); k++) { Link &lk = n.pred.links()[k]; lk.e = emap[(size_t)lk.e]; lk.to = nmap[(size_t)lk.to]; }
-            n2.push_back(std::move(n));
-        }
-        std::vector<GEdge, HugeAlloc<GEdge>> e2((size_t)ne);
-        for (size_t e = 0; e < edges.size(); e++) if (emap[e] >= 0) { GEdge &x = edges[e]; x.u = nmap[(size_t)x.u]; x.v = nmap[(size_t)x.v]; e2[(size_t)emap[e]] = std::move(x); }
-        nodes.swap(n2); edges.swap(e2);
-        for (auto &kv : at) kv.second = nmap[(size_t)kv.second];
-        for (int &x : start_of) x = nmap[(size_t)x];
-        made.clear(); made_on = false; begbits.clear();
-        permuted = true;
-    }
     void finish() {
         order.clear();
-        if (!permuted) {
-            for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);      // (a node's number IS its creation order: new_node hands both out together)
-        } else {
-            // by dictionary position: every node's `order` is its own number in [0, counter)
-            std::vector<int> at_pos((size_t)counter, -1);
-            for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) at_pos[(size_t)nodes[i].order] = (int)i;
-            for (int x : at_pos) if (x >= 0) order.push_back(x);
-        }
+        for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive) order.push_back((int)i);      // (a node's number IS its creation order: new_node hands both out together)
         edge_no.assign(edges.size(), -1);
         int ne = 0;
         for (int x : order) for (int e : nodes[(size_t)x].succ) edge_no[(size_t)e] = ne++;

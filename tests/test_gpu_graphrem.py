@@ -210,20 +210,3 @@ def test_graph_inputs_native_64bit_library(tmp_path):
     spelled, _ = C.spelled_by_file(fn)
     assert spelled == C.input_sequences(fa)
     assert open(fn).read() == open(_both_ways(tmp_path, [g_ab, fa[2]], "gf32")).read()
-
-
-@pytest.mark.parametrize("seed,kw", [(13, dict(snp=0.02, indelfrac=0.3)), (17, dict(snp=0.01, repeats=0.05, nruns=2))])
-def test_graph_inputs_native_with_the_nodes_laid_out_anew(tmp_path, monkeypatch, seed, kw):
-    """graphs read from files have their nodes renumbered in a topological order before the run (rv_graph::relayout, from 50 000 nodes on; RV_GRAPH_RELAYOUT=1: always) --
-    nothing of it may show: the same file as through the Python readers and callbacks"""
-    monkeypatch.setenv("RV_GRAPH_RELAYOUT", "1")
-    seqs = synth.family(40000, 8, seed=seed, **kw)
-    files = []
-    for k, s in enumerate(seqs):
-        p = tmp_path / ("r%d.fa" % k)
-        p.write_text(">rel%d\n%s\n" % (k, s.decode()))
-        files.append(str(p))
-    graphs = [rem.graph_rem(files[3 * j:3 * j + 3], str(tmp_path / ("rj%d.gfa" % j)))[2] for j in range(2)] + [rem.graph_rem(files[6:8], str(tmp_path / "rj2.gfa"))[2]]
-    fn = _both_ways(tmp_path, graphs, "relay")
-    spelled, _ = C.spelled_by_file(fn)
-    assert spelled == {"rel%d" % k: s.decode().upper() for k, s in enumerate(seqs)}

@@ -314,6 +314,9 @@ def graph_align_genomes(inputfiles, sa64=False, minlength=20, minn=2, contigs=Tr
             idx, G, loop = indexmod.index(), alngraph.AlnGraph(), None      # (half-filled: start over)
             loop_ok = False
     if loop is None:
+        if getattr(idx, "_h", None) is not None and not any(f.endswith(".gz") for f in inputfiles):
+            # one allocation of the (page-locked) host text instead of one per sequence: a file is never shorter than the text it adds
+            idx._dll.rv_reserve_text(idx._h, int(idx._dll.rv_n(idx._h)) + sum(os.path.getsize(f) for f in inputfiles) + 64)
         for f in inputfiles:
             if f.endswith(".gfa") or f.endswith(".gfa.gz"):
                 idx.addsample(os.path.basename(f))

@@ -219,7 +219,7 @@ struct rv_graph {
         n.b = b; n.e = e; n.aligned = aligned; n.alive = true; n.order = counter++;
         nodes.push_back(std::move(n));
         const int id = (int)nodes.size() - 1;
-        if (aligned >= 0) { at[b] = id; if (made_on) { made.put(b, id); mark_begin(b); } }
+        if (aligned >= 0) { if (use_map) at[b] = id; if (made_on) { made.put(b, id); mark_begin(b); } }
         return id;
     }
     // alngraph.py add_edge: one edge per (u, v); adding it again unites the path sets
@@ -231,6 +231,10 @@ struct rv_graph {
         nodes[(size_t)u].succ.push_back(e, v);
         nodes[(size_t)v].pred.push_back(e, u);
     }
+    // The position map costs a tree insertion per node made and an erasure per node broken.  The surgery of a finished run's anchors (rv_graph_replay, the follower of
+    // rv_set_replay_graph) needs none of it: an anchor's member always lies in a live node, whose begin is the nearest set bit of the bitmap in front of it (a dead node's begin
+    // never lies inside a live node's interval), and the hash names the node.  use_map = false while that surgery runs; compact() makes the map again.
+    bool use_map = true;
     bool has_dead = false;                          // a node or a link has gone since the last renumbering (compact() has work to do)
     void remove_node(int x) {
         has_dead = true;
@@ -238,8 +242,10 @@ struct rv_graph {
         for (int e : n.succ) { nodes[(size_t)edges[(size_t)e].v].pred.remove(e); edges[(size_t)e].u = -1; }
         for (int e : n.pred) { nodes[(size_t)edges[(size_t)e].u].succ.remove(e); edges[(size_t)e].u = -1; }
         n.succ.clear(); n.pred.clear(); n.off.clear(); n.alive = false;
-        auto it = at.find(n.b);
-        if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
+        if (use_map) {
+            auto it = at.find(n.b);
+            if (n.aligned >= 0 && it != at.end() && it->second == x) at.erase(it);
+        }
     }
     void mark_begin(int64_t b) {
         const size_t w = (size_t)(b >> 6);
@@ -254,13 +260,14 @@ struct rv_graph {
         uint64_t bits;
         if (w >= begbits.size()) { if (begbits.empty()) return node_at(pos); w = begbits.size() - 1; bits = begbits[w]; }
         else bits = begbits[w] & (~0ull >> (63 - (pos & 63)));
-        for (int guard = 0; !bits; guard++) { if (w == 0 || guard > 64) return node_at(pos); bits = begbits[--w]; }
+        for (int guard = 0; !bits; guard++) { if (w == 0 || (use_map && guard > 64)) return node_at(pos); bits = begbits[--w]; }      // (without the map: as far back as the node is long)
         const int64_t b = (int64_t)(w << 6) + 63 - __builtin_clzll(bits);
         const int id = made.get(b);
         if (id >= 0) { const GNode &n = nodes[(size_t)id]; if (n.alive && n.aligned >= 0 && n.b == b && pos < n.e) return id; }
         return node_at(pos);
     }
     int node_at(int64_t pos) {
+        if (!use_map) return -1;      // (the surgery of a finished run: the bitmap and the hash answer every look-up of a valid anchor, see use_map)
         auto it = at.upper_bound(pos);
         if (it == at.begin()) return -1;
         --it;
@@ -286,7 +293,7 @@ struct rv_graph {
             for (size_t k = 0; k < n_out; k++) pospaths.unite(out_tmp[k].second);
         }
         // (the old node leaves the position map first: the match or prefix node shares its begin)
-        { auto it = at.find(nb); if (it != at.end() && it->second == x) at.erase(it); }
+        if (use_map) { auto it = at.find(nb); if (it != at.end() && it->second == x) at.erase(it); }
         const int mn = new_node(pos, pos + l, 0);
         nodes[(size_t)mn].off.reserve(att.size());
         for (auto &a : att) nodes[(size_t)mn].off.push_back({a.first, a.second + (pos - nb)});
@@ -340,6 +347,14 @@ struct rv_graph {
     // dictionary), ids are renamed.
     void compact() {
         made.clear(); made_on = false; begbits.clear();
+        if (!use_map) {      // the map of the live sequence nodes, made in one go
+            use_map = true;
+            std::vector<std::pair<int64_t, int>> by_b;
+            for (size_t i = 0; i < nodes.size(); i++) if (nodes[i].alive && nodes[i].aligned >= 0) by_b.push_back({nodes[i].b, (int)i});
+            std::sort(by_b.begin(), by_b.end());
+            at.clear();
+            for (auto &kv : by_b) at.emplace_hint(at.end(), kv.first, kv.second);
+        }
         if (!has_dead) return;
         has_dead = false;
         std::vector<int> nmap(nodes.size(), -1), emap(edges.size(), -1);

@@ -24,6 +24,7 @@ extern "C" {
 static void replay_start(rv_graph *g, int nseq, const int64_t *begin, const int64_t *end) {
     g->nseq = nseq;
     g->made_on = true;      // (a member's node through the bitmap of begins and the hash, rv_graph::fast_node_at: new_node keeps both up)
+    g->use_map = false;     // (... and the position map is not kept while the anchors are applied: rv_graph.h use_map)
     // the FASTA reader's graph (utils.py:304-375): start sentinel, the sequence, end sentinel -- per sequence, in this order
     for (int s = 0; s < nseq; s++) {
         const int st = g->new_node(s, 0, -1), iv = g->new_node(begin[s], end[s], 0), en = g->new_node(s, 1, -1);

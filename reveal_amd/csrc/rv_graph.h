@@ -96,6 +96,43 @@ public:
     CIt end() const { return CIt{p() + n_}; }
 };
 
+// A node's offsets: path id -> offset in dictionary order, the first pair inside the node (a sequence of a FASTA input lies on one path: the anchors' surgery made and
+// freed a heap block per node it made).  The interface of the vector this replaces, as far as it was used.
+struct OffEnt { int first; int64_t second; };
+class OffVec {
+    uint32_t n_ = 0, cap_ = 1;
+    union { OffEnt inl_[1]; OffEnt *heap_; };
+    OffEnt *p() { return cap_ > 1 ? heap_ : inl_; }
+    const OffEnt *p() const { return cap_ > 1 ? heap_ : inl_; }
+    void take(OffVec &o) { n_ = o.n_; cap_ = o.cap_; if (cap_ > 1) heap_ = o.heap_; else inl_[0] = o.inl_[0]; o.n_ = 0; o.cap_ = 1; }
+    void copy(const OffVec &o) { n_ = 0; cap_ = 1; reserve(o.n_); for (uint32_t i = 0; i < o.n_; i++) p()[n_++] = o.p()[i]; }
+public:
+    OffVec() { inl_[0] = OffEnt{0, 0}; }
+    ~OffVec() { if (cap_ > 1) free(heap_); }
+    OffVec(const OffVec &o) { copy(o); }
+    OffVec(OffVec &&o) noexcept { take(o); }
+    OffVec &operator=(const OffVec &o) { if (this != &o) { if (cap_ > 1) free(heap_); copy(o); } return *this; }
+    OffVec &operator=(OffVec &&o) noexcept { if (this != &o) { if (cap_ > 1) free(heap_); take(o); } return *this; }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    void clear() { n_ = 0; }
+    void reserve(size_t want) {
+        if (want <= cap_) return;
+        OffEnt *q = (OffEnt *)malloc(sizeof(OffEnt) * want);
+        if (!q) throw std::bad_alloc();
+        memcpy(q, p(), sizeof(OffEnt) * n_);
+        if (cap_ > 1) free(heap_);
+        heap_ = q; cap_ = (uint32_t)want;
+    }
+    void push_back(const OffEnt &x) { if (n_ == cap_) reserve(cap_ < 4 ? 4 : (size_t)cap_ * 2); p()[n_++] = x; }
+    OffEnt &back() { return p()[n_ - 1]; }
+    const OffEnt &back() const { return p()[n_ - 1]; }
+    OffEnt *begin() { return p(); }
+    OffEnt *end() { return p() + n_; }
+    const OffEnt *begin() const { return p(); }
+    const OffEnt *end() const { return p() + n_; }
+};
+
 // A node is two cache lines (128 B, aligned): what a walk reads -- interval, flags, marks and the links it follows forwards -- in the first, the links backwards, the offsets and
 // the dictionary position in the second.
 struct alignas(64) GNode {
@@ -109,7 +146,7 @@ struct alignas(64) GNode {
     uint32_t ep_sub = 0, ep_walk = 0;               // belongs to the sub-index of the current graphalign call / reached by the current walk
     LinkVec succ;                                   // links forwards, in dictionary order (iterating yields edge ids)
     LinkVec pred;                                   // links backwards
-    std::vector<std::pair<int, int64_t>> off;       // path id -> offset, in dictionary order
+    OffVec off;                                     // path id -> offset, in dictionary order
     uint64_t order;                                 // position in the graph's node dictionary (creation order)
 };
 static_assert(sizeof(GNode) == 128 && offsetof(GNode, succ) + sizeof(LinkVec) <= 64 && offsetof(GNode, pred) + sizeof(LinkVec) <= 128, "GNode layout");
@@ -280,7 +317,7 @@ struct rv_graph {
         if (suffix) *suffix = -1;
         const int64_t nb = nodes[(size_t)x].b, ne = nodes[(size_t)x].e;
         if (nb == pos && ne == pos + l) return x;
-        const std::vector<std::pair<int, int64_t>> att = std::move(nodes[(size_t)x].off);      // (the node is about to go)
+        const OffVec att = std::move(nodes[(size_t)x].off);      // (the node is about to go)
         in_tmp.clear(); out_tmp.clear();
         for (int e : nodes[(size_t)x].pred) in_tmp.push_back({edges[(size_t)e].u, edges[(size_t)e].paths});
         for (int e : nodes[(size_t)x].succ) out_tmp.push_back({edges[(size_t)e].v, edges[(size_t)e].paths});
@@ -319,16 +356,16 @@ struct rv_graph {
     // rem.py:133-200: the first node absorbs the others
     int mergenodes(const std::vector<int> &mns) {
         const int ref = mns[0];
-        std::vector<std::pair<int, int64_t>> merged;      // an ordered mapping path -> offset: a later node's value for a path that is there replaces it in place
+        OffVec merged;      // an ordered mapping path -> offset: a later node's value for a path that is there replaces it in place
         for (int x : mns)
             for (auto &a : nodes[(size_t)x].off) {
                 if ((size_t)a.first >= pmark.size()) { pmark.resize((size_t)a.first + 64, 0); pwhere.resize(pmark.size(), 0); }
                 if (pwhere.size() < pmark.size()) pwhere.resize(pmark.size(), 0);
-                if (pmark[(size_t)a.first]) merged[(size_t)pwhere[(size_t)a.first]].second = a.second;
+                if (pmark[(size_t)a.first]) merged.begin()[(size_t)pwhere[(size_t)a.first]].second = a.second;
                 else { pmark[(size_t)a.first] = 1; pwhere[(size_t)a.first] = (int32_t)merged.size(); merged.push_back(a); }
             }
         for (auto &a : merged) pmark[(size_t)a.first] = 0;
-        nodes[(size_t)ref].off.swap(merged);
+        nodes[(size_t)ref].off = std::move(merged);
         nodes[(size_t)ref].aligned = 1;
         for (size_t k = 1; k < mns.size(); k++) {
             const int x = mns[k];

@@ -34,7 +34,7 @@ typedef struct rv_index rv_index;
 
 /* ---- library ------------------------------------------------------------ */
 const char *rv_last_error(void);
-int  rv_abi_version(void);              /* bumped on incompatible changes */
+int  rv_abi_version(void);              /* bumped on incompatible changes: 2 = rv_picker_info writes six values */
 int  rv_sa_bits(void);                  /* 32 or 64: which module this library is */
 int  rv_device_count(void);             /* visible HIP devices (0 = none) */
 

@@ -53,7 +53,7 @@ int g_rv_launch_trace = 0;
 extern "C" {
 
 const char *rv_last_error(void) { return g_err; }
-int rv_abi_version(void) { return 1; }
+int rv_abi_version(void) { return 2; }      /* 2: rv_picker_info writes six values (round 6) */
 int rv_sa_bits(void) { return (int)sizeof(sa_t) * 8; }
 int rv_device_count(void) {
     int n = 0;

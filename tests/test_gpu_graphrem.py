@@ -1,6 +1,8 @@
 """The Python-3 `reveal rem` graph driver on top of reveal_amd's own index (HIP path): same bodies as
 tests/test_cpu_graphrem.py runs with the reference's index -- BASELINE config 1's figures, graphs feeding graphs level by
 level (reveal/align.py:27-54), multi-genome and multi-contig inputs -- plus a synthetic hierarchical run."""
+import os
+
 import numpy as np
 import pytest
 
@@ -210,3 +212,27 @@ def test_graph_inputs_native_64bit_library(tmp_path):
     spelled, _ = C.spelled_by_file(fn)
     assert spelled == C.input_sequences(fa)
     assert open(fn).read() == open(_both_ways(tmp_path, [g_ab, fa[2]], "gf32")).read()
+
+
+def test_readers_behind_the_abi_fill_the_index_as_the_python_readers_do(tmp_path):
+    """rv_gfa_parse / rv_graph_adopt / rv_add_sequences put the segments into the index (text, separators, intervals, samples) exactly as alngraph.read_gfa + addsequence do"""
+    from reveal_amd import alngraph, reveallib
+    fa = C.fasta_files(tmp_path, ["1a", "1b", "1c", "1d", "1e"])
+    g_ab = rem.graph_rem(fa[:2], str(tmp_path / "ab.gfa"))[2]
+    g_de = rem.graph_rem(fa[3:], str(tmp_path / "de.gfa.gz"))[2]
+    inputs = [g_ab, fa[2], g_de]
+    ip, Gp = reveallib.index(), alngraph.AlnGraph()
+    for f in inputs:
+        if f.endswith(".fa"):
+            alngraph.read_fasta(f, ip, Gp)
+        else:
+            ip.addsample(os.path.basename(f))
+            alngraph.read_gfa(f, ip, Gp)
+    il, Gl = reveallib.index(), alngraph.AlnGraph()
+    lg = alngraph.LoopGraph.read(inputs, il, Gl)
+    assert il.n == ip.n and il.nsamples == ip.nsamples and il.samples == ip.samples
+    assert il.nodes == ip.nodes                      # (asked of the library: rv_node_list)
+    assert il.T == ip.T and il.nsep == ip.nsep
+    assert Gl.paths == Gp.paths and Gl.id2end == Gp.id2end
+    assert lg.snapshot() == alngraph.graph_snapshot(Gp)
+    lg.close()
